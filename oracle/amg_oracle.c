@@ -1,0 +1,1357 @@
+/*
+ * amg_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See amg_oracle.h for provenance.  Every routine cites the reference call site it
+ * stands behind (paths relative to /root/reference) and, because the arithmetic lives in
+ * un-vendored hypre, the published algorithm it restates.
+ *
+ * Determinism contract shared with the HIP product (so hierarchies can be compared
+ * entry by entry): rows are column-sorted; setup arithmetic is written as plain
+ * mul/add/div in a fixed order (compile with -ffp-contract=off).
+ */
+#include "amg_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_C_PT 1
+#define ORC_F_PT (-1)
+#define ORC_SF_PT (-3)
+
+/* ------------------------------------------------------------------ params */
+
+/* src/internal/amg.c:120-238 (HYPRE_USING_GPU branch when gpu_defaults) */
+void
+orc_amg_default_params(orc_amg_params *p, int gpu_defaults)
+{
+   p->coarsen_type    = gpu_defaults ? 8 : 10;
+   p->interp_type     = 6;
+   p->pmax            = 4;
+   p->trunc_factor    = 0.0;
+   p->strong_th       = 0.25;
+   p->max_row_sum     = 0.9;
+   p->max_coarse_size = 64;
+   p->min_coarse_size = 0;
+   p->max_levels      = 25;
+   p->relax_down      = gpu_defaults ? 18 : 13;
+   p->relax_up        = gpu_defaults ? 18 : 14;
+   p->relax_coarse    = 9;
+   p->sweeps_down     = 1;
+   p->sweeps_up       = 1;
+   p->sweeps_coarse   = 1;
+   p->relax_weight    = 1.0;
+   p->outer_weight    = 1.0;
+   p->seed            = 2747;
+}
+
+/* src/internal/pcg.c:15-25, src/internal/gmres.c:16-27 */
+void
+orc_krylov_default_params(orc_krylov_params *p, int gmres)
+{
+   p->max_iter   = gmres ? 300 : 100;
+   p->rtol       = 1.0e-6;
+   p->atol       = 0.0;
+   p->two_norm   = 1;
+   p->krylov_dim = 30;
+}
+
+/* --------------------------------------------------------------------- CSR */
+
+orc_csr *
+orc_csr_alloc(int nrows, int ncols, int nnz)
+{
+   orc_csr *A = (orc_csr *)calloc(1, sizeof(orc_csr));
+   A->nrows   = nrows;
+   A->ncols   = ncols;
+   A->rowptr  = (int *)calloc((size_t)nrows + 1, sizeof(int));
+   A->col     = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+   A->val     = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+   return A;
+}
+
+void
+orc_csr_free(orc_csr *A)
+{
+   if (!A) return;
+   free(A->rowptr);
+   free(A->col);
+   free(A->val);
+   free(A);
+}
+
+static void
+sort_row(int *c, double *v, int n)
+{
+   /* insertion sort: rows are short */
+   for (int a = 1; a < n; a++)
+   {
+      int    cc = c[a];
+      double vv = v[a];
+      int    b  = a - 1;
+      while (b >= 0 && c[b] > cc)
+      {
+         c[b + 1] = c[b];
+         v[b + 1] = v[b];
+         b--;
+      }
+      c[b + 1] = cc;
+      v[b + 1] = vv;
+   }
+}
+
+orc_csr *
+orc_csr_from_arrays(int nrows, int ncols, const int64_t *rowptr, const int64_t *cols,
+                    const double *vals)
+{
+   int64_t  base = rowptr[0];
+   int      nnz  = (int)(rowptr[nrows] - base);
+   orc_csr *A    = orc_csr_alloc(nrows, ncols, nnz);
+   for (int i = 0; i <= nrows; i++) A->rowptr[i] = (int)(rowptr[i] - base);
+   for (int k = 0; k < nnz; k++)
+   {
+      A->col[k] = (int)cols[base + k];
+      A->val[k] = vals[base + k];
+   }
+   for (int i = 0; i < nrows; i++)
+      sort_row(A->col + A->rowptr[i], A->val + A->rowptr[i], A->rowptr[i + 1] - A->rowptr[i]);
+   return A;
+}
+
+orc_csr *
+orc_csr_transpose(const orc_csr *A)
+{
+   int      nnz = A->rowptr[A->nrows];
+   orc_csr *T   = orc_csr_alloc(A->ncols, A->nrows, nnz);
+   for (int k = 0; k < nnz; k++) T->rowptr[A->col[k] + 1]++;
+   for (int j = 0; j < A->ncols; j++) T->rowptr[j + 1] += T->rowptr[j];
+   int *pos = (int *)malloc(sizeof(int) * (size_t)(A->ncols + 1));
+   memcpy(pos, T->rowptr, sizeof(int) * (size_t)(A->ncols + 1));
+   for (int i = 0; i < A->nrows; i++)
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+      {
+         int q     = pos[A->col[k]]++;
+         T->col[q] = i; /* ascending i: rows of T come out sorted */
+         T->val[q] = A->val[k];
+      }
+   free(pos);
+   return T;
+}
+
+/* ---------------------------------------------------------- lap7 generator */
+
+typedef struct {
+   int     gd[3], pd[3];
+   int64_t *ps[3];
+} lapmesh;
+
+static void
+mesh_init(lapmesh *m, int nx, int ny, int nz, int px, int py, int pz)
+{
+   /* examples/src/C_laplacian/laplacian.c:561-571: size*j + min(j, rest) */
+   m->gd[0] = nx; m->gd[1] = ny; m->gd[2] = nz;
+   m->pd[0] = px; m->pd[1] = py; m->pd[2] = pz;
+   for (int d = 0; d < 3; d++)
+   {
+      int size = m->gd[d] / m->pd[d];
+      int rest = m->gd[d] - size * m->pd[d];
+      m->ps[d] = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m->pd[d] + 1));
+      for (int j = 0; j <= m->pd[d]; j++) m->ps[d][j] = (int64_t)size * j + (j < rest ? j : rest);
+   }
+}
+
+static void
+mesh_free(lapmesh *m)
+{
+   for (int d = 0; d < 3; d++) free(m->ps[d]);
+}
+
+/* laplacian.c:504-520: blocks numbered in Cartesian rank order (z fastest over blocks),
+ * x fastest inside a block. */
+static int64_t
+mesh_idx(const lapmesh *m, const int64_t g[3], const int bc[3])
+{
+   int64_t **ps = (int64_t **)m->ps;
+   int64_t   lx = ps[0][bc[0] + 1] - ps[0][bc[0]];
+   int64_t   ly = ps[1][bc[1] + 1] - ps[1][bc[1]];
+   return ps[0][bc[0]] * m->gd[1] * m->gd[2] + ps[1][bc[1]] * m->gd[2] * lx +
+          ps[2][bc[2]] * lx * ly + ((g[2] - ps[2][bc[2]]) * ly + (g[1] - ps[1][bc[1]])) * lx +
+          (g[0] - ps[0][bc[0]]);
+}
+
+static int
+block_of(const int64_t *ps, int np, int64_t g)
+{
+   int b = 0;
+   while (b + 1 < np && g >= ps[b + 1]) b++;
+   return b;
+}
+
+void
+orc_lap7_partition(int nx, int ny, int nz, int px, int py, int pz, int rank,
+                   int64_t *ilower, int64_t *iupper)
+{
+   lapmesh m;
+   mesh_init(&m, nx, ny, nz, px, py, pz);
+   /* MPI_Cart_create row-major: rank = (cx*py + cy)*pz + cz */
+   int     bc[3] = {rank / (py * pz), (rank / pz) % py, rank % pz};
+   int64_t g[3]  = {m.ps[0][bc[0]], m.ps[1][bc[1]], m.ps[2][bc[2]]};
+   *ilower       = mesh_idx(&m, g, bc);
+   int64_t cnt   = (m.ps[0][bc[0] + 1] - g[0]) * (m.ps[1][bc[1] + 1] - g[1]) *
+                 (m.ps[2][bc[2] + 1] - g[2]);
+   *iupper = *ilower + cnt - 1;
+   mesh_free(&m);
+}
+
+orc_csr *
+orc_lap7(int nx, int ny, int nz, int px, int py, int pz, double cx, double cy, double cz,
+         int b_mode, double *b)
+{
+   lapmesh m;
+   mesh_init(&m, nx, ny, nz, px, py, pz);
+   int64_t N   = (int64_t)nx * ny * nz;
+   int64_t nnz = 7 * N - 2 * ((int64_t)nx * ny + (int64_t)ny * nz + (int64_t)nx * nz);
+   orc_csr *A  = orc_csr_alloc((int)N, (int)N, (int)nnz);
+   /* first pass: per-row counts (rows are visited in grid order, not index order) */
+   for (int64_t gz = 0; gz < nz; gz++)
+      for (int64_t gy = 0; gy < ny; gy++)
+         for (int64_t gx = 0; gx < nx; gx++)
+         {
+            int     bc[3] = {block_of(m.ps[0], px, gx), block_of(m.ps[1], py, gy),
+                             block_of(m.ps[2], pz, gz)};
+            int64_t g[3]  = {gx, gy, gz};
+            int64_t row   = mesh_idx(&m, g, bc);
+            int     cnt   = 1 + (gx > 0) + (gx < nx - 1) + (gy > 0) + (gy < ny - 1) + (gz > 0) +
+                      (gz < nz - 1);
+            A->rowptr[row + 1] = cnt;
+         }
+   for (int64_t i = 0; i < N; i++) A->rowptr[i + 1] += A->rowptr[i];
+   static const int dx[6] = {0, 0, -1, 1, 0, 0};
+   static const int dy[6] = {0, -1, 0, 0, 1, 0};
+   static const int dz[6] = {-1, 0, 0, 0, 0, 1};
+   const double     cc[6] = {cz, cy, cx, cx, cy, cz};
+   for (int64_t gz = 0; gz < nz; gz++)
+      for (int64_t gy = 0; gy < ny; gy++)
+         for (int64_t gx = 0; gx < nx; gx++)
+         {
+            int     bc[3] = {block_of(m.ps[0], px, gx), block_of(m.ps[1], py, gy),
+                             block_of(m.ps[2], pz, gz)};
+            int64_t g[3]  = {gx, gy, gz};
+            int64_t row   = mesh_idx(&m, g, bc);
+            int     q     = A->rowptr[row];
+            A->col[q]     = (int)row;
+            A->val[q++]   = 2.0 * (cx + cy + cz); /* laplacian.c:790 */
+            for (int s = 0; s < 6; s++)
+            {
+               int64_t h[3] = {gx + dx[s], gy + dy[s], gz + dz[s]};
+               if (h[0] < 0 || h[0] >= nx || h[1] < 0 || h[1] >= ny || h[2] < 0 || h[2] >= nz)
+                  continue; /* Dirichlet by truncation */
+               int nb[3]   = {block_of(m.ps[0], px, h[0]), block_of(m.ps[1], py, h[1]),
+                              block_of(m.ps[2], pz, h[2])};
+               A->col[q]   = (int)mesh_idx(&m, h, nb);
+               A->val[q++] = -cc[s];
+            }
+            sort_row(A->col + A->rowptr[row], A->val + A->rowptr[row], q - A->rowptr[row]);
+            if (b) b[row] = (b_mode == 1) ? 1.0 : ((gy == 0) ? 1.0 : 0.0); /* laplacian.c:898-905 */
+         }
+   mesh_free(&m);
+   return A;
+}
+
+/* ----------------------------------------------------------------- kernels */
+
+/* HYPRE_ParCSRMatrixMatvec, reached from src/internal/linsys.c:3031 */
+void
+orc_spmv(const orc_csr *A, double alpha, const double *x, double beta, double *y)
+{
+#pragma omp parallel for schedule(static)
+   for (int i = 0; i < A->nrows; i++)
+   {
+      double s = 0.0;
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) s += A->val[k] * x[A->col[k]];
+      y[i] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[i];
+   }
+}
+
+/* hypre_ParVectorInnerProd, reached from src/internal/linsys.c:2875 */
+double
+orc_dot(int n, const double *x, const double *y)
+{
+   double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+   for (int i = 0; i < n; i++) s += x[i] * y[i];
+   return s;
+}
+
+/* hypre_ParCSRComputeL1Norms.  option 1: sum_j |a_ij| (relax 18);
+ * option 4: a_ii + 0.5*sum_offd|a_ij| truncated -> on one rank just a_ii (relax 13/14/8). */
+void
+orc_l1_norms(const orc_csr *A, int option, double *l1)
+{
+   for (int i = 0; i < A->nrows; i++)
+   {
+      double s = 0.0, d = 0.0;
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+      {
+         s += fabs(A->val[k]);
+         if (A->col[k] == i) d = A->val[k];
+      }
+      if (option == 1)
+         l1[i] = (d < 0.0) ? -s : s;
+      else
+         l1[i] = d;
+   }
+}
+
+/* hypre_BoomerAMGRelax types selectable via src/internal/amg.c:360-375.
+ * One rank, relax_order 0 (lexicographic), all points. */
+void
+orc_relax(const orc_csr *A, const double *l1, int type, double w, const double *b, double *x,
+          double *tmp)
+{
+   const int n = A->nrows;
+   switch (type)
+   {
+      case 0:  /* weighted Jacobi: divide by a_ii */
+      case 7:
+      case 18: /* l1-Jacobi: divide by l1 */
+      {
+#pragma omp parallel for schedule(static)
+         for (int i = 0; i < n; i++)
+         {
+            double r = b[i], d = 0.0;
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+            {
+               r -= A->val[k] * x[A->col[k]];
+               if (A->col[k] == i) d = A->val[k];
+            }
+            if (type == 18) d = l1[i];
+            tmp[i] = x[i] + w * r / d;
+         }
+         memcpy(x, tmp, sizeof(double) * (size_t)n);
+         break;
+      }
+      case 3:  /* hybrid GS forward  */
+      case 13: /* l1 hybrid GS forward: one rank => l1 = a_ii */
+         for (int i = 0; i < n; i++)
+         {
+            double r = b[i], d = 0.0;
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+            {
+               r -= A->val[k] * x[A->col[k]];
+               if (A->col[k] == i) d = A->val[k];
+            }
+            if (type == 13) d = l1[i];
+            x[i] += w * r / d;
+         }
+         break;
+      case 4:  /* hybrid GS backward */
+      case 14:
+         for (int i = n - 1; i >= 0; i--)
+         {
+            double r = b[i], d = 0.0;
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+            {
+               r -= A->val[k] * x[A->col[k]];
+               if (A->col[k] == i) d = A->val[k];
+            }
+            if (type == 14) d = l1[i];
+            x[i] += w * r / d;
+         }
+         break;
+      case 6: /* symmetric GS */
+      case 8: /* l1 symmetric GS */
+         orc_relax(A, l1, type == 6 ? 3 : 13, w, b, x, tmp);
+         orc_relax(A, l1, type == 6 ? 4 : 14, w, b, x, tmp);
+         break;
+      default:
+         fprintf(stderr, "orc_relax: unsupported relax type %d\n", type);
+         abort();
+   }
+}
+
+/* hypre relax type 9 (coarse_type ge, src/internal/amg.c:190): hypre_gselim, no pivoting */
+int
+orc_gselim(double *a, double *x, int n)
+{
+   if (n == 1)
+   {
+      if (a[0] == 0.0) return 1;
+      x[0] /= a[0];
+      return 0;
+   }
+   for (int k = 0; k < n - 1; k++)
+   {
+      if (a[k * n + k] == 0.0) return 1;
+      for (int j = k + 1; j < n; j++)
+      {
+         if (a[j * n + k] != 0.0)
+         {
+            double f = a[j * n + k] / a[k * n + k];
+            for (int m = k + 1; m < n; m++) a[j * n + m] -= f * a[k * n + m];
+            x[j] -= f * x[k];
+         }
+      }
+   }
+   for (int k = n - 1; k > 0; k--)
+   {
+      if (a[k * n + k] == 0.0) return 1;
+      x[k] /= a[k * n + k];
+      for (int j = 0; j < k; j++)
+         if (a[j * n + k] != 0.0) x[j] -= x[k] * a[j * n + k];
+   }
+   if (a[0] == 0.0) return 1;
+   x[0] /= a[0];
+   return 0;
+}
+
+/* ------------------------------------------------------------------- setup */
+
+/* hypre_BoomerAMGCreateS; theta = coarsening.strong_th
+ * (src/internal/amg.c:156), max_row_sum (amg.c:155).  smask[k]=1 iff entry k is strong. */
+void
+orc_strength(const orc_csr *A, double theta, double max_row_sum, unsigned char *smask)
+{
+   for (int i = 0; i < A->nrows; i++)
+   {
+      double diag = 0.0, row_sum = 0.0, row_scale = 0.0;
+      int    k0 = A->rowptr[i], k1 = A->rowptr[i + 1];
+      for (int k = k0; k < k1; k++)
+         if (A->col[k] == i) diag = A->val[k];
+      for (int k = k0; k < k1; k++)
+      {
+         row_sum += A->val[k];
+         if (A->col[k] == i) continue;
+         if (diag < 0.0)
+            row_scale = (A->val[k] > row_scale) ? A->val[k] : row_scale;
+         else
+            row_scale = (A->val[k] < row_scale) ? A->val[k] : row_scale;
+      }
+      int weak_row = (max_row_sum < 1.0) && (diag != 0.0) && (fabs(row_sum / diag) > max_row_sum);
+      for (int k = k0; k < k1; k++)
+      {
+         int s = 0;
+         if (A->col[k] != i && !weak_row)
+         {
+            if (diag < 0.0)
+               s = A->val[k] > theta * row_scale;
+            else
+               s = A->val[k] < theta * row_scale;
+         }
+         smask[k] = (unsigned char)s;
+      }
+   }
+}
+
+static inline uint64_t
+mix64(uint64_t z)
+{
+   z += 0x9E3779B97F4A7C15ULL;
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+   return z ^ (z >> 31);
+}
+
+/* PMIS tie-break weight in [0,1): hypre uses hypre_Rand() seeded 2747+rank (upstream,
+ * unverifiable here; CPU and GPU hypre already disagree) -- we use a hash of the global
+ * row id so the split is partition independent. */
+static inline double
+pmis_rand(uint64_t seed, int level, int64_t gid)
+{
+   uint64_t h = mix64(mix64(seed + (uint64_t)level * 0x100000001B3ULL) ^ (uint64_t)gid);
+   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* strong transpose graph: for each j, the rows i with j in S_i */
+static void
+strong_transpose(const orc_csr *A, const unsigned char *smask, int **tp_out, int **tj_out)
+{
+   int  n  = A->nrows;
+   int *tp = (int *)calloc((size_t)n + 1, sizeof(int));
+   for (int i = 0; i < n; i++)
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         if (smask[k]) tp[A->col[k] + 1]++;
+   for (int j = 0; j < n; j++) tp[j + 1] += tp[j];
+   int *tj  = (int *)malloc(sizeof(int) * (size_t)(tp[n] > 0 ? tp[n] : 1));
+   int *pos = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+   memcpy(pos, tp, sizeof(int) * (size_t)(n + 1));
+   for (int i = 0; i < n; i++)
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         if (smask[k]) tj[pos[A->col[k]]++] = i;
+   free(pos);
+   *tp_out = tp;
+   *tj_out = tj;
+}
+
+/* hypre_BoomerAMGCoarsenPMIS (coarsen type 8, src/internal/amg.c:303-308), SURVEY App. A.5,
+ * written as synchronous rounds so a data-parallel implementation gives the same split. */
+void
+orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
+         int64_t row_offset, int *cf)
+{
+   int     n = A->nrows;
+   int    *tp, *tj;
+   double *meas = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+   char   *newc = (char *)malloc((size_t)(n > 0 ? n : 1));
+   strong_transpose(A, smask, &tp, &tj);
+   int undecided = 0;
+   for (int i = 0; i < n; i++)
+   {
+      int ns = 0;
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) ns += smask[k];
+      int nt  = tp[i + 1] - tp[i];
+      meas[i] = (double)nt + pmis_rand(seed, level, row_offset + i);
+      if (ns == 0)
+         cf[i] = ORC_SF_PT; /* no strong dependence: special F, never interpolated */
+      else if (nt == 0)
+         cf[i] = ORC_F_PT; /* measure < 1: nobody depends on it */
+      else
+      {
+         cf[i] = 0;
+         undecided++;
+      }
+   }
+   while (undecided > 0)
+   {
+      for (int i = 0; i < n; i++)
+      {
+         newc[i] = 0;
+         if (cf[i] != 0) continue;
+         int    is_max = 1;
+         double mi     = meas[i];
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1] && is_max; k++)
+         {
+            int j = A->col[k];
+            if (!smask[k] || cf[j] != 0) continue;
+            if (meas[j] > mi || (meas[j] == mi && j > i)) is_max = 0;
+         }
+         for (int k = tp[i]; k < tp[i + 1] && is_max; k++)
+         {
+            int j = tj[k];
+            if (cf[j] != 0) continue;
+            if (meas[j] > mi || (meas[j] == mi && j > i)) is_max = 0;
+         }
+         newc[i] = (char)is_max;
+      }
+      for (int i = 0; i < n; i++)
+         if (newc[i])
+         {
+            cf[i] = ORC_C_PT;
+            undecided--;
+         }
+      for (int i = 0; i < n; i++)
+      {
+         if (cf[i] != 0) continue;
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+            if (smask[k] && cf[A->col[k]] == ORC_C_PT)
+            {
+               cf[i] = ORC_F_PT;
+               undecided--;
+               break;
+            }
+      }
+   }
+   free(tp);
+   free(tj);
+   free(meas);
+   free(newc);
+}
+
+/* Measure buckets as FIFO doubly-linked lists: the structure hypre's Ruge first pass
+ * keeps (one list per measure value, new/updated points appended at the TAIL, next C
+ * point = HEAD of the highest non-empty list).  FIFO order is what makes the first
+ * level of a 7-pt grid come out red-black. */
+typedef struct {
+   int *head, *tail, *prev, *next, *key, nb, maxkey;
+} rsbuckets;
+
+static void
+bk_enter(rsbuckets *b, int i, int key)
+{
+   if (key >= b->nb)
+   {
+      int nn  = 2 * key + 8;
+      b->head = (int *)realloc(b->head, sizeof(int) * (size_t)nn);
+      b->tail = (int *)realloc(b->tail, sizeof(int) * (size_t)nn);
+      for (int q = b->nb; q < nn; q++) b->head[q] = b->tail[q] = -1;
+      b->nb = nn;
+   }
+   b->key[i]  = key;
+   b->next[i] = -1;
+   b->prev[i] = b->tail[key];
+   if (b->tail[key] >= 0) b->next[b->tail[key]] = i;
+   else b->head[key] = i;
+   b->tail[key] = i;
+   if (key > b->maxkey) b->maxkey = key;
+}
+static void
+bk_remove(rsbuckets *b, int i)
+{
+   int key = b->key[i];
+   if (b->prev[i] >= 0) b->next[b->prev[i]] = b->next[i];
+   else b->head[key] = b->next[i];
+   if (b->next[i] >= 0) b->prev[b->next[i]] = b->prev[i];
+   else b->tail[key] = b->prev[i];
+   b->prev[i] = b->next[i] = -1;
+}
+static int
+bk_top(rsbuckets *b)
+{
+   while (b->maxkey > 0 && b->head[b->maxkey] < 0) b->maxkey--;
+   return (b->maxkey > 0) ? b->head[b->maxkey] : -1;
+}
+
+/* hypre_BoomerAMGCoarsenRuge first pass == HMIS (type 10) on a single rank, where the
+ * "interior" is the whole grid and the trailing PMIS finds nothing left. */
+void
+orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
+{
+   int       n = A->nrows;
+   int      *tp, *tj;
+   rsbuckets B;
+   strong_transpose(A, smask, &tp, &tj);
+   B.nb     = 64;
+   B.maxkey = 0;
+   B.head   = (int *)malloc(sizeof(int) * (size_t)B.nb);
+   B.tail   = (int *)malloc(sizeof(int) * (size_t)B.nb);
+   for (int q = 0; q < B.nb; q++) B.head[q] = B.tail[q] = -1;
+   B.prev = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+   B.next = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+   B.key  = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+   int *meas = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+   for (int i = 0; i < n; i++)
+   {
+      int ns = 0;
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) ns += smask[k];
+      meas[i]   = tp[i + 1] - tp[i];
+      B.prev[i] = B.next[i] = -1;
+      B.key[i]  = 0;
+      cf[i]     = (ns == 0) ? ORC_SF_PT : 0;
+      if (cf[i] == ORC_SF_PT) meas[i] = 0;
+   }
+   /* ascending-index insertion; measure-0 points become F and the points they depend on
+    * gain weight (re-listed at the tail when already listed) */
+   for (int j = 0; j < n; j++)
+   {
+      if (cf[j] == ORC_SF_PT) continue;
+      if (meas[j] > 0) { bk_enter(&B, j, meas[j]); continue; }
+      cf[j] = ORC_F_PT;
+      for (int k = A->rowptr[j]; k < A->rowptr[j + 1]; k++)
+      {
+         int nb = A->col[k];
+         if (!smask[k] || cf[nb] == ORC_SF_PT) continue;
+         if (nb < j)
+         {
+            if (cf[nb] != 0) { meas[nb]++; continue; }
+            if (meas[nb] > 0) bk_remove(&B, nb);
+            meas[nb]++;
+            bk_enter(&B, nb, meas[nb]);
+         }
+         else
+            meas[nb]++;
+      }
+   }
+   for (;;)
+   {
+      int i = bk_top(&B);
+      if (i < 0) break;
+      bk_remove(&B, i);
+      cf[i]   = ORC_C_PT;
+      meas[i] = 0;
+      /* everything that strongly depends on i becomes F */
+      for (int k = tp[i]; k < tp[i + 1]; k++)
+      {
+         int j = tj[k];
+         if (cf[j] != 0) continue;
+         cf[j] = ORC_F_PT;
+         bk_remove(&B, j);
+         for (int kk = A->rowptr[j]; kk < A->rowptr[j + 1]; kk++)
+         {
+            int m = A->col[kk];
+            if (smask[kk] && cf[m] == 0)
+            {
+               bk_remove(&B, m);
+               meas[m]++;
+               bk_enter(&B, m, meas[m]);
+            }
+         }
+      }
+      /* points i depends on lose one potential dependant */
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+      {
+         int j = A->col[k];
+         if (!smask[k] || cf[j] != 0) continue;
+         bk_remove(&B, j);
+         meas[j]--;
+         if (meas[j] > 0)
+            bk_enter(&B, j, meas[j]);
+         else
+         {
+            cf[j] = ORC_F_PT;
+            for (int kk = A->rowptr[j]; kk < A->rowptr[j + 1]; kk++)
+            {
+               int m = A->col[kk];
+               if (smask[kk] && cf[m] == 0)
+               {
+                  bk_remove(&B, m);
+                  meas[m]++;
+                  bk_enter(&B, m, meas[m]);
+               }
+            }
+         }
+      }
+   }
+   free(tp); free(tj); free(B.head); free(B.tail); free(B.prev); free(B.next); free(B.key);
+   free(meas);
+}
+
+typedef struct {
+   int    c;
+   double w;
+} pent;
+
+static int
+pent_cmp_col(const void *a, const void *b)
+{
+   return ((const pent *)a)->c - ((const pent *)b)->c;
+}
+/* Descending-|w| quicksort in the K&R form hypre's hypre_qsort2_abs uses (pivot = middle
+ * element swapped to the front, strict '>' partition).  The exact form matters: on
+ * structured grids interpolation weights tie exactly (six 1/6 weights on a red-black
+ * 7-pt F point) and the tie order decides which pmax entries survive truncation.
+ * Iterative with an explicit stack so a GPU thread can run the identical sequence. */
+static void
+pent_qsort_abs(pent *v, int n)
+{
+   int stack[128], sp = 0;
+   stack[sp++] = 0;
+   stack[sp++] = n - 1;
+   while (sp > 0)
+   {
+      int right = stack[--sp], left = stack[--sp];
+      while (left < right)
+      {
+         int  mid = (left + right) / 2, last = left;
+         pent t   = v[left]; v[left] = v[mid]; v[mid] = t;
+         for (int i = left + 1; i <= right; i++)
+            if (fabs(v[i].w) > fabs(v[left].w))
+            {
+               ++last;
+               t = v[last]; v[last] = v[i]; v[i] = t;
+            }
+         t = v[left]; v[left] = v[last]; v[last] = t;
+         /* recurse (left, last-1) first, then (last+1, right): push the right part */
+         if (sp + 2 <= 128) { stack[sp++] = last + 1; stack[sp++] = right; }
+         right = last - 1;
+      }
+   }
+}
+
+/* hypre_BoomerAMGBuildExtPIInterp + hypre_BoomerAMGInterpTruncation (interp type 6,
+ * src/internal/amg.c:122-125,869,883-884), SURVEY App. A.6.  Rows column-sorted. */
+orc_csr *
+orc_interp_extpi(const orc_csr *A, const unsigned char *smask, const int *cf, int pmax,
+                 double trunc_factor)
+{
+   int  n    = A->nrows;
+   int *cidx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+   int  nc   = 0;
+   for (int i = 0; i < n; i++) cidx[i] = (cf[i] == ORC_C_PT) ? nc++ : -1;
+
+   int   *pm   = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)); /* position in current row */
+   int   *pst  = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)); /* stamp for pm */
+   int   *sfm  = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)); /* strong-F stamp */
+   for (int i = 0; i < n; i++) { pst[i] = -1; sfm[i] = -1; }
+   int    cap  = 64;
+   pent  *row  = (pent *)malloc(sizeof(pent) * (size_t)cap);
+   int   *rfine = (int *)malloc(sizeof(int) * (size_t)cap);
+
+   int     pcap = 4 * n + 16, pnnz = 0;
+   int    *prow = (int *)calloc((size_t)n + 1, sizeof(int));
+   int    *pcol = (int *)malloc(sizeof(int) * (size_t)pcap);
+   double *pval = (double *)malloc(sizeof(double) * (size_t)pcap);
+
+#define ENSURE_ROW(cnt)                                               \
+   if ((cnt) >= cap)                                                  \
+   {                                                                  \
+      cap *= 2;                                                       \
+      row   = (pent *)realloc(row, sizeof(pent) * (size_t)cap);       \
+      rfine = (int *)realloc(rfine, sizeof(int) * (size_t)cap);       \
+   }
+#define ADD_CHAT(j)                    \
+   if (pst[j] != i)                    \
+   {                                   \
+      ENSURE_ROW(cnt);                 \
+      pst[j]     = i;                  \
+      pm[j]      = cnt;                \
+      rfine[cnt] = (j);                \
+      row[cnt].c = cidx[j];            \
+      row[cnt].w = 0.0;                \
+      cnt++;                           \
+   }
+
+   for (int i = 0; i < n; i++)
+   {
+      int cnt = 0;
+      if (cf[i] == ORC_C_PT)
+      {
+         row[0].c = cidx[i];
+         row[0].w = 1.0;
+         cnt      = 1;
+      }
+      else if (cf[i] == ORC_F_PT)
+      {
+         int k0 = A->rowptr[i], k1 = A->rowptr[i + 1];
+         /* C-hat_i = C_i U (U_{k in F_i^s} C_k) */
+         for (int k = k0; k < k1; k++)
+         {
+            if (!smask[k]) continue;
+            int j = A->col[k];
+            if (cf[j] == ORC_C_PT) { ADD_CHAT(j); }
+            else if (cf[j] == ORC_F_PT)
+            {
+               sfm[j] = i;
+               for (int kk = A->rowptr[j]; kk < A->rowptr[j + 1]; kk++)
+               {
+                  int m = A->col[kk];
+                  if (smask[kk] && cf[m] == ORC_C_PT) { ADD_CHAT(m); }
+               }
+            }
+         }
+         double diagonal = 0.0;
+         for (int k = k0; k < k1; k++)
+            if (A->col[k] == i) diagonal = A->val[k];
+         for (int k = k0; k < k1; k++)
+         {
+            int j = A->col[k];
+            if (j == i) continue;
+            double aij = A->val[k];
+            if (pst[j] == i) row[pm[j]].w += aij;
+            else if (sfm[j] == i)
+            {
+               double ajj = 0.0, sum = 0.0;
+               int    j0 = A->rowptr[j], j1 = A->rowptr[j + 1];
+               for (int kk = j0; kk < j1; kk++)
+                  if (A->col[kk] == j) ajj = A->val[kk];
+               double sgn = (ajj < 0.0) ? -1.0 : 1.0;
+               for (int kk = j0; kk < j1; kk++)
+               {
+                  int m = A->col[kk];
+                  if ((pst[m] == i || m == i) && sgn * A->val[kk] < 0.0) sum += A->val[kk];
+               }
+               if (sum != 0.0)
+               {
+                  double distribute = aij / sum;
+                  for (int kk = j0; kk < j1; kk++)
+                  {
+                     int m = A->col[kk];
+                     if (sgn * A->val[kk] < 0.0)
+                     {
+                        if (pst[m] == i) row[pm[m]].w += distribute * A->val[kk];
+                        else if (m == i) diagonal += distribute * A->val[kk];
+                     }
+                  }
+               }
+               else
+                  diagonal += aij;
+            }
+            else if (cf[j] != ORC_SF_PT)
+               diagonal += aij; /* weak connection lumped into the diagonal */
+         }
+         if (diagonal != 0.0)
+            for (int q = 0; q < cnt; q++) row[q].w = row[q].w / (-diagonal);
+         /* truncation (row still in discovery order): relative threshold, then keep the
+          * pmax largest; each step rescales to preserve the row sum */
+         if (trunc_factor > 0.0 && cnt > 0)
+         {
+            double mx = 0.0, tot = 0.0, kept = 0.0;
+            for (int q = 0; q < cnt; q++) { if (fabs(row[q].w) > mx) mx = fabs(row[q].w); tot += row[q].w; }
+            int c2 = 0;
+            for (int q = 0; q < cnt; q++)
+               if (fabs(row[q].w) >= trunc_factor * mx) { row[c2++] = row[q]; kept += row[c2 - 1].w; }
+            cnt = c2;
+            if (kept != 0.0) { double sc = tot / kept; for (int q = 0; q < cnt; q++) row[q].w *= sc; }
+         }
+         if (pmax > 0 && cnt > pmax)
+         {
+            double tot = 0.0, kept = 0.0;
+            for (int q = 0; q < cnt; q++) tot += row[q].w;
+            pent_qsort_abs(row, cnt);
+            cnt = pmax;
+            for (int q = 0; q < cnt; q++) kept += row[q].w;
+            if (kept != 0.0) { double sc = tot / kept; for (int q = 0; q < cnt; q++) row[q].w *= sc; }
+         }
+      }
+      qsort(row, (size_t)cnt, sizeof(pent), pent_cmp_col); /* storage order: by column */
+      if (pnnz + cnt > pcap)
+      {
+         pcap = 2 * pcap + cnt;
+         pcol = (int *)realloc(pcol, sizeof(int) * (size_t)pcap);
+         pval = (double *)realloc(pval, sizeof(double) * (size_t)pcap);
+      }
+      for (int q = 0; q < cnt; q++) { pcol[pnnz] = row[q].c; pval[pnnz++] = row[q].w; }
+      prow[i + 1] = pnnz;
+   }
+#undef ADD_CHAT
+#undef ENSURE_ROW
+   orc_csr *P = (orc_csr *)calloc(1, sizeof(orc_csr));
+   P->nrows = n; P->ncols = nc; P->rowptr = prow; P->col = pcol; P->val = pval;
+   free(cidx); free(pm); free(pst); free(sfm); free(row); free(rfine);
+   return P;
+}
+
+/* row-wise Gustavson product C = X*Y with column-sorted rows */
+static orc_csr *
+spgemm(const orc_csr *X, const orc_csr *Y)
+{
+   int     n = X->nrows, m = Y->ncols;
+   int    *mark = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+   double *acc  = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+   int    *list = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+   for (int j = 0; j < m; j++) mark[j] = -1;
+   int     cap = X->rowptr[n] * 4 + 16, nnz = 0;
+   int    *cp  = (int *)calloc((size_t)n + 1, sizeof(int));
+   int    *cj  = (int *)malloc(sizeof(int) * (size_t)cap);
+   double *cv  = (double *)malloc(sizeof(double) * (size_t)cap);
+   for (int i = 0; i < n; i++)
+   {
+      int cnt = 0;
+      for (int k = X->rowptr[i]; k < X->rowptr[i + 1]; k++)
+      {
+         int    r = X->col[k];
+         double a = X->val[k];
+         for (int q = Y->rowptr[r]; q < Y->rowptr[r + 1]; q++)
+         {
+            int    j = Y->col[q];
+            double t = a * Y->val[q];
+            if (mark[j] != i) { mark[j] = i; acc[j] = t; list[cnt++] = j; }
+            else acc[j] += t;
+         }
+      }
+      /* sort the column list */
+      for (int a = 1; a < cnt; a++)
+      {
+         int v = list[a], b = a - 1;
+         while (b >= 0 && list[b] > v) { list[b + 1] = list[b]; b--; }
+         list[b + 1] = v;
+      }
+      if (nnz + cnt > cap)
+      {
+         cap = 2 * cap + cnt;
+         cj  = (int *)realloc(cj, sizeof(int) * (size_t)cap);
+         cv  = (double *)realloc(cv, sizeof(double) * (size_t)cap);
+      }
+      for (int a = 0; a < cnt; a++) { cj[nnz] = list[a]; cv[nnz++] = acc[list[a]]; }
+      cp[i + 1] = nnz;
+   }
+   free(mark); free(acc); free(list);
+   orc_csr *C = (orc_csr *)calloc(1, sizeof(orc_csr));
+   C->nrows = n; C->ncols = m; C->rowptr = cp; C->col = cj; C->val = cv;
+   return C;
+}
+
+/* Galerkin product P^T A P (hypre_BoomerAMGBuildCoarseOperator; rap2/mod_rap2 flags at
+ * src/internal/amg.c:946-950 select an equivalent two-SpGEMM formulation), App. A.7 */
+orc_csr *
+orc_rap(const orc_csr *A, const orc_csr *P)
+{
+   orc_csr *AP = spgemm(A, P);
+   orc_csr *R  = orc_csr_transpose(P);
+   orc_csr *Ac = spgemm(R, AP);
+   orc_csr_free(AP);
+   orc_csr_free(R);
+   return Ac;
+}
+
+/* --------------------------------------------------------------- hierarchy */
+
+struct orc_amg {
+   orc_amg_params p;
+   int            nlev;
+   orc_csr      **A, **P, **R;
+   int          **cf;
+   double       **l1d, **l1u; /* l1 vectors for down / up relax types */
+   double       **f, **u, **tmp;
+   double        *dense;      /* coarsest dense copy */
+};
+
+static int
+l1_option_for(int relax_type)
+{
+   return (relax_type == 18) ? 1 : 4;
+}
+
+/* hypre_BoomerAMGSetup reached from src/internal/precon.c:107; level loop per SURVEY
+ * App. A.2 (stop when rows <= max_coarse_size, at max_levels, or coarsening stalls). */
+orc_amg *
+orc_amg_setup(const orc_csr *A0, const orc_amg_params *p)
+{
+   orc_amg *h = (orc_amg *)calloc(1, sizeof(orc_amg));
+   h->p       = *p;
+   int maxl   = p->max_levels > 0 ? p->max_levels : 1;
+   h->A   = (orc_csr **)calloc((size_t)maxl, sizeof(void *));
+   h->P   = (orc_csr **)calloc((size_t)maxl, sizeof(void *));
+   h->R   = (orc_csr **)calloc((size_t)maxl, sizeof(void *));
+   h->cf  = (int **)calloc((size_t)maxl, sizeof(void *));
+   h->l1d = (double **)calloc((size_t)maxl, sizeof(void *));
+   h->l1u = (double **)calloc((size_t)maxl, sizeof(void *));
+   h->f   = (double **)calloc((size_t)maxl, sizeof(void *));
+   h->u   = (double **)calloc((size_t)maxl, sizeof(void *));
+   h->tmp = (double **)calloc((size_t)maxl, sizeof(void *));
+   /* own copy of level 0 */
+   {
+      int nnz = A0->rowptr[A0->nrows];
+      h->A[0] = orc_csr_alloc(A0->nrows, A0->ncols, nnz);
+      memcpy(h->A[0]->rowptr, A0->rowptr, sizeof(int) * (size_t)(A0->nrows + 1));
+      memcpy(h->A[0]->col, A0->col, sizeof(int) * (size_t)nnz);
+      memcpy(h->A[0]->val, A0->val, sizeof(double) * (size_t)nnz);
+   }
+   int lvl = 0;
+   int not_finished = (h->A[0]->nrows > p->max_coarse_size) && (maxl > 1);
+   while (not_finished)
+   {
+      const orc_csr *A   = h->A[lvl];
+      int            n   = A->nrows;
+      int            nnz = A->rowptr[n];
+      unsigned char *sm  = (unsigned char *)malloc((size_t)(nnz > 0 ? nnz : 1));
+      int           *cf  = (int *)malloc(sizeof(int) * (size_t)n);
+      orc_strength(A, p->strong_th, p->max_row_sum, sm);
+      if (p->coarsen_type == 8)
+         orc_pmis(A, sm, p->seed, lvl, 0, cf);
+      else
+         orc_rs_first_pass(A, sm, cf);
+      int nc = 0;
+      for (int i = 0; i < n; i++) nc += (cf[i] == ORC_C_PT);
+      if (nc == 0 || nc == n || nc < p->min_coarse_size)
+      {
+         free(sm); free(cf);
+         break;
+      }
+      h->cf[lvl] = cf;
+      h->P[lvl]  = orc_interp_extpi(A, sm, cf, p->pmax, p->trunc_factor);
+      h->R[lvl]  = orc_csr_transpose(h->P[lvl]);
+      free(sm);
+      h->A[lvl + 1] = orc_rap(A, h->P[lvl]);
+      lvl++;
+      if (lvl >= maxl - 1 || nc <= p->max_coarse_size) not_finished = 0;
+   }
+   h->nlev = lvl + 1;
+   for (int l = 0; l < h->nlev; l++)
+   {
+      int n     = h->A[l]->nrows;
+      h->l1d[l] = (double *)malloc(sizeof(double) * (size_t)n);
+      h->l1u[l] = (double *)malloc(sizeof(double) * (size_t)n);
+      orc_l1_norms(h->A[l], l1_option_for(p->relax_down), h->l1d[l]);
+      orc_l1_norms(h->A[l], l1_option_for(p->relax_up), h->l1u[l]);
+      h->f[l]   = (double *)calloc((size_t)n, sizeof(double));
+      h->u[l]   = (double *)calloc((size_t)n, sizeof(double));
+      h->tmp[l] = (double *)calloc((size_t)n, sizeof(double));
+   }
+   if (p->relax_coarse == 9)
+   {
+      int n    = h->A[h->nlev - 1]->nrows;
+      h->dense = (double *)malloc(sizeof(double) * (size_t)n * (size_t)n);
+   }
+   return h;
+}
+
+void
+orc_amg_free(orc_amg *h)
+{
+   if (!h) return;
+   for (int l = 0; l < h->nlev; l++)
+   {
+      orc_csr_free(h->A[l]);
+      orc_csr_free(h->P[l]);
+      orc_csr_free(h->R[l]);
+      free(h->cf[l]); free(h->l1d[l]); free(h->l1u[l]);
+      free(h->f[l]); free(h->u[l]); free(h->tmp[l]);
+   }
+   free(h->A); free(h->P); free(h->R); free(h->cf); free(h->l1d); free(h->l1u);
+   free(h->f); free(h->u); free(h->tmp); free(h->dense);
+   free(h);
+}
+
+int            orc_amg_num_levels(const orc_amg *h) { return h->nlev; }
+const orc_csr *orc_amg_A(const orc_amg *h, int l) { return h->A[l]; }
+const orc_csr *orc_amg_P(const orc_amg *h, int l) { return h->P[l]; }
+const int     *orc_amg_cf(const orc_amg *h, int l) { return h->cf[l]; }
+const double  *orc_amg_l1(const orc_amg *h, int l, int which) { return which ? h->l1u[l] : h->l1d[l]; }
+
+double
+orc_amg_operator_complexity(const orc_amg *h)
+{
+   double s = 0.0;
+   for (int l = 0; l < h->nlev; l++) s += (double)h->A[l]->rowptr[h->A[l]->nrows];
+   return s / (double)h->A[0]->rowptr[h->A[0]->nrows];
+}
+
+double
+orc_amg_grid_complexity(const orc_amg *h)
+{
+   double s = 0.0;
+   for (int l = 0; l < h->nlev; l++) s += (double)h->A[l]->nrows;
+   return s / (double)h->A[0]->nrows;
+}
+
+static void
+coarse_solve(orc_amg *h, int l, const double *b, double *x)
+{
+   const orc_csr *A = h->A[l];
+   int            n = A->nrows;
+   if (h->p.relax_coarse == 9)
+   {
+      memset(h->dense, 0, sizeof(double) * (size_t)n * (size_t)n);
+      for (int i = 0; i < n; i++)
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+            h->dense[(size_t)i * n + A->col[k]] = A->val[k];
+      memcpy(x, b, sizeof(double) * (size_t)n);
+      orc_gselim(h->dense, x, n);
+   }
+   else
+   {
+      for (int s = 0; s < h->p.sweeps_coarse; s++)
+         orc_relax(A, h->l1d[l], h->p.relax_coarse, h->p.relax_weight, b, x, h->tmp[l]);
+   }
+}
+
+/* hypre_BoomerAMGCycle, cycle type 1, reached through
+ * HYPRE_BoomerAMGSolve at src/internal/precon.c:108 with max_iter 1, tol 0
+ * (src/internal/amg.c:224-226). */
+void
+orc_amg_vcycle(orc_amg *h, const double *b, double *x)
+{
+   int L = h->nlev;
+   memcpy(h->f[0], b, sizeof(double) * (size_t)h->A[0]->nrows);
+   memcpy(h->u[0], x, sizeof(double) * (size_t)h->A[0]->nrows);
+   for (int l = 0; l < L - 1; l++)
+   {
+      const orc_csr *A = h->A[l];
+      int            n = A->nrows;
+      for (int s = 0; s < h->p.sweeps_down; s++)
+         orc_relax(A, h->l1d[l], h->p.relax_down, h->p.relax_weight, h->f[l], h->u[l], h->tmp[l]);
+      /* t = f - A u ; f_{l+1} = P^T t */
+      memcpy(h->tmp[l], h->f[l], sizeof(double) * (size_t)n);
+      orc_spmv(A, -1.0, h->u[l], 1.0, h->tmp[l]);
+      orc_spmv(h->R[l], 1.0, h->tmp[l], 0.0, h->f[l + 1]);
+      memset(h->u[l + 1], 0, sizeof(double) * (size_t)h->A[l + 1]->nrows);
+   }
+   if (L == 1)
+   {
+      coarse_solve(h, 0, h->f[0], h->u[0]);
+   }
+   else
+   {
+      coarse_solve(h, L - 1, h->f[L - 1], h->u[L - 1]);
+      for (int l = L - 2; l >= 0; l--)
+      {
+         const orc_csr *A = h->A[l];
+         orc_spmv(h->P[l], 1.0, h->u[l + 1], 1.0, h->u[l]);
+         for (int s = 0; s < h->p.sweeps_up; s++)
+            orc_relax(A, h->l1u[l], h->p.relax_up, h->p.relax_weight, h->f[l], h->u[l], h->tmp[l]);
+      }
+   }
+   memcpy(x, h->u[0], sizeof(double) * (size_t)h->A[0]->nrows);
+}
+
+/* ------------------------------------------------------------------ Krylov */
+
+static void
+apply_precond(const orc_csr *A, orc_amg *h, const double *r, double *z)
+{
+   int n = A->nrows;
+   if (!h)
+   {
+      memcpy(z, r, sizeof(double) * (size_t)n);
+      return;
+   }
+   memset(z, 0, sizeof(double) * (size_t)n); /* hypre clears the vector first */
+   orc_amg_vcycle(h, r, z);
+}
+
+/* hypre_PCGSolve as driven by src/internal/solver.c:561-620 with the settings of
+ * src/internal/pcg.c:55-72 (two_norm 1, rel_change 0, stop_crit 0); SURVEY App. A.1. */
+int
+orc_pcg(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b, double *x,
+        double *resid_hist, int *converged, double *final_rel)
+{
+   int     n = A->nrows, it = 0;
+   double *r = (double *)malloc(sizeof(double) * (size_t)n);
+   double *p = (double *)malloc(sizeof(double) * (size_t)n);
+   double *s = (double *)malloc(sizeof(double) * (size_t)n);
+   *converged = 0;
+   double bi_prod;
+   if (kp->two_norm)
+      bi_prod = orc_dot(n, b, b);
+   else
+   {
+      apply_precond(A, h, b, p);
+      bi_prod = orc_dot(n, p, b);
+   }
+   if (bi_prod == 0.0)
+   {
+      memcpy(x, b, sizeof(double) * (size_t)n);
+      *final_rel = 0.0;
+      if (resid_hist) resid_hist[0] = 0.0;
+      free(r); free(p); free(s);
+      return 0;
+   }
+   double eps = kp->rtol * kp->rtol;
+   {
+      double a2 = kp->atol * kp->atol / bi_prod;
+      if (a2 > eps) eps = a2;
+   }
+   memcpy(r, b, sizeof(double) * (size_t)n);
+   orc_spmv(A, -1.0, x, 1.0, r);
+   apply_precond(A, h, r, p);
+   double gamma  = orc_dot(n, r, p);
+   double i_prod = kp->two_norm ? orc_dot(n, r, r) : gamma;
+   if (resid_hist) resid_hist[0] = sqrt(i_prod);
+   while (it + 1 <= kp->max_iter)
+   {
+      it++;
+      orc_spmv(A, 1.0, p, 0.0, s);
+      double sdotp = orc_dot(n, s, p);
+      if (sdotp == 0.0) { it--; break; }
+      double alpha = gamma / sdotp;
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < n; i++)
+      {
+         x[i] += alpha * p[i];
+         r[i] -= alpha * s[i];
+      }
+      apply_precond(A, h, r, s);
+      double gamma_new = orc_dot(n, r, s);
+      i_prod           = kp->two_norm ? orc_dot(n, r, r) : gamma_new;
+      if (resid_hist) resid_hist[it] = sqrt(i_prod);
+      if (i_prod / bi_prod < eps)
+      {
+         *converged = 1;
+         break;
+      }
+      if (gamma_new < 1.0e-292 && -gamma_new < 1.0e-292) break;
+      double beta = gamma_new / gamma;
+      gamma       = gamma_new;
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < n; i++) p[i] = s[i] + beta * p[i];
+   }
+   *final_rel = sqrt(i_prod / bi_prod);
+   free(r); free(p); free(s);
+   return it;
+}
+
+/* hypre_GMRESSolve (right preconditioning, restart k, modified Gram-Schmidt, Givens),
+ * reached through solver_ops[SOLVER_GMRES] src/internal/solver.c:217-228 with args
+ * src/internal/gmres.c:16-27; SURVEY App. A.8. */
+int
+orc_gmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b, double *x,
+          double *resid_hist, int *converged, double *final_rel)
+{
+   int      n = A->nrows, k = kp->krylov_dim, iter = 0;
+   double **V  = (double **)malloc(sizeof(double *) * (size_t)(k + 1));
+   for (int i = 0; i <= k; i++) V[i] = (double *)malloc(sizeof(double) * (size_t)n);
+   double *w  = (double *)malloc(sizeof(double) * (size_t)n);
+   double *r  = (double *)malloc(sizeof(double) * (size_t)n);
+   double *H  = (double *)calloc((size_t)(k + 1) * (size_t)k, sizeof(double)); /* H[i*k + j] */
+   double *cs = (double *)calloc((size_t)k, sizeof(double));
+   double *sn = (double *)calloc((size_t)k, sizeof(double));
+   double *rs = (double *)calloc((size_t)k + 1, sizeof(double));
+   *converged    = 0;
+   double b_norm = sqrt(orc_dot(n, b, b));
+   memcpy(V[0], b, sizeof(double) * (size_t)n);
+   orc_spmv(A, -1.0, x, 1.0, V[0]);
+   double r_norm   = sqrt(orc_dot(n, V[0], V[0]));
+   double den_norm = (b_norm > 0.0) ? b_norm : r_norm;
+   double epsilon  = kp->rtol * den_norm;
+   if (kp->atol > epsilon) epsilon = kp->atol;
+   if (resid_hist) resid_hist[0] = r_norm;
+   if (r_norm == 0.0)
+   {
+      *converged = 1;
+      *final_rel = 0.0;
+      goto done;
+   }
+   while (iter < kp->max_iter)
+   {
+      rs[0] = r_norm;
+      if (r_norm <= epsilon && iter > 0)
+      {
+         /* true residual check */
+         memcpy(r, b, sizeof(double) * (size_t)n);
+         orc_spmv(A, -1.0, x, 1.0, r);
+         r_norm = sqrt(orc_dot(n, r, r));
+         if (r_norm <= epsilon) { *converged = 1; break; }
+         memcpy(V[0], r, sizeof(double) * (size_t)n);
+         rs[0] = r_norm;
+      }
+      double t = 1.0 / r_norm;
+      for (int i = 0; i < n; i++) V[0][i] *= t;
+      int i = 0;
+      while (i < k && iter < kp->max_iter)
+      {
+         i++;
+         iter++;
+         apply_precond(A, h, V[i - 1], r);
+         orc_spmv(A, 1.0, r, 0.0, V[i]);
+         for (int j = 0; j < i; j++)
+         {
+            double hji         = orc_dot(n, V[j], V[i]);
+            H[j * k + (i - 1)] = hji;
+            for (int q = 0; q < n; q++) V[i][q] -= hji * V[j][q];
+         }
+         double tn          = sqrt(orc_dot(n, V[i], V[i]));
+         H[i * k + (i - 1)] = tn;
+         if (tn != 0.0)
+         {
+            double ti = 1.0 / tn;
+            for (int q = 0; q < n; q++) V[i][q] *= ti;
+         }
+         for (int j = 1; j < i; j++)
+         {
+            double hv                = H[(j - 1) * k + (i - 1)];
+            H[(j - 1) * k + (i - 1)] = cs[j - 1] * hv + sn[j - 1] * H[j * k + (i - 1)];
+            H[j * k + (i - 1)]       = -sn[j - 1] * hv + cs[j - 1] * H[j * k + (i - 1)];
+         }
+         double hh = H[(i - 1) * k + (i - 1)], hn = H[i * k + (i - 1)];
+         double gm = sqrt(hh * hh + hn * hn);
+         if (gm == 0.0) gm = 1.0e-16;
+         cs[i - 1] = hh / gm;
+         sn[i - 1] = hn / gm;
+         rs[i]     = -sn[i - 1] * rs[i - 1];
+         rs[i - 1] = cs[i - 1] * rs[i - 1];
+         H[(i - 1) * k + (i - 1)] = cs[i - 1] * hh + sn[i - 1] * hn;
+         r_norm                   = fabs(rs[i]);
+         if (resid_hist) resid_hist[iter] = r_norm;
+         if (r_norm <= epsilon) break;
+      }
+      /* solve the upper triangular system, update x through the preconditioner */
+      rs[i - 1] = rs[i - 1] / H[(i - 1) * k + (i - 1)];
+      for (int q = i - 2; q >= 0; q--)
+      {
+         double tt = rs[q];
+         for (int j = q + 1; j < i; j++) tt -= H[q * k + j] * rs[j];
+         rs[q] = tt / H[q * k + q];
+      }
+      for (int q = 0; q < n; q++) w[q] = rs[i - 1] * V[i - 1][q];
+      for (int j = i - 2; j >= 0; j--)
+         for (int q = 0; q < n; q++) w[q] += rs[j] * V[j][q];
+      apply_precond(A, h, w, r);
+      for (int q = 0; q < n; q++) x[q] += r[q];
+      /* restart residual */
+      memcpy(V[0], b, sizeof(double) * (size_t)n);
+      orc_spmv(A, -1.0, x, 1.0, V[0]);
+      double true_norm = sqrt(orc_dot(n, V[0], V[0]));
+      if (r_norm <= epsilon)
+      {
+         r_norm = true_norm;
+         if (true_norm <= epsilon) { *converged = 1; break; }
+      }
+      else
+         r_norm = true_norm;
+   }
+   *final_rel = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
+done:
+   for (int i = 0; i <= k; i++) free(V[i]);
+   free(V); free(w); free(r); free(H); free(cs); free(sn); free(rs);
+   return iter;
+}

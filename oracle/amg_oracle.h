@@ -1,0 +1,128 @@
+/*
+ * amg_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the algorithms that the reference (hypredrive) reaches
+ * through its op tables src/internal/solver.c:204-253 and src/internal/precon.c:106-157,
+ * i.e. hypre's ParCSR PCG / GMRES + BoomerAMG V-cycle.  hypre itself is a
+ * third-party dependency that is NOT vendored under /root/reference and is not
+ * version pinned (cmake/HYPREDRV_Deps.cmake:1048, HYPRE_VERSION "master"; refOutputs
+ * were made with a v3.0.0 build, examples/refOutput/laplacian.txt:42), so this file
+ * restates the published algorithms (Ruge-Stueben strength, PMIS/HMIS coarsening,
+ * extended+i interpolation, Galerkin RAP, l1 smoothers, PCG) and is pinned only by
+ * the reference's own checked-in outputs (examples/refOutput/{ex1,ex2,laplacian}.txt)
+ * and unit-test known answers -- see tests/test_oracle_pins.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ */
+#ifndef AMG_ORACLE_H
+#define AMG_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+   int     nrows, ncols;
+   int    *rowptr; /* nrows+1 */
+   int    *col;    /* nnz, ascending inside each row */
+   double *val;    /* nnz */
+} orc_csr;
+
+/* Parameter contract = reference AMG_args (include/internal/amg.h:108-123) with the
+ * defaults of src/internal/amg.c:120-238. */
+typedef struct {
+   int    coarsen_type;    /* 8 PMIS (hypre-GPU default), 10 HMIS, 6 Falgout->RS pass */
+   int    interp_type;     /* 6 extended+i */
+   int    pmax;            /* interpolation.max_nnz_row = 4 */
+   double trunc_factor;    /* 0.0 */
+   double strong_th;       /* 0.25 */
+   double max_row_sum;     /* 0.9 */
+   int    max_coarse_size; /* 64 */
+   int    min_coarse_size; /* 0 */
+   int    max_levels;      /* 25 */
+   int    relax_down;      /* 18 (GPU default) or 13 */
+   int    relax_up;        /* 18 or 14 */
+   int    relax_coarse;    /* 9 */
+   int    sweeps_down;     /* 1 */
+   int    sweeps_up;       /* 1 */
+   int    sweeps_coarse;   /* 1 */
+   double relax_weight;    /* 1.0 */
+   double outer_weight;    /* 1.0 */
+   uint64_t seed;          /* PMIS tie-break hash seed */
+} orc_amg_params;
+
+typedef struct orc_amg orc_amg; /* hierarchy handle */
+
+typedef struct {
+   int    max_iter;     /* 100 */
+   double rtol;         /* 1e-6 */
+   double atol;         /* 0 */
+   int    two_norm;     /* 1 */
+   int    krylov_dim;   /* GMRES only: 30 */
+} orc_krylov_params;
+
+void orc_amg_default_params(orc_amg_params *p, int gpu_defaults);
+void orc_krylov_default_params(orc_krylov_params *p, int gmres);
+
+/* CSR utilities */
+orc_csr *orc_csr_alloc(int nrows, int ncols, int nnz);
+void     orc_csr_free(orc_csr *A);
+orc_csr *orc_csr_from_arrays(int nrows, int ncols, const int64_t *rowptr,
+                             const int64_t *cols, const double *vals); /* copies + sorts rows */
+orc_csr *orc_csr_transpose(const orc_csr *A);
+
+/* Benchmark matrix: examples/src/C_laplacian/laplacian.c:719-921 (7-pt, Dirichlet by
+ * truncation) in the block-partition numbering of laplacian.c:504-520.  Returns the
+ * GLOBAL matrix; b (length N) gets 1 on the global y=0 plane else 0 (b_mode 0), or all
+ * ones (b_mode 1 == the ps3d10pt7 data set of examples/ex1.yml). */
+orc_csr *orc_lap7(int nx, int ny, int nz, int px, int py, int pz, double cx, double cy,
+                  double cz, int b_mode, double *b);
+/* Row range owned by rank r in that numbering. */
+void orc_lap7_partition(int nx, int ny, int nz, int px, int py, int pz, int rank,
+                        int64_t *ilower, int64_t *iupper);
+
+/* Kernels */
+void   orc_spmv(const orc_csr *A, double alpha, const double *x, double beta, double *y);
+double orc_dot(int n, const double *x, const double *y);
+void   orc_l1_norms(const orc_csr *A, int option, double *l1); /* 1: full row, 4: diag (1 rank) */
+void   orc_relax(const orc_csr *A, const double *l1, int type, double weight,
+                 const double *b, double *x, double *tmp);
+
+/* Setup pieces (exposed for per-kernel parity tests) */
+void orc_strength(const orc_csr *A, double theta, double max_row_sum, unsigned char *smask);
+void orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
+              int64_t row_offset, int *cf); /* cf: 1 C, -1 F, -3 special F */
+void orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf);
+orc_csr *orc_interp_extpi(const orc_csr *A, const unsigned char *smask, const int *cf,
+                          int pmax, double trunc_factor);
+orc_csr *orc_rap(const orc_csr *A, const orc_csr *P);
+
+/* Hierarchy */
+orc_amg *orc_amg_setup(const orc_csr *A, const orc_amg_params *p);
+void     orc_amg_free(orc_amg *h);
+int      orc_amg_num_levels(const orc_amg *h);
+const orc_csr *orc_amg_A(const orc_amg *h, int lvl);
+const orc_csr *orc_amg_P(const orc_amg *h, int lvl); /* NULL on coarsest */
+const int     *orc_amg_cf(const orc_amg *h, int lvl);
+const double  *orc_amg_l1(const orc_amg *h, int lvl, int which); /* 0 down, 1 up */
+double   orc_amg_operator_complexity(const orc_amg *h);
+double   orc_amg_grid_complexity(const orc_amg *h);
+void     orc_amg_vcycle(orc_amg *h, const double *b, double *x); /* x must hold the initial guess */
+
+/* Krylov (hypre_PCGSolve / hypre_GMRESSolve restatements).
+ * h == NULL -> unpreconditioned.  resid_hist[k] = ||r_k||_2 for k=0..iters
+ * (needs max_iter+1 doubles).  Returns iterations; *converged, *final_rel set. */
+int orc_pcg(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b,
+            double *x, double *resid_hist, int *converged, double *final_rel);
+int orc_gmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b,
+              double *x, double *resid_hist, int *converged, double *final_rel);
+
+/* Dense no-pivot Gaussian elimination (hypre relax type 9). a is n*n row-major, destroyed. */
+int orc_gselim(double *a, double *x, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

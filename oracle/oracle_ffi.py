@@ -1,0 +1,315 @@
+"""ctypes binding of the CPU ORACLE (oracle/amg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Product code (hypredrive_amd/) must never import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class CsrStruct(C.Structure):
+    _fields_ = [("nrows", C.c_int), ("ncols", C.c_int), ("rowptr", C.POINTER(C.c_int)),
+                ("col", C.POINTER(C.c_int)), ("val", C.POINTER(C.c_double))]
+
+
+class AmgParams(C.Structure):
+    _fields_ = [("coarsen_type", C.c_int), ("interp_type", C.c_int), ("pmax", C.c_int),
+                ("trunc_factor", C.c_double), ("strong_th", C.c_double),
+                ("max_row_sum", C.c_double), ("max_coarse_size", C.c_int),
+                ("min_coarse_size", C.c_int), ("max_levels", C.c_int),
+                ("relax_down", C.c_int), ("relax_up", C.c_int), ("relax_coarse", C.c_int),
+                ("sweeps_down", C.c_int), ("sweeps_up", C.c_int), ("sweeps_coarse", C.c_int),
+                ("relax_weight", C.c_double), ("outer_weight", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+class KrylovParams(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
+                ("two_norm", C.c_int), ("krylov_dim", C.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "amg_oracle.c")
+    if force or not os.path.exists(so) or (
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = C.CDLL(build())
+    P = C.POINTER
+    cp = P(CsrStruct)
+    dp = P(C.c_double)
+    ip = P(C.c_int)
+    L.orc_amg_default_params.argtypes = [P(AmgParams), C.c_int]
+    L.orc_krylov_default_params.argtypes = [P(KrylovParams), C.c_int]
+    L.orc_csr_free.argtypes = [cp]
+    L.orc_csr_from_arrays.restype = cp
+    L.orc_csr_from_arrays.argtypes = [C.c_int, C.c_int, P(C.c_int64), P(C.c_int64), dp]
+    L.orc_csr_transpose.restype = cp
+    L.orc_csr_transpose.argtypes = [cp]
+    L.orc_lap7.restype = cp
+    L.orc_lap7.argtypes = [C.c_int] * 6 + [C.c_double] * 3 + [C.c_int, dp]
+    L.orc_lap7_partition.argtypes = [C.c_int] * 7 + [P(C.c_int64), P(C.c_int64)]
+    L.orc_spmv.argtypes = [cp, C.c_double, dp, C.c_double, dp]
+    L.orc_dot.restype = C.c_double
+    L.orc_dot.argtypes = [C.c_int, dp, dp]
+    L.orc_l1_norms.argtypes = [cp, C.c_int, dp]
+    L.orc_relax.argtypes = [cp, dp, C.c_int, C.c_double, dp, dp, dp]
+    L.orc_strength.argtypes = [cp, C.c_double, C.c_double, P(C.c_ubyte)]
+    L.orc_pmis.argtypes = [cp, P(C.c_ubyte), C.c_uint64, C.c_int, C.c_int64, ip]
+    L.orc_rs_first_pass.argtypes = [cp, P(C.c_ubyte), ip]
+    L.orc_interp_extpi.restype = cp
+    L.orc_interp_extpi.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double]
+    L.orc_rap.restype = cp
+    L.orc_rap.argtypes = [cp, cp]
+    L.orc_amg_setup.restype = C.c_void_p
+    L.orc_amg_setup.argtypes = [cp, P(AmgParams)]
+    L.orc_amg_free.argtypes = [C.c_void_p]
+    L.orc_amg_num_levels.argtypes = [C.c_void_p]
+    L.orc_amg_A.restype = cp
+    L.orc_amg_A.argtypes = [C.c_void_p, C.c_int]
+    L.orc_amg_P.restype = cp
+    L.orc_amg_P.argtypes = [C.c_void_p, C.c_int]
+    L.orc_amg_cf.restype = ip
+    L.orc_amg_cf.argtypes = [C.c_void_p, C.c_int]
+    L.orc_amg_l1.restype = dp
+    L.orc_amg_l1.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_amg_operator_complexity.restype = C.c_double
+    L.orc_amg_operator_complexity.argtypes = [C.c_void_p]
+    L.orc_amg_grid_complexity.restype = C.c_double
+    L.orc_amg_grid_complexity.argtypes = [C.c_void_p]
+    L.orc_amg_vcycle.argtypes = [C.c_void_p, dp, dp]
+    for f in (L.orc_pcg, L.orc_gmres):
+        f.restype = C.c_int
+        f.argtypes = [cp, C.c_void_p, P(KrylovParams), dp, dp, dp, ip, dp]
+    L.orc_gselim.argtypes = [dp, dp, C.c_int]
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Csr:
+    """Owns (or borrows) an orc_csr*; exposes numpy views."""
+
+    def __init__(self, ptr, owned=True):
+        self.ptr = ptr
+        self.owned = owned
+
+    def __del__(self):
+        if getattr(self, "owned", False) and self.ptr:
+            lib().orc_csr_free(self.ptr)
+            self.ptr = None
+
+    @property
+    def nrows(self):
+        return self.ptr.contents.nrows
+
+    @property
+    def ncols(self):
+        return self.ptr.contents.ncols
+
+    @property
+    def rowptr(self):
+        return np.ctypeslib.as_array(self.ptr.contents.rowptr, shape=(self.nrows + 1,))
+
+    @property
+    def nnz(self):
+        return int(self.rowptr[-1])
+
+    @property
+    def col(self):
+        return np.ctypeslib.as_array(self.ptr.contents.col, shape=(max(self.nnz, 1),))[:self.nnz]
+
+    @property
+    def val(self):
+        return np.ctypeslib.as_array(self.ptr.contents.val, shape=(max(self.nnz, 1),))[:self.nnz]
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.val.copy(), self.col.copy(), self.rowptr.copy()),
+                             shape=(self.nrows, self.ncols))
+
+    @staticmethod
+    def from_arrays(nrows, ncols, rowptr, cols, vals):
+        rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+        cj = np.ascontiguousarray(cols, dtype=np.int64)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        p = lib().orc_csr_from_arrays(nrows, ncols, rp.ctypes.data_as(C.POINTER(C.c_int64)),
+                                      cj.ctypes.data_as(C.POINTER(C.c_int64)), _dp(v))
+        return Csr(p)
+
+    @staticmethod
+    def from_scipy(m):
+        m = m.tocsr()
+        return Csr.from_arrays(m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
+
+
+def lap7(nx, ny, nz, P=(1, 1, 1), c=(1.0, 1.0, 1.0), b_mode=0):
+    n = nx * ny * nz
+    b = np.zeros(n)
+    p = lib().orc_lap7(nx, ny, nz, P[0], P[1], P[2], c[0], c[1], c[2], b_mode, _dp(b))
+    return Csr(p), b
+
+
+def lap7_partition(nx, ny, nz, P, rank):
+    lo = C.c_int64()
+    hi = C.c_int64()
+    lib().orc_lap7_partition(nx, ny, nz, P[0], P[1], P[2], rank, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def amg_params(gpu_defaults=True, **kw):
+    p = AmgParams()
+    lib().orc_amg_default_params(C.byref(p), 1 if gpu_defaults else 0)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def krylov_params(gmres=False, **kw):
+    p = KrylovParams()
+    lib().orc_krylov_default_params(C.byref(p), 1 if gmres else 0)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def spmv(A, x, alpha=1.0, beta=0.0, y=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(A.nrows) if y is None else np.ascontiguousarray(y, dtype=np.float64).copy()
+    lib().orc_spmv(A.ptr, alpha, _dp(x), beta, _dp(y))
+    return y
+
+
+def l1_norms(A, option=1):
+    out = np.zeros(A.nrows)
+    lib().orc_l1_norms(A.ptr, option, _dp(out))
+    return out
+
+
+def relax(A, l1, rtype, weight, b, x):
+    x = np.ascontiguousarray(x, dtype=np.float64).copy()
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    tmp = np.zeros(A.nrows)
+    l1 = np.ascontiguousarray(l1, dtype=np.float64)
+    lib().orc_relax(A.ptr, _dp(l1), rtype, weight, _dp(b), _dp(x), _dp(tmp))
+    return x
+
+
+def strength(A, theta=0.25, max_row_sum=0.9):
+    sm = np.zeros(max(A.nnz, 1), dtype=np.uint8)
+    lib().orc_strength(A.ptr, theta, max_row_sum, sm.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return sm[:A.nnz]
+
+
+def pmis(A, smask, seed=2747, level=0, row_offset=0):
+    cf = np.zeros(A.nrows, dtype=np.int32)
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    lib().orc_pmis(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), seed, level, row_offset,
+                   cf.ctypes.data_as(C.POINTER(C.c_int)))
+    return cf
+
+
+def rs_first_pass(A, smask):
+    cf = np.zeros(A.nrows, dtype=np.int32)
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    lib().orc_rs_first_pass(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                            cf.ctypes.data_as(C.POINTER(C.c_int)))
+    return cf
+
+
+def interp_extpi(A, smask, cf, pmax=4, trunc_factor=0.0):
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    cfa = np.ascontiguousarray(cf, dtype=np.int32)
+    return Csr(lib().orc_interp_extpi(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                      cfa.ctypes.data_as(C.POINTER(C.c_int)), pmax,
+                                      trunc_factor))
+
+
+def rap(A, P):
+    return Csr(lib().orc_rap(A.ptr, P.ptr))
+
+
+class Amg:
+    def __init__(self, A, params=None):
+        self.A = A
+        self.params = params if params is not None else amg_params(True)
+        self.h = lib().orc_amg_setup(A.ptr, C.byref(self.params))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_amg_free(self.h)
+            self.h = None
+
+    @property
+    def num_levels(self):
+        return lib().orc_amg_num_levels(self.h)
+
+    def level_A(self, l):
+        return Csr(lib().orc_amg_A(self.h, l), owned=False)
+
+    def level_P(self, l):
+        p = lib().orc_amg_P(self.h, l)
+        return Csr(p, owned=False) if p else None
+
+    def level_cf(self, l):
+        n = self.level_A(l).nrows
+        p = lib().orc_amg_cf(self.h, l)
+        return np.ctypeslib.as_array(p, shape=(n,)).copy() if p else None
+
+    def level_l1(self, l, which=0):
+        n = self.level_A(l).nrows
+        return np.ctypeslib.as_array(lib().orc_amg_l1(self.h, l, which), shape=(n,)).copy()
+
+    @property
+    def operator_complexity(self):
+        return lib().orc_amg_operator_complexity(self.h)
+
+    @property
+    def grid_complexity(self):
+        return lib().orc_amg_grid_complexity(self.h)
+
+    def vcycle(self, b, x0=None):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+        lib().orc_amg_vcycle(self.h, _dp(b), _dp(x))
+        return x
+
+
+def _krylov(fn, A, b, amg, kp, x0):
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+    hist = np.zeros(kp.max_iter + 2)
+    conv = C.c_int()
+    frel = C.c_double()
+    it = fn(A.ptr, amg.h if amg is not None else None, C.byref(kp), _dp(b), _dp(x), _dp(hist),
+            C.byref(conv), C.byref(frel))
+    return dict(x=x, iters=it, converged=bool(conv.value), final_rel=frel.value,
+                hist=hist[:it + 1].copy())
+
+
+def pcg(A, b, amg=None, kp=None, x0=None):
+    return _krylov(lib().orc_pcg, A, b, amg, kp or krylov_params(False), x0)
+
+
+def gmres(A, b, amg=None, kp=None, x0=None):
+    return _krylov(lib().orc_gmres, A, b, amg, kp or krylov_params(True), x0)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Extract the numeric pins the reference keeps in its checked-in outputs
+(examples/refOutput/*.txt) into tests/golden/ref_pins.json.
+
+Run in the build container (needs /root/reference); the JSON is committed because the
+reference does not travel to the GPU box.  Only numbers are extracted -- no reference
+source text is stored.
+"""
+import json
+import os
+import re
+import sys
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_pins.json")
+
+
+def stats_rows(txt):
+    rows = []
+    for m in re.finditer(r"^\|\s+(\d+) \|\s+([\d.]*) \|\s+([\d.]+) \|\s+([\d.]+) \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|",
+                         txt, re.M):
+        rows.append(dict(entry=int(m.group(1)), r0=float(m.group(5)), rel=float(m.group(6)),
+                         iters=int(m.group(7))))
+    return rows
+
+
+def main():
+    pins = {}
+    ro = os.path.join(REF, "examples", "refOutput")
+    ex1 = open(os.path.join(ro, "ex1.txt")).read()
+    m = re.search(r"with (\d+) rows and (\d+) nonzeros", ex1)
+    pins["ex1"] = dict(source="examples/refOutput/ex1.txt:17,27", rows=int(m.group(1)),
+                       nnz=int(m.group(2)), stats=stats_rows(ex1),
+                       config="10^3 7-pt, b=ones, PCG + BoomerAMG CPU defaults (HMIS, ext+i, hl1GS 13/14)")
+    ex2 = open(os.path.join(ro, "ex2.txt")).read()
+    ops = [dict(lev=int(a), rows=int(b), nnz=int(c)) for a, b, c in
+           re.findall(r"^\s+(\d+)\s+(\d+)\s+(\d+)\s+[\d.]+\s+\d+\s+\d+\s+[\d.]+\s+\S+\s+\S+\s*$", ex2, re.M)]
+    interp = [dict(lev=int(a), rows=int(b), cols=int(c), min=int(d), max=int(e)) for a, b, c, d, e in
+              re.findall(r"^\s+(\d+)\s+(\d+) x (\d+)\s+(\d+)\s+(\d+)\s+[\d.]+", ex2, re.M)]
+    hist = [(int(a), float(b), float(c)) for a, b, c in
+            re.findall(r"^\s+(\d+)\s+([\d.]+e[+-]\d+)\s+[\d.]+\s+([\d.]+e[+-]\d+)\s*$", ex2, re.M)]
+    cx = re.search(r"grid = ([\d.]+)\s+operator = ([\d.]+)", ex2)
+    bb = re.search(r"<b,b>: (\S+)", ex2)
+    pins["ex2"] = dict(source="examples/refOutput/ex2.txt:124-139,160-169", operators=ops,
+                       interp=interp, grid_complexity=float(cx.group(1)),
+                       operator_complexity=float(cx.group(2)), bdotb=float(bb.group(1)),
+                       history=[dict(it=a, rnorm=b, rel=c) for a, b, c in hist],
+                       stats=stats_rows(ex2),
+                       config="same matrix on 4 ranks, PMIS + ext+i(4) + hl1GS 13/14 + FSAI level-0 smoother")
+    lap = open(os.path.join(ro, "laplacian.txt")).read()
+    pins["laplacian"] = dict(source="examples/refOutput/laplacian.txt:10-16,34-38",
+                             stats=stats_rows(lap),
+                             config="10^3 generator defaults, b=1 on y=0 plane, presets pcg+poisson, CPU defaults")
+    # analytic unit-test anchors (tests/test_linsys.c:4126-4155, tests/test_setmatrix_from_csr.c:397-417)
+    pins["unit"] = dict(norms_of_1_m2_3=dict(L1=6.0, L2=14.0 ** 0.5, Linf=3.0),
+                        one_by_one=dict(a=3.0, b=6.0, x_norm=2.0, tol=1e-6))
+    json.dump(pins, open(OUT, "w"), indent=1, sort_keys=True)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,189 @@
+"""Pin the CPU oracle against every numeric anchor the reference holds for this path
+(numbers extracted into tests/golden/ref_pins.json by
+tests/golden/make_ref_pins.py) and against scipy as an independent check."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+def test_lap7_shape_and_values(orc, pins):
+    A, b = orc.lap7(10, 10, 10, b_mode=1)
+    assert A.nrows == pins["ex1"]["rows"] and A.nnz == pins["ex1"]["nnz"]
+    S = A.to_scipy()
+    # row sums min 0 / max 3, entries/row 4..7 (examples/refOutput/ex2.txt:125)
+    rs = np.asarray(S.sum(axis=1)).ravel()
+    assert rs.min() == 0.0 and rs.max() == 3.0
+    cnt = np.diff(S.indptr)
+    assert cnt.min() == 4 and cnt.max() == 7
+    assert np.all(S.diagonal() == 6.0)
+    assert abs(np.linalg.norm(b) - pins["ex1"]["stats"][0]["r0"]) < 0.05  # 3.16e+01
+    assert (S != S.T).nnz == 0
+
+
+def test_lap7_generator_rhs_and_blocks(orc, pins):
+    A, b = orc.lap7(10, 10, 10, b_mode=0)
+    assert np.linalg.norm(b) == pytest.approx(pins["laplacian"]["stats"][0]["r0"])  # 1.00e+01
+    # block-partitioned numbering is a symmetric permutation of the lexicographic one
+    A1 = A.to_scipy()
+    A2, b2 = orc.lap7(10, 10, 10, P=(2, 2, 1))
+    A2 = A2.to_scipy()
+    assert A2.nnz == A1.nnz and (A2 != A2.T).nnz == 0
+    e1 = np.sort(spla.eigsh(A1, k=3, which="LA", return_eigenvectors=False))
+    e2 = np.sort(spla.eigsh(A2, k=3, which="LA", return_eigenvectors=False))
+    assert np.allclose(e1, e2, rtol=1e-10)
+    assert b2.sum() == b.sum()
+    lo0, hi0 = orc.lap7_partition(10, 10, 10, (2, 2, 1), 0)
+    lo3, hi3 = orc.lap7_partition(10, 10, 10, (2, 2, 1), 3)
+    assert (lo0, hi0) == (0, 249) and (lo3, hi3) == (750, 999)
+
+
+def test_pin_ex1_cpu_defaults(orc, pins):
+    """examples/refOutput/ex1.txt:27 -- 6 iterations, final 4.98e-08."""
+    A, b = orc.lap7(10, 10, 10, b_mode=1)
+    amg = orc.Amg(A, orc.amg_params(False))
+    r = orc.pcg(A, b, amg)
+    ref = pins["ex1"]["stats"][0]
+    assert r["converged"] and r["iters"] == ref["iters"]
+    S = A.to_scipy()
+    true_rel = np.linalg.norm(b - S @ r["x"]) / np.linalg.norm(b)
+    # hypre's list/hash orders on coarse levels are upstream detail: 2 % on the 6-iteration residual
+    assert true_rel == pytest.approx(ref["rel"], rel=0.02)
+
+
+def test_pin_laplacian_driver(orc, pins):
+    """examples/refOutput/laplacian.txt:34-38 -- 5 iterations, 6.12e-07."""
+    A, b = orc.lap7(10, 10, 10, b_mode=0)
+    amg = orc.Amg(A, orc.amg_params(False))
+    r = orc.pcg(A, b, amg)
+    ref = pins["laplacian"]["stats"][0]
+    assert r["converged"] and r["iters"] == ref["iters"]
+    S = A.to_scipy()
+    true_rel = np.linalg.norm(b - S @ r["x"]) / np.linalg.norm(b)
+    assert true_rel == pytest.approx(ref["rel"], rel=0.02)
+
+
+def test_pin_ex2_pmis_hierarchy(orc, pins):
+    """examples/refOutput/ex2.txt:124-139: PMIS/ext+i hierarchy 1000/351/62, nnz 6400/7485/1986,
+    P rows 1..4 entries, complexities 1.413 / 2.48.  hypre's RNG stream (and the 4-rank
+    partition) cannot be reproduced, so sizes are compared to a few percent."""
+    A, b = orc.lap7(10, 10, 10, b_mode=1)
+    amg = orc.Amg(A, orc.amg_params(True))
+    ref = pins["ex2"]
+    assert amg.num_levels == len(ref["operators"])
+    for l, op in enumerate(ref["operators"]):
+        Al = amg.level_A(l)
+        assert Al.nrows == pytest.approx(op["rows"], rel=0.12), (l, Al.nrows)
+        assert Al.nnz == pytest.approx(op["nnz"], rel=0.15), (l, Al.nnz)
+    assert amg.grid_complexity == pytest.approx(ref["grid_complexity"], rel=0.02)
+    assert amg.operator_complexity == pytest.approx(ref["operator_complexity"], rel=0.05)
+    for l, ip in enumerate(ref["interp"]):
+        P = amg.level_P(l)
+        cnt = np.diff(P.rowptr)
+        assert cnt.max() == ip["max"]
+        rs = np.asarray(P.to_scipy().sum(axis=1)).ravel()
+        assert rs.max() <= 1.0 + 1e-12
+    # <b,b> = 1000 (ex2.txt:160)
+    assert float(b @ b) == ref["bdotb"]
+
+
+def test_pmis_is_valid_mis(orc):
+    A, _ = orc.lap7(12, 9, 7)
+    sm = orc.strength(A)
+    cf = orc.pmis(A, sm)
+    S = A.to_scipy()
+    S.data = sm.astype(float)
+    S.eliminate_zeros()
+    G = ((S + S.T) > 0).tocsr()
+    C = cf == 1
+    # independence: no two C points strongly connected; maximality: every F has a strong C
+    assert G[C][:, C].nnz == 0
+    dep = S.tocsr()
+    for i in np.where(cf == -1)[0]:
+        nb = dep.indices[dep.indptr[i]:dep.indptr[i + 1]]
+        assert C[nb].any()
+    assert set(np.unique(cf)) <= {1, -1, -3}
+
+
+def test_rap_matches_scipy(orc):
+    A, _ = orc.lap7(9, 8, 7)
+    sm = orc.strength(A)
+    cf = orc.pmis(A, sm)
+    P = orc.interp_extpi(A, sm, cf)
+    Ac = orc.rap(A, P)
+    Ps, As = P.to_scipy(), A.to_scipy()
+    ref = (Ps.T @ As @ Ps).tocsr()
+    d = (Ac.to_scipy() - ref)
+    assert abs(d).max() < 1e-13
+    rp, cj = Ac.rowptr, Ac.col
+    for i in range(Ac.nrows):  # rows column-sorted, no duplicates
+        assert np.all(np.diff(cj[rp[i]:rp[i + 1]]) > 0)
+
+
+def test_interp_partition_of_unity_interior(orc):
+    """Interior rows of a zero-row-sum operator interpolate constants exactly."""
+    A, _ = orc.lap7(10, 10, 10)
+    sm = orc.strength(A)
+    cf = orc.pmis(A, sm)
+    P = orc.interp_extpi(A, sm, cf).to_scipy()
+    rs = np.asarray(P.sum(axis=1)).ravel()
+    S = A.to_scipy()
+    interior = np.asarray(S.sum(axis=1)).ravel() == 0.0
+    fpts = (cf == -1) & interior
+    assert fpts.sum() > 50
+    assert np.allclose(rs[fpts], 1.0, atol=1e-12)
+    assert np.all(rs[cf == 1] == 1.0)
+
+
+def test_pcg_matches_scipy_solution(orc):
+    A, b = orc.lap7(8, 8, 8, b_mode=1)
+    r = orc.pcg(A, b, None, orc.krylov_params(False, rtol=1e-12, max_iter=500))
+    x = spla.spsolve(A.to_scipy().tocsc(), b)
+    assert r["converged"]
+    assert np.linalg.norm(r["x"] - x) / np.linalg.norm(x) < 1e-10
+
+
+def test_gmres_amg_converges(orc):
+    A, b = orc.lap7(10, 10, 10, b_mode=0)
+    amg = orc.Amg(A, orc.amg_params(True))
+    r = orc.gmres(A, b, amg)
+    S = A.to_scipy()
+    assert r["converged"]
+    assert np.linalg.norm(b - S @ r["x"]) / np.linalg.norm(b) < 1e-6
+    assert r["iters"] <= 12
+
+
+def test_unit_anchor_one_by_one(orc, pins):
+    """tests/test_setmatrix_from_csr.c:397-417: 3x = 6 -> ||x|| = 2."""
+    u = pins["unit"]["one_by_one"]
+    A = orc.Csr.from_arrays(1, 1, [0, 1], [0], [u["a"]])
+    amg = orc.Amg(A, orc.amg_params(True))
+    assert amg.num_levels == 1
+    r = orc.pcg(A, np.array([u["b"]]), amg)
+    assert abs(np.linalg.norm(r["x"]) - u["x_norm"]) < u["tol"]
+
+
+def test_unit_anchor_1d_laplacian(orc):
+    """tests/test_setmatrix_from_csr.c:168-199: 1-D Laplacian n=16 solves."""
+    n = 16
+    T = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(n, n), format="csr")
+    A = orc.Csr.from_scipy(T)
+    b = np.ones(n)
+    r = orc.pcg(A, b, orc.Amg(A, orc.amg_params(True)))
+    assert r["converged"] and np.linalg.norm(r["x"]) > 0
+    assert np.allclose(T @ r["x"], b, atol=1e-5)
+
+
+def test_zero_rhs_returns_zero(orc):
+    A, _ = orc.lap7(5, 5, 5)
+    r = orc.pcg(A, np.zeros(A.nrows), None)
+    assert r["iters"] == 0 and np.all(r["x"] == 0)
+
+
+def test_init_guess_exact_zero_iters(orc):
+    """tests/test_init_guess.c:247-270: x0 = ones on b = A*1 -> residual 0."""
+    A, _ = orc.lap7(6, 6, 6)
+    S = A.to_scipy()
+    b = S @ np.ones(A.nrows)
+    r = orc.pcg(A, b, None, x0=np.ones(A.nrows))
+    assert r["hist"][0] == 0.0 or r["iters"] <= 1
