@@ -1,0 +1,9 @@
+"""hypredrive_amd -- MI355X-native AMG-Krylov solve path behind the hypredrive API.
+
+Thin ctypes binding over libhypredrv_amd.so (HIP kernels + C ABI, see include/*.h).
+There is no CPU fallback: every compute call fails loudly when the HIP library or a
+device is missing.
+"""
+from . import _lib  # noqa: F401
+from ._lib import (AmgParams, KrylovParams, Csr, Amg, load, device_count, device_name,  # noqa: F401
+                   lap7, pcg, gmres, solve_timed, time_kernel, LibraryError)

@@ -1,0 +1,337 @@
+"""ctypes binding of the kernel-level C ABI (include/hypredrv_amd.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "lib", "libhypredrv_amd.so")
+_L = None
+
+
+class LibraryError(RuntimeError):
+    pass
+
+
+class AmgParams(C.Structure):
+    _fields_ = [("coarsen_type", C.c_int), ("interp_type", C.c_int), ("pmax", C.c_int),
+                ("trunc_factor", C.c_double), ("strong_th", C.c_double),
+                ("max_row_sum", C.c_double), ("max_coarse_size", C.c_int),
+                ("min_coarse_size", C.c_int), ("max_levels", C.c_int),
+                ("relax_down", C.c_int), ("relax_up", C.c_int), ("relax_coarse", C.c_int),
+                ("sweeps_down", C.c_int), ("sweeps_up", C.c_int), ("sweeps_coarse", C.c_int),
+                ("relax_weight", C.c_double), ("outer_weight", C.c_double),
+                ("seed", C.c_uint64)]
+
+    @staticmethod
+    def default(**kw):
+        p = AmgParams()
+        load().hda_amg_default_params(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise KeyError(k)
+            setattr(p, k, v)
+        return p
+
+
+class KrylovParams(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
+                ("two_norm", C.c_int), ("krylov_dim", C.c_int)]
+
+    @staticmethod
+    def default(gmres=False, **kw):
+        p = KrylovParams()
+        load().hda_krylov_default_params(C.byref(p), 1 if gmres else 0)
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise KeyError(k)
+            setattr(p, k, v)
+        return p
+
+
+# every symbol include/hypredrv_amd.h declares (checked by tests/test_cabi_symbols.py)
+SYMBOLS = [
+    "hda_last_error", "hda_device_count", "hda_device_name", "hda_device_sync",
+    "hda_amg_default_params", "hda_krylov_default_params", "hda_csr_create", "hda_csr_destroy",
+    "hda_csr_dims", "hda_csr_download", "hda_lap7_create", "hda_spmv", "hda_relax", "hda_dot",
+    "hda_l1_norms", "hda_strength", "hda_pmis", "hda_interp_extpi", "hda_rap", "hda_transpose",
+    "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
+    "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
+    "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_timed",
+]
+
+
+def load():
+    """Load libhypredrv_amd.so; raises (never falls back) when it is missing."""
+    global _L
+    if _L is not None:
+        return _L
+    if not os.path.exists(_LIBPATH):
+        raise LibraryError(
+            f"{_LIBPATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the MI355X solve path has no CPU fallback)")
+    L = C.CDLL(_LIBPATH)
+    P = C.POINTER
+    dp, ip, vp = P(C.c_double), P(C.c_int), C.c_void_p
+    L.hda_last_error.restype = C.c_char_p
+    L.hda_device_name.argtypes = [C.c_char_p, C.c_int]
+    L.hda_amg_default_params.argtypes = [P(AmgParams)]
+    L.hda_amg_default_params.restype = None
+    L.hda_krylov_default_params.argtypes = [P(KrylovParams), C.c_int]
+    L.hda_krylov_default_params.restype = None
+    L.hda_csr_create.argtypes = [C.c_int, C.c_int, P(C.c_int64), P(C.c_int64), dp, P(vp)]
+    L.hda_csr_destroy.argtypes = [vp]
+    L.hda_csr_dims.argtypes = [vp, ip, ip, ip]
+    L.hda_csr_download.argtypes = [vp, ip, ip, dp]
+    L.hda_lap7_create.argtypes = [ip, ip, ip, dp, P(vp), dp]
+    L.hda_spmv.argtypes = [vp, C.c_double, dp, C.c_double, dp]
+    L.hda_relax.argtypes = [vp, C.c_int, C.c_double, C.c_int, dp, dp]
+    L.hda_dot.argtypes = [C.c_int, dp, dp, dp]
+    L.hda_l1_norms.argtypes = [vp, C.c_int, dp]
+    L.hda_strength.argtypes = [vp, C.c_double, C.c_double, P(C.c_ubyte)]
+    L.hda_pmis.argtypes = [vp, P(C.c_ubyte), C.c_uint64, C.c_int, C.c_int64, ip]
+    L.hda_interp_extpi.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
+    L.hda_rap.argtypes = [vp, vp, P(vp)]
+    L.hda_transpose.argtypes = [vp, P(vp)]
+    L.hda_spgemm.argtypes = [vp, vp, P(vp)]
+    L.hda_amg_create.argtypes = [P(AmgParams), vp, P(vp)]
+    L.hda_amg_destroy.argtypes = [vp]
+    L.hda_amg_num_levels.argtypes = [vp]
+    L.hda_amg_level_matrix.argtypes = [vp, C.c_int, C.c_int, P(vp)]
+    L.hda_amg_level_cf.argtypes = [vp, C.c_int, ip]
+    L.hda_amg_complexities.argtypes = [vp, dp, dp]
+    L.hda_amg_vcycle_bytes.argtypes = [vp]
+    L.hda_amg_vcycle_bytes.restype = C.c_double
+    L.hda_amg_vcycle.argtypes = [vp, dp, dp]
+    for f in (L.hda_pcg, L.hda_gmres):
+        f.argtypes = [vp, vp, P(KrylovParams), dp, dp, dp, ip, ip, dp]
+    L.hda_time_kernel.argtypes = [C.c_int, vp, vp, C.c_int, dp, dp]
+    L.hda_solve_timed.argtypes = [vp, P(AmgParams), P(KrylovParams), dp, C.c_int, dp, dp, ip, dp, dp,
+                                  dp, dp, dp, ip]
+    _L = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise LibraryError(f"libhypredrv_amd error {rc}: {load().hda_last_error().decode()}")
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def device_count():
+    return load().hda_device_count()
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    _check(load().hda_device_name(buf, 256))
+    return buf.value.decode()
+
+
+class Csr:
+    """CSR block resident in HBM."""
+
+    def __init__(self, handle, owned=True, keep=None):
+        self.h = handle
+        self.owned = owned
+        self._keep = keep
+        self.rhs = None
+
+    def __del__(self):
+        if getattr(self, "owned", False) and self.h:
+            load().hda_csr_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def from_arrays(nrows, ncols, rowptr, cols, vals):
+        rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+        cj = np.ascontiguousarray(cols, dtype=np.int64)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        out = C.c_void_p()
+        _check(load().hda_csr_create(nrows, ncols, rp.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     cj.ctypes.data_as(C.POINTER(C.c_int64)), _dp(v), C.byref(out)))
+        return Csr(out)
+
+    @staticmethod
+    def from_scipy(m):
+        m = m.tocsr()
+        return Csr.from_arrays(m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
+
+    @property
+    def dims(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(load().hda_csr_dims(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    nrows = property(lambda s: s.dims[0])
+    ncols = property(lambda s: s.dims[1])
+    nnz = property(lambda s: s.dims[2])
+
+    def download(self):
+        n, m, nnz = self.dims
+        rp = np.zeros(n + 1, dtype=np.int32)
+        cj = np.zeros(max(nnz, 1), dtype=np.int32)
+        v = np.zeros(max(nnz, 1), dtype=np.float64)
+        _check(load().hda_csr_download(self.h, _ip(rp), _ip(cj), _dp(v)))
+        return rp, cj[:nnz], v[:nnz]
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rp, cj, v = self.download()
+        n, m, _ = self.dims
+        return sp.csr_matrix((v, cj, rp), shape=(n, m))
+
+    def spmv(self, x, alpha=1.0, beta=0.0, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(self.nrows) if y is None else np.ascontiguousarray(y, dtype=np.float64).copy()
+        _check(load().hda_spmv(self.h, alpha, _dp(x), beta, _dp(y)))
+        return y
+
+    def relax(self, b, x, relax_type=18, weight=1.0, sweeps=1):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        _check(load().hda_relax(self.h, relax_type, weight, sweeps, _dp(b), _dp(x)))
+        return x
+
+    def l1_norms(self, option=1):
+        out = np.zeros(self.nrows)
+        _check(load().hda_l1_norms(self.h, option, _dp(out)))
+        return out
+
+    def strength(self, theta=0.25, max_row_sum=0.9):
+        sm = np.zeros(max(self.nnz, 1), dtype=np.uint8)
+        _check(load().hda_strength(self.h, theta, max_row_sum, sm.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return sm[:self.nnz]
+
+    def pmis(self, smask, seed=2747, level=0, row_offset=0):
+        sm = np.ascontiguousarray(np.concatenate([smask, np.zeros(1, np.uint8)]), dtype=np.uint8)
+        cf = np.zeros(max(self.nrows, 1), dtype=np.int32)
+        _check(load().hda_pmis(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), seed, level, row_offset, _ip(cf)))
+        return cf[:self.nrows]
+
+    def interp_extpi(self, smask, cf, pmax=4, trunc_factor=0.0):
+        sm = np.ascontiguousarray(np.concatenate([smask, np.zeros(1, np.uint8)]), dtype=np.uint8)
+        cfa = np.ascontiguousarray(np.concatenate([cf, np.zeros(1, np.int32)]), dtype=np.int32)
+        out = C.c_void_p()
+        _check(load().hda_interp_extpi(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cfa), pmax,
+                                       trunc_factor, C.byref(out)))
+        return Csr(out)
+
+    def rap(self, P):
+        out = C.c_void_p()
+        _check(load().hda_rap(self.h, P.h, C.byref(out)))
+        return Csr(out)
+
+    def transpose(self):
+        out = C.c_void_p()
+        _check(load().hda_transpose(self.h, C.byref(out)))
+        return Csr(out)
+
+    def matmul(self, Y):
+        out = C.c_void_p()
+        _check(load().hda_spgemm(self.h, Y.h, C.byref(out)))
+        return Csr(out)
+
+
+def lap7(nx, ny, nz, c=(1.0, 1.0, 1.0), want_rhs=True):
+    """7-pt Laplacian generated in HBM (examples/src/C_laplacian/laplacian.c:719-921)."""
+    n = (C.c_int * 3)(nx, ny, nz)
+    P = (C.c_int * 3)(1, 1, 1)
+    pc = (C.c_int * 3)(0, 0, 0)
+    cc = (C.c_double * 3)(*c)
+    out = C.c_void_p()
+    rhs = np.zeros(nx * ny * nz) if want_rhs else None
+    _check(load().hda_lap7_create(n, P, pc, cc, C.byref(out), _dp(rhs) if want_rhs else None))
+    A = Csr(out)
+    A.rhs = rhs
+    return A
+
+
+class Amg:
+    def __init__(self, A, params=None):
+        self.A = A
+        self.params = params if params is not None else AmgParams.default()
+        self.h = C.c_void_p()
+        _check(load().hda_amg_create(C.byref(self.params), A.h, C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            load().hda_amg_destroy(self.h)
+            self.h = None
+
+    @property
+    def num_levels(self):
+        return load().hda_amg_num_levels(self.h)
+
+    def level_matrix(self, level, which=0):
+        out = C.c_void_p()
+        _check(load().hda_amg_level_matrix(self.h, level, which, C.byref(out)))
+        return Csr(out, owned=False, keep=self)
+
+    def level_cf(self, level):
+        n = self.level_matrix(level, 0).nrows
+        cf = np.zeros(n, dtype=np.int32)
+        _check(load().hda_amg_level_cf(self.h, level, _ip(cf)))
+        return cf
+
+    @property
+    def complexities(self):
+        g, o = C.c_double(), C.c_double()
+        _check(load().hda_amg_complexities(self.h, C.byref(g), C.byref(o)))
+        return g.value, o.value
+
+    @property
+    def vcycle_bytes(self):
+        return load().hda_amg_vcycle_bytes(self.h)
+
+    def vcycle(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b)
+        _check(load().hda_amg_vcycle(self.h, _dp(b), _dp(x)))
+        return x
+
+
+def _krylov(fn, A, b, amg, kp, x0):
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
+    hist = np.zeros(kp.max_iter + 2)
+    it, conv, frel = C.c_int(), C.c_int(), C.c_double()
+    _check(fn(A.h, amg.h if amg is not None else None, C.byref(kp), _dp(b), _dp(x), _dp(hist),
+              C.byref(it), C.byref(conv), C.byref(frel)))
+    return dict(x=x, iters=it.value, converged=bool(conv.value), final_rel=frel.value,
+                hist=hist[:it.value + 1].copy())
+
+
+def pcg(A, b, amg=None, kp=None, x0=None):
+    return _krylov(load().hda_pcg, A, b, amg, kp or KrylovParams.default(False), x0)
+
+
+def gmres(A, b, amg=None, kp=None, x0=None):
+    return _krylov(load().hda_gmres, A, b, amg, kp or KrylovParams.default(True), x0)
+
+
+def time_kernel(kind, A, amg=None, reps=20):
+    ms, by = C.c_double(), C.c_double()
+    _check(load().hda_time_kernel(kind, A.h, amg.h if amg is not None else None, reps, C.byref(ms), C.byref(by)))
+    return ms.value, by.value
+
+
+def solve_timed(A, ap=None, kp=None, b=None, solver=0):
+    ap = ap or AmgParams.default()
+    kp = kp or KrylovParams.default(bool(solver))
+    d = [C.c_double() for _ in range(8)]
+    it, nl = C.c_int(), C.c_int()
+    bb = None if b is None else _dp(np.ascontiguousarray(b, dtype=np.float64))
+    _check(load().hda_solve_timed(A.h, C.byref(ap), C.byref(kp), bb, solver, C.byref(d[0]), C.byref(d[1]),
+                                  C.byref(it), C.byref(d[2]), C.byref(d[3]), C.byref(d[4]), C.byref(d[5]),
+                                  C.byref(d[6]), C.byref(nl)))
+    return dict(setup_ms=d[0].value, solve_ms=d[1].value, iters=it.value, final_rel=d[2].value,
+                r0=d[3].value, true_rel=d[4].value, bytes_per_iter=d[5].value,
+                op_complexity=d[6].value, num_levels=nl.value)

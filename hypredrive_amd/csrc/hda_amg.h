@@ -1,0 +1,88 @@
+// hda_amg.h -- device-resident BoomerAMG-style hierarchy and V-cycle (single rank block).
+// Parameter contract: reference AMG_args (include/internal/amg.h:108-123) as forwarded by
+// hypredrv_AMGCreate (src/internal/amg.c:864-1035) to the HYPRE_BoomerAMGSet* setters.
+#pragma once
+
+#include "hda_kernels.h"
+
+#include <memory>
+
+namespace hda {
+
+struct AmgParams {
+   // coarsening (src/internal/amg.c:138-157)
+   int    coarsen_type    = 8;  // PMIS (hypre-GPU default); 10 HMIS, 6 Falgout not on device
+   double strong_th       = 0.25;
+   double max_row_sum     = 0.9;
+   int    max_coarse_size = 64;
+   int    min_coarse_size = 0;
+   int    max_levels      = 25;
+   // interpolation (amg.c:120-128)
+   int    interp_type  = 6; // extended+i
+   int    pmax         = 4;
+   double trunc_factor = 0.0;
+   // relaxation (amg.c:178-199)
+   int    relax_down = 18, relax_up = 18, relax_coarse = 9;
+   int    sweeps_down = 1, sweeps_up = 1, sweeps_coarse = 1;
+   double relax_weight = 1.0, outer_weight = 1.0;
+   // solver knobs (amg.c:222-226)
+   int    max_iter = 1;
+   double tol      = 0.0;
+   int    print_level = 0;
+   uint64_t seed = 2747; // PMIS tie-break hash seed
+};
+
+struct AmgLevel {
+   DCsr           A, P, R;
+   DArray<int>    cf;
+   DArray<double> dinv_down, dinv_up; // relax_weight / l1 (or / a_ii), per cycle direction
+   DArray<double> f, u, u2, t;
+};
+
+class Amg {
+ public:
+   explicit Amg(const AmgParams &p) : prm(p) {}
+   // hypre_BoomerAMGSetup (src/internal/precon.c:107): A is borrowed for level 0.
+   void setup(const DCsr &A);
+   // HYPRE_BoomerAMGSolve as a preconditioner (precon.c:108): one V(nu1,nu2) from x = 0.
+   // dot_slot >= 0: also emit block partials of <b, x> (fuses PCG's <r, z>).
+   void apply(const double *b, double *x, int dot_slot = -1);
+   // general solve entry: max_iter cycles starting from the x passed in
+   void solve(const double *b, double *x);
+
+   int           num_levels() const { return (int)levels.size(); }
+   const DCsr   &level_A(int l) const { return l == 0 ? *A0 : levels[l].A; }
+   AmgLevel     &level(int l) { return levels[l]; }
+   double        operator_complexity() const;
+   double        grid_complexity() const;
+   // algorithmic HBM bytes of one V-cycle (SURVEY 8(d) formulas on the built hierarchy)
+   double        vcycle_bytes() const;
+   AmgParams     prm;
+   double        setup_times[8] = {0}; // strength, coarsen, interp, rap, misc (diagnostic)
+
+ private:
+   void cycle(const double *b, double *x, bool zero_guess, int dot_slot);
+   void relax(int l, int type, const double *dinv, const double *b, double *&cur, double *&alt,
+              bool zero_guess, int dot_slot);
+   const DCsr           *A0 = nullptr;
+   std::vector<AmgLevel> levels;
+   DArray<double>        coarse_invT; // dense inverse of the coarsest operator (column-major)
+   int                   coarse_n = 0;
+   bool                  coarse_dense = false;
+};
+
+// ---- setup kernels (hda_amg_setup.hip); exposed for per-kernel parity tests -------------
+// hypre_BoomerAMGCreateS: smask[k] = 1 iff entry k of A is a strong connection.
+void amg_strength(const DCsr &A, double theta, double max_row_sum, unsigned char *smask);
+// hypre_BoomerAMGCoarsenPMIS: cf[i] = 1 C, -1 F, -3 special F. row_offset = global id of row 0.
+void amg_pmis(const DCsr &A, const unsigned char *smask, uint64_t seed, int level,
+              long long row_offset, int *cf);
+// hypre_BoomerAMGBuildExtPIInterp + InterpTruncation: P (nrows x nc), rows column-sorted.
+void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax,
+                      double trunc_factor, DCsr &P);
+// hypre_ParCSRMatMat-style product C = X*Y, deterministic accumulation order, rows sorted.
+void spgemm(const DCsr &X, const DCsr &Y, DCsr &C);
+// hypre_BoomerAMGBuildCoarseOperator: Ac = R*(A*P) with R = P^T
+void amg_rap(const DCsr &A, const DCsr &P, const DCsr &R, DCsr &Ac);
+
+} // namespace hda

@@ -1,0 +1,964 @@
+// hda_amg_setup.hip -- AMG setup on the device: strength of connection, PMIS C/F
+// splitting, extended+i interpolation with truncation, deterministic SpGEMM for the
+// Galerkin product.  (upstream algorithms in App. A.4-A.7.)
+//
+// Determinism: every floating-point accumulation below runs in the same order as the
+// sequential CPU oracle (one thread owns a row and walks it in ascending k), the file is
+// built with -ffp-contract=off, and integer set algorithms (PMIS) are formulated as
+// synchronous rounds.  The hierarchy is therefore bit-reproducible run to run and
+// independent of the launch geometry.
+#include "hda_amg.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace hda {
+
+#define STREAM (Context::get().stream)
+
+void exclusive_scan64(long n, const int *in, long long *out); // hda_kernels.hip
+
+// ---------------------------------------------------------------- strength
+
+__global__ __launch_bounds__(256) void k_strength(int n, const int *__restrict__ rp,
+                                                  const int *__restrict__ cj,
+                                                  const double *__restrict__ v, double theta,
+                                                  double mrs, unsigned char *__restrict__ smask,
+                                                  int *__restrict__ ns)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   const int k0 = rp[i], k1 = rp[i + 1];
+   double    diag = 0.0, row_sum = 0.0, row_scale = 0.0;
+   for (int k = k0; k < k1; k++)
+      if (cj[k] == i) diag = v[k];
+   for (int k = k0; k < k1; k++)
+   {
+      const double a = v[k];
+      row_sum += a;
+      if (cj[k] == i) continue;
+      if (diag < 0.0) row_scale = (a > row_scale) ? a : row_scale;
+      else row_scale = (a < row_scale) ? a : row_scale;
+   }
+   const bool weak = (mrs < 1.0) && (diag != 0.0) && (fabs(row_sum / diag) > mrs);
+   int        cnt  = 0;
+   for (int k = k0; k < k1; k++)
+   {
+      int s = 0;
+      if (cj[k] != i && !weak) s = (diag < 0.0) ? (v[k] > theta * row_scale) : (v[k] < theta * row_scale);
+      smask[k] = (unsigned char)s;
+      cnt += s;
+   }
+   ns[i] = cnt;
+}
+
+static void strength_ns(const DCsr &A, double theta, double mrs, unsigned char *smask, int *ns)
+{
+   if (A.nrows)
+      k_strength<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data(),
+                                                             theta, mrs, smask, ns);
+}
+
+void amg_strength(const DCsr &A, double theta, double max_row_sum, unsigned char *smask)
+{
+   DArray<int> ns((size_t)A.nrows + 1);
+   strength_ns(A, theta, max_row_sum, smask, ns.data());
+}
+
+// -------------------------------------------------------------------- PMIS
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+   z += 0x9E3779B97F4A7C15ULL;
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+   return z ^ (z >> 31);
+}
+// tie-break weight in [0,1): hash of the GLOBAL row id => partition independent
+__device__ __forceinline__ double pmis_rand(unsigned long long seed, int level, long long gid)
+{
+   unsigned long long h = mix64(mix64(seed + (unsigned long long)level * 0x100000001B3ULL) ^ (unsigned long long)gid);
+   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ __launch_bounds__(256) void k_indeg(int nnz, const int *__restrict__ cj,
+                                               const unsigned char *__restrict__ smask, int *indeg)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256)
+      if (smask[k]) atomicAdd(&indeg[cj[k]], 1);
+}
+
+__global__ __launch_bounds__(256) void k_pmis_init(int n, const int *__restrict__ ns,
+                                                   const int *__restrict__ indeg,
+                                                   unsigned long long seed, int level,
+                                                   long long row_offset, double *__restrict__ meas,
+                                                   int *__restrict__ cf, int *counter)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   const int nt = indeg[i];
+   meas[i]      = (double)nt + pmis_rand(seed, level, row_offset + i);
+   int c;
+   if (ns[i] == 0) c = -3;      // no strong dependence: special F, never interpolated
+   else if (nt == 0) c = -1;    // measure < 1: nobody depends on it
+   else { c = 0; atomicAdd(counter, 1); }
+   cf[i] = c;
+}
+
+// one edge visit decides both endpoints (hypre's IndepSet loop): the neighbourhood is S u S^T
+__global__ __launch_bounds__(256) void k_pmis_mark(int n, const int *__restrict__ rp,
+                                                   const int *__restrict__ cj,
+                                                   const unsigned char *__restrict__ smask,
+                                                   const int *__restrict__ cf,
+                                                   const double *__restrict__ meas, unsigned char *notmax)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n || cf[i] != 0) return;
+   const double mi = meas[i];
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+   {
+      if (!smask[k]) continue;
+      const int j = cj[k];
+      if (cf[j] != 0) continue;
+      const double mj = meas[j];
+      if (mj > mi || (mj == mi && j > i)) notmax[i] = 1;
+      else notmax[j] = 1;
+   }
+}
+__global__ __launch_bounds__(256) void k_pmis_setC(int n, int *__restrict__ cf, unsigned char *__restrict__ notmax)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   if (cf[i] == 0 && !notmax[i]) cf[i] = 1;
+   notmax[i] = 0;
+}
+__global__ __launch_bounds__(256) void k_pmis_setF(int n, const int *__restrict__ rp,
+                                                   const int *__restrict__ cj,
+                                                   const unsigned char *__restrict__ smask, int *cf, int *counter)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n || cf[i] != 0) return;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (smask[k] && cf[cj[k]] == 1)
+      {
+         cf[i] = -1;
+         return;
+      }
+   atomicAdd(counter, 1);
+}
+
+static void pmis_core(const DCsr &A, const unsigned char *smask, const int *ns, uint64_t seed, int level,
+                      long long row_offset, int *cf)
+{
+   const int n = A.nrows;
+   if (!n) return;
+   DArray<int>           indeg((size_t)n), counter(1);
+   DArray<double>        meas((size_t)n);
+   DArray<unsigned char> notmax((size_t)n);
+   indeg.zero();
+   notmax.zero();
+   counter.zero();
+   const int g = ceil_div(n, 256);
+   if (A.nnz) k_indeg<<<std::min(ceil_div(A.nnz, 256), 1 << 16), 256, 0, STREAM>>>(A.nnz, A.col.data(), smask, indeg.data());
+   k_pmis_init<<<g, 256, 0, STREAM>>>(n, ns, indeg.data(), seed, level, row_offset, meas.data(), cf, counter.data());
+   int left = 0;
+   counter.download(&left, 1);
+   int rounds = 0;
+   while (left > 0)
+   {
+      counter.zero();
+      k_pmis_mark<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, meas.data(), notmax.data());
+      k_pmis_setC<<<g, 256, 0, STREAM>>>(n, cf, notmax.data());
+      k_pmis_setF<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data());
+      counter.download(&left, 1);
+      HDA_REQUIRE(++rounds < 10000, "PMIS did not terminate");
+   }
+}
+
+__global__ __launch_bounds__(256) void k_count_strong(int n, const int *__restrict__ rp,
+                                                      const unsigned char *__restrict__ sm, int *__restrict__ ns)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int c = 0;
+   for (int k = rp[i]; k < rp[i + 1]; k++) c += sm[k];
+   ns[i] = c;
+}
+
+void amg_pmis(const DCsr &A, const unsigned char *smask, uint64_t seed, int level, long long row_offset, int *cf)
+{
+   DArray<int> ns((size_t)A.nrows + 1);
+   if (A.nrows) k_count_strong<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), smask, ns.data());
+   pmis_core(A, smask, ns.data(), seed, level, row_offset, cf);
+}
+
+// ------------------------------------------------------------ interpolation
+
+__device__ __forceinline__ unsigned hash_slot(int key, int lg)
+{
+   return (lg == 0) ? 0u : (((unsigned)key * 2654435761u) >> (32 - lg));
+}
+__device__ __forceinline__ int pow2ceil_dev(int x)
+{
+   int p = 1;
+   while (p < x) p <<= 1;
+   return p;
+}
+
+__global__ __launch_bounds__(256) void k_count_strongC(int n, const int *__restrict__ rp,
+                                                       const int *__restrict__ cj,
+                                                       const unsigned char *__restrict__ smask,
+                                                       const int *__restrict__ cf, int *__restrict__ nsC)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int c = 0;
+   for (int k = rp[i]; k < rp[i + 1]; k++) c += (smask[k] && cf[cj[k]] == 1);
+   nsC[i] = c;
+}
+
+__global__ __launch_bounds__(256) void k_interp_ub(int n, const int *__restrict__ rp,
+                                                   const int *__restrict__ cj,
+                                                   const unsigned char *__restrict__ smask,
+                                                   const int *__restrict__ cf, const int *__restrict__ nsC,
+                                                   int *__restrict__ ub, int *__restrict__ hsz,
+                                                   int *__restrict__ cmark)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   const int c = cf[i];
+   cmark[i]    = (c == 1);
+   int u = 0, h = 0;
+   if (c == 1) u = 1;
+   else if (c == -1)
+   {
+      for (int k = rp[i]; k < rp[i + 1]; k++)
+      {
+         if (!smask[k]) continue;
+         const int j  = cj[k];
+         const int cj_ = cf[j];
+         if (cj_ == 1) u += 1;
+         else if (cj_ == -1) u += nsC[j];
+      }
+      h = u ? max(8, pow2ceil_dev(2 * u)) : 0;
+   }
+   ub[i]  = u;
+   hsz[i] = h;
+}
+
+struct PEnt {
+   int    c;
+   double w;
+};
+
+// Descending-|w| quicksort in the K&R form (pivot = middle element swapped to the front,
+// strict '>' partition) -- the tie order it produces decides which pmax of several equal
+// weights survive truncation, so it is part of the algorithm's definition (see oracle).
+__device__ void qsort_abs(int *L, double *W, int n)
+{
+   int stack[64], sp = 0;
+   stack[sp++] = 0;
+   stack[sp++] = n - 1;
+   while (sp > 0)
+   {
+      int right = stack[--sp], left = stack[--sp];
+      while (left < right)
+      {
+         const int mid = (left + right) / 2;
+         int       last = left, ti;
+         double    td;
+         ti = L[left]; L[left] = L[mid]; L[mid] = ti;
+         td = W[left]; W[left] = W[mid]; W[mid] = td;
+         const double piv = fabs(W[left]);
+         for (int i = left + 1; i <= right; i++)
+            if (fabs(W[i]) > piv)
+            {
+               ++last;
+               ti = L[last]; L[last] = L[i]; L[i] = ti;
+               td = W[last]; W[last] = W[i]; W[i] = td;
+            }
+         ti = L[left]; L[left] = L[last]; L[last] = ti;
+         td = W[left]; W[left] = W[last]; W[last] = td;
+         if (last - left < right - last)
+         {
+            stack[sp++] = last + 1; stack[sp++] = right;
+            right = last - 1;
+         }
+         else
+         {
+            stack[sp++] = left; stack[sp++] = last - 1;
+            left = last + 1;
+         }
+      }
+   }
+}
+
+__global__ __launch_bounds__(256) void k_interp_build(
+   int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+   const unsigned char *__restrict__ smask, const int *__restrict__ cf,
+   const long long *__restrict__ uofs, const long long *__restrict__ hofs, int *__restrict__ lcol,
+   double *__restrict__ lw, int *__restrict__ htab, int pmax, double trunc_factor, int *__restrict__ pcnt)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   const int c = cf[i];
+   int      *L = lcol + uofs[i];
+   double   *W = lw + uofs[i];
+   if (c == 1)
+   {
+      L[0]    = i;
+      W[0]    = 1.0;
+      pcnt[i] = 1;
+      return;
+   }
+   if (c != -1)
+   {
+      pcnt[i] = 0;
+      return;
+   }
+   int      *H    = htab + hofs[i];
+   const int hs   = (int)(hofs[i + 1] - hofs[i]);
+   const int mask = hs - 1;
+   int       lg   = 0;
+   while ((1 << lg) < hs) lg++;
+   int cnt = 0;
+   auto find = [&](int m) -> int {
+      if (hs == 0) return -1;
+      unsigned h = hash_slot(m, lg);
+      for (;;)
+      {
+         const int e = H[h];
+         if (e < 0) return -1;
+         if (L[e] == m) return e;
+         h = (h + 1) & mask;
+      }
+   };
+   auto add = [&](int m) {
+      unsigned h = hash_slot(m, lg);
+      for (;;)
+      {
+         const int e = H[h];
+         if (e < 0)
+         {
+            H[h]   = cnt;
+            L[cnt] = m;
+            W[cnt] = 0.0;
+            cnt++;
+            return;
+         }
+         if (L[e] == m) return;
+         h = (h + 1) & mask;
+      }
+   };
+   const int k0 = rp[i], k1 = rp[i + 1];
+   // C-hat_i = C_i U (U_{j in F_i^s} C_j), discovery order
+   for (int k = k0; k < k1; k++)
+   {
+      if (!smask[k]) continue;
+      const int j = cj[k];
+      if (cf[j] == 1) add(j);
+      else if (cf[j] == -1)
+         for (int kk = rp[j]; kk < rp[j + 1]; kk++)
+         {
+            const int m = cj[kk];
+            if (smask[kk] && cf[m] == 1) add(m);
+         }
+   }
+   double diagonal = 0.0;
+   for (int k = k0; k < k1; k++)
+      if (cj[k] == i) diagonal = v[k];
+   for (int k = k0; k < k1; k++)
+   {
+      const int j = cj[k];
+      if (j == i) continue;
+      const double aij = v[k];
+      const int    e   = find(j);
+      if (e >= 0) W[e] += aij;
+      else if (smask[k] && cf[j] == -1)
+      {
+         const int j0 = rp[j], j1 = rp[j + 1];
+         double    ajj = 0.0, sum = 0.0;
+         for (int kk = j0; kk < j1; kk++)
+            if (cj[kk] == j) ajj = v[kk];
+         const double sgn = (ajj < 0.0) ? -1.0 : 1.0;
+         for (int kk = j0; kk < j1; kk++)
+         {
+            const int m = cj[kk];
+            if (sgn * v[kk] < 0.0 && (m == i || find(m) >= 0)) sum += v[kk];
+         }
+         if (sum != 0.0)
+         {
+            const double distribute = aij / sum;
+            for (int kk = j0; kk < j1; kk++)
+            {
+               const int m = cj[kk];
+               if (sgn * v[kk] < 0.0)
+               {
+                  const int em = find(m);
+                  if (em >= 0) W[em] += distribute * v[kk];
+                  else if (m == i) diagonal += distribute * v[kk];
+               }
+            }
+         }
+         else
+            diagonal += aij;
+      }
+      else if (cf[j] != -3)
+         diagonal += aij; // weak connection lumped into the diagonal
+   }
+   if (diagonal != 0.0)
+      for (int q = 0; q < cnt; q++) W[q] = W[q] / (-diagonal);
+   if (trunc_factor > 0.0 && cnt > 0)
+   {
+      double mx = 0.0, tot = 0.0, kept = 0.0;
+      for (int q = 0; q < cnt; q++)
+      {
+         if (fabs(W[q]) > mx) mx = fabs(W[q]);
+         tot += W[q];
+      }
+      int c2 = 0;
+      for (int q = 0; q < cnt; q++)
+         if (fabs(W[q]) >= trunc_factor * mx)
+         {
+            L[c2] = L[q];
+            W[c2] = W[q];
+            kept += W[c2];
+            c2++;
+         }
+      cnt = c2;
+      if (kept != 0.0)
+      {
+         const double sc = tot / kept;
+         for (int q = 0; q < cnt; q++) W[q] *= sc;
+      }
+   }
+   if (pmax > 0 && cnt > pmax)
+   {
+      double tot = 0.0, kept = 0.0;
+      for (int q = 0; q < cnt; q++) tot += W[q];
+      qsort_abs(L, W, cnt);
+      cnt = pmax;
+      for (int q = 0; q < cnt; q++) kept += W[q];
+      if (kept != 0.0)
+      {
+         const double sc = tot / kept;
+         for (int q = 0; q < cnt; q++) W[q] *= sc;
+      }
+   }
+   // storage order: ascending (fine == coarse) column
+   for (int a = 1; a < cnt; a++)
+   {
+      const int    cc = L[a];
+      const double ww = W[a];
+      int          b  = a - 1;
+      while (b >= 0 && L[b] > cc)
+      {
+         L[b + 1] = L[b];
+         W[b + 1] = W[b];
+         b--;
+      }
+      L[b + 1] = cc;
+      W[b + 1] = ww;
+   }
+   pcnt[i] = cnt;
+}
+
+__global__ __launch_bounds__(256) void k_interp_gather(int n, const long long *__restrict__ uofs,
+                                                       const int *__restrict__ prp,
+                                                       const int *__restrict__ lcol,
+                                                       const double *__restrict__ lw,
+                                                       const int *__restrict__ cidx, int *__restrict__ pc,
+                                                       double *__restrict__ pv)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   const int       s = prp[i], e = prp[i + 1];
+   const long long o = uofs[i];
+   for (int q = s; q < e; q++)
+   {
+      pc[q] = cidx[lcol[o + (q - s)]];
+      pv[q] = lw[o + (q - s)];
+   }
+}
+
+void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax,
+                      double trunc_factor, DCsr &P)
+{
+   const int n = A.nrows;
+   const int g = ceil_div(std::max(n, 1), 256);
+   DArray<int>       nsC((size_t)n + 1), ub((size_t)n + 1), hsz((size_t)n + 1), cmark((size_t)n + 1), cidx((size_t)n + 1);
+   DArray<long long> uofs((size_t)n + 1), hofs((size_t)n + 1);
+   k_count_strongC<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, nsC.data());
+   k_interp_ub<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, nsC.data(), ub.data(), hsz.data(), cmark.data());
+   exclusive_scan(n, cmark.data(), cidx.data(), nullptr);
+   exclusive_scan64(n, ub.data(), uofs.data());
+   exclusive_scan64(n, hsz.data(), hofs.data());
+   long long tot_u = 0, tot_h = 0;
+   int       nc    = 0;
+   HDA_HIP(hipMemcpyAsync(&tot_u, uofs.data() + n, 8, hipMemcpyDeviceToHost, STREAM));
+   HDA_HIP(hipMemcpyAsync(&tot_h, hofs.data() + n, 8, hipMemcpyDeviceToHost, STREAM));
+   HDA_HIP(hipMemcpyAsync(&nc, cidx.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   DArray<int>    lcol((size_t)std::max<long long>(tot_u, 1)), htab((size_t)std::max<long long>(tot_h, 1));
+   DArray<double> lw((size_t)std::max<long long>(tot_u, 1));
+   HDA_HIP(hipMemsetAsync(htab.data(), 0xFF, sizeof(int) * htab.size(), STREAM));
+   DArray<int> pcnt((size_t)n + 1);
+   k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(),
+                                         hofs.data(), lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data());
+   P.nrows = n;
+   P.ncols = nc;
+   P.rowptr.alloc((size_t)n + 1);
+   exclusive_scan(n, pcnt.data(), P.rowptr.data(), nullptr);
+   HDA_HIP(hipMemcpyAsync(&P.nnz, P.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   P.col.alloc((size_t)std::max(P.nnz, 1));
+   P.val.alloc((size_t)std::max(P.nnz, 1));
+   k_interp_gather<<<g, 256, 0, STREAM>>>(n, uofs.data(), P.rowptr.data(), lcol.data(), lw.data(), cidx.data(),
+                                          P.col.data(), P.val.data());
+}
+
+// ------------------------------------------------------------------ SpGEMM
+
+__global__ __launch_bounds__(256) void k_spgemm_ub(int n, const int *__restrict__ xrp,
+                                                   const int *__restrict__ xcj,
+                                                   const int *__restrict__ yrp, int ycols,
+                                                   int *__restrict__ hsz)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   long u = 0;
+   for (int k = xrp[i]; k < xrp[i + 1]; k++)
+   {
+      const int r = xcj[k];
+      u += yrp[r + 1] - yrp[r];
+   }
+   if (u > ycols) u = ycols; // cannot have more distinct columns than Y has
+   hsz[i] = u ? max(4, pow2ceil_dev((int)(2 * u))) : 0;
+}
+
+// One thread per output row; products are visited in (k ascending, q ascending) order and
+// accumulated per column in that order -- the same order as a sequential Gustavson pass.
+template <bool NUMERIC>
+__global__ __launch_bounds__(256) void k_spgemm_hash(int r0, int r1, const int *__restrict__ xrp,
+                                                     const int *__restrict__ xcj,
+                                                     const double *__restrict__ xv,
+                                                     const int *__restrict__ yrp,
+                                                     const int *__restrict__ ycj,
+                                                     const double *__restrict__ yv,
+                                                     const long long *__restrict__ hofs, long long hbase,
+                                                     int *__restrict__ hkey, double *__restrict__ hval,
+                                                     int *__restrict__ cnt)
+{
+   const int i = r0 + blockIdx.x * 256 + threadIdx.x;
+   if (i >= r1) return;
+   const long long o  = hofs[i] - hbase;
+   const int       hs = (int)(hofs[i + 1] - hofs[i]);
+   int             c  = 0;
+   if (hs)
+   {
+      int      *K    = hkey + o;
+      double   *V    = hval + o;
+      const int mask = hs - 1;
+      int       lg   = 0;
+      while ((1 << lg) < hs) lg++;
+      for (int k = xrp[i]; k < xrp[i + 1]; k++)
+      {
+         const int    r = xcj[k];
+         const double a = NUMERIC ? xv[k] : 0.0;
+         for (int q = yrp[r]; q < yrp[r + 1]; q++)
+         {
+            const int    j = ycj[q];
+            const double t = NUMERIC ? a * yv[q] : 0.0;
+            unsigned     h = hash_slot(j, lg);
+            for (;;)
+            {
+               const int key = K[h];
+               if (key < 0)
+               {
+                  K[h] = j;
+                  if (NUMERIC) V[h] = t;
+                  c++;
+                  break;
+               }
+               if (key == j)
+               {
+                  if (NUMERIC) V[h] += t;
+                  break;
+               }
+               h = (h + 1) & mask;
+            }
+         }
+      }
+   }
+   cnt[i] = c;
+}
+
+__global__ __launch_bounds__(256) void k_spgemm_gather(int r0, int r1, const long long *__restrict__ hofs,
+                                                       long long hbase, const int *__restrict__ hkey,
+                                                       const double *__restrict__ hval,
+                                                       const int *__restrict__ crp, int *__restrict__ ccj,
+                                                       double *__restrict__ cv)
+{
+   const int i = r0 + blockIdx.x * 256 + threadIdx.x;
+   if (i >= r1) return;
+   const long long o  = hofs[i] - hbase;
+   const int       hs = (int)(hofs[i + 1] - hofs[i]);
+   const int       s  = crp[i];
+   int             w  = s;
+   for (int h = 0; h < hs; h++)
+   {
+      const int key = hkey[o + h];
+      if (key < 0) continue;
+      // insertion into the sorted prefix [s, w)
+      const double val = hval[o + h];
+      int          b   = w - 1;
+      while (b >= s && ccj[b] > key)
+      {
+         ccj[b + 1] = ccj[b];
+         cv[b + 1]  = cv[b];
+         b--;
+      }
+      ccj[b + 1] = key;
+      cv[b + 1]  = val;
+      w++;
+   }
+}
+
+static long long spgemm_slot_budget()
+{
+   static long long b = -1;
+   if (b < 0)
+   {
+      const char *e = getenv("HDA_SPGEMM_SLOTS");
+      b             = e ? atoll(e) : (1LL << 31); // 2 Gi slots = 24 GiB of keys+values
+      if (b < 1024) b = 1024;
+   }
+   return b;
+}
+
+void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
+{
+   HDA_REQUIRE(X.ncols <= Y.nrows || X.nnz == 0, "spgemm: inner dimensions");
+   const int n = X.nrows;
+   C.nrows     = n;
+   C.ncols     = Y.ncols;
+   C.rowptr.alloc((size_t)n + 1);
+   if (n == 0)
+   {
+      C.rowptr.zero();
+      C.nnz = 0;
+      C.col.alloc(1);
+      C.val.alloc(1);
+      return;
+   }
+   const int         g = ceil_div(n, 256);
+   DArray<int>       hsz((size_t)n + 1), cnt((size_t)n + 1);
+   DArray<long long> hofs((size_t)n + 1);
+   k_spgemm_ub<<<g, 256, 0, STREAM>>>(n, X.rowptr.data(), X.col.data(), Y.rowptr.data(), Y.ncols, hsz.data());
+   exclusive_scan64(n, hsz.data(), hofs.data());
+   long long H = 0;
+   HDA_HIP(hipMemcpyAsync(&H, hofs.data() + n, 8, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   const long long budget = spgemm_slot_budget();
+   // batches of rows whose tables fit the budget
+   std::vector<int>       bstart{0};
+   std::vector<long long> hofs_h;
+   if (H > budget)
+   {
+      hofs_h.resize((size_t)n + 1);
+      hofs.download(hofs_h.data(), (size_t)n + 1);
+      int r = 0;
+      while (r < n)
+      {
+         long long base = hofs_h[r];
+         int       e    = (int)(std::upper_bound(hofs_h.begin() + r, hofs_h.end(), base + budget) - hofs_h.begin()) - 1;
+         if (e <= r) e = r + 1; // a single row larger than the budget still gets its table
+         r = e;
+         bstart.push_back(r);
+      }
+   }
+   else
+      bstart.push_back(n);
+   const int nb = (int)bstart.size() - 1;
+   long long maxslots = 0;
+   if (nb == 1) maxslots = H;
+   else
+      for (int b = 0; b < nb; b++) maxslots = std::max(maxslots, hofs_h[bstart[b + 1]] - hofs_h[bstart[b]]);
+   DArray<int>    hkey((size_t)std::max<long long>(maxslots, 1));
+   DArray<double> hval((size_t)std::max<long long>(maxslots, 1));
+   auto run_batch = [&](int b, bool numeric) {
+      const int       r0 = bstart[b], r1 = bstart[b + 1];
+      const long long hb = (nb == 1) ? 0 : hofs_h[r0];
+      const long long hs = (nb == 1) ? H : hofs_h[r1] - hb;
+      if (hs) HDA_HIP(hipMemsetAsync(hkey.data(), 0xFF, sizeof(int) * (size_t)hs, STREAM));
+      const int gb = ceil_div(r1 - r0, 256);
+      if (numeric)
+         k_spgemm_hash<true><<<gb, 256, 0, STREAM>>>(r0, r1, X.rowptr.data(), X.col.data(), X.val.data(), Y.rowptr.data(),
+                                                     Y.col.data(), Y.val.data(), hofs.data(), hb, hkey.data(), hval.data(), cnt.data());
+      else
+         k_spgemm_hash<false><<<gb, 256, 0, STREAM>>>(r0, r1, X.rowptr.data(), X.col.data(), X.val.data(), Y.rowptr.data(),
+                                                      Y.col.data(), Y.val.data(), hofs.data(), hb, hkey.data(), hval.data(), cnt.data());
+   };
+   auto gather_batch = [&](int b) {
+      const int       r0 = bstart[b], r1 = bstart[b + 1];
+      const long long hb = (nb == 1) ? 0 : hofs_h[r0];
+      k_spgemm_gather<<<ceil_div(r1 - r0, 256), 256, 0, STREAM>>>(r0, r1, hofs.data(), hb, hkey.data(), hval.data(),
+                                                                 C.rowptr.data(), C.col.data(), C.val.data());
+   };
+   auto finish_rowptr = [&]() {
+      exclusive_scan(n, cnt.data(), C.rowptr.data(), nullptr);
+      HDA_HIP(hipMemcpyAsync(&C.nnz, C.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+      Context::get().sync();
+      C.col.alloc((size_t)std::max(C.nnz, 1));
+      C.val.alloc((size_t)std::max(C.nnz, 1));
+   };
+   if (nb == 1)
+   {
+      run_batch(0, true);
+      finish_rowptr();
+      gather_batch(0);
+   }
+   else
+   {
+      for (int b = 0; b < nb; b++) run_batch(b, false); // symbolic: counts only
+      finish_rowptr();
+      for (int b = 0; b < nb; b++)
+      {
+         run_batch(b, true);
+         gather_batch(b);
+      }
+   }
+}
+
+void amg_rap(const DCsr &A, const DCsr &P, const DCsr &R, DCsr &Ac)
+{
+   DCsr AP;
+   spgemm(A, P, AP);
+   spgemm(R, AP, Ac);
+}
+
+// --------------------------------------------------------------- hierarchy
+
+static bool is_jacobi_type(int t) { return t == 18 || t == 0 || t == 7; }
+
+static void build_dinv(const DCsr &A, int relax_type, double weight, DArray<double> &dinv)
+{
+   DArray<double> d((size_t)A.nrows);
+   dinv.alloc((size_t)A.nrows);
+   l1_row_norms(A, relax_type == 18 ? 1 : 4, d.data());
+   make_dinv(A.nrows, d.data(), weight, dinv.data());
+}
+
+void Amg::setup(const DCsr &A)
+{
+   HDA_REQUIRE(prm.coarsen_type == 8, "device AMG setup implements PMIS coarsening (type 8) only");
+   HDA_REQUIRE(prm.interp_type == 6, "device AMG setup implements extended+i interpolation (type 6) only");
+   HDA_REQUIRE(is_jacobi_type(prm.relax_down) && is_jacobi_type(prm.relax_up),
+               "device V-cycle implements Jacobi-type smoothers (relax types 0, 7, 18) only");
+   A0 = &A;
+   levels.clear();
+   levels.reserve((size_t)std::max(prm.max_levels, 1));
+   levels.emplace_back();
+   const int maxl        = std::max(prm.max_levels, 1);
+   int       lvl         = 0;
+   bool      not_finished = (A.nrows > prm.max_coarse_size) && (maxl > 1);
+   while (not_finished)
+   {
+      const DCsr &Al = level_A(lvl);
+      const int   n  = Al.nrows;
+      DArray<unsigned char> sm((size_t)std::max(Al.nnz, 1));
+      DArray<int>           ns((size_t)n + 1), cf((size_t)n);
+      strength_ns(Al, prm.strong_th, prm.max_row_sum, sm.data(), ns.data());
+      pmis_core(Al, sm.data(), ns.data(), prm.seed, lvl, 0, cf.data());
+      DCsr P;
+      amg_interp_extpi(Al, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, P);
+      const int nc = P.ncols;
+      if (nc == 0 || nc == n || nc < prm.min_coarse_size) break;
+      AmgLevel &L = levels[lvl];
+      L.cf        = std::move(cf);
+      L.P         = std::move(P);
+      transpose(L.P, L.R);
+      levels.emplace_back();
+      amg_rap(Al, levels[lvl].P, levels[lvl].R, levels[lvl + 1].A);
+      lvl++;
+      if (lvl >= maxl - 1 || nc <= prm.max_coarse_size) not_finished = false;
+   }
+   const int L = (int)levels.size();
+   for (int l = 0; l < L; l++)
+   {
+      const DCsr &Al = level_A(l);
+      AmgLevel   &lv = levels[l];
+      build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down);
+      build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up);
+      const size_t n = (size_t)Al.nrows;
+      if (l > 0) { lv.f.alloc(n); lv.u.alloc(n); }
+      lv.u2.alloc(n);
+      lv.t.alloc(n);
+   }
+   // coarsest operator: dense inverse when relax_coarse is Gaussian elimination (type 9)
+   const DCsr &Ac = level_A(L - 1);
+   coarse_n       = Ac.nrows;
+   coarse_dense   = (prm.relax_coarse == 9) && coarse_n <= 1024;
+   if (coarse_dense && coarse_n > 0)
+   {
+      DArray<double> dense((size_t)coarse_n * coarse_n);
+      coarse_invT.alloc((size_t)coarse_n * coarse_n);
+      csr_to_dense(Ac, dense.data());
+      dense_invert(coarse_n, dense.data(), coarse_invT.data());
+   }
+   Context::get().sync();
+}
+
+double Amg::operator_complexity() const
+{
+   double s = 0.0;
+   for (int l = 0; l < num_levels(); l++) s += (double)level_A(l).nnz;
+   return s / (double)std::max(level_A(0).nnz, 1);
+}
+double Amg::grid_complexity() const
+{
+   double s = 0.0;
+   for (int l = 0; l < num_levels(); l++) s += (double)level_A(l).nrows;
+   return s / (double)std::max(level_A(0).nrows, 1);
+}
+
+static double spmv_bytes(const DCsr &M) { return 12.0 * M.nnz + 4.0 * (M.nrows + 1) + 8.0 * M.ncols + 8.0 * M.nrows; }
+
+// V(1,1) per level = smoothing sweeps + residual SpMV (+8n for b) + P^T apply
+// + P apply-add (+8n), on the actual hierarchy; the zero-guess first sweep is elementwise.
+double Amg::vcycle_bytes() const
+{
+   double    s = 0.0;
+   const int L = num_levels();
+   for (int l = 0; l < L - 1; l++)
+   {
+      const DCsr &A = level_A(l);
+      const double n = A.nrows;
+      s += 24.0 * n;                                            // zero-guess sweep: dinv, f -> u
+      s += (prm.sweeps_down - 1) * (spmv_bytes(A) + 16.0 * n);  // further pre-sweeps
+      s += spmv_bytes(A) + 8.0 * n;                             // residual
+      s += spmv_bytes(levels[l].R);                             // restriction
+      s += spmv_bytes(levels[l].P) + 8.0 * n;                   // prolongation-add
+      s += prm.sweeps_up * (spmv_bytes(A) + 16.0 * n);          // post-sweeps
+   }
+   s += 8.0 * coarse_n * coarse_n + 16.0 * coarse_n;
+   return s;
+}
+
+// ----------------------------------------------------------------- V-cycle
+
+void Amg::relax(int l, int type, const double *dinv, const double *b, double *&cur, double *&alt,
+                bool zero_guess, int dot_slot)
+{
+   const DCsr &A = level_A(l);
+   (void)type;
+   if (zero_guess)
+   {
+      jacobi_zero_guess(A.nrows, dinv, b, cur);
+      if (dot_slot >= 0) dot(A.nrows, b, cur, dot_slot);
+   }
+   else
+   {
+      jacobi(A, dinv, b, cur, alt, dot_slot);
+      std::swap(cur, alt);
+   }
+}
+
+void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
+{
+   const int L = num_levels();
+   const int n0 = level_A(0).nrows;
+   if (L == 1)
+   {
+      if (coarse_dense) dense_apply(coarse_n, coarse_invT.data(), b, x);
+      else
+      {
+         double *cur = x, *alt = levels[0].u2.data();
+         bool    zg  = zero_guess;
+         int     swaps = 0;
+         for (int s = 0; s < prm.sweeps_coarse; s++)
+         {
+            if (!zg) swaps++;
+            relax(0, prm.relax_coarse == 9 ? 18 : prm.relax_coarse, levels[0].dinv_down.data(), b, cur, alt, zg, -1);
+            zg = false;
+         }
+         if (cur != x) copy(n0, cur, x);
+      }
+      if (dot_slot >= 0) dot(n0, b, x, dot_slot);
+      return;
+   }
+   std::vector<double *> sol((size_t)L, nullptr);
+   // level-0 buffer choice so the last out-of-place sweep lands in x
+   const int swaps0 = (prm.sweeps_down - (zero_guess && prm.sweeps_down > 0 ? 1 : 0)) + prm.sweeps_up;
+   double   *cur, *alt;
+   if (zero_guess && (swaps0 & 1)) { cur = levels[0].u2.data(); alt = x; }
+   else { cur = x; alt = levels[0].u2.data(); }
+   const double *f = b;
+   for (int l = 0; l < L - 1; l++)
+   {
+      const DCsr &A  = level_A(l);
+      AmgLevel   &lv = levels[l];
+      bool        zg = zero_guess || l > 0;
+      if (zg && prm.sweeps_down == 0) fill(A.nrows, 0.0, cur);
+      for (int s = 0; s < prm.sweeps_down; s++)
+      {
+         relax(l, prm.relax_down, lv.dinv_down.data(), f, cur, alt, zg, -1);
+         zg = false;
+      }
+      residual(A, cur, f, lv.t.data());
+      AmgLevel &nx = levels[l + 1];
+      spmv(lv.R, 1.0, lv.t.data(), 0.0, nullptr, nx.f.data());
+      sol[l] = cur;
+      // remember the spare buffer of this level in u2/x bookkeeping
+      if (l == 0) { /* alt stays paired with cur */ }
+      // descend
+      f = nx.f.data();
+      // save level-l alt in t? no: alt is recomputed on the way up
+      if (l + 1 < L - 1) { cur = nx.u.data(); alt = nx.u2.data(); }
+   }
+   // coarsest
+   {
+      AmgLevel &lc = levels[L - 1];
+      if (coarse_dense) dense_apply(coarse_n, coarse_invT.data(), lc.f.data(), lc.u.data());
+      else
+      {
+         double *c2 = lc.u.data(), *a2 = lc.u2.data();
+         bool    zg = true;
+         for (int s = 0; s < std::max(prm.sweeps_coarse, 1); s++)
+         {
+            relax(L - 1, 18, lc.dinv_down.data(), lc.f.data(), c2, a2, zg, -1);
+            zg = false;
+         }
+         if (c2 != lc.u.data()) copy(coarse_n, c2, lc.u.data());
+      }
+      sol[L - 1] = lc.u.data();
+   }
+   for (int l = L - 2; l >= 0; l--)
+   {
+      const DCsr &A  = level_A(l);
+      AmgLevel   &lv = levels[l];
+      double     *c  = sol[l];
+      double     *a;
+      if (l == 0) a = (c == x) ? levels[0].u2.data() : x;
+      else a = (c == lv.u.data()) ? lv.u2.data() : lv.u.data();
+      const double *fl = (l == 0) ? b : lv.f.data();
+      spmv(lv.P, 1.0, sol[l + 1], 1.0, c, c);
+      for (int s = 0; s < prm.sweeps_up; s++)
+      {
+         const bool last = (l == 0) && (s == prm.sweeps_up - 1);
+         relax(l, prm.relax_up, lv.dinv_up.data(), fl, c, a, false, last ? dot_slot : -1);
+      }
+      sol[l] = c;
+   }
+   if (sol[0] != x) copy(n0, sol[0], x);
+   if (dot_slot >= 0 && prm.sweeps_up == 0) dot(n0, b, x, dot_slot);
+}
+
+void Amg::apply(const double *b, double *x, int dot_slot) { cycle(b, x, true, dot_slot); }
+
+void Amg::solve(const double *b, double *x)
+{
+   for (int it = 0; it < std::max(prm.max_iter, 1); it++) cycle(b, x, false, -1);
+}
+
+} // namespace hda

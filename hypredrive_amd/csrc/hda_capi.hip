@@ -1,0 +1,533 @@
+// hda_capi.hip -- kernel-level C ABI (include/hypredrv_amd.h).  Host buffers in / out.
+#include "../../include/hypredrv_amd.h"
+
+#include "hda_krylov.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+using namespace hda;
+
+struct hda_csr_s {
+   DCsr           m;
+   DArray<double> rhs; // optional device rhs (generator)
+   bool           borrowed = false;
+   const DCsr    *ref      = nullptr; // for borrowed handles
+   const DCsr    &get() const { return ref ? *ref : m; }
+};
+struct hda_amg_s {
+   std::unique_ptr<Amg>                    amg;
+   hda_csr_t                               A = nullptr;
+   std::vector<std::unique_ptr<hda_csr_s>> views;
+};
+
+static thread_local std::string g_err;
+
+extern "C" const char *hda_last_error(void) { return g_err.c_str(); }
+
+extern "C" int hda_device_count(void)
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+   return n;
+}
+
+#define HDA_TRY                           \
+   try                                    \
+   {                                      \
+      if (hda_device_count() < 1)         \
+      {                                   \
+         g_err = "no HIP device visible: the MI355X solve path has no CPU fallback"; \
+         return HDA_ERR_NO_DEVICE;        \
+      }
+#define HDA_CATCH                         \
+   }                                      \
+   catch (const std::exception &e)        \
+   {                                      \
+      g_err = e.what();                   \
+      return HDA_ERR_RUNTIME;             \
+   }                                      \
+   return HDA_OK;
+
+extern "C" int hda_device_name(char *buf, int len)
+{
+   HDA_TRY
+   hipDeviceProp_t p;
+   HDA_HIP(hipGetDeviceProperties(&p, Context::get().device));
+   snprintf(buf, (size_t)len, "%s (%s), %d CUs", p.name, p.gcnArchName, p.multiProcessorCount);
+   HDA_CATCH
+}
+
+extern "C" int hda_device_sync(void)
+{
+   HDA_TRY
+   Context::get().sync();
+   HDA_CATCH
+}
+
+extern "C" void hda_amg_default_params(hda_amg_params *p)
+{
+   AmgParams d;
+   p->coarsen_type = d.coarsen_type; p->interp_type = d.interp_type; p->pmax = d.pmax;
+   p->trunc_factor = d.trunc_factor; p->strong_th = d.strong_th; p->max_row_sum = d.max_row_sum;
+   p->max_coarse_size = d.max_coarse_size; p->min_coarse_size = d.min_coarse_size; p->max_levels = d.max_levels;
+   p->relax_down = d.relax_down; p->relax_up = d.relax_up; p->relax_coarse = d.relax_coarse;
+   p->sweeps_down = d.sweeps_down; p->sweeps_up = d.sweeps_up; p->sweeps_coarse = d.sweeps_coarse;
+   p->relax_weight = d.relax_weight; p->outer_weight = d.outer_weight; p->seed = d.seed;
+}
+extern "C" void hda_krylov_default_params(hda_krylov_params *p, int gmres)
+{
+   p->max_iter = gmres ? 300 : 100; p->rtol = 1.0e-6; p->atol = 0.0; p->two_norm = 1; p->krylov_dim = 30;
+}
+
+static AmgParams to_params(const hda_amg_params *p)
+{
+   AmgParams a;
+   if (!p) return a;
+   a.coarsen_type = p->coarsen_type; a.interp_type = p->interp_type; a.pmax = p->pmax;
+   a.trunc_factor = p->trunc_factor; a.strong_th = p->strong_th; a.max_row_sum = p->max_row_sum;
+   a.max_coarse_size = p->max_coarse_size; a.min_coarse_size = p->min_coarse_size; a.max_levels = p->max_levels;
+   a.relax_down = p->relax_down; a.relax_up = p->relax_up; a.relax_coarse = p->relax_coarse;
+   a.sweeps_down = p->sweeps_down; a.sweeps_up = p->sweeps_up; a.sweeps_coarse = p->sweeps_coarse;
+   a.relax_weight = p->relax_weight; a.outer_weight = p->outer_weight; a.seed = p->seed;
+   return a;
+}
+static KrylovParams to_kparams(const hda_krylov_params *p)
+{
+   KrylovParams k;
+   if (!p) return k;
+   k.max_iter = p->max_iter; k.rtol = p->rtol; k.atol = p->atol; k.two_norm = p->two_norm; k.krylov_dim = p->krylov_dim;
+   return k;
+}
+
+// ------------------------------------------------------------------ matrices
+
+__global__ void k_cols64_to_32(long nnz, const long long *__restrict__ in, long long offset, int *__restrict__ out)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256) out[k] = (int)(in[k] - offset);
+}
+
+extern "C" int hda_csr_create(int nrows, int ncols, const int64_t *rowptr, const int64_t *cols,
+                              const double *vals, hda_csr_t *out)
+{
+   HDA_TRY
+   if (nrows < 0 || ncols < 0 || !out || (nrows > 0 && (!rowptr))) { g_err = "bad argument"; return HDA_ERR_ARG; }
+   auto         h    = std::make_unique<hda_csr_s>();
+   const int64_t base = nrows ? rowptr[0] : 0;
+   const int64_t nnz  = nrows ? rowptr[nrows] - base : 0;
+   HDA_REQUIRE(nnz >= 0 && nnz < (1LL << 31), "local nnz must fit int32");
+   std::vector<int> rp((size_t)nrows + 1, 0), cj((size_t)nnz);
+   for (int i = 0; i <= nrows && nrows; i++) rp[(size_t)i] = (int)(rowptr[i] - base);
+   for (int64_t k = 0; k < nnz; k++)
+   {
+      const int64_t c = cols[base + k];
+      HDA_REQUIRE(c >= 0 && c < ncols, "column index out of range");
+      cj[(size_t)k] = (int)c;
+   }
+   h->m.nrows = nrows; h->m.ncols = ncols; h->m.nnz = (int)nnz;
+   h->m.rowptr.upload(rp.data(), rp.size());
+   h->m.col.alloc((size_t)std::max<int64_t>(nnz, 1));
+   h->m.val.alloc((size_t)std::max<int64_t>(nnz, 1));
+   if (nnz)
+   {
+      h->m.col.upload(cj.data(), (size_t)nnz);
+      h->m.val.upload(vals + base, (size_t)nnz);
+   }
+   sort_rows(h->m);
+   Context::get().sync();
+   *out = h.release();
+   HDA_CATCH
+}
+
+extern "C" int hda_csr_destroy(hda_csr_t A)
+{
+   if (!A) return HDA_OK;
+   try { if (hda_device_count() > 0) Context::get().sync(); } catch (...) {}
+   delete A;
+   return HDA_OK;
+}
+
+extern "C" int hda_csr_dims(hda_csr_t A, int *nrows, int *ncols, int *nnz)
+{
+   if (!A) { g_err = "null matrix"; return HDA_ERR_ARG; }
+   if (nrows) *nrows = A->get().nrows;
+   if (ncols) *ncols = A->get().ncols;
+   if (nnz) *nnz = A->get().nnz;
+   return HDA_OK;
+}
+
+extern "C" int hda_csr_download(hda_csr_t A, int *rowptr, int *col, double *val)
+{
+   HDA_TRY
+   const DCsr &m = A->get();
+   if (rowptr) m.rowptr.download(rowptr, (size_t)m.nrows + 1);
+   if (col && m.nnz) m.col.download(col, (size_t)m.nnz);
+   if (val && m.nnz) m.val.download(val, (size_t)m.nnz);
+   HDA_CATCH
+}
+
+extern "C" int hda_lap7_create(const int n[3], const int P[3], const int pc[3], const double c[3],
+                               hda_csr_t *A, double *rhs_host)
+{
+   HDA_TRY
+   HDA_REQUIRE(P[0] == 1 && P[1] == 1 && P[2] == 1, "hda_lap7_create builds the single-block matrix; use the IJ path for partitions");
+   const long long N = (long long)n[0] * n[1] * n[2];
+   HDA_REQUIRE(N < (1LL << 31) / 7, "grid too large for int32 local indexing");
+   auto h     = std::make_unique<hda_csr_s>();
+   h->m.nrows = h->m.ncols = (int)N;
+   h->m.rowptr.alloc((size_t)N + 1);
+   const long long nnz = 7 * N - 2 * ((long long)n[0] * n[1] + (long long)n[1] * n[2] + (long long)n[0] * n[2]);
+   h->m.nnz = (int)nnz;
+   DArray<long long> cols64((size_t)nnz);
+   h->m.col.alloc((size_t)nnz);
+   h->m.val.alloc((size_t)nnz);
+   h->rhs.alloc((size_t)N);
+   lap7_generate(n, P, pc, c, h->m.rowptr.data(), cols64.data(), h->m.val.data(), h->rhs.data(), (int)N);
+   k_cols64_to_32<<<2048, 256, 0, Context::get().stream>>>(nnz, cols64.data(), 0, h->m.col.data());
+   sort_rows(h->m);
+   if (rhs_host) h->rhs.download(rhs_host, (size_t)N);
+   Context::get().sync();
+   *A = h.release();
+   HDA_CATCH
+}
+
+// ------------------------------------------------------------- K1 / K2 / K9
+
+extern "C" int hda_spmv(hda_csr_t A, double alpha, const double *x, double beta, double *y)
+{
+   HDA_TRY
+   const DCsr    &m = A->get();
+   DArray<double> dx, dy;
+   dx.upload(x, (size_t)m.ncols);
+   dy.upload(y, (size_t)m.nrows);
+   spmv(m, alpha, dx.data(), beta, dy.data(), dy.data());
+   dy.download(y, (size_t)m.nrows);
+   HDA_CATCH
+}
+
+extern "C" int hda_relax(hda_csr_t A, int relax_type, double weight, int sweeps, const double *b, double *x)
+{
+   HDA_TRY
+   const DCsr &m = A->get();
+   HDA_REQUIRE(relax_type == 18 || relax_type == 0 || relax_type == 7, "device relax: Jacobi types 0/7/18 only");
+   DArray<double> d((size_t)m.nrows), dinv((size_t)m.nrows), db, x0, x1;
+   l1_row_norms(m, relax_type == 18 ? 1 : 4, d.data());
+   make_dinv(m.nrows, d.data(), weight, dinv.data());
+   db.upload(b, (size_t)m.nrows);
+   x0.upload(x, (size_t)m.ncols);
+   x1.alloc((size_t)m.ncols);
+   double *cur = x0.data(), *alt = x1.data();
+   for (int s = 0; s < sweeps; s++)
+   {
+      jacobi(m, dinv.data(), db.data(), cur, alt, -1);
+      std::swap(cur, alt);
+   }
+   HDA_HIP(hipMemcpyAsync(x, cur, sizeof(double) * (size_t)m.nrows, hipMemcpyDeviceToHost, Context::get().stream));
+   Context::get().sync();
+   HDA_CATCH
+}
+
+extern "C" int hda_dot(int n, const double *x, const double *y, double *result)
+{
+   HDA_TRY
+   DArray<double> dx, dy;
+   dx.upload(x, (size_t)n);
+   dy.upload(y, (size_t)n);
+   dot(n, dx.data(), dy.data(), 0);
+   finalize(0, S_TMP);
+   *result = read_scalar(S_TMP);
+   HDA_CATCH
+}
+
+extern "C" int hda_l1_norms(hda_csr_t A, int option, double *l1)
+{
+   HDA_TRY
+   const DCsr    &m = A->get();
+   DArray<double> d((size_t)m.nrows);
+   l1_row_norms(m, option, d.data());
+   d.download(l1, (size_t)m.nrows);
+   HDA_CATCH
+}
+
+// ------------------------------------------------------------- K4 / K5 / K6
+
+extern "C" int hda_strength(hda_csr_t A, double theta, double max_row_sum, unsigned char *smask)
+{
+   HDA_TRY
+   const DCsr           &m = A->get();
+   DArray<unsigned char> sm((size_t)std::max(m.nnz, 1));
+   amg_strength(m, theta, max_row_sum, sm.data());
+   if (m.nnz) sm.download(smask, (size_t)m.nnz);
+   HDA_CATCH
+}
+
+extern "C" int hda_pmis(hda_csr_t A, const unsigned char *smask, uint64_t seed, int level,
+                        int64_t row_offset, int *cf)
+{
+   HDA_TRY
+   const DCsr           &m = A->get();
+   DArray<unsigned char> sm;
+   sm.upload(smask, (size_t)std::max(m.nnz, 1));
+   DArray<int> dcf((size_t)std::max(m.nrows, 1));
+   amg_pmis(m, sm.data(), seed, level, row_offset, dcf.data());
+   if (m.nrows) dcf.download(cf, (size_t)m.nrows);
+   HDA_CATCH
+}
+
+extern "C" int hda_interp_extpi(hda_csr_t A, const unsigned char *smask, const int *cf, int pmax,
+                                double trunc_factor, hda_csr_t *P)
+{
+   HDA_TRY
+   const DCsr           &m = A->get();
+   DArray<unsigned char> sm;
+   DArray<int>           dcf;
+   sm.upload(smask, (size_t)std::max(m.nnz, 1));
+   dcf.upload(cf, (size_t)std::max(m.nrows, 1));
+   auto h = std::make_unique<hda_csr_s>();
+   amg_interp_extpi(m, sm.data(), dcf.data(), pmax, trunc_factor, h->m);
+   Context::get().sync();
+   *P = h.release();
+   HDA_CATCH
+}
+
+extern "C" int hda_transpose(hda_csr_t A, hda_csr_t *T)
+{
+   HDA_TRY
+   auto h = std::make_unique<hda_csr_s>();
+   transpose(A->get(), h->m);
+   Context::get().sync();
+   *T = h.release();
+   HDA_CATCH
+}
+
+extern "C" int hda_spgemm(hda_csr_t X, hda_csr_t Y, hda_csr_t *C)
+{
+   HDA_TRY
+   auto h = std::make_unique<hda_csr_s>();
+   spgemm(X->get(), Y->get(), h->m);
+   Context::get().sync();
+   *C = h.release();
+   HDA_CATCH
+}
+
+extern "C" int hda_rap(hda_csr_t A, hda_csr_t P, hda_csr_t *Ac)
+{
+   HDA_TRY
+   DCsr R;
+   transpose(P->get(), R);
+   auto h = std::make_unique<hda_csr_s>();
+   amg_rap(A->get(), P->get(), R, h->m);
+   Context::get().sync();
+   *Ac = h.release();
+   HDA_CATCH
+}
+
+// ------------------------------------------------------------------ hierarchy
+
+extern "C" int hda_amg_create(const hda_amg_params *p, hda_csr_t A, hda_amg_t *out)
+{
+   HDA_TRY
+   auto h = std::make_unique<hda_amg_s>();
+   h->amg = std::make_unique<Amg>(to_params(p));
+   h->A   = A;
+   h->amg->setup(A->get());
+   *out = h.release();
+   HDA_CATCH
+}
+extern "C" int hda_amg_destroy(hda_amg_t h)
+{
+   if (!h) return HDA_OK;
+   try { if (hda_device_count() > 0) Context::get().sync(); } catch (...) {}
+   delete h;
+   return HDA_OK;
+}
+extern "C" int hda_amg_num_levels(hda_amg_t h) { return h ? h->amg->num_levels() : 0; }
+
+extern "C" int hda_amg_level_matrix(hda_amg_t h, int level, int which, hda_csr_t *out)
+{
+   HDA_TRY
+   HDA_REQUIRE(level >= 0 && level < h->amg->num_levels(), "level out of range");
+   const DCsr *m = nullptr;
+   if (which == 0) m = &h->amg->level_A(level);
+   else
+   {
+      HDA_REQUIRE(level < h->amg->num_levels() - 1, "no transfer operator on the coarsest level");
+      m = (which == 1) ? &h->amg->level(level).P : &h->amg->level(level).R;
+   }
+   auto v      = std::make_unique<hda_csr_s>();
+   v->borrowed = true;
+   v->ref      = m;
+   *out        = v.get();
+   h->views.push_back(std::move(v));
+   HDA_CATCH
+}
+extern "C" int hda_amg_level_cf(hda_amg_t h, int level, int *cf)
+{
+   HDA_TRY
+   HDA_REQUIRE(level >= 0 && level < h->amg->num_levels() - 1, "level has no C/F splitting");
+   auto &L = h->amg->level(level);
+   L.cf.download(cf, L.cf.size());
+   HDA_CATCH
+}
+extern "C" int hda_amg_complexities(hda_amg_t h, double *grid, double *op)
+{
+   if (!h) return HDA_ERR_ARG;
+   if (grid) *grid = h->amg->grid_complexity();
+   if (op) *op = h->amg->operator_complexity();
+   return HDA_OK;
+}
+extern "C" double hda_amg_vcycle_bytes(hda_amg_t h) { return h ? h->amg->vcycle_bytes() : 0.0; }
+
+extern "C" int hda_amg_vcycle(hda_amg_t h, const double *b, double *x)
+{
+   HDA_TRY
+   const int      n = h->amg->level_A(0).nrows;
+   DArray<double> db, dx((size_t)std::max(h->amg->level_A(0).ncols, 1));
+   db.upload(b, (size_t)n);
+   h->amg->apply(db.data(), dx.data(), -1);
+   dx.download(x, (size_t)n);
+   HDA_CATCH
+}
+
+// --------------------------------------------------------------------- Krylov
+
+static int run_krylov(bool use_gmres, hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b,
+                      double *x, double *hist, int *iters, int *converged, double *final_rel)
+{
+   HDA_TRY
+   const DCsr    &m = A->get();
+   DArray<double> db, dx;
+   db.upload(b, (size_t)m.nrows);
+   dx.alloc((size_t)std::max(m.ncols, 1));
+   dx.zero();
+   HDA_HIP(hipMemcpyAsync(dx.data(), x, sizeof(double) * (size_t)m.nrows, hipMemcpyHostToDevice, Context::get().stream));
+   Context::get().sync();
+   PrecondFn M;
+   if (amg) M = [amg](const double *r, double *z, int slot) { amg->amg->apply(r, z, slot); };
+   KrylovParams  k   = to_kparams(kp);
+   KrylovResult  res = use_gmres ? gmres(m, M, k, db.data(), dx.data()) : pcg(m, M, k, db.data(), dx.data());
+   dx.download(x, (size_t)m.nrows);
+   if (hist)
+      for (size_t i = 0; i < res.hist.size() && i < (size_t)k.max_iter + 1; i++) hist[i] = res.hist[i];
+   if (iters) *iters = res.iters;
+   if (converged) *converged = res.converged ? 1 : 0;
+   if (final_rel) *final_rel = res.final_rel;
+   HDA_CATCH
+}
+extern "C" int hda_pcg(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
+                       double *hist, int *iters, int *converged, double *final_rel)
+{
+   return run_krylov(false, A, amg, kp, b, x, hist, iters, converged, final_rel);
+}
+extern "C" int hda_gmres(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
+                         double *hist, int *iters, int *converged, double *final_rel)
+{
+   return run_krylov(true, A, amg, kp, b, x, hist, iters, converged, final_rel);
+}
+
+// ---------------------------------------------------------------- measurement
+
+static double spmv_alg_bytes(const DCsr &M) { return 12.0 * M.nnz + 4.0 * (M.nrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows; }
+
+extern "C" int hda_time_kernel(int kind, hda_csr_t A, hda_amg_t amg, int reps, double *avg_ms, double *bytes)
+{
+   HDA_TRY
+   Context       &ctx = Context::get();
+   const DCsr    &m   = A->get();
+   const size_t   nv  = (size_t)std::max(m.ncols, 1);
+   DArray<double> x(nv), y(nv), b(nv), dinv(nv);
+   fill((int)nv, 1.0, x.data());
+   fill((int)nv, 0.5, b.data());
+   {
+      DArray<double> d((size_t)m.nrows);
+      l1_row_norms(m, 1, d.data());
+      make_dinv(m.nrows, d.data(), 1.0, dinv.data());
+   }
+   auto launch = [&]() {
+      switch (kind)
+      {
+         case 0: spmv(m, 1.0, x.data(), 0.0, nullptr, y.data()); break;
+         case 1: jacobi(m, dinv.data(), b.data(), x.data(), y.data(), -1); break;
+         case 2: residual(m, x.data(), b.data(), y.data()); break;
+         case 3: HDA_REQUIRE(amg, "V-cycle timing needs a hierarchy"); amg->amg->apply(b.data(), y.data(), -1); break;
+         default: throw Error("unknown kernel kind");
+      }
+   };
+   for (int w = 0; w < 3; w++) launch();
+   hipEvent_t e0, e1;
+   HDA_HIP(hipEventCreate(&e0));
+   HDA_HIP(hipEventCreate(&e1));
+   HDA_HIP(hipEventRecord(e0, ctx.stream));
+   for (int r = 0; r < reps; r++) launch();
+   HDA_HIP(hipEventRecord(e1, ctx.stream));
+   HDA_HIP(hipEventSynchronize(e1));
+   float ms = 0.f;
+   HDA_HIP(hipEventElapsedTime(&ms, e0, e1));
+   (void)hipEventDestroy(e0);
+   (void)hipEventDestroy(e1);
+   if (avg_ms) *avg_ms = (double)ms / std::max(reps, 1);
+   if (bytes)
+   {
+      const double sb = spmv_alg_bytes(m);
+      *bytes = (kind == 0) ? sb : (kind == 1) ? sb + 16.0 * m.nrows : (kind == 2) ? sb + 8.0 * m.nrows : amg->amg->vcycle_bytes();
+   }
+   HDA_CATCH
+}
+
+extern "C" int hda_solve_timed(hda_csr_t A, const hda_amg_params *ap, const hda_krylov_params *kp,
+                               const double *b_host, int solver, double *setup_ms, double *solve_ms,
+                               int *iters, double *final_rel, double *r0_norm, double *true_rel,
+                               double *bytes_per_iter, double *op_complexity, int *num_levels)
+{
+   HDA_TRY
+   using clk        = std::chrono::steady_clock;
+   Context       &ctx = Context::get();
+   const DCsr    &m   = A->get();
+   const int      n   = m.nrows;
+   DArray<double> b, x((size_t)std::max(m.ncols, 1)), r((size_t)std::max(n, 1));
+   if (b_host) b.upload(b_host, (size_t)n);
+   else
+   {
+      HDA_REQUIRE(A->rhs.size() == (size_t)n, "no right-hand side: pass b or build A with hda_lap7_create");
+      b.copy_from(A->rhs);
+   }
+   x.zero();
+   ctx.sync();
+   // "prec" timer (src/internal/solver.c:288-302): AMG setup
+   auto t0 = clk::now();
+   Amg  amg(to_params(ap));
+   amg.setup(m);
+   ctx.sync();
+   auto t1 = clk::now();
+   // initial residual norm, untimed (solver.c:666)
+   residual(m, x.data(), b.data(), r.data());
+   dot(n, r.data(), r.data(), 0);
+   finalize(0, S_TMP);
+   const double r0 = std::sqrt(read_scalar(S_TMP));
+   dot(n, b.data(), b.data(), 0);
+   finalize(0, S_TMP);
+   const double bn = std::sqrt(read_scalar(S_TMP));
+   PrecondFn M = [&amg](const double *rr, double *zz, int slot) { amg.apply(rr, zz, slot); };
+   ctx.sync();
+   // "solve" timer (solver.c:668-683)
+   auto         t2  = clk::now();
+   KrylovResult res = solver ? gmres(m, M, to_kparams(kp), b.data(), x.data()) : pcg(m, M, to_kparams(kp), b.data(), x.data());
+   ctx.sync();
+   auto t3 = clk::now();
+   // true relative residual, untimed (solver.c:686-690)
+   residual(m, x.data(), b.data(), r.data());
+   dot(n, r.data(), r.data(), 0);
+   finalize(0, S_TMP);
+   const double rn = std::sqrt(read_scalar(S_TMP));
+   if (setup_ms) *setup_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+   if (solve_ms) *solve_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+   if (iters) *iters = res.iters;
+   if (final_rel) *final_rel = res.final_rel;
+   if (r0_norm) *r0_norm = r0;
+   if (true_rel) *true_rel = (bn > 0.0) ? rn / bn : rn;
+   if (bytes_per_iter) *bytes_per_iter = pcg_iteration_bytes(m) + amg.vcycle_bytes();
+   if (op_complexity) *op_complexity = amg.operator_complexity();
+   if (num_levels) *num_levels = amg.num_levels();
+   HDA_CATCH
+}

@@ -1,0 +1,146 @@
+// hda_common.h -- shared host-side plumbing of the MI355X (gfx950) solve path.
+// Device memory comes from the stream-ordered HIP pool (hipMallocAsync) so AMG setup does
+// not pay a device-wide sync per temporary; everything runs on one stream per context.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace hda {
+
+struct Error : std::runtime_error {
+   using std::runtime_error::runtime_error;
+};
+
+#define HDA_HIP(expr)                                                                    \
+   do {                                                                                  \
+      hipError_t _e = (expr);                                                            \
+      if (_e != hipSuccess)                                                              \
+      {                                                                                  \
+         char _buf[512];                                                                 \
+         snprintf(_buf, sizeof(_buf), "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), \
+                  __FILE__, __LINE__, #expr);                                            \
+         throw ::hda::Error(_buf);                                                       \
+      }                                                                                  \
+   } while (0)
+
+#define HDA_REQUIRE(cond, msg)                                                     \
+   do {                                                                            \
+      if (!(cond))                                                                 \
+      {                                                                            \
+         char _buf[512];                                                           \
+         snprintf(_buf, sizeof(_buf), "%s (%s) at %s:%d", msg, #cond, __FILE__, __LINE__); \
+         throw ::hda::Error(_buf);                                                 \
+      }                                                                            \
+   } while (0)
+
+// Number of per-block partial sums every fused reduction writes (fixed so that the
+// summation tree -- and therefore every dot product -- is run-to-run deterministic).
+constexpr int kRedBlocks  = 2048; // 8 blocks (32 waves) per CU on 256 CUs
+constexpr int kRedThreads = 256;
+
+// One per process (per GPU): stream, reduction scratch, pinned scalars.
+struct Context {
+   hipStream_t stream      = nullptr;
+   double     *partials    = nullptr; // [kNumSlots][kRedBlocks] block partials
+   double     *scalars     = nullptr; // device scalars (gamma, alpha, ...)
+   double     *host_scalars = nullptr; // pinned host mirror for async read-back
+   hipEvent_t  ev           = nullptr;
+   int         device       = 0;
+   static constexpr int kNumSlots   = 8;
+   static constexpr int kNumScalars = 64;
+
+   static Context &get();
+   void            sync() { HDA_HIP(hipStreamSynchronize(stream)); }
+   double         *slot(int s) { return partials + (size_t)s * kRedBlocks; }
+
+ private:
+   Context();
+};
+
+// Stream-ordered device array.
+template <class T>
+class DArray {
+ public:
+   DArray() = default;
+   explicit DArray(size_t n) { alloc(n); }
+   DArray(const DArray &) = delete;
+   DArray &operator=(const DArray &) = delete;
+   DArray(DArray &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+   DArray &operator=(DArray &&o) noexcept
+   {
+      if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+      return *this;
+   }
+   ~DArray() { release(); }
+
+   void alloc(size_t n)
+   {
+      release();
+      n_ = n;
+      if (n == 0) return;
+      HDA_HIP(hipMallocAsync((void **)&p_, n * sizeof(T), Context::get().stream));
+   }
+   void release()
+   {
+      if (p_) (void)hipFreeAsync(p_, Context::get().stream);
+      p_ = nullptr;
+      n_ = 0;
+   }
+   void zero()
+   {
+      if (n_) HDA_HIP(hipMemsetAsync(p_, 0, n_ * sizeof(T), Context::get().stream));
+   }
+   void upload(const T *h, size_t n)
+   {
+      if (n_ != n) alloc(n);
+      if (n) HDA_HIP(hipMemcpyAsync(p_, h, n * sizeof(T), hipMemcpyHostToDevice, Context::get().stream));
+      Context::get().sync(); // host buffer may be pageable / transient
+   }
+   void download(T *h, size_t n) const
+   {
+      HDA_REQUIRE(n <= n_, "download larger than array");
+      if (n) HDA_HIP(hipMemcpyAsync(h, p_, n * sizeof(T), hipMemcpyDeviceToHost, Context::get().stream));
+      Context::get().sync();
+   }
+   std::vector<T> to_host() const
+   {
+      std::vector<T> v(n_);
+      download(v.data(), n_);
+      return v;
+   }
+   void copy_from(const DArray<T> &o)
+   {
+      if (n_ != o.n_) alloc(o.n_);
+      if (n_) HDA_HIP(hipMemcpyAsync(p_, o.p_, n_ * sizeof(T), hipMemcpyDeviceToDevice, Context::get().stream));
+   }
+   T       *data() { return p_; }
+   const T *data() const { return p_; }
+   size_t   size() const { return n_; }
+
+ private:
+   T     *p_ = nullptr;
+   size_t n_ = 0;
+};
+
+// Local CSR block resident in HBM. int32 indices, fp64 values, rows column-sorted.
+// ncols may exceed nrows: columns >= nrows address the ghost tail of an extended vector
+// (row-partitioned case: [owned | halo]).
+struct DCsr {
+   int            nrows = 0, ncols = 0, nnz = 0;
+   DArray<int>    rowptr; // nrows+1
+   DArray<int>    col;    // nnz
+   DArray<double> val;    // nnz
+   double         avg_row() const { return nrows ? (double)nnz / nrows : 0.0; }
+};
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+} // namespace hda

@@ -1,0 +1,70 @@
+// hda_kernels.h -- launch wrappers of the solve-phase HIP kernels (gfx950).
+// Each wrapper names the hypre entry point it replaces on the reference's hot path
+// (SURVEY.md 2.4, K1/K2/K7/K8/K9).
+#pragma once
+
+#include "hda_common.h"
+
+namespace hda {
+
+// ---- K1: CSR SpMV family (replaces HYPRE_ParCSRMatrixMatvec, reached from
+// src/internal/linsys.c:3031 and every PCG iteration via src/internal/solver.c:614).
+// y_out = alpha*A*x + beta*y_in   (y_in may alias y_out; beta==0 never reads y_in)
+void spmv(const DCsr &A, double alpha, const double *x, double beta, const double *y_in,
+          double *y_out);
+// y = A*x and block partials of <y, w> into slot (fused dot, K9)
+void spmv_dot(const DCsr &A, const double *x, double *y, const double *w, int slot);
+// out = b - A*x
+void residual(const DCsr &A, const double *x, const double *b, double *out);
+
+// ---- K2: l1-Jacobi / weighted Jacobi sweep (hypre_BoomerAMGRelax types 18 / 0,7;
+// selected by src/internal/amg.c:183-186,360-375).  dinv = weight / l1 (or / a_ii).
+// x_out = x_in + dinv .* (b - A*x_in).  dot_slot >= 0 also emits partials of <b, x_out>.
+void jacobi(const DCsr &A, const double *dinv, const double *b, const double *x_in,
+            double *x_out, int dot_slot);
+// first sweep from a zero guess: x = dinv .* b
+void jacobi_zero_guess(int n, const double *dinv, const double *b, double *x);
+
+// ---- K9: fused BLAS-1 of the PCG recurrences (hypre_PCGSolve inner loop, reached from
+// solver_ops[SOLVER_PCG].solve src/internal/solver.c:211).
+enum Scalar : int {
+   S_GAMMA0 = 0, S_GAMMA1 = 1, S_SP = 2, S_RR = 3, S_BB = 4, S_TMP = 5, S_TMP2 = 6,
+   S_GMRES = 8 /* .. S_GMRES + krylov_dim + 1 */
+};
+void dot(int n, const double *x, const double *y, int slot);              // partials only
+void finalize(int slot, int scalar_idx);                                  // scalars[idx] = sum(slot)
+void finalize_n(int first_slot, int nslots, int first_scalar);            // several at once
+void cg_update(int n, int gamma_idx, const double *p, const double *s, double *x, double *r,
+               int rr_slot); // alpha = gamma/S_SP; x += alpha p; r -= alpha s; partials <r,r>
+void cg_direction(int n, int gamma_old_idx, int gamma_new_idx, const double *z, double *p);
+void axpy(int n, double a, const double *x, double *y);                   // y += a x
+void axpy_dev(int n, int scalar_idx, double sign, const double *x, double *y); // y += sign*scalars[idx]*x
+void scale(int n, double a, double *x);
+void scale_inv_sqrt_dev(int n, int scalar_idx, double *x);                // x /= sqrt(scalars[idx])
+void copy(int n, const double *x, double *y);
+void fill(int n, double v, double *x);
+void mul(int n, const double *a, const double *b, double *out);           // out = a .* b
+double read_scalar(int idx);                                              // sync read-back
+void   read_scalars_async(int first, int count);                          // -> ctx.host_scalars, records ctx.ev
+
+// ---- K8: coarsest-level dense solve (hypre relax type 9, src/internal/amg.c:190).
+// inv is the n x n row-major inverse built at setup; x = inv * b with one workgroup.
+void dense_apply(int n, const double *inv, const double *b, double *x);
+// In-place Gauss-Jordan inverse of an n x n row-major matrix (no pivoting, like gselim).
+void dense_invert(int n, double *a, double *inv);
+void csr_to_dense(const DCsr &A, double *dense);
+
+// ---- utilities
+void exclusive_scan(int n, const int *in, int *out, int *total_out_dev); // out[i] = sum_{j<i} in[j]; out[n] = total
+void l1_row_norms(const DCsr &A, int option, double *l1);   // hypre_ParCSRComputeL1Norms opt 1 / 4
+void extract_diag(const DCsr &A, double *d);
+void make_dinv(int n, const double *d, double weight, double *dinv);
+void sort_rows(DCsr &A);                                    // column-sort every row in place
+void transpose(const DCsr &A, DCsr &T);                     // rows of T sorted
+// 7-pt Laplacian generator on device (examples/src/C_laplacian/laplacian.c:719-921),
+// rows [ilower, iupper] of the block-partitioned numbering; cols are GLOBAL ids (int64).
+void lap7_generate(const int n[3], const int P[3], const int pc[3], const double c[3],
+                   int rowptr_out[], long long cols_out[], double vals_out[], double rhs_out[],
+                   int local_n);
+
+} // namespace hda

@@ -1,0 +1,768 @@
+// hda_kernels.hip -- solve-phase kernels for CDNA4 (gfx950, wave64).
+//
+// All of these are HBM-bandwidth bound (SpMV arithmetic intensity ~0.13 flop/B), so the
+// design rules are the memory ones: a lane group of LPR lanes walks one CSR row so that a
+// wave reads a contiguous run of (col,val) pairs; two independent rows per lane group are
+// in flight to cover HBM latency; per-row sums are combined with wave shuffles; every
+// dot product is produced as kRedBlocks block partials in a fixed tree (deterministic) and
+// fused into the kernel that already streams the operands.
+#include "hda_kernels.h"
+
+#include <cmath>
+
+namespace hda {
+
+// ------------------------------------------------------------------ context
+
+Context::Context()
+{
+   HDA_HIP(hipGetDevice(&device));
+   HDA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+   hipMemPool_t pool;
+   HDA_HIP(hipDeviceGetDefaultMemPool(&pool, device));
+   uint64_t thresh = UINT64_MAX; // keep freed blocks cached in the pool
+   HDA_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thresh));
+   HDA_HIP(hipMalloc((void **)&partials, sizeof(double) * kNumSlots * kRedBlocks));
+   HDA_HIP(hipMemset(partials, 0, sizeof(double) * kNumSlots * kRedBlocks));
+   HDA_HIP(hipMalloc((void **)&scalars, sizeof(double) * kNumScalars));
+   HDA_HIP(hipMemset(scalars, 0, sizeof(double) * kNumScalars));
+   HDA_HIP(hipHostMalloc((void **)&host_scalars, sizeof(double) * kNumScalars, hipHostMallocDefault));
+   HDA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+}
+
+Context &Context::get()
+{
+   static Context ctx;
+   return ctx;
+}
+
+#define STREAM (Context::get().stream)
+
+// ------------------------------------------------------- device reductions
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+   return v;
+}
+
+// fixed-order sum over a 256-thread block; every thread gets the result
+__device__ __forceinline__ double block_sum(double v)
+{
+   __shared__ double sm[4];
+   v = wave_sum(v);
+   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+   __syncthreads();
+   double t = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+   __syncthreads();
+   return t;
+}
+
+template <int LPR>
+__device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+   for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+   return v;
+}
+
+__global__ __launch_bounds__(kRedThreads) void k_finalize(const double *__restrict__ partials,
+                                                           int first_slot, double *scalars,
+                                                           int first_scalar)
+{
+   const double *p = partials + (size_t)(first_slot + blockIdx.x) * kRedBlocks;
+   double        s = 0.0;
+   for (int i = threadIdx.x; i < kRedBlocks; i += kRedThreads) s += p[i];
+   s = block_sum(s);
+   if (threadIdx.x == 0) scalars[first_scalar + blockIdx.x] = s;
+}
+
+void finalize_n(int first_slot, int nslots, int first_scalar)
+{
+   Context &c = Context::get();
+   k_finalize<<<nslots, kRedThreads, 0, c.stream>>>(c.partials, first_slot, c.scalars, first_scalar);
+}
+void finalize(int slot, int scalar_idx) { finalize_n(slot, 1, scalar_idx); }
+
+double read_scalar(int idx)
+{
+   Context &c = Context::get();
+   double   v;
+   HDA_HIP(hipMemcpyAsync(&v, c.scalars + idx, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+   c.sync();
+   return v;
+}
+
+void read_scalars_async(int first, int count)
+{
+   Context &c = Context::get();
+   HDA_HIP(hipMemcpyAsync(c.host_scalars + first, c.scalars + first, sizeof(double) * count,
+                          hipMemcpyDeviceToHost, c.stream));
+   HDA_HIP(hipEventRecord(c.ev, c.stream));
+}
+
+// -------------------------------------------------------------------- SpMV
+
+enum { MODE_PLAIN = 0, MODE_RESID = 1, MODE_JACOBI = 2 };
+
+// One lane group (LPR lanes) per row, two rows in flight per group, grid-stride.
+//  MODE_PLAIN : out = alpha*Ax + beta*yin       DOT: partial += out_i * w_i
+//  MODE_RESID : out = b - Ax
+//  MODE_JACOBI: out = xin + dinv*(b - A xin)    DOT: partial += b_i * out_i
+template <int LPR, int MODE, bool DOT>
+__global__ __launch_bounds__(256) void k_spmv(int n, const int *__restrict__ rowptr,
+                                              const int *__restrict__ col,
+                                              const double *__restrict__ val,
+                                              const double *__restrict__ x, double alpha,
+                                              double beta, const double *yin,
+                                              const double *__restrict__ b,
+                                              const double *__restrict__ dinv,
+                                              const double *__restrict__ w, double *out,
+                                              double *__restrict__ partial)
+{
+   const int  lane = threadIdx.x & (LPR - 1);
+   const long G    = (long)gridDim.x * (256 / LPR);
+   const long gid  = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+   double     acc  = 0.0;
+   for (long r0 = gid; r0 < n; r0 += 2 * G)
+   {
+      const long r1 = r0 + G;
+      const bool h1 = r1 < n;
+      int        s0 = rowptr[r0], e0 = rowptr[r0 + 1];
+      int        s1 = 0, e1 = 0;
+      if (h1) { s1 = rowptr[r1]; e1 = rowptr[r1 + 1]; }
+      int    k0 = s0 + lane, k1 = s1 + lane;
+      double a0 = 0.0, a1 = 0.0;
+      if (k0 < e0) a0 = val[k0] * x[col[k0]];
+      if (k1 < e1) a1 = val[k1] * x[col[k1]];
+      for (k0 += LPR; k0 < e0; k0 += LPR) a0 += val[k0] * x[col[k0]];
+      for (k1 += LPR; k1 < e1; k1 += LPR) a1 += val[k1] * x[col[k1]];
+      a0 = group_sum<LPR>(a0);
+      a1 = group_sum<LPR>(a1);
+      if (lane == 0)
+      {
+         double o0, o1 = 0.0;
+         if (MODE == MODE_PLAIN)
+         {
+            o0 = (beta == 0.0) ? alpha * a0 : alpha * a0 + beta * yin[r0];
+            if (h1) o1 = (beta == 0.0) ? alpha * a1 : alpha * a1 + beta * yin[r1];
+            if (DOT) { acc += o0 * w[r0]; if (h1) acc += o1 * w[r1]; }
+         }
+         else if (MODE == MODE_RESID)
+         {
+            o0 = b[r0] - a0;
+            if (h1) o1 = b[r1] - a1;
+         }
+         else
+         {
+            const double b0 = b[r0];
+            o0              = x[r0] + dinv[r0] * (b0 - a0);
+            if (DOT) acc += b0 * o0;
+            if (h1)
+            {
+               const double b1 = b[r1];
+               o1              = x[r1] + dinv[r1] * (b1 - a1);
+               if (DOT) acc += b1 * o1;
+            }
+         }
+         out[r0] = o0;
+         if (h1) out[r1] = o1;
+      }
+   }
+   if (DOT)
+   {
+      acc = block_sum(acc);
+      if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+   }
+}
+
+static int pick_lpr(const DCsr &A)
+{
+   double a = A.avg_row();
+   if (a <= 5.0) return 4;
+   if (a <= 10.0) return 8;
+   if (a <= 20.0) return 16;
+   if (a <= 40.0) return 32;
+   return 64;
+}
+
+template <int MODE, bool DOT>
+static void launch_spmv(const DCsr &A, const double *x, double alpha, double beta,
+                        const double *yin, const double *b, const double *dinv, const double *w,
+                        double *out, double *partial)
+{
+   if (A.nrows == 0 && !DOT) return;
+   const int lpr  = pick_lpr(A);
+   long      need = ((long)A.nrows * lpr + 511) / 512; // two rows per group
+   int       grid = DOT ? kRedBlocks : (int)std::min<long>(std::max<long>(need, 1), kRedBlocks);
+#define HDA_LAUNCH(L)                                                                         \
+   k_spmv<L, MODE, DOT><<<grid, 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(),      \
+                                                  A.val.data(), x, alpha, beta, yin, b, dinv,  \
+                                                  w, out, partial)
+   switch (lpr)
+   {
+      case 4: HDA_LAUNCH(4); break;
+      case 8: HDA_LAUNCH(8); break;
+      case 16: HDA_LAUNCH(16); break;
+      case 32: HDA_LAUNCH(32); break;
+      default: HDA_LAUNCH(64); break;
+   }
+#undef HDA_LAUNCH
+}
+
+void spmv(const DCsr &A, double alpha, const double *x, double beta, const double *y_in, double *y_out)
+{
+   launch_spmv<MODE_PLAIN, false>(A, x, alpha, beta, y_in, nullptr, nullptr, nullptr, y_out, nullptr);
+}
+void spmv_dot(const DCsr &A, const double *x, double *y, const double *w, int slot)
+{
+   launch_spmv<MODE_PLAIN, true>(A, x, 1.0, 0.0, nullptr, nullptr, nullptr, w, y, Context::get().slot(slot));
+}
+void residual(const DCsr &A, const double *x, const double *b, double *out)
+{
+   launch_spmv<MODE_RESID, false>(A, x, 1.0, 0.0, nullptr, b, nullptr, nullptr, out, nullptr);
+}
+void jacobi(const DCsr &A, const double *dinv, const double *b, const double *x_in, double *x_out, int dot_slot)
+{
+   if (dot_slot >= 0)
+      launch_spmv<MODE_JACOBI, true>(A, x_in, 1.0, 0.0, nullptr, b, dinv, nullptr, x_out, Context::get().slot(dot_slot));
+   else
+      launch_spmv<MODE_JACOBI, false>(A, x_in, 1.0, 0.0, nullptr, b, dinv, nullptr, x_out, nullptr);
+}
+
+// ------------------------------------------------------------------ BLAS-1
+
+static inline int ew_grid(long n) { return (int)std::min<long>(std::max<long>((n + 511) / 512, 1), kRedBlocks); }
+
+__global__ __launch_bounds__(256) void k_mul(int n, const double *__restrict__ a,
+                                             const double *__restrict__ b, double *__restrict__ o)
+{
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) o[i] = a[i] * b[i];
+}
+void mul(int n, const double *a, const double *b, double *out)
+{
+   if (n) k_mul<<<ew_grid(n), 256, 0, STREAM>>>(n, a, b, out);
+}
+void jacobi_zero_guess(int n, const double *dinv, const double *b, double *x) { mul(n, dinv, b, x); }
+
+__global__ __launch_bounds__(256) void k_dot(int n, const double *__restrict__ x,
+                                             const double *__restrict__ y, double *__restrict__ partial)
+{
+   double acc = 0.0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += x[i] * y[i];
+   acc = block_sum(acc);
+   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+void dot(int n, const double *x, const double *y, int slot)
+{
+   k_dot<<<kRedBlocks, 256, 0, STREAM>>>(n, x, y, Context::get().slot(slot));
+}
+
+__global__ __launch_bounds__(256) void k_cg_update(int n, const double *__restrict__ scalars,
+                                                   int gamma_idx, const double *__restrict__ p,
+                                                   const double *__restrict__ s, double *__restrict__ x,
+                                                   double *__restrict__ r, double *__restrict__ partial)
+{
+   const double alpha = scalars[gamma_idx] / scalars[S_SP];
+   double       acc   = 0.0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+   {
+      x[i] += alpha * p[i];
+      const double ri = r[i] - alpha * s[i];
+      r[i]            = ri;
+      acc += ri * ri;
+   }
+   acc = block_sum(acc);
+   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+void cg_update(int n, int gamma_idx, const double *p, const double *s, double *x, double *r, int rr_slot)
+{
+   Context &c = Context::get();
+   k_cg_update<<<kRedBlocks, 256, 0, c.stream>>>(n, c.scalars, gamma_idx, p, s, x, r, c.slot(rr_slot));
+}
+
+__global__ __launch_bounds__(256) void k_cg_dir(int n, const double *__restrict__ scalars, int go,
+                                                int gn, const double *__restrict__ z, double *__restrict__ p)
+{
+   const double beta = scalars[gn] / scalars[go];
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = z[i] + beta * p[i];
+}
+void cg_direction(int n, int gamma_old_idx, int gamma_new_idx, const double *z, double *p)
+{
+   if (n) k_cg_dir<<<ew_grid(n), 256, 0, STREAM>>>(n, Context::get().scalars, gamma_old_idx, gamma_new_idx, z, p);
+}
+
+__global__ __launch_bounds__(256) void k_axpy(int n, double a, const double *__restrict__ x, double *__restrict__ y)
+{
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+void axpy(int n, double a, const double *x, double *y)
+{
+   if (n) k_axpy<<<ew_grid(n), 256, 0, STREAM>>>(n, a, x, y);
+}
+__global__ __launch_bounds__(256) void k_axpy_dev(int n, const double *__restrict__ scalars, int idx,
+                                                  double sign, const double *__restrict__ x, double *__restrict__ y)
+{
+   const double a = sign * scalars[idx];
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+void axpy_dev(int n, int scalar_idx, double sign, const double *x, double *y)
+{
+   if (n) k_axpy_dev<<<ew_grid(n), 256, 0, STREAM>>>(n, Context::get().scalars, scalar_idx, sign, x, y);
+}
+__global__ __launch_bounds__(256) void k_scale(int n, double a, double *__restrict__ x)
+{
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= a;
+}
+void scale(int n, double a, double *x)
+{
+   if (n) k_scale<<<ew_grid(n), 256, 0, STREAM>>>(n, a, x);
+}
+__global__ __launch_bounds__(256) void k_scale_isq(int n, const double *__restrict__ scalars, int idx, double *__restrict__ x)
+{
+   const double t = scalars[idx];
+   const double a = (t > 0.0) ? 1.0 / sqrt(t) : 0.0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= a;
+}
+void scale_inv_sqrt_dev(int n, int scalar_idx, double *x)
+{
+   if (n) k_scale_isq<<<ew_grid(n), 256, 0, STREAM>>>(n, Context::get().scalars, scalar_idx, x);
+}
+void copy(int n, const double *x, double *y)
+{
+   if (n) HDA_HIP(hipMemcpyAsync(y, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, STREAM));
+}
+__global__ __launch_bounds__(256) void k_fill(int n, double v, double *__restrict__ x)
+{
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = v;
+}
+void fill(int n, double v, double *x)
+{
+   if (n == 0) return;
+   if (v == 0.0) HDA_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, STREAM));
+   else k_fill<<<ew_grid(n), 256, 0, STREAM>>>(n, v, x);
+}
+
+// ------------------------------------------------------- dense coarse solve
+
+// x = inv * b ; invT is the inverse stored column-major (invT[j*n+i] = inv[i][j]) so that
+// consecutive threads read consecutive addresses.
+__global__ __launch_bounds__(256) void k_dense_apply(int n, const double *__restrict__ invT,
+                                                     const double *__restrict__ b, double *__restrict__ x)
+{
+   extern __shared__ double sb[];
+   for (int j = threadIdx.x; j < n; j += 256) sb[j] = b[j];
+   __syncthreads();
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n)
+   {
+      double s = 0.0;
+      for (int j = 0; j < n; j++) s += invT[(size_t)j * n + i] * sb[j];
+      x[i] = s;
+   }
+}
+void dense_apply(int n, const double *invT, const double *b, double *x)
+{
+   if (n) k_dense_apply<<<ceil_div(n, 256), 256, sizeof(double) * (size_t)n, STREAM>>>(n, invT, b, x);
+}
+
+__global__ void k_csr_to_dense(int n, const int *__restrict__ rp, const int *__restrict__ cj,
+                               const double *__restrict__ v, double *__restrict__ d)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n)
+      for (int k = rp[i]; k < rp[i + 1]; k++) d[(size_t)i * n + cj[k]] = v[k];
+}
+void csr_to_dense(const DCsr &A, double *dense)
+{
+   int n = A.nrows;
+   if (!n) return;
+   HDA_HIP(hipMemsetAsync(dense, 0, sizeof(double) * (size_t)n * n, STREAM));
+   k_csr_to_dense<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), dense);
+}
+
+// Gauss-Jordan on [a | I] by one workgroup, no pivoting (hypre_gselim does none either);
+// result written transposed (column-major inverse) for k_dense_apply.
+__global__ __launch_bounds__(1024) void k_dense_invert(int n, double *a, double *inv, double *invT)
+{
+   const int t = threadIdx.x, nt = blockDim.x;
+   for (int q = t; q < n * n; q += nt) inv[q] = ((q / n) == (q % n)) ? 1.0 : 0.0;
+   __syncthreads();
+   for (int k = 0; k < n; k++)
+   {
+      const double piv  = a[(size_t)k * n + k];
+      const double ipiv = (piv != 0.0) ? 1.0 / piv : 0.0;
+      __syncthreads();
+      for (int j = t; j < n; j += nt)
+      {
+         a[(size_t)k * n + j] *= ipiv;
+         inv[(size_t)k * n + j] *= ipiv;
+      }
+      __syncthreads();
+      for (int q = t; q < n * n; q += nt)
+      {
+         const int i = q / n, j = q % n;
+         if (i == k) continue;
+         const double f = a[(size_t)i * n + k];
+         if (f != 0.0 && j != k)
+         {
+            a[(size_t)i * n + j] -= f * a[(size_t)k * n + j];
+         }
+      }
+      for (int q = t; q < n * n; q += nt)
+      {
+         const int i = q / n, j = q % n;
+         if (i == k) continue;
+         const double f = a[(size_t)i * n + k];
+         if (f != 0.0) inv[(size_t)i * n + j] -= f * inv[(size_t)k * n + j];
+      }
+      __syncthreads();
+      for (int i = t; i < n; i += nt)
+         if (i != k) a[(size_t)i * n + k] = 0.0;
+      __syncthreads();
+   }
+   for (int q = t; q < n * n; q += nt) invT[(size_t)(q % n) * n + (q / n)] = inv[q];
+}
+void dense_invert(int n, double *a, double *invT)
+{
+   if (!n) return;
+   DArray<double> tmp((size_t)n * n);
+   k_dense_invert<<<1, 1024, 0, STREAM>>>(n, a, tmp.data(), invT);
+}
+
+// -------------------------------------------------------------------- scan
+
+template <class T>
+__global__ __launch_bounds__(256) void k_scan_blocksum(long n, const int *__restrict__ in, T *__restrict__ bsum)
+{
+   const long base = (long)blockIdx.x * 1024;
+   T          s    = 0;
+   for (int q = 0; q < 4; q++)
+   {
+      long i = base + threadIdx.x * 4 + q;
+      if (i < n) s += in[i];
+   }
+   // integer block sum
+   __shared__ T sm[256];
+   sm[threadIdx.x] = s;
+   __syncthreads();
+   for (int o = 128; o > 0; o >>= 1)
+   {
+      if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) bsum[blockIdx.x] = sm[0];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_scan_apply(long n, const int *__restrict__ in,
+                                                    const T *__restrict__ bofs, T *__restrict__ out)
+{
+   const long base = (long)blockIdx.x * 1024;
+   T          v[4], s = 0;
+   for (int q = 0; q < 4; q++)
+   {
+      long i = base + threadIdx.x * 4 + q;
+      v[q]   = (i < n) ? (T)in[i] : (T)0;
+      s += v[q];
+   }
+   __shared__ T sm[256];
+   sm[threadIdx.x] = s;
+   __syncthreads();
+   // Hillis-Steele inclusive scan over 256 thread sums
+   for (int o = 1; o < 256; o <<= 1)
+   {
+      T add = (threadIdx.x >= o) ? sm[threadIdx.x - o] : (T)0;
+      __syncthreads();
+      sm[threadIdx.x] += add;
+      __syncthreads();
+   }
+   T run = bofs[blockIdx.x] + sm[threadIdx.x] - s;
+   for (int q = 0; q < 4; q++)
+   {
+      long i = base + threadIdx.x * 4 + q;
+      if (i < n) out[i] = run;
+      run += v[q];
+      if (i == n - 1) out[n] = run;
+   }
+}
+
+// serial scan of a short array by one thread (top of the recursion)
+template <class T>
+__global__ void k_scan_serial(long n, const T *__restrict__ in, T *__restrict__ out)
+{
+   T run = 0;
+   for (long i = 0; i < n; i++)
+   {
+      T v    = in[i];
+      out[i] = run;
+      run += v;
+   }
+   out[n] = run;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_scan_blocksum_T(long n, const T *__restrict__ in, T *__restrict__ bsum)
+{
+   const long base = (long)blockIdx.x * 1024;
+   T          s    = 0;
+   for (int q = 0; q < 4; q++)
+   {
+      long i = base + threadIdx.x * 4 + q;
+      if (i < n) s += in[i];
+   }
+   __shared__ T sm[256];
+   sm[threadIdx.x] = s;
+   __syncthreads();
+   for (int o = 128; o > 0; o >>= 1)
+   {
+      if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) bsum[blockIdx.x] = sm[0];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_scan_apply_T(long n, const T *__restrict__ in,
+                                                      const T *__restrict__ bofs, T *__restrict__ out)
+{
+   const long base = (long)blockIdx.x * 1024;
+   T          v[4], s = 0;
+   for (int q = 0; q < 4; q++)
+   {
+      long i = base + threadIdx.x * 4 + q;
+      v[q]   = (i < n) ? in[i] : (T)0;
+      s += v[q];
+   }
+   __shared__ T sm[256];
+   sm[threadIdx.x] = s;
+   __syncthreads();
+   for (int o = 1; o < 256; o <<= 1)
+   {
+      T add = (threadIdx.x >= o) ? sm[threadIdx.x - o] : (T)0;
+      __syncthreads();
+      sm[threadIdx.x] += add;
+      __syncthreads();
+   }
+   T run = bofs[blockIdx.x] + sm[threadIdx.x] - s;
+   for (int q = 0; q < 4; q++)
+   {
+      long i = base + threadIdx.x * 4 + q;
+      if (i < n) out[i] = run;
+      run += v[q];
+      if (i == n - 1) out[n] = run;
+   }
+}
+
+// exclusive scan of block sums (recursive); in/out type T
+template <class T>
+static void scan_T(long n, const T *in, T *out)
+{
+   if (n <= 4096)
+   {
+      k_scan_serial<T><<<1, 1, 0, STREAM>>>(n, in, out);
+      return;
+   }
+   long      nb = (n + 1023) / 1024;
+   DArray<T> bsum((size_t)nb), bofs((size_t)nb + 1);
+   k_scan_blocksum_T<T><<<(int)nb, 256, 0, STREAM>>>(n, in, bsum.data());
+   scan_T<T>(nb, bsum.data(), bofs.data());
+   k_scan_apply_T<T><<<(int)nb, 256, 0, STREAM>>>(n, in, bofs.data(), out);
+}
+
+template <class T>
+static void scan_from_int(long n, const int *in, T *out)
+{
+   if (n == 0)
+   {
+      HDA_HIP(hipMemsetAsync(out, 0, sizeof(T), STREAM));
+      return;
+   }
+   long      nb = (n + 1023) / 1024;
+   DArray<T> bsum((size_t)nb), bofs((size_t)nb + 1);
+   k_scan_blocksum<T><<<(int)nb, 256, 0, STREAM>>>(n, in, bsum.data());
+   scan_T<T>(nb, bsum.data(), bofs.data());
+   k_scan_apply<T><<<(int)nb, 256, 0, STREAM>>>(n, in, bofs.data(), out);
+}
+
+void exclusive_scan(int n, const int *in, int *out, int *total_out_dev)
+{
+   scan_from_int<int>(n, in, out);
+   if (total_out_dev)
+      HDA_HIP(hipMemcpyAsync(total_out_dev, out + n, sizeof(int), hipMemcpyDeviceToDevice, STREAM));
+}
+void exclusive_scan64(long n, const int *in, long long *out) { scan_from_int<long long>(n, in, out); }
+
+// ------------------------------------------------------------- row utilities
+
+// hypre_ParCSRComputeL1Norms: option 1 = sum_j |a_ij| (sign of a_ii), option 4 = a_ii on
+// a single rank.  One thread per row, ascending k: bit-identical to the oracle.
+__global__ __launch_bounds__(256) void k_l1(int n, const int *__restrict__ rp, const int *__restrict__ cj,
+                                            const double *__restrict__ v, int option, double *__restrict__ l1)
+{
+   int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   double s = 0.0, d = 0.0;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+   {
+      s += fabs(v[k]);
+      if (cj[k] == i) d = v[k];
+   }
+   l1[i] = (option == 1) ? ((d < 0.0) ? -s : s) : d;
+}
+void l1_row_norms(const DCsr &A, int option, double *l1)
+{
+   if (A.nrows) k_l1<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
+}
+void extract_diag(const DCsr &A, double *d) { l1_row_norms(A, 4, d); }
+
+__global__ __launch_bounds__(256) void k_dinv(int n, const double *__restrict__ d, double w, double *__restrict__ o)
+{
+   int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) o[i] = (d[i] != 0.0) ? w / d[i] : 0.0;
+}
+void make_dinv(int n, const double *d, double weight, double *dinv)
+{
+   if (n) k_dinv<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, d, weight, dinv);
+}
+
+__global__ __launch_bounds__(256) void k_sort_rows(int n, const int *__restrict__ rp, int *cj, double *v)
+{
+   int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   const int s = rp[i], e = rp[i + 1];
+   for (int a = s + 1; a < e; a++)
+   {
+      int    c  = cj[a];
+      double x  = v[a];
+      int    bq = a - 1;
+      while (bq >= s && cj[bq] > c)
+      {
+         cj[bq + 1] = cj[bq];
+         v[bq + 1]  = v[bq];
+         bq--;
+      }
+      cj[bq + 1] = c;
+      v[bq + 1]  = x;
+   }
+}
+void sort_rows(DCsr &A)
+{
+   if (A.nrows) k_sort_rows<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data());
+}
+
+__global__ __launch_bounds__(256) void k_count_cols(int nnz, const int *__restrict__ cj, int *cnt)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256) atomicAdd(&cnt[cj[k]], 1);
+}
+__global__ __launch_bounds__(256) void k_transpose_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                        const double *__restrict__ v, int *cursor,
+                                                        int *__restrict__ tj, double *__restrict__ tv)
+{
+   int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+   {
+      int q = atomicAdd(&cursor[cj[k]], 1);
+      tj[q] = i;
+      tv[q] = v[k];
+   }
+}
+// T = A^T.  Atomic scatter then per-row sort => deterministic, rows ascending.
+void transpose(const DCsr &A, DCsr &T)
+{
+   T.nrows = A.ncols;
+   T.ncols = A.nrows;
+   T.nnz   = A.nnz;
+   T.rowptr.alloc((size_t)T.nrows + 1);
+   T.col.alloc((size_t)std::max(T.nnz, 1));
+   T.val.alloc((size_t)std::max(T.nnz, 1));
+   DArray<int> cnt((size_t)T.nrows + 1);
+   cnt.zero();
+   if (A.nnz) k_count_cols<<<ew_grid(A.nnz), 256, 0, STREAM>>>(A.nnz, A.col.data(), cnt.data());
+   exclusive_scan(T.nrows, cnt.data(), T.rowptr.data(), nullptr);
+   cnt.copy_from(T.rowptr); // cursor
+   if (A.nrows)
+      k_transpose_fill<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data(),
+                                                                 cnt.data(), T.col.data(), T.val.data());
+   sort_rows(T);
+}
+
+// ------------------------------------------------------ 7-pt generator
+
+struct LapGeom {
+   int       n[3];     // global grid
+   int       ln[3];    // local block dims
+   long long st[3];    // local block starts (global coords)
+   long long ilower;   // first global row of this block
+   int       P[3], pc[3];
+   long long ps[3][9]; // partition starts per dim (P <= 8 per dim)
+   double    c[3];
+};
+
+__device__ inline long long lap_gidx(const LapGeom &g, long long x, long long y, long long z)
+{
+   // owner block of (x,y,z), then laplacian.c:504-520 numbering
+   int b[3];
+   long long q[3] = {x, y, z};
+   for (int d = 0; d < 3; d++)
+   {
+      int bb = 0;
+      while (bb + 1 < g.P[d] && q[d] >= g.ps[d][bb + 1]) bb++;
+      b[d] = bb;
+   }
+   long long lx = g.ps[0][b[0] + 1] - g.ps[0][b[0]];
+   long long ly = g.ps[1][b[1] + 1] - g.ps[1][b[1]];
+   return g.ps[0][b[0]] * g.n[1] * g.n[2] + g.ps[1][b[1]] * g.n[2] * lx + g.ps[2][b[2]] * lx * ly +
+          ((z - g.ps[2][b[2]]) * ly + (y - g.ps[1][b[1]])) * lx + (x - g.ps[0][b[0]]);
+}
+
+__global__ __launch_bounds__(256) void k_lap7_count(LapGeom g, int local_n, int *cnt)
+{
+   int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= local_n) return;
+   long long x = g.st[0] + i % g.ln[0], y = g.st[1] + (i / g.ln[0]) % g.ln[1], z = g.st[2] + i / (g.ln[0] * g.ln[1]);
+   cnt[i] = 1 + (x > 0) + (x < g.n[0] - 1) + (y > 0) + (y < g.n[1] - 1) + (z > 0) + (z < g.n[2] - 1);
+}
+__global__ __launch_bounds__(256) void k_lap7_fill(LapGeom g, int local_n, const int *__restrict__ rp,
+                                                   long long *__restrict__ cols, double *__restrict__ vals,
+                                                   double *__restrict__ rhs)
+{
+   int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= local_n) return;
+   long long x = g.st[0] + i % g.ln[0], y = g.st[1] + (i / g.ln[0]) % g.ln[1], z = g.st[2] + i / (g.ln[0] * g.ln[1]);
+   int       q = rp[i];
+   cols[q]     = g.ilower + i;
+   vals[q++]   = 2.0 * (g.c[0] + g.c[1] + g.c[2]);
+   if (z > 0) { cols[q] = lap_gidx(g, x, y, z - 1); vals[q++] = -g.c[2]; }
+   if (y > 0) { cols[q] = lap_gidx(g, x, y - 1, z); vals[q++] = -g.c[1]; }
+   if (x > 0) { cols[q] = lap_gidx(g, x - 1, y, z); vals[q++] = -g.c[0]; }
+   if (x < g.n[0] - 1) { cols[q] = lap_gidx(g, x + 1, y, z); vals[q++] = -g.c[0]; }
+   if (y < g.n[1] - 1) { cols[q] = lap_gidx(g, x, y + 1, z); vals[q++] = -g.c[1]; }
+   if (z < g.n[2] - 1) { cols[q] = lap_gidx(g, x, y, z + 1); vals[q++] = -g.c[2]; }
+   rhs[i] = (y == 0) ? 1.0 : 0.0;
+}
+
+void lap7_generate(const int n[3], const int P[3], const int pc[3], const double c[3], int rowptr_out[],
+                   long long cols_out[], double vals_out[], double rhs_out[], int local_n)
+{
+   LapGeom g;
+   for (int d = 0; d < 3; d++)
+   {
+      HDA_REQUIRE(P[d] >= 1 && P[d] <= 8, "lap7: at most 8 blocks per dimension");
+      g.n[d] = n[d]; g.P[d] = P[d]; g.pc[d] = pc[d]; g.c[d] = c[d];
+      int size = n[d] / P[d], rest = n[d] - size * P[d];
+      for (int j = 0; j <= P[d]; j++) g.ps[d][j] = (long long)size * j + (j < rest ? j : rest);
+      g.st[d] = g.ps[d][pc[d]];
+      g.ln[d] = (int)(g.ps[d][pc[d] + 1] - g.ps[d][pc[d]]);
+   }
+   long long lx = g.ln[0], ly = g.ln[1];
+   g.ilower = g.ps[0][pc[0]] * n[1] * n[2] + g.ps[1][pc[1]] * n[2] * lx + g.ps[2][pc[2]] * lx * ly;
+   HDA_REQUIRE((long long)g.ln[0] * g.ln[1] * g.ln[2] == local_n, "lap7: local size mismatch");
+   DArray<int> cnt((size_t)local_n + 1);
+   k_lap7_count<<<ceil_div(local_n, 256), 256, 0, STREAM>>>(g, local_n, cnt.data());
+   exclusive_scan(local_n, cnt.data(), rowptr_out, nullptr);
+   k_lap7_fill<<<ceil_div(local_n, 256), 256, 0, STREAM>>>(g, local_n, rowptr_out, cols_out, vals_out, rhs_out);
+}
+
+} // namespace hda

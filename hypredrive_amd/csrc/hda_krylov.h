@@ -1,0 +1,43 @@
+// hda_krylov.h -- device-resident Krylov solvers (PCG, GMRES) over a local CSR block.
+// Parameter contracts: PCG_args src/internal/pcg.c:15-25, GMRES_args src/internal/gmres.c:16-27.
+#pragma once
+
+#include "hda_amg.h"
+
+#include <functional>
+
+namespace hda {
+
+struct KrylovParams {
+   int    max_iter    = 100;
+   double rtol        = 1.0e-6;
+   double atol        = 0.0;
+   int    two_norm    = 1;
+   int    print_level = 0;
+   int    krylov_dim  = 30; // GMRES
+   int    min_iter    = 0;  // GMRES
+   int    skip_real_res_check = 0;
+};
+
+struct KrylovResult {
+   int                 iters     = 0;
+   bool                converged = false;
+   double              final_rel = 0.0; // recurrence ||r||/||b|| (HYPRE_*GetFinalRelativeResidualNorm)
+   std::vector<double> hist;            // ||r_k||_2, k = 0..iters
+};
+
+// Preconditioner seam = what hypre's Krylov expects of a preconditioner
+// (HYPRE_Int (*)(void*, void*, void*, void*), src/internal/solver.c:27,94-97):
+// z = M^-1 r starting from z = 0; if dot_slot >= 0 the callee must also leave block
+// partials of <r, z> in that slot (lets the V-cycle's last sweep fuse PCG's <r, z>).
+using PrecondFn = std::function<void(const double *r, double *z, int dot_slot)>;
+
+// hypre_PCGSolve (reached from solver_ops[SOLVER_PCG].solve, src/internal/solver.c:211)
+KrylovResult pcg(const DCsr &A, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
+// hypre_GMRESSolve (solver_ops[SOLVER_GMRES], src/internal/solver.c:217-228)
+KrylovResult gmres(const DCsr &A, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
+
+// algorithmic HBM bytes of one PCG iteration excluding the preconditioner
+double pcg_iteration_bytes(const DCsr &A);
+
+} // namespace hda

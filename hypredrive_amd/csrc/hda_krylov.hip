@@ -1,0 +1,222 @@
+// hda_krylov.hip -- PCG and GMRES with all vectors and recurrence scalars resident in HBM.
+// The host only sees one 8-byte residual norm per iteration, copied asynchronously while
+// the next V-cycle is already enqueued (hypre applies the preconditioner BEFORE testing
+// convergence too -- SURVEY App. A.1 -- so the iteration count is unchanged).
+#include "hda_krylov.h"
+
+#include <cmath>
+
+namespace hda {
+
+double pcg_iteration_bytes(const DCsr &A)
+{
+   const double n = A.nrows;
+   // SpMV + fused <s,p> (reads p again: 8n) ; x,r update + <r,r> : 48n ; p = z + beta p : 24n
+   return (12.0 * A.nnz + 4.0 * (n + 1) + 8.0 * A.ncols + 8.0 * n) + 8.0 * n + 48.0 * n + 24.0 * n;
+}
+
+KrylovResult pcg(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
+{
+   Context     &ctx = Context::get();
+   const int    n   = A.nrows;
+   KrylovResult res;
+   DArray<double> r((size_t)std::max(n, 1)), p((size_t)std::max(A.ncols, 1)), s((size_t)std::max(n, 1));
+   if (A.ncols > n) p.zero(); // ghost tail of the search direction
+
+   auto precond = [&](const double *rr, double *zz, int slot) {
+      if (M) M(rr, zz, slot);
+      else
+      {
+         copy(n, rr, zz);
+         if (slot >= 0) dot(n, rr, zz, slot);
+      }
+   };
+
+   // bi_prod = <b,b> (two_norm) or <C b, b>
+   double bi_prod;
+   if (kp.two_norm)
+   {
+      dot(n, b, b, 0);
+      finalize(0, S_BB);
+   }
+   else
+   {
+      precond(b, p.data(), 0);
+      finalize(0, S_BB);
+   }
+   bi_prod = read_scalar(S_BB);
+   if (bi_prod == 0.0)
+   {
+      copy(n, b, x); // hypre: zero rhs => x = b = 0
+      ctx.sync();
+      res.hist.push_back(0.0);
+      return res;
+   }
+   double eps = kp.rtol * kp.rtol;
+   {
+      const double a2 = kp.atol * kp.atol / bi_prod;
+      if (a2 > eps) eps = a2;
+   }
+   // r = b - A x ; p = C r ; gamma = <r,p>
+   residual(A, x, b, r.data());
+   precond(r.data(), p.data(), 2);
+   finalize(2, S_GAMMA0);
+   dot(n, r.data(), r.data(), 1);
+   finalize(1, S_RR);
+   read_scalars_async(S_GAMMA0, 4); // gamma0, gamma1, sp, rr
+   HDA_HIP(hipEventSynchronize(ctx.ev));
+   double i_prod = kp.two_norm ? ctx.host_scalars[S_RR] : ctx.host_scalars[S_GAMMA0];
+   res.hist.push_back(std::sqrt(std::fabs(i_prod)));
+   int it = 0;
+   while (it + 1 <= kp.max_iter)
+   {
+      it++;
+      const int go = S_GAMMA0 + ((it - 1) & 1), gn = S_GAMMA0 + (it & 1);
+      spmv_dot(A, p.data(), s.data(), p.data(), 0);
+      finalize(0, S_SP);
+      cg_update(n, go, p.data(), s.data(), x, r.data(), 1);
+      finalize(1, S_RR);
+      read_scalars_async(S_GAMMA0, 4);
+      precond(r.data(), s.data(), 2);
+      finalize(2, gn);
+      cg_direction(n, go, gn, s.data(), p.data());
+      HDA_HIP(hipEventSynchronize(ctx.ev));
+      const double sp = ctx.host_scalars[S_SP];
+      if (sp == 0.0 || !std::isfinite(sp))
+      {
+         it--; // hypre: <s,p> == 0 is a breakdown, the update was not meaningful
+         break;
+      }
+      i_prod = kp.two_norm ? ctx.host_scalars[S_RR] : read_scalar(gn);
+      res.hist.push_back(std::sqrt(std::fabs(i_prod)));
+      if (kp.print_level >= 2)
+         printf("%5d    %e    %f    %e\n", it, res.hist.back(),
+                res.hist[res.hist.size() - 2] > 0 ? res.hist.back() / res.hist[res.hist.size() - 2] : 0.0,
+                std::sqrt(i_prod / bi_prod));
+      if (i_prod / bi_prod < eps)
+      {
+         res.converged = true;
+         break;
+      }
+   }
+   ctx.sync();
+   res.iters     = it;
+   res.final_rel = std::sqrt(std::fabs(i_prod) / bi_prod);
+   return res;
+}
+
+KrylovResult gmres(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
+{
+   Context     &ctx = Context::get();
+   const int    n = A.nrows, k = std::max(kp.krylov_dim, 1);
+   KrylovResult res;
+   HDA_REQUIRE(S_GMRES + k + 2 <= Context::kNumScalars, "krylov_dim too large for the scalar block");
+   const size_t vlen = (size_t)std::max(A.ncols, 1);
+   std::vector<DArray<double>> V((size_t)k + 1);
+   for (auto &v : V) v.alloc((size_t)std::max(n, 1));
+   DArray<double> w(vlen), r(vlen);
+   if (A.ncols > n) { w.zero(); r.zero(); }
+   std::vector<double> H((size_t)(k + 1) * k, 0.0), cs((size_t)k), sn((size_t)k), rs((size_t)k + 1);
+
+   auto precond = [&](const double *rr, double *zz) {
+      if (M) M(rr, zz, -1);
+      else copy(n, rr, zz);
+   };
+   auto norm2 = [&](const double *v) {
+      dot(n, v, v, 0);
+      finalize(0, S_TMP);
+      return std::sqrt(read_scalar(S_TMP));
+   };
+   const double b_norm = norm2(b);
+   residual(A, x, b, V[0].data());
+   double r_norm         = norm2(V[0].data());
+   const double den_norm = (b_norm > 0.0) ? b_norm : r_norm;
+   double       epsilon  = std::max(kp.atol, kp.rtol * den_norm);
+   res.hist.push_back(r_norm);
+   int iter = 0;
+   if (r_norm == 0.0)
+   {
+      res.converged = true;
+      return res;
+   }
+   while (iter < kp.max_iter)
+   {
+      rs[0] = r_norm;
+      if (r_norm <= epsilon && iter >= kp.min_iter && iter > 0)
+      {
+         residual(A, x, b, r.data());
+         r_norm = norm2(r.data());
+         if (r_norm <= epsilon) { res.converged = true; break; }
+         copy(n, r.data(), V[0].data());
+         rs[0] = r_norm;
+      }
+      scale(n, 1.0 / r_norm, V[0].data());
+      int i = 0;
+      while (i < k && iter < kp.max_iter)
+      {
+         i++;
+         iter++;
+         precond(V[i - 1].data(), r.data());
+         spmv(A, 1.0, r.data(), 0.0, nullptr, V[i].data());
+         // modified Gram-Schmidt with the coefficients kept on the device
+         for (int j = 0; j < i; j++)
+         {
+            dot(n, V[j].data(), V[i].data(), 0);
+            finalize(0, S_GMRES + j);
+            axpy_dev(n, S_GMRES + j, -1.0, V[j].data(), V[i].data());
+         }
+         dot(n, V[i].data(), V[i].data(), 0);
+         finalize(0, S_GMRES + i);
+         scale_inv_sqrt_dev(n, S_GMRES + i, V[i].data());
+         read_scalars_async(S_GMRES, i + 1);
+         HDA_HIP(hipEventSynchronize(ctx.ev));
+         for (int j = 0; j < i; j++) H[(size_t)j * k + (i - 1)] = ctx.host_scalars[S_GMRES + j];
+         H[(size_t)i * k + (i - 1)] = std::sqrt(ctx.host_scalars[S_GMRES + i]);
+         for (int j = 1; j < i; j++)
+         {
+            const double hv                  = H[(size_t)(j - 1) * k + (i - 1)];
+            H[(size_t)(j - 1) * k + (i - 1)] = cs[j - 1] * hv + sn[j - 1] * H[(size_t)j * k + (i - 1)];
+            H[(size_t)j * k + (i - 1)]       = -sn[j - 1] * hv + cs[j - 1] * H[(size_t)j * k + (i - 1)];
+         }
+         const double hh = H[(size_t)(i - 1) * k + (i - 1)], hn = H[(size_t)i * k + (i - 1)];
+         double       gm = std::sqrt(hh * hh + hn * hn);
+         if (gm == 0.0) gm = 1.0e-16;
+         cs[i - 1] = hh / gm;
+         sn[i - 1] = hn / gm;
+         rs[i]     = -sn[i - 1] * rs[i - 1];
+         rs[i - 1] = cs[i - 1] * rs[i - 1];
+         H[(size_t)(i - 1) * k + (i - 1)] = cs[i - 1] * hh + sn[i - 1] * hn;
+         r_norm                           = std::fabs(rs[i]);
+         res.hist.push_back(r_norm);
+         if (kp.print_level >= 2) printf("%5d    %e    %e\n", iter, r_norm, r_norm / den_norm);
+         if (r_norm <= epsilon && iter >= kp.min_iter) break;
+      }
+      rs[i - 1] = rs[i - 1] / H[(size_t)(i - 1) * k + (i - 1)];
+      for (int q = i - 2; q >= 0; q--)
+      {
+         double tt = rs[q];
+         for (int j = q + 1; j < i; j++) tt -= H[(size_t)q * k + j] * rs[j];
+         rs[q] = tt / H[(size_t)q * k + q];
+      }
+      copy(n, V[i - 1].data(), w.data());
+      scale(n, rs[i - 1], w.data());
+      for (int j = i - 2; j >= 0; j--) axpy(n, rs[j], V[j].data(), w.data());
+      precond(w.data(), r.data());
+      axpy(n, 1.0, r.data(), x);
+      residual(A, x, b, V[0].data());
+      const double true_norm = norm2(V[0].data());
+      if (r_norm <= epsilon)
+      {
+         r_norm = true_norm;
+         if (kp.skip_real_res_check || true_norm <= epsilon) { res.converged = true; break; }
+      }
+      else
+         r_norm = true_norm;
+   }
+   ctx.sync();
+   res.iters     = iter;
+   res.final_rel = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
+   return res;
+}
+
+} // namespace hda

@@ -1,0 +1,135 @@
+/*
+ * hypredrv_amd.h -- kernel-level C ABI of the MI355X solve path (libhypredrv_amd.so).
+ *
+ * This is the seam the parity tests drive: one entry point per hot-path operation, plain
+ * pointers and sizes, host buffers in / host buffers out (the library stages them through
+ * HBM).  Each entry names the hypre function it stands in for and the place the reference
+ * reaches it (paths relative to the hypredrive tree).  The reference-facing boundary --
+ * the HYPREDRV_ functions and the HYPRE_IJ / HYPRE_ParCSR / HYPRE_BoomerAMG subset -- is declared in
+ * HYPREDRV.h / HYPRE*.h next to this file and is implemented on top of these.
+ *
+ * All functions return 0 on success; on failure a non-zero code is returned and
+ * hda_last_error() describes it.  Nothing here falls back to the CPU: without a HIP device
+ * every compute entry fails with HDA_ERR_NO_DEVICE.
+ */
+#ifndef HYPREDRV_AMD_H
+#define HYPREDRV_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDA_OK 0
+#define HDA_ERR_NO_DEVICE 1
+#define HDA_ERR_RUNTIME 2
+#define HDA_ERR_ARG 3
+
+typedef struct hda_csr_s *hda_csr_t; /* CSR block resident in HBM (int32 idx, fp64) */
+typedef struct hda_amg_s *hda_amg_t; /* AMG hierarchy resident in HBM */
+
+/* AMG_args contract: include/internal/amg.h:108-123, defaults src/internal/amg.c:120-238
+ * (HYPRE_USING_GPU branch). Same field order as the oracle's orc_amg_params. */
+typedef struct {
+   int      coarsen_type, interp_type, pmax;
+   double   trunc_factor, strong_th, max_row_sum;
+   int      max_coarse_size, min_coarse_size, max_levels;
+   int      relax_down, relax_up, relax_coarse;
+   int      sweeps_down, sweeps_up, sweeps_coarse;
+   double   relax_weight, outer_weight;
+   uint64_t seed;
+} hda_amg_params;
+
+/* PCG_args src/internal/pcg.c:15-25 / GMRES_args src/internal/gmres.c:16-27 */
+typedef struct {
+   int    max_iter;
+   double rtol, atol;
+   int    two_norm, krylov_dim;
+} hda_krylov_params;
+
+const char *hda_last_error(void);
+int         hda_device_count(void);           /* 0 when no HIP device is visible */
+int         hda_device_name(char *buf, int len);
+int         hda_device_sync(void);
+
+void hda_amg_default_params(hda_amg_params *p);           /* amg.c:120-238, GPU branch */
+void hda_krylov_default_params(hda_krylov_params *p, int gmres);
+
+/* ---- matrices -------------------------------------------------------------------- */
+/* HYPRE_IJMatrixSetValues + Assemble for a local block (src/internal/linsys.c:1190-1405):
+ * copies, converts to int32, column-sorts rows. */
+int hda_csr_create(int nrows, int ncols, const int64_t *rowptr, const int64_t *cols,
+                   const double *vals, hda_csr_t *out);
+int hda_csr_destroy(hda_csr_t A);
+int hda_csr_dims(hda_csr_t A, int *nrows, int *ncols, int *nnz);
+int hda_csr_download(hda_csr_t A, int *rowptr, int *col, double *val);
+/* 7-pt Laplacian of examples/src/C_laplacian/laplacian.c:719-921 generated in HBM for the
+ * block (pc) of a P[0] x P[1] x P[2] partition; columns of other blocks are dropped when
+ * keep_offproc == 0 (single-rank tests) -- rhs gets 1 on the global y = 0 plane. */
+int hda_lap7_create(const int n[3], const int P[3], const int pc[3], const double c[3],
+                    hda_csr_t *A, double *rhs_host /* may be NULL */);
+
+/* ---- K1 / K2 / K9 ------------------------------------------------------------------ */
+/* HYPRE_ParCSRMatrixMatvec (src/internal/linsys.c:3031): y = alpha*A*x + beta*y */
+int hda_spmv(hda_csr_t A, double alpha, const double *x, double beta, double *y);
+/* hypre_BoomerAMGRelax (types 0, 7, 18): `sweeps` sweeps of x += w*(b - A x)/d in place */
+int hda_relax(hda_csr_t A, int relax_type, double weight, int sweeps, const double *b, double *x);
+/* hypre_ParVectorInnerProd (src/internal/linsys.c:2875) */
+int hda_dot(int n, const double *x, const double *y, double *result);
+/* hypre_ParCSRComputeL1Norms option 1 / 4 */
+int hda_l1_norms(hda_csr_t A, int option, double *l1);
+
+/* ---- K4 / K5 / K6 ------------------------------------------------------------------ */
+/* hypre_BoomerAMGCreateS */
+int hda_strength(hda_csr_t A, double theta, double max_row_sum, unsigned char *smask);
+/* hypre_BoomerAMGCoarsenPMIS (coarsen type 8) */
+int hda_pmis(hda_csr_t A, const unsigned char *smask, uint64_t seed, int level,
+             int64_t row_offset, int *cf);
+/* hypre_BoomerAMGBuildExtPIInterp + hypre_BoomerAMGInterpTruncation */
+int hda_interp_extpi(hda_csr_t A, const unsigned char *smask, const int *cf, int pmax,
+                     double trunc_factor, hda_csr_t *P);
+/* hypre_BoomerAMGBuildCoarseOperator (P^T A P) */
+int hda_rap(hda_csr_t A, hda_csr_t P, hda_csr_t *Ac);
+int hda_transpose(hda_csr_t A, hda_csr_t *T);
+int hda_spgemm(hda_csr_t X, hda_csr_t Y, hda_csr_t *C);
+
+/* ---- hierarchy + V-cycle ----------------------------------------------------------- */
+/* HYPRE_BoomerAMGCreate/Setup (src/internal/precon.c:107) */
+int hda_amg_create(const hda_amg_params *p, hda_csr_t A, hda_amg_t *out);
+int hda_amg_destroy(hda_amg_t h);
+int hda_amg_num_levels(hda_amg_t h);
+/* which: 0 = A_l, 1 = P_l, 2 = R_l; returns a borrowed handle (do not destroy) */
+int hda_amg_level_matrix(hda_amg_t h, int level, int which, hda_csr_t *out);
+int hda_amg_level_cf(hda_amg_t h, int level, int *cf);
+int hda_amg_complexities(hda_amg_t h, double *grid, double *op);
+double hda_amg_vcycle_bytes(hda_amg_t h);
+/* HYPRE_BoomerAMGSolve as preconditioner (src/internal/precon.c:108): x = V-cycle(b) from 0 */
+int hda_amg_vcycle(hda_amg_t h, const double *b, double *x);
+
+/* ---- Krylov ------------------------------------------------------------------------ */
+/* HYPRE_ParCSRPCGSolve / HYPRE_ParCSRGMRESSolve (src/internal/solver.c:211,222). amg may be
+ * NULL (no preconditioner). hist needs max_iter+1 doubles (may be NULL). x in/out. */
+int hda_pcg(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
+            double *hist, int *iters, int *converged, double *final_rel);
+int hda_gmres(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
+              double *hist, int *iters, int *converged, double *final_rel);
+
+/* ---- measurement (bench.py) -------------------------------------------------------- */
+/* Times `reps` launches of one kernel with HIP events on the library's stream, vectors
+ * resident in HBM.  kind: 0 SpMV, 1 l1-Jacobi sweep, 2 residual, 3 V-cycle (needs amg).
+ * Returns average milliseconds per launch and the algorithmic bytes per launch. */
+int hda_time_kernel(int kind, hda_csr_t A, hda_amg_t amg, int reps, double *avg_ms, double *bytes);
+/* Device-resident AMG-PCG solve of A x = b with x0 = 0 (b on device from hda_lap7_create's
+ * generator when b == NULL): returns "prec"/"solve" phase times measured like the
+ * reference's Stats timers (src/internal/solver.c:288-302,668-683). */
+int hda_solve_timed(hda_csr_t A, const hda_amg_params *ap, const hda_krylov_params *kp,
+                    const double *b_host, int solver /*0 pcg,1 gmres*/, double *setup_ms,
+                    double *solve_ms, int *iters, double *final_rel, double *r0_norm,
+                    double *true_rel, double *bytes_per_iter, double *op_complexity,
+                    int *num_levels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

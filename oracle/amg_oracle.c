@@ -740,9 +740,18 @@ pent_qsort_abs(pent *v, int n)
                t = v[last]; v[last] = v[i]; v[i] = t;
             }
          t = v[left]; v[left] = v[last]; v[last] = t;
-         /* recurse (left, last-1) first, then (last+1, right): push the right part */
-         if (sp + 2 <= 128) { stack[sp++] = last + 1; stack[sp++] = right; }
-         right = last - 1;
+         /* the two sub-ranges are disjoint, so processing order does not change the
+          * result: loop on the smaller one, push the larger (stack depth <= log2 n) */
+         if (last - left < right - last)
+         {
+            stack[sp++] = last + 1; stack[sp++] = right;
+            right = last - 1;
+         }
+         else
+         {
+            stack[sp++] = left; stack[sp++] = last - 1;
+            left = last + 1;
+         }
       }
    }
 }

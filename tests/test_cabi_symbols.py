@@ -1,0 +1,67 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads, exports every symbol
+the headers declare, and refuses to compute without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hda_[a-z0-9_]+|HYPREDRV_[A-Za-z0-9_]+|HYPRE_[A-Za-z0-9]+)\s*\(", txt)))
+
+
+def test_kernel_abi_exports_every_declared_symbol():
+    import hypredrive_amd as h
+    L = h.load()
+    names = [n for n in _declared("hypredrv_amd.h") if n.startswith("hda_")]
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/hypredrv_amd.h but not exported"
+    assert sorted(names) == sorted(h._lib.SYMBOLS)
+
+
+def test_param_struct_layout_matches_oracle(orc):
+    """hda_amg_params and the oracle's orc_amg_params share one layout + the GPU defaults
+    of src/internal/amg.c:120-238."""
+    import hypredrive_amd as h
+    hp = h.AmgParams.default()
+    op = orc.amg_params(True)
+    for (name, _t) in h.AmgParams._fields_:
+        assert getattr(hp, name) == getattr(op, name), name
+    assert C.sizeof(h.AmgParams) == C.sizeof(orc.AmgParams)
+    assert (hp.coarsen_type, hp.relax_down, hp.relax_up, hp.relax_coarse) == (8, 18, 18, 9)
+    assert (hp.pmax, hp.strong_th, hp.max_row_sum, hp.max_coarse_size, hp.max_levels) == (4, 0.25, 0.9, 64, 25)
+    kp = h.KrylovParams.default(False)
+    assert (kp.max_iter, kp.rtol, kp.two_norm) == (100, 1e-6, 1)
+    kg = h.KrylovParams.default(True)
+    assert (kg.max_iter, kg.krylov_dim) == (300, 30)
+
+
+def test_no_silent_cpu_fallback():
+    import hypredrive_amd as h
+    if h.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(h.LibraryError, match="no HIP device"):
+        h.lap7(4, 4, 4)
+    with pytest.raises(h.LibraryError, match="no HIP device"):
+        h.Csr.from_arrays(1, 1, [0, 1], [0], [1.0])
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under hypredrive_amd/ or include/ may
+    reference it."""
+    bad = []
+    for base in ("hypredrive_amd", "include"):
+        for dp, _dn, fn in os.walk(os.path.join(ROOT, base)):
+            for f in fn:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".c", "Makefile")):
+                    t = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"oracle_ffi|amg_oracle|liboracle|from oracle|import oracle", t):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,322 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same inputs.
+
+Bars: bit-exact for integer/index work (strength mask, C/F splitting, sparsity patterns) and
+for the setup arithmetic that is defined in a fixed order (interpolation weights, RAP, l1
+norms); 1e-13 relative for wave-parallel fp64 reductions (SpMV, smoothers, V-cycle);
+identical iteration counts and residual histories to 1e-10 relative for AMG-PCG on an
+identical hierarchy.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+RTOL_REDUCE = 1e-13
+
+
+@pytest.fixture(scope="module")
+def hd():
+    import hypredrive_amd as h
+    assert h.device_count() >= 1, "no HIP device"
+    return h
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def rand_spd(n, density, seed):
+    rng = np.random.default_rng(seed)
+    M = sp.random(n, n, density=density, random_state=rng, format="csr")
+    M = M + M.T
+    M = M + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel() + 1.0)
+    return M.tocsr()
+
+
+def both(orc, hd, M):
+    return orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+
+
+# ---------------------------------------------------------------- K1 SpMV
+
+@pytest.mark.parametrize("shape", [(10, 10, 10), (33, 17, 9), (64, 64, 64)])
+def test_spmv_lap7(orc, hd, shape):
+    Ao, _ = orc.lap7(*shape)
+    Ah = hd.lap7(*shape)
+    n = Ao.nrows
+    # generator parity: identical CSR
+    rp, cj, v = Ah.download()
+    assert np.array_equal(rp, Ao.rowptr) and np.array_equal(cj, Ao.col) and np.array_equal(v, Ao.val)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(n)
+    y0 = rng.standard_normal(n)
+    assert rel(Ah.spmv(x), orc.spmv(Ao, x)) < RTOL_REDUCE
+    assert rel(Ah.spmv(x, -1.0, 1.0, y0), orc.spmv(Ao, x, -1.0, 1.0, y0)) < RTOL_REDUCE
+
+
+@pytest.mark.parametrize("n,density", [(1, 1.0), (7, 0.5), (300, 0.02), (2000, 0.01), (500, 0.2)])
+def test_spmv_irregular(orc, hd, n, density):
+    """ragged rows, empty rows, all lane-group widths"""
+    M = rand_spd(n, density, 3)
+    M = M.tolil()
+    if n > 5:
+        M[3, :] = 0  # an empty row
+    M = M.tocsr()
+    M.eliminate_zeros()
+    Ao, Ah = both(orc, hd, M)
+    x = np.random.default_rng(2).standard_normal(n)
+    assert rel(Ah.spmv(x), M @ x) < 1e-12
+    assert rel(Ah.spmv(x), orc.spmv(Ao, x)) < 1e-12
+
+
+def test_spmv_rectangular(orc, hd):
+    rng = np.random.default_rng(5)
+    M = sp.random(123, 57, density=0.1, random_state=rng, format="csr")
+    Ao, Ah = both(orc, hd, M)
+    x = rng.standard_normal(57)
+    assert rel(Ah.spmv(x), M @ x) < 1e-12
+
+
+def test_dot_and_norm_anchor(hd, pins):
+    """tests/test_linsys.c:4126-4155: L2 norm of [1,-2,3] = sqrt(14)."""
+    import ctypes as C
+    v = np.array([1.0, -2.0, 3.0])
+    out = C.c_double()
+    L = hd.load()
+    assert L.hda_dot(3, v.ctypes.data_as(C.POINTER(C.c_double)), v.ctypes.data_as(C.POINTER(C.c_double)),
+                     C.byref(out)) == 0
+    assert np.sqrt(out.value) == pytest.approx(pins["unit"]["norms_of_1_m2_3"]["L2"], rel=1e-15)
+    big = np.random.default_rng(0).standard_normal(1_000_003)
+    assert L.hda_dot(big.size, big.ctypes.data_as(C.POINTER(C.c_double)),
+                     big.ctypes.data_as(C.POINTER(C.c_double)), C.byref(out)) == 0
+    assert out.value == pytest.approx(float(big @ big), rel=1e-13)
+
+
+# ------------------------------------------------------------- K2 smoothers
+
+@pytest.mark.parametrize("rtype,weight", [(18, 1.0), (0, 0.8), (7, 1.0)])
+def test_relax_jacobi(orc, hd, rtype, weight):
+    Ao, b = orc.lap7(12, 11, 10, b_mode=1)
+    Ah = hd.lap7(12, 11, 10)
+    x0 = np.random.default_rng(4).standard_normal(Ao.nrows)
+    l1 = orc.l1_norms(Ao, 1 if rtype == 18 else 4)
+    xo = x0
+    for _ in range(3):
+        xo = orc.relax(Ao, l1, rtype, weight, b, xo)
+    xh = Ah.relax(b, x0, rtype, weight, sweeps=3)
+    assert rel(xh, xo) < RTOL_REDUCE
+    assert np.array_equal(Ah.l1_norms(1), orc.l1_norms(Ao, 1))  # bit-exact
+
+
+# ----------------------------------------------------------- K4 strength/PMIS
+
+@pytest.mark.parametrize("shape", [(10, 10, 10), (20, 7, 13), (40, 40, 40)])
+def test_strength_and_pmis_bit_exact(orc, hd, shape):
+    Ao, _ = orc.lap7(*shape)
+    Ah = hd.lap7(*shape)
+    so = orc.strength(Ao)
+    sh = Ah.strength()
+    assert np.array_equal(so, sh)
+    co = orc.pmis(Ao, so, seed=2747, level=0)
+    ch = Ah.pmis(sh, seed=2747, level=0)
+    assert np.array_equal(co, ch)
+    assert set(np.unique(ch)) <= {1, -1, -3}
+
+
+def test_strength_pmis_irregular(orc, hd):
+    M = rand_spd(1500, 0.004, 9)
+    M = (-abs(M) + 2 * sp.diags(M.diagonal())).tocsr()  # M-matrix-like: negative off-diagonals
+    Ao, Ah = both(orc, hd, M)
+    for theta, mrs in ((0.25, 0.9), (0.5, 1.0), (0.1, 0.5)):
+        so, sh = orc.strength(Ao, theta, mrs), Ah.strength(theta, mrs)
+        assert np.array_equal(so, sh)
+        assert np.array_equal(orc.pmis(Ao, so, 7, 2, 100), Ah.pmis(sh, 7, 2, 100))
+
+
+# ------------------------------------------------------- K5 interpolation, K6 RAP
+
+@pytest.mark.parametrize("shape,pmax,tf", [((10, 10, 10), 4, 0.0), ((16, 9, 12), 4, 0.0),
+                                           ((12, 12, 12), 0, 0.0), ((12, 12, 12), 3, 0.2)])
+def test_interp_and_rap_bit_exact(orc, hd, shape, pmax, tf):
+    Ao, _ = orc.lap7(*shape)
+    Ah = hd.lap7(*shape)
+    sm = orc.strength(Ao)
+    cf = orc.pmis(Ao, sm)
+    Po = orc.interp_extpi(Ao, sm, cf, pmax, tf)
+    Ph = Ah.interp_extpi(sm, cf, pmax, tf)
+    rp, cj, v = Ph.download()
+    assert np.array_equal(rp, Po.rowptr) and np.array_equal(cj, Po.col)
+    assert np.array_equal(v, Po.val), np.abs(v - Po.val).max()
+    Aco = orc.rap(Ao, Po)
+    Ach = Ah.rap(Ph)
+    rp, cj, v = Ach.download()
+    assert np.array_equal(rp, Aco.rowptr) and np.array_equal(cj, Aco.col)
+    assert np.array_equal(v, Aco.val), np.abs(v - Aco.val).max()
+
+
+def test_spgemm_and_transpose_vs_scipy(orc, hd, monkeypatch):
+    rng = np.random.default_rng(11)
+    X = sp.random(400, 300, density=0.03, random_state=rng, format="csr")
+    Y = sp.random(300, 250, density=0.05, random_state=rng, format="csr")
+    Xh, Yh = hd.Csr.from_scipy(X), hd.Csr.from_scipy(Y)
+    Ch = Xh.matmul(Yh).to_scipy()
+    ref = (X @ Y).tocsr()
+    assert abs(Ch - ref).max() < 1e-13
+    assert (Ch != 0).nnz >= ref.nnz  # structural entries kept
+    T = Xh.transpose().to_scipy()
+    assert abs(T - X.T.tocsr()).max() == 0.0
+    rp, cj, _ = Xh.transpose().download()
+    for i in range(300):
+        assert np.all(np.diff(cj[rp[i]:rp[i + 1]]) > 0)
+
+
+# ------------------------------------------------------------------ hierarchy
+
+@pytest.mark.parametrize("shape", [(10, 10, 10), (24, 24, 24), (48, 32, 20)])
+def test_hierarchy_identical_to_oracle(orc, hd, shape):
+    Ao, b = orc.lap7(*shape)
+    Ah = hd.lap7(*shape)
+    ho = orc.Amg(Ao, orc.amg_params(True))
+    hh = hd.Amg(Ah)
+    assert hh.num_levels == ho.num_levels
+    for l in range(ho.num_levels):
+        rp, cj, v = hh.level_matrix(l, 0).download()
+        Al = ho.level_A(l)
+        assert np.array_equal(rp, Al.rowptr) and np.array_equal(cj, Al.col), f"A pattern level {l}"
+        assert np.array_equal(v, Al.val), f"A values level {l}: {np.abs(v - Al.val).max()}"
+        if l < ho.num_levels - 1:
+            assert np.array_equal(hh.level_cf(l), ho.level_cf(l)), f"C/F level {l}"
+            rp, cj, v = hh.level_matrix(l, 1).download()
+            Pl = ho.level_P(l)
+            assert np.array_equal(rp, Pl.rowptr) and np.array_equal(cj, Pl.col)
+            assert np.array_equal(v, Pl.val)
+    g, o = hh.complexities
+    assert g == pytest.approx(ho.grid_complexity, rel=1e-15)
+    assert o == pytest.approx(ho.operator_complexity, rel=1e-15)
+    # one V-cycle from zero
+    r = np.random.default_rng(3).standard_normal(Ao.nrows)
+    assert rel(hh.vcycle(r), ho.vcycle(r)) < 1e-12
+
+
+def test_pin_ex2_hierarchy_on_gpu(hd, pins):
+    """examples/refOutput/ex2.txt:124-139 against the HIP-built hierarchy."""
+    import scipy.sparse as sp  # noqa
+    A = hd.lap7(10, 10, 10)
+    amg = hd.Amg(A)
+    ref = pins["ex2"]
+    assert amg.num_levels == len(ref["operators"])
+    for l, op in enumerate(ref["operators"]):
+        n, _, nnz = amg.level_matrix(l, 0).dims
+        assert n == pytest.approx(op["rows"], rel=0.12)
+        assert nnz == pytest.approx(op["nnz"], rel=0.15)
+    g, o = amg.complexities
+    assert g == pytest.approx(ref["grid_complexity"], rel=0.02)
+    assert o == pytest.approx(ref["operator_complexity"], rel=0.05)
+
+
+# --------------------------------------------------------------------- Krylov
+
+@pytest.mark.parametrize("shape,bmode", [((10, 10, 10), 1), ((10, 10, 10), 0), ((32, 32, 32), 0),
+                                          ((40, 25, 17), 1)])
+def test_amg_pcg_matches_oracle(orc, hd, shape, bmode):
+    Ao, b = orc.lap7(*shape, b_mode=bmode)
+    Ah = hd.lap7(*shape)
+    ro = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True)))
+    rh = hd.pcg(Ah, b, hd.Amg(Ah))
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
+    assert rel(rh["x"], ro["x"]) < 1e-10
+    S = Ao.to_scipy()
+    assert np.linalg.norm(b - S @ rh["x"]) / np.linalg.norm(b) < 1e-6
+
+
+def test_unpreconditioned_cg_matches_oracle(orc, hd):
+    Ao, b = orc.lap7(9, 9, 9, b_mode=1)
+    Ah = hd.lap7(9, 9, 9)
+    kp_o = orc.krylov_params(False, max_iter=200, rtol=1e-10)
+    kp_h = hd.KrylovParams.default(False, max_iter=200, rtol=1e-10)
+    ro = orc.pcg(Ao, b, None, kp_o)
+    rh = hd.pcg(Ah, b, None, kp_h)
+    assert rh["iters"] == ro["iters"] and rh["converged"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-8)
+
+
+def test_gmres_amg_matches_oracle(orc, hd):
+    Ao, b = orc.lap7(16, 16, 16, b_mode=0)
+    Ah = hd.lap7(16, 16, 16)
+    ro = orc.gmres(Ao, b, orc.Amg(Ao, orc.amg_params(True)))
+    rh = hd.gmres(Ah, b, hd.Amg(Ah))
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-8)
+    assert rel(rh["x"], ro["x"]) < 1e-8
+
+
+def test_edge_cases(orc, hd, pins):
+    # 1x1 system 3x = 6 (tests/test_setmatrix_from_csr.c:397-417)
+    u = pins["unit"]["one_by_one"]
+    A = hd.Csr.from_arrays(1, 1, [0, 1], [0], [u["a"]])
+    r = hd.pcg(A, np.array([u["b"]]), hd.Amg(A))
+    assert abs(np.linalg.norm(r["x"]) - u["x_norm"]) < u["tol"]
+    # 1-D Laplacian n = 16 (tests/test_setmatrix_from_csr.c:168-199): single level, GE
+    T = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(16, 16), format="csr")
+    A = hd.Csr.from_scipy(T)
+    amg = hd.Amg(A)
+    assert amg.num_levels == 1
+    r = hd.pcg(A, np.ones(16), amg)
+    assert r["converged"] and np.allclose(T @ r["x"], np.ones(16), atol=1e-6)
+    # zero rhs -> 0 iterations, x = 0
+    A = hd.lap7(5, 5, 5)
+    r = hd.pcg(A, np.zeros(125), None)
+    assert r["iters"] == 0 and np.all(r["x"] == 0)
+    # exact initial guess (tests/test_init_guess.c:247-270)
+    Ao, _ = orc.lap7(5, 5, 5)
+    b = Ao.to_scipy() @ np.ones(125)
+    r = hd.pcg(A, b, None, x0=np.ones(125))
+    assert r["hist"][0] < 1e-12 * np.linalg.norm(b) or r["iters"] <= 1
+
+
+def test_spgemm_batched_equals_unbatched(orc, hd):
+    """Force the row-batched SpGEMM path with a tiny hash budget (env read once per process,
+    so run in a subprocess)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, hypredrive_amd as h\n"
+        "A = h.lap7(14,14,14); sm = A.strength(); cf = A.pmis(sm); P = A.interp_extpi(sm, cf)\n"
+        "rp, cj, v = A.rap(P).download(); np.savez('/tmp/_rap_%s.npz' % __import__('os').environ.get('HDA_SPGEMM_SLOTS','d'), rp=rp, cj=cj, v=v)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for slots in ("d", "4096"):
+        env = dict(os.environ, PYTHONPATH=root)
+        if slots != "d":
+            env["HDA_SPGEMM_SLOTS"] = slots
+        else:
+            env.pop("HDA_SPGEMM_SLOTS", None)
+        subprocess.check_call([sys.executable, "-c", code], env=env, cwd=root)
+    a, b = np.load("/tmp/_rap_d.npz"), np.load("/tmp/_rap_4096.npz")
+    for k in ("rp", "cj", "v"):
+        assert np.array_equal(a[k], b[k])
+
+
+# ------------------------------------------------- full-size property checks
+
+def test_full_size_spmv_properties(hd):
+    """256^3 (BASELINE config 2): linearity and A*1 = row sums, no oracle needed."""
+    n = 256
+    A = hd.lap7(n, n, n, want_rhs=False)
+    N, _, nnz = A.dims
+    assert N == n ** 3 and nnz == 7 * N - 6 * n * n
+    ones = np.ones(N)
+    y = A.spmv(ones)
+    g = np.arange(n)
+    bx = (g == 0).astype(float) + (g == n - 1)
+    rs = (bx[None, None, :] + bx[None, :, None] + bx[:, None, None]).ravel()  # x fastest
+    assert np.array_equal(y, rs)
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal(N), rng.standard_normal(N)
+    lhs = A.spmv(2.0 * u - 3.0 * v)
+    rhs = 2.0 * A.spmv(u) - 3.0 * A.spmv(v)
+    assert rel(lhs, rhs) < 1e-13
+    # symmetry: <Au, v> == <u, Av>
+    assert abs(A.spmv(u) @ v - u @ A.spmv(v)) / abs(u @ A.spmv(v)) < 1e-12
