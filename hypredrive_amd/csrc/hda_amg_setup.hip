@@ -10,6 +10,7 @@
 #include "hda_amg.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 
 namespace hda {
@@ -163,6 +164,7 @@ static void pmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
    k_pmis_init<<<g, 256, 0, STREAM>>>(n, ns, indeg.data(), seed, level, row_offset, meas.data(), cf, counter.data());
    int left = 0;
    counter.download(&left, 1);
+   HDA_TRACE("  pmis: init done, undecided=%d", left);
    int rounds = 0;
    while (left > 0)
    {
@@ -490,7 +492,9 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    DArray<long long> uofs((size_t)n + 1), hofs((size_t)n + 1);
    k_count_strongC<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, nsC.data());
    k_interp_ub<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, nsC.data(), ub.data(), hsz.data(), cmark.data());
+   HDA_TRACE("  interp: ub done");
    exclusive_scan(n, cmark.data(), cidx.data(), nullptr);
+   HDA_TRACE("  interp: scan cidx done");
    exclusive_scan64(n, ub.data(), uofs.data());
    exclusive_scan64(n, hsz.data(), hofs.data());
    long long tot_u = 0, tot_h = 0;
@@ -503,8 +507,10 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    DArray<double> lw((size_t)std::max<long long>(tot_u, 1));
    HDA_HIP(hipMemsetAsync(htab.data(), 0xFF, sizeof(int) * htab.size(), STREAM));
    DArray<int> pcnt((size_t)n + 1);
+   HDA_TRACE("  interp: build (tot_u=%lld tot_h=%lld nc=%d)", tot_u, tot_h, nc);
    k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(),
                                          hofs.data(), lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data());
+   HDA_TRACE("  interp: build done");
    P.nrows = n;
    P.ncols = nc;
    P.rowptr.alloc((size_t)n + 1);
@@ -659,6 +665,7 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
    long long H = 0;
    HDA_HIP(hipMemcpyAsync(&H, hofs.data() + n, 8, hipMemcpyDeviceToHost, STREAM));
    Context::get().sync();
+   HDA_TRACE("  spgemm: n=%d H=%lld", n, H);
    const long long budget = spgemm_slot_budget();
    // batches of rows whose tables fit the budget
    std::vector<int>       bstart{0};
@@ -715,8 +722,11 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
    if (nb == 1)
    {
       run_batch(0, true);
+      HDA_TRACE("  spgemm: numeric done");
       finish_rowptr();
+      HDA_TRACE("  spgemm: rowptr done nnz=%d", C.nnz);
       gather_batch(0);
+      HDA_TRACE("  spgemm: gather done");
    }
    else
    {
@@ -762,24 +772,48 @@ void Amg::setup(const DCsr &A)
    const int maxl        = std::max(prm.max_levels, 1);
    int       lvl         = 0;
    bool      not_finished = (A.nrows > prm.max_coarse_size) && (maxl > 1);
+   static const bool verbose = getenv("HDA_VERBOSE") != nullptr;
+   auto tick = [&]() {
+      if (verbose) Context::get().sync();
+      return std::chrono::steady_clock::now();
+   };
+   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+   };
    while (not_finished)
    {
       const DCsr &Al = level_A(lvl);
       const int   n  = Al.nrows;
       DArray<unsigned char> sm((size_t)std::max(Al.nnz, 1));
       DArray<int>           ns((size_t)n + 1), cf((size_t)n);
+      HDA_TRACE("level %d: strength (n=%d nnz=%d)", lvl, n, Al.nnz);
+      auto t0 = tick();
       strength_ns(Al, prm.strong_th, prm.max_row_sum, sm.data(), ns.data());
+      HDA_TRACE("level %d: pmis", lvl);
+      auto t1 = tick();
       pmis_core(Al, sm.data(), ns.data(), prm.seed, lvl, 0, cf.data());
+      HDA_TRACE("level %d: interp", lvl);
+      auto t2 = tick();
       DCsr P;
       amg_interp_extpi(Al, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, P);
+      auto t3 = tick();
       const int nc = P.ncols;
       if (nc == 0 || nc == n || nc < prm.min_coarse_size) break;
       AmgLevel &L = levels[lvl];
       L.cf        = std::move(cf);
       L.P         = std::move(P);
+      HDA_TRACE("level %d: transpose", lvl);
       transpose(L.P, L.R);
+      HDA_TRACE("level %d: rap", lvl);
+      auto t4 = tick();
       levels.emplace_back();
       amg_rap(Al, levels[lvl].P, levels[lvl].R, levels[lvl + 1].A);
+      auto t5 = tick();
+      if (verbose)
+         fprintf(stderr, "[hda] setup level %d: n=%d nnz=%d -> nc=%d nnzP=%d nnzAc=%d | strength %.2f pmis %.2f interp %.2f transpose %.2f rap %.2f ms\n",
+                 lvl, n, Al.nnz, nc, levels[lvl].P.nnz, levels[lvl + 1].A.nnz, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5));
+      setup_times[0] += ms(t0, t1); setup_times[1] += ms(t1, t2); setup_times[2] += ms(t2, t3);
+      setup_times[3] += ms(t3, t4); setup_times[4] += ms(t4, t5);
       lvl++;
       if (lvl >= maxl - 1 || nc <= prm.max_coarse_size) not_finished = false;
    }

@@ -65,6 +65,17 @@ struct Context {
    Context();
 };
 
+// Caching device allocator.  Everything in this library runs on ONE stream, so a block
+// released by the host can be handed to the next request immediately: any kernel that
+// still reads it was enqueued earlier on the same stream than any kernel of the new owner.
+// (hipMallocAsync/hipFreeAsync pools were tried first and deadlocked inside the runtime on
+// ROCm 7.2 / gfx950 when a freed 50 MB block was re-requested at another size.)
+void *pool_alloc(size_t bytes);
+void  pool_free(void *p);
+void  pool_trim(); // sync + return all cached blocks to the driver
+size_t pool_bytes_in_use();
+size_t pool_bytes_peak();
+
 // Stream-ordered device array.
 template <class T>
 class DArray {
@@ -86,11 +97,11 @@ class DArray {
       release();
       n_ = n;
       if (n == 0) return;
-      HDA_HIP(hipMallocAsync((void **)&p_, n * sizeof(T), Context::get().stream));
+      p_ = (T *)pool_alloc(n * sizeof(T));
    }
    void release()
    {
-      if (p_) (void)hipFreeAsync(p_, Context::get().stream);
+      if (p_) pool_free(p_);
       p_ = nullptr;
       n_ = 0;
    }
@@ -140,6 +151,23 @@ struct DCsr {
    DArray<double> val;    // nnz
    double         avg_row() const { return nrows ? (double)nnz / nrows : 0.0; }
 };
+
+// HDA_VERBOSE=1: phase trace on stderr (each trace point synchronises the stream)
+inline bool verbose()
+{
+   static const bool v = getenv("HDA_VERBOSE") != nullptr;
+   return v;
+}
+#define HDA_TRACE(...)                                 \
+   do {                                                \
+      if (::hda::verbose())                            \
+      {                                                \
+         ::hda::Context::get().sync();                 \
+         fprintf(stderr, "[hda] " __VA_ARGS__);        \
+         fprintf(stderr, "\n");                        \
+         fflush(stderr);                               \
+      }                                                \
+   } while (0)
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -8,7 +8,10 @@
 // fused into the kernel that already streams the operands.
 #include "hda_kernels.h"
 
+#include <algorithm>
 #include <cmath>
+#include <map>
+#include <unordered_map>
 
 namespace hda {
 
@@ -18,10 +21,6 @@ Context::Context()
 {
    HDA_HIP(hipGetDevice(&device));
    HDA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-   hipMemPool_t pool;
-   HDA_HIP(hipDeviceGetDefaultMemPool(&pool, device));
-   uint64_t thresh = UINT64_MAX; // keep freed blocks cached in the pool
-   HDA_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thresh));
    HDA_HIP(hipMalloc((void **)&partials, sizeof(double) * kNumSlots * kRedBlocks));
    HDA_HIP(hipMemset(partials, 0, sizeof(double) * kNumSlots * kRedBlocks));
    HDA_HIP(hipMalloc((void **)&scalars, sizeof(double) * kNumScalars));
@@ -35,6 +34,76 @@ Context &Context::get()
    static Context ctx;
    return ctx;
 }
+
+// ---------------------------------------------------------------- allocator
+
+namespace {
+struct Pool {
+   std::multimap<size_t, void *>      free_;  // size -> block
+   std::unordered_map<void *, size_t> size_;  // every block we own
+   size_t                             in_use = 0, cached = 0, peak = 0;
+} g_pool;
+constexpr size_t kAlign = 512;
+} // namespace
+
+void *pool_alloc(size_t bytes)
+{
+   if (bytes == 0) return nullptr;
+   const size_t want = (bytes + kAlign - 1) / kAlign * kAlign;
+   // best fit, but never waste more than 25 % (+64 KiB) of a cached block
+   auto it = g_pool.free_.lower_bound(want);
+   if (it != g_pool.free_.end() && it->first <= want + want / 4 + 65536)
+   {
+      void *p = it->second;
+      g_pool.cached -= it->first;
+      g_pool.in_use += it->first;
+      g_pool.free_.erase(it);
+      g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
+      return p;
+   }
+   void      *p = nullptr;
+   hipError_t e = hipMalloc(&p, want);
+   if (e != hipSuccess)
+   {
+      (void)hipGetLastError();
+      pool_trim(); // give cached blocks back and retry once
+      e = hipMalloc(&p, want);
+   }
+   if (e != hipSuccess)
+   {
+      char buf[256];
+      snprintf(buf, sizeof(buf), "device allocation of %zu bytes failed: %s (in use %zu)", want, hipGetErrorString(e), g_pool.in_use);
+      throw Error(buf);
+   }
+   g_pool.size_[p] = want;
+   g_pool.in_use += want;
+   g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
+   return p;
+}
+
+void pool_free(void *p)
+{
+   if (!p) return;
+   auto it = g_pool.size_.find(p);
+   if (it == g_pool.size_.end()) return;
+   g_pool.in_use -= it->second;
+   g_pool.cached += it->second;
+   g_pool.free_.emplace(it->second, p);
+}
+
+void pool_trim()
+{
+   (void)hipStreamSynchronize(Context::get().stream);
+   for (auto &kv : g_pool.free_)
+   {
+      g_pool.size_.erase(kv.second);
+      (void)hipFree(kv.second);
+   }
+   g_pool.free_.clear();
+   g_pool.cached = 0;
+}
+size_t pool_bytes_in_use() { return g_pool.in_use; }
+size_t pool_bytes_peak() { return g_pool.peak; }
 
 #define STREAM (Context::get().stream)
 
