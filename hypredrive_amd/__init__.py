@@ -6,4 +6,5 @@ device is missing.
 """
 from . import _lib  # noqa: F401
 from ._lib import (AmgParams, KrylovParams, Csr, Amg, load, device_count, device_name,  # noqa: F401
-                   lap7, pcg, gmres, solve_timed, time_kernel, LibraryError)
+                   lap7, pcg, gmres, solve_device, time_kernel, pcg_iteration_bytes, memory_stats,
+                   sync, LibraryError)

@@ -57,7 +57,8 @@ SYMBOLS = [
     "hda_l1_norms", "hda_strength", "hda_pmis", "hda_interp_extpi", "hda_rap", "hda_transpose",
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
     "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
-    "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_timed",
+    "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
+    "hda_pcg_iteration_bytes", "hda_memory_stats",
 ]
 
 
@@ -106,8 +107,10 @@ def load():
     for f in (L.hda_pcg, L.hda_gmres):
         f.argtypes = [vp, vp, P(KrylovParams), dp, dp, dp, ip, ip, dp]
     L.hda_time_kernel.argtypes = [C.c_int, vp, vp, C.c_int, dp, dp]
-    L.hda_solve_timed.argtypes = [vp, P(AmgParams), P(KrylovParams), dp, C.c_int, dp, dp, ip, dp, dp,
-                                  dp, dp, dp, ip]
+    L.hda_solve_device.argtypes = [vp, vp, P(KrylovParams), C.c_int, dp, C.c_int, dp, ip, dp, dp, dp, dp]
+    L.hda_pcg_iteration_bytes.argtypes = [vp]
+    L.hda_pcg_iteration_bytes.restype = C.c_double
+    L.hda_memory_stats.argtypes = [dp, dp]
     _L = L
     return L
 
@@ -323,15 +326,29 @@ def time_kernel(kind, A, amg=None, reps=20):
     return ms.value, by.value
 
 
-def solve_timed(A, ap=None, kp=None, b=None, solver=0):
-    ap = ap or AmgParams.default()
+def solve_device(A, amg=None, kp=None, b=None, solver=0, nsolves=1, profile_k1=True):
+    """nsolves device-resident solves from x0 = 0 against an existing hierarchy."""
     kp = kp or KrylovParams.default(bool(solver))
-    d = [C.c_double() for _ in range(8)]
-    it, nl = C.c_int(), C.c_int()
+    times = np.zeros(max(nsolves, 1))
+    it = C.c_int()
+    d = [C.c_double() for _ in range(4)]
     bb = None if b is None else _dp(np.ascontiguousarray(b, dtype=np.float64))
-    _check(load().hda_solve_timed(A.h, C.byref(ap), C.byref(kp), bb, solver, C.byref(d[0]), C.byref(d[1]),
-                                  C.byref(it), C.byref(d[2]), C.byref(d[3]), C.byref(d[4]), C.byref(d[5]),
-                                  C.byref(d[6]), C.byref(nl)))
-    return dict(setup_ms=d[0].value, solve_ms=d[1].value, iters=it.value, final_rel=d[2].value,
-                r0=d[3].value, true_rel=d[4].value, bytes_per_iter=d[5].value,
-                op_complexity=d[6].value, num_levels=nl.value)
+    _check(load().hda_solve_device(A.h, amg.h if amg is not None else None, C.byref(kp), solver, bb, nsolves,
+                                   _dp(times), C.byref(it), C.byref(d[0]), C.byref(d[1]), C.byref(d[2]),
+                                   C.byref(d[3]) if profile_k1 else None))
+    return dict(solve_ms=times, iters=it.value, final_rel=d[0].value, r0=d[1].value, true_rel=d[2].value,
+                k1_avg_ms=d[3].value)
+
+
+def pcg_iteration_bytes(A):
+    return load().hda_pcg_iteration_bytes(A.h)
+
+
+def memory_stats():
+    a, b = C.c_double(), C.c_double()
+    load().hda_memory_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def sync():
+    _check(load().hda_device_sync())

@@ -475,10 +475,9 @@ extern "C" int hda_time_kernel(int kind, hda_csr_t A, hda_amg_t amg, int reps, d
    HDA_CATCH
 }
 
-extern "C" int hda_solve_timed(hda_csr_t A, const hda_amg_params *ap, const hda_krylov_params *kp,
-                               const double *b_host, int solver, double *setup_ms, double *solve_ms,
-                               int *iters, double *final_rel, double *r0_norm, double *true_rel,
-                               double *bytes_per_iter, double *op_complexity, int *num_levels)
+extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, int solver,
+                                const double *b_host, int nsolves, double *solve_ms, int *iters,
+                                double *final_rel, double *r0_norm, double *true_rel, double *k1_avg_ms)
 {
    HDA_TRY
    using clk        = std::chrono::steady_clock;
@@ -493,13 +492,6 @@ extern "C" int hda_solve_timed(hda_csr_t A, const hda_amg_params *ap, const hda_
       b.copy_from(A->rhs);
    }
    x.zero();
-   ctx.sync();
-   // "prec" timer (src/internal/solver.c:288-302): AMG setup
-   auto t0 = clk::now();
-   Amg  amg(to_params(ap));
-   amg.setup(m);
-   ctx.sync();
-   auto t1 = clk::now();
    // initial residual norm, untimed (solver.c:666)
    residual(m, x.data(), b.data(), r.data());
    dot(n, r.data(), r.data(), 0);
@@ -508,26 +500,43 @@ extern "C" int hda_solve_timed(hda_csr_t A, const hda_amg_params *ap, const hda_
    dot(n, b.data(), b.data(), 0);
    finalize(0, S_TMP);
    const double bn = std::sqrt(read_scalar(S_TMP));
-   PrecondFn M = [&amg](const double *rr, double *zz, int slot) { amg.apply(rr, zz, slot); };
-   ctx.sync();
-   // "solve" timer (solver.c:668-683)
-   auto         t2  = clk::now();
-   KrylovResult res = solver ? gmres(m, M, to_kparams(kp), b.data(), x.data()) : pcg(m, M, to_kparams(kp), b.data(), x.data());
-   ctx.sync();
-   auto t3 = clk::now();
+   PrecondFn M;
+   if (amg) M = [amg](const double *rr, double *zz, int slot) { amg->amg->apply(rr, zz, slot); };
+   KrylovParams k = to_kparams(kp);
+   k.profile_k1   = (k1_avg_ms != nullptr);
+   KrylovResult res;
+   double       k1_sum = 0.0;
+   long         k1_cnt = 0;
+   for (int s = 0; s < std::max(nsolves, 1); s++)
+   {
+      x.zero(); // HYPREDRV_LinearSystemResetInitialGuess
+      ctx.sync();
+      auto t0 = clk::now();
+      res     = solver ? gmres(m, M, k, b.data(), x.data()) : pcg(m, M, k, b.data(), x.data());
+      ctx.sync();
+      auto t1 = clk::now();
+      if (solve_ms) solve_ms[s] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+      k1_sum += res.k1_ms_sum;
+      k1_cnt += res.k1_count;
+   }
    // true relative residual, untimed (solver.c:686-690)
    residual(m, x.data(), b.data(), r.data());
    dot(n, r.data(), r.data(), 0);
    finalize(0, S_TMP);
    const double rn = std::sqrt(read_scalar(S_TMP));
-   if (setup_ms) *setup_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-   if (solve_ms) *solve_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
    if (iters) *iters = res.iters;
    if (final_rel) *final_rel = res.final_rel;
    if (r0_norm) *r0_norm = r0;
    if (true_rel) *true_rel = (bn > 0.0) ? rn / bn : rn;
-   if (bytes_per_iter) *bytes_per_iter = pcg_iteration_bytes(m) + amg.vcycle_bytes();
-   if (op_complexity) *op_complexity = amg.operator_complexity();
-   if (num_levels) *num_levels = amg.num_levels();
+   if (k1_avg_ms) *k1_avg_ms = k1_cnt ? k1_sum / (double)k1_cnt : 0.0;
    HDA_CATCH
+}
+
+extern "C" double hda_pcg_iteration_bytes(hda_csr_t A) { return A ? pcg_iteration_bytes(A->get()) : 0.0; }
+
+extern "C" int hda_memory_stats(double *in_use, double *peak)
+{
+   if (in_use) *in_use = (double)pool_bytes_in_use();
+   if (peak) *peak = (double)pool_bytes_peak();
+   return HDA_OK;
 }

@@ -17,6 +17,7 @@ struct KrylovParams {
    int    krylov_dim  = 30; // GMRES
    int    min_iter    = 0;  // GMRES
    int    skip_real_res_check = 0;
+   bool   profile_k1 = false; // bracket each PCG SpMV launch with HIP events
 };
 
 struct KrylovResult {
@@ -24,6 +25,8 @@ struct KrylovResult {
    bool                converged = false;
    double              final_rel = 0.0; // recurrence ||r||/||b|| (HYPRE_*GetFinalRelativeResidualNorm)
    std::vector<double> hist;            // ||r_k||_2, k = 0..iters
+   double              k1_ms_sum = 0.0; // profile_k1: summed duration of the PCG SpMV launches
+   int                 k1_count  = 0;
 };
 
 // Preconditioner seam = what hypre's Krylov expects of a preconditioner

@@ -68,10 +68,23 @@ KrylovResult pcg(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, cons
    double i_prod = kp.two_norm ? ctx.host_scalars[S_RR] : ctx.host_scalars[S_GAMMA0];
    res.hist.push_back(std::sqrt(std::fabs(i_prod)));
    int it = 0;
+   std::vector<hipEvent_t> evs;
    while (it + 1 <= kp.max_iter)
    {
       it++;
       const int go = S_GAMMA0 + ((it - 1) & 1), gn = S_GAMMA0 + (it & 1);
+      if (kp.profile_k1)
+      {
+         hipEvent_t e0, e1;
+         HDA_HIP(hipEventCreate(&e0));
+         HDA_HIP(hipEventCreate(&e1));
+         HDA_HIP(hipEventRecord(e0, ctx.stream));
+         spmv_dot(A, p.data(), s.data(), p.data(), 0);
+         HDA_HIP(hipEventRecord(e1, ctx.stream));
+         evs.push_back(e0);
+         evs.push_back(e1);
+      }
+      else
       spmv_dot(A, p.data(), s.data(), p.data(), 0);
       finalize(0, S_SP);
       cg_update(n, go, p.data(), s.data(), x, r.data(), 1);
@@ -100,6 +113,17 @@ KrylovResult pcg(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, cons
       }
    }
    ctx.sync();
+   for (size_t e = 0; e + 1 < evs.size(); e += 2)
+   {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, evs[e], evs[e + 1]) == hipSuccess)
+      {
+         res.k1_ms_sum += ms;
+         res.k1_count++;
+      }
+      (void)hipEventDestroy(evs[e]);
+      (void)hipEventDestroy(evs[e + 1]);
+   }
    res.iters     = it;
    res.final_rel = std::sqrt(std::fabs(i_prod) / bi_prod);
    return res;

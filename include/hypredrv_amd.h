@@ -120,14 +120,20 @@ int hda_gmres(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const dou
  * resident in HBM.  kind: 0 SpMV, 1 l1-Jacobi sweep, 2 residual, 3 V-cycle (needs amg).
  * Returns average milliseconds per launch and the algorithmic bytes per launch. */
 int hda_time_kernel(int kind, hda_csr_t A, hda_amg_t amg, int reps, double *avg_ms, double *bytes);
-/* Device-resident AMG-PCG solve of A x = b with x0 = 0 (b on device from hda_lap7_create's
- * generator when b == NULL): returns "prec"/"solve" phase times measured like the
- * reference's Stats timers (src/internal/solver.c:288-302,668-683). */
-int hda_solve_timed(hda_csr_t A, const hda_amg_params *ap, const hda_krylov_params *kp,
-                    const double *b_host, int solver /*0 pcg,1 gmres*/, double *setup_ms,
-                    double *solve_ms, int *iters, double *final_rel, double *r0_norm,
-                    double *true_rel, double *bytes_per_iter, double *op_complexity,
-                    int *num_levels);
+/* Device-resident Krylov solves of A x = b, x0 = 0, repeated `nsolves` times against an
+ * existing hierarchy (amg may be NULL): the reference's solve loop
+ * (examples/src/C_laplacian/laplacian.c:445-463) with the "solve" phase timed like its Stats
+ * timer (src/internal/solver.c:668-683: initial and final true-residual evaluations are
+ * outside the timed region).  b == NULL uses the generator's rhs stored with A.
+ * solve_ms gets nsolves entries.  k1_avg_ms = average duration of the level-0 PCG SpMV
+ * kernel measured with HIP events inside those solves (0 for GMRES). */
+int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, int solver,
+                     const double *b_host, int nsolves, double *solve_ms, int *iters,
+                     double *final_rel, double *r0_norm, double *true_rel, double *k1_avg_ms);
+/* algorithmic HBM bytes of one PCG iteration without the preconditioner */
+double hda_pcg_iteration_bytes(hda_csr_t A);
+/* allocator statistics (bytes) */
+int hda_memory_stats(double *in_use, double *peak);
 
 #ifdef __cplusplus
 }
