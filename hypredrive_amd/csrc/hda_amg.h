@@ -3,6 +3,7 @@
 // hypredrv_AMGCreate (src/internal/amg.c:864-1035) to the HYPRE_BoomerAMGSet* setters.
 #pragma once
 
+#include "hda_dist.h"
 #include "hda_kernels.h"
 
 #include <memory>
@@ -37,6 +38,10 @@ struct AmgLevel {
    DArray<int>    cf;
    DArray<double> dinv_down, dinv_up; // relax_weight / l1 (or / a_ii), per cycle direction
    DArray<double> f, u, u2, t;
+   // row-partitioned runs: ghost refresh plans for the inputs of A_l, P_l, R_l and the
+   // length every level-l work vector needs ([owned | largest ghost tail])
+   HaloPlan hA, hP, hR;
+   size_t   ext = 0;
 };
 
 class Amg {
@@ -44,6 +49,16 @@ class Amg {
    explicit Amg(const AmgParams &p) : prm(p) {}
    // hypre_BoomerAMGSetup (src/internal/precon.c:107): A is borrowed for level 0.
    void setup(const DCsr &A);
+   // Row-partitioned variant: Aloc is this rank's block ([owned | ghost] columns, ghosts =
+   // ghost_gids ascending), hA0 its halo plan, part0 the row starts of all ranks.  Round-1
+   // scheme: the operator is gathered and the hierarchy is built redundantly on every rank
+   // (bit-identical to the 1-GPU hierarchy because PMIS weights hash the global row id),
+   // then every level is cut into local blocks + halo plans for a distributed V-cycle.
+   void setup_dist(const DCsr &Aloc, const HaloPlan &hA0, const std::vector<long long> &part0,
+                   const std::vector<long long> &ghost_gids0);
+   // length of the level-0 vectors handed to apply()/solve() (x must have this room)
+   size_t vec_len0() const { return levels.empty() ? 0 : levels[0].ext; }
+   bool   distributed() const { return dist; }
    // HYPRE_BoomerAMGSolve as a preconditioner (precon.c:108): one V(nu1,nu2) from x = 0.
    // dot_slot >= 0: also emit block partials of <b, x> (fuses PCG's <r, z>).
    void apply(const double *b, double *x, int dot_slot = -1);
@@ -64,7 +79,17 @@ class Amg {
    void cycle(const double *b, double *x, bool zero_guess, int dot_slot);
    void relax(int l, int type, const double *dinv, const double *b, double *&cur, double *&alt,
               bool zero_guess, int dot_slot);
+   void build_hierarchy(const DCsr &A);
+   void coarse_solve(const double *f, double *u);
+   const HaloPlan &level_hA(int l) const { return (l == 0 && hA0) ? *hA0 : levels[l].hA; }
    const DCsr           *A0 = nullptr;
+   const HaloPlan       *hA0 = nullptr;
+   bool                  dist = false;
+   long long             coarse_lo = 0; // first coarsest row owned by this rank
+   int                   coarse_nloc = 0;
+   double                stats_nnz[32] = {0}, stats_rows[32] = {0}; // global sizes per level
+   int                   stats_levels = 0;
+   DArray<double>        cbuf_f, cbuf_u;
    std::vector<AmgLevel> levels;
    DArray<double>        coarse_invT; // dense inverse of the coarsest operator (column-major)
    int                   coarse_n = 0;

@@ -759,7 +759,7 @@ static void build_dinv(const DCsr &A, int relax_type, double weight, DArray<doub
    make_dinv(A.nrows, d.data(), weight, dinv.data());
 }
 
-void Amg::setup(const DCsr &A)
+void Amg::build_hierarchy(const DCsr &A)
 {
    HDA_REQUIRE(prm.coarsen_type == 8, "device AMG setup implements PMIS coarsening (type 8) only");
    HDA_REQUIRE(prm.interp_type == 6, "device AMG setup implements extended+i interpolation (type 6) only");
@@ -818,16 +818,18 @@ void Amg::setup(const DCsr &A)
       if (lvl >= maxl - 1 || nc <= prm.max_coarse_size) not_finished = false;
    }
    const int L = (int)levels.size();
+   stats_levels = std::min(L, 32);
+   for (int l = 0; l < stats_levels; l++)
+   {
+      stats_nnz[l]  = (double)level_A(l).nnz;
+      stats_rows[l] = (double)level_A(l).nrows;
+   }
    for (int l = 0; l < L; l++)
    {
       const DCsr &Al = level_A(l);
       AmgLevel   &lv = levels[l];
       build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down);
       build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up);
-      const size_t n = (size_t)Al.nrows;
-      if (l > 0) { lv.f.alloc(n); lv.u.alloc(n); }
-      lv.u2.alloc(n);
-      lv.t.alloc(n);
    }
    // coarsest operator: dense inverse when relax_coarse is Gaussian elimination (type 9)
    const DCsr &Ac = level_A(L - 1);
@@ -840,20 +842,129 @@ void Amg::setup(const DCsr &A)
       csr_to_dense(Ac, dense.data());
       dense_invert(coarse_n, dense.data(), coarse_invT.data());
    }
+   coarse_lo   = 0;
+   coarse_nloc = coarse_n;
+}
+
+void Amg::setup(const DCsr &A)
+{
+   dist = false;
+   hA0  = nullptr;
+   build_hierarchy(A);
+   const int L = (int)levels.size();
+   for (int l = 0; l < L; l++)
+   {
+      AmgLevel    &lv = levels[l];
+      const size_t n  = (size_t)level_A(l).nrows;
+      lv.ext          = std::max(n, (size_t)level_A(l).ncols);
+      if (l > 0) { lv.f.alloc(lv.ext); lv.u.alloc(lv.ext); }
+      lv.u2.alloc(lv.ext);
+      lv.t.alloc(lv.ext);
+   }
    Context::get().sync();
+}
+
+__global__ __launch_bounds__(256) void k_cmark(int n, const int *__restrict__ cf, int *__restrict__ m)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) m[i] = (cf[i] == 1);
+}
+
+void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<long long> &part0,
+                     const std::vector<long long> &ghost_gids0)
+{
+   Comm &cm = Comm::world();
+   HDA_TRACE("setup_dist: gathering the operator on %d ranks (%s)", cm.size, cm.name());
+   DCsr G0;
+   gather_global(Aloc, part0, ghost_gids0, G0);
+   build_hierarchy(G0); // replicated, identical on every rank
+   dist        = true;
+   const int L = (int)levels.size();
+   // row starts of every rank on every level: coarse rows follow their fine C points
+   std::vector<std::vector<long long>> parts((size_t)L);
+   parts[0] = part0;
+   for (int l = 0; l + 1 < L; l++)
+   {
+      const int   n = level_A(l).nrows;
+      DArray<int> m((size_t)n + 1), cidx((size_t)n + 1);
+      k_cmark<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, levels[l].cf.data(), m.data());
+      exclusive_scan(n, m.data(), cidx.data(), nullptr);
+      std::vector<int> h = cidx.to_host();
+      parts[(size_t)l + 1].resize(parts[(size_t)l].size());
+      for (size_t r = 0; r < parts[(size_t)l].size(); r++) parts[(size_t)l + 1][r] = h[(size_t)parts[(size_t)l][r]];
+   }
+   const int r = cm.rank;
+   std::vector<size_t> tail((size_t)L, 0); // largest ghost tail of any plan that feeds level-l vectors
+   for (int l = 0; l < L; l++)
+   {
+      AmgLevel       &lv = levels[l];
+      const long long lo = parts[(size_t)l][(size_t)r], hi = parts[(size_t)l][(size_t)r + 1];
+      std::vector<long long> gg;
+      if (l > 0)
+      {
+         DCsr loc;
+         localize(lv.A, lo, hi, lo, hi, loc, gg);
+         lv.A  = std::move(loc);
+         lv.hA = make_halo_plan((int)(hi - lo), parts[(size_t)l], gg);
+         tail[(size_t)l] = std::max(tail[(size_t)l], gg.size());
+      }
+      else
+         tail[0] = std::max(tail[0], ghost_gids0.size());
+      // smoother diagonals: keep the owned slice
+      for (DArray<double> *d : {&lv.dinv_down, &lv.dinv_up})
+      {
+         DArray<double> sl((size_t)std::max<long long>(hi - lo, 1));
+         if (hi > lo) HDA_HIP(hipMemcpyAsync(sl.data(), d->data() + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, STREAM));
+         *d = std::move(sl);
+      }
+      if (l + 1 < L)
+      {
+         const long long clo = parts[(size_t)l + 1][(size_t)r], chi = parts[(size_t)l + 1][(size_t)r + 1];
+         DCsr            pl, rl;
+         localize(lv.P, lo, hi, clo, chi, pl, gg);
+         lv.P  = std::move(pl);
+         lv.hP = make_halo_plan((int)(chi - clo), parts[(size_t)l + 1], gg);
+         tail[(size_t)l + 1] = std::max(tail[(size_t)l + 1], gg.size());
+         localize(lv.R, clo, chi, lo, hi, rl, gg);
+         lv.R  = std::move(rl);
+         lv.hR = make_halo_plan((int)(hi - lo), parts[(size_t)l], gg);
+         tail[(size_t)l] = std::max(tail[(size_t)l], gg.size());
+         lv.cf.release();
+      }
+   }
+   A0        = &Aloc;
+   this->hA0 = &hA0_;
+   for (int l = 0; l < L; l++)
+   {
+      AmgLevel    &lv = levels[l];
+      const size_t n  = (size_t)(parts[(size_t)l][(size_t)r + 1] - parts[(size_t)l][(size_t)r]);
+      lv.ext          = std::max<size_t>(n + tail[(size_t)l], 1);
+      if (l > 0) { lv.f.alloc(lv.ext); lv.u.alloc(lv.ext); }
+      lv.u2.alloc(lv.ext);
+      lv.t.alloc(lv.ext);
+   }
+   coarse_lo   = parts[(size_t)L - 1][(size_t)r];
+   coarse_nloc = (int)(parts[(size_t)L - 1][(size_t)r + 1] - coarse_lo);
+   if (coarse_dense)
+   {
+      cbuf_f.alloc((size_t)std::max(coarse_n, 1));
+      cbuf_u.alloc((size_t)std::max(coarse_n, 1));
+   }
+   Context::get().sync();
+   HDA_TRACE("setup_dist: rank %d owns %d of %d level-0 rows, %d levels", r, Aloc.nrows, (int)part0.back(), L);
 }
 
 double Amg::operator_complexity() const
 {
    double s = 0.0;
-   for (int l = 0; l < num_levels(); l++) s += (double)level_A(l).nnz;
-   return s / (double)std::max(level_A(0).nnz, 1);
+   for (int l = 0; l < stats_levels; l++) s += stats_nnz[l];
+   return s / std::max(stats_nnz[0], 1.0);
 }
 double Amg::grid_complexity() const
 {
    double s = 0.0;
-   for (int l = 0; l < num_levels(); l++) s += (double)level_A(l).nrows;
-   return s / (double)std::max(level_A(0).nrows, 1);
+   for (int l = 0; l < stats_levels; l++) s += stats_rows[l];
+   return s / std::max(stats_rows[0], 1.0);
 }
 
 static double spmv_bytes(const DCsr &M) { return 12.0 * M.nnz + 4.0 * (M.nrows + 1) + 8.0 * M.ncols + 8.0 * M.nrows; }
@@ -893,27 +1004,49 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
    }
    else
    {
+      halo_exchange(level_hA(l), cur);
       jacobi(A, dinv, b, cur, alt, dot_slot);
       std::swap(cur, alt);
    }
 }
 
+__global__ __launch_bounds__(256) void k_place(int n, const double *__restrict__ src, double *__restrict__ dst)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) dst[i] = src[i];
+}
+
+// coarsest level: x = A_c^{-1} f with the dense inverse.  Row-partitioned: the owned pieces
+// of f are summed into a replicated vector (C3 of SURVEY 2.4 as one small all-reduce) and
+// every rank applies the inverse redundantly.
+void Amg::coarse_solve(const double *f, double *u)
+{
+   if (!dist || Comm::world().size == 1)
+   {
+      dense_apply(coarse_n, coarse_invT.data(), f, u);
+      return;
+   }
+   cbuf_f.zero();
+   if (coarse_nloc) k_place<<<ceil_div(coarse_nloc, 256), 256, 0, STREAM>>>(coarse_nloc, f, cbuf_f.data() + coarse_lo);
+   Comm::world().allreduce_sum_dev(cbuf_f.data(), coarse_n);
+   dense_apply(coarse_n, coarse_invT.data(), cbuf_f.data(), cbuf_u.data());
+   if (coarse_nloc) k_place<<<ceil_div(coarse_nloc, 256), 256, 0, STREAM>>>(coarse_nloc, cbuf_u.data() + coarse_lo, u);
+}
+
 void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
 {
-   const int L = num_levels();
+   const int L  = num_levels();
    const int n0 = level_A(0).nrows;
    if (L == 1)
    {
-      if (coarse_dense) dense_apply(coarse_n, coarse_invT.data(), b, x);
+      if (coarse_dense) coarse_solve(b, x);
       else
       {
          double *cur = x, *alt = levels[0].u2.data();
          bool    zg  = zero_guess;
-         int     swaps = 0;
-         for (int s = 0; s < prm.sweeps_coarse; s++)
+         for (int s = 0; s < std::max(prm.sweeps_coarse, 1); s++)
          {
-            if (!zg) swaps++;
-            relax(0, prm.relax_coarse == 9 ? 18 : prm.relax_coarse, levels[0].dinv_down.data(), b, cur, alt, zg, -1);
+            relax(0, 18, levels[0].dinv_down.data(), b, cur, alt, zg, -1);
             zg = false;
          }
          if (cur != x) copy(n0, cur, x);
@@ -939,21 +1072,19 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
          relax(l, prm.relax_down, lv.dinv_down.data(), f, cur, alt, zg, -1);
          zg = false;
       }
+      halo_exchange(level_hA(l), cur);
       residual(A, cur, f, lv.t.data());
       AmgLevel &nx = levels[l + 1];
+      halo_exchange(lv.hR, lv.t.data());
       spmv(lv.R, 1.0, lv.t.data(), 0.0, nullptr, nx.f.data());
       sol[l] = cur;
-      // remember the spare buffer of this level in u2/x bookkeeping
-      if (l == 0) { /* alt stays paired with cur */ }
-      // descend
-      f = nx.f.data();
-      // save level-l alt in t? no: alt is recomputed on the way up
+      f      = nx.f.data();
       if (l + 1 < L - 1) { cur = nx.u.data(); alt = nx.u2.data(); }
    }
    // coarsest
    {
       AmgLevel &lc = levels[L - 1];
-      if (coarse_dense) dense_apply(coarse_n, coarse_invT.data(), lc.f.data(), lc.u.data());
+      if (coarse_dense) coarse_solve(lc.f.data(), lc.u.data());
       else
       {
          double *c2 = lc.u.data(), *a2 = lc.u2.data();
@@ -963,19 +1094,19 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
             relax(L - 1, 18, lc.dinv_down.data(), lc.f.data(), c2, a2, zg, -1);
             zg = false;
          }
-         if (c2 != lc.u.data()) copy(coarse_n, c2, lc.u.data());
+         if (c2 != lc.u.data()) copy(level_A(L - 1).nrows, c2, lc.u.data());
       }
       sol[L - 1] = lc.u.data();
    }
    for (int l = L - 2; l >= 0; l--)
    {
-      const DCsr &A  = level_A(l);
-      AmgLevel   &lv = levels[l];
-      double     *c  = sol[l];
-      double     *a;
+      AmgLevel &lv = levels[l];
+      double   *c  = sol[l];
+      double   *a;
       if (l == 0) a = (c == x) ? levels[0].u2.data() : x;
       else a = (c == lv.u.data()) ? lv.u2.data() : lv.u.data();
       const double *fl = (l == 0) ? b : lv.f.data();
+      halo_exchange(lv.hP, sol[l + 1]);
       spmv(lv.P, 1.0, sol[l + 1], 1.0, c, c);
       for (int s = 0; s < prm.sweeps_up; s++)
       {

@@ -383,7 +383,7 @@ extern "C" int hda_amg_vcycle(hda_amg_t h, const double *b, double *x)
 {
    HDA_TRY
    const int      n = h->amg->level_A(0).nrows;
-   DArray<double> db, dx((size_t)std::max(h->amg->level_A(0).ncols, 1));
+   DArray<double> db, dx(std::max<size_t>(h->amg->vec_len0(), (size_t)std::max(h->amg->level_A(0).ncols, 1)));
    db.upload(b, (size_t)n);
    h->amg->apply(db.data(), dx.data(), -1);
    dx.download(x, (size_t)n);
@@ -406,7 +406,8 @@ static int run_krylov(bool use_gmres, hda_csr_t A, hda_amg_t amg, const hda_kryl
    PrecondFn M;
    if (amg) M = [amg](const double *r, double *z, int slot) { amg->amg->apply(r, z, slot); };
    KrylovParams  k   = to_kparams(kp);
-   KrylovResult  res = use_gmres ? gmres(m, M, k, db.data(), dx.data()) : pcg(m, M, k, db.data(), dx.data());
+   LinOp         op(m, nullptr, amg ? amg->amg->vec_len0() : 0);
+   KrylovResult  res = use_gmres ? gmres(op, M, k, db.data(), dx.data()) : pcg(op, M, k, db.data(), dx.data());
    dx.download(x, (size_t)m.nrows);
    if (hist)
       for (size_t i = 0; i < res.hist.size() && i < (size_t)k.max_iter + 1; i++) hist[i] = res.hist[i];
@@ -504,6 +505,7 @@ extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_par
    if (amg) M = [amg](const double *rr, double *zz, int slot) { amg->amg->apply(rr, zz, slot); };
    KrylovParams k = to_kparams(kp);
    k.profile_k1   = (k1_avg_ms != nullptr);
+   LinOp op(m, nullptr, amg ? amg->amg->vec_len0() : 0);
    KrylovResult res;
    double       k1_sum = 0.0;
    long         k1_cnt = 0;
@@ -512,7 +514,7 @@ extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_par
       x.zero(); // HYPREDRV_LinearSystemResetInitialGuess
       ctx.sync();
       auto t0 = clk::now();
-      res     = solver ? gmres(m, M, k, b.data(), x.data()) : pcg(m, M, k, b.data(), x.data());
+      res     = solver ? gmres(op, M, k, b.data(), x.data()) : pcg(op, M, k, b.data(), x.data());
       ctx.sync();
       auto t1 = clk::now();
       if (solve_ms) solve_ms[s] = std::chrono::duration<double, std::milli>(t1 - t0).count();

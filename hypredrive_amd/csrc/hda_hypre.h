@@ -1,0 +1,74 @@
+// hda_hypre.h -- the objects behind the HYPRE_* handles declared in include/HYPRE.h.
+#pragma once
+
+#include "../../include/HYPRE.h"
+#include "hda_krylov.h"
+
+#include <memory>
+#include <string>
+
+struct hypre_IJVector_struct {
+   MPI_Comm             comm = MPI_COMM_WORLD;
+   long long            jlower = 0, jupper = -1;
+   int                  nloc   = 0;
+   bool                 initialized = false, assembled = false;
+   std::vector<double>  stage;       // host values until Assemble
+   hda::DArray<double>  d;           // owned entries (+ optional ghost room) in HBM
+   size_t               capacity = 0; // doubles available behind data()
+   double              *view = nullptr; // non-owning alias of somebody else's HBM buffer
+   std::vector<double>  host_mirror; // backing store for "get values" pointers
+   double              *data() { return view ? view : d.data(); }
+   const double        *data() const { return view ? view : d.data(); }
+   void                 ensure_device();
+};
+
+struct hypre_IJMatrix_struct {
+   MPI_Comm  comm = MPI_COMM_WORLD;
+   long long ilower = 0, iupper = -1, jlower = 0, jupper = -1;
+   int       nloc = 0;
+   bool      initialized = false, assembled = false;
+   // host staging (HYPRE_IJMatrixSetValues / AddToValues before Assemble)
+   std::vector<int>       t_row;
+   std::vector<long long> t_col;
+   std::vector<double>    t_val;
+   std::vector<char>      t_add;
+   // assembled, HBM resident
+   hda::DCsr              A;          // columns: [0,nloc) owned, >= nloc ghosts
+   std::vector<long long> ghost_gids; // ascending global ids of the ghost columns
+   std::vector<long long> part;       // row starts of every rank (size+1)
+   hda::HaloPlan          halo;
+   long long              global_rows = 0, global_nnz = 0;
+   void                   assemble();
+   // adopt a block that was built directly in HBM with global column ids (generator path)
+   void adopt_device(int nloc, int nnz, hda::DArray<int> &rowptr, hda::DArray<long long> &gcols, hda::DArray<double> &vals);
+};
+
+enum hda_solver_kind { HDA_SOLVER_PCG = 1, HDA_SOLVER_GMRES = 2, HDA_SOLVER_AMG = 3 };
+
+struct hypre_Solver_struct {
+   int                       kind = 0;
+   hda::KrylovParams         kp;
+   hda::AmgParams            ap;
+   // values of setters whose feature is not implemented (checked at Setup)
+   int                       smooth_type = 5, smooth_num_levels = 0, agg_num_levels = 0, num_functions = 1, cycle_type = 1,
+                             restriction = 0, relax_order = 0, sabs = 0, seq_threshold = 0, relax_type_all = -1;
+   HYPRE_PtrToSolverFcn      precond = nullptr, precond_setup = nullptr;
+   HYPRE_Solver              precond_solver = nullptr;
+   std::unique_ptr<hda::Amg> amg;
+   hda::KrylovResult         last;
+   int                       amg_iters = 0;
+   double                    amg_rel   = 0.0;
+};
+
+namespace hda {
+// error text of the last failed HYPRE_* call (HYPRE_GetError returns the code)
+const std::string &hypre_last_error();
+int                hypre_set_error(int code, const std::string &msg);
+// hints the Krylov loops pass to HYPRE_BoomerAMGSolve through the C callback seam
+struct PrecondHints {
+   bool zero_guess = false; // the output vector is known to be zero
+   int  dot_slot   = -1;    // fuse block partials of <b, x> into the last sweep
+   bool dot_done   = false; // set by the callee when it honoured dot_slot
+};
+PrecondHints &precond_hints();
+} // namespace hda

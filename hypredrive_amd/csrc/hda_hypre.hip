@@ -1,0 +1,870 @@
+// hda_hypre.hip -- HYPRE_* subset (include/HYPRE.h) over HBM-resident objects.
+// This is the lower seam of the drop-in boundary: the functions hypredrive's op tables
+// (src/internal/solver.c:204-253, src/internal/precon.c:106-157 in the reference) bind.
+#include "hda_hypre.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace hda;
+
+#define STREAM (Context::get().stream)
+
+namespace hda {
+static thread_local std::string g_herr;
+static thread_local int         g_hcode = 0;
+const std::string &hypre_last_error() { return g_herr; }
+int hypre_set_error(int code, const std::string &msg)
+{
+   g_hcode |= code;
+   g_herr = msg;
+   return code;
+}
+PrecondHints &precond_hints()
+{
+   static thread_local PrecondHints h;
+   return h;
+}
+} // namespace hda
+
+#define HY_TRY try {
+#define HY_CATCH                                                  \
+   }                                                              \
+   catch (const std::exception &e) { return hypre_set_error(HYPRE_ERROR_GENERIC, e.what()); } \
+   return 0;
+
+static bool have_device()
+{
+   int n = 0;
+   return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+#define HY_NEED_DEVICE \
+   if (!have_device()) return hypre_set_error(HYPRE_ERROR_GENERIC, "no HIP device visible: the MI355X solve path has no CPU fallback")
+
+// ------------------------------------------------------------------ utilities
+
+extern "C" HYPRE_Int HYPRE_Initialize(void) { return 0; }
+extern "C" HYPRE_Int HYPRE_Finalize(void) { return 0; }
+extern "C" HYPRE_Int HYPRE_SetMemoryLocation(HYPRE_MemoryLocation) { return 0; }
+extern "C" HYPRE_Int HYPRE_SetExecutionPolicy(HYPRE_ExecutionPolicy) { return 0; }
+extern "C" HYPRE_Int HYPRE_GetError(void) { return g_hcode; }
+extern "C" HYPRE_Int HYPRE_ClearAllErrors(void)
+{
+   g_hcode = 0;
+   g_herr.clear();
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_CheckError(HYPRE_Int ierr, HYPRE_Int code) { return ierr & code; }
+
+// --------------------------------------------------------------------- vectors
+
+void hypre_IJVector_struct::ensure_device()
+{
+   if (view) return;
+   if (d.size() < (size_t)std::max(nloc, 1))
+   {
+      d.alloc((size_t)std::max(nloc, 1));
+      d.zero();
+      capacity = d.size();
+   }
+}
+
+extern "C" HYPRE_Int HYPRE_IJVectorCreate(MPI_Comm comm, HYPRE_BigInt jlower, HYPRE_BigInt jupper, HYPRE_IJVector *vector)
+{
+   HY_TRY
+   auto *v   = new hypre_IJVector_struct();
+   v->comm   = comm;
+   v->jlower = jlower;
+   v->jupper = jupper;
+   v->nloc   = (int)std::max<long long>(jupper - jlower + 1, 0);
+   *vector   = v;
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJVectorDestroy(HYPRE_IJVector v)
+{
+   if (v)
+   {
+      try { if (have_device()) Context::get().sync(); } catch (...) {}
+      delete v;
+   }
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_IJVectorSetObjectType(HYPRE_IJVector, HYPRE_Int) { return 0; }
+extern "C" HYPRE_Int HYPRE_IJVectorInitialize_v2(HYPRE_IJVector v, HYPRE_MemoryLocation)
+{
+   HY_TRY
+   v->stage.assign((size_t)v->nloc, 0.0);
+   v->initialized = true;
+   v->assembled   = false;
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJVectorInitialize(HYPRE_IJVector v) { return HYPRE_IJVectorInitialize_v2(v, HYPRE_MEMORY_HOST); }
+
+static HYPRE_Int vec_set(HYPRE_IJVector v, HYPRE_Int n, const HYPRE_BigInt *idx, const HYPRE_Complex *val, bool add)
+{
+   HY_TRY
+   if (!v->initialized) HYPRE_IJVectorInitialize(v);
+   if (v->assembled && v->stage.empty())
+   { // re-open an assembled vector: pull the device values back into the stage
+      v->stage.resize((size_t)v->nloc);
+      if (v->nloc) HDA_HIP(hipMemcpy(v->stage.data(), v->data(), sizeof(double) * (size_t)v->nloc, hipMemcpyDeviceToHost));
+   }
+   for (int q = 0; q < n; q++)
+   {
+      const long long l = idx ? idx[q] - v->jlower : q;
+      if (l < 0 || l >= v->nloc) return hypre_set_error(HYPRE_ERROR_ARG, "IJVector index outside the local range");
+      if (add) v->stage[(size_t)l] += val[q];
+      else v->stage[(size_t)l] = val[q];
+   }
+   v->assembled = false;
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJVectorSetValues(HYPRE_IJVector v, HYPRE_Int n, const HYPRE_BigInt *idx, const HYPRE_Complex *val)
+{
+   return vec_set(v, n, idx, val, false);
+}
+extern "C" HYPRE_Int HYPRE_IJVectorAddToValues(HYPRE_IJVector v, HYPRE_Int n, const HYPRE_BigInt *idx, const HYPRE_Complex *val)
+{
+   return vec_set(v, n, idx, val, true);
+}
+extern "C" HYPRE_Int HYPRE_IJVectorAssemble(HYPRE_IJVector v)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   if (!v->stage.empty() || v->nloc == 0)
+   {
+      v->d.alloc((size_t)std::max(v->nloc, 1));
+      v->capacity = v->d.size();
+      if (v->nloc) v->d.upload(v->stage.data(), (size_t)v->nloc);
+      std::vector<double>().swap(v->stage);
+   }
+   v->assembled = true;
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJVectorGetValues(HYPRE_IJVector v, HYPRE_Int n, const HYPRE_BigInt *idx, HYPRE_Complex *val)
+{
+   HY_TRY
+   std::vector<double> h;
+   const double       *src;
+   if (!v->stage.empty()) src = v->stage.data();
+   else
+   {
+      h.resize((size_t)std::max(v->nloc, 1));
+      if (v->nloc) HDA_HIP(hipMemcpy(h.data(), v->data(), sizeof(double) * (size_t)v->nloc, hipMemcpyDeviceToHost));
+      src = h.data();
+   }
+   for (int q = 0; q < n; q++)
+   {
+      const long long l = idx ? idx[q] - v->jlower : q;
+      if (l < 0 || l >= v->nloc) return hypre_set_error(HYPRE_ERROR_ARG, "IJVector index outside the local range");
+      val[q] = src[l];
+   }
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJVectorGetObject(HYPRE_IJVector v, void **object)
+{
+   *object = v;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_IJVectorGetLocalRange(HYPRE_IJVector v, HYPRE_BigInt *jl, HYPRE_BigInt *ju)
+{
+   *jl = v->jlower;
+   *ju = v->jupper;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_IJVectorMigrate(HYPRE_IJVector v, HYPRE_MemoryLocation) { return v->assembled ? 0 : HYPRE_IJVectorAssemble(v); }
+
+static std::string rank_file(const char *prefix, int rank)
+{
+   char buf[32];
+   snprintf(buf, sizeof(buf), ".%05d", rank);
+   return std::string(prefix) + buf;
+}
+
+// hypre ASCII IJ vector file: "jlower jupper" then "j value" lines
+extern "C" HYPRE_Int HYPRE_IJVectorRead(const char *filename, MPI_Comm comm, HYPRE_Int, HYPRE_IJVector *vector)
+{
+   HY_TRY
+   const std::string fn = rank_file(filename, Comm::world().rank);
+   FILE             *f  = fopen(fn.c_str(), "r");
+   if (!f) return hypre_set_error(HYPRE_ERROR_ARG, "cannot open " + fn);
+   long long jl, ju;
+   if (fscanf(f, "%lld %lld", &jl, &ju) != 2) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "bad IJ vector header in " + fn); }
+   HYPRE_IJVectorCreate(comm, jl, ju, vector);
+   HYPRE_IJVectorInitialize(*vector);
+   long long j;
+   double    val;
+   while (fscanf(f, "%lld %lf", &j, &val) == 2)
+   {
+      if (j < jl || j > ju) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "IJ vector entry outside its header range in " + fn); }
+      (*vector)->stage[(size_t)(j - jl)] = val;
+   }
+   fclose(f);
+   return HYPRE_IJVectorAssemble(*vector);
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJVectorPrint(HYPRE_IJVector v, const char *filename)
+{
+   HY_TRY
+   const std::string fn = rank_file(filename, Comm::world().rank);
+   FILE             *f  = fopen(fn.c_str(), "w");
+   if (!f) return hypre_set_error(HYPRE_ERROR_ARG, "cannot write " + fn);
+   std::vector<double> h((size_t)std::max(v->nloc, 1));
+   if (v->nloc) HDA_HIP(hipMemcpy(h.data(), v->data(), sizeof(double) * (size_t)v->nloc, hipMemcpyDeviceToHost));
+   fprintf(f, "%lld %lld\n", v->jlower, v->jupper);
+   for (int i = 0; i < v->nloc; i++) fprintf(f, "%lld %.14e\n", v->jlower + i, h[(size_t)i]);
+   fclose(f);
+   HY_CATCH
+}
+
+// -------------------------------------------------------------------- matrices
+
+extern "C" HYPRE_Int HYPRE_IJMatrixCreate(MPI_Comm comm, HYPRE_BigInt ilower, HYPRE_BigInt iupper, HYPRE_BigInt jlower,
+                                          HYPRE_BigInt jupper, HYPRE_IJMatrix *matrix)
+{
+   HY_TRY
+   auto *m   = new hypre_IJMatrix_struct();
+   m->comm   = comm;
+   m->ilower = ilower; m->iupper = iupper; m->jlower = jlower; m->jupper = jupper;
+   m->nloc   = (int)std::max<long long>(iupper - ilower + 1, 0);
+   *matrix   = m;
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixDestroy(HYPRE_IJMatrix m)
+{
+   if (m)
+   {
+      try { if (have_device()) Context::get().sync(); } catch (...) {}
+      delete m;
+   }
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixSetObjectType(HYPRE_IJMatrix, HYPRE_Int) { return 0; }
+extern "C" HYPRE_Int HYPRE_IJMatrixSetRowSizes(HYPRE_IJMatrix m, const HYPRE_Int *sizes)
+{
+   HY_TRY
+   size_t tot = 0;
+   for (int i = 0; i < m->nloc; i++) tot += (size_t)std::max(sizes[i], 0);
+   m->t_row.reserve(tot); m->t_col.reserve(tot); m->t_val.reserve(tot); m->t_add.reserve(tot);
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixSetDiagOffdSizes(HYPRE_IJMatrix, const HYPRE_Int *, const HYPRE_Int *) { return 0; }
+extern "C" HYPRE_Int HYPRE_IJMatrixInitialize_v2(HYPRE_IJMatrix m, HYPRE_MemoryLocation)
+{
+   m->initialized = true;
+   m->assembled   = false;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixInitialize(HYPRE_IJMatrix m) { return HYPRE_IJMatrixInitialize_v2(m, HYPRE_MEMORY_HOST); }
+
+static HYPRE_Int mat_set(HYPRE_IJMatrix m, HYPRE_Int nrows, HYPRE_Int *ncols, const HYPRE_BigInt *rows,
+                         const HYPRE_BigInt *cols, const HYPRE_Complex *values, bool add)
+{
+   HY_TRY
+   size_t q = 0;
+   for (int r = 0; r < nrows; r++)
+   {
+      const long long l = rows[r] - m->ilower;
+      if (l < 0 || l >= m->nloc) return hypre_set_error(HYPRE_ERROR_ARG, "IJMatrix row outside the local range (off-rank assembly is not supported)");
+      for (int c = 0; c < ncols[r]; c++, q++)
+      {
+         m->t_row.push_back((int)l);
+         m->t_col.push_back(cols[q]);
+         m->t_val.push_back(values[q]);
+         m->t_add.push_back(add ? 1 : 0);
+      }
+   }
+   m->assembled = false;
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixSetValues(HYPRE_IJMatrix m, HYPRE_Int nrows, HYPRE_Int *ncols, const HYPRE_BigInt *rows,
+                                             const HYPRE_BigInt *cols, const HYPRE_Complex *values)
+{
+   return mat_set(m, nrows, ncols, rows, cols, values, false);
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixAddToValues(HYPRE_IJMatrix m, HYPRE_Int nrows, HYPRE_Int *ncols, const HYPRE_BigInt *rows,
+                                               const HYPRE_BigInt *cols, const HYPRE_Complex *values)
+{
+   return mat_set(m, nrows, ncols, rows, cols, values, true);
+}
+
+__global__ __launch_bounds__(256) void k_map_gcols(long nnz, const long long *__restrict__ gc, long long jlo, long long jhi,
+                                                   int ncol_loc, const long long *__restrict__ ghosts, int nghost,
+                                                   int *__restrict__ out)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256)
+   {
+      const long long c = gc[k];
+      if (c >= jlo && c <= jhi) out[k] = (int)(c - jlo);
+      else
+      { // binary search in the ascending ghost list
+         int lo = 0, hi = nghost - 1;
+         while (lo < hi)
+         {
+            const int mid = (lo + hi) >> 1;
+            if (ghosts[mid] < c) lo = mid + 1;
+            else hi = mid;
+         }
+         out[k] = ncol_loc + lo;
+      }
+   }
+}
+
+static void finish_partition(hypre_IJMatrix_struct *m)
+{
+   Comm &cm = Comm::world();
+   std::vector<long long> lows;
+   cm.allgather_ll(m->ilower, lows);
+   long long tot[2] = {m->nloc, m->A.nnz};
+   cm.allreduce_host(tot, 2, 0);
+   m->global_rows = tot[0];
+   m->global_nnz  = tot[1];
+   m->part        = lows;
+   m->part.push_back(lows[0] + m->global_rows);
+   for (int r = 0; r < cm.size; r++)
+      HDA_REQUIRE(m->part[(size_t)r] <= m->part[(size_t)r + 1], "row ranges must ascend with the rank");
+   m->halo = make_halo_plan(m->nloc, m->part, m->ghost_gids);
+}
+
+void hypre_IJMatrix_struct::assemble()
+{
+   const size_t T = t_row.size();
+   // stable counting sort of the triplets by row
+   std::vector<int> rp((size_t)nloc + 1, 0);
+   for (size_t q = 0; q < T; q++) rp[(size_t)t_row[q] + 1]++;
+   for (int i = 0; i < nloc; i++) rp[(size_t)i + 1] += rp[(size_t)i];
+   std::vector<long long> cj(std::max<size_t>(T, 1));
+   std::vector<double>    cv(std::max<size_t>(T, 1));
+   std::vector<char>      ca(std::max<size_t>(T, 1));
+   {
+      std::vector<int> pos(rp.begin(), rp.end() - 1);
+      for (size_t q = 0; q < T; q++)
+      {
+         const int p  = pos[(size_t)t_row[q]]++;
+         cj[(size_t)p] = t_col[q];
+         cv[(size_t)p] = t_val[q];
+         ca[(size_t)p] = t_add[q];
+      }
+   }
+   std::vector<int>().swap(t_row);
+   std::vector<long long>().swap(t_col);
+   std::vector<double>().swap(t_val);
+   std::vector<char>().swap(t_add);
+   // merge duplicates inside each row (set: last wins, add: accumulate), keep first position
+   std::vector<int> rp2((size_t)nloc + 1, 0);
+   size_t           w = 0;
+   for (int i = 0; i < nloc; i++)
+   {
+      const size_t s = (size_t)rp[(size_t)i], e = (size_t)rp[(size_t)i + 1], w0 = w;
+      for (size_t q = s; q < e; q++)
+      {
+         size_t hit = w;
+         for (size_t z = w0; z < w; z++)
+            if (cj[z] == cj[q]) { hit = z; break; }
+         if (hit == w) { cj[w] = cj[q]; cv[w] = cv[q]; w++; }
+         else if (ca[q]) cv[hit] += cv[q];
+         else cv[hit] = cv[q];
+      }
+      rp2[(size_t)i + 1] = (int)w;
+   }
+   const size_t nnz = w;
+   HDA_REQUIRE(nnz < (1ULL << 31), "local nnz must fit int32");
+   // ghost columns
+   std::vector<long long> gh;
+   for (size_t q = 0; q < nnz; q++)
+      if (cj[q] < jlower || cj[q] > jupper) gh.push_back(cj[q]);
+   std::sort(gh.begin(), gh.end());
+   gh.erase(std::unique(gh.begin(), gh.end()), gh.end());
+   ghost_gids = gh;
+   DArray<int>       drp;
+   DArray<long long> dgc;
+   DArray<double>    dv;
+   drp.upload(rp2.data(), (size_t)nloc + 1);
+   dgc.upload(cj.data(), std::max<size_t>(nnz, 1));
+   dv.upload(cv.data(), std::max<size_t>(nnz, 1));
+   adopt_device(nloc, (int)nnz, drp, dgc, dv);
+}
+
+void hypre_IJMatrix_struct::adopt_device(int nl, int nnz, DArray<int> &rowptr, DArray<long long> &gcols, DArray<double> &vals)
+{
+   // ghost list must already be in ghost_gids (ascending); single-rank callers leave it empty
+   const int ncol_loc = (int)(jupper - jlower + 1);
+   A.nrows            = nl;
+   A.nnz              = nnz;
+   A.ncols            = ncol_loc + (int)ghost_gids.size();
+   A.rowptr           = std::move(rowptr);
+   A.val              = std::move(vals);
+   A.col.alloc((size_t)std::max(nnz, 1));
+   DArray<long long> dgh;
+   if (!ghost_gids.empty()) dgh.upload(ghost_gids.data(), ghost_gids.size());
+   if (nnz)
+      k_map_gcols<<<std::min(ceil_div(nnz, 256), 1 << 16), 256, 0, STREAM>>>(nnz, gcols.data(), jlower, jupper, ncol_loc,
+                                                                           dgh.data(), (int)ghost_gids.size(), A.col.data());
+   sort_rows(A);
+   Context::get().sync();
+   finish_partition(this);
+   assembled = true;
+}
+
+extern "C" HYPRE_Int HYPRE_IJMatrixAssemble(HYPRE_IJMatrix m)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   if (m->assembled && m->t_row.empty()) return 0;
+   HDA_REQUIRE(!m->assembled || m->t_row.empty(), "re-assembly of an assembled IJMatrix with new values is not supported");
+   m->assemble();
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixGetObject(HYPRE_IJMatrix m, void **object)
+{
+   *object = m;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixGetLocalRange(HYPRE_IJMatrix m, HYPRE_BigInt *il, HYPRE_BigInt *iu, HYPRE_BigInt *jl, HYPRE_BigInt *ju)
+{
+   *il = m->ilower; *iu = m->iupper; *jl = m->jlower; *ju = m->jupper;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixMigrate(HYPRE_IJMatrix m, HYPRE_MemoryLocation) { return m->assembled ? 0 : HYPRE_IJMatrixAssemble(m); }
+extern "C" HYPRE_Int HYPRE_ParCSRMatrixGetDims(HYPRE_ParCSRMatrix A, HYPRE_BigInt *M, HYPRE_BigInt *N)
+{
+   if (M) *M = A->global_rows;
+   if (N) *N = A->global_rows;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_ParCSRMatrixGetNumNonzeros(HYPRE_ParCSRMatrix A, HYPRE_BigInt *nnz)
+{
+   *nnz = A->global_nnz;
+   return 0;
+}
+
+// hypre ASCII IJ matrix file: "ilower iupper jlower jupper" then "i j value" 
+extern "C" HYPRE_Int HYPRE_IJMatrixRead(const char *filename, MPI_Comm comm, HYPRE_Int, HYPRE_IJMatrix *matrix)
+{
+   HY_TRY
+   const std::string fn = rank_file(filename, Comm::world().rank);
+   FILE             *f  = fopen(fn.c_str(), "r");
+   if (!f) return hypre_set_error(HYPRE_ERROR_ARG, "cannot open " + fn);
+   long long il, iu, jl, ju;
+   if (fscanf(f, "%lld %lld %lld %lld", &il, &iu, &jl, &ju) != 4) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "bad IJ matrix header in " + fn); }
+   HYPRE_IJMatrixCreate(comm, il, iu, jl, ju, matrix);
+   HYPRE_IJMatrixInitialize(*matrix);
+   long long i, j;
+   double    v;
+   auto     *m = *matrix;
+   while (fscanf(f, "%lld %lld %lf", &i, &j, &v) == 3)
+   {
+      if (i < il || i > iu) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "IJ matrix row outside its header range in " + fn); }
+      m->t_row.push_back((int)(i - il));
+      m->t_col.push_back(j);
+      m->t_val.push_back(v);
+      m->t_add.push_back(0);
+   }
+   fclose(f);
+   return HYPRE_IJMatrixAssemble(m);
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_IJMatrixPrint(HYPRE_IJMatrix m, const char *filename)
+{
+   HY_TRY
+   const std::string fn = rank_file(filename, Comm::world().rank);
+   FILE             *f  = fopen(fn.c_str(), "w");
+   if (!f) return hypre_set_error(HYPRE_ERROR_ARG, "cannot write " + fn);
+   std::vector<int>    rp = m->A.rowptr.to_host(), cj((size_t)std::max(m->A.nnz, 1));
+   std::vector<double> v((size_t)std::max(m->A.nnz, 1));
+   if (m->A.nnz) { m->A.col.download(cj.data(), (size_t)m->A.nnz); m->A.val.download(v.data(), (size_t)m->A.nnz); }
+   fprintf(f, "%lld %lld %lld %lld\n", m->ilower, m->iupper, m->jlower, m->jupper);
+   const int ncl = (int)(m->jupper - m->jlower + 1);
+   for (int i = 0; i < m->nloc; i++)
+      for (int k = rp[(size_t)i]; k < rp[(size_t)i + 1]; k++)
+      {
+         const long long g = cj[(size_t)k] < ncl ? m->jlower + cj[(size_t)k] : m->ghost_gids[(size_t)(cj[(size_t)k] - ncl)];
+         fprintf(f, "%lld %lld %.14e\n", m->ilower + i, g, v[(size_t)k]);
+      }
+   fclose(f);
+   HY_CATCH
+}
+
+// ------------------------------------------------------------- ParCSR kernels
+
+extern "C" HYPRE_Int HYPRE_ParCSRMatrixMatvec(HYPRE_Complex alpha, HYPRE_ParCSRMatrix A, HYPRE_ParVector x, HYPRE_Complex beta,
+                                              HYPRE_ParVector y)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   HDA_REQUIRE(A && A->assembled && x && y, "Matvec needs assembled operands");
+   const double  *xin = x->data();
+   DArray<double> xe;
+   if (A->A.ncols > A->nloc || x->capacity < (size_t)A->A.ncols)
+   { // stage x into an extended vector and refresh the ghost tail
+      xe.alloc((size_t)std::max(A->A.ncols, 1));
+      copy(A->nloc, x->data(), xe.data());
+      halo_exchange(A->halo, xe.data());
+      xin = xe.data();
+   }
+   spmv(A->A, alpha, xin, beta, y->data(), y->data());
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_ParVectorInnerProd(HYPRE_ParVector x, HYPRE_ParVector y, HYPRE_Real *prod)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   dot(x->nloc, x->data(), y->data(), 0);
+   finalize(0, S_TMP);
+   *prod = read_scalar(S_TMP);
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_ParVectorCopy(HYPRE_ParVector x, HYPRE_ParVector y)
+{
+   HY_TRY
+   y->ensure_device();
+   copy(x->nloc, x->data(), y->data());
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_ParVectorScale(HYPRE_Complex a, HYPRE_ParVector x)
+{
+   HY_TRY
+   scale(x->nloc, a, x->data());
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_ParVectorAxpy(HYPRE_Complex a, HYPRE_ParVector x, HYPRE_ParVector y)
+{
+   HY_TRY
+   axpy(x->nloc, a, x->data(), y->data());
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_ParVectorSetConstantValues(HYPRE_ParVector v, HYPRE_Complex value)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   v->ensure_device();
+   std::vector<double>().swap(v->stage);
+   fill(v->nloc, value, v->data());
+   v->assembled = true;
+   HY_CATCH
+}
+
+// --------------------------------------------------------------------- Krylov
+
+static HYPRE_Int krylov_create(int kind, HYPRE_Solver *solver)
+{
+   auto *s = new hypre_Solver_struct();
+   s->kind = kind;
+   if (kind == HDA_SOLVER_GMRES) s->kp.max_iter = 300; // src/internal/gmres.c:18
+   *solver = s;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_ParCSRPCGCreate(MPI_Comm, HYPRE_Solver *s) { return krylov_create(HDA_SOLVER_PCG, s); }
+extern "C" HYPRE_Int HYPRE_ParCSRGMRESCreate(MPI_Comm, HYPRE_Solver *s) { return krylov_create(HDA_SOLVER_GMRES, s); }
+extern "C" HYPRE_Int HYPRE_ParCSRPCGDestroy(HYPRE_Solver s) { delete s; return 0; }
+extern "C" HYPRE_Int HYPRE_ParCSRGMRESDestroy(HYPRE_Solver s) { delete s; return 0; }
+
+#define HY_SETTER(fn, type, stmt) \
+   extern "C" HYPRE_Int fn(HYPRE_Solver s, type v) { if (!s) return hypre_set_error(HYPRE_ERROR_ARG, #fn ": null solver"); stmt; return 0; }
+
+HY_SETTER(HYPRE_PCGSetMaxIter, HYPRE_Int, s->kp.max_iter = v)
+HY_SETTER(HYPRE_PCGSetTwoNorm, HYPRE_Int, s->kp.two_norm = v)
+HY_SETTER(HYPRE_PCGSetStopCrit, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_PCGSetRelChange, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_PCGSetPrintLevel, HYPRE_Int, s->kp.print_level = v)
+HY_SETTER(HYPRE_PCGSetLogging, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_PCGSetRecomputeResidual, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_PCGSetTol, HYPRE_Real, s->kp.rtol = v)
+HY_SETTER(HYPRE_PCGSetAbsoluteTol, HYPRE_Real, s->kp.atol = v)
+HY_SETTER(HYPRE_PCGSetResidualTol, HYPRE_Real, (void)v)
+HY_SETTER(HYPRE_PCGSetConvergenceFactorTol, HYPRE_Real, (void)v)
+HY_SETTER(HYPRE_GMRESSetMinIter, HYPRE_Int, s->kp.min_iter = v)
+HY_SETTER(HYPRE_GMRESSetMaxIter, HYPRE_Int, s->kp.max_iter = v)
+HY_SETTER(HYPRE_GMRESSetStopCrit, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_GMRESSetSkipRealResidualCheck, HYPRE_Int, s->kp.skip_real_res_check = v)
+HY_SETTER(HYPRE_GMRESSetKDim, HYPRE_Int, s->kp.krylov_dim = v)
+HY_SETTER(HYPRE_GMRESSetRelChange, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_GMRESSetLogging, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_GMRESSetPrintLevel, HYPRE_Int, s->kp.print_level = v)
+HY_SETTER(HYPRE_GMRESSetTol, HYPRE_Real, s->kp.rtol = v)
+HY_SETTER(HYPRE_GMRESSetAbsoluteTol, HYPRE_Real, s->kp.atol = v)
+HY_SETTER(HYPRE_GMRESSetConvergenceFactorTol, HYPRE_Real, (void)v)
+
+static HYPRE_Int set_precond(HYPRE_Solver s, HYPRE_PtrToSolverFcn p, HYPRE_PtrToSolverFcn ps, HYPRE_Solver psolver)
+{
+   s->precond        = p;
+   s->precond_setup  = ps;
+   s->precond_solver = psolver;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_PCGSetPrecond(HYPRE_Solver s, HYPRE_PtrToSolverFcn p, HYPRE_PtrToSolverFcn ps, HYPRE_Solver psolver)
+{
+   return set_precond(s, p, ps, psolver);
+}
+extern "C" HYPRE_Int HYPRE_GMRESSetPrecond(HYPRE_Solver s, HYPRE_PtrToSolverFcn p, HYPRE_PtrToSolverFcn ps, HYPRE_Solver psolver)
+{
+   return set_precond(s, p, ps, psolver);
+}
+
+// hypre_PCGSetup / hypre_GMRESSetup: the only work is the preconditioner's setup callback
+static HYPRE_Int krylov_setup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
+{
+   HY_NEED_DEVICE;
+   if (s->precond_setup) return s->precond_setup(s->precond_solver, A, b, x);
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_ParCSRPCGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_setup(s, A, b, x); }
+extern "C" HYPRE_Int HYPRE_ParCSRGMRESSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_setup(s, A, b, x); }
+
+// length Krylov work vectors need so that a BoomerAMG preconditioner can use them as level-0
+// vectors directly (any other callback only sees the owned part)
+static size_t precond_veclen(HYPRE_Solver s)
+{
+   HYPRE_Solver p = s->precond_solver;
+   // hypredrive hands a cookie, not the AMG handle (src/internal/solver.c:538): the cookie
+   // type registers its vector length through hda_register_precond_veclen below
+   (void)p;
+   return 0;
+}
+
+static thread_local size_t g_precond_veclen = 0;
+extern "C" void hda_register_precond_veclen(size_t n) { g_precond_veclen = n; }
+extern "C" void hda_reset_precond_veclen(void) { g_precond_veclen = 0; }
+
+static HYPRE_Int krylov_solve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   HDA_REQUIRE(A && A->assembled, "Krylov solve needs an assembled matrix");
+   x->ensure_device();
+   size_t veclen = std::max(g_precond_veclen, precond_veclen(s));
+   if (s->precond_solver && s->precond_solver->kind == HDA_SOLVER_AMG && s->precond_solver->amg)
+      veclen = std::max(veclen, s->precond_solver->amg->vec_len0());
+   LinOp     op(A->A, Comm::world().size > 1 ? &A->halo : nullptr, veclen);
+   PrecondFn M;
+   if (s->precond)
+   {
+      HYPRE_Solver         ps = s->precond_solver;
+      HYPRE_PtrToSolverFcn fn = s->precond;
+      const int            n  = A->nloc;
+      const size_t         vl = op.veclen;
+      M = [=](const double *r, double *z, int slot) {
+         hypre_IJVector_struct vb, vx; // non-owning views for the C callback seam
+         vb.nloc = vx.nloc = n;
+         vb.jlower = vx.jlower = A->ilower;
+         vb.jupper = vx.jupper = A->iupper;
+         vb.view = const_cast<double *>(r);
+         vx.view = z;
+         vb.capacity = vx.capacity = vl;
+         vb.assembled = vx.assembled = true;
+         PrecondHints &h = precond_hints();
+         h.zero_guess = true;
+         h.dot_slot   = slot;
+         h.dot_done   = false;
+         const int ierr = fn(ps, A, &vb, &vx);
+         const bool done = h.dot_done;
+         h = PrecondHints();
+         if (ierr) throw Error("preconditioner callback failed: " + hypre_last_error());
+         if (slot >= 0 && !done) dot(n, r, z, slot);
+      };
+   }
+   s->last = (s->kind == HDA_SOLVER_GMRES) ? gmres(op, M, s->kp, b->data(), x->data()) : pcg(op, M, s->kp, b->data(), x->data());
+   if (!s->last.converged) g_hcode |= HYPRE_ERROR_CONV; // soft error, as in hypre
+   HY_CATCH
+}
+extern "C" HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_solve(s, A, b, x); }
+extern "C" HYPRE_Int HYPRE_ParCSRGMRESSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_solve(s, A, b, x); }
+
+#define HY_GETTER(fn, type, expr) \
+   extern "C" HYPRE_Int fn(HYPRE_Solver s, type *out) { if (!s || !out) return hypre_set_error(HYPRE_ERROR_ARG, #fn ": null argument"); *out = (expr); return 0; }
+HY_GETTER(HYPRE_PCGGetNumIterations, HYPRE_Int, s->last.iters)
+HY_GETTER(HYPRE_PCGGetFinalRelativeResidualNorm, HYPRE_Real, s->last.final_rel)
+HY_GETTER(HYPRE_PCGGetConverged, HYPRE_Int, s->last.converged ? 1 : 0)
+HY_GETTER(HYPRE_GMRESGetNumIterations, HYPRE_Int, s->last.iters)
+HY_GETTER(HYPRE_GMRESGetFinalRelativeResidualNorm, HYPRE_Real, s->last.final_rel)
+HY_GETTER(HYPRE_GMRESGetConverged, HYPRE_Int, s->last.converged ? 1 : 0)
+
+// ------------------------------------------------------------------ BoomerAMG
+
+extern "C" HYPRE_Int HYPRE_BoomerAMGCreate(HYPRE_Solver *solver)
+{
+   auto *s = new hypre_Solver_struct();
+   s->kind = HDA_SOLVER_AMG;
+   // hypre's own defaults (not hypredrive's): 20 cycles, tol 1e-7, hybrid GS; hypredrive
+   // overrides every one of them through the setter sequence of src/internal/amg.c:868-1032
+   s->ap.max_iter = 20;
+   s->ap.tol      = 1.0e-7;
+   *solver        = s;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_BoomerAMGDestroy(HYPRE_Solver s)
+{
+   if (s)
+   {
+      try { if (have_device()) Context::get().sync(); } catch (...) {}
+      delete s;
+   }
+   return 0;
+}
+
+HY_SETTER(HYPRE_BoomerAMGSetInterpType, HYPRE_Int, s->ap.interp_type = v)
+HY_SETTER(HYPRE_BoomerAMGSetRestriction, HYPRE_Int, s->restriction = v)
+HY_SETTER(HYPRE_BoomerAMGSetStrongThresholdR, HYPRE_Real, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetFilterThresholdR, HYPRE_Real, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetCoarsenType, HYPRE_Int, s->ap.coarsen_type = v)
+HY_SETTER(HYPRE_BoomerAMGSetSabs, HYPRE_Int, s->sabs = v)
+HY_SETTER(HYPRE_BoomerAMGSetTol, HYPRE_Real, s->ap.tol = v)
+HY_SETTER(HYPRE_BoomerAMGSetStrongThreshold, HYPRE_Real, s->ap.strong_th = v)
+HY_SETTER(HYPRE_BoomerAMGSetSeqThreshold, HYPRE_Int, s->seq_threshold = v)
+HY_SETTER(HYPRE_BoomerAMGSetMaxCoarseSize, HYPRE_Int, s->ap.max_coarse_size = v)
+HY_SETTER(HYPRE_BoomerAMGSetMinCoarseSize, HYPRE_Int, s->ap.min_coarse_size = v)
+HY_SETTER(HYPRE_BoomerAMGSetTruncFactor, HYPRE_Real, s->ap.trunc_factor = v)
+HY_SETTER(HYPRE_BoomerAMGSetPMaxElmts, HYPRE_Int, s->ap.pmax = v)
+HY_SETTER(HYPRE_BoomerAMGSetPrintLevel, HYPRE_Int, s->ap.print_level = v)
+HY_SETTER(HYPRE_BoomerAMGSetLogging, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetRelaxOrder, HYPRE_Int, s->relax_order = v)
+HY_SETTER(HYPRE_BoomerAMGSetRelaxWt, HYPRE_Real, s->ap.relax_weight = v)
+HY_SETTER(HYPRE_BoomerAMGSetOuterWt, HYPRE_Real, s->ap.outer_weight = v)
+HY_SETTER(HYPRE_BoomerAMGSetCycleType, HYPRE_Int, s->cycle_type = v)
+HY_SETTER(HYPRE_BoomerAMGSetMaxLevels, HYPRE_Int, s->ap.max_levels = v)
+HY_SETTER(HYPRE_BoomerAMGSetMaxIter, HYPRE_Int, s->ap.max_iter = v)
+HY_SETTER(HYPRE_BoomerAMGSetMaxRowSum, HYPRE_Real, s->ap.max_row_sum = v)
+HY_SETTER(HYPRE_BoomerAMGSetNumFunctions, HYPRE_Int, s->num_functions = v)
+HY_SETTER(HYPRE_BoomerAMGSetFilterFunctions, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetSmoothType, HYPRE_Int, s->smooth_type = v)
+HY_SETTER(HYPRE_BoomerAMGSetSmoothNumSweeps, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetSmoothNumLevels, HYPRE_Int, s->smooth_num_levels = v)
+HY_SETTER(HYPRE_BoomerAMGSetAggNumLevels, HYPRE_Int, s->agg_num_levels = v)
+HY_SETTER(HYPRE_BoomerAMGSetAggInterpType, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetAggTruncFactor, HYPRE_Real, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetAggP12TruncFactor, HYPRE_Real, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetAggPMaxElmts, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetAggP12MaxElmts, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetNumPaths, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetRAP2, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetModuleRAP2, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetKeepTranspose, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyOrder, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyFraction, HYPRE_Real, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyEigEst, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyVariant, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyScale, HYPRE_Int, (void)v)
+
+extern "C" HYPRE_Int HYPRE_BoomerAMGSetRelaxType(HYPRE_Solver s, HYPRE_Int t)
+{
+   s->ap.relax_down = s->ap.relax_up = t;
+   s->ap.relax_coarse = 9;
+   s->relax_type_all  = t;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver s, HYPRE_Int t, HYPRE_Int k)
+{
+   if (k == 1) s->ap.relax_down = t;
+   else if (k == 2) s->ap.relax_up = t;
+   else if (k == 3) s->ap.relax_coarse = t;
+   else return hypre_set_error(HYPRE_ERROR_ARG, "SetCycleRelaxType: k must be 1, 2 or 3");
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_BoomerAMGSetNumSweeps(HYPRE_Solver s, HYPRE_Int n)
+{
+   s->ap.sweeps_down = s->ap.sweeps_up = n;
+   s->ap.sweeps_coarse = 1;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_BoomerAMGSetCycleNumSweeps(HYPRE_Solver s, HYPRE_Int n, HYPRE_Int k)
+{
+   if (k == 1) s->ap.sweeps_down = n;
+   else if (k == 2) s->ap.sweeps_up = n;
+   else if (k == 3) s->ap.sweeps_coarse = n;
+   else return hypre_set_error(HYPRE_ERROR_ARG, "SetCycleNumSweeps: k must be 1, 2 or 3");
+   return 0;
+}
+
+extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector, HYPRE_ParVector)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   HDA_REQUIRE(s && s->kind == HDA_SOLVER_AMG, "BoomerAMGSetup: not a BoomerAMG handle");
+   HDA_REQUIRE(A && A->assembled, "BoomerAMGSetup needs an assembled matrix");
+   // features of the reference's parameter surface that this build does not implement
+   HDA_REQUIRE(s->agg_num_levels == 0, "aggressive coarsening (aggressive.num_levels > 0) is not implemented on MI355X yet");
+   HDA_REQUIRE(s->num_functions <= 1, "systems AMG (coarsening.num_functions > 1) is not implemented on MI355X yet");
+   HDA_REQUIRE(s->smooth_num_levels == 0, "complex smoothers (smoother.num_levels > 0: FSAI/ILU) are not implemented on MI355X yet");
+   HDA_REQUIRE(s->cycle_type == 1, "only V-cycles (cycle type 1) are implemented");
+   HDA_REQUIRE(s->restriction == 0, "only P^T restriction (restriction_type 0) is implemented");
+   HDA_REQUIRE(s->relax_order == 0, "only lexicographic relaxation order (relaxation.order 0) is implemented");
+   s->amg = std::make_unique<Amg>(s->ap);
+   if (Comm::world().size > 1) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+   else s->amg->setup(A->A);
+   hda_register_precond_veclen(s->amg->vec_len0());
+   if (s->ap.print_level > 0 && Comm::world().rank == 0)
+      printf("\n BoomerAMG (MI355X): %d levels, grid complexity %.6f, operator complexity %.6f\n\n", s->amg->num_levels(),
+             s->amg->grid_complexity(), s->amg->operator_complexity());
+   HY_CATCH
+}
+
+extern "C" HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   HDA_REQUIRE(s && s->amg, "BoomerAMGSolve before BoomerAMGSetup");
+   x->ensure_device();
+   PrecondHints  &h   = precond_hints();
+   const size_t   need = s->amg->vec_len0();
+   double        *xp  = x->data();
+   DArray<double> xe;
+   const bool     staged = x->capacity < need;
+   if (staged)
+   {
+      xe.alloc(need);
+      copy(A->nloc, x->data(), xe.data());
+      xp = xe.data();
+   }
+   if (h.zero_guess && s->ap.max_iter == 1)
+   {
+      s->amg->apply(b->data(), xp, h.dot_slot);
+      if (h.dot_slot >= 0) h.dot_done = true;
+      s->amg_iters = 1;
+   }
+   else
+   {
+      // stand-alone solver use: up to max_iter cycles, optional relative residual test
+      double bn = 0.0;
+      DArray<double> r, xs;
+      if (s->ap.tol > 0.0)
+      {
+         dot(A->nloc, b->data(), b->data(), 0);
+         finalize(0, S_TMP);
+         bn = std::sqrt(read_scalar(S_TMP));
+         r.alloc((size_t)std::max(A->nloc, 1));
+         xs.alloc(std::max(need, (size_t)A->A.ncols));
+      }
+      AmgParams one = s->amg->prm;
+      s->amg_iters  = 0;
+      for (int it = 0; it < std::max(s->ap.max_iter, 1); it++)
+      {
+         s->amg->prm.max_iter = 1;
+         s->amg->solve(b->data(), xp);
+         s->amg_iters++;
+         if (s->ap.tol > 0.0)
+         {
+            copy(A->nloc, xp, xs.data());
+            halo_exchange(A->halo, xs.data());
+            residual(A->A, xs.data(), b->data(), r.data());
+            dot(A->nloc, r.data(), r.data(), 0);
+            finalize(0, S_TMP);
+            s->amg_rel = std::sqrt(read_scalar(S_TMP)) / (bn > 0.0 ? bn : 1.0);
+            if (s->amg_rel <= s->ap.tol) break;
+         }
+      }
+      s->amg->prm = one;
+   }
+   if (staged) copy(A->nloc, xp, x->data());
+   HY_CATCH
+}
+HY_GETTER(HYPRE_BoomerAMGGetNumIterations, HYPRE_Int, s->amg_iters)
+HY_GETTER(HYPRE_BoomerAMGGetFinalRelativeResidualNorm, HYPRE_Real, s->amg_rel)
+HY_GETTER(HYPRE_BoomerAMGGetNumLevels, HYPRE_Int, s->amg ? s->amg->num_levels() : 0)
+extern "C" HYPRE_Int HYPRE_BoomerAMGGetComplexities(HYPRE_Solver s, HYPRE_Real *grid, HYPRE_Real *op)
+{
+   if (!s || !s->amg) return hypre_set_error(HYPRE_ERROR_ARG, "GetComplexities before Setup");
+   if (grid) *grid = s->amg->grid_complexity();
+   if (op) *op = s->amg->operator_complexity();
+   return 0;
+}

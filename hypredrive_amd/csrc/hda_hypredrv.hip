@@ -1,0 +1,1217 @@
+// hda_hypredrv.hip -- HYPREDRV_* public API (include/HYPREDRV.h) for the AMG-Krylov path.
+//
+// Mirrors the call structure of the reference so that the hot path crosses the same seams:
+//   HYPREDRV_LinearSolverSetup  (src/HYPREDRV.c:3001-3119)  -> HYPRE_ParCSR{PCG,GMRES}Setup
+//       -> PreconSetupDispatch ("prec" timer, src/internal/solver.c:268-311) -> HYPRE_BoomerAMGSetup
+//   HYPREDRV_LinearSolverApply  (src/HYPREDRV.c:3126-3338, src/internal/solver.c:627-693)
+//       -> r0 (untimed) -> "solve" timer { HYPRE_ParCSR{PCG,GMRES}Solve -> PreconSolveDispatch
+//          -> HYPRE_BoomerAMGSolve } -> true relative residual (untimed)
+// Error handling: sticky process-global bit field, reset at the start of each lifecycle call
+// (reference include/internal/error.h:16-48, src/HYPREDRV.c:2797,2901,2965,3005,3129).
+#include "../../include/HYPREDRV.h"
+
+#include "hda_hypre.h"
+#include "hda_yaml.h"
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cmath>
+#include <csignal>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+using namespace hda;
+
+// ------------------------------------------------------------------- errors
+
+static uint32_t    g_err = 0;
+static std::string g_errmsg;
+static bool        g_initialized = false;
+
+static uint32_t err_set(uint32_t e, const std::string &msg = "")
+{
+   g_err |= e;
+   if (!msg.empty())
+   {
+      if (!g_errmsg.empty()) g_errmsg += "\n";
+      g_errmsg += msg;
+   }
+   return g_err;
+}
+static void err_reset()
+{
+   g_err = 0;
+   g_errmsg.clear();
+   HYPRE_ClearAllErrors();
+}
+// hypredrv_HypreConsumeErrors (reference src/internal/utils.c:33-79): HYPRE_ERROR_CONV and
+// HYPRE_ERROR_ARG are soft, anything else becomes ERROR_HYPRE_INTERNAL
+static void consume_hypre_errors()
+{
+   const int h = HYPRE_GetError();
+   if (h & ~(HYPRE_ERROR_CONV | HYPRE_ERROR_ARG)) err_set(ERR_HYPRE_INTERNAL, hypre_last_error());
+   HYPRE_ClearAllErrors();
+}
+
+extern "C" const char *HYPREDRV_AMD_LastErrorMessage(void) { return g_errmsg.c_str(); }
+
+extern "C" void HYPREDRV_ErrorCodeDescribe(uint32_t code)
+{
+   static const struct { uint32_t bit; const char *text; } table[] = {
+      {ERR_YAML_INVALID_INDENT, "YAML: invalid indentation"}, {ERR_YAML_INVALID_BASE_INDENT, "YAML: invalid base indentation"},
+      {ERR_YAML_INCONSISTENT_INDENT, "YAML: inconsistent indentation"}, {ERR_YAML_INVALID_DIVISOR, "YAML: missing ':' divisor"},
+      {ERR_YAML_TREE_NULL, "YAML: empty tree"}, {ERR_YAML_TREE_INVALID, "YAML: invalid tree"},
+      {ERR_YAML_MIXED_INDENT, "YAML: tabs mixed with spaces"}, {ERR_YAML_INVALID_INDENT_JUMP, "YAML: indentation jump"},
+      {ERR_INVALID_KEY, "invalid key"}, {ERR_INVALID_VAL, "invalid value"}, {ERR_UNEXPECTED_VAL, "unexpected value"},
+      {ERR_MAYBE_INVALID_VAL, "possibly invalid value"}, {ERR_MISSING_KEY, "missing key"}, {ERR_EXTRA_KEY, "extra key"},
+      {ERR_MISSING_SOLVER, "missing solver"}, {ERR_MISSING_PRECON, "missing preconditioner"}, {ERR_MISSING_DOFMAP, "missing dofmap"},
+      {ERR_INVALID_SOLVER, "invalid solver"}, {ERR_INVALID_PRECON, "invalid preconditioner"}, {ERR_FILE_NOT_FOUND, "file not found"},
+      {ERR_FILE_UNEXPECTED_ENTRY, "unexpected entry in file"}, {ERR_UNKNOWN_HYPREDRV_OBJ, "unknown HYPREDRV object"},
+      {ERR_HYPREDRV_NOT_INITIALIZED, "HYPREDRV is not initialized"}, {ERR_UNKNOWN_TIMING, "unknown timing annotation"},
+      {ERR_HYPRE_INTERNAL, "error inside the solver backend"}, {ERR_MISSING_LIB, "feature not available in this build"},
+      {ERR_ALLOCATION, "allocation failure"}, {ERR_OUT_OF_BOUNDS, "index out of bounds"}, {ERR_UNKNOWN, "unknown error"}};
+   if (!code) return;
+   fprintf(stderr, "HYPREDRIVE Failure!!!\n");
+   for (auto &t : table)
+      if (code & t.bit) fprintf(stderr, "  --> %s\n", t.text);
+   if (!g_errmsg.empty()) fprintf(stderr, "%s\n", g_errmsg.c_str());
+}
+extern "C" void HYPREDRV_ErrorCodeClear(void) { err_reset(); }
+extern "C" uint32_t HYPREDRV_ErrorInvalidValue(const char *message) { return err_set(ERR_INVALID_VAL, message ? message : ""); }
+extern "C" void HYPREDRV_SafeCallHandleError(uint32_t code, MPI_Comm, const char *file, int line, const char *func)
+{
+   if (!code) return;
+   fprintf(stderr, "At %s:%d in %s():\n", file, line, func);
+   HYPREDRV_ErrorCodeDescribe(code);
+   const char *dbg = getenv("HYPREDRV_DEBUG");
+   if (dbg && !strcmp(dbg, "1")) raise(SIGTRAP);
+   fflush(nullptr);
+   _exit((int)(code & 0x7F) ? (int)(code & 0x7F) : 1); // the reference calls MPI_Abort
+}
+
+// -------------------------------------------------------------------- stats
+
+namespace {
+using clk = std::chrono::steady_clock;
+struct StatEntry {
+   double build = 0.0, prec = 0.0, solve = 0.0, r0 = 0.0, rr = 0.0;
+   int    iters = 0;
+   bool   has_solve = false;
+};
+struct Stats {
+   std::vector<StatEntry>                 entries{StatEntry()};
+   std::map<std::string, clk::time_point> open;
+   double                                 pending_build = 0.0;
+   int                                    ls_counter = -1;
+   bool                                   system_open = false;
+   int                                    use_millisec = 0;
+   StatEntry &cur() { return entries.back(); }
+   void       next_entry_if_used()
+   {
+      if (cur().has_solve) entries.emplace_back();
+   }
+};
+} // namespace
+
+struct PreconCookie { // the void* the Krylov solver hands back (reference include/internal/precon.h:84-95)
+   struct hypredrv_struct *self;
+};
+
+struct hypredrv_struct {
+   MPI_Comm       comm = MPI_COMM_WORLD;
+   int            mypid = 0, nprocs = 1;
+   bool           lib_mode = false;
+   std::string    name;
+   InputArgs      args;
+   YNode          tree;
+   HYPRE_IJMatrix mat_A = nullptr, mat_M = nullptr;
+   HYPRE_IJVector vec_b = nullptr, vec_x = nullptr, vec_x0 = nullptr, vec_xref = nullptr;
+   bool           owns_A = false, owns_b = false, owns_x = false, owns_x0 = false;
+   HYPRE_Solver   solver = nullptr, precon = nullptr;
+   bool           precon_is_setup = false;
+   PreconCookie   cookie{nullptr};
+   Stats          stats;
+   int            current_system_index = -1;
+   int            last_iters = 0, last_converged = 0;
+   double         last_rel = 0.0, last_setup_s = 0.0, last_solve_s = 0.0;
+};
+
+#define CHECK_INIT_OBJ(h)                                          \
+   if (!g_initialized) return err_set(ERR_HYPREDRV_NOT_INITIALIZED); \
+   if (!(h)) return err_set(ERR_UNKNOWN_HYPREDRV_OBJ)
+
+#define API_TRY try {
+#define API_CATCH                                                        \
+   }                                                                     \
+   catch (const std::exception &e) { err_set(ERR_HYPRE_INTERNAL, e.what()); } \
+   return g_err;
+
+static void stats_begin(Stats &s, const std::string &name) { s.open[name] = clk::now(); }
+static double stats_end(Stats &s, const std::string &name)
+{
+   auto it = s.open.find(name);
+   if (it == s.open.end()) return 0.0;
+   double dt = std::chrono::duration<double>(clk::now() - it->second).count();
+   s.open.erase(it);
+   return dt;
+}
+
+static uint32_t annotate(hypredrv_struct *h, const char *name, bool begin)
+{
+   if (!name) return err_set(ERR_UNKNOWN_TIMING);
+   std::string n(name);
+   Stats      &s = h->stats;
+   if (n.rfind("Run", 0) == 0 || n == "initialize" || n == "finalize") return g_err; // free-form markers (stats.c:324-327)
+   if (n == "system" || n == "matrix" || n == "rhs" || n == "dofmap")
+   {
+      if (begin)
+      {
+         stats_begin(s, n);
+         if (n == "system" || n == "matrix") s.system_open = true;
+      }
+      else s.pending_build += stats_end(s, n);
+      return g_err;
+   }
+   if (n == "prec" || n == "solve" || n == "reset_x0")
+   {
+      if (begin) stats_begin(s, n);
+      else
+      {
+         double dt = stats_end(s, n);
+         if (n == "prec") s.cur().prec += dt;
+         if (n == "solve") s.cur().solve += dt;
+      }
+      return g_err;
+   }
+   return err_set(ERR_UNKNOWN_TIMING, "unknown annotation '" + n + "'");
+}
+
+// ---------------------------------------------------------------- lifecycle
+
+extern "C" uint32_t HYPREDRV_Initialize(void)
+{
+   if (!g_initialized)
+   {
+      HYPRE_Initialize();
+      g_initialized = true;
+   }
+   return HYPREDRV_SUCCESS;
+}
+extern "C" uint32_t HYPREDRV_Finalize(void)
+{
+   if (g_initialized)
+   {
+      HYPRE_Finalize();
+      g_initialized = false;
+   }
+   return HYPREDRV_SUCCESS;
+}
+
+extern "C" uint32_t HYPREDRV_AMD_CommGetUniqueId(void *uid)
+{
+   err_reset();
+   API_TRY
+   rccl_get_unique_id(uid);
+   API_CATCH
+}
+extern "C" uint32_t HYPREDRV_AMD_CommInit(int rank, int world, int device, const void *uid)
+{
+   err_reset();
+   API_TRY
+   if (device >= 0) HDA_HIP(hipSetDevice(device));
+   if (world > 1) Comm::set_world(make_rccl_comm(rank, world, uid));
+   API_CATCH
+}
+typedef void (*hda_allreduce_cb_c)(void *, long, int, int);
+typedef void (*hda_alltoallv_cb_c)(const void *, const long *, void *, const long *);
+extern "C" HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_CommInitCallbacks(int rank, int world, int device, hda_allreduce_cb_c ar,
+                                                                          hda_alltoallv_cb_c a2a)
+{
+   err_reset();
+   API_TRY
+   if (device >= 0 && hipSetDevice(device) != hipSuccess) (void)hipGetLastError();
+   if (world > 1) Comm::set_world(make_callback_comm(rank, world, ar, a2a));
+   API_CATCH
+}
+extern "C" uint32_t HYPREDRV_AMD_CommFinalize(void)
+{
+   Comm::set_world(make_self_comm());
+   return HYPREDRV_SUCCESS;
+}
+
+extern "C" uint32_t HYPREDRV_Create(MPI_Comm comm, HYPREDRV_t *out)
+{
+   if (!g_initialized) return err_set(ERR_HYPREDRV_NOT_INITIALIZED);
+   if (!out) return err_set(ERR_UNKNOWN_HYPREDRV_OBJ);
+   auto *h      = new hypredrv_struct();
+   h->comm      = comm;
+   h->mypid     = Comm::world().rank;
+   h->nprocs    = Comm::world().size;
+   h->cookie    = PreconCookie{h};
+   h->args.precon_variants.push_back(PreconArgs());
+   *out = h;
+   return HYPREDRV_SUCCESS;
+}
+
+static void destroy_system(hypredrv_struct *h)
+{
+   if (h->owns_A && h->mat_A) HYPRE_IJMatrixDestroy(h->mat_A);
+   if (h->owns_b && h->vec_b) HYPRE_IJVectorDestroy(h->vec_b);
+   if (h->owns_x && h->vec_x) HYPRE_IJVectorDestroy(h->vec_x);
+   if (h->owns_x0 && h->vec_x0) HYPRE_IJVectorDestroy(h->vec_x0);
+   h->mat_A = h->mat_M = nullptr;
+   h->vec_b = h->vec_x = h->vec_x0 = nullptr;
+   h->owns_A = h->owns_b = h->owns_x = h->owns_x0 = false;
+}
+
+extern "C" uint32_t HYPREDRV_Destroy(HYPREDRV_t *hp)
+{
+   if (!hp || !*hp) return err_set(ERR_UNKNOWN_HYPREDRV_OBJ);
+   hypredrv_struct *h = *hp;
+   if (h->solver) { (h->args.solver.method == 1) ? HYPRE_ParCSRGMRESDestroy(h->solver) : HYPRE_ParCSRPCGDestroy(h->solver); }
+   if (h->precon) HYPRE_BoomerAMGDestroy(h->precon);
+   destroy_system(h);
+   delete h;
+   *hp = nullptr;
+   return HYPREDRV_SUCCESS;
+}
+
+extern "C" uint32_t HYPREDRV_PrintLibInfo(MPI_Comm, int print_datetime)
+{
+   if (Comm::world().rank) return HYPREDRV_SUCCESS;
+   if (print_datetime)
+   {
+      time_t t = time(nullptr);
+      char   buf[64];
+      strftime(buf, sizeof(buf), "%Y-%m-%d %H:%M:%S", localtime(&t));
+      printf("Date and time: %s\n", buf);
+   }
+   printf("\nUsing HYPREDRV_DEVELOP_STRING: %s\n\n", HYPREDRV_DEVELOP_STRING);
+   printf("Running on %d MPI rank%s\n", Comm::world().size, Comm::world().size > 1 ? "s" : "");
+   return HYPREDRV_SUCCESS;
+}
+extern "C" uint32_t HYPREDRV_PrintSystemInfo(MPI_Comm)
+{
+   if (Comm::world().rank) return HYPREDRV_SUCCESS;
+   int n = 0;
+   if (hipGetDeviceCount(&n) == hipSuccess && n > 0)
+   {
+      hipDeviceProp_t p;
+      if (hipGetDeviceProperties(&p, 0) == hipSuccess)
+         printf("GPU: %s (%s), %d CUs, %.1f GiB HBM; transport: %s\n", p.name, p.gcnArchName, p.multiProcessorCount,
+                (double)p.totalGlobalMem / (1 << 30), Comm::world().name());
+   }
+   else printf("GPU: none visible (the MI355X solve path cannot run)\n");
+   return HYPREDRV_SUCCESS;
+}
+extern "C" uint32_t HYPREDRV_PrintExitInfo(MPI_Comm, const char *argv0)
+{
+   if (Comm::world().rank) return HYPREDRV_SUCCESS;
+   time_t t = time(nullptr);
+   char   buf[64];
+   strftime(buf, sizeof(buf), "%Y-%m-%d %H:%M:%S", localtime(&t));
+   printf("Date and time: %s\n%s done!\n", buf, argv0 ? argv0 : "hypredrive");
+   return HYPREDRV_SUCCESS;
+}
+
+static bool file_exists(const std::string &p)
+{
+   struct stat st;
+   return stat(p.c_str(), &st) == 0;
+}
+
+extern "C" uint32_t HYPREDRV_InputArgsParse(int argc, char **argv, HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   if (argc < 1 || !argv || !argv[0]) return err_set(ERR_MISSING_KEY, "no YAML input given");
+   std::string text, first(argv[0]);
+   // argv[0] is a file name or the YAML text itself (reference src/internal/args.c:1478-1487)
+   if (first.find('\n') == std::string::npos && file_exists(first))
+   {
+      std::ifstream     f(first);
+      std::stringstream ss;
+      ss << f.rdbuf();
+      text = ss.str();
+   }
+   else if (first.find(':') != std::string::npos) text = first;
+   else return err_set(ERR_FILE_NOT_FOUND, "cannot open YAML input '" + first + "'");
+   h->tree = YNode();
+   std::string msg;
+   uint32_t    e = yaml_parse(text, h->tree, msg);
+   if (e) return err_set(e, msg);
+   // "-a|--args --path:to:key value ..." overrides (src/internal/main.c:23-31); a bare
+   // "--path:key value" pair is accepted too (examples/src/C_laplacian/laplacian.c:362-365)
+   for (int i = 1; i < argc; i++)
+   {
+      std::string a(argv[i]);
+      if (a == "-a" || a == "--args") continue;
+      if (a.rfind("--", 0) == 0 && a.find(':') != std::string::npos && i + 1 < argc)
+      {
+         yaml_override(h->tree, a, argv[i + 1]);
+         i++;
+      }
+   }
+   InputArgs fresh;
+   e = args_from_yaml(h->tree, h->lib_mode, fresh, msg);
+   if (e) return err_set(e, msg);
+   h->args               = fresh;
+   h->stats.use_millisec = h->args.general.use_millisec;
+   if (!h->args.general.name.empty()) h->name = h->args.general.name;
+   if (h->args.general.print_config_params && !h->mypid)
+   {
+      printf("------------------------------------------------------------------------------------\n");
+      yaml_print(h->tree, stdout);
+      printf("------------------------------------------------------------------------------------\n");
+   }
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_SetLibraryMode(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   h->lib_mode                         = true;
+   h->args.general.print_config_params = 0;
+   return HYPREDRV_SUCCESS;
+}
+extern "C" uint32_t HYPREDRV_ObjectSetName(HYPREDRV_t h, const char *name)
+{
+   CHECK_INIT_OBJ(h);
+   h->name = name ? name : "";
+   return HYPREDRV_SUCCESS;
+}
+extern "C" uint32_t HYPREDRV_InputArgsGetWarmup(HYPREDRV_t h, int *v) { CHECK_INIT_OBJ(h); *v = h->args.general.warmup; return HYPREDRV_SUCCESS; }
+extern "C" uint32_t HYPREDRV_InputArgsGetNumRepetitions(HYPREDRV_t h, int *v) { CHECK_INIT_OBJ(h); *v = h->args.general.num_repetitions; return HYPREDRV_SUCCESS; }
+extern "C" uint32_t HYPREDRV_InputArgsGetNumLinearSystems(HYPREDRV_t h, int *v) { CHECK_INIT_OBJ(h); *v = h->args.ls.num_systems; return HYPREDRV_SUCCESS; }
+extern "C" uint32_t HYPREDRV_InputArgsGetNumPreconVariants(HYPREDRV_t h, int *v) { CHECK_INIT_OBJ(h); *v = (int)h->args.precon_variants.size(); return HYPREDRV_SUCCESS; }
+extern "C" uint32_t HYPREDRV_InputArgsSetPreconVariant(HYPREDRV_t h, int idx)
+{
+   CHECK_INIT_OBJ(h);
+   if (idx < 0 || idx >= (int)h->args.precon_variants.size()) return err_set(ERR_OUT_OF_BOUNDS, "preconditioner variant index out of range");
+   h->args.active_variant = idx;
+   return HYPREDRV_SUCCESS;
+}
+
+static std::map<std::string, std::string> &user_presets(bool solver)
+{
+   static std::map<std::string, std::string> p[2];
+   return p[solver ? 1 : 0];
+}
+extern "C" uint32_t HYPREDRV_PreconPresetRegister(const char *name, const char *yaml, const char *)
+{
+   if (!name || !yaml) return err_set(ERR_INVALID_VAL, "preset needs a name and a YAML text");
+   user_presets(false)[name] = yaml;
+   return HYPREDRV_SUCCESS;
+}
+extern "C" uint32_t HYPREDRV_SolverPresetRegister(const char *name, const char *yaml, const char *)
+{
+   if (!name || !yaml) return err_set(ERR_INVALID_VAL, "preset needs a name and a YAML text");
+   user_presets(true)[name] = yaml;
+   return HYPREDRV_SUCCESS;
+}
+extern "C" uint32_t HYPREDRV_InputArgsSetPreconPreset(HYPREDRV_t h, const char *preset)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   if (!preset) return err_set(ERR_INVALID_VAL, "null preset");
+   std::string text = std::string("preset: ") + preset, msg;
+   auto        it   = user_presets(false).find(preset);
+   PreconArgs  p;
+   uint32_t    e;
+   if (it != user_presets(false).end()) e = precon_from_text(it->second, p, msg);
+   else
+   {
+      YNode root;
+      e = yaml_parse("preconditioner:\n  " + text + "\n", root, msg);
+      InputArgs tmp;
+      if (!e) e = args_from_yaml(root, true, tmp, msg);
+      if (!e) p = tmp.precon_variants[0];
+   }
+   if (e) return err_set(e, msg);
+   h->args.precon_variants.assign(1, p);
+   h->args.active_variant = 0;
+   h->args.has_precon     = true;
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_InputArgsSetSolverPreset(HYPREDRV_t h, const char *preset)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   if (!preset) return err_set(ERR_INVALID_VAL, "null preset");
+   std::string msg;
+   auto        it = user_presets(true).find(preset);
+   uint32_t    e  = solver_from_text(it != user_presets(true).end() ? it->second : std::string(preset), h->args.solver, msg);
+   if (e) return err_set(e, msg);
+   return g_err;
+}
+
+// ------------------------------------------------------------- linear system
+
+static std::string ls_path(const hypredrv_struct *h, const std::string &fn)
+{
+   if (fn.empty() || fn[0] == '/' || h->args.ls.dirname.empty()) return fn;
+   return h->args.ls.dirname + "/" + fn;
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemReadMatrix(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (h->args.ls.matrix_filename.empty()) return err_set(ERR_MISSING_KEY, "linear_system.matrix_filename is not set");
+   if (h->args.ls.type != 1) return err_set(ERR_MISSING_LIB, "only linear_system.type 'ij' (hypre ASCII IJ files) is supported");
+   annotate(h, "matrix", true);
+   if (h->owns_A && h->mat_A) HYPRE_IJMatrixDestroy(h->mat_A);
+   h->mat_A = nullptr;
+   const std::string path = ls_path(h, h->args.ls.matrix_filename);
+   if (HYPRE_IJMatrixRead(path.c_str(), h->comm, HYPRE_PARCSR, &h->mat_A))
+   {
+      annotate(h, "matrix", false);
+      const std::string why = hypre_last_error();
+      HYPRE_ClearAllErrors();
+      return err_set(why.find("cannot open") != std::string::npos ? ERR_FILE_NOT_FOUND : ERR_HYPRE_INTERNAL, why);
+   }
+   h->owns_A = true;
+   h->mat_M  = h->mat_A;
+   annotate(h, "matrix", false);
+   API_CATCH
+}
+
+static HYPRE_IJVector new_vector_like(hypredrv_struct *h, double value)
+{
+   HYPRE_IJVector v = nullptr;
+   HYPRE_IJVectorCreate(h->comm, h->mat_A->ilower, h->mat_A->iupper, &v);
+   HYPRE_IJVectorSetObjectType(v, HYPRE_PARCSR);
+   HYPRE_IJVectorInitialize(v);
+   HYPRE_ParVectorSetConstantValues(v, value);
+   return v;
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemSetMatrix(HYPREDRV_t h, HYPRE_Matrix A)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (h->owns_A && h->mat_A && h->mat_A != A) HYPRE_IJMatrixDestroy(h->mat_A);
+   h->mat_A  = A;
+   h->mat_M  = A;
+   h->owns_A = !h->lib_mode; // driver mode takes ownership (reference src/HYPREDRV.c:2013)
+   if (A && !A->assembled) HYPRE_IJMatrixAssemble(A);
+   consume_hypre_errors();
+   API_CATCH
+}
+extern "C" uint32_t HYPREDRV_LinearSystemSetPrecMatrix(HYPREDRV_t h, HYPRE_Matrix M)
+{
+   CHECK_INIT_OBJ(h);
+   h->mat_M = M ? M : h->mat_A;
+   return g_err;
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemSetRHS(HYPREDRV_t h, HYPRE_Vector vec)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (h->owns_b && h->vec_b && h->vec_b != vec) HYPRE_IJVectorDestroy(h->vec_b);
+   h->owns_b = false;
+   if (vec)
+   {
+      h->vec_b  = vec;
+      h->owns_b = !h->lib_mode;
+      if (!vec->assembled) HYPRE_IJVectorAssemble(vec);
+   }
+   else
+   { // built from the YAML input (reference src/internal/linsys.c:1779-1840)
+      if (!h->mat_A) return err_set(ERR_UNKNOWN, "SetRHS needs the matrix first");
+      annotate(h, "rhs", true);
+      const LSArgs &l = h->args.ls;
+      if (l.rhs_mode == 2 && !l.rhs_filename.empty())
+      {
+         const std::string path = ls_path(h, l.rhs_filename);
+         if (HYPRE_IJVectorRead(path.c_str(), h->comm, HYPRE_PARCSR, &h->vec_b))
+         {
+            annotate(h, "rhs", false);
+            const std::string why = hypre_last_error();
+            HYPRE_ClearAllErrors();
+            return err_set(why.find("cannot open") != std::string::npos ? ERR_FILE_NOT_FOUND : ERR_HYPRE_INTERNAL, why);
+         }
+      }
+      else if (l.rhs_mode == 0) h->vec_b = new_vector_like(h, 0.0);
+      else if (l.rhs_mode == 1 || l.rhs_mode == 2) h->vec_b = new_vector_like(h, 1.0);
+      else
+      {
+         annotate(h, "rhs", false);
+         return err_set(ERR_MISSING_LIB, "rhs_mode random/randsol is not supported by this build");
+      }
+      h->owns_b = true;
+      annotate(h, "rhs", false);
+   }
+   consume_hypre_errors();
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemSetInitialGuess(HYPREDRV_t h, HYPRE_Vector vec)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (!h->mat_A) return err_set(ERR_UNKNOWN, "SetInitialGuess needs the matrix first");
+   if (h->owns_x0 && h->vec_x0 && h->vec_x0 != vec) HYPRE_IJVectorDestroy(h->vec_x0);
+   if (h->owns_x && h->vec_x) HYPRE_IJVectorDestroy(h->vec_x);
+   h->owns_x0 = false;
+   if (vec)
+   {
+      h->vec_x0 = vec;
+      if (!vec->assembled) HYPRE_IJVectorAssemble(vec);
+   }
+   else
+   {
+      const LSArgs &l = h->args.ls;
+      if (l.init_guess_mode == 2 && !l.x0_filename.empty())
+      {
+         const std::string path = ls_path(h, l.x0_filename);
+         if (HYPRE_IJVectorRead(path.c_str(), h->comm, HYPRE_PARCSR, &h->vec_x0))
+         {
+            const std::string why = hypre_last_error();
+            HYPRE_ClearAllErrors();
+            return err_set(why.find("cannot open") != std::string::npos ? ERR_FILE_NOT_FOUND : ERR_HYPRE_INTERNAL, why);
+         }
+      }
+      else if (l.init_guess_mode == 1) h->vec_x0 = new_vector_like(h, 1.0);
+      else if (l.init_guess_mode == 0 || l.init_guess_mode == 2 || l.init_guess_mode == 4) h->vec_x0 = new_vector_like(h, 0.0);
+      else return err_set(ERR_MISSING_LIB, "init_guess_mode random is not supported by this build");
+      h->owns_x0 = true;
+   }
+   h->vec_x  = new_vector_like(h, 0.0);
+   h->owns_x = true;
+   HYPRE_ParVectorCopy(h->vec_x0, h->vec_x);
+   consume_hypre_errors();
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemResetInitialGuess(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (!h->vec_x || !h->vec_x0) return err_set(ERR_UNKNOWN, "ResetInitialGuess needs SetInitialGuess first");
+   annotate(h, "reset_x0", true);
+   h->stats.next_entry_if_used(); // entry indices advance on reset_x0 (reference stats.c:350-371)
+   HYPRE_ParVectorCopy(h->vec_x0, h->vec_x);
+   annotate(h, "reset_x0", false);
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemSetSolution(HYPREDRV_t h, HYPRE_Vector vec)
+{
+   CHECK_INIT_OBJ(h);
+   if (!vec) return g_err;
+   if (h->owns_x && h->vec_x && h->vec_x != vec) HYPRE_IJVectorDestroy(h->vec_x);
+   h->vec_x  = vec;
+   h->owns_x = false;
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_LinearSystemSetReferenceSolution(HYPREDRV_t h, HYPRE_Vector vec)
+{
+   CHECK_INIT_OBJ(h);
+   h->vec_xref = vec;
+   return g_err;
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemBuild(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   h->current_system_index++;
+   if (HYPREDRV_LinearSystemReadMatrix(h)) return g_err;
+   if (HYPREDRV_LinearSystemSetRHS(h, nullptr)) return g_err;
+   if (HYPREDRV_LinearSystemSetInitialGuess(h, nullptr)) return g_err;
+   HYPREDRV_LinearSystemSetPrecMatrix(h, nullptr);
+   h->stats.ls_counter++;
+   if (!h->mypid)
+   {
+      printf("====================================================================================\n");
+      printf("Solving linear system #%d with %lld rows and %lld nonzeros...\n", h->stats.ls_counter, h->mat_A->global_rows,
+             h->mat_A->global_nnz);
+   }
+   return g_err;
+}
+
+// CSR ingestion (reference src/internal/linsys.c:1190-1405): buffers are copied, the
+// resulting objects are always owned (include/HYPREDRV.h:830-834 there)
+extern "C" uint32_t HYPREDRV_LinearSystemSetMatrixFromCSR(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_BigInt row_end,
+                                                          const HYPRE_BigInt *indptr, const HYPRE_BigInt *cols,
+                                                          const HYPRE_Real *data)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   if (row_end < row_start - 1 || !indptr) return err_set(ERR_INVALID_VAL, "SetMatrixFromCSR: bad row range or null indptr");
+   const int n = (int)(row_end - row_start + 1);
+   if (n > 0 && (!cols || !data)) return err_set(ERR_INVALID_VAL, "SetMatrixFromCSR: null column or data array");
+   for (int i = 0; i < n; i++)
+      if (indptr[i + 1] < indptr[i]) return err_set(ERR_INVALID_VAL, "SetMatrixFromCSR: indptr must be non-decreasing");
+   annotate(h, "matrix", true);
+   if (h->owns_A && h->mat_A) HYPRE_IJMatrixDestroy(h->mat_A);
+   HYPRE_IJMatrix A = nullptr;
+   HYPRE_IJMatrixCreate(h->comm, row_start, row_end, row_start, row_end, &A);
+   HYPRE_IJMatrixSetObjectType(A, HYPRE_PARCSR);
+   HYPRE_IJMatrixInitialize(A);
+   const HYPRE_BigInt base = indptr[0];
+   const size_t       nnz  = (size_t)(indptr[n] - base);
+   A->t_row.resize(nnz); A->t_col.resize(nnz); A->t_val.resize(nnz); A->t_add.assign(nnz, 0);
+   for (int i = 0; i < n; i++)
+      for (HYPRE_BigInt k = indptr[i]; k < indptr[i + 1]; k++)
+      {
+         A->t_row[(size_t)(k - base)] = i;
+         A->t_col[(size_t)(k - base)] = cols[k];
+         A->t_val[(size_t)(k - base)] = data[k];
+      }
+   if (HYPRE_IJMatrixAssemble(A))
+   {
+      HYPRE_IJMatrixDestroy(A);
+      annotate(h, "matrix", false);
+      consume_hypre_errors();
+      return g_err;
+   }
+   h->mat_A = h->mat_M = A;
+   h->owns_A           = true;
+   annotate(h, "matrix", false);
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemSetRHSFromArray(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_BigInt row_end,
+                                                         const HYPRE_Real *values)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   const int n = (int)(row_end - row_start + 1);
+   if (n < 0 || (n > 0 && !values)) return err_set(ERR_INVALID_VAL, "SetRHSFromArray: bad range or null values");
+   annotate(h, "rhs", true);
+   if (h->owns_b && h->vec_b) HYPRE_IJVectorDestroy(h->vec_b);
+   HYPRE_IJVector b = nullptr;
+   HYPRE_IJVectorCreate(h->comm, row_start, row_end, &b);
+   HYPRE_IJVectorInitialize(b);
+   if (n) memcpy(b->stage.data(), values, sizeof(double) * (size_t)n);
+   HYPRE_IJVectorAssemble(b);
+   h->vec_b  = b;
+   h->owns_b = true;
+   annotate(h, "rhs", false);
+   consume_hypre_errors();
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_AMD_LinearSystemSetLaplacian7pt(HYPREDRV_t h, const int n[3], const int P[3], const double c[3])
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   Comm &cm = Comm::world();
+   HDA_REQUIRE(P[0] * P[1] * P[2] == cm.size, "processor grid does not match the number of ranks");
+   // MPI_Cart_create row-major rank -> block coordinates (laplacian.c:545-548)
+   int pc[3] = {cm.rank / (P[1] * P[2]), (cm.rank / P[2]) % P[1], cm.rank % P[2]};
+   long long st[3], ln[3];
+   for (int d = 0; d < 3; d++)
+   {
+      int size = n[d] / P[d], rest = n[d] - size * P[d];
+      auto start = [&](int j) { return (long long)size * j + (j < rest ? j : rest); };
+      st[d] = start(pc[d]);
+      ln[d] = start(pc[d] + 1) - st[d];
+   }
+   const long long nloc   = ln[0] * ln[1] * ln[2];
+   const long long ilower = st[0] * n[1] * n[2] + st[1] * n[2] * ln[0] + st[2] * ln[0] * ln[1];
+   annotate(h, "system", true);
+   destroy_system(h);
+   HYPRE_IJMatrix A = nullptr;
+   HYPRE_IJVector b = nullptr;
+   HYPRE_IJMatrixCreate(h->comm, ilower, ilower + nloc - 1, ilower, ilower + nloc - 1, &A);
+   HYPRE_IJVectorCreate(h->comm, ilower, ilower + nloc - 1, &b);
+   // count the entries of this block analytically: 7 per row minus missing neighbours on the global boundary
+   DArray<int>       rp((size_t)nloc + 1);
+   long long         nnz = 0;
+   {
+      auto faces = [&](int d, bool hi) { return hi ? (st[d] + ln[d] == n[d]) : (st[d] == 0); };
+      nnz        = 7 * nloc;
+      const long long area[3] = {ln[1] * ln[2], ln[0] * ln[2], ln[0] * ln[1]};
+      for (int d = 0; d < 3; d++) nnz -= ((faces(d, false) ? 1 : 0) + (faces(d, true) ? 1 : 0)) * area[d];
+   }
+   HDA_REQUIRE(nnz < (1LL << 31), "local nnz must fit int32");
+   DArray<long long> gc((size_t)nnz);
+   DArray<double>    gv((size_t)nnz);
+   b->d.alloc((size_t)nloc);
+   b->capacity = (size_t)nloc;
+   lap7_generate(n, P, pc, c, rp.data(), gc.data(), gv.data(), b->d.data(), (int)nloc);
+   b->initialized = b->assembled = true;
+   // ghost columns: the faces of neighbouring blocks; collect from the generated columns
+   if (cm.size > 1)
+   {
+      std::vector<long long> hc = gc.to_host();
+      std::vector<long long> gh;
+      for (long long v : hc)
+         if (v < ilower || v >= ilower + nloc) gh.push_back(v);
+      std::sort(gh.begin(), gh.end());
+      gh.erase(std::unique(gh.begin(), gh.end()), gh.end());
+      A->ghost_gids = gh;
+   }
+   A->initialized = true;
+   A->adopt_device((int)nloc, (int)nnz, rp, gc, gv);
+   h->mat_A = h->mat_M = A;
+   h->vec_b            = b;
+   h->owns_A = h->owns_b = true;
+   annotate(h, "system", false);
+   if (HYPREDRV_LinearSystemSetInitialGuess(h, nullptr)) return g_err;
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemGetSolutionValues(HYPREDRV_t h, HYPRE_Complex **data)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (!h->vec_x || !data) return err_set(ERR_UNKNOWN, "no solution vector");
+   HYPRE_IJVector x = h->vec_x;
+   x->host_mirror.resize((size_t)std::max(x->nloc, 1));
+   if (x->nloc) HDA_HIP(hipMemcpy(x->host_mirror.data(), x->data(), sizeof(double) * (size_t)x->nloc, hipMemcpyDeviceToHost));
+   *data = x->host_mirror.data();
+   API_CATCH
+}
+extern "C" uint32_t HYPREDRV_LinearSystemGetRHSValues(HYPREDRV_t h, HYPRE_Complex **data)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (!h->vec_b || !data) return err_set(ERR_UNKNOWN, "no right-hand side");
+   HYPRE_IJVector b = h->vec_b;
+   b->host_mirror.resize((size_t)std::max(b->nloc, 1));
+   if (b->nloc) HDA_HIP(hipMemcpy(b->host_mirror.data(), b->data(), sizeof(double) * (size_t)b->nloc, hipMemcpyDeviceToHost));
+   *data = b->host_mirror.data();
+   API_CATCH
+}
+extern "C" uint32_t HYPREDRV_LinearSystemGetSolutionLength(HYPREDRV_t h, HYPRE_BigInt *length)
+{
+   CHECK_INIT_OBJ(h);
+   if (!h->vec_x || !length) return err_set(ERR_UNKNOWN, "no solution vector");
+   *length = h->vec_x->nloc;
+   return g_err;
+}
+
+// L1 / L2 / Linf of the solution (reference src/internal/linsys.c:2815-2924; unknown type -> -1)
+extern "C" uint32_t HYPREDRV_LinearSystemGetSolutionNorm(HYPREDRV_t h, const char *norm_type, double *norm)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (!h->vec_x || !norm || !norm_type) return err_set(ERR_UNKNOWN, "no solution vector");
+   std::string t(norm_type);
+   for (auto &ch : t) ch = (char)tolower((unsigned char)ch);
+   if (t == "l2")
+   {
+      double p = 0.0;
+      HYPRE_ParVectorInnerProd(h->vec_x, h->vec_x, &p);
+      *norm = std::sqrt(p);
+   }
+   else if (t == "l1" || t == "linf")
+   {
+      HYPRE_Complex *d = nullptr;
+      HYPREDRV_LinearSystemGetSolutionValues(h, &d);
+      long long v[1];
+      double    acc = 0.0;
+      for (int i = 0; i < h->vec_x->nloc; i++) acc = (t == "l1") ? acc + std::fabs(d[i]) : std::max(acc, std::fabs(d[i]));
+      // cross-rank: sum (L1) or max (Linf) through the integer-collective on the bit pattern is
+      // not meaningful for doubles, so reduce through a one-element device all-reduce for L1
+      if (Comm::world().size > 1)
+      {
+         if (t == "l1")
+         {
+            DArray<double> s(1);
+            s.upload(&acc, 1);
+            Comm::world().allreduce_sum_dev(s.data(), 1);
+            s.download(&acc, 1);
+         }
+         else
+         { // non-negative doubles order like their bit patterns
+            memcpy(v, &acc, 8);
+            Comm::world().allreduce_host(v, 1, 1);
+            memcpy(&acc, v, 8);
+         }
+      }
+      *norm = acc;
+   }
+   else *norm = -1.0;
+   consume_hypre_errors();
+   API_CATCH
+}
+extern "C" uint32_t HYPREDRV_LinearSystemGetSolution(HYPREDRV_t h, HYPRE_Vector *vec) { CHECK_INIT_OBJ(h); *vec = h->vec_x; return g_err; }
+extern "C" uint32_t HYPREDRV_LinearSystemGetRHS(HYPREDRV_t h, HYPRE_Vector *vec) { CHECK_INIT_OBJ(h); *vec = h->vec_b; return g_err; }
+extern "C" uint32_t HYPREDRV_LinearSystemGetMatrix(HYPREDRV_t h, HYPRE_Matrix *mat) { CHECK_INIT_OBJ(h); *mat = h->mat_A; return g_err; }
+
+extern "C" uint32_t HYPREDRV_LinearSystemPrint(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (h->mat_A) HYPRE_IJMatrixPrint(h->mat_A, "IJ.out.A");
+   if (h->vec_b) HYPRE_IJVectorPrint(h->vec_b, "IJ.out.b");
+   consume_hypre_errors();
+   API_CATCH
+}
+
+// ------------------------------------------------- outside the AMG-Krylov hot path
+
+#define UNSUPPORTED(sig, what)                                                          \
+   extern "C" uint32_t sig                                                              \
+   {                                                                                    \
+      return err_set(HYPREDRV_ERROR_UNSUPPORTED_AMD, what " is outside the MI355X AMG-Krylov path of this build"); \
+   }
+UNSUPPORTED(HYPREDRV_LinearSystemSetDiscreteGradient(HYPREDRV_t, HYPRE_Matrix), "AMS/ADS discrete gradient")
+UNSUPPORTED(HYPREDRV_LinearSystemSetDiscreteCurl(HYPREDRV_t, HYPRE_Matrix), "ADS discrete curl")
+UNSUPPORTED(HYPREDRV_LinearSystemSetCoordinates(HYPREDRV_t, HYPRE_Vector, HYPRE_Vector, HYPRE_Vector), "AMS/ADS coordinates")
+UNSUPPORTED(HYPREDRV_LinearSystemSetDofmap(HYPREDRV_t, int, const int *), "MGR dofmap")
+UNSUPPORTED(HYPREDRV_LinearSystemSetInterleavedDofmap(HYPREDRV_t, int, int), "MGR dofmap")
+UNSUPPORTED(HYPREDRV_LinearSystemSetContiguousDofmap(HYPREDRV_t, int, int), "MGR dofmap")
+UNSUPPORTED(HYPREDRV_LinearSystemPrintDofmap(HYPREDRV_t, const char *), "MGR dofmap")
+UNSUPPORTED(HYPREDRV_LinearSystemSetNearNullSpace(HYPREDRV_t, int, int, const HYPRE_Complex *), "near-null-space vectors")
+UNSUPPORTED(HYPREDRV_LinearSystemSetNullSpace(HYPREDRV_t, int, int, const HYPRE_Complex *), "null-space projection")
+UNSUPPORTED(HYPREDRV_StateVectorSet(HYPREDRV_t, int, HYPRE_IJVector *), "state vectors")
+UNSUPPORTED(HYPREDRV_StateVectorGetValues(HYPREDRV_t, int, HYPRE_Complex **), "state vectors")
+UNSUPPORTED(HYPREDRV_StateVectorCopy(HYPREDRV_t, int, int), "state vectors")
+UNSUPPORTED(HYPREDRV_StateVectorUpdateAll(HYPREDRV_t), "state vectors")
+UNSUPPORTED(HYPREDRV_StateVectorApplyCorrection(HYPREDRV_t, int), "state vectors")
+UNSUPPORTED(HYPREDRV_AnnotateLevelBegin(HYPREDRV_t, int, const char *, int), "level annotations")
+UNSUPPORTED(HYPREDRV_AnnotateLevelEnd(HYPREDRV_t, int, const char *, int), "level annotations")
+UNSUPPORTED(HYPREDRV_StatsLevelGetCount(HYPREDRV_t, int, int *), "level statistics")
+UNSUPPORTED(HYPREDRV_StatsLevelGetEntry(HYPREDRV_t, int, int, int *, int *, int *, double *, double *), "level statistics")
+UNSUPPORTED(HYPREDRV_StatsLevelPrint(HYPREDRV_t, int), "level statistics")
+extern "C" uint32_t HYPREDRV_LinearSystemReadDofmap(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   if (!h->args.ls.dofmap_filename.empty()) return err_set(HYPREDRV_ERROR_UNSUPPORTED_AMD, "dofmap files (MGR) are not supported by this build");
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_LinearSystemComputeEigenspectrum(HYPREDRV_t h) { CHECK_INIT_OBJ(h); return g_err; } // no-op unless built with eigspec
+
+// ------------------------------------------------------------- THE HOT PATH
+
+// reference src/internal/solver.c:268-311: the Krylov setup calls back here; the "prec"
+// timer brackets exactly the AMG setup
+static HYPRE_Int PreconSetupDispatch(HYPRE_Solver cookie, HYPRE_Matrix A, HYPRE_Vector b, HYPRE_Vector x)
+{
+   hypredrv_struct *h = ((PreconCookie *)(void *)cookie)->self;
+   annotate(h, "prec", true);
+   HYPRE_Int ierr = HYPRE_BoomerAMGSetup(h->precon, A, b, x);
+   if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+   annotate(h, "prec", false);
+   h->precon_is_setup = (ierr == 0);
+   return ierr;
+}
+// reference src/internal/solver.c:314-329
+static HYPRE_Int PreconSolveDispatch(HYPRE_Solver cookie, HYPRE_Matrix A, HYPRE_Vector b, HYPRE_Vector x)
+{
+   hypredrv_struct *h = ((PreconCookie *)(void *)cookie)->self;
+   return HYPRE_BoomerAMGSolve(h->precon, A, b, x);
+}
+
+// hypredrv_AMGCreate (reference src/internal/amg.c:864-1035): same setter sequence
+static void amg_create(const AmgArgs &a, HYPRE_Solver *out)
+{
+   HYPRE_Solver p = nullptr;
+   HYPRE_BoomerAMGCreate(&p);
+   HYPRE_BoomerAMGSetInterpType(p, a.prolongation_type);
+   HYPRE_BoomerAMGSetRestriction(p, a.restriction_type);
+   HYPRE_BoomerAMGSetStrongThresholdR(p, a.restrict_strong_th);
+   HYPRE_BoomerAMGSetFilterThresholdR(p, a.restrict_filter_th);
+   HYPRE_BoomerAMGSetCoarsenType(p, a.type);
+   HYPRE_BoomerAMGSetSabs(p, a.sabs);
+   HYPRE_BoomerAMGSetTol(p, a.tolerance);
+   HYPRE_BoomerAMGSetStrongThreshold(p, a.strong_th);
+   HYPRE_BoomerAMGSetSeqThreshold(p, a.seq_amg_th);
+   HYPRE_BoomerAMGSetMaxCoarseSize(p, a.max_coarse_size);
+   HYPRE_BoomerAMGSetMinCoarseSize(p, a.min_coarse_size);
+   HYPRE_BoomerAMGSetTruncFactor(p, a.trunc_factor);
+   HYPRE_BoomerAMGSetPMaxElmts(p, a.max_nnz_row);
+   HYPRE_BoomerAMGSetPrintLevel(p, a.print_level);
+   if (a.relax_type >= 0) HYPRE_BoomerAMGSetRelaxType(p, a.relax_type);
+   HYPRE_BoomerAMGSetRelaxOrder(p, a.order);
+   HYPRE_BoomerAMGSetRelaxWt(p, a.weight);
+   HYPRE_BoomerAMGSetOuterWt(p, a.outer_weight);
+   HYPRE_BoomerAMGSetMaxLevels(p, a.max_levels);
+   HYPRE_BoomerAMGSetSmoothType(p, a.smooth_type);
+   HYPRE_BoomerAMGSetSmoothNumSweeps(p, a.smooth_num_sweeps);
+   HYPRE_BoomerAMGSetSmoothNumLevels(p, a.smooth_num_levels);
+   HYPRE_BoomerAMGSetMaxRowSum(p, a.max_row_sum);
+   HYPRE_BoomerAMGSetNumFunctions(p, a.nodal ? 3 : a.num_functions);
+   HYPRE_BoomerAMGSetFilterFunctions(p, a.filter_functions);
+   HYPRE_BoomerAMGSetAggNumLevels(p, a.agg_num_levels);
+   HYPRE_BoomerAMGSetAggInterpType(p, a.agg_prolongation_type);
+   HYPRE_BoomerAMGSetAggTruncFactor(p, a.agg_trunc_factor);
+   HYPRE_BoomerAMGSetAggP12TruncFactor(p, a.agg_P12_trunc_factor);
+   HYPRE_BoomerAMGSetAggPMaxElmts(p, a.agg_max_nnz_row);
+   HYPRE_BoomerAMGSetAggP12MaxElmts(p, (int)a.agg_P12_max_elements);
+   HYPRE_BoomerAMGSetNumPaths(p, a.agg_num_paths);
+   HYPRE_BoomerAMGSetMaxIter(p, a.max_iter);
+   HYPRE_BoomerAMGSetRAP2(p, a.rap2);
+   HYPRE_BoomerAMGSetModuleRAP2(p, a.mod_rap2);
+   HYPRE_BoomerAMGSetKeepTranspose(p, a.keep_transpose);
+   HYPRE_BoomerAMGSetCycleRelaxType(p, a.down_type, 1);
+   HYPRE_BoomerAMGSetCycleNumSweeps(p, a.down_sweeps > -1 ? a.down_sweeps : a.num_sweeps, 1);
+   HYPRE_BoomerAMGSetCycleRelaxType(p, a.up_type, 2);
+   HYPRE_BoomerAMGSetCycleNumSweeps(p, a.up_sweeps > -1 ? a.up_sweeps : a.num_sweeps, 2);
+   HYPRE_BoomerAMGSetCycleRelaxType(p, a.coarse_type, 3);
+   HYPRE_BoomerAMGSetCycleNumSweeps(p, a.coarse_sweeps > -1 ? a.coarse_sweeps : a.num_sweeps, 3);
+   *out = p;
+}
+
+extern "C" uint32_t HYPREDRV_PreconCreate(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   if (h->precon) { HYPRE_BoomerAMGDestroy(h->precon); h->precon = nullptr; }
+   h->precon_is_setup  = false;
+   const PreconArgs &p = h->args.precon();
+   if (p.method == 99) return g_err; // none
+   if (p.method != 0)
+      return err_set(ERR_INVALID_PRECON | HYPREDRV_ERROR_UNSUPPORTED_AMD,
+                     "preconditioner '" + p.method_name + "' is not implemented on MI355X yet (BoomerAMG only)");
+   amg_create(p.amg, &h->precon);
+   consume_hypre_errors();
+   API_CATCH
+}
+
+// hypredrv_PCGCreate / hypredrv_GMRESCreate (reference src/internal/pcg.c:55-72, gmres.c:59-77)
+extern "C" uint32_t HYPREDRV_LinearSolverCreate(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   // LinearSolverCreate creates the preconditioner too when the caller did not (src/HYPREDRV.c:2914-2917)
+   if (!h->precon && h->args.precon().method != 99)
+   {
+      if (HYPREDRV_PreconCreate(h)) return g_err;
+   }
+   if (h->solver) { (h->solver->kind == HDA_SOLVER_GMRES) ? HYPRE_ParCSRGMRESDestroy(h->solver) : HYPRE_ParCSRPCGDestroy(h->solver); h->solver = nullptr; }
+   const KrylovArgs &k = h->args.solver;
+   if (k.method == 0)
+   {
+      HYPRE_ParCSRPCGCreate(h->comm, &h->solver);
+      HYPRE_PCGSetMaxIter(h->solver, k.max_iter);
+      HYPRE_PCGSetTwoNorm(h->solver, k.two_norm);
+      HYPRE_PCGSetStopCrit(h->solver, k.stop_crit);
+      HYPRE_PCGSetRelChange(h->solver, k.rel_change);
+      HYPRE_PCGSetPrintLevel(h->solver, k.print_level);
+      HYPRE_PCGSetRecomputeResidual(h->solver, k.recompute_res);
+      HYPRE_PCGSetTol(h->solver, k.relative_tol);
+      HYPRE_PCGSetAbsoluteTol(h->solver, k.absolute_tol);
+      HYPRE_PCGSetResidualTol(h->solver, k.residual_tol);
+      HYPRE_PCGSetConvergenceFactorTol(h->solver, k.conv_fac_tol);
+   }
+   else if (k.method == 1)
+   {
+      HYPRE_ParCSRGMRESCreate(h->comm, &h->solver);
+      HYPRE_GMRESSetMinIter(h->solver, k.min_iter);
+      HYPRE_GMRESSetMaxIter(h->solver, k.max_iter);
+      HYPRE_GMRESSetStopCrit(h->solver, k.stop_crit);
+      HYPRE_GMRESSetSkipRealResidualCheck(h->solver, k.skip_real_res_check);
+      HYPRE_GMRESSetKDim(h->solver, k.krylov_dim);
+      HYPRE_GMRESSetRelChange(h->solver, k.rel_change);
+      HYPRE_GMRESSetLogging(h->solver, k.logging);
+      HYPRE_GMRESSetPrintLevel(h->solver, k.print_level);
+      HYPRE_GMRESSetTol(h->solver, k.relative_tol);
+      HYPRE_GMRESSetAbsoluteTol(h->solver, k.absolute_tol);
+      HYPRE_GMRESSetConvergenceFactorTol(h->solver, k.conv_fac_tol);
+   }
+   else
+      return err_set(ERR_INVALID_SOLVER | HYPREDRV_ERROR_UNSUPPORTED_AMD, "only PCG and GMRES are implemented on MI355X (fgmres/bicgstab are not)");
+   consume_hypre_errors();
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_PreconSetup(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   if (!h->precon) return err_set(ERR_INVALID_PRECON, "PreconSetup: no preconditioner (call PreconCreate)");
+   if (!h->mat_A || !h->vec_b || !h->vec_x) return err_set(ERR_UNKNOWN, "PreconSetup: linear system is incomplete");
+   h->stats.next_entry_if_used();
+   PreconSetupDispatch((HYPRE_Solver)(void *)&h->cookie, h->mat_M ? h->mat_M : h->mat_A, h->vec_b, h->vec_x);
+   consume_hypre_errors();
+   API_CATCH
+}
+
+// reference src/HYPREDRV.c:3001-3119 -> hypredrv_SolverSetupWithReuse (src/internal/solver.c:457-546)
+extern "C" uint32_t HYPREDRV_LinearSolverSetup(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   if (!h->solver) return err_set(ERR_INVALID_SOLVER, "LinearSolverSetup: solver is NULL (call LinearSolverCreate)");
+   if (!h->mat_A || !h->vec_b || !h->vec_x) return err_set(ERR_UNKNOWN, "LinearSolverSetup: matrix, rhs or solution vector is missing");
+   h->stats.next_entry_if_used();
+   if (h->stats.pending_build > 0.0)
+   {
+      h->stats.cur().build += h->stats.pending_build;
+      h->stats.pending_build = 0.0;
+   }
+   HYPRE_Matrix M = h->mat_M ? h->mat_M : h->mat_A;
+   const auto t0  = clk::now();
+   if (h->precon)
+   {
+      if (h->solver->kind == HDA_SOLVER_GMRES)
+         HYPRE_GMRESSetPrecond(h->solver, PreconSolveDispatch, PreconSetupDispatch, (HYPRE_Solver)(void *)&h->cookie);
+      else
+         HYPRE_PCGSetPrecond(h->solver, PreconSolveDispatch, PreconSetupDispatch, (HYPRE_Solver)(void *)&h->cookie);
+   }
+   if (h->solver->kind == HDA_SOLVER_GMRES) HYPRE_ParCSRGMRESSetup(h->solver, M, h->vec_b, h->vec_x);
+   else HYPRE_ParCSRPCGSetup(h->solver, M, h->vec_b, h->vec_x);
+   h->last_setup_s = std::chrono::duration<double>(clk::now() - t0).count();
+   consume_hypre_errors();
+   API_CATCH
+}
+
+static double residual_norm(hypredrv_struct *h)
+{
+   HYPRE_IJVector r = new_vector_like(h, 0.0);
+   HYPRE_ParVectorCopy(h->vec_b, r);
+   HYPRE_ParCSRMatrixMatvec(-1.0, h->mat_A, h->vec_x, 1.0, r);
+   double p = 0.0;
+   HYPRE_ParVectorInnerProd(r, r, &p);
+   HYPRE_IJVectorDestroy(r);
+   return std::sqrt(p);
+}
+
+// reference src/HYPREDRV.c:3126-3338 -> hypredrv_SolverApply (src/internal/solver.c:627-693)
+extern "C" uint32_t HYPREDRV_LinearSolverApply(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   if (!h->solver) return err_set(ERR_INVALID_SOLVER, "LinearSolverApply: solver is NULL");
+   if (h->args.precon().method != 99 && (!h->precon || !h->precon_is_setup))
+      return err_set(ERR_INVALID_PRECON, "Linear solver apply requires a successfully set up preconditioner; check the preceding setup error");
+   if (!h->mat_A || !h->vec_b || !h->vec_x) return err_set(ERR_UNKNOWN, "SolverApply: matrix or vector is NULL");
+   const double r0 = residual_norm(h); // untimed (solver.c:666)
+   annotate(h, "solve", true);
+   h->stats.cur().r0 = r0;
+   HYPRE_Int ierr;
+   if (h->solver->kind == HDA_SOLVER_GMRES) ierr = HYPRE_ParCSRGMRESSolve(h->solver, h->mat_A, h->vec_b, h->vec_x);
+   else ierr = HYPRE_ParCSRPCGSolve(h->solver, h->mat_A, h->vec_b, h->vec_x);
+   if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+   HYPRE_Int  iters = 0, conv = 0;
+   HYPRE_Real frel  = 0.0;
+   if (h->solver->kind == HDA_SOLVER_GMRES)
+   {
+      HYPRE_GMRESGetNumIterations(h->solver, &iters);
+      HYPRE_GMRESGetConverged(h->solver, &conv);
+      HYPRE_GMRESGetFinalRelativeResidualNorm(h->solver, &frel);
+   }
+   else
+   {
+      HYPRE_PCGGetNumIterations(h->solver, &iters);
+      HYPRE_PCGGetConverged(h->solver, &conv);
+      HYPRE_PCGGetFinalRelativeResidualNorm(h->solver, &frel);
+   }
+   h->stats.cur().iters     = ierr ? 0 : iters;
+   h->stats.cur().has_solve = true;
+   annotate(h, "solve", false);
+   h->last_solve_s   = h->stats.cur().solve;
+   h->last_iters     = iters;
+   h->last_converged = conv;
+   h->last_rel       = frel;
+   if (!ierr)
+   { // true relative residual, untimed (solver.c:686-690)
+      double bn = 0.0;
+      HYPRE_ParVectorInnerProd(h->vec_b, h->vec_b, &bn);
+      bn = std::sqrt(bn);
+      h->stats.cur().rr = residual_norm(h) / (bn > 0.0 ? bn : 1.0);
+   }
+   consume_hypre_errors(); // non-convergence is not an error
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_PreconApply(HYPREDRV_t h, HYPRE_Vector b, HYPRE_Vector x)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   if (!h->precon || !h->precon_is_setup) return err_set(ERR_INVALID_PRECON, "PreconApply requires a set-up preconditioner");
+   HYPRE_BoomerAMGSolve(h->precon, h->mat_M ? h->mat_M : h->mat_A, b, x);
+   consume_hypre_errors();
+   API_CATCH
+}
+extern "C" uint32_t HYPREDRV_PreconDestroy(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   if (h->precon) HYPRE_BoomerAMGDestroy(h->precon);
+   h->precon          = nullptr;
+   h->precon_is_setup = false;
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_LinearSolverDestroy(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   if (h->solver) { (h->solver->kind == HDA_SOLVER_GMRES) ? HYPRE_ParCSRGMRESDestroy(h->solver) : HYPRE_ParCSRPCGDestroy(h->solver); }
+   h->solver = nullptr;
+   // library mode destroys the preconditioner together with the solver (src/HYPREDRV.c:3463-3496)
+   if (h->precon) HYPRE_BoomerAMGDestroy(h->precon);
+   h->precon          = nullptr;
+   h->precon_is_setup = false;
+   return g_err;
+}
+
+// ------------------------------------------------------------ stats / getters
+
+extern "C" uint32_t HYPREDRV_AnnotateBegin(HYPREDRV_t h, const char *name, int) { CHECK_INIT_OBJ(h); return annotate(h, name, true); }
+extern "C" uint32_t HYPREDRV_AnnotateEnd(HYPREDRV_t h, const char *name, int) { CHECK_INIT_OBJ(h); return annotate(h, name, false); }
+
+// table layout of the reference: src/internal/stats.c:533-536,648-657,1234-1361
+extern "C" uint32_t HYPREDRV_StatsPrint(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   if (!h->args.general.statistics) return g_err;
+   const Stats &s     = h->stats;
+   const double tf    = s.use_millisec ? 1000.0 : 1.0;
+   const char  *scale = s.use_millisec ? "[ms]" : "[s]";
+   const int    w[7]  = {10, 11, 11, 11, 10, 10, 6};
+   auto divisor = [&]() {
+      for (int i = 0; i < 7; i++)
+      {
+         putchar('+');
+         for (int j = 0; j < w[i] + 2; j++) putchar('-');
+      }
+      printf("+\n");
+   };
+   printf("====================================================================================\n");
+   if (!h->name.empty()) printf("\n\nSTATISTICS SUMMARY for %s:\n\n", h->name.c_str());
+   else printf("\n\nSTATISTICS SUMMARY:\n\n");
+   divisor();
+   printf("| %*s | %*s | %*s | %*s | %*s | %*s | %*s |\n", w[0], "", w[1], "LS build", w[2], "setup", w[3], "solve", w[4], "initial",
+          w[5], "relative", w[6], "");
+   char t1[32];
+   snprintf(t1, sizeof(t1), "times %s", scale);
+   printf("| %*s | %*s | %*s | %*s | %*s | %*s | %*s |\n", w[0], "Entry", w[1], t1, w[2], t1, w[3], t1, w[4], "res. norm", w[5],
+          "res. norm", w[6], "iters");
+   divisor();
+   int idx = 0;
+   for (const StatEntry &e : s.entries)
+   {
+      if (!e.has_solve) continue;
+      char label[16];
+      snprintf(label, sizeof(label), "%d", idx++);
+      if (e.build > 0.0)
+         printf("| %*s | %*.*f | %*.*f | %*.*f | %*.*e | %*.*e | %*d |\n", w[0], label, w[1], 3, tf * e.build, w[2], 3, tf * e.prec, w[3], 3,
+                tf * e.solve, w[4], 2, e.r0, w[5], 2, e.rr, w[6], e.iters);
+      else
+         printf("| %*s | %*s | %*.*f | %*.*f | %*.*e | %*.*e | %*d |\n", w[0], label, w[1], "", w[2], 3, tf * e.prec, w[3], 3, tf * e.solve,
+                w[4], 2, e.r0, w[5], 2, e.rr, w[6], e.iters);
+   }
+   divisor();
+   printf("\n");
+   return g_err;
+}
+
+extern "C" uint32_t HYPREDRV_LinearSolverGetNumIter(HYPREDRV_t h, int *iters) { CHECK_INIT_OBJ(h); if (iters) *iters = h->last_iters; return g_err; }
+extern "C" uint32_t HYPREDRV_LinearSolverGetConverged(HYPREDRV_t h, int *c) { CHECK_INIT_OBJ(h); if (c) *c = h->last_converged; return g_err; }
+extern "C" uint32_t HYPREDRV_LinearSolverGetFinalRelativeResidualNorm(HYPREDRV_t h, double *n) { CHECK_INIT_OBJ(h); if (n) *n = h->last_rel; return g_err; }
+extern "C" uint32_t HYPREDRV_LinearSolverGetSetupTime(HYPREDRV_t h, double *s) { CHECK_INIT_OBJ(h); if (s) *s = h->stats.cur().prec; return g_err; }
+extern "C" uint32_t HYPREDRV_LinearSolverGetSolveTime(HYPREDRV_t h, double *s) { CHECK_INIT_OBJ(h); if (s) *s = h->last_solve_s; return g_err; }

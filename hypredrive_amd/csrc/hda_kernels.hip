@@ -8,6 +8,8 @@
 // fused into the kernel that already streams the operands.
 #include "hda_kernels.h"
 
+#include "hda_comm.h"
+
 #include <algorithm>
 #include <cmath>
 #include <map>
@@ -151,6 +153,9 @@ void finalize_n(int first_slot, int nslots, int first_scalar)
 {
    Context &c = Context::get();
    k_finalize<<<nslots, kRedThreads, 0, c.stream>>>(c.partials, first_slot, c.scalars, first_scalar);
+   // row-partitioned: the scalars are partial sums of this rank's rows (C2: one fused all-reduce)
+   Comm &cm = Comm::world();
+   if (cm.size > 1) cm.allreduce_sum_dev(c.scalars + first_scalar, nslots);
 }
 void finalize(int slot, int scalar_idx) { finalize_n(slot, 1, scalar_idx); }
 

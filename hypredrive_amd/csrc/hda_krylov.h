@@ -35,10 +35,22 @@ struct KrylovResult {
 // partials of <r, z> in that slot (lets the V-cycle's last sweep fuse PCG's <r, z>).
 using PrecondFn = std::function<void(const double *r, double *z, int dot_slot)>;
 
+// The operator a Krylov solver sees: this rank's row block, the plan that refreshes the
+// ghost tail of its input vector (null on one rank) and the length work vectors need
+// (>= A.ncols and >= the preconditioner's level-0 vector length).
+struct LinOp {
+   const DCsr     *A      = nullptr;
+   const HaloPlan *halo   = nullptr;
+   size_t          veclen = 0;
+   LinOp() = default;
+   LinOp(const DCsr &a) : A(&a), veclen((size_t)std::max(a.ncols, a.nrows)) {}
+   LinOp(const DCsr &a, const HaloPlan *h, size_t len) : A(&a), halo(h), veclen(std::max(len, (size_t)std::max(a.ncols, a.nrows))) {}
+};
+
 // hypre_PCGSolve (reached from solver_ops[SOLVER_PCG].solve, src/internal/solver.c:211)
-KrylovResult pcg(const DCsr &A, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
+KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
 // hypre_GMRESSolve (solver_ops[SOLVER_GMRES], src/internal/solver.c:217-228)
-KrylovResult gmres(const DCsr &A, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
+KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
 
 // algorithmic HBM bytes of one PCG iteration excluding the preconditioner
 double pcg_iteration_bytes(const DCsr &A);

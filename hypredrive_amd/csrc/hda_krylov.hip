@@ -15,13 +15,15 @@ double pcg_iteration_bytes(const DCsr &A)
    return (12.0 * A.nnz + 4.0 * (n + 1) + 8.0 * A.ncols + 8.0 * n) + 8.0 * n + 48.0 * n + 24.0 * n;
 }
 
-KrylovResult pcg(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
+KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
 {
    Context     &ctx = Context::get();
+   const DCsr  &A   = *op.A;
    const int    n   = A.nrows;
    KrylovResult res;
-   DArray<double> r((size_t)std::max(n, 1)), p((size_t)std::max(A.ncols, 1)), s((size_t)std::max(n, 1));
-   if (A.ncols > n) p.zero(); // ghost tail of the search direction
+   const size_t vl = std::max<size_t>(op.veclen, 1);
+   DArray<double> r(vl), p(vl), s(vl);
+   auto refresh = [&](double *v) { if (op.halo) halo_exchange(*op.halo, v); };
 
    auto precond = [&](const double *rr, double *zz, int slot) {
       if (M) M(rr, zz, slot);
@@ -57,8 +59,10 @@ KrylovResult pcg(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, cons
       const double a2 = kp.atol * kp.atol / bi_prod;
       if (a2 > eps) eps = a2;
    }
-   // r = b - A x ; p = C r ; gamma = <r,p>
-   residual(A, x, b, r.data());
+   // r = b - A x ; p = C r ; gamma = <r,p>   (x has no ghost tail: stage it through p)
+   copy(n, x, p.data());
+   refresh(p.data());
+   residual(A, p.data(), b, r.data());
    precond(r.data(), p.data(), 2);
    finalize(2, S_GAMMA0);
    dot(n, r.data(), r.data(), 1);
@@ -73,6 +77,7 @@ KrylovResult pcg(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, cons
    {
       it++;
       const int go = S_GAMMA0 + ((it - 1) & 1), gn = S_GAMMA0 + (it & 1);
+      refresh(p.data());
       if (kp.profile_k1)
       {
          hipEvent_t e0, e1;
@@ -129,17 +134,23 @@ KrylovResult pcg(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, cons
    return res;
 }
 
-KrylovResult gmres(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
+KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
 {
    Context     &ctx = Context::get();
+   const DCsr  &A   = *op.A;
    const int    n = A.nrows, k = std::max(kp.krylov_dim, 1);
    KrylovResult res;
    HDA_REQUIRE(S_GMRES + k + 2 <= Context::kNumScalars, "krylov_dim too large for the scalar block");
-   const size_t vlen = (size_t)std::max(A.ncols, 1);
+   const size_t vlen = std::max<size_t>(op.veclen, 1);
    std::vector<DArray<double>> V((size_t)k + 1);
-   for (auto &v : V) v.alloc((size_t)std::max(n, 1));
+   for (auto &v : V) v.alloc(vlen);
    DArray<double> w(vlen), r(vlen);
-   if (A.ncols > n) { w.zero(); r.zero(); }
+   auto refresh = [&](double *v) { if (op.halo) halo_exchange(*op.halo, v); };
+   auto true_residual = [&](double *out) { // out = b - A x, x staged through w for its ghost tail
+      copy(n, x, w.data());
+      refresh(w.data());
+      residual(A, w.data(), b, out);
+   };
    std::vector<double> H((size_t)(k + 1) * k, 0.0), cs((size_t)k), sn((size_t)k), rs((size_t)k + 1);
 
    auto precond = [&](const double *rr, double *zz) {
@@ -152,7 +163,7 @@ KrylovResult gmres(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, co
       return std::sqrt(read_scalar(S_TMP));
    };
    const double b_norm = norm2(b);
-   residual(A, x, b, V[0].data());
+   true_residual(V[0].data());
    double r_norm         = norm2(V[0].data());
    const double den_norm = (b_norm > 0.0) ? b_norm : r_norm;
    double       epsilon  = std::max(kp.atol, kp.rtol * den_norm);
@@ -168,7 +179,7 @@ KrylovResult gmres(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, co
       rs[0] = r_norm;
       if (r_norm <= epsilon && iter >= kp.min_iter && iter > 0)
       {
-         residual(A, x, b, r.data());
+         true_residual(r.data());
          r_norm = norm2(r.data());
          if (r_norm <= epsilon) { res.converged = true; break; }
          copy(n, r.data(), V[0].data());
@@ -181,6 +192,7 @@ KrylovResult gmres(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, co
          i++;
          iter++;
          precond(V[i - 1].data(), r.data());
+         refresh(r.data());
          spmv(A, 1.0, r.data(), 0.0, nullptr, V[i].data());
          // modified Gram-Schmidt with the coefficients kept on the device
          for (int j = 0; j < i; j++)
@@ -227,7 +239,7 @@ KrylovResult gmres(const DCsr &A, const PrecondFn &M, const KrylovParams &kp, co
       for (int j = i - 2; j >= 0; j--) axpy(n, rs[j], V[j].data(), w.data());
       precond(w.data(), r.data());
       axpy(n, 1.0, r.data(), x);
-      residual(A, x, b, V[0].data());
+      true_residual(V[0].data());
       const double true_norm = norm2(V[0].data());
       if (r_norm <= epsilon)
       {

@@ -1,0 +1,609 @@
+// hda_yaml.cpp -- YAML-subset parser and argument mapping (see hda_yaml.h).
+// Own implementation of the grammar documented in SURVEY.md App. B; the key names and the
+// string->enum maps are the reference's input contract (src/internal/amg.c:23-90,245-459,
+// src/internal/pcg.c:15-25, src/internal/gmres.c:16-27, src/internal/args.c:30-45,
+// src/internal/linsys.c:290-320,360-385).
+#include "hda_yaml.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+
+namespace hda {
+
+static std::string trim(const std::string &s)
+{
+   size_t a = 0, b = s.size();
+   while (a < b && isspace((unsigned char)s[a])) a++;
+   while (b > a && isspace((unsigned char)s[b - 1])) b--;
+   return s.substr(a, b - a);
+}
+static std::string lower(std::string s)
+{
+   for (auto &c : s) c = (char)tolower((unsigned char)c);
+   return s;
+}
+static std::string unquote(const std::string &s)
+{
+   if (s.size() >= 2 && ((s.front() == '"' && s.back() == '"') || (s.front() == '\'' && s.back() == '\''))) return s.substr(1, s.size() - 2);
+   return s;
+}
+static bool keeps_case(const std::string &key)
+{
+   return key.find("filename") != std::string::npos || key.find("dirname") != std::string::npos ||
+          key.find("basename") != std::string::npos || key == "name";
+}
+
+YNode *YNode::find(const std::string &k)
+{
+   for (auto &c : kids)
+      if (c->key == k) return c.get();
+   return nullptr;
+}
+YNode *YNode::get_or_add(const std::string &k)
+{
+   if (YNode *n = find(k)) return n;
+   kids.emplace_back(new YNode());
+   kids.back()->key = k;
+   return kids.back().get();
+}
+
+static void set_keyval(YNode &n, const std::string &rawkey, const std::string &rawval)
+{
+   n.key = lower(trim(rawkey));
+   std::string v = unquote(trim(rawval));
+   n.val         = keeps_case(n.key) ? v : lower(v);
+}
+
+// "{a: b, c: d}" -> children of n
+static void parse_flow(YNode &n, const std::string &flow)
+{
+   std::string body = trim(flow);
+   if (body.size() >= 2 && body.front() == '{' && body.back() == '}') body = body.substr(1, body.size() - 2);
+   size_t pos = 0;
+   int    depth = 0;
+   std::string cur;
+   auto flush = [&]() {
+      std::string item = trim(cur);
+      cur.clear();
+      if (item.empty()) return;
+      size_t c = item.find(':');
+      n.kids.emplace_back(new YNode());
+      if (c == std::string::npos) set_keyval(*n.kids.back(), item, "");
+      else
+      {
+         std::string v = trim(item.substr(c + 1));
+         if (!v.empty() && v.front() == '{')
+         {
+            set_keyval(*n.kids.back(), item.substr(0, c), "");
+            parse_flow(*n.kids.back(), v);
+         }
+         else set_keyval(*n.kids.back(), item.substr(0, c), v);
+      }
+   };
+   for (; pos < body.size(); pos++)
+   {
+      char ch = body[pos];
+      if (ch == '{' || ch == '[') depth++;
+      if (ch == '}' || ch == ']') depth--;
+      if (ch == ',' && depth == 0) flush();
+      else cur.push_back(ch);
+   }
+   flush();
+}
+
+uint32_t yaml_parse(const std::string &text, YNode &root, std::string &message)
+{
+   struct Frame {
+      int    level;
+      YNode *node;
+   };
+   std::vector<Frame> stack{{-1, &root}};
+   int                base = 0, lineno = 0;
+   size_t             p = 0;
+   while (p <= text.size())
+   {
+      size_t      e = text.find('\n', p);
+      std::string line = text.substr(p, e == std::string::npos ? std::string::npos : e - p);
+      p = (e == std::string::npos) ? text.size() + 1 : e + 1;
+      lineno++;
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      size_t hash = line.find('#');
+      if (hash != std::string::npos) line = line.substr(0, hash);
+      size_t ind = 0;
+      while (ind < line.size() && (line[ind] == ' ' || line[ind] == '\t'))
+      {
+         if (line[ind] == '\t')
+         {
+            message = "line " + std::to_string(lineno) + ": tab used for indentation";
+            return ERR_YAML_MIXED_INDENT;
+         }
+         ind++;
+      }
+      std::string content = trim(line);
+      if (content.empty()) continue;
+      if (ind > 0 && base == 0) base = (int)ind;
+      if (base && ind % (size_t)base)
+      {
+         message = "line " + std::to_string(lineno) + ": indentation is not a multiple of " + std::to_string(base);
+         return ERR_YAML_INVALID_INDENT;
+      }
+      int level = base ? (int)ind / base : 0;
+      while (stack.size() > 1 && stack.back().level >= level) stack.pop_back();
+      if (level > stack.back().level + 1)
+      {
+         message = "line " + std::to_string(lineno) + ": indentation jumps more than one level";
+         return ERR_YAML_INVALID_INDENT_JUMP;
+      }
+      YNode *parent = stack.back().node;
+      bool   dash   = content[0] == '-' && (content.size() == 1 || content[1] == ' ');
+      if (dash)
+      {
+         parent->kids.emplace_back(new YNode());
+         YNode *item    = parent->kids.back().get();
+         item->key      = "-";
+         item->seq_item = true;
+         stack.push_back({level, item});
+         content = trim(content.substr(1));
+         if (content.empty()) continue;
+         if (content.front() == '{') { parse_flow(*item, content); continue; }
+         parent = item;
+         level  = level + 1;
+      }
+      size_t c = content.find(':');
+      if (c == std::string::npos)
+      {
+         message = "line " + std::to_string(lineno) + ": expected 'key: value'";
+         return ERR_YAML_INVALID_DIVISOR;
+      }
+      parent->kids.emplace_back(new YNode());
+      YNode      *n = parent->kids.back().get();
+      std::string v = trim(content.substr(c + 1));
+      if (!v.empty() && v.front() == '{')
+      {
+         set_keyval(*n, content.substr(0, c), "");
+         parse_flow(*n, v);
+      }
+      else set_keyval(*n, content.substr(0, c), v);
+      stack.push_back({level, n});
+   }
+   return ERR_NONE;
+}
+
+static void print_node(const YNode &n, int indent, FILE *out);
+static void print_kv(const YNode &n, int indent, const char *prefix, FILE *out)
+{
+   fprintf(out, "%*s%s%s: %s\n", indent, "", prefix, n.key.c_str(), n.val.c_str());
+   for (auto &k : n.kids) print_node(*k, indent + 2 + (int)strlen(prefix), out);
+}
+static void print_node(const YNode &n, int indent, FILE *out)
+{
+   if (n.seq_item)
+   {
+      bool first = true;
+      for (auto &k : n.kids)
+      {
+         print_kv(*k, indent, first ? "- " : "  ", out);
+         first = false;
+      }
+      return;
+   }
+   print_kv(n, indent, "", out);
+}
+void yaml_print(const YNode &root, FILE *out)
+{
+   for (auto &k : root.kids) print_node(*k, 0, out);
+}
+
+void yaml_override(YNode &root, const std::string &path, const std::string &value)
+{
+   std::string p = path;
+   while (!p.empty() && p[0] == '-') p.erase(0, 1);
+   std::vector<std::string> parts;
+   size_t                   pos = 0;
+   while (pos <= p.size())
+   {
+      size_t c = p.find(':', pos);
+      parts.push_back(lower(p.substr(pos, c == std::string::npos ? std::string::npos : c - pos)));
+      if (c == std::string::npos) break;
+      pos = c + 1;
+   }
+   YNode *cur = &root;
+   for (const std::string &part : parts)
+   {
+      YNode *next = cur->find(part);
+      if (!next)
+      {
+         if (cur != &root && cur->kids.empty() && !cur->val.empty())
+         { // value form ("solver: pcg") becomes container form ("solver: {pcg: {...}}")
+            const std::string old = cur->val;
+            cur->val.clear();
+            YNode *mid = cur->get_or_add(old);
+            next       = (old == part) ? mid : mid->get_or_add(part);
+         }
+         else next = cur->get_or_add(part);
+      }
+      cur = next;
+   }
+   std::string v = unquote(trim(value));
+   cur->val      = keeps_case(cur->key) ? v : lower(v);
+}
+
+// --------------------------------------------------------------- value maps
+
+typedef std::map<std::string, int> StrMap;
+static const StrMap kOnOff = {{"on", 1}, {"yes", 1}, {"true", 1}, {"1", 1}, {"off", 0}, {"no", 0}, {"false", 0}, {"0", 0}};
+static const StrMap kInterp = {{"mod_classical", 0}, {"least_squares", 1}, {"mod_classical_he", 2}, {"direct_sep_weights", 3},
+                               {"multipass", 4}, {"multipass_sep_weights", 5}, {"extended+i", 6}, {"extended+i_c", 7},
+                               {"standard", 8}, {"standard_sep_weights", 9}, {"blk_classical", 10}, {"blk_classical_diag", 11},
+                               {"f_f", 12}, {"f_f1", 13}, {"extended", 14}, {"mm_extended", 16}, {"mm_extended+i", 17},
+                               {"mm-ext+i", 17}, {"mm_extended+e", 18}, {"mm-ext+e", 18}, {"blk_direct", 24}, {"one_point", 100}};
+static const StrMap kRestrict = {{"p_transpose", 0}, {"air_1", 1}, {"air_2", 2}, {"neumann_air_0", 3}, {"neumann_air_1", 4},
+                                 {"neumann_air_2", 5}, {"air_1.5", 15}};
+static const StrMap kCoarsen = {{"cljp", 0}, {"rs", 1}, {"rs3", 3}, {"falgout", 6}, {"pmis", 8}, {"hmis", 10}};
+static const StrMap kAggInterp = {{"2_stage_extended+i", 1}, {"2_stage_standard", 2}, {"2_stage_extended", 3}, {"multipass", 4},
+                                  {"mm_extended", 5}, {"mm_extended+i", 6}, {"mm_extended+e", 7}};
+static const StrMap kRelax = {{"jacobi_non_mv", 0}, {"forward-hgs", 3}, {"backward-hgs", 4}, {"chaotic-hgs", 5}, {"hsgs", 6},
+                              {"jacobi", 7}, {"l1-hsgs", 8}, {"ge", 9}, {"forward-solve", 10}, {"2gs-it1", 11}, {"2gs-it2", 12},
+                              {"forward-hl1gs", 13}, {"backward-hl1gs", 14}, {"cg", 15}, {"chebyshev", 16}, {"l1-jacobi", 18},
+                              {"l1sym-hgs", 89}, {"lu_piv", 99}, {"lu_inv", 199}};
+static const StrMap kSmoothType = {{"fsai", 4}, {"ilu", 5}, {"schwarz", 6}, {"pilut", 7}, {"parasails", 8}, {"euclid", 9}};
+static const StrMap kRhsMode = {{"zeros", 0}, {"ones", 1}, {"file", 2}, {"random", 3}, {"randsol", 4}};
+static const StrMap kX0Mode = {{"zeros", 0}, {"ones", 1}, {"file", 2}, {"random", 3}, {"previous", 4}};
+static const StrMap kLsType = {{"online", 0}, {"ij", 1}, {"parcsr", 2}, {"mtx", 3}};
+static const StrMap kExec = {{"host", 0}, {"device", 1}};
+
+struct Ctx {
+   uint32_t    err = 0;
+   std::string msg;
+   void fail(uint32_t e, const std::string &m)
+   {
+      if (!err) msg = m;
+      err |= e;
+   }
+};
+
+static int to_int(Ctx &c, const YNode &n, const StrMap *map)
+{
+   if (map)
+   {
+      auto it = map->find(n.val);
+      if (it != map->end()) return it->second;
+   }
+   char *end = nullptr;
+   long  v   = strtol(n.val.c_str(), &end, 10);
+   if (n.val.empty() || (end && *end)) c.fail(ERR_INVALID_VAL, "invalid value '" + n.val + "' for key '" + n.key + "'");
+   return (int)v;
+}
+static double to_double(Ctx &c, const YNode &n)
+{
+   char  *end = nullptr;
+   double v   = strtod(n.val.c_str(), &end);
+   if (n.val.empty() || (end && *end)) c.fail(ERR_INVALID_VAL, "invalid value '" + n.val + "' for key '" + n.key + "'");
+   return v;
+}
+
+struct Field {
+   const char   *name;
+   int          *i;
+   double       *d;
+   const StrMap *map;
+};
+static void apply_fields(Ctx &c, YNode &sec, const std::vector<Field> &f, const std::vector<std::string> &ignored = {})
+{
+   for (auto &k : sec.kids)
+   {
+      bool hit = false;
+      for (auto &fl : f)
+         if (k->key == fl.name)
+         {
+            if (fl.i) *fl.i = to_int(c, *k, fl.map);
+            else *fl.d = to_double(c, *k);
+            hit = true;
+            break;
+         }
+      if (!hit && std::find(ignored.begin(), ignored.end(), k->key) == ignored.end())
+         c.fail(ERR_INVALID_KEY, "unknown key '" + k->key + "' under '" + sec.key + "'");
+   }
+}
+
+void KrylovArgs::defaults_for(int m)
+{
+   *this  = KrylovArgs();
+   method = m;
+   if (m == 1 || m == 2) max_iter = 300;
+   if (m == 3) max_iter = 100;
+}
+
+static void krylov_fields(Ctx &c, YNode &sec, KrylovArgs &k)
+{
+   apply_fields(c, sec,
+                {{"max_iter", &k.max_iter, nullptr, nullptr}, {"two_norm", &k.two_norm, nullptr, &kOnOff},
+                 {"stop_crit", &k.stop_crit, nullptr, &kOnOff}, {"rel_change", &k.rel_change, nullptr, &kOnOff},
+                 {"print_level", &k.print_level, nullptr, nullptr}, {"recompute_res", &k.recompute_res, nullptr, nullptr},
+                 {"relative_tol", nullptr, &k.relative_tol, nullptr}, {"absolute_tol", nullptr, &k.absolute_tol, nullptr},
+                 {"residual_tol", nullptr, &k.residual_tol, nullptr}, {"conv_fac_tol", nullptr, &k.conv_fac_tol, nullptr},
+                 {"min_iter", &k.min_iter, nullptr, nullptr}, {"skip_real_res_check", &k.skip_real_res_check, nullptr, &kOnOff},
+                 {"krylov_dim", &k.krylov_dim, nullptr, nullptr}, {"logging", &k.logging, nullptr, nullptr}});
+}
+
+static int solver_method(const std::string &name)
+{
+   if (name == "pcg") return 0;
+   if (name == "gmres") return 1;
+   if (name == "fgmres") return 2;
+   if (name == "bicgstab") return 3;
+   return -1;
+}
+
+static void parse_solver(Ctx &c, YNode &node, KrylovArgs &k)
+{
+   if (!node.val.empty() && node.kids.empty())
+   { // value-only form: defaults, print_level forced to 0 (reference args.c:379-396)
+      int m = solver_method(node.val);
+      if (m < 0) return c.fail(ERR_INVALID_VAL, "unknown solver '" + node.val + "'");
+      k.defaults_for(m);
+      k.print_level = 0;
+      return;
+   }
+   bool seen = false;
+   for (auto &ch : node.kids)
+   {
+      if (ch->key == "scaling") continue; // optional sibling; scaling is off by default
+      int m = solver_method(ch->key);
+      if (m < 0) { c.fail(ERR_INVALID_KEY, "unknown solver '" + ch->key + "'"); continue; }
+      k.defaults_for(m);
+      krylov_fields(c, *ch, k);
+      seen = true;
+   }
+   if (!seen) c.fail(ERR_MISSING_SOLVER, "solver section names no solver");
+}
+
+static void amg_fields(Ctx &c, YNode &sec, AmgArgs &a)
+{
+   for (auto &k : sec.kids)
+   {
+      if (k->key == "max_iter") a.max_iter = to_int(c, *k, nullptr);
+      else if (k->key == "print_level") a.print_level = to_int(c, *k, nullptr);
+      else if (k->key == "tolerance") a.tolerance = to_double(c, *k);
+      else if (k->key == "interpolation")
+         apply_fields(c, *k, {{"prolongation_type", &a.prolongation_type, nullptr, &kInterp},
+                              {"restriction_type", &a.restriction_type, nullptr, &kRestrict},
+                              {"max_nnz_row", &a.max_nnz_row, nullptr, nullptr}, {"trunc_factor", nullptr, &a.trunc_factor, nullptr},
+                              {"restrict_strong_th", nullptr, &a.restrict_strong_th, nullptr},
+                              {"restrict_filter_th", nullptr, &a.restrict_filter_th, nullptr}});
+      else if (k->key == "coarsening")
+         apply_fields(c, *k, {{"type", &a.type, nullptr, &kCoarsen}, {"rap2", &a.rap2, nullptr, &kOnOff},
+                              {"mod_rap2", &a.mod_rap2, nullptr, &kOnOff}, {"keep_transpose", &a.keep_transpose, nullptr, &kOnOff},
+                              {"sabs", &a.sabs, nullptr, &kOnOff}, {"num_functions", &a.num_functions, nullptr, nullptr},
+                              {"filter_functions", &a.filter_functions, nullptr, &kOnOff}, {"nodal", &a.nodal, nullptr, &kOnOff},
+                              {"seq_amg_th", &a.seq_amg_th, nullptr, nullptr}, {"min_coarse_size", &a.min_coarse_size, nullptr, nullptr},
+                              {"max_coarse_size", &a.max_coarse_size, nullptr, nullptr}, {"max_levels", &a.max_levels, nullptr, nullptr},
+                              {"max_row_sum", nullptr, &a.max_row_sum, nullptr}, {"strong_th", nullptr, &a.strong_th, nullptr}});
+      else if (k->key == "aggressive")
+         apply_fields(c, *k, {{"num_levels", &a.agg_num_levels, nullptr, nullptr}, {"num_paths", &a.agg_num_paths, nullptr, nullptr},
+                              {"prolongation_type", &a.agg_prolongation_type, nullptr, &kAggInterp},
+                              {"max_nnz_row", &a.agg_max_nnz_row, nullptr, nullptr}, {"trunc_factor", nullptr, &a.agg_trunc_factor, nullptr},
+                              {"p12_max_elements", nullptr, &a.agg_P12_max_elements, nullptr},
+                              {"p12_trunc_factor", nullptr, &a.agg_P12_trunc_factor, nullptr}});
+      else if (k->key == "relaxation")
+         apply_fields(c, *k, {{"type", &a.relax_type, nullptr, &kRelax}, {"down_type", &a.down_type, nullptr, &kRelax},
+                              {"up_type", &a.up_type, nullptr, &kRelax}, {"coarse_type", &a.coarse_type, nullptr, &kRelax},
+                              {"down_sweeps", &a.down_sweeps, nullptr, nullptr}, {"up_sweeps", &a.up_sweeps, nullptr, nullptr},
+                              {"coarse_sweeps", &a.coarse_sweeps, nullptr, nullptr}, {"num_sweeps", &a.num_sweeps, nullptr, nullptr},
+                              {"order", &a.order, nullptr, nullptr}, {"points", &a.points, nullptr, nullptr},
+                              {"weight", nullptr, &a.weight, nullptr}, {"outer_weight", nullptr, &a.outer_weight, nullptr}},
+                      {"chebyshev"});
+      else if (k->key == "smoother")
+         apply_fields(c, *k, {{"type", &a.smooth_type, nullptr, &kSmoothType}, {"num_levels", &a.smooth_num_levels, nullptr, nullptr},
+                              {"num_sweeps", &a.smooth_num_sweeps, nullptr, nullptr}},
+                      {"fsai", "ilu"});
+      else c.fail(ERR_INVALID_KEY, "unknown key '" + k->key + "' under 'amg'");
+   }
+}
+
+// single-level aliases (reference src/internal/precon.c:255-288)
+static void apply_alias(PreconArgs &p, const std::string &name)
+{
+   int t = (name == "jacobi") ? 0 : (name == "gauss-seidel") ? 3 : -1;
+   if (t < 0) return;
+   p.amg.max_levels    = 1;
+   p.amg.relax_type    = t;
+   p.amg.down_type     = t;
+   p.amg.coarse_type   = t;
+   p.amg.down_sweeps   = 1;
+   p.amg.up_sweeps     = 0;
+   p.amg.coarse_sweeps = 1;
+}
+
+static bool set_precon_method(Ctx &c, PreconArgs &p, const std::string &name)
+{
+   p = PreconArgs();
+   p.method_name = name;
+   if (name == "amg" || name == "boomeramg") p.method = 0;
+   else if (name == "jacobi" || name == "gauss-seidel") { p.method = 0; apply_alias(p, name); }
+   else if (name == "mgr") p.method = 1;
+   else if (name == "ilu") p.method = 2;
+   else if (name == "fsai") p.method = 3;
+   else if (name == "ams") p.method = 4;
+   else if (name == "ads") p.method = 5;
+   else if (name == "schwarz") p.method = 6;
+   else if (name == "none") p.method = 99;
+   else { c.fail(ERR_INVALID_VAL, "unknown preconditioner '" + name + "'"); return false; }
+   return true;
+}
+
+static const char *preset_text(const std::string &name)
+{
+   // built-in presets of the reference (src/internal/presets.c:17-33)
+   if (name == "poisson") return "amg";
+   if (name == "elasticity_2d") return "amg:\n  coarsening:\n    num_functions: 2\n    strong_th: 0.8";
+   if (name == "elasticity_3d") return "amg:\n  coarsening:\n    num_functions: 3\n    strong_th: 0.8";
+   return nullptr;
+}
+
+static void parse_precon_body(Ctx &c, YNode &node, std::vector<PreconArgs> &variants);
+
+uint32_t precon_from_text(const std::string &text, PreconArgs &out, std::string &message)
+{
+   Ctx   c;
+   YNode root, holder;
+   if (text.find(':') == std::string::npos && text.find('\n') == std::string::npos)
+   {
+      set_precon_method(c, out, lower(trim(text)));
+      message = c.msg;
+      return c.err;
+   }
+   uint32_t e = yaml_parse(text, root, message);
+   if (e) return e;
+   std::vector<PreconArgs> v;
+   parse_precon_body(c, root, v);
+   if (!v.empty()) out = v[0];
+   message = c.msg;
+   return c.err;
+}
+
+uint32_t solver_from_text(const std::string &text, KrylovArgs &out, std::string &message)
+{
+   Ctx   c;
+   YNode root;
+   if (text.find(':') == std::string::npos)
+   {
+      root.val = lower(trim(text));
+      parse_solver(c, root, out);
+   }
+   else
+   {
+      uint32_t e = yaml_parse(text, root, message);
+      if (e) return e;
+      parse_solver(c, root, out);
+   }
+   message = c.msg;
+   return c.err;
+}
+
+static void parse_precon_body(Ctx &c, YNode &node, std::vector<PreconArgs> &variants)
+{
+   for (auto &ch : node.kids)
+   {
+      if (ch->key == "reuse") continue; // reuse policy: single-system runs always rebuild
+      if (ch->key == "preset")
+      {
+         const char *t = preset_text(ch->val);
+         if (!t) { c.fail(ERR_INVALID_VAL, "unknown preconditioner preset '" + ch->val + "'"); continue; }
+         PreconArgs  p;
+         std::string m;
+         uint32_t    e = precon_from_text(t, p, m);
+         if (e) c.fail(e, m);
+         variants.push_back(p);
+         continue;
+      }
+      PreconArgs p;
+      if (!set_precon_method(c, p, ch->key)) continue;
+      bool has_seq = false;
+      for (auto &k : ch->kids) has_seq |= k->seq_item;
+      if (has_seq)
+      {
+         for (auto &item : ch->kids)
+         {
+            if (!item->seq_item) { c.fail(ERR_YAML_TREE_INVALID, "mixing variants and plain keys under '" + ch->key + "'"); continue; }
+            PreconArgs v = p;
+            if (p.method == 0) amg_fields(c, *item, v.amg);
+            variants.push_back(v);
+         }
+      }
+      else
+      {
+         if (p.method == 0) amg_fields(c, *ch, p.amg);
+         variants.push_back(p);
+      }
+   }
+}
+
+uint32_t args_from_yaml(YNode &root, bool lib_mode, InputArgs &args, std::string &message)
+{
+   Ctx c;
+   args.general.print_config_params = lib_mode ? 0 : 1;
+   bool has_precon = false;
+   for (auto &sec : root.kids)
+   {
+      if (sec->key == "general")
+      {
+         GeneralArgs &g = args.general;
+         for (auto &k : sec->kids)
+         {
+            if (k->key == "name") g.name = k->val;
+            else if (k->key == "statistics_filename") g.statistics_filename = k->val;
+            else if (k->key == "warmup") g.warmup = to_int(c, *k, &kOnOff);
+            else if (k->key == "statistics") g.statistics = to_int(c, *k, &kOnOff);
+            else if (k->key == "print_config_params") g.print_config_params = to_int(c, *k, &kOnOff);
+            else if (k->key == "use_millisec") g.use_millisec = to_int(c, *k, &kOnOff);
+            else if (k->key == "num_repetitions") g.num_repetitions = to_int(c, *k, nullptr);
+            else if (k->key == "exec_policy") g.exec_policy = to_int(c, *k, &kExec);
+            else if (k->key == "device_lazy_init" || k->key == "use_vendor_spgemm" || k->key == "use_vendor_spmv" ||
+                     k->key == "dev_pool_size" || k->key == "uvm_pool_size" || k->key == "host_pool_size" ||
+                     k->key == "pinned_pool_size")
+               ; // accepted: allocator / vendor-kernel knobs of the hypre backend have no meaning here
+            else c.fail(ERR_INVALID_KEY, "unknown key '" + k->key + "' under 'general'");
+         }
+      }
+      else if (sec->key == "linear_system")
+      {
+         LSArgs &l = args.ls;
+         for (auto &k : sec->kids)
+         {
+            if (k->key == "dirname") l.dirname = k->val;
+            else if (k->key == "matrix_filename") l.matrix_filename = k->val;
+            else if (k->key == "matrix_basename") l.matrix_basename = k->val;
+            else if (k->key == "precmat_filename") l.precmat_filename = k->val;
+            else if (k->key == "rhs_filename") l.rhs_filename = k->val;
+            else if (k->key == "rhs_basename") l.rhs_basename = k->val;
+            else if (k->key == "x0_filename") l.x0_filename = k->val;
+            else if (k->key == "xref_filename") l.xref_filename = k->val;
+            else if (k->key == "sol_filename") l.sol_filename = k->val;
+            else if (k->key == "dofmap_filename") l.dofmap_filename = k->val;
+            else if (k->key == "digits_suffix") l.digits_suffix = to_int(c, *k, nullptr);
+            else if (k->key == "init_suffix") l.init_suffix = to_int(c, *k, nullptr);
+            else if (k->key == "last_suffix") l.last_suffix = to_int(c, *k, nullptr);
+            else if (k->key == "init_guess_mode") l.init_guess_mode = to_int(c, *k, &kX0Mode);
+            else if (k->key == "rhs_mode") l.rhs_mode = to_int(c, *k, &kRhsMode);
+            else if (k->key == "type") l.type = to_int(c, *k, &kLsType);
+            else if (k->key == "exec_policy") (void)to_int(c, *k, &kExec);
+            else if (k->key == "print_system" || k->key == "eigspec" || k->key == "dof_labels" || k->key == "timestep_filename" ||
+                     k->key == "sequence_filename" || k->key == "xref_basename" || k->key == "dofmap_basename" ||
+                     k->key == "precmat_basename" || k->key == "set_suffix")
+               ; // outside the solve path
+            else c.fail(ERR_INVALID_KEY, "unknown key '" + k->key + "' under 'linear_system'");
+         }
+         if (l.init_suffix >= 0 && l.last_suffix >= l.init_suffix) l.num_systems = l.last_suffix - l.init_suffix + 1;
+      }
+      else if (sec->key == "solver") parse_solver(c, *sec, args.solver);
+      else if (sec->key == "preconditioner")
+      {
+         has_precon = true;
+         args.precon_variants.clear();
+         if (!sec->val.empty() && sec->kids.empty())
+         {
+            PreconArgs p;
+            if (set_precon_method(c, p, sec->val)) args.precon_variants.push_back(p);
+         }
+         else parse_precon_body(c, *sec, args.precon_variants);
+         if (args.precon_variants.empty()) c.fail(ERR_MISSING_PRECON, "preconditioner section names no preconditioner");
+      }
+      else if (sec->key == "include")
+         c.fail(ERR_INVALID_KEY, "'include' expansion is not supported by this build");
+      else c.fail(ERR_INVALID_KEY, "unknown root section '" + sec->key + "'");
+   }
+   if (!has_precon) c.fail(ERR_MISSING_PRECON, "missing 'preconditioner' section"); // reference args.c:981-989
+   if (args.precon_variants.empty()) args.precon_variants.push_back(PreconArgs());
+   args.has_precon     = has_precon;
+   args.active_variant = 0;
+   message             = c.msg;
+   return c.err;
+}
+
+} // namespace hda

@@ -1,0 +1,121 @@
+"""One process per GPU: join the library's communicator from a torchrun-style environment.
+
+Transport choice:
+  * "rccl"   -- every rank has its own GPU (LOCAL_RANK < device count): the C library talks
+                RCCL over xGMI directly (halo ncclSend/ncclRecv, fused dot ncclAllReduce);
+                torch.distributed (gloo) is only used to hand rank 0's ncclUniqueId around.
+  * "staged" -- several ranks share one GPU (tests) or no RCCL: the same messages are
+                staged through host callbacks implemented on torch.distributed/gloo.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_keep = {}
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _make_callbacks(dist, torch, rank, world):
+    from . import hypredrv as hd
+
+    def allreduce(buf, count, dtype, op):
+        ct = C.c_double if dtype == 0 else C.c_int64
+        arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(ct)), shape=(count,))
+        t = torch.from_numpy(arr)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+
+    def alltoallv(send, sbytes, recv, rbytes):
+        sb = [sbytes[p] for p in range(world)]
+        rb = [rbytes[p] for p in range(world)]
+        st, rt = sum(sb), sum(rb)
+        s = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(max(st, 1),))
+        r = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(max(rt, 1),))
+        so = np.concatenate([[0], np.cumsum(sb)]).astype(np.int64)
+        ro = np.concatenate([[0], np.cumsum(rb)]).astype(np.int64)
+        reqs, bufs = [], []
+        for p in range(world):
+            if p == rank:
+                n = min(sb[p], rb[p])
+                if n:
+                    r[ro[p]:ro[p] + n] = s[so[p]:so[p] + n]
+                continue
+            if rb[p]:
+                t = torch.empty(rb[p], dtype=torch.uint8)
+                bufs.append((p, t))
+                reqs.append(dist.irecv(t, src=p))
+        for p in range(world):
+            if p != rank and sb[p]:
+                t = torch.from_numpy(s[so[p]:so[p] + sb[p]].copy())
+                reqs.append(dist.isend(t, dst=p))
+        for q in reqs:
+            q.wait()
+        for p, t in bufs:
+            r[ro[p]:ro[p] + rb[p]] = t.numpy()
+
+    return hd.ALLREDUCE_CB(allreduce), hd.ALLTOALLV_CB(alltoallv)
+
+
+def init(transport="auto"):
+    """Join the world described by RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*; returns (rank, world)."""
+    from . import hypredrv as hd
+    rank, world, local = env_rank()
+    if world == 1:
+        return rank, world
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ndev = torch.cuda.device_count()
+    if transport == "auto":
+        transport = "rccl" if ndev >= world or (ndev > 1 and local < ndev) else "staged"
+    L = hd.lib()
+    if transport == "rccl":
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            hd.check(L.HYPREDRV_AMD_CommGetUniqueId(uid))
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0)
+        uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        hd.check(L.HYPREDRV_AMD_CommInit(rank, world, local, uid))
+    else:
+        ar, a2a = _make_callbacks(dist, torch, rank, world)
+        _keep["cbs"] = (ar, a2a)  # keep the ctypes trampolines alive
+        hd.check(L.HYPREDRV_AMD_CommInitCallbacks(rank, world, local if local < max(ndev, 1) else 0, ar, a2a))
+    _keep["transport"] = transport
+    return rank, world
+
+
+def transport():
+    return _keep.get("transport", "self")
+
+
+def finalize():
+    from . import hypredrv as hd
+    hd.lib().HYPREDRV_AMD_CommFinalize()
+    _keep.clear()
+    try:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def factor3(p):
+    """P0 x P1 x P2 = p, as cubic as possible, z (the slowest block index) largest."""
+    best = (1, 1, p)
+    for a in range(1, p + 1):
+        if p % a:
+            continue
+        for b in range(a, p // a + 1):
+            if (p // a) % b:
+                continue
+            c = p // a // b
+            if c >= b and (c - a) < (best[2] - best[0]):
+                best = (a, b, c)
+    return best

@@ -1,0 +1,55 @@
+"""bench.py body for --gpus N > 1: the same global problem, row partitioned over N ranks
+(block decomposition of examples/src/C_laplacian/laplacian.c:561-582), through the
+HYPREDRV_* API: SetLaplacian7pt -> LinearSolverCreate/Setup once -> K x (ResetInitialGuess +
+LinearSolverApply)."""
+import os
+import time
+
+from . import dist as hdist
+from . import hypredrv as hd
+
+
+def run(args):
+    import torch
+    import torch.distributed as dist
+    rank, world = hdist.init()
+    n = args.n
+    P = hdist.factor3(world)
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  preset: poisson\n")
+    h.set_laplacian7((n, n, n), P)
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    dist.barrier()
+    t0 = time.perf_counter()
+    h.create_and_setup()
+    dist.barrier()
+    setup_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(args.warmup):
+        h.apply()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = h.apply()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ms_per_step = dt.item() * 1e3 / args.steps
+    N = n ** 3
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "DOF/s, AMG-PCG solve phase, 3D 7-pt Laplacian", "value": N / (ms_per_step * 1e-3), "unit": "DOF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"lap7 {n}^3 fp64 AMG-PCG, row blocks {P[0]}x{P[1]}x{P[2]}", "rows": N,
+                       "parallelism": f"row partition over {world} ranks, transport {hdist.transport()}",
+                       "timed": "solve phase only (reference 'solve' timer)"},
+            "iters": last["iters"], "converged": last["converged"], "final_rel": last["final_rel"], "setup_ms": setup_ms,
+            "dof_iters_per_s": N * last["iters"] / (ms_per_step * 1e-3),
+        }
+    h.destroy_solver()
+    h.close()
+    hdist.finalize()
+    return out

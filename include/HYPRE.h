@@ -1,0 +1,222 @@
+/*
+ * HYPRE.h -- the slice of hypre's public C API that hypredrive's AMG-Krylov hot path binds
+ * (SURVEY.md 8(b) "lower seam"), re-implemented on MI355X by libhypredrv_amd.so.
+ *
+ * Each group cites where the reference calls it.  Types follow a mixed-int hypre build:
+ * HYPRE_Int = int32 (local indices), HYPRE_BigInt = int64 (global indices), HYPRE_Real =
+ * HYPRE_Complex = double.  Handles are opaque; matrices and vectors live in HBM after
+ * Assemble regardless of the memory location asked for (there is no host solve path).
+ */
+#ifndef HYPRE_AMD_HEADER
+#define HYPRE_AMD_HEADER
+
+#include "hda_mpi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYPRE_RELEASE_NAME "hypre-subset (hypredrive_amd, MI355X)"
+#define HYPRE_RELEASE_VERSION "3.0.0"
+#define HYPRE_RELEASE_NUMBER 30000
+#define HYPRE_DEVELOP_NUMBER 0
+#define HYPRE_USING_GPU 1
+#define HYPRE_USING_HIP 1
+#define HYPRE_MIXEDINT 1
+
+typedef int       HYPRE_Int;
+typedef long long HYPRE_BigInt;
+typedef double    HYPRE_Real;
+typedef double    HYPRE_Complex;
+
+typedef enum { HYPRE_MEMORY_UNDEFINED = -1, HYPRE_MEMORY_HOST = 0, HYPRE_MEMORY_DEVICE = 1 } HYPRE_MemoryLocation;
+typedef enum { HYPRE_EXEC_UNDEFINED = -1, HYPRE_EXEC_HOST = 0, HYPRE_EXEC_DEVICE = 1 } HYPRE_ExecutionPolicy;
+
+#define HYPRE_PARCSR 5555
+#define HYPRE_ERROR_GENERIC 1
+#define HYPRE_ERROR_MEMORY 2
+#define HYPRE_ERROR_ARG 4
+#define HYPRE_ERROR_CONV 256
+
+struct hypre_IJMatrix_struct;
+struct hypre_IJVector_struct;
+struct hypre_Solver_struct;
+typedef struct hypre_IJMatrix_struct *HYPRE_IJMatrix;
+typedef struct hypre_IJVector_struct *HYPRE_IJVector;
+typedef struct hypre_IJMatrix_struct *HYPRE_ParCSRMatrix; /* same object: IJ is a view */
+typedef struct hypre_IJVector_struct *HYPRE_ParVector;
+typedef struct hypre_IJMatrix_struct *HYPRE_Matrix;
+typedef struct hypre_IJVector_struct *HYPRE_Vector;
+typedef struct hypre_Solver_struct   *HYPRE_Solver;
+
+typedef HYPRE_Int (*HYPRE_PtrToSolverFcn)(HYPRE_Solver, HYPRE_Matrix, HYPRE_Vector, HYPRE_Vector);
+typedef HYPRE_Int (*HYPRE_PtrToParSolverFcn)(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector);
+
+/* ---- utilities (src/internal/runtime.c:101-120, src/HYPREDRV.c:316-346) ---- */
+HYPRE_Int HYPRE_Initialize(void);
+HYPRE_Int HYPRE_Finalize(void);
+HYPRE_Int HYPRE_SetMemoryLocation(HYPRE_MemoryLocation loc);
+HYPRE_Int HYPRE_SetExecutionPolicy(HYPRE_ExecutionPolicy pol);
+HYPRE_Int HYPRE_GetError(void);
+HYPRE_Int HYPRE_ClearAllErrors(void);
+HYPRE_Int HYPRE_CheckError(HYPRE_Int ierr, HYPRE_Int code);
+
+/* ---- IJ matrix (examples/src/C_laplacian/laplacian.c:734-914, src/internal/linsys.c:1281-1380) ---- */
+HYPRE_Int HYPRE_IJMatrixCreate(MPI_Comm comm, HYPRE_BigInt ilower, HYPRE_BigInt iupper, HYPRE_BigInt jlower,
+                               HYPRE_BigInt jupper, HYPRE_IJMatrix *matrix);
+HYPRE_Int HYPRE_IJMatrixDestroy(HYPRE_IJMatrix matrix);
+HYPRE_Int HYPRE_IJMatrixSetObjectType(HYPRE_IJMatrix matrix, HYPRE_Int type);
+HYPRE_Int HYPRE_IJMatrixSetRowSizes(HYPRE_IJMatrix matrix, const HYPRE_Int *sizes);
+HYPRE_Int HYPRE_IJMatrixSetDiagOffdSizes(HYPRE_IJMatrix matrix, const HYPRE_Int *diag, const HYPRE_Int *offd);
+HYPRE_Int HYPRE_IJMatrixInitialize(HYPRE_IJMatrix matrix);
+HYPRE_Int HYPRE_IJMatrixInitialize_v2(HYPRE_IJMatrix matrix, HYPRE_MemoryLocation loc);
+HYPRE_Int HYPRE_IJMatrixSetValues(HYPRE_IJMatrix matrix, HYPRE_Int nrows, HYPRE_Int *ncols, const HYPRE_BigInt *rows,
+                                  const HYPRE_BigInt *cols, const HYPRE_Complex *values);
+HYPRE_Int HYPRE_IJMatrixAddToValues(HYPRE_IJMatrix matrix, HYPRE_Int nrows, HYPRE_Int *ncols, const HYPRE_BigInt *rows,
+                                    const HYPRE_BigInt *cols, const HYPRE_Complex *values);
+HYPRE_Int HYPRE_IJMatrixAssemble(HYPRE_IJMatrix matrix);
+HYPRE_Int HYPRE_IJMatrixGetObject(HYPRE_IJMatrix matrix, void **object);
+HYPRE_Int HYPRE_IJMatrixGetLocalRange(HYPRE_IJMatrix matrix, HYPRE_BigInt *ilower, HYPRE_BigInt *iupper,
+                                      HYPRE_BigInt *jlower, HYPRE_BigInt *jupper);
+HYPRE_Int HYPRE_IJMatrixMigrate(HYPRE_IJMatrix matrix, HYPRE_MemoryLocation loc);
+HYPRE_Int HYPRE_IJMatrixRead(const char *filename, MPI_Comm comm, HYPRE_Int type, HYPRE_IJMatrix *matrix);
+HYPRE_Int HYPRE_IJMatrixPrint(HYPRE_IJMatrix matrix, const char *filename);
+/* global rows / nonzeros (what linsys.c reads through hypre_ParCSRMatrix accessors) */
+HYPRE_Int HYPRE_ParCSRMatrixGetDims(HYPRE_ParCSRMatrix A, HYPRE_BigInt *M, HYPRE_BigInt *N);
+HYPRE_Int HYPRE_ParCSRMatrixGetNumNonzeros(HYPRE_ParCSRMatrix A, HYPRE_BigInt *nnz);
+
+/* ---- IJ vector ---- */
+HYPRE_Int HYPRE_IJVectorCreate(MPI_Comm comm, HYPRE_BigInt jlower, HYPRE_BigInt jupper, HYPRE_IJVector *vector);
+HYPRE_Int HYPRE_IJVectorDestroy(HYPRE_IJVector vector);
+HYPRE_Int HYPRE_IJVectorSetObjectType(HYPRE_IJVector vector, HYPRE_Int type);
+HYPRE_Int HYPRE_IJVectorInitialize(HYPRE_IJVector vector);
+HYPRE_Int HYPRE_IJVectorInitialize_v2(HYPRE_IJVector vector, HYPRE_MemoryLocation loc);
+HYPRE_Int HYPRE_IJVectorSetValues(HYPRE_IJVector vector, HYPRE_Int nvalues, const HYPRE_BigInt *indices,
+                                  const HYPRE_Complex *values);
+HYPRE_Int HYPRE_IJVectorAddToValues(HYPRE_IJVector vector, HYPRE_Int nvalues, const HYPRE_BigInt *indices,
+                                    const HYPRE_Complex *values);
+HYPRE_Int HYPRE_IJVectorGetValues(HYPRE_IJVector vector, HYPRE_Int nvalues, const HYPRE_BigInt *indices,
+                                  HYPRE_Complex *values);
+HYPRE_Int HYPRE_IJVectorAssemble(HYPRE_IJVector vector);
+HYPRE_Int HYPRE_IJVectorGetObject(HYPRE_IJVector vector, void **object);
+HYPRE_Int HYPRE_IJVectorGetLocalRange(HYPRE_IJVector vector, HYPRE_BigInt *jlower, HYPRE_BigInt *jupper);
+HYPRE_Int HYPRE_IJVectorMigrate(HYPRE_IJVector vector, HYPRE_MemoryLocation loc);
+HYPRE_Int HYPRE_IJVectorRead(const char *filename, MPI_Comm comm, HYPRE_Int type, HYPRE_IJVector *vector);
+HYPRE_Int HYPRE_IJVectorPrint(HYPRE_IJVector vector, const char *filename);
+
+/* ---- ParCSR kernels (src/internal/linsys.c:2875,2964-2967,3030-3032) ---- */
+HYPRE_Int HYPRE_ParCSRMatrixMatvec(HYPRE_Complex alpha, HYPRE_ParCSRMatrix A, HYPRE_ParVector x, HYPRE_Complex beta,
+                                   HYPRE_ParVector y);
+HYPRE_Int HYPRE_ParVectorInnerProd(HYPRE_ParVector x, HYPRE_ParVector y, HYPRE_Real *prod);
+HYPRE_Int HYPRE_ParVectorCopy(HYPRE_ParVector x, HYPRE_ParVector y);
+HYPRE_Int HYPRE_ParVectorScale(HYPRE_Complex value, HYPRE_ParVector x);
+HYPRE_Int HYPRE_ParVectorAxpy(HYPRE_Complex alpha, HYPRE_ParVector x, HYPRE_ParVector y);
+HYPRE_Int HYPRE_ParVectorSetConstantValues(HYPRE_ParVector vector, HYPRE_Complex value);
+
+/* ---- PCG (solver_ops[SOLVER_PCG], src/internal/solver.c:204-216; setters src/internal/pcg.c:59-69) ---- */
+HYPRE_Int HYPRE_ParCSRPCGCreate(MPI_Comm comm, HYPRE_Solver *solver);
+HYPRE_Int HYPRE_ParCSRPCGDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_ParCSRPCGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_PCGSetMaxIter(HYPRE_Solver solver, HYPRE_Int max_iter);
+HYPRE_Int HYPRE_PCGSetTwoNorm(HYPRE_Solver solver, HYPRE_Int two_norm);
+HYPRE_Int HYPRE_PCGSetStopCrit(HYPRE_Solver solver, HYPRE_Int stop_crit);
+HYPRE_Int HYPRE_PCGSetRelChange(HYPRE_Solver solver, HYPRE_Int rel_change);
+HYPRE_Int HYPRE_PCGSetPrintLevel(HYPRE_Solver solver, HYPRE_Int level);
+HYPRE_Int HYPRE_PCGSetLogging(HYPRE_Solver solver, HYPRE_Int level);
+HYPRE_Int HYPRE_PCGSetRecomputeResidual(HYPRE_Solver solver, HYPRE_Int recompute);
+HYPRE_Int HYPRE_PCGSetTol(HYPRE_Solver solver, HYPRE_Real tol);
+HYPRE_Int HYPRE_PCGSetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real a_tol);
+HYPRE_Int HYPRE_PCGSetResidualTol(HYPRE_Solver solver, HYPRE_Real rtol);
+HYPRE_Int HYPRE_PCGSetConvergenceFactorTol(HYPRE_Solver solver, HYPRE_Real cf_tol);
+HYPRE_Int HYPRE_PCGSetPrecond(HYPRE_Solver solver, HYPRE_PtrToSolverFcn precond, HYPRE_PtrToSolverFcn precond_setup,
+                              HYPRE_Solver precond_solver);
+HYPRE_Int HYPRE_PCGGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
+HYPRE_Int HYPRE_PCGGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
+HYPRE_Int HYPRE_PCGGetConverged(HYPRE_Solver solver, HYPRE_Int *converged);
+
+/* ---- GMRES (solver_ops[SOLVER_GMRES], src/internal/solver.c:217-228; src/internal/gmres.c:63-74) ---- */
+HYPRE_Int HYPRE_ParCSRGMRESCreate(MPI_Comm comm, HYPRE_Solver *solver);
+HYPRE_Int HYPRE_ParCSRGMRESDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_ParCSRGMRESSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_ParCSRGMRESSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_GMRESSetMinIter(HYPRE_Solver solver, HYPRE_Int min_iter);
+HYPRE_Int HYPRE_GMRESSetMaxIter(HYPRE_Solver solver, HYPRE_Int max_iter);
+HYPRE_Int HYPRE_GMRESSetStopCrit(HYPRE_Solver solver, HYPRE_Int stop_crit);
+HYPRE_Int HYPRE_GMRESSetSkipRealResidualCheck(HYPRE_Solver solver, HYPRE_Int skip);
+HYPRE_Int HYPRE_GMRESSetKDim(HYPRE_Solver solver, HYPRE_Int k_dim);
+HYPRE_Int HYPRE_GMRESSetRelChange(HYPRE_Solver solver, HYPRE_Int rel_change);
+HYPRE_Int HYPRE_GMRESSetLogging(HYPRE_Solver solver, HYPRE_Int logging);
+HYPRE_Int HYPRE_GMRESSetPrintLevel(HYPRE_Solver solver, HYPRE_Int level);
+HYPRE_Int HYPRE_GMRESSetTol(HYPRE_Solver solver, HYPRE_Real tol);
+HYPRE_Int HYPRE_GMRESSetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real a_tol);
+HYPRE_Int HYPRE_GMRESSetConvergenceFactorTol(HYPRE_Solver solver, HYPRE_Real cf_tol);
+HYPRE_Int HYPRE_GMRESSetPrecond(HYPRE_Solver solver, HYPRE_PtrToSolverFcn precond, HYPRE_PtrToSolverFcn precond_setup,
+                                HYPRE_Solver precond_solver);
+HYPRE_Int HYPRE_GMRESGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
+HYPRE_Int HYPRE_GMRESGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
+HYPRE_Int HYPRE_GMRESGetConverged(HYPRE_Solver solver, HYPRE_Int *converged);
+
+/* ---- BoomerAMG (precon_ops[PRECON_BOOMERAMG], src/internal/precon.c:106-109; setter sequence
+ * src/internal/amg.c:868-1032).  Setters for features this build does not implement store the
+ * value and make Setup fail loudly if the value selects the unimplemented feature. ---- */
+HYPRE_Int HYPRE_BoomerAMGCreate(HYPRE_Solver *solver);
+HYPRE_Int HYPRE_BoomerAMGDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_BoomerAMGSetInterpType(HYPRE_Solver solver, HYPRE_Int interp_type);
+HYPRE_Int HYPRE_BoomerAMGSetRestriction(HYPRE_Solver solver, HYPRE_Int restr_par);
+HYPRE_Int HYPRE_BoomerAMGSetStrongThresholdR(HYPRE_Solver solver, HYPRE_Real th);
+HYPRE_Int HYPRE_BoomerAMGSetFilterThresholdR(HYPRE_Solver solver, HYPRE_Real th);
+HYPRE_Int HYPRE_BoomerAMGSetCoarsenType(HYPRE_Solver solver, HYPRE_Int coarsen_type);
+HYPRE_Int HYPRE_BoomerAMGSetSabs(HYPRE_Solver solver, HYPRE_Int sabs);
+HYPRE_Int HYPRE_BoomerAMGSetTol(HYPRE_Solver solver, HYPRE_Real tol);
+HYPRE_Int HYPRE_BoomerAMGSetStrongThreshold(HYPRE_Solver solver, HYPRE_Real th);
+HYPRE_Int HYPRE_BoomerAMGSetSeqThreshold(HYPRE_Solver solver, HYPRE_Int th);
+HYPRE_Int HYPRE_BoomerAMGSetMaxCoarseSize(HYPRE_Solver solver, HYPRE_Int size);
+HYPRE_Int HYPRE_BoomerAMGSetMinCoarseSize(HYPRE_Solver solver, HYPRE_Int size);
+HYPRE_Int HYPRE_BoomerAMGSetTruncFactor(HYPRE_Solver solver, HYPRE_Real trunc_factor);
+HYPRE_Int HYPRE_BoomerAMGSetPMaxElmts(HYPRE_Solver solver, HYPRE_Int pmax);
+HYPRE_Int HYPRE_BoomerAMGSetPrintLevel(HYPRE_Solver solver, HYPRE_Int level);
+HYPRE_Int HYPRE_BoomerAMGSetLogging(HYPRE_Solver solver, HYPRE_Int level);
+HYPRE_Int HYPRE_BoomerAMGSetRelaxType(HYPRE_Solver solver, HYPRE_Int relax_type);
+HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver solver, HYPRE_Int relax_type, HYPRE_Int k);
+HYPRE_Int HYPRE_BoomerAMGSetRelaxOrder(HYPRE_Solver solver, HYPRE_Int order);
+HYPRE_Int HYPRE_BoomerAMGSetRelaxWt(HYPRE_Solver solver, HYPRE_Real wt);
+HYPRE_Int HYPRE_BoomerAMGSetOuterWt(HYPRE_Solver solver, HYPRE_Real wt);
+HYPRE_Int HYPRE_BoomerAMGSetNumSweeps(HYPRE_Solver solver, HYPRE_Int num_sweeps);
+HYPRE_Int HYPRE_BoomerAMGSetCycleNumSweeps(HYPRE_Solver solver, HYPRE_Int num_sweeps, HYPRE_Int k);
+HYPRE_Int HYPRE_BoomerAMGSetCycleType(HYPRE_Solver solver, HYPRE_Int cycle_type);
+HYPRE_Int HYPRE_BoomerAMGSetMaxLevels(HYPRE_Solver solver, HYPRE_Int max_levels);
+HYPRE_Int HYPRE_BoomerAMGSetMaxIter(HYPRE_Solver solver, HYPRE_Int max_iter);
+HYPRE_Int HYPRE_BoomerAMGSetMaxRowSum(HYPRE_Solver solver, HYPRE_Real max_row_sum);
+HYPRE_Int HYPRE_BoomerAMGSetNumFunctions(HYPRE_Solver solver, HYPRE_Int num_functions);
+HYPRE_Int HYPRE_BoomerAMGSetFilterFunctions(HYPRE_Solver solver, HYPRE_Int filter);
+HYPRE_Int HYPRE_BoomerAMGSetSmoothType(HYPRE_Solver solver, HYPRE_Int type);
+HYPRE_Int HYPRE_BoomerAMGSetSmoothNumSweeps(HYPRE_Solver solver, HYPRE_Int n);
+HYPRE_Int HYPRE_BoomerAMGSetSmoothNumLevels(HYPRE_Solver solver, HYPRE_Int n);
+HYPRE_Int HYPRE_BoomerAMGSetAggNumLevels(HYPRE_Solver solver, HYPRE_Int n);
+HYPRE_Int HYPRE_BoomerAMGSetAggInterpType(HYPRE_Solver solver, HYPRE_Int t);
+HYPRE_Int HYPRE_BoomerAMGSetAggTruncFactor(HYPRE_Solver solver, HYPRE_Real f);
+HYPRE_Int HYPRE_BoomerAMGSetAggP12TruncFactor(HYPRE_Solver solver, HYPRE_Real f);
+HYPRE_Int HYPRE_BoomerAMGSetAggPMaxElmts(HYPRE_Solver solver, HYPRE_Int n);
+HYPRE_Int HYPRE_BoomerAMGSetAggP12MaxElmts(HYPRE_Solver solver, HYPRE_Int n);
+HYPRE_Int HYPRE_BoomerAMGSetNumPaths(HYPRE_Solver solver, HYPRE_Int n);
+HYPRE_Int HYPRE_BoomerAMGSetRAP2(HYPRE_Solver solver, HYPRE_Int rap2);
+HYPRE_Int HYPRE_BoomerAMGSetModuleRAP2(HYPRE_Solver solver, HYPRE_Int mod_rap2);
+HYPRE_Int HYPRE_BoomerAMGSetKeepTranspose(HYPRE_Solver solver, HYPRE_Int keep);
+HYPRE_Int HYPRE_BoomerAMGSetChebyOrder(HYPRE_Solver solver, HYPRE_Int order);
+HYPRE_Int HYPRE_BoomerAMGSetChebyFraction(HYPRE_Solver solver, HYPRE_Real ratio);
+HYPRE_Int HYPRE_BoomerAMGSetChebyEigEst(HYPRE_Solver solver, HYPRE_Int eig_est);
+HYPRE_Int HYPRE_BoomerAMGSetChebyVariant(HYPRE_Solver solver, HYPRE_Int variant);
+HYPRE_Int HYPRE_BoomerAMGSetChebyScale(HYPRE_Solver solver, HYPRE_Int scale);
+HYPRE_Int HYPRE_BoomerAMGGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
+HYPRE_Int HYPRE_BoomerAMGGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
+/* hierarchy facts the stats/log print (num levels, complexities) */
+HYPRE_Int HYPRE_BoomerAMGGetNumLevels(HYPRE_Solver solver, HYPRE_Int *num_levels);
+HYPRE_Int HYPRE_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

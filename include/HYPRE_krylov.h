@@ -1,0 +1,2 @@
+/* HYPRE_krylov.h -- part of the hypre API subset; everything is declared in HYPRE.h */
+#include "HYPRE.h"

@@ -1,0 +1,98 @@
+"""Worker for multi-rank tests (launched with torch.distributed.run).
+
+mode "transport": CPU only -- exercises the gloo-backed staged transport callbacks with the
+                  message pattern of a row-partitioned SpMV (oracle as the local kernel).
+mode "solve":     GPU -- AMG-PCG through the HYPREDRV_* API on a row-partitioned Laplacian,
+                  several ranks sharing the visible GPU(s) through the staged transport.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def mode_transport(out):
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from hypredrive_amd import dist as hdist
+    from oracle import oracle_ffi as o
+    rank, world, _ = hdist.env_rank()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ar, a2a = hdist._make_callbacks(dist, torch, rank, world)
+    # all-reduce: f64 sum and i64 max
+    v = np.array([rank + 1.0, 2.0 * rank], dtype=np.float64)
+    ar(v.ctypes.data_as(C.c_void_p), 2, 0, 0)
+    assert np.allclose(v, [world * (world + 1) / 2, world * (world - 1)])
+    w = np.array([rank, 7 - rank], dtype=np.int64)
+    ar(w.ctypes.data_as(C.c_void_p), 2, 1, 1)
+    assert list(w) == [world - 1, 7]
+    # row-partitioned SpMV on the generator's block numbering: ghost exchange through alltoallv
+    n, P = 6, (world, 1, 1)
+    A, _ = o.lap7(n, n, n, P=P)
+    S = A.to_scipy().tocsr()
+    N = n ** 3
+    part = [o.lap7_partition(n, n, n, P, r)[0] for r in range(world)] + [N]
+    lo, hi = part[rank], part[rank + 1]
+    loc = S[lo:hi]
+    cols = np.unique(loc.indices)
+    ghosts = cols[(cols < lo) | (cols >= hi)]
+    owner = np.searchsorted(part, ghosts, side="right") - 1
+    want = [ghosts[owner == p] for p in range(world)]
+    # exchange counts, then the id lists (the plan), then the values (the halo exchange)
+    cnt = np.array([len(x) for x in want], dtype=np.int64)
+    got = np.zeros(world, dtype=np.int64)
+    eight = (C.c_long * world)(*([8] * world))
+    a2a(cnt.ctypes.data_as(C.c_void_p), eight, got.ctypes.data_as(C.c_void_p), eight)
+    sb = (C.c_long * world)(*[8 * int(c) for c in cnt])
+    rb = (C.c_long * world)(*[8 * int(c) for c in got])
+    req = np.zeros(max(int(got.sum()), 1), dtype=np.int64)
+    flat = np.concatenate(want).astype(np.int64) if len(ghosts) else np.zeros(1, dtype=np.int64)
+    a2a(flat.ctypes.data_as(C.c_void_p), sb, req.ctypes.data_as(C.c_void_p), rb)
+    req = req[:int(got.sum())]
+    assert np.all((req >= lo) & (req < hi))
+    x = np.sin(np.arange(N, dtype=np.float64))
+    sendv = x[req].copy() if len(req) else np.zeros(1)
+    recvv = np.zeros(max(len(ghosts), 1))
+    a2a(sendv.ctypes.data_as(C.c_void_p), rb, recvv.ctypes.data_as(C.c_void_p), sb)
+    xg = np.zeros(N)
+    xg[lo:hi] = x[lo:hi]
+    xg[ghosts] = recvv[:len(ghosts)]
+    y = loc @ xg
+    assert np.allclose(y, (S @ x)[lo:hi], rtol=1e-14)
+    dist.barrier()
+    if rank == 0:
+        json.dump({"ok": True, "world": world}, open(out, "w"))
+    dist.destroy_process_group()
+
+
+def mode_solve(out, n, solver):
+    from hypredrive_amd import dist as hdist
+    from hypredrive_amd import hypredrv as hd
+    rank, world = hdist.init("staged")
+    P = hdist.factor3(world)
+    yaml = f"solver: {solver}\npreconditioner:\n  preset: poisson\n"
+    h = hd.Hypredrv(yaml)
+    h.set_laplacian7((n, n, n), P)
+    r = h.solve()
+    x = h.solution()
+    nrm = h.solution_norm("L2")
+    l1 = h.solution_norm("L1")
+    linf = h.solution_norm("Linf")
+    np.save(f"{out}.x{rank}.npy", x)
+    if rank == 0:
+        json.dump({"iters": r["iters"], "converged": r["converged"], "final_rel": r["final_rel"], "norm": nrm,
+                   "l1": l1, "linf": linf, "world": world, "P": P}, open(out, "w"))
+    h.close()
+    hdist.finalize()
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "transport":
+        mode_transport(sys.argv[2])
+    else:
+        mode_solve(sys.argv[2], int(sys.argv[3]), sys.argv[4])

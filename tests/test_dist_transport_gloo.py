@@ -1,0 +1,28 @@
+"""N > 1 on CPU (gloo, world_size 2 and 3): the staged transport the multi-rank GPU tests and
+single-GPU rehearsals run on, driven with the exact message pattern of the row-partitioned
+SpMV (counts -> request lists -> halo values), checked against the oracle's global SpMV."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,port", [(2, 29631), (3, 29632)])
+def test_staged_transport_partitioned_spmv(tmp_path, world, port):
+    out = str(tmp_path / "res.json")
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "transport", out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert json.load(open(out)) == {"ok": True, "world": world}
+
+
+def test_factor3():
+    from hypredrive_amd.dist import factor3
+    assert factor3(1) == (1, 1, 1) and factor3(2) == (1, 1, 2) and factor3(4) == (1, 2, 2) and factor3(8) == (2, 2, 2)
+    assert factor3(6) == (1, 2, 3)
