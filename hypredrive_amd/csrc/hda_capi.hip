@@ -436,7 +436,7 @@ extern "C" int hda_time_kernel(int kind, hda_csr_t A, hda_amg_t amg, int reps, d
    HDA_TRY
    Context       &ctx = Context::get();
    const DCsr    &m   = A->get();
-   const size_t   nv  = (size_t)std::max(m.ncols, 1);
+   const size_t   nv  = (size_t)std::max(std::max(m.ncols, m.nrows), 1); // x needs ncols, y/b/dinv need nrows
    DArray<double> x(nv), y(nv), b(nv), dinv(nv);
    fill((int)nv, 1.0, x.data());
    fill((int)nv, 0.5, b.data());
@@ -451,7 +451,11 @@ extern "C" int hda_time_kernel(int kind, hda_csr_t A, hda_amg_t amg, int reps, d
          case 0: spmv(m, 1.0, x.data(), 0.0, nullptr, y.data()); break;
          case 1: jacobi(m, dinv.data(), b.data(), x.data(), y.data(), -1); break;
          case 2: residual(m, x.data(), b.data(), y.data()); break;
-         case 3: HDA_REQUIRE(amg, "V-cycle timing needs a hierarchy"); amg->amg->apply(b.data(), y.data(), -1); break;
+         case 3:
+            HDA_REQUIRE(amg, "V-cycle timing needs a hierarchy");
+            HDA_REQUIRE(nv >= amg->amg->vec_len0(), "vector too short for the hierarchy");
+            amg->amg->apply(b.data(), y.data(), -1);
+            break;
          default: throw Error("unknown kernel kind");
       }
    };

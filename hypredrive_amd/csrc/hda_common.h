@@ -150,6 +150,10 @@ struct DCsr {
    DArray<int>    col;    // nnz
    DArray<double> val;    // nnz
    double         avg_row() const { return nrows ? (double)nnz / nrows : 0.0; }
+   // streaming plan of the LDS-staged SpMV (built lazily by the first product): chunk c owns
+   // the rows whose first entry lies in [c*kChunk, (c+1)*kChunk)
+   mutable DArray<int> chunk_row; // nchunks+1
+   mutable int         nchunks = 0, maxrow = -1;
 };
 
 // HDA_VERBOSE=1: phase trace on stderr (each trace point synchronises the stream)

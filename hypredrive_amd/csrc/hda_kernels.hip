@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <unordered_map>
 
@@ -261,12 +262,154 @@ static int pick_lpr(const DCsr &A)
    return 64;
 }
 
+// ---- LDS-staged streaming SpMV ---------------------------------------------------------
+// The vector kernel above leaves lanes idle whenever row lengths do not match the lane-group
+// width and issues narrow, row-shaped loads.  Here a workgroup streams a contiguous chunk of
+// ~kChunk entries with fully coalesced (val, col) loads, multiplies by the gathered x and
+// parks the products in LDS; rows are then reduced out of LDS by lane groups sized to the
+// number of rows in the chunk.  Chunks are dealt to workgroups so that workgroups sharing an
+// XCD (blockIdx % 8) walk a contiguous eighth of the matrix: every XCD's L2 then holds one
+// window of x instead of all eight holding the same one.
+constexpr int kChunk     = 2048;
+constexpr int kMaxRowLds = 1024; // rows longer than this use the vector kernel
+
+__global__ __launch_bounds__(256) void k_chunk_rows(int nchunks, int nrows, const int *__restrict__ rowptr, int *__restrict__ chunk_row)
+{
+   const int c = blockIdx.x * 256 + threadIdx.x;
+   if (c > nchunks) return;
+   if (c == nchunks) { chunk_row[c] = nrows; return; }
+   const int target = c * kChunk;
+   int       lo = 0, hi = nrows; // smallest r with rowptr[r] >= target
+   while (lo < hi)
+   {
+      const int mid = (lo + hi) >> 1;
+      if (rowptr[mid] < target) lo = mid + 1;
+      else hi = mid;
+   }
+   chunk_row[c] = lo;
+}
+__global__ __launch_bounds__(256) void k_max_row(int n, const int *__restrict__ rowptr, int *mx)
+{
+   int m = 0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = max(m, rowptr[i + 1] - rowptr[i]);
+   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+   if ((threadIdx.x & 63) == 0) atomicMax(mx, m);
+}
+
+static void ensure_plan(const DCsr &A)
+{
+   if (A.maxrow >= 0) return;
+   DArray<int> mx(1);
+   mx.zero();
+   if (A.nrows) k_max_row<<<std::min(ceil_div(A.nrows, 256), 1024), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), mx.data());
+   int m = 0;
+   mx.download(&m, 1);
+   A.maxrow  = m;
+   A.nchunks = std::max(1, ceil_div(A.nnz, kChunk));
+   A.chunk_row.alloc((size_t)A.nchunks + 1);
+   k_chunk_rows<<<ceil_div(A.nchunks + 1, 256), 256, 0, STREAM>>>(A.nchunks, A.nrows, A.rowptr.data(), A.chunk_row.data());
+}
+
+template <int MODE, bool DOT>
+__global__ __launch_bounds__(256) void k_spmv_stream(int nchunks, const int *__restrict__ chunk_row,
+                                                     const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                     const double *__restrict__ val, const double *__restrict__ x,
+                                                     double alpha, double beta, const double *yin,
+                                                     const double *__restrict__ b, const double *__restrict__ dinv,
+                                                     const double *__restrict__ w, double *out,
+                                                     double *__restrict__ partial)
+{
+   extern __shared__ double prod[];
+   const int tid  = threadIdx.x;
+   const int xcd  = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+   const int nper = (nchunks + 7) >> 3;
+   double    acc  = 0.0;
+   for (int i = slot; i < nper; i += nslot)
+   {
+      const int c = xcd * nper + i;
+      if (c >= nchunks) break;
+      const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
+      if (r0 == r1) continue;
+      const int k0 = rowptr[r0], k1 = rowptr[r1];
+      // stage 1: products -> LDS, four independent (val, col, x) triples in flight per lane
+      int k = k0 + tid;
+      for (; k + 768 < k1; k += 1024)
+      {
+         const double v0 = val[k], v1 = val[k + 256], v2 = val[k + 512], v3 = val[k + 768];
+         const int    c0 = col[k], c1 = col[k + 256], c2 = col[k + 512], c3 = col[k + 768];
+         const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+         prod[k - k0]       = v0 * x0;
+         prod[k - k0 + 256] = v1 * x1;
+         prod[k - k0 + 512] = v2 * x2;
+         prod[k - k0 + 768] = v3 * x3;
+      }
+      for (; k < k1; k += 256) prod[k - k0] = val[k] * x[col[k]];
+      __syncthreads();
+      // stage 2: L lanes per row, L = largest power of two with rows*L <= 256
+      const int nr = r1 - r0;
+      int       L  = 1;
+      while (L < 64 && nr * (L << 1) <= 256) L <<= 1;
+      const int lane = tid & (L - 1);
+      for (int rr = tid / L; rr < nr; rr += 256 / L)
+      {
+         const int r = r0 + rr;
+         const int s = rowptr[r] - k0, e = rowptr[r + 1] - k0;
+         double    sum = 0.0;
+         for (int q = s + lane; q < e; q += L) sum += prod[q];
+         for (int o = L >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+         if (lane == 0)
+         {
+            double o0;
+            if (MODE == MODE_PLAIN)
+            {
+               o0 = (beta == 0.0) ? alpha * sum : alpha * sum + beta * yin[r];
+               if (DOT) acc += o0 * w[r];
+            }
+            else if (MODE == MODE_RESID) o0 = b[r] - sum;
+            else
+            {
+               const double br = b[r];
+               o0              = x[r] + dinv[r] * (br - sum);
+               if (DOT) acc += br * o0;
+            }
+            out[r] = o0;
+         }
+      }
+      __syncthreads();
+   }
+   if (DOT)
+   {
+      acc = block_sum(acc);
+      if (tid == 0) partial[blockIdx.x] = acc;
+   }
+}
+
+static int spmv_mode()
+{
+   static int m = -1;
+   if (m < 0)
+   {
+      const char *e = getenv("HDA_SPMV");
+      m             = (e && !strcmp(e, "vector")) ? 1 : 0;
+   }
+   return m;
+}
+
 template <int MODE, bool DOT>
 static void launch_spmv(const DCsr &A, const double *x, double alpha, double beta,
                         const double *yin, const double *b, const double *dinv, const double *w,
                         double *out, double *partial)
 {
    if (A.nrows == 0 && !DOT) return;
+   ensure_plan(A);
+   if (spmv_mode() == 0 && A.maxrow <= kMaxRowLds)
+   {
+      const int    grid = DOT ? kRedBlocks : std::min(kRedBlocks, ((A.nchunks + 7) / 8) * 8);
+      const size_t lds  = sizeof(double) * (size_t)(kChunk + A.maxrow);
+      k_spmv_stream<MODE, DOT><<<grid, 256, lds, STREAM>>>(A.nchunks, A.chunk_row.data(), A.rowptr.data(), A.col.data(),
+                                                           A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial);
+      return;
+   }
    const int lpr  = pick_lpr(A);
    long      need = ((long)A.nrows * lpr + 511) / 512; // two rows per group
    int       grid = DOT ? kRedBlocks : (int)std::min<long>(std::max<long>(need, 1), kRedBlocks);
