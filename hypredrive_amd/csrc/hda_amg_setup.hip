@@ -642,7 +642,7 @@ static long long spgemm_slot_budget()
    return b;
 }
 
-void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
+static void spgemm_hash(const DCsr &X, const DCsr &Y, DCsr &C)
 {
    HDA_REQUIRE(X.ncols <= Y.nrows || X.nnz == 0, "spgemm: inner dimensions");
    const int n = X.nrows;
@@ -738,6 +738,290 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
          gather_batch(b);
       }
    }
+}
+
+// ---- expand / sort / compress SpGEMM in LDS ---------------------------------------------
+// A workgroup takes a run of consecutive rows holding ~T products, expands the products in
+// enumeration order p (k ascending over the X row, q ascending over the Y row) into LDS as
+// keys (local row | column | p), bitonic-sorts the keys, and sums every (row, column)
+// segment sequentially in p order -- exactly the accumulation order of a sequential
+// Gustavson pass, so results stay bit-identical to the oracle, with coalesced global
+// traffic and no global hash tables.  Two passes (count, then fill) avoid scratch storage.
+
+__global__ __launch_bounds__(256) void k_entry_len(int nnz, const int *__restrict__ xcj, const int *__restrict__ yrp, int *__restrict__ len)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256)
+   {
+      const int r = xcj[k];
+      len[k]      = yrp[r + 1] - yrp[r];
+   }
+}
+__global__ __launch_bounds__(256) void k_row_np_max(int n, const int *__restrict__ xrp, const long long *__restrict__ eoff, int *mx)
+{
+   int m = 0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+   {
+      const long long d = eoff[xrp[i + 1]] - eoff[xrp[i]];
+      m                 = max(m, (int)min(d, (long long)0x7fffffff));
+   }
+   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+   if ((threadIdx.x & 63) == 0) atomicMax(mx, m);
+}
+__global__ __launch_bounds__(256) void k_esc_chunk_rows(int nchunks, int nrows, long long T, const int *__restrict__ xrp,
+                                                        const long long *__restrict__ eoff, int *__restrict__ chunk_row)
+{
+   const int c = blockIdx.x * 256 + threadIdx.x;
+   if (c > nchunks) return;
+   if (c == nchunks) { chunk_row[c] = nrows; return; }
+   const long long target = (long long)c * T;
+   int             lo = 0, hi = nrows; // smallest r whose first product index >= target
+   while (lo < hi)
+   {
+      const int mid = (lo + hi) >> 1;
+      if (eoff[xrp[mid]] < target) lo = mid + 1;
+      else hi = mid;
+   }
+   chunk_row[c] = lo;
+}
+
+constexpr int kEscEntries = 1536; // X entries of a chunk staged in LDS for the expansion
+
+// One pass: products -> LDS keys, sort, segment sums in enumeration order, results written to
+// a scratch CSR whose rows start at rowstart[i] (<= the row's first product index), counts in cnt.
+__global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, int cap, const int *__restrict__ chunk_row,
+                                                    const int *__restrict__ xrp, const int *__restrict__ xcj,
+                                                    const double *__restrict__ xv, const int *__restrict__ yrp,
+                                                    const int *__restrict__ ycj, const double *__restrict__ yv,
+                                                    const long long *__restrict__ eoff, long long *__restrict__ rowstart,
+                                                    int *__restrict__ cnt, int *__restrict__ scol, double *__restrict__ sval)
+{
+   extern __shared__ unsigned long long esc_lds[];
+   unsigned long long *keys = esc_lds;                   // cap keys
+   double             *vals = (double *)(esc_lds + cap); // cap products, indexed by p (never moved)
+   int                *eofs = (int *)(esc_lds + 2 * cap); // kEscEntries+1 entry offsets relative to p0
+   int                *erow = eofs + kEscEntries + 1;      // local row of every staged entry
+   __shared__ int      scan[256];
+   const int           tid = threadIdx.x;
+   for (int c = blockIdx.x; c < nchunks; c += gridDim.x)
+   {
+      const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
+      if (r0 == r1) continue;
+      const int       e0 = xrp[r0], e1 = xrp[r1], ne = e1 - e0;
+      const long long p0 = eoff[e0];
+      const int       span = (int)(eoff[e1] - p0);
+      if (span == 0) continue;
+      int S = 256;
+      while (S < span) S <<= 1;
+      const bool staged = ne <= kEscEntries;
+      if (staged)
+      { // entry offsets and entry -> local row, coalesced
+         for (int q = tid; q <= ne; q += 256) eofs[q] = (int)(eoff[e0 + q] - p0);
+         for (int r = r0 + tid; r < r1; r += 256)
+            for (int e = xrp[r]; e < xrp[r + 1]; e++) erow[e - e0] = r - r0;
+         __syncthreads();
+      }
+      // ---- expand: one product per lane; its X entry by binary search (LDS when staged)
+      for (int p = tid; p < S; p += 256)
+      {
+         unsigned long long key = ~0ULL;
+         if (p < span)
+         {
+            int e, lrow, q;
+            if (staged)
+            {
+               int lo = 0, hi = ne - 1; // last entry with eofs <= p
+               while (lo < hi)
+               {
+                  const int mid = (lo + hi + 1) >> 1;
+                  if (eofs[mid] <= p) lo = mid;
+                  else hi = mid - 1;
+               }
+               e    = e0 + lo;
+               lrow = erow[lo];
+               q    = p - eofs[lo];
+            }
+            else
+            {
+               const long long gp = p0 + p;
+               int             lo = e0, hi = e1 - 1;
+               while (lo < hi)
+               {
+                  const int mid = (lo + hi + 1) >> 1;
+                  if (eoff[mid] <= gp) lo = mid;
+                  else hi = mid - 1;
+               }
+               e      = lo;
+               int rl = r0, rh = r1 - 1;
+               while (rl < rh)
+               {
+                  const int mid = (rl + rh + 1) >> 1;
+                  if (xrp[mid] <= e) rl = mid;
+                  else rh = mid - 1;
+               }
+               lrow = rl - r0;
+               q    = (int)(gp - eoff[e]);
+            }
+            const int yq = yrp[xcj[e]] + q;
+            key          = ((unsigned long long)lrow << 44) | ((unsigned long long)(unsigned)ycj[yq] << 13) | (unsigned long long)p;
+            vals[p]      = xv[e] * yv[yq];
+         }
+         keys[p] = key;
+      }
+      __syncthreads();
+      // ---- bitonic sort of S keys
+      for (int k = 2; k <= S; k <<= 1)
+         for (int j = k >> 1; j > 0; j >>= 1)
+         {
+            for (int t = tid; t < (S >> 1); t += 256)
+            {
+               const int i = ((t / j) * (j << 1)) + (t % j), q = i + j;
+               const unsigned long long a = keys[i], b = keys[q];
+               const bool up = ((i & k) == 0);
+               if ((a > b) == up) { keys[i] = b; keys[q] = a; }
+            }
+            __syncthreads();
+         }
+      // ---- heads of (row, column) segments; inclusive head count per sorted position
+      const int per = S >> 8, t0 = tid * per;
+      int       local = 0;
+      for (int t = t0; t < t0 + per && t < span; t++) local += (t == 0) || ((keys[t] >> 13) != (keys[t - 1] >> 13));
+      scan[tid] = local;
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1)
+      {
+         const int add = (tid >= o) ? scan[tid - o] : 0;
+         __syncthreads();
+         scan[tid] += add;
+         __syncthreads();
+      }
+      int incl = scan[tid] - local; // heads before this lane's range
+      for (int t = t0; t < t0 + per && t < span; t++)
+      {
+         const unsigned long long kt = keys[t];
+         const bool head = (t == 0) || ((kt >> 13) != (keys[t - 1] >> 13));
+         incl += head;
+         const int row = r0 + (int)(kt >> 44);
+         if (head)
+         {
+            if (t == 0 || (kt >> 44) != (keys[t - 1] >> 44)) rowstart[row] = p0 + (incl - 1);
+            double sum = vals[kt & 0x1FFF];
+            for (int u = t + 1; u < span && (keys[u] >> 13) == (kt >> 13); u++) sum += vals[keys[u] & 0x1FFF];
+            scol[p0 + incl - 1] = (int)((kt >> 13) & 0x7FFFFFFF);
+            sval[p0 + incl - 1] = sum;
+         }
+         if (t == span - 1 || (keys[t + 1] >> 44) != (kt >> 44)) cnt[row] = incl; // provisional: heads up to the row's end
+      }
+      __syncthreads();
+   }
+}
+
+// cnt[row] currently holds (#heads in the chunk up to the row's end); turn it into the row's
+// own count using rowstart, which holds chunk_base + (#heads before the row)
+__global__ __launch_bounds__(256) void k_esc_fix_counts(int n, const int *__restrict__ xrp, const long long *__restrict__ eoff,
+                                                        const int *__restrict__ chunk_of_row_base_dummy, const long long *__restrict__ rowstart,
+                                                        const long long *__restrict__ chunkbase, int *__restrict__ cnt)
+{
+   (void)xrp; (void)eoff; (void)chunk_of_row_base_dummy;
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   if (cnt[i] > 0) cnt[i] = (int)(chunkbase[i] + cnt[i] - rowstart[i]);
+}
+
+// chunkbase[i] = first product index of the chunk that owns row i
+__global__ __launch_bounds__(256) void k_esc_chunkbase(int nchunks, const int *__restrict__ chunk_row, const int *__restrict__ xrp,
+                                                       const long long *__restrict__ eoff, long long *__restrict__ chunkbase)
+{
+   const int c = blockIdx.x;
+   if (c >= nchunks) return;
+   const int       r0 = chunk_row[c], r1 = chunk_row[c + 1];
+   const long long p0 = (r0 < r1) ? eoff[xrp[r0]] : 0;
+   for (int r = r0 + threadIdx.x; r < r1; r += 256) chunkbase[r] = p0;
+}
+
+// C rows out of the scratch rows, 8 lanes per row
+__global__ __launch_bounds__(256) void k_esc_compact(int n, const int *__restrict__ crp, const long long *__restrict__ rowstart,
+                                                     const int *__restrict__ scol, const double *__restrict__ sval,
+                                                     int *__restrict__ ccj, double *__restrict__ cv)
+{
+   const int  lane = threadIdx.x & 7;
+   const long G    = (long)gridDim.x * 32;
+   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 3; i < n; i += G)
+   {
+      const int       s = crp[i], e = crp[i + 1];
+      const long long o = rowstart[i];
+      for (int q = s + lane; q < e; q += 8)
+      {
+         ccj[q] = scol[o + (q - s)];
+         cv[q]  = sval[o + (q - s)];
+      }
+   }
+}
+
+static bool use_hash_spgemm()
+{
+   static int m = -1;
+   if (m < 0)
+   {
+      const char *e = getenv("HDA_SPGEMM");
+      m             = (e && !strcmp(e, "hash")) ? 1 : 0;
+   }
+   return m == 1;
+}
+
+void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
+{
+   HDA_REQUIRE(X.ncols <= Y.nrows || X.nnz == 0, "spgemm: inner dimensions");
+   const int n = X.nrows;
+   if (n == 0 || X.nnz == 0 || use_hash_spgemm()) return spgemm_hash(X, Y, C);
+   DArray<int>       elen((size_t)X.nnz + 1), mx(1);
+   DArray<long long> eoff((size_t)X.nnz + 1);
+   k_entry_len<<<std::min(ceil_div(X.nnz, 256), 1 << 16), 256, 0, STREAM>>>(X.nnz, X.col.data(), Y.rowptr.data(), elen.data());
+   exclusive_scan64(X.nnz, elen.data(), eoff.data());
+   mx.zero();
+   k_row_np_max<<<std::min(ceil_div(n, 256), 1024), 256, 0, STREAM>>>(n, X.rowptr.data(), eoff.data(), mx.data());
+   long long total = 0;
+   int       maxnp = 0;
+   HDA_HIP(hipMemcpyAsync(&total, eoff.data() + X.nnz, 8, hipMemcpyDeviceToHost, STREAM));
+   HDA_HIP(hipMemcpyAsync(&maxnp, mx.data(), 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   // chunk target T and LDS capacity 2T: a chunk spans < T + maxnp <= 2T products
+   int T = 1024;
+   while (T < maxnp) T <<= 1;
+   HDA_TRACE("  spgemm(esc): n=%d products=%lld max/row=%d T=%d", n, total, maxnp, T);
+   static const long long scratch_cap = getenv("HDA_ESC_SCRATCH") ? atoll(getenv("HDA_ESC_SCRATCH")) : (3LL << 30); // products
+   if (T > 4096 || Y.ncols >= (1LL << 31) || total > scratch_cap) return spgemm_hash(X, Y, C); // outside the LDS path
+   const int cap     = 2 * T;
+   const int nchunks = (int)std::max<long long>(1, (total + T - 1) / T);
+   DArray<int>       chunk_row((size_t)nchunks + 1), cnt((size_t)n + 1);
+   DArray<long long> rowstart((size_t)n + 1), chunkbase((size_t)n + 1);
+   DArray<int>       scol((size_t)std::max<long long>(total, 1));
+   DArray<double>    sval((size_t)std::max<long long>(total, 1));
+   k_esc_chunk_rows<<<ceil_div(nchunks + 1, 256), 256, 0, STREAM>>>(nchunks, n, T, X.rowptr.data(), eoff.data(), chunk_row.data());
+   k_esc_chunkbase<<<nchunks, 256, 0, STREAM>>>(nchunks, chunk_row.data(), X.rowptr.data(), eoff.data(), chunkbase.data());
+   cnt.zero();
+   const size_t lds  = (size_t)cap * 16 + (size_t)(2 * kEscEntries + 2) * 4;
+   const int    grid = std::min(nchunks, 256 * 8);
+   static bool  attr_done = false;
+   if (!attr_done)
+   {
+      HDA_HIP(hipFuncSetAttribute((const void *)k_spgemm_esc, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16 + (2 * kEscEntries + 2) * 4));
+      attr_done = true;
+   }
+   k_spgemm_esc<<<grid, 256, lds, STREAM>>>(nchunks, cap, chunk_row.data(), X.rowptr.data(), X.col.data(), X.val.data(),
+                                            Y.rowptr.data(), Y.col.data(), Y.val.data(), eoff.data(), rowstart.data(), cnt.data(),
+                                            scol.data(), sval.data());
+   k_esc_fix_counts<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, nullptr, nullptr, nullptr, rowstart.data(), chunkbase.data(), cnt.data());
+   C.nrows = n;
+   C.ncols = Y.ncols;
+   C.rowptr.alloc((size_t)n + 1);
+   exclusive_scan(n, cnt.data(), C.rowptr.data(), nullptr);
+   HDA_HIP(hipMemcpyAsync(&C.nnz, C.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   C.col.alloc((size_t)std::max(C.nnz, 1));
+   C.val.alloc((size_t)std::max(C.nnz, 1));
+   k_esc_compact<<<std::min(ceil_div((long long)n * 8, 256), 1 << 16), 256, 0, STREAM>>>(n, C.rowptr.data(), rowstart.data(), scol.data(),
+                                                                                  sval.data(), C.col.data(), C.val.data());
+   HDA_TRACE("  spgemm(esc): nnz=%d", C.nnz);
 }
 
 void amg_rap(const DCsr &A, const DCsr &P, const DCsr &R, DCsr &Ac)

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int nchunks, const int *__r
       const int k0 = rowptr[r0], k1 = rowptr[r1];
       // stage 1: products -> LDS, four independent (val, col, x) triples in flight per lane
       int k = k0 + tid;
-      for (; k + 768 < k1; k += 1024)
+for (; k + 768 < k1; k += 1024)
       {
          const double v0 = val[k], v1 = val[k + 256], v2 = val[k + 512], v3 = val[k + 768];
          const int    c0 = col[k], c1 = col[k + 256], c2 = col[k + 512], c3 = col[k + 768];
