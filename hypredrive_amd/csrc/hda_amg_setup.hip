@@ -224,13 +224,13 @@ __global__ __launch_bounds__(256) void k_interp_ub(int n, const int *__restrict_
                                                    const unsigned char *__restrict__ smask,
                                                    const int *__restrict__ cf, const int *__restrict__ nsC,
                                                    int *__restrict__ ub, int *__restrict__ hsz,
-                                                   int *__restrict__ cmark)
+                                                   int *__restrict__ cmark, int *__restrict__ nt)
 {
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
    const int c = cf[i];
    cmark[i]    = (c == 1);
-   int u = 0, h = 0;
+   int u = 0, h = 0, t = 0;
    if (c == 1) u = 1;
    else if (c == -1)
    {
@@ -240,12 +240,13 @@ __global__ __launch_bounds__(256) void k_interp_ub(int n, const int *__restrict_
          const int j  = cj[k];
          const int cj_ = cf[j];
          if (cj_ == 1) u += 1;
-         else if (cj_ == -1) u += nsC[j];
+         else if (cj_ == -1) { u += nsC[j]; t += rp[j + 1] - rp[j]; }
       }
       h = u ? max(8, pow2ceil_dev(2 * u)) : 0;
    }
    ub[i]  = u;
    hsz[i] = h;
+   nt[i]  = t;
 }
 
 struct PEnt {
@@ -299,10 +300,12 @@ __global__ __launch_bounds__(256) void k_interp_build(
    int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
    const unsigned char *__restrict__ smask, const int *__restrict__ cf,
    const long long *__restrict__ uofs, const long long *__restrict__ hofs, int *__restrict__ lcol,
-   double *__restrict__ lw, int *__restrict__ htab, int pmax, double trunc_factor, int *__restrict__ pcnt)
+   double *__restrict__ lw, int *__restrict__ htab, int pmax, double trunc_factor, int *__restrict__ pcnt,
+   const unsigned char *__restrict__ rowmode)
 {
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
+   if (rowmode && !rowmode[i]) return; // handled by the wave-per-row kernel
    const int c = cf[i];
    int      *L = lcol + uofs[i];
    double   *W = lw + uofs[i];
@@ -440,6 +443,15 @@ __global__ __launch_bounds__(256) void k_interp_build(
       for (int q = 0; q < cnt; q++) tot += W[q];
       qsort_abs(L, W, cnt);
       cnt = pmax;
+      for (int a = 1; a < cnt; a++) // kept set -> column order before summing (see oracle)
+      {
+         const int    cc = L[a];
+         const double ww = W[a];
+         int          b  = a - 1;
+         while (b >= 0 && L[b] > cc) { L[b + 1] = L[b]; W[b + 1] = W[b]; b--; }
+         L[b + 1] = cc;
+         W[b + 1] = ww;
+      }
       for (int q = 0; q < cnt; q++) kept += W[q];
       if (kept != 0.0)
       {
@@ -465,6 +477,461 @@ __global__ __launch_bounds__(256) void k_interp_build(
    pcnt[i] = cnt;
 }
 
+// ---- wave-per-row extended+i interpolation ------------------------------------------------
+// Same arithmetic, in the same order, as k_interp_build (and the oracle), but one wavefront
+// owns a row: the row, the candidate set C-hat_i (discovery order) and the weight
+// accumulators live in LDS; strong-F neighbour rows are read 64 entries at a time
+// (coalesced).  Order-sensitive sums stay sequential: the per-neighbour sum walks the
+// ballot bits in ascending kk, and within one neighbour row every target occurs once, so the
+// 64 lanes of a batch update distinct accumulators while batches and neighbours are visited
+// in order.  Rows that do not fit the LDS budget are flagged for k_interp_build.
+__host__ __device__ inline size_t interp_wave_doubles(int cap_row, int cap_ub, int cap_nbr)
+{ // doubles: rval[cap_row] Wv[cap_ub] nval[cap_nbr] misc[2]; ints: 5*cap_row + 2 + 4*cap_ub + cap_nbr
+   return (size_t)cap_row + cap_ub + cap_nbr + 2 + ((size_t)cap_row * 5 + 2 + (size_t)cap_ub * 4 + cap_nbr + 1) / 2 + 1;
+}
+#define WAVE_SYNC()                                         \
+   do {                                                     \
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+      __builtin_amdgcn_wave_barrier();                      \
+   } while (0)
+
+__global__ __launch_bounds__(256) void k_interp_rowmode(int n, const int *__restrict__ rp, const int *__restrict__ ub,
+                                                        const int *__restrict__ nt, int cap_row, int cap_ub, int cap_nbr,
+                                                        unsigned char *__restrict__ rowmode, int *__restrict__ hsz)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   (void)nt; (void)cap_nbr; // long neighbour lists are read from global memory by the wave kernel
+   const bool big = (rp[i + 1] - rp[i]) > cap_row || ub[i] > cap_ub;
+   rowmode[i]     = big ? 1 : 0;
+   if (!big) hsz[i] = 0; // no global hash table for rows the wave kernel handles
+}
+__global__ __launch_bounds__(256) void k_max3(int n, const int *__restrict__ rp, const int *__restrict__ ub, const int *__restrict__ nt, int *mx)
+{
+   int a = 0, b = 0, c = 0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+   {
+      a = max(a, rp[i + 1] - rp[i]);
+      b = max(b, ub[i]);
+      c = max(c, nt[i]);
+   }
+   for (int o = 32; o > 0; o >>= 1) { a = max(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); c = max(c, __shfl_xor(c, o)); }
+   if ((threadIdx.x & 63) == 0) { atomicMax(&mx[0], a); atomicMax(&mx[1], b); atomicMax(&mx[2], c); }
+}
+
+__global__ __launch_bounds__(256) void k_interp_wave(
+   int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+   const unsigned char *__restrict__ smask, const int *__restrict__ cf, const int *__restrict__ nsC,
+   const long long *__restrict__ uofs, int cap_row, int cap_ub, int cap_nbr, int pmax, double trunc_factor,
+   const unsigned char *__restrict__ rowmode, int *__restrict__ lcol, double *__restrict__ lw, int *__restrict__ pcnt)
+{
+   extern __shared__ double ilds[];
+   const int    wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   const size_t per  = interp_wave_doubles(cap_row, cap_ub, cap_nbr);
+   double      *rval = ilds + wave * per, *Wv = rval + cap_row, *nval = Wv + cap_ub, *misc = nval + cap_nbr;
+   int         *rcol = (int *)(misc + 2), *rtype = rcol + cap_row, *rofs = rtype + cap_row; // rofs: cap_row + 1
+   int         *noff = rofs + cap_row + 1, *nbeg = noff + cap_row + 1;                      // neighbour-row staging: offsets, global starts
+   int         *craw = nbeg + cap_row, *ucol = craw + cap_ub, *htb = ucol + cap_ub;         // htb: 2*cap_ub slots, col -> pos+1
+   int         *ncol = htb + 2 * cap_ub;                                                    // ncol: cap_nbr (bit 31 = strong C entry)
+   const int    hmask = 2 * cap_ub - 1;
+   auto lookup = [&](int m) -> int { // position of column m in C-hat_i or -1
+      unsigned h = ((unsigned)m * 2654435761u) & (unsigned)hmask;
+      for (;;)
+      {
+         const int e = htb[h];
+         if (e == 0) return -1;
+         if (ucol[e - 1] == m) return e - 1;
+         h = (h + 1) & (unsigned)hmask;
+      }
+   };
+   const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+   enum { T_DIAG = 0, T_SC = 1, T_SF = 2, T_OTHER = 3 };
+   for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4)
+   {
+      if (rowmode[i]) continue;
+      const int c = cf[i];
+      if (c == 1)
+      {
+         if (lane == 0) { lcol[uofs[i]] = i; lw[uofs[i]] = 1.0; pcnt[i] = 1; }
+         continue;
+      }
+      if (c != -1)
+      {
+         if (lane == 0) pcnt[i] = 0;
+         continue;
+      }
+      const int k0 = rp[i], nk = rp[i + 1] - k0;
+      // ---- 1. stage the row, classify entries, candidate offsets per entry
+      int running = 0;
+      for (int base = 0; base < nk; base += 64)
+      {
+         const int k = base + lane;
+         int       cntk = 0;
+         if (k < nk)
+         {
+            const int j  = cj[k0 + k];
+            const int cfj = cf[j];
+            const bool st = smask[k0 + k] != 0;
+            int t = T_OTHER;
+            if (j == i) t = T_DIAG;
+            else if (st && cfj == 1) { t = T_SC; cntk = 1; }
+            else if (st && cfj == -1) { t = T_SF; cntk = nsC[j]; }
+            rcol[k]  = j;
+            rval[k]  = v[k0 + k];
+            rtype[k] = t | (cfj == -3 ? 8 : 0) | (cfj == 1 ? 16 : 0);
+         }
+         int incl = cntk; // inclusive scan over the wave
+         for (int o = 1; o < 64; o <<= 1)
+         {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+         }
+         if (k < nk) rofs[k] = running + incl - cntk;
+         running += __shfl(incl, 63);
+      }
+      const int ncand = running;
+      WAVE_SYNC();
+      // ---- 1b. stage the strong-F neighbour rows in LDS (one flat, fully parallel copy)
+      int nrun = 0;
+      for (int base = 0; base < nk; base += 64)
+      {
+         const int k  = base + lane;
+         int       ln = 0, js = 0;
+         if (k < nk && (rtype[k] & 7) == T_SF)
+         {
+            const int j = rcol[k];
+            js          = rp[j];
+            ln          = rp[j + 1] - js;
+         }
+         int incl = ln;
+         for (int o = 1; o < 64; o <<= 1)
+         {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+         }
+         if (k < nk) { noff[k] = nrun + incl - ln; nbeg[k] = js; }
+         nrun += __shfl(incl, 63);
+      }
+      const int  nbr_total = nrun;
+      const bool staged    = nbr_total <= cap_nbr; // otherwise neighbour rows are read from global memory
+      if (lane == 0) noff[nk] = nbr_total;
+      WAVE_SYNC();
+      if (staged)
+      {
+         for (int fb = 0; fb < nbr_total; fb += 256)
+         { // four independent 64-entry batches in flight
+            int g[4], m[4];
+            double a[4];
+            unsigned char sm[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+               const int f = fb + 64 * u + lane;
+               g[u]        = -1;
+               if (f < nbr_total)
+               {
+                  int lo = 0, hi = nk - 1; // last k with noff[k] <= f (zero-length entries share offsets)
+                  while (lo < hi)
+                  {
+                     const int mid = (lo + hi + 1) >> 1;
+                     if (noff[mid] <= f) lo = mid;
+                     else hi = mid - 1;
+                  }
+                  g[u] = nbeg[lo] + (f - noff[lo]);
+               }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+               if (g[u] >= 0) { m[u] = cj[g[u]]; a[u] = v[g[u]]; sm[u] = smask[g[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+               if (g[u] >= 0)
+               {
+                  const int f = fb + 64 * u + lane;
+                  nval[f]     = a[u];
+                  ncol[f]     = m[u] | ((sm[u] && cf[m[u]] == 1) ? (int)0x80000000 : 0);
+               }
+         }
+      }
+      WAVE_SYNC();
+      // neighbour-row entry e of neighbour k (e relative to the row): column, value, strong-C flag
+      auto nb_col = [&](int k, int e) -> int { return staged ? (ncol[noff[k] + e] & 0x7FFFFFFF) : cj[nbeg[k] + e]; };
+      auto nb_val = [&](int k, int e) -> double { return staged ? nval[noff[k] + e] : v[nbeg[k] + e]; };
+      auto nb_sc  = [&](int k, int e) -> bool {
+         if (staged) return ncol[noff[k] + e] < 0;
+         const int g = nbeg[k] + e;
+         return smask[g] && cf[cj[g]] == 1;
+      };
+      // ---- 2. candidates in discovery order
+      for (int k = 0; k < nk; k++)
+      {
+         const int t = rtype[k] & 7;
+         if (t == T_SC) { if (lane == 0) craw[rofs[k]] = rcol[k]; }
+         else if (t == T_SF)
+         {
+            const int nj = noff[k + 1] - noff[k];
+            int       q = rofs[k];
+            for (int base = 0; base < nj; base += 64)
+            {
+               const int kk = base + lane;
+               bool      f  = false;
+               int       m  = 0;
+               if (kk < nj)
+               {
+                  m = nb_col(k, kk);
+                  f = nb_sc(k, kk);
+               }
+               const unsigned long long b = __ballot(f);
+               if (f) craw[q + __popcll(b & lt)] = m;
+               q += __popcll(b);
+            }
+         }
+      }
+      WAVE_SYNC();
+      // ---- 3. first occurrences -> C-hat_i in discovery order (ucol), accumulators to zero
+      int cnt = 0;
+      for (int base = 0; base < ncand; base += 64)
+      {
+         const int ci = base + lane;
+         bool      uq = false;
+         int       m  = 0;
+         if (ci < ncand)
+         {
+            m  = craw[ci];
+            uq = true;
+            for (int e = 0; e < ci; e++)
+               if (craw[e] == m) { uq = false; break; }
+         }
+         const unsigned long long b = __ballot(uq);
+         if (uq)
+         {
+            const int pos = cnt + __popcll(b & lt);
+            ucol[pos]     = m;
+            Wv[pos]       = 0.0;
+         }
+         cnt += __popcll(b);
+      }
+      WAVE_SYNC();
+      for (int q = lane; q <= hmask; q += 64) htb[q] = 0;
+      WAVE_SYNC();
+      for (int q = lane; q < cnt; q += 64)
+      { // set semantics: any insertion order gives the same lookups
+         unsigned h = ((unsigned)ucol[q] * 2654435761u) & (unsigned)hmask;
+         while (atomicCAS(&htb[h], 0, q + 1) != 0) h = (h + 1) & (unsigned)hmask;
+      }
+      WAVE_SYNC();
+      // ---- 4. weights, neighbours visited in ascending k
+      if (lane == 0)
+      {
+         double d = 0.0;
+         for (int k = 0; k < nk; k++)
+            if ((rtype[k] & 7) == T_DIAG) d = rval[k];
+         misc[0] = d;
+      }
+      WAVE_SYNC();
+      for (int k = 0; k < nk; k++)
+      {
+         const int    t = rtype[k];
+         const int    j = rcol[k];
+         const double aij = rval[k];
+         if ((t & 7) == T_DIAG) continue;
+         if (t & 16)
+         { // a C point: member of C-hat_i?
+            const int pos = lookup(j);
+            if (pos >= 0)
+            {
+               if (lane == 0) Wv[pos] += aij;
+               WAVE_SYNC();
+               continue;
+            }
+         }
+         if ((t & 7) == T_SF)
+         {
+            const int nj = noff[k + 1] - noff[k];
+            // a_jj and its sign
+            double ajj = 0.0;
+            for (int base = 0; base < nj; base += 64)
+            {
+               const int kk = base + lane;
+               const bool hit = kk < nj && nb_col(k, kk) == j;
+               const unsigned long long b = __ballot(hit);
+               const double             a = hit ? nb_val(k, kk) : 0.0;
+               if (b) ajj = __shfl(a, __ffsll((long long)b) - 1);
+            }
+            const double sgn = (ajj < 0.0) ? -1.0 : 1.0;
+            // ordered sum over the qualifying entries of row j
+            double sum = 0.0;
+            for (int base = 0; base < nj; base += 64)
+            {
+               const int kk = base + lane;
+               bool      cond = false;
+               double    a    = 0.0;
+               if (kk < nj)
+               {
+                  const int m = nb_col(k, kk);
+                  a           = nb_val(k, kk);
+                  if (sgn * a < 0.0) cond = (m == i) || lookup(m) >= 0;
+               }
+               unsigned long long bits = __ballot(cond);
+               while (bits)
+               {
+                  const int l = __ffsll((long long)bits) - 1;
+                  sum += __shfl(a, l);
+                  bits &= bits - 1;
+               }
+            }
+            if (sum != 0.0)
+            {
+               const double distribute = aij / sum;
+               for (int base = 0; base < nj; base += 64)
+               {
+                  const int kk = base + lane;
+                  if (kk < nj)
+                  {
+                     const int    m = nb_col(k, kk);
+                     const double a = nb_val(k, kk);
+                     if (sgn * a < 0.0)
+                     {
+                        const int pos = lookup(m);
+                        if (pos >= 0) Wv[pos] += distribute * a;
+                        else if (m == i) misc[0] += distribute * a;
+                     }
+                  }
+                  WAVE_SYNC();
+               }
+            }
+            else
+            {
+               if (lane == 0) misc[0] += aij;
+               WAVE_SYNC();
+            }
+            continue;
+         }
+         if (!(t & 8))
+         { // weak connection lumped into the diagonal
+            if (lane == 0) misc[0] += aij;
+            WAVE_SYNC();
+         }
+      }
+      WAVE_SYNC();
+      const double diagonal = misc[0];
+      if (diagonal != 0.0)
+         for (int q = lane; q < cnt; q += 64) Wv[q] = Wv[q] / (-diagonal);
+      WAVE_SYNC();
+      // ---- 5. truncation and output (serial parts on lane 0, exactly the oracle's sequence)
+      const long long o = uofs[i];
+      int             out_cnt = cnt;
+      if (trunc_factor > 0.0 && cnt > 0)
+      {
+         if (lane == 0)
+         {
+            double mx = 0.0, tot = 0.0, kept = 0.0;
+            for (int q = 0; q < cnt; q++)
+            {
+               if (fabs(Wv[q]) > mx) mx = fabs(Wv[q]);
+               tot += Wv[q];
+            }
+            int c2 = 0;
+            for (int q = 0; q < cnt; q++)
+               if (fabs(Wv[q]) >= trunc_factor * mx)
+               {
+                  ucol[c2] = ucol[q];
+                  Wv[c2]   = Wv[q];
+                  kept += Wv[c2];
+                  c2++;
+               }
+            if (kept != 0.0)
+            {
+               const double sc = tot / kept;
+               for (int q = 0; q < c2; q++) Wv[q] *= sc;
+            }
+            rofs[0] = c2;
+         }
+         WAVE_SYNC();
+         cnt = out_cnt = rofs[0];
+      }
+      if (pmax > 0 && cnt > pmax)
+      {
+         // does a group of equal |w| straddle the cut?  If not the kept set is the top pmax.
+         bool straddle = false;
+         for (int base = 0; base < cnt; base += 64)
+         {
+            const int q = base + lane;
+            bool      s = false;
+            if (q < cnt)
+            {
+               const double aq = fabs(Wv[q]);
+               int          gt = 0, eq = 0;
+               for (int r = 0; r < cnt; r++)
+               {
+                  const double ar = fabs(Wv[r]);
+                  gt += ar > aq;
+                  eq += ar == aq;
+               }
+               s = gt < pmax && gt + eq > pmax;
+               craw[q]  = gt; // rank by strict dominance
+            }
+            straddle = straddle || __ballot(s) != 0ULL;
+         }
+         WAVE_SYNC();
+         if (lane == 0)
+         {
+            double tot = 0.0, kept = 0.0;
+            for (int q = 0; q < cnt; q++) tot += Wv[q];
+            int    kc[16];
+            double kw[16];
+            int    nkpt = 0;
+            if (!straddle)
+            {
+               for (int q = 0; q < cnt && nkpt < pmax && nkpt < 16; q++)
+                  if (craw[q] < pmax) { kc[nkpt] = ucol[q]; kw[nkpt] = Wv[q]; nkpt++; }
+            }
+            else
+            {
+               qsort_abs(ucol, Wv, cnt); // exact tie order of the reference algorithm
+               for (int q = 0; q < pmax && q < 16; q++) { kc[q] = ucol[q]; kw[q] = Wv[q]; }
+               nkpt = pmax < 16 ? pmax : 16;
+            }
+            for (int a = 1; a < nkpt; a++)
+            {
+               const int    cc = kc[a];
+               const double ww = kw[a];
+               int          b  = a - 1;
+               while (b >= 0 && kc[b] > cc) { kc[b + 1] = kc[b]; kw[b + 1] = kw[b]; b--; }
+               kc[b + 1] = cc;
+               kw[b + 1] = ww;
+            }
+            for (int q = 0; q < nkpt; q++) kept += kw[q];
+            const double sc = (kept != 0.0) ? tot / kept : 1.0;
+            for (int q = 0; q < nkpt; q++)
+            {
+               lcol[o + q] = kc[q];
+               lw[o + q]   = (kept != 0.0) ? kw[q] * sc : kw[q];
+            }
+            pcnt[i] = nkpt;
+         }
+      }
+      else
+      { // few entries: column order by insertion on lane 0
+         if (lane == 0)
+         {
+            for (int a = 1; a < out_cnt; a++)
+            {
+               const int    cc = ucol[a];
+               const double ww = Wv[a];
+               int          b  = a - 1;
+               while (b >= 0 && ucol[b] > cc) { ucol[b + 1] = ucol[b]; Wv[b + 1] = Wv[b]; b--; }
+               ucol[b + 1] = cc;
+               Wv[b + 1]   = ww;
+            }
+            for (int q = 0; q < out_cnt; q++) { lcol[o + q] = ucol[q]; lw[o + q] = Wv[q]; }
+            pcnt[i] = out_cnt;
+         }
+      }
+      WAVE_SYNC();
+   }
+}
+
 __global__ __launch_bounds__(256) void k_interp_gather(int n, const long long *__restrict__ uofs,
                                                        const int *__restrict__ prp,
                                                        const int *__restrict__ lcol,
@@ -488,13 +955,30 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
 {
    const int n = A.nrows;
    const int g = ceil_div(std::max(n, 1), 256);
-   DArray<int>       nsC((size_t)n + 1), ub((size_t)n + 1), hsz((size_t)n + 1), cmark((size_t)n + 1), cidx((size_t)n + 1);
+   DArray<int>       nsC((size_t)n + 1), ub((size_t)n + 1), hsz((size_t)n + 1), cmark((size_t)n + 1), cidx((size_t)n + 1), nt((size_t)n + 1);
    DArray<long long> uofs((size_t)n + 1), hofs((size_t)n + 1);
    k_count_strongC<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, nsC.data());
-   k_interp_ub<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, nsC.data(), ub.data(), hsz.data(), cmark.data());
+   k_interp_ub<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, nsC.data(), ub.data(), hsz.data(), cmark.data(), nt.data());
    HDA_TRACE("  interp: ub done");
    exclusive_scan(n, cmark.data(), cidx.data(), nullptr);
-   HDA_TRACE("  interp: scan cidx done");
+   // rows that fit the LDS budget go to the wave-per-row kernel, the rest keep the global-hash kernel
+   DArray<unsigned char> rowmode((size_t)n + 1);
+   DArray<int>           mx(3);
+   mx.zero();
+   k_max3<<<std::min(g, 1024), 256, 0, STREAM>>>(n, A.rowptr.data(), ub.data(), nt.data(), mx.data());
+   int hmx[3] = {0, 0, 0};
+   mx.download(hmx, 3);
+   static const char *imode = getenv("HDA_INTERP"); // "thread" / "wave" force one kernel (diagnostics)
+   // short rows (fine grids): one thread per row keeps 64 rows in flight per wave; long rows: one wave per row
+   bool use_wave = pmax > 0 && pmax <= 16 && hmx[0] > 16;
+   if (imode && !strcmp(imode, "thread")) use_wave = false;
+   if (imode && !strcmp(imode, "wave")) use_wave = pmax > 0 && pmax <= 16;
+   int cap_row = 8, cap_ub = 16, cap_nbr = 64;
+   while (cap_row < hmx[0] && cap_row < 256) cap_row <<= 1;
+   while (cap_ub < hmx[1] && cap_ub < 1024) cap_ub <<= 1;
+   while (cap_nbr < hmx[2] && cap_nbr < 1024) cap_nbr <<= 1;
+   if (use_wave)
+      k_interp_rowmode<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), ub.data(), nt.data(), cap_row, cap_ub, cap_nbr, rowmode.data(), hsz.data());
    exclusive_scan64(n, ub.data(), uofs.data());
    exclusive_scan64(n, hsz.data(), hofs.data());
    long long tot_u = 0, tot_h = 0;
@@ -505,11 +989,28 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    Context::get().sync();
    DArray<int>    lcol((size_t)std::max<long long>(tot_u, 1)), htab((size_t)std::max<long long>(tot_h, 1));
    DArray<double> lw((size_t)std::max<long long>(tot_u, 1));
-   HDA_HIP(hipMemsetAsync(htab.data(), 0xFF, sizeof(int) * htab.size(), STREAM));
+   if (tot_h) HDA_HIP(hipMemsetAsync(htab.data(), 0xFF, sizeof(int) * htab.size(), STREAM));
    DArray<int> pcnt((size_t)n + 1);
-   HDA_TRACE("  interp: build (tot_u=%lld tot_h=%lld nc=%d)", tot_u, tot_h, nc);
-   k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(),
-                                         hofs.data(), lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data());
+   HDA_TRACE("  interp: build (tot_u=%lld tot_h=%lld nc=%d maxrow=%d maxub=%d maxnbr=%d wave=%d)", tot_u, tot_h, nc, hmx[0], hmx[1], hmx[2], (int)use_wave);
+   if (use_wave)
+   {
+      const size_t lds = interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * 4;
+      static bool  attr = false;
+      if (!attr)
+      {
+         HDA_HIP(hipFuncSetAttribute((const void *)k_interp_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+         attr = true;
+      }
+      k_interp_wave<<<std::min(ceil_div(n, 4), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf,
+                                                                          nsC.data(), uofs.data(), cap_row, cap_ub, cap_nbr, pmax, trunc_factor,
+                                                                          rowmode.data(), lcol.data(), lw.data(), pcnt.data());
+      if (tot_h)
+         k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
+                                               lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), rowmode.data());
+   }
+   else
+      k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
+                                            lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), nullptr);
    HDA_TRACE("  interp: build done");
    P.nrows = n;
    P.ncols = nc;

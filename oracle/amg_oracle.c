@@ -887,6 +887,9 @@ orc_interp_extpi(const orc_csr *A, const unsigned char *smask, const int *cf, in
             for (int q = 0; q < cnt; q++) tot += row[q].w;
             pent_qsort_abs(row, cnt);
             cnt = pmax;
+            /* the kept SET is what the sort decides; sums run in column order so that a
+             * data-parallel top-k selection gives bit-identical weights */
+            qsort(row, (size_t)cnt, sizeof(pent), pent_cmp_col);
             for (int q = 0; q < cnt; q++) kept += row[q].w;
             if (kept != 0.0) { double sc = tot / kept; for (int q = 0; q < cnt; q++) row[q].w *= sc; }
          }
