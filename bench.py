@@ -102,7 +102,7 @@ def run_single(args):
         "solve_phase_hbm_gbs": bytes_solve / (ms_per_step * 1e-3) / 1e9,
         "solve_phase_hbm_frac": bytes_solve / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "dof_iters_per_s": N * iters / (ms_per_step * 1e-3),
-        "roofline": {"kernel": "k_spmv<8,PLAIN,DOT> (level-0 PCG SpMV with fused <s,p>)", "bound": "hbm",
+        "roofline": {"kernel": "k_spmv_stream<PLAIN,DOT> (level-0 PCG SpMV, LDS-staged, fused <s,p>)", "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_launch": k1_bytes, "avg_ms": k1_ms},
@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=256, help="grid points per dimension (global)")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="grid size of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="grid size of the CPU-baseline sample (about 20 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     args = ap.parse_args()

@@ -2,6 +2,7 @@
 #include "../../include/hypredrv_amd.h"
 
 #include "hda_krylov.h"
+#include "hda_comm.h"
 
 #include <chrono>
 #include <cmath>
@@ -545,4 +546,40 @@ extern "C" int hda_memory_stats(double *in_use, double *peak)
    if (in_use) *in_use = (double)pool_bytes_in_use();
    if (peak) *peak = (double)pool_bytes_peak();
    return HDA_OK;
+}
+
+extern "C" int hda_comm_selftest(void)
+{
+   HDA_TRY
+   Comm &cm = Comm::world();
+   // device all-reduce of [rank+1, 1]
+   DArray<double> d(2);
+   double         hv[2] = {(double)cm.rank + 1.0, 1.0};
+   d.upload(hv, 2);
+   cm.allreduce_sum_dev(d.data(), 2);
+   d.download(hv, 2);
+   HDA_REQUIRE(hv[0] == 0.5 * cm.size * (cm.size + 1) && hv[1] == (double)cm.size, "device all-reduce gave a wrong sum");
+   // host all-reduce (max of rank)
+   long long m[1] = {cm.rank};
+   cm.allreduce_host(m, 1, 1);
+   HDA_REQUIRE(m[0] == cm.size - 1, "host all-reduce(max) is wrong");
+   // host all-to-all: rank r sends (r*100 + p) to p
+   std::vector<long long> snd((size_t)cm.size), rcv((size_t)cm.size);
+   std::vector<long>      eight((size_t)cm.size, 8);
+   for (int p = 0; p < cm.size; p++) snd[(size_t)p] = cm.rank * 100 + p;
+   cm.alltoallv_host(snd.data(), eight.data(), rcv.data(), eight.data());
+   for (int p = 0; p < cm.size; p++) HDA_REQUIRE(rcv[(size_t)p] == p * 100 + cm.rank, "host all-to-all is wrong");
+   // device neighbour exchange: one double to every other rank
+   std::vector<int> cnt((size_t)cm.size, 1);
+   cnt[(size_t)cm.rank] = 0;
+   const int      np = cm.size - 1;
+   DArray<double> sb((size_t)std::max(np, 1)), rb((size_t)std::max(np, 1));
+   std::vector<double> hs((size_t)std::max(np, 1), (double)cm.rank), hr((size_t)std::max(np, 1), -1.0);
+   sb.upload(hs.data(), hs.size());
+   rb.upload(hr.data(), hr.size());
+   cm.exchange_dev(sb.data(), cnt.data(), rb.data(), cnt.data());
+   rb.download(hr.data(), hr.size());
+   for (int p = 0, q = 0; p < cm.size; p++)
+      if (p != cm.rank) { HDA_REQUIRE(hr[(size_t)q] == (double)p, "device exchange is wrong"); q++; }
+   HDA_CATCH
 }

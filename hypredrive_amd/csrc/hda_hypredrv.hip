@@ -224,7 +224,8 @@ extern "C" uint32_t HYPREDRV_AMD_CommInit(int rank, int world, int device, const
    err_reset();
    API_TRY
    if (device >= 0) HDA_HIP(hipSetDevice(device));
-   if (world > 1) Comm::set_world(make_rccl_comm(rank, world, uid));
+   // HDA_FORCE_RCCL: build a 1-rank RCCL communicator too (transport self-test on a single GPU)
+   if (world > 1 || getenv("HDA_FORCE_RCCL")) Comm::set_world(make_rccl_comm(rank, world, uid));
    API_CATCH
 }
 typedef void (*hda_allreduce_cb_c)(void *, long, int, int);

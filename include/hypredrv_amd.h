@@ -132,6 +132,9 @@ int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, in
                      double *final_rel, double *r0_norm, double *true_rel, double *k1_avg_ms);
 /* algorithmic HBM bytes of one PCG iteration without the preconditioner */
 double hda_pcg_iteration_bytes(hda_csr_t A);
+/* Exercises the active rank-to-rank transport (RCCL, staged callbacks or self): device
+ * all-reduce, host all-reduce, host all-to-all.  Returns 0 when every result is right. */
+int hda_comm_selftest(void);
 /* allocator statistics (bytes) */
 int hda_memory_stats(double *in_use, double *peak);
 

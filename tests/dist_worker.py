@@ -74,6 +74,8 @@ def mode_solve(out, n, solver):
     from hypredrive_amd import dist as hdist
     from hypredrive_amd import hypredrv as hd
     rank, world = hdist.init("staged")
+    import hypredrive_amd as h
+    assert h.load().hda_comm_selftest() == 0, h.load().hda_last_error()
     P = hdist.factor3(world)
     yaml = f"solver: {solver}\npreconditioner:\n  preset: poisson\n"
     h = hd.Hypredrv(yaml)

@@ -196,3 +196,23 @@ def test_reference_laplacian_driver_unmodified(orc):
     assert r.returncode == 0, r.stdout + r.stderr
     row = re.search(r"^\|\s+0 \|.*\|\s+(\S+) \|\s+(\d+) \|$", r.stdout, re.M)
     assert row and float(row.group(1)) < 1e-6
+
+
+def test_rccl_transport_single_rank_selftest():
+    """RCCL refuses two ranks on one GPU, so the builder cannot run it multi-rank; at least
+    exercise the whole RCCL code path (dlopen, ncclGetUniqueId, ncclCommInitRank, all-reduce,
+    grouped send/recv plumbing) with a 1-rank communicator, in a fresh process."""
+    code = (
+        "import ctypes as C, os\n"
+        "os.environ['HDA_FORCE_RCCL'] = '1'\n"
+        "from hypredrive_amd import hypredrv as hd\n"
+        "L = hd.lib(); uid = (C.c_ubyte * 128)()\n"
+        "hd.check(L.HYPREDRV_AMD_CommGetUniqueId(uid))\n"
+        "hd.check(L.HYPREDRV_AMD_CommInit(0, 1, 0, uid))\n"
+        "assert L.hda_comm_selftest() == 0, L.hda_last_error()\n"
+        "h = hd.Hypredrv('solver: pcg\\npreconditioner: amg\\n'); h.set_laplacian7((12, 12, 12)); r = h.solve()\n"
+        "assert r['converged']\n"
+        "hd.check(L.HYPREDRV_AMD_CommFinalize()); print('rccl-ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT),
+                       timeout=600)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
