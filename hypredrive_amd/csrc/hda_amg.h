@@ -90,6 +90,11 @@ class Amg {
    double                stats_nnz[32] = {0}, stats_rows[32] = {0}; // global sizes per level
    int                   stats_levels = 0;
    DArray<double>        cbuf_f, cbuf_u;
+   // row-partitioned runs: levels with few rows stay whole on every rank and are cycled
+   // redundantly after one small all-reduce of the restricted residual
+   std::unique_ptr<Amg>  tail;
+   DCsr                  own_A0; // level-0 operator of a tail hierarchy
+   void                  adopt_tail(Amg &parent, int first_level);
    std::vector<AmgLevel> levels;
    DArray<double>        coarse_invT; // dense inverse of the coarsest operator (column-major)
    int                   coarse_n = 0;

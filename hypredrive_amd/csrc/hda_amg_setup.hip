@@ -1663,8 +1663,8 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
    DCsr G0;
    gather_global(Aloc, part0, ghost_gids0, G0);
    build_hierarchy(G0); // replicated, identical on every rank
-   dist        = true;
-   const int L = (int)levels.size();
+   dist  = true;
+   int L = (int)levels.size();
    // row starts of every rank on every level: coarse rows follow their fine C points
    std::vector<std::vector<long long>> parts((size_t)L);
    parts[0] = part0;
@@ -1679,25 +1679,46 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
       for (size_t r = 0; r < parts[(size_t)l].size(); r++) parts[(size_t)l + 1][r] = h[(size_t)parts[(size_t)l][r]];
    }
    const int r = cm.rank;
-   std::vector<size_t> tail((size_t)L, 0); // largest ghost tail of any plan that feeds level-l vectors
+   // Levels with few rows are latency-bound when partitioned (4 halo exchanges per level and
+   // cycle): keep them whole on every rank instead.  The restricted residual of the first such
+   // level is summed into a replicated vector (one small all-reduce) and the rest of the
+   // V-cycle runs redundantly on the replicated matrices this setup already holds.
+   static const long long rep_rows = getenv("HDA_REPLICATE_ROWS") ? atoll(getenv("HDA_REPLICATE_ROWS")) : 100000;
+   int first_rep = L - 1;
+   for (int l = 1; l < L; l++)
+      if (level_A(l).nrows <= rep_rows) { first_rep = l; break; }
+   const long long rep_n   = level_A(first_rep).nrows;
+   const bool      has_tail = first_rep < L - 1;
+   if (has_tail)
+   {
+      tail = std::make_unique<Amg>(prm);
+      tail->adopt_tail(*this, first_rep);
+      levels.resize((size_t)first_rep + 1);
+      levels[(size_t)first_rep] = AmgLevel();
+      coarse_n     = (int)rep_n;
+      coarse_dense = true; // coarse_solve() hands over to the tail
+   }
+   L = (int)levels.size();
+   std::vector<size_t> tail_len((size_t)L, 0); // largest ghost tail of any plan that feeds level-l vectors
    for (int l = 0; l < L; l++)
    {
       AmgLevel       &lv = levels[l];
       const long long lo = parts[(size_t)l][(size_t)r], hi = parts[(size_t)l][(size_t)r + 1];
       std::vector<long long> gg;
-      if (l > 0)
+      if (l > 0 && !(has_tail && l == L - 1))
       {
          DCsr loc;
          localize(lv.A, lo, hi, lo, hi, loc, gg);
          lv.A  = std::move(loc);
          lv.hA = make_halo_plan((int)(hi - lo), parts[(size_t)l], gg);
-         tail[(size_t)l] = std::max(tail[(size_t)l], gg.size());
+         tail_len[(size_t)l] = std::max(tail_len[(size_t)l], gg.size());
       }
       else
-         tail[0] = std::max(tail[0], ghost_gids0.size());
+         tail_len[0] = std::max(tail_len[0], ghost_gids0.size());
       // smoother diagonals: keep the owned slice
       for (DArray<double> *d : {&lv.dinv_down, &lv.dinv_up})
       {
+         if (d->size() == 0) continue; // stub level in front of a replicated tail
          DArray<double> sl((size_t)std::max<long long>(hi - lo, 1));
          if (hi > lo) HDA_HIP(hipMemcpyAsync(sl.data(), d->data() + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, STREAM));
          *d = std::move(sl);
@@ -1709,11 +1730,11 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
          localize(lv.P, lo, hi, clo, chi, pl, gg);
          lv.P  = std::move(pl);
          lv.hP = make_halo_plan((int)(chi - clo), parts[(size_t)l + 1], gg);
-         tail[(size_t)l + 1] = std::max(tail[(size_t)l + 1], gg.size());
+         tail_len[(size_t)l + 1] = std::max(tail_len[(size_t)l + 1], gg.size());
          localize(lv.R, clo, chi, lo, hi, rl, gg);
          lv.R  = std::move(rl);
          lv.hR = make_halo_plan((int)(hi - lo), parts[(size_t)l], gg);
-         tail[(size_t)l] = std::max(tail[(size_t)l], gg.size());
+         tail_len[(size_t)l] = std::max(tail_len[(size_t)l], gg.size());
          lv.cf.release();
       }
    }
@@ -1723,7 +1744,7 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
    {
       AmgLevel    &lv = levels[l];
       const size_t n  = (size_t)(parts[(size_t)l][(size_t)r + 1] - parts[(size_t)l][(size_t)r]);
-      lv.ext          = std::max<size_t>(n + tail[(size_t)l], 1);
+      lv.ext          = std::max<size_t>(n + tail_len[(size_t)l], 1);
       if (l > 0) { lv.f.alloc(lv.ext); lv.u.alloc(lv.ext); }
       lv.u2.alloc(lv.ext);
       lv.t.alloc(lv.ext);
@@ -1733,10 +1754,38 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
    if (coarse_dense)
    {
       cbuf_f.alloc((size_t)std::max(coarse_n, 1));
-      cbuf_u.alloc((size_t)std::max(coarse_n, 1));
+      cbuf_u.alloc(std::max<size_t>((size_t)std::max(coarse_n, 1), tail ? tail->vec_len0() : 0));
    }
    Context::get().sync();
-   HDA_TRACE("setup_dist: rank %d owns %d of %d level-0 rows, %d levels", r, Aloc.nrows, (int)part0.back(), L);
+   HDA_TRACE("setup_dist: rank %d owns %d of %d level-0 rows, %d partitioned levels%s", r, Aloc.nrows, (int)part0.back(), L,
+             tail ? " + replicated tail" : "");
+}
+
+// Take levels [first_level, end) of a freshly built (replicated) hierarchy as an independent
+// single-rank hierarchy.
+void Amg::adopt_tail(Amg &parent, int first_level)
+{
+   dist = false;
+   hA0  = nullptr;
+   levels.clear();
+   for (size_t l = (size_t)first_level; l < parent.levels.size(); l++) levels.push_back(std::move(parent.levels[l]));
+   own_A0       = std::move(levels[0].A);
+   A0           = &own_A0;
+   coarse_invT  = std::move(parent.coarse_invT);
+   coarse_n     = parent.coarse_n;
+   coarse_dense = parent.coarse_dense;
+   coarse_lo    = 0;
+   coarse_nloc  = coarse_n;
+   stats_levels = 0;
+   for (size_t l = 0; l < levels.size(); l++)
+   {
+      AmgLevel    &lv = levels[l];
+      const size_t n  = (size_t)level_A((int)l).nrows;
+      lv.ext          = std::max<size_t>(n, 1);
+      if (l > 0) { lv.f.alloc(lv.ext); lv.u.alloc(lv.ext); }
+      lv.u2.alloc(lv.ext);
+      lv.t.alloc(lv.ext);
+   }
 }
 
 double Amg::operator_complexity() const
@@ -1814,7 +1863,8 @@ void Amg::coarse_solve(const double *f, double *u)
    cbuf_f.zero();
    if (coarse_nloc) k_place<<<ceil_div(coarse_nloc, 256), 256, 0, STREAM>>>(coarse_nloc, f, cbuf_f.data() + coarse_lo);
    Comm::world().allreduce_sum_dev(cbuf_f.data(), coarse_n);
-   dense_apply(coarse_n, coarse_invT.data(), cbuf_f.data(), cbuf_u.data());
+   if (tail) tail->cycle(cbuf_f.data(), cbuf_u.data(), true, -1); // replicated coarse levels, redundantly on every rank
+   else dense_apply(coarse_n, coarse_invT.data(), cbuf_f.data(), cbuf_u.data());
    if (coarse_nloc) k_place<<<ceil_div(coarse_nloc, 256), 256, 0, STREAM>>>(coarse_nloc, cbuf_u.data() + coarse_lo, u);
 }
 

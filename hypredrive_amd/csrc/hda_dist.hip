@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_pack(int n, const int *__restrict__ idx
 void halo_exchange(const HaloPlan &h, double *x_ext)
 {
    Comm &cm = Comm::world();
-   if (cm.size == 1) return;
+   if (cm.size == 1 || h.send_counts.empty()) return; // no plan: operator is not partitioned (replicated tail)
    if (h.send_total) k_pack<<<ceil_div(h.send_total, 256), 256, 0, STREAM>>>(h.send_total, h.send_idx.data(), x_ext, (double *)h.send_buf.data());
    cm.exchange_dev(h.send_buf.data(), h.send_counts.data(), x_ext + h.nloc, h.recv_counts.data());
 }
