@@ -13,11 +13,14 @@ def run(args):
     import torch
     import torch.distributed as dist
     rank, world = hdist.init()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and local < torch.cuda.device_count():
+        torch.cuda.set_device(local)
     n = args.n
     P = hdist.factor3(world)
     h = hd.Hypredrv("solver: pcg\npreconditioner:\n  preset: poisson\n")
     h.set_laplacian7((n, n, n), P)
-    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     h.create_and_setup()
