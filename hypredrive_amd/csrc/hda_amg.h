@@ -33,8 +33,22 @@ struct AmgParams {
    uint64_t seed = 2747; // PMIS tie-break hash seed
 };
 
+// dependency levels of the local pattern for Gauss-Seidel sweeps (hda_gs.hip)
+struct GsPlan {
+   DArray<int>                      perm;      // rows grouped by level, ascending inside a level
+   DArray<int>                      d_lvl_ptr; // device copy of lvl_ptr
+   std::vector<int>                 lvl_ptr;   // nlev + 1 offsets into perm
+   std::vector<std::pair<int, int>> segments;  // launch groups [first level, last level)
+   int                              nlev  = 0;
+   bool                             built = false;
+};
+void build_gs_plan(const DCsr &A, GsPlan &plan);
+// one hybrid Gauss-Seidel sweep in place: x_i += dinv_i (b_i - A_i x), rows in sequential order
+void gs_sweep(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, double *x, bool forward);
+
 struct AmgLevel {
    DCsr           A, P, R;
+   GsPlan         gs;
    DArray<int>    cf;
    DArray<double> dinv_down, dinv_up; // relax_weight / l1 (or / a_ii), per cycle direction
    DArray<double> f, u, u2, t;
@@ -80,6 +94,7 @@ class Amg {
    void relax(int l, int type, const double *dinv, const double *b, double *&cur, double *&alt,
               bool zero_guess, int dot_slot);
    void build_hierarchy(const DCsr &A);
+   void build_smoother_data(int l); // divisors (and Gauss-Seidel level sets) of level l on the matrix the cycle uses
    void coarse_solve(const double *f, double *u);
    const HaloPlan &level_hA(int l) const { return (l == 0 && hA0) ? *hA0 : levels[l].hA; }
    const DCsr           *A0 = nullptr;

@@ -1535,21 +1535,41 @@ void amg_rap(const DCsr &A, const DCsr &P, const DCsr &R, DCsr &Ac)
 // --------------------------------------------------------------- hierarchy
 
 static bool is_jacobi_type(int t) { return t == 18 || t == 0 || t == 7; }
+static bool is_gs_type(int t) { return t == 3 || t == 4 || t == 6 || t == 8 || t == 13 || t == 14; }
+static bool is_l1_gs_type(int t) { return t == 8 || t == 13 || t == 14; }
 
+// divisor of the sweep: l1 row sums (18), hypre's "option 4" l1 (13/14/8: a_ii plus half the
+// off-rank row sum) or the plain diagonal (0/7/3/4/6).  Extracting the diagonal is option 4
+// with the ghost part ignored, which is what columns < nrows give.
 static void build_dinv(const DCsr &A, int relax_type, double weight, DArray<double> &dinv)
 {
-   DArray<double> d((size_t)A.nrows);
-   dinv.alloc((size_t)A.nrows);
-   l1_row_norms(A, relax_type == 18 ? 1 : 4, d.data());
+   DArray<double> d((size_t)std::max(A.nrows, 1));
+   dinv.alloc((size_t)std::max(A.nrows, 1));
+   if (relax_type == 18) l1_row_norms(A, 1, d.data());
+   else if (is_l1_gs_type(relax_type)) l1_row_norms(A, 4, d.data());
+   else extract_diag(A, d.data());
    make_dinv(A.nrows, d.data(), weight, dinv.data());
+}
+
+void Amg::build_smoother_data(int l)
+{
+   const DCsr &Al = level_A(l);
+   AmgLevel   &lv = levels[(size_t)l];
+   build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down);
+   build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up);
+   const bool last = (l == num_levels() - 1);
+   const bool gs   = is_gs_type(prm.relax_down) || is_gs_type(prm.relax_up) || (last && is_gs_type(prm.relax_coarse));
+   if (gs && !lv.gs.built) build_gs_plan(Al, lv.gs);
 }
 
 void Amg::build_hierarchy(const DCsr &A)
 {
    HDA_REQUIRE(prm.coarsen_type == 8, "device AMG setup implements PMIS coarsening (type 8) only");
    HDA_REQUIRE(prm.interp_type == 6, "device AMG setup implements extended+i interpolation (type 6) only");
-   HDA_REQUIRE(is_jacobi_type(prm.relax_down) && is_jacobi_type(prm.relax_up),
-               "device V-cycle implements Jacobi-type smoothers (relax types 0, 7, 18) only");
+   HDA_REQUIRE((is_jacobi_type(prm.relax_down) || is_gs_type(prm.relax_down)) && (is_jacobi_type(prm.relax_up) || is_gs_type(prm.relax_up)),
+               "device V-cycle implements Jacobi (0, 7, 18) and hybrid Gauss-Seidel (3, 4, 6, 8, 13, 14) smoothers");
+   HDA_REQUIRE(prm.relax_coarse == 9 || is_jacobi_type(prm.relax_coarse) || is_gs_type(prm.relax_coarse),
+               "coarse relaxation must be Gaussian elimination (9), Jacobi or hybrid Gauss-Seidel");
    A0 = &A;
    levels.clear();
    levels.reserve((size_t)std::max(prm.max_levels, 1));
@@ -1609,13 +1629,6 @@ void Amg::build_hierarchy(const DCsr &A)
       stats_nnz[l]  = (double)level_A(l).nnz;
       stats_rows[l] = (double)level_A(l).nrows;
    }
-   for (int l = 0; l < L; l++)
-   {
-      const DCsr &Al = level_A(l);
-      AmgLevel   &lv = levels[l];
-      build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down);
-      build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up);
-   }
    // coarsest operator: dense inverse when relax_coarse is Gaussian elimination (type 9)
    const DCsr &Ac = level_A(L - 1);
    coarse_n       = Ac.nrows;
@@ -1641,6 +1654,7 @@ void Amg::setup(const DCsr &A)
    {
       AmgLevel    &lv = levels[l];
       const size_t n  = (size_t)level_A(l).nrows;
+      build_smoother_data(l);
       lv.ext          = std::max(n, (size_t)level_A(l).ncols);
       if (l > 0) { lv.f.alloc(lv.ext); lv.u.alloc(lv.ext); }
       lv.u2.alloc(lv.ext);
@@ -1715,14 +1729,6 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
       }
       else
          tail_len[0] = std::max(tail_len[0], ghost_gids0.size());
-      // smoother diagonals: keep the owned slice
-      for (DArray<double> *d : {&lv.dinv_down, &lv.dinv_up})
-      {
-         if (d->size() == 0) continue; // stub level in front of a replicated tail
-         DArray<double> sl((size_t)std::max<long long>(hi - lo, 1));
-         if (hi > lo) HDA_HIP(hipMemcpyAsync(sl.data(), d->data() + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, STREAM));
-         *d = std::move(sl);
-      }
       if (l + 1 < L)
       {
          const long long clo = parts[(size_t)l + 1][(size_t)r], chi = parts[(size_t)l + 1][(size_t)r + 1];
@@ -1744,6 +1750,7 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
    {
       AmgLevel    &lv = levels[l];
       const size_t n  = (size_t)(parts[(size_t)l][(size_t)r + 1] - parts[(size_t)l][(size_t)r]);
+      if (!(has_tail && l == L - 1)) build_smoother_data(l); // divisors / GS level sets of the LOCAL block (ghost columns = off-rank part)
       lv.ext          = std::max<size_t>(n + tail_len[(size_t)l], 1);
       if (l > 0) { lv.f.alloc(lv.ext); lv.u.alloc(lv.ext); }
       lv.u2.alloc(lv.ext);
@@ -1781,6 +1788,7 @@ void Amg::adopt_tail(Amg &parent, int first_level)
    {
       AmgLevel    &lv = levels[l];
       const size_t n  = (size_t)level_A((int)l).nrows;
+      build_smoother_data((int)l);
       lv.ext          = std::max<size_t>(n, 1);
       if (l > 0) { lv.f.alloc(lv.ext); lv.u.alloc(lv.ext); }
       lv.u2.alloc(lv.ext);
@@ -1830,7 +1838,22 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
                 bool zero_guess, int dot_slot)
 {
    const DCsr &A = level_A(l);
-   (void)type;
+   if (is_gs_type(type))
+   { // in place; ghosts frozen for the sweep
+      if (zero_guess) fill((int)levels[(size_t)l].ext, 0.0, cur);
+      else halo_exchange(level_hA(l), cur);
+      const GsPlan &g = levels[(size_t)l].gs;
+      if (type == 3 || type == 13) gs_sweep(A, g, dinv, b, cur, true);
+      else if (type == 4 || type == 14) gs_sweep(A, g, dinv, b, cur, false);
+      else
+      { // symmetric: forward then backward, ghost values refreshed in between as hypre's two relax calls do
+         gs_sweep(A, g, dinv, b, cur, true);
+         halo_exchange(level_hA(l), cur);
+         gs_sweep(A, g, dinv, b, cur, false);
+      }
+      if (dot_slot >= 0) dot(A.nrows, b, cur, dot_slot);
+      return;
+   }
    if (zero_guess)
    {
       jacobi_zero_guess(A.nrows, dinv, b, cur);
@@ -1881,7 +1904,7 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
          bool    zg  = zero_guess;
          for (int s = 0; s < std::max(prm.sweeps_coarse, 1); s++)
          {
-            relax(0, 18, levels[0].dinv_down.data(), b, cur, alt, zg, -1);
+            relax(0, prm.relax_coarse == 9 ? 18 : prm.relax_coarse, levels[0].dinv_down.data(), b, cur, alt, zg, -1);
             zg = false;
          }
          if (cur != x) copy(n0, cur, x);
@@ -1891,7 +1914,8 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
    }
    std::vector<double *> sol((size_t)L, nullptr);
    // level-0 buffer choice so the last out-of-place sweep lands in x
-   const int swaps0 = (prm.sweeps_down - (zero_guess && prm.sweeps_down > 0 ? 1 : 0)) + prm.sweeps_up;
+   const int swaps0 = (is_jacobi_type(prm.relax_down) ? (prm.sweeps_down - (zero_guess && prm.sweeps_down > 0 ? 1 : 0)) : 0) +
+                      (is_jacobi_type(prm.relax_up) ? prm.sweeps_up : 0); // out-of-place sweeps on level 0
    double   *cur, *alt;
    if (zero_guess && (swaps0 & 1)) { cur = levels[0].u2.data(); alt = x; }
    else { cur = x; alt = levels[0].u2.data(); }
@@ -1926,7 +1950,7 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
          bool    zg = true;
          for (int s = 0; s < std::max(prm.sweeps_coarse, 1); s++)
          {
-            relax(L - 1, 18, lc.dinv_down.data(), lc.f.data(), c2, a2, zg, -1);
+            relax(L - 1, prm.relax_coarse == 9 ? 18 : prm.relax_coarse, lc.dinv_down.data(), lc.f.data(), c2, a2, zg, -1);
             zg = false;
          }
          if (c2 != lc.u.data()) copy(level_A(L - 1).nrows, c2, lc.u.data());

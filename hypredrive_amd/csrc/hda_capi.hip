@@ -210,19 +210,33 @@ extern "C" int hda_spmv(hda_csr_t A, double alpha, const double *x, double beta,
 extern "C" int hda_relax(hda_csr_t A, int relax_type, double weight, int sweeps, const double *b, double *x)
 {
    HDA_TRY
-   const DCsr &m = A->get();
-   HDA_REQUIRE(relax_type == 18 || relax_type == 0 || relax_type == 7, "device relax: Jacobi types 0/7/18 only");
-   DArray<double> d((size_t)m.nrows), dinv((size_t)m.nrows), db, x0, x1;
-   l1_row_norms(m, relax_type == 18 ? 1 : 4, d.data());
+   const DCsr &m      = A->get();
+   const bool  jacobi_t = relax_type == 18 || relax_type == 0 || relax_type == 7;
+   const bool  gs_t     = relax_type == 3 || relax_type == 4 || relax_type == 6 || relax_type == 8 || relax_type == 13 || relax_type == 14;
+   HDA_REQUIRE(jacobi_t || gs_t, "device relax: Jacobi (0/7/18) or hybrid Gauss-Seidel (3/4/6/8/13/14)");
+   DArray<double> d((size_t)std::max(m.nrows, 1)), dinv((size_t)std::max(m.nrows, 1)), db, x0, x1;
+   if (relax_type == 18) l1_row_norms(m, 1, d.data());
+   else if (relax_type == 13 || relax_type == 14 || relax_type == 8) l1_row_norms(m, 4, d.data());
+   else extract_diag(m, d.data());
    make_dinv(m.nrows, d.data(), weight, dinv.data());
    db.upload(b, (size_t)m.nrows);
-   x0.upload(x, (size_t)m.ncols);
-   x1.alloc((size_t)m.ncols);
+   x0.upload(x, (size_t)std::max(m.ncols, m.nrows));
+   x1.alloc((size_t)std::max(m.ncols, m.nrows));
    double *cur = x0.data(), *alt = x1.data();
+   GsPlan  plan;
+   if (gs_t) build_gs_plan(m, plan);
    for (int s = 0; s < sweeps; s++)
    {
-      jacobi(m, dinv.data(), db.data(), cur, alt, -1);
-      std::swap(cur, alt);
+      if (jacobi_t)
+      {
+         jacobi(m, dinv.data(), db.data(), cur, alt, -1);
+         std::swap(cur, alt);
+      }
+      else
+      {
+         if (relax_type == 3 || relax_type == 13 || relax_type == 6 || relax_type == 8) gs_sweep(m, plan, dinv.data(), db.data(), cur, true);
+         if (relax_type == 4 || relax_type == 14 || relax_type == 6 || relax_type == 8) gs_sweep(m, plan, dinv.data(), db.data(), cur, false);
+      }
    }
    HDA_HIP(hipMemcpyAsync(x, cur, sizeof(double) * (size_t)m.nrows, hipMemcpyDeviceToHost, Context::get().stream));
    Context::get().sync();

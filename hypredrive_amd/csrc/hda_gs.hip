@@ -1,0 +1,201 @@
+// hda_gs.hip -- hybrid Gauss-Seidel sweeps (hypre relax types 3/4/6 and the l1 variants
+// 13/14/8) with exactly hypre's semantics: Gauss-Seidel over the rank's
+// own rows in ascending (forward) or descending (backward) order, ghost values frozen for
+// the sweep ("hybrid" = Jacobi across ranks).
+//
+// A sequential sweep is a DAG: row i must see the new values of its lower neighbours and the
+// old values of its upper ones.  Rows are therefore grouped into dependency levels of the
+// symmetrised local pattern (level(i) = 1 + max level of lower neighbours); rows of one level
+// are mutually non-adjacent, so a level is a data-parallel launch and the result equals the
+// sequential sweep.  A backward sweep walks the same levels in reverse.  Runs of small
+// levels are fused into one single-workgroup launch separated by workgroup barriers, so the
+// ramp-up/ramp-down of the wavefront (and whole coarse grids) do not pay one launch per level.
+#include "hda_amg.h"
+
+#include <algorithm>
+
+namespace hda {
+
+#define STREAM (Context::get().stream)
+
+// distinct neighbours of row i in pattern(A) U pattern(A^T), restricted to owned columns,
+// visited in ascending order; f(j) is called once per neighbour j != i
+template <class F>
+__device__ __forceinline__ void for_each_sym_neighbour(int i, int n, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                       const int *__restrict__ trp, const int *__restrict__ tcj, F f)
+{
+   int a = rp[i], ae = rp[i + 1], t = trp[i], te = trp[i + 1];
+   while (a < ae || t < te)
+   {
+      const int ja = (a < ae) ? cj[a] : 0x7fffffff, jt = (t < te) ? tcj[t] : 0x7fffffff;
+      const int j  = min(ja, jt);
+      if (ja == j) a++;
+      if (jt == j) t++;
+      if (j >= n) break; // ghost columns sort last
+      if (j != i) f(j);
+   }
+}
+
+__global__ __launch_bounds__(256) void k_gs_indeg(int n, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                  const int *__restrict__ trp, const int *__restrict__ tcj, int *__restrict__ indeg,
+                                                  int *__restrict__ perm, int *counter)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int d = 0;
+   for_each_sym_neighbour(i, n, rp, cj, trp, tcj, [&](int j) { d += (j < i); });
+   indeg[i] = d;
+   if (d == 0) perm[atomicAdd(counter, 1)] = i;
+}
+
+__global__ __launch_bounds__(256) void k_gs_expand(int nf, const int *__restrict__ frontier, int n, const int *__restrict__ rp,
+                                                   const int *__restrict__ cj, const int *__restrict__ trp,
+                                                   const int *__restrict__ tcj, int *indeg, int *__restrict__ next, int *counter)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q >= nf) return;
+   const int i = frontier[q];
+   for_each_sym_neighbour(i, n, rp, cj, trp, tcj, [&](int j) {
+      if (j > i && atomicSub(&indeg[j], 1) == 1) next[atomicAdd(counter, 1)] = j;
+   });
+}
+
+// ascending row ids inside every level: deterministic launch contents and better locality
+__global__ __launch_bounds__(256) void k_gs_mark(int n, const int *__restrict__ perm, const int *__restrict__ lvl_of_pos,
+                                                 int *__restrict__ level_of_row)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) level_of_row[perm[q]] = lvl_of_pos[q];
+}
+
+void build_gs_plan(const DCsr &A, GsPlan &plan)
+{
+   const int n = A.nrows;
+   plan        = GsPlan();
+   plan.built  = true;
+   plan.perm.alloc((size_t)std::max(n, 1));
+   plan.lvl_ptr.assign(1, 0);
+   if (n == 0) return;
+   DCsr T;
+   transpose(A, T); // rows of T = columns of A; only rows < n are consulted
+   DArray<int> indeg((size_t)n), counter(1);
+   counter.zero();
+   k_gs_indeg<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(),
+                                                   plan.perm.data(), counter.data());
+   int done = 0, nf = 0;
+   counter.download(&nf, 1);
+   while (nf > 0)
+   {
+      plan.lvl_ptr.push_back(done + nf);
+      const int *cur = plan.perm.data() + done;
+      done += nf;
+      if (done >= n) break;
+      counter.zero();
+      k_gs_expand<<<ceil_div(nf, 256), 256, 0, STREAM>>>(nf, cur, n, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(),
+                                                        indeg.data(), plan.perm.data() + done, counter.data());
+      counter.download(&nf, 1);
+   }
+   HDA_REQUIRE(done == n, "Gauss-Seidel level scheduling did not reach every row");
+   plan.nlev = (int)plan.lvl_ptr.size() - 1;
+   // level of every row -> stable counting order = ascending rows inside each level
+   {
+      std::vector<int> lvl_of_pos((size_t)n);
+      for (int L = 0; L < plan.nlev; L++)
+         for (int q = plan.lvl_ptr[(size_t)L]; q < plan.lvl_ptr[(size_t)L + 1]; q++) lvl_of_pos[(size_t)q] = L;
+      DArray<int> dpos, lrow((size_t)n);
+      dpos.upload(lvl_of_pos.data(), (size_t)n);
+      k_gs_mark<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), dpos.data(), lrow.data());
+      std::vector<int> hl = lrow.to_host(), cursor(plan.lvl_ptr.begin(), plan.lvl_ptr.end() - 1), hp((size_t)n);
+      for (int i = 0; i < n; i++) hp[(size_t)cursor[(size_t)hl[(size_t)i]]++] = i;
+      plan.perm.upload(hp.data(), (size_t)n);
+   }
+   // launch segments: big levels alone, runs of small levels fused into one workgroup
+   const int small = 512;
+   int       L     = 0;
+   while (L < plan.nlev)
+   {
+      const int sz = plan.lvl_ptr[(size_t)L + 1] - plan.lvl_ptr[(size_t)L];
+      if (sz > small) { plan.segments.push_back({L, L + 1}); L++; continue; }
+      int E = L;
+      while (E < plan.nlev && plan.lvl_ptr[(size_t)E + 1] - plan.lvl_ptr[(size_t)E] <= small) E++;
+      plan.segments.push_back({L, E});
+      L = E;
+   }
+   plan.d_lvl_ptr.upload(plan.lvl_ptr.data(), plan.lvl_ptr.size());
+   Context::get().sync();
+}
+
+// x_i += dinv_i * (b_i - sum_j a_ij x_j) for the rows of one level; LPR lanes per row
+template <int LPR>
+__device__ __forceinline__ void gs_rows(int first, int count, int tid, int nthreads, const int *__restrict__ perm,
+                                        const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                        const double *__restrict__ dinv, const double *__restrict__ b, double *x)
+{
+   const int lane = tid & (LPR - 1);
+   for (int q = tid / LPR; q < count; q += nthreads / LPR)
+   {
+      const int i = perm[first + q];
+      double    s = 0.0;
+      for (int k = rp[i] + lane; k < rp[i + 1]; k += LPR) s += v[k] * x[cj[k]];
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) x[i] += dinv[i] * (b[i] - s);
+   }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gs_level(int first, int count, const int *__restrict__ perm, const int *__restrict__ rp,
+                                                  const int *__restrict__ cj, const double *__restrict__ v,
+                                                  const double *__restrict__ dinv, const double *__restrict__ b, double *x)
+{
+   gs_rows<LPR>(first, count, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, perm, rp, cj, v, dinv, b, x);
+}
+
+// levels [l0, l1) by ONE workgroup, forward or backward, a barrier between levels
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gs_levels_fused(int l0, int l1, int backward, const int *__restrict__ lvl_ptr,
+                                                         const int *__restrict__ perm, const int *__restrict__ rp,
+                                                         const int *__restrict__ cj, const double *__restrict__ v,
+                                                         const double *__restrict__ dinv, const double *__restrict__ b, double *x)
+{
+   for (int s = 0; s < l1 - l0; s++)
+   {
+      const int L = backward ? (l1 - 1 - s) : (l0 + s);
+      gs_rows<LPR>(lvl_ptr[L], lvl_ptr[L + 1] - lvl_ptr[L], threadIdx.x, 256, perm, rp, cj, v, dinv, b, x);
+      __threadfence_block();
+      __syncthreads();
+   }
+}
+
+template <int LPR>
+static void gs_sweep_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, double *x, bool forward)
+{
+   const int ns = (int)p.segments.size();
+   for (int si = 0; si < ns; si++)
+   {
+      const auto &sg = p.segments[(size_t)(forward ? si : ns - 1 - si)];
+      if (sg.second - sg.first == 1 && p.lvl_ptr[(size_t)sg.first + 1] - p.lvl_ptr[(size_t)sg.first] > 512)
+      {
+         const int first = p.lvl_ptr[(size_t)sg.first], count = p.lvl_ptr[(size_t)sg.first + 1] - first;
+         const int grid  = std::min(ceil_div((long long)count * LPR, 256), 2048);
+         k_gs_level<LPR><<<grid, 256, 0, STREAM>>>(first, count, p.perm.data(), A.rowptr.data(), A.col.data(), A.val.data(), dinv, b, x);
+      }
+      else
+         k_gs_levels_fused<LPR><<<1, 256, 0, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
+                                                      A.rowptr.data(), A.col.data(), A.val.data(), dinv, b, x);
+   }
+}
+
+// hypre_BoomerAMGRelax types 3/13 (forward) and 4/14 (backward); dinv = weight / d with
+// d = a_ii (3/4) or the l1 divisor of option 4 (13/14)
+void gs_sweep(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, double *x, bool forward)
+{
+   HDA_REQUIRE(plan.built, "Gauss-Seidel plan missing");
+   if (A.nrows == 0) return;
+   const double a = A.avg_row();
+   if (a <= 10.0) gs_sweep_t<8>(A, plan, dinv, b, x, forward);
+   else if (a <= 40.0) gs_sweep_t<32>(A, plan, dinv, b, x, forward);
+   else gs_sweep_t<64>(A, plan, dinv, b, x, forward);
+}
+
+} // namespace hda

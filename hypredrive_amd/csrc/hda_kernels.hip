@@ -819,13 +819,20 @@ __global__ __launch_bounds__(256) void k_l1(int n, const int *__restrict__ rp, c
 {
    int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
-   double s = 0.0, d = 0.0;
+   double s = 0.0, d = 0.0, off = 0.0;
    for (int k = rp[i]; k < rp[i + 1]; k++)
    {
       s += fabs(v[k]);
       if (cj[k] == i) d = v[k];
+      if (cj[k] >= n) off += fabs(v[k]); // ghost (off-rank) columns
    }
-   l1[i] = (option == 1) ? ((d < 0.0) ? -s : s) : d;
+   if (option == 1) l1[i] = (d < 0.0) ? -s : s;
+   else
+   { // option 4: a_ii + 0.5 * sum_offd |a_ij|, truncated to a_ii when within 4/3 of it
+      double t = fabs(d) + 0.5 * off;
+      if (t <= (4.0 / 3.0) * fabs(d)) t = fabs(d);
+      l1[i] = (d < 0.0) ? -t : t;
+   }
 }
 void l1_row_norms(const DCsr &A, int option, double *l1)
 {

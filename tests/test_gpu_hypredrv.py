@@ -133,13 +133,20 @@ def test_cli_runs_ex1_unchanged(orc, pins):
     assert float(row.group(5)) < 1e-6
 
 
-@pytest.mark.parametrize("cfg", ["examples/ex1-preset.yml", "examples/ex1-gmres.yml", "examples/ex2-gpu.yml", "examples/ex1-jacobi.yml"])
+@pytest.mark.parametrize("cfg", ["examples/ex1-preset.yml", "examples/ex1-gmres.yml", "examples/ex2-gpu.yml", "examples/ex1-jacobi.yml",
+                                 "examples/ex1-gs.yml", "examples/ex2-hl1gs.yml"])
 def test_cli_other_examples(cfg):
     cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
     r = subprocess.run([cli, "-q", cfg], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     row = re.search(r"^\|\s+0 \|.*\|\s+(\S+) \|\s+(\d+) \|$", r.stdout, re.M)
-    assert row and float(row.group(1)) < 1e-6
+    assert row
+    if "ex1-gs" in cfg:
+        # one forward Gauss-Seidel sweep is a nonsymmetric preconditioner: PCG need not converge, and
+        # non-convergence is not an error (reference src/internal/utils.c:33-79)
+        assert int(row.group(2)) <= 500
+        return
+    assert float(row.group(1)) < 1e-6
     if "ex2" in cfg:  # print_level 2: residual history in hypre's format
         assert re.search(r"^\s+1\s+\d\.\d+e[+-]\d+", r.stdout, re.M)
 

@@ -109,6 +109,38 @@ def test_relax_jacobi(orc, hd, rtype, weight):
     assert np.array_equal(Ah.l1_norms(1), orc.l1_norms(Ao, 1))  # bit-exact
 
 
+@pytest.mark.parametrize("rtype", [3, 4, 6, 13, 14, 8])
+def test_relax_hybrid_gauss_seidel(orc, hd, rtype):
+    """K3: level-scheduled sweeps reproduce the sequential sweep of the oracle (one rank:
+    l1 divisor = a_ii, so 13/14/8 equal 3/4/6)."""
+    Ao, b = orc.lap7(11, 9, 8, b_mode=1)
+    Ah = hd.lap7(11, 9, 8)
+    x0 = np.random.default_rng(7).standard_normal(Ao.nrows)
+    l1 = orc.l1_norms(Ao, 4)
+    xo = x0
+    for _ in range(2):
+        xo = orc.relax(Ao, l1, rtype, 1.0, b, xo)
+    assert rel(Ah.relax(b, x0, rtype, 1.0, sweeps=2), xo) < RTOL_REDUCE
+    # irregular symmetric pattern
+    M = rand_spd(700, 0.01, 21)
+    Mo, Mh = both(orc, hd, M)
+    bb = np.random.default_rng(8).standard_normal(700)
+    xo = orc.relax(Mo, orc.l1_norms(Mo, 4), rtype, 0.9, bb, np.zeros(700))
+    assert rel(Mh.relax(bb, np.zeros(700), rtype, 0.9, sweeps=1), xo) < 1e-12
+
+
+def test_gauss_seidel_nonsymmetric_pattern(orc, hd):
+    """anti-dependencies of a structurally nonsymmetric matrix are honoured (levels come from A u A^T)"""
+    rng = np.random.default_rng(5)
+    M = sp.random(400, 400, density=0.02, random_state=rng, format="csr") + sp.diags(np.full(400, 5.0))
+    M = M.tocsr()
+    Mo, Mh = both(orc, hd, M)
+    bb = rng.standard_normal(400)
+    for rtype in (3, 4):
+        xo = orc.relax(Mo, orc.l1_norms(Mo, 4), rtype, 1.0, bb, np.ones(400))
+        assert rel(Mh.relax(bb, np.ones(400), rtype, 1.0, sweeps=1), xo) < 1e-12
+
+
 # ----------------------------------------------------------- K4 strength/PMIS
 
 @pytest.mark.parametrize("shape", [(10, 10, 10), (20, 7, 13), (40, 40, 40)])
@@ -229,6 +261,19 @@ def test_amg_pcg_matches_oracle(orc, hd, shape, bmode):
     assert rel(rh["x"], ro["x"]) < 1e-10
     S = Ao.to_scipy()
     assert np.linalg.norm(b - S @ rh["x"]) / np.linalg.norm(b) < 1e-6
+
+
+@pytest.mark.parametrize("down,up", [(13, 14), (3, 4), (6, 6)])
+def test_amg_pcg_hybrid_gs_matches_oracle(orc, hd, down, up):
+    """PMIS + ext+i hierarchy with hybrid (l1) Gauss-Seidel smoothing, the relaxation of the
+    reference's examples/ex2.yml:50-51, against the oracle."""
+    Ao, b = orc.lap7(14, 14, 14, b_mode=1)
+    Ah = hd.lap7(14, 14, 14)
+    ro = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True, relax_down=down, relax_up=up)))
+    rh = hd.pcg(Ah, b, hd.Amg(Ah, hd.AmgParams.default(relax_down=down, relax_up=up)))
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-9)
+    assert rel(rh["x"], ro["x"]) < 1e-9
 
 
 def test_unpreconditioned_cg_matches_oracle(orc, hd):
