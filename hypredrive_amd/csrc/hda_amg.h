@@ -70,6 +70,9 @@ class Amg {
    // then every level is cut into local blocks + halo plans for a distributed V-cycle.
    void setup_dist(const DCsr &Aloc, const HaloPlan &hA0, const std::vector<long long> &part0,
                    const std::vector<long long> &ghost_gids0);
+   // fully partitioned setup (distributed PMIS / ext+i / RAP; only levels below HDA_REPLICATE_ROWS are gathered)
+   void setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0, const std::vector<long long> &part0,
+                               const std::vector<long long> &ghost_gids0);
    // length of the level-0 vectors handed to apply()/solve() (x must have this room)
    size_t vec_len0() const { return levels.empty() ? 0 : levels[0].ext; }
    bool   distributed() const { return dist; }
@@ -104,6 +107,7 @@ class Amg {
    int                   coarse_nloc = 0;
    double                stats_nnz[32] = {0}, stats_rows[32] = {0}; // global sizes per level
    int                   stats_levels = 0;
+   int                   level0 = 0; // PMIS level index of this hierarchy's level 0 (tail of a partitioned hierarchy)
    DArray<double>        cbuf_f, cbuf_u;
    // row-partitioned runs: levels with few rows stay whole on every rank and are cycled
    // redundantly after one small all-reduce of the restricted residual

@@ -89,16 +89,17 @@ __global__ __launch_bounds__(256) void k_indeg(int nnz, const int *__restrict__ 
       if (smask[k]) atomicAdd(&indeg[cj[k]], 1);
 }
 
-__global__ __launch_bounds__(256) void k_pmis_init(int n, const int *__restrict__ ns,
+// rows [r0, r0 + n); global id of row i = gid[i] when a table is given, else row_offset + i
+__global__ __launch_bounds__(256) void k_pmis_init(int r0, int n, const int *__restrict__ ns,
                                                    const int *__restrict__ indeg,
                                                    unsigned long long seed, int level,
-                                                   long long row_offset, double *__restrict__ meas,
-                                                   int *__restrict__ cf, int *counter)
+                                                   long long row_offset, const long long *__restrict__ gid,
+                                                   double *__restrict__ meas, int *__restrict__ cf, int *counter)
 {
-   const int i = blockIdx.x * 256 + threadIdx.x;
-   if (i >= n) return;
+   const int i = r0 + blockIdx.x * 256 + threadIdx.x;
+   if (i >= r0 + n) return;
    const int nt = indeg[i];
-   meas[i]      = (double)nt + pmis_rand(seed, level, row_offset + i);
+   meas[i]      = (double)nt + pmis_rand(seed, level, gid ? gid[i] : row_offset + i);
    int c;
    if (ns[i] == 0) c = -3;      // no strong dependence: special F, never interpolated
    else if (nt == 0) c = -1;    // measure < 1: nobody depends on it
@@ -111,10 +112,10 @@ __global__ __launch_bounds__(256) void k_pmis_mark(int n, const int *__restrict_
                                                    const int *__restrict__ cj,
                                                    const unsigned char *__restrict__ smask,
                                                    const int *__restrict__ cf,
-                                                   const double *__restrict__ meas, unsigned char *notmax)
+                                                   const double *__restrict__ meas, unsigned char *notmax, int r0)
 {
-   const int i = blockIdx.x * 256 + threadIdx.x;
-   if (i >= n || cf[i] != 0) return;
+   const int i = r0 + blockIdx.x * 256 + threadIdx.x;
+   if (i >= r0 + n || cf[i] != 0) return;
    const double mi = meas[i];
    for (int k = rp[i]; k < rp[i + 1]; k++)
    {
@@ -122,23 +123,23 @@ __global__ __launch_bounds__(256) void k_pmis_mark(int n, const int *__restrict_
       const int j = cj[k];
       if (cf[j] != 0) continue;
       const double mj = meas[j];
-      if (mj > mi || (mj == mi && j > i)) notmax[i] = 1;
+      if (mj > mi || (mj == mi && j > i)) notmax[i] = 1; // index order == global id order in both layouts used
       else notmax[j] = 1;
    }
 }
-__global__ __launch_bounds__(256) void k_pmis_setC(int n, int *__restrict__ cf, unsigned char *__restrict__ notmax)
+__global__ __launch_bounds__(256) void k_pmis_setC(int n, int *__restrict__ cf, unsigned char *__restrict__ notmax, int r0)
 {
-   const int i = blockIdx.x * 256 + threadIdx.x;
-   if (i >= n) return;
+   const int i = r0 + blockIdx.x * 256 + threadIdx.x;
+   if (i >= r0 + n) return;
    if (cf[i] == 0 && !notmax[i]) cf[i] = 1;
    notmax[i] = 0;
 }
 __global__ __launch_bounds__(256) void k_pmis_setF(int n, const int *__restrict__ rp,
                                                    const int *__restrict__ cj,
-                                                   const unsigned char *__restrict__ smask, int *cf, int *counter)
+                                                   const unsigned char *__restrict__ smask, int *cf, int *counter, int r0)
 {
-   const int i = blockIdx.x * 256 + threadIdx.x;
-   if (i >= n || cf[i] != 0) return;
+   const int i = r0 + blockIdx.x * 256 + threadIdx.x;
+   if (i >= r0 + n || cf[i] != 0) return;
    for (int k = rp[i]; k < rp[i + 1]; k++)
       if (smask[k] && cf[cj[k]] == 1)
       {
@@ -161,7 +162,7 @@ static void pmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
    counter.zero();
    const int g = ceil_div(n, 256);
    if (A.nnz) k_indeg<<<std::min(ceil_div(A.nnz, 256), 1 << 16), 256, 0, STREAM>>>(A.nnz, A.col.data(), smask, indeg.data());
-   k_pmis_init<<<g, 256, 0, STREAM>>>(n, ns, indeg.data(), seed, level, row_offset, meas.data(), cf, counter.data());
+   k_pmis_init<<<g, 256, 0, STREAM>>>(0, n, ns, indeg.data(), seed, level, row_offset, nullptr, meas.data(), cf, counter.data());
    int left = 0;
    counter.download(&left, 1);
    HDA_TRACE("  pmis: init done, undecided=%d", left);
@@ -169,9 +170,9 @@ static void pmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
    while (left > 0)
    {
       counter.zero();
-      k_pmis_mark<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, meas.data(), notmax.data());
-      k_pmis_setC<<<g, 256, 0, STREAM>>>(n, cf, notmax.data());
-      k_pmis_setF<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data());
+      k_pmis_mark<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, meas.data(), notmax.data(), 0);
+      k_pmis_setC<<<g, 256, 0, STREAM>>>(n, cf, notmax.data(), 0);
+      k_pmis_setF<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data(), 0);
       counter.download(&left, 1);
       HDA_REQUIRE(++rounds < 10000, "PMIS did not terminate");
    }
@@ -1596,7 +1597,7 @@ void Amg::build_hierarchy(const DCsr &A)
       strength_ns(Al, prm.strong_th, prm.max_row_sum, sm.data(), ns.data());
       HDA_TRACE("level %d: pmis", lvl);
       auto t1 = tick();
-      pmis_core(Al, sm.data(), ns.data(), prm.seed, lvl, 0, cf.data());
+      pmis_core(Al, sm.data(), ns.data(), prm.seed, lvl + level0, 0, cf.data());
       HDA_TRACE("level %d: interp", lvl);
       auto t2 = tick();
       DCsr P;
@@ -1983,6 +1984,792 @@ void Amg::apply(const double *b, double *x, int dot_slot) { cycle(b, x, true, do
 void Amg::solve(const double *b, double *x)
 {
    for (int it = 0; it < std::max(prm.max_iter, 1); it++) cycle(b, x, false, -1);
+}
+
+} // namespace hda
+
+// =========================================================================================
+// Partitioned AMG setup: every rank keeps only its row block.
+//
+// Per level a rank builds an EXTENDED view E of its block: its own rows plus the rows of its
+// layer-1 ghost nodes (fetched from their owners), in an index space that lists every node
+// touched (owned, ghosts, ghosts of ghosts) in ascending GLOBAL id.  Because that order is
+// the global order, the single-rank kernels (strength, ext+i) run unchanged on E and give
+// bit-identical results for the owned rows; PMIS runs its synchronous rounds on the owned
+// rows with measure / C-F / "not a maximum" values exchanged for the ghosts; the Galerkin
+// product is formed from local rows and the coarse rows owned elsewhere are shipped to their
+// owners and added there.  Ghost-layer bookkeeping is surface-sized and done on the host.
+// =========================================================================================
+namespace hda {
+namespace {
+
+int owner_of(long long g, const std::vector<long long> &part)
+{
+   return (int)(std::upper_bound(part.begin(), part.end(), g) - part.begin()) - 1;
+}
+
+struct ExtPlan { // exchange of per-node arrays indexed by extended node id
+   int              nsend = 0, nrecv = 0;
+   std::vector<int> send_counts, recv_counts;
+   DArray<int>      send_idx, recv_idx;
+   DArray<double>   sbuf, rbuf;
+};
+
+struct ExtLevel {
+   long long              lo = 0, hi = 0;
+   int                    nloc = 0, off = 0, next = 0;
+   std::vector<long long> gid; // global id of every extended node, ascending
+   DArray<long long>      gid_dev;
+   DCsr                   E;   // next x next; rows of owned + layer-1 ghost nodes, columns = extended ids
+   ExtPlan                plan;
+   long long              ext_of(long long g) const
+   {
+      if (g >= lo && g < hi) return off + (g - lo);
+      return std::lower_bound(gid.begin(), gid.end(), g) - gid.begin();
+   }
+};
+
+__global__ __launch_bounds__(256) void k_gather_d(int n, const int *__restrict__ idx, const double *__restrict__ src, double *__restrict__ dst)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) dst[q] = src[idx[q]];
+}
+__global__ __launch_bounds__(256) void k_scatter_d(int n, const int *__restrict__ idx, const double *__restrict__ src, double *__restrict__ dst)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) dst[idx[q]] = src[q];
+}
+__global__ __launch_bounds__(256) void k_scatter_add_d(int n, const int *__restrict__ idx, const double *__restrict__ src, double *dst)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) atomicAdd(&dst[idx[q]], src[q]); // integer-valued payloads only: order independent
+}
+__global__ __launch_bounds__(256) void k_i2d(int n, const int *__restrict__ a, double *__restrict__ b)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) b[q] = (double)a[q];
+}
+__global__ __launch_bounds__(256) void k_d2i(int n, const double *__restrict__ a, int *__restrict__ b)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) b[q] = (int)a[q];
+}
+__global__ __launch_bounds__(256) void k_uc2d(int n, const unsigned char *__restrict__ a, double *__restrict__ b)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) b[q] = (double)a[q];
+}
+__global__ __launch_bounds__(256) void k_d2uc_or(int r0, int n, const double *__restrict__ a, unsigned char *__restrict__ b)
+{
+   const int q = r0 + blockIdx.x * 256 + threadIdx.x;
+   if (q < r0 + n && a[q] > 0.0) b[q] = 1;
+}
+
+void build_ext_plan(ExtPlan &p, const std::vector<long long> &gid, int off, int nloc, long long lo, const std::vector<long long> &part)
+{
+   Comm &cm = Comm::world();
+   p        = ExtPlan();
+   p.send_counts.assign((size_t)cm.size, 0);
+   p.recv_counts.assign((size_t)cm.size, 0);
+   std::vector<int>       ridx;
+   std::vector<long long> want;
+   for (int e = 0; e < (int)gid.size(); e++)
+      if (e < off || e >= off + nloc)
+      {
+         const int o = owner_of(gid[(size_t)e], part);
+         HDA_REQUIRE(o >= 0 && o < cm.size && o != cm.rank, "extended node without a remote owner");
+         p.recv_counts[(size_t)o]++;
+         ridx.push_back(e);
+         want.push_back(gid[(size_t)e]);
+      }
+   std::vector<long>      eight((size_t)cm.size, 8), sb((size_t)cm.size), rb((size_t)cm.size);
+   std::vector<long long> w((size_t)cm.size), asked((size_t)cm.size);
+   for (int q = 0; q < cm.size; q++) w[(size_t)q] = p.recv_counts[(size_t)q];
+   cm.alltoallv_host(w.data(), eight.data(), asked.data(), eight.data());
+   long tot = 0;
+   for (int q = 0; q < cm.size; q++)
+   {
+      p.send_counts[(size_t)q] = (int)asked[(size_t)q];
+      sb[(size_t)q]            = 8L * p.recv_counts[(size_t)q];
+      rb[(size_t)q]            = 8L * p.send_counts[(size_t)q];
+      tot += p.send_counts[(size_t)q];
+   }
+   std::vector<long long> req((size_t)std::max<long>(tot, 1));
+   if (want.empty()) want.push_back(0);
+   cm.alltoallv_host(want.data(), sb.data(), req.data(), rb.data());
+   std::vector<int> sidx((size_t)std::max<long>(tot, 1));
+   for (long q = 0; q < tot; q++)
+   {
+      const long long l = req[(size_t)q] - lo;
+      HDA_REQUIRE(l >= 0 && l < nloc, "peer requested a node this rank does not own");
+      sidx[(size_t)q] = off + (int)l;
+   }
+   p.nsend = (int)tot;
+   p.nrecv = (int)ridx.size();
+   if (ridx.empty()) ridx.push_back(0);
+   p.send_idx.upload(sidx.data(), sidx.size());
+   p.recv_idx.upload(ridx.data(), ridx.size());
+   p.sbuf.alloc((size_t)std::max(p.nsend, 1));
+   p.rbuf.alloc((size_t)std::max(p.nrecv, 1));
+}
+
+void ext_exchange(ExtPlan &p, double *arr) // owners' values -> ghost copies
+{
+   Comm &cm = Comm::world();
+   if (p.nsend) k_gather_d<<<ceil_div(p.nsend, 256), 256, 0, STREAM>>>(p.nsend, p.send_idx.data(), arr, p.sbuf.data());
+   cm.exchange_dev(p.sbuf.data(), p.send_counts.data(), p.rbuf.data(), p.recv_counts.data());
+   if (p.nrecv) k_scatter_d<<<ceil_div(p.nrecv, 256), 256, 0, STREAM>>>(p.nrecv, p.recv_idx.data(), p.rbuf.data(), arr);
+}
+void ext_reverse_add(ExtPlan &p, double *arr) // ghost copies' values added into the owners' entries
+{
+   Comm &cm = Comm::world();
+   if (p.nrecv) k_gather_d<<<ceil_div(p.nrecv, 256), 256, 0, STREAM>>>(p.nrecv, p.recv_idx.data(), arr, p.rbuf.data());
+   cm.exchange_dev(p.rbuf.data(), p.recv_counts.data(), p.sbuf.data(), p.send_counts.data());
+   if (p.nsend) k_scatter_add_d<<<ceil_div(p.nsend, 256), 256, 0, STREAM>>>(p.nsend, p.send_idx.data(), p.sbuf.data(), arr);
+}
+void ext_exchange_int(ExtPlan &p, int n, int *arr, DArray<double> &tmp)
+{
+   k_i2d<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, arr, tmp.data());
+   ext_exchange(p, tmp.data());
+   k_d2i<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, tmp.data(), arr);
+}
+
+// ---- rows of the nodes peers asked for (halo plan h): lengths, then (global column, value) pairs
+__global__ __launch_bounds__(256) void k_rows_len(int nr, const int *__restrict__ rows, const int *__restrict__ rp, double *__restrict__ len)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < nr) len[q] = (double)(rp[rows[q] + 1] - rp[rows[q]]);
+}
+__global__ __launch_bounds__(256) void k_rows_pack(int nr, const int *__restrict__ rows, const int *__restrict__ rp,
+                                                   const int *__restrict__ ofs, const long long *__restrict__ gcol,
+                                                   const double *__restrict__ val, double *__restrict__ out)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q >= nr) return;
+   const int s = rp[rows[q]], e = rp[rows[q] + 1];
+   double   *o = out + 2 * (size_t)ofs[q];
+   for (int k = s; k < e; k++)
+   {
+      o[2 * (k - s)]     = (double)gcol[k];
+      o[2 * (k - s) + 1] = val[k];
+   }
+}
+
+// send_idx/send_counts/recv_counts describe who gets which of my rows; returns the received rows
+// (in the order of my ghost list) as a host CSR with global columns
+void fetch_rows(int nsend, const int *send_idx_dev, const std::vector<int> &send_counts, int nrecv,
+                const std::vector<int> &recv_counts, const int *rp, const long long *gcol, const double *val,
+                std::vector<int> &grp, std::vector<long long> &gc, std::vector<double> &gv)
+{
+   Comm          &cm = Comm::world();
+   DArray<double> slen((size_t)std::max(nsend, 1)), rlen((size_t)std::max(nrecv, 1));
+   if (nsend) k_rows_len<<<ceil_div(nsend, 256), 256, 0, STREAM>>>(nsend, send_idx_dev, rp, slen.data());
+   cm.exchange_dev(slen.data(), send_counts.data(), rlen.data(), recv_counts.data());
+   std::vector<double> hs((size_t)std::max(nsend, 1)), hr((size_t)std::max(nrecv, 1));
+   slen.download(hs.data(), hs.size());
+   rlen.download(hr.data(), hr.size());
+   std::vector<int> sofs((size_t)nsend + 1, 0), sc2((size_t)cm.size, 0), rc2((size_t)cm.size, 0);
+   for (int q = 0; q < nsend; q++) sofs[(size_t)q + 1] = sofs[(size_t)q] + (int)hs[(size_t)q];
+   grp.assign((size_t)nrecv + 1, 0);
+   for (int q = 0; q < nrecv; q++) grp[(size_t)q + 1] = grp[(size_t)q] + (int)hr[(size_t)q];
+   {
+      int a = 0, b = 0;
+      for (int p = 0; p < cm.size; p++)
+      {
+         int s = 0, r = 0;
+         for (int q = 0; q < send_counts[(size_t)p]; q++) s += (int)hs[(size_t)(a + q)];
+         for (int q = 0; q < recv_counts[(size_t)p]; q++) r += (int)hr[(size_t)(b + q)];
+         a += send_counts[(size_t)p];
+         b += recv_counts[(size_t)p];
+         sc2[(size_t)p] = 2 * s;
+         rc2[(size_t)p] = 2 * r;
+      }
+   }
+   const int      stot = sofs[(size_t)nsend], rtot = grp[(size_t)nrecv];
+   DArray<int>    dofs;
+   DArray<double> sdat((size_t)std::max(2 * stot, 1)), rdat((size_t)std::max(2 * rtot, 1));
+   dofs.upload(sofs.data(), sofs.size());
+   if (nsend) k_rows_pack<<<ceil_div(nsend, 256), 256, 0, STREAM>>>(nsend, send_idx_dev, rp, dofs.data(), gcol, val, sdat.data());
+   cm.exchange_dev(sdat.data(), sc2.data(), rdat.data(), rc2.data());
+   std::vector<double> hd((size_t)std::max(2 * rtot, 1));
+   rdat.download(hd.data(), hd.size());
+   gc.resize((size_t)rtot);
+   gv.resize((size_t)rtot);
+   for (int k = 0; k < rtot; k++)
+   {
+      gc[(size_t)k] = (long long)hd[2 * (size_t)k];
+      gv[(size_t)k] = hd[2 * (size_t)k + 1];
+   }
+}
+
+__global__ __launch_bounds__(256) void k_loc2gcol(long nnz, const int *__restrict__ cj, int ncl, long long lo,
+                                                  const long long *__restrict__ ghosts, long long *__restrict__ out)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256)
+      out[k] = (cj[k] < ncl) ? lo + cj[k] : ghosts[cj[k] - ncl];
+}
+__global__ __launch_bounds__(256) void k_copy_rows_mapped(int nrows, const int *__restrict__ srp, const int *__restrict__ scj,
+                                                          const double *__restrict__ sv, const int *__restrict__ colmap,
+                                                          const int *__restrict__ drp, int *__restrict__ dcj, double *__restrict__ dv)
+{ // row i of the source goes to destination row pointer drp[i] (drp already offset by the caller)
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= nrows) return;
+   const int s = srp[i], e = srp[i + 1], d = drp[i];
+   for (int k = s; k < e; k++)
+   {
+      dcj[d + (k - s)] = colmap ? colmap[scj[k]] : scj[k];
+      dv[d + (k - s)]  = sv[k];
+   }
+}
+__global__ __launch_bounds__(256) void k_scatter_entries(int n, const int *__restrict__ pos, const int *__restrict__ c,
+                                                         const double *__restrict__ v, int *__restrict__ dcj, double *__restrict__ dv)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) { dcj[pos[q]] = c[q]; dv[pos[q]] = v[q]; }
+}
+
+// CSR from (a) a device CSR whose rows go to destination rows base..base+nsrc with mapped
+// columns and (b) host rows (dst row, col, val); every destination row is filled by one source
+void assemble_csr(int nrows, int ncols, int base, const DCsr &src, const int *colmap_dev, const std::vector<int> &hrow,
+                  const std::vector<int> &hrp, const std::vector<int> &hcol, const std::vector<double> &hval, DCsr &out)
+{
+   std::vector<int> srp = src.rowptr.to_host();
+   std::vector<int> rp((size_t)nrows + 1, 0);
+   for (int i = 0; i < src.nrows; i++) rp[(size_t)(base + i) + 1] = srp[(size_t)i + 1] - srp[(size_t)i];
+   for (size_t q = 0; q < hrow.size(); q++) rp[(size_t)hrow[q] + 1] += hrp[q + 1] - hrp[q];
+   for (int i = 0; i < nrows; i++) rp[(size_t)i + 1] += rp[(size_t)i];
+   out.nrows = nrows;
+   out.ncols = ncols;
+   out.nnz   = rp[(size_t)nrows];
+   out.rowptr.upload(rp.data(), rp.size());
+   out.col.alloc((size_t)std::max(out.nnz, 1));
+   out.val.alloc((size_t)std::max(out.nnz, 1));
+   if (src.nrows)
+      k_copy_rows_mapped<<<ceil_div(src.nrows, 256), 256, 0, STREAM>>>(src.nrows, src.rowptr.data(), src.col.data(), src.val.data(), colmap_dev,
+                                                                      out.rowptr.data() + base, out.col.data(), out.val.data());
+   // host rows may land on rows that also got device entries (R: transpose part + received part)
+   std::vector<int> fill((size_t)nrows, 0);
+   for (int i = 0; i < src.nrows; i++) fill[(size_t)(base + i)] = srp[(size_t)i + 1] - srp[(size_t)i];
+   std::vector<int> pos(hcol.size());
+   for (size_t q = 0; q < hrow.size(); q++)
+      for (int k = hrp[q]; k < hrp[q + 1]; k++) pos[(size_t)k] = rp[(size_t)hrow[q]] + fill[(size_t)hrow[q]]++;
+   if (!hcol.empty())
+   {
+      DArray<int>    dp, dc;
+      DArray<double> dv;
+      dp.upload(pos.data(), pos.size());
+      dc.upload(hcol.data(), hcol.size());
+      dv.upload(hval.data(), hval.size());
+      k_scatter_entries<<<ceil_div((long long)hcol.size(), 256), 256, 0, STREAM>>>((int)hcol.size(), dp.data(), dc.data(), dv.data(),
+                                                                                 out.col.data(), out.val.data());
+   }
+   sort_rows(out);
+   Context::get().sync();
+}
+
+void slice_rows(const DCsr &M, int r0, int r1, DCsr &out)
+{
+   int k0 = 0, k1 = 0;
+   HDA_HIP(hipMemcpyAsync(&k0, M.rowptr.data() + r0, 4, hipMemcpyDeviceToHost, STREAM));
+   HDA_HIP(hipMemcpyAsync(&k1, M.rowptr.data() + r1, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   out.nrows = r1 - r0;
+   out.ncols = M.ncols;
+   out.nnz   = k1 - k0;
+   std::vector<int> rp((size_t)out.nrows + 1);
+   HDA_HIP(hipMemcpy(rp.data(), M.rowptr.data() + r0, sizeof(int) * rp.size(), hipMemcpyDeviceToHost));
+   for (auto &x : rp) x -= k0;
+   out.rowptr.upload(rp.data(), rp.size());
+   out.col.alloc((size_t)std::max(out.nnz, 1));
+   out.val.alloc((size_t)std::max(out.nnz, 1));
+   if (out.nnz)
+   {
+      HDA_HIP(hipMemcpyAsync(out.col.data(), M.col.data() + k0, sizeof(int) * (size_t)out.nnz, hipMemcpyDeviceToDevice, STREAM));
+      HDA_HIP(hipMemcpyAsync(out.val.data(), M.val.data() + k0, sizeof(double) * (size_t)out.nnz, hipMemcpyDeviceToDevice, STREAM));
+   }
+}
+
+// build the extended view of one level
+void build_ext_level(const DCsr &Aloc, const std::vector<long long> &ghosts, const std::vector<long long> &part, const HaloPlan &hA,
+                     ExtLevel &X)
+{
+   Comm &cm = Comm::world();
+   X.lo     = part[(size_t)cm.rank];
+   X.hi     = part[(size_t)cm.rank + 1];
+   X.nloc   = (int)(X.hi - X.lo);
+   HDA_REQUIRE(Aloc.nrows == X.nloc, "ext level: block size mismatch");
+   DArray<long long> dgh, gcol((size_t)std::max(Aloc.nnz, 1));
+   {
+      std::vector<long long> g = ghosts;
+      if (g.empty()) g.push_back(0);
+      dgh.upload(g.data(), g.size());
+   }
+   if (Aloc.nnz)
+      k_loc2gcol<<<std::min(ceil_div(Aloc.nnz, 256), 1 << 16), 256, 0, STREAM>>>(Aloc.nnz, Aloc.col.data(), X.nloc, X.lo, dgh.data(), gcol.data());
+   std::vector<int>       grp;
+   std::vector<long long> gc;
+   std::vector<double>    gv;
+   fetch_rows(hA.send_total, hA.send_idx.data(), hA.send_counts, (int)ghosts.size(), hA.recv_counts, Aloc.rowptr.data(), gcol.data(),
+              Aloc.val.data(), grp, gc, gv);
+   // node list: ghosts, then columns of ghost rows that are neither owned nor ghosts
+   std::vector<long long> other = ghosts;
+   for (long long c : gc)
+      if (c < X.lo || c >= X.hi) other.push_back(c);
+   std::sort(other.begin(), other.end());
+   other.erase(std::unique(other.begin(), other.end()), other.end());
+   X.off = (int)(std::lower_bound(other.begin(), other.end(), X.lo) - other.begin());
+   X.gid.clear();
+   X.gid.insert(X.gid.end(), other.begin(), other.begin() + X.off);
+   for (long long g = X.lo; g < X.hi; g++) X.gid.push_back(g);
+   X.gid.insert(X.gid.end(), other.begin() + X.off, other.end());
+   X.next = (int)X.gid.size();
+   X.gid_dev.upload(X.gid.data(), X.gid.size());
+   // local solve-layout column -> extended id
+   std::vector<int> cmap((size_t)std::max(Aloc.ncols, 1));
+   for (int c = 0; c < X.nloc; c++) cmap[(size_t)c] = X.off + c;
+   for (size_t g = 0; g < ghosts.size(); g++) cmap[(size_t)X.nloc + g] = (int)X.ext_of(ghosts[g]);
+   DArray<int> dcmap;
+   dcmap.upload(cmap.data(), cmap.size());
+   std::vector<int>    hrow(ghosts.size()), hcol(gc.size());
+   for (size_t g = 0; g < ghosts.size(); g++) hrow[g] = (int)X.ext_of(ghosts[g]);
+   for (size_t k = 0; k < gc.size(); k++) hcol[k] = (int)X.ext_of(gc[k]);
+   assemble_csr(X.next, X.next, X.off, Aloc, dcmap.data(), hrow, grp, hcol, gv, X.E);
+   build_ext_plan(X.plan, X.gid, X.off, X.nloc, X.lo, part);
+}
+
+// PMIS on the owned rows of E with ghost values exchanged every round
+void pmis_dist(ExtLevel &X, const unsigned char *smask, const int *ns, uint64_t seed, int level, int *cf)
+{
+   Comm                 &cm = Comm::world();
+   const int             n  = X.next, g = ceil_div(std::max(X.nloc, 1), 256), gn = ceil_div(std::max(n, 1), 256);
+   DArray<int>           indeg((size_t)n), counter(1);
+   DArray<double>        meas((size_t)n), tmp((size_t)n);
+   DArray<unsigned char> notmax((size_t)n);
+   indeg.zero();
+   notmax.zero();
+   meas.zero();
+   counter.zero();
+   HDA_HIP(hipMemsetAsync(cf, 0, sizeof(int) * (size_t)n, STREAM));
+   int e0 = 0, e1 = 0;
+   HDA_HIP(hipMemcpyAsync(&e0, X.E.rowptr.data() + X.off, 4, hipMemcpyDeviceToHost, STREAM));
+   HDA_HIP(hipMemcpyAsync(&e1, X.E.rowptr.data() + X.off + X.nloc, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   if (e1 > e0) k_indeg<<<std::min(ceil_div(e1 - e0, 256), 1 << 16), 256, 0, STREAM>>>(e1 - e0, X.E.col.data() + e0, smask + e0, indeg.data());
+   // in-degree contributions that landed on ghost copies go to the owners
+   k_i2d<<<gn, 256, 0, STREAM>>>(n, indeg.data(), tmp.data());
+   ext_reverse_add(X.plan, tmp.data());
+   k_d2i<<<gn, 256, 0, STREAM>>>(n, tmp.data(), indeg.data());
+   if (X.nloc) k_pmis_init<<<g, 256, 0, STREAM>>>(X.off, X.nloc, ns, indeg.data(), seed, level, 0, X.gid_dev.data(), meas.data(), cf, counter.data());
+   ext_exchange(X.plan, meas.data());
+   ext_exchange_int(X.plan, n, cf, tmp);
+   long long left = 0;
+   {
+      int c = 0;
+      counter.download(&c, 1);
+      left = c;
+      cm.allreduce_host(&left, 1, 0);
+   }
+   int rounds = 0;
+   while (left > 0)
+   {
+      if (X.nloc) k_pmis_mark<<<g, 256, 0, STREAM>>>(X.nloc, X.E.rowptr.data(), X.E.col.data(), smask, cf, meas.data(), notmax.data(), X.off);
+      k_uc2d<<<gn, 256, 0, STREAM>>>(n, notmax.data(), tmp.data());
+      ext_reverse_add(X.plan, tmp.data());
+      if (X.nloc) k_d2uc_or<<<g, 256, 0, STREAM>>>(X.off, X.nloc, tmp.data(), notmax.data());
+      if (X.nloc) k_pmis_setC<<<g, 256, 0, STREAM>>>(X.nloc, cf, notmax.data(), X.off);
+      notmax.zero();
+      ext_exchange_int(X.plan, n, cf, tmp);
+      counter.zero();
+      if (X.nloc) k_pmis_setF<<<g, 256, 0, STREAM>>>(X.nloc, X.E.rowptr.data(), X.E.col.data(), smask, cf, counter.data(), X.off);
+      ext_exchange_int(X.plan, n, cf, tmp);
+      int c = 0;
+      counter.download(&c, 1);
+      left = c;
+      cm.allreduce_host(&left, 1, 0);
+      HDA_REQUIRE(++rounds < 10000, "distributed PMIS did not terminate");
+   }
+}
+
+__global__ __launch_bounds__(256) void k_cg_owned(int nloc, int off, const int *__restrict__ cf, const int *__restrict__ cidx, long long coff,
+                                                  double *__restrict__ cg)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < nloc) cg[off + i] = (cf[off + i] == 1) ? (double)(coff + cidx[i]) : -1.0;
+}
+__global__ __launch_bounds__(256) void k_cmark_ext(int n, const int *__restrict__ cf, int *__restrict__ m)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) m[i] = (cf[i] == 1);
+}
+__global__ __launch_bounds__(256) void k_cgc(int n, const int *__restrict__ cf, const int *__restrict__ cidxE, const double *__restrict__ cg,
+                                             long long *__restrict__ cgc)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n && cf[i] == 1) cgc[cidxE[i]] = (long long)cg[i];
+}
+__global__ __launch_bounds__(256) void k_map_cols(long nnz, const int *__restrict__ in, const int *__restrict__ map, int *__restrict__ out)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256) out[k] = map[in[k]];
+}
+__global__ __launch_bounds__(256) void k_cols_to_gid(long nnz, const int *__restrict__ in, const long long *__restrict__ gid, long long *__restrict__ out)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256) out[k] = gid[in[k]];
+}
+
+// solve-layout block out of a matrix whose columns are compact ids with known global ids (host,
+// ascending): owned global columns [clo, chi) -> [0, ncl), the others -> ncl + rank among the
+// referenced ones (ghost list returned)
+void localize_cols(const DCsr &M, const std::vector<long long> &colgid, long long clo, long long chi, DCsr &L,
+                   std::vector<long long> &ghosts)
+{
+   const int   nc = (int)colgid.size();
+   const int   qlo = (int)(std::lower_bound(colgid.begin(), colgid.end(), clo) - colgid.begin());
+   const int   qhi = (int)(std::lower_bound(colgid.begin(), colgid.end(), chi) - colgid.begin());
+   const int   ncl = (int)(chi - clo);
+   // which non-owned columns are referenced
+   std::vector<int> used((size_t)std::max(nc, 1), 0);
+   {
+      DArray<int> flags((size_t)std::max(nc, 1));
+      flags.zero();
+      struct K {
+      };
+      std::vector<int> hc((size_t)std::max(M.nnz, 1));
+      if (M.nnz) M.col.download(hc.data(), (size_t)M.nnz);
+      for (int k = 0; k < M.nnz; k++) used[(size_t)hc[(size_t)k]] = 1;
+   }
+   std::vector<int> map((size_t)std::max(nc, 1), 0);
+   ghosts.clear();
+   for (int q = 0; q < nc; q++)
+   {
+      if (q >= qlo && q < qhi)
+      {
+         HDA_REQUIRE(colgid[(size_t)q] - clo == q - qlo, "owned coarse ids must be contiguous in the compact space");
+         map[(size_t)q] = (int)(colgid[(size_t)q] - clo);
+      }
+      else if (used[(size_t)q])
+      {
+         map[(size_t)q] = ncl + (int)ghosts.size();
+         ghosts.push_back(colgid[(size_t)q]);
+      }
+   }
+   DArray<int> dmap;
+   dmap.upload(map.data(), map.size());
+   L.nrows = M.nrows;
+   L.ncols = ncl + (int)ghosts.size();
+   L.nnz   = M.nnz;
+   L.rowptr.copy_from(M.rowptr);
+   L.col.alloc((size_t)std::max(M.nnz, 1));
+   L.val.copy_from(M.val);
+   if (M.nnz) k_map_cols<<<std::min(ceil_div(M.nnz, 256), 1 << 16), 256, 0, STREAM>>>(M.nnz, M.col.data(), dmap.data(), L.col.data());
+   sort_rows(L);
+   Context::get().sync();
+}
+
+} // namespace
+
+void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<long long> &part0,
+                                 const std::vector<long long> &ghost_gids0)
+{
+   Comm &cm = Comm::world();
+   HDA_REQUIRE(prm.coarsen_type == 8 && prm.interp_type == 6, "partitioned setup: PMIS + extended+i only");
+   static const long long rep_rows = getenv("HDA_REPLICATE_ROWS") ? atoll(getenv("HDA_REPLICATE_ROWS")) : 100000;
+   dist = true;
+   A0   = &Aloc;
+   hA0  = &hA0_;
+   levels.clear();
+   levels.reserve((size_t)std::max(prm.max_levels, 1) + 1);
+   levels.emplace_back();
+   const int              maxl = std::max(prm.max_levels, 1);
+   std::vector<long long> part = part0, ghosts = ghost_gids0;
+   std::vector<size_t>    tail_len(1, ghost_gids0.size());
+   stats_levels = 0;
+   int l = 0;
+   for (;; l++)
+   {
+      const DCsr     &Al   = level_A(l);
+      const HaloPlan &hl   = level_hA(l);
+      const long long nglob = part.back();
+      {
+         long long t[1] = {Al.nnz};
+         cm.allreduce_host(t, 1, 0);
+         if (stats_levels < 32) { stats_nnz[stats_levels] = (double)t[0]; stats_rows[stats_levels] = (double)nglob; stats_levels++; }
+      }
+      const bool stop = (nglob <= prm.max_coarse_size) || (l >= maxl - 1) || (l >= 1 && nglob <= rep_rows);
+      if (stop) break;
+      HDA_TRACE("partitioned setup level %d: %lld rows, %d local", l, nglob, Al.nrows);
+      ExtLevel X;
+      build_ext_level(Al, ghosts, part, hl, X);
+      const int n = X.next;
+      DArray<unsigned char> sm((size_t)std::max(X.E.nnz, 1));
+      DArray<int>           ns((size_t)n + 1), cf((size_t)n + 1);
+      strength_ns(X.E, prm.strong_th, prm.max_row_sum, sm.data(), ns.data());
+      pmis_dist(X, sm.data(), ns.data(), prm.seed, l + level0, cf.data());
+      // global coarse numbering
+      DArray<int> cm_own((size_t)X.nloc + 1), cidx((size_t)X.nloc + 1);
+      k_cmark_ext<<<ceil_div(std::max(X.nloc, 1), 256), 256, 0, STREAM>>>(X.nloc, cf.data() + X.off, cm_own.data());
+      exclusive_scan(X.nloc, cm_own.data(), cidx.data(), nullptr);
+      int ncl = 0;
+      HDA_HIP(hipMemcpyAsync(&ncl, cidx.data() + X.nloc, 4, hipMemcpyDeviceToHost, STREAM));
+      Context::get().sync();
+      std::vector<long long> cnts, partc((size_t)cm.size + 1, 0);
+      cm.allgather_ll(ncl, cnts);
+      for (int r = 0; r < cm.size; r++) partc[(size_t)r + 1] = partc[(size_t)r] + cnts[(size_t)r];
+      const long long ncglob = partc.back(), clo = partc[(size_t)cm.rank], chi = partc[(size_t)cm.rank + 1];
+      if (ncglob == 0 || ncglob == nglob || ncglob < prm.min_coarse_size) break;
+      DArray<double> cg((size_t)n);
+      fill(n, -1.0, cg.data());
+      if (X.nloc) k_cg_owned<<<ceil_div(X.nloc, 256), 256, 0, STREAM>>>(X.nloc, X.off, cf.data(), cidx.data(), clo, cg.data());
+      ext_exchange(X.plan, cg.data());
+      // interpolation on E (rows of ghost nodes are by-products and ignored)
+      DCsr PE;
+      amg_interp_extpi(X.E, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, PE);
+      DArray<int> cmE((size_t)n + 1), cidxE((size_t)n + 1);
+      k_cmark_ext<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, cf.data(), cmE.data());
+      exclusive_scan(n, cmE.data(), cidxE.data(), nullptr);
+      const int         nce = PE.ncols;
+      DArray<long long> cgc((size_t)std::max(nce, 1));
+      k_cgc<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, cf.data(), cidxE.data(), cg.data(), cgc.data());
+      std::vector<long long> cgc_h((size_t)nce);
+      if (nce) cgc.download(cgc_h.data(), (size_t)nce);
+      DCsr Pown;
+      slice_rows(PE, X.off, X.off + X.nloc, Pown);
+      // ---- P in solve layout + halo plan for coarse vectors
+      AmgLevel              &lv = levels[(size_t)l];
+      std::vector<long long> ghostc;
+      localize_cols(Pown, cgc_h, clo, chi, lv.P, ghostc);
+      lv.hP = make_halo_plan((int)(chi - clo), partc, ghostc);
+      // ---- R = P^T rows of owned coarse points: local transpose + entries of remote fine rows
+      std::vector<int>    prp = Pown.rowptr.to_host(), pcj((size_t)std::max(Pown.nnz, 1));
+      std::vector<double> pv((size_t)std::max(Pown.nnz, 1));
+      if (Pown.nnz) { Pown.col.download(pcj.data(), (size_t)Pown.nnz); Pown.val.download(pv.data(), (size_t)Pown.nnz); }
+      struct Trip { long long c, i; double w; };
+      std::vector<std::vector<Trip>> out((size_t)cm.size);
+      for (int i = 0; i < X.nloc; i++)
+         for (int k = prp[(size_t)i]; k < prp[(size_t)i + 1]; k++)
+         {
+            const long long g = cgc_h[(size_t)pcj[(size_t)k]];
+            if (g < clo || g >= chi) out[(size_t)owner_of(g, partc)].push_back({g, X.lo + i, pv[(size_t)k]});
+         }
+      std::vector<Trip> recv_t;
+      {
+         std::vector<long>      eight((size_t)cm.size, 8), sb((size_t)cm.size), rb((size_t)cm.size);
+         std::vector<long long> sc((size_t)cm.size), rc((size_t)cm.size);
+         std::vector<Trip>      flat;
+         for (int p = 0; p < cm.size; p++) { sc[(size_t)p] = (long long)out[(size_t)p].size(); flat.insert(flat.end(), out[(size_t)p].begin(), out[(size_t)p].end()); }
+         cm.alltoallv_host(sc.data(), eight.data(), rc.data(), eight.data());
+         long tot = 0;
+         for (int p = 0; p < cm.size; p++) { sb[(size_t)p] = (long)(sc[(size_t)p] * sizeof(Trip)); rb[(size_t)p] = (long)(rc[(size_t)p] * sizeof(Trip)); tot += (long)rc[(size_t)p]; }
+         recv_t.resize((size_t)std::max<long>(tot, 1));
+         if (flat.empty()) flat.resize(1);
+         cm.alltoallv_host(flat.data(), sb.data(), recv_t.data(), rb.data());
+         recv_t.resize((size_t)tot);
+      }
+      {
+         DCsr PT, Rown;
+         transpose(lv.P, PT);
+         slice_rows(PT, 0, (int)(chi - clo), Rown);
+         std::sort(recv_t.begin(), recv_t.end(), [](const Trip &a, const Trip &b) { return a.c != b.c ? a.c < b.c : a.i < b.i; });
+         std::vector<long long> gf;
+         for (auto &t : recv_t) gf.push_back(t.i);
+         std::sort(gf.begin(), gf.end());
+         gf.erase(std::unique(gf.begin(), gf.end()), gf.end());
+         std::vector<int>    hrow, hrp(1, 0), hcol;
+         std::vector<double> hval;
+         for (size_t q = 0; q < recv_t.size(); q++)
+         {
+            const int row = (int)(recv_t[q].c - clo);
+            if (hrow.empty() || hrow.back() != row) { hrow.push_back(row); hrp.push_back(hrp.back()); }
+            hrp.back()++;
+            hcol.push_back(X.nloc + (int)(std::lower_bound(gf.begin(), gf.end(), recv_t[q].i) - gf.begin()));
+            hval.push_back(recv_t[q].w);
+         }
+         assemble_csr((int)(chi - clo), X.nloc + (int)gf.size(), 0, Rown, nullptr, hrow, hrp, hcol, hval, lv.R);
+         lv.hR = make_halo_plan(X.nloc, part, gf);
+         tail_len[(size_t)l] = std::max(tail_len[(size_t)l], gf.size());
+      }
+      // ---- Galerkin product
+      DCsr Ac_loc;
+      std::vector<long long> ghosts_next;
+      {
+         // P rows of my ghost nodes (global coarse columns)
+         DArray<long long> gcolP((size_t)std::max(Pown.nnz, 1));
+         if (Pown.nnz) k_cols_to_gid<<<std::min(ceil_div(Pown.nnz, 256), 1 << 16), 256, 0, STREAM>>>(Pown.nnz, Pown.col.data(), cgc.data(), gcolP.data());
+         std::vector<int>       grp;
+         std::vector<long long> gc;
+         std::vector<double>    gv;
+         fetch_rows(hl.send_total, hl.send_idx.data(), hl.send_counts, (int)ghosts.size(), hl.recv_counts, Pown.rowptr.data(), gcolP.data(),
+                    Pown.val.data(), grp, gc, gv);
+         // coarse extended space CX = ids seen in E  U  ids in the fetched rows
+         std::vector<long long> CX = cgc_h, extra = gc;
+         std::sort(extra.begin(), extra.end());
+         extra.erase(std::unique(extra.begin(), extra.end()), extra.end());
+         {
+            std::vector<long long> u;
+            std::set_union(CX.begin(), CX.end(), extra.begin(), extra.end(), std::back_inserter(u));
+            CX.swap(u);
+         }
+         auto cx_of = [&](long long g) { return (int)(std::lower_bound(CX.begin(), CX.end(), g) - CX.begin()); };
+         std::vector<int> mapq((size_t)std::max(nce, 1));
+         for (int q = 0; q < nce; q++) mapq[(size_t)q] = cx_of(cgc_h[(size_t)q]);
+         DArray<int> dmapq;
+         dmapq.upload(mapq.data(), mapq.size());
+         // Pe: rows of every extended node (owned: computed here; layer-1 ghosts: fetched; others empty)
+         std::vector<int> hrow(ghosts.size()), hcol(gc.size());
+         for (size_t g = 0; g < ghosts.size(); g++) hrow[g] = (int)X.ext_of(ghosts[g]);
+         for (size_t k = 0; k < gc.size(); k++) hcol[k] = cx_of(gc[k]);
+         DCsr Pe, Eown, AP, PeOwn, PT, T;
+         assemble_csr(n, (int)CX.size(), X.off, Pown, dmapq.data(), hrow, grp, hcol, gv, Pe);
+         slice_rows(X.E, X.off, X.off + X.nloc, Eown);
+         spgemm(Eown, Pe, AP);
+         slice_rows(Pe, X.off, X.off + X.nloc, PeOwn);
+         transpose(PeOwn, PT);
+         spgemm(PT, AP, T);
+         // rows of coarse points owned elsewhere go to their owners
+         const int qlo = cx_of(clo), qhi = qlo + (int)(chi - clo);
+         std::vector<int>    trp = T.rowptr.to_host(), tcj((size_t)std::max(T.nnz, 1));
+         std::vector<double> tv((size_t)std::max(T.nnz, 1));
+         if (T.nnz) { T.col.download(tcj.data(), (size_t)T.nnz); T.val.download(tv.data(), (size_t)T.nnz); }
+         struct Ent { long long r, c; double w; };
+         std::vector<std::vector<Ent>> eout((size_t)cm.size);
+         for (int q = 0; q < (int)CX.size(); q++)
+         {
+            if (q >= qlo && q < qhi) continue;
+            if (trp[(size_t)q + 1] == trp[(size_t)q]) continue;
+            const int o = owner_of(CX[(size_t)q], partc);
+            for (int k = trp[(size_t)q]; k < trp[(size_t)q + 1]; k++) eout[(size_t)o].push_back({CX[(size_t)q], CX[(size_t)tcj[(size_t)k]], tv[(size_t)k]});
+         }
+         std::vector<Ent> erecv;
+         {
+            std::vector<long>      eight((size_t)cm.size, 8), sb((size_t)cm.size), rb((size_t)cm.size);
+            std::vector<long long> sc((size_t)cm.size), rc((size_t)cm.size);
+            std::vector<Ent>       flat;
+            for (int p = 0; p < cm.size; p++) { sc[(size_t)p] = (long long)eout[(size_t)p].size(); flat.insert(flat.end(), eout[(size_t)p].begin(), eout[(size_t)p].end()); }
+            cm.alltoallv_host(sc.data(), eight.data(), rc.data(), eight.data());
+            long tot = 0;
+            for (int p = 0; p < cm.size; p++) { sb[(size_t)p] = (long)(sc[(size_t)p] * sizeof(Ent)); rb[(size_t)p] = (long)(rc[(size_t)p] * sizeof(Ent)); tot += (long)rc[(size_t)p]; }
+            erecv.resize((size_t)std::max<long>(tot, 1));
+            if (flat.empty()) flat.resize(1);
+            cm.alltoallv_host(flat.data(), sb.data(), erecv.data(), rb.data());
+            erecv.resize((size_t)tot);
+         }
+         // second compact space CX2 = CX U received columns; A_c(owned) = T(owned rows) + received rows
+         std::vector<long long> CX2 = CX, ec;
+         for (auto &e : erecv) ec.push_back(e.c);
+         std::sort(ec.begin(), ec.end());
+         ec.erase(std::unique(ec.begin(), ec.end()), ec.end());
+         {
+            std::vector<long long> u;
+            std::set_union(CX2.begin(), CX2.end(), ec.begin(), ec.end(), std::back_inserter(u));
+            CX2.swap(u);
+         }
+         auto cx2_of = [&](long long g) { return (int)(std::lower_bound(CX2.begin(), CX2.end(), g) - CX2.begin()); };
+         std::vector<int> map2(CX.size());
+         for (size_t q = 0; q < CX.size(); q++) map2[q] = cx2_of(CX[q]);
+         DArray<int> dmap2;
+         dmap2.upload(map2.data(), std::max<size_t>(map2.size(), 1));
+         DCsr Town;
+         slice_rows(T, qlo, qhi, Town);
+         const int ncl_i = (int)(chi - clo);
+         // stacked operand Y = [Town ; Recv] and X = [I | I]: deterministic sum Town + Recv through the ESC product
+         std::stable_sort(erecv.begin(), erecv.end(), [](const Ent &a, const Ent &b) { return a.r != b.r ? a.r < b.r : a.c < b.c; });
+         std::vector<int>    hrow2, hrp2(1, 0), hcol2;
+         std::vector<double> hval2;
+         for (auto &e : erecv)
+         {
+            const int row = ncl_i + (int)(e.r - clo);
+            if (hrow2.empty() || hrow2.back() != row) { hrow2.push_back(row); hrp2.push_back(hrp2.back()); }
+            hrp2.back()++;
+            hcol2.push_back(cx2_of(e.c));
+            hval2.push_back(e.w);
+         }
+         DCsr Y, Xs, Ac;
+         assemble_csr(2 * ncl_i, (int)CX2.size(), 0, Town, dmap2.data(), hrow2, hrp2, hcol2, hval2, Y);
+         {
+            std::vector<int>    xrp((size_t)ncl_i + 1), xcj((size_t)2 * ncl_i + 1);
+            std::vector<double> xv((size_t)2 * ncl_i + 1, 1.0);
+            for (int i = 0; i < ncl_i; i++) { xrp[(size_t)i] = 2 * i; xcj[(size_t)2 * i] = i; xcj[(size_t)2 * i + 1] = ncl_i + i; }
+            xrp[(size_t)ncl_i] = 2 * ncl_i;
+            Xs.nrows = ncl_i; Xs.ncols = 2 * ncl_i; Xs.nnz = 2 * ncl_i;
+            Xs.rowptr.upload(xrp.data(), xrp.size());
+            Xs.col.upload(xcj.data(), xcj.size());
+            Xs.val.upload(xv.data(), xv.size());
+         }
+         spgemm(Xs, Y, Ac);
+         localize_cols(Ac, CX2, clo, chi, Ac_loc, ghosts_next);
+      }
+      levels.emplace_back();
+      levels[(size_t)l + 1].A  = std::move(Ac_loc);
+      levels[(size_t)l + 1].hA = make_halo_plan((int)(chi - clo), partc, ghosts_next);
+      tail_len[(size_t)l]      = std::max(tail_len[(size_t)l], ghosts.size());
+      tail_len.push_back(std::max(ghostc.size(), ghosts_next.size()));
+      part   = partc;
+      ghosts = ghosts_next;
+   }
+   // ---- the remaining (small) operator is gathered and finished redundantly on every rank
+   {
+      const DCsr &Al = level_A(l);
+      tail           = std::make_unique<Amg>(prm);
+      tail->level0   = l + level0;
+      gather_global(Al, part, ghosts, tail->own_A0);
+      tail->setup(tail->own_A0);
+      for (int t = 1; t < tail->stats_levels && stats_levels < 32; t++, stats_levels++)
+      {
+         stats_nnz[stats_levels]  = tail->stats_nnz[t];
+         stats_rows[stats_levels] = tail->stats_rows[t];
+      }
+      coarse_n     = (int)part.back();
+      coarse_dense = true;
+      coarse_lo    = part[(size_t)cm.rank];
+      coarse_nloc  = (int)(part[(size_t)cm.rank + 1] - coarse_lo);
+      cbuf_f.alloc((size_t)std::max(coarse_n, 1));
+      cbuf_u.alloc(std::max<size_t>((size_t)std::max(coarse_n, 1), tail->vec_len0()));
+      if (l > 0) levels[(size_t)l].A = DCsr(); // the stub level keeps only vectors
+   }
+   const int L = (int)levels.size();
+   for (int q = 0; q < L; q++)
+   {
+      AmgLevel    &lv = levels[(size_t)q];
+      const size_t nq = (q == L - 1) ? (size_t)coarse_nloc : (size_t)level_A(q).nrows;
+      if (q < L - 1) build_smoother_data(q);
+      lv.ext = std::max<size_t>(nq + tail_len[(size_t)q], 1);
+      if (q > 0) { lv.f.alloc(lv.ext); lv.u.alloc(lv.ext); }
+      lv.u2.alloc(lv.ext);
+      lv.t.alloc(lv.ext);
+   }
+   Context::get().sync();
+   HDA_TRACE("partitioned setup: %d partitioned levels + replicated tail of %d levels", L - 1, tail->num_levels());
+   if (getenv("HDA_DIST_CHECK"))
+   { // development aid: the replicated setup is the specification of this one
+      Amg ref(prm);
+      ref.setup_dist(Aloc, hA0_, part0, ghost_gids0);
+      auto cmp = [&](const char *what, int q, const DCsr &a, const DCsr &b, double tol) {
+         const std::string tag = std::string(what) + " on level " + std::to_string(q) + " (" + std::to_string(a.nrows) + "x" + std::to_string(a.ncols) + "/" + std::to_string(a.nnz) +
+                                 " vs " + std::to_string(b.nrows) + "x" + std::to_string(b.ncols) + "/" + std::to_string(b.nnz) + ")";
+         HDA_REQUIRE(a.nrows == b.nrows && a.ncols == b.ncols && a.nnz == b.nnz, ("HDA_DIST_CHECK: shape differs: " + tag).c_str());
+         std::vector<int>    ra = a.rowptr.to_host(), rb = b.rowptr.to_host(), ca((size_t)std::max(a.nnz, 1)), cb((size_t)std::max(a.nnz, 1));
+         std::vector<double> va((size_t)std::max(a.nnz, 1)), vb((size_t)std::max(a.nnz, 1));
+         if (a.nnz) { a.col.download(ca.data(), (size_t)a.nnz); b.col.download(cb.data(), (size_t)a.nnz); a.val.download(va.data(), (size_t)a.nnz); b.val.download(vb.data(), (size_t)a.nnz); }
+         HDA_REQUIRE(std::equal(ra.begin(), ra.begin() + a.nrows + 1, rb.begin()), "HDA_DIST_CHECK: row pointers differ");
+         double worst = 0.0, big = 0.0;
+         for (int k = 0; k < a.nnz; k++)
+         {
+            HDA_REQUIRE(ca[(size_t)k] == cb[(size_t)k], ("HDA_DIST_CHECK: columns differ: " + tag).c_str());
+            worst = std::max(worst, std::fabs(va[(size_t)k] - vb[(size_t)k]));
+            big   = std::max(big, std::fabs(vb[(size_t)k]));
+         }
+         HDA_REQUIRE(worst <= tol * std::max(big, 1e-300), ("HDA_DIST_CHECK: values differ by " + std::to_string(worst / std::max(big, 1e-300)) + ": " + tag).c_str());
+         fprintf(stderr, "[hda] dist check rank %d level %d %s: identical pattern, max rel diff %.2e\n", cm.rank, q, what, worst / std::max(big, 1e-300));
+      };
+      HDA_REQUIRE(ref.num_levels() == num_levels(), "HDA_DIST_CHECK: level count differs");
+      for (int q = 0; q < L - 1; q++)
+      {
+         if (q > 0) cmp("A", q, levels[(size_t)q].A, ref.levels[(size_t)q].A, q == 1 ? 1e-13 : 1e-10);
+         cmp("P", q, levels[(size_t)q].P, ref.levels[(size_t)q].P, q == 0 ? 0.0 : 1e-10);
+         cmp("R", q, levels[(size_t)q].R, ref.levels[(size_t)q].R, q == 0 ? 0.0 : 1e-10);
+      }
+      const int mine = num_levels() + (tail ? tail->num_levels() - 1 : 0), theirs = ref.num_levels() + (ref.tail ? ref.tail->num_levels() - 1 : 0);
+      HDA_REQUIRE(mine == theirs, "HDA_DIST_CHECK: total hierarchy depth differs");
+   }
 }
 
 } // namespace hda

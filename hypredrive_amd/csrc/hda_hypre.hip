@@ -790,7 +790,14 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    HDA_REQUIRE(s->restriction == 0, "only P^T restriction (restriction_type 0) is implemented");
    HDA_REQUIRE(s->relax_order == 0, "only lexicographic relaxation order (relaxation.order 0) is implemented");
    s->amg = std::make_unique<Amg>(s->ap);
-   if (Comm::world().size > 1) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+   if (Comm::world().size > 1)
+   {
+      // HDA_DIST_SETUP=partitioned: every setup phase on the row blocks (PMIS + ext+i only);
+      // replicated (default): every rank builds the whole hierarchy and keeps its rows
+      const char *mode = getenv("HDA_DIST_SETUP");
+      if (mode && !strcmp(mode, "partitioned")) s->amg->setup_dist_partitioned(A->A, A->halo, A->part, A->ghost_gids);
+      else s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+   }
    else s->amg->setup(A->A);
    hda_register_precond_veclen(s->amg->vec_len0());
    if (s->ap.print_level > 0 && Comm::world().rank == 0)
