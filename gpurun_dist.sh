@@ -11,3 +11,9 @@ run() { # world n solver rep_rows
 }
 rm -f gpurun_out/dist.log
 run 2 16 pcg 100000 && run 2 16 pcg 0 && run 4 20 pcg 0 && run 4 24 pcg 700 && run 3 12 gmres 0 && run 4 48 pcg 2000
+# timing view of the phases at a larger block (no self-check)
+echo "=== timing world=2 n=128" | tee -a gpurun_out/dist.log
+HDA_DIST_CHECK= HDA_VERBOSE=1 HDA_REPLICATE_ROWS=100000 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 \
+   --master-port 29790 tests/dist_worker.py solve gpurun_out/dist_t.json 128 pcg > gpurun_out/dist_timing.log 2>&1 || { echo FAILED; tail -30 gpurun_out/dist_timing.log; exit 1; }
+grep "partitioned setup" gpurun_out/dist_timing.log | tail -20
+cat gpurun_out/dist_t.json

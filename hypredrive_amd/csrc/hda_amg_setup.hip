@@ -1998,7 +1998,8 @@ void Amg::solve(const double *b, double *x)
 // bit-identical results for the owned rows; PMIS runs its synchronous rounds on the owned
 // rows with measure / C-F / "not a maximum" values exchanged for the ghosts; the Galerkin
 // product is formed from local rows and the coarse rows owned elsewhere are shipped to their
-// owners and added there.  Ghost-layer bookkeeping is surface-sized and done on the host.
+// owners and merged there.  Everything proportional to the block volume stays on the device;
+// the host only handles ghost-layer (surface-sized) bookkeeping.
 // =========================================================================================
 namespace hda {
 namespace {
@@ -2006,6 +2007,69 @@ namespace {
 int owner_of(long long g, const std::vector<long long> &part)
 {
    return (int)(std::upper_bound(part.begin(), part.end(), g) - part.begin()) - 1;
+}
+
+// ascending global ids of the form [below ... | lo .. hi-1 | above ...]
+struct IdSpace {
+   long long              lo = 0, hi = 0;
+   std::vector<long long> below, above;
+   int       off() const { return (int)below.size(); }
+   int       nown() const { return (int)(hi - lo); }
+   int       size() const { return off() + nown() + (int)above.size(); }
+   int       nother() const { return (int)(below.size() + above.size()); }
+   long long other(int q) const { return q < off() ? below[(size_t)q] : above[(size_t)(q - off())]; } // q-th non-owned id
+   int       other_pos(int q) const { return q < off() ? q : q + nown(); }                               // its index in the space
+   int       of(long long g) const
+   {
+      if (g < lo) return (int)(std::lower_bound(below.begin(), below.end(), g) - below.begin());
+      if (g >= hi) return off() + nown() + (int)(std::lower_bound(above.begin(), above.end(), g) - above.begin());
+      return off() + (int)(g - lo);
+   }
+   void set(long long lo_, long long hi_, std::vector<long long> &ids) // ids: non-owned, any order, duplicates allowed
+   {
+      lo = lo_;
+      hi = hi_;
+      std::sort(ids.begin(), ids.end());
+      ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+      auto m = std::lower_bound(ids.begin(), ids.end(), lo);
+      below.assign(ids.begin(), m);
+      above.assign(m, ids.end());
+      HDA_REQUIRE(above.empty() || above.front() >= hi, "id space: owned id listed as foreign");
+   }
+};
+
+__global__ __launch_bounds__(256) void k_iota_ll(int n, long long first, long long *__restrict__ out)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) out[i] = first + i;
+}
+__global__ __launch_bounds__(256) void k_iota_i(int n, int first, int *__restrict__ out)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) out[i] = first + i;
+}
+
+void space_gids_to_device(const IdSpace &S, DArray<long long> &d)
+{
+   d.alloc((size_t)std::max(S.size(), 1));
+   if (S.off()) HDA_HIP(hipMemcpyAsync(d.data(), S.below.data(), 8 * S.below.size(), hipMemcpyHostToDevice, STREAM));
+   if (S.nown()) k_iota_ll<<<ceil_div(S.nown(), 256), 256, 0, STREAM>>>(S.nown(), S.lo, d.data() + S.off());
+   if (!S.above.empty()) HDA_HIP(hipMemcpyAsync(d.data() + S.off() + S.nown(), S.above.data(), 8 * S.above.size(), hipMemcpyHostToDevice, STREAM));
+   Context::get().sync();
+}
+
+// index map from a space into a superspace with the same owned range
+void space_map(const IdSpace &from, const IdSpace &to, DArray<int> &map)
+{
+   HDA_REQUIRE(from.lo == to.lo && from.hi == to.hi, "space map: different owned ranges");
+   map.alloc((size_t)std::max(from.size(), 1));
+   std::vector<int> b(from.below.size()), a(from.above.size());
+   for (size_t q = 0; q < b.size(); q++) b[q] = to.of(from.below[q]);
+   for (size_t q = 0; q < a.size(); q++) a[q] = to.of(from.above[q]);
+   if (!b.empty()) HDA_HIP(hipMemcpyAsync(map.data(), b.data(), 4 * b.size(), hipMemcpyHostToDevice, STREAM));
+   if (from.nown()) k_iota_i<<<ceil_div(from.nown(), 256), 256, 0, STREAM>>>(from.nown(), to.off(), map.data() + from.off());
+   if (!a.empty()) HDA_HIP(hipMemcpyAsync(map.data() + from.off() + from.nown(), a.data(), 4 * a.size(), hipMemcpyHostToDevice, STREAM));
+   Context::get().sync();
 }
 
 struct ExtPlan { // exchange of per-node arrays indexed by extended node id
@@ -2016,17 +2080,11 @@ struct ExtPlan { // exchange of per-node arrays indexed by extended node id
 };
 
 struct ExtLevel {
-   long long              lo = 0, hi = 0;
-   int                    nloc = 0, off = 0, next = 0;
-   std::vector<long long> gid; // global id of every extended node, ascending
-   DArray<long long>      gid_dev;
-   DCsr                   E;   // next x next; rows of owned + layer-1 ghost nodes, columns = extended ids
-   ExtPlan                plan;
-   long long              ext_of(long long g) const
-   {
-      if (g >= lo && g < hi) return off + (g - lo);
-      return std::lower_bound(gid.begin(), gid.end(), g) - gid.begin();
-   }
+   IdSpace           S; // every node this rank touches on the level
+   int               nloc = 0, off = 0, next = 0;
+   DArray<long long> gid_dev;
+   DCsr              E; // next x next; rows of owned + layer-1 ghost nodes, columns = extended ids
+   ExtPlan           plan;
 };
 
 __global__ __launch_bounds__(256) void k_gather_d(int n, const int *__restrict__ idx, const double *__restrict__ src, double *__restrict__ dst)
@@ -2065,23 +2123,24 @@ __global__ __launch_bounds__(256) void k_d2uc_or(int r0, int n, const double *__
    if (q < r0 + n && a[q] > 0.0) b[q] = 1;
 }
 
-void build_ext_plan(ExtPlan &p, const std::vector<long long> &gid, int off, int nloc, long long lo, const std::vector<long long> &part)
+void build_ext_plan(ExtPlan &p, const IdSpace &S, const std::vector<long long> &part)
 {
    Comm &cm = Comm::world();
    p        = ExtPlan();
    p.send_counts.assign((size_t)cm.size, 0);
    p.recv_counts.assign((size_t)cm.size, 0);
-   std::vector<int>       ridx;
-   std::vector<long long> want;
-   for (int e = 0; e < (int)gid.size(); e++)
-      if (e < off || e >= off + nloc)
-      {
-         const int o = owner_of(gid[(size_t)e], part);
-         HDA_REQUIRE(o >= 0 && o < cm.size && o != cm.rank, "extended node without a remote owner");
-         p.recv_counts[(size_t)o]++;
-         ridx.push_back(e);
-         want.push_back(gid[(size_t)e]);
-      }
+   const int              no = S.nother();
+   std::vector<int>       ridx((size_t)std::max(no, 1), 0);
+   std::vector<long long> want((size_t)std::max(no, 1), 0);
+   for (int q = 0; q < no; q++)
+   { // ascending ids => grouped by ascending owner
+      const long long g = S.other(q);
+      const int       o = owner_of(g, part);
+      HDA_REQUIRE(o >= 0 && o < cm.size && o != cm.rank, "extended node without a remote owner");
+      p.recv_counts[(size_t)o]++;
+      ridx[(size_t)q] = S.other_pos(q);
+      want[(size_t)q] = g;
+   }
    std::vector<long>      eight((size_t)cm.size, 8), sb((size_t)cm.size), rb((size_t)cm.size);
    std::vector<long long> w((size_t)cm.size), asked((size_t)cm.size);
    for (int q = 0; q < cm.size; q++) w[(size_t)q] = p.recv_counts[(size_t)q];
@@ -2095,18 +2154,16 @@ void build_ext_plan(ExtPlan &p, const std::vector<long long> &gid, int off, int 
       tot += p.send_counts[(size_t)q];
    }
    std::vector<long long> req((size_t)std::max<long>(tot, 1));
-   if (want.empty()) want.push_back(0);
    cm.alltoallv_host(want.data(), sb.data(), req.data(), rb.data());
-   std::vector<int> sidx((size_t)std::max<long>(tot, 1));
+   std::vector<int> sidx((size_t)std::max<long>(tot, 1), 0);
    for (long q = 0; q < tot; q++)
    {
-      const long long l = req[(size_t)q] - lo;
-      HDA_REQUIRE(l >= 0 && l < nloc, "peer requested a node this rank does not own");
-      sidx[(size_t)q] = off + (int)l;
+      const long long l = req[(size_t)q] - S.lo;
+      HDA_REQUIRE(l >= 0 && l < S.nown(), "peer requested a node this rank does not own");
+      sidx[(size_t)q] = S.off() + (int)l;
    }
    p.nsend = (int)tot;
-   p.nrecv = (int)ridx.size();
-   if (ridx.empty()) ridx.push_back(0);
+   p.nrecv = no;
    p.send_idx.upload(sidx.data(), sidx.size());
    p.recv_idx.upload(ridx.data(), ridx.size());
    p.sbuf.alloc((size_t)std::max(p.nsend, 1));
@@ -2134,7 +2191,7 @@ void ext_exchange_int(ExtPlan &p, int n, int *arr, DArray<double> &tmp)
    k_d2i<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, tmp.data(), arr);
 }
 
-// ---- rows of the nodes peers asked for (halo plan h): lengths, then (global column, value) pairs
+// ---- rows of the nodes peers asked for: lengths, then (global column, value) pairs
 __global__ __launch_bounds__(256) void k_rows_len(int nr, const int *__restrict__ rows, const int *__restrict__ rp, double *__restrict__ len)
 {
    const int q = blockIdx.x * 256 + threadIdx.x;
@@ -2150,16 +2207,24 @@ __global__ __launch_bounds__(256) void k_rows_pack(int nr, const int *__restrict
    double   *o = out + 2 * (size_t)ofs[q];
    for (int k = s; k < e; k++)
    {
-      o[2 * (k - s)]     = (double)gcol[k];
+      o[2 * (k - s)]     = (double)gcol[k]; // exact below 2^53
       o[2 * (k - s) + 1] = val[k];
    }
 }
 
-// send_idx/send_counts/recv_counts describe who gets which of my rows; returns the received rows
-// (in the order of my ghost list) as a host CSR with global columns
+// host sparse rows: row q of the list has entries [rp[q], rp[q+1])
+struct HostRows {
+   std::vector<int>       row; // destination row of every listed row (filled by the caller)
+   std::vector<int>       rp{0};
+   std::vector<long long> gcol;
+   std::vector<int>       col;
+   std::vector<double>    val;
+};
+
+// the rows named by send_idx (grouped by destination) go to the peers; what arrives (in the
+// order of this rank's ghost list) is returned with global columns
 void fetch_rows(int nsend, const int *send_idx_dev, const std::vector<int> &send_counts, int nrecv,
-                const std::vector<int> &recv_counts, const int *rp, const long long *gcol, const double *val,
-                std::vector<int> &grp, std::vector<long long> &gc, std::vector<double> &gv)
+                const std::vector<int> &recv_counts, const int *rp, const long long *gcol, const double *val, HostRows &out)
 {
    Comm          &cm = Comm::world();
    DArray<double> slen((size_t)std::max(nsend, 1)), rlen((size_t)std::max(nrecv, 1));
@@ -2170,22 +2235,19 @@ void fetch_rows(int nsend, const int *send_idx_dev, const std::vector<int> &send
    rlen.download(hr.data(), hr.size());
    std::vector<int> sofs((size_t)nsend + 1, 0), sc2((size_t)cm.size, 0), rc2((size_t)cm.size, 0);
    for (int q = 0; q < nsend; q++) sofs[(size_t)q + 1] = sofs[(size_t)q] + (int)hs[(size_t)q];
-   grp.assign((size_t)nrecv + 1, 0);
-   for (int q = 0; q < nrecv; q++) grp[(size_t)q + 1] = grp[(size_t)q] + (int)hr[(size_t)q];
+   out.rp.assign((size_t)nrecv + 1, 0);
+   for (int q = 0; q < nrecv; q++) out.rp[(size_t)q + 1] = out.rp[(size_t)q] + (int)hr[(size_t)q];
    {
       int a = 0, b = 0;
       for (int p = 0; p < cm.size; p++)
       {
-         int s = 0, r = 0;
-         for (int q = 0; q < send_counts[(size_t)p]; q++) s += (int)hs[(size_t)(a + q)];
-         for (int q = 0; q < recv_counts[(size_t)p]; q++) r += (int)hr[(size_t)(b + q)];
+         sc2[(size_t)p] = 2 * (sofs[(size_t)(a + send_counts[(size_t)p])] - sofs[(size_t)a]);
+         rc2[(size_t)p] = 2 * (out.rp[(size_t)(b + recv_counts[(size_t)p])] - out.rp[(size_t)b]);
          a += send_counts[(size_t)p];
          b += recv_counts[(size_t)p];
-         sc2[(size_t)p] = 2 * s;
-         rc2[(size_t)p] = 2 * r;
       }
    }
-   const int      stot = sofs[(size_t)nsend], rtot = grp[(size_t)nrecv];
+   const int      stot = sofs[(size_t)nsend], rtot = out.rp[(size_t)nrecv];
    DArray<int>    dofs;
    DArray<double> sdat((size_t)std::max(2 * stot, 1)), rdat((size_t)std::max(2 * rtot, 1));
    dofs.upload(sofs.data(), sofs.size());
@@ -2193,12 +2255,12 @@ void fetch_rows(int nsend, const int *send_idx_dev, const std::vector<int> &send
    cm.exchange_dev(sdat.data(), sc2.data(), rdat.data(), rc2.data());
    std::vector<double> hd((size_t)std::max(2 * rtot, 1));
    rdat.download(hd.data(), hd.size());
-   gc.resize((size_t)rtot);
-   gv.resize((size_t)rtot);
+   out.gcol.resize((size_t)rtot);
+   out.val.resize((size_t)rtot);
    for (int k = 0; k < rtot; k++)
    {
-      gc[(size_t)k] = (long long)hd[2 * (size_t)k];
-      gv[(size_t)k] = hd[2 * (size_t)k + 1];
+      out.gcol[(size_t)k] = (long long)hd[2 * (size_t)k];
+      out.val[(size_t)k]  = hd[2 * (size_t)k + 1];
    }
 }
 
@@ -2208,10 +2270,20 @@ __global__ __launch_bounds__(256) void k_loc2gcol(long nnz, const int *__restric
    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256)
       out[k] = (cj[k] < ncl) ? lo + cj[k] : ghosts[cj[k] - ncl];
 }
+__global__ __launch_bounds__(256) void k_row_len(int n, const int *__restrict__ rp, int *__restrict__ len)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) len[i] = rp[i + 1] - rp[i];
+}
+__global__ __launch_bounds__(256) void k_add_len(int n, const int *__restrict__ row, const int *__restrict__ hrp, int *len)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) atomicAdd(&len[row[q]], hrp[q + 1] - hrp[q]);
+}
 __global__ __launch_bounds__(256) void k_copy_rows_mapped(int nrows, const int *__restrict__ srp, const int *__restrict__ scj,
                                                           const double *__restrict__ sv, const int *__restrict__ colmap,
                                                           const int *__restrict__ drp, int *__restrict__ dcj, double *__restrict__ dv)
-{ // row i of the source goes to destination row pointer drp[i] (drp already offset by the caller)
+{ // source row i -> destination offset drp[i] (the caller passes rowptr + base)
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= nrows) return;
    const int s = srp[i], e = srp[i + 1], d = drp[i];
@@ -2221,50 +2293,67 @@ __global__ __launch_bounds__(256) void k_copy_rows_mapped(int nrows, const int *
       dv[d + (k - s)]  = sv[k];
    }
 }
-__global__ __launch_bounds__(256) void k_scatter_entries(int n, const int *__restrict__ pos, const int *__restrict__ c,
-                                                         const double *__restrict__ v, int *__restrict__ dcj, double *__restrict__ dv)
-{
+__global__ __launch_bounds__(256) void k_place_rows(int n, const int *__restrict__ row, const int *__restrict__ hrp, const int *__restrict__ hc,
+                                                    const double *__restrict__ hv, int base, int nsrc, const int *__restrict__ srp,
+                                                    const int *__restrict__ drp, int *__restrict__ dcj, double *__restrict__ dv)
+{ // listed row q lands after the device-side entries (if any) of its destination row
    const int q = blockIdx.x * 256 + threadIdx.x;
-   if (q < n) { dcj[pos[q]] = c[q]; dv[pos[q]] = v[q]; }
+   if (q >= n) return;
+   const int r = row[q];
+   int       d = drp[r];
+   if (r >= base && r < base + nsrc) d += srp[r - base + 1] - srp[r - base];
+   for (int k = hrp[q]; k < hrp[q + 1]; k++, d++)
+   {
+      dcj[d] = hc[k];
+      dv[d]  = hv[k];
+   }
 }
 
-// CSR from (a) a device CSR whose rows go to destination rows base..base+nsrc with mapped
-// columns and (b) host rows (dst row, col, val); every destination row is filled by one source
-void assemble_csr(int nrows, int ncols, int base, const DCsr &src, const int *colmap_dev, const std::vector<int> &hrow,
-                  const std::vector<int> &hrp, const std::vector<int> &hcol, const std::vector<double> &hval, DCsr &out)
+// CSR from (a) a device CSR whose rows land on rows base.. with mapped columns and (b) listed
+// host rows (distinct destination rows; a destination may also receive device entries when
+// the two column sets are disjoint).  Rows come out column-sorted.
+void assemble_csr(int nrows, int ncols, int base, const DCsr &src, const int *colmap_dev, const HostRows &H, DCsr &out)
 {
-   std::vector<int> srp = src.rowptr.to_host();
-   std::vector<int> rp((size_t)nrows + 1, 0);
-   for (int i = 0; i < src.nrows; i++) rp[(size_t)(base + i) + 1] = srp[(size_t)i + 1] - srp[(size_t)i];
-   for (size_t q = 0; q < hrow.size(); q++) rp[(size_t)hrow[q] + 1] += hrp[q + 1] - hrp[q];
-   for (int i = 0; i < nrows; i++) rp[(size_t)i + 1] += rp[(size_t)i];
+   const int   nh = (int)H.row.size();
+   DArray<int> len((size_t)nrows + 1), drow, drp, dc;
+   DArray<double> dv;
+   len.zero();
+   if (src.nrows) k_row_len<<<ceil_div(src.nrows, 256), 256, 0, STREAM>>>(src.nrows, src.rowptr.data(), len.data() + base);
+   if (nh)
+   {
+      drow.upload(H.row.data(), (size_t)nh);
+      drp.upload(H.rp.data(), (size_t)nh + 1);
+      k_add_len<<<ceil_div(nh, 256), 256, 0, STREAM>>>(nh, drow.data(), drp.data(), len.data());
+   }
    out.nrows = nrows;
    out.ncols = ncols;
-   out.nnz   = rp[(size_t)nrows];
-   out.rowptr.upload(rp.data(), rp.size());
+   out.rowptr.alloc((size_t)nrows + 1);
+   exclusive_scan(nrows, len.data(), out.rowptr.data(), nullptr);
+   HDA_HIP(hipMemcpyAsync(&out.nnz, out.rowptr.data() + nrows, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
    out.col.alloc((size_t)std::max(out.nnz, 1));
    out.val.alloc((size_t)std::max(out.nnz, 1));
    if (src.nrows)
       k_copy_rows_mapped<<<ceil_div(src.nrows, 256), 256, 0, STREAM>>>(src.nrows, src.rowptr.data(), src.col.data(), src.val.data(), colmap_dev,
                                                                       out.rowptr.data() + base, out.col.data(), out.val.data());
-   // host rows may land on rows that also got device entries (R: transpose part + received part)
-   std::vector<int> fill((size_t)nrows, 0);
-   for (int i = 0; i < src.nrows; i++) fill[(size_t)(base + i)] = srp[(size_t)i + 1] - srp[(size_t)i];
-   std::vector<int> pos(hcol.size());
-   for (size_t q = 0; q < hrow.size(); q++)
-      for (int k = hrp[q]; k < hrp[q + 1]; k++) pos[(size_t)k] = rp[(size_t)hrow[q]] + fill[(size_t)hrow[q]]++;
-   if (!hcol.empty())
+   if (nh && !H.col.empty())
    {
-      DArray<int>    dp, dc;
-      DArray<double> dv;
-      dp.upload(pos.data(), pos.size());
-      dc.upload(hcol.data(), hcol.size());
-      dv.upload(hval.data(), hval.size());
-      k_scatter_entries<<<ceil_div((long long)hcol.size(), 256), 256, 0, STREAM>>>((int)hcol.size(), dp.data(), dc.data(), dv.data(),
-                                                                                 out.col.data(), out.val.data());
+      dc.upload(H.col.data(), H.col.size());
+      dv.upload(H.val.data(), H.val.size());
+      k_place_rows<<<ceil_div(nh, 256), 256, 0, STREAM>>>(nh, drow.data(), drp.data(), dc.data(), dv.data(), base, src.nrows, src.rowptr.data(),
+                                                         out.rowptr.data(), out.col.data(), out.val.data());
    }
+   out.chunk_row.release();
+   out.nchunks = 0;
+   out.maxrow  = -1;
    sort_rows(out);
    Context::get().sync();
+}
+
+__global__ __launch_bounds__(256) void k_shift(int n, const int *__restrict__ in, int by, int *__restrict__ out)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) out[i] = in[i] - by;
 }
 
 void slice_rows(const DCsr &M, int r0, int r1, DCsr &out)
@@ -2276,10 +2365,8 @@ void slice_rows(const DCsr &M, int r0, int r1, DCsr &out)
    out.nrows = r1 - r0;
    out.ncols = M.ncols;
    out.nnz   = k1 - k0;
-   std::vector<int> rp((size_t)out.nrows + 1);
-   HDA_HIP(hipMemcpy(rp.data(), M.rowptr.data() + r0, sizeof(int) * rp.size(), hipMemcpyDeviceToHost));
-   for (auto &x : rp) x -= k0;
-   out.rowptr.upload(rp.data(), rp.size());
+   out.rowptr.alloc((size_t)out.nrows + 1);
+   k_shift<<<ceil_div(out.nrows + 1, 256), 256, 0, STREAM>>>(out.nrows + 1, M.rowptr.data() + r0, k0, out.rowptr.data());
    out.col.alloc((size_t)std::max(out.nnz, 1));
    out.val.alloc((size_t)std::max(out.nnz, 1));
    if (out.nnz)
@@ -2289,15 +2376,33 @@ void slice_rows(const DCsr &M, int r0, int r1, DCsr &out)
    }
 }
 
+// a (small) slice of rows as host rows
+void rows_to_host(const DCsr &M, int r0, int r1, std::vector<int> &rp, std::vector<int> &cj, std::vector<double> &v)
+{
+   rp.assign((size_t)(r1 - r0) + 1, 0);
+   if (r1 <= r0) { cj.clear(); v.clear(); return; }
+   HDA_HIP(hipMemcpyAsync(rp.data(), M.rowptr.data() + r0, 4 * rp.size(), hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   const int k0 = rp.front(), k1 = rp.back();
+   cj.resize((size_t)(k1 - k0));
+   v.resize((size_t)(k1 - k0));
+   if (k1 > k0)
+   {
+      HDA_HIP(hipMemcpyAsync(cj.data(), M.col.data() + k0, 4 * cj.size(), hipMemcpyDeviceToHost, STREAM));
+      HDA_HIP(hipMemcpyAsync(v.data(), M.val.data() + k0, 8 * v.size(), hipMemcpyDeviceToHost, STREAM));
+      Context::get().sync();
+   }
+   for (auto &x : rp) x -= k0;
+}
+
 // build the extended view of one level
 void build_ext_level(const DCsr &Aloc, const std::vector<long long> &ghosts, const std::vector<long long> &part, const HaloPlan &hA,
                      ExtLevel &X)
 {
-   Comm &cm = Comm::world();
-   X.lo     = part[(size_t)cm.rank];
-   X.hi     = part[(size_t)cm.rank + 1];
-   X.nloc   = (int)(X.hi - X.lo);
-   HDA_REQUIRE(Aloc.nrows == X.nloc, "ext level: block size mismatch");
+   Comm           &cm = Comm::world();
+   const long long lo = part[(size_t)cm.rank], hi = part[(size_t)cm.rank + 1];
+   X.nloc             = (int)(hi - lo);
+   HDA_REQUIRE(Aloc.nrows == X.nloc && Aloc.ncols == X.nloc + (int)ghosts.size(), "ext level: block shape mismatch");
    DArray<long long> dgh, gcol((size_t)std::max(Aloc.nnz, 1));
    {
       std::vector<long long> g = ghosts;
@@ -2305,36 +2410,34 @@ void build_ext_level(const DCsr &Aloc, const std::vector<long long> &ghosts, con
       dgh.upload(g.data(), g.size());
    }
    if (Aloc.nnz)
-      k_loc2gcol<<<std::min(ceil_div(Aloc.nnz, 256), 1 << 16), 256, 0, STREAM>>>(Aloc.nnz, Aloc.col.data(), X.nloc, X.lo, dgh.data(), gcol.data());
-   std::vector<int>       grp;
-   std::vector<long long> gc;
-   std::vector<double>    gv;
+      k_loc2gcol<<<std::min(ceil_div(Aloc.nnz, 256), 1 << 16), 256, 0, STREAM>>>(Aloc.nnz, Aloc.col.data(), X.nloc, lo, dgh.data(), gcol.data());
+   HostRows H;
    fetch_rows(hA.send_total, hA.send_idx.data(), hA.send_counts, (int)ghosts.size(), hA.recv_counts, Aloc.rowptr.data(), gcol.data(),
-              Aloc.val.data(), grp, gc, gv);
+              Aloc.val.data(), H);
    // node list: ghosts, then columns of ghost rows that are neither owned nor ghosts
    std::vector<long long> other = ghosts;
-   for (long long c : gc)
-      if (c < X.lo || c >= X.hi) other.push_back(c);
-   std::sort(other.begin(), other.end());
-   other.erase(std::unique(other.begin(), other.end()), other.end());
-   X.off = (int)(std::lower_bound(other.begin(), other.end(), X.lo) - other.begin());
-   X.gid.clear();
-   X.gid.insert(X.gid.end(), other.begin(), other.begin() + X.off);
-   for (long long g = X.lo; g < X.hi; g++) X.gid.push_back(g);
-   X.gid.insert(X.gid.end(), other.begin() + X.off, other.end());
-   X.next = (int)X.gid.size();
-   X.gid_dev.upload(X.gid.data(), X.gid.size());
-   // local solve-layout column -> extended id
-   std::vector<int> cmap((size_t)std::max(Aloc.ncols, 1));
-   for (int c = 0; c < X.nloc; c++) cmap[(size_t)c] = X.off + c;
-   for (size_t g = 0; g < ghosts.size(); g++) cmap[(size_t)X.nloc + g] = (int)X.ext_of(ghosts[g]);
-   DArray<int> dcmap;
-   dcmap.upload(cmap.data(), cmap.size());
-   std::vector<int>    hrow(ghosts.size()), hcol(gc.size());
-   for (size_t g = 0; g < ghosts.size(); g++) hrow[g] = (int)X.ext_of(ghosts[g]);
-   for (size_t k = 0; k < gc.size(); k++) hcol[k] = (int)X.ext_of(gc[k]);
-   assemble_csr(X.next, X.next, X.off, Aloc, dcmap.data(), hrow, grp, hcol, gv, X.E);
-   build_ext_plan(X.plan, X.gid, X.off, X.nloc, X.lo, part);
+   for (long long c : H.gcol)
+      if (c < lo || c >= hi) other.push_back(c);
+   X.S.set(lo, hi, other);
+   X.off  = X.S.off();
+   X.next = X.S.size();
+   space_gids_to_device(X.S, X.gid_dev);
+   // solve-layout column -> extended id
+   DArray<int> cmap((size_t)std::max(Aloc.ncols, 1));
+   if (X.nloc) k_iota_i<<<ceil_div(X.nloc, 256), 256, 0, STREAM>>>(X.nloc, X.off, cmap.data());
+   if (!ghosts.empty())
+   {
+      std::vector<int> gm(ghosts.size());
+      for (size_t g = 0; g < ghosts.size(); g++) gm[g] = X.S.of(ghosts[g]);
+      HDA_HIP(hipMemcpyAsync(cmap.data() + X.nloc, gm.data(), 4 * gm.size(), hipMemcpyHostToDevice, STREAM));
+      Context::get().sync();
+   }
+   H.row.resize(ghosts.size());
+   H.col.resize(H.gcol.size());
+   for (size_t g = 0; g < ghosts.size(); g++) H.row[g] = X.S.of(ghosts[g]);
+   for (size_t k = 0; k < H.gcol.size(); k++) H.col[k] = X.S.of(H.gcol[k]);
+   assemble_csr(X.next, X.next, X.off, Aloc, cmap.data(), H, X.E);
+   build_ext_plan(X.plan, X.S, part);
 }
 
 // PMIS on the owned rows of E with ghost values exchanged every round
@@ -2415,54 +2518,175 @@ __global__ __launch_bounds__(256) void k_cols_to_gid(long nnz, const int *__rest
 {
    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256) out[k] = gid[in[k]];
 }
-
-// solve-layout block out of a matrix whose columns are compact ids with known global ids (host,
-// ascending): owned global columns [clo, chi) -> [0, ncl), the others -> ncl + rank among the
-// referenced ones (ghost list returned)
-void localize_cols(const DCsr &M, const std::vector<long long> &colgid, long long clo, long long chi, DCsr &L,
-                   std::vector<long long> &ghosts)
+__global__ __launch_bounds__(256) void k_flag_cols(long nnz, const int *__restrict__ cj, int *flags)
 {
-   const int   nc = (int)colgid.size();
-   const int   qlo = (int)(std::lower_bound(colgid.begin(), colgid.end(), clo) - colgid.begin());
-   const int   qhi = (int)(std::lower_bound(colgid.begin(), colgid.end(), chi) - colgid.begin());
-   const int   ncl = (int)(chi - clo);
-   // which non-owned columns are referenced
-   std::vector<int> used((size_t)std::max(nc, 1), 0);
-   {
-      DArray<int> flags((size_t)std::max(nc, 1));
-      flags.zero();
-      struct K {
-      };
-      std::vector<int> hc((size_t)std::max(M.nnz, 1));
-      if (M.nnz) M.col.download(hc.data(), (size_t)M.nnz);
-      for (int k = 0; k < M.nnz; k++) used[(size_t)hc[(size_t)k]] = 1;
-   }
-   std::vector<int> map((size_t)std::max(nc, 1), 0);
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256) flags[cj[k]] = 1;
+}
+
+// solve-layout block of a matrix whose columns live in the id space C: owned columns ->
+// [0, nown), the foreign columns that are referenced -> nown + rank in ascending id (list returned)
+void localize_cols(const DCsr &M, const IdSpace &C, DCsr &L, std::vector<long long> &ghosts)
+{
+   const int   nc = C.size(), no = C.nother();
+   DArray<int> flags((size_t)std::max(nc, 1)), map((size_t)std::max(nc, 1));
+   flags.zero();
+   if (M.nnz) k_flag_cols<<<std::min(ceil_div(M.nnz, 256), 1 << 16), 256, 0, STREAM>>>(M.nnz, M.col.data(), flags.data());
+   std::vector<int> fb(C.below.size()), fa(C.above.size());
+   if (!fb.empty()) HDA_HIP(hipMemcpyAsync(fb.data(), flags.data(), 4 * fb.size(), hipMemcpyDeviceToHost, STREAM));
+   if (!fa.empty()) HDA_HIP(hipMemcpyAsync(fa.data(), flags.data() + C.off() + C.nown(), 4 * fa.size(), hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
    ghosts.clear();
-   for (int q = 0; q < nc; q++)
+   for (int q = 0; q < no; q++)
    {
-      if (q >= qlo && q < qhi)
-      {
-         HDA_REQUIRE(colgid[(size_t)q] - clo == q - qlo, "owned coarse ids must be contiguous in the compact space");
-         map[(size_t)q] = (int)(colgid[(size_t)q] - clo);
-      }
-      else if (used[(size_t)q])
-      {
-         map[(size_t)q] = ncl + (int)ghosts.size();
-         ghosts.push_back(colgid[(size_t)q]);
-      }
+      int &f = q < C.off() ? fb[(size_t)q] : fa[(size_t)(q - C.off())];
+      if (f) { f = C.nown() + (int)ghosts.size(); ghosts.push_back(C.other(q)); }
    }
-   DArray<int> dmap;
-   dmap.upload(map.data(), map.size());
+   if (!fb.empty()) HDA_HIP(hipMemcpyAsync(map.data(), fb.data(), 4 * fb.size(), hipMemcpyHostToDevice, STREAM));
+   if (C.nown()) k_iota_i<<<ceil_div(C.nown(), 256), 256, 0, STREAM>>>(C.nown(), 0, map.data() + C.off());
+   if (!fa.empty()) HDA_HIP(hipMemcpyAsync(map.data() + C.off() + C.nown(), fa.data(), 4 * fa.size(), hipMemcpyHostToDevice, STREAM));
    L.nrows = M.nrows;
-   L.ncols = ncl + (int)ghosts.size();
+   L.ncols = C.nown() + (int)ghosts.size();
    L.nnz   = M.nnz;
    L.rowptr.copy_from(M.rowptr);
    L.col.alloc((size_t)std::max(M.nnz, 1));
    L.val.copy_from(M.val);
-   if (M.nnz) k_map_cols<<<std::min(ceil_div(M.nnz, 256), 1 << 16), 256, 0, STREAM>>>(M.nnz, M.col.data(), dmap.data(), L.col.data());
+   if (M.nnz) k_map_cols<<<std::min(ceil_div(M.nnz, 256), 1 << 16), 256, 0, STREAM>>>(M.nnz, M.col.data(), map.data(), L.col.data());
+   L.chunk_row.release();
+   L.nchunks = 0;
+   L.maxrow  = -1;
    sort_rows(L);
    Context::get().sync();
+}
+
+// entries of M whose column is outside [q0, q1): (row, col, val) triplets on the host
+__global__ __launch_bounds__(256) void k_count_outside(int n, const int *__restrict__ rp, const int *__restrict__ cj, int q0, int q1, int *__restrict__ cnt)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int c = 0;
+   for (int k = rp[i]; k < rp[i + 1]; k++) c += (cj[k] < q0 || cj[k] >= q1);
+   cnt[i] = c;
+}
+__global__ __launch_bounds__(256) void k_write_outside(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                       int q0, int q1, const int *__restrict__ pos, int *__restrict__ oi, int *__restrict__ oc,
+                                                       double *__restrict__ ov)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int d = pos[i];
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (cj[k] < q0 || cj[k] >= q1)
+      {
+         oi[d] = i;
+         oc[d] = cj[k];
+         ov[d] = v[k];
+         d++;
+      }
+}
+void entries_outside(const DCsr &M, int q0, int q1, std::vector<int> &oi, std::vector<int> &oc, std::vector<double> &ov)
+{
+   const int   n = M.nrows;
+   DArray<int> cnt((size_t)n + 1), pos((size_t)n + 1);
+   cnt.zero();
+   if (n) k_count_outside<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, M.rowptr.data(), M.col.data(), q0, q1, cnt.data());
+   exclusive_scan(n, cnt.data(), pos.data(), nullptr);
+   int tot = 0;
+   HDA_HIP(hipMemcpyAsync(&tot, pos.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   oi.resize((size_t)tot);
+   oc.resize((size_t)tot);
+   ov.resize((size_t)tot);
+   if (!tot) return;
+   DArray<int>    di((size_t)tot), dc((size_t)tot);
+   DArray<double> dv((size_t)tot);
+   k_write_outside<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, M.rowptr.data(), M.col.data(), M.val.data(), q0, q1, pos.data(), di.data(), dc.data(), dv.data());
+   di.download(oi.data(), (size_t)tot);
+   dc.download(oc.data(), (size_t)tot);
+   dv.download(ov.data(), (size_t)tot);
+}
+
+// C = A + B for column-sorted rows, B given as a (mostly empty) device CSR over the same rows;
+// a row's sum is formed in ascending column order, A's entry before B's
+__global__ __launch_bounds__(256) void k_merge_count(int n, const int *__restrict__ arp, const int *__restrict__ acj, const int *__restrict__ brp,
+                                                     const int *__restrict__ bcj, int *__restrict__ cnt)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int a = arp[i], ae = arp[i + 1], b = brp[i], be = brp[i + 1], c = 0;
+   if (b == be) { cnt[i] = ae - a; return; }
+   while (a < ae && b < be)
+   {
+      const int ja = acj[a], jb = bcj[b];
+      a += (ja <= jb);
+      b += (jb <= ja);
+      c++;
+   }
+   cnt[i] = c + (ae - a) + (be - b);
+}
+__global__ __launch_bounds__(256) void k_merge_write(int n, const int *__restrict__ arp, const int *__restrict__ acj, const double *__restrict__ av,
+                                                     const int *__restrict__ brp, const int *__restrict__ bcj, const double *__restrict__ bv,
+                                                     const int *__restrict__ crp, int *__restrict__ ccj, double *__restrict__ cv)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int a = arp[i], ae = arp[i + 1], b = brp[i], be = brp[i + 1], d = crp[i];
+   while (a < ae || b < be)
+   {
+      const int ja = (a < ae) ? acj[a] : 0x7fffffff, jb = (b < be) ? bcj[b] : 0x7fffffff;
+      if (ja < jb) { ccj[d] = ja; cv[d] = av[a++]; }
+      else if (jb < ja) { ccj[d] = jb; cv[d] = bv[b++]; }
+      else { ccj[d] = ja; cv[d] = av[a++] + bv[b++]; }
+      d++;
+   }
+}
+void add_rows(const DCsr &A, const DCsr &B, DCsr &C)
+{
+   HDA_REQUIRE(A.nrows == B.nrows && A.ncols == B.ncols, "add_rows: shapes differ");
+   const int   n = A.nrows;
+   DArray<int> cnt((size_t)n + 1);
+   cnt.zero();
+   C.nrows = n;
+   C.ncols = A.ncols;
+   C.rowptr.alloc((size_t)n + 1);
+   if (n) k_merge_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), B.rowptr.data(), B.col.data(), cnt.data());
+   exclusive_scan(n, cnt.data(), C.rowptr.data(), nullptr);
+   HDA_HIP(hipMemcpyAsync(&C.nnz, C.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   C.col.alloc((size_t)std::max(C.nnz, 1));
+   C.val.alloc((size_t)std::max(C.nnz, 1));
+   if (n)
+      k_merge_write<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), B.rowptr.data(), B.col.data(), B.val.data(),
+                                                         C.rowptr.data(), C.col.data(), C.val.data());
+}
+
+// (destination id, second id, value) records to the owners of the destination ids
+struct Rec {
+   long long a, b;
+   double    w;
+};
+void route_records(std::vector<std::vector<Rec>> &out, std::vector<Rec> &in)
+{
+   Comm                  &cm = Comm::world();
+   std::vector<long>      eight((size_t)cm.size, 8), sb((size_t)cm.size), rb((size_t)cm.size);
+   std::vector<long long> sc((size_t)cm.size), rc((size_t)cm.size);
+   std::vector<Rec>       flat;
+   for (int p = 0; p < cm.size; p++)
+   {
+      sc[(size_t)p] = (long long)out[(size_t)p].size();
+      flat.insert(flat.end(), out[(size_t)p].begin(), out[(size_t)p].end());
+   }
+   cm.alltoallv_host(sc.data(), eight.data(), rc.data(), eight.data());
+   long tot = 0;
+   for (int p = 0; p < cm.size; p++)
+   {
+      sb[(size_t)p] = (long)(sc[(size_t)p] * (long long)sizeof(Rec));
+      rb[(size_t)p] = (long)(rc[(size_t)p] * (long long)sizeof(Rec));
+      tot += (long)rc[(size_t)p];
+   }
+   in.resize((size_t)std::max<long>(tot, 1));
+   if (flat.empty()) flat.resize(1);
+   cm.alltoallv_host(flat.data(), sb.data(), in.data(), rb.data());
+   in.resize((size_t)tot);
 }
 
 } // namespace
@@ -2473,6 +2697,14 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
    Comm &cm = Comm::world();
    HDA_REQUIRE(prm.coarsen_type == 8 && prm.interp_type == 6, "partitioned setup: PMIS + extended+i only");
    static const long long rep_rows = getenv("HDA_REPLICATE_ROWS") ? atoll(getenv("HDA_REPLICATE_ROWS")) : 100000;
+   const bool verbose = getenv("HDA_VERBOSE") != nullptr;
+   auto tick = [&]() {
+      if (verbose) Context::get().sync();
+      return std::chrono::steady_clock::now();
+   };
+   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+   };
    dist = true;
    A0   = &Aloc;
    hA0  = &hA0_;
@@ -2486,8 +2718,8 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
    int l = 0;
    for (;; l++)
    {
-      const DCsr     &Al   = level_A(l);
-      const HaloPlan &hl   = level_hA(l);
+      const DCsr     &Al    = level_A(l);
+      const HaloPlan &hl    = level_hA(l);
       const long long nglob = part.back();
       {
          long long t[1] = {Al.nnz};
@@ -2496,15 +2728,18 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
       }
       const bool stop = (nglob <= prm.max_coarse_size) || (l >= maxl - 1) || (l >= 1 && nglob <= rep_rows);
       if (stop) break;
-      HDA_TRACE("partitioned setup level %d: %lld rows, %d local", l, nglob, Al.nrows);
+      auto t0 = tick();
       ExtLevel X;
       build_ext_level(Al, ghosts, part, hl, X);
-      const int n = X.next;
+      const int       n = X.next;
+      const long long lo = X.S.lo;
+      auto t1 = tick();
       DArray<unsigned char> sm((size_t)std::max(X.E.nnz, 1));
       DArray<int>           ns((size_t)n + 1), cf((size_t)n + 1);
       strength_ns(X.E, prm.strong_th, prm.max_row_sum, sm.data(), ns.data());
       pmis_dist(X, sm.data(), ns.data(), prm.seed, l + level0, cf.data());
-      // global coarse numbering
+      auto t2 = tick();
+      // global coarse numbering: rank blocks in rank order, C points in row order
       DArray<int> cm_own((size_t)X.nloc + 1), cidx((size_t)X.nloc + 1);
       k_cmark_ext<<<ceil_div(std::max(X.nloc, 1), 256), 256, 0, STREAM>>>(X.nloc, cf.data() + X.off, cm_own.data());
       exclusive_scan(X.nloc, cm_own.data(), cidx.data(), nullptr);
@@ -2520,186 +2755,183 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
       fill(n, -1.0, cg.data());
       if (X.nloc) k_cg_owned<<<ceil_div(X.nloc, 256), 256, 0, STREAM>>>(X.nloc, X.off, cf.data(), cidx.data(), clo, cg.data());
       ext_exchange(X.plan, cg.data());
-      // interpolation on E (rows of ghost nodes are by-products and ignored)
+      // interpolation on E (the rows of ghost nodes are by-products and dropped)
       DCsr PE;
       amg_interp_extpi(X.E, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, PE);
+      sm.release();
+      auto t3 = tick();
+      // coarse id space seen from here: compact column q of PE <-> global coarse id
       DArray<int> cmE((size_t)n + 1), cidxE((size_t)n + 1);
       k_cmark_ext<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, cf.data(), cmE.data());
       exclusive_scan(n, cmE.data(), cidxE.data(), nullptr);
-      const int         nce = PE.ncols;
+      int q3[3] = {0, 0, 0};
+      HDA_HIP(hipMemcpyAsync(&q3[0], cidxE.data() + X.off, 4, hipMemcpyDeviceToHost, STREAM));
+      HDA_HIP(hipMemcpyAsync(&q3[1], cidxE.data() + X.off + X.nloc, 4, hipMemcpyDeviceToHost, STREAM));
+      HDA_HIP(hipMemcpyAsync(&q3[2], cidxE.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+      Context::get().sync();
+      const int qlo = q3[0], qhi = q3[1], nce = q3[2];
+      HDA_REQUIRE(nce == PE.ncols && qhi - qlo == ncl, "partitioned setup: coarse numbering of the extended block is inconsistent");
       DArray<long long> cgc((size_t)std::max(nce, 1));
       k_cgc<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, cf.data(), cidxE.data(), cg.data(), cgc.data());
-      std::vector<long long> cgc_h((size_t)nce);
-      if (nce) cgc.download(cgc_h.data(), (size_t)nce);
+      IdSpace C1;
+      {
+         std::vector<long long> oth((size_t)(nce - ncl));
+         if (qlo) HDA_HIP(hipMemcpyAsync(oth.data(), cgc.data(), 8 * (size_t)qlo, hipMemcpyDeviceToHost, STREAM));
+         if (nce > qhi) HDA_HIP(hipMemcpyAsync(oth.data() + qlo, cgc.data() + qhi, 8 * (size_t)(nce - qhi), hipMemcpyDeviceToHost, STREAM));
+         Context::get().sync();
+         C1.set(clo, chi, oth);
+         HDA_REQUIRE(C1.off() == qlo && C1.size() == nce, "partitioned setup: coarse ids of ghost C points are not monotone");
+      }
       DCsr Pown;
       slice_rows(PE, X.off, X.off + X.nloc, Pown);
+      PE = DCsr();
       // ---- P in solve layout + halo plan for coarse vectors
       AmgLevel              &lv = levels[(size_t)l];
       std::vector<long long> ghostc;
-      localize_cols(Pown, cgc_h, clo, chi, lv.P, ghostc);
-      lv.hP = make_halo_plan((int)(chi - clo), partc, ghostc);
-      // ---- R = P^T rows of owned coarse points: local transpose + entries of remote fine rows
-      std::vector<int>    prp = Pown.rowptr.to_host(), pcj((size_t)std::max(Pown.nnz, 1));
-      std::vector<double> pv((size_t)std::max(Pown.nnz, 1));
-      if (Pown.nnz) { Pown.col.download(pcj.data(), (size_t)Pown.nnz); Pown.val.download(pv.data(), (size_t)Pown.nnz); }
-      struct Trip { long long c, i; double w; };
-      std::vector<std::vector<Trip>> out((size_t)cm.size);
-      for (int i = 0; i < X.nloc; i++)
-         for (int k = prp[(size_t)i]; k < prp[(size_t)i + 1]; k++)
-         {
-            const long long g = cgc_h[(size_t)pcj[(size_t)k]];
-            if (g < clo || g >= chi) out[(size_t)owner_of(g, partc)].push_back({g, X.lo + i, pv[(size_t)k]});
-         }
-      std::vector<Trip> recv_t;
+      localize_cols(Pown, C1, lv.P, ghostc);
+      lv.hP = make_halo_plan(ncl, partc, ghostc);
+      // ---- R: rows of P^T for the owned coarse points = local transpose + entries of fine rows owned elsewhere
+      std::vector<Rec> recv_t;
       {
-         std::vector<long>      eight((size_t)cm.size, 8), sb((size_t)cm.size), rb((size_t)cm.size);
-         std::vector<long long> sc((size_t)cm.size), rc((size_t)cm.size);
-         std::vector<Trip>      flat;
-         for (int p = 0; p < cm.size; p++) { sc[(size_t)p] = (long long)out[(size_t)p].size(); flat.insert(flat.end(), out[(size_t)p].begin(), out[(size_t)p].end()); }
-         cm.alltoallv_host(sc.data(), eight.data(), rc.data(), eight.data());
-         long tot = 0;
-         for (int p = 0; p < cm.size; p++) { sb[(size_t)p] = (long)(sc[(size_t)p] * sizeof(Trip)); rb[(size_t)p] = (long)(rc[(size_t)p] * sizeof(Trip)); tot += (long)rc[(size_t)p]; }
-         recv_t.resize((size_t)std::max<long>(tot, 1));
-         if (flat.empty()) flat.resize(1);
-         cm.alltoallv_host(flat.data(), sb.data(), recv_t.data(), rb.data());
-         recv_t.resize((size_t)tot);
+         std::vector<int>    oi, oc;
+         std::vector<double> ov;
+         entries_outside(Pown, qlo, qhi, oi, oc, ov);
+         std::vector<std::vector<Rec>> out((size_t)cm.size);
+         for (size_t k = 0; k < oi.size(); k++)
+         {
+            const long long g = C1.other(oc[k] < qlo ? oc[k] : oc[k] - ncl);
+            out[(size_t)owner_of(g, partc)].push_back({g, lo + oi[k], ov[k]});
+         }
+         route_records(out, recv_t);
       }
       {
          DCsr PT, Rown;
          transpose(lv.P, PT);
-         slice_rows(PT, 0, (int)(chi - clo), Rown);
-         std::sort(recv_t.begin(), recv_t.end(), [](const Trip &a, const Trip &b) { return a.c != b.c ? a.c < b.c : a.i < b.i; });
+         slice_rows(PT, 0, ncl, Rown);
+         std::sort(recv_t.begin(), recv_t.end(), [](const Rec &x, const Rec &y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
          std::vector<long long> gf;
-         for (auto &t : recv_t) gf.push_back(t.i);
+         for (auto &t : recv_t) gf.push_back(t.b);
          std::sort(gf.begin(), gf.end());
          gf.erase(std::unique(gf.begin(), gf.end()), gf.end());
-         std::vector<int>    hrow, hrp(1, 0), hcol;
-         std::vector<double> hval;
+         HostRows H;
          for (size_t q = 0; q < recv_t.size(); q++)
          {
-            const int row = (int)(recv_t[q].c - clo);
-            if (hrow.empty() || hrow.back() != row) { hrow.push_back(row); hrp.push_back(hrp.back()); }
-            hrp.back()++;
-            hcol.push_back(X.nloc + (int)(std::lower_bound(gf.begin(), gf.end(), recv_t[q].i) - gf.begin()));
-            hval.push_back(recv_t[q].w);
+            const int row = (int)(recv_t[q].a - clo);
+            if (H.row.empty() || H.row.back() != row) { H.row.push_back(row); H.rp.push_back(H.rp.back()); }
+            H.rp.back()++;
+            H.col.push_back(X.nloc + (int)(std::lower_bound(gf.begin(), gf.end(), recv_t[q].b) - gf.begin()));
+            H.val.push_back(recv_t[q].w);
          }
-         assemble_csr((int)(chi - clo), X.nloc + (int)gf.size(), 0, Rown, nullptr, hrow, hrp, hcol, hval, lv.R);
+         assemble_csr(ncl, X.nloc + (int)gf.size(), 0, Rown, nullptr, H, lv.R);
          lv.hR = make_halo_plan(X.nloc, part, gf);
          tail_len[(size_t)l] = std::max(tail_len[(size_t)l], gf.size());
       }
+      auto t4 = tick();
       // ---- Galerkin product
-      DCsr Ac_loc;
+      DCsr                   Ac_loc;
       std::vector<long long> ghosts_next;
       {
-         // P rows of my ghost nodes (global coarse columns)
+         // P rows of my ghost nodes, with global coarse columns
          DArray<long long> gcolP((size_t)std::max(Pown.nnz, 1));
          if (Pown.nnz) k_cols_to_gid<<<std::min(ceil_div(Pown.nnz, 256), 1 << 16), 256, 0, STREAM>>>(Pown.nnz, Pown.col.data(), cgc.data(), gcolP.data());
-         std::vector<int>       grp;
-         std::vector<long long> gc;
-         std::vector<double>    gv;
+         HostRows H;
          fetch_rows(hl.send_total, hl.send_idx.data(), hl.send_counts, (int)ghosts.size(), hl.recv_counts, Pown.rowptr.data(), gcolP.data(),
-                    Pown.val.data(), grp, gc, gv);
-         // coarse extended space CX = ids seen in E  U  ids in the fetched rows
-         std::vector<long long> CX = cgc_h, extra = gc;
-         std::sort(extra.begin(), extra.end());
-         extra.erase(std::unique(extra.begin(), extra.end()), extra.end());
+                    Pown.val.data(), H);
+         gcolP.release();
+         // coarse space C2 = C1 U columns of the fetched rows
+         IdSpace C2;
          {
-            std::vector<long long> u;
-            std::set_union(CX.begin(), CX.end(), extra.begin(), extra.end(), std::back_inserter(u));
-            CX.swap(u);
+            std::vector<long long> oth;
+            oth.insert(oth.end(), C1.below.begin(), C1.below.end());
+            oth.insert(oth.end(), C1.above.begin(), C1.above.end());
+            for (long long c : H.gcol)
+               if (c < clo || c >= chi) oth.push_back(c);
+            C2.set(clo, chi, oth);
          }
-         auto cx_of = [&](long long g) { return (int)(std::lower_bound(CX.begin(), CX.end(), g) - CX.begin()); };
-         std::vector<int> mapq((size_t)std::max(nce, 1));
-         for (int q = 0; q < nce; q++) mapq[(size_t)q] = cx_of(cgc_h[(size_t)q]);
-         DArray<int> dmapq;
-         dmapq.upload(mapq.data(), mapq.size());
-         // Pe: rows of every extended node (owned: computed here; layer-1 ghosts: fetched; others empty)
-         std::vector<int> hrow(ghosts.size()), hcol(gc.size());
-         for (size_t g = 0; g < ghosts.size(); g++) hrow[g] = (int)X.ext_of(ghosts[g]);
-         for (size_t k = 0; k < gc.size(); k++) hcol[k] = cx_of(gc[k]);
+         DArray<int> map12;
+         space_map(C1, C2, map12);
+         H.row.resize(ghosts.size());
+         H.col.resize(H.gcol.size());
+         for (size_t g = 0; g < ghosts.size(); g++) H.row[g] = X.S.of(ghosts[g]);
+         for (size_t k = 0; k < H.gcol.size(); k++) H.col[k] = C2.of(H.gcol[k]);
+         // Pe: P rows of every extended node (owned: computed here; layer-1 ghosts: fetched; layer 2: not needed)
          DCsr Pe, Eown, AP, PeOwn, PT, T;
-         assemble_csr(n, (int)CX.size(), X.off, Pown, dmapq.data(), hrow, grp, hcol, gv, Pe);
+         assemble_csr(n, C2.size(), X.off, Pown, map12.data(), H, Pe);
          slice_rows(X.E, X.off, X.off + X.nloc, Eown);
+         X.E = DCsr();
          spgemm(Eown, Pe, AP);
+         Eown = DCsr();
          slice_rows(Pe, X.off, X.off + X.nloc, PeOwn);
+         Pe = DCsr();
          transpose(PeOwn, PT);
+         PeOwn = DCsr();
          spgemm(PT, AP, T);
+         PT = DCsr();
+         AP = DCsr();
          // rows of coarse points owned elsewhere go to their owners
-         const int qlo = cx_of(clo), qhi = qlo + (int)(chi - clo);
-         std::vector<int>    trp = T.rowptr.to_host(), tcj((size_t)std::max(T.nnz, 1));
-         std::vector<double> tv((size_t)std::max(T.nnz, 1));
-         if (T.nnz) { T.col.download(tcj.data(), (size_t)T.nnz); T.val.download(tv.data(), (size_t)T.nnz); }
-         struct Ent { long long r, c; double w; };
-         std::vector<std::vector<Ent>> eout((size_t)cm.size);
-         for (int q = 0; q < (int)CX.size(); q++)
+         const int                     q2lo = C2.off(), q2hi = q2lo + ncl;
+         std::vector<std::vector<Rec>> eout((size_t)cm.size);
+         for (int side = 0; side < 2; side++)
          {
-            if (q >= qlo && q < qhi) continue;
-            if (trp[(size_t)q + 1] == trp[(size_t)q]) continue;
-            const int o = owner_of(CX[(size_t)q], partc);
-            for (int k = trp[(size_t)q]; k < trp[(size_t)q + 1]; k++) eout[(size_t)o].push_back({CX[(size_t)q], CX[(size_t)tcj[(size_t)k]], tv[(size_t)k]});
+            const int           r0 = side ? q2hi : 0, r1 = side ? C2.size() : q2lo;
+            std::vector<int>    trp, tcj;
+            std::vector<double> tv;
+            rows_to_host(T, r0, r1, trp, tcj, tv);
+            for (int q = r0; q < r1; q++)
+            {
+               const long long g = C2.other(q < q2lo ? q : q - ncl);
+               const int       o = owner_of(g, partc);
+               for (int k = trp[(size_t)(q - r0)]; k < trp[(size_t)(q - r0) + 1]; k++)
+               {
+                  const int       c  = tcj[(size_t)k];
+                  const long long gc = (c >= q2lo && c < q2hi) ? clo + (c - q2lo) : C2.other(c < q2lo ? c : c - ncl);
+                  eout[(size_t)o].push_back({g, gc, tv[(size_t)k]});
+               }
+            }
          }
-         std::vector<Ent> erecv;
+         std::vector<Rec> erecv;
+         route_records(eout, erecv);
+         // C3 = C2 U received columns; A_c(owned rows) = T(owned rows) + received rows
+         IdSpace C3;
          {
-            std::vector<long>      eight((size_t)cm.size, 8), sb((size_t)cm.size), rb((size_t)cm.size);
-            std::vector<long long> sc((size_t)cm.size), rc((size_t)cm.size);
-            std::vector<Ent>       flat;
-            for (int p = 0; p < cm.size; p++) { sc[(size_t)p] = (long long)eout[(size_t)p].size(); flat.insert(flat.end(), eout[(size_t)p].begin(), eout[(size_t)p].end()); }
-            cm.alltoallv_host(sc.data(), eight.data(), rc.data(), eight.data());
-            long tot = 0;
-            for (int p = 0; p < cm.size; p++) { sb[(size_t)p] = (long)(sc[(size_t)p] * sizeof(Ent)); rb[(size_t)p] = (long)(rc[(size_t)p] * sizeof(Ent)); tot += (long)rc[(size_t)p]; }
-            erecv.resize((size_t)std::max<long>(tot, 1));
-            if (flat.empty()) flat.resize(1);
-            cm.alltoallv_host(flat.data(), sb.data(), erecv.data(), rb.data());
-            erecv.resize((size_t)tot);
+            std::vector<long long> oth;
+            oth.insert(oth.end(), C2.below.begin(), C2.below.end());
+            oth.insert(oth.end(), C2.above.begin(), C2.above.end());
+            for (auto &e : erecv)
+               if (e.b < clo || e.b >= chi) oth.push_back(e.b);
+            C3.set(clo, chi, oth);
          }
-         // second compact space CX2 = CX U received columns; A_c(owned) = T(owned rows) + received rows
-         std::vector<long long> CX2 = CX, ec;
-         for (auto &e : erecv) ec.push_back(e.c);
-         std::sort(ec.begin(), ec.end());
-         ec.erase(std::unique(ec.begin(), ec.end()), ec.end());
+         DArray<int> map23;
+         space_map(C2, C3, map23);
+         DCsr Town, Town3, B, Ac;
+         slice_rows(T, q2lo, q2hi, Town);
+         T = DCsr();
+         assemble_csr(ncl, C3.size(), 0, Town, map23.data(), HostRows(), Town3);
+         Town = DCsr();
+         // received rows: sorted by (row, column, sender order), duplicates pre-summed in that order
+         std::stable_sort(erecv.begin(), erecv.end(), [](const Rec &x, const Rec &y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+         HostRows HB;
+         for (size_t q = 0; q < erecv.size(); q++)
          {
-            std::vector<long long> u;
-            std::set_union(CX2.begin(), CX2.end(), ec.begin(), ec.end(), std::back_inserter(u));
-            CX2.swap(u);
+            const int row = (int)(erecv[q].a - clo), c = C3.of(erecv[q].b);
+            if (HB.row.empty() || HB.row.back() != row) { HB.row.push_back(row); HB.rp.push_back(HB.rp.back()); }
+            if (HB.rp.back() > HB.rp[HB.rp.size() - 2] && HB.col.back() == c) { HB.val.back() += erecv[q].w; continue; }
+            HB.rp.back()++;
+            HB.col.push_back(c);
+            HB.val.push_back(erecv[q].w);
          }
-         auto cx2_of = [&](long long g) { return (int)(std::lower_bound(CX2.begin(), CX2.end(), g) - CX2.begin()); };
-         std::vector<int> map2(CX.size());
-         for (size_t q = 0; q < CX.size(); q++) map2[q] = cx2_of(CX[q]);
-         DArray<int> dmap2;
-         dmap2.upload(map2.data(), std::max<size_t>(map2.size(), 1));
-         DCsr Town;
-         slice_rows(T, qlo, qhi, Town);
-         const int ncl_i = (int)(chi - clo);
-         // stacked operand Y = [Town ; Recv] and X = [I | I]: deterministic sum Town + Recv through the ESC product
-         std::stable_sort(erecv.begin(), erecv.end(), [](const Ent &a, const Ent &b) { return a.r != b.r ? a.r < b.r : a.c < b.c; });
-         std::vector<int>    hrow2, hrp2(1, 0), hcol2;
-         std::vector<double> hval2;
-         for (auto &e : erecv)
-         {
-            const int row = ncl_i + (int)(e.r - clo);
-            if (hrow2.empty() || hrow2.back() != row) { hrow2.push_back(row); hrp2.push_back(hrp2.back()); }
-            hrp2.back()++;
-            hcol2.push_back(cx2_of(e.c));
-            hval2.push_back(e.w);
-         }
-         DCsr Y, Xs, Ac;
-         assemble_csr(2 * ncl_i, (int)CX2.size(), 0, Town, dmap2.data(), hrow2, hrp2, hcol2, hval2, Y);
-         {
-            std::vector<int>    xrp((size_t)ncl_i + 1), xcj((size_t)2 * ncl_i + 1);
-            std::vector<double> xv((size_t)2 * ncl_i + 1, 1.0);
-            for (int i = 0; i < ncl_i; i++) { xrp[(size_t)i] = 2 * i; xcj[(size_t)2 * i] = i; xcj[(size_t)2 * i + 1] = ncl_i + i; }
-            xrp[(size_t)ncl_i] = 2 * ncl_i;
-            Xs.nrows = ncl_i; Xs.ncols = 2 * ncl_i; Xs.nnz = 2 * ncl_i;
-            Xs.rowptr.upload(xrp.data(), xrp.size());
-            Xs.col.upload(xcj.data(), xcj.size());
-            Xs.val.upload(xv.data(), xv.size());
-         }
-         spgemm(Xs, Y, Ac);
-         localize_cols(Ac, CX2, clo, chi, Ac_loc, ghosts_next);
+         assemble_csr(ncl, C3.size(), 0, DCsr(), nullptr, HB, B);
+         add_rows(Town3, B, Ac);
+         Town3 = DCsr();
+         localize_cols(Ac, C3, Ac_loc, ghosts_next);
       }
+      auto t5 = tick();
+      if (verbose)
+         fprintf(stderr, "[hda] partitioned setup rank %d level %d: n=%d (+%d ext) nnz=%d -> nc=%d nnzAc=%d | ext %.2f strength+pmis %.2f interp %.2f P/R %.2f rap %.2f ms\n",
+                 cm.rank, l, X.nloc, n - X.nloc, Al.nnz, ncl, Ac_loc.nnz, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5));
       levels.emplace_back();
       levels[(size_t)l + 1].A  = std::move(Ac_loc);
-      levels[(size_t)l + 1].hA = make_halo_plan((int)(chi - clo), partc, ghosts_next);
+      levels[(size_t)l + 1].hA = make_halo_plan(ncl, partc, ghosts_next);
       tail_len[(size_t)l]      = std::max(tail_len[(size_t)l], ghosts.size());
       tail_len.push_back(std::max(ghostc.size(), ghosts_next.size()));
       part   = partc;
@@ -2718,12 +2950,12 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
          stats_rows[stats_levels] = tail->stats_rows[t];
       }
       coarse_n     = (int)part.back();
-      coarse_dense = true;
+      coarse_dense = true; // coarse_solve() hands over to the tail
       coarse_lo    = part[(size_t)cm.rank];
       coarse_nloc  = (int)(part[(size_t)cm.rank + 1] - coarse_lo);
       cbuf_f.alloc((size_t)std::max(coarse_n, 1));
       cbuf_u.alloc(std::max<size_t>((size_t)std::max(coarse_n, 1), tail->vec_len0()));
-      if (l > 0) levels[(size_t)l].A = DCsr(); // the stub level keeps only vectors
+      if (l > 0) levels[(size_t)l].A = DCsr(); // the hand-over level keeps only vectors
    }
    const int L = (int)levels.size();
    for (int q = 0; q < L; q++)
@@ -2738,7 +2970,7 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
    }
    Context::get().sync();
    HDA_TRACE("partitioned setup: %d partitioned levels + replicated tail of %d levels", L - 1, tail->num_levels());
-   if (getenv("HDA_DIST_CHECK"))
+   if (const char *chk = getenv("HDA_DIST_CHECK"); chk && *chk && *chk != '0')
    { // development aid: the replicated setup is the specification of this one
       Amg ref(prm);
       ref.setup_dist(Aloc, hA0_, part0, ghost_gids0);

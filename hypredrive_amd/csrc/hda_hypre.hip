@@ -792,11 +792,12 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    s->amg = std::make_unique<Amg>(s->ap);
    if (Comm::world().size > 1)
    {
-      // HDA_DIST_SETUP=partitioned: every setup phase on the row blocks (PMIS + ext+i only);
-      // replicated (default): every rank builds the whole hierarchy and keeps its rows
+      // partitioned (default): every setup phase works on the row blocks; replicated
+      // (HDA_DIST_SETUP=replicated): every rank builds the whole hierarchy and keeps its rows --
+      // the specification the partitioned setup is checked against (HDA_DIST_CHECK=1)
       const char *mode = getenv("HDA_DIST_SETUP");
-      if (mode && !strcmp(mode, "partitioned")) s->amg->setup_dist_partitioned(A->A, A->halo, A->part, A->ghost_gids);
-      else s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+      if (mode && !strcmp(mode, "replicated")) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+      else s->amg->setup_dist_partitioned(A->A, A->halo, A->part, A->ghost_gids);
    }
    else s->amg->setup(A->A);
    hda_register_precond_veclen(s->amg->vec_len0());

@@ -70,18 +70,40 @@ def init(transport="auto"):
     if not dist.is_initialized():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     ndev = torch.cuda.device_count()
+    forced = os.environ.get("HDA_TRANSPORT")  # "rccl" | "staged": overrides the choice below
+    if forced:
+        transport = forced
     if transport == "auto":
         transport = "rccl" if ndev >= world or (ndev > 1 and local < ndev) else "staged"
     L = hd.lib()
     if transport == "rccl":
-        uid = (C.c_ubyte * 128)()
-        if rank == 0:
-            hd.check(L.HYPREDRV_AMD_CommGetUniqueId(uid))
-        box = [bytes(uid)]
-        dist.broadcast_object_list(box, src=0)
-        uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
-        hd.check(L.HYPREDRV_AMD_CommInit(rank, world, local, uid))
-    else:
+        # join RCCL and prove the communicator works (all-reduce + neighbour exchange self-test);
+        # if ANY rank fails, every rank falls back to the host-staged transport: slower
+        # messages, same kernels and results.  Set HDA_TRANSPORT=rccl to make this fatal.
+        err = None
+        try:
+            uid = (C.c_ubyte * 128)()
+            if rank == 0:
+                hd.check(L.HYPREDRV_AMD_CommGetUniqueId(uid))
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+            hd.check(L.HYPREDRV_AMD_CommInit(rank, world, local, uid))
+            from . import load
+            if load().hda_comm_selftest() != 0:
+                raise RuntimeError("RCCL self-test failed: " + load().hda_last_error().decode())
+        except Exception as e:  # noqa: BLE001 - agreement below decides what happens
+            err = e
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            if forced == "rccl":
+                raise RuntimeError(f"RCCL transport unavailable on some rank (this rank: {err})")
+            if rank == 0:
+                print(f"[hypredrive_amd] RCCL transport unavailable ({err}); using the host-staged transport", flush=True)
+            L.HYPREDRV_AMD_CommFinalize()
+            transport = "staged"
+    if transport == "staged":
         ar, a2a = _make_callbacks(dist, torch, rank, world)
         _keep["cbs"] = (ar, a2a)  # keep the ctypes trampolines alive
         hd.check(L.HYPREDRV_AMD_CommInitCallbacks(rank, world, local if local < max(ndev, 1) else 0, ar, a2a))

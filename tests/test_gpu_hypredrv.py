@@ -159,15 +159,20 @@ def test_cli_overrides():
     assert row and int(row.group(1)) == 3
 
 
-@pytest.mark.parametrize("world,n,solver,port,rep_rows", [(2, 16, "pcg", 29641, 100000), (4, 20, "pcg", 29642, 0),
-                                                          (4, 24, "pcg", 29644, 700), (3, 12, "gmres", 29643, 100000)])
-def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solver, port, rep_rows):
+@pytest.mark.parametrize("world,n,solver,port,rep_rows,setup", [
+    (2, 16, "pcg", 29641, 100000, "partitioned"), (4, 20, "pcg", 29642, 0, "partitioned"), (4, 24, "pcg", 29644, 700, "partitioned"),
+    (3, 12, "gmres", 29643, 0, "partitioned"), (4, 40, "pcg", 29645, 2000, "partitioned"), (4, 24, "pcg", 29646, 700, "replicated")])
+def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solver, port, rep_rows, setup):
     """Several ranks on one GPU through the staged transport: identical hierarchy (PMIS hashes
     global ids) => same iteration count as one rank, same solution to rounding.  rep_rows
     (HDA_REPLICATE_ROWS) moves the split between partitioned levels and the replicated tail:
-    0 = every level partitioned, 700 = two partitioned levels + tail, 100000 = tail from level 1."""
+    0 = every level partitioned, 700 = two partitioned levels + tail, 100000 = tail from level 1.
+    setup = "partitioned": distributed PMIS / ext+i / Galerkin product on the row blocks, run with
+    HDA_DIST_CHECK=1, i.e. every level is compared inside the library with the replicated setup
+    (same patterns; P, R of level 0 bit-identical; coarser operators to 1e-13 / 1e-10)."""
     out = str(tmp_path / "res.json")
-    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS=str(rep_rows))
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS=str(rep_rows), HDA_DIST_SETUP=setup,
+               HDA_DIST_CHECK="1" if setup == "partitioned" else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "solve", out, str(n), solver]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
