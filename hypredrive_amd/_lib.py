@@ -56,7 +56,7 @@ SYMBOLS = [
     "hda_csr_dims", "hda_csr_download", "hda_lap7_create", "hda_spmv", "hda_relax", "hda_dot",
     "hda_l1_norms", "hda_strength", "hda_pmis", "hda_interp_extpi", "hda_rap", "hda_transpose",
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
-    "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
+    "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest",
 ]
@@ -111,6 +111,9 @@ def load():
     L.hda_pcg_iteration_bytes.argtypes = [vp]
     L.hda_pcg_iteration_bytes.restype = C.c_double
     L.hda_memory_stats.argtypes = [dp, dp]
+    L.hda_format_bytes.argtypes = [vp, vp, dp, dp, dp, ip]
+    L.hda_probe_spmv.argtypes = [vp, C.c_int]
+    L.hda_probe_read.argtypes = [dp, ip]
     _L = L
     return L
 
@@ -342,6 +345,24 @@ def solve_device(A, amg=None, kp=None, b=None, solver=0, nsolves=1, profile_k1=T
 
 def pcg_iteration_bytes(A):
     return load().hda_pcg_iteration_bytes(A.h)
+
+
+def format_bytes(A, amg=None):
+    """Bytes really streamed when operators are stencil-coded: dict(pcg_iteration, vcycle, spmv, coded)."""
+    a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+    _check(load().hda_format_bytes(A.h, amg.h if amg is not None else None, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+    return {"pcg_iteration": a.value, "vcycle": b.value, "spmv": c.value, "coded": bool(d.value)}
+
+
+def probe_spmv(A, mode):
+    """Arm the launch-timing probe on matrix A (None disarms); mode 0 y=Ax, 1 residual, 2 Jacobi sweep."""
+    _check(load().hda_probe_spmv(A.h if A is not None else None, mode))
+
+
+def probe_read():
+    ms, n = C.c_double(), C.c_int()
+    _check(load().hda_probe_read(C.byref(ms), C.byref(n)))
+    return ms.value, n.value
 
 
 def memory_stats():

@@ -88,7 +88,7 @@ class Amg {
    double        operator_complexity() const;
    double        grid_complexity() const;
    // algorithmic HBM bytes of one V-cycle (SURVEY 8(d) formulas on the built hierarchy)
-   double        vcycle_bytes() const;
+   double        vcycle_bytes(bool format = false) const; // format: bytes the kernels read (coded operators), else the CSR figure
    AmgParams     prm;
    double        setup_times[8] = {0}; // strength, coarsen, interp, rap, misc (diagnostic)
 

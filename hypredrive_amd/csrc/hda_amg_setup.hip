@@ -1561,6 +1561,10 @@ void Amg::build_smoother_data(int l)
    const bool last = (l == num_levels() - 1);
    const bool gs   = is_gs_type(prm.relax_down) || is_gs_type(prm.relax_up) || (last && is_gs_type(prm.relax_coarse));
    if (gs && !lv.gs.built) build_gs_plan(Al, lv.gs);
+   // launch plans of the operators the cycle applies (chunk plans, stencil coding attempt):
+   // part of the setup, not of the first solve
+   spmv_prepare(Al);
+   if (!last) { spmv_prepare(lv.P); spmv_prepare(lv.R); }
 }
 
 void Amg::build_hierarchy(const DCsr &A)
@@ -1810,11 +1814,11 @@ double Amg::grid_complexity() const
    return s / std::max(stats_rows[0], 1.0);
 }
 
-static double spmv_bytes(const DCsr &M) { return 12.0 * M.nnz + 4.0 * (M.nrows + 1) + 8.0 * M.ncols + 8.0 * M.nrows; }
+static double spmv_bytes(const DCsr &M, bool format) { return matrix_stream_bytes(M, format) + 4.0 * (M.nrows + 1) + 8.0 * M.ncols + 8.0 * M.nrows; }
 
 // V(1,1) per level = smoothing sweeps + residual SpMV (+8n for b) + P^T apply
 // + P apply-add (+8n), on the actual hierarchy; the zero-guess first sweep is elementwise.
-double Amg::vcycle_bytes() const
+double Amg::vcycle_bytes(bool format) const
 {
    double    s = 0.0;
    const int L = num_levels();
@@ -1823,11 +1827,11 @@ double Amg::vcycle_bytes() const
       const DCsr &A = level_A(l);
       const double n = A.nrows;
       s += 24.0 * n;                                            // zero-guess sweep: dinv, f -> u
-      s += (prm.sweeps_down - 1) * (spmv_bytes(A) + 16.0 * n);  // further pre-sweeps
-      s += spmv_bytes(A) + 8.0 * n;                             // residual
-      s += spmv_bytes(levels[l].R);                             // restriction
-      s += spmv_bytes(levels[l].P) + 8.0 * n;                   // prolongation-add
-      s += prm.sweeps_up * (spmv_bytes(A) + 16.0 * n);          // post-sweeps
+      s += (prm.sweeps_down - 1) * (spmv_bytes(A, format) + 16.0 * n);  // further pre-sweeps
+      s += spmv_bytes(A, format) + 8.0 * n;                             // residual
+      s += spmv_bytes(levels[l].R, format);                             // restriction
+      s += spmv_bytes(levels[l].P, format) + 8.0 * n;                   // prolongation-add
+      s += prm.sweeps_up * (spmv_bytes(A, format) + 16.0 * n);          // post-sweeps
    }
    s += 8.0 * coarse_n * coarse_n + 16.0 * coarse_n;
    return s;

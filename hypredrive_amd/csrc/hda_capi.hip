@@ -555,6 +555,31 @@ extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_par
 
 extern "C" double hda_pcg_iteration_bytes(hda_csr_t A) { return A ? pcg_iteration_bytes(A->get()) : 0.0; }
 
+extern "C" int hda_format_bytes(hda_csr_t A, hda_amg_t amg, double *pcg_iteration, double *vcycle, double *spmv, int *coded)
+{
+   HDA_TRY
+   const DCsr &m = A->get();
+   if (pcg_iteration) *pcg_iteration = pcg_iteration_bytes(m, true);
+   if (vcycle) *vcycle = amg ? amg->amg->vcycle_bytes(true) : 0.0;
+   if (spmv) *spmv = matrix_stream_bytes(m, true) + 4.0 * (m.nrows + 1.0) + 8.0 * m.ncols + 8.0 * m.nrows;
+   if (coded) *coded = (m.coded == 1);
+   HDA_CATCH
+}
+
+extern "C" int hda_probe_spmv(hda_csr_t A, int mode)
+{
+   HDA_TRY
+   HDA_REQUIRE(mode >= 0 && mode <= 2, "probe mode: 0 plain, 1 residual, 2 Jacobi");
+   spmv_probe_set(A ? &A->get() : nullptr, A ? mode : -1);
+   HDA_CATCH
+}
+extern "C" int hda_probe_read(double *avg_ms, int *count)
+{
+   HDA_TRY
+   spmv_probe_read(avg_ms, count);
+   HDA_CATCH
+}
+
 extern "C" int hda_memory_stats(double *in_use, double *peak)
 {
    if (in_use) *in_use = (double)pool_bytes_in_use();

@@ -154,6 +154,19 @@ struct DCsr {
    // the rows whose first entry lies in [c*kChunk, (c+1)*kChunk)
    mutable DArray<int> chunk_row; // nchunks+1
    mutable int         nchunks = 0, maxrow = -1;
+   // stencil-coded shadow of (col, val) for operators with few distinct (col - row, value)
+   // pairs (constant-coefficient discretisations): one byte per entry indexing a dictionary of
+   // <= 255 pairs, 255 = "escape, read (col, val) from the plain arrays".  Built lazily next to
+   // the streaming plan; products and their order are those of the plain arrays.
+   mutable DArray<unsigned char> code;       // nnz (padded to a multiple of 4)
+   mutable DArray<double>        dict_val;   // 256
+   mutable DArray<int>           dict_delta; // 256
+   mutable int                   coded = -1, escapes = 0; // -1 not examined, 0 plain, 1 coded; entries outside the dictionary
+   void reset_plan() const
+   {
+      chunk_row.release(); code.release(); dict_val.release(); dict_delta.release();
+      nchunks = 0; maxrow = -1; coded = -1;
+   }
 };
 
 // HDA_VERBOSE=1: phase trace on stderr (each trace point synchronises the stream)

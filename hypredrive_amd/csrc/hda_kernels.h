@@ -59,6 +59,15 @@ void exclusive_scan(int n, const int *in, int *out, int *total_out_dev); // out[
 void l1_row_norms(const DCsr &A, int option, double *l1);   // hypre_ParCSRComputeL1Norms opt 1 / 4
 void extract_diag(const DCsr &A, double *d);
 void make_dinv(int n, const double *d, double weight, double *dinv);
+// bytes of (col, val) one product streams: plain = 12 nnz; stencil-coded = 1 nnz (+ 12 per escape);
+// format = true asks for what the kernels really read, false for the CSR figure of SURVEY 8(d)
+double matrix_stream_bytes(const DCsr &A, bool format);
+// build the launch plans of A now (chunk plan, stencil coding attempt) instead of at its first product
+void spmv_prepare(const DCsr &A);
+// timing probe: bracket every launch of mode `mode` (0 plain, 1 residual, 2 Jacobi) on matrix A
+// with HIP events on the library stream; read returns the average launch duration
+void spmv_probe_set(const DCsr *A, int mode);
+void spmv_probe_read(double *avg_ms, int *count);
 void sort_rows(DCsr &A);                                    // column-sort every row in place
 void transpose(const DCsr &A, DCsr &T);                     // rows of T sorted
 // 7-pt Laplacian generator on device (examples/src/C_laplacian/laplacian.c:719-921),

@@ -384,6 +384,276 @@ for (; k + 768 < k1; k += 1024)
    }
 }
 
+
+// ---- stencil-coded SpMV ------------------------------------------------------------------
+// HBM-bound kernels get faster only by moving fewer bytes.  A constant-coefficient operator
+// (the 7-pt Laplacian of the headline benchmark, hypredrive's ps3d10pt7 examples, any level-0
+// stencil matrix) repeats a handful of (column offset, value) pairs: entry k is then stored as
+// one byte code[k] naming a dictionary pair, 12 B -> 1 B per entry.  Entries whose pair is not
+// in the dictionary (ghost columns of a row block, boundary oddities) carry code 255 and are
+// read from the plain CSR arrays, which stay in place for the setup kernels.  The arithmetic
+// is unchanged: same doubles, same products, same order.
+constexpr int      kDictSlots = 255;
+constexpr uint64_t kEmptyKey  = 0xffffffffffffffffull;
+
+__device__ __forceinline__ uint64_t pair_key(double v, int delta)
+{
+   uint64_t h = (uint64_t)__double_as_longlong(v) ^ ((uint64_t)(uint32_t)delta * 0x9e3779b97f4a7c15ull);
+   h ^= h >> 29;
+   h *= 0xbf58476d1ce4e5b9ull;
+   h ^= h >> 32;
+   return h == kEmptyKey ? 0 : h;
+}
+
+// pass 1: claim dictionary slots (first come, first served).  Rows i = first, first + stride, ...;
+// a pair that finds the table full counts as a failure, and once the failures exceed `limit`
+// the remaining rows give up: an operator without a small pair alphabet is rejected in
+// microseconds (sampling pass) instead of probing a full table for every entry.
+__global__ __launch_bounds__(256) void k_code_collect(int n, int stride, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                      const double *__restrict__ v, unsigned long long *keys, double *dval, int *ddelta,
+                                                      int *fails, int limit)
+{
+   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * stride;
+   if (i >= n || *(volatile int *)fails > limit) return;
+   int bad = 0;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+   {
+      const double   val = v[k];
+      const int      d   = cj[k] - (int)i;
+      const uint64_t key = pair_key(val, d);
+      int            s   = (int)(key % kDictSlots);
+      bool           ok  = false;
+      for (int probe = 0; probe < kDictSlots; probe++)
+      {
+         unsigned long long cur = keys[s];
+         if (cur == kEmptyKey) cur = atomicCAS(&keys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
+         if (cur == kEmptyKey) { dval[s] = val; ddelta[s] = d; ok = true; break; } // this thread claimed the slot
+         if (cur == key) { ok = true; break; }                                    // present (or a hash twin: resolved in pass 2)
+         s = (s + 1 == kDictSlots) ? 0 : s + 1;
+      }
+      bad += !ok;
+   }
+   if (bad) atomicAdd(fails, bad);
+}
+// pass 2: encode against the finished dictionary, exact comparison of the pair
+__global__ __launch_bounds__(256) void k_code_encode(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                     const unsigned long long *__restrict__ keys, const double *__restrict__ dval,
+                                                     const int *__restrict__ ddelta, unsigned char *__restrict__ code, int *escapes)
+{
+   __shared__ unsigned long long sk[256];
+   __shared__ double             sv[256];
+   __shared__ int                sd[256];
+   if (threadIdx.x < kDictSlots) { sk[threadIdx.x] = keys[threadIdx.x]; sv[threadIdx.x] = dval[threadIdx.x]; sd[threadIdx.x] = ddelta[threadIdx.x]; }
+   __syncthreads();
+   const int i   = blockIdx.x * 256 + threadIdx.x;
+   int       esc = 0;
+   if (i < n)
+      for (int k = rp[i]; k < rp[i + 1]; k++)
+      {
+         const double   val = v[k];
+         const int      d   = cj[k] - i;
+         const uint64_t key = pair_key(val, d);
+         int            s   = (int)(key % kDictSlots), c = 255;
+         for (int probe = 0; probe < kDictSlots; probe++)
+         {
+            const unsigned long long cur = sk[s];
+            if (cur == kEmptyKey) break;
+            if (cur == key)
+            {
+               if (__double_as_longlong(sv[s]) == __double_as_longlong(val) && sd[s] == d) c = s;
+               break;
+            }
+            s = (s + 1 == kDictSlots) ? 0 : s + 1;
+         }
+         code[k] = (unsigned char)c;
+         esc += (c == 255);
+      }
+   for (int o = 32; o > 0; o >>= 1) esc += __shfl_xor(esc, o);
+   if ((threadIdx.x & 63) == 0 && esc) atomicAdd(escapes, esc);
+}
+static bool coded_enabled()
+{
+   static const bool on = !(getenv("HDA_CODED") && atoi(getenv("HDA_CODED")) == 0);
+   return on;
+}
+
+// decide once per matrix whether the coded form pays: big enough to be bandwidth-bound and at
+// most 1 entry in 16 escaping
+static void ensure_coded(const DCsr &A)
+{
+   if (A.coded >= 0) return;
+   A.coded = 0;
+   if (!coded_enabled() || A.nnz < (1 << 18) || A.maxrow > 64) return;
+   DArray<unsigned long long> keys(256);
+   DArray<int>                esc(1);
+   HDA_HIP(hipMemsetAsync(keys.data(), 0xff, 256 * sizeof(unsigned long long), STREAM));
+   esc.zero();
+   A.dict_val.alloc(256);
+   A.dict_delta.alloc(256);
+   A.dict_val.zero();
+   A.dict_delta.zero();
+   auto reject = [&]() {
+      A.code.release();
+      A.dict_val.release();
+      A.dict_delta.release();
+   };
+   // sampling pass over ~64K rows: more than 1 sampled entry in 16 outside the table ends the
+   // attempt (a few are expected: ghost columns of a row block have no fixed offset)
+   DArray<int> fails(1);
+   fails.zero();
+   const int stride = std::max(1, A.nrows / 65536), ns = ceil_div(A.nrows, stride);
+   const int slimit = (int)(ns * A.avg_row() / 16.0);
+   k_code_collect<<<ceil_div(ns, 256), 256, 0, STREAM>>>(A.nrows, stride, A.rowptr.data(), A.col.data(), A.val.data(), keys.data(),
+                                                         A.dict_val.data(), A.dict_delta.data(), fails.data(), slimit);
+   int nf = 0;
+   fails.download(&nf, 1);
+   if (nf > slimit) return reject();
+   fails.zero();
+   A.code.alloc(((size_t)A.nnz + 3 + 16) & ~(size_t)3); // row kernels read up to 3 words past an entry
+   const int g = ceil_div(A.nrows, 256);
+   if (stride > 1)
+   {
+      k_code_collect<<<g, 256, 0, STREAM>>>(A.nrows, 1, A.rowptr.data(), A.col.data(), A.val.data(), keys.data(), A.dict_val.data(),
+                                            A.dict_delta.data(), fails.data(), A.nnz / 16);
+      fails.download(&nf, 1);
+      if ((long long)nf * 16 > A.nnz) return reject();
+   }
+   k_code_encode<<<g, 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data(), keys.data(), A.dict_val.data(), A.dict_delta.data(),
+                                        A.code.data(), esc.data());
+   int e = 0;
+   esc.download(&e, 1);
+   if ((long long)e * 16 > A.nnz) return reject();
+   A.coded   = 1;
+   A.escapes = e;
+   HDA_TRACE("coded SpMV for %d x %d, nnz %d: %d escapes (%.3f %%)", A.nrows, A.ncols, A.nnz, e, 100.0 * e / std::max(A.nnz, 1));
+}
+
+// Row-per-lane kernel of the coded product: no LDS staging, no barriers.  A lane fetches the
+// (<= 8) code bytes of its row as three aligned words straight from HBM (neighbouring lanes
+// read neighbouring bytes), decodes them against the dictionary in LDS and keeps all of the
+// row's gathers in flight at once.  Longer rows take further batches of eight.  (Measured on
+// 256^3: LDS-staged code chunks 220-260 us, two / four rows per lane 160 / 257 us, this 144 us.)
+struct CodedBatch {
+   int    j[8], cc[8];
+   double v[8];
+};
+__device__ __forceinline__ void coded_decode(CodedBatch &B, int r, int q, int e, const unsigned int *__restrict__ cwords,
+                                             const double *sv, const int *sd, const int *__restrict__ col, const double *__restrict__ val)
+{
+   const unsigned int *p  = cwords + (q >> 2);
+   const unsigned int  w0 = p[0], w1 = p[1], w2 = p[2];
+   const int           o  = q & 3;
+   const unsigned int  lo = __builtin_amdgcn_alignbyte(w1, w0, o), hi = __builtin_amdgcn_alignbyte(w2, w1, o);
+   bool                esc = false;
+#pragma unroll
+   for (int u = 0; u < 8; u++)
+   {
+      const int c = (int)(((u < 4 ? lo : hi) >> (8 * (u & 3))) & 255u);
+      B.cc[u]     = (q + u < e) ? c : 256;
+      B.j[u]      = (q + u < e) ? r + sd[c] : 0;
+      B.v[u]      = sv[c];
+      esc |= (B.cc[u] == 255);
+   }
+   if (esc)
+   {
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+         if (B.cc[u] == 255) { B.j[u] = col[q + u]; B.v[u] = val[q + u]; }
+   }
+}
+template <int MODE, bool DOT>
+__global__ __launch_bounds__(256) void k_spmv_coded_row(int nrows, const int *__restrict__ rowptr, const unsigned char *__restrict__ code,
+                                                        const double *__restrict__ dval, const int *__restrict__ ddelta,
+                                                        const int *__restrict__ col, const double *__restrict__ val,
+                                                        const double *__restrict__ x, double alpha, double beta, const double *yin,
+                                                        const double *__restrict__ b, const double *__restrict__ dinv,
+                                                        const double *__restrict__ w, double *out, double *__restrict__ partial)
+{
+   __shared__ double sv[256];
+   __shared__ int    sd[256];
+   const int tid = threadIdx.x;
+   sv[tid]       = dval[tid];
+   sd[tid]       = ddelta[tid];
+   __syncthreads();
+   const unsigned int *__restrict__ cwords = (const unsigned int *)code;
+   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+   constexpr int H = 1, T = 256 * H; // rows per lane (more than one lowers occupancy and loses), rows per tile
+   const int per = (((nrows + 7) >> 3) + T - 1) / T * T; // rows per XCD, whole tiles
+   double    acc = 0.0;
+   for (int tile = slot; tile * T < per; tile += nslot)
+   {
+      const int  base = xcd * per + tile * T;
+      int        rr[H], s[H], e[H], q[H];
+      double     e0[H], e1[H], e2[H], sum[H];
+      CodedBatch B[H];
+#pragma unroll
+      for (int h = 0; h < H; h++)
+      {
+         rr[h]           = base + 256 * h + tid;
+         const bool live = rr[h] < nrows;
+         s[h]            = live ? rowptr[rr[h]] : 0;
+         e[h]            = live ? rowptr[rr[h] + 1] : 0;
+         e0[h] = e1[h] = e2[h] = 0.0;
+         sum[h]          = 0.0;
+         if (live)
+         {
+            const int r = rr[h];
+            if (MODE == MODE_PLAIN) { if (beta != 0.0) e0[h] = yin[r]; if (DOT) e1[h] = w[r]; }
+            else if (MODE == MODE_RESID) e0[h] = b[r];
+            else { e0[h] = b[r]; e1[h] = dinv[r]; e2[h] = x[r]; }
+         }
+      }
+      bool more = false;
+#pragma unroll
+      for (int h = 0; h < H; h++) { q[h] = s[h]; more |= q[h] < e[h]; }
+      while (more)
+      {
+         double xv[H][8];
+#pragma unroll
+         for (int h = 0; h < H; h++) coded_decode(B[h], rr[h], q[h], e[h], cwords, sv, sd, col, val);
+#pragma unroll
+         for (int h = 0; h < H; h++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) xv[h][u] = x[B[h].j[u]];
+#pragma unroll
+         for (int h = 0; h < H; h++)
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+               const double t = sum[h] + B[h].v[u] * xv[h][u];
+               sum[h]         = (B[h].cc[u] != 256) ? t : sum[h];
+            }
+         more = false;
+#pragma unroll
+         for (int h = 0; h < H; h++) { q[h] = min(q[h] + 8, max(e[h], q[h])); more |= q[h] < e[h]; }
+      }
+#pragma unroll
+      for (int h = 0; h < H; h++)
+      {
+         const int r = rr[h];
+         if (r >= nrows) continue;
+         double o0;
+         if (MODE == MODE_PLAIN)
+         {
+            o0 = (beta == 0.0) ? alpha * sum[h] : alpha * sum[h] + beta * e0[h];
+            if (DOT) acc += o0 * e1[h];
+         }
+         else if (MODE == MODE_RESID) o0 = e0[h] - sum[h];
+         else
+         {
+            o0 = e2[h] + e1[h] * (e0[h] - sum[h]);
+            if (DOT) acc += e0[h] * o0;
+         }
+         out[r] = o0;
+      }
+   }
+   if (DOT)
+   {
+      acc = block_sum(acc);
+      if (tid == 0) partial[blockIdx.x] = acc;
+   }
+}
+
 static int spmv_mode()
 {
    static int m = -1;
@@ -396,12 +666,21 @@ static int spmv_mode()
 }
 
 template <int MODE, bool DOT>
-static void launch_spmv(const DCsr &A, const double *x, double alpha, double beta,
+static void launch_spmv_impl(const DCsr &A, const double *x, double alpha, double beta,
                         const double *yin, const double *b, const double *dinv, const double *w,
                         double *out, double *partial)
 {
    if (A.nrows == 0 && !DOT) return;
    ensure_plan(A);
+   ensure_coded(A);
+   if (A.coded == 1 && spmv_mode() == 0)
+   {
+      const int per  = (((A.nrows + 7) >> 3) + 255) / 256 * 256; // rows per XCD (as in the kernel)
+      const int grid = DOT ? kRedBlocks : std::min(kRedBlocks, 8 * (per / 256));
+      k_spmv_coded_row<MODE, DOT><<<grid, 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.code.data(), A.dict_val.data(), A.dict_delta.data(),
+                                                            A.col.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial);
+      return;
+   }
    if (spmv_mode() == 0 && A.maxrow <= kMaxRowLds)
    {
       const int    grid = DOT ? kRedBlocks : std::min(kRedBlocks, ((A.nchunks + 7) / 8) * 8);
@@ -426,6 +705,69 @@ static void launch_spmv(const DCsr &A, const double *x, double alpha, double bet
       default: HDA_LAUNCH(64); break;
    }
 #undef HDA_LAUNCH
+}
+
+namespace {
+struct SpmvProbe {
+   const DCsr             *A    = nullptr;
+   int                     mode = -1;
+   std::vector<hipEvent_t> evs;
+} g_probe;
+} // namespace
+void spmv_prepare(const DCsr &A)
+{
+   if (A.nrows == 0) return;
+   ensure_plan(A);
+   ensure_coded(A);
+}
+void spmv_probe_set(const DCsr *A, int mode)
+{
+   for (hipEvent_t e : g_probe.evs) (void)hipEventDestroy(e);
+   g_probe.evs.clear();
+   g_probe.A    = A;
+   g_probe.mode = mode;
+}
+void spmv_probe_read(double *avg_ms, int *count)
+{
+   Context::get().sync();
+   double s = 0.0;
+   int    c = 0;
+   for (size_t e = 0; e + 1 < g_probe.evs.size(); e += 2)
+   {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, g_probe.evs[e], g_probe.evs[e + 1]) == hipSuccess) { s += ms; c++; }
+   }
+   if (avg_ms) *avg_ms = c ? s / c : 0.0;
+   if (count) *count = c;
+}
+double matrix_stream_bytes(const DCsr &A, bool format)
+{
+   if (format)
+   {
+      ensure_plan(A);
+      ensure_coded(A);
+      if (A.coded == 1) return 1.0 * A.nnz + 12.0 * A.escapes;
+   }
+   return 12.0 * A.nnz;
+}
+
+template <int MODE, bool DOT>
+static void launch_spmv(const DCsr &A, const double *x, double alpha, double beta, const double *yin, const double *b, const double *dinv,
+                        const double *w, double *out, double *partial)
+{
+   if (g_probe.A == &A && g_probe.mode == MODE && g_probe.evs.size() < 4096)
+   {
+      hipEvent_t e0, e1;
+      HDA_HIP(hipEventCreate(&e0));
+      HDA_HIP(hipEventCreate(&e1));
+      HDA_HIP(hipEventRecord(e0, STREAM));
+      launch_spmv_impl<MODE, DOT>(A, x, alpha, beta, yin, b, dinv, w, out, partial);
+      HDA_HIP(hipEventRecord(e1, STREAM));
+      g_probe.evs.push_back(e0);
+      g_probe.evs.push_back(e1);
+      return;
+   }
+   launch_spmv_impl<MODE, DOT>(A, x, alpha, beta, yin, b, dinv, w, out, partial);
 }
 
 void spmv(const DCsr &A, double alpha, const double *x, double beta, const double *y_in, double *y_out)

@@ -53,6 +53,6 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &p, con
 KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
 
 // algorithmic HBM bytes of one PCG iteration excluding the preconditioner
-double pcg_iteration_bytes(const DCsr &A);
+double pcg_iteration_bytes(const DCsr &A, bool format = false); // format: what the kernels read (coded operators), else CSR figure
 
 } // namespace hda

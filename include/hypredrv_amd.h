@@ -132,6 +132,15 @@ int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, in
                      double *final_rel, double *r0_norm, double *true_rel, double *k1_avg_ms);
 /* algorithmic HBM bytes of one PCG iteration without the preconditioner */
 double hda_pcg_iteration_bytes(hda_csr_t A);
+/* Bytes the kernels really stream when operators are held in the stencil-coded form (1 B per
+ * entry + dictionary instead of 12 B; DESIGN.md "coded operators"): one PCG iteration, one
+ * V-cycle, one plain product with A.  Equal to the CSR figures when nothing is coded. */
+int hda_format_bytes(hda_csr_t A, hda_amg_t amg, double *pcg_iteration, double *vcycle, double *spmv, int *coded);
+/* Timing probe: bracket every product launch of `mode` (0 y=Ax, 1 residual, 2 Jacobi sweep) on
+ * matrix A (e.g. a view from hda_amg_level_matrix) with HIP events on the library stream;
+ * hda_probe_read synchronises and returns the average launch duration.  A = NULL disarms. */
+int hda_probe_spmv(hda_csr_t A, int mode);
+int hda_probe_read(double *avg_ms, int *count);
 /* Exercises the active rank-to-rank transport (RCCL, staged callbacks or self): device
  * all-reduce, host all-reduce, host all-to-all.  Returns 0 when every result is right. */
 int hda_comm_selftest(void);

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 counter passes over the same bench.py command into HBM traffic per launch.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py ...
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01c
+
+FETCH_SIZE / WRITE_SIZE come in KB.  On gfx950 FETCH_SIZE reports half of the bytes of a
+streamed read (MI355X_MICROARCH.md, HBM section); the factor is re-derived here from this run's
+own k_cg_dir launches, whose byte count is known exactly (reads z, p; writes p; 8 B per lane),
+and applied to every kernel.  Writes: <tag>_pmc_summary.csv (per kernel: calls, max / median of
+both counters) and profiles/traffic.json (the launches bench.py quotes)."""
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+from collections import defaultdict
+
+
+def load(d, counter):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    assert files, f"no counter_collection.csv under {d}"
+    rows = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def main():
+    fdir, wdir, tag = sys.argv[1:4]
+    F, W = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+    byk = defaultdict(lambda: {"F": [], "W": []})
+    for _, k, v in F:
+        byk[k]["F"].append(v)
+    for _, k, v in W:
+        byk[k]["W"].append(v)
+    with open(tag + "_pmc_summary.csv", "w") as o:
+        o.write("kernel,calls,FETCH_SIZE_max_KB,FETCH_SIZE_median_KB,WRITE_SIZE_max_KB,WRITE_SIZE_median_KB\n")
+        for k, d in sorted(byk.items(), key=lambda kv: -sum(kv[1]["F"])):
+            f, w = d["F"] or [0.0], d["W"] or [0.0]
+            o.write(f'"{k}",{len(d["F"])},{max(f):.1f},{statistics.median(f):.1f},{max(w):.1f},{statistics.median(w):.1f}\n')
+
+    def med(name_part, counter, top_cluster=False):
+        vals = [v for k, d in byk.items() if name_part in k for v in d[counter]]
+        if not vals:
+            return None
+        if top_cluster:  # the launches on the largest operator: within 5 % of the maximum
+            m = max(vals)
+            vals = [v for v in vals if v >= 0.95 * m]
+        return statistics.median(vals)
+
+    n = 256 ** 3
+    cal_f, cal_w = med("k_cg_dir", "F", True), med("k_cg_dir", "W", True)
+    fetch_factor = (2 * 8.0 * n / 1024) / cal_f if cal_f else 2.0
+    write_factor = (8.0 * n / 1024) / cal_w if cal_w else 1.0
+    out = {"formula": "traffic = fetch_factor * FETCH_SIZE*1024 + write_factor * WRITE_SIZE*1024",
+           "calibration": {"kernel": "k_cg_dir on 256^3 (reads z,p = 268435456 B, writes p = 134217728 B, 8 B/lane streaming)",
+                           "FETCH_SIZE_KB": cal_f, "WRITE_SIZE_KB": cal_w, "fetch_factor": fetch_factor, "write_factor": write_factor},
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 "
+                     f"--no-cpu-baseline --no-kernel-table; summary in {os.path.basename(tag)}_pmc_summary.csv"}
+
+    def traffic(name_part, top_cluster):
+        f, w = med(name_part, "F", top_cluster), med(name_part, "W", top_cluster)
+        if f is None:
+            return None, None, None
+        return fetch_factor * f * 1024 + write_factor * (w or 0.0) * 1024, f, w
+
+    for key, part, top in (("k_spmv_level0", "k_spmv_coded_row<0, true>", False), ("k_spmv_level0", "k_spmv_stream<0, true>", False)):
+        t, f, w = traffic(part, top)
+        if t is not None and key + "_bytes_per_launch" not in out:
+            out[key + "_bytes_per_launch"] = t
+            out[key] = {"kernel": part, "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
+    # Jacobi sweep on the largest plain-CSR operator (bench.py's dominant kernel): level 1 when level 0 is coded
+    t, f, w = traffic("k_spmv_stream<2, false>", True)
+    if t is not None:
+        lvl = 1 if "k_spmv_coded_row<0, true>" in "".join(byk.keys()) else 0
+        out[f"k_spmv_stream_jacobi_level{lvl}_bytes_per_launch"] = t
+        out[f"k_spmv_stream_jacobi_level{lvl}"] = {"kernel": "k_spmv_stream<2, false>, launches within 5 % of the largest FETCH_SIZE",
+                                                   "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
+    json.dump(out, open(os.path.join(os.path.dirname(tag) or ".", "traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
