@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # repo root
 import hypredrive_amd as h, sys, os
 n = 256
 A = h.lap7(n,n,n, want_rhs=False)

@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # repo root
 import hypredrive_amd as h, time, sys, os
 print(h.device_name(), flush=True)
 sizes = [int(a) for a in sys.argv[1:]] or [32, 48, 64]
