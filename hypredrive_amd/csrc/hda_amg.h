@@ -12,7 +12,7 @@ namespace hda {
 
 struct AmgParams {
    // coarsening (src/internal/amg.c:138-157)
-   int    coarsen_type    = 8;  // PMIS (hypre-GPU default); 10 HMIS, 6 Falgout not on device
+   int    coarsen_type    = 8;  // PMIS (hypre-GPU default); 10 HMIS = Ruge first pass (one device thread, small systems); others not on device
    double strong_th       = 0.25;
    double max_row_sum     = 0.9;
    int    max_coarse_size = 64;

@@ -195,6 +195,160 @@ void amg_pmis(const DCsr &A, const unsigned char *smask, uint64_t seed, int leve
    pmis_core(A, smask, ns.data(), seed, level, row_offset, cf);
 }
 
+// ------------------------------------------------------------ Ruge first pass (HMIS on one rank)
+// hypre's coarsen type 10 (HMIS, the CPU default the reference's refOutputs were made with,
+// src/internal/amg.c:303-308) is the first pass of Ruge-Stueben on each rank's interior
+// followed by PMIS on what is left; on a single rank the first pass decides everything.  The
+// pass is a priority-queue sweep: the next C point is the HEAD of the highest non-empty measure
+// bucket, buckets are FIFO lists.  That order is the algorithm, so it runs as ONE device thread
+// (kept on the device so the setup never leaves HBM).  Meant for parity runs on the
+// reference's small examples; PMIS is the coarsening for large problems.
+struct RsBuckets {
+   int *head, *tail, *prev, *next, *key;
+   int  maxkey;
+};
+__device__ inline void bk_enter(RsBuckets &b, int i, int key)
+{
+   b.key[i]  = key;
+   b.next[i] = -1;
+   b.prev[i] = b.tail[key];
+   if (b.tail[key] >= 0) b.next[b.tail[key]] = i;
+   else b.head[key] = i;
+   b.tail[key] = i;
+   if (key > b.maxkey) b.maxkey = key;
+}
+__device__ inline void bk_remove(RsBuckets &b, int i)
+{
+   const int key = b.key[i];
+   if (b.prev[i] >= 0) b.next[b.prev[i]] = b.next[i];
+   else b.head[key] = b.next[i];
+   if (b.next[i] >= 0) b.prev[b.next[i]] = b.prev[i];
+   else b.tail[key] = b.prev[i];
+   b.prev[i] = b.next[i] = -1;
+}
+// S = strong entries of A (CSR, rp/cj), T = its transpose (tp/tj, ascending); work arrays sized n+1 / nb
+__global__ void k_rs_first_pass(int n, const int *__restrict__ rp, const int *__restrict__ cj, const int *__restrict__ tp,
+                                const int *__restrict__ tj, int nb, int *head, int *tail, int *prev, int *next, int *key, int *meas, int *cf)
+{
+   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+   RsBuckets B{head, tail, prev, next, key, 0};
+   for (int q = 0; q < nb; q++) head[q] = tail[q] = -1;
+   for (int i = 0; i < n; i++)
+   {
+      meas[i] = tp[i + 1] - tp[i];
+      prev[i] = next[i] = -1;
+      key[i]  = 0;
+      cf[i]   = (rp[i + 1] == rp[i]) ? -3 : 0; // no strong dependence: special F, never interpolated
+      if (cf[i] == -3) meas[i] = 0;
+   }
+   // ascending-index insertion; measure-0 points become F and the points they depend on gain
+   // weight (re-listed at the tail when already listed)
+   for (int j = 0; j < n; j++)
+   {
+      if (cf[j] == -3) continue;
+      if (meas[j] > 0) { bk_enter(B, j, meas[j]); continue; }
+      cf[j] = -1;
+      for (int k = rp[j]; k < rp[j + 1]; k++)
+      {
+         const int m = cj[k];
+         if (cf[m] == -3) continue;
+         if (m < j)
+         {
+            if (cf[m] != 0) { meas[m]++; continue; }
+            if (meas[m] > 0) bk_remove(B, m);
+            meas[m]++;
+            bk_enter(B, m, meas[m]);
+         }
+         else meas[m]++;
+      }
+   }
+   for (;;)
+   {
+      while (B.maxkey > 0 && head[B.maxkey] < 0) B.maxkey--;
+      if (B.maxkey <= 0) break;
+      const int i = head[B.maxkey];
+      bk_remove(B, i);
+      cf[i]   = 1;
+      meas[i] = 0;
+      for (int k = tp[i]; k < tp[i + 1]; k++)
+      { // everything that strongly depends on i becomes F
+         const int j = tj[k];
+         if (cf[j] != 0) continue;
+         cf[j] = -1;
+         bk_remove(B, j);
+         for (int kk = rp[j]; kk < rp[j + 1]; kk++)
+         {
+            const int m = cj[kk];
+            if (cf[m] == 0)
+            {
+               bk_remove(B, m);
+               meas[m]++;
+               bk_enter(B, m, meas[m]);
+            }
+         }
+      }
+      for (int k = rp[i]; k < rp[i + 1]; k++)
+      { // points i depends on lose one potential dependant
+         const int j = cj[k];
+         if (cf[j] != 0) continue;
+         bk_remove(B, j);
+         meas[j]--;
+         if (meas[j] > 0) bk_enter(B, j, meas[j]);
+         else
+         {
+            cf[j] = -1;
+            for (int kk = rp[j]; kk < rp[j + 1]; kk++)
+            {
+               const int m = cj[kk];
+               if (cf[m] == 0)
+               {
+                  bk_remove(B, m);
+                  meas[m]++;
+                  bk_enter(B, m, meas[m]);
+               }
+            }
+         }
+      }
+   }
+}
+__global__ __launch_bounds__(256) void k_strong_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                     const unsigned char *__restrict__ sm, const int *__restrict__ srp, int *__restrict__ scj,
+                                                     double *__restrict__ sv)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int d = srp[i];
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (sm[k]) { scj[d] = cj[k]; sv[d] = 1.0; d++; }
+}
+constexpr int kRsMaxRows = 200000; // one device thread: ~1 us per dependent access
+
+void amg_rs_first_pass(const DCsr &A, const unsigned char *smask, const int *ns, int *cf)
+{
+   const int n = A.nrows;
+   if (!n) return;
+   HDA_REQUIRE(n <= kRsMaxRows, "HMIS / Ruge first pass runs as one device thread (parity with the reference's CPU defaults on small "
+                                "systems); use PMIS (coarsening type pmis) above 200000 rows");
+   DCsr S, T;
+   S.nrows = n;
+   S.ncols = A.ncols;
+   S.rowptr.alloc((size_t)n + 1);
+   exclusive_scan(n, ns, S.rowptr.data(), nullptr);
+   HDA_HIP(hipMemcpyAsync(&S.nnz, S.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   S.col.alloc((size_t)std::max(S.nnz, 1));
+   S.val.alloc((size_t)std::max(S.nnz, 1));
+   k_strong_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, S.rowptr.data(), S.col.data(), S.val.data());
+   transpose(S, T);
+   // a measure never exceeds the number of points that can still come to depend on a point
+   // plus the increments it receives: both bounded by its degree in S u S^T
+   const int   nb = n + 2;
+   DArray<int> head((size_t)nb), tail((size_t)nb), prev((size_t)n + 1), next((size_t)n + 1), key((size_t)n + 1), meas((size_t)n + 1);
+   k_rs_first_pass<<<1, 1, 0, STREAM>>>(n, S.rowptr.data(), S.col.data(), T.rowptr.data(), T.col.data(), nb, head.data(), tail.data(), prev.data(),
+                                        next.data(), key.data(), meas.data(), cf);
+   Context::get().sync();
+}
+
 // ------------------------------------------------------------ interpolation
 
 __device__ __forceinline__ unsigned hash_slot(int key, int lg)
@@ -1569,7 +1723,7 @@ void Amg::build_smoother_data(int l)
 
 void Amg::build_hierarchy(const DCsr &A)
 {
-   HDA_REQUIRE(prm.coarsen_type == 8, "device AMG setup implements PMIS coarsening (type 8) only");
+   HDA_REQUIRE(prm.coarsen_type == 8 || prm.coarsen_type == 10, "device AMG setup implements PMIS (8) and, on one rank, HMIS (10) coarsening");
    HDA_REQUIRE(prm.interp_type == 6, "device AMG setup implements extended+i interpolation (type 6) only");
    HDA_REQUIRE((is_jacobi_type(prm.relax_down) || is_gs_type(prm.relax_down)) && (is_jacobi_type(prm.relax_up) || is_gs_type(prm.relax_up)),
                "device V-cycle implements Jacobi (0, 7, 18) and hybrid Gauss-Seidel (3, 4, 6, 8, 13, 14) smoothers");
@@ -1601,7 +1755,8 @@ void Amg::build_hierarchy(const DCsr &A)
       strength_ns(Al, prm.strong_th, prm.max_row_sum, sm.data(), ns.data());
       HDA_TRACE("level %d: pmis", lvl);
       auto t1 = tick();
-      pmis_core(Al, sm.data(), ns.data(), prm.seed, lvl + level0, 0, cf.data());
+      if (prm.coarsen_type == 10) amg_rs_first_pass(Al, sm.data(), ns.data(), cf.data());
+      else pmis_core(Al, sm.data(), ns.data(), prm.seed, lvl + level0, 0, cf.data());
       HDA_TRACE("level %d: interp", lvl);
       auto t2 = tick();
       DCsr P;

@@ -796,7 +796,8 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
       // (HDA_DIST_SETUP=replicated): every rank builds the whole hierarchy and keeps its rows --
       // the specification the partitioned setup is checked against (HDA_DIST_CHECK=1)
       const char *mode = getenv("HDA_DIST_SETUP");
-      if (mode && !strcmp(mode, "replicated")) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+      // (HMIS = sequential Ruge pass: only the replicated scheme can run it, on the gathered operator)
+      if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
       else s->amg->setup_dist_partitioned(A->A, A->halo, A->part, A->ghost_gids);
    }
    else s->amg->setup(A->A);

@@ -134,7 +134,7 @@ def test_cli_runs_ex1_unchanged(orc, pins):
 
 
 @pytest.mark.parametrize("cfg", ["examples/ex1-preset.yml", "examples/ex1-gmres.yml", "examples/ex2-gpu.yml", "examples/ex1-jacobi.yml",
-                                 "examples/ex1-gs.yml", "examples/ex2-hl1gs.yml"])
+                                 "examples/ex1-gs.yml", "examples/ex2-hl1gs.yml", "examples/ex1-cpudefaults.yml"])
 def test_cli_other_examples(cfg):
     cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
     r = subprocess.run([cli, "-q", cfg], capture_output=True, text=True, cwd=ROOT)
@@ -147,6 +147,10 @@ def test_cli_other_examples(cfg):
         assert int(row.group(2)) <= 500
         return
     assert float(row.group(1)) < 1e-6
+    if "cpudefaults" in cfg:
+        # the reference's own output for this input and these (CPU-default) options:
+        # examples/refOutput/ex1.txt:27 -- 6 iterations, 4.98e-08
+        assert int(row.group(2)) == 6 and float(row.group(1)) == pytest.approx(4.98e-08, rel=0.02)
     if "ex2" in cfg:  # print_level 2: residual history in hypre's format
         assert re.search(r"^\s+1\s+\d\.\d+e[+-]\d+", r.stdout, re.M)
 

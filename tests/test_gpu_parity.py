@@ -231,6 +231,47 @@ def test_hierarchy_identical_to_oracle(orc, hd, shape):
     assert rel(hh.vcycle(r), ho.vcycle(r)) < 1e-12
 
 
+@pytest.mark.parametrize("shape", [(10, 10, 10), (16, 12, 9)])
+def test_hmis_hl1gs_cpu_defaults_identical_to_oracle(orc, hd, shape):
+    """The reference's CPU defaults (src/internal/amg.c:120-238: HMIS = Ruge first pass on one rank,
+    hybrid l1 Gauss-Seidel 13/14) on the device: same C/F splitting, same hierarchy, same PCG history."""
+    Ao, b = orc.lap7(*shape, b_mode=1)
+    Ah = hd.lap7(*shape)
+    po = orc.amg_params(False)
+    ph = hd.AmgParams.default(coarsen_type=po.coarsen_type, relax_down=po.relax_down, relax_up=po.relax_up, relax_coarse=po.relax_coarse)
+    assert po.coarsen_type == 10 and (po.relax_down, po.relax_up) == (13, 14)
+    ho, hh = orc.Amg(Ao, po), hd.Amg(Ah, ph)
+    assert hh.num_levels == ho.num_levels
+    for l in range(ho.num_levels - 1):
+        assert np.array_equal(hh.level_cf(l), ho.level_cf(l)), f"C/F level {l}"
+        rp, cj, v = hh.level_matrix(l + 1, 0).download()
+        Al = ho.level_A(l + 1)
+        assert np.array_equal(rp, Al.rowptr) and np.array_equal(cj, Al.col) and np.array_equal(v, Al.val)
+    ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
+
+
+def test_pin_ex1_reference_cpu_defaults_on_gpu(hd, pins):
+    """examples/refOutput/ex1.txt:27 reproduced by the product itself (not only by the oracle):
+    10^3 7-pt, b = 1, PCG + BoomerAMG with the reference's CPU defaults -> 6 iterations, 4.98e-08."""
+    A = hd.lap7(10, 10, 10)
+    b = np.ones(1000)
+    amg = hd.Amg(A, hd.AmgParams.default(coarsen_type=10, relax_down=13, relax_up=14, relax_coarse=9))
+    r = hd.pcg(A, b, amg)
+    ref = pins["ex1"]["stats"][0]
+    assert r["converged"] and r["iters"] == ref["iters"] == 6
+    S = A.to_scipy()
+    true_rel = np.linalg.norm(b - S @ r["x"]) / np.linalg.norm(b)
+    assert true_rel == pytest.approx(ref["rel"], rel=0.02)
+
+
+def test_hmis_refuses_large_systems(hd):
+    A = hd.lap7(64, 64, 64)  # 262144 rows > the one-thread limit
+    with pytest.raises(hd.LibraryError, match="HMIS"):
+        hd.Amg(A, hd.AmgParams.default(coarsen_type=10))
+
+
 def test_pin_ex2_hierarchy_on_gpu(hd, pins):
     """examples/refOutput/ex2.txt:124-139 against the HIP-built hierarchy."""
     import scipy.sparse as sp  # noqa
