@@ -204,6 +204,88 @@ extern "C" HYPRE_Int HYPRE_IJVectorRead(const char *filename, MPI_Comm comm, HYP
    return HYPRE_IJVectorAssemble(*vector);
    HY_CATCH
 }
+// hypredrive's multipart binary files (reference src/internal/vector.c:92-380, matrix.c:142-860):
+// "<prefix>.<part %05d>.bin"; g_nparts parts are dealt to the ranks in contiguous groups, the
+// first (g_nparts mod ranks) ranks holding one more.
+static void my_parts(long long g_nparts, int &first, int &count)
+{
+   Comm &cm = Comm::world();
+   count    = (int)(g_nparts / cm.size) + (cm.rank < (int)(g_nparts % cm.size) ? 1 : 0);
+   first    = cm.rank * (int)(g_nparts / cm.size) + std::min<int>(cm.rank, (int)(g_nparts % cm.size));
+}
+static std::string part_file(const char *prefix, int part)
+{
+   char buf[40];
+   snprintf(buf, sizeof(buf), ".%05d.bin", part);
+   return std::string(prefix) + buf;
+}
+extern "C" int hda_count_binary_parts(const char *prefix)
+{
+   int n = 0;
+   for (;; n++)
+   {
+      FILE *f = fopen(part_file(prefix, n).c_str(), "rb");
+      if (!f) break;
+      fclose(f);
+   }
+   return n;
+}
+// all ranks agree on success before anything collective happens (as the reference does)
+static bool all_ok(bool mine)
+{
+   long long v = mine ? 0 : 1;
+   Comm::world().allreduce_host(&v, 1, 1);
+   return v == 0;
+}
+
+// vector part: 8 x u64 header ([1] bytes per value, [5] rows of the part), then the values
+extern "C" HYPRE_Int hda_IJVectorReadMultipartBinary(const char *prefix, MPI_Comm comm, long long g_nparts, HYPRE_IJVector *vector)
+{
+   HY_TRY
+   *vector = nullptr;
+   Comm &cm = Comm::world();
+   if (g_nparts < cm.size) return hypre_set_error(HYPRE_ERROR_GENERIC, "Invalid number of parts!");
+   int first = 0, count = 0;
+   my_parts(g_nparts, first, count);
+   std::vector<double> vals;
+   std::string         why;
+   for (int p = first; p < first + count && why.empty(); p++)
+   {
+      const std::string fn = part_file(prefix, p);
+      FILE             *f  = fopen(fn.c_str(), "rb");
+      if (!f) { why = "cannot open " + fn; break; }
+      uint64_t hd[8];
+      if (fread(hd, 8, 8, f) != 8) why = "Could not read header from " + fn;
+      else if (hd[5] > (1ull << 31)) why = "Vector row count exceeds per-part limit in " + fn;
+      else if (hd[1] == 8)
+      {
+         const size_t o = vals.size();
+         vals.resize(o + (size_t)hd[5]);
+         if (hd[5] && fread(vals.data() + o, 8, (size_t)hd[5], f) != hd[5]) why = "Could not read coeficients from " + fn;
+      }
+      else if (hd[1] == 4)
+      {
+         std::vector<float> b((size_t)hd[5]);
+         if (hd[5] && fread(b.data(), 4, (size_t)hd[5], f) != hd[5]) why = "Could not read coeficients from " + fn;
+         vals.insert(vals.end(), b.begin(), b.end());
+      }
+      else why = "Invalid coefficient data type size at " + fn;
+      fclose(f);
+   }
+   for (double x : vals)
+      if (!std::isfinite(x) && why.empty()) why = std::string("Detected non-finite vector coefficient while reading ") + prefix;
+   if (!all_ok(why.empty())) return hypre_set_error(HYPRE_ERROR_GENERIC, why.empty() ? "another rank could not read its vector parts" : why);
+   std::vector<long long> cnts;
+   cm.allgather_ll((long long)vals.size(), cnts);
+   long long lo = 0;
+   for (int r = 0; r < cm.rank; r++) lo += cnts[(size_t)r];
+   HYPRE_IJVectorCreate(comm, lo, lo + (long long)vals.size() - 1, vector);
+   HYPRE_IJVectorInitialize(*vector);
+   std::copy(vals.begin(), vals.end(), (*vector)->stage.begin());
+   return HYPRE_IJVectorAssemble(*vector);
+   HY_CATCH
+}
+
 extern "C" HYPRE_Int HYPRE_IJVectorPrint(HYPRE_IJVector v, const char *filename)
 {
    HY_TRY
@@ -465,6 +547,143 @@ extern "C" HYPRE_Int HYPRE_IJMatrixRead(const char *filename, MPI_Comm comm, HYP
    return HYPRE_IJMatrixAssemble(m);
    HY_CATCH
 }
+// matrix part: 11 x u64 header ([1] bytes per index, [2] bytes per value, [3]/[4] global rows /
+// columns, [6] entries of the part, [7]..[8] its rows), then rows[], cols[] (global ids), vals[]
+extern "C" HYPRE_Int hda_IJMatrixReadMultipartBinary(const char *prefix, MPI_Comm comm, long long g_nparts, HYPRE_IJMatrix *matrix)
+{
+   HY_TRY
+   *matrix = nullptr;
+   Comm &cm = Comm::world();
+   if (g_nparts < cm.size) return hypre_set_error(HYPRE_ERROR_GENERIC, "Invalid number of parts!");
+   int first = 0, count = 0;
+   my_parts(g_nparts, first, count);
+   std::vector<long long> rows, cols;
+   std::vector<double>    vals;
+   long long              nrows_mine = 0;
+   std::string            why;
+   auto read_idx = [&](FILE *f, uint64_t width, uint64_t n, std::vector<long long> &out) -> bool {
+      const size_t o = out.size();
+      out.resize(o + (size_t)n);
+      if (width == 8) return n == 0 || fread(out.data() + o, 8, (size_t)n, f) == n;
+      std::vector<uint32_t> b((size_t)n);
+      if (n && fread(b.data(), 4, (size_t)n, f) != n) return false;
+      for (size_t q = 0; q < (size_t)n; q++) out[o + q] = (long long)b[q];
+      return true;
+   };
+   for (int p = first; p < first + count && why.empty(); p++)
+   {
+      const std::string fn = part_file(prefix, p);
+      FILE             *f  = fopen(fn.c_str(), "rb");
+      if (!f) { why = "cannot open " + fn; break; }
+      uint64_t hd[11];
+      if (fread(hd, 8, 11, f) != 11) why = "Could not read header from " + fn;
+      else if (hd[8] < hd[7]) why = "Invalid matrix row range in " + fn;
+      else if (hd[1] != 4 && hd[1] != 8) why = "Invalid row/col data type size at " + fn;
+      else if (hd[2] != 4 && hd[2] != 8) why = "Invalid coefficient data type size at " + fn;
+      else if (hd[6] > (1ull << 31)) why = "Matrix nnz exceeds per-part limit in " + fn;
+      else
+      {
+         const size_t o = rows.size();
+         if (!read_idx(f, hd[1], hd[6], rows) || !read_idx(f, hd[1], hd[6], cols)) why = "Could not read row/column indices from " + fn;
+         else if (hd[2] == 8)
+         {
+            vals.resize(o + (size_t)hd[6]);
+            if (hd[6] && fread(vals.data() + o, 8, (size_t)hd[6], f) != hd[6]) why = "Could not read coefficients from " + fn;
+         }
+         else
+         {
+            std::vector<float> b((size_t)hd[6]);
+            if (hd[6] && fread(b.data(), 4, (size_t)hd[6], f) != hd[6]) why = "Could not read coefficients from " + fn;
+            vals.insert(vals.end(), b.begin(), b.end());
+         }
+         for (size_t q = o; q < rows.size() && why.empty(); q++)
+         {
+            if (rows[q] < 0 || cols[q] < 0 || (uint64_t)rows[q] >= hd[3] || (uint64_t)cols[q] >= hd[4])
+               why = "Detected out-of-bounds matrix entry while reading " + fn;
+            else if (q < vals.size() && !std::isfinite(vals[q])) why = "Detected non-finite matrix coefficient while reading " + fn;
+         }
+         nrows_mine += (long long)(hd[8] - hd[7] + 1);
+      }
+      fclose(f);
+   }
+   if (!all_ok(why.empty())) return hypre_set_error(HYPRE_ERROR_GENERIC, why.empty() ? "another rank could not read its matrix parts" : why);
+   std::vector<long long> cnts;
+   cm.allgather_ll(nrows_mine, cnts);
+   long long lo = 0;
+   for (int r = 0; r < cm.rank; r++) lo += cnts[(size_t)r];
+   HYPRE_IJMatrixCreate(comm, lo, lo + nrows_mine - 1, lo, lo + nrows_mine - 1, matrix);
+   HYPRE_IJMatrixInitialize(*matrix);
+   auto *m = *matrix;
+   for (size_t q = 0; q < rows.size(); q++)
+   {
+      if (rows[q] < lo || rows[q] >= lo + nrows_mine) return hypre_set_error(HYPRE_ERROR_GENERIC, std::string("matrix part holds a row outside its rank's block in ") + prefix);
+      m->t_row.push_back((int)(rows[q] - lo));
+      m->t_col.push_back(cols[q]);
+      m->t_val.push_back(vals[q]);
+      m->t_add.push_back(0);
+   }
+   return HYPRE_IJMatrixAssemble(m);
+   HY_CATCH
+}
+
+// Matrix Market coordinate file (real / integer / pattern; general or symmetric), one file for
+// the whole matrix: every rank parses it and keeps an equal contiguous block of rows.
+extern "C" HYPRE_Int HYPRE_IJMatrixReadMM(const char *filename, MPI_Comm comm, HYPRE_Int, HYPRE_IJMatrix *matrix)
+{
+   HY_TRY
+   *matrix = nullptr;
+   FILE *f = fopen(filename, "r");
+   if (!f) return hypre_set_error(HYPRE_ERROR_ARG, std::string("cannot open ") + filename);
+   char line[1024];
+   if (!fgets(line, sizeof(line), f)) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, std::string("empty Matrix Market file ") + filename); }
+   std::string banner(line);
+   for (auto &c : banner) c = (char)tolower(c);
+   if (banner.find("%%matrixmarket") != 0 || banner.find("coordinate") == std::string::npos || banner.find("complex") != std::string::npos)
+   {
+      fclose(f);
+      return hypre_set_error(HYPRE_ERROR_GENERIC, std::string("unsupported Matrix Market banner in ") + filename);
+   }
+   const bool pattern = banner.find("pattern") != std::string::npos;
+   const bool sym     = banner.find(" symmetric") != std::string::npos;
+   const bool skew    = banner.find("skew-symmetric") != std::string::npos;
+   long long  M = 0, N = 0, NZ = 0;
+   while (fgets(line, sizeof(line), f))
+      if (line[0] != '%' && sscanf(line, "%lld %lld %lld", &M, &N, &NZ) == 3) break;
+   if (M <= 0 || N != M) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, std::string("Matrix Market size line missing or matrix not square in ") + filename); }
+   Comm           &cm = Comm::world();
+   const long long lo = M * cm.rank / cm.size, hi = M * (cm.rank + 1) / cm.size;
+   HYPRE_IJMatrixCreate(comm, lo, hi - 1, lo, hi - 1, matrix);
+   HYPRE_IJMatrixInitialize(*matrix);
+   auto *m   = *matrix;
+   auto  put = [&](long long i, long long j, double v) {
+      if (i < lo || i >= hi) return;
+      m->t_row.push_back((int)(i - lo));
+      m->t_col.push_back(j);
+      m->t_val.push_back(v);
+      m->t_add.push_back(1); // duplicate entries of a Matrix Market file are summed
+   };
+   long long got = 0;
+   while (got < NZ && fgets(line, sizeof(line), f))
+   {
+      if (line[0] == '%' || line[0] == '\n') continue;
+      long long i, j;
+      double    v = 1.0;
+      const int k = pattern ? sscanf(line, "%lld %lld", &i, &j) : sscanf(line, "%lld %lld %lf", &i, &j, &v);
+      if (k != (pattern ? 2 : 3) || i < 1 || j < 1 || i > M || j > N || !std::isfinite(v))
+      {
+         fclose(f);
+         return hypre_set_error(HYPRE_ERROR_GENERIC, std::string("bad entry in Matrix Market file ") + filename);
+      }
+      got++;
+      put(i - 1, j - 1, v);
+      if ((sym || skew) && i != j) put(j - 1, i - 1, skew ? -v : v);
+   }
+   fclose(f);
+   if (got != NZ) return hypre_set_error(HYPRE_ERROR_GENERIC, std::string("Matrix Market file ends early: ") + filename);
+   return HYPRE_IJMatrixAssemble(m);
+   HY_CATCH
+}
+
 extern "C" HYPRE_Int HYPRE_IJMatrixPrint(HYPRE_IJMatrix m, const char *filename)
 {
    HY_TRY

@@ -465,22 +465,39 @@ extern "C" uint32_t HYPREDRV_LinearSystemReadMatrix(HYPREDRV_t h)
    CHECK_INIT_OBJ(h);
    API_TRY
    if (h->args.ls.matrix_filename.empty()) return err_set(ERR_MISSING_KEY, "linear_system.matrix_filename is not set");
-   if (h->args.ls.type != 1) return err_set(ERR_MISSING_LIB, "only linear_system.type 'ij' (hypre ASCII IJ files) is supported");
+   if (h->args.ls.type != 1 && h->args.ls.type != 3)
+      return err_set(ERR_MISSING_LIB, "linear_system.type must be 'ij' (hypre ASCII or hypredrive multipart binary files) or 'mtx' (Matrix Market)");
    annotate(h, "matrix", true);
    if (h->owns_A && h->mat_A) HYPRE_IJMatrixDestroy(h->mat_A);
    h->mat_A = nullptr;
    const std::string path = ls_path(h, h->args.ls.matrix_filename);
-   if (HYPRE_IJMatrixRead(path.c_str(), h->comm, HYPRE_PARCSR, &h->mat_A))
+   // reference src/internal/linsys.c:946-1000: binary parts win over ASCII files of the same prefix
+   HYPRE_Int rc;
+   if (h->args.ls.type == 3) rc = HYPRE_IJMatrixReadMM(path.c_str(), h->comm, HYPRE_PARCSR, &h->mat_A);
+   else if (const int np = hda_count_binary_parts(path.c_str()); np > 0) rc = hda_IJMatrixReadMultipartBinary(path.c_str(), h->comm, np, &h->mat_A);
+   else rc = HYPRE_IJMatrixRead(path.c_str(), h->comm, HYPRE_PARCSR, &h->mat_A);
+   if (rc)
    {
       annotate(h, "matrix", false);
       const std::string why = hypre_last_error();
       HYPRE_ClearAllErrors();
-      return err_set(why.find("cannot open") != std::string::npos ? ERR_FILE_NOT_FOUND : ERR_HYPRE_INTERNAL, why);
+      h->mat_A = nullptr;
+      const bool missing = why.find("cannot open") != std::string::npos;
+      const bool badfile = why.find("Could not read") != std::string::npos || why.find("Invalid") != std::string::npos ||
+                           why.find("Detected") != std::string::npos || why.find("exceeds") != std::string::npos;
+      return err_set(missing ? ERR_FILE_NOT_FOUND : badfile ? ERR_FILE_UNEXPECTED_ENTRY : ERR_HYPRE_INTERNAL, why);
    }
    h->owns_A = true;
    h->mat_M  = h->mat_A;
    annotate(h, "matrix", false);
    API_CATCH
+}
+
+// ASCII "<prefix>.<rank>" or multipart binary "<prefix>.<part>.bin" (reference linsys.c:884)
+static HYPRE_Int read_vector_file(hypredrv_struct *h, const std::string &path, HYPRE_IJVector *v)
+{
+   if (const int np = hda_count_binary_parts(path.c_str()); np > 0) return hda_IJVectorReadMultipartBinary(path.c_str(), h->comm, np, v);
+   return HYPRE_IJVectorRead(path.c_str(), h->comm, HYPRE_PARCSR, v);
 }
 
 static HYPRE_IJVector new_vector_like(hypredrv_struct *h, double value)
@@ -532,7 +549,7 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetRHS(HYPREDRV_t h, HYPRE_Vector vec)
       if (l.rhs_mode == 2 && !l.rhs_filename.empty())
       {
          const std::string path = ls_path(h, l.rhs_filename);
-         if (HYPRE_IJVectorRead(path.c_str(), h->comm, HYPRE_PARCSR, &h->vec_b))
+         if (read_vector_file(h, path, &h->vec_b))
          {
             annotate(h, "rhs", false);
             const std::string why = hypre_last_error();
@@ -573,7 +590,7 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetInitialGuess(HYPREDRV_t h, HYPRE_Vec
       if (l.init_guess_mode == 2 && !l.x0_filename.empty())
       {
          const std::string path = ls_path(h, l.x0_filename);
-         if (HYPRE_IJVectorRead(path.c_str(), h->comm, HYPRE_PARCSR, &h->vec_x0))
+         if (read_vector_file(h, path, &h->vec_x0))
          {
             const std::string why = hypre_last_error();
             HYPRE_ClearAllErrors();

@@ -12,6 +12,7 @@ _configured = False
 ERROR_INVALID_SOLVER = 0x00020000
 ERROR_INVALID_PRECON = 0x00040000
 ERROR_FILE_NOT_FOUND = 0x00080000
+ERROR_FILE_UNEXPECTED_ENTRY = 0x00100000
 ERROR_UNKNOWN_HYPREDRV_OBJ = 0x00200000
 ERROR_NOT_INITIALIZED = 0x00400000
 ERROR_UNKNOWN_TIMING = 0x00800000

@@ -80,6 +80,14 @@ HYPRE_Int HYPRE_IJMatrixGetLocalRange(HYPRE_IJMatrix matrix, HYPRE_BigInt *ilowe
                                       HYPRE_BigInt *jlower, HYPRE_BigInt *jupper);
 HYPRE_Int HYPRE_IJMatrixMigrate(HYPRE_IJMatrix matrix, HYPRE_MemoryLocation loc);
 HYPRE_Int HYPRE_IJMatrixRead(const char *filename, MPI_Comm comm, HYPRE_Int type, HYPRE_IJMatrix *matrix);
+/* Matrix Market coordinate file (reference src/internal/linsys.c:986, linear_system.type mtx) */
+HYPRE_Int HYPRE_IJMatrixReadMM(const char *filename, MPI_Comm comm, HYPRE_Int type, HYPRE_IJMatrix *matrix);
+/* hypredrive's multipart binary containers "<prefix>.<part %05d>.bin" (reference
+ * src/internal/matrix.c:142 hypredrv_IJMatrixReadMultipartBinary, src/internal/vector.c:92
+ * hypredrv_IJVectorReadMultipartBinary; part count as hypredrv_CountNumberOfPartitions) */
+int       hda_count_binary_parts(const char *prefix);
+HYPRE_Int hda_IJMatrixReadMultipartBinary(const char *prefix, MPI_Comm comm, long long g_nparts, HYPRE_IJMatrix *matrix);
+HYPRE_Int hda_IJVectorReadMultipartBinary(const char *prefix, MPI_Comm comm, long long g_nparts, HYPRE_IJVector *vector);
 HYPRE_Int HYPRE_IJMatrixPrint(HYPRE_IJMatrix matrix, const char *filename);
 /* global rows / nonzeros (what linsys.c reads through hypre_ParCSRMatrix accessors) */
 HYPRE_Int HYPRE_ParCSRMatrixGetDims(HYPRE_ParCSRMatrix A, HYPRE_BigInt *M, HYPRE_BigInt *N);

@@ -235,3 +235,94 @@ def test_rccl_transport_single_rank_selftest():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT),
                        timeout=600)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ----------------------------------------------------------- on-disk containers
+
+def _lap_coo(n=10):
+    import scipy.sparse as sp
+    I = sp.identity(n)
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    A = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)).tocsr()
+    A.sort_indices()
+    return A
+
+
+def _write_binary_parts(prefix_A, prefix_b, A, nparts, idx_bytes=8, val_bytes=8):
+    """The reference's multipart containers (src/internal/matrix.c:142-300: 11 x u64 header, rows, cols,
+    vals; src/internal/vector.c:92-380: 8 x u64 header, vals)."""
+    N = A.shape[0]
+    it = np.uint64 if idx_bytes == 8 else np.uint32
+    vt = np.float64 if val_bytes == 8 else np.float32
+    for p in range(nparts):
+        lo, hi = p * N // nparts, (p + 1) * N // nparts
+        blk = A[lo:hi].tocoo()
+        hd = np.zeros(11, dtype=np.uint64)
+        hd[1], hd[2], hd[3], hd[4], hd[5], hd[6], hd[7], hd[8], hd[9], hd[10] = idx_bytes, val_bytes, N, N, hi - lo, blk.nnz, lo, hi - 1, 0, N - 1
+        with open(f"{prefix_A}.{p:05d}.bin", "wb") as f:
+            hd.tofile(f)
+            (blk.row + lo).astype(it).tofile(f)
+            blk.col.astype(it).tofile(f)
+            blk.data.astype(vt).tofile(f)
+        hv = np.zeros(8, dtype=np.uint64)
+        hv[1], hv[5] = val_bytes, hi - lo
+        with open(f"{prefix_b}.{p:05d}.bin", "wb") as f:
+            hv.tofile(f)
+            np.ones(hi - lo, dtype=vt).tofile(f)
+
+
+def _solve_files(hd, tmp_path, extra=""):
+    h = hd.Hypredrv(f"linear_system:\n  dirname: {tmp_path}\n  matrix_filename: A\n  rhs_filename: b\n{extra}solver: pcg\npreconditioner: amg\n")
+    hd.check(hd.lib().HYPREDRV_LinearSystemBuild(h.h))
+    r = h.solve()
+    nrm = h.solution_norm("L2")
+    h.close()
+    return r, nrm
+
+
+@pytest.mark.parametrize("nparts,ib,vb", [(1, 8, 8), (3, 4, 8), (2, 8, 4)])
+def test_multipart_binary_files_match_ascii(hd, orc, tmp_path, nparts, ib, vb):
+    """linear_system files in hypredrive's multipart binary container (one rank reads all parts,
+    32- or 64-bit indices, float or double coefficients) solve like the ASCII ps3d10pt7 data."""
+    A = _lap_coo(10)
+    _write_binary_parts(str(tmp_path / "A"), str(tmp_path / "b"), A, nparts, ib, vb)
+    r, nrm = _solve_files(hd, tmp_path)
+    Ao, b = orc.lap7(10, 10, 10, b_mode=1)
+    ref = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True)))
+    assert r["converged"] and r["iters"] == ref["iters"]
+    assert nrm == pytest.approx(np.linalg.norm(ref["x"]), rel=1e-6)
+
+
+def test_multipart_binary_bad_files_are_errors(hd, tmp_path):
+    """Truncated header / wrong index width -> ERROR_FILE_UNEXPECTED_ENTRY, as tests/test_vector.c:189-212
+    and the validation in src/internal/matrix.c:36-131 demand; the handle stays usable."""
+    (tmp_path / "A.00000.bin").write_bytes(np.zeros(4, dtype=np.uint64).tobytes())
+    h = hd.Hypredrv(f"linear_system:\n  dirname: {tmp_path}\n  matrix_filename: A\n  rhs_filename: b\nsolver: pcg\npreconditioner: amg\n")
+    code = hd.lib().HYPREDRV_LinearSystemReadMatrix(h.h)
+    assert code & hd.ERROR_FILE_UNEXPECTED_ENTRY
+    hdr = np.zeros(11, dtype=np.uint64)
+    hdr[1], hdr[2], hdr[3], hdr[4], hdr[8] = 2, 8, 4, 4, 3
+    (tmp_path / "A.00000.bin").write_bytes(hdr.tobytes())
+    code = hd.lib().HYPREDRV_LinearSystemReadMatrix(h.h)
+    assert code & hd.ERROR_FILE_UNEXPECTED_ENTRY
+    h.close()
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_matrix_market_file(hd, orc, tmp_path, symmetric):
+    """linear_system.type mtx (reference src/internal/linsys.c:986 HYPRE_IJMatrixReadMM)."""
+    import scipy.sparse as sp
+    A = _lap_coo(10)
+    M = sp.tril(A).tocoo() if symmetric else A.tocoo()
+    with open(tmp_path / "A", "w") as f:
+        f.write(f"%%MatrixMarket matrix coordinate real {'symmetric' if symmetric else 'general'}\n% 7-pt Laplacian\n")
+        f.write(f"{A.shape[0]} {A.shape[1]} {M.nnz}\n")
+        for i, j, v in zip(M.row, M.col, M.data):
+            f.write(f"{i + 1} {j + 1} {v:.17g}\n")
+    h = hd.Hypredrv(f"linear_system:\n  type: mtx\n  dirname: {tmp_path}\n  matrix_filename: A\n  rhs_mode: ones\nsolver: pcg\npreconditioner: amg\n")
+    hd.check(hd.lib().HYPREDRV_LinearSystemBuild(h.h))
+    r = h.solve()
+    Ao, b = orc.lap7(10, 10, 10, b_mode=1)
+    ref = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True)))
+    assert r["converged"] and r["iters"] == ref["iters"]
+    h.close()
