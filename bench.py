@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per dimension (global)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="grid size of the CPU-baseline sample (about 20 s of CPU work)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: --grid is the block of every rank (global grid = block x rank grid, "
+                    "BASELINE config 3 = --grid 256 on 8 GPUs) instead of the global problem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     args = ap.parse_args()
