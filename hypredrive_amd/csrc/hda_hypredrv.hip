@@ -99,9 +99,15 @@ extern "C" void HYPREDRV_SafeCallHandleError(uint32_t code, MPI_Comm, const char
 namespace {
 using clk = std::chrono::steady_clock;
 struct StatEntry {
-   double build = 0.0, prec = 0.0, solve = 0.0, r0 = 0.0, rr = 0.0;
-   int    iters = 0;
-   bool   has_solve = false;
+   double      build = 0.0, prec = 0.0, solve = 0.0, r0 = 0.0, rr = 0.0;
+   int         iters = 0;
+   bool        has_solve = false;
+   std::string path; // "timestep.newton.system" when level annotations are active (reference stats.c:232-307)
+};
+// hierarchical annotations (reference src/internal/stats.c:953-1122, include/HYPREDRV.h:2021-2079)
+constexpr int kStatsMaxLevels = 10;
+struct LevelEntry {
+   int id, solve_start, solve_end; // entry-index range [start, end) covered by the region
 };
 struct Stats {
    std::vector<StatEntry>                 entries{StatEntry()};
@@ -110,6 +116,20 @@ struct Stats {
    int                                    ls_counter = -1;
    bool                                   system_open = false;
    int                                    use_millisec = 0;
+   // level annotations
+   std::string             level_name[kStatsMaxLevels];
+   bool                    level_open[kStatsMaxLevels] = {};
+   int                     level_current_id[kStatsMaxLevels] = {};
+   int                     level_solve_start[kStatsMaxLevels] = {};
+   std::vector<LevelEntry> level_entries[kStatsMaxLevels];
+   int                     systems_solved = 0; // flat 1-based counter of linear systems (leaf of the path)
+   bool                    new_system = true;  // a matrix was set since the last solve
+   int  solved_entries() const
+   {
+      int c = 0;
+      for (const StatEntry &e : entries) c += e.has_solve ? 1 : 0;
+      return c;
+   }
    StatEntry &cur() { return entries.back(); }
    void       next_entry_if_used()
    {
@@ -172,13 +192,22 @@ static uint32_t annotate(hypredrv_struct *h, const char *name, bool begin)
       if (begin)
       {
          stats_begin(s, n);
-         if (n == "system" || n == "matrix") s.system_open = true;
+         if (n == "system" || n == "matrix") { s.system_open = true; s.new_system = true; }
       }
       else s.pending_build += stats_end(s, n);
       return g_err;
    }
    if (n == "prec" || n == "solve" || n == "reset_x0")
    {
+      if (begin && n == "solve")
+      { // first solve of a new system advances the flat counter; active levels prefix the entry's path
+         if (s.new_system) { s.systems_solved++; s.new_system = false; }
+         std::string p;
+         for (int l = 0; l < kStatsMaxLevels; l++)
+            if (s.level_open[l] && s.level_current_id[l] > 0) p += (p.empty() ? "" : ".") + std::to_string(s.level_current_id[l]);
+         if (!p.empty()) p += "." + std::to_string(s.systems_solved);
+         s.cur().path = p;
+      }
       if (begin) stats_begin(s, n);
       else
       {
@@ -489,6 +518,7 @@ extern "C" uint32_t HYPREDRV_LinearSystemReadMatrix(HYPREDRV_t h)
    }
    h->owns_A = true;
    h->mat_M  = h->mat_A;
+   h->stats.new_system = true;
    annotate(h, "matrix", false);
    API_CATCH
 }
@@ -517,6 +547,7 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetMatrix(HYPREDRV_t h, HYPRE_Matrix A)
    if (h->owns_A && h->mat_A && h->mat_A != A) HYPRE_IJMatrixDestroy(h->mat_A);
    h->mat_A  = A;
    h->mat_M  = A;
+   h->stats.new_system = true;
    h->owns_A = !h->lib_mode; // driver mode takes ownership (reference src/HYPREDRV.c:2013)
    if (A && !A->assembled) HYPRE_IJMatrixAssemble(A);
    consume_hypre_errors();
@@ -893,11 +924,102 @@ UNSUPPORTED(HYPREDRV_StateVectorGetValues(HYPREDRV_t, int, HYPRE_Complex **), "s
 UNSUPPORTED(HYPREDRV_StateVectorCopy(HYPREDRV_t, int, int), "state vectors")
 UNSUPPORTED(HYPREDRV_StateVectorUpdateAll(HYPREDRV_t), "state vectors")
 UNSUPPORTED(HYPREDRV_StateVectorApplyCorrection(HYPREDRV_t, int), "state vectors")
-UNSUPPORTED(HYPREDRV_AnnotateLevelBegin(HYPREDRV_t, int, const char *, int), "level annotations")
-UNSUPPORTED(HYPREDRV_AnnotateLevelEnd(HYPREDRV_t, int, const char *, int), "level annotations")
-UNSUPPORTED(HYPREDRV_StatsLevelGetCount(HYPREDRV_t, int, int *), "level statistics")
-UNSUPPORTED(HYPREDRV_StatsLevelGetEntry(HYPREDRV_t, int, int, int *, int *, int *, double *, double *), "level statistics")
-UNSUPPORTED(HYPREDRV_StatsLevelPrint(HYPREDRV_t, int), "level statistics")
+static std::string level_region(const char *name, int id) { return id >= 0 ? std::string(name) + "-" + std::to_string(id) : std::string(name); }
+extern "C" uint32_t HYPREDRV_AnnotateLevelBegin(HYPREDRV_t h, int level, const char *name, int id)
+{
+   CHECK_INIT_OBJ(h);
+   if (!name) return err_set(ERR_UNKNOWN_TIMING);
+   if (level < 0 || level >= kStatsMaxLevels) return err_set(ERR_INVALID_VAL, "Annotation level " + std::to_string(level) + " out of range [0, 10)");
+   Stats &s = h->stats;
+   if (s.level_open[level]) return err_set(ERR_INVALID_VAL, "Level " + std::to_string(level) + " already has active annotation '" + s.level_name[level] + "'");
+   s.level_open[level]        = true;
+   s.level_name[level]        = level_region(name, id);
+   s.level_current_id[level]++;
+   s.level_solve_start[level] = s.solved_entries();
+   for (int c = level + 1; c < kStatsMaxLevels; c++) s.level_current_id[c] = 0; // child ids are local to the parent
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_AnnotateLevelEnd(HYPREDRV_t h, int level, const char *name, int id)
+{
+   CHECK_INIT_OBJ(h);
+   if (!name) return err_set(ERR_UNKNOWN_TIMING);
+   if (level < 0 || level >= kStatsMaxLevels) return err_set(ERR_INVALID_VAL, "Annotation level " + std::to_string(level) + " out of range [0, 10)");
+   Stats &s = h->stats;
+   if (!s.level_open[level]) return g_err; // an end without a begin is a no-op (reference stats.c:1081-1086)
+   const std::string region = level_region(name, id);
+   if (region != s.level_name[level])
+      return err_set(ERR_INVALID_VAL, "Level " + std::to_string(level) + " annotation mismatch: expected '" + s.level_name[level] + "', got '" + region + "'");
+   s.level_entries[level].push_back({s.level_current_id[level], s.level_solve_start[level], s.solved_entries()});
+   s.level_open[level] = false;
+   s.level_name[level].clear();
+   return g_err;
+}
+static void level_totals(const Stats &s, const LevelEntry &e, int *nsolves, int *iters, double *setup, double *solve)
+{
+   int    q = 0, n = 0, it = 0;
+   double ps = 0.0, ss = 0.0;
+   for (const StatEntry &x : s.entries)
+   {
+      if (!x.has_solve) continue;
+      if (q >= e.solve_start && q < e.solve_end) { n++; it += x.iters; ps += x.prec; ss += x.solve; }
+      q++;
+   }
+   if (nsolves) *nsolves = n;
+   if (iters) *iters = it;
+   if (setup) *setup = ps;
+   if (solve) *solve = ss;
+}
+extern "C" uint32_t HYPREDRV_StatsLevelGetCount(HYPREDRV_t h, int level, int *count)
+{
+   CHECK_INIT_OBJ(h);
+   if (level < 0 || level >= kStatsMaxLevels) return err_set(ERR_INVALID_VAL, "level out of range");
+   if (count) *count = (int)h->stats.level_entries[level].size();
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_StatsLevelGetEntry(HYPREDRV_t h, int level, int index, int *entry_id, int *num_solves, int *linear_iters,
+                                                double *setup_time, double *solve_time)
+{
+   CHECK_INIT_OBJ(h);
+   if (level < 0 || level >= kStatsMaxLevels || index < 0 || index >= (int)h->stats.level_entries[level].size())
+      return err_set(ERR_UNKNOWN, "StatsLevelGetEntry: invalid level " + std::to_string(level) + " or index " + std::to_string(index));
+   const LevelEntry &e = h->stats.level_entries[level][(size_t)index];
+   if (entry_id) *entry_id = e.id;
+   level_totals(h->stats, e, num_solves, linear_iters, setup_time, solve_time);
+   return g_err;
+}
+// text of the reference's summary: src/internal/stats.c:1750-1768
+extern "C" uint32_t HYPREDRV_StatsLevelPrint(HYPREDRV_t h, int level)
+{
+   CHECK_INIT_OBJ(h);
+   if (level < 0 || level >= kStatsMaxLevels || h->mypid) return g_err;
+   const Stats &s     = h->stats;
+   const int    count = (int)s.level_entries[level].size();
+   if (!count) return g_err;
+   long long tsolves = 0, tlin = 0;
+   double    tsetup = 0.0, tsolve = 0.0;
+   for (const LevelEntry &e : s.level_entries[level])
+   {
+      int    n = 0, it = 0;
+      double ps = 0.0, ss = 0.0;
+      level_totals(s, e, &n, &it, &ps, &ss);
+      tsolves += n; tlin += it; tsetup += ps; tsolve += ss;
+   }
+   const double ai = tsolves ? (double)tlin / (double)tsolves : 0.0, as = tsolves ? tsetup / (double)tsolves : 0.0,
+                av = tsolves ? tsolve / (double)tsolves : 0.0;
+   printf("\n");
+   printf("Aggregate Summary:\n");
+   printf("--------------------------------------------------------------\n");
+   printf("Total number of Non-linear iterations: %lld\n", tsolves);
+   printf("Total number of linear iterations:     %lld\n", tlin);
+   printf("Avg. LS iterations:                    %.2f\n", ai);
+   printf("Avg. LS times: (setup, solve, total):  %.4f, %.4f, %.4f\n", as, av, as + av);
+   printf("Total LS times: (setup, solve, total): %.4f, %.4f, %.4f\n", tsetup, tsolve, tsetup + tsolve);
+   printf("Avg. LS iterations per timestep:       %.2f\n", (double)tlin / count);
+   printf("Avg. LS times per timestep: (s, s, t): %.4f, %.4f, %.4f\n", tsetup / count, tsolve / count, (tsetup + tsolve) / count);
+   printf("--------------------------------------------------------------\n");
+   printf("\n");
+   return g_err;
+}
 extern "C" uint32_t HYPREDRV_LinearSystemReadDofmap(HYPREDRV_t h)
 {
    CHECK_INIT_OBJ(h);
@@ -1207,15 +1329,23 @@ extern "C" uint32_t HYPREDRV_StatsPrint(HYPREDRV_t h)
           w[5], "relative", w[6], "");
    char t1[32];
    snprintf(t1, sizeof(t1), "times %s", scale);
-   printf("| %*s | %*s | %*s | %*s | %*s | %*s | %*s |\n", w[0], "Entry", w[1], t1, w[2], t1, w[3], t1, w[4], "res. norm", w[5],
+   bool use_path = false;
+   for (const StatEntry &e : s.entries) use_path |= (e.has_solve && !e.path.empty());
+   printf("| %*s | %*s | %*s | %*s | %*s | %*s | %*s |\n", w[0], use_path ? "Path" : "Entry", w[1], t1, w[2], t1, w[3], t1, w[4], "res. norm", w[5],
           "res. norm", w[6], "iters");
    divisor();
    int idx = 0;
    for (const StatEntry &e : s.entries)
    {
       if (!e.has_solve) continue;
-      char label[16];
-      snprintf(label, sizeof(label), "%d", idx++);
+      char label[32];
+      if (use_path && !e.path.empty())
+      { // long paths keep their tail (reference stats.c:612-622)
+         if (e.path.size() <= 10) snprintf(label, sizeof(label), "%s", e.path.c_str());
+         else snprintf(label, sizeof(label), "...%s", e.path.c_str() + (e.path.size() - 7));
+         idx++;
+      }
+      else snprintf(label, sizeof(label), "%d", idx++);
       if (e.build > 0.0)
          printf("| %*s | %*.*f | %*.*f | %*.*f | %*.*e | %*.*e | %*d |\n", w[0], label, w[1], 3, tf * e.build, w[2], 3, tf * e.prec, w[3], 3,
                 tf * e.solve, w[4], 2, e.r0, w[5], 2, e.rr, w[6], e.iters);

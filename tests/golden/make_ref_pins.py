@@ -51,6 +51,14 @@ def main():
     pins["laplacian"] = dict(source="examples/refOutput/laplacian.txt:10-16,34-38",
                              stats=stats_rows(lap),
                              config="10^3 generator defaults, b=1 on y=0 plane, presets pcg+poisson, CPU defaults")
+    # second example driver: time-dependent convection-diffusion, GMRES + BoomerAMG (examples/src/C_convdif)
+    cd = open(os.path.join(ro, "convdif.txt")).read()
+    steps = [dict(step=int(a), lin=int(b), cmax=float(c), mass=float(d)) for a, b, c, d in
+             re.findall(r"^Time step:\s+(\d+) \|.*\| Lin:\s+(\d+) \| min\(c\)=\s*\S+ max\(c\)=\s*(\S+) mass=(\S+)", cd, re.M)]
+    paths = [dict(path=a, r0=float(b), rel=float(c), iters=int(d)) for a, b, c, d in
+             re.findall(r"^\|\s+(\d+\.\d+) \|\s+[\d.]* \|\s+[\d.]+ \|\s+[\d.]+ \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", cd, re.M)]
+    pins["convdif"] = dict(source="examples/refOutput/convdif.txt:26-35,55-64", steps=steps, paths=paths,
+                           config="64x16x16 cells, 10 growing time steps, presets gmres + poisson (CPU defaults)")
     # analytic unit-test anchors (tests/test_linsys.c:4126-4155, tests/test_setmatrix_from_csr.c:397-417)
     pins["unit"] = dict(norms_of_1_m2_3=dict(L1=6.0, L2=14.0 ** 0.5, Linf=3.0),
                         one_by_one=dict(a=3.0, b=6.0, x_norm=2.0, tol=1e-6))
