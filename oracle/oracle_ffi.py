@@ -47,6 +47,15 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # libgomp sizes its team when it is loaded: a GPU box exposes hundreds of logical CPUs but
+    # gives this process a small share, and an oversubscribed, spinning team turns the small
+    # parity problems into minutes.  Default to the CPUs we may run on (at most 16), passive waits.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(avail, 16))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     L = C.CDLL(build())
     P = C.POINTER
     cp = P(CsrStruct)

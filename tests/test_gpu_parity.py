@@ -338,6 +338,27 @@ def test_gmres_amg_matches_oracle(orc, hd):
     assert rel(rh["x"], ro["x"]) < 1e-8
 
 
+@pytest.mark.parametrize("kdim,precond", [(5, False), (4, True), (30, False)])
+def test_gmres_restarts_match_oracle(orc, hd, kdim, precond):
+    """Restarted GMRES(k) across several cycles (unpreconditioned 12^3 needs ~35 iterations; a
+    Jacobi-only "AMG" with max_levels 1 a few cycles of 4): iteration count, history and solution
+    against the oracle; also x0 != 0."""
+    Ao, b = orc.lap7(12, 12, 12, b_mode=1)
+    Ah = hd.lap7(12, 12, 12)
+    ko = orc.krylov_params(True, krylov_dim=kdim, max_iter=200)
+    kh = hd.KrylovParams.default(True, krylov_dim=kdim, max_iter=200)
+    mo = orc.Amg(Ao, orc.amg_params(True, max_levels=1, relax_coarse=18)) if precond else None
+    mh = hd.Amg(Ah, hd.AmgParams.default(max_levels=1, relax_coarse=18)) if precond else None
+    x0 = np.linspace(-1.0, 1.0, Ao.nrows)
+    for guess in (None, x0):
+        ro = orc.gmres(Ao, b, mo, ko, x0=guess)
+        rh = hd.gmres(Ah, b, mh, kh, x0=guess)
+        assert ro["iters"] > kdim or kdim == 30
+        assert rh["converged"] == ro["converged"] and rh["iters"] == ro["iters"]
+        assert np.allclose(rh["hist"], ro["hist"], rtol=1e-8)
+        assert rel(rh["x"], ro["x"]) < 1e-8
+
+
 def test_edge_cases(orc, hd, pins):
     # 1x1 system 3x = 6 (tests/test_setmatrix_from_csr.c:397-417)
     u = pins["unit"]["one_by_one"]
