@@ -217,33 +217,53 @@ def test_reference_laplacian_driver_unmodified(orc):
     assert row and float(row.group(1)) < 1e-6
 
 
+def _run_convdif(cfg):
+    exe = os.path.join(ROOT, "build", "convdif_ref")
+    if not os.path.exists(exe):
+        pytest.skip("build/convdif_ref not built (needs /root/reference + MPICH at build time)")
+    r = subprocess.run([exe, "-i", cfg, "-v", "1"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    steps = re.findall(r"^Time step:\s+(\d+) \|.*\| Lin:\s+(\d+) \| min\(c\)=\s*\S+ max\(c\)=\s*(\S+) mass=(\S+)", r.stdout, re.M)
+    rows = re.findall(r"^\|\s+(\d+\.\d+) \|\s+[\d.]* \|\s+[\d.]+ \|\s+[\d.]+ \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
+    return r.stdout, steps, rows
+
+
 def test_reference_convdif_driver_unmodified(pins):
     """The reference's second self-contained driver (examples/src/C_convdif/convdif.c: implicit
     convection-diffusion time stepping, nonsymmetric operator, GMRES(30) + BoomerAMG, library mode,
     level annotations), compiled UNMODIFIED against include/ + libhypredrv_amd.so, run with the
-    reference's CPU-default AMG options (examples/convdif-cpudefaults.yml).  Against
-    examples/refOutput/convdif.txt: the initial residual norms of all ten systems and the printed
-    physics (max c, total mass) agree to every printed digit.  Iteration counts are NOT a pin here: the
-    reference takes 64 in total and ends each solve near 1e-9, this build needs 44 and stops as soon as
-    1e-6 is met (hypre's own stopping rule as far as it can be known offline) -- recorded, not hidden."""
-    exe = os.path.join(ROOT, "build", "convdif_ref")
-    if not os.path.exists(exe):
-        pytest.skip("build/convdif_ref not built (needs /root/reference + MPICH at build time)")
-    r = subprocess.run([exe, "-i", "examples/convdif-cpudefaults.yml", "-v", "1"], capture_output=True, text=True, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    reference's CPU-default AMG options.  Against examples/refOutput/convdif.txt: the initial
+    residual norms of all ten systems and the printed physics (max c, total mass) agree to every
+    printed digit, the table carries the same "timestep.system" paths and the aggregate summary."""
+    out, steps, rows = _run_convdif("examples/convdif-cpudefaults.yml")
     ref = pins["convdif"]
-    steps = re.findall(r"^Time step:\s+(\d+) \|.*\| Lin:\s+(\d+) \| min\(c\)=\s*\S+ max\(c\)=\s*(\S+) mass=(\S+)", r.stdout, re.M)
     assert len(steps) == len(ref["steps"]) == 10
     for got, want in zip(steps, ref["steps"]):
         assert int(got[0]) == want["step"]
         assert float(got[2]) == pytest.approx(want["cmax"], rel=2e-3)   # printed with 3 digits
         assert float(got[3]) == pytest.approx(want["mass"], rel=2e-6)   # printed with 7 digits
-        assert 1 <= int(got[1]) <= want["lin"] + 1
-    rows = re.findall(r"^\|\s+(\d+\.\d+) \|\s+[\d.]* \|\s+[\d.]+ \|\s+[\d.]+ \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
+        assert 1 <= int(got[1]) <= want["lin"]
     assert [x[0] for x in rows] == [p["path"] for p in ref["paths"]]        # "1.1" ... "10.10"
     assert [x[1] for x in rows] == [f"{p['r0']:.2e}" for p in ref["paths"]]  # same systems: same ||b - A x0||
     assert all(float(x[2]) < 1e-6 for x in rows)
-    assert "Aggregate Summary:" in r.stdout and "Total number of Non-linear iterations: 10" in r.stdout
+    assert "Aggregate Summary:" in out and "Total number of Non-linear iterations: 10" in out
+
+
+def test_reference_convdif_iteration_counts(pins):
+    """Iteration counts of refOutput/convdif.txt (4 5 5 5 6 7 7 8 8 9, finals 1.8e-10..8.9e-9): the file
+    behaves like relative_tol 1e-8 (the driver's preset gives 1e-6 today; the checked-in outputs are
+    older than the code).  With 1e-8 this build takes 4 5 5 5 5 6 6 6 7 7: identical on the first
+    four systems, at most 2 fewer at the high-CFL end, finals in the same decade.  The bar written
+    here: every count within [ref - 2, ref], every final residual below 1e-8."""
+    _, steps, rows = _run_convdif("examples/convdif-cpudefaults-tol8.yml")
+    ref = pins["convdif"]
+    got = [int(x[3]) for x in rows]
+    want = [p["iters"] for p in ref["paths"]]
+    assert got[:4] == want[:4]
+    assert all(w - 2 <= g <= w for g, w in zip(got, want)), (got, want)
+    assert all(float(x[2]) < 1e-8 for x in rows)
+    for g, w in zip(steps, ref["steps"]):
+        assert float(g[3]) == pytest.approx(w["mass"], rel=2e-6)
 
 
 def test_rccl_transport_single_rank_selftest():
