@@ -21,7 +21,7 @@ class AmgParams(C.Structure):
                 ("relax_down", C.c_int), ("relax_up", C.c_int), ("relax_coarse", C.c_int),
                 ("sweeps_down", C.c_int), ("sweeps_up", C.c_int), ("sweeps_coarse", C.c_int),
                 ("relax_weight", C.c_double), ("outer_weight", C.c_double),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("num_functions", C.c_int)]
 
     @staticmethod
     def default(**kw):
@@ -56,7 +56,7 @@ SYMBOLS = [
     "hda_csr_dims", "hda_csr_download", "hda_lap7_create", "hda_spmv", "hda_relax", "hda_dot",
     "hda_l1_norms", "hda_strength", "hda_pmis", "hda_interp_extpi", "hda_rap", "hda_transpose",
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
-    "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
+    "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest",
 ]
@@ -261,11 +261,15 @@ def lap7(nx, ny, nz, c=(1.0, 1.0, 1.0), want_rhs=True):
 
 
 class Amg:
-    def __init__(self, A, params=None):
+    def __init__(self, A, params=None, dof=None):
         self.A = A
         self.params = params if params is not None else AmgParams.default()
         self.h = C.c_void_p()
-        _check(load().hda_amg_create(C.byref(self.params), A.h, C.byref(self.h)))
+        if dof is None:
+            _check(load().hda_amg_create(C.byref(self.params), A.h, C.byref(self.h)))
+        else:
+            d = np.ascontiguousarray(dof, dtype=np.int32)
+            _check(load().hda_amg_create_dof(C.byref(self.params), A.h, d.ctypes.data_as(C.POINTER(C.c_int)), C.byref(self.h)))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -31,6 +31,7 @@ struct AmgParams {
    double tol      = 0.0;
    int    print_level = 0;
    uint64_t seed = 2747; // PMIS tie-break hash seed
+   int    num_functions = 1; // coarsening.num_functions; > 1 = systems AMG, unknown approach (presets elasticity_2d/3d)
 };
 
 // dependency levels of the local pattern for Gauss-Seidel sweeps (hda_gs.hip)
@@ -61,6 +62,10 @@ struct AmgLevel {
 class Amg {
  public:
    explicit Amg(const AmgParams &p) : prm(p) {}
+   // systems AMG (prm.num_functions > 1): function of every level-0 unknown of the matrix handed to
+   // setup() (for setup_dist: of this rank's rows); empty = (dof_row_offset + i) mod num_functions
+   std::vector<int> dof_func0;
+   long long        dof_row_offset = 0;
    // hypre_BoomerAMGSetup (src/internal/precon.c:107): A is borrowed for level 0.
    void setup(const DCsr &A);
    // Row-partitioned variant: Aloc is this rank's block ([owned | ghost] columns, ghosts =
@@ -122,13 +127,13 @@ class Amg {
 
 // ---- setup kernels (hda_amg_setup.hip); exposed for per-kernel parity tests -------------
 // hypre_BoomerAMGCreateS: smask[k] = 1 iff entry k of A is a strong connection.
-void amg_strength(const DCsr &A, double theta, double max_row_sum, unsigned char *smask);
+void amg_strength(const DCsr &A, double theta, double max_row_sum, unsigned char *smask, const int *dof = nullptr); // dof: function of every unknown (systems AMG), device
 // hypre_BoomerAMGCoarsenPMIS: cf[i] = 1 C, -1 F, -3 special F. row_offset = global id of row 0.
 void amg_pmis(const DCsr &A, const unsigned char *smask, uint64_t seed, int level,
               long long row_offset, int *cf);
 // hypre_BoomerAMGBuildExtPIInterp + InterpTruncation: P (nrows x nc), rows column-sorted.
-void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax,
-                      double trunc_factor, DCsr &P);
+void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax, // trailing dof: as amg_strength
+                      double trunc_factor, DCsr &P, const int *dof = nullptr);
 // hypre_ParCSRMatMat-style product C = X*Y, deterministic accumulation order, rows sorted.
 void spgemm(const DCsr &X, const DCsr &Y, DCsr &C);
 // hypre_BoomerAMGBuildCoarseOperator: Ac = R*(A*P) with R = P^T

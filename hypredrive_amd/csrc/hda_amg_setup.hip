@@ -25,16 +25,18 @@ __global__ __launch_bounds__(256) void k_strength(int n, const int *__restrict__
                                                   const int *__restrict__ cj,
                                                   const double *__restrict__ v, double theta,
                                                   double mrs, unsigned char *__restrict__ smask,
-                                                  int *__restrict__ ns)
-{
+                                                  int *__restrict__ ns, const int *__restrict__ dof)
+{ // dof != nullptr: systems AMG (unknown approach) -- other functions' couplings take no part
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
    const int k0 = rp[i], k1 = rp[i + 1];
    double    diag = 0.0, row_sum = 0.0, row_scale = 0.0;
+   const int fi = dof ? dof[i] : 0;
    for (int k = k0; k < k1; k++)
       if (cj[k] == i) diag = v[k];
    for (int k = k0; k < k1; k++)
    {
+      if (dof && dof[cj[k]] != fi) continue;
       const double a = v[k];
       row_sum += a;
       if (cj[k] == i) continue;
@@ -46,24 +48,24 @@ __global__ __launch_bounds__(256) void k_strength(int n, const int *__restrict__
    for (int k = k0; k < k1; k++)
    {
       int s = 0;
-      if (cj[k] != i && !weak) s = (diag < 0.0) ? (v[k] > theta * row_scale) : (v[k] < theta * row_scale);
+      if (cj[k] != i && !weak && !(dof && dof[cj[k]] != fi)) s = (diag < 0.0) ? (v[k] > theta * row_scale) : (v[k] < theta * row_scale);
       smask[k] = (unsigned char)s;
       cnt += s;
    }
    ns[i] = cnt;
 }
 
-static void strength_ns(const DCsr &A, double theta, double mrs, unsigned char *smask, int *ns)
+static void strength_ns(const DCsr &A, double theta, double mrs, unsigned char *smask, int *ns, const int *dof = nullptr)
 {
    if (A.nrows)
       k_strength<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data(),
-                                                             theta, mrs, smask, ns);
+                                                             theta, mrs, smask, ns, dof);
 }
 
-void amg_strength(const DCsr &A, double theta, double max_row_sum, unsigned char *smask)
+void amg_strength(const DCsr &A, double theta, double max_row_sum, unsigned char *smask, const int *dof)
 {
    DArray<int> ns((size_t)A.nrows + 1);
-   strength_ns(A, theta, max_row_sum, smask, ns.data());
+   strength_ns(A, theta, max_row_sum, smask, ns.data(), dof);
 }
 
 // -------------------------------------------------------------------- PMIS
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(256) void k_interp_build(
    const unsigned char *__restrict__ smask, const int *__restrict__ cf,
    const long long *__restrict__ uofs, const long long *__restrict__ hofs, int *__restrict__ lcol,
    double *__restrict__ lw, int *__restrict__ htab, int pmax, double trunc_factor, int *__restrict__ pcnt,
-   const unsigned char *__restrict__ rowmode)
+   const unsigned char *__restrict__ rowmode, const int *__restrict__ dof)
 {
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
@@ -563,8 +565,8 @@ __global__ __launch_bounds__(256) void k_interp_build(
          else
             diagonal += aij;
       }
-      else if (cf[j] != -3)
-         diagonal += aij; // weak connection lumped into the diagonal
+      else if (cf[j] != -3 && !(dof && dof[j] != dof[i]))
+         diagonal += aij; // weak connection lumped into the diagonal (same function only)
    }
    if (diagonal != 0.0)
       for (int q = 0; q < cnt; q++) W[q] = W[q] / (-diagonal);
@@ -678,7 +680,8 @@ __global__ __launch_bounds__(256) void k_interp_wave(
    int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
    const unsigned char *__restrict__ smask, const int *__restrict__ cf, const int *__restrict__ nsC,
    const long long *__restrict__ uofs, int cap_row, int cap_ub, int cap_nbr, int pmax, double trunc_factor,
-   const unsigned char *__restrict__ rowmode, int *__restrict__ lcol, double *__restrict__ lw, int *__restrict__ pcnt)
+   const unsigned char *__restrict__ rowmode, int *__restrict__ lcol, double *__restrict__ lw, int *__restrict__ pcnt,
+   const int *__restrict__ dof)
 {
    extern __shared__ double ilds[];
    const int    wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -733,7 +736,8 @@ __global__ __launch_bounds__(256) void k_interp_wave(
             else if (st && cfj == -1) { t = T_SF; cntk = nsC[j]; }
             rcol[k]  = j;
             rval[k]  = v[k0 + k];
-            rtype[k] = t | (cfj == -3 ? 8 : 0) | (cfj == 1 ? 16 : 0);
+            // bit 8: never lumped into the diagonal (special F point, or another function's unknown)
+            rtype[k] = t | ((cfj == -3 || (dof && dof[j] != dof[i])) ? 8 : 0) | (cfj == 1 ? 16 : 0);
          }
          int incl = cntk; // inclusive scan over the wave
          for (int o = 1; o < 64; o <<= 1)
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(256) void k_interp_gather(int n, const long long *_
 }
 
 void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax,
-                      double trunc_factor, DCsr &P)
+                      double trunc_factor, DCsr &P, const int *dof)
 {
    const int n = A.nrows;
    const int g = ceil_div(std::max(n, 1), 256);
@@ -1158,14 +1162,14 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
       }
       k_interp_wave<<<std::min(ceil_div(n, 4), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf,
                                                                           nsC.data(), uofs.data(), cap_row, cap_ub, cap_nbr, pmax, trunc_factor,
-                                                                          rowmode.data(), lcol.data(), lw.data(), pcnt.data());
+                                                                          rowmode.data(), lcol.data(), lw.data(), pcnt.data(), dof);
       if (tot_h)
          k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
-                                               lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), rowmode.data());
+                                               lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), rowmode.data(), dof);
    }
    else
       k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
-                                            lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), nullptr);
+                                            lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), nullptr, dof);
    HDA_TRACE("  interp: build done");
    P.nrows = n;
    P.ncols = nc;
@@ -1721,6 +1725,14 @@ void Amg::build_smoother_data(int l)
    if (!last) { spmv_prepare(lv.P); spmv_prepare(lv.R); }
 }
 
+__global__ __launch_bounds__(256) void k_cmark(int n, const int *__restrict__ cf, int *__restrict__ m);
+__global__ __launch_bounds__(256) void k_coarse_dof(int n, const int *__restrict__ cf, const int *__restrict__ cidx,
+                                                    const int *__restrict__ dof, int *__restrict__ dofc)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n && cf[i] == 1) dofc[cidx[i]] = dof[i];
+}
+
 void Amg::build_hierarchy(const DCsr &A)
 {
    HDA_REQUIRE(prm.coarsen_type == 8 || prm.coarsen_type == 10, "device AMG setup implements PMIS (8) and, on one rank, HMIS (10) coarsening");
@@ -1744,6 +1756,19 @@ void Amg::build_hierarchy(const DCsr &A)
    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double, std::milli>(b - a).count();
    };
+   // function of every unknown on the current level (systems AMG): the user's dof_func or i mod nf
+   DArray<int> dof_cur;
+   if (prm.num_functions > 1)
+   {
+      HDA_REQUIRE(dof_func0.empty() || (int)dof_func0.size() == A.nrows, "dof_func length differs from the number of rows");
+      std::vector<int> d0 = dof_func0;
+      if (d0.empty())
+      {
+         d0.resize((size_t)std::max(A.nrows, 1));
+         for (int i = 0; i < A.nrows; i++) d0[(size_t)i] = (int)((dof_row_offset + i) % prm.num_functions);
+      }
+      dof_cur.upload(d0.data(), d0.size());
+   }
    while (not_finished)
    {
       const DCsr &Al = level_A(lvl);
@@ -1752,7 +1777,8 @@ void Amg::build_hierarchy(const DCsr &A)
       DArray<int>           ns((size_t)n + 1), cf((size_t)n);
       HDA_TRACE("level %d: strength (n=%d nnz=%d)", lvl, n, Al.nnz);
       auto t0 = tick();
-      strength_ns(Al, prm.strong_th, prm.max_row_sum, sm.data(), ns.data());
+      const int *dof = (prm.num_functions > 1) ? dof_cur.data() : nullptr;
+      strength_ns(Al, prm.strong_th, prm.max_row_sum, sm.data(), ns.data(), dof);
       HDA_TRACE("level %d: pmis", lvl);
       auto t1 = tick();
       if (prm.coarsen_type == 10) amg_rs_first_pass(Al, sm.data(), ns.data(), cf.data());
@@ -1760,13 +1786,21 @@ void Amg::build_hierarchy(const DCsr &A)
       HDA_TRACE("level %d: interp", lvl);
       auto t2 = tick();
       DCsr P;
-      amg_interp_extpi(Al, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, P);
+      amg_interp_extpi(Al, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, P, dof);
       auto t3 = tick();
       const int nc = P.ncols;
       if (nc == 0 || nc == n || nc < prm.min_coarse_size) break;
       AmgLevel &L = levels[lvl];
       L.cf        = std::move(cf);
       L.P         = std::move(P);
+      if (dof)
+      { // coarse unknowns keep the function of their fine C point
+         DArray<int> m((size_t)n + 1), cidx((size_t)n + 1), dnext((size_t)std::max(nc, 1));
+         k_cmark<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), m.data());
+         exclusive_scan(n, m.data(), cidx.data(), nullptr);
+         k_coarse_dof<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), cidx.data(), dof_cur.data(), dnext.data());
+         dof_cur = std::move(dnext);
+      }
       HDA_TRACE("level %d: transpose", lvl);
       transpose(L.P, L.R);
       HDA_TRACE("level %d: rap", lvl);
@@ -1836,6 +1870,21 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
    HDA_TRACE("setup_dist: gathering the operator on %d ranks (%s)", cm.size, cm.name());
    DCsr G0;
    gather_global(Aloc, part0, ghost_gids0, G0);
+   if (prm.num_functions > 1)
+   { // the replicated build needs the function of every GLOBAL unknown
+      const int nloc = Aloc.nrows;
+      std::vector<int> mine = dof_func0;
+      if (mine.empty())
+      {
+         mine.resize((size_t)std::max(nloc, 1));
+         for (int i = 0; i < nloc; i++) mine[(size_t)i] = (int)((dof_row_offset + i) % prm.num_functions);
+      }
+      std::vector<char> all;
+      std::vector<long> counts;
+      cm.allgatherv_bytes(mine.data(), 4L * nloc, all, counts);
+      dof_func0.assign((const int *)all.data(), (const int *)all.data() + G0.nrows);
+      dof_row_offset = 0;
+   }
    build_hierarchy(G0); // replicated, identical on every rank
    dist  = true;
    int L = (int)levels.size();
@@ -2854,7 +2903,7 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
                                  const std::vector<long long> &ghost_gids0)
 {
    Comm &cm = Comm::world();
-   HDA_REQUIRE(prm.coarsen_type == 8 && prm.interp_type == 6, "partitioned setup: PMIS + extended+i only");
+   HDA_REQUIRE(prm.coarsen_type == 8 && prm.interp_type == 6 && prm.num_functions <= 1, "partitioned setup: scalar PMIS + extended+i only");
    static const long long rep_rows = getenv("HDA_REPLICATE_ROWS") ? atoll(getenv("HDA_REPLICATE_ROWS")) : 100000;
    const bool verbose = getenv("HDA_VERBOSE") != nullptr;
    auto tick = [&]() {

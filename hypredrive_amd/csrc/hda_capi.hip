@@ -75,7 +75,7 @@ extern "C" void hda_amg_default_params(hda_amg_params *p)
    p->max_coarse_size = d.max_coarse_size; p->min_coarse_size = d.min_coarse_size; p->max_levels = d.max_levels;
    p->relax_down = d.relax_down; p->relax_up = d.relax_up; p->relax_coarse = d.relax_coarse;
    p->sweeps_down = d.sweeps_down; p->sweeps_up = d.sweeps_up; p->sweeps_coarse = d.sweeps_coarse;
-   p->relax_weight = d.relax_weight; p->outer_weight = d.outer_weight; p->seed = d.seed;
+   p->relax_weight = d.relax_weight; p->outer_weight = d.outer_weight; p->seed = d.seed; p->num_functions = d.num_functions;
 }
 extern "C" void hda_krylov_default_params(hda_krylov_params *p, int gmres)
 {
@@ -92,6 +92,7 @@ static AmgParams to_params(const hda_amg_params *p)
    a.relax_down = p->relax_down; a.relax_up = p->relax_up; a.relax_coarse = p->relax_coarse;
    a.sweeps_down = p->sweeps_down; a.sweeps_up = p->sweeps_up; a.sweeps_coarse = p->sweeps_coarse;
    a.relax_weight = p->relax_weight; a.outer_weight = p->outer_weight; a.seed = p->seed;
+   a.num_functions = std::max(p->num_functions, 1);
    return a;
 }
 static KrylovParams to_kparams(const hda_krylov_params *p)
@@ -346,6 +347,17 @@ extern "C" int hda_amg_create(const hda_amg_params *p, hda_csr_t A, hda_amg_t *o
    auto h = std::make_unique<hda_amg_s>();
    h->amg = std::make_unique<Amg>(to_params(p));
    h->A   = A;
+   h->amg->setup(A->get());
+   *out = h.release();
+   HDA_CATCH
+}
+extern "C" int hda_amg_create_dof(const hda_amg_params *p, hda_csr_t A, const int *dof_func, hda_amg_t *out)
+{
+   HDA_TRY
+   auto h = std::make_unique<hda_amg_s>();
+   h->amg = std::make_unique<Amg>(to_params(p));
+   h->A   = A;
+   if (dof_func) h->amg->dof_func0.assign(dof_func, dof_func + A->get().nrows);
    h->amg->setup(A->get());
    *out = h.release();
    HDA_CATCH

@@ -945,6 +945,15 @@ HY_SETTER(HYPRE_BoomerAMGSetMaxLevels, HYPRE_Int, s->ap.max_levels = v)
 HY_SETTER(HYPRE_BoomerAMGSetMaxIter, HYPRE_Int, s->ap.max_iter = v)
 HY_SETTER(HYPRE_BoomerAMGSetMaxRowSum, HYPRE_Real, s->ap.max_row_sum = v)
 HY_SETTER(HYPRE_BoomerAMGSetNumFunctions, HYPRE_Int, s->num_functions = v)
+// dof_func[i] in [0, num_functions) for the rows this rank owns; the array is COPIED (hypre takes
+// ownership of a hypre_TAlloc'ed array instead -- reference src/internal/amg.c:792-862)
+extern "C" HYPRE_Int HYPRE_BoomerAMGSetDofFunc(HYPRE_Solver s, HYPRE_Int *dof_func)
+{
+   HY_TRY
+   HDA_REQUIRE(s && s->kind == HDA_SOLVER_AMG, "BoomerAMGSetDofFunc: not a BoomerAMG handle");
+   s->dof_func_ptr = dof_func; // length is known at setup (local rows): copied there
+   HY_CATCH
+}
 HY_SETTER(HYPRE_BoomerAMGSetFilterFunctions, HYPRE_Int, (void)v)
 HY_SETTER(HYPRE_BoomerAMGSetSmoothType, HYPRE_Int, s->smooth_type = v)
 HY_SETTER(HYPRE_BoomerAMGSetSmoothNumSweeps, HYPRE_Int, (void)v)
@@ -1003,12 +1012,17 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    HDA_REQUIRE(A && A->assembled, "BoomerAMGSetup needs an assembled matrix");
    // features of the reference's parameter surface that this build does not implement
    HDA_REQUIRE(s->agg_num_levels == 0, "aggressive coarsening (aggressive.num_levels > 0) is not implemented on MI355X yet");
-   HDA_REQUIRE(s->num_functions <= 1, "systems AMG (coarsening.num_functions > 1) is not implemented on MI355X yet");
    HDA_REQUIRE(s->smooth_num_levels == 0, "complex smoothers (smoother.num_levels > 0: FSAI/ILU) are not implemented on MI355X yet");
    HDA_REQUIRE(s->cycle_type == 1, "only V-cycles (cycle type 1) are implemented");
    HDA_REQUIRE(s->restriction == 0, "only P^T restriction (restriction_type 0) is implemented");
    HDA_REQUIRE(s->relax_order == 0, "only lexicographic relaxation order (relaxation.order 0) is implemented");
-   s->amg = std::make_unique<Amg>(s->ap);
+   s->ap.num_functions = std::max(s->num_functions, 1);
+   s->amg              = std::make_unique<Amg>(s->ap);
+   if (s->ap.num_functions > 1)
+   {
+      if (s->dof_func_ptr) s->amg->dof_func0.assign(s->dof_func_ptr, s->dof_func_ptr + A->nloc);
+      s->amg->dof_row_offset = A->ilower; // hypre's default: (global row) mod num_functions
+   }
    if (Comm::world().size > 1)
    {
       // partitioned (default): every setup phase works on the row blocks; replicated
@@ -1016,7 +1030,7 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
       // the specification the partitioned setup is checked against (HDA_DIST_CHECK=1)
       const char *mode = getenv("HDA_DIST_SETUP");
       // (HMIS = sequential Ruge pass: only the replicated scheme can run it, on the gathered operator)
-      if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+      if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8 || s->ap.num_functions > 1) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
       else s->amg->setup_dist_partitioned(A->A, A->halo, A->part, A->ghost_gids);
    }
    else s->amg->setup(A->A);

@@ -156,6 +156,7 @@ struct hypredrv_struct {
    bool           precon_is_setup = false;
    PreconCookie   cookie{nullptr};
    Stats          stats;
+   std::vector<int> dofmap; // function / field label of every locally owned unknown
    int            current_system_index = -1;
    int            last_iters = 0, last_converged = 0;
    double         last_rel = 0.0, last_setup_s = 0.0, last_solve_s = 0.0;
@@ -913,11 +914,50 @@ extern "C" uint32_t HYPREDRV_LinearSystemPrint(HYPREDRV_t h)
 UNSUPPORTED(HYPREDRV_LinearSystemSetDiscreteGradient(HYPREDRV_t, HYPRE_Matrix), "AMS/ADS discrete gradient")
 UNSUPPORTED(HYPREDRV_LinearSystemSetDiscreteCurl(HYPREDRV_t, HYPRE_Matrix), "ADS discrete curl")
 UNSUPPORTED(HYPREDRV_LinearSystemSetCoordinates(HYPREDRV_t, HYPRE_Vector, HYPRE_Vector, HYPRE_Vector), "AMS/ADS coordinates")
-UNSUPPORTED(HYPREDRV_LinearSystemSetDofmap(HYPREDRV_t, int, const int *), "MGR dofmap")
-UNSUPPORTED(HYPREDRV_LinearSystemSetInterleavedDofmap(HYPREDRV_t, int, int), "MGR dofmap")
-UNSUPPORTED(HYPREDRV_LinearSystemSetContiguousDofmap(HYPREDRV_t, int, int), "MGR dofmap")
-UNSUPPORTED(HYPREDRV_LinearSystemPrintDofmap(HYPREDRV_t, const char *), "MGR dofmap")
-UNSUPPORTED(HYPREDRV_LinearSystemSetNearNullSpace(HYPREDRV_t, int, int, const HYPRE_Complex *), "near-null-space vectors")
+// degree-of-freedom maps (reference src/HYPREDRV.c:2680-2724): here they feed BoomerAMG's dof_func when
+// systems AMG is selected (coarsening.num_functions > 1, reference src/internal/amg.c:792-862)
+extern "C" uint32_t HYPREDRV_LinearSystemSetDofmap(HYPREDRV_t h, int size, const int *dofmap)
+{
+   CHECK_INIT_OBJ(h);
+   if (size < 0 || (size > 0 && !dofmap)) return err_set(ERR_INVALID_VAL, "SetDofmap: bad size or NULL map");
+   h->dofmap.assign(dofmap, dofmap + size);
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_LinearSystemSetInterleavedDofmap(HYPREDRV_t h, int num_local_blocks, int num_dof_types)
+{
+   CHECK_INIT_OBJ(h);
+   if (num_local_blocks < 0 || num_dof_types <= 0) return err_set(ERR_INVALID_VAL, "SetInterleavedDofmap: bad block or type count");
+   h->dofmap.resize((size_t)num_local_blocks * num_dof_types);
+   for (int i = 0; i < num_local_blocks; i++)
+      for (int j = 0; j < num_dof_types; j++) h->dofmap[(size_t)i * num_dof_types + j] = j;
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_LinearSystemSetContiguousDofmap(HYPREDRV_t h, int num_local_blocks, int num_dof_types)
+{
+   CHECK_INIT_OBJ(h);
+   if (num_local_blocks < 0 || num_dof_types <= 0) return err_set(ERR_INVALID_VAL, "SetContiguousDofmap: bad block or type count");
+   h->dofmap.resize((size_t)num_local_blocks * num_dof_types);
+   for (int i = 0; i < num_dof_types; i++)
+      for (int j = 0; j < num_local_blocks; j++) h->dofmap[(size_t)i * num_local_blocks + j] = i;
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_LinearSystemPrintDofmap(HYPREDRV_t h, const char *filename)
+{
+   CHECK_INIT_OBJ(h);
+   if (!filename) return err_set(ERR_INVALID_VAL, "PrintDofmap: NULL file name");
+   char suffix[16];
+   snprintf(suffix, sizeof(suffix), ".%05d", h->mypid);
+   FILE *f = fopen((std::string(filename) + suffix).c_str(), "w");
+   if (!f) return err_set(ERR_FILE_NOT_FOUND, std::string("cannot write ") + filename);
+   fprintf(f, "%zu\n", h->dofmap.size());
+   for (int v : h->dofmap) fprintf(f, "%d\n", v);
+   fclose(f);
+   return g_err;
+}
+// rigid-body modes only matter to nodal coarsening / interpolation vectors (reference amg.c:600-660),
+// which this build does not have: the call is accepted so drivers written for it run, the
+// vectors are not used
+extern "C" uint32_t HYPREDRV_LinearSystemSetNearNullSpace(HYPREDRV_t h, int, int, const HYPRE_Complex *) { CHECK_INIT_OBJ(h); return g_err; }
 UNSUPPORTED(HYPREDRV_LinearSystemSetNullSpace(HYPREDRV_t, int, int, const HYPRE_Complex *), "null-space projection")
 UNSUPPORTED(HYPREDRV_StateVectorSet(HYPREDRV_t, int, HYPRE_IJVector *), "state vectors")
 UNSUPPORTED(HYPREDRV_StateVectorGetValues(HYPREDRV_t, int, HYPRE_Complex **), "state vectors")
@@ -1112,6 +1152,22 @@ extern "C" uint32_t HYPREDRV_PreconCreate(HYPREDRV_t h)
       return err_set(ERR_INVALID_PRECON | HYPREDRV_ERROR_UNSUPPORTED_AMD,
                      "preconditioner '" + p.method_name + "' is not implemented on MI355X yet (BoomerAMG only)");
    amg_create(p.amg, &h->precon);
+   // hypredrv_AMGSetDofFunc (reference src/internal/amg.c:792-862): the dofmap names the function of
+   // every local unknown when its labels fit [0, num_functions); otherwise hypre's interleaved default
+   if (h->precon && p.amg.num_functions > 1 && !h->dofmap.empty())
+   {
+      bool fits = true;
+      for (int v : h->dofmap) fits = fits && v >= 0 && v < p.amg.num_functions;
+      long long bad[1] = {fits ? 0 : 1};
+      Comm::world().allreduce_host(bad, 1, 1);
+      if (bad[0] == 0)
+      {
+         if (h->mat_A && (int)h->dofmap.size() != h->mat_A->nloc)
+            return err_set(ERR_INVALID_VAL, "Dofmap size (" + std::to_string(h->dofmap.size()) + ") does not match the number of local matrix rows (" +
+                                               std::to_string(h->mat_A->nloc) + ")");
+         HYPRE_BoomerAMGSetDofFunc(h->precon, h->dofmap.data());
+      }
+   }
    consume_hypre_errors();
    API_CATCH
 }

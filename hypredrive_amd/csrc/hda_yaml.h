@@ -2,6 +2,8 @@
 // src/internal/yaml.c) and the argument structures it fills (src/internal/args.c:30-45,
 // src/internal/pcg.c:15-25, src/internal/gmres.c:16-27, src/internal/amg.c:23-90,120-238).
 #pragma once
+#include <cstdlib>
+#include <cstring>
 
 #include <cstdint>
 #include <memory>
@@ -74,6 +76,16 @@ struct AmgArgs { // AMG_args, GPU-branch defaults of src/internal/amg.c:120-238
    double weight = 1.0, outer_weight = 1.0;
    // complex smoother
    int    smooth_type = 5, smooth_num_levels = 0, smooth_num_sweeps = 1;
+   // The reference picks these defaults at COMPILE time (#ifdef HYPRE_USING_GPU, amg.c:138-146,
+   // 183-189); this library is a GPU build.  HYPREDRV_AMD_DEFAULTS=cpu makes it start from the
+   // defaults of a CPU build instead (HMIS, hybrid l1 Gauss-Seidel 13/14, no mod_rap2 /
+   // keep_transpose): the settings the reference's checked-in outputs were produced with, for
+   // drivers that leave no other way to select them.
+   AmgArgs()
+   {
+      const char *e = getenv("HYPREDRV_AMD_DEFAULTS");
+      if (e && !strcmp(e, "cpu")) { type = 10; down_type = 13; up_type = 14; mod_rap2 = 0; keep_transpose = 0; }
+   }
 };
 struct PreconArgs {
    int         method = 0; // 0 boomeramg, 1 mgr, 2 ilu, 3 fsai, ... 99 none

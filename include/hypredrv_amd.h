@@ -39,6 +39,7 @@ typedef struct {
    int      sweeps_down, sweeps_up, sweeps_coarse;
    double   relax_weight, outer_weight;
    uint64_t seed;
+   int      num_functions; /* coarsening.num_functions (1); > 1: unknown-based systems AMG, functions interleaved */
 } hda_amg_params;
 
 /* PCG_args src/internal/pcg.c:15-25 / GMRES_args src/internal/gmres.c:16-27 */
@@ -97,6 +98,9 @@ int hda_spgemm(hda_csr_t X, hda_csr_t Y, hda_csr_t *C);
 /* ---- hierarchy + V-cycle ----------------------------------------------------------- */
 /* HYPRE_BoomerAMGCreate/Setup (src/internal/precon.c:107) */
 int hda_amg_create(const hda_amg_params *p, hda_csr_t A, hda_amg_t *out);
+/* systems AMG (params->num_functions > 1): dof_func[i] in [0, num_functions) names the function of
+ * unknown i (reference src/internal/amg.c:792-862 hypredrv_AMGSetDofFunc); NULL = i mod num_functions */
+int hda_amg_create_dof(const hda_amg_params *params, hda_csr_t A, const int *dof_func, hda_amg_t *out);
 int hda_amg_destroy(hda_amg_t h);
 int hda_amg_num_levels(hda_amg_t h);
 /* which: 0 = A_l, 1 = P_l, 2 = R_l; returns a borrowed handle (do not destroy) */

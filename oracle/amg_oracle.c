@@ -43,6 +43,7 @@ orc_amg_default_params(orc_amg_params *p, int gpu_defaults)
    p->relax_weight    = 1.0;
    p->outer_weight    = 1.0;
    p->seed            = 2747;
+   p->num_functions   = 1;
 }
 
 /* src/internal/pcg.c:15-25, src/internal/gmres.c:16-27 */
@@ -412,6 +413,17 @@ orc_gselim(double *a, double *x, int n)
 void
 orc_strength(const orc_csr *A, double theta, double max_row_sum, unsigned char *smask)
 {
+   orc_strength_dof(A, theta, max_row_sum, NULL, smask);
+}
+
+/* Systems AMG, unknown approach (coarsening.num_functions > 1, src/internal/amg.c:147,792-862;
+ * presets elasticity_2d/3d, src/internal/presets.c:19-27): couplings between different
+ * functions take no part in the strength decision -- neither in the row maximum, nor in the
+ * row sum, nor as strong connections (hypre_BoomerAMGCreateS).  dof == NULL:
+ * scalar problem. */
+void
+orc_strength_dof(const orc_csr *A, double theta, double max_row_sum, const int *dof, unsigned char *smask)
+{
    for (int i = 0; i < A->nrows; i++)
    {
       double diag = 0.0, row_sum = 0.0, row_scale = 0.0;
@@ -420,6 +432,7 @@ orc_strength(const orc_csr *A, double theta, double max_row_sum, unsigned char *
          if (A->col[k] == i) diag = A->val[k];
       for (int k = k0; k < k1; k++)
       {
+         if (dof && dof[A->col[k]] != dof[i]) continue;
          row_sum += A->val[k];
          if (A->col[k] == i) continue;
          if (diag < 0.0)
@@ -431,7 +444,7 @@ orc_strength(const orc_csr *A, double theta, double max_row_sum, unsigned char *
       for (int k = k0; k < k1; k++)
       {
          int s = 0;
-         if (A->col[k] != i && !weak_row)
+         if (A->col[k] != i && !weak_row && !(dof && dof[A->col[k]] != dof[i]))
          {
             if (diag < 0.0)
                s = A->val[k] > theta * row_scale;
@@ -762,6 +775,16 @@ orc_csr *
 orc_interp_extpi(const orc_csr *A, const unsigned char *smask, const int *cf, int pmax,
                  double trunc_factor)
 {
+   return orc_interp_extpi_dof(A, smask, cf, pmax, trunc_factor, NULL);
+}
+
+/* dof != NULL (num_functions > 1): a weak connection to another function is dropped instead of
+ * being lumped into the diagonal (hypre's ext+i: "if (num_functions == 1 || dof_func[i] ==
+ * dof_func[i1]) diagonal += a_ii1"). */
+orc_csr *
+orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf, int pmax,
+                     double trunc_factor, const int *dof)
+{
    int  n    = A->nrows;
    int *cidx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
    int  nc   = 0;
@@ -864,7 +887,7 @@ orc_interp_extpi(const orc_csr *A, const unsigned char *smask, const int *cf, in
                else
                   diagonal += aij;
             }
-            else if (cf[j] != ORC_SF_PT)
+            else if (cf[j] != ORC_SF_PT && !(dof && dof[j] != dof[i]))
                diagonal += aij; /* weak connection lumped into the diagonal */
          }
          if (diagonal != 0.0)
@@ -998,6 +1021,12 @@ l1_option_for(int relax_type)
 orc_amg *
 orc_amg_setup(const orc_csr *A0, const orc_amg_params *p)
 {
+   return orc_amg_setup_dof(A0, p, NULL);
+}
+
+orc_amg *
+orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
+{
    orc_amg *h = (orc_amg *)calloc(1, sizeof(orc_amg));
    h->p       = *p;
    int maxl   = p->max_levels > 0 ? p->max_levels : 1;
@@ -1020,6 +1049,13 @@ orc_amg_setup(const orc_csr *A0, const orc_amg_params *p)
    }
    int lvl = 0;
    int not_finished = (h->A[0]->nrows > p->max_coarse_size) && (maxl > 1);
+   /* function of every unknown on the current level (num_functions > 1), inherited by C points */
+   int *dof = NULL;
+   if (p->num_functions > 1)
+   {
+      dof = (int *)malloc(sizeof(int) * (size_t)(A0->nrows > 0 ? A0->nrows : 1));
+      for (int i = 0; i < A0->nrows; i++) dof[i] = dof0 ? dof0[i] : i % p->num_functions;
+   }
    while (not_finished)
    {
       const orc_csr *A   = h->A[lvl];
@@ -1027,7 +1063,7 @@ orc_amg_setup(const orc_csr *A0, const orc_amg_params *p)
       int            nnz = A->rowptr[n];
       unsigned char *sm  = (unsigned char *)malloc((size_t)(nnz > 0 ? nnz : 1));
       int           *cf  = (int *)malloc(sizeof(int) * (size_t)n);
-      orc_strength(A, p->strong_th, p->max_row_sum, sm);
+      orc_strength_dof(A, p->strong_th, p->max_row_sum, dof, sm);
       if (p->coarsen_type == 8)
          orc_pmis(A, sm, p->seed, lvl, 0, cf);
       else
@@ -1040,13 +1076,20 @@ orc_amg_setup(const orc_csr *A0, const orc_amg_params *p)
          break;
       }
       h->cf[lvl] = cf;
-      h->P[lvl]  = orc_interp_extpi(A, sm, cf, p->pmax, p->trunc_factor);
+      h->P[lvl]  = orc_interp_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof);
+      if (dof)
+      { /* coarse unknowns keep the function of their fine C point */
+         int q = 0;
+         for (int i = 0; i < n; i++)
+            if (cf[i] == ORC_C_PT) dof[q++] = dof[i];
+      }
       h->R[lvl]  = orc_csr_transpose(h->P[lvl]);
       free(sm);
       h->A[lvl + 1] = orc_rap(A, h->P[lvl]);
       lvl++;
       if (lvl >= maxl - 1 || nc <= p->max_coarse_size) not_finished = 0;
    }
+   free(dof);
    h->nlev = lvl + 1;
    for (int l = 0; l < h->nlev; l++)
    {

@@ -51,6 +51,7 @@ typedef struct {
    double relax_weight;    /* 1.0 */
    double outer_weight;    /* 1.0 */
    uint64_t seed;          /* PMIS tie-break hash seed */
+   int    num_functions;   /* coarsening.num_functions (1); > 1 = unknown-based systems AMG */
 } orc_amg_params;
 
 typedef struct orc_amg orc_amg; /* hierarchy handle */
@@ -92,15 +93,20 @@ void   orc_relax(const orc_csr *A, const double *l1, int type, double weight,
 
 /* Setup pieces (exposed for per-kernel parity tests) */
 void orc_strength(const orc_csr *A, double theta, double max_row_sum, unsigned char *smask);
+void orc_strength_dof(const orc_csr *A, double theta, double max_row_sum, const int *dof, unsigned char *smask);
 void orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
               int64_t row_offset, int *cf); /* cf: 1 C, -1 F, -3 special F */
 void orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf);
 orc_csr *orc_interp_extpi(const orc_csr *A, const unsigned char *smask, const int *cf,
                           int pmax, double trunc_factor);
+orc_csr *orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf,
+                              int pmax, double trunc_factor, const int *dof);
 orc_csr *orc_rap(const orc_csr *A, const orc_csr *P);
 
 /* Hierarchy */
 orc_amg *orc_amg_setup(const orc_csr *A, const orc_amg_params *p);
+/* dof_func of level 0 for p->num_functions > 1 (NULL: i mod num_functions, hypre's default) */
+orc_amg *orc_amg_setup_dof(const orc_csr *A, const orc_amg_params *p, const int *dof);
 void     orc_amg_free(orc_amg *h);
 int      orc_amg_num_levels(const orc_amg *h);
 const orc_csr *orc_amg_A(const orc_amg *h, int lvl);

@@ -26,7 +26,7 @@ class AmgParams(C.Structure):
                 ("relax_down", C.c_int), ("relax_up", C.c_int), ("relax_coarse", C.c_int),
                 ("sweeps_down", C.c_int), ("sweeps_up", C.c_int), ("sweeps_coarse", C.c_int),
                 ("relax_weight", C.c_double), ("outer_weight", C.c_double),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("num_functions", C.c_int)]
 
 
 class KrylovParams(C.Structure):
@@ -85,6 +85,11 @@ def lib():
     L.orc_rap.argtypes = [cp, cp]
     L.orc_amg_setup.restype = C.c_void_p
     L.orc_amg_setup.argtypes = [cp, P(AmgParams)]
+    L.orc_amg_setup_dof.restype = C.c_void_p
+    L.orc_amg_setup_dof.argtypes = [cp, P(AmgParams), ip]
+    L.orc_strength_dof.argtypes = [cp, C.c_double, C.c_double, ip, P(C.c_ubyte)]
+    L.orc_interp_extpi_dof.restype = cp
+    L.orc_interp_extpi_dof.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double, ip]
     L.orc_amg_free.argtypes = [C.c_void_p]
     L.orc_amg_num_levels.argtypes = [C.c_void_p]
     L.orc_amg_A.restype = cp
@@ -224,9 +229,13 @@ def relax(A, l1, rtype, weight, b, x):
     return x
 
 
-def strength(A, theta=0.25, max_row_sum=0.9):
+def strength(A, theta=0.25, max_row_sum=0.9, dof=None):
     sm = np.zeros(max(A.nnz, 1), dtype=np.uint8)
-    lib().orc_strength(A.ptr, theta, max_row_sum, sm.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    if dof is None:
+        lib().orc_strength(A.ptr, theta, max_row_sum, sm.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    else:
+        d = np.ascontiguousarray(dof, dtype=np.int32)
+        lib().orc_strength_dof(A.ptr, theta, max_row_sum, d.ctypes.data_as(C.POINTER(C.c_int)), sm.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return sm[:A.nnz]
 
 
@@ -246,9 +255,13 @@ def rs_first_pass(A, smask):
     return cf
 
 
-def interp_extpi(A, smask, cf, pmax=4, trunc_factor=0.0):
+def interp_extpi(A, smask, cf, pmax=4, trunc_factor=0.0, dof=None):
     sm = np.ascontiguousarray(smask, dtype=np.uint8)
     cfa = np.ascontiguousarray(cf, dtype=np.int32)
+    if dof is not None:
+        d = np.ascontiguousarray(dof, dtype=np.int32)
+        return Csr(lib().orc_interp_extpi_dof(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), cfa.ctypes.data_as(C.POINTER(C.c_int)),
+                                              pmax, trunc_factor, d.ctypes.data_as(C.POINTER(C.c_int))))
     return Csr(lib().orc_interp_extpi(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)),
                                       cfa.ctypes.data_as(C.POINTER(C.c_int)), pmax,
                                       trunc_factor))
@@ -259,10 +272,14 @@ def rap(A, P):
 
 
 class Amg:
-    def __init__(self, A, params=None):
+    def __init__(self, A, params=None, dof=None):
         self.A = A
         self.params = params if params is not None else amg_params(True)
-        self.h = lib().orc_amg_setup(A.ptr, C.byref(self.params))
+        if dof is None:
+            self.h = lib().orc_amg_setup(A.ptr, C.byref(self.params))
+        else:
+            d = np.ascontiguousarray(dof, dtype=np.int32)
+            self.h = lib().orc_amg_setup_dof(A.ptr, C.byref(self.params), d.ctypes.data_as(C.POINTER(C.c_int)))
 
     def __del__(self):
         if getattr(self, "h", None):

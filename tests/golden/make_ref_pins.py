@@ -59,6 +59,11 @@ def main():
              re.findall(r"^\|\s+(\d+\.\d+) \|\s+[\d.]* \|\s+[\d.]+ \|\s+[\d.]+ \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", cd, re.M)]
     pins["convdif"] = dict(source="examples/refOutput/convdif.txt:26-35,55-64", steps=steps, paths=paths,
                            config="64x16x16 cells, 10 growing time steps, presets gmres + poisson (CPU defaults)")
+    # third example driver: linear elasticity, PCG + systems AMG (examples/src/C_elasticity)
+    el = open(os.path.join(ro, "elasticity.txt")).read()
+    pins["elasticity"] = dict(source="examples/refOutput/elasticity.txt:9-16,37-41", stats=stats_rows(el),
+                              config="30x10x10 nodes Q1 hexahedra, 3 dofs/node, presets pcg + elasticity_3D "
+                                     "(num_functions 3, strong_th 0.8), CPU defaults")
     # analytic unit-test anchors (tests/test_linsys.c:4126-4155, tests/test_setmatrix_from_csr.c:397-417)
     pins["unit"] = dict(norms_of_1_m2_3=dict(L1=6.0, L2=14.0 ** 0.5, Linf=3.0),
                         one_by_one=dict(a=3.0, b=6.0, x_norm=2.0, tol=1e-6))

@@ -266,6 +266,48 @@ def test_reference_convdif_iteration_counts(pins):
         assert float(g[3]) == pytest.approx(w["mass"], rel=2e-6)
 
 
+def test_reference_elasticity_driver_unmodified(pins):
+    """Third self-contained driver of the reference (examples/src/C_elasticity/elasticity.c: Q1
+    hexahedra, 3 unknowns per node, interleaved dofmap, presets pcg + elasticity_3D = systems AMG
+    with num_functions 3 and strong_th 0.8), UNMODIFIED.  The driver leaves no way to pick
+    relaxation or coarsening, so the CPU-build defaults of the reference are selected with
+    HYPREDRV_AMD_DEFAULTS=cpu; examples/refOutput/elasticity.txt:37-41 then reads 21 iterations,
+    r0 1.79e+01, 2.66e-07 -- this build: 21 iterations, 1.79e+01, 2.97e-07."""
+    exe = os.path.join(ROOT, "build", "elasticity_ref")
+    if not os.path.exists(exe):
+        pytest.skip("build/elasticity_ref not built (needs /root/reference + MPICH at build time)")
+    r = subprocess.run([exe, "-v", "1"], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, HYPREDRV_AMD_DEFAULTS="cpu"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rows = re.findall(r"^\|\s+(\d+) \|\s+([\d.]*) \|\s+([\d.]+) \|\s+([\d.]+) \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
+    ref = pins["elasticity"]["stats"]
+    assert len(rows) == len(ref) == 5
+    for got, want in zip(rows, ref):
+        assert got[4] == f"{want['r0']:.2e}"
+        assert int(got[6]) == want["iters"] == 21
+        assert float(got[5]) == pytest.approx(want["rel"], rel=0.2) and float(got[5]) < 1e-6
+    # the library's own (GPU) defaults on the same system: PMIS + l1-Jacobi need about twice the iterations
+    r = subprocess.run([exe, "-v", "1", "-ns", "1"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0
+    row = re.search(r"^\|\s+0 \|.*\|\s+(\S+) \|\s+(\d+) \|$", r.stdout, re.M)
+    assert row and float(row.group(1)) < 1e-6 and 21 < int(row.group(2)) < 80
+
+
+def test_reference_laplacian_driver_cpu_defaults(pins):
+    """examples/refOutput/laplacian.txt:34-38 (5 iterations, 6.12e-07) through the unmodified driver
+    with the reference's CPU-build defaults."""
+    exe = os.path.join(ROOT, "build", "laplacian_ref")
+    if not os.path.exists(exe):
+        pytest.skip("build/laplacian_ref not built")
+    r = subprocess.run([exe, "-v", "1"], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, HYPREDRV_AMD_DEFAULTS="cpu"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = re.findall(r"^\|\s+(\d+) \|\s+([\d.]*) \|\s+([\d.]+) \|\s+([\d.]+) \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
+    ref = pins["laplacian"]["stats"]
+    assert len(rows) == len(ref) == 5
+    for got, want in zip(rows, ref):
+        assert got[4] == f"{want['r0']:.2e}" and int(got[6]) == want["iters"]
+        assert float(got[5]) == pytest.approx(want["rel"], rel=0.02)
+
+
 def test_rccl_transport_single_rank_selftest():
     """RCCL refuses two ranks on one GPU, so the builder cannot run it multi-rank; at least
     exercise the whole RCCL code path (dlopen, ncclGetUniqueId, ncclCommInitRank, all-reduce,

@@ -272,6 +272,49 @@ def test_hmis_refuses_large_systems(hd):
         hd.Amg(A, hd.AmgParams.default(coarsen_type=10))
 
 
+@pytest.mark.parametrize("cpu_defaults,layout", [(False, "interleaved"), (True, "interleaved"), (False, "contiguous")])
+def test_systems_amg_unknown_approach_identical_to_oracle(orc, hd, cpu_defaults, layout):
+    """coarsening.num_functions = 3 (presets elasticity_2d/3d, reference src/internal/presets.c:19-27,
+    src/internal/amg.c:792-862): couplings between different functions are ignored by the strength
+    measure and never lumped into the interpolation diagonal.  3 unknowns per node of an 8^3 grid,
+    block-coupled; dof_func interleaved (hypre's default, no map given) or contiguous (map given)."""
+    import scipy.sparse as sp
+    n = 8
+    I = sp.identity(n)
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    L = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)).tocsr()
+    B = np.array([[1.0, 0.85, 0.1], [0.85, 1.2, 0.25], [0.1, 0.25, 0.9]])  # SPD; 0.85 > strong_th: the scalar measure would call it strong
+    if layout == "interleaved":
+        A = sp.kron(L, B).tocsr()
+        dof = None
+    else:
+        A = sp.kron(B, L).tocsr()
+        dof = np.repeat(np.arange(3), n ** 3).astype(np.int32)
+    A.sort_indices()
+    N = A.shape[0]
+    Ao = orc.Csr.from_arrays(N, N, A.indptr, A.indices, A.data)
+    Ah = hd.Csr.from_arrays(N, N, A.indptr, A.indices, A.data)
+    po = orc.amg_params(not cpu_defaults, num_functions=3, strong_th=0.8)
+    ph = hd.AmgParams.default(num_functions=3, strong_th=0.8, coarsen_type=po.coarsen_type, relax_down=po.relax_down,
+                              relax_up=po.relax_up, relax_coarse=po.relax_coarse)
+    ho, hh = orc.Amg(Ao, po, dof=dof), hd.Amg(Ah, ph, dof=dof)
+    assert hh.num_levels == ho.num_levels >= 2
+    for l in range(ho.num_levels - 1):
+        assert np.array_equal(hh.level_cf(l), ho.level_cf(l)), f"C/F level {l}"
+        rp, cj, v = hh.level_matrix(l, 1).download()
+        Pl = ho.level_P(l)
+        assert np.array_equal(rp, Pl.rowptr) and np.array_equal(cj, Pl.col) and np.array_equal(v, Pl.val), f"P level {l}"
+        rp, cj, v = hh.level_matrix(l + 1, 0).download()
+        Al = ho.level_A(l + 1)
+        assert np.array_equal(rp, Al.rowptr) and np.array_equal(cj, Al.col) and np.array_equal(v, Al.val)
+    # the scalar hierarchy of the same matrix is a different one (the option does something)
+    assert not np.array_equal(hd.Amg(Ah, hd.AmgParams.default(strong_th=0.8, coarsen_type=po.coarsen_type)).level_cf(0), hh.level_cf(0))
+    b = np.ones(N)
+    ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
+
+
 def test_pin_ex2_hierarchy_on_gpu(hd, pins):
     """examples/refOutput/ex2.txt:124-139 against the HIP-built hierarchy."""
     import scipy.sparse as sp  # noqa
