@@ -112,8 +112,15 @@ def test_lifecycle_guards_and_error_bits(hd):
     assert L.HYPREDRV_LinearSolverApply(None) & hd.ERROR_UNKNOWN_HYPREDRV_OBJ
     L.HYPREDRV_ErrorCodeClear()
     # out-of-path entry points report instead of silently succeeding
+    assert L.HYPREDRV_LinearSystemSetNullSpace(h.h, 2, 1, None) & hd.ERROR_UNSUPPORTED_AMD
+    L.HYPREDRV_ErrorCodeClear()
+    # dofmaps are host-side bookkeeping (they feed BoomerAMG's dof_func): valid without a GPU, validated
     dm = (C.c_int * 2)(0, 1)
-    assert L.HYPREDRV_LinearSystemSetDofmap(h.h, 2, dm) & hd.ERROR_UNSUPPORTED_AMD
+    assert L.HYPREDRV_LinearSystemSetDofmap(h.h, 2, dm) == 0
+    assert L.HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, 4, 3) == 0 and L.HYPREDRV_LinearSystemSetContiguousDofmap(h.h, 4, 3) == 0
+    assert L.HYPREDRV_LinearSystemSetDofmap(h.h, 2, None) & hd.ERROR_INVALID_VAL
+    L.HYPREDRV_ErrorCodeClear()
+    assert L.HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, 4, 0) & hd.ERROR_INVALID_VAL
     L.HYPREDRV_ErrorCodeClear()
     # unsupported solver / preconditioner selections fail at Create, loudly
     h2 = hd.Hypredrv("solver: bicgstab\npreconditioner: amg\n")
