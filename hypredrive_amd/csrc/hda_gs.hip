@@ -151,9 +151,9 @@ __global__ __launch_bounds__(256) void k_gs_level(int first, int count, const in
    gs_rows<LPR>(first, count, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, perm, rp, cj, v, dinv, b, x);
 }
 
-// levels [l0, l1) by ONE workgroup, forward or backward, a barrier between levels
+// levels [l0, l1) by ONE workgroup of 16 wavefronts, forward or backward, a barrier between levels
 template <int LPR>
-__global__ __launch_bounds__(256) void k_gs_levels_fused(int l0, int l1, int backward, const int *__restrict__ lvl_ptr,
+__global__ __launch_bounds__(1024) void k_gs_levels_fused(int l0, int l1, int backward, const int *__restrict__ lvl_ptr,
                                                          const int *__restrict__ perm, const int *__restrict__ rp,
                                                          const int *__restrict__ cj, const double *__restrict__ v,
                                                          const double *__restrict__ dinv, const double *__restrict__ b, double *x)
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_gs_levels_fused(int l0, int l1, int bac
    for (int s = 0; s < l1 - l0; s++)
    {
       const int L = backward ? (l1 - 1 - s) : (l0 + s);
-      gs_rows<LPR>(lvl_ptr[L], lvl_ptr[L + 1] - lvl_ptr[L], threadIdx.x, 256, perm, rp, cj, v, dinv, b, x);
+      gs_rows<LPR>(lvl_ptr[L], lvl_ptr[L + 1] - lvl_ptr[L], threadIdx.x, blockDim.x, perm, rp, cj, v, dinv, b, x);
       __threadfence_block();
       __syncthreads();
    }
@@ -181,7 +181,7 @@ static void gs_sweep_t(const DCsr &A, const GsPlan &p, const double *dinv, const
          k_gs_level<LPR><<<grid, 256, 0, STREAM>>>(first, count, p.perm.data(), A.rowptr.data(), A.col.data(), A.val.data(), dinv, b, x);
       }
       else
-         k_gs_levels_fused<LPR><<<1, 256, 0, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
+         k_gs_levels_fused<LPR><<<1, 1024, 0, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
                                                       A.rowptr.data(), A.col.data(), A.val.data(), dinv, b, x);
    }
 }
