@@ -62,6 +62,15 @@ def lib():
         "HYPREDRV_AMD_CommFinalize": [],
         "HYPREDRV_AMD_LinearSystemSetLaplacian7pt": [vp, ip, ip, dp],
         "HYPREDRV_LinearSystemSetDofmap": [vp, C.c_int, ip],
+        "HYPREDRV_LinearSystemSetInterleavedDofmap": [vp, C.c_int, C.c_int],
+        "HYPREDRV_LinearSystemSetContiguousDofmap": [vp, C.c_int, C.c_int],
+        "HYPREDRV_LinearSystemSetNullSpace": [vp, C.c_int, C.c_int, dp],
+        "HYPREDRV_LinearSystemReadMatrix": [vp],
+        "HYPREDRV_AnnotateLevelBegin": [vp, C.c_int, C.c_char_p, C.c_int],
+        "HYPREDRV_AnnotateLevelEnd": [vp, C.c_int, C.c_char_p, C.c_int],
+        "HYPREDRV_StatsLevelGetCount": [vp, C.c_int, ip],
+        "HYPREDRV_StatsLevelGetEntry": [vp, C.c_int, C.c_int, ip, ip, ip, dp, dp],
+        "HYPREDRV_StatsLevelPrint": [vp, C.c_int],
     }
     for name, args in sig.items():
         f = getattr(L, name)

@@ -1,6 +1,7 @@
 """GPU tests of the reference-facing boundary (HYPREDRV_* / HYPRE_*): the CSR-ingestion tests
 of the reference (tests/test_setmatrix_from_csr.c), its CLI on examples/ex1.yml, the generator
 path of examples/src/C_laplacian/laplacian.c, and the row-partitioned path on several ranks."""
+import ctypes as C
 import json
 import os
 import re
@@ -264,6 +265,49 @@ def test_reference_convdif_iteration_counts(pins):
     assert all(float(x[2]) < 1e-8 for x in rows)
     for g, w in zip(steps, ref["steps"]):
         assert float(g[3]) == pytest.approx(w["mass"], rel=2e-6)
+
+
+def test_level_annotations_and_level_stats(hd):
+    """HYPREDRV_AnnotateLevelBegin/End + StatsLevelGetCount/GetEntry (reference src/internal/stats.c:953-1122,
+    1615-1690; behaviours of tests/test_stats.c:28-152,275-335): a level entry aggregates the solves
+    between its begin and end; child ids restart under every parent; misuse is ERROR_INVALID_VAL;
+    an End without a Begin is a no-op."""
+    L = hd.lib()
+    h = hd.Hypredrv("solver: pcg\npreconditioner: amg\n")
+    h.set_laplacian7((10, 10, 10))
+    its = []
+    for t in range(2):
+        assert L.HYPREDRV_AnnotateLevelBegin(h.h, 0, b"timestep", t) == 0
+        for n in range(2):
+            assert L.HYPREDRV_AnnotateLevelBegin(h.h, 1, b"newton", n) == 0
+            its.append(h.solve()["iters"])
+            assert L.HYPREDRV_AnnotateLevelEnd(h.h, 1, b"newton", n) == 0
+        assert L.HYPREDRV_AnnotateLevelEnd(h.h, 0, b"timestep", t) == 0
+    cnt = C.c_int()
+    assert L.HYPREDRV_StatsLevelGetCount(h.h, 0, C.byref(cnt)) == 0 and cnt.value == 2
+    assert L.HYPREDRV_StatsLevelGetCount(h.h, 1, C.byref(cnt)) == 0 and cnt.value == 4
+    eid, ns, li = C.c_int(), C.c_int(), C.c_int()
+    ts, tv = C.c_double(), C.c_double()
+    assert L.HYPREDRV_StatsLevelGetEntry(h.h, 0, 1, C.byref(eid), C.byref(ns), C.byref(li), C.byref(ts), C.byref(tv)) == 0
+    assert (eid.value, ns.value, li.value) == (2, 2, its[2] + its[3]) and ts.value > 0 and tv.value > 0
+    assert L.HYPREDRV_StatsLevelGetEntry(h.h, 1, 3, C.byref(eid), C.byref(ns), C.byref(li), None, None) == 0
+    assert (eid.value, ns.value, li.value) == (2, 1, its[3])     # second newton step of its timestep
+    assert L.HYPREDRV_StatsLevelGetEntry(h.h, 0, 0, None, None, None, None, None) == 0
+    assert L.HYPREDRV_StatsLevelGetEntry(h.h, 0, -1, C.byref(eid), None, None, None, None) != 0
+    L.HYPREDRV_ErrorCodeClear()
+    assert L.HYPREDRV_StatsLevelGetCount(h.h, 12, C.byref(cnt)) & hd.ERROR_INVALID_VAL
+    L.HYPREDRV_ErrorCodeClear()
+    # misuse
+    assert L.HYPREDRV_AnnotateLevelEnd(h.h, 2, b"never_begun", 0) == 0
+    assert L.HYPREDRV_AnnotateLevelBegin(h.h, 0, b"timestep", 7) == 0
+    assert L.HYPREDRV_AnnotateLevelBegin(h.h, 0, b"timestep", 8) & hd.ERROR_INVALID_VAL
+    L.HYPREDRV_ErrorCodeClear()
+    assert L.HYPREDRV_AnnotateLevelEnd(h.h, 0, b"other", 7) & hd.ERROR_INVALID_VAL
+    L.HYPREDRV_ErrorCodeClear()
+    assert L.HYPREDRV_AnnotateLevelEnd(h.h, 0, b"timestep", 7) == 0
+    assert L.HYPREDRV_AnnotateLevelBegin(h.h, 10, b"deep", 0) & hd.ERROR_INVALID_VAL
+    L.HYPREDRV_ErrorCodeClear()
+    h.close()
 
 
 def test_reference_elasticity_driver_unmodified(pins):
