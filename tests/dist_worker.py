@@ -93,8 +93,51 @@ def mode_solve(out, n, solver):
     hdist.finalize()
 
 
+def random_mmatrix(seed, n):
+    """Irregular symmetric M-matrix, identical on every rank (seeded)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    m = 6 * n
+    i, j = rng.integers(0, n, m), rng.integers(0, n, m)
+    # mostly local couplings plus a few long-range ones: ghost layers of very different sizes
+    j = np.where(rng.uniform(size=m) < 0.9, np.clip(i + rng.integers(-40, 41, m), 0, n - 1), j)
+    keep = i != j
+    i, j = i[keep], j[keep]
+    w = rng.uniform(0.05, 1.0, i.size)
+    W = sp.coo_matrix((w, (i, j)), shape=(n, n)).tocsr()
+    W = W + W.T
+    d = np.asarray(W.sum(axis=1)).ravel() + rng.uniform(0.01, 0.2, n)
+    A = (sp.diags(d) - W).tocsr()
+    A.sort_indices()
+    return A
+
+
+def mode_csr(out, n, seed):
+    """Row blocks of an irregular matrix through HYPREDRV_LinearSystemSetMatrixFromCSR on every rank
+    (reference tests/test_setmatrix_from_csr_mpi.c), AMG-PCG on the row-partitioned system."""
+    from hypredrive_amd import dist as hdist
+    from hypredrive_amd import hypredrv as hd
+    rank, world = hdist.init("staged")
+    A = random_mmatrix(seed, n)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    blk = A[lo:hi]
+    h = hd.Hypredrv("solver: pcg\npreconditioner: amg\n")
+    h.set_matrix_csr(lo, hi - 1, blk.indptr, blk.indices, blk.data)
+    h.set_rhs_array(lo, hi - 1, np.ones(hi - lo))
+    h.finish_system()
+    r = h.solve()
+    nrm = h.solution_norm("L2")
+    if rank == 0:
+        json.dump({"iters": r["iters"], "converged": r["converged"], "final_rel": r["final_rel"], "norm": nrm, "world": world},
+                  open(out, "w"))
+    h.close()
+    hdist.finalize()
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "transport":
         mode_transport(sys.argv[2])
+    elif sys.argv[1] == "csr":
+        mode_csr(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     else:
         mode_solve(sys.argv[2], int(sys.argv[3]), sys.argv[4])

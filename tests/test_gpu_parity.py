@@ -315,6 +315,62 @@ def test_systems_amg_unknown_approach_identical_to_oracle(orc, hd, cpu_defaults,
     assert np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
 
 
+def _random_system(seed, kind):
+    """Irregular test operators: weighted graph Laplacians (M-matrices), a version with positive
+    off-diagonals mixed in, an unsymmetric convection-like one, and one with a negative diagonal."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(300, 900))
+    m = n * int(rng.integers(3, 9))
+    i, j = rng.integers(0, n, m), rng.integers(0, n, m)
+    keep = i != j
+    i, j = i[keep], j[keep]
+    w = rng.uniform(0.05, 1.0, i.size) * (10.0 ** rng.integers(-2, 2, i.size))
+    if kind == "mixed":
+        w *= np.where(rng.uniform(size=i.size) < 0.15, -0.3, 1.0)
+    W = sp.coo_matrix((w, (i, j)), shape=(n, n)).tocsr()
+    if kind != "unsym":
+        W = W + W.T
+    else:
+        W = W + 0.3 * W.T
+    W.sum_duplicates()
+    d = np.asarray(abs(W).sum(axis=1)).ravel() + rng.uniform(0.01, 0.5, n)
+    A = (sp.diags(d) - W).tocsr()
+    if kind == "negdiag":
+        A = -A
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("kind", ["mmatrix", "mixed", "unsym", "negdiag"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_operators_hierarchy_identical_to_oracle(orc, hd, kind, seed):
+    """Differential test on irregular sparsity (no grid structure, rows of very different length,
+    weights over four decades): strength, PMIS, ext+i with truncation, Galerkin products and the
+    solve must still agree with the oracle bit for bit / to 1e-10."""
+    A = _random_system(100 * seed + len(kind), kind)
+    N = A.shape[0]
+    Ao = orc.Csr.from_arrays(N, N, A.indptr, A.indices, A.data)
+    Ah = hd.Csr.from_arrays(N, N, A.indptr, A.indices, A.data)
+    ho, hh = orc.Amg(Ao, orc.amg_params(True)), hd.Amg(Ah)
+    assert hh.num_levels == ho.num_levels
+    for l in range(ho.num_levels - 1):
+        assert np.array_equal(hh.level_cf(l), ho.level_cf(l)), f"C/F level {l}"
+        rp, cj, v = hh.level_matrix(l, 1).download()
+        Pl = ho.level_P(l)
+        assert np.array_equal(rp, Pl.rowptr) and np.array_equal(cj, Pl.col) and np.array_equal(v, Pl.val), f"P level {l}"
+        rp, cj, v = hh.level_matrix(l + 1, 0).download()
+        Al = ho.level_A(l + 1)
+        assert np.array_equal(rp, Al.rowptr) and np.array_equal(cj, Al.col) and np.array_equal(v, Al.val), f"A level {l + 1}"
+    b = np.random.default_rng(seed).standard_normal(N)
+    if kind == "unsym":
+        ro, rh = orc.gmres(Ao, b, ho), hd.gmres(Ah, b, hh)
+    else:
+        ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+    assert rh["converged"] == ro["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-8, atol=0)
+
+
 def test_pin_ex2_hierarchy_on_gpu(hd, pins):
     """examples/refOutput/ex2.txt:124-139 against the HIP-built hierarchy."""
     import scipy.sparse as sp  # noqa
