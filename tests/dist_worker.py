@@ -76,7 +76,7 @@ def mode_solve(out, n, solver):
     rank, world = hdist.init("staged")
     import hypredrive_amd as h
     assert h.load().hda_comm_selftest() == 0, h.load().hda_last_error()
-    P = hdist.factor3(world)
+    P = tuple(int(v) for v in os.environ["HDA_TEST_P"].split(",")) if os.environ.get("HDA_TEST_P") else hdist.factor3(world)
     yaml = f"solver: {solver}\npreconditioner:\n  preset: poisson\n"
     h = hd.Hypredrv(yaml)
     h.set_laplacian7((n, n, n), P)

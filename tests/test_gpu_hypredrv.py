@@ -167,7 +167,7 @@ def test_cli_overrides():
 @pytest.mark.parametrize("world,n,solver,port,rep_rows,setup", [
     (2, 16, "pcg", 29641, 100000, "partitioned"), (4, 20, "pcg", 29642, 0, "partitioned"), (4, 24, "pcg", 29644, 700, "partitioned"),
     (3, 12, "gmres", 29643, 0, "partitioned"), (4, 40, "pcg", 29645, 2000, "partitioned"), (4, 24, "pcg", 29646, 700, "replicated")])
-def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solver, port, rep_rows, setup):
+def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solver, port, rep_rows, setup, P=None):
     """Several ranks on one GPU through the staged transport: identical hierarchy (PMIS hashes
     global ids) => same iteration count as one rank, same solution to rounding.  rep_rows
     (HDA_REPLICATE_ROWS) moves the split between partitioned levels and the replicated tail:
@@ -178,6 +178,8 @@ def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solve
     out = str(tmp_path / "res.json")
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS=str(rep_rows), HDA_DIST_SETUP=setup,
                HDA_DIST_CHECK="1" if setup == "partitioned" else "0")
+    if P:
+        env["HDA_TEST_P"] = ",".join(str(v) for v in P)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "solve", out, str(n), solver]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -194,6 +196,13 @@ def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solve
     assert res["l1"] == pytest.approx(h.solution_norm("L1"), rel=1e-6)
     assert res["linf"] == pytest.approx(h.solution_norm("Linf"), rel=1e-6)
     assert np.linalg.norm(x) == pytest.approx(res["norm"], rel=1e-12)
+
+
+@pytest.mark.parametrize("world,n,P,port", [(2, 16, (2, 1, 1), 29651), (4, 20, (2, 2, 1), 29652), (4, 18, (2, 1, 2), 29653)])
+def test_row_partitioned_x_and_y_splits(hd, tmp_path, world, n, P, port):
+    """Rank grids that cut the x direction (the fastest index inside a block of the generator's
+    numbering, laplacian.c:504-520), as the 2x2x2 grid of an 8-GPU run does."""
+    test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, "pcg", port, 300, "partitioned", P=P)
 
 
 @pytest.mark.parametrize("world,n,seed,rep_rows", [(3, 4000, 11, 0), (4, 6000, 12, 500)])
