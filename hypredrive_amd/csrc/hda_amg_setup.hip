@@ -2037,7 +2037,8 @@ double Amg::vcycle_bytes(bool format) const
       s += spmv_bytes(levels[l].P, format) + 8.0 * n;                   // prolongation-add
       s += prm.sweeps_up * (spmv_bytes(A, format) + 16.0 * n);          // post-sweeps
    }
-   s += 8.0 * coarse_n * coarse_n + 16.0 * coarse_n;
+   if (tail) s += tail->vcycle_bytes(format) + 16.0 * coarse_n; // replicated coarse levels: every rank does all of it
+   else s += 8.0 * coarse_n * coarse_n + 16.0 * coarse_n;
    return s;
 }
 

@@ -1066,6 +1066,21 @@ extern "C" uint32_t HYPREDRV_LinearSystemReadDofmap(HYPREDRV_t h)
    if (!h->args.ls.dofmap_filename.empty()) return err_set(HYPREDRV_ERROR_UNSUPPORTED_AMD, "dofmap files (MGR) are not supported by this build");
    return g_err;
 }
+// bytes THIS rank streams per Krylov iteration (operator product + vector updates) and per
+// V-cycle with the hierarchy that was set up: [0] CSR figures of SURVEY 8(d), [1] the formats
+// actually read (coded operators).  bench.py sums them over the ranks.
+extern "C" uint32_t HYPREDRV_AMD_SolvePhaseBytes(HYPREDRV_t h, double iteration[2], double vcycle[2])
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (!h->mat_A || !h->precon || !h->precon->amg) return err_set(ERR_UNKNOWN, "SolvePhaseBytes: set up the solver first");
+   for (int f = 0; f < 2; f++)
+   {
+      iteration[f] = pcg_iteration_bytes(h->mat_A->A, f == 1);
+      vcycle[f]    = h->precon->amg->vcycle_bytes(f == 1);
+   }
+   API_CATCH
+}
 extern "C" uint32_t HYPREDRV_LinearSystemComputeEigenspectrum(HYPREDRV_t h) { CHECK_INIT_OBJ(h); return g_err; } // no-op unless built with eigspec
 
 // ------------------------------------------------------------- THE HOT PATH

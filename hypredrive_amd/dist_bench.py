@@ -42,6 +42,12 @@ def run(args):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     ms_per_step = dt.item() * 1e3 / args.steps
     N = gn[0] * gn[1] * gn[2]
+    # solve-phase byte rate summed over the ranks: iters Krylov iterations + (iters + 1) V-cycles each
+    (it_csr, it_fmt), (vc_csr, vc_fmt) = h.solve_phase_bytes()
+    k = last["iters"]
+    by = torch.tensor([k * it_csr + (k + 1) * vc_csr, k * it_fmt + (k + 1) * vc_fmt], dtype=torch.float64)
+    dist.all_reduce(by, op=dist.ReduceOp.SUM)
+    gbs_csr, gbs_fmt = (by / (ms_per_step * 1e-3) / 1e9).tolist()
     out = None
     if rank == 0:
         out = {
@@ -53,6 +59,10 @@ def run(args):
                        "timed": "solve phase only (reference 'solve' timer)"},
             "iters": last["iters"], "converged": last["converged"], "final_rel": last["final_rel"], "setup_ms": setup_ms,
             "dof_iters_per_s": N * last["iters"] / (ms_per_step * 1e-3),
+            # aggregate over all ranks; fractions against world x 8 TB/s.  CSR-equivalent bytes and
+            # bytes in the formats actually streamed (level 0 is stencil-coded); the replicated coarse tail counts on every rank
+            "solve_phase_hbm_gbs": gbs_csr, "solve_phase_hbm_frac": gbs_csr / (8000.0 * world),
+            "solve_phase_format_gbs": gbs_fmt, "solve_phase_format_frac": gbs_fmt / (8000.0 * world),
         }
     h.destroy_solver()
     h.close()

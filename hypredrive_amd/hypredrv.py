@@ -71,6 +71,7 @@ def lib():
         "HYPREDRV_StatsLevelGetCount": [vp, C.c_int, ip],
         "HYPREDRV_StatsLevelGetEntry": [vp, C.c_int, C.c_int, ip, ip, ip, dp, dp],
         "HYPREDRV_StatsLevelPrint": [vp, C.c_int],
+        "HYPREDRV_AMD_SolvePhaseBytes": [vp, dp, dp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -184,6 +185,12 @@ class Hypredrv:
         v = C.c_double()
         check(lib().HYPREDRV_LinearSystemGetSolutionNorm(self.h, kind.encode(), C.byref(v)))
         return v.value
+
+    def solve_phase_bytes(self):
+        """(iteration, vcycle) bytes of this rank: each a pair (CSR figure, bytes in the formats read)."""
+        it, vc = (C.c_double * 2)(), (C.c_double * 2)()
+        check(lib().HYPREDRV_AMD_SolvePhaseBytes(self.h, it, vc))
+        return (it[0], it[1]), (vc[0], vc[1])
 
     def stats_print(self):
         check(lib().HYPREDRV_StatsPrint(self.h))

@@ -149,6 +149,9 @@ HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_LinearSystemSetLaplacian7pt(HYPREDR
                                                                          const int P[3], const double c[3]);
 /* Last error text of the MI355X backend (the reference prints through ErrorCodeDescribe). */
 HYPREDRV_EXPORT_SYMBOL const char *HYPREDRV_AMD_LastErrorMessage(void);
+/* measurement hook of bench.py: bytes this rank streams per Krylov iteration and per V-cycle,
+ * [0] as CSR, [1] in the formats actually read */
+HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_SolvePhaseBytes(HYPREDRV_t hypredrv, double iteration[2], double vcycle[2]);
 
 #ifdef __cplusplus
 }
