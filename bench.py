@@ -39,6 +39,7 @@ def cpu_baseline(sample_n):
         avail = os.cpu_count() or 1
     threads = int(os.environ.get("OMP_NUM_THREADS", min(avail, 16)))
     os.environ["OMP_NUM_THREADS"] = str(threads)  # read when libgomp initialises (first oracle call)
+    os.environ.setdefault("OMP_WAIT_POLICY", "active")  # the baseline gets spinning barriers (the test default is passive)
     A, b = o.lap7(sample_n, sample_n, sample_n)
     t0 = time.perf_counter()
     amg = o.Amg(A, o.amg_params(True))
