@@ -79,6 +79,9 @@ class Amg {
    void setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0, const std::vector<long long> &part0,
                                const std::vector<long long> &ghost_gids0);
    // length of the level-0 vectors handed to apply()/solve() (x must have this room)
+   // solve-phase renumbering of the coarse levels (hda_reorder.hip); 0 = none
+   void   reorder_levels();
+   int    reordered_levels = 0;
    size_t vec_len0() const { return levels.empty() ? 0 : levels[0].ext; }
    bool   distributed() const { return dist; }
    // HYPRE_BoomerAMGSolve as a preconditioner (precon.c:108): one V(nu1,nu2) from x = 0.

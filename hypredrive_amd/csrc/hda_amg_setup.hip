@@ -1843,6 +1843,7 @@ void Amg::setup(const DCsr &A)
    dist = false;
    hA0  = nullptr;
    build_hierarchy(A);
+   reorder_levels(); // solve-phase numbering of the big coarse levels (the setup above stays in natural order)
    const int L = (int)levels.size();
    for (int l = 0; l < L; l++)
    {

@@ -6,6 +6,8 @@ norms); 1e-13 relative for wave-parallel fp64 reductions (SpMV, smoothers, V-cyc
 identical iteration counts and residual histories to 1e-10 relative for AMG-PCG on an
 identical hierarchy.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -456,6 +458,41 @@ def test_gmres_restarts_match_oracle(orc, hd, kdim, precond):
         assert rh["converged"] == ro["converged"] and rh["iters"] == ro["iters"]
         assert np.allclose(rh["hist"], ro["hist"], rtol=1e-8)
         assert rel(rh["x"], ro["x"]) < 1e-8
+
+
+def test_solve_phase_renumbering_is_a_similarity(orc):
+    """Coarse levels are renumbered for the solve (hda_reorder.hip: nested clusters by strongest
+    interpolation parent) above HDA_REORDER rows, 50000 by default -- i.e. never in the small parity
+    cases.  Forced down to 300 rows in a fresh process: the preconditioner is the same operator, so
+    PCG/GMRES take the oracle's iterations and histories agree to rounding; the renumbered level
+    operators are permutations of the oracle's (same multiset of values, same row-length multiset)."""
+    import subprocess
+    import sys
+    code = """
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import hypredrive_amd as hd
+from oracle import oracle_ffi as orc
+Ao, b = orc.lap7(24, 20, 18, b_mode=0)
+Ah = hd.lap7(24, 20, 18)
+ho, hh = orc.Amg(Ao, orc.amg_params(True)), hd.Amg(Ah)
+ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+rg, rq = orc.gmres(Ao, b, ho), hd.gmres(Ah, b, hh)
+rp, cj, v = hh.level_matrix(1, 0).download()
+A1 = ho.level_A(1)
+print(json.dumps(dict(it=[ro["iters"], rh["iters"], rg["iters"], rq["iters"]],
+      hist=float(np.max(np.abs(np.array(rh["hist"]) / np.array(ro["hist"]) - 1.0))),
+      x=float(np.linalg.norm(rh["x"] - ro["x"]) / np.linalg.norm(ro["x"])),
+      same_order=bool(np.array_equal(cj, A1.col)), vals=bool(np.array_equal(np.sort(v), np.sort(A1.val))),
+      lens=bool(np.array_equal(np.sort(np.diff(rp)), np.sort(np.diff(A1.rowptr)))), nlev=[ho.num_levels, hh.num_levels])))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, HDA_REORDER="300"), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["it"][0] == res["it"][1] and res["it"][2] == res["it"][3] and res["nlev"][0] == res["nlev"][1]
+    assert res["hist"] < 1e-9 and res["x"] < 1e-9
+    assert not res["same_order"] and res["vals"] and res["lens"]
 
 
 def test_edge_cases(orc, hd, pins):
