@@ -1212,9 +1212,53 @@ __global__ __launch_bounds__(256) void k_sort_rows(int n, const int *__restrict_
       v[bq + 1]  = x;
    }
 }
+// one wavefront per row of up to 64 entries: lane k holds entry k, bitonic network over the lanes
+// (columns of a row are distinct, so the order is unique); longer rows fall back to insertion
+__global__ __launch_bounds__(256) void k_sort_rows_wave(int n, const int *__restrict__ rp, int *cj, double *v)
+{
+   const int lane = threadIdx.x & 63;
+   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 6; i < n; i += ((long)gridDim.x * 256) >> 6)
+   {
+      const int s = rp[i], len = rp[i + 1] - s;
+      if (len > 64)
+      {
+         if (lane == 0)
+            for (int a = s + 1; a < s + len; a++)
+            {
+               const int    c = cj[a];
+               const double x = v[a];
+               int          bq = a - 1;
+               while (bq >= s && cj[bq] > c) { cj[bq + 1] = cj[bq]; v[bq + 1] = v[bq]; bq--; }
+               cj[bq + 1] = c;
+               v[bq + 1]  = x;
+            }
+         continue;
+      }
+      if (len < 2) continue;
+      int    c = (lane < len) ? cj[s + lane] : 0x7fffffff;
+      double x = (lane < len) ? v[s + lane] : 0.0;
+#pragma unroll
+      for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+         for (int j = k >> 1; j > 0; j >>= 1)
+         {
+            const int    oc = __shfl_xor(c, j);
+            const double ox = __shfl_xor(x, j);
+            const bool   up = ((lane & k) == 0);          // ascending block
+            const bool   lo = ((lane & j) == 0);          // this lane keeps the smaller of the pair when ascending
+            const bool   take = (lo == up) ? (oc < c) : (oc > c);
+            if (take) { c = oc; x = ox; }
+         }
+      if (lane < len) { cj[s + lane] = c; v[s + lane] = x; }
+   }
+}
 void sort_rows(DCsr &A)
 {
-   if (A.nrows) k_sort_rows<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data());
+   if (!A.nrows) return;
+   if (A.avg_row() > 12.0)
+      k_sort_rows_wave<<<std::min(ceil_div((long long)A.nrows * 64, 256), 1 << 16), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(),
+                                                                                                 A.val.data());
+   else k_sort_rows<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data());
 }
 
 __global__ __launch_bounds__(256) void k_count_cols(int nnz, const int *__restrict__ cj, int *cnt)
