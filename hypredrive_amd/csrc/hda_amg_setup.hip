@@ -1956,6 +1956,9 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
    }
    A0        = &Aloc;
    this->hA0 = &hA0_;
+   coarse_lo   = parts[(size_t)L - 1][(size_t)r];
+   coarse_nloc = (int)(parts[(size_t)L - 1][(size_t)r + 1] - coarse_lo);
+   if (has_tail) reorder_levels(); // (without a tail the last level is a real operator level: left alone)
    for (int l = 0; l < L; l++)
    {
       AmgLevel    &lv = levels[l];
@@ -3168,6 +3171,7 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
       if (l > 0) levels[(size_t)l].A = DCsr(); // the hand-over level keeps only vectors
    }
    const int L = (int)levels.size();
+   reorder_levels(); // solve-phase numbering of this rank's unknowns on the big partitioned levels
    for (int q = 0; q < L; q++)
    {
       AmgLevel    &lv = levels[(size_t)q];

@@ -28,6 +28,7 @@ namespace {
 
 // strongest interpolation source of every row of P (first maximum in column order); rows
 // without entries keep their proportional position
+// (row blocks: only columns < nc, the coarse points this rank owns, can be parents)
 __global__ __launch_bounds__(256) void k_parent(int n, int nc, const int *__restrict__ rp, const int *__restrict__ cj,
                                                 const double *__restrict__ v, int *__restrict__ parent)
 {
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void k_parent(int n, int nc, const int *__rest
    for (int k = rp[i]; k < rp[i + 1]; k++)
    {
       const double a = fabs(v[k]);
-      if (a > bv) { bv = a; best = cj[k]; }
+      if (cj[k] < nc && a > bv) { bv = a; best = cj[k]; }
    }
    parent[i] = (best >= 0) ? best : (int)(((long long)i * nc) / max(n, 1));
 }
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void k_perm_len(int n, const int *__restrict__
 }
 // LPR lanes copy one row: the source rows are scattered, a lane group reads each of them coalesced
 template <int LPR>
-__global__ __launch_bounds__(256) void k_perm_copy(int n, const int *__restrict__ perm, const int *__restrict__ col_rank,
+__global__ __launch_bounds__(256) void k_perm_copy(int n, const int *__restrict__ perm, const int *__restrict__ col_rank, int nown,
                                                    const int *__restrict__ srp, const int *__restrict__ scj, const double *__restrict__ sv,
                                                    const int *__restrict__ drp, int *__restrict__ dcj, double *__restrict__ dv)
 {
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(256) void k_perm_copy(int n, const int *__restrict_
       const int s = srp[i], e = srp[i + 1], d = drp[q];
       for (int k = s + lane; k < e; k += LPR)
       {
-         dcj[d + (k - s)] = col_rank ? col_rank[scj[k]] : scj[k];
+         const int c      = scj[k];
+         dcj[d + (k - s)] = (col_rank && c < nown) ? col_rank[c] : c; // ghost columns keep their slot
          dv[d + (k - s)]  = sv[k];
       }
    }
@@ -88,9 +90,9 @@ __global__ __launch_bounds__(256) void k_gather_i(int n, const int *__restrict__
    if (q < n) dst[q] = src[idx[q]];
 }
 
-// out = rows of M taken in the order perm (new -> old; null = unchanged), columns renamed by
-// col_rank (old -> new; null = unchanged), rows column-sorted again
-void permute_csr(DCsr &M, const int *perm, const int *col_rank)
+// out = rows of M taken in the order perm (new -> old; null = unchanged), owned columns (< nown)
+// renamed by col_rank (old -> new; null = unchanged), rows column-sorted again
+void permute_csr(DCsr &M, const int *perm, const int *col_rank, int nown)
 {
    const int n = M.nrows;
    DCsr      out;
@@ -108,16 +110,27 @@ void permute_csr(DCsr &M, const int *perm, const int *col_rank)
    {
       const int grid = std::min(ceil_div((long long)n * 8, 256), 1 << 16);
       if (M.avg_row() > 12.0)
-         k_perm_copy<32><<<std::min(ceil_div((long long)n * 32, 256), 1 << 16), 256, 0, STREAM>>>(n, perm, col_rank, M.rowptr.data(), M.col.data(),
+         k_perm_copy<32><<<std::min(ceil_div((long long)n * 32, 256), 1 << 16), 256, 0, STREAM>>>(n, perm, col_rank, nown, M.rowptr.data(), M.col.data(),
                                                                                             M.val.data(), out.rowptr.data(), out.col.data(),
                                                                                             out.val.data());
       else
-         k_perm_copy<8><<<grid, 256, 0, STREAM>>>(n, perm, col_rank, M.rowptr.data(), M.col.data(), M.val.data(), out.rowptr.data(),
+         k_perm_copy<8><<<grid, 256, 0, STREAM>>>(n, perm, col_rank, nown, M.rowptr.data(), M.col.data(), M.val.data(), out.rowptr.data(),
                                                   out.col.data(), out.val.data());
    }
    if (col_rank) sort_rows(out);
    M = std::move(out);
    M.reset_plan();
+}
+
+__global__ __launch_bounds__(256) void k_remap(int n, const int *__restrict__ rank, int *__restrict__ idx)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) idx[q] = rank[idx[q]];
+}
+// the owned unknowns a halo plan packs are renamed with their level
+void remap_halo(HaloPlan &h, const int *rank)
+{
+   if (h.send_total) k_remap<<<ceil_div(h.send_total, 256), 256, 0, STREAM>>>(h.send_total, rank, h.send_idx.data());
 }
 
 } // namespace
@@ -127,10 +140,19 @@ void Amg::reorder_levels()
    static const long long min_rows = getenv("HDA_REORDER") ? atoll(getenv("HDA_REORDER")) : 50000; // 0 disables
    const int L = num_levels();
    if (min_rows <= 0 || L < 3) return;
+   if (dist)
+   { // the level-by-level self check compares two setups entry by entry: keep both in natural order
+      const char *chk = getenv("HDA_DIST_CHECK");
+      if (chk && *chk && *chk != '0') return;
+   }
    // Gauss-Seidel sweeps depend on the numbering: hypre's semantics are the natural order
    auto gs = [](int t) { return t == 3 || t == 4 || t == 6 || t == 8 || t == 13 || t == 14; };
    if (gs(prm.relax_down) || gs(prm.relax_up) || gs(prm.relax_coarse)) return;
-   // levels 1 .. last with at least min_rows rows are renumbered; the next one anchors the recursion
+   // Row blocks (dist): only the unknowns this rank owns are renumbered -- ghost slots are numbered
+   // by global id and stay -- and the level handed over to the replicated tail keeps its order.
+   // nown(l) = owned unknowns of level l; the last level of `levels` is the coarsest / hand-over one.
+   auto nown = [&](int l) { return (l == L - 1) ? (dist ? coarse_nloc : level_A(l).nrows) : level_A(l).nrows; };
+   // levels 1 .. last with at least min_rows rows are renumbered
    int last = 0;
    for (int l = 1; l <= L - 2; l++)
       if (level_A(l).nrows >= min_rows) last = l;
@@ -142,7 +164,7 @@ void Amg::reorder_levels()
    for (int l = top; l >= 1; l--)
    {
       const DCsr &P = levels[(size_t)l].P; // level l -> l+1
-      const int   n = P.nrows, nc = P.ncols;
+      const int   n = P.nrows, nc = dist ? nown(l + 1) : P.ncols;
       DArray<int> parent((size_t)std::max(n, 1));
       DArray<unsigned long long> keys((size_t)std::max(n, 1)), sorted((size_t)std::max(n, 1));
       k_parent<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, nc, P.rowptr.data(), P.col.data(), P.val.data(), parent.data());
@@ -160,13 +182,21 @@ void Amg::reorder_levels()
       AmgLevel  &lv = levels[(size_t)l];
       const int *pl = perm[(size_t)l].data(), *rl = rank[(size_t)l].data();
       const int *rn = (l + 1 <= last) ? rank[(size_t)l + 1].data() : nullptr, *pn = (l + 1 <= last) ? perm[(size_t)l + 1].data() : nullptr;
-      permute_csr(lv.A, pl, rl);                      // A_l: rows and columns
-      permute_csr(lv.P, pl, rn);                      // P_l: rows level l, columns level l+1
-      permute_csr(lv.R, pn, rl);                      // R_l: rows level l+1, columns level l
+      const int nl = nown(l), nn = nown(l + 1);
+      permute_csr(lv.A, pl, rl, nl);                  // A_l: rows and owned columns
+      permute_csr(lv.P, pl, rn, nn);                  // P_l: rows level l, columns level l+1
+      permute_csr(lv.R, pn, rl, nl);                  // R_l: rows level l+1, columns level l
+      if (dist)
+      { // the owned unknowns the halo plans pack: inputs of A_l and R_l are level-l vectors, of P_l level l+1
+         remap_halo(lv.hA, rl);
+         remap_halo(lv.hR, rl);
+         if (rn) remap_halo(lv.hP, rn);
+      }
       if (l == 1)
       { // level 0 keeps the user's numbering: only the level-1 side of its transfer operators moves
-         permute_csr(levels[0].P, nullptr, rl);
-         permute_csr(levels[0].R, pl, nullptr);
+         permute_csr(levels[0].P, nullptr, rl, nl);
+         permute_csr(levels[0].R, pl, nullptr, 0);
+         if (dist) remap_halo(levels[0].hP, rl);
       }
       // the C/F marker of the level follows its rows (kept consistent for level_cf())
       if (lv.cf.size() >= (size_t)lv.A.nrows && lv.A.nrows)

@@ -167,7 +167,7 @@ def test_cli_overrides():
 @pytest.mark.parametrize("world,n,solver,port,rep_rows,setup", [
     (2, 16, "pcg", 29641, 100000, "partitioned"), (4, 20, "pcg", 29642, 0, "partitioned"), (4, 24, "pcg", 29644, 700, "partitioned"),
     (3, 12, "gmres", 29643, 0, "partitioned"), (4, 40, "pcg", 29645, 2000, "partitioned"), (4, 24, "pcg", 29646, 700, "replicated")])
-def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solver, port, rep_rows, setup, P=None):
+def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solver, port, rep_rows, setup, P=None, reorder=None):
     """Several ranks on one GPU through the staged transport: identical hierarchy (PMIS hashes
     global ids) => same iteration count as one rank, same solution to rounding.  rep_rows
     (HDA_REPLICATE_ROWS) moves the split between partitioned levels and the replicated tail:
@@ -180,6 +180,9 @@ def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solve
                HDA_DIST_CHECK="1" if setup == "partitioned" else "0")
     if P:
         env["HDA_TEST_P"] = ",".join(str(v) for v in P)
+    if reorder is not None:  # solve-phase renumbering forced onto small row blocks; the entry-wise self check is off then
+        env["HDA_REORDER"] = str(reorder)
+        env["HDA_DIST_CHECK"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "solve", out, str(n), solver]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -196,6 +199,15 @@ def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solve
     assert res["l1"] == pytest.approx(h.solution_norm("L1"), rel=1e-6)
     assert res["linf"] == pytest.approx(h.solution_norm("Linf"), rel=1e-6)
     assert np.linalg.norm(x) == pytest.approx(res["norm"], rel=1e-12)
+
+
+@pytest.mark.parametrize("world,n,rep_rows,setup,port", [(4, 24, 700, "partitioned", 29655), (2, 20, 300, "partitioned", 29656),
+                                                        (4, 24, 700, "replicated", 29657), (2, 32, 0, "partitioned", 29658)])
+def test_row_partitioned_with_renumbered_blocks(hd, tmp_path, world, n, rep_rows, setup, port):
+    """The solve-phase renumbering (hda_reorder.hip) on row blocks: only owned unknowns move, the halo
+    send lists follow them, ghost slots and the level handed to the replicated tail keep their order.
+    Forced down to 150 rows; same iterations and solution as one rank."""
+    test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, "pcg", port, rep_rows, setup, reorder=150)
 
 
 @pytest.mark.parametrize("world,n,P,port", [(2, 16, (2, 1, 1), 29651), (4, 20, (2, 2, 1), 29652), (4, 18, (2, 1, 2), 29653)])
