@@ -310,17 +310,26 @@ static void ensure_plan(const DCsr &A)
    k_chunk_rows<<<ceil_div(A.nchunks + 1, 256), 256, 0, STREAM>>>(A.nchunks, A.nrows, A.rowptr.data(), A.chunk_row.data());
 }
 
-template <int MODE, bool DOT>
+// VC: value-coded operator (see "value-coded SpMV" below) -- the 8-byte value stream is replaced by
+// one-byte codes into a 255-entry dictionary held in LDS; code 255 = read the value array
+template <int MODE, bool DOT, bool VC>
 __global__ __launch_bounds__(256) void k_spmv_stream(int nchunks, const int *__restrict__ chunk_row,
                                                      const int *__restrict__ rowptr, const int *__restrict__ col,
                                                      const double *__restrict__ val, const double *__restrict__ x,
                                                      double alpha, double beta, const double *yin,
                                                      const double *__restrict__ b, const double *__restrict__ dinv,
                                                      const double *__restrict__ w, double *out,
-                                                     double *__restrict__ partial)
+                                                     double *__restrict__ partial, const unsigned char *__restrict__ code,
+                                                     const double *__restrict__ dval)
 {
    extern __shared__ double prod[];
+   __shared__ double sdict[VC ? 256 : 1];
    const int tid  = threadIdx.x;
+   if (VC)
+   {
+      sdict[tid] = dval[tid];
+      __syncthreads();
+   }
    const int xcd  = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
    const int nper = (nchunks + 7) >> 3;
    double    acc  = 0.0;
@@ -335,7 +344,16 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int nchunks, const int *__r
       int k = k0 + tid;
 for (; k + 768 < k1; k += 1024)
       {
-         const double v0 = val[k], v1 = val[k + 256], v2 = val[k + 512], v3 = val[k + 768];
+         double v0, v1, v2, v3;
+         if (VC)
+         {
+            const int q0 = code[k], q1 = code[k + 256], q2 = code[k + 512], q3 = code[k + 768];
+            v0 = (q0 != 255) ? sdict[q0] : val[k];
+            v1 = (q1 != 255) ? sdict[q1] : val[k + 256];
+            v2 = (q2 != 255) ? sdict[q2] : val[k + 512];
+            v3 = (q3 != 255) ? sdict[q3] : val[k + 768];
+         }
+         else { v0 = val[k]; v1 = val[k + 256]; v2 = val[k + 512]; v3 = val[k + 768]; }
          const int    c0 = col[k], c1 = col[k + 256], c2 = col[k + 512], c3 = col[k + 768];
          const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
          prod[k - k0]       = v0 * x0;
@@ -343,7 +361,13 @@ for (; k + 768 < k1; k += 1024)
          prod[k - k0 + 512] = v2 * x2;
          prod[k - k0 + 768] = v3 * x3;
       }
-      for (; k < k1; k += 256) prod[k - k0] = val[k] * x[col[k]];
+      for (; k < k1; k += 256)
+      {
+         double vv;
+         if (VC) { const int q0 = code[k]; vv = (q0 != 255) ? sdict[q0] : val[k]; }
+         else vv = val[k];
+         prod[k - k0] = vv * x[col[k]];
+      }
       __syncthreads();
       // stage 2: L lanes per row, L = largest power of two with rows*L <= 256
       const int nr = r1 - r0;
@@ -479,6 +503,7 @@ static bool coded_enabled()
 
 // decide once per matrix whether the coded form pays: big enough to be bandwidth-bound and at
 // most 1 entry in 16 escaping
+static void ensure_vcoded(const DCsr &A);
 static void ensure_coded(const DCsr &A)
 {
    if (A.coded >= 0) return;
@@ -496,6 +521,7 @@ static void ensure_coded(const DCsr &A)
       A.code.release();
       A.dict_val.release();
       A.dict_delta.release();
+      ensure_vcoded(A); // the weights may still repeat even if the (offset, value) pairs do not
    };
    // sampling pass over ~64K rows: more than 1 sampled entry in 16 outside the table ends the
    // attempt (a few are expected: ghost columns of a row block have no fixed offset)
@@ -654,6 +680,125 @@ __global__ __launch_bounds__(256) void k_spmv_coded_row(int nrows, const int *__
    }
 }
 
+
+// ---- value-coded SpMV ----------------------------------------------------------------------
+// Interpolation operators of a constant-coefficient problem repeat their WEIGHTS even though the
+// column offsets are irregular (level-0 P of the 7-pt benchmark: 1300 distinct values, the 255
+// most frequent cover 91 % of the entries).  Such an operator keeps its column array and replaces
+// the 8-byte value by a one-byte code: 12 B -> 5 B per entry; rarer values carry code 255 and are
+// read from the value array.  Same products, same order.  The codes are consumed by the LDS-staged
+// streaming kernel (a row-per-lane kernel like the stencil one was 1.5x SLOWER here: irregular rows).
+constexpr int kVHashSlots = 8192;
+
+__device__ __forceinline__ unsigned vhash(unsigned long long key)
+{
+   key ^= key >> 31;
+   key *= 0x9e3779b97f4a7c15ull;
+   key ^= key >> 29;
+   return (unsigned)key & (kVHashSlots - 1);
+}
+// histogram of a 1-in-`stride` sample of the values
+__global__ __launch_bounds__(256) void k_vhist(long nnz, int stride, const double *__restrict__ v, unsigned long long *keys, int *counts, int *distinct)
+{
+   for (long k = ((long)blockIdx.x * 256 + threadIdx.x) * stride; k < nnz; k += (long)gridDim.x * 256 * stride)
+   {
+      if (*(volatile int *)distinct > kVHashSlots / 2) return; // too many different values: give up early
+      const unsigned long long key = (unsigned long long)__double_as_longlong(v[k]);
+      unsigned                 s   = vhash(key);
+      for (int probe = 0; probe < kVHashSlots; probe++)
+      {
+         unsigned long long cur = keys[s];
+         if (cur == kEmptyKey)
+         {
+            cur = atomicCAS(&keys[s], (unsigned long long)kEmptyKey, key);
+            if (cur == kEmptyKey) { atomicAdd(distinct, 1); cur = key; }
+         }
+         if (cur == key) { atomicAdd(&counts[s], 1); break; }
+         s = (s + 1) & (kVHashSlots - 1);
+      }
+   }
+}
+__global__ __launch_bounds__(256) void k_vencode(long nnz, const double *__restrict__ v, const unsigned long long *__restrict__ keys,
+                                                 const int *__restrict__ slot_code, unsigned char *__restrict__ code, int *escapes)
+{
+   int esc = 0;
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256)
+   {
+      const unsigned long long key = (unsigned long long)__double_as_longlong(v[k]);
+      unsigned                 s   = vhash(key);
+      int                      c   = 255;
+      for (int probe = 0; probe < kVHashSlots; probe++)
+      {
+         const unsigned long long cur = keys[s];
+         if (cur == kEmptyKey) break;
+         if (cur == key) { c = slot_code[s]; break; }
+         s = (s + 1) & (kVHashSlots - 1);
+      }
+      code[k] = (unsigned char)c;
+      esc += (c == 255);
+   }
+   for (int o = 32; o > 0; o >>= 1) esc += __shfl_xor(esc, o);
+   if ((threadIdx.x & 63) == 0 && esc) atomicAdd(escapes, esc);
+}
+
+static void ensure_vcoded(const DCsr &A)
+{ // called when the (offset, value) coding was rejected; leaves A.coded = 2 on success
+   if (A.nnz < (1 << 20) || A.maxrow > 64) return;
+   DArray<unsigned long long> keys((size_t)kVHashSlots);
+   DArray<int>                counts((size_t)kVHashSlots), distinct(1), esc(1);
+   HDA_HIP(hipMemsetAsync(keys.data(), 0xff, sizeof(unsigned long long) * kVHashSlots, STREAM));
+   counts.zero();
+   distinct.zero();
+   esc.zero();
+   // a small strided probe rejects operators with irregular values (every Galerkin coarse operator)
+   // before the larger sample that ranks the values by frequency
+   int nd = 0;
+   k_vhist<<<64, 256, 0, STREAM>>>(A.nnz, std::max(1, A.nnz / 65536), A.val.data(), keys.data(), counts.data(), distinct.data());
+   distinct.download(&nd, 1);
+   if (nd > 2048) return;
+   HDA_HIP(hipMemsetAsync(keys.data(), 0xff, sizeof(unsigned long long) * kVHashSlots, STREAM));
+   counts.zero();
+   distinct.zero();
+   k_vhist<<<1024, 256, 0, STREAM>>>(A.nnz, 64, A.val.data(), keys.data(), counts.data(), distinct.data());
+   distinct.download(&nd, 1);
+   if (nd > kVHashSlots / 2) return;
+   std::vector<unsigned long long> hk = keys.to_host();
+   std::vector<int>                hc = counts.to_host();
+   std::vector<int>                order;
+   long                            total = 0;
+   for (int s = 0; s < kVHashSlots; s++)
+      if (hk[(size_t)s] != kEmptyKey) { order.push_back(s); total += hc[(size_t)s]; }
+   std::sort(order.begin(), order.end(), [&](int a, int b) { return hc[(size_t)a] != hc[(size_t)b] ? hc[(size_t)a] > hc[(size_t)b] : hk[(size_t)a] < hk[(size_t)b]; });
+   long                covered = 0;
+   std::vector<int>    slot_code((size_t)kVHashSlots, 255);
+   std::vector<double> dict(256, 0.0);
+   for (size_t q = 0; q < order.size() && q < 255; q++)
+   {
+      slot_code[(size_t)order[q]] = (int)q;
+      long long bits              = (long long)hk[(size_t)order[q]];
+      memcpy(&dict[q], &bits, 8);
+      covered += hc[(size_t)order[q]];
+   }
+   if (total == 0 || covered * 10 < total * 7) return; // less than 70 % of the sample covered: not worth it
+   DArray<int> dsc;
+   dsc.upload(slot_code.data(), slot_code.size());
+   A.dict_val.upload(dict.data(), dict.size());
+   A.code.alloc(((size_t)A.nnz + 3 + 16) & ~(size_t)3);
+   k_vencode<<<2048, 256, 0, STREAM>>>(A.nnz, A.val.data(), keys.data(), dsc.data(), A.code.data(), esc.data());
+   int e = 0;
+   esc.download(&e, 1);
+   if ((long long)e * 10 > (long long)A.nnz * 3)
+   {
+      A.code.release();
+      A.dict_val.release();
+      return;
+   }
+   A.coded   = 2;
+   A.escapes = e;
+   HDA_TRACE("value-coded SpMV for %d x %d, nnz %d: %d distinct values sampled, %d escapes (%.2f %%)", A.nrows, A.ncols, A.nnz, nd, e,
+             100.0 * e / std::max(A.nnz, 1));
+}
+
 static int spmv_mode()
 {
    static int m = -1;
@@ -685,8 +830,12 @@ static void launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
    {
       const int    grid = DOT ? kRedBlocks : std::min(kRedBlocks, ((A.nchunks + 7) / 8) * 8);
       const size_t lds  = sizeof(double) * (size_t)(kChunk + A.maxrow);
-      k_spmv_stream<MODE, DOT><<<grid, 256, lds, STREAM>>>(A.nchunks, A.chunk_row.data(), A.rowptr.data(), A.col.data(),
-                                                           A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial);
+      if (A.coded == 2)
+         k_spmv_stream<MODE, DOT, true><<<grid, 256, lds, STREAM>>>(A.nchunks, A.chunk_row.data(), A.rowptr.data(), A.col.data(), A.val.data(), x,
+                                                                    alpha, beta, yin, b, dinv, w, out, partial, A.code.data(), A.dict_val.data());
+      else
+         k_spmv_stream<MODE, DOT, false><<<grid, 256, lds, STREAM>>>(A.nchunks, A.chunk_row.data(), A.rowptr.data(), A.col.data(), A.val.data(), x,
+                                                                     alpha, beta, yin, b, dinv, w, out, partial, nullptr, nullptr);
       return;
    }
    const int lpr  = pick_lpr(A);
@@ -747,6 +896,7 @@ double matrix_stream_bytes(const DCsr &A, bool format)
       ensure_plan(A);
       ensure_coded(A);
       if (A.coded == 1) return 1.0 * A.nnz + 12.0 * A.escapes;
+      if (A.coded == 2) return 5.0 * A.nnz + 8.0 * A.escapes;
    }
    return 12.0 * A.nnz;
 }
