@@ -70,17 +70,17 @@ def main():
             return None, None, None
         return fetch_factor * f * 1024 + write_factor * (w or 0.0) * 1024, f, w
 
-    for key, part, top in (("k_spmv_level0", "k_spmv_coded_row<0, true>", False), ("k_spmv_level0", "k_spmv_stream<0, true>", False)):
+    for key, part, top in (("k_spmv_level0", "k_spmv_coded_row<0, true>", False), ("k_spmv_level0", "k_spmv_stream<0, true", False)):
         t, f, w = traffic(part, top)
         if t is not None and key + "_bytes_per_launch" not in out:
             out[key + "_bytes_per_launch"] = t
             out[key] = {"kernel": part, "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
     # Jacobi sweep on the largest plain-CSR operator (bench.py's dominant kernel): level 1 when level 0 is coded
-    t, f, w = traffic("k_spmv_stream<2, false>", True)
+    t, f, w = traffic("k_spmv_stream<2, false", True)
     if t is not None:
         lvl = 1 if "k_spmv_coded_row<0, true>" in "".join(byk.keys()) else 0
         out[f"k_spmv_stream_jacobi_level{lvl}_bytes_per_launch"] = t
-        out[f"k_spmv_stream_jacobi_level{lvl}"] = {"kernel": "k_spmv_stream<2, false>, launches within 5 % of the largest FETCH_SIZE",
+        out[f"k_spmv_stream_jacobi_level{lvl}"] = {"kernel": "k_spmv_stream<2, false[, false]>, launches within 5 % of the largest FETCH_SIZE",
                                                    "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
     json.dump(out, open(os.path.join(os.path.dirname(tag) or ".", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
