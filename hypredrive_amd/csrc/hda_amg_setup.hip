@@ -1135,7 +1135,11 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    int cap_row = 8, cap_ub = 16, cap_nbr = 64;
    while (cap_row < hmx[0] && cap_row < 256) cap_row <<= 1;
    while (cap_ub < hmx[1] && cap_ub < 1024) cap_ub <<= 1;
-   while (cap_nbr < hmx[2] && cap_nbr < 1024) cap_nbr <<= 1;
+   // neighbour-row staging area per wave: 512 entries measured best at 256^3 (level 2: 85 -> 49 ms against
+   // 1024, because two workgroups then fit a CU's LDS; below 512 level 1 loses its staging: 113 -> 137 ms)
+   static const int nbr_cap_max = getenv("HDA_INTERP_NBR") ? atoi(getenv("HDA_INTERP_NBR")) : 512;
+   while (cap_nbr < hmx[2] && cap_nbr < nbr_cap_max) cap_nbr <<= 1;
+   while (cap_nbr > 64 && interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * 4 > 150 * 1024) cap_nbr >>= 1; // four waves must fit the LDS budget
    if (use_wave)
       k_interp_rowmode<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), ub.data(), nt.data(), cap_row, cap_ub, cap_nbr, rowmode.data(), hsz.data());
    exclusive_scan64(n, ub.data(), uofs.data());
@@ -1715,7 +1719,8 @@ void Amg::build_smoother_data(int l)
    const DCsr &Al = level_A(l);
    AmgLevel   &lv = levels[(size_t)l];
    build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down);
-   build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up);
+   if (prm.relax_up == prm.relax_down) lv.dinv_up.copy_from(lv.dinv_down); // same divisors: a copy, not a second pass over A
+   else build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up);
    const bool last = (l == num_levels() - 1);
    const bool gs   = is_gs_type(prm.relax_down) || is_gs_type(prm.relax_up) || (last && is_gs_type(prm.relax_coarse));
    if (gs && !lv.gs.built) build_gs_plan(Al, lv.gs);
