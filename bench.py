@@ -100,8 +100,9 @@ def run_single(args):
     iters = res["iters"]
     # bytes of one solve: iters PCG iterations + (iters + 1) V-cycles.  "algorithmic" = the CSR
     # figures of SURVEY 8(d); "format" = what the kernels stream with coded operators
-    bytes_solve = iters * h.pcg_iteration_bytes(A) + (iters + 1) * amg.vcycle_bytes
-    bytes_solve_fmt = iters * fb0["pcg_iteration"] + (iters + 1) * fb0["vcycle"]
+    ncyc = res["precond_calls"]  # V-cycles really run: hypre's PCG runs iters + 1, the last one unused; here it is skipped
+    bytes_solve = iters * h.pcg_iteration_bytes(A) + ncyc * amg.vcycle_bytes
+    bytes_solve_fmt = iters * fb0["pcg_iteration"] + ncyc * fb0["vcycle"]
     dn, dc, dnnz = Ad.dims
     dom_bytes = spmv_bytes(dn, dc, dnnz) + 16.0 * dn          # + b, dinv of the sweep
     dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -128,7 +129,7 @@ def run_single(args):
         "config": {"workload": f"lap7 {n}^3 fp64 AMG-PCG (PMIS, ext+i Pmax 4, l1-Jacobi V(1,1), GE coarse), "
                                f"BASELINE config 2", "rows": N, "nnz": nnz, "parallelism": "1 GPU",
                    "rtol": 1e-6, "timed": "solve phase only (reference 'solve' timer); setup_ms is the 'prec' timer"},
-        "iters": iters, "true_rel_res": res["true_rel"], "setup_ms": setup_ms, "setup_cold_ms": setup_cold_ms,
+        "iters": iters, "vcycles": ncyc, "true_rel_res": res["true_rel"], "setup_ms": setup_ms, "setup_cold_ms": setup_cold_ms,
         "solve_ms_each": [float(x) for x in res["solve_ms"]],
         "num_levels": amg.num_levels, "operator_complexity": o, "grid_complexity": g,
         # CSR-equivalent rate (SURVEY 8(d) bytes / time) and the rate of bytes really streamed

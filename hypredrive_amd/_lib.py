@@ -56,7 +56,7 @@ SYMBOLS = [
     "hda_csr_dims", "hda_csr_download", "hda_lap7_create", "hda_spmv", "hda_relax", "hda_dot",
     "hda_l1_norms", "hda_strength", "hda_pmis", "hda_interp_extpi", "hda_rap", "hda_transpose",
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
-    "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
+    "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest",
 ]
@@ -344,7 +344,7 @@ def solve_device(A, amg=None, kp=None, b=None, solver=0, nsolves=1, profile_k1=T
                                    _dp(times), C.byref(it), C.byref(d[0]), C.byref(d[1]), C.byref(d[2]),
                                    C.byref(d[3]) if profile_k1 else None))
     return dict(solve_ms=times, iters=it.value, final_rel=d[0].value, r0=d[1].value, true_rel=d[2].value,
-                k1_avg_ms=d[3].value)
+                k1_avg_ms=d[3].value, precond_calls=load().hda_last_precond_calls())
 
 
 def pcg_iteration_bytes(A):

@@ -507,6 +507,8 @@ extern "C" int hda_time_kernel(int kind, hda_csr_t A, hda_amg_t amg, int reps, d
    HDA_CATCH
 }
 
+extern "C" int hda_last_precond_calls(void) { return last_precond_calls(); }
+
 extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, int solver,
                                 const double *b_host, int nsolves, double *solve_ms, int *iters,
                                 double *final_rel, double *r0_norm, double *true_rel, double *k1_avg_ms)

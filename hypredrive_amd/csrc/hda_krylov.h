@@ -27,6 +27,7 @@ struct KrylovResult {
    std::vector<double> hist;            // ||r_k||_2, k = 0..iters
    double              k1_ms_sum = 0.0; // profile_k1: summed duration of the PCG SpMV launches
    int                 k1_count  = 0;
+   int                 precond_calls = 0; // preconditioner applications actually enqueued (PCG)
 };
 
 // Preconditioner seam = what hypre's Krylov expects of a preconditioner
@@ -53,6 +54,7 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &p, con
 KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
 
 // algorithmic HBM bytes of one PCG iteration excluding the preconditioner
+int    last_precond_calls(); // preconditioner applications enqueued by the last pcg() call
 double pcg_iteration_bytes(const DCsr &A, bool format = false); // format: what the kernels read (coded operators), else CSR figure
 
 } // namespace hda

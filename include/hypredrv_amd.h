@@ -131,6 +131,9 @@ int hda_time_kernel(int kind, hda_csr_t A, hda_amg_t amg, int reps, double *avg_
  * outside the timed region).  b == NULL uses the generator's rhs stored with A.
  * solve_ms gets nsolves entries.  k1_avg_ms = average duration of the level-0 PCG SpMV
  * kernel measured with HIP events inside those solves (0 for GMRES). */
+/* preconditioner applications the last hda_solve_device solve enqueued (PCG skips the one hypre
+ * computes and discards after the final residual test) */
+int hda_last_precond_calls(void);
 int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, int solver,
                      const double *b_host, int nsolves, double *solve_ms, int *iters,
                      double *final_rel, double *r0_norm, double *true_rel, double *k1_avg_ms);
