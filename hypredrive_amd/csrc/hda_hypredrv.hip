@@ -157,6 +157,8 @@ struct hypredrv_struct {
    PreconCookie   cookie{nullptr};
    Stats          stats;
    std::vector<int> dofmap; // function / field label of every locally owned unknown
+   std::vector<HYPRE_IJVector> state; // borrowed time-level vectors (host resident), logical index i = state[(state_first + i) % n]
+   int            state_first = 0;
    int            current_system_index = -1;
    int            last_iters = 0, last_converged = 0;
    double         last_rel = 0.0, last_setup_s = 0.0, last_solve_s = 0.0;
@@ -959,11 +961,67 @@ extern "C" uint32_t HYPREDRV_LinearSystemPrintDofmap(HYPREDRV_t h, const char *f
 // vectors are not used
 extern "C" uint32_t HYPREDRV_LinearSystemSetNearNullSpace(HYPREDRV_t h, int, int, const HYPRE_Complex *) { CHECK_INIT_OBJ(h); return g_err; }
 UNSUPPORTED(HYPREDRV_LinearSystemSetNullSpace(HYPREDRV_t, int, int, const HYPRE_Complex *), "null-space projection")
-UNSUPPORTED(HYPREDRV_StateVectorSet(HYPREDRV_t, int, HYPRE_IJVector *), "state vectors")
-UNSUPPORTED(HYPREDRV_StateVectorGetValues(HYPREDRV_t, int, HYPRE_Complex **), "state vectors")
-UNSUPPORTED(HYPREDRV_StateVectorCopy(HYPREDRV_t, int, int), "state vectors")
-UNSUPPORTED(HYPREDRV_StateVectorUpdateAll(HYPREDRV_t), "state vectors")
-UNSUPPORTED(HYPREDRV_StateVectorApplyCorrection(HYPREDRV_t, int), "state vectors")
+// State vectors (reference src/HYPREDRV.c state-vector block, include/HYPREDRV.h:1521-1695): the
+// time levels of a nonlinear / transient driver.  The drivers create them HOST-initialised and
+// read and write them through raw pointers between solves, so they live in host memory here: the
+// storage is the IJVector's host stage, the logical -> physical mapping rotates, and the Newton
+// correction is the device solution copied back once per call.
+extern "C" uint32_t HYPREDRV_StateVectorSet(HYPREDRV_t h, int nstates, HYPRE_IJVector *vecs)
+{
+   CHECK_INIT_OBJ(h);
+   if (nstates <= 0 || !vecs) return err_set(ERR_INVALID_VAL, "StateVectorSet: need at least one vector");
+   h->state.clear();
+   for (int s = 0; s < nstates; s++)
+   {
+      HYPRE_IJVector v = vecs[s];
+      if (!v) return err_set(ERR_INVALID_VAL, "StateVectorSet: NULL vector in the list");
+      if (v->stage.size() != (size_t)v->nloc) v->stage.assign((size_t)v->nloc, 0.0);
+      h->state.push_back(v);
+   }
+   h->state_first = 0;
+   return g_err;
+}
+static HYPRE_IJVector state_at(hypredrv_struct *h, int index)
+{
+   const int n = (int)h->state.size();
+   if (n == 0 || index < 0 || index >= n) return nullptr;
+   return h->state[(size_t)((h->state_first + index) % n)];
+}
+extern "C" uint32_t HYPREDRV_StateVectorGetValues(HYPREDRV_t h, int index, HYPRE_Complex **data_ptr)
+{
+   CHECK_INIT_OBJ(h);
+   HYPRE_IJVector v = state_at(h, index);
+   if (!v || !data_ptr) return err_set(ERR_INVALID_VAL, "StateVectorGetValues: index outside the states set with StateVectorSet");
+   *data_ptr = v->stage.data();
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_StateVectorCopy(HYPREDRV_t h, int index_in, int index_out)
+{
+   CHECK_INIT_OBJ(h);
+   HYPRE_IJVector a = state_at(h, index_in), b = state_at(h, index_out);
+   if (!a || !b || a->nloc != b->nloc) return err_set(ERR_INVALID_VAL, "StateVectorCopy: bad indices or incompatible sizes");
+   if (a != b) std::copy(a->stage.begin(), a->stage.end(), b->stage.begin());
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_StateVectorUpdateAll(HYPREDRV_t h)
+{
+   CHECK_INIT_OBJ(h);
+   if (h->state.empty()) return err_set(ERR_INVALID_VAL, "StateVectorUpdateAll: no state vectors set");
+   h->state_first = (h->state_first + 1) % (int)h->state.size(); // logical 0 <- what was logical 1, ...
+   return g_err;
+}
+extern "C" uint32_t HYPREDRV_StateVectorApplyCorrection(HYPREDRV_t h, int state_idx)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   HYPRE_IJVector v = state_at(h, state_idx);
+   if (!v) return err_set(ERR_INVALID_VAL, "StateVectorApplyCorrection: index outside the states set with StateVectorSet");
+   if (!h->vec_x || h->vec_x->nloc != v->nloc) return err_set(ERR_UNKNOWN, "StateVectorApplyCorrection: no solution vector of matching size");
+   std::vector<double> dx((size_t)std::max(v->nloc, 1));
+   if (v->nloc) HDA_HIP(hipMemcpy(dx.data(), h->vec_x->data(), sizeof(double) * (size_t)v->nloc, hipMemcpyDeviceToHost));
+   for (int i = 0; i < v->nloc; i++) v->stage[(size_t)i] += dx[(size_t)i];
+   API_CATCH
+}
 static std::string level_region(const char *name, int id) { return id >= 0 ? std::string(name) + "-" + std::to_string(id) : std::string(name); }
 extern "C" uint32_t HYPREDRV_AnnotateLevelBegin(HYPREDRV_t h, int level, const char *name, int id)
 {

@@ -385,6 +385,26 @@ def test_reference_elasticity_driver_unmodified(pins):
     assert row and float(row.group(1)) < 1e-6 and 21 < int(row.group(2)) < 80
 
 
+def test_reference_heatflow_driver_unmodified():
+    """Fourth unmodified driver (examples/src/C_heatflow/heatflow.c: transient nonlinear heat conduction,
+    Newton iterations inside time steps, GMRES + BoomerAMG, HYPREDRV_StateVector* for the time levels,
+    two annotation levels).  No checked-in output exists for it; the checks are the driver's own:
+    every Newton solve converges, the error against its manufactured solution stays at
+    discretisation level, energy decays, and the table carries "timestep.newton.system" paths."""
+    exe = os.path.join(ROOT, "build", "heatflow_ref")
+    if not os.path.exists(exe):
+        pytest.skip("build/heatflow_ref not built (needs /root/reference + MPICH at build time)")
+    r = subprocess.run([exe, "-v", "1"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    steps = re.findall(r"^Time step:\s+(\d+) \|.*\| NL:\s+(\d+) \| Lin:\s+(\d+) \|.*L2\(Err\)=(\S+) \| E=(\S+)", r.stdout, re.M)
+    assert len(steps) >= 5
+    assert all(int(s[1]) >= 1 and 1 <= int(s[2]) <= 40 and float(s[3]) < 2e-2 for s in steps)
+    E = [float(s[4]) for s in steps]
+    assert all(b < a for a, b in zip(E, E[1:]))               # T = 0 on one face, insulated elsewhere: energy decays
+    rows = re.findall(r"^\|\s+(\d+\.\d+\.\d+) \|.*\|\s+(\S+) \|\s+(\d+) \|$", r.stdout, re.M)
+    assert len(rows) >= len(steps) and rows[0][0] == "1.1.1" and all(float(x[1]) < 1e-6 for x in rows)
+
+
 def test_reference_laplacian_driver_cpu_defaults(pins):
     """examples/refOutput/laplacian.txt:34-38 (5 iterations, 6.12e-07) through the unmodified driver
     with the reference's CPU-build defaults."""
