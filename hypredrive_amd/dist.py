@@ -77,6 +77,18 @@ def init(transport="auto"):
         transport = "rccl" if ndev >= world or (ndev > 1 and local < ndev) else "staged"
     L = hd.lib()
     if transport == "rccl":
+        # RCCL refuses two ranks on one device, and the refusing rank leaves its peers blocked inside
+        # ncclCommInitRank: find that out BEFORE touching RCCL (single node: the device index is the identity)
+        mine = local if local < max(ndev, 1) else 0
+        devs = [None] * world
+        dist.all_gather_object(devs, (os.uname().nodename, mine))
+        if len(set(devs)) < world:
+            if forced == "rccl":
+                raise RuntimeError(f"RCCL needs one GPU per rank; ranks share devices: {devs}")
+            if rank == 0:
+                print("[hypredrive_amd] several ranks share a GPU: using the host-staged transport", flush=True)
+            transport = "staged"
+    if transport == "rccl":
         # join RCCL and prove the communicator works (all-reduce + neighbour exchange self-test);
         # if ANY rank fails, every rank falls back to the host-staged transport: slower
         # messages, same kernels and results.  Set HDA_TRANSPORT=rccl to make this fatal.
