@@ -495,6 +495,38 @@ print(json.dumps(dict(it=[ro["iters"], rh["iters"], rg["iters"], rq["iters"]],
     assert not res["same_order"] and res["vals"] and res["lens"]
 
 
+def test_coded_operators_change_no_result():
+    """Stencil-coded A (1 B/entry), value-coded level-0 P/R (5 B/entry) and the solve-phase renumbering
+    only change how operators are stored: a 96^3 AMG-PCG solve with all of them (default) and with
+    none (HDA_CODED=0 HDA_REORDER=0) must take the same iterations, and agree in the solution to
+    rounding.  Fresh processes, because the switches are read once."""
+    import json
+    import subprocess
+    import sys
+    code = """
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import hypredrive_amd as hd
+A = hd.lap7(96, 96, 96)
+amg = hd.Amg(A)
+b = np.zeros(96 ** 3); b[:96 * 96] = 1.0
+r = hd.pcg(A, b, amg)
+fb = hd.format_bytes(A, amg)
+print(json.dumps(dict(it=r["iters"], hist=list(map(float, r["hist"])), xn=float(np.linalg.norm(r["x"])), x0=[float(v) for v in r["x"][::50021]],
+                      coded=fb["coded"], ratio=fb["vcycle"] / amg.vcycle_bytes)))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for env in ({}, {"HDA_CODED": "0", "HDA_REORDER": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    a, b = out
+    assert a["coded"] and not b["coded"] and a["ratio"] < 0.9 and b["ratio"] == 1.0   # fewer bytes streamed
+    assert a["it"] == b["it"]
+    assert np.allclose(a["hist"], b["hist"], rtol=1e-9) and np.allclose(a["x0"], b["x0"], rtol=1e-9, atol=1e-12)
+    assert a["xn"] == pytest.approx(b["xn"], rel=1e-10)
+
+
 def test_edge_cases(orc, hd, pins):
     # 1x1 system 3x = 6 (tests/test_setmatrix_from_csr.c:397-417)
     u = pins["unit"]["one_by_one"]
