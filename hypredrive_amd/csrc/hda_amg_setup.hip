@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void k_max3(int n, const int *__restrict__ rp,
    if ((threadIdx.x & 63) == 0) { atomicMax(&mx[0], a); atomicMax(&mx[1], b); atomicMax(&mx[2], c); }
 }
 
-__global__ __launch_bounds__(256) void k_interp_wave(
+__global__ __launch_bounds__(256, 3) void k_interp_wave(
    int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
    const unsigned char *__restrict__ smask, const int *__restrict__ cf, const int *__restrict__ nsC,
    const long long *__restrict__ uofs, int cap_row, int cap_ub, int cap_nbr, int pmax, double trunc_factor,
@@ -1135,9 +1135,14 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    int cap_row = 8, cap_ub = 16, cap_nbr = 64;
    while (cap_row < hmx[0] && cap_row < 256) cap_row <<= 1;
    while (cap_ub < hmx[1] && cap_ub < 1024) cap_ub <<= 1;
-   // neighbour-row staging area per wave: 512 entries measured best at 256^3 (level 2: 85 -> 49 ms against
-   // 1024, because two workgroups then fit a CU's LDS; below 512 level 1 loses its staging: 113 -> 137 ms)
-   static const int nbr_cap_max = getenv("HDA_INTERP_NBR") ? atoi(getenv("HDA_INTERP_NBR")) : 512;
+   // Neighbour-row staging area per wave.  The kernel is held to 168 VGPRs (three waves per SIMD), so
+   // LDS decides the occupancy: where the neighbour rows of a typical row (about half of avg_row^2
+   // entries) fit 512 entries they are staged (level 1 of the 256^3 benchmark: 86 ms against 106 with
+   // 256); where they would not fit anyway the smaller area lets three workgroups share a CU (level 2:
+   // 38 ms against 50).  HDA_INTERP_NBR overrides.
+   static const int nbr_env = getenv("HDA_INTERP_NBR") ? atoi(getenv("HDA_INTERP_NBR")) : 0;
+   const double     est_nbr = 0.5 * A.avg_row() * A.avg_row();
+   const int        nbr_cap_max = nbr_env > 0 ? nbr_env : (est_nbr <= 768.0 ? 512 : 256);
    while (cap_nbr < hmx[2] && cap_nbr < nbr_cap_max) cap_nbr <<= 1;
    while (cap_nbr > 64 && interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * 4 > 150 * 1024) cap_nbr >>= 1; // four waves must fit the LDS budget
    if (use_wave)
@@ -1448,7 +1453,7 @@ __global__ __launch_bounds__(256) void k_esc_chunk_rows(int nchunks, int nrows, 
    chunk_row[c] = lo;
 }
 
-constexpr int kEscEntries = 1536; // X entries of a chunk staged in LDS for the expansion
+constexpr int kEscEntries = 640; // X entries of a chunk staged in LDS for the expansion
 
 // One pass: products -> LDS keys, sort, segment sums in enumeration order, results written to
 // a scratch CSR whose rows start at rowstart[i] (<= the row's first product index), counts in cnt.
