@@ -1133,7 +1133,7 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    if (imode && !strcmp(imode, "thread")) use_wave = false;
    if (imode && !strcmp(imode, "wave")) use_wave = pmax > 0 && pmax <= 16;
    int cap_row = 8, cap_ub = 16, cap_nbr = 64;
-   while (cap_row < hmx[0] && cap_row < 256) cap_row <<= 1;
+   cap_row = std::min(256, std::max(8, (hmx[0] + 31) / 32 * 32)); // rows longer than 256 entries keep the thread kernel
    while (cap_ub < hmx[1] && cap_ub < 1024) cap_ub <<= 1;
    // Neighbour-row staging area per wave.  The kernel is held to 168 VGPRs (three waves per SIMD), so
    // LDS decides the occupancy: where the neighbour rows of a typical row (about half of avg_row^2
