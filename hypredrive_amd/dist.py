@@ -9,6 +9,7 @@ Transport choice:
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -86,7 +87,7 @@ def init(transport="auto"):
             if forced == "rccl":
                 raise RuntimeError(f"RCCL needs one GPU per rank; ranks share devices: {devs}")
             if rank == 0:
-                print("[hypredrive_amd] several ranks share a GPU: using the host-staged transport", flush=True)
+                print("[hypredrive_amd] several ranks share a GPU: using the host-staged transport", file=sys.stderr, flush=True)
             transport = "staged"
     if transport == "rccl":
         # join RCCL and prove the communicator works (all-reduce + neighbour exchange self-test);
@@ -112,7 +113,7 @@ def init(transport="auto"):
             if forced == "rccl":
                 raise RuntimeError(f"RCCL transport unavailable on some rank (this rank: {err})")
             if rank == 0:
-                print(f"[hypredrive_amd] RCCL transport unavailable ({err}); using the host-staged transport", flush=True)
+                print(f"[hypredrive_amd] RCCL transport unavailable ({err}); using the host-staged transport", file=sys.stderr, flush=True)
             L.HYPREDRV_AMD_CommFinalize()
             transport = "staged"
     if transport == "staged":
