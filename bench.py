@@ -132,6 +132,7 @@ def run_single(args):
         "iters": iters, "vcycles": ncyc, "true_rel_res": res["true_rel"], "setup_ms": setup_ms, "setup_cold_ms": setup_cold_ms,
         "solve_ms_each": [float(x) for x in res["solve_ms"]],
         "num_levels": amg.num_levels, "operator_complexity": o, "grid_complexity": g,
+        "hbm_in_use_gb": h.memory_stats()[0] / 1e9, "hbm_peak_gb": h.memory_stats()[1] / 1e9,  # library allocator: resident after setup / peak during it
         # CSR-equivalent rate (SURVEY 8(d) bytes / time) and the rate of bytes really streamed
         "solve_phase_hbm_gbs": gbs(bytes_solve, ms_per_step),
         "solve_phase_hbm_frac": gbs(bytes_solve, ms_per_step) / HBM_PEAK_GBS,
