@@ -1657,7 +1657,14 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
    int T = 1024;
    while (T < maxnp) T <<= 1;
    HDA_TRACE("  spgemm(esc): n=%d products=%lld max/row=%d T=%d", n, total, maxnp, T);
-   static const long long scratch_cap = getenv("HDA_ESC_SCRATCH") ? atoll(getenv("HDA_ESC_SCRATCH")) : (3LL << 30); // products
+   // product scratch (12 B each) may take up to 30 % of the device memory: 7 G products on a 288 GB part,
+   // enough for the 512^3 benchmark's largest Galerkin product (5 G); beyond it the hash path takes over
+   static const long long scratch_cap = [] {
+      if (getenv("HDA_ESC_SCRATCH")) return atoll(getenv("HDA_ESC_SCRATCH"));
+      size_t freeb = 0, totalb = 0;
+      if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return 3LL << 30;
+      return (long long)(0.3 * (double)totalb / 12.0);
+   }(); // products
    if (T > 4096 || Y.ncols >= (1LL << 31) || total > scratch_cap) return spgemm_hash(X, Y, C); // outside the LDS path
    const int cap     = 2 * T;
    const int nchunks = (int)std::max<long long>(1, (total + T - 1) / T);
