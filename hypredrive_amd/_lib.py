@@ -58,7 +58,7 @@ SYMBOLS = [
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
-    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest",
+    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total",
 ]
 
 
@@ -111,6 +111,7 @@ def load():
     L.hda_pcg_iteration_bytes.argtypes = [vp]
     L.hda_pcg_iteration_bytes.restype = C.c_double
     L.hda_memory_stats.argtypes = [dp, dp]
+    L.hda_check_row_total.argtypes = [C.c_longlong, C.c_int]
     L.hda_format_bytes.argtypes = [vp, vp, dp, dp, dp, ip]
     L.hda_probe_spmv.argtypes = [vp, C.c_int]
     L.hda_probe_read.argtypes = [dp, ip]
@@ -367,6 +368,11 @@ def probe_read():
     ms, n = C.c_double(), C.c_int()
     _check(load().hda_probe_read(C.byref(ms), C.byref(n)))
     return ms.value, n.value
+
+
+def check_row_total(nrows, row_len):
+    """Run the int32 size guard of the setup stages on nrows rows of row_len entries (raises LibraryError past 2^31-1)."""
+    _check(load().hda_check_row_total(int(nrows), int(row_len)))
 
 
 def memory_stats():

@@ -1183,6 +1183,7 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    P.nrows = n;
    P.ncols = nc;
    P.rowptr.alloc((size_t)n + 1);
+   require_int32_total(n, pcnt.data(), "interpolation operator");
    exclusive_scan(n, pcnt.data(), P.rowptr.data(), nullptr);
    HDA_HIP(hipMemcpyAsync(&P.nnz, P.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
    Context::get().sync();
@@ -1382,6 +1383,7 @@ static void spgemm_hash(const DCsr &X, const DCsr &Y, DCsr &C)
                                                                  C.rowptr.data(), C.col.data(), C.val.data());
    };
    auto finish_rowptr = [&]() {
+      require_int32_total(n, cnt.data(), "sparse product");
       exclusive_scan(n, cnt.data(), C.rowptr.data(), nullptr);
       HDA_HIP(hipMemcpyAsync(&C.nnz, C.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
       Context::get().sync();
@@ -1690,6 +1692,7 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
    C.nrows = n;
    C.ncols = Y.ncols;
    C.rowptr.alloc((size_t)n + 1);
+   require_int32_total(n, cnt.data(), "sparse product");
    exclusive_scan(n, cnt.data(), C.rowptr.data(), nullptr);
    HDA_HIP(hipMemcpyAsync(&C.nnz, C.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
    Context::get().sync();
@@ -2558,6 +2561,7 @@ void assemble_csr(int nrows, int ncols, int base, const DCsr &src, const int *co
    out.nrows = nrows;
    out.ncols = ncols;
    out.rowptr.alloc((size_t)nrows + 1);
+   require_int32_total(nrows, len.data(), "assembled row block");
    exclusive_scan(nrows, len.data(), out.rowptr.data(), nullptr);
    HDA_HIP(hipMemcpyAsync(&out.nnz, out.rowptr.data() + nrows, 4, hipMemcpyDeviceToHost, STREAM));
    Context::get().sync();
@@ -2879,6 +2883,7 @@ void add_rows(const DCsr &A, const DCsr &B, DCsr &C)
    C.ncols = A.ncols;
    C.rowptr.alloc((size_t)n + 1);
    if (n) k_merge_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), B.rowptr.data(), B.col.data(), cnt.data());
+   require_int32_total(n, cnt.data(), "merged row block");
    exclusive_scan(n, cnt.data(), C.rowptr.data(), nullptr);
    HDA_HIP(hipMemcpyAsync(&C.nnz, C.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
    Context::get().sync();

@@ -594,6 +594,17 @@ extern "C" int hda_probe_read(double *avg_ms, int *count)
    HDA_CATCH
 }
 
+extern "C" int hda_check_row_total(long long nrows, int row_len)
+{
+   HDA_TRY
+   HDA_REQUIRE(nrows >= 0 && nrows < (1LL << 31) && row_len >= 0, "bad arguments");
+   DArray<int>      len((size_t)std::max<long long>(nrows, 1));
+   std::vector<int> h((size_t)nrows, row_len);
+   if (nrows) len.upload(h.data(), (size_t)nrows);
+   require_int32_total((long)nrows, len.data(), "row block");
+   HDA_CATCH
+}
+
 extern "C" int hda_memory_stats(double *in_use, double *peak)
 {
    if (in_use) *in_use = (double)pool_bytes_in_use();

@@ -1302,6 +1302,26 @@ void exclusive_scan(int n, const int *in, int *out, int *total_out_dev)
 }
 void exclusive_scan64(long n, const int *in, long long *out) { scan_from_int<long long>(n, in, out); }
 
+__global__ __launch_bounds__(256) void k_sum64(long n, const int *__restrict__ in, unsigned long long *out)
+{
+   unsigned long long s = 0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += (unsigned long long)in[i];
+   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+   if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+// matrices are indexed with int32: a row-length array whose sum does not fit is a clear error, not a wrap-around
+void require_int32_total(long n, const int *counts, const char *what)
+{
+   DArray<unsigned long long> t(1);
+   t.zero();
+   if (n) k_sum64<<<(int)std::min<long>((n + 255) / 256, 1024), 256, 0, STREAM>>>(n, counts, t.data());
+   unsigned long long h = 0;
+   t.download(&h, 1);
+   if (h >= (1ull << 31))
+      throw Error(std::string(what) + " would have " + std::to_string(h) + " entries: more than int32 indexing holds (2^31-1); "
+                  "partition the problem over more GPUs");
+}
+
 // ------------------------------------------------------------- row utilities
 
 // hypre_ParCSRComputeL1Norms: option 1 = sum_j |a_ij| (sign of a_ii), option 4 = a_ii on

@@ -153,6 +153,11 @@ int hda_probe_read(double *avg_ms, int *count);
 int hda_comm_selftest(void);
 /* allocator statistics (bytes) */
 int hda_memory_stats(double *in_use, double *peak);
+/* Matrices are int32-indexed (hypre's HYPRE_Int in its default build, HYPRE_config.h).  Every setup
+ * stage that sizes an operator (interpolation, sparse products, routed row blocks) checks the 64-bit
+ * sum of its row lengths first and returns HDA_ERR with a message instead of wrapping around.  This
+ * entry runs that check on nrows rows of row_len entries (test hook for the guard). */
+int hda_check_row_total(long long nrows, int row_len);
 
 #ifdef __cplusplus
 }

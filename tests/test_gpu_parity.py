@@ -595,3 +595,14 @@ def test_full_size_spmv_properties(hd):
     assert rel(lhs, rhs) < 1e-13
     # symmetry: <Au, v> == <u, Av>
     assert abs(A.spmv(u) @ v - u @ A.spmv(v)) / abs(u @ A.spmv(v)) < 1e-12
+
+
+def test_int32_size_guard(hd):
+    """Operators are int32-indexed (HYPRE_Int in hypre's default build): a setup stage whose output
+    would pass 2^31-1 entries must stop with an error, never wrap around."""
+    from hypredrive_amd import _lib
+    _lib.check_row_total(1 << 20, 2047)            # 2^31 - 2^20: fits
+    with pytest.raises(_lib.LibraryError, match="int32"):
+        _lib.check_row_total(1 << 20, 2048)        # exactly 2^31
+    with pytest.raises(_lib.LibraryError, match="int32"):
+        _lib.check_row_total(1 << 22, 1 << 20)
