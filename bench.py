@@ -8,8 +8,9 @@ right-hand side and hierarchy already resident in HBM.  DOF/s = N / solve-phase 
 exactly the reference's "solve" timer (src/internal/solver.c:668-683); AMG setup is the
 reference's separate "prec" timer and is reported beside it (setup_ms), not hidden.
 
-N = 1: BASELINE config 2 (256^3 on one MI355X).  N > 1: the same global problem row
-partitioned over N ranks (strong scaling, RCCL halo exchange + fused dot all-reduce).
+N = 1: BASELINE config 2 (256^3 on one MI355X).  N > 1: one 256^3 block per GPU, row
+partitioned (weak scaling; 8 GPUs = BASELINE config 3, 512^3), RCCL halo exchange + dot
+all-reduce.  --strong keeps the global problem at --grid^3 instead.
 """
 import argparse
 import json
@@ -124,7 +125,7 @@ def run_single(args):
         "unit": "DOF/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"lap7 {n}^3 fp64 AMG-PCG (PMIS, ext+i Pmax 4, l1-Jacobi V(1,1), GE coarse), "
                                f"BASELINE config 2", "rows": N, "nnz": nnz, "parallelism": "1 GPU",
@@ -174,8 +175,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per dimension (global)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="grid size of the CPU-baseline sample (about 20 s of CPU work)")
-    ap.add_argument("--weak", action="store_true", help="N > 1: --grid is the block of every rank (global grid = block x rank grid, "
-                    "BASELINE config 3 = --grid 256 on 8 GPUs) instead of the global problem")
+    ap.add_argument("--strong", action="store_true", help="N > 1: --grid is the GLOBAL problem, cut into N blocks (fixed-size series). Default is "
+                    "weak scaling: --grid is the block of every rank (global grid = block x rank grid; 256 on 8 GPUs = "
+                    "BASELINE config 3, 512^3)")
+    ap.add_argument("--weak", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     args = ap.parse_args()

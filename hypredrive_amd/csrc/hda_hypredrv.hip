@@ -1139,6 +1139,38 @@ extern "C" uint32_t HYPREDRV_AMD_SolvePhaseBytes(HYPREDRV_t h, double iteration[
    }
    API_CATCH
 }
+// Arms (arm != 0) the launch-timing probe on the Jacobi sweeps of this rank's largest operator kept
+// in plain CSR (level 0 is usually stencil-coded and cheaper) and returns its level and local sizes;
+// arm == 0 reads the average launch duration back and disarms.  bench.py's N > 1 roofline object.
+extern "C" uint32_t HYPREDRV_AMD_ProbeDominant(HYPREDRV_t h, int arm, int *level, double dims[3], double *avg_ms, int *count)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (!h->mat_A || !h->precon || !h->precon->amg) return err_set(ERR_UNKNOWN, "ProbeDominant: set up the solver first");
+   Amg &amg = *h->precon->amg;
+   if (arm)
+   {
+      int    best = 0;
+      double bn   = -1.0;
+      for (int l = 0; l + 1 < amg.num_levels(); l++)
+      {
+         const DCsr &M = amg.level_A(l);
+         spmv_prepare(M);
+         const double w = M.coded == 1 ? 0.0 : (double)M.nnz;
+         if (w > bn) { bn = w; best = l; }
+      }
+      const DCsr &M = amg.level_A(best);
+      if (level) *level = best;
+      if (dims) { dims[0] = M.nrows; dims[1] = M.ncols; dims[2] = M.nnz; }
+      spmv_probe_set(&M, 2);
+   }
+   else
+   {
+      spmv_probe_read(avg_ms, count);
+      spmv_probe_set(nullptr, -1);
+   }
+   API_CATCH
+}
 extern "C" uint32_t HYPREDRV_LinearSystemComputeEigenspectrum(HYPREDRV_t h) { CHECK_INIT_OBJ(h); return g_err; } // no-op unless built with eigspec
 
 // ------------------------------------------------------------- THE HOT PATH

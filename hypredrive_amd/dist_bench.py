@@ -19,7 +19,7 @@ def run(args):
     n = args.n
     P = hdist.factor3(world)
     h = hd.Hypredrv("solver: pcg\npreconditioner:\n  preset: poisson\n")
-    weak = bool(getattr(args, "weak", False))
+    weak = not bool(getattr(args, "strong", False))
     gn = (n * P[0], n * P[1], n * P[2]) if weak else (n, n, n)
     h.set_laplacian7(gn, P)
     torch.cuda.synchronize()
@@ -30,6 +30,7 @@ def run(args):
     setup_ms = (time.perf_counter() - t0) * 1e3
     for _ in range(args.warmup):
         h.apply()
+    dom = h.probe_dominant_arm()  # HIP events around this rank's dominant kernel inside the timed solves
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -41,6 +42,7 @@ def run(args):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     ms_per_step = dt.item() * 1e3 / args.steps
+    dom_ms, dom_count = h.probe_dominant_read()
     N = gn[0] * gn[1] * gn[2]
     # solve-phase byte rate summed over the ranks: iters Krylov iterations + (iters + 1) V-cycles each
     (it_csr, it_fmt), (vc_csr, vc_fmt) = h.solve_phase_bytes()
@@ -66,6 +68,12 @@ def run(args):
             "solve_phase_hbm_gbs": gbs_csr, "solve_phase_hbm_frac": gbs_csr / (8000.0 * world),
             "solve_phase_format_gbs": gbs_fmt, "solve_phase_format_frac": gbs_fmt / (8000.0 * world),
         }
+        lvl, dn, dc, dnnz = dom
+        dom_bytes = 12.0 * dnnz + 4.0 * (dn + 1) + 8.0 * dc + 8.0 * dn + 16.0 * dn  # SURVEY 8(d) Jacobi sweep, rank 0's block
+        dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out["roofline"] = {"kernel": f"k_spmv_stream<JACOBI> on rank 0's block of the level-{lvl} operator ({dn} rows, {dnnz} nnz, plain CSR), "
+                                     f"{dom_count} launches timed inside the solves", "bound": "hbm", "achieved": dom_gbs, "peak": 8000.0,
+                           "unit": "GB/s", "frac": dom_gbs / 8000.0, "traffic": None, "bytes_per_launch": dom_bytes, "avg_ms": dom_ms}
     h.destroy_solver()
     h.close()
     hdist.finalize()

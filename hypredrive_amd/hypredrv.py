@@ -72,6 +72,7 @@ def lib():
         "HYPREDRV_StatsLevelGetEntry": [vp, C.c_int, C.c_int, ip, ip, ip, dp, dp],
         "HYPREDRV_StatsLevelPrint": [vp, C.c_int],
         "HYPREDRV_AMD_SolvePhaseBytes": [vp, dp, dp],
+        "HYPREDRV_AMD_ProbeDominant": [vp, C.c_int, ip, dp, dp, ip],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -191,6 +192,17 @@ class Hypredrv:
         it, vc = (C.c_double * 2)(), (C.c_double * 2)()
         check(lib().HYPREDRV_AMD_SolvePhaseBytes(self.h, it, vc))
         return (it[0], it[1]), (vc[0], vc[1])
+
+    def probe_dominant_arm(self):
+        """Time every Jacobi-sweep launch on this rank's largest plain-CSR operator; returns (level, rows, cols, nnz)."""
+        lvl, dims = C.c_int(), (C.c_double * 3)()
+        check(lib().HYPREDRV_AMD_ProbeDominant(self.h, 1, C.byref(lvl), dims, None, None))
+        return lvl.value, int(dims[0]), int(dims[1]), int(dims[2])
+
+    def probe_dominant_read(self):
+        ms, n = C.c_double(), C.c_int()
+        check(lib().HYPREDRV_AMD_ProbeDominant(self.h, 0, None, None, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def stats_print(self):
         check(lib().HYPREDRV_StatsPrint(self.h))

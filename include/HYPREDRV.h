@@ -152,6 +152,10 @@ HYPREDRV_EXPORT_SYMBOL const char *HYPREDRV_AMD_LastErrorMessage(void);
 /* measurement hook of bench.py: bytes this rank streams per Krylov iteration and per V-cycle,
  * [0] as CSR, [1] in the formats actually read */
 HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_SolvePhaseBytes(HYPREDRV_t hypredrv, double iteration[2], double vcycle[2]);
+/* measurement hook of bench.py (N > 1): arm != 0 brackets every Jacobi-sweep launch on this rank's largest
+ * plain-CSR operator with HIP events (returns its level and local rows/cols/nnz); arm == 0 returns the
+ * average launch duration and disarms */
+HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_ProbeDominant(HYPREDRV_t hypredrv, int arm, int *level, double dims[3], double *avg_ms, int *count);
 
 #ifdef __cplusplus
 }
