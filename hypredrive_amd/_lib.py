@@ -21,7 +21,9 @@ class AmgParams(C.Structure):
                 ("relax_down", C.c_int), ("relax_up", C.c_int), ("relax_coarse", C.c_int),
                 ("sweeps_down", C.c_int), ("sweeps_up", C.c_int), ("sweeps_coarse", C.c_int),
                 ("relax_weight", C.c_double), ("outer_weight", C.c_double),
-                ("seed", C.c_uint64), ("num_functions", C.c_int)]
+                ("seed", C.c_uint64), ("num_functions", C.c_int),
+                ("smooth_num_levels", C.c_int), ("smooth_num_sweeps", C.c_int),
+                ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int)]
 
     @staticmethod
     def default(**kw):
@@ -58,7 +60,7 @@ SYMBOLS = [
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
-    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total",
+    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors",
 ]
 
 
@@ -97,6 +99,8 @@ def load():
     L.hda_spgemm.argtypes = [vp, vp, P(vp)]
     L.hda_amg_create.argtypes = [P(AmgParams), vp, P(vp)]
     L.hda_amg_destroy.argtypes = [vp]
+    L.hda_ilu_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(vp)]
+    L.hda_ilu_factors.argtypes = [vp, C.c_int, P(vp)]
     L.hda_amg_num_levels.argtypes = [vp]
     L.hda_amg_level_matrix.argtypes = [vp, C.c_int, C.c_int, P(vp)]
     L.hda_amg_level_cf.argtypes = [vp, C.c_int, ip]
@@ -286,6 +290,12 @@ class Amg:
         _check(load().hda_amg_level_matrix(self.h, level, which, C.byref(out)))
         return Csr(out, owned=False, keep=self)
 
+    def ilu_factors(self, level):
+        """Factors of the complex smoother (amg.smoother.type ilu) of a level."""
+        out = C.c_void_p()
+        _check(load().hda_ilu_factors(self.h, level, C.byref(out)))
+        return Csr(out, owned=False, keep=self)
+
     def level_cf(self, level):
         n = self.level_matrix(level, 0).nrows
         cf = np.zeros(n, dtype=np.int32)
@@ -307,6 +317,33 @@ class Amg:
         x = np.zeros_like(b)
         _check(load().hda_amg_vcycle(self.h, _dp(b), _dp(x)))
         return x
+
+
+class Ilu:
+    """'preconditioner: ilu': block-Jacobi ILU(0) of A's diagonal block; usable as amg= in pcg()/gmres()."""
+
+    def __init__(self, A, max_iter=1, tri_solve=1, lower_it=5, upper_it=5):
+        self.A = A
+        self.h = C.c_void_p()
+        _check(load().hda_ilu_create(A.h, max_iter, tri_solve, lower_it, upper_it, C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            load().hda_amg_destroy(self.h)
+            self.h = None
+
+    @property
+    def factors(self):
+        out = C.c_void_p()
+        _check(load().hda_ilu_factors(self.h, -1, C.byref(out)))
+        return Csr(out, owned=False, keep=self)
+
+    def apply(self, r):
+        """One application from a zero guess (max_iter iterations x += M^-1 (r - A x))."""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        _check(load().hda_amg_vcycle(self.h, _dp(r), _dp(z)))
+        return z
 
 
 def _krylov(fn, A, b, amg, kp, x0):

@@ -10,6 +10,13 @@
 
 namespace hda {
 
+// ILU_args subset that is implemented (src/internal/ilu.c:15-28): type bj-iluk, fill_level 0, reordering 0
+struct IluParams {
+   int tri_solve = 1;              // 1 exact substitutions (level scheduled), 0 Jacobi iterations on L and U
+   int lower_it = 5, upper_it = 5; // lower_jac_iters / upper_jac_iters
+   int max_iter = 1;               // iterations x += M^-1 (b - A x) per solve
+};
+
 struct AmgParams {
    // coarsening (src/internal/amg.c:138-157)
    int    coarsen_type    = 8;  // PMIS (hypre-GPU default); 10 HMIS = Ruge first pass (one device thread, small systems); others not on device
@@ -32,6 +39,10 @@ struct AmgParams {
    int    print_level = 0;
    uint64_t seed = 2747; // PMIS tie-break hash seed
    int    num_functions = 1; // coarsening.num_functions; > 1 = systems AMG, unknown approach (presets elasticity_2d/3d)
+   // complex smoother (amg.c:899-921): type 5 = ILU on levels < smooth_num_levels, replacing the relaxation
+   // sweeps there; one smoothing step = smooth_num_sweeps iterations u += M^-1 (f - A u)
+   int       smooth_type = 5, smooth_num_levels = 0, smooth_num_sweeps = 1;
+   IluParams ilu;
 };
 
 // dependency levels of the local pattern for Gauss-Seidel sweeps (hda_gs.hip)
@@ -47,9 +58,30 @@ void build_gs_plan(const DCsr &A, GsPlan &plan);
 // one hybrid Gauss-Seidel sweep in place: x_i += dinv_i (b_i - A_i x), rows in sequential order
 void gs_sweep(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, double *x, bool forward);
 
+// block-Jacobi ILU(0) of a rank's diagonal block (hda_ilu.hip)
+class Ilu {
+ public:
+   void        setup(const DCsr &A, const IluParams &p); // columns >= A.nrows (ghosts) are dropped
+   void        apply(const double *r, double *z);        // z = U^-1 L^-1 r; r and z must not alias
+   const DCsr &factors() const { return LU; }            // strict lower part = L (unit diagonal), rest = U
+   double      apply_bytes() const;
+   IluParams   prm;
+
+ private:
+   DCsr           LU;
+   DArray<int>    diag;
+   GsPlan         plan;
+   DArray<double> work;
+};
+
+void ilu_solve(Ilu &F, const DCsr &A, const HaloPlan *halo, const double *b, double *x, bool zero_guess, DArray<double> &r,
+               DArray<double> &c); // max_iter iterations x += M^-1 (b - A x)
+
 struct AmgLevel {
    DCsr           A, P, R;
    GsPlan         gs;
+   std::unique_ptr<Ilu> ilu; // complex smoother of this level, if any
+   DArray<double> ilu_r, ilu_c;
    DArray<int>    cf;
    DArray<double> dinv_down, dinv_up; // relax_weight / l1 (or / a_ii), per cycle direction
    DArray<double> f, u, u2, t;

@@ -1739,6 +1739,21 @@ void Amg::build_smoother_data(int l)
    const bool last = (l == num_levels() - 1);
    const bool gs   = is_gs_type(prm.relax_down) || is_gs_type(prm.relax_up) || (last && is_gs_type(prm.relax_coarse));
    if (gs && !lv.gs.built) build_gs_plan(Al, lv.gs);
+   // complex smoother (amg.c:899-921): ILU(0) of the rank's diagonal block on the first smooth_num_levels
+   // levels (counted from the finest level of the whole hierarchy), never on the coarsest
+   if (prm.smooth_num_levels > 0)
+   {
+      HDA_REQUIRE(prm.smooth_type == 5, "complex smoother: only ILU (type 5, bj-iluk with fill 0) is implemented");
+      if (l + level0 < prm.smooth_num_levels && !last)
+      {
+         lv.ilu = std::make_unique<Ilu>();
+         IluParams ip = prm.ilu;
+         ip.max_iter  = std::max(prm.smooth_num_sweeps, 1);
+         lv.ilu->setup(Al, ip);
+         lv.ilu_r.alloc((size_t)std::max(Al.nrows, 1));
+         lv.ilu_c.alloc((size_t)std::max(Al.nrows, 1));
+      }
+   }
    // launch plans of the operators the cycle applies (chunk plans, stencil coding attempt):
    // part of the setup, not of the first solve
    spmv_prepare(Al);
@@ -2072,6 +2087,20 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
                 bool zero_guess, int dot_slot)
 {
    const DCsr &A = level_A(l);
+   if (levels[(size_t)l].ilu)
+   { // complex smoother instead of the relaxation: max_iter iterations cur += M^-1 (b - A cur), in place
+      AmgLevel &lv = levels[(size_t)l];
+      for (int it = 0; it < lv.ilu->prm.max_iter; it++)
+      {
+         if (zero_guess && it == 0) { lv.ilu->apply(b, cur); continue; } // b - A*0 = b exactly
+         halo_exchange(level_hA(l), cur);
+         residual(A, cur, b, lv.ilu_r.data());
+         lv.ilu->apply(lv.ilu_r.data(), lv.ilu_c.data());
+         axpy(A.nrows, 1.0, lv.ilu_c.data(), cur);
+      }
+      if (dot_slot >= 0) dot(A.nrows, b, cur, dot_slot);
+      return;
+   }
    if (is_gs_type(type))
    { // in place; ghosts frozen for the sweep
       if (zero_guess) fill((int)levels[(size_t)l].ext, 0.0, cur);
@@ -2148,7 +2177,8 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
    }
    std::vector<double *> sol((size_t)L, nullptr);
    // level-0 buffer choice so the last out-of-place sweep lands in x
-   const int swaps0 = (is_jacobi_type(prm.relax_down) ? (prm.sweeps_down - (zero_guess && prm.sweeps_down > 0 ? 1 : 0)) : 0) +
+   const int swaps0 = levels[0].ilu ? 0 : // the complex smoother works in place
+                      (is_jacobi_type(prm.relax_down) ? (prm.sweeps_down - (zero_guess && prm.sweeps_down > 0 ? 1 : 0)) : 0) +
                       (is_jacobi_type(prm.relax_up) ? prm.sweeps_up : 0); // out-of-place sweeps on level 0
    double   *cur, *alt;
    if (zero_guess && (swaps0 & 1)) { cur = levels[0].u2.data(); alt = x; }

@@ -19,6 +19,8 @@ struct hda_csr_s {
 };
 struct hda_amg_s {
    std::unique_ptr<Amg>                    amg;
+   std::unique_ptr<Ilu>                    ilu; // handle made by hda_ilu_create: the preconditioner is one ILU solve
+   DArray<double>                          ilu_r, ilu_c;
    hda_csr_t                               A = nullptr;
    std::vector<std::unique_ptr<hda_csr_s>> views;
 };
@@ -76,6 +78,8 @@ extern "C" void hda_amg_default_params(hda_amg_params *p)
    p->relax_down = d.relax_down; p->relax_up = d.relax_up; p->relax_coarse = d.relax_coarse;
    p->sweeps_down = d.sweeps_down; p->sweeps_up = d.sweeps_up; p->sweeps_coarse = d.sweeps_coarse;
    p->relax_weight = d.relax_weight; p->outer_weight = d.outer_weight; p->seed = d.seed; p->num_functions = d.num_functions;
+   p->smooth_num_levels = d.smooth_num_levels; p->smooth_num_sweeps = d.smooth_num_sweeps;
+   p->ilu_tri_solve = d.ilu.tri_solve; p->ilu_lower_it = d.ilu.lower_it; p->ilu_upper_it = d.ilu.upper_it;
 }
 extern "C" void hda_krylov_default_params(hda_krylov_params *p, int gmres)
 {
@@ -93,6 +97,8 @@ static AmgParams to_params(const hda_amg_params *p)
    a.sweeps_down = p->sweeps_down; a.sweeps_up = p->sweeps_up; a.sweeps_coarse = p->sweeps_coarse;
    a.relax_weight = p->relax_weight; a.outer_weight = p->outer_weight; a.seed = p->seed;
    a.num_functions = std::max(p->num_functions, 1);
+   a.smooth_num_levels = p->smooth_num_levels; a.smooth_num_sweeps = p->smooth_num_sweeps;
+   a.ilu.tri_solve = p->ilu_tri_solve; a.ilu.lower_it = p->ilu_lower_it; a.ilu.upper_it = p->ilu_upper_it;
    return a;
 }
 static KrylovParams to_kparams(const hda_krylov_params *p)
@@ -369,7 +375,41 @@ extern "C" int hda_amg_destroy(hda_amg_t h)
    delete h;
    return HDA_OK;
 }
-extern "C" int hda_amg_num_levels(hda_amg_t h) { return h ? h->amg->num_levels() : 0; }
+extern "C" int hda_amg_num_levels(hda_amg_t h) { return (h && h->amg) ? h->amg->num_levels() : 0; }
+
+// "preconditioner: ilu" (reference src/internal/ilu.c): a handle the Krylov entry points accept in place of a hierarchy
+extern "C" int hda_ilu_create(hda_csr_t A, int max_iter, int tri_solve, int lower_it, int upper_it, hda_amg_t *out)
+{
+   HDA_TRY
+   auto h = std::make_unique<hda_amg_s>();
+   h->A   = A;
+   h->ilu = std::make_unique<Ilu>();
+   IluParams p;
+   p.max_iter = max_iter; p.tri_solve = tri_solve; p.lower_it = lower_it; p.upper_it = upper_it;
+   h->ilu->setup(A->get(), p);
+   *out = h.release();
+   HDA_CATCH
+}
+// factors (strict lower part L with unit diagonal, rest U) of the stand-alone handle (level < 0) or of
+// the complex smoother of an AMG level
+extern "C" int hda_ilu_factors(hda_amg_t h, int level, hda_csr_t *out)
+{
+   HDA_TRY
+   const Ilu *F = nullptr;
+   if (level < 0) F = h->ilu.get();
+   else
+   {
+      HDA_REQUIRE(h->amg && level < h->amg->num_levels(), "level out of range");
+      F = h->amg->level(level).ilu.get();
+   }
+   HDA_REQUIRE(F, "no ILU factorisation on this handle / level");
+   auto v      = std::make_unique<hda_csr_s>();
+   v->borrowed = true;
+   v->ref      = &F->factors();
+   *out        = v.get();
+   h->views.push_back(std::move(v));
+   HDA_CATCH
+}
 
 extern "C" int hda_amg_level_matrix(hda_amg_t h, int level, int which, hda_csr_t *out)
 {
@@ -409,6 +449,15 @@ extern "C" double hda_amg_vcycle_bytes(hda_amg_t h) { return h ? h->amg->vcycle_
 extern "C" int hda_amg_vcycle(hda_amg_t h, const double *b, double *x)
 {
    HDA_TRY
+   if (h->ilu)
+   { // one application of the ILU preconditioner from a zero guess
+      const DCsr    &m = h->A->get();
+      DArray<double> db, dx((size_t)std::max(std::max(m.ncols, m.nrows), 1));
+      db.upload(b, (size_t)m.nrows);
+      ilu_solve(*h->ilu, m, nullptr, db.data(), dx.data(), true, h->ilu_r, h->ilu_c);
+      dx.download(x, (size_t)m.nrows);
+      return HDA_OK;
+   }
    const int      n = h->amg->level_A(0).nrows;
    DArray<double> db, dx(std::max<size_t>(h->amg->vec_len0(), (size_t)std::max(h->amg->level_A(0).ncols, 1)));
    db.upload(b, (size_t)n);
@@ -431,9 +480,14 @@ static int run_krylov(bool use_gmres, hda_csr_t A, hda_amg_t amg, const hda_kryl
    HDA_HIP(hipMemcpyAsync(dx.data(), x, sizeof(double) * (size_t)m.nrows, hipMemcpyHostToDevice, Context::get().stream));
    Context::get().sync();
    PrecondFn M;
-   if (amg) M = [amg](const double *r, double *z, int slot) { amg->amg->apply(r, z, slot); };
+   if (amg && amg->ilu)
+      M = [amg, &m](const double *r, double *z, int slot) {
+         ilu_solve(*amg->ilu, m, nullptr, r, z, true, amg->ilu_r, amg->ilu_c);
+         if (slot >= 0) dot(m.nrows, r, z, slot);
+      };
+   else if (amg) M = [amg](const double *r, double *z, int slot) { amg->amg->apply(r, z, slot); };
    KrylovParams  k   = to_kparams(kp);
-   LinOp         op(m, nullptr, amg ? amg->amg->vec_len0() : 0);
+   LinOp         op(m, nullptr, (amg && amg->amg) ? amg->amg->vec_len0() : 0);
    KrylovResult  res = use_gmres ? gmres(op, M, k, db.data(), dx.data()) : pcg(op, M, k, db.data(), dx.data());
    dx.download(x, (size_t)m.nrows);
    if (hist)

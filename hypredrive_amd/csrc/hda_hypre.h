@@ -43,7 +43,7 @@ struct hypre_IJMatrix_struct {
    void adopt_device(int nloc, int nnz, hda::DArray<int> &rowptr, hda::DArray<long long> &gcols, hda::DArray<double> &vals);
 };
 
-enum hda_solver_kind { HDA_SOLVER_PCG = 1, HDA_SOLVER_GMRES = 2, HDA_SOLVER_AMG = 3 };
+enum hda_solver_kind { HDA_SOLVER_PCG = 1, HDA_SOLVER_GMRES = 2, HDA_SOLVER_AMG = 3, HDA_SOLVER_ILU = 4 };
 
 struct hypre_Solver_struct {
    int                       kind = 0;
@@ -56,6 +56,11 @@ struct hypre_Solver_struct {
    HYPRE_PtrToSolverFcn      precond = nullptr, precond_setup = nullptr;
    HYPRE_Solver              precond_solver = nullptr;
    std::unique_ptr<hda::Amg> amg;
+   // HYPRE_ILU* handle, and the ILU arguments of BoomerAMG's complex smoother (HYPRE_BoomerAMGSetILU*)
+   std::unique_ptr<hda::Ilu> ilu;
+   hda::IluParams            ilup;
+   int                       ilu_type = 0, ilu_fill = 0, ilu_reordering = 0; // checked at Setup: bj-iluk / 0 / 0 only
+   hda::DArray<double>       ilu_r, ilu_c;
    hda::KrylovResult         last;
    int                       amg_iters = 0;
    double                    amg_rel   = 0.0;

@@ -956,7 +956,17 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetDofFunc(HYPRE_Solver s, HYPRE_Int *dof_fu
 }
 HY_SETTER(HYPRE_BoomerAMGSetFilterFunctions, HYPRE_Int, (void)v)
 HY_SETTER(HYPRE_BoomerAMGSetSmoothType, HYPRE_Int, s->smooth_type = v)
-HY_SETTER(HYPRE_BoomerAMGSetSmoothNumSweeps, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetSmoothNumSweeps, HYPRE_Int, s->ap.smooth_num_sweeps = v)
+// ILU arguments of the complex smoother (reference src/internal/amg.c:903-921)
+HY_SETTER(HYPRE_BoomerAMGSetILUType, HYPRE_Int, s->ilu_type = v)
+HY_SETTER(HYPRE_BoomerAMGSetILULevel, HYPRE_Int, s->ilu_fill = v)
+HY_SETTER(HYPRE_BoomerAMGSetILULocalReordering, HYPRE_Int, s->ilu_reordering = v)
+HY_SETTER(HYPRE_BoomerAMGSetILUTriSolve, HYPRE_Int, s->ilup.tri_solve = v)
+HY_SETTER(HYPRE_BoomerAMGSetILULowerJacobiIters, HYPRE_Int, s->ilup.lower_it = v)
+HY_SETTER(HYPRE_BoomerAMGSetILUUpperJacobiIters, HYPRE_Int, s->ilup.upper_it = v)
+HY_SETTER(HYPRE_BoomerAMGSetILUDroptol, HYPRE_Real, (void)v)   // threshold variants (ilut) only
+HY_SETTER(HYPRE_BoomerAMGSetILUMaxRowNnz, HYPRE_Int, (void)v)  // threshold variants only
+HY_SETTER(HYPRE_BoomerAMGSetILUMaxIter, HYPRE_Int, s->ap.smooth_num_sweeps = v) // amg.c:921 passes smoother.num_sweeps
 HY_SETTER(HYPRE_BoomerAMGSetSmoothNumLevels, HYPRE_Int, s->smooth_num_levels = v)
 HY_SETTER(HYPRE_BoomerAMGSetAggNumLevels, HYPRE_Int, s->agg_num_levels = v)
 HY_SETTER(HYPRE_BoomerAMGSetAggInterpType, HYPRE_Int, (void)v)
@@ -1012,7 +1022,15 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    HDA_REQUIRE(A && A->assembled, "BoomerAMGSetup needs an assembled matrix");
    // features of the reference's parameter surface that this build does not implement
    HDA_REQUIRE(s->agg_num_levels == 0, "aggressive coarsening (aggressive.num_levels > 0) is not implemented on MI355X yet");
-   HDA_REQUIRE(s->smooth_num_levels == 0, "complex smoothers (smoother.num_levels > 0: FSAI/ILU) are not implemented on MI355X yet");
+   if (s->smooth_num_levels > 0)
+   {
+      HDA_REQUIRE(s->smooth_type == 5, "complex smoother: only ILU (smoother.type ilu) is implemented on MI355X; FSAI, Schwarz, Pilut, ParaSails, Euclid are not");
+      HDA_REQUIRE(s->ilu_type == 0 && s->ilu_fill == 0 && s->ilu_reordering == 0,
+                  "ILU smoother: only type bj-iluk with fill_level 0 and reordering 0 is implemented");
+   }
+   s->ap.smooth_type       = s->smooth_type;
+   s->ap.smooth_num_levels = std::max(s->smooth_num_levels, 0);
+   s->ap.ilu               = s->ilup;
    HDA_REQUIRE(s->cycle_type == 1, "only V-cycles (cycle type 1) are implemented");
    HDA_REQUIRE(s->restriction == 0, "only P^T restriction (restriction_type 0) is implemented");
    HDA_REQUIRE(s->relax_order == 0, "only lexicographic relaxation order (relaxation.order 0) is implemented");
@@ -1030,7 +1048,7 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
       // the specification the partitioned setup is checked against (HDA_DIST_CHECK=1)
       const char *mode = getenv("HDA_DIST_SETUP");
       // (HMIS = sequential Ruge pass: only the replicated scheme can run it, on the gathered operator)
-      if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8 || s->ap.num_functions > 1) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+      if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8 || s->ap.num_functions > 1 || s->ap.smooth_num_levels > 1) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
       else s->amg->setup_dist_partitioned(A->A, A->halo, A->part, A->ghost_gids);
    }
    else s->amg->setup(A->A);
@@ -1100,6 +1118,74 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    if (staged) copy(A->nloc, xp, x->data());
    HY_CATCH
 }
+// ------------------------------------------------------------------------ ILU
+// HYPRE_ILU* as driven by hypredrv_ILUCreate (reference src/internal/ilu.c:63-115) and the
+// precon_ops table (src/internal/precon.c).  Implemented: type 0 (bj-iluk), fill level 0, no reordering.
+
+extern "C" HYPRE_Int HYPRE_ILUCreate(HYPRE_Solver *solver)
+{
+   auto *s = new hypre_Solver_struct();
+   s->kind = HDA_SOLVER_ILU;
+   s->ilup.max_iter = 20; // hypre's own default; hypredrive sets 1 (ilu.c:17)
+   *solver = s;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_ILUDestroy(HYPRE_Solver s) { return HYPRE_BoomerAMGDestroy(s); }
+HY_SETTER(HYPRE_ILUSetType, HYPRE_Int, s->ilu_type = v)
+HY_SETTER(HYPRE_ILUSetLevelOfFill, HYPRE_Int, s->ilu_fill = v)
+HY_SETTER(HYPRE_ILUSetLocalReordering, HYPRE_Int, s->ilu_reordering = v)
+HY_SETTER(HYPRE_ILUSetTriSolve, HYPRE_Int, s->ilup.tri_solve = v)
+HY_SETTER(HYPRE_ILUSetLowerJacobiIters, HYPRE_Int, s->ilup.lower_it = v)
+HY_SETTER(HYPRE_ILUSetUpperJacobiIters, HYPRE_Int, s->ilup.upper_it = v)
+HY_SETTER(HYPRE_ILUSetPrintLevel, HYPRE_Int, s->ap.print_level = v)
+HY_SETTER(HYPRE_ILUSetMaxIter, HYPRE_Int, s->ilup.max_iter = v)
+HY_SETTER(HYPRE_ILUSetTol, HYPRE_Real, s->ap.tol = v)
+HY_SETTER(HYPRE_ILUSetMaxNnzPerRow, HYPRE_Int, (void)v)     // threshold variants only
+HY_SETTER(HYPRE_ILUSetDropThreshold, HYPRE_Real, (void)v)   // threshold variants only
+HY_SETTER(HYPRE_ILUSetSchurMaxIter, HYPRE_Int, (void)v)     // Schur-complement variants only
+HY_SETTER(HYPRE_ILUSetNSHDropThreshold, HYPRE_Real, (void)v)
+
+extern "C" HYPRE_Int HYPRE_ILUSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector, HYPRE_ParVector)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   HDA_REQUIRE(s && s->kind == HDA_SOLVER_ILU, "ILUSetup: not an ILU handle");
+   HDA_REQUIRE(A && A->assembled, "ILUSetup needs an assembled matrix");
+   HDA_REQUIRE(s->ilu_type == 0, "ILU: only type bj-iluk (0) is implemented on MI355X; ilut / gmres- / nsh- / ras- / ddpq- variants are not");
+   HDA_REQUIRE(s->ilu_fill == 0, "ILU: only fill_level 0 is implemented");
+   HDA_REQUIRE(s->ilu_reordering == 0, "ILU: only reordering 0 (natural order) is implemented");
+   s->ilu = std::make_unique<Ilu>();
+   s->ilu->setup(A->A, s->ilup);
+   hda_register_precond_veclen((size_t)std::max(A->A.ncols, A->A.nrows));
+   HY_CATCH
+}
+
+extern "C" HYPRE_Int HYPRE_ILUSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   HDA_REQUIRE(s && s->ilu, "ILUSolve before ILUSetup");
+   x->ensure_device();
+   PrecondHints  &h    = precond_hints();
+   const bool     multi = Comm::world().size > 1;
+   const size_t   need = (size_t)std::max(A->A.ncols, A->A.nrows);
+   double        *xp   = x->data();
+   DArray<double> xe;
+   const bool     staged = x->capacity < need;
+   if (staged)
+   {
+      xe.alloc(need);
+      copy(A->nloc, x->data(), xe.data());
+      xp = xe.data();
+   }
+   ilu_solve(*s->ilu, A->A, multi ? &A->halo : nullptr, b->data(), xp, h.zero_guess, s->ilu_r, s->ilu_c);
+   s->amg_iters = std::max(s->ilup.max_iter, 1);
+   if (staged) copy(A->nloc, xp, x->data());
+   HY_CATCH
+}
+HY_GETTER(HYPRE_ILUGetNumIterations, HYPRE_Int, s->amg_iters)
+HY_GETTER(HYPRE_ILUGetFinalRelativeResidualNorm, HYPRE_Real, s->amg_rel)
+
 HY_GETTER(HYPRE_BoomerAMGGetNumIterations, HYPRE_Int, s->amg_iters)
 HY_GETTER(HYPRE_BoomerAMGGetFinalRelativeResidualNorm, HYPRE_Real, s->amg_rel)
 HY_GETTER(HYPRE_BoomerAMGGetNumLevels, HYPRE_Int, s->amg ? s->amg->num_levels() : 0)

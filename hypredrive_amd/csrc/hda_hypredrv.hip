@@ -1181,7 +1181,7 @@ static HYPRE_Int PreconSetupDispatch(HYPRE_Solver cookie, HYPRE_Matrix A, HYPRE_
 {
    hypredrv_struct *h = ((PreconCookie *)(void *)cookie)->self;
    annotate(h, "prec", true);
-   HYPRE_Int ierr = HYPRE_BoomerAMGSetup(h->precon, A, b, x);
+   HYPRE_Int ierr = (h->precon->kind == HDA_SOLVER_ILU) ? HYPRE_ILUSetup(h->precon, A, b, x) : HYPRE_BoomerAMGSetup(h->precon, A, b, x);
    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
    annotate(h, "prec", false);
    h->precon_is_setup = (ierr == 0);
@@ -1191,7 +1191,29 @@ static HYPRE_Int PreconSetupDispatch(HYPRE_Solver cookie, HYPRE_Matrix A, HYPRE_
 static HYPRE_Int PreconSolveDispatch(HYPRE_Solver cookie, HYPRE_Matrix A, HYPRE_Vector b, HYPRE_Vector x)
 {
    hypredrv_struct *h = ((PreconCookie *)(void *)cookie)->self;
-   return HYPRE_BoomerAMGSolve(h->precon, A, b, x);
+   return (h->precon->kind == HDA_SOLVER_ILU) ? HYPRE_ILUSolve(h->precon, A, b, x) : HYPRE_BoomerAMGSolve(h->precon, A, b, x);
+}
+
+// hypredrv_ILUCreate (reference src/internal/ilu.c:63-115): same setter sequence
+static void ilu_create(const IluArgs &a, HYPRE_Solver *out)
+{
+   HYPRE_Solver p = nullptr;
+   HYPRE_ILUCreate(&p);
+   HYPRE_ILUSetType(p, a.type);
+   HYPRE_ILUSetLevelOfFill(p, a.fill_level);
+   HYPRE_ILUSetLocalReordering(p, a.reordering);
+   HYPRE_ILUSetTriSolve(p, a.tri_solve);
+   HYPRE_ILUSetLowerJacobiIters(p, a.lower_jac_iters);
+   HYPRE_ILUSetUpperJacobiIters(p, a.upper_jac_iters);
+   HYPRE_ILUSetPrintLevel(p, a.print_level);
+   HYPRE_ILUSetMaxIter(p, a.max_iter);
+   HYPRE_ILUSetTol(p, a.tolerance);
+   HYPRE_ILUSetMaxNnzPerRow(p, a.max_row_nnz);
+   HYPRE_ILUSetDropThreshold(p, a.droptol);
+   const bool schur = a.type == 10 || a.type == 11 || a.type == 20 || a.type == 21 || a.type == 40 || a.type == 41 || a.type == 50;
+   if (schur) HYPRE_ILUSetSchurMaxIter(p, a.schur_max_iter);
+   if (a.type == 20 || a.type == 21) HYPRE_ILUSetNSHDropThreshold(p, a.nsh_droptol);
+   *out = p;
 }
 
 // hypredrv_AMGCreate (reference src/internal/amg.c:864-1035): same setter sequence
@@ -1222,6 +1244,15 @@ static void amg_create(const AmgArgs &a, HYPRE_Solver *out)
    HYPRE_BoomerAMGSetSmoothNumSweeps(p, a.smooth_num_sweeps);
    HYPRE_BoomerAMGSetSmoothNumLevels(p, a.smooth_num_levels);
    HYPRE_BoomerAMGSetMaxRowSum(p, a.max_row_sum);
+   HYPRE_BoomerAMGSetILUType(p, a.smooth_ilu.type);
+   HYPRE_BoomerAMGSetILULocalReordering(p, a.smooth_ilu.reordering);
+   HYPRE_BoomerAMGSetILUTriSolve(p, a.smooth_ilu.tri_solve);
+   HYPRE_BoomerAMGSetILULowerJacobiIters(p, a.smooth_ilu.lower_jac_iters);
+   HYPRE_BoomerAMGSetILUUpperJacobiIters(p, a.smooth_ilu.upper_jac_iters);
+   HYPRE_BoomerAMGSetILULevel(p, a.smooth_ilu.fill_level);
+   HYPRE_BoomerAMGSetILUDroptol(p, a.smooth_ilu.droptol);
+   HYPRE_BoomerAMGSetILUMaxRowNnz(p, a.smooth_ilu.max_row_nnz);
+   HYPRE_BoomerAMGSetILUMaxIter(p, a.smooth_num_sweeps);
    HYPRE_BoomerAMGSetNumFunctions(p, a.nodal ? 3 : a.num_functions);
    HYPRE_BoomerAMGSetFilterFunctions(p, a.filter_functions);
    HYPRE_BoomerAMGSetAggNumLevels(p, a.agg_num_levels);
@@ -1253,9 +1284,15 @@ extern "C" uint32_t HYPREDRV_PreconCreate(HYPREDRV_t h)
    h->precon_is_setup  = false;
    const PreconArgs &p = h->args.precon();
    if (p.method == 99) return g_err; // none
+   if (p.method == 2)
+   {
+      ilu_create(p.ilu, &h->precon);
+      consume_hypre_errors();
+      return g_err;
+   }
    if (p.method != 0)
       return err_set(ERR_INVALID_PRECON | HYPREDRV_ERROR_UNSUPPORTED_AMD,
-                     "preconditioner '" + p.method_name + "' is not implemented on MI355X yet (BoomerAMG only)");
+                     "preconditioner '" + p.method_name + "' is not implemented on MI355X yet (BoomerAMG and ILU only)");
    amg_create(p.amg, &h->precon);
    // hypredrv_AMGSetDofFunc (reference src/internal/amg.c:792-862): the dofmap names the function of
    // every local unknown when its labels fit [0, num_functions); otherwise hypre's interleaved default
@@ -1434,7 +1471,8 @@ extern "C" uint32_t HYPREDRV_PreconApply(HYPREDRV_t h, HYPRE_Vector b, HYPRE_Vec
    err_reset();
    API_TRY
    if (!h->precon || !h->precon_is_setup) return err_set(ERR_INVALID_PRECON, "PreconApply requires a set-up preconditioner");
-   HYPRE_BoomerAMGSolve(h->precon, h->mat_M ? h->mat_M : h->mat_A, b, x);
+   if (h->precon->kind == HDA_SOLVER_ILU) HYPRE_ILUSolve(h->precon, h->mat_M ? h->mat_M : h->mat_A, b, x);
+   else HYPRE_BoomerAMGSolve(h->precon, h->mat_M ? h->mat_M : h->mat_A, b, x);
    consume_hypre_errors();
    API_CATCH
 }

@@ -1,0 +1,286 @@
+// hda_ilu.hip -- block-Jacobi ILU(0): hypre's "bj-iluk" with fill level 0 and no local
+// reordering, the configuration the reference builds in hypredrv_ILUCreate
+// (src/internal/ilu.c:63-115, defaults :15-28) and, as BoomerAMG's complex smoother, in
+// src/internal/amg.c:899-921.  hypre is not part of the reference tree; the arithmetic is the
+// textbook IKJ ILU(0) on the rank's diagonal block (ghost columns dropped), rows in natural
+// order -- the definition the CPU checker of the test suite restates.  PARITY UNPINNED
+// against hypre: no checked-in reference output uses ILU on data that is present.
+//
+// Device mapping.  Factorising row i needs the finished rows k < i it is coupled to, and the
+// two substitutions have the same dependency DAG, so all three reuse the dependency levels
+// of the Gauss-Seidel plan (hda_gs.hip): rows of one level are mutually non-adjacent, a
+// level is one data-parallel launch, runs of small levels are fused into one workgroup with
+// barriers.  The factorisation applies its updates to an entry in ascending pivot order
+// whatever the schedule, so the factors are bit-identical to the sequential algorithm.
+// tri_solve = 0 replaces the substitutions by Jacobi iterations on the triangular systems
+// (ilu.c:21-23): plain streaming passes, the form that suits the GPU.
+#include "hda_amg.h"
+
+#include <algorithm>
+
+namespace hda {
+
+#define STREAM (Context::get().stream)
+
+namespace {
+
+enum { OP_FACTOR = 0, OP_LOWER = 1, OP_UPPER = 2 };
+constexpr int kLanes = 8; // lanes per row in the substitutions and Jacobi passes
+
+__global__ __launch_bounds__(256) void k_ilu_count(int n, const int *__restrict__ rp, const int *__restrict__ cj, int *__restrict__ cnt)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int c = 0;
+   for (int k = rp[i]; k < rp[i + 1]; k++) c += (cj[k] < n);
+   cnt[i] = c;
+}
+
+// copy the diagonal block; flag bit 0: a row without diagonal entry, bit 1: a row that is not column-sorted
+__global__ __launch_bounds__(256) void k_ilu_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                  const int *__restrict__ orp, int *__restrict__ ocj, double *__restrict__ ov,
+                                                  int *__restrict__ diag, int *flag)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int q = orp[i], d = -1, prev = -1, bad = 0;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+   {
+      const int j = cj[k];
+      if (j >= n) continue;
+      if (j <= prev) bad = 2;
+      prev = j;
+      if (j == i) d = q;
+      ocj[q] = j;
+      ov[q]  = v[k];
+      q++;
+   }
+   diag[i] = d;
+   if (d < 0) bad |= 1;
+   if (bad) atomicOr(flag, bad);
+}
+
+__global__ __launch_bounds__(256) void k_ilu_diag(int n, const int *__restrict__ rp, const int *__restrict__ cj, int *__restrict__ diag)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int d = -1;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (cj[k] == i) d = k;
+   diag[i] = d;
+}
+
+// one row of the IKJ factorisation (Saad, Alg. 10.4): for every k < i of the row in ascending order,
+// l_ik = a_ik / u_kk, then a_ij -= l_ik u_kj for the j > k that row i holds
+__device__ __forceinline__ void ilu_factor_row(int i, const int *__restrict__ rp, const int *__restrict__ cj, double *v,
+                                               const int *__restrict__ dg, int *flag)
+{
+   const int e = rp[i + 1], di = dg[i];
+   for (int kk = rp[i]; kk < di; kk++)
+   {
+      const int    k   = cj[kk];
+      const double lik = v[kk] / v[dg[k]];
+      v[kk]            = lik;
+      int pi = kk + 1;
+      for (int jj = dg[k] + 1; jj < rp[k + 1]; jj++)
+      {
+         const int j = cj[jj];
+         while (pi < e && cj[pi] < j) pi++;
+         if (pi == e) break;
+         if (cj[pi] == j) v[pi] -= lik * v[jj];
+      }
+   }
+   if (v[di] == 0.0) atomicOr(flag, 4);
+}
+
+// rows [first, first + count) of the level permutation
+template <int OP>
+__device__ __forceinline__ void ilu_rows(int first, int count, int tid, int nthreads, const int *__restrict__ perm,
+                                         const int *__restrict__ rp, const int *__restrict__ cj, double *v,
+                                         const int *__restrict__ dg, double *x, int *flag)
+{
+   if (OP == OP_FACTOR)
+   {
+      for (int q = tid; q < count; q += nthreads) ilu_factor_row(perm[first + q], rp, cj, v, dg, flag);
+      return;
+   }
+   const int lane = tid & (kLanes - 1);
+   for (int q = tid / kLanes; q < count; q += nthreads / kLanes)
+   {
+      const int i  = perm[first + q];
+      const int lo = (OP == OP_LOWER) ? rp[i] : dg[i] + 1, hi = (OP == OP_LOWER) ? dg[i] : rp[i + 1];
+      double    s  = 0.0;
+      for (int k = lo + lane; k < hi; k += kLanes) s += v[k] * x[cj[k]];
+#pragma unroll
+      for (int o = kLanes / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) x[i] = (OP == OP_LOWER) ? (x[i] - s) : (x[i] - s) / v[dg[i]];
+   }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_ilu_level(int first, int count, const int *__restrict__ perm, const int *__restrict__ rp,
+                                                   const int *__restrict__ cj, double *v, const int *__restrict__ dg, double *x, int *flag)
+{
+   ilu_rows<OP>(first, count, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, perm, rp, cj, v, dg, x, flag);
+}
+
+// levels [l0, l1) by one workgroup, ascending (factor, lower) or descending (upper), a barrier between levels
+template <int OP>
+__global__ __launch_bounds__(1024) void k_ilu_fused(int l0, int l1, const int *__restrict__ lvl_ptr, const int *__restrict__ perm,
+                                                    const int *__restrict__ rp, const int *__restrict__ cj, double *v,
+                                                    const int *__restrict__ dg, double *x, int *flag)
+{
+   for (int s = 0; s < l1 - l0; s++)
+   {
+      const int L = (OP == OP_UPPER) ? (l1 - 1 - s) : (l0 + s);
+      ilu_rows<OP>(lvl_ptr[L], lvl_ptr[L + 1] - lvl_ptr[L], threadIdx.x, blockDim.x, perm, rp, cj, v, dg, x, flag);
+      __threadfence_block();
+      __syncthreads();
+   }
+}
+
+template <int OP>
+void run_levels(const DCsr &LU, const GsPlan &p, const int *dg, double *x, int *flag)
+{
+   const int ns  = (int)p.segments.size();
+   double   *v   = const_cast<double *>(LU.val.data());
+   const int per = (OP == OP_FACTOR) ? 1 : kLanes;
+   for (int si = 0; si < ns; si++)
+   {
+      const auto &sg    = p.segments[(size_t)(OP == OP_UPPER ? ns - 1 - si : si)];
+      const int   first = p.lvl_ptr[(size_t)sg.first], count = p.lvl_ptr[(size_t)sg.first + 1] - first;
+      if (sg.second - sg.first == 1 && count > 512)
+         k_ilu_level<OP><<<std::min(ceil_div((long long)count * per, 256), 2048), 256, 0, STREAM>>>(
+            first, count, p.perm.data(), LU.rowptr.data(), LU.col.data(), v, dg, x, flag);
+      else
+         k_ilu_fused<OP><<<1, 1024, 0, STREAM>>>(sg.first, sg.second, p.d_lvl_ptr.data(), p.perm.data(), LU.rowptr.data(), LU.col.data(),
+                                                 v, dg, x, flag);
+   }
+}
+
+// one Jacobi iteration on a triangular system: LOWER out = rhs - L~ in, UPPER out = (rhs - U~ in) / d
+template <int OP>
+__global__ __launch_bounds__(256) void k_ilu_jacobi(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                    const int *__restrict__ dg, const double *__restrict__ rhs, const double *__restrict__ in,
+                                                    double *__restrict__ out)
+{
+   const int t = blockIdx.x * 256 + threadIdx.x, i = t / kLanes, lane = t & (kLanes - 1);
+   if (i >= n) return; // whole lane groups leave together (256 is a multiple of kLanes)
+   const int lo = (OP == OP_LOWER) ? rp[i] : dg[i] + 1, hi = (OP == OP_LOWER) ? dg[i] : rp[i + 1];
+   double    s  = 0.0;
+   for (int k = lo + lane; k < hi; k += kLanes) s += v[k] * in[cj[k]];
+#pragma unroll
+   for (int o = kLanes / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+   if (lane == 0) out[i] = (OP == OP_LOWER) ? (rhs[i] - s) : (rhs[i] - s) / v[dg[i]];
+}
+
+__global__ __launch_bounds__(256) void k_ilu_dscale(int n, const double *__restrict__ v, const int *__restrict__ dg, const double *__restrict__ y,
+                                                    double *__restrict__ z)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) z[i] = y[i] / v[dg[i]];
+}
+
+} // namespace
+
+void Ilu::setup(const DCsr &A, const IluParams &p)
+{
+   prm         = p;
+   prm.lower_it = std::max(p.lower_it, 1);
+   prm.upper_it = std::max(p.upper_it, 1);
+   const int n = A.nrows;
+   LU          = DCsr();
+   LU.nrows = LU.ncols = n;
+   LU.rowptr.alloc((size_t)n + 1);
+   diag.alloc((size_t)std::max(n, 1));
+   DArray<int> cnt((size_t)n + 1), flag(1);
+   cnt.zero();
+   flag.zero();
+   if (n) k_ilu_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), cnt.data());
+   require_int32_total(n, cnt.data(), "ILU factor");
+   exclusive_scan(n, cnt.data(), LU.rowptr.data(), nullptr);
+   HDA_HIP(hipMemcpyAsync(&LU.nnz, LU.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   LU.col.alloc((size_t)std::max(LU.nnz, 1));
+   LU.val.alloc((size_t)std::max(LU.nnz, 1));
+   if (n)
+      k_ilu_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), LU.rowptr.data(), LU.col.data(),
+                                                      LU.val.data(), diag.data(), flag.data());
+   int f = 0;
+   flag.download(&f, 1);
+   HDA_REQUIRE(!(f & 1), "ILU(0): a row of the diagonal block has no diagonal entry");
+   if (f & 2)
+   { // e.g. a level whose rows were left unsorted by the solve-phase renumbering
+      sort_rows(LU);
+      k_ilu_diag<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, LU.rowptr.data(), LU.col.data(), diag.data());
+   }
+   build_gs_plan(LU, plan);
+   flag.zero();
+   run_levels<OP_FACTOR>(LU, plan, diag.data(), nullptr, flag.data());
+   flag.download(&f, 1);
+   HDA_REQUIRE(!(f & 4), "ILU(0): zero pivot");
+   work.alloc((size_t)std::max(n, 1) * 2);
+}
+
+// z = U^{-1} L^{-1} r   (r and z may not alias)
+void Ilu::apply(const double *r, double *z)
+{
+   const int n = LU.nrows;
+   if (n == 0) return;
+   if (prm.tri_solve)
+   {
+      copy(n, r, z);
+      run_levels<OP_LOWER>(LU, plan, diag.data(), z, nullptr);
+      run_levels<OP_UPPER>(LU, plan, diag.data(), z, nullptr);
+      return;
+   }
+   // Jacobi iterations from a zero guess: the first one is y = r (resp. z = D^{-1} y)
+   const int     grid = ceil_div((long long)n * kLanes, 256);
+   double       *ya = work.data(), *yb = work.data() + n;
+   const double *y = r;
+   for (int it = 1; it < prm.lower_it; it++)
+   {
+      double *out = (it & 1) ? ya : yb;
+      k_ilu_jacobi<OP_LOWER><<<grid, 256, 0, STREAM>>>(n, LU.rowptr.data(), LU.col.data(), LU.val.data(), diag.data(), r, y, out);
+      y = out;
+   }
+   // y now lives in r, ya or yb; the upper iterations ping-pong between z and the free half of work
+   double *spare = (y == ya) ? yb : ya;
+   k_ilu_dscale<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, LU.val.data(), diag.data(), y, (prm.upper_it & 1) ? z : spare);
+   const double *zin = (prm.upper_it & 1) ? z : spare;
+   for (int it = 1; it < prm.upper_it; it++)
+   {
+      double *out = (zin == z) ? spare : z;
+      k_ilu_jacobi<OP_UPPER><<<grid, 256, 0, STREAM>>>(n, LU.rowptr.data(), LU.col.data(), LU.val.data(), diag.data(), y, zin, out);
+      zin = out;
+   }
+   // upper_it - 1 swaps starting from the buffer chosen above end in z
+}
+
+// hypre_ILUSolve as hypredrive uses it (preconditioner: ilu, or stand-alone): max_iter iterations of
+// x += M^{-1} (b - A x).  x must have room for A's ghost columns when A is a row block (halo != null).
+void ilu_solve(Ilu &F, const DCsr &A, const HaloPlan *halo, const double *b, double *x, bool zero_guess, DArray<double> &r, DArray<double> &c)
+{
+   const int n = A.nrows;
+   if (r.size() < (size_t)std::max(n, 1)) r.alloc((size_t)std::max(n, 1));
+   if (c.size() < (size_t)std::max(n, 1)) c.alloc((size_t)std::max(n, 1));
+   for (int it = 0; it < std::max(F.prm.max_iter, 1); it++)
+   {
+      if (zero_guess && it == 0) { F.apply(b, x); continue; } // b - A*0 = b exactly
+      if (halo) halo_exchange(*halo, x);
+      residual(A, x, b, r.data());
+      F.apply(r.data(), c.data());
+      axpy(n, 1.0, c.data(), x);
+   }
+}
+
+// algorithmic HBM bytes of one apply (factors once per pass, vectors in and out)
+double Ilu::apply_bytes() const
+{
+   const double n = LU.nrows, nnz = LU.nnz;
+   const double pass = 12.0 * nnz / 2.0 + 8.0 * n + 24.0 * n; // half the pattern, rowptr + diag, rhs/in/out
+   const int    passes = prm.tri_solve ? 2 : (prm.lower_it - 1) + (prm.upper_it - 1) + 1;
+   return pass * passes;
+}
+
+} // namespace hda

@@ -151,6 +151,7 @@ void Amg::reorder_levels()
    // Gauss-Seidel sweeps depend on the numbering: hypre's semantics are the natural order
    auto gs = [](int t) { return t == 3 || t == 4 || t == 6 || t == 8 || t == 13 || t == 14; };
    if (gs(prm.relax_down) || gs(prm.relax_up) || gs(prm.relax_coarse)) return;
+   if (prm.smooth_num_levels > 1) return; // so does an ILU factorisation (level 0 is never renumbered)
    // Row blocks (dist): only the unknowns this rank owns are renumbered -- ghost slots are numbered
    // by global id and stay -- and the level handed over to the replicated tail keeps its order.
    // nown(l) = owned unknowns of level l; the last level of `levels` is the coarsest / hand-over one.

@@ -319,6 +319,20 @@ void KrylovArgs::defaults_for(int m)
    if (m == 3) max_iter = 100;
 }
 
+// ILU_FIELDS and the type names of hypredrv_ILUGetValidValues (reference src/internal/ilu.c:15-28, :45-55)
+static const StrMap kIluType = {{"bj-iluk", 0}, {"bj-ilut", 1}, {"gmres-iluk", 10}, {"gmres-ilut", 11}, {"nsh-iluk", 20}, {"nsh-ilut", 21},
+                                {"ras-iluk", 30}, {"ras-ilut", 31}, {"ddpq-gmres-iluk", 40}, {"ddpq-gmres-ilut", 41}, {"rap-mod-ilu0", 50}};
+static void ilu_fields(Ctx &c, YNode &sec, IluArgs &a)
+{
+   apply_fields(c, sec,
+                {{"max_iter", &a.max_iter, nullptr, nullptr}, {"print_level", &a.print_level, nullptr, nullptr}, {"type", &a.type, nullptr, &kIluType},
+                 {"fill_level", &a.fill_level, nullptr, nullptr}, {"reordering", &a.reordering, nullptr, nullptr},
+                 {"tri_solve", &a.tri_solve, nullptr, &kOnOff}, {"lower_jac_iters", &a.lower_jac_iters, nullptr, nullptr},
+                 {"upper_jac_iters", &a.upper_jac_iters, nullptr, nullptr}, {"max_row_nnz", &a.max_row_nnz, nullptr, nullptr},
+                 {"schur_max_iter", &a.schur_max_iter, nullptr, nullptr}, {"droptol", nullptr, &a.droptol, nullptr},
+                 {"nsh_droptol", nullptr, &a.nsh_droptol, nullptr}, {"tolerance", nullptr, &a.tolerance, nullptr}});
+}
+
 static void krylov_fields(Ctx &c, YNode &sec, KrylovArgs &k)
 {
    apply_fields(c, sec,
@@ -399,9 +413,13 @@ static void amg_fields(Ctx &c, YNode &sec, AmgArgs &a)
                               {"weight", nullptr, &a.weight, nullptr}, {"outer_weight", nullptr, &a.outer_weight, nullptr}},
                       {"chebyshev"});
       else if (k->key == "smoother")
+      {
          apply_fields(c, *k, {{"type", &a.smooth_type, nullptr, &kSmoothType}, {"num_levels", &a.smooth_num_levels, nullptr, nullptr},
                               {"num_sweeps", &a.smooth_num_sweeps, nullptr, nullptr}},
                       {"fsai", "ilu"});
+         for (auto &q : k->kids)
+            if (q->key == "ilu") ilu_fields(c, *q, a.smooth_ilu);
+      }
       else c.fail(ERR_INVALID_KEY, "unknown key '" + k->key + "' under 'amg'");
    }
 }
@@ -513,12 +531,14 @@ static void parse_precon_body(Ctx &c, YNode &node, std::vector<PreconArgs> &vari
             if (!item->seq_item) { c.fail(ERR_YAML_TREE_INVALID, "mixing variants and plain keys under '" + ch->key + "'"); continue; }
             PreconArgs v = p;
             if (p.method == 0) amg_fields(c, *item, v.amg);
+            else if (p.method == 2) ilu_fields(c, *item, v.ilu);
             variants.push_back(v);
          }
       }
       else
       {
          if (p.method == 0) amg_fields(c, *ch, p.amg);
+         else if (p.method == 2) ilu_fields(c, *ch, p.ilu);
          variants.push_back(p);
       }
    }

@@ -57,6 +57,11 @@ struct KrylovArgs {
    int    min_iter = 0, skip_real_res_check = 0, krylov_dim = 30, logging = 1;
    void   defaults_for(int m);
 };
+struct IluArgs { // ILU_args, defaults of src/internal/ilu.c:15-28
+   int    max_iter = 1, print_level = 0, type = 0, fill_level = 0, reordering = 0, tri_solve = 1, lower_jac_iters = 5,
+          upper_jac_iters = 5, max_row_nnz = 200, schur_max_iter = 3;
+   double droptol = 1.0e-2, nsh_droptol = 1.0e-2, tolerance = 0.0;
+};
 struct AmgArgs { // AMG_args, GPU-branch defaults of src/internal/amg.c:120-238
    int    max_iter = 1, print_level = 0;
    double tolerance = 0.0;
@@ -76,6 +81,7 @@ struct AmgArgs { // AMG_args, GPU-branch defaults of src/internal/amg.c:120-238
    double weight = 1.0, outer_weight = 1.0;
    // complex smoother
    int    smooth_type = 5, smooth_num_levels = 0, smooth_num_sweeps = 1;
+   IluArgs smooth_ilu;
    // The reference picks these defaults at COMPILE time (#ifdef HYPRE_USING_GPU, amg.c:138-146,
    // 183-189); this library is a GPU build.  HYPREDRV_AMD_DEFAULTS=cpu makes it start from the
    // defaults of a CPU build instead (HMIS, hybrid l1 Gauss-Seidel 13/14, no mod_rap2 /
@@ -91,6 +97,7 @@ struct PreconArgs {
    int         method = 0; // 0 boomeramg, 1 mgr, 2 ilu, 3 fsai, ... 99 none
    std::string method_name = "amg";
    AmgArgs     amg;
+   IluArgs     ilu;
 };
 struct InputArgs {
    GeneralArgs             general;

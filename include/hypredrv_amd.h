@@ -40,6 +40,9 @@ typedef struct {
    double   relax_weight, outer_weight;
    uint64_t seed;
    int      num_functions; /* coarsening.num_functions (1); > 1: unknown-based systems AMG, functions interleaved */
+   /* complex smoother (src/internal/amg.c:899-921), ILU only: bj-iluk, fill 0, natural order on levels < smooth_num_levels */
+   int      smooth_num_levels, smooth_num_sweeps;
+   int      ilu_tri_solve, ilu_lower_it, ilu_upper_it; /* ILU_args tri_solve / lower_jac_iters / upper_jac_iters (ilu.c:21-23) */
 } hda_amg_params;
 
 /* PCG_args src/internal/pcg.c:15-25 / GMRES_args src/internal/gmres.c:16-27 */
@@ -102,6 +105,13 @@ int hda_amg_create(const hda_amg_params *p, hda_csr_t A, hda_amg_t *out);
  * unknown i (reference src/internal/amg.c:792-862 hypredrv_AMGSetDofFunc); NULL = i mod num_functions */
 int hda_amg_create_dof(const hda_amg_params *params, hda_csr_t A, const int *dof_func, hda_amg_t *out);
 int hda_amg_destroy(hda_amg_t h);
+/* "preconditioner: ilu" (reference src/internal/ilu.c:63-115; bj-iluk, fill 0, natural order): block-Jacobi ILU(0) of A's
+ * diagonal block; the handle is accepted by hda_pcg / hda_gmres / hda_amg_vcycle (= one application from a zero guess)
+ * in place of a hierarchy.  max_iter iterations x += M^-1 (b - A x) per application. */
+int hda_ilu_create(hda_csr_t A, int max_iter, int tri_solve, int lower_it, int upper_it, hda_amg_t *out);
+/* borrowed view of the factors: strict lower part = L (unit diagonal), rest = U.  level < 0: the handle of
+ * hda_ilu_create; level >= 0: the complex smoother of that AMG level. */
+int hda_ilu_factors(hda_amg_t h, int level, hda_csr_t *out);
 int hda_amg_num_levels(hda_amg_t h);
 /* which: 0 = A_l, 1 = P_l, 2 = R_l; returns a borrowed handle (do not destroy) */
 int hda_amg_level_matrix(hda_amg_t h, int level, int which, hda_csr_t *out);

@@ -1000,14 +1000,169 @@ orc_rap(const orc_csr *A, const orc_csr *P)
 
 /* --------------------------------------------------------------- hierarchy */
 
+
+/* ------------------------------------------------------------------ ILU(0), block Jacobi
+ * hypre's "bj-iluk" with fill level 0 and no local reordering, as the reference configures it
+ * (src/internal/ilu.c:15-28 defaults, :63-115 setter sequence; smoother form amg.c:899-921).
+ * hypre is not in the reference tree: this is the textbook IKJ ILU(0) (Saad, Iterative Methods,
+ * Alg. 10.4) on the diagonal blocks of the row partition, rows in natural order.  PARITY
+ * UNPINNED: no checked-in reference output uses ILU on data that is present. */
+struct orc_ilu {
+   int      n;
+   orc_csr *LU;   /* pattern of the diagonal blocks; strict lower part = L (unit diagonal), rest = U */
+   int     *diag; /* position of the diagonal entry of every row */
+   int      tri_solve, lower_it, upper_it;
+   double  *y, *w;
+};
+
+void orc_ilu_free(orc_ilu *F);
+
+orc_ilu *
+orc_ilu0_setup(const orc_csr *A, int nparts, const int64_t *part, int tri_solve, int lower_it, int upper_it)
+{
+   int      n   = A->nrows;
+   int64_t  one[2] = {0, n};
+   if (nparts <= 0 || !part) { nparts = 1; part = one; }
+   orc_ilu *F = (orc_ilu *)calloc(1, sizeof(orc_ilu));
+   F->n = n; F->tri_solve = tri_solve; F->lower_it = lower_it < 1 ? 1 : lower_it; F->upper_it = upper_it < 1 ? 1 : upper_it;
+   int *blk_lo = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)), *blk_hi = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+   for (int p = 0; p < nparts; p++)
+      for (int64_t i = part[p]; i < part[p + 1]; i++) { blk_lo[i] = (int)part[p]; blk_hi[i] = (int)part[p + 1]; }
+   int nnz = 0;
+   for (int i = 0; i < n; i++)
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) nnz += (A->col[k] >= blk_lo[i] && A->col[k] < blk_hi[i]);
+   F->LU   = orc_csr_alloc(n, n, nnz);
+   F->diag = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+   int q = 0;
+   for (int i = 0; i < n; i++)
+   {
+      F->LU->rowptr[i] = q;
+      F->diag[i]       = -1;
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         if (A->col[k] >= blk_lo[i] && A->col[k] < blk_hi[i])
+         {
+            if (A->col[k] == i) F->diag[i] = q;
+            F->LU->col[q] = A->col[k];
+            F->LU->val[q] = A->val[k];
+            q++;
+         }
+   }
+   F->LU->rowptr[n] = q;
+   free(blk_lo); free(blk_hi);
+   const int *rp = F->LU->rowptr, *cj = F->LU->col;
+   double    *v  = F->LU->val;
+   for (int i = 0; i < n; i++)
+   {
+      if (F->diag[i] < 0) { orc_ilu_free(F); return NULL; } /* structurally missing diagonal */
+      for (int kk = rp[i]; kk < F->diag[i]; kk++)
+      {
+         const int    k   = cj[kk];
+         const double lik = v[kk] / v[F->diag[k]];
+         v[kk]            = lik;
+         int pi = kk + 1;
+         for (int jj = F->diag[k] + 1; jj < rp[k + 1]; jj++)
+         {
+            const int j = cj[jj];
+            while (pi < rp[i + 1] && cj[pi] < j) pi++;
+            if (pi == rp[i + 1]) break;
+            if (cj[pi] == j) v[pi] -= lik * v[jj];
+         }
+      }
+      if (v[F->diag[i]] == 0.0) { orc_ilu_free(F); return NULL; } /* zero pivot */
+   }
+   F->y = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+   F->w = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+   return F;
+}
+
+void
+orc_ilu_free(orc_ilu *F)
+{
+   if (!F) return;
+   orc_csr_free(F->LU);
+   free(F->diag); free(F->y); free(F->w);
+   free(F);
+}
+
+const orc_csr *orc_ilu_factors(const orc_ilu *F) { return F->LU; }
+
+/* z = U^{-1} L^{-1} r.  tri_solve 1: exact substitutions; 0: lower_it / upper_it Jacobi
+ * iterations from a zero guess on (I + L~) y = r and (D + U~) z = y (ilu.c:21-23). */
+void
+orc_ilu_apply(orc_ilu *F, const double *r, double *z)
+{
+   const int     n  = F->n;
+   const int    *rp = F->LU->rowptr, *cj = F->LU->col, *dg = F->diag;
+   const double *v  = F->LU->val;
+   double       *y  = F->y, *w = F->w;
+   if (F->tri_solve)
+   {
+      for (int i = 0; i < n; i++)
+      {
+         double s = r[i];
+         for (int k = rp[i]; k < dg[i]; k++) s -= v[k] * y[cj[k]];
+         y[i] = s;
+      }
+      for (int i = n - 1; i >= 0; i--)
+      {
+         double s = y[i];
+         for (int k = dg[i] + 1; k < rp[i + 1]; k++) s -= v[k] * z[cj[k]];
+         z[i] = s / v[dg[i]];
+      }
+      return;
+   }
+   memcpy(y, r, sizeof(double) * (size_t)n); /* first iteration from y = 0 */
+   for (int it = 1; it < F->lower_it; it++)
+   {
+      for (int i = 0; i < n; i++)
+      {
+         double s = r[i];
+         for (int k = rp[i]; k < dg[i]; k++) s -= v[k] * y[cj[k]];
+         w[i] = s;
+      }
+      memcpy(y, w, sizeof(double) * (size_t)n);
+   }
+   for (int i = 0; i < n; i++) z[i] = y[i] / v[dg[i]];
+   for (int it = 1; it < F->upper_it; it++)
+   {
+      for (int i = 0; i < n; i++)
+      {
+         double s = y[i];
+         for (int k = dg[i] + 1; k < rp[i + 1]; k++) s -= v[k] * z[cj[k]];
+         w[i] = s / v[dg[i]];
+      }
+      memcpy(z, w, sizeof(double) * (size_t)n);
+   }
+}
+
+/* hypre_ILUSolve as an iteration: x += M^{-1} (b - A x), iters times; tmp, cor length n */
+static void
+ilu_iterate(orc_ilu *F, const orc_csr *A, int iters, const double *b, double *x, double *tmp, double *cor)
+{
+   const int n = A->nrows;
+   for (int it = 0; it < iters; it++)
+   {
+      memcpy(tmp, b, sizeof(double) * (size_t)n);
+      orc_spmv(A, -1.0, x, 1.0, tmp);
+      orc_ilu_apply(F, tmp, cor);
+      for (int i = 0; i < n; i++) x[i] += cor[i];
+   }
+}
+
 struct orc_amg {
    orc_amg_params p;
    int            nlev;
    orc_csr      **A, **P, **R;
    int          **cf;
    double       **l1d, **l1u; /* l1 vectors for down / up relax types */
-   double       **f, **u, **tmp;
+   double       **f, **u, **tmp, **cor;
    double        *dense;      /* coarsest dense copy */
+   /* complex smoother (src/internal/amg.c:899-921): ILU on the first smooth_levels levels */
+   orc_ilu      **ilu;
+   int            smooth_levels, smooth_sweeps;
+   orc_ilu       *ilu_only;   /* handle made by orc_precond_ilu: the "hierarchy" is one ILU solve */
+   const orc_csr *ilu_A;
+   int            ilu_max_iter;
 };
 
 static int
@@ -1114,8 +1269,16 @@ void
 orc_amg_free(orc_amg *h)
 {
    if (!h) return;
+   if (h->ilu_only)
+   {
+      orc_ilu_free(h->ilu_only);
+      free(h);
+      return;
+   }
    for (int l = 0; l < h->nlev; l++)
    {
+      if (h->ilu && h->ilu[l]) orc_ilu_free(h->ilu[l]);
+      if (h->cor && h->cor[l]) free(h->cor[l]);
       orc_csr_free(h->A[l]);
       orc_csr_free(h->P[l]);
       orc_csr_free(h->R[l]);
@@ -1124,7 +1287,53 @@ orc_amg_free(orc_amg *h)
    }
    free(h->A); free(h->P); free(h->R); free(h->cf); free(h->l1d); free(h->l1u);
    free(h->f); free(h->u); free(h->tmp); free(h->dense);
+   free(h->ilu); free(h->cor);
    free(h);
+}
+
+int
+orc_amg_set_ilu_smoother(orc_amg *h, int num_levels, int num_sweeps, int nparts, const int64_t *part, int tri_solve,
+                         int lower_it, int upper_it)
+{
+   if (h->ilu_only) return 1;
+   /* hypre smooths levels < smooth_num_levels that still have a coarser level below them */
+   int K = num_levels < h->nlev - 1 ? num_levels : h->nlev - 1;
+   if (K < 0) K = 0;
+   h->ilu = (orc_ilu **)calloc((size_t)(h->nlev > 0 ? h->nlev : 1), sizeof(void *));
+   h->cor = (double **)calloc((size_t)(h->nlev > 0 ? h->nlev : 1), sizeof(void *));
+   int64_t  one[2] = {0, h->A[0]->nrows};
+   if (nparts <= 0 || !part) { nparts = 1; part = one; }
+   int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nparts + 1));
+   memcpy(cur, part, sizeof(int64_t) * (size_t)(nparts + 1));
+   for (int l = 0; l < K; l++)
+   {
+      h->ilu[l] = orc_ilu0_setup(h->A[l], nparts, cur, tri_solve, lower_it, upper_it);
+      if (!h->ilu[l]) { free(cur); return 2; }
+      h->cor[l] = (double *)calloc((size_t)h->A[l]->nrows, sizeof(double));
+      /* coarse ids ascend with the fine ids of the C points: block p keeps a contiguous range */
+      int64_t c = 0, p = 0;
+      for (int64_t i = 0; i <= h->A[l]->nrows; i++)
+      {
+         while (p <= nparts && cur[p] == i) { cur[p] = c; p++; }
+         if (i < h->A[l]->nrows && h->cf[l][i] > 0) c++;
+      }
+   }
+   free(cur);
+   h->smooth_levels = K;
+   h->smooth_sweeps = num_sweeps < 1 ? 1 : num_sweeps;
+   return 0;
+}
+
+orc_amg *
+orc_precond_ilu(const orc_csr *A, int max_iter, int nparts, const int64_t *part, int tri_solve, int lower_it, int upper_it)
+{
+   orc_ilu *F = orc_ilu0_setup(A, nparts, part, tri_solve, lower_it, upper_it);
+   if (!F) return NULL;
+   orc_amg *h      = (orc_amg *)calloc(1, sizeof(orc_amg));
+   h->ilu_only     = F;
+   h->ilu_A        = A;
+   h->ilu_max_iter = max_iter < 1 ? 1 : max_iter;
+   return h;
 }
 
 int            orc_amg_num_levels(const orc_amg *h) { return h->nlev; }
@@ -1176,6 +1385,14 @@ coarse_solve(orc_amg *h, int l, const double *b, double *x)
 void
 orc_amg_vcycle(orc_amg *h, const double *b, double *x)
 {
+   if (h->ilu_only)
+   { /* preconditioner: ilu (precon.c op table): max_iter iterations of x += M^{-1}(b - A x) */
+      const int n   = h->ilu_A->nrows;
+      double   *tmp = (double *)malloc(sizeof(double) * (size_t)n), *cor = (double *)malloc(sizeof(double) * (size_t)n);
+      ilu_iterate(h->ilu_only, h->ilu_A, h->ilu_max_iter, b, x, tmp, cor);
+      free(tmp); free(cor);
+      return;
+   }
    int L = h->nlev;
    memcpy(h->f[0], b, sizeof(double) * (size_t)h->A[0]->nrows);
    memcpy(h->u[0], x, sizeof(double) * (size_t)h->A[0]->nrows);
@@ -1184,7 +1401,10 @@ orc_amg_vcycle(orc_amg *h, const double *b, double *x)
       const orc_csr *A = h->A[l];
       int            n = A->nrows;
       for (int s = 0; s < h->p.sweeps_down; s++)
-         orc_relax(A, h->l1d[l], h->p.relax_down, h->p.relax_weight, h->f[l], h->u[l], h->tmp[l]);
+      {
+         if (l < h->smooth_levels) ilu_iterate(h->ilu[l], A, h->smooth_sweeps, h->f[l], h->u[l], h->tmp[l], h->cor[l]);
+         else orc_relax(A, h->l1d[l], h->p.relax_down, h->p.relax_weight, h->f[l], h->u[l], h->tmp[l]);
+      }
       /* t = f - A u ; f_{l+1} = P^T t */
       memcpy(h->tmp[l], h->f[l], sizeof(double) * (size_t)n);
       orc_spmv(A, -1.0, h->u[l], 1.0, h->tmp[l]);
@@ -1203,7 +1423,10 @@ orc_amg_vcycle(orc_amg *h, const double *b, double *x)
          const orc_csr *A = h->A[l];
          orc_spmv(h->P[l], 1.0, h->u[l + 1], 1.0, h->u[l]);
          for (int s = 0; s < h->p.sweeps_up; s++)
-            orc_relax(A, h->l1u[l], h->p.relax_up, h->p.relax_weight, h->f[l], h->u[l], h->tmp[l]);
+         {
+            if (l < h->smooth_levels) ilu_iterate(h->ilu[l], A, h->smooth_sweeps, h->f[l], h->u[l], h->tmp[l], h->cor[l]);
+            else orc_relax(A, h->l1u[l], h->p.relax_up, h->p.relax_weight, h->f[l], h->u[l], h->tmp[l]);
+         }
       }
    }
    memcpy(x, h->u[0], sizeof(double) * (size_t)h->A[0]->nrows);

@@ -117,6 +117,21 @@ double   orc_amg_operator_complexity(const orc_amg *h);
 double   orc_amg_grid_complexity(const orc_amg *h);
 void     orc_amg_vcycle(orc_amg *h, const double *b, double *x); /* x must hold the initial guess */
 
+/* ILU(0) on the diagonal blocks of a row partition (hypre "bj-iluk", fill 0, natural order; reference
+ * argument surface src/internal/ilu.c:15-28).  part = nparts+1 row starts (NULL: one block).
+ * Returns NULL on a missing diagonal or a zero pivot.  PARITY UNPINNED (see amg_oracle.c). */
+typedef struct orc_ilu orc_ilu;
+orc_ilu *orc_ilu0_setup(const orc_csr *A, int nparts, const int64_t *part, int tri_solve, int lower_it, int upper_it);
+void     orc_ilu_free(orc_ilu *F);
+const orc_csr *orc_ilu_factors(const orc_ilu *F);        /* L (strict lower, unit diagonal) and U in A's block pattern */
+void     orc_ilu_apply(orc_ilu *F, const double *r, double *z); /* z = U^-1 L^-1 r */
+/* AMG complex smoother (amg.c:899-921): ILU replaces the relaxation sweeps on levels < num_levels; one
+ * smoothing step = num_sweeps iterations u += M^-1 (f - A u).  Call after orc_amg_setup*. Returns 0 on success. */
+int      orc_amg_set_ilu_smoother(orc_amg *h, int num_levels, int num_sweeps, int nparts, const int64_t *part,
+                                  int tri_solve, int lower_it, int upper_it);
+/* "preconditioner: ilu": a handle usable wherever the Krylov routines take a hierarchy */
+orc_amg *orc_precond_ilu(const orc_csr *A, int max_iter, int nparts, const int64_t *part, int tri_solve, int lower_it, int upper_it);
+
 /* Krylov (hypre_PCGSolve / hypre_GMRESSolve restatements).
  * h == NULL -> unpreconditioned.  resid_hist[k] = ||r_k||_2 for k=0..iters
  * (needs max_iter+1 doubles).  Returns iterations; *converged, *final_rel set. */

@@ -109,6 +109,17 @@ def lib():
         f.restype = C.c_int
         f.argtypes = [cp, C.c_void_p, P(KrylovParams), dp, dp, dp, ip, dp]
     L.orc_gselim.argtypes = [dp, dp, C.c_int]
+    i64p = P(C.c_int64)
+    L.orc_ilu0_setup.restype = C.c_void_p
+    L.orc_ilu0_setup.argtypes = [cp, C.c_int, i64p, C.c_int, C.c_int, C.c_int]
+    L.orc_ilu_free.argtypes = [C.c_void_p]
+    L.orc_ilu_factors.restype = cp
+    L.orc_ilu_factors.argtypes = [C.c_void_p]
+    L.orc_ilu_apply.argtypes = [C.c_void_p, dp, dp]
+    L.orc_amg_set_ilu_smoother.restype = C.c_int
+    L.orc_amg_set_ilu_smoother.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i64p, C.c_int, C.c_int, C.c_int]
+    L.orc_precond_ilu.restype = C.c_void_p
+    L.orc_precond_ilu.argtypes = [cp, C.c_int, C.c_int, i64p, C.c_int, C.c_int, C.c_int]
     _LIB = L
     return L
 
@@ -319,6 +330,65 @@ class Amg:
         x = np.zeros_like(b) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
         lib().orc_amg_vcycle(self.h, _dp(b), _dp(x))
         return x
+
+    def set_ilu_smoother(self, num_levels=1, num_sweeps=1, part=None, tri_solve=1, lower_it=5, upper_it=5):
+        """amg.smoother.type ilu: ILU(0) replaces the relaxation sweeps on the first num_levels levels."""
+        n, pp, keep = _part(part)
+        rc = lib().orc_amg_set_ilu_smoother(self.h, num_levels, num_sweeps, n, pp, tri_solve, lower_it, upper_it)
+        if rc:
+            raise ValueError(f"ILU smoother setup failed ({rc})")
+
+
+def _part(part):
+    if part is None:
+        return 0, None, None
+    a = np.ascontiguousarray(part, dtype=np.int64)
+    return len(a) - 1, a.ctypes.data_as(C.POINTER(C.c_int64)), a
+
+
+class Ilu:
+    """ILU(0) of the diagonal blocks of a row partition (part = row starts, None = one block)."""
+
+    def __init__(self, A, part=None, tri_solve=1, lower_it=5, upper_it=5):
+        self.A = A
+        n, pp, self._keep = _part(part)
+        self.h = lib().orc_ilu0_setup(A.ptr, n, pp, tri_solve, lower_it, upper_it)
+        if not self.h:
+            raise ValueError("ILU(0): missing diagonal or zero pivot")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_ilu_free(self.h)
+            self.h = None
+
+    @property
+    def factors(self):
+        return Csr(lib().orc_ilu_factors(self.h), owned=False)
+
+    def apply(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        lib().orc_ilu_apply(self.h, _dp(r), _dp(z))
+        return z
+
+
+class IluPrecond:
+    """'preconditioner: ilu' for pcg()/gmres(): max_iter iterations of x += M^-1 (b - A x)."""
+
+    def __init__(self, A, max_iter=1, part=None, tri_solve=1, lower_it=5, upper_it=5):
+        self.A = A
+        n, pp, self._keep = _part(part)
+        self.h = lib().orc_precond_ilu(A.ptr, max_iter, n, pp, tri_solve, lower_it, upper_it)
+        if not self.h:
+            raise ValueError("ILU(0): missing diagonal or zero pivot")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_amg_free(self.h)
+            self.h = None
+
+    def vcycle(self, b, x0=None):
+        return Amg.vcycle(self, b, x0)
 
 
 def _krylov(fn, A, b, amg, kp, x0):

@@ -121,7 +121,7 @@ def mode_csr(out, n, seed):
     A = random_mmatrix(seed, n)
     lo, hi = rank * n // world, (rank + 1) * n // world
     blk = A[lo:hi]
-    h = hd.Hypredrv("solver: pcg\npreconditioner: amg\n")
+    h = hd.Hypredrv(os.environ.get("HDA_TEST_YAML", "solver: pcg\npreconditioner: amg\n"))
     h.set_matrix_csr(lo, hi - 1, blk.indptr, blk.indices, blk.data)
     h.set_rhs_array(lo, hi - 1, np.ones(hi - lo))
     h.finish_system()

@@ -27,14 +27,19 @@ def test_kernel_abi_exports_every_declared_symbol():
 
 
 def test_param_struct_layout_matches_oracle(orc):
-    """hda_amg_params and the oracle's orc_amg_params share one layout + the GPU defaults
-    of src/internal/amg.c:120-238."""
+    """hda_amg_params starts with the oracle's orc_amg_params (same fields, order and GPU defaults of
+    src/internal/amg.c:120-238); the complex-smoother fields follow (the oracle takes them through
+    orc_amg_set_ilu_smoother)."""
     import hypredrive_amd as h
     hp = h.AmgParams.default()
     op = orc.amg_params(True)
-    for (name, _t) in h.AmgParams._fields_:
+    shared = [n for (n, _t) in orc.AmgParams._fields_]
+    assert [n for (n, _t) in h.AmgParams._fields_][:len(shared)] == shared
+    for name in shared:
         assert getattr(hp, name) == getattr(op, name), name
-    assert C.sizeof(h.AmgParams) == C.sizeof(orc.AmgParams)
+        assert getattr(h.AmgParams, name).offset == getattr(orc.AmgParams, name).offset, name
+    # ILU_args defaults of src/internal/ilu.c:21-23 and smoother off (amg.c:237)
+    assert (hp.smooth_num_levels, hp.smooth_num_sweeps, hp.ilu_tri_solve, hp.ilu_lower_it, hp.ilu_upper_it) == (0, 1, 1, 5, 5)
     assert (hp.coarsen_type, hp.relax_down, hp.relax_up, hp.relax_coarse) == (8, 18, 18, 9)
     assert (hp.pmax, hp.strong_th, hp.max_row_sum, hp.max_coarse_size, hp.max_levels) == (4, 0.25, 0.9, 64, 25)
     kp = h.KrylovParams.default(False)

@@ -530,3 +530,84 @@ def test_matrix_market_file(hd, orc, tmp_path, symmetric):
     ref = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True)))
     assert r["converged"] and r["iters"] == ref["iters"]
     h.close()
+
+
+# ------------------------------------------------- ILU(0): preconditioner and AMG complex smoother through the YAML surface
+
+ILU_YAML = "solver:\n  gmres:\n    relative_tol: 1.0e-8\npreconditioner:\n  ilu:\n    type: bj-iluk\n    fill_level: 0\n    max_iter: {mi}\n    tri_solve: {ts}\n"
+AMG_ILU_YAML = ("solver: pcg\npreconditioner:\n  amg:\n    smoother:\n      type: ilu\n      num_levels: {nl}\n      num_sweeps: {ns}\n"
+                "      ilu:\n        type: bj-iluk\n        tri_solve: {ts}\n")
+
+
+@pytest.mark.parametrize("mi,ts", [(1, 1), (2, 0)])
+def test_yaml_ilu_preconditioner_matches_oracle(hd, orc, mi, ts):
+    """'preconditioner: ilu' (reference examples/ex1b.yml selects it the same way; keys of src/internal/ilu.c:15-28)
+    under GMRES: iteration count and solution of the oracle's block-Jacobi ILU(0)."""
+    Ao, b = orc.lap7(12, 12, 12)
+    ref = orc.gmres(Ao, b, orc.IluPrecond(Ao, max_iter=mi, tri_solve=ts), orc.krylov_params(True, rtol=1e-8))
+    h = hd.Hypredrv(ILU_YAML.format(mi=mi, ts=ts))
+    h.set_laplacian7((12, 12, 12))
+    r = h.solve()
+    assert r["converged"] and r["iters"] == ref["iters"]
+    assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-8
+    h.close()
+
+
+@pytest.mark.parametrize("nl,ns,ts", [(1, 1, 1), (2, 2, 0)])
+def test_yaml_amg_ilu_smoother_matches_oracle(hd, orc, nl, ns, ts):
+    """amg.smoother.type ilu / num_levels / num_sweeps (reference examples/ex8.yml variant 4, amg.c:899-921)."""
+    Ao, b = orc.lap7(14, 14, 14)
+    ao = orc.Amg(Ao, orc.amg_params(True))
+    ao.set_ilu_smoother(num_levels=nl, num_sweeps=ns, tri_solve=ts)
+    ref = orc.pcg(Ao, b, ao)
+    h = hd.Hypredrv(AMG_ILU_YAML.format(nl=nl, ns=ns, ts=ts))
+    h.set_laplacian7((14, 14, 14))
+    r = h.solve()
+    assert r["converged"] and r["iters"] == ref["iters"]
+    assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-9
+    h.close()
+
+
+def test_yaml_unimplemented_ilu_variants_fail_loudly(hd):
+    for extra in ("type: bj-ilut", "fill_level: 1", "reordering: 1"):
+        h = hd.Hypredrv("solver: gmres\npreconditioner:\n  ilu:\n    " + extra + "\n")
+        h.set_laplacian7((6, 6, 6))
+        with pytest.raises(hd.HypredrvError, match="implemented"):
+            h.solve()
+        hd.lib().HYPREDRV_ErrorCodeClear()
+        h.close()
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    smoother:\n      type: fsai\n      num_levels: 1\n")
+    h.set_laplacian7((6, 6, 6))
+    with pytest.raises(hd.HypredrvError, match="ILU"):
+        h.solve()
+    hd.lib().HYPREDRV_ErrorCodeClear()
+    h.close()
+
+
+@pytest.mark.parametrize("world,kind", [(3, "ilu"), (4, "amg-ilu")])
+def test_row_partitioned_ilu_is_block_jacobi(hd, orc, tmp_path, world, kind):
+    """Row blocks on several ranks: the ILU is the block-Jacobi one (every rank factorises its diagonal
+    block, ghost couplings enter only through the residual) -- same iteration count as the oracle's ILU
+    on the same partition, as preconditioner and as level-0 smoother of the partitioned AMG hierarchy."""
+    n, seed = 3000, 21
+    out = str(tmp_path / "res.json")
+    yaml = ILU_YAML.format(mi=1, ts=1) if kind == "ilu" else AMG_ILU_YAML.format(nl=1, ns=1, ts=1)
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS="400", HDA_TEST_YAML=yaml)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29670 + world), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    res = json.load(open(out))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import random_mmatrix
+    A = random_mmatrix(seed, n)
+    Ao = orc.Csr.from_scipy(A)
+    part = [k * n // world for k in range(world + 1)]
+    if kind == "ilu":
+        ref = orc.gmres(Ao, np.ones(n), orc.IluPrecond(Ao, part=part), orc.krylov_params(True, rtol=1e-8))
+    else:
+        ao = orc.Amg(Ao, orc.amg_params(True))
+        ao.set_ilu_smoother(num_levels=1, num_sweeps=1, part=part)
+        ref = orc.pcg(Ao, np.ones(n), ao)
+    assert res["converged"] and res["iters"] == ref["iters"]
+    assert res["norm"] == pytest.approx(np.linalg.norm(ref["x"]), rel=1e-7)

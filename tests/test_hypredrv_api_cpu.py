@@ -126,8 +126,14 @@ def test_lifecycle_guards_and_error_bits(hd):
     h2 = hd.Hypredrv("solver: bicgstab\npreconditioner: amg\n")
     assert L.HYPREDRV_LinearSolverCreate(h2.h) & (hd.ERROR_INVALID_SOLVER | hd.ERROR_HYPRE_INTERNAL)
     L.HYPREDRV_ErrorCodeClear()
-    h3 = hd.Hypredrv("solver: pcg\npreconditioner: ilu\n")
+    h3 = hd.Hypredrv("solver: pcg\npreconditioner: mgr\n")
     assert L.HYPREDRV_PreconCreate(h3.h) & hd.ERROR_INVALID_PRECON
+    L.HYPREDRV_ErrorCodeClear()
+    # ILU is created from its YAML block (ilu.c:15-28 keys); unknown keys are rejected at parse time
+    h4 = hd.Hypredrv("solver: gmres\npreconditioner:\n  ilu:\n    type: bj-iluk\n    fill_level: 0\n    tri_solve: 0\n    lower_jac_iters: 3\n")
+    assert L.HYPREDRV_PreconCreate(h4.h) == 0
+    with pytest.raises(hd.HypredrvError):
+        hd.Hypredrv("solver: pcg\npreconditioner:\n  ilu:\n    no_such_key: 1\n")
     L.HYPREDRV_ErrorCodeClear()
 
 

@@ -187,3 +187,93 @@ def test_init_guess_exact_zero_iters(orc):
     b = S @ np.ones(A.nrows)
     r = orc.pcg(A, b, None, x0=np.ones(A.nrows))
     assert r["hist"][0] == 0.0 or r["iters"] <= 1
+
+
+# ------------------------------------------------------------------ ILU(0) (parity unpinned: analytic anchors only)
+
+def _lu_split(F):
+    import scipy.sparse as sp
+    LU = F.factors.to_scipy()
+    n = LU.shape[0]
+    return (sp.tril(LU, -1) + sp.eye(n)).tocsr(), sp.triu(LU).tocsr()
+
+
+def test_ilu0_defining_property(orc):
+    """ILU(0): (L U)_ij = a_ij on the pattern of A, nothing stored outside it (Saad, Prop. 10.4)."""
+    import scipy.sparse as sp
+    for A in (orc.lap7(7, 6, 5, b_mode=1)[0],
+              orc.Csr.from_scipy((sp.random(120, 120, density=0.06, random_state=3, format="csr")
+                                  + sp.diags(np.full(120, 4.0))).tocsr())):  # second one: non-symmetric pattern
+        S = A.to_scipy()
+        F = orc.Ilu(A)
+        L, U = _lu_split(F)
+        assert (F.factors.to_scipy() != 0).nnz <= S.nnz
+        E = (L @ U - S).tocsr()
+        pat = (abs(S) > 0).astype(float)
+        assert abs(E.multiply(pat)).max() < 1e-13 * abs(S).max()
+
+
+def test_ilu0_tridiagonal_is_exact_lu(orc):
+    """No fill on a tridiagonal matrix: ILU(0) = LU, so the preconditioned solve ends after one iteration."""
+    import scipy.sparse as sp
+    n = 50
+    T = sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]).tocsr()
+    A = orc.Csr.from_scipy(T)
+    b = np.arange(1.0, n + 1.0)
+    F = orc.Ilu(A)
+    assert np.allclose(T @ F.apply(b), b, rtol=0, atol=1e-11)
+    k = np.arange(2, n + 1)  # pivots of the 1-D Laplacian: u_kk = (k + 1) / k, k = 1..n
+    U = _lu_split(F)[1]
+    assert np.allclose(U.diagonal()[1:], (k + 1.0) / k)
+    r = orc.pcg(A, b, orc.IluPrecond(A))
+    assert r["converged"] and r["iters"] == 1
+
+
+def test_ilu_apply_variants(orc):
+    """exact substitutions = scipy's triangular solves; the Jacobi-iterative form (ilu.c:21-23) converges to it
+    (strictly triangular iteration matrices are nilpotent) and block Jacobi = ILU of the block diagonal."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    A, b = orc.lap7(6, 6, 6, b_mode=0)
+    b = b + np.linspace(0.0, 1.0, A.nrows)
+    F = orc.Ilu(A)
+    L, U = _lu_split(F)
+    z = F.apply(b)
+    z_ref = spla.spsolve_triangular(U, spla.spsolve_triangular(L, b, lower=True), lower=False)
+    assert np.allclose(z, z_ref, rtol=1e-13, atol=0)
+    errs = [np.linalg.norm(orc.Ilu(A, tri_solve=0, lower_it=k, upper_it=k).apply(b) - z) for k in (1, 3, 5, 9, 40)]
+    assert all(e1 > e2 for e1, e2 in zip(errs, errs[1:-1])) and errs[-1] < 1e-12 * np.linalg.norm(z)
+    part = [0, 70, 150, A.nrows]
+    S = A.to_scipy().tolil()
+    for p in range(3):  # cut the couplings between blocks
+        lo, hi = part[p], part[p + 1]
+        S[lo:hi, :lo] = 0
+        S[lo:hi, hi:] = 0
+    Fb = orc.Ilu(A, part=part)
+    Fd = orc.Ilu(orc.Csr.from_scipy(S.tocsr()))
+    assert np.array_equal(Fb.apply(b), Fd.apply(b))
+
+
+def test_ilu_as_preconditioner_and_smoother(orc):
+    A, b = orc.lap7(10, 10, 10, b_mode=1)
+    plain = orc.pcg(A, b)
+    ilu = orc.pcg(A, b, orc.IluPrecond(A))
+    assert ilu["converged"] and ilu["iters"] < plain["iters"]
+    two = orc.gmres(A, b, orc.IluPrecond(A, max_iter=2))
+    one = orc.gmres(A, b, orc.IluPrecond(A, max_iter=1))
+    assert two["converged"] and two["iters"] < one["iters"]
+    amg = orc.Amg(A, orc.amg_params(True))
+    base = orc.pcg(A, b, amg)
+    amg.set_ilu_smoother(num_levels=1, num_sweeps=1)
+    sm = orc.pcg(A, b, amg)
+    assert sm["converged"] and sm["iters"] < base["iters"]
+    S = A.to_scipy()
+    assert np.linalg.norm(b - S @ sm["x"]) / np.linalg.norm(b) < 1e-6
+
+
+def test_ilu_rejects_missing_diagonal(orc):
+    import scipy.sparse as sp
+    M = sp.csr_matrix(np.array([[0.0, 1.0], [1.0, 2.0]]))
+    M.eliminate_zeros()
+    with pytest.raises(ValueError):
+        orc.Ilu(orc.Csr.from_scipy(M))
