@@ -69,9 +69,10 @@ class Ilu {
 
  private:
    DCsr           LU;
+   DCsr           Ls, Us; // tri_solve 0: strict lower triangle / diagonal + upper triangle, one stream each
    DArray<int>    diag;
    GsPlan         plan;
-   DArray<double> work;
+   DArray<double> work, dinv;
 };
 
 void ilu_solve(Ilu &F, const DCsr &A, const HaloPlan *halo, const double *b, double *x, bool zero_guess, DArray<double> &r,

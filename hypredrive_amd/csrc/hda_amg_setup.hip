@@ -1667,7 +1667,7 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
       if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return 3LL << 30;
       return (long long)(0.3 * (double)totalb / 12.0);
    }(); // products
-   if (T > 4096 || Y.ncols >= (1LL << 31) || total > scratch_cap) return spgemm_hash(X, Y, C); // outside the LDS path
+   if (T > 4096 || total > scratch_cap) return spgemm_hash(X, Y, C); // outside the LDS path
    const int cap     = 2 * T;
    const int nchunks = (int)std::max<long long>(1, (total + T - 1) / T);
    DArray<int>       chunk_row((size_t)nchunks + 1), cnt((size_t)n + 1);
@@ -2069,12 +2069,22 @@ double Amg::vcycle_bytes(bool format) const
    {
       const DCsr &A = level_A(l);
       const double n = A.nrows;
-      s += 24.0 * n;                                            // zero-guess sweep: dinv, f -> u
-      s += (prm.sweeps_down - 1) * (spmv_bytes(A, format) + 16.0 * n);  // further pre-sweeps
+      if (levels[l].ilu)
+      { // complex smoother: every step but the very first (zero guess) is residual + ILU application + update
+         const double app = levels[l].ilu->apply_bytes(), step = spmv_bytes(A, format) + 8.0 * n + app + 24.0 * n;
+         const int    it  = levels[l].ilu->prm.max_iter;
+         s += prm.sweeps_down > 0 ? app + (prm.sweeps_down * it - 1) * step : 0.0;
+         s += prm.sweeps_up * it * step;
+      }
+      else
+      {
+         s += 24.0 * n;                                            // zero-guess sweep: dinv, f -> u
+         s += (prm.sweeps_down - 1) * (spmv_bytes(A, format) + 16.0 * n);  // further pre-sweeps
+         s += prm.sweeps_up * (spmv_bytes(A, format) + 16.0 * n);          // post-sweeps
+      }
       s += spmv_bytes(A, format) + 8.0 * n;                             // residual
       s += spmv_bytes(levels[l].R, format);                             // restriction
       s += spmv_bytes(levels[l].P, format) + 8.0 * n;                   // prolongation-add
-      s += prm.sweeps_up * (spmv_bytes(A, format) + 16.0 * n);          // post-sweeps
    }
    if (tail) s += tail->vcycle_bytes(format) + 16.0 * coarse_n; // replicated coarse levels: every rank does all of it
    else s += 8.0 * coarse_n * coarse_n + 16.0 * coarse_n;

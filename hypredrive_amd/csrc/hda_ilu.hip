@@ -25,7 +25,7 @@ namespace hda {
 namespace {
 
 enum { OP_FACTOR = 0, OP_LOWER = 1, OP_UPPER = 2 };
-constexpr int kLanes = 8; // lanes per row in the substitutions and Jacobi passes
+constexpr int kLanes = 8; // lanes per row in the substitutions
 
 __global__ __launch_bounds__(256) void k_ilu_count(int n, const int *__restrict__ rp, const int *__restrict__ cj, int *__restrict__ cnt)
 {
@@ -158,27 +158,27 @@ void run_levels(const DCsr &LU, const GsPlan &p, const int *dg, double *x, int *
    }
 }
 
-// one Jacobi iteration on a triangular system: LOWER out = rhs - L~ in, UPPER out = (rhs - U~ in) / d
-template <int OP>
-__global__ __launch_bounds__(256) void k_ilu_jacobi(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
-                                                    const int *__restrict__ dg, const double *__restrict__ rhs, const double *__restrict__ in,
-                                                    double *__restrict__ out)
-{
-   const int t = blockIdx.x * 256 + threadIdx.x, i = t / kLanes, lane = t & (kLanes - 1);
-   if (i >= n) return; // whole lane groups leave together (256 is a multiple of kLanes)
-   const int lo = (OP == OP_LOWER) ? rp[i] : dg[i] + 1, hi = (OP == OP_LOWER) ? dg[i] : rp[i + 1];
-   double    s  = 0.0;
-   for (int k = lo + lane; k < hi; k += kLanes) s += v[k] * in[cj[k]];
-#pragma unroll
-   for (int o = kLanes / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-   if (lane == 0) out[i] = (OP == OP_LOWER) ? (rhs[i] - s) : (rhs[i] - s) / v[dg[i]];
-}
-
-__global__ __launch_bounds__(256) void k_ilu_dscale(int n, const double *__restrict__ v, const int *__restrict__ dg, const double *__restrict__ y,
-                                                    double *__restrict__ z)
+// split the factors for the Jacobi-iterative solves: Ls = strict lower part, Us = diagonal + strict upper part
+__global__ __launch_bounds__(256) void k_ilu_split_count(int n, const int *__restrict__ rp, const int *__restrict__ dg, int *__restrict__ nl,
+                                                         int *__restrict__ nu)
 {
    const int i = blockIdx.x * 256 + threadIdx.x;
-   if (i < n) z[i] = y[i] / v[dg[i]];
+   if (i >= n) return;
+   nl[i] = dg[i] - rp[i];
+   nu[i] = rp[i + 1] - dg[i];
+}
+__global__ __launch_bounds__(256) void k_ilu_split_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                        const int *__restrict__ dg, const int *__restrict__ lrp, int *__restrict__ lcj,
+                                                        double *__restrict__ lv, const int *__restrict__ urp, int *__restrict__ ucj,
+                                                        double *__restrict__ uv, double *__restrict__ dinv)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int q = lrp[i];
+   for (int k = rp[i]; k < dg[i]; k++, q++) { lcj[q] = cj[k]; lv[q] = v[k]; }
+   q = urp[i];
+   for (int k = dg[i]; k < rp[i + 1]; k++, q++) { ucj[q] = cj[k]; uv[q] = v[k]; }
+   dinv[i] = 1.0 / v[dg[i]];
 }
 
 } // namespace
@@ -220,6 +220,34 @@ void Ilu::setup(const DCsr &A, const IluParams &p)
    flag.download(&f, 1);
    HDA_REQUIRE(!(f & 4), "ILU(0): zero pivot");
    work.alloc((size_t)std::max(n, 1) * 2);
+   Ls = DCsr();
+   Us = DCsr();
+   if (!prm.tri_solve && n)
+   { // the iterations are plain products with the two triangles: keep each in its own CSR so that a pass
+     // streams only its half, through the same kernels (and launch plans) as every other operator
+      DArray<int> nl((size_t)n + 1), nu((size_t)n + 1);
+      nl.zero();
+      nu.zero();
+      k_ilu_split_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, LU.rowptr.data(), diag.data(), nl.data(), nu.data());
+      Ls.nrows = Ls.ncols = Us.nrows = Us.ncols = n;
+      Ls.rowptr.alloc((size_t)n + 1);
+      Us.rowptr.alloc((size_t)n + 1);
+      exclusive_scan(n, nl.data(), Ls.rowptr.data(), nullptr);
+      exclusive_scan(n, nu.data(), Us.rowptr.data(), nullptr);
+      HDA_HIP(hipMemcpyAsync(&Ls.nnz, Ls.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+      HDA_HIP(hipMemcpyAsync(&Us.nnz, Us.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+      Context::get().sync();
+      Ls.col.alloc((size_t)std::max(Ls.nnz, 1));
+      Ls.val.alloc((size_t)std::max(Ls.nnz, 1));
+      Us.col.alloc((size_t)std::max(Us.nnz, 1));
+      Us.val.alloc((size_t)std::max(Us.nnz, 1));
+      dinv.alloc((size_t)n);
+      k_ilu_split_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, LU.rowptr.data(), LU.col.data(), LU.val.data(), diag.data(), Ls.rowptr.data(),
+                                                            Ls.col.data(), Ls.val.data(), Us.rowptr.data(), Us.col.data(), Us.val.data(),
+                                                            dinv.data());
+      spmv_prepare(Ls);
+      spmv_prepare(Us);
+   }
 }
 
 // z = U^{-1} L^{-1} r   (r and z may not alias)
@@ -234,24 +262,25 @@ void Ilu::apply(const double *r, double *z)
       run_levels<OP_UPPER>(LU, plan, diag.data(), z, nullptr);
       return;
    }
-   // Jacobi iterations from a zero guess: the first one is y = r (resp. z = D^{-1} y)
-   const int     grid = ceil_div((long long)n * kLanes, 256);
+   // Jacobi iterations from a zero guess: the first one is y = r (resp. z = D^{-1} y); then
+   // y <- r - L~ y is a residual with the strict lower triangle, and z <- D^{-1}(y - U~ z) is a Jacobi
+   // sweep z + D^{-1}(y - (D + U~) z) with the upper triangle that includes the diagonal
    double       *ya = work.data(), *yb = work.data() + n;
    const double *y = r;
    for (int it = 1; it < prm.lower_it; it++)
    {
       double *out = (it & 1) ? ya : yb;
-      k_ilu_jacobi<OP_LOWER><<<grid, 256, 0, STREAM>>>(n, LU.rowptr.data(), LU.col.data(), LU.val.data(), diag.data(), r, y, out);
+      residual(Ls, y, r, out);
       y = out;
    }
    // y now lives in r, ya or yb; the upper iterations ping-pong between z and the free half of work
    double *spare = (y == ya) ? yb : ya;
-   k_ilu_dscale<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, LU.val.data(), diag.data(), y, (prm.upper_it & 1) ? z : spare);
+   mul(n, dinv.data(), y, (prm.upper_it & 1) ? z : spare);
    const double *zin = (prm.upper_it & 1) ? z : spare;
    for (int it = 1; it < prm.upper_it; it++)
    {
       double *out = (zin == z) ? spare : z;
-      k_ilu_jacobi<OP_UPPER><<<grid, 256, 0, STREAM>>>(n, LU.rowptr.data(), LU.col.data(), LU.val.data(), diag.data(), y, zin, out);
+      jacobi(Us, dinv.data(), y, zin, out, -1);
       zin = out;
    }
    // upper_it - 1 swaps starting from the buffer chosen above end in z
@@ -277,10 +306,10 @@ void ilu_solve(Ilu &F, const DCsr &A, const HaloPlan *halo, const double *b, dou
 // algorithmic HBM bytes of one apply (factors once per pass, vectors in and out)
 double Ilu::apply_bytes() const
 {
-   const double n = LU.nrows, nnz = LU.nnz;
-   const double pass = 12.0 * nnz / 2.0 + 8.0 * n + 24.0 * n; // half the pattern, rowptr + diag, rhs/in/out
-   const int    passes = prm.tri_solve ? 2 : (prm.lower_it - 1) + (prm.upper_it - 1) + 1;
-   return pass * passes;
+   const double n = LU.nrows;
+   if (prm.tri_solve) return 2.0 * (12.0 * LU.nnz / 2.0 + 8.0 * n + 24.0 * n) + 16.0 * n; // two substitutions over half the pattern each + the copy
+   const double lower = 12.0 * Ls.nnz + 4.0 * (n + 1) + 24.0 * n, upper = 12.0 * Us.nnz + 4.0 * (n + 1) + 32.0 * n;
+   return (prm.lower_it - 1) * lower + 24.0 * n + (prm.upper_it - 1) * upper;
 }
 
 } // namespace hda
