@@ -60,7 +60,7 @@ SYMBOLS = [
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
-    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors",
+    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab",
 ]
 
 
@@ -108,7 +108,7 @@ def load():
     L.hda_amg_vcycle_bytes.argtypes = [vp]
     L.hda_amg_vcycle_bytes.restype = C.c_double
     L.hda_amg_vcycle.argtypes = [vp, dp, dp]
-    for f in (L.hda_pcg, L.hda_gmres):
+    for f in (L.hda_pcg, L.hda_gmres, L.hda_fgmres, L.hda_bicgstab):
         f.argtypes = [vp, vp, P(KrylovParams), dp, dp, dp, ip, ip, dp]
     L.hda_time_kernel.argtypes = [C.c_int, vp, vp, C.c_int, dp, dp]
     L.hda_solve_device.argtypes = [vp, vp, P(KrylovParams), C.c_int, dp, C.c_int, dp, ip, dp, dp, dp, dp]
@@ -363,6 +363,14 @@ def pcg(A, b, amg=None, kp=None, x0=None):
 
 def gmres(A, b, amg=None, kp=None, x0=None):
     return _krylov(load().hda_gmres, A, b, amg, kp or KrylovParams.default(True), x0)
+
+
+def fgmres(A, b, amg=None, kp=None, x0=None):
+    return _krylov(load().hda_fgmres, A, b, amg, kp or KrylovParams.default(True), x0)
+
+
+def bicgstab(A, b, amg=None, kp=None, x0=None):
+    return _krylov(load().hda_bicgstab, A, b, amg, kp or KrylovParams.default(False), x0)
 
 
 def time_kernel(kind, A, amg=None, reps=20):

@@ -468,7 +468,7 @@ extern "C" int hda_amg_vcycle(hda_amg_t h, const double *b, double *x)
 
 // --------------------------------------------------------------------- Krylov
 
-static int run_krylov(bool use_gmres, hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b,
+static int run_krylov(int kind, hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b,
                       double *x, double *hist, int *iters, int *converged, double *final_rel)
 {
    HDA_TRY
@@ -488,7 +488,8 @@ static int run_krylov(bool use_gmres, hda_csr_t A, hda_amg_t amg, const hda_kryl
    else if (amg) M = [amg](const double *r, double *z, int slot) { amg->amg->apply(r, z, slot); };
    KrylovParams  k   = to_kparams(kp);
    LinOp         op(m, nullptr, (amg && amg->amg) ? amg->amg->vec_len0() : 0);
-   KrylovResult  res = use_gmres ? gmres(op, M, k, db.data(), dx.data()) : pcg(op, M, k, db.data(), dx.data());
+   KrylovResult  res = kind == 1 ? gmres(op, M, k, db.data(), dx.data()) : kind == 2 ? fgmres(op, M, k, db.data(), dx.data())
+                     : kind == 3 ? bicgstab(op, M, k, db.data(), dx.data()) : pcg(op, M, k, db.data(), dx.data());
    dx.download(x, (size_t)m.nrows);
    if (hist)
       for (size_t i = 0; i < res.hist.size() && i < (size_t)k.max_iter + 1; i++) hist[i] = res.hist[i];
@@ -500,12 +501,22 @@ static int run_krylov(bool use_gmres, hda_csr_t A, hda_amg_t amg, const hda_kryl
 extern "C" int hda_pcg(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
                        double *hist, int *iters, int *converged, double *final_rel)
 {
-   return run_krylov(false, A, amg, kp, b, x, hist, iters, converged, final_rel);
+   return run_krylov(0, A, amg, kp, b, x, hist, iters, converged, final_rel);
 }
 extern "C" int hda_gmres(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
                          double *hist, int *iters, int *converged, double *final_rel)
 {
-   return run_krylov(true, A, amg, kp, b, x, hist, iters, converged, final_rel);
+   return run_krylov(1, A, amg, kp, b, x, hist, iters, converged, final_rel);
+}
+extern "C" int hda_fgmres(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
+                          double *hist, int *iters, int *converged, double *final_rel)
+{
+   return run_krylov(2, A, amg, kp, b, x, hist, iters, converged, final_rel);
+}
+extern "C" int hda_bicgstab(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
+                            double *hist, int *iters, int *converged, double *final_rel)
+{
+   return run_krylov(3, A, amg, kp, b, x, hist, iters, converged, final_rel);
 }
 
 // ---------------------------------------------------------------- measurement

@@ -43,7 +43,7 @@ struct hypre_IJMatrix_struct {
    void adopt_device(int nloc, int nnz, hda::DArray<int> &rowptr, hda::DArray<long long> &gcols, hda::DArray<double> &vals);
 };
 
-enum hda_solver_kind { HDA_SOLVER_PCG = 1, HDA_SOLVER_GMRES = 2, HDA_SOLVER_AMG = 3, HDA_SOLVER_ILU = 4 };
+enum hda_solver_kind { HDA_SOLVER_PCG = 1, HDA_SOLVER_GMRES = 2, HDA_SOLVER_AMG = 3, HDA_SOLVER_ILU = 4, HDA_SOLVER_FGMRES = 5, HDA_SOLVER_BICGSTAB = 6 };
 
 struct hypre_Solver_struct {
    int                       kind = 0;

@@ -770,12 +770,16 @@ static HYPRE_Int krylov_create(int kind, HYPRE_Solver *solver)
 {
    auto *s = new hypre_Solver_struct();
    s->kind = kind;
-   if (kind == HDA_SOLVER_GMRES) s->kp.max_iter = 300; // src/internal/gmres.c:18
+   if (kind == HDA_SOLVER_GMRES || kind == HDA_SOLVER_FGMRES) s->kp.max_iter = 300; // src/internal/gmres.c:18, fgmres.c:17
    *solver = s;
    return 0;
 }
 extern "C" HYPRE_Int HYPRE_ParCSRPCGCreate(MPI_Comm, HYPRE_Solver *s) { return krylov_create(HDA_SOLVER_PCG, s); }
 extern "C" HYPRE_Int HYPRE_ParCSRGMRESCreate(MPI_Comm, HYPRE_Solver *s) { return krylov_create(HDA_SOLVER_GMRES, s); }
+extern "C" HYPRE_Int HYPRE_ParCSRFlexGMRESCreate(MPI_Comm, HYPRE_Solver *s) { return krylov_create(HDA_SOLVER_FGMRES, s); }
+extern "C" HYPRE_Int HYPRE_ParCSRBiCGSTABCreate(MPI_Comm, HYPRE_Solver *s) { return krylov_create(HDA_SOLVER_BICGSTAB, s); }
+extern "C" HYPRE_Int HYPRE_ParCSRFlexGMRESDestroy(HYPRE_Solver s) { delete s; return 0; }
+extern "C" HYPRE_Int HYPRE_ParCSRBiCGSTABDestroy(HYPRE_Solver s) { delete s; return 0; }
 extern "C" HYPRE_Int HYPRE_ParCSRPCGDestroy(HYPRE_Solver s) { delete s; return 0; }
 extern "C" HYPRE_Int HYPRE_ParCSRGMRESDestroy(HYPRE_Solver s) { delete s; return 0; }
 
@@ -805,6 +809,24 @@ HY_SETTER(HYPRE_GMRESSetTol, HYPRE_Real, s->kp.rtol = v)
 HY_SETTER(HYPRE_GMRESSetAbsoluteTol, HYPRE_Real, s->kp.atol = v)
 HY_SETTER(HYPRE_GMRESSetConvergenceFactorTol, HYPRE_Real, (void)v)
 
+// FlexGMRES (reference src/internal/fgmres.c:36-48) and BiCGSTAB (src/internal/bicgstab.c:41-55) setter sequences
+HY_SETTER(HYPRE_FlexGMRESSetMinIter, HYPRE_Int, s->kp.min_iter = v)
+HY_SETTER(HYPRE_FlexGMRESSetMaxIter, HYPRE_Int, s->kp.max_iter = v)
+HY_SETTER(HYPRE_FlexGMRESSetKDim, HYPRE_Int, s->kp.krylov_dim = v)
+HY_SETTER(HYPRE_FlexGMRESSetLogging, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_FlexGMRESSetPrintLevel, HYPRE_Int, s->kp.print_level = v)
+HY_SETTER(HYPRE_FlexGMRESSetTol, HYPRE_Real, s->kp.rtol = v)
+HY_SETTER(HYPRE_FlexGMRESSetAbsoluteTol, HYPRE_Real, s->kp.atol = v)
+HY_SETTER(HYPRE_FlexGMRESSetConvergenceFactorTol, HYPRE_Real, (void)v)
+HY_SETTER(HYPRE_BiCGSTABSetMinIter, HYPRE_Int, s->kp.min_iter = v)
+HY_SETTER(HYPRE_BiCGSTABSetMaxIter, HYPRE_Int, s->kp.max_iter = v)
+HY_SETTER(HYPRE_BiCGSTABSetStopCrit, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BiCGSTABSetLogging, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BiCGSTABSetPrintLevel, HYPRE_Int, s->kp.print_level = v)
+HY_SETTER(HYPRE_BiCGSTABSetTol, HYPRE_Real, s->kp.rtol = v)
+HY_SETTER(HYPRE_BiCGSTABSetAbsoluteTol, HYPRE_Real, s->kp.atol = v)
+HY_SETTER(HYPRE_BiCGSTABSetConvergenceFactorTol, HYPRE_Real, (void)v)
+
 static HYPRE_Int set_precond(HYPRE_Solver s, HYPRE_PtrToSolverFcn p, HYPRE_PtrToSolverFcn ps, HYPRE_Solver psolver)
 {
    s->precond        = p;
@@ -820,6 +842,14 @@ extern "C" HYPRE_Int HYPRE_GMRESSetPrecond(HYPRE_Solver s, HYPRE_PtrToSolverFcn 
 {
    return set_precond(s, p, ps, psolver);
 }
+extern "C" HYPRE_Int HYPRE_FlexGMRESSetPrecond(HYPRE_Solver s, HYPRE_PtrToSolverFcn p, HYPRE_PtrToSolverFcn ps, HYPRE_Solver psolver)
+{
+   return set_precond(s, p, ps, psolver);
+}
+extern "C" HYPRE_Int HYPRE_BiCGSTABSetPrecond(HYPRE_Solver s, HYPRE_PtrToSolverFcn p, HYPRE_PtrToSolverFcn ps, HYPRE_Solver psolver)
+{
+   return set_precond(s, p, ps, psolver);
+}
 
 // hypre_PCGSetup / hypre_GMRESSetup: the only work is the preconditioner's setup callback
 static HYPRE_Int krylov_setup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
@@ -830,6 +860,8 @@ static HYPRE_Int krylov_setup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVec
 }
 extern "C" HYPRE_Int HYPRE_ParCSRPCGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_setup(s, A, b, x); }
 extern "C" HYPRE_Int HYPRE_ParCSRGMRESSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_setup(s, A, b, x); }
+extern "C" HYPRE_Int HYPRE_ParCSRFlexGMRESSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_setup(s, A, b, x); }
+extern "C" HYPRE_Int HYPRE_ParCSRBiCGSTABSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_setup(s, A, b, x); }
 
 // length Krylov work vectors need so that a BoomerAMG preconditioner can use them as level-0
 // vectors directly (any other callback only sees the owned part)
@@ -883,12 +915,17 @@ static HYPRE_Int krylov_solve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVec
          if (slot >= 0 && !done) dot(n, r, z, slot);
       };
    }
-   s->last = (s->kind == HDA_SOLVER_GMRES) ? gmres(op, M, s->kp, b->data(), x->data()) : pcg(op, M, s->kp, b->data(), x->data());
+   s->last = (s->kind == HDA_SOLVER_GMRES)      ? gmres(op, M, s->kp, b->data(), x->data())
+             : (s->kind == HDA_SOLVER_FGMRES)   ? fgmres(op, M, s->kp, b->data(), x->data())
+             : (s->kind == HDA_SOLVER_BICGSTAB) ? bicgstab(op, M, s->kp, b->data(), x->data())
+                                                : pcg(op, M, s->kp, b->data(), x->data());
    if (!s->last.converged) g_hcode |= HYPRE_ERROR_CONV; // soft error, as in hypre
    HY_CATCH
 }
 extern "C" HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_solve(s, A, b, x); }
 extern "C" HYPRE_Int HYPRE_ParCSRGMRESSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_solve(s, A, b, x); }
+extern "C" HYPRE_Int HYPRE_ParCSRFlexGMRESSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_solve(s, A, b, x); }
+extern "C" HYPRE_Int HYPRE_ParCSRBiCGSTABSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x) { return krylov_solve(s, A, b, x); }
 
 #define HY_GETTER(fn, type, expr) \
    extern "C" HYPRE_Int fn(HYPRE_Solver s, type *out) { if (!s || !out) return hypre_set_error(HYPRE_ERROR_ARG, #fn ": null argument"); *out = (expr); return 0; }
@@ -898,6 +935,12 @@ HY_GETTER(HYPRE_PCGGetConverged, HYPRE_Int, s->last.converged ? 1 : 0)
 HY_GETTER(HYPRE_GMRESGetNumIterations, HYPRE_Int, s->last.iters)
 HY_GETTER(HYPRE_GMRESGetFinalRelativeResidualNorm, HYPRE_Real, s->last.final_rel)
 HY_GETTER(HYPRE_GMRESGetConverged, HYPRE_Int, s->last.converged ? 1 : 0)
+HY_GETTER(HYPRE_FlexGMRESGetNumIterations, HYPRE_Int, s->last.iters)
+HY_GETTER(HYPRE_FlexGMRESGetFinalRelativeResidualNorm, HYPRE_Real, s->last.final_rel)
+HY_GETTER(HYPRE_FlexGMRESGetConverged, HYPRE_Int, s->last.converged ? 1 : 0)
+HY_GETTER(HYPRE_BiCGSTABGetNumIterations, HYPRE_Int, s->last.iters)
+HY_GETTER(HYPRE_BiCGSTABGetFinalRelativeResidualNorm, HYPRE_Real, s->last.final_rel)
+HY_GETTER(hypre_BiCGSTABGetConverged, HYPRE_Int, s->last.converged ? 1 : 0) // internal API the reference uses (solver.c:198-202)
 
 // ------------------------------------------------------------------ BoomerAMG
 

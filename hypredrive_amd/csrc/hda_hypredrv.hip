@@ -306,7 +306,7 @@ extern "C" uint32_t HYPREDRV_Destroy(HYPREDRV_t *hp)
 {
    if (!hp || !*hp) return err_set(ERR_UNKNOWN_HYPREDRV_OBJ);
    hypredrv_struct *h = *hp;
-   if (h->solver) { (h->args.solver.method == 1) ? HYPRE_ParCSRGMRESDestroy(h->solver) : HYPRE_ParCSRPCGDestroy(h->solver); }
+   if (h->solver) HYPRE_ParCSRPCGDestroy(h->solver); // every Krylov handle is the same struct
    if (h->precon) HYPRE_BoomerAMGDestroy(h->precon);
    destroy_system(h);
    delete h;
@@ -1175,6 +1175,37 @@ extern "C" uint32_t HYPREDRV_LinearSystemComputeEigenspectrum(HYPREDRV_t h) { CH
 
 // ------------------------------------------------------------- THE HOT PATH
 
+// the reference's solver_ops table (src/internal/solver.c:204-253), indexed by the kind of the Krylov handle
+struct SolverOps {
+   HYPRE_Int (*set_precond)(HYPRE_Solver, HYPRE_PtrToSolverFcn, HYPRE_PtrToSolverFcn, HYPRE_Solver);
+   HYPRE_Int (*setup)(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector);
+   HYPRE_Int (*solve)(HYPRE_Solver, HYPRE_ParCSRMatrix, HYPRE_ParVector, HYPRE_ParVector);
+   HYPRE_Int (*destroy)(HYPRE_Solver);
+   HYPRE_Int (*get_num_iterations)(HYPRE_Solver, HYPRE_Int *);
+   HYPRE_Int (*get_converged)(HYPRE_Solver, HYPRE_Int *);
+   HYPRE_Int (*get_final_rel_res_norm)(HYPRE_Solver, HYPRE_Real *);
+};
+static const SolverOps &solver_ops(const HYPRE_Solver s)
+{
+   static const SolverOps pcg = {HYPRE_PCGSetPrecond, HYPRE_ParCSRPCGSetup, HYPRE_ParCSRPCGSolve, HYPRE_ParCSRPCGDestroy,
+                                 HYPRE_PCGGetNumIterations, HYPRE_PCGGetConverged, HYPRE_PCGGetFinalRelativeResidualNorm};
+   static const SolverOps gmres = {HYPRE_GMRESSetPrecond, HYPRE_ParCSRGMRESSetup, HYPRE_ParCSRGMRESSolve, HYPRE_ParCSRGMRESDestroy,
+                                   HYPRE_GMRESGetNumIterations, HYPRE_GMRESGetConverged, HYPRE_GMRESGetFinalRelativeResidualNorm};
+   static const SolverOps fgmres = {HYPRE_FlexGMRESSetPrecond, HYPRE_ParCSRFlexGMRESSetup, HYPRE_ParCSRFlexGMRESSolve,
+                                    HYPRE_ParCSRFlexGMRESDestroy, HYPRE_FlexGMRESGetNumIterations, HYPRE_FlexGMRESGetConverged,
+                                    HYPRE_FlexGMRESGetFinalRelativeResidualNorm};
+   static const SolverOps bicgstab = {HYPRE_BiCGSTABSetPrecond, HYPRE_ParCSRBiCGSTABSetup, HYPRE_ParCSRBiCGSTABSolve,
+                                      HYPRE_ParCSRBiCGSTABDestroy, HYPRE_BiCGSTABGetNumIterations, hypre_BiCGSTABGetConverged,
+                                      HYPRE_BiCGSTABGetFinalRelativeResidualNorm};
+   switch (s->kind)
+   {
+      case HDA_SOLVER_GMRES: return gmres;
+      case HDA_SOLVER_FGMRES: return fgmres;
+      case HDA_SOLVER_BICGSTAB: return bicgstab;
+      default: return pcg;
+   }
+}
+
 // reference src/internal/solver.c:268-311: the Krylov setup calls back here; the "prec"
 // timer brackets exactly the AMG setup
 static HYPRE_Int PreconSetupDispatch(HYPRE_Solver cookie, HYPRE_Matrix A, HYPRE_Vector b, HYPRE_Vector x)
@@ -1325,7 +1356,7 @@ extern "C" uint32_t HYPREDRV_LinearSolverCreate(HYPREDRV_t h)
    {
       if (HYPREDRV_PreconCreate(h)) return g_err;
    }
-   if (h->solver) { (h->solver->kind == HDA_SOLVER_GMRES) ? HYPRE_ParCSRGMRESDestroy(h->solver) : HYPRE_ParCSRPCGDestroy(h->solver); h->solver = nullptr; }
+   if (h->solver) { solver_ops(h->solver).destroy(h->solver); h->solver = nullptr; }
    const KrylovArgs &k = h->args.solver;
    if (k.method == 0)
    {
@@ -1356,8 +1387,31 @@ extern "C" uint32_t HYPREDRV_LinearSolverCreate(HYPREDRV_t h)
       HYPRE_GMRESSetAbsoluteTol(h->solver, k.absolute_tol);
       HYPRE_GMRESSetConvergenceFactorTol(h->solver, k.conv_fac_tol);
    }
+   else if (k.method == 2)
+   { // hypredrv_FGMRESCreate (reference src/internal/fgmres.c:36-48)
+      HYPRE_ParCSRFlexGMRESCreate(h->comm, &h->solver);
+      HYPRE_FlexGMRESSetMinIter(h->solver, k.min_iter);
+      HYPRE_FlexGMRESSetMaxIter(h->solver, k.max_iter);
+      HYPRE_FlexGMRESSetKDim(h->solver, k.krylov_dim);
+      HYPRE_FlexGMRESSetLogging(h->solver, k.logging);
+      HYPRE_FlexGMRESSetPrintLevel(h->solver, k.print_level);
+      HYPRE_FlexGMRESSetTol(h->solver, k.relative_tol);
+      HYPRE_FlexGMRESSetAbsoluteTol(h->solver, k.absolute_tol);
+   }
+   else if (k.method == 3)
+   { // hypredrv_BiCGSTABCreate (reference src/internal/bicgstab.c:41-55)
+      HYPRE_ParCSRBiCGSTABCreate(h->comm, &h->solver);
+      HYPRE_BiCGSTABSetMinIter(h->solver, k.min_iter);
+      HYPRE_BiCGSTABSetMaxIter(h->solver, k.max_iter);
+      HYPRE_BiCGSTABSetStopCrit(h->solver, k.stop_crit);
+      HYPRE_BiCGSTABSetLogging(h->solver, k.logging);
+      HYPRE_BiCGSTABSetPrintLevel(h->solver, k.print_level);
+      HYPRE_BiCGSTABSetTol(h->solver, k.relative_tol);
+      HYPRE_BiCGSTABSetAbsoluteTol(h->solver, k.absolute_tol);
+      HYPRE_BiCGSTABSetConvergenceFactorTol(h->solver, k.conv_fac_tol);
+   }
    else
-      return err_set(ERR_INVALID_SOLVER | HYPREDRV_ERROR_UNSUPPORTED_AMD, "only PCG and GMRES are implemented on MI355X (fgmres/bicgstab are not)");
+      return err_set(ERR_INVALID_SOLVER, "unknown solver method");
    consume_hypre_errors();
    API_CATCH
 }
@@ -1391,15 +1445,9 @@ extern "C" uint32_t HYPREDRV_LinearSolverSetup(HYPREDRV_t h)
    }
    HYPRE_Matrix M = h->mat_M ? h->mat_M : h->mat_A;
    const auto t0  = clk::now();
-   if (h->precon)
-   {
-      if (h->solver->kind == HDA_SOLVER_GMRES)
-         HYPRE_GMRESSetPrecond(h->solver, PreconSolveDispatch, PreconSetupDispatch, (HYPRE_Solver)(void *)&h->cookie);
-      else
-         HYPRE_PCGSetPrecond(h->solver, PreconSolveDispatch, PreconSetupDispatch, (HYPRE_Solver)(void *)&h->cookie);
-   }
-   if (h->solver->kind == HDA_SOLVER_GMRES) HYPRE_ParCSRGMRESSetup(h->solver, M, h->vec_b, h->vec_x);
-   else HYPRE_ParCSRPCGSetup(h->solver, M, h->vec_b, h->vec_x);
+   const SolverOps &ops = solver_ops(h->solver);
+   if (h->precon) ops.set_precond(h->solver, PreconSolveDispatch, PreconSetupDispatch, (HYPRE_Solver)(void *)&h->cookie);
+   ops.setup(h->solver, M, h->vec_b, h->vec_x);
    h->last_setup_s = std::chrono::duration<double>(clk::now() - t0).count();
    consume_hypre_errors();
    API_CATCH
@@ -1429,24 +1477,14 @@ extern "C" uint32_t HYPREDRV_LinearSolverApply(HYPREDRV_t h)
    const double r0 = residual_norm(h); // untimed (solver.c:666)
    annotate(h, "solve", true);
    h->stats.cur().r0 = r0;
-   HYPRE_Int ierr;
-   if (h->solver->kind == HDA_SOLVER_GMRES) ierr = HYPRE_ParCSRGMRESSolve(h->solver, h->mat_A, h->vec_b, h->vec_x);
-   else ierr = HYPRE_ParCSRPCGSolve(h->solver, h->mat_A, h->vec_b, h->vec_x);
+   const SolverOps &ops  = solver_ops(h->solver);
+   const HYPRE_Int  ierr = ops.solve(h->solver, h->mat_A, h->vec_b, h->vec_x);
    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
    HYPRE_Int  iters = 0, conv = 0;
    HYPRE_Real frel  = 0.0;
-   if (h->solver->kind == HDA_SOLVER_GMRES)
-   {
-      HYPRE_GMRESGetNumIterations(h->solver, &iters);
-      HYPRE_GMRESGetConverged(h->solver, &conv);
-      HYPRE_GMRESGetFinalRelativeResidualNorm(h->solver, &frel);
-   }
-   else
-   {
-      HYPRE_PCGGetNumIterations(h->solver, &iters);
-      HYPRE_PCGGetConverged(h->solver, &conv);
-      HYPRE_PCGGetFinalRelativeResidualNorm(h->solver, &frel);
-   }
+   ops.get_num_iterations(h->solver, &iters);
+   ops.get_converged(h->solver, &conv);
+   ops.get_final_rel_res_norm(h->solver, &frel);
    h->stats.cur().iters     = ierr ? 0 : iters;
    h->stats.cur().has_solve = true;
    annotate(h, "solve", false);
@@ -1489,7 +1527,7 @@ extern "C" uint32_t HYPREDRV_LinearSolverDestroy(HYPREDRV_t h)
 {
    CHECK_INIT_OBJ(h);
    err_reset();
-   if (h->solver) { (h->solver->kind == HDA_SOLVER_GMRES) ? HYPRE_ParCSRGMRESDestroy(h->solver) : HYPRE_ParCSRPCGDestroy(h->solver); }
+   if (h->solver) solver_ops(h->solver).destroy(h->solver);
    h->solver = nullptr;
    // library mode destroys the preconditioner together with the solver (src/HYPREDRV.c:3463-3496)
    if (h->precon) HYPRE_BoomerAMGDestroy(h->precon);

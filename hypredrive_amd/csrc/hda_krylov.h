@@ -52,6 +52,9 @@ struct LinOp {
 KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
 // hypre_GMRESSolve (solver_ops[SOLVER_GMRES], src/internal/solver.c:217-228)
 KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
+// hypre_FlexGMRESSolve (solver_ops[SOLVER_FGMRES], solver.c:229-240) and hypre_BiCGSTABSolve (solver.c:241-252)
+KrylovResult fgmres(const LinOp &op, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
+KrylovResult bicgstab(const LinOp &op, const PrecondFn &M, const KrylovParams &p, const double *b, double *x);
 
 // algorithmic HBM bytes of one PCG iteration excluding the preconditioner
 int    last_precond_calls(); // preconditioner applications enqueued by the last pcg() call

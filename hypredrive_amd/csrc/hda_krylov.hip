@@ -164,7 +164,7 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
    return res;
 }
 
-KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
+static KrylovResult gmres_core(bool flexible, const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
 {
    Context     &ctx = Context::get();
    const DCsr  &A   = *op.A;
@@ -175,6 +175,9 @@ KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, 
    std::vector<DArray<double>> V((size_t)k + 1);
    for (auto &v : V) v.alloc(vlen);
    DArray<double> w(vlen), r(vlen);
+   // FlexGMRES keeps the preconditioned directions z_j = M^-1 v_j and updates x with them
+   std::vector<DArray<double>> Z(flexible ? (size_t)k : 0);
+   for (auto &z : Z) z.alloc(vlen);
    auto refresh = [&](double *v) { if (op.halo) halo_exchange(*op.halo, v); };
    auto true_residual = [&](double *out) { // out = b - A x, x staged through w for its ghost tail
       copy(n, x, w.data());
@@ -221,9 +224,10 @@ KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, 
       {
          i++;
          iter++;
-         precond(V[i - 1].data(), r.data());
-         refresh(r.data());
-         spmv(A, 1.0, r.data(), 0.0, nullptr, V[i].data());
+         double *zi = flexible ? Z[(size_t)i - 1].data() : r.data();
+         precond(V[i - 1].data(), zi);
+         refresh(zi);
+         spmv(A, 1.0, zi, 0.0, nullptr, V[i].data());
          // modified Gram-Schmidt with the coefficients kept on the device
          for (int j = 0; j < i; j++)
          {
@@ -264,11 +268,16 @@ KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, 
          for (int j = q + 1; j < i; j++) tt -= H[(size_t)q * k + j] * rs[j];
          rs[q] = tt / H[(size_t)q * k + q];
       }
-      copy(n, V[i - 1].data(), w.data());
-      scale(n, rs[i - 1], w.data());
-      for (int j = i - 2; j >= 0; j--) axpy(n, rs[j], V[j].data(), w.data());
-      precond(w.data(), r.data());
-      axpy(n, 1.0, r.data(), x);
+      if (flexible)
+         for (int j = i - 1; j >= 0; j--) axpy(n, rs[j], Z[(size_t)j].data(), x);
+      else
+      {
+         copy(n, V[i - 1].data(), w.data());
+         scale(n, rs[i - 1], w.data());
+         for (int j = i - 2; j >= 0; j--) axpy(n, rs[j], V[j].data(), w.data());
+         precond(w.data(), r.data());
+         axpy(n, 1.0, r.data(), x);
+      }
       true_residual(V[0].data());
       const double true_norm = norm2(V[0].data());
       if (r_norm <= epsilon)
@@ -280,6 +289,98 @@ KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, 
          r_norm = true_norm;
    }
    ctx.sync();
+   res.iters     = iter;
+   res.final_rel = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
+   return res;
+}
+
+KrylovResult gmres(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
+{
+   return gmres_core(false, op, M, kp, b, x);
+}
+KrylovResult fgmres(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
+{
+   return gmres_core(true, op, M, kp, b, x);
+}
+
+// Right-preconditioned BiCGSTAB (van der Vorst 1992) with r0* = r0, stopping on
+// ||r|| <= max(atol, rtol ||b||) and accepting only after the true residual has been recomputed.
+// The four inner products of an iteration come back to the host (the recurrence needs their quotients
+// before the next kernel can be parameterised); everything else stays on the device.
+KrylovResult bicgstab(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
+{
+   const DCsr  &A = *op.A;
+   const int    n = A.nrows;
+   KrylovResult res;
+   const size_t vlen = std::max<size_t>(op.veclen, 1);
+   DArray<double> r0(vlen), r(vlen), p(vlen), v(vlen), q(vlen), s(vlen), w(vlen);
+   auto refresh = [&](double *y) { if (op.halo) halo_exchange(*op.halo, y); };
+   auto true_residual = [&](double *out) {
+      copy(n, x, w.data());
+      refresh(w.data());
+      residual(A, w.data(), b, out);
+   };
+   auto precond = [&](const double *rr, double *zz) {
+      if (M) M(rr, zz, -1);
+      else copy(n, rr, zz);
+   };
+   auto inner = [&](const double *a, const double *c) {
+      dot(n, a, c, 0);
+      finalize(0, S_TMP);
+      return read_scalar(S_TMP);
+   };
+   true_residual(r0.data());
+   copy(n, r0.data(), r.data());
+   copy(n, r0.data(), p.data());
+   const double b_norm = std::sqrt(inner(b, b));
+   double       rho    = inner(r0.data(), r0.data());
+   double       r_norm = std::sqrt(rho);
+   const double den    = (b_norm > 0.0) ? b_norm : r_norm;
+   const double eps    = std::max(kp.atol, kp.rtol * den);
+   res.hist.push_back(r_norm);
+   int iter = 0;
+   if (r_norm == 0.0)
+   {
+      res.converged = true;
+      return res;
+   }
+   while (iter < kp.max_iter)
+   {
+      iter++;
+      precond(p.data(), v.data());
+      refresh(v.data());
+      spmv(A, 1.0, v.data(), 0.0, nullptr, q.data());
+      const double temp = inner(r0.data(), q.data());
+      if (temp == 0.0) break; // breakdown
+      const double alpha = rho / temp;
+      axpy(n, alpha, v.data(), x);
+      axpy(n, -alpha, q.data(), r.data());
+      precond(r.data(), v.data());
+      refresh(v.data());
+      spmv(A, 1.0, v.data(), 0.0, nullptr, s.data());
+      const double gn = inner(r.data(), s.data()), gd = inner(s.data(), s.data());
+      const double gamma = (gn == 0.0 && gd == 0.0) ? 0.0 : gn / gd;
+      axpy(n, gamma, v.data(), x);
+      axpy(n, -gamma, s.data(), r.data());
+      r_norm = std::sqrt(inner(r.data(), r.data()));
+      res.hist.push_back(r_norm);
+      if (kp.print_level >= 2) printf("%5d    %e    %e\n", iter, r_norm, r_norm / den);
+      if (r_norm <= eps && iter >= kp.min_iter)
+      {
+         true_residual(r.data());
+         r_norm = std::sqrt(inner(r.data(), r.data()));
+         if (r_norm <= eps) { res.converged = true; break; }
+      }
+      if (rho == 0.0 || gamma == 0.0) break; // breakdown
+      double beta = 1.0 / rho;
+      rho         = inner(r0.data(), r.data());
+      beta *= rho;
+      // p = r + beta (alpha / gamma) (p - gamma q)
+      axpy(n, -gamma, q.data(), p.data());
+      scale(n, beta * alpha / gamma, p.data());
+      axpy(n, 1.0, r.data(), p.data());
+   }
+   Context::get().sync();
    res.iters     = iter;
    res.final_rel = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
    return res;

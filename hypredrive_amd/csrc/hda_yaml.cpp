@@ -616,7 +616,12 @@ uint32_t args_from_yaml(YNode &root, bool lib_mode, InputArgs &args, std::string
       }
       else if (sec->key == "include")
          c.fail(ERR_INVALID_KEY, "'include' expansion is not supported by this build");
-      else c.fail(ERR_INVALID_KEY, "unknown root section '" + sec->key + "'");
+      else
+      { // the reference only looks its root sections up by name (args.c:235,261,300,982): anything else is left
+        // unvisited and tolerated (its echo marks it "INVALID ENTRY"), e.g. the stray top-level 'ilu:' block of
+        // examples/ex1b.yml.  Same here: ignored, with a note on stderr.
+         fprintf(stderr, "hypredrive (MI355X): ignoring unknown root section '%s'\n", sec->key.c_str());
+      }
    }
    if (!has_precon) c.fail(ERR_MISSING_PRECON, "missing 'preconditioner' section"); // reference args.c:981-989
    if (args.precon_variants.empty()) args.precon_variants.push_back(PreconArgs());

@@ -128,6 +128,11 @@ int hda_pcg(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const doubl
             double *hist, int *iters, int *converged, double *final_rel);
 int hda_gmres(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
               double *hist, int *iters, int *converged, double *final_rel);
+/* hypre_FlexGMRESSolve / hypre_BiCGSTABSolve (solver_ops[SOLVER_FGMRES / SOLVER_BICGSTAB], src/internal/solver.c:229-252) */
+int hda_fgmres(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
+              double *hist, int *iters, int *converged, double *final_rel);
+int hda_bicgstab(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, const double *b, double *x,
+              double *hist, int *iters, int *converged, double *final_rel);
 
 /* ---- measurement (bench.py) -------------------------------------------------------- */
 /* Times `reps` launches of one kernel with HIP events on the library's stream, vectors

@@ -1521,13 +1521,20 @@ orc_pcg(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double 
 /* hypre_GMRESSolve (right preconditioning, restart k, modified Gram-Schmidt, Givens),
  * reached through solver_ops[SOLVER_GMRES] src/internal/solver.c:217-228 with args
  * src/internal/gmres.c:16-27; SURVEY App. A.8. */
-int
-orc_gmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b, double *x,
-          double *resid_hist, int *converged, double *final_rel)
+static int
+gmres_core(int flexible, const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b, double *x,
+           double *resid_hist, int *converged, double *final_rel)
 {
    int      n = A->nrows, k = kp->krylov_dim, iter = 0;
    double **V  = (double **)malloc(sizeof(double *) * (size_t)(k + 1));
    for (int i = 0; i <= k; i++) V[i] = (double *)malloc(sizeof(double) * (size_t)n);
+   /* FlexGMRES keeps the preconditioned directions z_j = M^-1 v_j and updates x with them */
+   double **Z = NULL;
+   if (flexible)
+   {
+      Z = (double **)malloc(sizeof(double *) * (size_t)k);
+      for (int i = 0; i < k; i++) Z[i] = (double *)malloc(sizeof(double) * (size_t)n);
+   }
    double *w  = (double *)malloc(sizeof(double) * (size_t)n);
    double *r  = (double *)malloc(sizeof(double) * (size_t)n);
    double *H  = (double *)calloc((size_t)(k + 1) * (size_t)k, sizeof(double)); /* H[i*k + j] */
@@ -1569,8 +1576,9 @@ orc_gmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const doubl
       {
          i++;
          iter++;
-         apply_precond(A, h, V[i - 1], r);
-         orc_spmv(A, 1.0, r, 0.0, V[i]);
+         double *zi = flexible ? Z[i - 1] : r;
+         apply_precond(A, h, V[i - 1], zi);
+         orc_spmv(A, 1.0, zi, 0.0, V[i]);
          for (int j = 0; j < i; j++)
          {
             double hji         = orc_dot(n, V[j], V[i]);
@@ -1610,11 +1618,19 @@ orc_gmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const doubl
          for (int j = q + 1; j < i; j++) tt -= H[q * k + j] * rs[j];
          rs[q] = tt / H[q * k + q];
       }
-      for (int q = 0; q < n; q++) w[q] = rs[i - 1] * V[i - 1][q];
-      for (int j = i - 2; j >= 0; j--)
-         for (int q = 0; q < n; q++) w[q] += rs[j] * V[j][q];
-      apply_precond(A, h, w, r);
-      for (int q = 0; q < n; q++) x[q] += r[q];
+      if (flexible)
+      {
+         for (int j = i - 1; j >= 0; j--)
+            for (int q = 0; q < n; q++) x[q] += rs[j] * Z[j][q];
+      }
+      else
+      {
+         for (int q = 0; q < n; q++) w[q] = rs[i - 1] * V[i - 1][q];
+         for (int j = i - 2; j >= 0; j--)
+            for (int q = 0; q < n; q++) w[q] += rs[j] * V[j][q];
+         apply_precond(A, h, w, r);
+         for (int q = 0; q < n; q++) x[q] += r[q];
+      }
       /* restart residual */
       memcpy(V[0], b, sizeof(double) * (size_t)n);
       orc_spmv(A, -1.0, x, 1.0, V[0]);
@@ -1630,6 +1646,93 @@ orc_gmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const doubl
    *final_rel = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
 done:
    for (int i = 0; i <= k; i++) free(V[i]);
+   if (Z)
+   {
+      for (int i = 0; i < k; i++) free(Z[i]);
+      free(Z);
+   }
    free(V); free(w); free(r); free(H); free(cs); free(sn); free(rs);
+   return iter;
+}
+
+int
+orc_gmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b, double *x,
+          double *resid_hist, int *converged, double *final_rel)
+{
+   return gmres_core(0, A, h, kp, b, x, resid_hist, converged, final_rel);
+}
+
+/* hypre_FlexGMRESSolve (solver_ops[SOLVER_FGMRES], src/internal/solver.c:229-240; args fgmres.c:15-22) */
+int
+orc_fgmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b, double *x,
+           double *resid_hist, int *converged, double *final_rel)
+{
+   return gmres_core(1, A, h, kp, b, x, resid_hist, converged, final_rel);
+}
+
+/* hypre_BiCGSTABSolve (solver_ops[SOLVER_BICGSTAB], src/internal/solver.c:241-252; args bicgstab.c:15-23):
+ * right-preconditioned BiCGSTAB (van der Vorst 1992), r0* = r0, stop on ||r|| <= max(atol, rtol ||b||) with
+ * the true residual recomputed before accepting.  PARITY UNPINNED: no reference output uses it. */
+int
+orc_bicgstab(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b, double *x,
+             double *resid_hist, int *converged, double *final_rel)
+{
+   int     n  = A->nrows, iter = 0;
+   double *r0 = (double *)malloc(sizeof(double) * (size_t)n), *r = (double *)malloc(sizeof(double) * (size_t)n);
+   double *p  = (double *)malloc(sizeof(double) * (size_t)n), *v = (double *)malloc(sizeof(double) * (size_t)n);
+   double *q  = (double *)malloc(sizeof(double) * (size_t)n), *s = (double *)malloc(sizeof(double) * (size_t)n);
+   *converged = 0;
+   memcpy(r0, b, sizeof(double) * (size_t)n);
+   orc_spmv(A, -1.0, x, 1.0, r0);
+   memcpy(r, r0, sizeof(double) * (size_t)n);
+   memcpy(p, r0, sizeof(double) * (size_t)n);
+   double b_norm = sqrt(orc_dot(n, b, b));
+   double res    = orc_dot(n, r0, r0);
+   double r_norm = sqrt(res);
+   double den    = (b_norm > 0.0) ? b_norm : r_norm;
+   double eps    = kp->rtol * den;
+   if (kp->atol > eps) eps = kp->atol;
+   if (resid_hist) resid_hist[0] = r_norm;
+   if (r_norm == 0.0)
+   {
+      *converged = 1;
+      *final_rel = 0.0;
+      goto done;
+   }
+   while (iter < kp->max_iter)
+   {
+      iter++;
+      apply_precond(A, h, p, v);
+      orc_spmv(A, 1.0, v, 0.0, q);
+      double temp = orc_dot(n, r0, q);
+      if (temp == 0.0) break; /* breakdown */
+      double alpha = res / temp;
+      for (int i = 0; i < n; i++) x[i] += alpha * v[i];
+      for (int i = 0; i < n; i++) r[i] -= alpha * q[i];
+      apply_precond(A, h, r, v);
+      orc_spmv(A, 1.0, v, 0.0, s);
+      double gn = orc_dot(n, r, s), gd = orc_dot(n, s, s);
+      double gamma = (gn == 0.0 && gd == 0.0) ? 0.0 : gn / gd;
+      for (int i = 0; i < n; i++) x[i] += gamma * v[i];
+      for (int i = 0; i < n; i++) r[i] -= gamma * s[i];
+      r_norm = sqrt(orc_dot(n, r, r));
+      if (resid_hist) resid_hist[iter] = r_norm;
+      if (r_norm <= eps)
+      { /* accept only on the true residual */
+         memcpy(r, b, sizeof(double) * (size_t)n);
+         orc_spmv(A, -1.0, x, 1.0, r);
+         r_norm = sqrt(orc_dot(n, r, r));
+         if (r_norm <= eps) { *converged = 1; break; }
+      }
+      if (res == 0.0 || gamma == 0.0) break; /* breakdown */
+      double beta = 1.0 / res;
+      res         = orc_dot(n, r0, r);
+      beta *= res;
+      double c = beta * alpha / gamma;
+      for (int i = 0; i < n; i++) p[i] = r[i] + c * (p[i] - gamma * q[i]);
+   }
+   *final_rel = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
+done:
+   free(r0); free(r); free(p); free(v); free(q); free(s);
    return iter;
 }

@@ -139,6 +139,11 @@ int orc_pcg(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const dou
             double *x, double *resid_hist, int *converged, double *final_rel);
 int orc_gmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b,
               double *x, double *resid_hist, int *converged, double *final_rel);
+/* hypre_FlexGMRESSolve / hypre_BiCGSTABSolve restatements (solver.c:229-252); parity unpinned */
+int orc_fgmres(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b,
+               double *x, double *resid_hist, int *converged, double *final_rel);
+int orc_bicgstab(const orc_csr *A, orc_amg *h, const orc_krylov_params *kp, const double *b,
+                 double *x, double *resid_hist, int *converged, double *final_rel);
 
 /* Dense no-pivot Gaussian elimination (hypre relax type 9). a is n*n row-major, destroyed. */
 int orc_gselim(double *a, double *x, int n);

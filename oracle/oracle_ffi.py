@@ -105,7 +105,7 @@ def lib():
     L.orc_amg_grid_complexity.restype = C.c_double
     L.orc_amg_grid_complexity.argtypes = [C.c_void_p]
     L.orc_amg_vcycle.argtypes = [C.c_void_p, dp, dp]
-    for f in (L.orc_pcg, L.orc_gmres):
+    for f in (L.orc_pcg, L.orc_gmres, L.orc_fgmres, L.orc_bicgstab):
         f.restype = C.c_int
         f.argtypes = [cp, C.c_void_p, P(KrylovParams), dp, dp, dp, ip, dp]
     L.orc_gselim.argtypes = [dp, dp, C.c_int]
@@ -409,3 +409,11 @@ def pcg(A, b, amg=None, kp=None, x0=None):
 
 def gmres(A, b, amg=None, kp=None, x0=None):
     return _krylov(lib().orc_gmres, A, b, amg, kp or krylov_params(True), x0)
+
+
+def fgmres(A, b, amg=None, kp=None, x0=None):
+    return _krylov(lib().orc_fgmres, A, b, amg, kp or krylov_params(True), x0)
+
+
+def bicgstab(A, b, amg=None, kp=None, x0=None):
+    return _krylov(lib().orc_bicgstab, A, b, amg, kp or krylov_params(False), x0)

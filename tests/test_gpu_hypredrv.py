@@ -136,7 +136,7 @@ def test_cli_runs_ex1_unchanged(orc, pins):
 
 @pytest.mark.parametrize("cfg", ["examples/ex1-preset.yml", "examples/ex1-gmres.yml", "examples/ex2-gpu.yml", "examples/ex1-jacobi.yml",
                                  "examples/ex1-gs.yml", "examples/ex2-hl1gs.yml", "examples/ex1-cpudefaults.yml",
-                                 "examples/ex1b-gmres-ilu.yml", "examples/ex8-ilu-smoother.yml"])
+                                 "examples/ex1b-gmres-ilu.yml", "examples/ex8-ilu-smoother.yml", "examples/ex1a.yml", "examples/ex1b.yml"])
 def test_cli_other_examples(cfg):
     cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
     r = subprocess.run([cli, "-q", cfg], capture_output=True, text=True, cwd=ROOT)
@@ -612,3 +612,17 @@ def test_row_partitioned_ilu_is_block_jacobi(hd, orc, tmp_path, world, kind):
         ref = orc.pcg(Ao, np.ones(n), ao)
     assert res["converged"] and res["iters"] == ref["iters"]
     assert res["norm"] == pytest.approx(np.linalg.norm(ref["x"]), rel=1e-7)
+
+
+@pytest.mark.parametrize("solver,precon", [("bicgstab", "amg"), ("bicgstab", "ilu"), ("fgmres", "amg")])
+def test_yaml_bicgstab_and_fgmres(hd, orc, solver, precon):
+    """examples/ex1a.yml (bicgstab + amg) and ex1b.yml (bicgstab + ilu) of the reference select these by name."""
+    Ao, b = orc.lap7(12, 12, 12)
+    po = orc.Amg(Ao, orc.amg_params(True)) if precon == "amg" else orc.IluPrecond(Ao)
+    ref = (orc.bicgstab if solver == "bicgstab" else orc.fgmres)(Ao, b, po)
+    h = hd.Hypredrv(f"solver: {solver}\npreconditioner: {precon}\n")
+    h.set_laplacian7((12, 12, 12))
+    r = h.solve()
+    assert r["converged"] and r["iters"] == ref["iters"]
+    assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-7
+    h.close()

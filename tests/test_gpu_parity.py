@@ -686,3 +686,23 @@ def test_ilu_errors_are_loud(hd):
     Z = sp.csr_matrix(np.array([[1.0, 1.0], [1.0, 1.0]]))  # second pivot 1 - 1*1 = 0
     with pytest.raises(hd.LibraryError, match="pivot"):
         hd.Ilu(hd.Csr.from_scipy(Z))
+
+
+@pytest.mark.parametrize("precond", ["amg", "ilu", None])
+def test_fgmres_and_bicgstab_match_oracle(orc, hd, precond):
+    """solver_ops[SOLVER_FGMRES / SOLVER_BICGSTAB] (reference src/internal/solver.c:229-252): same iteration counts and
+    residual histories as the oracle's restatements."""
+    Ao, b = orc.lap7(13, 12, 11, b_mode=1)
+    Ah = hd.lap7(13, 12, 11)
+    po = {"amg": lambda: orc.Amg(Ao, orc.amg_params(True)), "ilu": lambda: orc.IluPrecond(Ao), None: lambda: None}[precond]()
+    ph = {"amg": lambda: hd.Amg(Ah), "ilu": lambda: hd.Ilu(Ah), None: lambda: None}[precond]()
+    ko, kh = orc.krylov_params(True, rtol=1e-9, krylov_dim=7), hd.KrylovParams.default(True, rtol=1e-9, krylov_dim=7)
+    ro, rh = orc.fgmres(Ao, b, po, ko), hd.fgmres(Ah, b, ph, kh)   # krylov_dim 7: restarts included
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-7)
+    assert rel(rh["x"], ro["x"]) < 1e-8
+    ko, kh = orc.krylov_params(False, rtol=1e-9, max_iter=300), hd.KrylovParams.default(False, rtol=1e-9, max_iter=300)
+    ro, rh = orc.bicgstab(Ao, b, po, ko), hd.bicgstab(Ah, b, ph, kh)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-5 if precond is None else 1e-7)  # BiCGSTAB amplifies rounding over many steps
+    assert rel(rh["x"], ro["x"]) < 1e-7

@@ -122,10 +122,15 @@ def test_lifecycle_guards_and_error_bits(hd):
     L.HYPREDRV_ErrorCodeClear()
     assert L.HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, 4, 0) & hd.ERROR_INVALID_VAL
     L.HYPREDRV_ErrorCodeClear()
-    # unsupported solver / preconditioner selections fail at Create, loudly
-    h2 = hd.Hypredrv("solver: bicgstab\npreconditioner: amg\n")
-    assert L.HYPREDRV_LinearSolverCreate(h2.h) & (hd.ERROR_INVALID_SOLVER | hd.ERROR_HYPRE_INTERNAL)
+    # all four Krylov methods of solver.c:204-253 are created from their YAML blocks; unknown names fail at parse time
+    for name in ("pcg", "gmres", "fgmres", "bicgstab"):
+        h2 = hd.Hypredrv(f"solver:\n  {name}:\n    max_iter: 50\n    relative_tol: 1.0e-8\npreconditioner: amg\n")
+        assert L.HYPREDRV_LinearSolverCreate(h2.h) == 0, name
+        assert L.HYPREDRV_LinearSolverDestroy(h2.h) == 0
+    with pytest.raises(hd.HypredrvError):
+        hd.Hypredrv("solver: cgs\npreconditioner: amg\n")
     L.HYPREDRV_ErrorCodeClear()
+    # unsupported preconditioner selections fail at Create, loudly
     h3 = hd.Hypredrv("solver: pcg\npreconditioner: mgr\n")
     assert L.HYPREDRV_PreconCreate(h3.h) & hd.ERROR_INVALID_PRECON
     L.HYPREDRV_ErrorCodeClear()

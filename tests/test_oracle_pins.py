@@ -277,3 +277,21 @@ def test_ilu_rejects_missing_diagonal(orc):
     M.eliminate_zeros()
     with pytest.raises(ValueError):
         orc.Ilu(orc.Csr.from_scipy(M))
+
+
+def test_fgmres_and_bicgstab_restatements(orc):
+    """FlexGMRES = GMRES in exact arithmetic for a fixed preconditioner; BiCGSTAB converges to the same solution
+    and, unpreconditioned on an SPD matrix, needs about half of CG's iterations (two products each)."""
+    A, b = orc.lap7(10, 10, 10, b_mode=1)
+    S = A.to_scipy()
+    amg = orc.Amg(A, orc.amg_params(True))
+    g, f = orc.gmres(A, b, amg), orc.fgmres(A, b, amg)
+    assert f["converged"] and f["iters"] == g["iters"] and np.allclose(f["hist"], g["hist"], rtol=1e-9)
+    kp = orc.krylov_params(False, max_iter=400, rtol=1e-8)
+    bs = orc.bicgstab(A, b, None, kp)
+    cg = orc.pcg(A, b, None, kp)
+    assert bs["converged"] and 0.3 * cg["iters"] <= bs["iters"] <= cg["iters"]
+    assert np.linalg.norm(b - S @ bs["x"]) / np.linalg.norm(b) <= 1e-8
+    ba = orc.bicgstab(A, b, amg)
+    assert ba["converged"] and ba["iters"] < orc.pcg(A, b, amg)["iters"]
+    assert orc.bicgstab(A, np.zeros(A.nrows))["iters"] == 0
