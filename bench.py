@@ -30,6 +30,19 @@ def spmv_bytes(nrows, ncols, nnz):
     return 12.0 * nnz + 4.0 * (nrows + 1) + 8.0 * ncols + 8.0 * nrows
 
 
+def find_hypre():
+    """BASELINE.md's second CPU number needs a hypre installation on the box: look where one would be (no network,
+    nothing is installed by this script).  Returns the include directory or None."""
+    import glob
+    roots = [os.environ.get(k) for k in ("HYPRE_ROOT", "HYPRE_DIR", "HYPRE_HOME")]
+    roots += ["/usr", "/usr/local", "/opt/hypre", "/opt/rocm", "/opt/conda", os.path.expanduser("~/.local")]
+    roots += glob.glob("/opt/*hypre*") + glob.glob("/opt/spack/opt/spack/*/*/hypre-*")
+    for r in roots:
+        if r and os.path.exists(os.path.join(r, "include", "HYPRE.h")):
+            return os.path.join(r, "include")
+    return None
+
+
 def cpu_baseline(sample_n):
     """Time the CPU oracle (kind 'port') on a bounded sample of the same workload."""
     from oracle import oracle_ffi as o
@@ -56,7 +69,9 @@ def cpu_baseline(sample_n):
             "sample": f"lap7 {sample_n}^3 AMG-PCG solve phase (oracle/amg_oracle.c, OpenMP SpMV/Jacobi/dots on {threads} threads), "
                       f"{r['iters']} iters, median of 5 solves {med:.3f} s (min {min(times):.3f}); serial oracle setup "
                       f"{t1 - t0:.1f} s not counted",
-            "iters": r["iters"]}
+            "iters": r["iters"],
+            # a hypre install would allow the reference's own CPU path as a second baseline; none has been found on these boxes
+            "hypre_on_box": find_hypre()}
 
 
 def run_single(args):
