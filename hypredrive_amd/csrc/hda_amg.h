@@ -111,6 +111,12 @@ class Amg {
    // fully partitioned setup (distributed PMIS / ext+i / RAP; only levels below HDA_REPLICATE_ROWS are gathered)
    void setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0, const std::vector<long long> &part0,
                                const std::vector<long long> &ghost_gids0);
+   // A reused hierarchy applied to a later system of a sequence (preconditioner.reuse): hypre's
+   // BoomerAMGSolve takes level 0 from the matrix of the call, everything else from the setup.  Same here:
+   // the level-0 operator (and its halo plan) is swapped, divisors and coarse levels stay.
+   void rebind(const DCsr &A, const HaloPlan *hA);
+   // (a later matrix can land on the address of a freed one: compare the sizes seen at setup / rebind too)
+   bool bound_to(const DCsr &A) const { return A0 == &A && A.nrows == a0_dims[0] && A.ncols == a0_dims[1] && A.nnz == a0_dims[2]; }
    // length of the level-0 vectors handed to apply()/solve() (x must have this room)
    // solve-phase renumbering of the coarse levels (hda_reorder.hip); 0 = none
    void   reorder_levels();
@@ -142,6 +148,7 @@ class Amg {
    void coarse_solve(const double *f, double *u);
    const HaloPlan &level_hA(int l) const { return (l == 0 && hA0) ? *hA0 : levels[l].hA; }
    const DCsr           *A0 = nullptr;
+   int                   a0_dims[3] = {0, 0, 0}; // rows, columns, entries of the level-0 operator when it was bound
    const HaloPlan       *hA0 = nullptr;
    bool                  dist = false;
    long long             coarse_lo = 0; // first coarsest row owned by this rank

@@ -1777,6 +1777,7 @@ void Amg::build_hierarchy(const DCsr &A)
    HDA_REQUIRE(prm.relax_coarse == 9 || is_jacobi_type(prm.relax_coarse) || is_gs_type(prm.relax_coarse),
                "coarse relaxation must be Gaussian elimination (9), Jacobi or hybrid Gauss-Seidel");
    A0 = &A;
+   a0_dims[0] = A.nrows; a0_dims[1] = A.ncols; a0_dims[2] = A.nnz;
    levels.clear();
    levels.reserve((size_t)std::max(prm.max_levels, 1));
    levels.emplace_back();
@@ -1893,6 +1894,18 @@ void Amg::setup(const DCsr &A)
    Context::get().sync();
 }
 
+void Amg::rebind(const DCsr &A, const HaloPlan *hA)
+{
+   HDA_REQUIRE(A0, "rebind before setup");
+   HDA_REQUIRE(A.nrows == a0_dims[0], "a reused preconditioner needs a matrix with the same number of local rows as the one it was built for");
+   HDA_REQUIRE((size_t)std::max(A.ncols, A.nrows) <= levels[0].ext,
+               "a reused preconditioner needs a matrix whose ghost layer fits the one it was built for");
+   A0 = &A;
+   a0_dims[0] = A.nrows; a0_dims[1] = A.ncols; a0_dims[2] = A.nnz;
+   if (dist) hA0 = hA;
+   spmv_prepare(A);
+}
+
 __global__ __launch_bounds__(256) void k_cmark(int n, const int *__restrict__ cf, int *__restrict__ m)
 {
    const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1990,6 +2003,7 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
       }
    }
    A0        = &Aloc;
+   a0_dims[0] = Aloc.nrows; a0_dims[1] = Aloc.ncols; a0_dims[2] = Aloc.nnz;
    this->hA0 = &hA0_;
    coarse_lo   = parts[(size_t)L - 1][(size_t)r];
    coarse_nloc = (int)(parts[(size_t)L - 1][(size_t)r + 1] - coarse_lo);
@@ -2026,6 +2040,7 @@ void Amg::adopt_tail(Amg &parent, int first_level)
    for (size_t l = (size_t)first_level; l < parent.levels.size(); l++) levels.push_back(std::move(parent.levels[l]));
    own_A0       = std::move(levels[0].A);
    A0           = &own_A0;
+   a0_dims[0] = own_A0.nrows; a0_dims[1] = own_A0.ncols; a0_dims[2] = own_A0.nnz;
    coarse_invT  = std::move(parent.coarse_invT);
    coarse_n     = parent.coarse_n;
    coarse_dense = parent.coarse_dense;
@@ -2982,6 +2997,7 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
    };
    dist = true;
    A0   = &Aloc;
+   a0_dims[0] = Aloc.nrows; a0_dims[1] = Aloc.ncols; a0_dims[2] = Aloc.nnz;
    hA0  = &hA0_;
    levels.clear();
    levels.reserve((size_t)std::max(prm.max_levels, 1) + 1);

@@ -1107,6 +1107,7 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    HY_NEED_DEVICE;
    HY_TRY
    HDA_REQUIRE(s && s->amg, "BoomerAMGSolve before BoomerAMGSetup");
+   if (!s->amg->bound_to(A->A)) s->amg->rebind(A->A, Comm::world().size > 1 ? &A->halo : nullptr); // reused hierarchy, later system
    x->ensure_device();
    PrecondHints  &h   = precond_hints();
    const size_t   need = s->amg->vec_len0();

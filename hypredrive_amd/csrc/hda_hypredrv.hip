@@ -1175,6 +1175,25 @@ extern "C" uint32_t HYPREDRV_LinearSystemComputeEigenspectrum(HYPREDRV_t h) { CH
 
 // ------------------------------------------------------------- THE HOT PATH
 
+// hypredrv_PreconReuseShouldRebuild, static policy (reference src/internal/precon_reuse.c:774-827), and the
+// collective form of src/HYPREDRV.c:233-256: every rank takes the maximum of the local decisions
+static bool reuse_should_rebuild(hypredrv_struct *h)
+{
+   const ReuseArgs &a  = h->args.reuse;
+   const int        id = std::max(h->stats.systems_solved, 0); // = StatsGetLinearSystemID + 1
+   int              rebuild;
+   if (a.enabled && !a.linear_system_ids.empty())
+      rebuild = std::find(a.linear_system_ids.begin(), a.linear_system_ids.end(), id) != a.linear_system_ids.end() ? 1 : 0;
+   else
+   {
+      const int freq = (a.enabled && a.frequency > 0) ? a.frequency : 0;
+      rebuild        = (id % (freq + 1)) == 0 ? 1 : 0;
+   }
+   long long v[1] = {rebuild};
+   Comm::world().allreduce_host(v, 1, 1); // max
+   return v[0] != 0;
+}
+
 // the reference's solver_ops table (src/internal/solver.c:204-253), indexed by the kind of the Krylov handle
 struct SolverOps {
    HYPRE_Int (*set_precond)(HYPRE_Solver, HYPRE_PtrToSolverFcn, HYPRE_PtrToSolverFcn, HYPRE_Solver);
@@ -1311,6 +1330,8 @@ extern "C" uint32_t HYPREDRV_PreconCreate(HYPREDRV_t h)
    CHECK_INIT_OBJ(h);
    err_reset();
    API_TRY
+   // src/HYPREDRV.c:2801-2808: an existing preconditioner is recreated only when the reuse policy says so
+   if (h->precon && !reuse_should_rebuild(h)) return g_err;
    if (h->precon) { HYPRE_BoomerAMGDestroy(h->precon); h->precon = nullptr; }
    h->precon_is_setup  = false;
    const PreconArgs &p = h->args.precon();
@@ -1352,7 +1373,8 @@ extern "C" uint32_t HYPREDRV_LinearSolverCreate(HYPREDRV_t h)
    err_reset();
    API_TRY
    // LinearSolverCreate creates the preconditioner too when the caller did not (src/HYPREDRV.c:2914-2917)
-   if (!h->precon && h->args.precon().method != 99)
+   // ... and re-evaluates the reuse policy when one exists and is set up (src/HYPREDRV.c:2905-2917)
+   if ((!h->precon || h->precon_is_setup) && h->args.precon().method != 99)
    {
       if (HYPREDRV_PreconCreate(h)) return g_err;
    }
@@ -1447,7 +1469,10 @@ extern "C" uint32_t HYPREDRV_LinearSolverSetup(HYPREDRV_t h)
    const auto t0  = clk::now();
    const SolverOps &ops = solver_ops(h->solver);
    if (h->precon) ops.set_precond(h->solver, PreconSolveDispatch, PreconSetupDispatch, (HYPRE_Solver)(void *)&h->cookie);
-   ops.setup(h->solver, M, h->vec_b, h->vec_x);
+   // reuse decision (src/HYPREDRV.c:3010-3020): a preconditioner that is set up is kept unless the policy asks
+   // for a rebuild on this system; the Krylov setup has no other work, so it is skipped with it
+   const bool skip_precon_setup = h->precon && h->precon_is_setup && !reuse_should_rebuild(h);
+   if (!skip_precon_setup) ops.setup(h->solver, M, h->vec_b, h->vec_x);
    h->last_setup_s = std::chrono::duration<double>(clk::now() - t0).count();
    consume_hypre_errors();
    API_CATCH
@@ -1518,21 +1543,24 @@ extern "C" uint32_t HYPREDRV_PreconDestroy(HYPREDRV_t h)
 {
    CHECK_INIT_OBJ(h);
    err_reset();
-   if (h->precon) HYPRE_BoomerAMGDestroy(h->precon);
-   h->precon          = nullptr;
-   h->precon_is_setup = false;
-   return g_err;
+   API_TRY
+   // src/HYPREDRV.c:3403-3452: destroyed only when the next system will rebuild it, otherwise kept for reuse
+   if (h->precon && reuse_should_rebuild(h))
+   {
+      HYPRE_BoomerAMGDestroy(h->precon);
+      h->precon          = nullptr;
+      h->precon_is_setup = false;
+   }
+   API_CATCH
 }
 extern "C" uint32_t HYPREDRV_LinearSolverDestroy(HYPREDRV_t h)
 {
    CHECK_INIT_OBJ(h);
    err_reset();
+   // the preconditioner goes first, through the policy-aware PreconDestroy (src/HYPREDRV.c:3463-3496)
+   if (h->precon && HYPREDRV_PreconDestroy(h)) return g_err;
    if (h->solver) solver_ops(h->solver).destroy(h->solver);
    h->solver = nullptr;
-   // library mode destroys the preconditioner together with the solver (src/HYPREDRV.c:3463-3496)
-   if (h->precon) HYPRE_BoomerAMGDestroy(h->precon);
-   h->precon          = nullptr;
-   h->precon_is_setup = false;
    return g_err;
 }
 

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <sstream>
 
 namespace hda {
 
@@ -464,6 +465,75 @@ static const char *preset_text(const std::string &name)
    return nullptr;
 }
 
+// preconditioner.reuse: value form (always | static | adaptive) or a block with enabled / frequency /
+// linear_system_ids / per_timestep / type; same combinations rejected as in the reference
+// (precon_reuse.c:2478-2550).  The adaptive policy and per_timestep need the reference's timestep files and
+// solve-history model, which this build does not carry.
+static void parse_reuse(Ctx &c, YNode &node, ReuseArgs &r)
+{
+   r = ReuseArgs();
+   auto is_always = [](const std::string &v) { return lower(trim(v)) == "always"; };
+   auto unsupported = [&](const char *what) { c.fail(ERR_INVALID_VAL, std::string("preconditioner.reuse ") + what + " is not implemented on MI355X (static policy only)"); };
+   if (node.kids.empty())
+   {
+      const std::string v = lower(trim(node.val));
+      if (v.empty()) return;
+      if (is_always(v)) { r.enabled = 1; r.linear_system_ids = {0}; }
+      else if (v == "static") r.enabled = 1;
+      else if (v == "adaptive") unsupported("type: adaptive");
+      else c.fail(ERR_INVALID_VAL, "Invalid preconditioner.reuse value: '" + node.val + "'");
+      return;
+   }
+   bool seen_enabled = false, seen_freq = false, seen_ids = false, seen_ts = false, always = false;
+   for (auto &k : node.kids)
+   {
+      if (k->key == "enabled") { r.enabled = to_int(c, *k, &kOnOff); seen_enabled = true; }
+      else if (k->key == "frequency")
+      {
+         r.frequency = to_int(c, *k, nullptr);
+         if (r.frequency < 0) c.fail(ERR_INVALID_VAL, "Invalid value for preconditioner.reuse.frequency: '" + k->val + "'");
+         seen_freq = true;
+      }
+      else if (k->key == "linear_system_ids" || k->key == "linear_solver_ids")
+      {
+         std::string s = k->val;
+         for (auto &q : k->kids) s += " " + (q->val.empty() ? q->key : q->val); // block sequence form
+         for (char &ch : s)
+            if (ch == '[' || ch == ']' || ch == ',') ch = ' ';
+         std::istringstream is(s);
+         std::string        tok;
+         r.linear_system_ids.clear();
+         while (is >> tok)
+         {
+            char *end = nullptr;
+            long  v   = strtol(tok.c_str(), &end, 10);
+            if (!end || *end) { c.fail(ERR_INVALID_VAL, "Failed to parse preconditioner.reuse.linear_system_ids"); break; }
+            r.linear_system_ids.push_back((int)v);
+         }
+         if (r.linear_system_ids.empty()) c.fail(ERR_INVALID_VAL, "Failed to parse preconditioner.reuse.linear_system_ids");
+         seen_ids = true;
+      }
+      else if (k->key == "per_timestep") { seen_ts = to_int(c, *k, &kOnOff) != 0; }
+      else if (k->key == "type" || k->key == "policy")
+      {
+         const std::string v = lower(trim(k->val));
+         if (is_always(v)) always = true;
+         else if (v == "adaptive") unsupported("type: adaptive");
+         else if (v != "static") c.fail(ERR_INVALID_VAL, "Invalid value for preconditioner.reuse.type: '" + k->val + "'");
+      }
+      else if (k->key == "guards" || k->key == "adaptive") unsupported(("block '" + k->key + "'").c_str());
+      else c.fail(ERR_INVALID_KEY, "Unknown key under preconditioner.reuse: '" + k->key + "'");
+   }
+   if (!seen_enabled) r.enabled = 1;
+   if (seen_ts) unsupported("per_timestep");
+   if (always && !r.enabled) c.fail(ERR_INVALID_VAL, "preconditioner.reuse always cannot be combined with enabled: off");
+   if (always && (seen_freq || seen_ids || seen_ts))
+      c.fail(ERR_INVALID_VAL, "preconditioner.reuse always cannot be combined with frequency, linear_system_ids, or per_timestep");
+   if (seen_ids && (seen_freq || seen_ts)) c.fail(ERR_INVALID_VAL, "preconditioner.reuse.linear_system_ids cannot be combined with frequency or per_timestep");
+   if (always) r.linear_system_ids = {0};
+   if (!r.enabled) { r.linear_system_ids.clear(); r.frequency = 0; }
+}
+
 static void parse_precon_body(Ctx &c, YNode &node, std::vector<PreconArgs> &variants);
 
 uint32_t precon_from_text(const std::string &text, PreconArgs &out, std::string &message)
@@ -508,7 +578,7 @@ static void parse_precon_body(Ctx &c, YNode &node, std::vector<PreconArgs> &vari
 {
    for (auto &ch : node.kids)
    {
-      if (ch->key == "reuse") continue; // reuse policy: single-system runs always rebuild
+      if (ch->key == "reuse") continue; // parsed by args_from_yaml (parse_reuse)
       if (ch->key == "preset")
       {
          const char *t = preset_text(ch->val);
@@ -611,7 +681,12 @@ uint32_t args_from_yaml(YNode &root, bool lib_mode, InputArgs &args, std::string
             PreconArgs p;
             if (set_precon_method(c, p, sec->val)) args.precon_variants.push_back(p);
          }
-         else parse_precon_body(c, *sec, args.precon_variants);
+         else
+         {
+            for (auto &ch : sec->kids)
+               if (ch->key == "reuse") parse_reuse(c, *ch, args.reuse);
+            parse_precon_body(c, *sec, args.precon_variants);
+         }
          if (args.precon_variants.empty()) c.fail(ERR_MISSING_PRECON, "preconditioner section names no preconditioner");
       }
       else if (sec->key == "include")

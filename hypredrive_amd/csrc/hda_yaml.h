@@ -99,6 +99,11 @@ struct PreconArgs {
    AmgArgs     amg;
    IluArgs     ilu;
 };
+// preconditioner.reuse (reference src/internal/precon_reuse.c:2280-2567): the static policy
+struct ReuseArgs {
+   int              enabled = 0, frequency = 0;
+   std::vector<int> linear_system_ids; // rebuild exactly on these systems ("always" = {0})
+};
 struct InputArgs {
    GeneralArgs             general;
    LSArgs                  ls;
@@ -106,6 +111,7 @@ struct InputArgs {
    std::vector<PreconArgs> precon_variants; // >= 1
    int                     active_variant = 0;
    bool                    has_precon = false;
+   ReuseArgs               reuse;
    PreconArgs             &precon() { return precon_variants[(size_t)active_variant]; }
 };
 

@@ -1291,6 +1291,24 @@ orc_amg_free(orc_amg *h)
    free(h);
 }
 
+/* A hierarchy kept for a later system of a sequence (preconditioner.reuse, reference src/HYPREDRV.c:3010-3020):
+ * hypre's BoomerAMGSolve takes level 0 from the matrix of the call and everything else -- smoother divisors,
+ * transfer operators, coarse levels -- from the setup.  Returns 0 on success. */
+int
+orc_amg_rebind_level0(orc_amg *h, const orc_csr *A)
+{
+   if (h->ilu_only) { h->ilu_A = A; return 0; }
+   if (A->nrows != h->A[0]->nrows || A->ncols != h->A[0]->ncols) return 1;
+   int      nnz = A->rowptr[A->nrows];
+   orc_csr *C   = orc_csr_alloc(A->nrows, A->ncols, nnz);
+   memcpy(C->rowptr, A->rowptr, sizeof(int) * (size_t)(A->nrows + 1));
+   memcpy(C->col, A->col, sizeof(int) * (size_t)nnz);
+   memcpy(C->val, A->val, sizeof(double) * (size_t)nnz);
+   orc_csr_free(h->A[0]);
+   h->A[0] = C;
+   return 0;
+}
+
 int
 orc_amg_set_ilu_smoother(orc_amg *h, int num_levels, int num_sweeps, int nparts, const int64_t *part, int tri_solve,
                          int lower_it, int upper_it)

@@ -116,6 +116,8 @@ const double  *orc_amg_l1(const orc_amg *h, int lvl, int which); /* 0 down, 1 up
 double   orc_amg_operator_complexity(const orc_amg *h);
 double   orc_amg_grid_complexity(const orc_amg *h);
 void     orc_amg_vcycle(orc_amg *h, const double *b, double *x); /* x must hold the initial guess */
+/* preconditioner reuse: level 0 := A (same size), the rest of the hierarchy as it was set up; 0 on success */
+int      orc_amg_rebind_level0(orc_amg *h, const orc_csr *A);
 
 /* ILU(0) on the diagonal blocks of a row partition (hypre "bj-iluk", fill 0, natural order; reference
  * argument surface src/internal/ilu.c:15-28).  part = nparts+1 row starts (NULL: one block).

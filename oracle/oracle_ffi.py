@@ -109,6 +109,8 @@ def lib():
         f.restype = C.c_int
         f.argtypes = [cp, C.c_void_p, P(KrylovParams), dp, dp, dp, ip, dp]
     L.orc_gselim.argtypes = [dp, dp, C.c_int]
+    L.orc_amg_rebind_level0.restype = C.c_int
+    L.orc_amg_rebind_level0.argtypes = [C.c_void_p, cp]
     i64p = P(C.c_int64)
     L.orc_ilu0_setup.restype = C.c_void_p
     L.orc_ilu0_setup.argtypes = [cp, C.c_int, i64p, C.c_int, C.c_int, C.c_int]
@@ -330,6 +332,12 @@ class Amg:
         x = np.zeros_like(b) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).copy()
         lib().orc_amg_vcycle(self.h, _dp(b), _dp(x))
         return x
+
+    def rebind_level0(self, A):
+        """Keep the hierarchy, take level 0 from A (a later system of a sequence: preconditioner.reuse)."""
+        if lib().orc_amg_rebind_level0(self.h, A.ptr):
+            raise ValueError("rebind: size mismatch")
+        self.A = A
 
     def set_ilu_smoother(self, num_levels=1, num_sweeps=1, part=None, tri_solve=1, lower_it=5, upper_it=5):
         """amg.smoother.type ilu: ILU(0) replaces the relaxation sweeps on the first num_levels levels."""

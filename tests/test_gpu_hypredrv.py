@@ -626,3 +626,70 @@ def test_yaml_bicgstab_and_fgmres(hd, orc, solver, precon):
     assert r["converged"] and r["iters"] == ref["iters"]
     assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-7
     h.close()
+
+
+# ------------------------------------------------- preconditioner.reuse (static policy; src/HYPREDRV.c:233-256, 3010-3020)
+
+def _sequence(orc, k):
+    """k systems of a 'time stepping' sequence on one sparsity pattern: lap7 + (1 + 0.5 s) I."""
+    import scipy.sparse as sp
+    A0, b = orc.lap7(12, 11, 10)
+    S = A0.to_scipy()
+    return [(S + (0.2 + 0.6 * s) * sp.identity(S.shape[0])).tocsr() for s in range(k)], b
+
+
+@pytest.mark.parametrize("reuse,rebuild_on", [("\n    frequency: 1\n", {0, 2, 4}), (" always\n", {0}),
+                                              ("\n    linear_system_ids: [0, 3]\n", {0, 3}), ("\n    enabled: off\n", {0, 1, 2, 3, 4})])
+def test_precon_reuse_over_a_sequence_matches_oracle(hd, orc, reuse, rebuild_on):
+    """Five systems through SetMatrixFromCSR + Create/Setup/Apply/Destroy each (library flow).  On the systems the policy
+    does not rebuild, the hierarchy of the last rebuild is applied with the NEW matrix on level 0 (hypre's BoomerAMGSolve
+    semantics): iteration counts and solutions equal the oracle doing exactly that, and the setup timer shows no setup."""
+    mats, b = _sequence(orc, 5)
+    n = mats[0].shape[0]
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    print_level: 0\n  reuse:" + reuse)
+    amg_o = None
+    for s, S in enumerate(mats):
+        Ao = orc.Csr.from_scipy(S)
+        if s in rebuild_on:
+            amg_o = orc.Amg(Ao, orc.amg_params(True))
+        else:
+            amg_o.rebind_level0(Ao)
+        ref = orc.pcg(Ao, b, amg_o)
+        h.set_matrix_csr(0, n - 1, S.indptr, S.indices, S.data)
+        h.set_rhs_array(0, n - 1, b)
+        h.finish_system()
+        r = h.solve()
+        assert r["converged"] and r["iters"] == ref["iters"], (s, r["iters"], ref["iters"])
+        assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-9
+        if s in rebuild_on:
+            assert r["setup_s"] > 1e-4
+        else:
+            assert r["setup_s"] < 1e-4, (s, r["setup_s"])
+    h.close()
+
+
+def test_precon_reuse_repeated_solves_of_one_system(hd):
+    """The laplacian driver's loop (5 x Create/Setup/Apply/Destroy on the same system) with reuse: always builds once."""
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    print_level: 0\n  reuse: always\n")
+    h.set_laplacian7((16, 16, 16))
+    rs = [h.solve() for _ in range(5)]
+    assert all(r["converged"] and r["iters"] == rs[0]["iters"] for r in rs)
+    assert rs[0]["setup_s"] > 1e-4 and all(r["setup_s"] < 1e-4 for r in rs[1:])
+    h.close()
+
+
+def test_precon_reuse_rejects_a_different_size(hd, orc):
+    import scipy.sparse as sp
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    print_level: 0\n  reuse: always\n")
+    for n in (400, 500):
+        S = (sp.diags([-np.ones(n - 1), 2.5 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])).tocsr()
+        h.set_matrix_csr(0, n - 1, S.indptr, S.indices, S.data)
+        h.set_rhs_array(0, n - 1, np.ones(n))
+        h.finish_system()
+        if n == 400:
+            assert h.solve()["converged"]
+        else:
+            with pytest.raises(hd.HypredrvError, match="same number of local rows"):
+                h.solve()
+            hd.lib().HYPREDRV_ErrorCodeClear()
+    h.close()

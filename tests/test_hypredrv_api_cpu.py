@@ -162,3 +162,23 @@ def test_cli_reports_missing_input_and_missing_gpu():
     if h.device_count() == 0:
         r = subprocess.run([cli, "-q", "examples/ex1.yml"], capture_output=True, text=True, cwd=ROOT)
         assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+def test_precon_reuse_yaml(hd):
+    """preconditioner.reuse (reference src/internal/precon_reuse.c:2280-2567): value and block forms of the static
+    policy parse; the combinations the reference rejects are rejected; what needs its timestep files / history model
+    (adaptive, per_timestep) says so."""
+    base = "solver: pcg\npreconditioner:\n  amg:\n    print_level: 0\n  reuse:"
+    for ok in (" always\n", " static\n", "\n    frequency: 2\n", "\n    enabled: off\n    frequency: 3\n",
+               "\n    linear_system_ids: [0, 3, 5]\n", "\n    type: always\n", "\n    linear_solver_ids: [1]\n"):
+        hd.Hypredrv(base + ok).close()
+    for bad, msg in ((" sometimes\n", "Invalid preconditioner.reuse value"), ("\n    frequency: -1\n", "frequency"),
+                     ("\n    type: always\n    frequency: 2\n", "always cannot be combined"),
+                     ("\n    type: always\n    enabled: off\n", "enabled: off"),
+                     ("\n    linear_system_ids: [0, 2]\n    frequency: 1\n", "cannot be combined"),
+                     ("\n    no_such_key: 1\n", "Unknown key under preconditioner.reuse"),
+                     (" adaptive\n", "not implemented"), ("\n    per_timestep: on\n", "not implemented"),
+                     ("\n    adaptive:\n      rebuild_threshold: 2.0\n", "not implemented")):
+        with pytest.raises(hd.HypredrvError, match=msg):
+            hd.Hypredrv(base + bad)
+        hd.lib().HYPREDRV_ErrorCodeClear()
