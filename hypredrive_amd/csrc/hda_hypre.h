@@ -52,7 +52,7 @@ struct hypre_Solver_struct {
    // values of setters whose feature is not implemented (checked at Setup)
    const int                *dof_func_ptr = nullptr; // HYPRE_BoomerAMGSetDofFunc (borrowed until Setup)
    int                       smooth_type = 5, smooth_num_levels = 0, agg_num_levels = 0, num_functions = 1, cycle_type = 1,
-                             restriction = 0, relax_order = 0, sabs = 0, seq_threshold = 0, relax_type_all = -1;
+                             restriction = 0, relax_order = 0, sabs = 0, seq_threshold = 0, relax_type_all = -1, filter_functions = 0;
    HYPRE_PtrToSolverFcn      precond = nullptr, precond_setup = nullptr;
    HYPRE_Solver              precond_solver = nullptr;
    std::unique_ptr<hda::Amg> amg;

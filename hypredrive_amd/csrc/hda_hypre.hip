@@ -997,7 +997,7 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetDofFunc(HYPRE_Solver s, HYPRE_Int *dof_fu
    s->dof_func_ptr = dof_func; // length is known at setup (local rows): copied there
    HY_CATCH
 }
-HY_SETTER(HYPRE_BoomerAMGSetFilterFunctions, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetFilterFunctions, HYPRE_Int, s->filter_functions = v)
 HY_SETTER(HYPRE_BoomerAMGSetSmoothType, HYPRE_Int, s->smooth_type = v)
 HY_SETTER(HYPRE_BoomerAMGSetSmoothNumSweeps, HYPRE_Int, s->ap.smooth_num_sweeps = v)
 // ILU arguments of the complex smoother (reference src/internal/amg.c:903-921)
@@ -1075,6 +1075,7 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    s->ap.smooth_num_levels = std::max(s->smooth_num_levels, 0);
    s->ap.ilu               = s->ilup;
    HDA_REQUIRE(s->cycle_type == 1, "only V-cycles (cycle type 1) are implemented");
+   HDA_REQUIRE(s->filter_functions == 0 || s->num_functions <= 1, "coarsening.filter_functions is not implemented for systems AMG");
    HDA_REQUIRE(s->restriction == 0, "only P^T restriction (restriction_type 0) is implemented");
    HDA_REQUIRE(s->relax_order == 0, "only lexicographic relaxation order (relaxation.order 0) is implemented");
    s->ap.num_functions = std::max(s->num_functions, 1);

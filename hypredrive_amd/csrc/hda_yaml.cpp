@@ -368,7 +368,14 @@ static void parse_solver(Ctx &c, YNode &node, KrylovArgs &k)
    bool seen = false;
    for (auto &ch : node.kids)
    {
-      if (ch->key == "scaling") continue; // optional sibling; scaling is off by default
+      if (ch->key == "scaling")
+      { // solver.scaling (reference src/internal/scaling.c): off by default.  The scaled branch of
+        // LinearSolverSetup/Apply is not built here: asking for it is an error, not a silently unscaled solve
+         for (auto &q : ch->kids)
+            if (q->key == "enabled" && to_int(c, *q, &kOnOff) != 0)
+               c.fail(ERR_INVALID_VAL, "solver.scaling is not implemented on MI355X (set scaling.enabled: off)");
+         continue;
+      }
       int m = solver_method(ch->key);
       if (m < 0) { c.fail(ERR_INVALID_KEY, "unknown solver '" + ch->key + "'"); continue; }
       k.defaults_for(m);

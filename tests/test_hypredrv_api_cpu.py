@@ -182,3 +182,11 @@ def test_precon_reuse_yaml(hd):
         with pytest.raises(hd.HypredrvError, match=msg):
             hd.Hypredrv(base + bad)
         hd.lib().HYPREDRV_ErrorCodeClear()
+
+
+def test_scaling_request_is_an_error(hd):
+    """solver.scaling (reference src/internal/scaling.c) is off by default; enabling it must not be ignored silently."""
+    hd.Hypredrv("solver:\n  pcg:\n    max_iter: 10\n  scaling:\n    enabled: off\npreconditioner: amg\n").close()
+    with pytest.raises(hd.HypredrvError, match="scaling is not implemented"):
+        hd.Hypredrv("solver:\n  pcg:\n    max_iter: 10\n  scaling:\n    enabled: yes\n    type: rhs_l2\npreconditioner: amg\n")
+    hd.lib().HYPREDRV_ErrorCodeClear()
