@@ -251,9 +251,9 @@ def test_reference_laplacian_driver_unmodified(orc):
     against include/HYPREDRV.h + libhypredrv_amd.so by __graft_entry__.build(): same table as
     examples/refOutput/laplacian.txt:34-38 (5 entries, r0 = 1.00e+01, LS build only on entry 0);
     iteration count = oracle with the hypre-GPU defaults this library ships."""
-    exe = os.path.join(ROOT, "build", "laplacian_ref")
+    exe = os.path.join(ROOT, "oracle", "_ref", "laplacian_ref")
     if not os.path.exists(exe):
-        pytest.skip("build/laplacian_ref not built (needs /root/reference + MPICH at build time)")
+        pytest.skip("oracle/_ref/laplacian_ref not built (needs /root/reference + MPICH at build time)")
     r = subprocess.run([exe, "-v", "1"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     rows = re.findall(r"^\|\s+(\d+) \|\s+([\d.]*) \|\s+([\d.]+) \|\s+([\d.]+) \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
@@ -269,9 +269,9 @@ def test_reference_laplacian_driver_unmodified(orc):
 
 
 def _run_convdif(cfg):
-    exe = os.path.join(ROOT, "build", "convdif_ref")
+    exe = os.path.join(ROOT, "oracle", "_ref", "convdif_ref")
     if not os.path.exists(exe):
-        pytest.skip("build/convdif_ref not built (needs /root/reference + MPICH at build time)")
+        pytest.skip("oracle/_ref/convdif_ref not built (needs /root/reference + MPICH at build time)")
     r = subprocess.run([exe, "-i", cfg, "-v", "1"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     steps = re.findall(r"^Time step:\s+(\d+) \|.*\| Lin:\s+(\d+) \| min\(c\)=\s*\S+ max\(c\)=\s*(\S+) mass=(\S+)", r.stdout, re.M)
@@ -367,9 +367,9 @@ def test_reference_elasticity_driver_unmodified(pins):
     relaxation or coarsening, so the CPU-build defaults of the reference are selected with
     HYPREDRV_AMD_DEFAULTS=cpu; examples/refOutput/elasticity.txt:37-41 then reads 21 iterations,
     r0 1.79e+01, 2.66e-07 -- this build: 21 iterations, 1.79e+01, 2.97e-07."""
-    exe = os.path.join(ROOT, "build", "elasticity_ref")
+    exe = os.path.join(ROOT, "oracle", "_ref", "elasticity_ref")
     if not os.path.exists(exe):
-        pytest.skip("build/elasticity_ref not built (needs /root/reference + MPICH at build time)")
+        pytest.skip("oracle/_ref/elasticity_ref not built (needs /root/reference + MPICH at build time)")
     r = subprocess.run([exe, "-v", "1"], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, HYPREDRV_AMD_DEFAULTS="cpu"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     rows = re.findall(r"^\|\s+(\d+) \|\s+([\d.]*) \|\s+([\d.]+) \|\s+([\d.]+) \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
@@ -392,9 +392,9 @@ def test_reference_heatflow_driver_unmodified():
     two annotation levels).  No checked-in output exists for it; the checks are the driver's own:
     every Newton solve converges, the error against its manufactured solution stays at
     discretisation level, energy decays, and the table carries "timestep.newton.system" paths."""
-    exe = os.path.join(ROOT, "build", "heatflow_ref")
+    exe = os.path.join(ROOT, "oracle", "_ref", "heatflow_ref")
     if not os.path.exists(exe):
-        pytest.skip("build/heatflow_ref not built (needs /root/reference + MPICH at build time)")
+        pytest.skip("oracle/_ref/heatflow_ref not built (needs /root/reference + MPICH at build time)")
     r = subprocess.run([exe, "-v", "1"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     steps = re.findall(r"^Time step:\s+(\d+) \|.*\| NL:\s+(\d+) \| Lin:\s+(\d+) \|.*L2\(Err\)=(\S+) \| E=(\S+)", r.stdout, re.M)
@@ -409,9 +409,9 @@ def test_reference_heatflow_driver_unmodified():
 def test_reference_laplacian_driver_cpu_defaults(pins):
     """examples/refOutput/laplacian.txt:34-38 (5 iterations, 6.12e-07) through the unmodified driver
     with the reference's CPU-build defaults."""
-    exe = os.path.join(ROOT, "build", "laplacian_ref")
+    exe = os.path.join(ROOT, "oracle", "_ref", "laplacian_ref")
     if not os.path.exists(exe):
-        pytest.skip("build/laplacian_ref not built")
+        pytest.skip("oracle/_ref/laplacian_ref not built")
     r = subprocess.run([exe, "-v", "1"], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, HYPREDRV_AMD_DEFAULTS="cpu"))
     assert r.returncode == 0, r.stdout + r.stderr
     rows = re.findall(r"^\|\s+(\d+) \|\s+([\d.]*) \|\s+([\d.]+) \|\s+([\d.]+) \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
