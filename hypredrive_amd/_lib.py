@@ -36,6 +36,11 @@ class AmgParams(C.Structure):
         return p
 
 
+class MgrLevelParams(C.Structure):
+    _fields_ = [("n_f_labels", C.c_int), ("f_labels", C.POINTER(C.c_int)), ("interp_type", C.c_int), ("restrict_type", C.c_int),
+                ("frelax_type", C.c_int), ("frelax_sweeps", C.c_int), ("grelax_type", C.c_int), ("grelax_sweeps", C.c_int)]
+
+
 class KrylovParams(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
                 ("two_norm", C.c_int), ("krylov_dim", C.c_int)]
@@ -60,7 +65,7 @@ SYMBOLS = [
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
-    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab",
+    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
 ]
 
 
@@ -99,6 +104,8 @@ def load():
     L.hda_spgemm.argtypes = [vp, vp, P(vp)]
     L.hda_amg_create.argtypes = [P(AmgParams), vp, P(vp)]
     L.hda_amg_destroy.argtypes = [vp]
+    L.hda_mgr_create.argtypes = [vp, ip, C.c_int, P(MgrLevelParams), P(AmgParams), C.c_int, P(vp)]
+    L.hda_mgr_matrix.argtypes = [vp, C.c_int, C.c_int, P(vp)]
     L.hda_ilu_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(vp)]
     L.hda_ilu_factors.argtypes = [vp, C.c_int, P(vp)]
     L.hda_amg_num_levels.argtypes = [vp]
@@ -311,6 +318,55 @@ class Amg:
     @property
     def vcycle_bytes(self):
         return load().hda_amg_vcycle_bytes(self.h)
+
+    def vcycle(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b)
+        _check(load().hda_amg_vcycle(self.h, _dp(b), _dp(x)))
+        return x
+
+
+MGR_INTERP = {"injection": 0, "l1-jacobi": 1, "jacobi": 2}
+MGR_RESTRICT = {"injection": 0, "jacobi": 2, "columped": 14}
+MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18}
+MGR_GRELAX = {"none": -1, "h-fgs": 3, "h-bgs": 4, "h-ssor": 6, "l1-hfgs": 13, "l1-hbgs": 14, "l1-hsgs": 88}
+
+
+class Mgr:
+    """'preconditioner: mgr': multigrid reduction by dof labels; levels = list of dicts with the YAML keys of
+    mgr.level.N (f_dofs, prolongation_type, restriction_type, f_relaxation, g_relaxation [, f_sweeps, g_sweeps]).
+    Usable as amg= in pcg()/gmres()/fgmres()/bicgstab()."""
+
+    def __init__(self, A, labels, levels, coarse_params=None, max_iter=1):
+        self.A = A
+        self.labels = np.ascontiguousarray(labels, dtype=np.int32)
+        self.params = coarse_params if coarse_params is not None else AmgParams.default()
+        arr = (MgrLevelParams * max(len(levels), 1))()
+        self._keep = []
+        for k, lv in enumerate(levels):
+            f = np.ascontiguousarray(lv["f_dofs"], dtype=np.int32)
+            self._keep.append(f)
+            arr[k].n_f_labels = len(f)
+            arr[k].f_labels = f.ctypes.data_as(C.POINTER(C.c_int))
+            arr[k].interp_type = MGR_INTERP[lv.get("prolongation_type", "injection")]
+            arr[k].restrict_type = MGR_RESTRICT[lv.get("restriction_type", "injection")]
+            arr[k].frelax_type = MGR_FRELAX[lv.get("f_relaxation", "jacobi")]
+            arr[k].frelax_sweeps = lv.get("f_sweeps", 1)
+            arr[k].grelax_type = MGR_GRELAX[lv.get("g_relaxation", "none")]
+            arr[k].grelax_sweeps = lv.get("g_sweeps", 1)
+        self.nlevels = len(levels)
+        self.h = C.c_void_p()
+        _check(load().hda_mgr_create(A.h, _ip(self.labels), len(levels), arr, C.byref(self.params), max_iter, C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            load().hda_amg_destroy(self.h)
+            self.h = None
+
+    def matrix(self, level, which=0):
+        out = C.c_void_p()
+        _check(load().hda_mgr_matrix(self.h, level, which, C.byref(out)))
+        return Csr(out, owned=False, keep=self)
 
     def vcycle(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64)

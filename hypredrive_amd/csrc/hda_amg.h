@@ -7,6 +7,7 @@
 #include "hda_kernels.h"
 
 #include <memory>
+#include <vector>
 
 namespace hda {
 
@@ -166,6 +167,48 @@ class Amg {
    DArray<double>        coarse_invT; // dense inverse of the coarsest operator (column-major)
    int                   coarse_n = 0;
    bool                  coarse_dense = false;
+};
+
+// ---- MGR (hda_mgr.hip): multigrid reduction by dof labels, BoomerAMG on the coarsest system.
+// Parameter contract: reference MGR_args / MGRlvl_args (include/internal/mgr.h:132-178), defaults src/internal/mgr.c:1226-1330.
+struct MgrLevelParams {
+   std::vector<int> f_labels;          // level.N.f_dofs
+   int interp_type = 0;                // prolongation_type: 0 injection, 1 l1-jacobi, 2 jacobi
+   int restrict_type = 0;              // restriction_type: 0 injection, 2 jacobi, 14 columped
+   int coarse_type = 0;                // coarse_level_type: 0 rap
+   int frelax_type = 7, frelax_sweeps = 1;   // f_relaxation: 7 jacobi, 18 l1-jacobi
+   int grelax_type = -1, grelax_sweeps = 1;  // g_relaxation: -1 none, 3/4/6/13/14 hybrid GS, 88 l1-hsgs
+};
+struct MgrParams {
+   std::vector<MgrLevelParams> levels;
+   AmgParams                   coarse; // coarsest_level: amg
+   int                         max_iter = 1;
+};
+class Mgr {
+ public:
+   explicit Mgr(const MgrParams &p) : prm(p) {}
+   void        setup(const DCsr &A, const std::vector<int> &labels); // labels: dofmap of the local rows; A is borrowed for level 0
+   void        solve(const double *b, double *x, bool zero_guess);   // max_iter cycles
+   int         num_reduction_levels() const { return (int)lv.size(); }
+   const DCsr &matrix(int level, int which) const; // which 0 operator (level == reduction levels: coarsest), 1 P, 2 R
+   size_t      vec_len0() const { return lv.empty() ? 0 : (size_t)std::max(lv[0].A->ncols, lv[0].n); }
+   MgrParams   prm;
+
+ private:
+   struct Level {
+      DCsr           A_own;
+      const DCsr    *A = nullptr;
+      DCsr           P, R;
+      DArray<int>    labels, cf, cidx;
+      DArray<double> dinvF, dinvG, f, u, u2, t;
+      GsPlan         gs;
+      int            n = 0, nc = 0;
+   };
+   double *cycle(int l, const double *f, double *u, bool zero);
+   std::vector<Level>   lv;
+   DCsr                 Ac;
+   std::unique_ptr<Amg> camg;
+   DArray<double>       fc, uc;
 };
 
 // ---- setup kernels (hda_amg_setup.hip); exposed for per-kernel parity tests -------------

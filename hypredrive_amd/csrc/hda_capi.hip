@@ -20,6 +20,7 @@ struct hda_csr_s {
 struct hda_amg_s {
    std::unique_ptr<Amg>                    amg;
    std::unique_ptr<Ilu>                    ilu; // handle made by hda_ilu_create: the preconditioner is one ILU solve
+   std::unique_ptr<Mgr>                    mgr; // handle made by hda_mgr_create: the preconditioner is one MGR solve
    DArray<double>                          ilu_r, ilu_c;
    hda_csr_t                               A = nullptr;
    std::vector<std::unique_ptr<hda_csr_s>> views;
@@ -390,6 +391,43 @@ extern "C" int hda_ilu_create(hda_csr_t A, int max_iter, int tri_solve, int lowe
    *out = h.release();
    HDA_CATCH
 }
+// "preconditioner: mgr" (reference src/internal/mgr.c): multigrid reduction by dof labels
+extern "C" int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const hda_mgr_level_params *levels,
+                              const hda_amg_params *coarsest_amg, int max_iter, hda_amg_t *out)
+{
+   HDA_TRY
+   HDA_REQUIRE(labels && levels && nlevels > 0, "hda_mgr_create: labels and at least one level are needed");
+   MgrParams p;
+   p.coarse   = to_params(coarsest_amg);
+   p.max_iter = max_iter;
+   for (int l = 0; l < nlevels; l++)
+   {
+      MgrLevelParams q;
+      q.f_labels.assign(levels[l].f_labels, levels[l].f_labels + levels[l].n_f_labels);
+      q.interp_type = levels[l].interp_type; q.restrict_type = levels[l].restrict_type;
+      q.frelax_type = levels[l].frelax_type; q.frelax_sweeps = levels[l].frelax_sweeps;
+      q.grelax_type = levels[l].grelax_type; q.grelax_sweeps = levels[l].grelax_sweeps;
+      p.levels.push_back(q);
+   }
+   auto h = std::make_unique<hda_amg_s>();
+   h->A   = A;
+   h->mgr = std::make_unique<Mgr>(p);
+   h->mgr->setup(A->get(), std::vector<int>(labels, labels + A->get().nrows));
+   *out = h.release();
+   HDA_CATCH
+}
+// borrowed view: which 0 operator of the level (level == reduction levels: the coarsest system), 1 P, 2 R
+extern "C" int hda_mgr_matrix(hda_amg_t h, int level, int which, hda_csr_t *out)
+{
+   HDA_TRY
+   HDA_REQUIRE(h && h->mgr, "not an MGR handle");
+   auto v      = std::make_unique<hda_csr_s>();
+   v->borrowed = true;
+   v->ref      = &h->mgr->matrix(level, which);
+   *out        = v.get();
+   h->views.push_back(std::move(v));
+   HDA_CATCH
+}
 // factors (strict lower part L with unit diagonal, rest U) of the stand-alone handle (level < 0) or of
 // the complex smoother of an AMG level
 extern "C" int hda_ilu_factors(hda_amg_t h, int level, hda_csr_t *out)
@@ -449,6 +487,15 @@ extern "C" double hda_amg_vcycle_bytes(hda_amg_t h) { return h ? h->amg->vcycle_
 extern "C" int hda_amg_vcycle(hda_amg_t h, const double *b, double *x)
 {
    HDA_TRY
+   if (h->mgr)
+   { // one application of the MGR preconditioner from a zero guess
+      const DCsr    &m = h->A->get();
+      DArray<double> db, dx((size_t)std::max(std::max(m.ncols, m.nrows), 1));
+      db.upload(b, (size_t)m.nrows);
+      h->mgr->solve(db.data(), dx.data(), true);
+      dx.download(x, (size_t)m.nrows);
+      return HDA_OK;
+   }
    if (h->ilu)
    { // one application of the ILU preconditioner from a zero guess
       const DCsr    &m = h->A->get();
@@ -480,7 +527,12 @@ static int run_krylov(int kind, hda_csr_t A, hda_amg_t amg, const hda_krylov_par
    HDA_HIP(hipMemcpyAsync(dx.data(), x, sizeof(double) * (size_t)m.nrows, hipMemcpyHostToDevice, Context::get().stream));
    Context::get().sync();
    PrecondFn M;
-   if (amg && amg->ilu)
+   if (amg && amg->mgr)
+      M = [amg, &m](const double *r, double *z, int slot) {
+         amg->mgr->solve(r, z, true);
+         if (slot >= 0) dot(m.nrows, r, z, slot);
+      };
+   else if (amg && amg->ilu)
       M = [amg, &m](const double *r, double *z, int slot) {
          ilu_solve(*amg->ilu, m, nullptr, r, z, true, amg->ilu_r, amg->ilu_c);
          if (slot >= 0) dot(m.nrows, r, z, slot);

@@ -109,6 +109,22 @@ int hda_amg_destroy(hda_amg_t h);
  * diagonal block; the handle is accepted by hda_pcg / hda_gmres / hda_amg_vcycle (= one application from a zero guess)
  * in place of a hierarchy.  max_iter iterations x += M^-1 (b - A x) per application. */
 int hda_ilu_create(hda_csr_t A, int max_iter, int tri_solve, int lower_it, int upper_it, hda_amg_t *out);
+/* "preconditioner: mgr" (reference src/internal/mgr.c; MGRlvl_args include/internal/mgr.h:132-147): multigrid reduction
+ * by dof labels with BoomerAMG on the coarsest system.  labels = dofmap of A's rows.  Implemented per level:
+ * prolongation injection (0) / l1-jacobi (1) / jacobi (2); restriction injection (0) / jacobi (2) / columped (14);
+ * f_relaxation jacobi (7) / l1-jacobi (18); g_relaxation none (-1) / hybrid (l1) Gauss-Seidel (3, 4, 6, 13, 14, 88);
+ * coarse grid by Galerkin product.  One rank.  The handle is accepted by the Krylov entry points and hda_amg_vcycle. */
+typedef struct {
+   int        n_f_labels;
+   const int *f_labels; /* level.N.f_dofs */
+   int        interp_type, restrict_type;
+   int        frelax_type, frelax_sweeps;
+   int        grelax_type, grelax_sweeps;
+} hda_mgr_level_params;
+int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const hda_mgr_level_params *levels,
+                   const hda_amg_params *coarsest_amg, int max_iter, hda_amg_t *out);
+/* borrowed view: which 0 = operator of the level (level == nlevels: the coarsest system), 1 = P, 2 = R */
+int hda_mgr_matrix(hda_amg_t h, int level, int which, hda_csr_t *out);
 /* borrowed view of the factors: strict lower part = L (unit diagonal), rest = U.  level < 0: the handle of
  * hda_ilu_create; level >= 0: the complex smoother of that AMG level. */
 int hda_ilu_factors(hda_amg_t h, int level, hda_csr_t *out);

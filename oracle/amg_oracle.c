@@ -1149,6 +1149,10 @@ ilu_iterate(orc_ilu *F, const orc_csr *A, int iters, const double *b, double *x,
    }
 }
 
+struct orc_mgr;
+static void mgr_solve(struct orc_mgr *M, const double *b, double *x);
+static void mgr_free(struct orc_mgr *M);
+
 struct orc_amg {
    orc_amg_params p;
    int            nlev;
@@ -1160,6 +1164,7 @@ struct orc_amg {
    /* complex smoother (src/internal/amg.c:899-921): ILU on the first smooth_levels levels */
    orc_ilu      **ilu;
    int            smooth_levels, smooth_sweeps;
+   struct orc_mgr *mgr;       /* handle made by orc_precond_mgr: the "hierarchy" is one MGR cycle */
    orc_ilu       *ilu_only;   /* handle made by orc_precond_ilu: the "hierarchy" is one ILU solve */
    const orc_csr *ilu_A;
    int            ilu_max_iter;
@@ -1269,6 +1274,12 @@ void
 orc_amg_free(orc_amg *h)
 {
    if (!h) return;
+   if (h->mgr)
+   {
+      mgr_free(h->mgr);
+      free(h);
+      return;
+   }
    if (h->ilu_only)
    {
       orc_ilu_free(h->ilu_only);
@@ -1403,6 +1414,11 @@ coarse_solve(orc_amg *h, int l, const double *b, double *x)
 void
 orc_amg_vcycle(orc_amg *h, const double *b, double *x)
 {
+   if (h->mgr)
+   {
+      mgr_solve(h->mgr, b, x);
+      return;
+   }
    if (h->ilu_only)
    { /* preconditioner: ilu (precon.c op table): max_iter iterations of x += M^{-1}(b - A x) */
       const int n   = h->ilu_A->nrows;
@@ -1448,6 +1464,238 @@ orc_amg_vcycle(orc_amg *h, const double *b, double *x)
       }
    }
    memcpy(x, h->u[0], sizeof(double) * (size_t)h->A[0]->nrows);
+}
+
+
+/* ------------------------------------------------------------------ MGR (multigrid reduction)
+ * hypre's MGR as hypredrive configures it (reference src/internal/mgr.c: defaults :1226-1330, name maps
+ * :1553-1721; arg tree include/internal/mgr.h:132-178).  hypre is not in the reference tree; this restates
+ * the published method (Ries/Trottenberg/Winter; hypre reference manual, "MGR") for the option subset below.
+ * PARITY UNPINNED: the reference's MGR outputs (refOutput/ex3..ex7) need data sets that are not in the tree.
+ *
+ * Per reduction level: unknowns whose label is in f_labels are F points, the rest C points (ascending order
+ * keeps their relative numbering).  P = [W; I], R = [Z I], A_c = R A P (coarse_level_type rap).
+ *   prolongation 0 injection W = 0 | 2 jacobi W = -D_FF^-1 A_FC | 1 l1-jacobi W = -diag(l1(A_FF))^-1 A_FC
+ *   restriction  0 injection Z = 0 | 2 jacobi Z = -A_CF D_FF^-1  | 14 columped Z = -A_CF diag(colsum(A_FF))^-1
+ * Cycle (cycle 1, smoothing position "pre"): global relaxation sweeps on all points, F-relaxation sweeps
+ * (Jacobi on the F rows of the whole operator: u_F += D_FF^-1 (f - A u)_F), restrict the residual, recurse,
+ * u += P e_c.  Coarsest level: one BoomerAMG V-cycle from a zero guess. */
+typedef struct {
+   orc_csr *A, *P, *R;
+   int      n, nc;
+   int     *labels, *cf, *cidx;
+   double  *dinvF, *l1g;
+   double  *f, *u, *t;
+   int      frelax_sweeps, grelax_type, grelax_sweeps;
+} mgr_level;
+
+struct orc_mgr {
+   int        nlev; /* reduction levels */
+   mgr_level *lv;
+   orc_csr   *Ac;   /* coarsest operator */
+   orc_amg   *camg;
+   double    *fc, *uc;
+   int        max_iter;
+};
+
+static int
+label_in(int lab, const int *set, int n)
+{
+   for (int i = 0; i < n; i++)
+      if (set[i] == lab) return 1;
+   return 0;
+}
+
+orc_amg *
+orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mgr_level_params *lp,
+                const orc_amg_params *coarse_amg, int max_iter)
+{
+   struct orc_mgr *M = (struct orc_mgr *)calloc(1, sizeof(struct orc_mgr));
+   M->nlev     = nlevels;
+   M->lv       = (mgr_level *)calloc((size_t)(nlevels > 0 ? nlevels : 1), sizeof(mgr_level));
+   M->max_iter = max_iter < 1 ? 1 : max_iter;
+   /* level 0 works on a copy so that every level owns its operator */
+   orc_csr *A = orc_csr_alloc(A0->nrows, A0->ncols, A0->rowptr[A0->nrows]);
+   memcpy(A->rowptr, A0->rowptr, sizeof(int) * (size_t)(A0->nrows + 1));
+   memcpy(A->col, A0->col, sizeof(int) * (size_t)A0->rowptr[A0->nrows]);
+   memcpy(A->val, A0->val, sizeof(double) * (size_t)A0->rowptr[A0->nrows]);
+   int *labels = (int *)malloc(sizeof(int) * (size_t)(A->nrows > 0 ? A->nrows : 1));
+   memcpy(labels, labels0, sizeof(int) * (size_t)A->nrows);
+   for (int l = 0; l < nlevels; l++)
+   {
+      mgr_level *L = &M->lv[l];
+      const int  n = A->nrows;
+      L->A = A; L->n = n; L->labels = labels;
+      L->frelax_sweeps = lp[l].frelax_sweeps; L->grelax_type = lp[l].grelax_type; L->grelax_sweeps = lp[l].grelax_sweeps;
+      L->cf    = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+      L->cidx  = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+      L->dinvF = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+      int nc = 0;
+      for (int i = 0; i < n; i++)
+      {
+         L->cf[i]   = label_in(labels[i], lp[l].f_labels, lp[l].n_f_labels) ? -1 : 1;
+         L->cidx[i] = (L->cf[i] > 0) ? nc++ : -1;
+      }
+      L->nc = nc;
+      /* F-point divisors: a_ii (frelax 7) or the l1 norm of the whole row (18) */
+      double *dF = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));   /* a_ii on F rows */
+      double *l1F = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));  /* sum_j in F |a_ij| on F rows */
+      double *csum = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); /* column sums of A_FF */
+      for (int i = 0; i < n; i++)
+      {
+         if (L->cf[i] > 0) continue;
+         double l1 = 0.0;
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         {
+            const int j = A->col[k];
+            l1 += fabs(A->val[k]);
+            if (j == i) dF[i] = A->val[k];
+            if (L->cf[j] < 0) { l1F[i] += fabs(A->val[k]); csum[j] += A->val[k]; } /* rows ascending: fixed order per column */
+         }
+         const double d = (lp[l].frelax_type == 18) ? l1 : dF[i];
+         L->dinvF[i]    = (d != 0.0) ? 1.0 / d : 0.0;
+      }
+      /* P */
+      {
+         int nnz = 0;
+         for (int i = 0; i < n; i++)
+         {
+            if (L->cf[i] > 0) { nnz++; continue; }
+            if (lp[l].interp_type == 0) continue;
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) nnz += (L->cf[A->col[k]] > 0);
+         }
+         orc_csr *P = orc_csr_alloc(n, nc, nnz);
+         int q = 0;
+         for (int i = 0; i < n; i++)
+         {
+            P->rowptr[i] = q;
+            if (L->cf[i] > 0) { P->col[q] = L->cidx[i]; P->val[q++] = 1.0; continue; }
+            if (lp[l].interp_type == 0) continue;
+            const double d = (lp[l].interp_type == 1) ? l1F[i] : dF[i];
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+               if (L->cf[A->col[k]] > 0) { P->col[q] = L->cidx[A->col[k]]; P->val[q++] = -A->val[k] / d; }
+         }
+         P->rowptr[n] = q;
+         L->P = P;
+      }
+      /* R */
+      {
+         int nnz = 0;
+         for (int i = 0; i < n; i++)
+         {
+            if (L->cf[i] < 0) continue;
+            nnz++;
+            if (lp[l].restrict_type == 0) continue;
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) nnz += (L->cf[A->col[k]] < 0);
+         }
+         orc_csr *R = orc_csr_alloc(nc, n, nnz);
+         int q = 0, c = 0;
+         for (int i = 0; i < n; i++)
+         {
+            if (L->cf[i] < 0) continue;
+            R->rowptr[c++] = q;
+            int placed = 0; /* keep columns ascending: the identity entry goes where i sorts */
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1] && lp[l].restrict_type != 0; k++)
+            {
+               const int j = A->col[k];
+               if (L->cf[j] > 0) continue;
+               if (!placed && j > i) { R->col[q] = i; R->val[q++] = 1.0; placed = 1; }
+               const double d = (lp[l].restrict_type == 14) ? csum[j] : dF[j];
+               R->col[q] = j; R->val[q++] = -A->val[k] / d;
+            }
+            if (!placed) { R->col[q] = i; R->val[q++] = 1.0; }
+         }
+         R->rowptr[nc] = q;
+         L->R = R;
+      }
+      free(dF); free(l1F); free(csum);
+      /* global relaxation divisors */
+      if (L->grelax_type >= 0)
+      {
+         L->l1g = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+         orc_l1_norms(A, (L->grelax_type == 18) ? 1 : 4, L->l1g);
+      }
+      L->f = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+      L->u = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+      L->t = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+      /* coarse operator and its labels */
+      orc_csr *AP = spgemm(A, L->P);
+      orc_csr *Ac = spgemm(L->R, AP);
+      orc_csr_free(AP);
+      int *lc = (int *)malloc(sizeof(int) * (size_t)(nc > 0 ? nc : 1));
+      for (int i = 0; i < n; i++)
+         if (L->cf[i] > 0) lc[L->cidx[i]] = labels[i];
+      A = Ac;
+      labels = lc;
+   }
+   M->Ac   = A;
+   free(labels);
+   M->camg = orc_amg_setup(A, coarse_amg);
+   M->fc   = (double *)calloc((size_t)(A->nrows > 0 ? A->nrows : 1), sizeof(double));
+   M->uc   = (double *)calloc((size_t)(A->nrows > 0 ? A->nrows : 1), sizeof(double));
+   orc_amg *h = (orc_amg *)calloc(1, sizeof(orc_amg));
+   h->mgr     = M;
+   return h;
+}
+
+static void
+mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
+{
+   if (l == M->nlev)
+   {
+      memset(u, 0, sizeof(double) * (size_t)M->Ac->nrows);
+      orc_amg_vcycle(M->camg, f, u);
+      return;
+   }
+   mgr_level *L = &M->lv[l];
+   const int  n = L->n;
+   if (L->grelax_type >= 0)
+      for (int s = 0; s < L->grelax_sweeps; s++)
+         orc_relax(L->A, L->l1g, L->grelax_type == 88 ? 8 : L->grelax_type, 1.0, f, u, L->t);
+   for (int s = 0; s < L->frelax_sweeps; s++)
+   {
+      memcpy(L->t, f, sizeof(double) * (size_t)n);
+      orc_spmv(L->A, -1.0, u, 1.0, L->t);
+      for (int i = 0; i < n; i++) u[i] += L->dinvF[i] * L->t[i];
+   }
+   memcpy(L->t, f, sizeof(double) * (size_t)n);
+   orc_spmv(L->A, -1.0, u, 1.0, L->t);
+   double *fc = (l + 1 < M->nlev) ? M->lv[l + 1].f : M->fc;
+   double *uc = (l + 1 < M->nlev) ? M->lv[l + 1].u : M->uc;
+   orc_spmv(L->R, 1.0, L->t, 0.0, fc);
+   memset(uc, 0, sizeof(double) * (size_t)L->nc);
+   mgr_cycle(M, l + 1, fc, uc);
+   orc_spmv(L->P, 1.0, uc, 1.0, u);
+}
+
+static void
+mgr_solve(struct orc_mgr *M, const double *b, double *x)
+{
+   for (int it = 0; it < M->max_iter; it++) mgr_cycle(M, 0, b, x);
+}
+
+static void
+mgr_free(struct orc_mgr *M)
+{
+   for (int l = 0; l < M->nlev; l++)
+   {
+      mgr_level *L = &M->lv[l];
+      orc_csr_free(L->A); orc_csr_free(L->P); orc_csr_free(L->R);
+      free(L->labels); free(L->cf); free(L->cidx); free(L->dinvF); free(L->l1g); free(L->f); free(L->u); free(L->t);
+   }
+   orc_csr_free(M->Ac);
+   orc_amg_free(M->camg);
+   free(M->fc); free(M->uc); free(M->lv);
+   free(M);
+}
+
+const orc_csr *
+orc_mgr_matrix(const orc_amg *h, int level, int which) /* which: 0 A_level (level == nlev: coarsest), 1 P, 2 R */
+{
+   const struct orc_mgr *M = h->mgr;
+   if (!M || level < 0 || level > M->nlev) return NULL;
+   if (level == M->nlev) return which == 0 ? M->Ac : NULL;
+   return which == 0 ? M->lv[level].A : which == 1 ? M->lv[level].P : M->lv[level].R;
 }
 
 /* ------------------------------------------------------------------ Krylov */

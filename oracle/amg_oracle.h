@@ -134,6 +134,21 @@ int      orc_amg_set_ilu_smoother(orc_amg *h, int num_levels, int num_sweeps, in
 /* "preconditioner: ilu": a handle usable wherever the Krylov routines take a hierarchy */
 orc_amg *orc_precond_ilu(const orc_csr *A, int max_iter, int nparts, const int64_t *part, int tri_solve, int lower_it, int upper_it);
 
+/* MGR (reference src/internal/mgr.c; option subset and algorithm: see amg_oracle.c).  PARITY UNPINNED. */
+typedef struct {
+   int        n_f_labels;
+   const int *f_labels;      /* level.N.f_dofs: labels eliminated on this reduction level */
+   int        interp_type;   /* prolongation_type: 0 injection, 1 l1-jacobi, 2 jacobi */
+   int        restrict_type; /* restriction_type: 0 injection, 2 jacobi, 14 columped */
+   int        frelax_type;   /* f_relaxation: 7 jacobi (default), 18 l1-jacobi */
+   int        frelax_sweeps; /* 1 */
+   int        grelax_type;   /* g_relaxation: -1 none (default), 3/4/6/13/14 hybrid GS, 88 l1-hsgs, 18 l1-jacobi */
+   int        grelax_sweeps; /* 1 */
+} orc_mgr_level_params;
+orc_amg *orc_precond_mgr(const orc_csr *A, const int *labels, int nlevels, const orc_mgr_level_params *levels,
+                         const orc_amg_params *coarsest_amg, int max_iter);
+const orc_csr *orc_mgr_matrix(const orc_amg *h, int level, int which); /* 0 A (level == nlevels: coarsest), 1 P, 2 R */
+
 /* Krylov (hypre_PCGSolve / hypre_GMRESSolve restatements).
  * h == NULL -> unpreconditioned.  resid_hist[k] = ||r_k||_2 for k=0..iters
  * (needs max_iter+1 doubles).  Returns iterations; *converged, *final_rel set. */

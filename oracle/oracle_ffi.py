@@ -29,6 +29,11 @@ class AmgParams(C.Structure):
                 ("seed", C.c_uint64), ("num_functions", C.c_int)]
 
 
+class MgrLevelParams(C.Structure):
+    _fields_ = [("n_f_labels", C.c_int), ("f_labels", C.POINTER(C.c_int)), ("interp_type", C.c_int), ("restrict_type", C.c_int),
+                ("frelax_type", C.c_int), ("frelax_sweeps", C.c_int), ("grelax_type", C.c_int), ("grelax_sweeps", C.c_int)]
+
+
 class KrylovParams(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
                 ("two_norm", C.c_int), ("krylov_dim", C.c_int)]
@@ -109,6 +114,10 @@ def lib():
         f.restype = C.c_int
         f.argtypes = [cp, C.c_void_p, P(KrylovParams), dp, dp, dp, ip, dp]
     L.orc_gselim.argtypes = [dp, dp, C.c_int]
+    L.orc_precond_mgr.restype = C.c_void_p
+    L.orc_precond_mgr.argtypes = [cp, ip, C.c_int, P(MgrLevelParams), P(AmgParams), C.c_int]
+    L.orc_mgr_matrix.restype = cp
+    L.orc_mgr_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_amg_rebind_level0.restype = C.c_int
     L.orc_amg_rebind_level0.argtypes = [C.c_void_p, cp]
     i64p = P(C.c_int64)
@@ -394,6 +403,56 @@ class IluPrecond:
         if getattr(self, "h", None):
             lib().orc_amg_free(self.h)
             self.h = None
+
+    def vcycle(self, b, x0=None):
+        return Amg.vcycle(self, b, x0)
+
+
+MGR_INTERP = {"injection": 0, "l1-jacobi": 1, "jacobi": 2}
+MGR_RESTRICT = {"injection": 0, "jacobi": 2, "columped": 14}
+MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18}
+MGR_GRELAX = {"none": -1, "h-fgs": 3, "h-bgs": 4, "h-ssor": 6, "l1-hfgs": 13, "l1-hbgs": 14, "l1-hsgs": 88}
+
+
+def mgr_level_list(levels):
+    """levels: list of dicts with the YAML keys of mgr.level.N (f_dofs, prolongation_type, restriction_type,
+    f_relaxation, g_relaxation [, f_sweeps, g_sweeps]) -> ctypes array + keep-alive list"""
+    arr = (MgrLevelParams * max(len(levels), 1))()
+    keep = []
+    for k, lv in enumerate(levels):
+        f = np.ascontiguousarray(lv["f_dofs"], dtype=np.int32)
+        keep.append(f)
+        arr[k].n_f_labels = len(f)
+        arr[k].f_labels = f.ctypes.data_as(C.POINTER(C.c_int))
+        arr[k].interp_type = MGR_INTERP[lv.get("prolongation_type", "injection")]
+        arr[k].restrict_type = MGR_RESTRICT[lv.get("restriction_type", "injection")]
+        arr[k].frelax_type = MGR_FRELAX[lv.get("f_relaxation", "jacobi")]
+        arr[k].frelax_sweeps = lv.get("f_sweeps", 1)
+        arr[k].grelax_type = MGR_GRELAX[lv.get("g_relaxation", "none")]
+        arr[k].grelax_sweeps = lv.get("g_sweeps", 1)
+    return arr, keep
+
+
+class MgrPrecond:
+    """'preconditioner: mgr' for pcg()/gmres()/...: multigrid reduction by dof labels, BoomerAMG on the coarsest system."""
+
+    def __init__(self, A, labels, levels, coarse_params=None, max_iter=1):
+        self.A = A
+        self.labels = np.ascontiguousarray(labels, dtype=np.int32)
+        self.params = coarse_params if coarse_params is not None else amg_params(True)
+        arr, self._keep = mgr_level_list(levels)
+        self.nlevels = len(levels)
+        self.h = lib().orc_precond_mgr(A.ptr, self.labels.ctypes.data_as(C.POINTER(C.c_int)), len(levels), arr,
+                                       C.byref(self.params), max_iter)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_amg_free(self.h)
+            self.h = None
+
+    def matrix(self, level, which=0):
+        """which: 0 operator of the level (level == number of reduction levels: the coarsest system), 1 P, 2 R"""
+        return Csr(lib().orc_mgr_matrix(self.h, level, which), owned=False)
 
     def vcycle(self, b, x0=None):
         return Amg.vcycle(self, b, x0)

@@ -706,3 +706,53 @@ def test_fgmres_and_bicgstab_match_oracle(orc, hd, precond):
     assert rh["converged"] and rh["iters"] == ro["iters"]
     assert np.allclose(rh["hist"], ro["hist"], rtol=1e-5 if precond is None else 1e-7)  # BiCGSTAB amplifies rounding over many steps
     assert rel(rh["x"], ro["x"]) < 1e-7
+
+
+# ------------------------------------------------- MGR (reference src/internal/mgr.c)
+
+def _three_field(n=10, seed=0):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_pins import three_field_system
+    return three_field_system(n, seed)
+
+
+MGR_CASES = [
+    [dict(f_dofs=[2], prolongation_type="jacobi")],
+    [dict(f_dofs=[2], prolongation_type="jacobi", restriction_type="jacobi")],
+    [dict(f_dofs=[2], prolongation_type="l1-jacobi", restriction_type="columped", f_relaxation="l1-jacobi", f_sweeps=2)],
+    [dict(f_dofs=[2])],
+    [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="l1-hsgs", restriction_type="columped")],   # ex3.yml
+    [dict(f_dofs=[1, 2], prolongation_type="jacobi", g_relaxation="h-fgs", g_sweeps=2)],
+]
+
+
+@pytest.mark.parametrize("levels", MGR_CASES)
+def test_mgr_matches_oracle(orc, hd, levels):
+    """Transfer operators and reduced operators bit-identical to the oracle (row kernels sum in column order, the
+    Galerkin product is the AMG setup's deterministic SpGEMM); one MGR application to 1e-12; same GMRES iterations."""
+    S, labels = _three_field(11, seed=3)
+    Ao, Ah = both(orc, hd, S)
+    Mo, Mh = orc.MgrPrecond(Ao, labels, levels), hd.Mgr(Ah, labels, levels)
+    for l in range(len(levels)):
+        for which in (1, 2):
+            a, b_ = Mo.matrix(l, which).to_scipy(), Mh.matrix(l, which).to_scipy()
+            assert np.array_equal(a.indptr, b_.indptr) and np.array_equal(a.indices, b_.indices) and np.array_equal(a.data, b_.data), (l, which)
+        a, b_ = Mo.matrix(l + 1, 0).to_scipy(), Mh.matrix(l + 1, 0).to_scipy()
+        assert np.array_equal(a.indptr, b_.indptr) and np.array_equal(a.indices, b_.indices) and np.array_equal(a.data, b_.data), l
+    r = np.random.default_rng(6).standard_normal(S.shape[0])
+    assert rel(Mh.vcycle(r), Mo.vcycle(r)) < 1e-12
+    b = np.ones(S.shape[0])
+    ro, rh = orc.gmres(Ao, b, Mo), hd.gmres(Ah, b, Mh)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-8)
+    assert rel(rh["x"], ro["x"]) < 1e-8
+
+
+def test_mgr_unimplemented_options_fail_loudly(hd):
+    S, labels = _three_field(6)
+    Ah = hd.Csr.from_scipy(S)
+    with pytest.raises(hd.LibraryError, match="f_dofs"):
+        hd.Mgr(Ah, labels, [dict(f_dofs=[7])])           # label that does not occur: nothing to eliminate
+    with pytest.raises(hd.LibraryError, match="f_dofs"):
+        hd.Mgr(Ah, labels, [dict(f_dofs=[0, 1, 2])])     # everything eliminated: no coarse system

@@ -295,3 +295,61 @@ def test_fgmres_and_bicgstab_restatements(orc):
     ba = orc.bicgstab(A, b, amg)
     assert ba["converged"] and ba["iters"] < orc.pcg(A, b, amg)["iters"]
     assert orc.bicgstab(A, np.zeros(A.nrows))["iters"] == 0
+
+
+# ------------------------------------------------------------------ MGR (parity unpinned: analytic anchors only)
+
+def three_field_system(n=10, seed=0):
+    """Interleaved 3-field model of a reservoir-like system (labels 0 = pressure-like, 1, 2 = local fields)."""
+    import scipy.sparse as sp
+    A1 = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    L2 = sp.kronsum(A1, A1).tocsr()
+    nc = n * n
+    I = sp.identity(nc)
+    rng = np.random.default_rng(seed)
+    d = lambda lo, hi: sp.diags(rng.uniform(lo, hi, nc))
+    K = sp.bmat([[L2 + d(0.5, 1.0), d(0.1, 0.3), d(0.05, 0.1)],
+                 [d(0.1, 0.2), 2.0 * I + 0.1 * L2, d(0.05, 0.1)],
+                 [d(0.05, 0.1), d(0.1, 0.2), d(2.5, 3.5)]]).tocsr()
+    perm = np.arange(3 * nc).reshape(3, nc).T.ravel()
+    Kp = K[perm][:, perm].tocsr()
+    Kp.sort_indices()
+    return Kp, np.tile([0, 1, 2], nc)
+
+
+def test_mgr_transfer_operators_and_schur_complement(orc):
+    """P = [W; I], R = [Z I], A_c = R A P.  With a diagonal A_FF, jacobi prolongation and injection restriction give
+    the exact Schur complement; jacobi restriction gives the same; columped divides by the column sums of A_FF."""
+    import scipy.sparse as sp
+    S, labels = three_field_system()
+    A = orc.Csr.from_scipy(S)
+    F, Cm = labels == 2, labels != 2
+    Aff, Afc, Acf, Acc = S[F][:, F], S[F][:, Cm], S[Cm][:, F], S[Cm][:, Cm]
+    schur = (Acc - Acf @ sp.diags(1.0 / Aff.diagonal()) @ Afc).tocsr()
+    for rt in ("injection", "jacobi", "columped"):
+        M = orc.MgrPrecond(A, labels, [dict(f_dofs=[2], prolongation_type="jacobi", restriction_type=rt)])
+        P, R = M.matrix(0, 1).to_scipy(), M.matrix(0, 2).to_scipy()
+        assert abs(P[Cm] - sp.identity(Cm.sum())).max() == 0 and abs(R[:, Cm] - sp.identity(Cm.sum())).max() == 0
+        assert abs(P[F] + sp.diags(1.0 / Aff.diagonal()) @ Afc).max() < 1e-15
+        assert abs(M.matrix(1, 0).to_scipy() - schur).max() < 1e-13   # A_FF diagonal: every variant reduces exactly
+        if rt == "columped":
+            cs = np.asarray(Aff.sum(axis=0)).ravel()
+            assert abs(R[:, F] + Acf @ sp.diags(1.0 / cs)).max() < 1e-15
+    M0 = orc.MgrPrecond(A, labels, [dict(f_dofs=[2])])                 # injection both ways: A_c = A_CC
+    assert abs(M0.matrix(1, 0).to_scipy() - Acc).max() == 0
+
+
+def test_mgr_two_reduction_levels_as_preconditioner(orc):
+    """The structure of the reference's examples/ex3.yml (level 0: f_dofs [2], jacobi prolongation; level 1: f_dofs [1],
+    l1-hsgs global relaxation, columped restriction; coarsest AMG) under GMRES."""
+    S, labels = three_field_system(12, seed=1)
+    A = orc.Csr.from_scipy(S)
+    b = np.ones(S.shape[0])
+    lev = [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="l1-hsgs", restriction_type="columped")]
+    M = orc.MgrPrecond(A, labels, lev)
+    assert [M.matrix(l, 0).nrows for l in range(3)] == [432, 288, 144]
+    r = orc.gmres(A, b, M)
+    plain = orc.gmres(A, b, None)
+    assert r["converged"] and r["iters"] < plain["iters"] / 2
+    assert np.linalg.norm(b - S @ r["x"]) / np.linalg.norm(b) < 1e-6
+    assert orc.fgmres(A, b, M)["iters"] == r["iters"]
