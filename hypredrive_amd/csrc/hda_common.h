@@ -55,7 +55,7 @@ struct Context {
    hipEvent_t  ev           = nullptr;
    int         device       = 0;
    static constexpr int kNumSlots   = 8;
-   static constexpr int kNumScalars = 64;
+   static constexpr int kNumScalars = 320; // recurrence scalars + GMRES Gram-Schmidt coefficients (krylov_dim up to ~300)
 
    static Context &get();
    void            sync() { HDA_HIP(hipStreamSynchronize(stream)); }

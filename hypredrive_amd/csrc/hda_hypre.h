@@ -43,7 +43,7 @@ struct hypre_IJMatrix_struct {
    void adopt_device(int nloc, int nnz, hda::DArray<int> &rowptr, hda::DArray<long long> &gcols, hda::DArray<double> &vals);
 };
 
-enum hda_solver_kind { HDA_SOLVER_PCG = 1, HDA_SOLVER_GMRES = 2, HDA_SOLVER_AMG = 3, HDA_SOLVER_ILU = 4, HDA_SOLVER_FGMRES = 5, HDA_SOLVER_BICGSTAB = 6 };
+enum hda_solver_kind { HDA_SOLVER_PCG = 1, HDA_SOLVER_GMRES = 2, HDA_SOLVER_AMG = 3, HDA_SOLVER_ILU = 4, HDA_SOLVER_FGMRES = 5, HDA_SOLVER_BICGSTAB = 6, HDA_SOLVER_MGR = 7 };
 
 struct hypre_Solver_struct {
    int                       kind = 0;
@@ -61,6 +61,14 @@ struct hypre_Solver_struct {
    hda::IluParams            ilup;
    int                       ilu_type = 0, ilu_fill = 0, ilu_reordering = 0; // checked at Setup: bj-iluk / 0 / 0 only
    hda::DArray<double>       ilu_r, ilu_c;
+   // HYPRE_MGR* handle: what the setters recorded (hypre's per-level arrays, copied), built at Setup
+   std::unique_ptr<hda::Mgr>     mgr;
+   int                           mgr_block_size = 0, mgr_levels = 0, mgr_max_iter = 1, mgr_cycle = 1, mgr_frelax_cycle = 1, mgr_gsmooth_cycle = 1;
+   double                        mgr_coarse_th = 0.0;
+   std::vector<std::vector<int>> mgr_c_labels; // C labels of every reduction level
+   const HYPRE_Int              *mgr_marker = nullptr; // borrowed until Setup, as in hypre
+   std::vector<int>              mgr_frelax, mgr_fsweeps, mgr_interp, mgr_restrict, mgr_coarse_method, mgr_gsmooth, mgr_giters;
+   HYPRE_Solver                  mgr_csolver = nullptr;
    hda::KrylovResult         last;
    int                       amg_iters = 0;
    double                    amg_rel   = 0.0;

@@ -1231,6 +1231,140 @@ extern "C" HYPRE_Int HYPRE_ILUSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
 HY_GETTER(HYPRE_ILUGetNumIterations, HYPRE_Int, s->amg_iters)
 HY_GETTER(HYPRE_ILUGetFinalRelativeResidualNorm, HYPRE_Real, s->amg_rel)
 
+// ------------------------------------------------------------------------ MGR
+// HYPRE_MGR* as driven by hypredrv_MGRCreate (reference src/internal/mgr.c:3782-3808 base settings, per-level
+// arrays after :3820).  hypre's calling convention is kept: C points of every reduction level by dof label
+// (SetCpointsByPointMarkerArray), per-level option arrays, a BoomerAMG handle as coarse solver.
+
+extern "C" HYPRE_Int HYPRE_MGRCreate(HYPRE_Solver *solver)
+{
+   auto *s = new hypre_Solver_struct();
+   s->kind = HDA_SOLVER_MGR;
+   *solver = s;
+   return 0;
+}
+extern "C" HYPRE_Int HYPRE_MGRDestroy(HYPRE_Solver s) { return HYPRE_BoomerAMGDestroy(s); }
+extern "C" HYPRE_Int HYPRE_MGRSetCpointsByPointMarkerArray(HYPRE_Solver s, HYPRE_Int block_size, HYPRE_Int max_num_levels,
+                                                           HYPRE_Int *num_block_coarse_points, HYPRE_Int **block_coarse_indexes,
+                                                           HYPRE_Int *point_marker_array)
+{
+   if (!s || max_num_levels < 0 || (max_num_levels > 0 && (!num_block_coarse_points || !block_coarse_indexes)))
+      return hypre_set_error(HYPRE_ERROR_ARG, "HYPRE_MGRSetCpointsByPointMarkerArray: bad arguments");
+   s->mgr_block_size = block_size;
+   s->mgr_levels     = max_num_levels;
+   s->mgr_marker     = point_marker_array;
+   s->mgr_c_labels.assign((size_t)max_num_levels, {});
+   for (int l = 0; l < max_num_levels; l++)
+      s->mgr_c_labels[(size_t)l].assign(block_coarse_indexes[l], block_coarse_indexes[l] + num_block_coarse_points[l]);
+   return 0;
+}
+#define HY_MGR_LEVEL_ARRAY(fn, member)                                                                       \
+   extern "C" HYPRE_Int fn(HYPRE_Solver s, HYPRE_Int *v)                                                      \
+   {                                                                                                         \
+      if (!s || (!v && s->mgr_levels > 0)) return hypre_set_error(HYPRE_ERROR_ARG, #fn ": null argument");   \
+      s->member.assign(v, v + s->mgr_levels);                                                                \
+      return 0;                                                                                              \
+   }
+HY_MGR_LEVEL_ARRAY(HYPRE_MGRSetLevelFRelaxType, mgr_frelax)
+HY_MGR_LEVEL_ARRAY(HYPRE_MGRSetLevelNumRelaxSweeps, mgr_fsweeps)
+HY_MGR_LEVEL_ARRAY(HYPRE_MGRSetLevelInterpType, mgr_interp)
+HY_MGR_LEVEL_ARRAY(HYPRE_MGRSetLevelRestrictType, mgr_restrict)
+HY_MGR_LEVEL_ARRAY(HYPRE_MGRSetCoarseGridMethod, mgr_coarse_method)
+HY_MGR_LEVEL_ARRAY(HYPRE_MGRSetLevelSmoothType, mgr_gsmooth)
+HY_MGR_LEVEL_ARRAY(HYPRE_MGRSetLevelSmoothIters, mgr_giters)
+HY_SETTER(HYPRE_MGRSetNonCpointsToFpoints, HYPRE_Int, (void)v) // every label is either C or F here
+HY_SETTER(HYPRE_MGRSetPMaxElmts, HYPRE_Int, (void)v)           // truncation of the classical-modified interpolation only
+HY_SETTER(HYPRE_MGRSetNonGalerkinMaxElmts, HYPRE_Int, (void)v) // non-Galerkin coarse grids only
+HY_SETTER(HYPRE_MGRSetMaxIter, HYPRE_Int, s->mgr_max_iter = v)
+HY_SETTER(HYPRE_MGRSetTol, HYPRE_Real, s->ap.tol = v)
+HY_SETTER(HYPRE_MGRSetPrintLevel, HYPRE_Int, s->ap.print_level = v)
+HY_SETTER(HYPRE_MGRSetCycleType, HYPRE_Int, s->mgr_cycle = v)
+HY_SETTER(HYPRE_MGRSetFRelaxCycle, HYPRE_Int, s->mgr_frelax_cycle = v)
+HY_SETTER(HYPRE_MGRSetGlobalSmoothCycle, HYPRE_Int, s->mgr_gsmooth_cycle = v)
+HY_SETTER(HYPRE_MGRSetTruncateCoarseGridThreshold, HYPRE_Real, s->mgr_coarse_th = v)
+HY_SETTER(HYPRE_MGRSetRelaxType, HYPRE_Int, (void)v) // per-level F-relaxation types are given explicitly
+extern "C" HYPRE_Int HYPRE_MGRSetCoarseSolver(HYPRE_Solver s, HYPRE_PtrToSolverFcn, HYPRE_PtrToSolverFcn, HYPRE_Solver coarse)
+{
+   if (!s) return hypre_set_error(HYPRE_ERROR_ARG, "HYPRE_MGRSetCoarseSolver: null solver");
+   s->mgr_csolver = coarse;
+   return 0;
+}
+
+extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector, HYPRE_ParVector)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   HDA_REQUIRE(s && s->kind == HDA_SOLVER_MGR, "MGRSetup: not an MGR handle");
+   HDA_REQUIRE(A && A->assembled, "MGRSetup needs an assembled matrix");
+   HDA_REQUIRE(s->mgr_levels > 0 && s->mgr_marker, "MGRSetup: no C points were set (HYPRE_MGRSetCpointsByPointMarkerArray)");
+   HDA_REQUIRE(s->mgr_cycle == 1, "MGR: only V-cycles (cycle 1) are implemented");
+   HDA_REQUIRE(s->mgr_frelax_cycle == 1 && s->mgr_gsmooth_cycle == 1, "MGR: only pre-smoothing (cycle_smooth_pos 1) is implemented");
+   HDA_REQUIRE(s->mgr_coarse_th == 0.0, "MGR: coarse_th (coarse grid truncation) is not implemented");
+   HDA_REQUIRE(!s->mgr_csolver || s->mgr_csolver->kind == HDA_SOLVER_AMG, "MGR coarsest_level: only BoomerAMG is implemented");
+   MgrParams p;
+   p.max_iter = s->mgr_max_iter;
+   if (s->mgr_csolver) p.coarse = s->mgr_csolver->ap;
+   else { AmgParams d; p.coarse = d; }
+   p.coarse.max_iter = 1; // one V-cycle per MGR cycle (amg.c:224-226 defaults)
+   // F labels of level l = C labels of level l-1 (all labels of the marker array for l = 0) that are no longer C
+   std::vector<int> labels(s->mgr_marker, s->mgr_marker + A->nloc);
+   std::vector<int> prev;
+   {
+      std::vector<int> seen = labels;
+      std::sort(seen.begin(), seen.end());
+      seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+      prev = seen;
+   }
+   auto at = [&](const std::vector<int> &v, int l, int dflt) { return (size_t)l < v.size() ? v[(size_t)l] : dflt; };
+   for (int l = 0; l < s->mgr_levels; l++)
+   {
+      MgrLevelParams   q;
+      std::vector<int> c = s->mgr_c_labels[(size_t)l];
+      std::sort(c.begin(), c.end());
+      for (int lab : prev)
+         if (!std::binary_search(c.begin(), c.end(), lab)) q.f_labels.push_back(lab);
+      q.interp_type   = at(s->mgr_interp, l, 0);
+      q.restrict_type = at(s->mgr_restrict, l, 0);
+      q.coarse_type   = at(s->mgr_coarse_method, l, 0);
+      q.frelax_type   = at(s->mgr_frelax, l, 7);
+      q.frelax_sweeps = at(s->mgr_fsweeps, l, 1);
+      q.grelax_type   = at(s->mgr_gsmooth, l, -1);
+      q.grelax_sweeps = at(s->mgr_giters, l, 1);
+      if (q.grelax_sweeps <= 0) q.grelax_type = -1; // hypre: no global smoothing without sweeps
+      p.levels.push_back(q);
+      prev = c;
+   }
+   s->mgr = std::make_unique<Mgr>(p);
+   s->mgr->setup(A->A, labels);
+   hda_register_precond_veclen(s->mgr->vec_len0());
+   HY_CATCH
+}
+
+extern "C" HYPRE_Int HYPRE_MGRSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
+{
+   HY_NEED_DEVICE;
+   HY_TRY
+   HDA_REQUIRE(s && s->mgr, "MGRSolve before MGRSetup");
+   x->ensure_device();
+   PrecondHints  &h    = precond_hints();
+   const size_t   need = s->mgr->vec_len0();
+   double        *xp   = x->data();
+   DArray<double> xe;
+   const bool     staged = x->capacity < need;
+   if (staged)
+   {
+      xe.alloc(need);
+      copy(A->nloc, x->data(), xe.data());
+      xp = xe.data();
+   }
+   s->mgr->solve(b->data(), xp, h.zero_guess);
+   s->amg_iters = std::max(s->mgr_max_iter, 1);
+   if (staged) copy(A->nloc, xp, x->data());
+   HY_CATCH
+}
+HY_GETTER(HYPRE_MGRGetNumIterations, HYPRE_Int, s->amg_iters)
+HY_GETTER(HYPRE_MGRGetFinalRelativeResidualNorm, HYPRE_Real, s->amg_rel)
+
 HY_GETTER(HYPRE_BoomerAMGGetNumIterations, HYPRE_Int, s->amg_iters)
 HY_GETTER(HYPRE_BoomerAMGGetFinalRelativeResidualNorm, HYPRE_Real, s->amg_rel)
 HY_GETTER(HYPRE_BoomerAMGGetNumLevels, HYPRE_Int, s->amg ? s->amg->num_levels() : 0)

@@ -157,6 +157,7 @@ struct hypredrv_struct {
    PreconCookie   cookie{nullptr};
    Stats          stats;
    std::vector<int> dofmap; // function / field label of every locally owned unknown
+   HYPRE_Solver     precon_aux = nullptr; // coarse solver owned together with an MGR preconditioner
    std::vector<HYPRE_IJVector> state; // borrowed time-level vectors (host resident), logical index i = state[(state_first + i) % n]
    int            state_first = 0;
    int            current_system_index = -1;
@@ -308,6 +309,7 @@ extern "C" uint32_t HYPREDRV_Destroy(HYPREDRV_t *hp)
    hypredrv_struct *h = *hp;
    if (h->solver) HYPRE_ParCSRPCGDestroy(h->solver); // every Krylov handle is the same struct
    if (h->precon) HYPRE_BoomerAMGDestroy(h->precon);
+   if (h->precon_aux) HYPRE_BoomerAMGDestroy(h->precon_aux);
    destroy_system(h);
    delete h;
    *hp = nullptr;
@@ -680,6 +682,7 @@ extern "C" uint32_t HYPREDRV_LinearSystemBuild(HYPREDRV_t h)
    if (HYPREDRV_LinearSystemSetRHS(h, nullptr)) return g_err;
    if (HYPREDRV_LinearSystemSetInitialGuess(h, nullptr)) return g_err;
    HYPREDRV_LinearSystemSetPrecMatrix(h, nullptr);
+   if (HYPREDRV_LinearSystemReadDofmap(h)) return g_err; // src/HYPREDRV.c LinearSystemBuild: the dofmap file, when one is named
    h->stats.ls_counter++;
    if (!h->mypid)
    {
@@ -1121,7 +1124,44 @@ extern "C" uint32_t HYPREDRV_StatsLevelPrint(HYPREDRV_t h, int level)
 extern "C" uint32_t HYPREDRV_LinearSystemReadDofmap(HYPREDRV_t h)
 {
    CHECK_INIT_OBJ(h);
-   if (!h->args.ls.dofmap_filename.empty()) return err_set(HYPREDRV_ERROR_UNSUPPORTED_AMD, "dofmap files (MGR) are not supported by this build");
+   // hypredrv_IntArrayParRead (reference src/internal/containers.c:443-620): parts prefix.%05d[.bin], a count then the labels
+   // (ASCII), or a size_t count then int32 labels (binary); the parts are dealt to the ranks in order
+   if (h->args.ls.dofmap_filename.empty()) return g_err;
+   std::string prefix = h->args.ls.dofmap_filename;
+   if (!h->args.ls.dirname.empty() && prefix[0] != '/') prefix = h->args.ls.dirname + "/" + prefix;
+   auto exists = [](const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; };
+   char buf[64];
+   snprintf(buf, sizeof buf, ".%05d.bin", 0);
+   const bool binary = exists(prefix + buf);
+   int        gparts = 0;
+   for (;; gparts++)
+   {
+      snprintf(buf, sizeof buf, binary ? ".%05d.bin" : ".%05d", gparts);
+      if (!exists(prefix + buf)) break;
+   }
+   if (gparts < h->nprocs) return err_set(ERR_FILE_UNEXPECTED_ENTRY, "Invalid dofmap filename \"" + prefix + "\" or invalid number of parts!");
+   int nparts = gparts / h->nprocs + (h->mypid < gparts % h->nprocs ? 1 : 0);
+   int first  = h->mypid * (gparts / h->nprocs) + std::min(h->mypid, gparts % h->nprocs);
+   h->dofmap.clear();
+   for (int part = first; part < first + nparts; part++)
+   {
+      snprintf(buf, sizeof buf, binary ? ".%05d.bin" : ".%05d", part);
+      FILE *f = fopen((prefix + buf).c_str(), binary ? "rb" : "r");
+      if (!f) return err_set(ERR_FILE_NOT_FOUND, "cannot open " + prefix + buf);
+      size_t n = 0, got = 0;
+      if ((binary ? fread(&n, sizeof(size_t), 1, f) : (size_t)fscanf(f, "%zu", &n)) != 1)
+      {
+         fclose(f);
+         return err_set(ERR_FILE_UNEXPECTED_ENTRY, "Invalid number of header entries!");
+      }
+      const size_t at = h->dofmap.size();
+      h->dofmap.resize(at + n);
+      if (binary) got = fread(h->dofmap.data() + at, sizeof(int), n, f);
+      else
+         while (got < n && fscanf(f, "%d", &h->dofmap[at + got]) == 1) got++;
+      fclose(f);
+      if (got != n) return err_set(ERR_FILE_UNEXPECTED_ENTRY, "Expected " + std::to_string(n) + ", but found " + std::to_string(got) + " coefficients!");
+   }
    return g_err;
 }
 // bytes THIS rank streams per Krylov iteration (operator product + vector updates) and per
@@ -1231,7 +1271,9 @@ static HYPRE_Int PreconSetupDispatch(HYPRE_Solver cookie, HYPRE_Matrix A, HYPRE_
 {
    hypredrv_struct *h = ((PreconCookie *)(void *)cookie)->self;
    annotate(h, "prec", true);
-   HYPRE_Int ierr = (h->precon->kind == HDA_SOLVER_ILU) ? HYPRE_ILUSetup(h->precon, A, b, x) : HYPRE_BoomerAMGSetup(h->precon, A, b, x);
+   HYPRE_Int ierr = (h->precon->kind == HDA_SOLVER_ILU)   ? HYPRE_ILUSetup(h->precon, A, b, x)
+                    : (h->precon->kind == HDA_SOLVER_MGR) ? HYPRE_MGRSetup(h->precon, A, b, x)
+                                                          : HYPRE_BoomerAMGSetup(h->precon, A, b, x);
    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
    annotate(h, "prec", false);
    h->precon_is_setup = (ierr == 0);
@@ -1241,7 +1283,9 @@ static HYPRE_Int PreconSetupDispatch(HYPRE_Solver cookie, HYPRE_Matrix A, HYPRE_
 static HYPRE_Int PreconSolveDispatch(HYPRE_Solver cookie, HYPRE_Matrix A, HYPRE_Vector b, HYPRE_Vector x)
 {
    hypredrv_struct *h = ((PreconCookie *)(void *)cookie)->self;
-   return (h->precon->kind == HDA_SOLVER_ILU) ? HYPRE_ILUSolve(h->precon, A, b, x) : HYPRE_BoomerAMGSolve(h->precon, A, b, x);
+   return (h->precon->kind == HDA_SOLVER_ILU)   ? HYPRE_ILUSolve(h->precon, A, b, x)
+          : (h->precon->kind == HDA_SOLVER_MGR) ? HYPRE_MGRSolve(h->precon, A, b, x)
+                                                : HYPRE_BoomerAMGSolve(h->precon, A, b, x);
 }
 
 // hypredrv_ILUCreate (reference src/internal/ilu.c:63-115): same setter sequence
@@ -1325,6 +1369,77 @@ static void amg_create(const AmgArgs &a, HYPRE_Solver *out)
    *out = p;
 }
 
+// hypredrv_MGRCreate (reference src/internal/mgr.c:3449-3900): C points of every reduction level by dof label, the
+// per-level option arrays, BoomerAMG as coarse solver -- handed over through hypre's own MGR calls
+static uint32_t mgr_create(hypredrv_struct *h, const MgrArgs &a)
+{
+   if (h->dofmap.empty())
+      return err_set(ERR_MISSING_DOFMAP, "MGR needs a dofmap (linear_system.dofmap_filename, HYPREDRV_LinearSystemSetDofmap or ...SetInterleavedDofmap)");
+   if (a.level.empty()) return err_set(ERR_MISSING_KEY, "preconditioner.mgr.level: at least level 0 with its f_dofs is needed");
+   if (a.coarsest_type > 0 || (!a.coarsest_block.empty() && a.coarsest_block != "reuse"))
+      return err_set(ERR_INVALID_PRECON | HYPREDRV_ERROR_UNSUPPORTED_AMD, "MGR coarsest_level: only BoomerAMG is implemented on MI355X");
+   const int nlev = (int)a.level.size();
+   // labels present (every rank sees the same set in a well-formed dofmap; one rank here)
+   std::vector<int> cur = h->dofmap;
+   std::sort(cur.begin(), cur.end());
+   cur.erase(std::unique(cur.begin(), cur.end()), cur.end());
+   const int nlabels = cur.empty() ? 0 : cur.back() + 1;
+   std::vector<std::vector<HYPRE_Int>> c_dofs((size_t)nlev);
+   std::vector<HYPRE_Int>              num_c((size_t)nlev), frelax((size_t)nlev), fsweeps((size_t)nlev), interp((size_t)nlev), restr((size_t)nlev),
+      coarse((size_t)nlev), gsm((size_t)nlev), git((size_t)nlev);
+   std::vector<HYPRE_Int *> c_ptr((size_t)nlev);
+   for (int l = 0; l < nlev; l++)
+   {
+      const MgrLevelArgs &L = a.level[(size_t)l];
+      if (L.f_dofs.empty()) return err_set(ERR_MISSING_KEY, "preconditioner.mgr.level." + std::to_string(l) + ".f_dofs is missing");
+      for (const std::string *b : {&L.f_block, &L.g_block})
+         if (!b->empty() && *b != "reuse")
+            return err_set(ERR_INVALID_PRECON | HYPREDRV_ERROR_UNSUPPORTED_AMD,
+                           "MGR level " + std::to_string(l) + ": a nested '" + *b + "' relaxation solver is not implemented on MI355X");
+      for (int f : L.f_dofs)
+         if (!std::binary_search(cur.begin(), cur.end(), f))
+            return err_set(ERR_INVALID_VAL, "MGR level " + std::to_string(l) + ": f_dofs label " + std::to_string(f) + " is not an unknown of this level");
+      for (int lab : cur)
+         if (std::find(L.f_dofs.begin(), L.f_dofs.end(), lab) == L.f_dofs.end()) c_dofs[(size_t)l].push_back(lab);
+      num_c[(size_t)l]   = (HYPRE_Int)c_dofs[(size_t)l].size();
+      c_ptr[(size_t)l]   = c_dofs[(size_t)l].data();
+      frelax[(size_t)l]  = L.f_type;
+      fsweeps[(size_t)l] = L.f_type < 0 ? 0 : L.f_sweeps;
+      interp[(size_t)l]  = L.prolongation_type;
+      restr[(size_t)l]   = L.restriction_type;
+      coarse[(size_t)l]  = L.coarse_level_type;
+      gsm[(size_t)l]     = L.g_type;
+      git[(size_t)l]     = L.g_type < 0 ? 0 : L.g_sweeps;
+      cur.assign(c_dofs[(size_t)l].begin(), c_dofs[(size_t)l].end());
+   }
+   HYPRE_Solver p = nullptr;
+   HYPRE_MGRCreate(&p);
+   HYPRE_MGRSetCpointsByPointMarkerArray(p, nlabels, nlev, num_c.data(), c_ptr.data(), h->dofmap.data());
+   HYPRE_MGRSetNonCpointsToFpoints(p, a.non_c_to_f);
+   HYPRE_MGRSetPMaxElmts(p, a.pmax);
+   HYPRE_MGRSetMaxIter(p, a.max_iter);
+   HYPRE_MGRSetTol(p, a.tolerance);
+   HYPRE_MGRSetPrintLevel(p, a.print_level);
+   HYPRE_MGRSetCycleType(p, a.cycle);
+   HYPRE_MGRSetFRelaxCycle(p, 1);
+   HYPRE_MGRSetGlobalSmoothCycle(p, 1);
+   HYPRE_MGRSetTruncateCoarseGridThreshold(p, a.coarse_th);
+   HYPRE_MGRSetRelaxType(p, a.relax_type);
+   HYPRE_MGRSetLevelFRelaxType(p, frelax.data());
+   HYPRE_MGRSetLevelNumRelaxSweeps(p, fsweeps.data());
+   HYPRE_MGRSetLevelInterpType(p, interp.data());
+   HYPRE_MGRSetLevelRestrictType(p, restr.data());
+   HYPRE_MGRSetCoarseGridMethod(p, coarse.data());
+   HYPRE_MGRSetLevelSmoothType(p, gsm.data());
+   HYPRE_MGRSetLevelSmoothIters(p, git.data());
+   HYPRE_MGRSetNonGalerkinMaxElmts(p, a.nonglk_max_elmts);
+   amg_create(a.coarsest_amg, &h->precon_aux);
+   HYPRE_MGRSetCoarseSolver(p, HYPRE_BoomerAMGSolve, HYPRE_BoomerAMGSetup, h->precon_aux);
+   h->precon = p;
+   consume_hypre_errors();
+   return g_err;
+}
+
 extern "C" uint32_t HYPREDRV_PreconCreate(HYPREDRV_t h)
 {
    CHECK_INIT_OBJ(h);
@@ -1333,6 +1448,7 @@ extern "C" uint32_t HYPREDRV_PreconCreate(HYPREDRV_t h)
    // src/HYPREDRV.c:2801-2808: an existing preconditioner is recreated only when the reuse policy says so
    if (h->precon && !reuse_should_rebuild(h)) return g_err;
    if (h->precon) { HYPRE_BoomerAMGDestroy(h->precon); h->precon = nullptr; }
+   if (h->precon_aux) { HYPRE_BoomerAMGDestroy(h->precon_aux); h->precon_aux = nullptr; }
    h->precon_is_setup  = false;
    const PreconArgs &p = h->args.precon();
    if (p.method == 99) return g_err; // none
@@ -1342,9 +1458,10 @@ extern "C" uint32_t HYPREDRV_PreconCreate(HYPREDRV_t h)
       consume_hypre_errors();
       return g_err;
    }
+   if (p.method == 1) return mgr_create(h, p.mgr);
    if (p.method != 0)
       return err_set(ERR_INVALID_PRECON | HYPREDRV_ERROR_UNSUPPORTED_AMD,
-                     "preconditioner '" + p.method_name + "' is not implemented on MI355X yet (BoomerAMG and ILU only)");
+                     "preconditioner '" + p.method_name + "' is not implemented on MI355X yet (BoomerAMG, ILU and MGR only)");
    amg_create(p.amg, &h->precon);
    // hypredrv_AMGSetDofFunc (reference src/internal/amg.c:792-862): the dofmap names the function of
    // every local unknown when its labels fit [0, num_functions); otherwise hypre's interleaved default
@@ -1535,6 +1652,7 @@ extern "C" uint32_t HYPREDRV_PreconApply(HYPREDRV_t h, HYPRE_Vector b, HYPRE_Vec
    API_TRY
    if (!h->precon || !h->precon_is_setup) return err_set(ERR_INVALID_PRECON, "PreconApply requires a set-up preconditioner");
    if (h->precon->kind == HDA_SOLVER_ILU) HYPRE_ILUSolve(h->precon, h->mat_M ? h->mat_M : h->mat_A, b, x);
+   else if (h->precon->kind == HDA_SOLVER_MGR) HYPRE_MGRSolve(h->precon, h->mat_M ? h->mat_M : h->mat_A, b, x);
    else HYPRE_BoomerAMGSolve(h->precon, h->mat_M ? h->mat_M : h->mat_A, b, x);
    consume_hypre_errors();
    API_CATCH
@@ -1548,7 +1666,9 @@ extern "C" uint32_t HYPREDRV_PreconDestroy(HYPREDRV_t h)
    if (h->precon && reuse_should_rebuild(h))
    {
       HYPRE_BoomerAMGDestroy(h->precon);
+      if (h->precon_aux) HYPRE_BoomerAMGDestroy(h->precon_aux);
       h->precon          = nullptr;
+      h->precon_aux      = nullptr;
       h->precon_is_setup = false;
    }
    API_CATCH

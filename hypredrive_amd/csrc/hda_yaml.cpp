@@ -334,6 +334,123 @@ static void ilu_fields(Ctx &c, YNode &sec, IluArgs &a)
                  {"nsh_droptol", nullptr, &a.nsh_droptol, nullptr}, {"tolerance", nullptr, &a.tolerance, nullptr}});
 }
 
+// mgr block (reference src/internal/mgr.c:1736-1870; value maps :1553-1721)
+static const StrMap kMgrInterp = {{"injection", 0}, {"l1-jacobi", 1}, {"jacobi", 2}, {"classical-mod", 3}, {"approx-inv", 4}, {"blk-jacobi", 12},
+                                  {"blk-rowlump", 13}, {"blk-rowsum", 13}, {"blk-absrowsum", 14}};
+static const StrMap kMgrRestrict = {{"injection", 0}, {"jacobi", 2}, {"approx-inv", 3}, {"air_1", 4}, {"air_1.5", 5}, {"blk-jacobi", 12},
+                                    {"cpr-like", 13}, {"columped", 14}, {"columped-partial", 15}};
+static const StrMap kMgrCoarse = {{"rap", 0}, {"galerkin", 0}, {"non-galerkin", 1}, {"cpr-like-diag", 2}, {"cpr-like-bdiag", 3}, {"approx-inv", 4}, {"acc", 5}};
+static const StrMap kMgrFrelax = {{"", -1}, {"none", -1}, {"single", 7}, {"jacobi", 7}, {"l1-jacobi", 18}, {"v(1,0)", 1}, {"amg", 2}, {"mgr", 100},
+                                  {"chebyshev", 16}, {"ilu", 32}, {"ge", 9}, {"spdirect", 29}, {"ge-piv", 99}, {"ge-inv", 199}, {"fsai", 33}, {"schwarz", 34}};
+static const StrMap kMgrGrelax = {{"", -1}, {"none", -1}, {"blk-jacobi", 0}, {"blk-gs", 1}, {"mixed-gs", 2}, {"amg", 20}, {"h-fgs", 3}, {"h-bgs", 4},
+                                  {"ch-gs", 5}, {"h-ssor", 6}, {"euclid", 8}, {"2stg-fgs", 11}, {"2stg-bgs", 12}, {"l1-hfgs", 13}, {"l1-hbgs", 14},
+                                  {"ilu", 16}, {"spdirect", 29}, {"l1-hsgs", 88}, {"fsai", 33}, {"schwarz", 34}};
+static const StrMap kMgrCoarsest = {{"def", -1}, {"amg", 0}, {"spdirect", 29}, {"ilu", 32}, {"fsai", 33}, {"schwarz", 34}};
+static const StrMap kMgrCycle = {{"v", 1}, {"w", 2}, {"1", 1}, {"2", 2}};
+
+static void amg_fields(Ctx &c, YNode &sec, AmgArgs &a);
+
+static std::vector<int> int_list(Ctx &c, YNode &k, const char *what)
+{
+   std::string s = k.val;
+   for (auto &q : k.kids) s += " " + (q->val.empty() ? q->key : q->val); // block sequence form
+   for (char &ch : s)
+      if (ch == '[' || ch == ']' || ch == ',') ch = ' ';
+   std::istringstream is(s);
+   std::string        tok;
+   std::vector<int>   out;
+   while (is >> tok)
+   {
+      char *end = nullptr;
+      long  v   = strtol(tok.c_str(), &end, 10);
+      if (!end || *end) { c.fail(ERR_INVALID_VAL, std::string(what) + ": '" + tok + "' is not an integer label (symbolic dof labels are not supported)"); break; }
+      out.push_back((int)v);
+   }
+   return out;
+}
+
+// f_relaxation / g_relaxation: a flat name, or a block with type / num_sweeps / a nested solver
+static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweeps, std::string &block)
+{
+   if (k.kids.empty())
+   {
+      type = to_int(c, k, &map);
+      return;
+   }
+   for (auto &q : k.kids)
+   {
+      if (q->key == "type") type = to_int(c, *q, &map);
+      else if (q->key == "num_sweeps") sweeps = to_int(c, *q, nullptr);
+      else if (q->key == "amg" || q->key == "ilu" || q->key == "fsai" || q->key == "mgr" || q->key == "schwarz" || q->key == "reuse")
+      {
+         block = q->key;
+         auto it = map.find(q->key);
+         if (it != map.end()) type = it->second;
+      }
+      else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under '" + k.key + "'");
+   }
+}
+
+static void mgr_fields(Ctx &c, YNode &sec, MgrArgs &m)
+{
+   for (auto &k : sec.kids)
+   {
+      if (k->key == "level")
+      {
+         for (auto &lvn : k->kids)
+         {
+            char *end = nullptr;
+            long  id  = strtol(lvn->key.c_str(), &end, 10);
+            if (!end || *end || id < 0 || id > 30) { c.fail(ERR_INVALID_KEY, "mgr.level: '" + lvn->key + "' is not a level index (e.g. \"0: { f_dofs: [2] }\")"); continue; }
+            if ((size_t)id >= m.level.size()) m.level.resize((size_t)id + 1);
+            MgrLevelArgs &L = m.level[(size_t)id];
+            for (auto &q : lvn->kids)
+            {
+               if (q->key == "f_dofs") L.f_dofs = int_list(c, *q, "f_dofs");
+               else if (q->key == "prolongation_type") L.prolongation_type = to_int(c, *q, &kMgrInterp);
+               else if (q->key == "restriction_type") L.restriction_type = to_int(c, *q, &kMgrRestrict);
+               else if (q->key == "coarse_level_type") L.coarse_level_type = to_int(c, *q, &kMgrCoarse);
+               else if (q->key == "f_relaxation") mgr_relax(c, *q, kMgrFrelax, L.f_type, L.f_sweeps, L.f_block);
+               else if (q->key == "g_relaxation") mgr_relax(c, *q, kMgrGrelax, L.g_type, L.g_sweeps, L.g_block);
+               else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under 'mgr.level." + lvn->key + "'");
+            }
+         }
+      }
+      else if (k->key == "coarsest_level")
+      {
+         if (k->kids.empty()) m.coarsest_type = to_int(c, *k, &kMgrCoarsest);
+         else
+            for (auto &q : k->kids)
+            {
+               if (q->key == "type") m.coarsest_type = to_int(c, *q, &kMgrCoarsest);
+               else if (q->key == "amg") { m.coarsest_type = 0; amg_fields(c, *q, m.coarsest_amg); }
+               else if (q->key == "ilu" || q->key == "fsai" || q->key == "schwarz" || q->key == "spdirect" || q->key == "reuse" || q->key == "krylov")
+               {
+                  m.coarsest_block = q->key;
+                  auto it = kMgrCoarsest.find(q->key);
+                  if (it != kMgrCoarsest.end()) m.coarsest_type = it->second;
+               }
+               else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under 'mgr.coarsest_level'");
+            }
+      }
+      else if (k->key == "non_c_to_f") m.non_c_to_f = to_int(c, *k, nullptr);
+      else if (k->key == "pmax") m.pmax = to_int(c, *k, nullptr);
+      else if (k->key == "max_iter") m.max_iter = to_int(c, *k, nullptr);
+      else if (k->key == "num_levels") m.num_levels = to_int(c, *k, nullptr);
+      else if (k->key == "relax_type") m.relax_type = to_int(c, *k, &kRelax);
+      else if (k->key == "print_level") m.print_level = to_int(c, *k, nullptr);
+      else if (k->key == "nonglk_max_elmts") m.nonglk_max_elmts = to_int(c, *k, nullptr);
+      else if (k->key == "tolerance") m.tolerance = to_double(c, *k);
+      else if (k->key == "coarse_th") m.coarse_th = to_double(c, *k);
+      else if (k->key == "cycle")
+      {
+         if (k->kids.empty()) m.cycle = to_int(c, *k, &kMgrCycle);
+         else c.fail(ERR_INVALID_VAL, "mgr.cycle blocks (smoothing positions) are not implemented on MI355X");
+      }
+      else c.fail(ERR_INVALID_KEY, "unknown key '" + k->key + "' under 'mgr'");
+   }
+}
+
 static void krylov_fields(Ctx &c, YNode &sec, KrylovArgs &k)
 {
    apply_fields(c, sec,
@@ -609,6 +726,7 @@ static void parse_precon_body(Ctx &c, YNode &node, std::vector<PreconArgs> &vari
             PreconArgs v = p;
             if (p.method == 0) amg_fields(c, *item, v.amg);
             else if (p.method == 2) ilu_fields(c, *item, v.ilu);
+            else if (p.method == 1) mgr_fields(c, *item, v.mgr);
             variants.push_back(v);
          }
       }
@@ -616,6 +734,7 @@ static void parse_precon_body(Ctx &c, YNode &node, std::vector<PreconArgs> &vari
       {
          if (p.method == 0) amg_fields(c, *ch, p.amg);
          else if (p.method == 2) ilu_fields(c, *ch, p.ilu);
+         else if (p.method == 1) mgr_fields(c, *ch, p.mgr);
          variants.push_back(p);
       }
    }

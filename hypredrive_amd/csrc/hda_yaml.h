@@ -93,11 +93,28 @@ struct AmgArgs { // AMG_args, GPU-branch defaults of src/internal/amg.c:120-238
       if (e && !strcmp(e, "cpu")) { type = 10; down_type = 13; up_type = 14; mod_rap2 = 0; keep_transpose = 0; }
    }
 };
+// MGR_args / MGRlvl_args (reference include/internal/mgr.h:132-178; defaults src/internal/mgr.c:1226-1330)
+struct MgrLevelArgs {
+   std::vector<int> f_dofs;
+   int prolongation_type = 0, restriction_type = 0, coarse_level_type = 0;
+   int f_type = 7, f_sweeps = 1; // f_relaxation
+   int g_type = -1, g_sweeps = 1; // g_relaxation
+   std::string f_block, g_block;  // nested solver blocks (amg / ilu / ...) named here are not implemented
+};
+struct MgrArgs {
+   int    non_c_to_f = 1, pmax = 0, max_iter = 1, num_levels = 0, relax_type = 7, print_level = 0, nonglk_max_elmts = 1, cycle = 1;
+   double tolerance = 0.0, coarse_th = 0.0;
+   std::vector<MgrLevelArgs> level;
+   int         coarsest_type = -1; // -1 / 0: BoomerAMG
+   std::string coarsest_block;     // anything but amg is not implemented
+   AmgArgs     coarsest_amg;
+};
 struct PreconArgs {
    int         method = 0; // 0 boomeramg, 1 mgr, 2 ilu, 3 fsai, ... 99 none
    std::string method_name = "amg";
    AmgArgs     amg;
    IluArgs     ilu;
+   MgrArgs     mgr;
 };
 // preconditioner.reuse (reference src/internal/precon_reuse.c:2280-2567): the static policy
 struct ReuseArgs {

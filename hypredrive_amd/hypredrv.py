@@ -19,6 +19,8 @@ ERROR_UNKNOWN_TIMING = 0x00800000
 ERROR_HYPRE_INTERNAL = 0x01000000
 ERROR_UNSUPPORTED_AMD = 0x02000000
 ERROR_MISSING_PRECON = 0x00008000
+ERROR_MISSING_DOFMAP = 0x00010000
+ERROR_MISSING_KEY = 0x00001000
 ERROR_INVALID_KEY = 0x00000100
 ERROR_INVALID_VAL = 0x00000200
 MPI_COMM_WORLD = 0x44000000

@@ -254,6 +254,39 @@ HYPRE_Int HYPRE_BoomerAMGSetILUDroptol(HYPRE_Solver solver, HYPRE_Real tol);
 HYPRE_Int HYPRE_BoomerAMGSetILUMaxRowNnz(HYPRE_Solver solver, HYPRE_Int n);
 HYPRE_Int HYPRE_BoomerAMGSetILUMaxIter(HYPRE_Solver solver, HYPRE_Int n);
 
+/* ---- MGR (reference src/internal/mgr.c:3782-3808 and the per-level arrays after :3820).  Implemented on MI355X: C points by
+ * dof label, prolongation injection / jacobi / l1-jacobi, restriction injection / jacobi / columped, Galerkin coarse grids,
+ * Jacobi / l1-Jacobi F-relaxation, hybrid (l1) Gauss-Seidel global relaxation, BoomerAMG coarse solver, V-cycle, one rank.
+ * Anything else is rejected at Setup. */
+HYPRE_Int HYPRE_MGRCreate(HYPRE_Solver *solver);
+HYPRE_Int HYPRE_MGRDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_MGRSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_MGRSetCpointsByPointMarkerArray(HYPRE_Solver solver, HYPRE_Int block_size, HYPRE_Int max_num_levels,
+                                                HYPRE_Int *num_block_coarse_points, HYPRE_Int **block_coarse_indexes,
+                                                HYPRE_Int *point_marker_array);
+HYPRE_Int HYPRE_MGRSetNonCpointsToFpoints(HYPRE_Solver solver, HYPRE_Int flag);
+HYPRE_Int HYPRE_MGRSetPMaxElmts(HYPRE_Solver solver, HYPRE_Int pmax);
+HYPRE_Int HYPRE_MGRSetNonGalerkinMaxElmts(HYPRE_Solver solver, HYPRE_Int n);
+HYPRE_Int HYPRE_MGRSetMaxIter(HYPRE_Solver solver, HYPRE_Int n);
+HYPRE_Int HYPRE_MGRSetTol(HYPRE_Solver solver, HYPRE_Real tol);
+HYPRE_Int HYPRE_MGRSetPrintLevel(HYPRE_Solver solver, HYPRE_Int level);
+HYPRE_Int HYPRE_MGRSetCycleType(HYPRE_Solver solver, HYPRE_Int cycle);
+HYPRE_Int HYPRE_MGRSetFRelaxCycle(HYPRE_Solver solver, HYPRE_Int pos);
+HYPRE_Int HYPRE_MGRSetGlobalSmoothCycle(HYPRE_Solver solver, HYPRE_Int pos);
+HYPRE_Int HYPRE_MGRSetTruncateCoarseGridThreshold(HYPRE_Solver solver, HYPRE_Real th);
+HYPRE_Int HYPRE_MGRSetRelaxType(HYPRE_Solver solver, HYPRE_Int type);
+HYPRE_Int HYPRE_MGRSetLevelFRelaxType(HYPRE_Solver solver, HYPRE_Int *types);
+HYPRE_Int HYPRE_MGRSetLevelNumRelaxSweeps(HYPRE_Solver solver, HYPRE_Int *sweeps);
+HYPRE_Int HYPRE_MGRSetLevelInterpType(HYPRE_Solver solver, HYPRE_Int *types);
+HYPRE_Int HYPRE_MGRSetLevelRestrictType(HYPRE_Solver solver, HYPRE_Int *types);
+HYPRE_Int HYPRE_MGRSetCoarseGridMethod(HYPRE_Solver solver, HYPRE_Int *methods);
+HYPRE_Int HYPRE_MGRSetLevelSmoothType(HYPRE_Solver solver, HYPRE_Int *types);
+HYPRE_Int HYPRE_MGRSetLevelSmoothIters(HYPRE_Solver solver, HYPRE_Int *iters);
+HYPRE_Int HYPRE_MGRSetCoarseSolver(HYPRE_Solver solver, HYPRE_PtrToSolverFcn solve, HYPRE_PtrToSolverFcn setup, HYPRE_Solver coarse_solver);
+HYPRE_Int HYPRE_MGRGetNumIterations(HYPRE_Solver solver, HYPRE_Int *n);
+HYPRE_Int HYPRE_MGRGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *r);
+
 /* ---- ILU (reference src/internal/ilu.c:63-115; op table src/internal/precon.c).  Implemented on
  * MI355X: type 0 (bj-iluk), fill level 0, no local reordering, exact or Jacobi-iterative triangular
  * solves; every other variant is rejected at Setup. */

@@ -131,7 +131,7 @@ def test_lifecycle_guards_and_error_bits(hd):
         hd.Hypredrv("solver: cgs\npreconditioner: amg\n")
     L.HYPREDRV_ErrorCodeClear()
     # unsupported preconditioner selections fail at Create, loudly
-    h3 = hd.Hypredrv("solver: pcg\npreconditioner: mgr\n")
+    h3 = hd.Hypredrv("solver: pcg\npreconditioner: fsai\n")
     assert L.HYPREDRV_PreconCreate(h3.h) & hd.ERROR_INVALID_PRECON
     L.HYPREDRV_ErrorCodeClear()
     # ILU is created from its YAML block (ilu.c:15-28 keys); unknown keys are rejected at parse time
@@ -190,3 +190,36 @@ def test_scaling_request_is_an_error(hd):
     with pytest.raises(hd.HypredrvError, match="scaling is not implemented"):
         hd.Hypredrv("solver:\n  pcg:\n    max_iter: 10\n  scaling:\n    enabled: yes\n    type: rhs_l2\npreconditioner: amg\n")
     hd.lib().HYPREDRV_ErrorCodeClear()
+
+
+EX3_MGR = ("solver: gmres\npreconditioner:\n  mgr:\n    level:\n      0:\n        f_dofs: [2]\n        prolongation_type: jacobi\n"
+           "      1:\n        f_dofs: [1]\n        g_relaxation: l1-hsgs\n        restriction_type: columped\n    coarsest_level: amg\n")
+
+
+def test_mgr_yaml_and_create(hd):
+    """The mgr block of the reference's examples/ex3.yml parses; creation needs a dofmap (ERROR_MISSING_DOFMAP) and
+    checks f_dofs against its labels; options outside the implemented subset are named."""
+    L = hd.lib()
+    h = hd.Hypredrv(EX3_MGR)
+    assert L.HYPREDRV_PreconCreate(h.h) & hd.ERROR_MISSING_DOFMAP
+    L.HYPREDRV_ErrorCodeClear()
+    assert L.HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, 5, 3) == 0
+    assert L.HYPREDRV_PreconCreate(h.h) == 0
+    assert L.HYPREDRV_PreconDestroy(h.h) == 0
+    h.close()
+    h = hd.Hypredrv(EX3_MGR.replace("f_dofs: [2]", "f_dofs: [7]"))
+    assert L.HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, 5, 3) == 0
+    assert L.HYPREDRV_PreconCreate(h.h) & hd.ERROR_INVALID_VAL
+    L.HYPREDRV_ErrorCodeClear()
+    h.close()
+    for text, msg in ((EX3_MGR.replace("coarsest_level: amg", "coarsest_level: spdirect"), "coarsest_level"),
+                      (EX3_MGR.replace("g_relaxation: l1-hsgs", "g_relaxation:\n          ilu:\n            max_iter: 1"), "nested 'ilu'")):
+        h = hd.Hypredrv(text)
+        assert L.HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, 5, 3) == 0
+        assert L.HYPREDRV_PreconCreate(h.h) & hd.ERROR_INVALID_PRECON
+        assert msg in hd.lib().HYPREDRV_AMD_LastErrorMessage().decode()
+        L.HYPREDRV_ErrorCodeClear()
+        h.close()
+    with pytest.raises(hd.HypredrvError, match="unknown key"):
+        hd.Hypredrv(EX3_MGR.replace("prolongation_type: jacobi", "prolongation: jacobi"))
+    L.HYPREDRV_ErrorCodeClear()
