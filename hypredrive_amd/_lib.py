@@ -329,7 +329,7 @@ class Amg:
 MGR_INTERP = {"injection": 0, "l1-jacobi": 1, "jacobi": 2}
 MGR_RESTRICT = {"injection": 0, "jacobi": 2, "columped": 14}
 MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18}
-MGR_GRELAX = {"none": -1, "h-fgs": 3, "h-bgs": 4, "h-ssor": 6, "l1-hfgs": 13, "l1-hbgs": 14, "l1-hsgs": 88}
+MGR_GRELAX = {"none": -1, "h-fgs": 3, "h-bgs": 4, "h-ssor": 6, "l1-hfgs": 13, "l1-hbgs": 14, "l1-hsgs": 88, "ilu": 16}
 
 
 class Mgr:

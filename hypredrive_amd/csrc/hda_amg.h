@@ -177,7 +177,7 @@ struct MgrLevelParams {
    int restrict_type = 0;              // restriction_type: 0 injection, 2 jacobi, 14 columped
    int coarse_type = 0;                // coarse_level_type: 0 rap
    int frelax_type = 7, frelax_sweeps = 1;   // f_relaxation: 7 jacobi, 18 l1-jacobi
-   int grelax_type = -1, grelax_sweeps = 1;  // g_relaxation: -1 none, 3/4/6/13/14 hybrid GS, 88 l1-hsgs
+   int grelax_type = -1, grelax_sweeps = 1;  // g_relaxation: -1 none, 3/4/6/13/14 hybrid GS, 88 l1-hsgs, 16 ilu
 };
 struct MgrParams {
    std::vector<MgrLevelParams> levels;
@@ -200,8 +200,9 @@ class Mgr {
       const DCsr    *A = nullptr;
       DCsr           P, R;
       DArray<int>    labels, cf, cidx;
-      DArray<double> dinvF, dinvG, f, u, u2, t;
+      DArray<double> dinvF, dinvG, f, u, u2, t, ilu_r, ilu_c;
       GsPlan         gs;
+      std::unique_ptr<Ilu> gilu; // g_relaxation ilu
       int            n = 0, nc = 0;
    };
    double *cycle(int l, const double *f, double *u, bool zero);

@@ -366,10 +366,12 @@ extern "C" uint32_t HYPREDRV_InputArgsParse(int argc, char **argv, HYPREDRV_t h)
    err_reset();
    API_TRY
    if (argc < 1 || !argv || !argv[0]) return err_set(ERR_MISSING_KEY, "no YAML input given");
-   std::string text, first(argv[0]);
+   std::string text, first(argv[0]), base_dir;
    // argv[0] is a file name or the YAML text itself (reference src/internal/args.c:1478-1487)
    if (first.find('\n') == std::string::npos && file_exists(first))
    {
+      const size_t slash = first.find_last_of('/');
+      if (slash != std::string::npos) base_dir = first.substr(0, slash);
       std::ifstream     f(first);
       std::stringstream ss;
       ss << f.rdbuf();
@@ -380,6 +382,8 @@ extern "C" uint32_t HYPREDRV_InputArgsParse(int argc, char **argv, HYPREDRV_t h)
    h->tree = YNode();
    std::string msg;
    uint32_t    e = yaml_parse(text, h->tree, msg);
+   if (e) return err_set(e, msg);
+   e = yaml_expand_includes(h->tree, base_dir, msg); // "include: file.yml" (solver / preconditioner blocks kept in their own files)
    if (e) return err_set(e, msg);
    // "-a|--args --path:to:key value ..." overrides (src/internal/main.c:23-31); a bare
    // "--path:key value" pair is accepted too (examples/src/C_laplacian/laplacian.c:362-365)

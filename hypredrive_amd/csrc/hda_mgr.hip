@@ -3,7 +3,7 @@
 // tree include/internal/mgr.h:132-178).  hypre is not part of the reference tree; this is the published
 // method (Ries / Trottenberg / Winter; hypre reference manual "MGR") for the option subset
 //   prolongation_type  injection | jacobi | l1-jacobi        restriction_type  injection | jacobi | columped
-//   f_relaxation       jacobi | l1-jacobi (n sweeps)          g_relaxation      none | hybrid (l1) Gauss-Seidel
+//   f_relaxation       jacobi | l1-jacobi (n sweeps)          g_relaxation      none | hybrid (l1) Gauss-Seidel | ilu (ILU(0))
 //   coarse_level_type  rap                                    coarsest_level    BoomerAMG (one V-cycle)
 // -- the same definition the CPU checker of the test suite restates.  PARITY UNPINNED against hypre: the
 // reference's MGR outputs need data sets that are not in its tree.  One rank only.
@@ -174,7 +174,8 @@ void Mgr::setup(const DCsr &A0, const std::vector<int> &labels0)
                   "MGR restriction_type: injection, jacobi and columped are implemented");
       HDA_REQUIRE(p.coarse_type == 0, "MGR coarse_level_type: only rap (Galerkin) is implemented");
       HDA_REQUIRE(p.frelax_type == 7 || p.frelax_type == 18, "MGR f_relaxation: jacobi (single) and l1-jacobi are implemented");
-      HDA_REQUIRE(p.grelax_type < 0 || gs_type(p.grelax_type), "MGR g_relaxation: none and the hybrid (l1) Gauss-Seidel types are implemented");
+      HDA_REQUIRE(p.grelax_type < 0 || gs_type(p.grelax_type) || p.grelax_type == 16,
+                  "MGR g_relaxation: none, the hybrid (l1) Gauss-Seidel types and ilu are implemented");
       HDA_REQUIRE(!p.f_labels.empty(), "MGR: a reduction level without f_dofs");
       const int n = A->nrows;
       L.A      = A;
@@ -226,7 +227,14 @@ void Mgr::setup(const DCsr &A0, const std::vector<int> &labels0)
                                                            L.R.val.data());
       }
       // global relaxation data
-      if (p.grelax_type >= 0)
+      if (p.grelax_type == 16)
+      { // hypre's default ILU as global smoother: block-Jacobi ILU(0), exact triangular solves
+         L.gilu = std::make_unique<Ilu>();
+         IluParams ip;
+         ip.max_iter = std::max(p.grelax_sweeps, 1);
+         L.gilu->setup(*A, ip);
+      }
+      else if (p.grelax_type >= 0)
       {
          DArray<double> d((size_t)n);
          const int      t = p.grelax_type == 88 ? 8 : p.grelax_type;
@@ -288,7 +296,12 @@ double *Mgr::cycle(int l, const double *f, double *u, bool zero)
    const DCsr           &A = *L.A;
    const int             n = L.n;
    double               *cur = u, *alt = L.u2.data();
-   if (p.grelax_type >= 0)
+   if (p.grelax_type == 16)
+   {
+      ilu_solve(*L.gilu, A, nullptr, f, cur, zero, L.ilu_r, L.ilu_c);
+      zero = false;
+   }
+   else if (p.grelax_type >= 0)
    {
       if (zero) fill(n, 0.0, cur);
       zero = false;

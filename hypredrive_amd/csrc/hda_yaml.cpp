@@ -312,6 +312,54 @@ static void apply_fields(Ctx &c, YNode &sec, const std::vector<Field> &f, const 
    }
 }
 
+static uint32_t expand_includes_rec(YNode &node, const std::string &base_dir, std::vector<std::string> &stack, std::string &message)
+{
+   for (size_t i = 0; i < node.kids.size(); i++)
+   {
+      YNode &k = *node.kids[i];
+      if (k.key == "include" && k.kids.empty() && !k.val.empty())
+      {
+         std::string path = k.val;
+         if (path[0] != '/' && !base_dir.empty()) path = base_dir + "/" + path;
+         if (stack.size() >= 10) { message = "YAML include depth exceeded max depth 10"; return ERR_YAML_TREE_INVALID; }
+         if (std::find(stack.begin(), stack.end(), path) != stack.end()) { message = "YAML include cycle detected at '" + path + "'"; return ERR_YAML_TREE_INVALID; }
+         FILE *f = fopen(path.c_str(), "r");
+         if (!f) { message = "cannot open included YAML file '" + path + "'"; return ERR_FILE_NOT_FOUND; }
+         std::string text;
+         char        buf[4096];
+         size_t      n;
+         while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+         fclose(f);
+         YNode    sub;
+         uint32_t e = yaml_parse(text, sub, message);
+         if (e) return e;
+         stack.push_back(path);
+         const size_t slash = path.find_last_of('/');
+         e                  = expand_includes_rec(sub, slash == std::string::npos ? std::string() : path.substr(0, slash), stack, message);
+         stack.pop_back();
+         if (e) return e;
+         // splice the included top-level entries where the include stood
+         std::vector<std::unique_ptr<YNode>> tail;
+         for (size_t j = i + 1; j < node.kids.size(); j++) tail.push_back(std::move(node.kids[j]));
+         node.kids.resize(i);
+         for (auto &q : sub.kids) node.kids.push_back(std::move(q));
+         const size_t added = node.kids.size() - i;
+         for (auto &q : tail) node.kids.push_back(std::move(q));
+         i += added;
+         i--;
+         continue;
+      }
+      uint32_t e = expand_includes_rec(k, base_dir, stack, message);
+      if (e) return e;
+   }
+   return 0;
+}
+uint32_t yaml_expand_includes(YNode &root, const std::string &base_dir, std::string &message)
+{
+   std::vector<std::string> stack;
+   return expand_includes_rec(root, base_dir, stack, message);
+}
+
 void KrylovArgs::defaults_for(int m)
 {
    *this  = KrylovArgs();
@@ -815,8 +863,6 @@ uint32_t args_from_yaml(YNode &root, bool lib_mode, InputArgs &args, std::string
          }
          if (args.precon_variants.empty()) c.fail(ERR_MISSING_PRECON, "preconditioner section names no preconditioner");
       }
-      else if (sec->key == "include")
-         c.fail(ERR_INVALID_KEY, "'include' expansion is not supported by this build");
       else
       { // the reference only looks its root sections up by name (args.c:235,261,300,982): anything else is left
         // unvisited and tolerated (its echo marks it "INVALID ENTRY"), e.g. the stray top-level 'ilu:' block of

@@ -39,6 +39,9 @@ uint32_t yaml_parse(const std::string &text, YNode &root, std::string &message);
 void     yaml_print(const YNode &root, FILE *out);
 // "--a:b:c value" override (reference: src/internal/yaml.c:2178)
 void     yaml_override(YNode &root, const std::string &path, const std::string &value);
+// "include: other.yml" anywhere in the tree is replaced by the parsed content of that file, looked up relative to
+// base_dir (reference src/internal/yaml.c:28-235: nested includes, depth limit, cycle detection)
+uint32_t yaml_expand_includes(YNode &root, const std::string &base_dir, std::string &message);
 
 struct GeneralArgs {
    std::string name, statistics_filename;

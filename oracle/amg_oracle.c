@@ -1485,7 +1485,8 @@ typedef struct {
    int      n, nc;
    int     *labels, *cf, *cidx;
    double  *dinvF, *l1g;
-   double  *f, *u, *t;
+   double  *f, *u, *t, *cor;
+   orc_ilu *gilu; /* g_relaxation ilu (type 16): ILU(0) of the level operator, hypre's default ILU */
    int      frelax_sweeps, grelax_type, grelax_sweeps;
 } mgr_level;
 
@@ -1610,7 +1611,12 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
       }
       free(dF); free(l1F); free(csum);
       /* global relaxation divisors */
-      if (L->grelax_type >= 0)
+      if (L->grelax_type == 16)
+      {
+         L->gilu = orc_ilu0_setup(A, 0, NULL, 1, 5, 5);
+         L->cor  = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+      }
+      else if (L->grelax_type >= 0)
       {
          L->l1g = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
          orc_l1_norms(A, (L->grelax_type == 18) ? 1 : 4, L->l1g);
@@ -1649,7 +1655,8 @@ mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
    }
    mgr_level *L = &M->lv[l];
    const int  n = L->n;
-   if (L->grelax_type >= 0)
+   if (L->grelax_type == 16 && L->gilu) ilu_iterate(L->gilu, L->A, L->grelax_sweeps, f, u, L->t, L->cor);
+   else if (L->grelax_type >= 0)
       for (int s = 0; s < L->grelax_sweeps; s++)
          orc_relax(L->A, L->l1g, L->grelax_type == 88 ? 8 : L->grelax_type, 1.0, f, u, L->t);
    for (int s = 0; s < L->frelax_sweeps; s++)
@@ -1681,7 +1688,8 @@ mgr_free(struct orc_mgr *M)
    {
       mgr_level *L = &M->lv[l];
       orc_csr_free(L->A); orc_csr_free(L->P); orc_csr_free(L->R);
-      free(L->labels); free(L->cf); free(L->cidx); free(L->dinvF); free(L->l1g); free(L->f); free(L->u); free(L->t);
+      free(L->labels); free(L->cf); free(L->cidx); free(L->dinvF); free(L->l1g); free(L->f); free(L->u); free(L->t); free(L->cor);
+      if (L->gilu) orc_ilu_free(L->gilu);
    }
    orc_csr_free(M->Ac);
    orc_amg_free(M->camg);

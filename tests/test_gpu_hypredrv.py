@@ -770,3 +770,37 @@ def test_reference_darcy_driver_unmodified():
         assert m and float(m.group(1)) < 1e-8, r.stdout[-2000:]
         row = re.search(r"^\|\s+0 \|.*\|\s+(\S+) \|\s+(\d+) \|$", r.stdout, re.M)
         assert row and float(row.group(1)) < 1e-9 and int(row.group(2)) <= 30
+
+
+def test_cli_include_and_ex4_style_mgr(tmp_path, orc):
+    """examples/ex5.yml of the reference keeps its solver and preconditioner blocks in files of their own
+    ("include: ex5-gmres.yml", "include: ex5-mgr.yml"); its MGR block (= ex4.yml's) uses ILU as global relaxation on the
+    second reduction level.  Same structure here on the generated 3-field system."""
+    (tmp_path / "inc-gmres.yml").write_text("gmres:\n  max_iter: 100\n  relative_tol: 1.0e-8\n")
+    (tmp_path / "inc-mgr.yml").write_text(
+        "mgr:\n  tolerance: 0.0\n  max_iter: 1\n  print_level: 0\n  coarse_th: 0.0\n  level:\n    0:\n      f_dofs: [2]\n      f_relaxation: jacobi\n"
+        "      g_relaxation: none\n      restriction_type: injection\n      prolongation_type: jacobi\n      coarse_level_type: rap\n\n    1:\n"
+        "      f_dofs: [1]\n      f_relaxation: jacobi\n      g_relaxation: ilu\n      restriction_type: columped\n      prolongation_type: injection\n"
+        "      coarse_level_type: rap\n\n  coarsest_level:\n    amg:\n      tolerance: 0.0\n      max_iter: 1\n      print_level: 0\n      coarsening:\n"
+        "        type: pmis\n        strong_th: 0.3\n")
+    d = os.path.join(ROOT, "data", "threefield", "np1")
+    (tmp_path / "main.yml").write_text(f"linear_system:\n  rhs_filename: {d}/IJ.out.b\n  matrix_filename: {d}/IJ.out.A\n  dofmap_filename: {d}/dofmap.out\n"
+                                       "solver:\n  include: inc-gmres.yml\n\npreconditioner:\n  include: inc-mgr.yml\n")
+    cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
+    r = subprocess.run([cli, "-q", str(tmp_path / "main.yml")], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    row = re.search(r"^\|\s+0 \|.*\|\s+(\S+) \|\s+(\d+) \|$", r.stdout, re.M)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_threefield import system
+    S, labels = system(16)
+    Ao = orc.Csr.from_scipy(S)
+    lev = [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="ilu", restriction_type="columped")]
+    ref = orc.gmres(Ao, np.ones(S.shape[0]), orc.MgrPrecond(Ao, labels, lev, orc.amg_params(True, strong_th=0.3)), orc.krylov_params(True, rtol=1e-8, max_iter=100))
+    assert row and int(row.group(2)) == ref["iters"] and float(row.group(1)) < 1e-8
+    # a missing include is an error, a cycle too
+    (tmp_path / "bad.yml").write_text("solver:\n  include: nowhere.yml\npreconditioner: amg\n")
+    r = subprocess.run([cli, "-q", str(tmp_path / "bad.yml")], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "nowhere.yml" in r.stdout + r.stderr
+    (tmp_path / "loop.yml").write_text("solver:\n  include: loop.yml\npreconditioner: amg\n")
+    r = subprocess.run([cli, "-q", str(tmp_path / "loop.yml")], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "cycle" in r.stdout + r.stderr
