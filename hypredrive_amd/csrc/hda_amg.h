@@ -169,6 +169,11 @@ class Amg {
    bool                  coarse_dense = false;
 };
 
+// row-partitioned sparse product and reverse halo sum (hda_amg_setup.hip), shared by the partitioned setups
+void dist_spgemm(const DCsr &X, const HaloPlan &hX, const DCsr &Y, const std::vector<long long> &y_ghosts,
+                 const std::vector<long long> &part_c, DCsr &C, std::vector<long long> &c_ghosts);
+void halo_reverse_add(const HaloPlan &h, double *x_ext);
+
 // ---- MGR (hda_mgr.hip): multigrid reduction by dof labels, BoomerAMG on the coarsest system.
 // Parameter contract: reference MGR_args / MGRlvl_args (include/internal/mgr.h:132-178), defaults src/internal/mgr.c:1226-1330.
 struct MgrLevelParams {
@@ -188,6 +193,9 @@ class Mgr {
  public:
    explicit Mgr(const MgrParams &p) : prm(p) {}
    void        setup(const DCsr &A, const std::vector<int> &labels); // labels: dofmap of the local rows; A is borrowed for level 0
+   // row block of a partitioned matrix: columns [owned | ghosts], hA its halo plan, part the row starts of all ranks
+   void        setup_dist(const DCsr &A, const HaloPlan &hA, const std::vector<long long> &part, const std::vector<long long> &ghost_gids,
+                          const std::vector<int> &labels);
    void        solve(const double *b, double *x, bool zero_guess);   // max_iter cycles
    int         num_reduction_levels() const { return (int)lv.size(); }
    const DCsr &matrix(int level, int which) const; // which 0 operator (level == reduction levels: coarsest), 1 P, 2 R
@@ -196,9 +204,12 @@ class Mgr {
 
  private:
    struct Level {
-      DCsr           A_own;
-      const DCsr    *A = nullptr;
-      DCsr           P, R;
+      DCsr            A_own;
+      const DCsr     *A = nullptr;
+      HaloPlan        hA_own, hP;
+      const HaloPlan *hA = nullptr;
+      size_t          flen = 0; // length the level's f / u need on behalf of the finer level's P
+      DCsr            P, R;
       DArray<int>    labels, cf, cidx;
       DArray<double> dinvF, dinvG, f, u, u2, t, ilu_r, ilu_c;
       GsPlan         gs;
@@ -206,10 +217,13 @@ class Mgr {
       int            n = 0, nc = 0;
    };
    double *cycle(int l, const double *f, double *u, bool zero);
-   std::vector<Level>   lv;
-   DCsr                 Ac;
-   std::unique_ptr<Amg> camg;
-   DArray<double>       fc, uc;
+   std::vector<Level>     lv;
+   DCsr                   Ac;
+   HaloPlan               hAc, hA0_none; // (hA0_none: the empty plan of a one-rank setup)
+   std::vector<long long> cparts, cghosts_;
+   size_t                 coarse_len = 0;
+   std::unique_ptr<Amg>   camg;
+   DArray<double>         fc, uc;
 };
 
 // ---- setup kernels (hda_amg_setup.hip); exposed for per-kernel parity tests -------------

@@ -2981,6 +2981,73 @@ void route_records(std::vector<std::vector<Rec>> &out, std::vector<Rec> &in)
 
 } // namespace
 
+// Row-partitioned product C = X * Y.  X: this rank's rows, columns [owned | ghosts] of a space whose owned rows
+// of Y this rank holds (hX = the halo plan of that space); Y: this rank's rows with columns [owned | y_ghosts]
+// of a second space with row starts part_c.  The rows of Y that X's ghost columns name are fetched from their
+// owners; the result comes back in solve layout, columns [owned | c_ghosts] (ascending global id).
+void dist_spgemm(const DCsr &X, const HaloPlan &hX, const DCsr &Y, const std::vector<long long> &y_ghosts,
+                 const std::vector<long long> &part_c, DCsr &C, std::vector<long long> &c_ghosts)
+{
+   Comm           &cm = Comm::world();
+   const long long lo = part_c[(size_t)cm.rank], hi = part_c[(size_t)cm.rank + 1];
+   const int       nown_c = (int)(hi - lo), nb = Y.nrows, ng = X.ncols - nb;
+   HDA_REQUIRE(ng >= 0 && ng == hX.nghost, "dist_spgemm: X's ghost columns do not match the halo plan");
+   HDA_REQUIRE(Y.ncols == nown_c + (int)y_ghosts.size(), "dist_spgemm: Y's ghost list does not match its columns");
+   DArray<long long> dgh, gcol((size_t)std::max(Y.nnz, 1));
+   {
+      std::vector<long long> g = y_ghosts;
+      if (g.empty()) g.push_back(0);
+      dgh.upload(g.data(), g.size());
+   }
+   if (Y.nnz) k_loc2gcol<<<std::min(ceil_div(Y.nnz, 256), 1 << 16), 256, 0, STREAM>>>(Y.nnz, Y.col.data(), nown_c, lo, dgh.data(), gcol.data());
+   HostRows H;
+   fetch_rows(hX.send_total, hX.send_idx.data(), hX.send_counts, ng, hX.recv_counts, Y.rowptr.data(), gcol.data(), Y.val.data(), H);
+   // column space of the extended Y: its own ghosts plus whatever the fetched rows reference
+   std::vector<long long> other = y_ghosts;
+   for (long long c : H.gcol)
+      if (c < lo || c >= hi) other.push_back(c);
+   IdSpace S;
+   S.set(lo, hi, other);
+   DArray<int> cmap((size_t)std::max(Y.ncols, 1));
+   if (nown_c) k_iota_i<<<ceil_div(nown_c, 256), 256, 0, STREAM>>>(nown_c, S.off(), cmap.data());
+   if (!y_ghosts.empty())
+   {
+      std::vector<int> gm(y_ghosts.size());
+      for (size_t g = 0; g < y_ghosts.size(); g++) gm[g] = S.of(y_ghosts[g]);
+      HDA_HIP(hipMemcpyAsync(cmap.data() + nown_c, gm.data(), 4 * gm.size(), hipMemcpyHostToDevice, STREAM));
+      Context::get().sync();
+   }
+   H.row.resize((size_t)ng);
+   H.col.resize(H.gcol.size());
+   for (int g = 0; g < ng; g++) H.row[(size_t)g] = nb + g; // X's ghost column g = row nb + g of the extended Y
+   for (size_t k = 0; k < H.gcol.size(); k++) H.col[k] = S.of(H.gcol[k]);
+   DCsr Yext, T;
+   assemble_csr(nb + ng, S.size(), 0, Y, cmap.data(), H, Yext);
+   spgemm(X, Yext, T);
+   localize_cols(T, S, C, c_ghosts);
+}
+
+__global__ __launch_bounds__(256) void k_scatter_add(int n, const int *__restrict__ idx, const double *__restrict__ src, double *dst)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) dst[idx[q]] += src[q];
+}
+// the ghost copies' values are added into their owners' entries (peer by peer, ascending rank: a fixed order)
+void halo_reverse_add(const HaloPlan &h, double *x_ext)
+{
+   Comm &cm = Comm::world();
+   if (cm.size == 1 || h.send_counts.empty()) return;
+   DArray<double> buf((size_t)std::max(h.send_total, 1));
+   cm.exchange_dev(x_ext + h.nloc, h.recv_counts.data(), buf.data(), h.send_counts.data());
+   int at = 0;
+   for (int p = 0; p < cm.size; p++)
+   { // indices inside one peer's list are distinct; different peers may name the same row
+      const int c = h.send_counts[(size_t)p];
+      if (c) k_scatter_add<<<ceil_div(c, 256), 256, 0, STREAM>>>(c, h.send_idx.data() + at, buf.data() + at, x_ext);
+      at += c;
+   }
+}
+
 void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<long long> &part0,
                                  const std::vector<long long> &ghost_gids0)
 {

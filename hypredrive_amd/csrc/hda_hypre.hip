@@ -1335,7 +1335,8 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
       prev = c;
    }
    s->mgr = std::make_unique<Mgr>(p);
-   s->mgr->setup(A->A, labels);
+   if (Comm::world().size > 1) s->mgr->setup_dist(A->A, A->halo, A->part, A->ghost_gids, labels);
+   else s->mgr->setup(A->A, labels);
    hda_register_precond_veclen(s->mgr->vec_len0());
    HY_CATCH
 }

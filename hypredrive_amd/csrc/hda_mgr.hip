@@ -6,7 +6,11 @@
 //   f_relaxation       jacobi | l1-jacobi (n sweeps)          g_relaxation      none | hybrid (l1) Gauss-Seidel | ilu (ILU(0))
 //   coarse_level_type  rap                                    coarsest_level    BoomerAMG (one V-cycle)
 // -- the same definition the CPU checker of the test suite restates.  PARITY UNPINNED against hypre: the
-// reference's MGR outputs need data sets that are not in its tree.  One rank only.
+// reference's MGR outputs need data sets that are not in its tree.
+// Row partitions: labels, C/F marks and coarse ids of the ghost columns come through the halo plan of the level's
+// operator; R reads the same ghost columns as A; P's ghost columns are the ghost C points; A_c = R (A P) is formed
+// by two row-partitioned products (dist_spgemm: the rows of the right factor that the ghost columns name are
+// fetched from their owners); the coarsest system goes to the row-partitioned BoomerAMG setup.
 //
 // Per reduction level the unknowns whose label is in f_labels are F points, the rest C points in their
 // relative order.  P = [W; I], R = [Z I] are built by row kernels (sequential sums per row: bit-identical to
@@ -16,6 +20,7 @@
 #include "hda_amg.h"
 
 #include <algorithm>
+#include <cstring>
 
 namespace hda {
 
@@ -46,7 +51,6 @@ __global__ __launch_bounds__(256) void k_mgr_rowstats(int n, const int *__restri
       for (int k = rp[i]; k < rp[i + 1]; k++)
       {
          const int j = cj[k];
-         if (j >= n) continue;
          b += fabs(v[k]);
          if (j == i) d = v[k];
          if (cf[j] < 0) a += fabs(v[k]);
@@ -55,16 +59,26 @@ __global__ __launch_bounds__(256) void k_mgr_rowstats(int n, const int *__restri
 }
 
 // column sums of A_FF through the transpose (rows of T ascend: the order of a sequential pass over A's rows)
-__global__ __launch_bounds__(256) void k_mgr_colsum(int n, const int *__restrict__ trp, const int *__restrict__ tcj, const double *__restrict__ tv,
+__global__ __launch_bounds__(256) void k_mgr_colsum(int ncols, const int *__restrict__ trp, const int *__restrict__ tcj, const double *__restrict__ tv,
                                                     const int *__restrict__ cf, double *__restrict__ csum)
-{
+{ // j runs over owned and ghost columns; the rows of T are this rank's rows of A
    const int j = blockIdx.x * 256 + threadIdx.x;
-   if (j >= n) return;
+   if (j >= ncols) return;
    double s = 0.0;
    if (cf[j] < 0)
       for (int k = trp[j]; k < trp[j + 1]; k++)
-         if (tcj[k] < n && cf[tcj[k]] < 0) s += tv[k];
+         if (cf[tcj[k]] < 0) s += tv[k];
    csum[j] = s;
+}
+__global__ __launch_bounds__(256) void k_mgr_i2d(int n, const int *__restrict__ in, double *__restrict__ out)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) out[i] = (double)in[i];
+}
+__global__ __launch_bounds__(256) void k_mgr_d2i(int n, const double *__restrict__ in, int *__restrict__ out)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) out[i] = (int)in[i];
 }
 
 __global__ __launch_bounds__(256) void k_mgr_dinvF(int n, const int *__restrict__ cf, const double *__restrict__ d, double *__restrict__ dinv)
@@ -82,7 +96,7 @@ __global__ __launch_bounds__(256) void k_mgr_P_count(int n, const int *__restric
    int c = 0;
    if (cf[i] > 0) c = 1;
    else if (interp != 0)
-      for (int k = rp[i]; k < rp[i + 1]; k++) c += (cj[k] < n && cf[cj[k]] > 0);
+      for (int k = rp[i]; k < rp[i + 1]; k++) c += (cf[cj[k]] > 0);
    cnt[i] = c;
 }
 __global__ __launch_bounds__(256) void k_mgr_P_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
@@ -95,7 +109,7 @@ __global__ __launch_bounds__(256) void k_mgr_P_fill(int n, const int *__restrict
    if (cf[i] > 0) { pcj[q] = cidx[i]; pv[q] = 1.0; return; }
    if (interp == 0) return;
    for (int k = rp[i]; k < rp[i + 1]; k++)
-      if (cj[k] < n && cf[cj[k]] > 0) { pcj[q] = cidx[cj[k]]; pv[q++] = -v[k] / d[i]; }
+      if (cf[cj[k]] > 0) { pcj[q] = cidx[cj[k]]; pv[q++] = -v[k] / d[i]; }
 }
 
 // R = [Z I]: row of C point i -> -a_ij / d_j for its F columns, 1 at column i, columns ascending (restrict 0: identity only)
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(256) void k_mgr_R_count(int n, const int *__restric
    if (i >= n || cf[i] < 0) return;
    int c = 1;
    if (restrict_type != 0)
-      for (int k = rp[i]; k < rp[i + 1]; k++) c += (cj[k] < n && cf[cj[k]] < 0);
+      for (int k = rp[i]; k < rp[i + 1]; k++) c += (cf[cj[k]] < 0);
    cnt[cidx[i]] = c;
 }
 __global__ __launch_bounds__(256) void k_mgr_R_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(256) void k_mgr_R_fill(int n, const int *__restrict
       for (int k = rp[i]; k < rp[i + 1]; k++)
       {
          const int j = cj[k];
-         if (j >= n || cf[j] > 0) continue;
+         if (cf[j] > 0) continue;
          if (!placed && j > i) { rcj[q] = i; rv[q++] = 1.0; placed = true; }
          rcj[q] = j;
          rv[q++] = -v[k] / d[j];
@@ -135,6 +149,18 @@ __global__ __launch_bounds__(256) void k_mgr_coarse_labels(int n, const int *__r
 {
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i < n && cf[i] > 0) lc[cidx[i]] = labels[i];
+}
+
+__global__ __launch_bounds__(256) void k_iota_add(int n, const int *__restrict__ in, int by, int *__restrict__ out)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) out[i] = in[i] + by;
+}
+// global coarse id of the owned C points (as doubles, for the halo exchange)
+__global__ __launch_bounds__(256) void k_mgr_cgid(int n, const int *__restrict__ cf, const int *__restrict__ cidx, double first, double *__restrict__ out)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) out[i] = cf[i] > 0 ? first + (double)cidx[i] : -1.0;
 }
 
 bool gs_type(int t) { return t == 3 || t == 4 || t == 6 || t == 8 || t == 13 || t == 14 || t == 88; }
@@ -156,14 +182,26 @@ void finish_csr(DCsr &M, int nrows, int ncols, DArray<int> &cnt)
 
 void Mgr::setup(const DCsr &A0, const std::vector<int> &labels0)
 {
-   HDA_REQUIRE(Comm::world().size == 1, "MGR on a row-partitioned matrix is not implemented on MI355X yet (one rank only)");
+   HDA_REQUIRE(Comm::world().size == 1, "MGR: a row-partitioned matrix needs setup_dist");
+   std::vector<long long> part = {0, (long long)A0.nrows}, ghosts;
+   setup_dist(A0, hA0_none, part, ghosts, labels0);
+}
+
+void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long long> &part0, const std::vector<long long> &ghosts0,
+                     const std::vector<int> &labels0)
+{
+   Comm      &cm    = Comm::world();
+   const bool multi = cm.size > 1;
    HDA_REQUIRE((int)labels0.size() == A0.nrows, "MGR: the dofmap must label every local row");
    HDA_REQUIRE(!prm.levels.empty(), "MGR: at least one reduction level (preconditioner.mgr.level.0.f_dofs) is needed");
+   HDA_REQUIRE(A0.ncols == A0.nrows + (int)ghosts0.size(), "MGR: ghost list does not match the matrix block");
    lv.clear();
    lv.resize(prm.levels.size());
-   const DCsr *A = &A0;
-   DArray<int> labels;
-   labels.upload(labels0.data(), labels0.size());
+   const DCsr             *A  = &A0;
+   const HaloPlan         *hA = &hA0;
+   std::vector<long long>  part = part0, ghosts = ghosts0;
+   DArray<int>             labels;
+   labels.upload(labels0.data(), std::max<size_t>(labels0.size(), 1));
    for (size_t l = 0; l < prm.levels.size(); l++)
    {
       const MgrLevelParams &p = prm.levels[l];
@@ -177,54 +215,110 @@ void Mgr::setup(const DCsr &A0, const std::vector<int> &labels0)
       HDA_REQUIRE(p.grelax_type < 0 || gs_type(p.grelax_type) || p.grelax_type == 16,
                   "MGR g_relaxation: none, the hybrid (l1) Gauss-Seidel types and ilu are implemented");
       HDA_REQUIRE(!p.f_labels.empty(), "MGR: a reduction level without f_dofs");
-      const int n = A->nrows;
-      L.A      = A;
-      L.n      = n;
-      L.labels = std::move(labels);
-      L.cf.alloc((size_t)std::max(n, 1));
-      L.cidx.alloc((size_t)n + 1);
-      DArray<int> fl, cmark((size_t)n + 1);
+      const int n = A->nrows, nx = A->ncols, ng = nx - n; // owned rows, owned + ghost columns
+      L.A  = A;
+      L.hA = hA;
+      L.n  = n;
+      // labels of the ghost columns, then C/F marks of owned and ghost unknowns
+      DArray<double> dtmp((size_t)std::max(nx, 1));
+      L.labels.alloc((size_t)std::max(nx, 1));
+      if (n) k_mgr_i2d<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, labels.data(), dtmp.data());
+      if (multi) halo_exchange(*hA, dtmp.data());
+      if (nx) k_mgr_d2i<<<ceil_div(nx, 256), 256, 0, STREAM>>>(nx, dtmp.data(), L.labels.data());
+      L.cf.alloc((size_t)std::max(nx, 1));
+      DArray<int> fl, cmark((size_t)nx + 1), cscan((size_t)nx + 1);
       fl.upload(p.f_labels.data(), p.f_labels.size());
       cmark.zero();
-      if (n) k_mgr_mark<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.labels.data(), fl.data(), (int)p.f_labels.size(), L.cf.data(), cmark.data());
-      exclusive_scan(n, cmark.data(), L.cidx.data(), nullptr);
-      HDA_HIP(hipMemcpyAsync(&L.nc, L.cidx.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+      if (nx) k_mgr_mark<<<ceil_div(nx, 256), 256, 0, STREAM>>>(nx, L.labels.data(), fl.data(), (int)p.f_labels.size(), L.cf.data(), cmark.data());
+      // coarse numbering: owned C points 0..nc-1 in order; ghost C points nc + their rank among the ghost C points
+      // (ghosts ascend by global id, so do their coarse ids)
+      int nc = 0, ncx = 0;
+      exclusive_scan(n, cmark.data(), cscan.data(), nullptr);
+      HDA_HIP(hipMemcpyAsync(&nc, cscan.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
       Context::get().sync();
-      HDA_REQUIRE(L.nc > 0 && L.nc < n, "MGR: a reduction level must keep some unknowns and eliminate some (check f_dofs against the dofmap labels)");
-      const int nc = L.nc;
-      // row statistics of the F rows, column sums of A_FF
-      DArray<double> dF((size_t)n), l1F((size_t)n), l1all((size_t)n), csum;
-      k_mgr_rowstats<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), A->val.data(), L.cf.data(), dF.data(), l1F.data(),
-                                                          l1all.data());
+      L.cidx.alloc((size_t)nx + 1);
+      L.cidx.copy_from(cscan);
+      if (ng)
+      {
+         DArray<int> gscan((size_t)ng + 1);
+         exclusive_scan(ng, cmark.data() + n, gscan.data(), nullptr);
+         k_iota_add<<<ceil_div(ng, 256), 256, 0, STREAM>>>(ng, gscan.data(), nc, L.cidx.data() + n);
+         HDA_HIP(hipMemcpyAsync(&ncx, gscan.data() + ng, 4, hipMemcpyDeviceToHost, STREAM));
+         Context::get().sync();
+      }
+      L.nc = nc;
+      // coarse row starts of every rank, global coarse ids of the ghost C points
+      std::vector<long long> cpart((size_t)cm.size + 1, 0);
+      {
+         std::vector<long long> all;
+         cm.allgather_ll(nc, all);
+         for (int r = 0; r < cm.size; r++) cpart[(size_t)r + 1] = cpart[(size_t)r] + all[(size_t)r];
+      }
+      long long tot[2] = {nc, n};
+      cm.allreduce_host(tot, 2, 0);
+      HDA_REQUIRE(tot[0] > 0 && tot[0] < tot[1], "MGR: a reduction level must keep some unknowns and eliminate some (check f_dofs against the dofmap labels)");
+      std::vector<long long> pghosts; // coarse ids of P's ghost columns
+      if (multi)
+      {
+         DArray<double> cg((size_t)std::max(nx, 1));
+         k_mgr_cgid<<<ceil_div(std::max(n, 1), 256), 256, 0, STREAM>>>(n, L.cf.data(), L.cidx.data(), (double)cpart[(size_t)cm.rank], cg.data());
+         halo_exchange(*hA, cg.data());
+         std::vector<double> hg((size_t)std::max(ng, 1));
+         std::vector<int>    hcf((size_t)std::max(ng, 1));
+         if (ng)
+         {
+            HDA_HIP(hipMemcpyAsync(hg.data(), cg.data() + n, 8 * (size_t)ng, hipMemcpyDeviceToHost, STREAM));
+            HDA_HIP(hipMemcpyAsync(hcf.data(), L.cf.data() + n, 4 * (size_t)ng, hipMemcpyDeviceToHost, STREAM));
+            Context::get().sync();
+         }
+         for (int g = 0; g < ng; g++)
+            if (hcf[(size_t)g] > 0) pghosts.push_back((long long)hg[(size_t)g]);
+         HDA_REQUIRE((int)pghosts.size() == ncx, "MGR: ghost coarse numbering is inconsistent");
+      }
+      // row statistics of the F rows (ghost F columns see their owners' values), column sums of A_FF
+      DArray<double> dF((size_t)std::max(nx, 1)), l1F((size_t)std::max(nx, 1)), l1all((size_t)std::max(nx, 1)), csum;
+      dF.zero();
+      if (n)
+         k_mgr_rowstats<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), A->val.data(), L.cf.data(), dF.data(), l1F.data(),
+                                                             l1all.data());
+      if (multi && p.restrict_type == 2) halo_exchange(*hA, dF.data());
       if (p.restrict_type == 14)
       {
          DCsr T;
          transpose(*A, T);
-         csum.alloc((size_t)n);
-         k_mgr_colsum<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, T.rowptr.data(), T.col.data(), T.val.data(), L.cf.data(), csum.data());
+         csum.alloc((size_t)std::max(nx, 1));
+         if (nx) k_mgr_colsum<<<ceil_div(nx, 256), 256, 0, STREAM>>>(nx, T.rowptr.data(), T.col.data(), T.val.data(), L.cf.data(), csum.data());
+         if (multi)
+         {
+            halo_reverse_add(*hA, csum.data()); // contributions of the rows other ranks own
+            halo_exchange(*hA, csum.data());
+         }
          Context::get().sync();
       }
-      L.dinvF.alloc((size_t)n);
-      k_mgr_dinvF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), p.frelax_type == 18 ? l1all.data() : dF.data(), L.dinvF.data());
-      // P
+      L.dinvF.alloc((size_t)std::max(n, 1));
+      if (n) k_mgr_dinvF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), p.frelax_type == 18 ? l1all.data() : dF.data(), L.dinvF.data());
+      // P (columns [owned coarse | ghost coarse])
       {
          DArray<int> cnt((size_t)n + 1);
          cnt.zero();
-         k_mgr_P_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), L.cf.data(), p.interp_type, cnt.data());
-         finish_csr(L.P, n, nc, cnt);
-         k_mgr_P_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), A->val.data(), L.cf.data(), L.cidx.data(), p.interp_type,
-                                                           p.interp_type == 1 ? l1F.data() : dF.data(), L.P.rowptr.data(), L.P.col.data(),
-                                                           L.P.val.data());
+         if (n) k_mgr_P_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), L.cf.data(), p.interp_type, cnt.data());
+         finish_csr(L.P, n, nc + ncx, cnt);
+         if (n)
+            k_mgr_P_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), A->val.data(), L.cf.data(), L.cidx.data(), p.interp_type,
+                                                              p.interp_type == 1 ? l1F.data() : dF.data(), L.P.rowptr.data(), L.P.col.data(),
+                                                              L.P.val.data());
+         if (multi) L.hP = make_halo_plan(nc, cpart, pghosts);
       }
-      // R
+      // R (columns = the fine columns of A, ghosts included)
       {
          DArray<int> cnt((size_t)nc + 1);
          cnt.zero();
-         k_mgr_R_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), L.cf.data(), L.cidx.data(), p.restrict_type, cnt.data());
-         finish_csr(L.R, nc, n, cnt);
-         k_mgr_R_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), A->val.data(), L.cf.data(), L.cidx.data(), p.restrict_type,
-                                                           p.restrict_type == 14 ? csum.data() : dF.data(), L.R.rowptr.data(), L.R.col.data(),
-                                                           L.R.val.data());
+         if (n) k_mgr_R_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), L.cf.data(), L.cidx.data(), p.restrict_type, cnt.data());
+         finish_csr(L.R, nc, nx, cnt);
+         if (n)
+            k_mgr_R_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), A->val.data(), L.cf.data(), L.cidx.data(), p.restrict_type,
+                                                              p.restrict_type == 14 ? csum.data() : dF.data(), L.R.rowptr.data(), L.R.col.data(),
+                                                              L.R.val.data());
       }
       // global relaxation data
       if (p.grelax_type == 16)
@@ -236,36 +330,65 @@ void Mgr::setup(const DCsr &A0, const std::vector<int> &labels0)
       }
       else if (p.grelax_type >= 0)
       {
-         DArray<double> d((size_t)n);
+         DArray<double> d((size_t)std::max(n, 1));
          const int      t = p.grelax_type == 88 ? 8 : p.grelax_type;
          if (t == 8 || t == 13 || t == 14) l1_row_norms(*A, 4, d.data());
          else extract_diag(*A, d.data());
-         L.dinvG.alloc((size_t)n);
+         L.dinvG.alloc((size_t)std::max(n, 1));
          make_dinv(n, d.data(), 1.0, L.dinvG.data());
          build_gs_plan(*A, L.gs);
       }
-      const size_t len = (size_t)std::max(std::max(A->ncols, n), 1);
-      if (l > 0) { L.f.alloc(len); L.u.alloc(len); }
+      // coarse operator A_c = R (A P), its ghost list and halo plan, the labels of its rows
+      Level                  *next = (l + 1 < prm.levels.size()) ? &lv[l + 1] : nullptr;
+      DCsr                   &Anext = next ? next->A_own : Ac;
+      std::vector<long long>  cghosts;
+      if (multi)
+      {
+         DCsr                   AP;
+         std::vector<long long> apg;
+         dist_spgemm(*A, *hA, L.P, pghosts, cpart, AP, apg);
+         dist_spgemm(L.R, *hA, AP, apg, cpart, Anext, cghosts);
+      }
+      else
+      {
+         DCsr AP;
+         spgemm(*A, L.P, AP);
+         spgemm(L.R, AP, Anext);
+      }
+      DArray<int> lc((size_t)std::max(nc, 1));
+      if (n) k_mgr_coarse_labels<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.cidx.data(), L.labels.data(), lc.data());
+      Context::get().sync();
+      HaloPlan &hnext = next ? next->hA_own : hAc;
+      if (multi) hnext = make_halo_plan(nc, cpart, cghosts);
+      // work vectors: every one may carry the ghost tail of A, of P (on the coarse side) or of A_c
+      const size_t len = (size_t)std::max(std::max(nx, n), 1);
+      if (l > 0) { L.f.alloc(std::max(len, L.flen)); L.u.alloc(std::max(len, L.flen)); }
       L.u2.alloc(len);
       L.t.alloc(len);
-      // coarse operator and its labels
-      DCsr AP;
-      spgemm(*A, L.P, AP);
-      DCsr &Anext = (l + 1 < prm.levels.size()) ? lv[l + 1].A_own : Ac;
-      spgemm(L.R, AP, Anext);
-      DArray<int> lc((size_t)std::max(nc, 1));
-      k_mgr_coarse_labels<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.cidx.data(), L.labels.data(), lc.data());
-      Context::get().sync();
+      const size_t clen = (size_t)std::max(std::max(Anext.ncols, L.P.ncols), 1);
+      if (next) next->flen = clen;
+      else coarse_len = clen;
       spmv_prepare(*A);
       spmv_prepare(L.P);
       spmv_prepare(L.R);
       labels = std::move(lc);
       A      = &Anext;
+      hA     = &hnext;
+      part   = cpart;
+      ghosts = cghosts;
    }
+   cparts  = part;
+   cghosts_ = ghosts;
    // coarsest system: BoomerAMG
    camg = std::make_unique<Amg>(prm.coarse);
-   camg->setup(Ac);
-   const size_t clen = std::max<size_t>(camg->vec_len0(), (size_t)std::max(Ac.ncols, 1));
+   if (multi)
+   {
+      const char *mode = getenv("HDA_DIST_SETUP");
+      if ((mode && !strcmp(mode, "replicated")) || prm.coarse.coarsen_type != 8 || prm.coarse.num_functions > 1) camg->setup_dist(Ac, hAc, cparts, cghosts_);
+      else camg->setup_dist_partitioned(Ac, hAc, cparts, cghosts_);
+   }
+   else camg->setup(Ac);
+   const size_t clen = std::max<size_t>(std::max(camg->vec_len0(), coarse_len), (size_t)std::max(Ac.ncols, 1));
    fc.alloc(clen);
    uc.alloc(clen);
    Context::get().sync();
@@ -295,36 +418,42 @@ double *Mgr::cycle(int l, const double *f, double *u, bool zero)
    const MgrLevelParams &p = prm.levels[(size_t)l];
    const DCsr           &A = *L.A;
    const int             n = L.n;
+   const bool            multi = Comm::world().size > 1;
    double               *cur = u, *alt = L.u2.data();
+   auto refresh = [&](double *v) { if (multi) halo_exchange(*L.hA, v); };
    if (p.grelax_type == 16)
    {
-      ilu_solve(*L.gilu, A, nullptr, f, cur, zero, L.ilu_r, L.ilu_c);
+      ilu_solve(*L.gilu, A, multi ? L.hA : nullptr, f, cur, zero, L.ilu_r, L.ilu_c);
       zero = false;
    }
    else if (p.grelax_type >= 0)
    {
-      if (zero) fill(n, 0.0, cur);
+      if (zero) fill((int)std::max(A.ncols, n), 0.0, cur);
       zero = false;
       for (int s = 0; s < std::max(p.grelax_sweeps, 1); s++)
       {
          const int t = p.grelax_type;
-         if (t == 3 || t == 13 || t == 6 || t == 8 || t == 88) gs_sweep(A, L.gs, L.dinvG.data(), f, cur, true);
-         if (t == 4 || t == 14 || t == 6 || t == 8 || t == 88) gs_sweep(A, L.gs, L.dinvG.data(), f, cur, false);
+         if (t == 3 || t == 13 || t == 6 || t == 8 || t == 88) { refresh(cur); gs_sweep(A, L.gs, L.dinvG.data(), f, cur, true); }
+         if (t == 4 || t == 14 || t == 6 || t == 8 || t == 88) { refresh(cur); gs_sweep(A, L.gs, L.dinvG.data(), f, cur, false); }
       }
    }
    for (int s = 0; s < p.frelax_sweeps; s++)
    {
       if (zero) { jacobi_zero_guess(n, L.dinvF.data(), f, cur); zero = false; continue; } // u = dinvF .* f
+      refresh(cur);
       jacobi(A, L.dinvF.data(), f, cur, alt, -1);
       std::swap(cur, alt);
    }
    if (zero) { fill(n, 0.0, cur); zero = false; }
+   refresh(cur);
    residual(A, cur, f, L.t.data());
    const bool last = (l + 1 == (int)lv.size());
    double    *fcl  = last ? fc.data() : lv[(size_t)l + 1].f.data();
    double    *ucl  = last ? uc.data() : lv[(size_t)l + 1].u.data();
+   refresh(L.t.data());
    spmv(L.R, 1.0, L.t.data(), 0.0, nullptr, fcl);
    double *ec = cycle(l + 1, fcl, ucl, true);
+   if (multi) halo_exchange(L.hP, ec);
    spmv(L.P, 1.0, ec, 1.0, cur, cur);
    return cur;
 }

@@ -256,7 +256,7 @@ HYPRE_Int HYPRE_BoomerAMGSetILUMaxIter(HYPRE_Solver solver, HYPRE_Int n);
 
 /* ---- MGR (reference src/internal/mgr.c:3782-3808 and the per-level arrays after :3820).  Implemented on MI355X: C points by
  * dof label, prolongation injection / jacobi / l1-jacobi, restriction injection / jacobi / columped, Galerkin coarse grids,
- * Jacobi / l1-Jacobi F-relaxation, hybrid (l1) Gauss-Seidel global relaxation, BoomerAMG coarse solver, V-cycle, one rank.
+ * Jacobi / l1-Jacobi F-relaxation, hybrid (l1) Gauss-Seidel or ILU(0) global relaxation, BoomerAMG coarse solver, V-cycle, one rank or a row partition.
  * Anything else is rejected at Setup. */
 HYPRE_Int HYPRE_MGRCreate(HYPRE_Solver *solver);
 HYPRE_Int HYPRE_MGRDestroy(HYPRE_Solver solver);

@@ -113,7 +113,7 @@ int hda_ilu_create(hda_csr_t A, int max_iter, int tri_solve, int lower_it, int u
  * by dof labels with BoomerAMG on the coarsest system.  labels = dofmap of A's rows.  Implemented per level:
  * prolongation injection (0) / l1-jacobi (1) / jacobi (2); restriction injection (0) / jacobi (2) / columped (14);
  * f_relaxation jacobi (7) / l1-jacobi (18); g_relaxation none (-1) / hybrid (l1) Gauss-Seidel (3, 4, 6, 13, 14, 88);
- * coarse grid by Galerkin product.  One rank.  The handle is accepted by the Krylov entry points and hda_amg_vcycle. */
+ * coarse grid by Galerkin product.  This test entry is single-rank (row partitions go through HYPRE_MGRSetup).  The handle is accepted by the Krylov entry points and hda_amg_vcycle. */
 typedef struct {
    int        n_f_labels;
    const int *f_labels; /* level.N.f_dofs */

@@ -134,9 +134,38 @@ def mode_csr(out, n, seed):
     hdist.finalize()
 
 
+def mode_mgr(out, n):
+    """Row blocks of the 3-field model system (rows cut anywhere, also inside a cell) with their slice of the dofmap;
+    GMRES + MGR from the YAML in HDA_TEST_YAML."""
+    from hypredrive_amd import dist as hdist
+    from hypredrive_amd import hypredrv as hd
+    rank, world = hdist.init("staged")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_pins import three_field_system
+    S, labels = three_field_system(n, seed=4)
+    N = S.shape[0]
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    blk = S[lo:hi]
+    h = hd.Hypredrv(os.environ["HDA_TEST_YAML"])
+    h.set_matrix_csr(lo, hi - 1, blk.indptr, blk.indices, blk.data)
+    h.set_rhs_array(lo, hi - 1, np.ones(hi - lo))
+    h.finish_system()
+    lab = np.ascontiguousarray(labels[lo:hi], dtype=np.int32)
+    import ctypes as C
+    hd.check(hd.lib().HYPREDRV_LinearSystemSetDofmap(h.h, hi - lo, lab.ctypes.data_as(C.POINTER(C.c_int))))
+    r = h.solve()
+    nrm = h.solution_norm("L2")
+    if rank == 0:
+        json.dump({"iters": r["iters"], "converged": r["converged"], "final_rel": r["final_rel"], "norm": nrm, "world": world}, open(out, "w"))
+    h.close()
+    hdist.finalize()
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "transport":
         mode_transport(sys.argv[2])
+    elif sys.argv[1] == "mgr":
+        mode_mgr(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "csr":
         mode_csr(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     else:
