@@ -197,6 +197,9 @@ class Mgr {
    void        setup_dist(const DCsr &A, const HaloPlan &hA, const std::vector<long long> &part, const std::vector<long long> &ghost_gids,
                           const std::vector<int> &labels);
    void        solve(const double *b, double *x, bool zero_guess);   // max_iter cycles
+   // preconditioner.reuse: a kept MGR applied to a later system takes level 0 from the matrix of the call (as hypre_MGRSolve does)
+   bool        bound_to(const DCsr &A) const { return !lv.empty() && lv[0].A == &A && A.nrows == a0_dims[0] && A.ncols == a0_dims[1] && A.nnz == a0_dims[2]; }
+   void        rebind(const DCsr &A, const HaloPlan *hA);
    int         num_reduction_levels() const { return (int)lv.size(); }
    const DCsr &matrix(int level, int which) const; // which 0 operator (level == reduction levels: coarsest), 1 P, 2 R
    size_t      vec_len0() const { return lv.empty() ? 0 : (size_t)std::max(lv[0].A->ncols, lv[0].n); }
@@ -222,6 +225,7 @@ class Mgr {
    HaloPlan               hAc, hA0_none; // (hA0_none: the empty plan of a one-rank setup)
    std::vector<long long> cparts, cghosts_;
    size_t                 coarse_len = 0;
+   int                    a0_dims[3] = {0, 0, 0};
    std::unique_ptr<Amg>   camg;
    DArray<double>         fc, uc;
 };

@@ -1346,6 +1346,7 @@ extern "C" HYPRE_Int HYPRE_MGRSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
    HY_NEED_DEVICE;
    HY_TRY
    HDA_REQUIRE(s && s->mgr, "MGRSolve before MGRSetup");
+   if (!s->mgr->bound_to(A->A)) s->mgr->rebind(A->A, Comm::world().size > 1 ? &A->halo : nullptr); // reused preconditioner, later system
    x->ensure_device();
    PrecondHints  &h    = precond_hints();
    const size_t   need = s->mgr->vec_len0();

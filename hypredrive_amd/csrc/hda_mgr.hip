@@ -197,6 +197,7 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
    HDA_REQUIRE(A0.ncols == A0.nrows + (int)ghosts0.size(), "MGR: ghost list does not match the matrix block");
    lv.clear();
    lv.resize(prm.levels.size());
+   a0_dims[0] = A0.nrows; a0_dims[1] = A0.ncols; a0_dims[2] = A0.nnz;
    const DCsr             *A  = &A0;
    const HaloPlan         *hA = &hA0;
    std::vector<long long>  part = part0, ghosts = ghosts0;
@@ -392,6 +393,17 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
    fc.alloc(clen);
    uc.alloc(clen);
    Context::get().sync();
+}
+
+void Mgr::rebind(const DCsr &A, const HaloPlan *hA)
+{
+   HDA_REQUIRE(!lv.empty(), "rebind before setup");
+   HDA_REQUIRE(A.nrows == a0_dims[0] && A.ncols == a0_dims[1],
+               "a reused MGR preconditioner needs a matrix with the same local rows and ghost layer as the one it was built for");
+   lv[0].A = &A;
+   if (hA) lv[0].hA = hA;
+   a0_dims[2] = A.nnz;
+   spmv_prepare(A);
 }
 
 const DCsr &Mgr::matrix(int level, int which) const

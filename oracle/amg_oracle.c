@@ -1152,6 +1152,7 @@ ilu_iterate(orc_ilu *F, const orc_csr *A, int iters, const double *b, double *x,
 struct orc_mgr;
 static void mgr_solve(struct orc_mgr *M, const double *b, double *x);
 static void mgr_free(struct orc_mgr *M);
+static int  mgr_rebind(struct orc_mgr *M, const orc_csr *A);
 
 struct orc_amg {
    orc_amg_params p;
@@ -1309,6 +1310,7 @@ int
 orc_amg_rebind_level0(orc_amg *h, const orc_csr *A)
 {
    if (h->ilu_only) { h->ilu_A = A; return 0; }
+   if (h->mgr) return mgr_rebind(h->mgr, A);
    if (A->nrows != h->A[0]->nrows || A->ncols != h->A[0]->ncols) return 1;
    int      nnz = A->rowptr[A->nrows];
    orc_csr *C   = orc_csr_alloc(A->nrows, A->ncols, nnz);
@@ -1695,6 +1697,20 @@ mgr_free(struct orc_mgr *M)
    orc_amg_free(M->camg);
    free(M->fc); free(M->uc); free(M->lv);
    free(M);
+}
+
+static int
+mgr_rebind(struct orc_mgr *M, const orc_csr *A)
+{
+   if (M->nlev < 1 || A->nrows != M->lv[0].A->nrows || A->ncols != M->lv[0].A->ncols) return 1;
+   int      nnz = A->rowptr[A->nrows];
+   orc_csr *C   = orc_csr_alloc(A->nrows, A->ncols, nnz);
+   memcpy(C->rowptr, A->rowptr, sizeof(int) * (size_t)(A->nrows + 1));
+   memcpy(C->col, A->col, sizeof(int) * (size_t)nnz);
+   memcpy(C->val, A->val, sizeof(double) * (size_t)nnz);
+   orc_csr_free(M->lv[0].A);
+   M->lv[0].A = C;
+   return 0;
 }
 
 const orc_csr *

@@ -450,6 +450,9 @@ class MgrPrecond:
             lib().orc_amg_free(self.h)
             self.h = None
 
+    def rebind_level0(self, A):
+        return Amg.rebind_level0(self, A)
+
     def matrix(self, level, which=0):
         """which: 0 operator of the level (level == number of reduction levels: the coarsest system), 1 P, 2 R"""
         return Csr(lib().orc_mgr_matrix(self.h, level, which), owned=False)

@@ -837,3 +837,31 @@ def test_row_partitioned_mgr(hd, orc, tmp_path, world, case, rep_rows):
     ref = orc.gmres(Ao, np.ones(S.shape[0]), orc.MgrPrecond(Ao, labels, lev), orc.krylov_params(True, rtol=1e-8))
     assert res["converged"] and abs(res["iters"] - ref["iters"]) <= slack, (res["iters"], ref["iters"])
     assert res["norm"] == pytest.approx(np.linalg.norm(ref["x"]), rel=1e-6)
+
+
+def test_precon_reuse_with_mgr(hd, orc):
+    """preconditioner.reuse with MGR: a kept MGR is applied to the next system with level 0 taken from the new matrix."""
+    import scipy.sparse as sp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_pins import three_field_system
+    S0, labels = three_field_system(12, seed=7)
+    n = S0.shape[0]
+    mats = [(S0 + 0.3 * s * sp.identity(n)).tocsr() for s in range(3)]
+    lev = [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="l1-hsgs", restriction_type="columped")]
+    h = hd.Hypredrv(EX3_MGR_YAML + "  reuse: always\n")
+    hd.check(hd.lib().HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, n // 3, 3))
+    Mo = None
+    for s, S in enumerate(mats):
+        Ao = orc.Csr.from_scipy(S)
+        if s == 0:
+            Mo = orc.MgrPrecond(Ao, labels, lev)
+        else:
+            Mo.rebind_level0(Ao)
+        ref = orc.gmres(Ao, np.ones(n), Mo, orc.krylov_params(True, rtol=1e-8))
+        h.set_matrix_csr(0, n - 1, S.indptr, S.indices, S.data)
+        h.set_rhs_array(0, n - 1, np.ones(n))
+        h.finish_system()
+        r = h.solve()
+        assert r["converged"] and r["iters"] == ref["iters"], (s, r["iters"], ref["iters"])
+        assert (r["setup_s"] > 1e-4) == (s == 0)
+    h.close()
