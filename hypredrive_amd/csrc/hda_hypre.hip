@@ -734,6 +734,14 @@ extern "C" HYPRE_Int HYPRE_ParVectorInnerProd(HYPRE_ParVector x, HYPRE_ParVector
    *prod = read_scalar(S_TMP);
    HY_CATCH
 }
+// HYPRE_IJVectorInnerProd (hypre >= 2.32; examples/src/C_lidcavity/lidcavity.c:1404): the IJ handle is the ParVector here
+extern "C" HYPRE_Int HYPRE_IJVectorInnerProd(HYPRE_IJVector x, HYPRE_IJVector y, HYPRE_Real *prod)
+{
+   if (!x || !y || !prod) return hypre_set_error(HYPRE_ERROR_ARG, "HYPRE_IJVectorInnerProd: null argument");
+   x->ensure_device();
+   y->ensure_device();
+   return HYPRE_ParVectorInnerProd(x, y, prod);
+}
 extern "C" HYPRE_Int HYPRE_ParVectorCopy(HYPRE_ParVector x, HYPRE_ParVector y)
 {
    HY_TRY

@@ -116,6 +116,7 @@ HYPRE_Int HYPRE_IJVectorPrint(HYPRE_IJVector vector, const char *filename);
 HYPRE_Int HYPRE_ParCSRMatrixMatvec(HYPRE_Complex alpha, HYPRE_ParCSRMatrix A, HYPRE_ParVector x, HYPRE_Complex beta,
                                    HYPRE_ParVector y);
 HYPRE_Int HYPRE_ParVectorInnerProd(HYPRE_ParVector x, HYPRE_ParVector y, HYPRE_Real *prod);
+HYPRE_Int HYPRE_IJVectorInnerProd(HYPRE_IJVector x, HYPRE_IJVector y, HYPRE_Real *prod); /* lidcavity.c:1404 */
 HYPRE_Int HYPRE_ParVectorCopy(HYPRE_ParVector x, HYPRE_ParVector y);
 HYPRE_Int HYPRE_ParVectorScale(HYPRE_Complex value, HYPRE_ParVector x);
 HYPRE_Int HYPRE_ParVectorAxpy(HYPRE_Complex alpha, HYPRE_ParVector x, HYPRE_ParVector y);

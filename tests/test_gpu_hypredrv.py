@@ -865,3 +865,23 @@ def test_precon_reuse_with_mgr(hd, orc):
         assert r["converged"] and r["iters"] == ref["iters"], (s, r["iters"], ref["iters"])
         assert (r["setup_s"] > 1e-4) == (s == 0)
     h.close()
+
+
+def test_reference_lidcavity_driver_unmodified():
+    """examples/src/C_lidcavity/lidcavity.c of the reference (lid-driven cavity: Newton on stabilised Q1-Q1 Navier-Stokes,
+    three unknowns per node, two annotation levels), UNMODIFIED, with its default solver block -- FGMRES(100) + systems
+    BoomerAMG (num_functions 3, strong_th 0.6) + ILU smoother on five levels -- passed through -i with bj-iluk / fill 0 in
+    place of bj-ilut (examples/lidcavity-ilu0.yml).  Newton converges in every time step; a handful of FGMRES iterations each."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "lidcavity_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/lidcavity_ref not built (needs /root/reference + MPICH at build time)")
+    r = subprocess.run([exe, "-i", "examples/lidcavity-ilu0.yml", "-n", "16", "16", "-tf", "2", "-v", "1"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "HYPREDRIVE Failure" not in r.stdout + r.stderr
+    rows = re.findall(r"^\|\s+(\d+)\.(\d+)\.\d+ \|.*\|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|$", r.stdout, re.M)
+    assert len(rows) >= 8
+    assert all(int(it) <= 30 and float(rr) < 1e-6 for _, _, _, rr, it in rows)
+    for step in sorted({ts for ts, _, _, _, _ in rows}):
+        r0 = [float(x[2]) for x in rows if x[0] == step]
+        assert r0[-1] < 1e-3 * r0[0]   # Newton residual (= initial residual of each linear solve) drops by orders of magnitude
