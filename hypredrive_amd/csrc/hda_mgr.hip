@@ -364,7 +364,7 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
       // work vectors: every one may carry the ghost tail of A, of P (on the coarse side) or of A_c
       const size_t len = (size_t)std::max(std::max(nx, n), 1);
       if (l > 0) { L.f.alloc(std::max(len, L.flen)); L.u.alloc(std::max(len, L.flen)); }
-      L.u2.alloc(len);
+      L.u2.alloc(std::max(len, L.flen)); // the cycle may hand u2 back to the finer level, whose P reads its own ghost tail in it
       L.t.alloc(len);
       const size_t clen = (size_t)std::max(std::max(Anext.ncols, L.P.ncols), 1);
       if (next) next->flen = clen;
