@@ -38,7 +38,8 @@ class AmgParams(C.Structure):
 
 class MgrLevelParams(C.Structure):
     _fields_ = [("n_f_labels", C.c_int), ("f_labels", C.POINTER(C.c_int)), ("interp_type", C.c_int), ("restrict_type", C.c_int),
-                ("frelax_type", C.c_int), ("frelax_sweeps", C.c_int), ("grelax_type", C.c_int), ("grelax_sweeps", C.c_int)]
+                ("frelax_type", C.c_int), ("frelax_sweeps", C.c_int), ("grelax_type", C.c_int), ("grelax_sweeps", C.c_int),
+                ("frelax_amg", C.POINTER(AmgParams))]
 
 
 class KrylovParams(C.Structure):
@@ -328,7 +329,7 @@ class Amg:
 
 MGR_INTERP = {"injection": 0, "l1-jacobi": 1, "jacobi": 2}
 MGR_RESTRICT = {"injection": 0, "jacobi": 2, "columped": 14}
-MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18}
+MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18, "amg": 2}
 MGR_GRELAX = {"none": -1, "h-fgs": 3, "h-bgs": 4, "h-ssor": 6, "l1-hfgs": 13, "l1-hbgs": 14, "l1-hsgs": 88, "ilu": 16}
 
 
@@ -354,6 +355,9 @@ class Mgr:
             arr[k].frelax_sweeps = lv.get("f_sweeps", 1)
             arr[k].grelax_type = MGR_GRELAX[lv.get("g_relaxation", "none")]
             arr[k].grelax_sweeps = lv.get("g_sweeps", 1)
+            if lv.get("f_amg") is not None:   # AmgParams of 'f_relaxation: {amg: {...}}'
+                self._keep.append(lv["f_amg"])
+                arr[k].frelax_amg = C.pointer(lv["f_amg"])
         self.nlevels = len(levels)
         self.h = C.c_void_p()
         _check(load().hda_mgr_create(A.h, _ip(self.labels), len(levels), arr, C.byref(self.params), max_iter, C.byref(self.h)))

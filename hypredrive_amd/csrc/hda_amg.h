@@ -181,7 +181,8 @@ struct MgrLevelParams {
    int interp_type = 0;                // prolongation_type: 0 injection, 1 l1-jacobi, 2 jacobi
    int restrict_type = 0;              // restriction_type: 0 injection, 2 jacobi, 14 columped
    int coarse_type = 0;                // coarse_level_type: 0 rap
-   int frelax_type = 7, frelax_sweeps = 1;   // f_relaxation: 7 jacobi, 18 l1-jacobi
+   int frelax_type = 7, frelax_sweeps = 1;   // f_relaxation: 7 jacobi, 18 l1-jacobi, 2 amg (one BoomerAMG cycle on A_FF)
+   AmgParams frelax_amg;                     // f_relaxation.amg block
    int grelax_type = -1, grelax_sweeps = 1;  // g_relaxation: -1 none, 3/4/6/13/14 hybrid GS, 88 l1-hsgs, 16 ilu
 };
 struct MgrParams {
@@ -217,6 +218,14 @@ class Mgr {
       DArray<double> dinvF, dinvG, f, u, u2, t, ilu_r, ilu_c;
       GsPlan         gs;
       std::unique_ptr<Ilu> gilu; // g_relaxation ilu
+      // f_relaxation amg: A_FF (columns [owned F | ghost F]), its halo plan and partition, the AMG on it
+      DCsr                   Aff;
+      HaloPlan               hFF;
+      std::vector<long long> fpart, fghosts;
+      DArray<int>            fidx;
+      std::unique_ptr<Amg>   famg;
+      DArray<double>         rF, eF;
+      int                    nf = 0;
       int            n = 0, nc = 0;
    };
    double *cycle(int l, const double *f, double *u, bool zero);

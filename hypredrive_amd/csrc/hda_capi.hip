@@ -407,6 +407,7 @@ extern "C" int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const
       q.interp_type = levels[l].interp_type; q.restrict_type = levels[l].restrict_type;
       q.frelax_type = levels[l].frelax_type; q.frelax_sweeps = levels[l].frelax_sweeps;
       q.grelax_type = levels[l].grelax_type; q.grelax_sweeps = levels[l].grelax_sweeps;
+      if (levels[l].frelax_amg) q.frelax_amg = to_params(levels[l].frelax_amg);
       p.levels.push_back(q);
    }
    auto h = std::make_unique<hda_amg_s>();

@@ -1298,6 +1298,14 @@ extern "C" HYPRE_Int HYPRE_MGRSetCoarseSolver(HYPRE_Solver s, HYPRE_PtrToSolverF
    return 0;
 }
 
+extern "C" HYPRE_Int HYPRE_MGRSetFSolverAtLevel(HYPRE_Solver s, HYPRE_Solver fsolver, HYPRE_Int level)
+{
+   if (!s || level < 0 || level > 30) return hypre_set_error(HYPRE_ERROR_ARG, "HYPRE_MGRSetFSolverAtLevel: bad arguments");
+   if ((size_t)level >= s->mgr_fsolver.size()) s->mgr_fsolver.resize((size_t)level + 1, nullptr);
+   s->mgr_fsolver[(size_t)level] = fsolver;
+   return 0;
+}
+
 extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector, HYPRE_ParVector)
 {
    HY_NEED_DEVICE;
@@ -1335,6 +1343,12 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
       q.restrict_type = at(s->mgr_restrict, l, 0);
       q.coarse_type   = at(s->mgr_coarse_method, l, 0);
       q.frelax_type   = at(s->mgr_frelax, l, 7);
+      if (q.frelax_type == 2)
+      {
+         HYPRE_Solver fs = (size_t)l < s->mgr_fsolver.size() ? s->mgr_fsolver[(size_t)l] : nullptr;
+         HDA_REQUIRE(!fs || fs->kind == HDA_SOLVER_AMG, "MGR f_relaxation: only a BoomerAMG F-solver is implemented");
+         if (fs) { q.frelax_amg = fs->ap; q.frelax_amg.num_functions = std::max(fs->num_functions, 1); }
+      }
       q.frelax_sweeps = at(s->mgr_fsweeps, l, 1);
       q.grelax_type   = at(s->mgr_gsmooth, l, -1);
       q.grelax_sweeps = at(s->mgr_giters, l, 1);

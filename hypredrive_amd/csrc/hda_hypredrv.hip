@@ -157,7 +157,7 @@ struct hypredrv_struct {
    PreconCookie   cookie{nullptr};
    Stats          stats;
    std::vector<int> dofmap; // function / field label of every locally owned unknown
-   HYPRE_Solver     precon_aux = nullptr; // coarse solver owned together with an MGR preconditioner
+   std::vector<HYPRE_Solver> precon_aux; // component solvers owned together with an MGR preconditioner (coarse, F-relaxation)
    std::vector<HYPRE_IJVector> state; // borrowed time-level vectors (host resident), logical index i = state[(state_first + i) % n]
    int            state_first = 0;
    int            current_system_index = -1;
@@ -309,7 +309,8 @@ extern "C" uint32_t HYPREDRV_Destroy(HYPREDRV_t *hp)
    hypredrv_struct *h = *hp;
    if (h->solver) HYPRE_ParCSRPCGDestroy(h->solver); // every Krylov handle is the same struct
    if (h->precon) HYPRE_BoomerAMGDestroy(h->precon);
-   if (h->precon_aux) HYPRE_BoomerAMGDestroy(h->precon_aux);
+   for (HYPRE_Solver a : h->precon_aux) HYPRE_BoomerAMGDestroy(a);
+   h->precon_aux.clear();
    destroy_system(h);
    delete h;
    *hp = nullptr;
@@ -1437,8 +1438,18 @@ static uint32_t mgr_create(hypredrv_struct *h, const MgrArgs &a)
    HYPRE_MGRSetLevelSmoothType(p, gsm.data());
    HYPRE_MGRSetLevelSmoothIters(p, git.data());
    HYPRE_MGRSetNonGalerkinMaxElmts(p, a.nonglk_max_elmts);
-   amg_create(a.coarsest_amg, &h->precon_aux);
-   HYPRE_MGRSetCoarseSolver(p, HYPRE_BoomerAMGSolve, HYPRE_BoomerAMGSetup, h->precon_aux);
+   for (int l = 0; l < nlev; l++)
+      if (a.level[(size_t)l].f_type == 2)
+      { // f_relaxation amg: a BoomerAMG handle for A_FF (reference mgr.c:2594, HYPRE_MGRSetFSolverAtLevel)
+         HYPRE_Solver fs = nullptr;
+         amg_create(a.level[(size_t)l].f_amg, &fs);
+         h->precon_aux.push_back(fs);
+         HYPRE_MGRSetFSolverAtLevel(p, fs, l);
+      }
+   HYPRE_Solver cs = nullptr;
+   amg_create(a.coarsest_amg, &cs);
+   h->precon_aux.push_back(cs);
+   HYPRE_MGRSetCoarseSolver(p, HYPRE_BoomerAMGSolve, HYPRE_BoomerAMGSetup, cs);
    h->precon = p;
    consume_hypre_errors();
    return g_err;
@@ -1452,7 +1463,8 @@ extern "C" uint32_t HYPREDRV_PreconCreate(HYPREDRV_t h)
    // src/HYPREDRV.c:2801-2808: an existing preconditioner is recreated only when the reuse policy says so
    if (h->precon && !reuse_should_rebuild(h)) return g_err;
    if (h->precon) { HYPRE_BoomerAMGDestroy(h->precon); h->precon = nullptr; }
-   if (h->precon_aux) { HYPRE_BoomerAMGDestroy(h->precon_aux); h->precon_aux = nullptr; }
+   for (HYPRE_Solver a : h->precon_aux) HYPRE_BoomerAMGDestroy(a);
+   h->precon_aux.clear();
    h->precon_is_setup  = false;
    const PreconArgs &p = h->args.precon();
    if (p.method == 99) return g_err; // none
@@ -1670,9 +1682,9 @@ extern "C" uint32_t HYPREDRV_PreconDestroy(HYPREDRV_t h)
    if (h->precon && reuse_should_rebuild(h))
    {
       HYPRE_BoomerAMGDestroy(h->precon);
-      if (h->precon_aux) HYPRE_BoomerAMGDestroy(h->precon_aux);
+      for (HYPRE_Solver a : h->precon_aux) HYPRE_BoomerAMGDestroy(a);
+      h->precon_aux.clear();
       h->precon          = nullptr;
-      h->precon_aux      = nullptr;
       h->precon_is_setup = false;
    }
    API_CATCH

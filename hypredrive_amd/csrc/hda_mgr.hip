@@ -3,7 +3,7 @@
 // tree include/internal/mgr.h:132-178).  hypre is not part of the reference tree; this is the published
 // method (Ries / Trottenberg / Winter; hypre reference manual "MGR") for the option subset
 //   prolongation_type  injection | jacobi | l1-jacobi        restriction_type  injection | jacobi | columped
-//   f_relaxation       jacobi | l1-jacobi (n sweeps)          g_relaxation      none | hybrid (l1) Gauss-Seidel | ilu (ILU(0))
+//   f_relaxation       jacobi | l1-jacobi | amg on A_FF       g_relaxation      none | hybrid (l1) Gauss-Seidel | ilu (ILU(0))
 //   coarse_level_type  rap                                    coarsest_level    BoomerAMG (one V-cycle)
 // -- the same definition the CPU checker of the test suite restates.  PARITY UNPINNED against hypre: the
 // reference's MGR outputs need data sets that are not in its tree.
@@ -163,6 +163,43 @@ __global__ __launch_bounds__(256) void k_mgr_cgid(int n, const int *__restrict__
    if (i < n) out[i] = cf[i] > 0 ? first + (double)cidx[i] : -1.0;
 }
 
+// A_FF: rows = owned F points in order, columns = F points (owned: their F index; ghost: fidx holds nf + rank)
+__global__ __launch_bounds__(256) void k_mgr_ff_count(int n, const int *__restrict__ rp, const int *__restrict__ cj, const int *__restrict__ cf,
+                                                      const int *__restrict__ fidx, int *__restrict__ cnt)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n || cf[i] > 0) return;
+   int c = 0;
+   for (int k = rp[i]; k < rp[i + 1]; k++) c += (cf[cj[k]] < 0);
+   cnt[fidx[i]] = c;
+}
+__global__ __launch_bounds__(256) void k_mgr_ff_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                     const int *__restrict__ cf, const int *__restrict__ fidx, const int *__restrict__ frp,
+                                                     int *__restrict__ fcj, double *__restrict__ fv)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n || cf[i] > 0) return;
+   int q = frp[fidx[i]];
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (cf[cj[k]] < 0) { fcj[q] = fidx[cj[k]]; fv[q++] = v[k]; }
+}
+__global__ __launch_bounds__(256) void k_mgr_gatherF(int n, const int *__restrict__ cf, const int *__restrict__ fidx, const double *__restrict__ t,
+                                                     double *__restrict__ rF)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n && cf[i] < 0) rF[fidx[i]] = t[i];
+}
+__global__ __launch_bounds__(256) void k_mgr_addF(int n, const int *__restrict__ cf, const int *__restrict__ fidx, const double *__restrict__ eF, double *u)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n && cf[i] < 0) u[i] += eF[fidx[i]];
+}
+__global__ __launch_bounds__(256) void k_mgr_fmark(int n, const int *__restrict__ cf, int *__restrict__ fm)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) fm[i] = cf[i] < 0 ? 1 : 0;
+}
+
 bool gs_type(int t) { return t == 3 || t == 4 || t == 6 || t == 8 || t == 13 || t == 14 || t == 88; }
 
 void finish_csr(DCsr &M, int nrows, int ncols, DArray<int> &cnt)
@@ -212,7 +249,8 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
       HDA_REQUIRE(p.restrict_type == 0 || p.restrict_type == 2 || p.restrict_type == 14,
                   "MGR restriction_type: injection, jacobi and columped are implemented");
       HDA_REQUIRE(p.coarse_type == 0, "MGR coarse_level_type: only rap (Galerkin) is implemented");
-      HDA_REQUIRE(p.frelax_type == 7 || p.frelax_type == 18, "MGR f_relaxation: jacobi (single) and l1-jacobi are implemented");
+      HDA_REQUIRE(p.frelax_type == 7 || p.frelax_type == 18 || p.frelax_type == 2, "MGR f_relaxation: jacobi (single), l1-jacobi and amg are implemented");
+      HDA_REQUIRE(p.frelax_type != 2 || p.frelax_amg.num_functions <= 1, "MGR f_relaxation amg: systems AMG (num_functions > 1) on A_FF is not implemented");
       HDA_REQUIRE(p.grelax_type < 0 || gs_type(p.grelax_type) || p.grelax_type == 16,
                   "MGR g_relaxation: none, the hybrid (l1) Gauss-Seidel types and ilu are implemented");
       HDA_REQUIRE(!p.f_labels.empty(), "MGR: a reduction level without f_dofs");
@@ -320,6 +358,74 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
             k_mgr_R_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), A->val.data(), L.cf.data(), L.cidx.data(), p.restrict_type,
                                                               p.restrict_type == 14 ? csum.data() : dF.data(), L.R.rowptr.data(), L.R.col.data(),
                                                               L.R.val.data());
+      }
+      // f_relaxation amg: A_FF in the relative order of the F points and a BoomerAMG hierarchy on it
+      if (p.frelax_type == 2)
+      {
+         DArray<int> fm((size_t)nx + 1), fs((size_t)nx + 1);
+         fm.zero();
+         if (nx) k_mgr_fmark<<<ceil_div(nx, 256), 256, 0, STREAM>>>(nx, L.cf.data(), fm.data());
+         exclusive_scan(n, fm.data(), fs.data(), nullptr);
+         int nf = 0, nfx = 0;
+         HDA_HIP(hipMemcpyAsync(&nf, fs.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+         Context::get().sync();
+         L.fidx.alloc((size_t)nx + 1);
+         L.fidx.copy_from(fs);
+         if (ng)
+         {
+            DArray<int> gs((size_t)ng + 1);
+            exclusive_scan(ng, fm.data() + n, gs.data(), nullptr);
+            k_iota_add<<<ceil_div(ng, 256), 256, 0, STREAM>>>(ng, gs.data(), nf, L.fidx.data() + n);
+            HDA_HIP(hipMemcpyAsync(&nfx, gs.data() + ng, 4, hipMemcpyDeviceToHost, STREAM));
+            Context::get().sync();
+         }
+         L.nf = nf;
+         L.fpart.assign((size_t)cm.size + 1, 0);
+         {
+            std::vector<long long> all;
+            cm.allgather_ll(nf, all);
+            for (int r = 0; r < cm.size; r++) L.fpart[(size_t)r + 1] = L.fpart[(size_t)r] + all[(size_t)r];
+         }
+         L.fghosts.clear();
+         if (multi)
+         { // global F ids of the ghost F columns (ascending with the ghosts' global ids)
+            DArray<double> fg((size_t)std::max(nx, 1));
+            k_mgr_cgid<<<ceil_div(std::max(n, 1), 256), 256, 0, STREAM>>>(n, fm.data(), L.fidx.data(), (double)L.fpart[(size_t)cm.rank], fg.data());
+            halo_exchange(*hA, fg.data());
+            std::vector<double> hg((size_t)std::max(ng, 1));
+            std::vector<int>    hcf((size_t)std::max(ng, 1));
+            if (ng)
+            {
+               HDA_HIP(hipMemcpyAsync(hg.data(), fg.data() + n, 8 * (size_t)ng, hipMemcpyDeviceToHost, STREAM));
+               HDA_HIP(hipMemcpyAsync(hcf.data(), L.cf.data() + n, 4 * (size_t)ng, hipMemcpyDeviceToHost, STREAM));
+               Context::get().sync();
+            }
+            for (int g = 0; g < ng; g++)
+               if (hcf[(size_t)g] < 0) L.fghosts.push_back((long long)hg[(size_t)g]);
+            HDA_REQUIRE((int)L.fghosts.size() == nfx, "MGR: ghost F numbering is inconsistent");
+         }
+         DArray<int> cnt((size_t)nf + 1);
+         cnt.zero();
+         if (n) k_mgr_ff_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), L.cf.data(), L.fidx.data(), cnt.data());
+         finish_csr(L.Aff, nf, nf + nfx, cnt);
+         if (n)
+            k_mgr_ff_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), A->val.data(), L.cf.data(), L.fidx.data(),
+                                                               L.Aff.rowptr.data(), L.Aff.col.data(), L.Aff.val.data());
+         sort_rows(L.Aff); // ghosts below the owned range sort after the owned columns in the block layout
+         AmgParams fp = p.frelax_amg;
+         fp.max_iter  = 1;
+         L.famg       = std::make_unique<Amg>(fp);
+         if (multi)
+         {
+            L.hFF = make_halo_plan(nf, L.fpart, L.fghosts);
+            const char *mode = getenv("HDA_DIST_SETUP");
+            if ((mode && !strcmp(mode, "replicated")) || fp.coarsen_type != 8) L.famg->setup_dist(L.Aff, L.hFF, L.fpart, L.fghosts);
+            else L.famg->setup_dist_partitioned(L.Aff, L.hFF, L.fpart, L.fghosts);
+         }
+         else L.famg->setup(L.Aff);
+         const size_t fl = std::max<size_t>(L.famg->vec_len0(), (size_t)std::max(L.Aff.ncols, 1));
+         L.rF.alloc(fl);
+         L.eF.alloc(fl);
       }
       // global relaxation data
       if (p.grelax_type == 16)
@@ -451,6 +557,16 @@ double *Mgr::cycle(int l, const double *f, double *u, bool zero)
    }
    for (int s = 0; s < p.frelax_sweeps; s++)
    {
+      if (p.frelax_type == 2)
+      { // e_F = AMG(A_FF) (f - A u)_F from a zero guess, u_F += e_F
+         if (zero) { fill((int)std::max(A.ncols, n), 0.0, cur); zero = false; }
+         refresh(cur);
+         residual(A, cur, f, L.t.data());
+         if (n) k_mgr_gatherF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.t.data(), L.rF.data());
+         L.famg->apply(L.rF.data(), L.eF.data(), -1);
+         if (n) k_mgr_addF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.eF.data(), cur);
+         continue;
+      }
       if (zero) { jacobi_zero_guess(n, L.dinvF.data(), f, cur); zero = false; continue; } // u = dinvF .* f
       refresh(cur);
       jacobi(A, L.dinvF.data(), f, cur, alt, -1);

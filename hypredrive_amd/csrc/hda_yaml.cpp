@@ -418,7 +418,7 @@ static std::vector<int> int_list(Ctx &c, YNode &k, const char *what)
 }
 
 // f_relaxation / g_relaxation: a flat name, or a block with type / num_sweeps / a nested solver
-static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweeps, std::string &block)
+static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweeps, std::string &block, AmgArgs *amg = nullptr)
 {
    if (k.kids.empty())
    {
@@ -429,7 +429,14 @@ static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweep
    {
       if (q->key == "type") type = to_int(c, *q, &map);
       else if (q->key == "num_sweeps") sweeps = to_int(c, *q, nullptr);
-      else if (q->key == "amg" || q->key == "ilu" || q->key == "fsai" || q->key == "mgr" || q->key == "schwarz" || q->key == "reuse")
+      else if (q->key == "amg" && amg)
+      {
+         auto it = map.find("amg");
+         if (it != map.end()) type = it->second;
+         amg_fields(c, *q, *amg);
+      }
+      else if (q->key == "reuse") { /* component reuse policy: every setup rebuilds here */ }
+      else if (q->key == "amg" || q->key == "ilu" || q->key == "fsai" || q->key == "mgr" || q->key == "schwarz")
       {
          block = q->key;
          auto it = map.find(q->key);
@@ -458,7 +465,7 @@ static void mgr_fields(Ctx &c, YNode &sec, MgrArgs &m)
                else if (q->key == "prolongation_type") L.prolongation_type = to_int(c, *q, &kMgrInterp);
                else if (q->key == "restriction_type") L.restriction_type = to_int(c, *q, &kMgrRestrict);
                else if (q->key == "coarse_level_type") L.coarse_level_type = to_int(c, *q, &kMgrCoarse);
-               else if (q->key == "f_relaxation") mgr_relax(c, *q, kMgrFrelax, L.f_type, L.f_sweeps, L.f_block);
+               else if (q->key == "f_relaxation") mgr_relax(c, *q, kMgrFrelax, L.f_type, L.f_sweeps, L.f_block, &L.f_amg);
                else if (q->key == "g_relaxation") mgr_relax(c, *q, kMgrGrelax, L.g_type, L.g_sweeps, L.g_block);
                else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under 'mgr.level." + lvn->key + "'");
             }

@@ -102,7 +102,8 @@ struct MgrLevelArgs {
    int prolongation_type = 0, restriction_type = 0, coarse_level_type = 0;
    int f_type = 7, f_sweeps = 1; // f_relaxation
    int g_type = -1, g_sweeps = 1; // g_relaxation
-   std::string f_block, g_block;  // nested solver blocks (amg / ilu / ...) named here are not implemented
+   std::string f_block, g_block;  // nested solver blocks named here (only f_relaxation.amg is implemented)
+   AmgArgs     f_amg;             // f_relaxation: {amg: {...}}
 };
 struct MgrArgs {
    int    non_c_to_f = 1, pmax = 0, max_iter = 1, num_levels = 0, relax_type = 7, print_level = 0, nonglk_max_elmts = 1, cycle = 1;

@@ -1489,6 +1489,11 @@ typedef struct {
    double  *dinvF, *l1g;
    double  *f, *u, *t, *cor;
    orc_ilu *gilu; /* g_relaxation ilu (type 16): ILU(0) of the level operator, hypre's default ILU */
+   /* f_relaxation amg (type 2): one BoomerAMG cycle on A_FF per sweep */
+   orc_csr *Aff;
+   orc_amg *famg;
+   int     *fidx, nf, frelax_type;
+   double  *rF, *eF;
    int      frelax_sweeps, grelax_type, grelax_sweeps;
 } mgr_level;
 
@@ -1529,6 +1534,7 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
       mgr_level *L = &M->lv[l];
       const int  n = A->nrows;
       L->A = A; L->n = n; L->labels = labels;
+      L->frelax_type   = lp[l].frelax_type;
       L->frelax_sweeps = lp[l].frelax_sweeps; L->grelax_type = lp[l].grelax_type; L->grelax_sweeps = lp[l].grelax_sweeps;
       L->cf    = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
       L->cidx  = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
@@ -1612,6 +1618,32 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
          L->R = R;
       }
       free(dF); free(l1F); free(csum);
+      if (lp[l].frelax_type == 2)
+      { /* A_FF in the relative order of the F points, BoomerAMG on it */
+         L->fidx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+         int nf = 0, nnzf = 0;
+         for (int i = 0; i < n; i++) L->fidx[i] = (L->cf[i] < 0) ? nf++ : -1;
+         for (int i = 0; i < n; i++)
+            if (L->cf[i] < 0)
+               for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) nnzf += (L->cf[A->col[k]] < 0);
+         L->nf  = nf;
+         L->Aff = orc_csr_alloc(nf, nf, nnzf);
+         int q = 0;
+         for (int i = 0; i < n; i++)
+         {
+            if (L->cf[i] > 0) continue;
+            L->Aff->rowptr[L->fidx[i]] = q;
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+               if (L->cf[A->col[k]] < 0) { L->Aff->col[q] = L->fidx[A->col[k]]; L->Aff->val[q++] = A->val[k]; }
+         }
+         L->Aff->rowptr[nf] = q;
+         orc_amg_params fp;
+         if (lp[l].frelax_amg) fp = *lp[l].frelax_amg;
+         else orc_amg_default_params(&fp, 1);
+         L->famg = orc_amg_setup(L->Aff, &fp);
+         L->rF   = (double *)calloc((size_t)(nf > 0 ? nf : 1), sizeof(double));
+         L->eF   = (double *)calloc((size_t)(nf > 0 ? nf : 1), sizeof(double));
+      }
       /* global relaxation divisors */
       if (L->grelax_type == 16)
       {
@@ -1665,7 +1697,17 @@ mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
    {
       memcpy(L->t, f, sizeof(double) * (size_t)n);
       orc_spmv(L->A, -1.0, u, 1.0, L->t);
-      for (int i = 0; i < n; i++) u[i] += L->dinvF[i] * L->t[i];
+      if (L->frelax_type == 2)
+      { /* e_F = AMG(A_FF) r_F from a zero guess, u_F += e_F */
+         for (int i = 0; i < n; i++)
+            if (L->cf[i] < 0) L->rF[L->fidx[i]] = L->t[i];
+         memset(L->eF, 0, sizeof(double) * (size_t)L->nf);
+         orc_amg_vcycle(L->famg, L->rF, L->eF);
+         for (int i = 0; i < n; i++)
+            if (L->cf[i] < 0) u[i] += L->eF[L->fidx[i]];
+      }
+      else
+         for (int i = 0; i < n; i++) u[i] += L->dinvF[i] * L->t[i];
    }
    memcpy(L->t, f, sizeof(double) * (size_t)n);
    orc_spmv(L->A, -1.0, u, 1.0, L->t);
@@ -1692,6 +1734,9 @@ mgr_free(struct orc_mgr *M)
       orc_csr_free(L->A); orc_csr_free(L->P); orc_csr_free(L->R);
       free(L->labels); free(L->cf); free(L->cidx); free(L->dinvF); free(L->l1g); free(L->f); free(L->u); free(L->t); free(L->cor);
       if (L->gilu) orc_ilu_free(L->gilu);
+      if (L->famg) orc_amg_free(L->famg);
+      if (L->Aff) orc_csr_free(L->Aff);
+      free(L->fidx); free(L->rF); free(L->eF);
    }
    orc_csr_free(M->Ac);
    orc_amg_free(M->camg);

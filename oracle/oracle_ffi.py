@@ -31,7 +31,8 @@ class AmgParams(C.Structure):
 
 class MgrLevelParams(C.Structure):
     _fields_ = [("n_f_labels", C.c_int), ("f_labels", C.POINTER(C.c_int)), ("interp_type", C.c_int), ("restrict_type", C.c_int),
-                ("frelax_type", C.c_int), ("frelax_sweeps", C.c_int), ("grelax_type", C.c_int), ("grelax_sweeps", C.c_int)]
+                ("frelax_type", C.c_int), ("frelax_sweeps", C.c_int), ("grelax_type", C.c_int), ("grelax_sweeps", C.c_int),
+                ("frelax_amg", C.POINTER(AmgParams))]
 
 
 class KrylovParams(C.Structure):
@@ -410,7 +411,7 @@ class IluPrecond:
 
 MGR_INTERP = {"injection": 0, "l1-jacobi": 1, "jacobi": 2}
 MGR_RESTRICT = {"injection": 0, "jacobi": 2, "columped": 14}
-MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18}
+MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18, "amg": 2}
 MGR_GRELAX = {"none": -1, "h-fgs": 3, "h-bgs": 4, "h-ssor": 6, "l1-hfgs": 13, "l1-hbgs": 14, "l1-hsgs": 88, "ilu": 16}
 
 
@@ -430,6 +431,9 @@ def mgr_level_list(levels):
         arr[k].frelax_sweeps = lv.get("f_sweeps", 1)
         arr[k].grelax_type = MGR_GRELAX[lv.get("g_relaxation", "none")]
         arr[k].grelax_sweeps = lv.get("g_sweeps", 1)
+        if lv.get("f_amg") is not None:   # AmgParams of 'f_relaxation: {amg: {...}}'
+            keep.append(lv["f_amg"])
+            arr[k].frelax_amg = C.pointer(lv["f_amg"])
     return arr, keep
 
 

@@ -816,7 +816,14 @@ MGR_DIST_CASES = {
 }
 
 
-@pytest.mark.parametrize("world,case,rep_rows", [(2, "jacobi-columped", 0), (3, "jacobi-columped", 100000), (4, "ex3", 0), (3, "ex3", 100000)])
+MGR_DIST_CASES["famg"] = ("solver:\n  gmres:\n    relative_tol: 1.0e-8\npreconditioner:\n  mgr:\n    level:\n      0:\n        f_dofs: [0]\n"
+                          "        f_relaxation:\n          amg:\n            max_iter: 1\n            coarsening:\n              strong_th: 0.3\n"
+                          "        prolongation_type: jacobi\n    coarsest_level: amg\n",
+                          [dict(f_dofs=[0], prolongation_type="jacobi", f_relaxation="amg", f_amg_kw=dict(strong_th=0.3))], 1)
+
+
+@pytest.mark.parametrize("world,case,rep_rows", [(2, "jacobi-columped", 0), (3, "jacobi-columped", 100000), (4, "ex3", 0), (3, "ex3", 100000),
+                                                 (3, "famg", 0), (2, "famg", 100000)])
 def test_row_partitioned_mgr(hd, orc, tmp_path, world, case, rep_rows):
     """MGR on a row-partitioned matrix (rows cut inside cells too): ghost labels / C-F marks / coarse ids through the halo plan,
     reduced operators by two row-partitioned products, BoomerAMG on the partitioned coarsest system.  Without global relaxation
@@ -834,6 +841,10 @@ def test_row_partitioned_mgr(hd, orc, tmp_path, world, case, rep_rows):
     from test_oracle_pins import three_field_system
     S, labels = three_field_system(n, seed=4)
     Ao = orc.Csr.from_scipy(S)
+    lev = [dict(l) for l in lev]
+    for l in lev:
+        if "f_amg_kw" in l:
+            l["f_amg"] = orc.amg_params(True, **l.pop("f_amg_kw"))
     ref = orc.gmres(Ao, np.ones(S.shape[0]), orc.MgrPrecond(Ao, labels, lev), orc.krylov_params(True, rtol=1e-8))
     assert res["converged"] and abs(res["iters"] - ref["iters"]) <= slack, (res["iters"], ref["iters"])
     assert res["norm"] == pytest.approx(np.linalg.norm(ref["x"]), rel=1e-6)

@@ -725,6 +725,8 @@ MGR_CASES = [
     [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="l1-hsgs", restriction_type="columped")],   # ex3.yml
     [dict(f_dofs=[1, 2], prolongation_type="jacobi", g_relaxation="h-fgs", g_sweeps=2)],
     [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="ilu", restriction_type="columped")],       # ex4.yml / ex5-mgr.yml
+    [dict(f_dofs=[0], prolongation_type="jacobi", f_relaxation="amg")],                                                      # AMG on A_FF (diffusive field eliminated first)
+    [dict(f_dofs=[1, 2], prolongation_type="jacobi", f_relaxation="amg", f_sweeps=2)],
 ]
 
 
