@@ -181,13 +181,16 @@ struct MgrLevelParams {
    int interp_type = 0;                // prolongation_type: 0 injection, 1 l1-jacobi, 2 jacobi
    int restrict_type = 0;              // restriction_type: 0 injection, 2 jacobi, 14 columped
    int coarse_type = 0;                // coarse_level_type: 0 rap
-   int frelax_type = 7, frelax_sweeps = 1;   // f_relaxation: 7 jacobi, 18 l1-jacobi, 2 amg (one BoomerAMG cycle on A_FF)
+   int frelax_type = 7, frelax_sweeps = 1;   // f_relaxation: 7 jacobi, 18 l1-jacobi, 2 amg (one BoomerAMG cycle on A_FF), 32 ilu (ILU(0) of A_FF)
    AmgParams frelax_amg;                     // f_relaxation.amg block
+   IluParams ilu;                            // ILU arguments of this level's ILU components (f_relaxation 32, g_relaxation 16)
    int grelax_type = -1, grelax_sweeps = 1;  // g_relaxation: -1 none, 3/4/6/13/14 hybrid GS, 88 l1-hsgs, 16 ilu
 };
 struct MgrParams {
    std::vector<MgrLevelParams> levels;
    AmgParams                   coarse; // coarsest_level: amg
+   bool                        coarse_is_ilu = false; // coarsest_level: ilu
+   IluParams                   coarse_ilu;
    int                         max_iter = 1;
 };
 class Mgr {
@@ -224,6 +227,7 @@ class Mgr {
       std::vector<long long> fpart, fghosts;
       DArray<int>            fidx;
       std::unique_ptr<Amg>   famg;
+      std::unique_ptr<Ilu>   filu; // f_relaxation ilu
       DArray<double>         rF, eF;
       int                    nf = 0;
       int            n = 0, nc = 0;
@@ -236,7 +240,8 @@ class Mgr {
    size_t                 coarse_len = 0;
    int                    a0_dims[3] = {0, 0, 0};
    std::unique_ptr<Amg>   camg;
-   DArray<double>         fc, uc;
+   std::unique_ptr<Ilu>   cilu; // coarsest_level ilu
+   DArray<double>         fc, uc, cilu_r, cilu_c;
 };
 
 // ---- setup kernels (hda_amg_setup.hip); exposed for per-kernel parity tests -------------

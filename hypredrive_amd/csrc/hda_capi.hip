@@ -400,6 +400,13 @@ extern "C" int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const
    MgrParams p;
    p.coarse   = to_params(coarsest_amg);
    p.max_iter = max_iter;
+   if (!coarsest_amg)
+   { // coarsest_level: ilu -- its arguments ride in the last level's entry
+      const hda_mgr_level_params &q = levels[nlevels - 1];
+      p.coarse_is_ilu        = true;
+      p.coarse_ilu.max_iter  = q.coarse_ilu_max_iter; p.coarse_ilu.tri_solve = q.coarse_ilu_tri_solve;
+      p.coarse_ilu.lower_it  = q.coarse_ilu_lower_it; p.coarse_ilu.upper_it = q.coarse_ilu_upper_it;
+   }
    for (int l = 0; l < nlevels; l++)
    {
       MgrLevelParams q;
@@ -408,6 +415,7 @@ extern "C" int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const
       q.frelax_type = levels[l].frelax_type; q.frelax_sweeps = levels[l].frelax_sweeps;
       q.grelax_type = levels[l].grelax_type; q.grelax_sweeps = levels[l].grelax_sweeps;
       if (levels[l].frelax_amg) q.frelax_amg = to_params(levels[l].frelax_amg);
+      q.ilu.tri_solve = levels[l].ilu_tri_solve; q.ilu.lower_it = levels[l].ilu_lower_it; q.ilu.upper_it = levels[l].ilu_upper_it;
       p.levels.push_back(q);
    }
    auto h = std::make_unique<hda_amg_s>();

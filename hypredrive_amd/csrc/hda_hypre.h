@@ -69,7 +69,7 @@ struct hypre_Solver_struct {
    const HYPRE_Int              *mgr_marker = nullptr; // borrowed until Setup, as in hypre
    std::vector<int>              mgr_frelax, mgr_fsweeps, mgr_interp, mgr_restrict, mgr_coarse_method, mgr_gsmooth, mgr_giters;
    HYPRE_Solver                  mgr_csolver = nullptr;
-   std::vector<HYPRE_Solver>     mgr_fsolver; // F-relaxation solver handles by level (HYPRE_MGRSetFSolverAtLevel)
+   std::vector<HYPRE_Solver>     mgr_fsolver, mgr_gsolver; // F-relaxation / global smoother handles by level (HYPRE_MGRSetFSolverAtLevel / SetGlobalSmootherAtLevel)
    hda::KrylovResult         last;
    int                       amg_iters = 0;
    double                    amg_rel   = 0.0;

@@ -1306,6 +1306,14 @@ extern "C" HYPRE_Int HYPRE_MGRSetFSolverAtLevel(HYPRE_Solver s, HYPRE_Solver fso
    return 0;
 }
 
+extern "C" HYPRE_Int HYPRE_MGRSetGlobalSmootherAtLevel(HYPRE_Solver s, HYPRE_Solver smoother, HYPRE_Int level)
+{
+   if (!s || level < 0 || level > 30) return hypre_set_error(HYPRE_ERROR_ARG, "HYPRE_MGRSetGlobalSmootherAtLevel: bad arguments");
+   if ((size_t)level >= s->mgr_gsolver.size()) s->mgr_gsolver.resize((size_t)level + 1, nullptr);
+   s->mgr_gsolver[(size_t)level] = smoother;
+   return 0;
+}
+
 extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVector, HYPRE_ParVector)
 {
    HY_NEED_DEVICE;
@@ -1316,10 +1324,18 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
    HDA_REQUIRE(s->mgr_cycle == 1, "MGR: only V-cycles (cycle 1) are implemented");
    HDA_REQUIRE(s->mgr_frelax_cycle == 1 && s->mgr_gsmooth_cycle == 1, "MGR: only pre-smoothing (cycle_smooth_pos 1) is implemented");
    HDA_REQUIRE(s->mgr_coarse_th == 0.0, "MGR: coarse_th (coarse grid truncation) is not implemented");
-   HDA_REQUIRE(!s->mgr_csolver || s->mgr_csolver->kind == HDA_SOLVER_AMG, "MGR coarsest_level: only BoomerAMG is implemented");
+   HDA_REQUIRE(!s->mgr_csolver || s->mgr_csolver->kind == HDA_SOLVER_AMG || s->mgr_csolver->kind == HDA_SOLVER_ILU,
+               "MGR coarsest_level: BoomerAMG and ILU are implemented");
+   auto ilu_ok = [](HYPRE_Solver q) { return q->ilu_type == 0 && q->ilu_fill == 0 && q->ilu_reordering == 0; };
    MgrParams p;
    p.max_iter = s->mgr_max_iter;
-   if (s->mgr_csolver) p.coarse = s->mgr_csolver->ap;
+   if (s->mgr_csolver && s->mgr_csolver->kind == HDA_SOLVER_ILU)
+   {
+      HDA_REQUIRE(ilu_ok(s->mgr_csolver), "MGR coarsest_level ilu: only type bj-iluk with fill_level 0 and reordering 0 is implemented");
+      p.coarse_is_ilu = true;
+      p.coarse_ilu    = s->mgr_csolver->ilup;
+   }
+   else if (s->mgr_csolver) p.coarse = s->mgr_csolver->ap;
    else { AmgParams d; p.coarse = d; }
    p.coarse.max_iter = 1; // one V-cycle per MGR cycle (amg.c:224-226 defaults)
    // F labels of level l = C labels of level l-1 (all labels of the marker array for l = 0) that are no longer C
@@ -1343,16 +1359,30 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
       q.restrict_type = at(s->mgr_restrict, l, 0);
       q.coarse_type   = at(s->mgr_coarse_method, l, 0);
       q.frelax_type   = at(s->mgr_frelax, l, 7);
-      if (q.frelax_type == 2)
+      if (q.frelax_type == 2 || q.frelax_type == 32)
       {
          HYPRE_Solver fs = (size_t)l < s->mgr_fsolver.size() ? s->mgr_fsolver[(size_t)l] : nullptr;
-         HDA_REQUIRE(!fs || fs->kind == HDA_SOLVER_AMG, "MGR f_relaxation: only a BoomerAMG F-solver is implemented");
-         if (fs) { q.frelax_amg = fs->ap; q.frelax_amg.num_functions = std::max(fs->num_functions, 1); }
+         HDA_REQUIRE(!fs || fs->kind == (q.frelax_type == 2 ? HDA_SOLVER_AMG : HDA_SOLVER_ILU), "MGR f_relaxation: the F-solver handle does not match its type (amg / ilu)");
+         if (fs && q.frelax_type == 2) { q.frelax_amg = fs->ap; q.frelax_amg.num_functions = std::max(fs->num_functions, 1); }
+         if (fs && q.frelax_type == 32)
+         {
+            HDA_REQUIRE(ilu_ok(fs), "MGR f_relaxation ilu: only type bj-iluk with fill_level 0 and reordering 0 is implemented");
+            q.ilu = fs->ilup;
+         }
       }
       q.frelax_sweeps = at(s->mgr_fsweeps, l, 1);
       q.grelax_type   = at(s->mgr_gsmooth, l, -1);
       q.grelax_sweeps = at(s->mgr_giters, l, 1);
       if (q.grelax_sweeps <= 0) q.grelax_type = -1; // hypre: no global smoothing without sweeps
+      if ((size_t)l < s->mgr_gsolver.size() && s->mgr_gsolver[(size_t)l])
+      { // a smoother object handed over with HYPRE_MGRSetGlobalSmootherAtLevel (mgr.c: ILU with its own arguments)
+         HYPRE_Solver gs = s->mgr_gsolver[(size_t)l];
+         HDA_REQUIRE(gs->kind == HDA_SOLVER_ILU && ilu_ok(gs), "MGR g_relaxation: only an ILU (bj-iluk, fill_level 0, reordering 0) smoother object is implemented");
+         q.grelax_type   = 16;
+         q.grelax_sweeps = std::max(q.grelax_sweeps, 1);
+         const IluParams keep = q.frelax_type == 32 ? q.ilu : gs->ilup;
+         q.ilu           = keep; // (one set of ILU arguments per level: the F-solver's wins when both are ILU)
+      }
       p.levels.push_back(q);
       prev = c;
    }

@@ -1381,8 +1381,8 @@ static uint32_t mgr_create(hypredrv_struct *h, const MgrArgs &a)
    if (h->dofmap.empty())
       return err_set(ERR_MISSING_DOFMAP, "MGR needs a dofmap (linear_system.dofmap_filename, HYPREDRV_LinearSystemSetDofmap or ...SetInterleavedDofmap)");
    if (a.level.empty()) return err_set(ERR_MISSING_KEY, "preconditioner.mgr.level: at least level 0 with its f_dofs is needed");
-   if (a.coarsest_type > 0 || (!a.coarsest_block.empty() && a.coarsest_block != "reuse"))
-      return err_set(ERR_INVALID_PRECON | HYPREDRV_ERROR_UNSUPPORTED_AMD, "MGR coarsest_level: only BoomerAMG is implemented on MI355X");
+   if ((a.coarsest_type > 0 && a.coarsest_type != 32) || !a.coarsest_block.empty())
+      return err_set(ERR_INVALID_PRECON | HYPREDRV_ERROR_UNSUPPORTED_AMD, "MGR coarsest_level: BoomerAMG and ILU are implemented on MI355X");
    const int nlev = (int)a.level.size();
    // labels present (every rank sees the same set in a well-formed dofmap; one rank here)
    std::vector<int> cur = h->dofmap;
@@ -1398,7 +1398,7 @@ static uint32_t mgr_create(hypredrv_struct *h, const MgrArgs &a)
       const MgrLevelArgs &L = a.level[(size_t)l];
       if (L.f_dofs.empty()) return err_set(ERR_MISSING_KEY, "preconditioner.mgr.level." + std::to_string(l) + ".f_dofs is missing");
       for (const std::string *b : {&L.f_block, &L.g_block})
-         if (!b->empty() && *b != "reuse")
+         if (!b->empty())
             return err_set(ERR_INVALID_PRECON | HYPREDRV_ERROR_UNSUPPORTED_AMD,
                            "MGR level " + std::to_string(l) + ": a nested '" + *b + "' relaxation solver is not implemented on MI355X");
       for (int f : L.f_dofs)
@@ -1439,17 +1439,37 @@ static uint32_t mgr_create(hypredrv_struct *h, const MgrArgs &a)
    HYPRE_MGRSetLevelSmoothIters(p, git.data());
    HYPRE_MGRSetNonGalerkinMaxElmts(p, a.nonglk_max_elmts);
    for (int l = 0; l < nlev; l++)
-      if (a.level[(size_t)l].f_type == 2)
-      { // f_relaxation amg: a BoomerAMG handle for A_FF (reference mgr.c:2594, HYPRE_MGRSetFSolverAtLevel)
+   {
+      const MgrLevelArgs &L = a.level[(size_t)l];
+      if (L.f_type == 2 || L.f_type == 32)
+      { // f_relaxation amg / ilu: a solver handle for A_FF (reference mgr.c:2594, HYPRE_MGRSetFSolverAtLevel)
          HYPRE_Solver fs = nullptr;
-         amg_create(a.level[(size_t)l].f_amg, &fs);
+         if (L.f_type == 2) amg_create(L.f_amg, &fs);
+         else ilu_create(L.f_ilu, &fs);
          h->precon_aux.push_back(fs);
          HYPRE_MGRSetFSolverAtLevel(p, fs, l);
       }
+      if (L.g_type == 16 && L.g_ilu_block)
+      { // g_relaxation with its own ilu block: a smoother object (HYPRE_MGRSetGlobalSmootherAtLevel); the flat
+        // "g_relaxation: ilu" is hypre's built-in type 16 with default ILU arguments
+         HYPRE_Solver gs = nullptr;
+         ilu_create(L.g_ilu, &gs);
+         h->precon_aux.push_back(gs);
+         HYPRE_MGRSetGlobalSmootherAtLevel(p, gs, l);
+      }
+   }
    HYPRE_Solver cs = nullptr;
-   amg_create(a.coarsest_amg, &cs);
+   if (a.coarsest_type == 32)
+   {
+      ilu_create(a.coarsest_ilu, &cs);
+      HYPRE_MGRSetCoarseSolver(p, HYPRE_ILUSolve, HYPRE_ILUSetup, cs);
+   }
+   else
+   {
+      amg_create(a.coarsest_amg, &cs);
+      HYPRE_MGRSetCoarseSolver(p, HYPRE_BoomerAMGSolve, HYPRE_BoomerAMGSetup, cs);
+   }
    h->precon_aux.push_back(cs);
-   HYPRE_MGRSetCoarseSolver(p, HYPRE_BoomerAMGSolve, HYPRE_BoomerAMGSetup, cs);
    h->precon = p;
    consume_hypre_errors();
    return g_err;

@@ -3,8 +3,8 @@
 // tree include/internal/mgr.h:132-178).  hypre is not part of the reference tree; this is the published
 // method (Ries / Trottenberg / Winter; hypre reference manual "MGR") for the option subset
 //   prolongation_type  injection | jacobi | l1-jacobi        restriction_type  injection | jacobi | columped
-//   f_relaxation       jacobi | l1-jacobi | amg on A_FF       g_relaxation      none | hybrid (l1) Gauss-Seidel | ilu (ILU(0))
-//   coarse_level_type  rap                                    coarsest_level    BoomerAMG (one V-cycle)
+//   f_relaxation       jacobi | l1-jacobi | amg / ilu on A_FF  g_relaxation      none | hybrid (l1) Gauss-Seidel | ilu (ILU(0))
+//   coarse_level_type  rap                                    coarsest_level    BoomerAMG (one V-cycle) | ilu
 // -- the same definition the CPU checker of the test suite restates.  PARITY UNPINNED against hypre: the
 // reference's MGR outputs need data sets that are not in its tree.
 // Row partitions: labels, C/F marks and coarse ids of the ghost columns come through the halo plan of the level's
@@ -249,7 +249,8 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
       HDA_REQUIRE(p.restrict_type == 0 || p.restrict_type == 2 || p.restrict_type == 14,
                   "MGR restriction_type: injection, jacobi and columped are implemented");
       HDA_REQUIRE(p.coarse_type == 0, "MGR coarse_level_type: only rap (Galerkin) is implemented");
-      HDA_REQUIRE(p.frelax_type == 7 || p.frelax_type == 18 || p.frelax_type == 2, "MGR f_relaxation: jacobi (single), l1-jacobi and amg are implemented");
+      HDA_REQUIRE(p.frelax_type == 7 || p.frelax_type == 18 || p.frelax_type == 2 || p.frelax_type == 32,
+                  "MGR f_relaxation: jacobi (single), l1-jacobi, amg and ilu are implemented");
       HDA_REQUIRE(p.frelax_type != 2 || p.frelax_amg.num_functions <= 1, "MGR f_relaxation amg: systems AMG (num_functions > 1) on A_FF is not implemented");
       HDA_REQUIRE(p.grelax_type < 0 || gs_type(p.grelax_type) || p.grelax_type == 16,
                   "MGR g_relaxation: none, the hybrid (l1) Gauss-Seidel types and ilu are implemented");
@@ -360,7 +361,7 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
                                                               L.R.val.data());
       }
       // f_relaxation amg: A_FF in the relative order of the F points and a BoomerAMG hierarchy on it
-      if (p.frelax_type == 2)
+      if (p.frelax_type == 2 || p.frelax_type == 32)
       {
          DArray<int> fm((size_t)nx + 1), fs((size_t)nx + 1);
          fm.zero();
@@ -412,18 +413,27 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
             k_mgr_ff_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A->rowptr.data(), A->col.data(), A->val.data(), L.cf.data(), L.fidx.data(),
                                                                L.Aff.rowptr.data(), L.Aff.col.data(), L.Aff.val.data());
          sort_rows(L.Aff); // ghosts below the owned range sort after the owned columns in the block layout
-         AmgParams fp = p.frelax_amg;
-         fp.max_iter  = 1;
-         L.famg       = std::make_unique<Amg>(fp);
-         if (multi)
-         {
-            L.hFF = make_halo_plan(nf, L.fpart, L.fghosts);
-            const char *mode = getenv("HDA_DIST_SETUP");
-            if ((mode && !strcmp(mode, "replicated")) || fp.coarsen_type != 8) L.famg->setup_dist(L.Aff, L.hFF, L.fpart, L.fghosts);
-            else L.famg->setup_dist_partitioned(L.Aff, L.hFF, L.fpart, L.fghosts);
+         size_t fl = (size_t)std::max(L.Aff.ncols, 1);
+         if (p.frelax_type == 32)
+         { // block-Jacobi ILU(0) of this rank's diagonal block of A_FF
+            L.filu = std::make_unique<Ilu>();
+            L.filu->setup(L.Aff, p.ilu);
          }
-         else L.famg->setup(L.Aff);
-         const size_t fl = std::max<size_t>(L.famg->vec_len0(), (size_t)std::max(L.Aff.ncols, 1));
+         else
+         {
+            AmgParams fp = p.frelax_amg;
+            fp.max_iter  = 1;
+            L.famg       = std::make_unique<Amg>(fp);
+            if (multi)
+            {
+               L.hFF = make_halo_plan(nf, L.fpart, L.fghosts);
+               const char *mode = getenv("HDA_DIST_SETUP");
+               if ((mode && !strcmp(mode, "replicated")) || fp.coarsen_type != 8) L.famg->setup_dist(L.Aff, L.hFF, L.fpart, L.fghosts);
+               else L.famg->setup_dist_partitioned(L.Aff, L.hFF, L.fpart, L.fghosts);
+            }
+            else L.famg->setup(L.Aff);
+            fl = std::max(fl, L.famg->vec_len0());
+         }
          L.rF.alloc(fl);
          L.eF.alloc(fl);
       }
@@ -431,8 +441,8 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
       if (p.grelax_type == 16)
       { // hypre's default ILU as global smoother: block-Jacobi ILU(0), exact triangular solves
          L.gilu = std::make_unique<Ilu>();
-         IluParams ip;
-         ip.max_iter = std::max(p.grelax_sweeps, 1);
+         IluParams ip = p.ilu;
+         ip.max_iter  = std::max(p.grelax_sweeps, 1);
          L.gilu->setup(*A, ip);
       }
       else if (p.grelax_type >= 0)
@@ -486,7 +496,19 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
    }
    cparts  = part;
    cghosts_ = ghosts;
-   // coarsest system: BoomerAMG
+   // coarsest system: BoomerAMG, or block-Jacobi ILU(0) iterations
+   if (prm.coarse_is_ilu)
+   {
+      camg.reset();
+      cilu = std::make_unique<Ilu>();
+      cilu->setup(Ac, prm.coarse_ilu);
+      const size_t clen = std::max(coarse_len, (size_t)std::max(Ac.ncols, 1));
+      fc.alloc(clen);
+      uc.alloc(clen);
+      Context::get().sync();
+      return;
+   }
+   cilu.reset();
    camg = std::make_unique<Amg>(prm.coarse);
    if (multi)
    {
@@ -529,7 +551,8 @@ double *Mgr::cycle(int l, const double *f, double *u, bool zero)
 {
    if (l == (int)lv.size())
    {
-      camg->apply(f, u, -1);
+      if (camg) camg->apply(f, u, -1);
+      else ilu_solve(*cilu, Ac, Comm::world().size > 1 ? &hAc : nullptr, f, u, true, cilu_r, cilu_c);
       return u;
    }
    Level                &L = lv[(size_t)l];
@@ -557,13 +580,14 @@ double *Mgr::cycle(int l, const double *f, double *u, bool zero)
    }
    for (int s = 0; s < p.frelax_sweeps; s++)
    {
-      if (p.frelax_type == 2)
-      { // e_F = AMG(A_FF) (f - A u)_F from a zero guess, u_F += e_F
+      if (p.frelax_type == 2 || p.frelax_type == 32)
+      { // e_F = M_FF^-1 (f - A u)_F (one BoomerAMG cycle from a zero guess, or one ILU(0) solve), u_F += e_F
          if (zero) { fill((int)std::max(A.ncols, n), 0.0, cur); zero = false; }
          refresh(cur);
          residual(A, cur, f, L.t.data());
          if (n) k_mgr_gatherF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.t.data(), L.rF.data());
-         L.famg->apply(L.rF.data(), L.eF.data(), -1);
+         if (L.famg) L.famg->apply(L.rF.data(), L.eF.data(), -1);
+         else L.filu->apply(L.rF.data(), L.eF.data());
          if (n) k_mgr_addF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.eF.data(), cur);
          continue;
       }

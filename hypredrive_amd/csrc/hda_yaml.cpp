@@ -418,7 +418,9 @@ static std::vector<int> int_list(Ctx &c, YNode &k, const char *what)
 }
 
 // f_relaxation / g_relaxation: a flat name, or a block with type / num_sweeps / a nested solver
-static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweeps, std::string &block, AmgArgs *amg = nullptr)
+static void ilu_fields(Ctx &c, YNode &sec, IluArgs &a);
+static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweeps, std::string &block, AmgArgs *amg = nullptr,
+                      IluArgs *ilu = nullptr, bool *ilu_block = nullptr)
 {
    if (k.kids.empty())
    {
@@ -434,6 +436,13 @@ static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweep
          auto it = map.find("amg");
          if (it != map.end()) type = it->second;
          amg_fields(c, *q, *amg);
+      }
+      else if (q->key == "ilu" && ilu)
+      {
+         auto it = map.find("ilu");
+         if (it != map.end()) type = it->second;
+         ilu_fields(c, *q, *ilu);
+         if (ilu_block) *ilu_block = true;
       }
       else if (q->key == "reuse") { /* component reuse policy: every setup rebuilds here */ }
       else if (q->key == "amg" || q->key == "ilu" || q->key == "fsai" || q->key == "mgr" || q->key == "schwarz")
@@ -465,8 +474,8 @@ static void mgr_fields(Ctx &c, YNode &sec, MgrArgs &m)
                else if (q->key == "prolongation_type") L.prolongation_type = to_int(c, *q, &kMgrInterp);
                else if (q->key == "restriction_type") L.restriction_type = to_int(c, *q, &kMgrRestrict);
                else if (q->key == "coarse_level_type") L.coarse_level_type = to_int(c, *q, &kMgrCoarse);
-               else if (q->key == "f_relaxation") mgr_relax(c, *q, kMgrFrelax, L.f_type, L.f_sweeps, L.f_block, &L.f_amg);
-               else if (q->key == "g_relaxation") mgr_relax(c, *q, kMgrGrelax, L.g_type, L.g_sweeps, L.g_block);
+               else if (q->key == "f_relaxation") mgr_relax(c, *q, kMgrFrelax, L.f_type, L.f_sweeps, L.f_block, &L.f_amg, &L.f_ilu);
+               else if (q->key == "g_relaxation") mgr_relax(c, *q, kMgrGrelax, L.g_type, L.g_sweeps, L.g_block, nullptr, &L.g_ilu, &L.g_ilu_block);
                else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under 'mgr.level." + lvn->key + "'");
             }
          }
@@ -479,7 +488,9 @@ static void mgr_fields(Ctx &c, YNode &sec, MgrArgs &m)
             {
                if (q->key == "type") m.coarsest_type = to_int(c, *q, &kMgrCoarsest);
                else if (q->key == "amg") { m.coarsest_type = 0; amg_fields(c, *q, m.coarsest_amg); }
-               else if (q->key == "ilu" || q->key == "fsai" || q->key == "schwarz" || q->key == "spdirect" || q->key == "reuse" || q->key == "krylov")
+               else if (q->key == "ilu") { m.coarsest_type = 32; ilu_fields(c, *q, m.coarsest_ilu); }
+               else if (q->key == "reuse") { /* component reuse policy: every setup rebuilds here */ }
+               else if (q->key == "fsai" || q->key == "schwarz" || q->key == "spdirect" || q->key == "krylov")
                {
                   m.coarsest_block = q->key;
                   auto it = kMgrCoarsest.find(q->key);

@@ -104,6 +104,8 @@ struct MgrLevelArgs {
    int g_type = -1, g_sweeps = 1; // g_relaxation
    std::string f_block, g_block;  // nested solver blocks named here (only f_relaxation.amg is implemented)
    AmgArgs     f_amg;             // f_relaxation: {amg: {...}}
+   IluArgs     f_ilu, g_ilu;      // f_relaxation / g_relaxation: {ilu: {...}}
+   bool        g_ilu_block = false; // g_relaxation came with its own ilu block (a smoother object, not hypre's built-in type 16)
 };
 struct MgrArgs {
    int    non_c_to_f = 1, pmax = 0, max_iter = 1, num_levels = 0, relax_type = 7, print_level = 0, nonglk_max_elmts = 1, cycle = 1;
@@ -112,6 +114,7 @@ struct MgrArgs {
    int         coarsest_type = -1; // -1 / 0: BoomerAMG
    std::string coarsest_block;     // anything but amg is not implemented
    AmgArgs     coarsest_amg;
+   IluArgs     coarsest_ilu;
 };
 struct PreconArgs {
    int         method = 0; // 0 boomeramg, 1 mgr, 2 ilu, 3 fsai, ... 99 none

@@ -257,7 +257,7 @@ HYPRE_Int HYPRE_BoomerAMGSetILUMaxIter(HYPRE_Solver solver, HYPRE_Int n);
 
 /* ---- MGR (reference src/internal/mgr.c:3782-3808 and the per-level arrays after :3820).  Implemented on MI355X: C points by
  * dof label, prolongation injection / jacobi / l1-jacobi, restriction injection / jacobi / columped, Galerkin coarse grids,
- * Jacobi / l1-Jacobi / BoomerAMG-on-A_FF F-relaxation, hybrid (l1) Gauss-Seidel or ILU(0) global relaxation, BoomerAMG coarse solver, V-cycle, one rank or a row partition.
+ * Jacobi / l1-Jacobi / BoomerAMG- or ILU-on-A_FF F-relaxation, hybrid (l1) Gauss-Seidel or ILU(0) global relaxation, BoomerAMG or ILU coarse solver, V-cycle, one rank or a row partition.
  * Anything else is rejected at Setup. */
 HYPRE_Int HYPRE_MGRCreate(HYPRE_Solver *solver);
 HYPRE_Int HYPRE_MGRDestroy(HYPRE_Solver solver);
@@ -284,7 +284,8 @@ HYPRE_Int HYPRE_MGRSetLevelRestrictType(HYPRE_Solver solver, HYPRE_Int *types);
 HYPRE_Int HYPRE_MGRSetCoarseGridMethod(HYPRE_Solver solver, HYPRE_Int *methods);
 HYPRE_Int HYPRE_MGRSetLevelSmoothType(HYPRE_Solver solver, HYPRE_Int *types);
 HYPRE_Int HYPRE_MGRSetLevelSmoothIters(HYPRE_Solver solver, HYPRE_Int *iters);
-HYPRE_Int HYPRE_MGRSetFSolverAtLevel(HYPRE_Solver solver, HYPRE_Solver fsolver, HYPRE_Int level); /* a BoomerAMG handle for A_FF */
+HYPRE_Int HYPRE_MGRSetFSolverAtLevel(HYPRE_Solver solver, HYPRE_Solver fsolver, HYPRE_Int level);       /* a BoomerAMG or ILU handle for A_FF */
+HYPRE_Int HYPRE_MGRSetGlobalSmootherAtLevel(HYPRE_Solver solver, HYPRE_Solver smoother, HYPRE_Int level); /* an ILU handle */
 HYPRE_Int HYPRE_MGRSetCoarseSolver(HYPRE_Solver solver, HYPRE_PtrToSolverFcn solve, HYPRE_PtrToSolverFcn setup, HYPRE_Solver coarse_solver);
 HYPRE_Int HYPRE_MGRGetNumIterations(HYPRE_Solver solver, HYPRE_Int *n);
 HYPRE_Int HYPRE_MGRGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *r);

@@ -112,8 +112,8 @@ int hda_ilu_create(hda_csr_t A, int max_iter, int tri_solve, int lower_it, int u
 /* "preconditioner: mgr" (reference src/internal/mgr.c; MGRlvl_args include/internal/mgr.h:132-147): multigrid reduction
  * by dof labels with BoomerAMG on the coarsest system.  labels = dofmap of A's rows.  Implemented per level:
  * prolongation injection (0) / l1-jacobi (1) / jacobi (2); restriction injection (0) / jacobi (2) / columped (14);
- * f_relaxation jacobi (7) / l1-jacobi (18) / one BoomerAMG cycle on A_FF (2); g_relaxation none (-1) / hybrid (l1) Gauss-Seidel (3, 4, 6, 13, 14, 88);
- * coarse grid by Galerkin product.  This test entry is single-rank (row partitions go through HYPRE_MGRSetup).  The handle is accepted by the Krylov entry points and hda_amg_vcycle. */
+ * f_relaxation jacobi (7) / l1-jacobi (18) / one BoomerAMG cycle (2) or ILU(0) solve (32) on A_FF; g_relaxation none (-1) / hybrid (l1) Gauss-Seidel (3, 4, 6, 13, 14, 88);
+ * coarse grid by Galerkin product; coarsest system by BoomerAMG or ILU(0) iterations.  This test entry is single-rank (row partitions go through HYPRE_MGRSetup).  The handle is accepted by the Krylov entry points and hda_amg_vcycle. */
 typedef struct {
    int        n_f_labels;
    const int *f_labels; /* level.N.f_dofs */
@@ -121,6 +121,9 @@ typedef struct {
    int        frelax_type, frelax_sweeps;
    int        grelax_type, grelax_sweeps;
    const hda_amg_params *frelax_amg; /* f_relaxation.amg block for frelax_type 2 (NULL: defaults) */
+   int        ilu_tri_solve, ilu_lower_it, ilu_upper_it; /* ILU arguments of this level's ILU components (frelax 32, grelax 16) */
+   /* coarsest_level: ilu -- read from the LAST level's entry when hda_mgr_create gets coarsest_amg == NULL */
+   int        coarse_ilu_max_iter, coarse_ilu_tri_solve, coarse_ilu_lower_it, coarse_ilu_upper_it;
 } hda_mgr_level_params;
 int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const hda_mgr_level_params *levels,
                    const hda_amg_params *coarsest_amg, int max_iter, hda_amg_t *out);

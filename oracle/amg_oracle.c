@@ -1492,6 +1492,7 @@ typedef struct {
    /* f_relaxation amg (type 2): one BoomerAMG cycle on A_FF per sweep */
    orc_csr *Aff;
    orc_amg *famg;
+   orc_ilu *filu; /* f_relaxation ilu (type 32): ILU(0) of A_FF */
    int     *fidx, nf, frelax_type;
    double  *rF, *eF;
    int      frelax_sweeps, grelax_type, grelax_sweeps;
@@ -1502,6 +1503,9 @@ struct orc_mgr {
    mgr_level *lv;
    orc_csr   *Ac;   /* coarsest operator */
    orc_amg   *camg;
+   orc_ilu   *cilu; /* coarsest_level ilu: coarse_ilu_iters iterations of x += M^-1 (f - A_c x) */
+   int        cilu_iters;
+   double    *ct, *cc;
    double    *fc, *uc;
    int        max_iter;
 };
@@ -1618,8 +1622,8 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
          L->R = R;
       }
       free(dF); free(l1F); free(csum);
-      if (lp[l].frelax_type == 2)
-      { /* A_FF in the relative order of the F points, BoomerAMG on it */
+      if (lp[l].frelax_type == 2 || lp[l].frelax_type == 32)
+      { /* A_FF in the relative order of the F points, BoomerAMG (2) or ILU(0) (32) on it */
          L->fidx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
          int nf = 0, nnzf = 0;
          for (int i = 0; i < n; i++) L->fidx[i] = (L->cf[i] < 0) ? nf++ : -1;
@@ -1637,17 +1641,21 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
                if (L->cf[A->col[k]] < 0) { L->Aff->col[q] = L->fidx[A->col[k]]; L->Aff->val[q++] = A->val[k]; }
          }
          L->Aff->rowptr[nf] = q;
-         orc_amg_params fp;
-         if (lp[l].frelax_amg) fp = *lp[l].frelax_amg;
-         else orc_amg_default_params(&fp, 1);
-         L->famg = orc_amg_setup(L->Aff, &fp);
+         if (lp[l].frelax_type == 2)
+         {
+            orc_amg_params fp;
+            if (lp[l].frelax_amg) fp = *lp[l].frelax_amg;
+            else orc_amg_default_params(&fp, 1);
+            L->famg = orc_amg_setup(L->Aff, &fp);
+         }
+         else L->filu = orc_ilu0_setup(L->Aff, 0, NULL, lp[l].ilu_tri_solve, lp[l].ilu_lower_it, lp[l].ilu_upper_it);
          L->rF   = (double *)calloc((size_t)(nf > 0 ? nf : 1), sizeof(double));
          L->eF   = (double *)calloc((size_t)(nf > 0 ? nf : 1), sizeof(double));
       }
       /* global relaxation divisors */
       if (L->grelax_type == 16)
       {
-         L->gilu = orc_ilu0_setup(A, 0, NULL, 1, 5, 5);
+         L->gilu = orc_ilu0_setup(A, 0, NULL, lp[l].ilu_tri_solve, lp[l].ilu_lower_it, lp[l].ilu_upper_it);
          L->cor  = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
       }
       else if (L->grelax_type >= 0)
@@ -1670,7 +1678,15 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
    }
    M->Ac   = A;
    free(labels);
-   M->camg = orc_amg_setup(A, coarse_amg);
+   if (coarse_amg) M->camg = orc_amg_setup(A, coarse_amg);
+   else
+   { /* coarsest_level: ilu (the ILU arguments ride in the last level's slots) */
+      const orc_mgr_level_params *q = &lp[nlevels - 1];
+      M->cilu       = orc_ilu0_setup(A, 0, NULL, q->coarse_ilu_tri_solve, q->coarse_ilu_lower_it, q->coarse_ilu_upper_it);
+      M->cilu_iters = q->coarse_ilu_max_iter < 1 ? 1 : q->coarse_ilu_max_iter;
+      M->ct         = (double *)calloc((size_t)(A->nrows > 0 ? A->nrows : 1), sizeof(double));
+      M->cc         = (double *)calloc((size_t)(A->nrows > 0 ? A->nrows : 1), sizeof(double));
+   }
    M->fc   = (double *)calloc((size_t)(A->nrows > 0 ? A->nrows : 1), sizeof(double));
    M->uc   = (double *)calloc((size_t)(A->nrows > 0 ? A->nrows : 1), sizeof(double));
    orc_amg *h = (orc_amg *)calloc(1, sizeof(orc_amg));
@@ -1684,7 +1700,8 @@ mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
    if (l == M->nlev)
    {
       memset(u, 0, sizeof(double) * (size_t)M->Ac->nrows);
-      orc_amg_vcycle(M->camg, f, u);
+      if (M->camg) orc_amg_vcycle(M->camg, f, u);
+      else ilu_iterate(M->cilu, M->Ac, M->cilu_iters, f, u, M->ct, M->cc);
       return;
    }
    mgr_level *L = &M->lv[l];
@@ -1697,12 +1714,13 @@ mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
    {
       memcpy(L->t, f, sizeof(double) * (size_t)n);
       orc_spmv(L->A, -1.0, u, 1.0, L->t);
-      if (L->frelax_type == 2)
-      { /* e_F = AMG(A_FF) r_F from a zero guess, u_F += e_F */
+      if (L->frelax_type == 2 || L->frelax_type == 32)
+      { /* e_F = M_FF^-1 r_F (one BoomerAMG cycle from a zero guess, or one ILU(0) solve), u_F += e_F */
          for (int i = 0; i < n; i++)
             if (L->cf[i] < 0) L->rF[L->fidx[i]] = L->t[i];
          memset(L->eF, 0, sizeof(double) * (size_t)L->nf);
-         orc_amg_vcycle(L->famg, L->rF, L->eF);
+         if (L->frelax_type == 2) orc_amg_vcycle(L->famg, L->rF, L->eF);
+         else orc_ilu_apply(L->filu, L->rF, L->eF);
          for (int i = 0; i < n; i++)
             if (L->cf[i] < 0) u[i] += L->eF[L->fidx[i]];
       }
@@ -1735,11 +1753,14 @@ mgr_free(struct orc_mgr *M)
       free(L->labels); free(L->cf); free(L->cidx); free(L->dinvF); free(L->l1g); free(L->f); free(L->u); free(L->t); free(L->cor);
       if (L->gilu) orc_ilu_free(L->gilu);
       if (L->famg) orc_amg_free(L->famg);
+      if (L->filu) orc_ilu_free(L->filu);
       if (L->Aff) orc_csr_free(L->Aff);
       free(L->fidx); free(L->rF); free(L->eF);
    }
    orc_csr_free(M->Ac);
    orc_amg_free(M->camg);
+   if (M->cilu) orc_ilu_free(M->cilu);
+   free(M->ct); free(M->cc);
    free(M->fc); free(M->uc); free(M->lv);
    free(M);
 }

@@ -140,11 +140,15 @@ typedef struct {
    const int *f_labels;      /* level.N.f_dofs: labels eliminated on this reduction level */
    int        interp_type;   /* prolongation_type: 0 injection, 1 l1-jacobi, 2 jacobi */
    int        restrict_type; /* restriction_type: 0 injection, 2 jacobi, 14 columped */
-   int        frelax_type;   /* f_relaxation: 7 jacobi (default), 18 l1-jacobi, 2 amg (one BoomerAMG cycle on A_FF) */
+   int        frelax_type;   /* f_relaxation: 7 jacobi (default), 18 l1-jacobi, 2 amg (one BoomerAMG cycle on A_FF), 32 ilu (ILU(0) of A_FF) */
    int        frelax_sweeps; /* 1 */
    int        grelax_type;   /* g_relaxation: -1 none (default), 3/4/6/13/14 hybrid GS, 88 l1-hsgs, 16 ilu (ILU(0)) */
    int        grelax_sweeps; /* 1 */
    const orc_amg_params *frelax_amg; /* f_relaxation.amg block (NULL: hypre-GPU defaults) */
+   /* ILU arguments of this level's ILU components (f_relaxation 32 and g_relaxation 16 share them; ilu.c:21-23) */
+   int        ilu_tri_solve, ilu_lower_it, ilu_upper_it;
+   /* coarsest_level: ilu -- read from the LAST level's entry when orc_precond_mgr gets coarsest_amg == NULL */
+   int        coarse_ilu_max_iter, coarse_ilu_tri_solve, coarse_ilu_lower_it, coarse_ilu_upper_it;
 } orc_mgr_level_params;
 orc_amg *orc_precond_mgr(const orc_csr *A, const int *labels, int nlevels, const orc_mgr_level_params *levels,
                          const orc_amg_params *coarsest_amg, int max_iter);

@@ -32,7 +32,9 @@ class AmgParams(C.Structure):
 class MgrLevelParams(C.Structure):
     _fields_ = [("n_f_labels", C.c_int), ("f_labels", C.POINTER(C.c_int)), ("interp_type", C.c_int), ("restrict_type", C.c_int),
                 ("frelax_type", C.c_int), ("frelax_sweeps", C.c_int), ("grelax_type", C.c_int), ("grelax_sweeps", C.c_int),
-                ("frelax_amg", C.POINTER(AmgParams))]
+                ("frelax_amg", C.POINTER(AmgParams)),
+                ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int),
+                ("coarse_ilu_max_iter", C.c_int), ("coarse_ilu_tri_solve", C.c_int), ("coarse_ilu_lower_it", C.c_int), ("coarse_ilu_upper_it", C.c_int)]
 
 
 class KrylovParams(C.Structure):
@@ -411,7 +413,7 @@ class IluPrecond:
 
 MGR_INTERP = {"injection": 0, "l1-jacobi": 1, "jacobi": 2}
 MGR_RESTRICT = {"injection": 0, "jacobi": 2, "columped": 14}
-MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18, "amg": 2}
+MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18, "amg": 2, "ilu": 32}
 MGR_GRELAX = {"none": -1, "h-fgs": 3, "h-bgs": 4, "h-ssor": 6, "l1-hfgs": 13, "l1-hbgs": 14, "l1-hsgs": 88, "ilu": 16}
 
 
@@ -434,20 +436,25 @@ def mgr_level_list(levels):
         if lv.get("f_amg") is not None:   # AmgParams of 'f_relaxation: {amg: {...}}'
             keep.append(lv["f_amg"])
             arr[k].frelax_amg = C.pointer(lv["f_amg"])
+        ilu = lv.get("ilu", {})           # ILU arguments of this level's ILU components
+        arr[k].ilu_tri_solve, arr[k].ilu_lower_it, arr[k].ilu_upper_it = ilu.get("tri_solve", 1), ilu.get("lower_jac_iters", 5), ilu.get("upper_jac_iters", 5)
+        cil = lv.get("coarsest_ilu", {})  # on the last level: 'coarsest_level: ilu'
+        arr[k].coarse_ilu_max_iter, arr[k].coarse_ilu_tri_solve = cil.get("max_iter", 1), cil.get("tri_solve", 1)
+        arr[k].coarse_ilu_lower_it, arr[k].coarse_ilu_upper_it = cil.get("lower_jac_iters", 5), cil.get("upper_jac_iters", 5)
     return arr, keep
 
 
 class MgrPrecond:
     """'preconditioner: mgr' for pcg()/gmres()/...: multigrid reduction by dof labels, BoomerAMG on the coarsest system."""
 
-    def __init__(self, A, labels, levels, coarse_params=None, max_iter=1):
+    def __init__(self, A, labels, levels, coarse_params=None, max_iter=1, coarsest="amg"):
         self.A = A
         self.labels = np.ascontiguousarray(labels, dtype=np.int32)
         self.params = coarse_params if coarse_params is not None else amg_params(True)
         arr, self._keep = mgr_level_list(levels)
         self.nlevels = len(levels)
         self.h = lib().orc_precond_mgr(A.ptr, self.labels.ctypes.data_as(C.POINTER(C.c_int)), len(levels), arr,
-                                       C.byref(self.params), max_iter)
+                                       C.byref(self.params) if coarsest == "amg" else None, max_iter)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -896,3 +896,29 @@ def test_reference_lidcavity_driver_unmodified():
     for step in sorted({ts for ts, _, _, _, _ in rows}):
         r0 = [float(x[2]) for x in rows if x[0] == step]
         assert r0[-1] < 1e-3 * r0[0]   # Newton residual (= initial residual of each linear solve) drops by orders of magnitude
+
+
+def test_yaml_mgr_component_solvers(hd, orc):
+    """MGR component solvers through the YAML surface: BoomerAMG on A_FF as F-relaxation, an ILU block (Jacobi-iterative
+    solves) as global relaxation on the second level, ILU iterations on the coarsest system -- against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_pins import three_field_system
+    S, labels = three_field_system(13, seed=9)
+    n = S.shape[0]
+    yaml = ("solver:\n  gmres:\n    relative_tol: 1.0e-8\npreconditioner:\n  mgr:\n    level:\n      0:\n        f_dofs: [0]\n        f_relaxation:\n          amg:\n"
+            "            max_iter: 1\n            coarsening:\n              strong_th: 0.4\n        prolongation_type: jacobi\n      1:\n        f_dofs: [1]\n"
+            "        g_relaxation:\n          ilu:\n            tri_solve: 0\n            lower_jac_iters: 4\n        restriction_type: columped\n"
+            "    coarsest_level:\n      ilu:\n        max_iter: 3\n")
+    Ao = orc.Csr.from_scipy(S)
+    lev = [dict(f_dofs=[0], f_relaxation="amg", f_amg=orc.amg_params(True, strong_th=0.4), prolongation_type="jacobi"),
+           dict(f_dofs=[1], g_relaxation="ilu", ilu=dict(tri_solve=0, lower_jac_iters=4), restriction_type="columped", coarsest_ilu=dict(max_iter=3))]
+    ref = orc.gmres(Ao, np.ones(n), orc.MgrPrecond(Ao, labels, lev, coarsest="ilu"), orc.krylov_params(True, rtol=1e-8))
+    h = hd.Hypredrv(yaml)
+    h.set_matrix_csr(0, n - 1, S.indptr, S.indices, S.data)
+    h.set_rhs_array(0, n - 1, np.ones(n))
+    h.finish_system()
+    hd.check(hd.lib().HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, n // 3, 3))
+    r = h.solve()
+    assert r["converged"] and r["iters"] == ref["iters"], (r["iters"], ref["iters"])
+    assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-8
+    h.close()

@@ -727,7 +727,21 @@ MGR_CASES = [
     [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="ilu", restriction_type="columped")],       # ex4.yml / ex5-mgr.yml
     [dict(f_dofs=[0], prolongation_type="jacobi", f_relaxation="amg")],                                                      # AMG on A_FF (diffusive field eliminated first)
     [dict(f_dofs=[1, 2], prolongation_type="jacobi", f_relaxation="amg", f_sweeps=2)],
+    [dict(f_dofs=[0], prolongation_type="jacobi", f_relaxation="ilu", ilu=dict(tri_solve=0, lower_jac_iters=3, upper_jac_iters=4))],  # ILU(0) of A_FF
+    [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="ilu", ilu=dict(tri_solve=0), restriction_type="columped")],
 ]
+
+
+def test_mgr_ilu_on_the_coarsest_level_matches_oracle(orc, hd):
+    S, labels = _three_field(11, seed=3)
+    Ao, Ah = both(orc, hd, S)
+    lev = [dict(f_dofs=[1, 2], prolongation_type="jacobi", coarsest_ilu=dict(max_iter=2, tri_solve=1))]
+    Mo, Mh = orc.MgrPrecond(Ao, labels, lev, coarsest="ilu"), hd.Mgr(Ah, labels, lev, coarsest="ilu")
+    r = np.random.default_rng(8).standard_normal(S.shape[0])
+    assert rel(Mh.vcycle(r), Mo.vcycle(r)) < 1e-12
+    b = np.ones(S.shape[0])
+    ro, rh = orc.gmres(Ao, b, Mo), hd.gmres(Ah, b, Mh)
+    assert rh["converged"] and rh["iters"] == ro["iters"] and np.allclose(rh["hist"], ro["hist"], rtol=1e-8)
 
 
 @pytest.mark.parametrize("levels", MGR_CASES)

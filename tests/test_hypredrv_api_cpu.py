@@ -213,13 +213,20 @@ def test_mgr_yaml_and_create(hd):
     L.HYPREDRV_ErrorCodeClear()
     h.close()
     for text, msg in ((EX3_MGR.replace("coarsest_level: amg", "coarsest_level: spdirect"), "coarsest_level"),
-                      (EX3_MGR.replace("g_relaxation: l1-hsgs", "g_relaxation:\n          ilu:\n            max_iter: 1"), "nested 'ilu'")):
+                      (EX3_MGR.replace("g_relaxation: l1-hsgs", "g_relaxation:\n          amg:\n            max_iter: 1"), "nested 'amg'")):
         h = hd.Hypredrv(text)
         assert L.HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, 5, 3) == 0
         assert L.HYPREDRV_PreconCreate(h.h) & hd.ERROR_INVALID_PRECON
         assert msg in hd.lib().HYPREDRV_AMD_LastErrorMessage().decode()
         L.HYPREDRV_ErrorCodeClear()
         h.close()
+    # component solvers that are implemented: amg / ilu as F-relaxation, an ilu block as global relaxation, ilu as coarsest solver
+    ok = (EX3_MGR.replace("prolongation_type: jacobi", "prolongation_type: jacobi\n        f_relaxation:\n          amg:\n            max_iter: 1")
+          .replace("g_relaxation: l1-hsgs", "g_relaxation:\n          ilu:\n            tri_solve: 0").replace("coarsest_level: amg", "coarsest_level:\n      ilu:\n        max_iter: 3"))
+    h = hd.Hypredrv(ok)
+    assert L.HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, 5, 3) == 0
+    assert L.HYPREDRV_PreconCreate(h.h) == 0
+    h.close()
     with pytest.raises(hd.HypredrvError, match="unknown key"):
         hd.Hypredrv(EX3_MGR.replace("prolongation_type: jacobi", "prolongation: jacobi"))
     L.HYPREDRV_ErrorCodeClear()
