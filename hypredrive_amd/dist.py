@@ -94,12 +94,19 @@ def init(transport="auto"):
         # if ANY rank fails, every rank falls back to the host-staged transport: slower
         # messages, same kernels and results.  Set HDA_TRANSPORT=rccl to make this fatal.
         err = None
-        try:
-            uid = (C.c_ubyte * 128)()
-            if rank == 0:
+        # rank 0's id (or its failure) reaches every rank in ONE collective, whatever happened on rank 0:
+        # a rank that skipped the broadcast would leave the others waiting in it
+        uid, box = (C.c_ubyte * 128)(), [None]
+        if rank == 0:
+            try:
                 hd.check(L.HYPREDRV_AMD_CommGetUniqueId(uid))
-            box = [bytes(uid)]
-            dist.broadcast_object_list(box, src=0)
+                box = [bytes(uid)]
+            except Exception as e:  # noqa: BLE001
+                err, box = e, [None]
+        dist.broadcast_object_list(box, src=0)
+        try:
+            if box[0] is None:
+                raise err or RuntimeError("rank 0 could not create an RCCL unique id")
             uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
             hd.check(L.HYPREDRV_AMD_CommInit(rank, world, local, uid))
             from . import load
