@@ -22,6 +22,8 @@ class AmgParams(C.Structure):
                 ("sweeps_down", C.c_int), ("sweeps_up", C.c_int), ("sweeps_coarse", C.c_int),
                 ("relax_weight", C.c_double), ("outer_weight", C.c_double),
                 ("seed", C.c_uint64), ("num_functions", C.c_int),
+                ("cheby_order", C.c_int), ("cheby_eig_est", C.c_int), ("cheby_variant", C.c_int), ("cheby_scale", C.c_int),
+                ("cheby_fraction", C.c_double),
                 ("smooth_num_levels", C.c_int), ("smooth_num_sweeps", C.c_int),
                 ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int)]
 

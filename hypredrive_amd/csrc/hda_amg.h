@@ -40,6 +40,9 @@ struct AmgParams {
    int    print_level = 0;
    uint64_t seed = 2747; // PMIS tie-break hash seed
    int    num_functions = 1; // coarsening.num_functions; > 1 = systems AMG, unknown approach (presets elasticity_2d/3d)
+   // relaxation.chebyshev (relax type 16; reference src/internal/cheby.c:15-20, amg.c:886-890)
+   int    cheby_order = 2, cheby_eig_est = 10, cheby_variant = 0, cheby_scale = 1;
+   double cheby_fraction = 0.3;
    // complex smoother (amg.c:899-921): type 5 = ILU on levels < smooth_num_levels, replacing the relaxation
    // sweeps there; one smoothing step = smooth_num_sweeps iterations u += M^-1 (f - A u)
    int       smooth_type = 5, smooth_num_levels = 0, smooth_num_sweeps = 1;
@@ -83,6 +86,9 @@ struct AmgLevel {
    DCsr           A, P, R;
    GsPlan         gs;
    std::unique_ptr<Ilu> ilu; // complex smoother of this level, if any
+   // Chebyshev smoother (relax type 16): D^-1/2 scaling, polynomial coefficients, work vectors
+   DArray<double> cheb_ds, cheb_v, cheb_w;
+   double         cheb_coef[5] = {0, 0, 0, 0, 0}, cheb_max_eig = 0.0, cheb_min_eig = 0.0;
    DArray<double> ilu_r, ilu_c;
    DArray<int>    cf;
    DArray<double> dinv_down, dinv_up; // relax_weight / l1 (or / a_ii), per cycle direction
@@ -146,6 +152,8 @@ class Amg {
               bool zero_guess, int dot_slot);
    void build_hierarchy(const DCsr &A);
    void build_smoother_data(int l); // divisors (and Gauss-Seidel level sets) of level l on the matrix the cycle uses
+   void build_cheby(int l);         // eigenvalue estimate and polynomial of the Chebyshev smoother
+   void cheby_sweep(int l, const double *b, double *u, bool zero_guess);
    void coarse_solve(const double *f, double *u);
    const HaloPlan &level_hA(int l) const { return (l == 0 && hA0) ? *hA0 : levels[l].hA; }
    const DCsr           *A0 = nullptr;

@@ -1159,6 +1159,7 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    DArray<double> lw((size_t)std::max<long long>(tot_u, 1));
    if (tot_h) HDA_HIP(hipMemsetAsync(htab.data(), 0xFF, sizeof(int) * htab.size(), STREAM));
    DArray<int> pcnt((size_t)n + 1);
+   pcnt.zero();
    HDA_TRACE("  interp: build (tot_u=%lld tot_h=%lld nc=%d maxrow=%d maxub=%d maxnbr=%d wave=%d)", tot_u, tot_h, nc, hmx[0], hmx[1], hmx[2], (int)use_wave);
    if (use_wave)
    {
@@ -1172,9 +1173,10 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
       k_interp_wave<<<std::min(ceil_div(n, 4), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf,
                                                                           nsC.data(), uofs.data(), cap_row, cap_ub, cap_nbr, pmax, trunc_factor,
                                                                           rowmode.data(), lcol.data(), lw.data(), pcnt.data(), dof);
-      if (tot_h)
-         k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
-                                               lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), rowmode.data(), dof);
+      // the rows the wave kernel left to the thread kernel (rowmode): also when none of them needs a hash table
+      // (C points and non-interpolated F points among them still have to report their entry count)
+      k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
+                                            lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), rowmode.data(), dof);
    }
    else
       k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
@@ -1739,6 +1741,7 @@ void Amg::build_smoother_data(int l)
    const bool last = (l == num_levels() - 1);
    const bool gs   = is_gs_type(prm.relax_down) || is_gs_type(prm.relax_up) || (last && is_gs_type(prm.relax_coarse));
    if (gs && !lv.gs.built) build_gs_plan(Al, lv.gs);
+   if (prm.relax_down == 16 || prm.relax_up == 16 || (last && prm.relax_coarse == 16)) build_cheby(l);
    // complex smoother (amg.c:899-921): ILU(0) of the rank's diagonal block on the first smooth_num_levels
    // levels (counted from the finest level of the whole hierarchy), never on the coarsest
    if (prm.smooth_num_levels > 0)
@@ -1772,10 +1775,12 @@ void Amg::build_hierarchy(const DCsr &A)
 {
    HDA_REQUIRE(prm.coarsen_type == 8 || prm.coarsen_type == 10, "device AMG setup implements PMIS (8) and, on one rank, HMIS (10) coarsening");
    HDA_REQUIRE(prm.interp_type == 6, "device AMG setup implements extended+i interpolation (type 6) only");
-   HDA_REQUIRE((is_jacobi_type(prm.relax_down) || is_gs_type(prm.relax_down)) && (is_jacobi_type(prm.relax_up) || is_gs_type(prm.relax_up)),
-               "device V-cycle implements Jacobi (0, 7, 18) and hybrid Gauss-Seidel (3, 4, 6, 8, 13, 14) smoothers");
-   HDA_REQUIRE(prm.relax_coarse == 9 || is_jacobi_type(prm.relax_coarse) || is_gs_type(prm.relax_coarse),
-               "coarse relaxation must be Gaussian elimination (9), Jacobi or hybrid Gauss-Seidel");
+   auto known = [](int t) { return is_jacobi_type(t) || is_gs_type(t) || t == 16; };
+   HDA_REQUIRE(known(prm.relax_down) && known(prm.relax_up),
+               "device V-cycle implements Jacobi (0, 7, 18), hybrid Gauss-Seidel (3, 4, 6, 8, 13, 14) and Chebyshev (16) smoothers");
+   HDA_REQUIRE(prm.relax_coarse == 9 || known(prm.relax_coarse), "coarse relaxation must be Gaussian elimination (9), Jacobi, hybrid Gauss-Seidel or Chebyshev");
+   HDA_REQUIRE(prm.cheby_variant == 0 || (prm.relax_down != 16 && prm.relax_up != 16 && prm.relax_coarse != 16),
+               "Chebyshev smoother: only variant 0 (the standard polynomial) is implemented");
    A0 = &A;
    a0_dims[0] = A.nrows; a0_dims[1] = A.ncols; a0_dims[2] = A.nnz;
    levels.clear();
@@ -2106,6 +2111,216 @@ double Amg::vcycle_bytes(bool format) const
    return s;
 }
 
+
+// ----------------------------------------------------------------- Chebyshev smoother (relax type 16)
+// hypre_ParCSRRelax_Cheby_Setup / _Solve with hypre_ParCSRMaxEigEstimateCG, restated: eigenvalues of
+// D^-1/2 A D^-1/2 from eig_est CG / Lanczos steps (start vector = PMIS hash of the row id instead of hypre_Rand),
+// upper = 1.1 lambda_max, lower = lambda_min + fraction (upper - lambda_min), residual polynomial
+// T_k((theta - t)/delta) / T_k(theta/delta); the sweep is u += D^-1/2 q(D^-1/2 A D^-1/2) D^-1/2 (f - A u) by Horner.
+__global__ __launch_bounds__(256) void k_cheb_ds(int n, const double *__restrict__ d, int scale, double *__restrict__ ds)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) ds[i] = (scale && d[i] != 0.0) ? 1.0 / sqrt(fabs(d[i])) : 1.0;
+}
+__global__ __launch_bounds__(256) void k_cheb_start(int n, unsigned long long seed, int level, long long first, double *__restrict__ r)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) r[i] = pmis_rand(seed, 1000 + level, first + i);
+}
+// out = c * r + (v ? ds .* v : 0)
+__global__ __launch_bounds__(256) void k_cheb_lin(int n, double c, const double *__restrict__ r, const double *__restrict__ ds,
+                                                  const double *v, double *out) // (out may be v)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) out[i] = v ? c * r[i] + ds[i] * v[i] : c * r[i];
+}
+__global__ __launch_bounds__(256) void k_cheb_scale(int n, const double *__restrict__ ds, double *x)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) x[i] *= ds[i];
+}
+__global__ __launch_bounds__(256) void k_cheb_add(int n, const double *__restrict__ ds, const double *__restrict__ w, double *u)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) u[i] += ds[i] * w[i];
+}
+__global__ __launch_bounds__(256) void k_cheb_rowsum(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                     const double *__restrict__ ds, double *__restrict__ out)
+{ // scaled absolute row sums (Gershgorin); ds carries the ghost tail
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   double s = 0.0;
+   for (int k = rp[i]; k < rp[i + 1]; k++) s += fabs(v[k]) * ds[i] * ds[cj[k]];
+   out[i] = s;
+}
+
+static void tridiag_extremes(int m, const double *d, const double *e, double &lo, double &hi)
+{ // extreme eigenvalues of the symmetric tridiagonal (d, e): bisection on the Sturm count
+   double g0 = d[0], g1 = d[0];
+   for (int i = 0; i < m; i++)
+   {
+      const double r = (i > 0 ? std::fabs(e[i - 1]) : 0.0) + (i < m - 1 ? std::fabs(e[i]) : 0.0);
+      g0 = std::min(g0, d[i] - r);
+      g1 = std::max(g1, d[i] + r);
+   }
+   for (int which = 0; which < 2; which++)
+   {
+      double a = g0, b = g1;
+      for (int it = 0; it < 200; it++)
+      {
+         const double x = 0.5 * (a + b);
+         double       q = d[0] - x;
+         int          cnt = (q < 0.0);
+         for (int i = 1; i < m; i++)
+         {
+            if (q == 0.0) q = 1e-300;
+            q = d[i] - x - e[i - 1] * e[i - 1] / q;
+            cnt += (q < 0.0);
+         }
+         if (cnt >= (which ? m : 1)) b = x;
+         else a = x;
+      }
+      (which ? hi : lo) = 0.5 * (a + b);
+   }
+}
+
+void Amg::build_cheby(int l)
+{
+   const DCsr &A  = level_A(l);
+   AmgLevel   &lv = levels[(size_t)l];
+   const int   n = A.nrows;
+   const size_t ext = (size_t)std::max(std::max(A.ncols, n), 1);
+   const bool  multi = dist && Comm::world().size > 1 && !level_hA(l).send_counts.empty();
+   const int   order = std::min(std::max(prm.cheby_order, 1), 4);
+   lv.cheb_ds.alloc(ext);
+   lv.cheb_v.alloc(ext);
+   lv.cheb_w.alloc(ext);
+   {
+      DArray<double> d((size_t)std::max(n, 1));
+      extract_diag(A, d.data());
+      if (n) k_cheb_ds<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, d.data(), prm.cheby_scale, lv.cheb_ds.data());
+      if (multi) halo_exchange(level_hA(l), lv.cheb_ds.data());
+   }
+   double max_eig = 0.0, min_eig = 0.0;
+   auto inner = [&](const double *a, const double *b) {
+      dot(n, a, b, 0);
+      finalize(0, S_TMP);
+      return read_scalar(S_TMP);
+   };
+   if (prm.cheby_eig_est > 0)
+   {
+      DArray<double> r(ext), p(ext), s(ext), t(ext);
+      // a distinct stream of hash values per rank block: the owned rows' position in the global numbering is not
+      // kept with the level, the rank is
+      const long long first = dist ? ((long long)Comm::world().rank << 40) : 0;
+      if (n) k_cheb_start<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, (unsigned long long)prm.seed, l + level0, first, r.data());
+      copy(n, r.data(), p.data());
+      double gamma = inner(r.data(), r.data()), beta = 1.0, alpha_old = 1.0;
+      std::vector<double> td, te;
+      const int steps = std::min(prm.cheby_eig_est, 60);
+      while ((int)td.size() < steps && gamma > 0.0)
+      {
+         mul(n, lv.cheb_ds.data(), p.data(), t.data());
+         if (multi) halo_exchange(level_hA(l), t.data());
+         spmv(A, 1.0, t.data(), 0.0, nullptr, s.data());
+         k_cheb_scale<<<ceil_div(std::max(n, 1), 256), 256, 0, STREAM>>>(n, lv.cheb_ds.data(), s.data());
+         const double sp = inner(s.data(), p.data());
+         if (sp == 0.0) break;
+         const double alpha = gamma / sp;
+         const int    m     = (int)td.size();
+         td.push_back(1.0 / alpha + (m > 0 ? beta / alpha_old : 0.0));
+         if (m > 0) te.push_back(std::sqrt(beta) / alpha_old);
+         axpy(n, -alpha, s.data(), r.data());
+         const double gnew = inner(r.data(), r.data());
+         beta      = gnew / gamma;
+         gamma     = gnew;
+         alpha_old = alpha;
+         // p = r + beta p
+         scale(n, beta, p.data());
+         axpy(n, 1.0, r.data(), p.data());
+      }
+      if (!td.empty())
+      {
+         te.push_back(0.0);
+         tridiag_extremes((int)td.size(), td.data(), te.data(), min_eig, max_eig);
+      }
+   }
+   else
+   {
+      DArray<double> rs((size_t)std::max(n, 1));
+      if (n) k_cheb_rowsum<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), lv.cheb_ds.data(), rs.data());
+      std::vector<double> h((size_t)std::max(n, 1), 0.0);
+      if (n) rs.download(h.data(), (size_t)n);
+      for (int i = 0; i < n; i++) max_eig = std::max(max_eig, h[(size_t)i]);
+      if (dist && Comm::world().size > 1)
+      { // global maximum through the integer max-reduction (bit pattern of a non-negative double orders like the value)
+         long long bits;
+         memcpy(&bits, &max_eig, 8);
+         Comm::world().allreduce_host(&bits, 1, 1);
+         memcpy(&max_eig, &bits, 8);
+      }
+   }
+   min_eig = std::max(min_eig, 0.0);
+   lv.cheb_max_eig = max_eig;
+   lv.cheb_min_eig = min_eig;
+   const double upper = 1.1 * max_eig, lower = min_eig + prm.cheby_fraction * (upper - min_eig);
+   const double th = 0.5 * (upper + lower), de = 0.5 * (upper - lower);
+   double      *c = lv.cheb_coef, den;
+   for (int i = 0; i < 5; i++) c[i] = 0.0;
+   switch (order)
+   { // q(t) with 1 - t q(t) = T_k((th - t)/de) / T_k(th/de)
+      case 1: c[0] = 1.0 / th; break;
+      case 2:
+         den  = de * de - 2.0 * th * th;
+         c[0] = -4.0 * th / den;
+         c[1] = 2.0 / den;
+         break;
+      case 3:
+         den  = 3.0 * de * de * th - 4.0 * th * th * th;
+         c[0] = (3.0 * de * de - 12.0 * th * th) / den;
+         c[1] = 12.0 * th / den;
+         c[2] = -4.0 / den;
+         break;
+      default:
+         den  = de * de * de * de - 8.0 * de * de * th * th + 8.0 * th * th * th * th;
+         c[0] = (32.0 * th * th * th - 16.0 * de * de * th) / den;
+         c[1] = (8.0 * de * de - 48.0 * th * th) / den;
+         c[2] = 32.0 * th / den;
+         c[3] = -8.0 / den;
+         break;
+   }
+}
+
+// one Chebyshev sweep in place: u += D^-1/2 q(.) D^-1/2 (b - A u)
+void Amg::cheby_sweep(int l, const double *b, double *u, bool zero_guess)
+{
+   const DCsr &A  = level_A(l);
+   AmgLevel   &lv = levels[(size_t)l];
+   const int   n = A.nrows, order = std::min(std::max(prm.cheby_order, 1), 4);
+   double     *r = lv.t.data(), *v = lv.cheb_v.data(), *w = lv.cheb_w.data();
+   const int   g = ceil_div(std::max(n, 1), 256);
+   if (zero_guess)
+   {
+      fill(n, 0.0, u);
+      mul(n, lv.cheb_ds.data(), b, r); // r = D^-1/2 (b - A*0)
+   }
+   else
+   {
+      halo_exchange(level_hA(l), u);
+      residual(A, u, b, r);
+      k_cheb_scale<<<g, 256, 0, STREAM>>>(n, lv.cheb_ds.data(), r);
+   }
+   k_cheb_lin<<<g, 256, 0, STREAM>>>(n, lv.cheb_coef[order - 1], r, lv.cheb_ds.data(), nullptr, w);
+   for (int c = order - 2; c >= 0; c--)
+   {
+      mul(n, lv.cheb_ds.data(), w, v);
+      halo_exchange(level_hA(l), v);
+      spmv(A, 1.0, v, 0.0, nullptr, w);
+      k_cheb_lin<<<g, 256, 0, STREAM>>>(n, lv.cheb_coef[c], r, lv.cheb_ds.data(), w, w);
+   }
+   k_cheb_add<<<g, 256, 0, STREAM>>>(n, lv.cheb_ds.data(), w, u);
+}
+
 // ----------------------------------------------------------------- V-cycle
 
 void Amg::relax(int l, int type, const double *dinv, const double *b, double *&cur, double *&alt,
@@ -2123,6 +2338,12 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
          lv.ilu->apply(lv.ilu_r.data(), lv.ilu_c.data());
          axpy(A.nrows, 1.0, lv.ilu_c.data(), cur);
       }
+      if (dot_slot >= 0) dot(A.nrows, b, cur, dot_slot);
+      return;
+   }
+   if (type == 16)
+   {
+      cheby_sweep(l, b, cur, zero_guess);
       if (dot_slot >= 0) dot(A.nrows, b, cur, dot_slot);
       return;
    }

@@ -79,6 +79,8 @@ extern "C" void hda_amg_default_params(hda_amg_params *p)
    p->relax_down = d.relax_down; p->relax_up = d.relax_up; p->relax_coarse = d.relax_coarse;
    p->sweeps_down = d.sweeps_down; p->sweeps_up = d.sweeps_up; p->sweeps_coarse = d.sweeps_coarse;
    p->relax_weight = d.relax_weight; p->outer_weight = d.outer_weight; p->seed = d.seed; p->num_functions = d.num_functions;
+   p->cheby_order = d.cheby_order; p->cheby_eig_est = d.cheby_eig_est; p->cheby_variant = d.cheby_variant; p->cheby_scale = d.cheby_scale;
+   p->cheby_fraction = d.cheby_fraction;
    p->smooth_num_levels = d.smooth_num_levels; p->smooth_num_sweeps = d.smooth_num_sweeps;
    p->ilu_tri_solve = d.ilu.tri_solve; p->ilu_lower_it = d.ilu.lower_it; p->ilu_upper_it = d.ilu.upper_it;
 }
@@ -98,6 +100,8 @@ static AmgParams to_params(const hda_amg_params *p)
    a.sweeps_down = p->sweeps_down; a.sweeps_up = p->sweeps_up; a.sweeps_coarse = p->sweeps_coarse;
    a.relax_weight = p->relax_weight; a.outer_weight = p->outer_weight; a.seed = p->seed;
    a.num_functions = std::max(p->num_functions, 1);
+   a.cheby_order = p->cheby_order; a.cheby_eig_est = p->cheby_eig_est; a.cheby_variant = p->cheby_variant; a.cheby_scale = p->cheby_scale;
+   a.cheby_fraction = p->cheby_fraction;
    a.smooth_num_levels = p->smooth_num_levels; a.smooth_num_sweeps = p->smooth_num_sweeps;
    a.ilu.tri_solve = p->ilu_tri_solve; a.ilu.lower_it = p->ilu_lower_it; a.ilu.upper_it = p->ilu_upper_it;
    return a;

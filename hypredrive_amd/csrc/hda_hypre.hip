@@ -1029,11 +1029,11 @@ HY_SETTER(HYPRE_BoomerAMGSetNumPaths, HYPRE_Int, (void)v)
 HY_SETTER(HYPRE_BoomerAMGSetRAP2, HYPRE_Int, (void)v)
 HY_SETTER(HYPRE_BoomerAMGSetModuleRAP2, HYPRE_Int, (void)v)
 HY_SETTER(HYPRE_BoomerAMGSetKeepTranspose, HYPRE_Int, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetChebyOrder, HYPRE_Int, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetChebyFraction, HYPRE_Real, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetChebyEigEst, HYPRE_Int, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetChebyVariant, HYPRE_Int, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetChebyScale, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyOrder, HYPRE_Int, s->ap.cheby_order = v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyFraction, HYPRE_Real, s->ap.cheby_fraction = v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyEigEst, HYPRE_Int, s->ap.cheby_eig_est = v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyVariant, HYPRE_Int, s->ap.cheby_variant = v)
+HY_SETTER(HYPRE_BoomerAMGSetChebyScale, HYPRE_Int, s->ap.cheby_scale = v)
 
 extern "C" HYPRE_Int HYPRE_BoomerAMGSetRelaxType(HYPRE_Solver s, HYPRE_Int t)
 {

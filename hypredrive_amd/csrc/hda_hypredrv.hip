@@ -1339,6 +1339,11 @@ static void amg_create(const AmgArgs &a, HYPRE_Solver *out)
    HYPRE_BoomerAMGSetRelaxWt(p, a.weight);
    HYPRE_BoomerAMGSetOuterWt(p, a.outer_weight);
    HYPRE_BoomerAMGSetMaxLevels(p, a.max_levels);
+   HYPRE_BoomerAMGSetChebyOrder(p, a.cheby_order); // amg.c:886-890
+   HYPRE_BoomerAMGSetChebyFraction(p, a.cheby_fraction);
+   HYPRE_BoomerAMGSetChebyEigEst(p, a.cheby_eig_est);
+   HYPRE_BoomerAMGSetChebyVariant(p, a.cheby_variant);
+   HYPRE_BoomerAMGSetChebyScale(p, a.cheby_scale);
    HYPRE_BoomerAMGSetSmoothType(p, a.smooth_type);
    HYPRE_BoomerAMGSetSmoothNumSweeps(p, a.smooth_num_sweeps);
    HYPRE_BoomerAMGSetSmoothNumLevels(p, a.smooth_num_levels);

@@ -596,6 +596,7 @@ static void amg_fields(Ctx &c, YNode &sec, AmgArgs &a)
                               {"p12_max_elements", nullptr, &a.agg_P12_max_elements, nullptr},
                               {"p12_trunc_factor", nullptr, &a.agg_P12_trunc_factor, nullptr}});
       else if (k->key == "relaxation")
+      {
          apply_fields(c, *k, {{"type", &a.relax_type, nullptr, &kRelax}, {"down_type", &a.down_type, nullptr, &kRelax},
                               {"up_type", &a.up_type, nullptr, &kRelax}, {"coarse_type", &a.coarse_type, nullptr, &kRelax},
                               {"down_sweeps", &a.down_sweeps, nullptr, nullptr}, {"up_sweeps", &a.up_sweeps, nullptr, nullptr},
@@ -603,6 +604,12 @@ static void amg_fields(Ctx &c, YNode &sec, AmgArgs &a)
                               {"order", &a.order, nullptr, nullptr}, {"points", &a.points, nullptr, nullptr},
                               {"weight", nullptr, &a.weight, nullptr}, {"outer_weight", nullptr, &a.outer_weight, nullptr}},
                       {"chebyshev"});
+         for (auto &q : k->kids)
+            if (q->key == "chebyshev")
+               apply_fields(c, *q, {{"order", &a.cheby_order, nullptr, nullptr}, {"eig_est", &a.cheby_eig_est, nullptr, nullptr},
+                                    {"variant", &a.cheby_variant, nullptr, nullptr}, {"scale", &a.cheby_scale, nullptr, nullptr},
+                                    {"fraction", nullptr, &a.cheby_fraction, nullptr}});
+      }
       else if (k->key == "smoother")
       {
          apply_fields(c, *k, {{"type", &a.smooth_type, nullptr, &kSmoothType}, {"num_levels", &a.smooth_num_levels, nullptr, nullptr},

@@ -82,6 +82,9 @@ struct AmgArgs { // AMG_args, GPU-branch defaults of src/internal/amg.c:120-238
    int    relax_type = -1, down_type = 18, up_type = 18, coarse_type = 9, down_sweeps = -1, up_sweeps = -1, coarse_sweeps = 1,
           num_sweeps = 1, order = 0, points = 0;
    double weight = 1.0, outer_weight = 1.0;
+   // relaxation.chebyshev (Cheby_args, reference src/internal/cheby.c:15-20)
+   int    cheby_order = 2, cheby_eig_est = 10, cheby_variant = 0, cheby_scale = 1;
+   double cheby_fraction = 0.3;
    // complex smoother
    int    smooth_type = 5, smooth_num_levels = 0, smooth_num_sweeps = 1;
    IluArgs smooth_ilu;

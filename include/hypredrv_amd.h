@@ -40,6 +40,9 @@ typedef struct {
    double   relax_weight, outer_weight;
    uint64_t seed;
    int      num_functions; /* coarsening.num_functions (1); > 1: unknown-based systems AMG, functions interleaved */
+   /* relaxation.chebyshev for relax type 16 (reference src/internal/cheby.c:15-20): order 2, eig_est 10, variant 0, scale 1, fraction 0.3 */
+   int      cheby_order, cheby_eig_est, cheby_variant, cheby_scale;
+   double   cheby_fraction;
    /* complex smoother (src/internal/amg.c:899-921), ILU only: bj-iluk, fill 0, natural order on levels < smooth_num_levels */
    int      smooth_num_levels, smooth_num_sweeps;
    int      ilu_tri_solve, ilu_lower_it, ilu_upper_it; /* ILU_args tri_solve / lower_jac_iters / upper_jac_iters (ilu.c:21-23) */

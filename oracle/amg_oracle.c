@@ -43,6 +43,7 @@ orc_amg_default_params(orc_amg_params *p, int gpu_defaults)
    p->relax_weight    = 1.0;
    p->outer_weight    = 1.0;
    p->seed            = 2747;
+   p->cheby_order = 2; p->cheby_eig_est = 10; p->cheby_variant = 0; p->cheby_scale = 1; p->cheby_fraction = 0.3;
    p->num_functions   = 1;
 }
 
@@ -998,6 +999,150 @@ orc_rap(const orc_csr *A, const orc_csr *P)
    return Ac;
 }
 
+
+/* ------------------------------------------------------------------ Chebyshev smoother (relax type 16)
+ * hypre_ParCSRRelax_Cheby_Setup / _Solve and hypre_ParCSRMaxEigEstimateCG as configured by
+ * HYPRE_BoomerAMGSetCheby{Order,Fraction,EigEst,Variant,Scale} (reference src/internal/amg.c:886-890, cheby.c:15-20).
+ * Restated from the published method: residual polynomial T_k((theta - t)/delta) / T_k(theta/delta) on
+ * [lower, upper], upper = 1.1 * lambda_max, lower = lambda_min + fraction (upper - lambda_min), eigenvalues of
+ * D^-1/2 A D^-1/2 (scale) estimated by eig_est CG / Lanczos steps (Gershgorin rows when eig_est = 0). */
+static void
+tridiag_extremes(int m, const double *d, const double *e, double *lo, double *hi)
+{ /* extreme eigenvalues of the symmetric tridiagonal (d, e) by bisection on the Sturm count */
+   double g0 = d[0], g1 = d[0];
+   for (int i = 0; i < m; i++)
+   {
+      double r = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i < m - 1 ? fabs(e[i]) : 0.0);
+      if (d[i] - r < g0) g0 = d[i] - r;
+      if (d[i] + r > g1) g1 = d[i] + r;
+   }
+   for (int which = 0; which < 2; which++)
+   { /* which 0: smallest (count(x) >= 1), 1: largest (count(x) >= m) */
+      double a = g0, b = g1;
+      for (int it = 0; it < 200; it++)
+      {
+         double x = 0.5 * (a + b), q = d[0] - x;
+         int    cnt = (q < 0.0);
+         for (int i = 1; i < m; i++)
+         {
+            if (q == 0.0) q = 1e-300;
+            q = d[i] - x - e[i - 1] * e[i - 1] / q;
+            cnt += (q < 0.0);
+         }
+         if (cnt >= (which ? m : 1)) b = x; else a = x;
+      }
+      if (which) *hi = 0.5 * (a + b); else *lo = 0.5 * (a + b);
+   }
+}
+
+void
+orc_cheby_setup(const orc_csr *A, int order, int eig_est, int variant, int scale, double fraction, uint64_t seed, int level,
+                double *ds, double coefs[5], double *max_eig_out, double *min_eig_out)
+{
+   (void)variant;
+   const int n = A->nrows;
+   if (order > 4) order = 4;
+   if (order < 1) order = 1;
+   for (int i = 0; i < n; i++)
+   {
+      double d = 1.0;
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         if (A->col[k] == i) d = A->val[k];
+      ds[i] = scale ? 1.0 / sqrt(fabs(d)) : 1.0;
+   }
+   double max_eig = 0.0, min_eig = 0.0;
+   if (eig_est > 0)
+   {
+      double *r = (double *)malloc(sizeof(double) * (size_t)n), *p = (double *)malloc(sizeof(double) * (size_t)n);
+      double *s = (double *)malloc(sizeof(double) * (size_t)n), *t = (double *)malloc(sizeof(double) * (size_t)n);
+      double  td[64], te[64];
+      for (int i = 0; i < n; i++) p[i] = r[i] = pmis_rand(seed, 1000 + level, i);
+      double gamma = orc_dot(n, r, r), beta = 1.0, alpha_old = 1.0;
+      int    m = 0;
+      const int steps = eig_est < 60 ? eig_est : 60;
+      while (m < steps && gamma > 0.0)
+      {
+         for (int i = 0; i < n; i++) t[i] = ds[i] * p[i];
+         orc_spmv(A, 1.0, t, 0.0, s);
+         for (int i = 0; i < n; i++) s[i] *= ds[i];
+         const double sp = orc_dot(n, s, p);
+         if (sp == 0.0) break;
+         const double alpha = gamma / sp;
+         td[m] = 1.0 / alpha + (m > 0 ? beta / alpha_old : 0.0);
+         if (m > 0) te[m - 1] = sqrt(beta) / alpha_old;
+         for (int i = 0; i < n; i++) r[i] -= alpha * s[i];
+         const double gnew = orc_dot(n, r, r);
+         beta      = gnew / gamma;
+         gamma     = gnew;
+         alpha_old = alpha;
+         for (int i = 0; i < n; i++) p[i] = r[i] + beta * p[i];
+         m++;
+      }
+      if (m > 0) tridiag_extremes(m, td, te, &min_eig, &max_eig);
+      free(r); free(p); free(s); free(t);
+   }
+   else
+   { /* Gershgorin: largest scaled absolute row sum */
+      for (int i = 0; i < n; i++)
+      {
+         double rs = 0.0;
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) rs += fabs(A->val[k]) * ds[i] * ds[A->col[k]];
+         if (rs > max_eig) max_eig = rs;
+      }
+   }
+   if (min_eig < 0.0) min_eig = 0.0;
+   const double upper = 1.1 * max_eig, lower = min_eig + fraction * (upper - min_eig);
+   const double th = 0.5 * (upper + lower), de = 0.5 * (upper - lower);
+   double den;
+   for (int i = 0; i < 5; i++) coefs[i] = 0.0;
+   switch (order)
+   { /* q(t) with 1 - t q(t) = T_k((th - t)/de) / T_k(th/de) */
+      case 1: coefs[0] = 1.0 / th; break;
+      case 2:
+         den      = de * de - 2.0 * th * th;
+         coefs[0] = -4.0 * th / den;
+         coefs[1] = 2.0 / den;
+         break;
+      case 3:
+         den      = 3.0 * de * de * th - 4.0 * th * th * th;
+         coefs[0] = (3.0 * de * de - 12.0 * th * th) / den;
+         coefs[1] = 12.0 * th / den;
+         coefs[2] = -4.0 / den;
+         break;
+      default:
+         den      = de * de * de * de - 8.0 * de * de * th * th + 8.0 * th * th * th * th;
+         coefs[0] = (32.0 * th * th * th - 16.0 * de * de * th) / den;
+         coefs[1] = (8.0 * de * de - 48.0 * th * th) / den;
+         coefs[2] = 32.0 * th / den;
+         coefs[3] = -8.0 / den;
+         break;
+   }
+   if (max_eig_out) *max_eig_out = max_eig;
+   if (min_eig_out) *min_eig_out = min_eig;
+}
+
+/* u += D^-1/2 q(D^-1/2 A D^-1/2) D^-1/2 (f - A u), q by Horner; r, v, w: work vectors of length n */
+void
+orc_cheby_apply(const orc_csr *A, int order, int scale, const double *ds, const double coefs[5], const double *f, double *u, double *r,
+                double *v, double *w)
+{
+   (void)scale; /* ds is all ones without scaling */
+   const int n = A->nrows;
+   if (order > 4) order = 4;
+   if (order < 1) order = 1;
+   memcpy(r, f, sizeof(double) * (size_t)n);
+   orc_spmv(A, -1.0, u, 1.0, r);
+   for (int i = 0; i < n; i++) r[i] *= ds[i];
+   for (int i = 0; i < n; i++) w[i] = coefs[order - 1] * r[i];
+   for (int c = order - 2; c >= 0; c--)
+   {
+      for (int i = 0; i < n; i++) v[i] = ds[i] * w[i];
+      orc_spmv(A, 1.0, v, 0.0, w);
+      for (int i = 0; i < n; i++) w[i] = coefs[c] * r[i] + ds[i] * w[i];
+   }
+   for (int i = 0; i < n; i++) u[i] += ds[i] * w[i];
+}
+
 /* --------------------------------------------------------------- hierarchy */
 
 
@@ -1161,6 +1306,8 @@ struct orc_amg {
    int          **cf;
    double       **l1d, **l1u; /* l1 vectors for down / up relax types */
    double       **f, **u, **tmp, **cor;
+   double       **cheb_ds, **cheb_w2, **cheb_w3; /* relax type 16 */
+   double        (*cheb_coef)[5];
    double        *dense;      /* coarsest dense copy */
    /* complex smoother (src/internal/amg.c:899-921): ILU on the first smooth_levels levels */
    orc_ilu      **ilu;
@@ -1200,6 +1347,10 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
    h->f   = (double **)calloc((size_t)maxl, sizeof(void *));
    h->u   = (double **)calloc((size_t)maxl, sizeof(void *));
    h->tmp = (double **)calloc((size_t)maxl, sizeof(void *));
+   h->cheb_ds   = (double **)calloc((size_t)maxl, sizeof(void *));
+   h->cheb_w2   = (double **)calloc((size_t)maxl, sizeof(void *));
+   h->cheb_w3   = (double **)calloc((size_t)maxl, sizeof(void *));
+   h->cheb_coef = (double (*)[5])calloc((size_t)maxl, sizeof(double[5]));
    /* own copy of level 0 */
    {
       int nnz = A0->rowptr[A0->nrows];
@@ -1262,6 +1413,14 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
       h->f[l]   = (double *)calloc((size_t)n, sizeof(double));
       h->u[l]   = (double *)calloc((size_t)n, sizeof(double));
       h->tmp[l] = (double *)calloc((size_t)n, sizeof(double));
+      if (p->relax_down == 16 || p->relax_up == 16 || p->relax_coarse == 16)
+      {
+         h->cheb_ds[l] = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+         h->cheb_w2[l] = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+         h->cheb_w3[l] = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+         orc_cheby_setup(h->A[l], p->cheby_order, p->cheby_eig_est, p->cheby_variant, p->cheby_scale, p->cheby_fraction, p->seed, l,
+                         h->cheb_ds[l], h->cheb_coef[l], NULL, NULL);
+      }
    }
    if (p->relax_coarse == 9)
    {
@@ -1296,10 +1455,12 @@ orc_amg_free(orc_amg *h)
       orc_csr_free(h->R[l]);
       free(h->cf[l]); free(h->l1d[l]); free(h->l1u[l]);
       free(h->f[l]); free(h->u[l]); free(h->tmp[l]);
+      free(h->cheb_ds[l]); free(h->cheb_w2[l]); free(h->cheb_w3[l]);
    }
    free(h->A); free(h->P); free(h->R); free(h->cf); free(h->l1d); free(h->l1u);
    free(h->f); free(h->u); free(h->tmp); free(h->dense);
    free(h->ilu); free(h->cor);
+   free(h->cheb_ds); free(h->cheb_w2); free(h->cheb_w3); free(h->cheb_coef);
    free(h);
 }
 
@@ -1389,6 +1550,15 @@ orc_amg_grid_complexity(const orc_amg *h)
    return s / (double)h->A[0]->nrows;
 }
 
+/* one relaxation sweep of the given type on level l (type 16: the Chebyshev polynomial smoother) */
+static void
+level_relax(orc_amg *h, int l, int type, const double *l1, const double *b, double *x)
+{
+   if (type == 16)
+      orc_cheby_apply(h->A[l], h->p.cheby_order, h->p.cheby_scale, h->cheb_ds[l], h->cheb_coef[l], b, x, h->tmp[l], h->cheb_w2[l], h->cheb_w3[l]);
+   else orc_relax(h->A[l], l1, type, h->p.relax_weight, b, x, h->tmp[l]);
+}
+
 static void
 coarse_solve(orc_amg *h, int l, const double *b, double *x)
 {
@@ -1406,7 +1576,7 @@ coarse_solve(orc_amg *h, int l, const double *b, double *x)
    else
    {
       for (int s = 0; s < h->p.sweeps_coarse; s++)
-         orc_relax(A, h->l1d[l], h->p.relax_coarse, h->p.relax_weight, b, x, h->tmp[l]);
+         level_relax(h, l, h->p.relax_coarse, h->l1d[l], b, x);
    }
 }
 
@@ -1439,7 +1609,7 @@ orc_amg_vcycle(orc_amg *h, const double *b, double *x)
       for (int s = 0; s < h->p.sweeps_down; s++)
       {
          if (l < h->smooth_levels) ilu_iterate(h->ilu[l], A, h->smooth_sweeps, h->f[l], h->u[l], h->tmp[l], h->cor[l]);
-         else orc_relax(A, h->l1d[l], h->p.relax_down, h->p.relax_weight, h->f[l], h->u[l], h->tmp[l]);
+         else level_relax(h, l, h->p.relax_down, h->l1d[l], h->f[l], h->u[l]);
       }
       /* t = f - A u ; f_{l+1} = P^T t */
       memcpy(h->tmp[l], h->f[l], sizeof(double) * (size_t)n);
@@ -1461,7 +1631,7 @@ orc_amg_vcycle(orc_amg *h, const double *b, double *x)
          for (int s = 0; s < h->p.sweeps_up; s++)
          {
             if (l < h->smooth_levels) ilu_iterate(h->ilu[l], A, h->smooth_sweeps, h->f[l], h->u[l], h->tmp[l], h->cor[l]);
-            else orc_relax(A, h->l1u[l], h->p.relax_up, h->p.relax_weight, h->f[l], h->u[l], h->tmp[l]);
+            else level_relax(h, l, h->p.relax_up, h->l1u[l], h->f[l], h->u[l]);
          }
       }
    }

@@ -52,6 +52,9 @@ typedef struct {
    double outer_weight;    /* 1.0 */
    uint64_t seed;          /* PMIS tie-break hash seed */
    int    num_functions;   /* coarsening.num_functions (1); > 1 = unknown-based systems AMG */
+   /* relaxation.chebyshev (relax type 16; reference src/internal/cheby.c:15-20): order 2, eig_est 10, variant 0, scale 1, fraction 0.3 */
+   int    cheby_order, cheby_eig_est, cheby_variant, cheby_scale;
+   double cheby_fraction;
 } orc_amg_params;
 
 typedef struct orc_amg orc_amg; /* hierarchy handle */
@@ -90,6 +93,14 @@ double orc_dot(int n, const double *x, const double *y);
 void   orc_l1_norms(const orc_csr *A, int option, double *l1); /* 1: full row, 4: diag (1 rank) */
 void   orc_relax(const orc_csr *A, const double *l1, int type, double weight,
                  const double *b, double *x, double *tmp);
+/* Chebyshev smoother (hypre relax type 16; published: Adams, Brezina, Hu, Tuminaro 2003).  PARITY UNPINNED: hypre's
+ * eigenvalue estimate starts from hypre_Rand values; here the start vector is the PMIS hash of the row id.
+ * orc_cheby_setup fills ds (length n; 1/sqrt(a_ii) when scale, else unused) and coefs[0..order-1] and returns the
+ * eigenvalue bounds it used; orc_cheby_apply performs u += p(A) (f - A u). */
+void   orc_cheby_setup(const orc_csr *A, int order, int eig_est, int variant, int scale, double fraction, uint64_t seed,
+                       int level, double *ds, double coefs[5], double *max_eig, double *min_eig);
+void   orc_cheby_apply(const orc_csr *A, int order, int scale, const double *ds, const double coefs[5], const double *f,
+                       double *u, double *r, double *v, double *w);
 
 /* Setup pieces (exposed for per-kernel parity tests) */
 void orc_strength(const orc_csr *A, double theta, double max_row_sum, unsigned char *smask);

@@ -26,7 +26,9 @@ class AmgParams(C.Structure):
                 ("relax_down", C.c_int), ("relax_up", C.c_int), ("relax_coarse", C.c_int),
                 ("sweeps_down", C.c_int), ("sweeps_up", C.c_int), ("sweeps_coarse", C.c_int),
                 ("relax_weight", C.c_double), ("outer_weight", C.c_double),
-                ("seed", C.c_uint64), ("num_functions", C.c_int)]
+                ("seed", C.c_uint64), ("num_functions", C.c_int),
+                ("cheby_order", C.c_int), ("cheby_eig_est", C.c_int), ("cheby_variant", C.c_int), ("cheby_scale", C.c_int),
+                ("cheby_fraction", C.c_double)]
 
 
 class MgrLevelParams(C.Structure):
@@ -117,6 +119,8 @@ def lib():
         f.restype = C.c_int
         f.argtypes = [cp, C.c_void_p, P(KrylovParams), dp, dp, dp, ip, dp]
     L.orc_gselim.argtypes = [dp, dp, C.c_int]
+    L.orc_cheby_setup.argtypes = [cp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_int, dp, dp, dp, dp]
+    L.orc_cheby_apply.argtypes = [cp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp]
     L.orc_precond_mgr.restype = C.c_void_p
     L.orc_precond_mgr.argtypes = [cp, ip, C.c_int, P(MgrLevelParams), P(AmgParams), C.c_int]
     L.orc_mgr_matrix.restype = cp
@@ -364,6 +368,25 @@ def _part(part):
         return 0, None, None
     a = np.ascontiguousarray(part, dtype=np.int64)
     return len(a) - 1, a.ctypes.data_as(C.POINTER(C.c_int64)), a
+
+
+class Cheby:
+    """Chebyshev smoother of relax type 16: setup (eigenvalue estimate + coefficients) and u += p(A)(f - A u)."""
+
+    def __init__(self, A, order=2, eig_est=10, variant=0, scale=1, fraction=0.3, seed=2747, level=0):
+        self.A, self.order, self.scale = A, order, scale
+        n = A.nrows
+        self.ds, self.coefs = np.zeros(n), np.zeros(5)
+        mx, mn = C.c_double(), C.c_double()
+        lib().orc_cheby_setup(A.ptr, order, eig_est, variant, scale, fraction, seed, level, _dp(self.ds), _dp(self.coefs), C.byref(mx), C.byref(mn))
+        self.max_eig, self.min_eig = mx.value, mn.value
+
+    def apply(self, f, u=None):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        u = np.zeros_like(f) if u is None else np.ascontiguousarray(u, dtype=np.float64).copy()
+        r, v, w = np.zeros_like(f), np.zeros_like(f), np.zeros_like(f)
+        lib().orc_cheby_apply(self.A.ptr, self.order, self.scale, _dp(self.ds), _dp(self.coefs), _dp(f), _dp(u), _dp(r), _dp(v), _dp(w))
+        return u
 
 
 class Ilu:

@@ -922,3 +922,43 @@ def test_yaml_mgr_component_solvers(hd, orc):
     assert r["converged"] and r["iters"] == ref["iters"], (r["iters"], ref["iters"])
     assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-8
     h.close()
+
+
+def test_yaml_chebyshev_relaxation(hd, orc):
+    """relaxation.down_type / up_type 16 with a chebyshev block (the first variants of the reference's examples/ex8.yml use
+    this smoother): iteration count and solution of the oracle."""
+    Ao, b = orc.lap7(12, 12, 12)
+    ref = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True, relax_down=16, relax_up=16, cheby_order=4, cheby_fraction=0.1)),
+                  orc.krylov_params(False, rtol=1e-9, max_iter=500))
+    h = hd.Hypredrv("solver:\n  pcg:\n    relative_tol: 1.0e-9\n    max_iter: 500\npreconditioner:\n  amg:\n    relaxation:\n      down_type: 16\n"
+                    "      up_type: chebyshev\n      chebyshev:\n        order: 4\n        fraction: 0.1\n")
+    h.set_laplacian7((12, 12, 12))
+    r = h.solve()
+    assert r["converged"] and r["iters"] == ref["iters"]
+    assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-8
+    h.close()
+
+
+def test_row_partitioned_chebyshev(hd, tmp_path):
+    """Chebyshev smoother on row blocks (3 ranks, partitioned setup): the eigenvalue estimate runs its products and dot
+    products across the ranks; same iteration count (+-1: every rank block draws its own start vector) as one rank."""
+    n, seed, world = 4000, 31, 3
+    out = str(tmp_path / "res.json")
+    yaml = "solver: pcg\npreconditioner:\n  amg:\n    relaxation:\n      down_type: 16\n      up_type: 16\n"
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS="500", HDA_TEST_YAML=yaml)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", "29691", os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    res = json.load(open(out))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import random_mmatrix
+    A = random_mmatrix(seed, n)
+    h = hd.Hypredrv(yaml)
+    h.set_matrix_csr(0, n - 1, A.indptr, A.indices, A.data)
+    h.set_rhs_array(0, n - 1, np.ones(n))
+    h.finish_system()
+    ref = h.solve()
+    assert res["converged"] and abs(res["iters"] - ref["iters"]) <= 1
+    assert res["norm"] == pytest.approx(h.solution_norm("L2"), rel=1e-6)
+    h.close()

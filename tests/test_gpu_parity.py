@@ -773,3 +773,29 @@ def test_mgr_unimplemented_options_fail_loudly(hd):
         hd.Mgr(Ah, labels, [dict(f_dofs=[7])])           # label that does not occur: nothing to eliminate
     with pytest.raises(hd.LibraryError, match="f_dofs"):
         hd.Mgr(Ah, labels, [dict(f_dofs=[0, 1, 2])])     # everything eliminated: no coarse system
+
+
+# ------------------------------------------------- Chebyshev smoother (relax type 16; reference src/internal/cheby.c, amg.c:886-890)
+
+@pytest.mark.parametrize("order,eig_est,scale,fraction", [(2, 10, 1, 0.3), (4, 10, 1, 0.1), (3, 0, 1, 0.3), (1, 5, 0, 0.3), (2, 10, 0, 0.2)])
+def test_amg_chebyshev_smoother_matches_oracle(orc, hd, order, eig_est, scale, fraction):
+    """AMG with the Chebyshev smoother on every level: same hierarchy, V-cycle to 1e-10 (the eigenvalue estimates are dot
+    products reduced in a different order), identical PCG iteration counts and histories."""
+    Ao, b = orc.lap7(15, 14, 13, b_mode=1)
+    Ah = hd.lap7(15, 14, 13)
+    kw = dict(relax_down=16, relax_up=16, cheby_order=order, cheby_eig_est=eig_est, cheby_scale=scale, cheby_fraction=fraction)
+    ao, ah = orc.Amg(Ao, orc.amg_params(True, **kw)), hd.Amg(Ah, hd.AmgParams.default(**kw))
+    assert ah.num_levels == ao.num_levels
+    r = np.random.default_rng(12).standard_normal(Ao.nrows)
+    assert rel(ah.vcycle(r), ao.vcycle(r)) < 1e-10
+    ro, rh = orc.pcg(Ao, b, ao), hd.pcg(Ah, b, ah)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-8)
+    if order >= 2:
+        assert ro["iters"] < orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True)))["iters"]
+
+
+def test_chebyshev_variant_1_is_refused(hd):
+    Ah = hd.lap7(6, 6, 6)
+    with pytest.raises(hd.LibraryError, match="variant 0"):
+        hd.Amg(Ah, hd.AmgParams.default(relax_down=16, relax_up=16, cheby_variant=1))

@@ -353,3 +353,38 @@ def test_mgr_two_reduction_levels_as_preconditioner(orc):
     assert r["converged"] and r["iters"] < plain["iters"] / 2
     assert np.linalg.norm(b - S @ r["x"]) / np.linalg.norm(b) < 1e-6
     assert orc.fgmres(A, b, M)["iters"] == r["iters"]
+
+
+# ------------------------------------------------------------------ Chebyshev smoother (relax type 16; parity unpinned)
+
+def test_cheby_polynomial_and_eigenvalue_estimate(orc):
+    """The coefficients are those of the residual polynomial T_k((theta - t)/delta) / T_k(theta/delta); the CG / Lanczos
+    estimate approaches the largest eigenvalue of D^-1/2 A D^-1/2 from below, Gershgorin bounds it from above; one sweep
+    is the matrix polynomial applied to the residual."""
+    import scipy.sparse as sp
+    from numpy.polynomial.chebyshev import Chebyshev
+    A, b = orc.lap7(9, 8, 7, b_mode=1)
+    S = A.to_scipy()
+    D = sp.diags(1.0 / np.sqrt(S.diagonal()))
+    lam = np.linalg.eigvalsh((D @ S @ D).toarray())
+    for order in (1, 2, 3, 4):
+        Cb = orc.Cheby(A, order=order, fraction=0.3)
+        assert 0.9 * lam[-1] < Cb.max_eig <= lam[-1] * (1 + 1e-12) and Cb.min_eig >= lam[0] * (1 - 1e-12)
+        upper = 1.1 * Cb.max_eig
+        lower = Cb.min_eig + 0.3 * (upper - Cb.min_eig)
+        th, de = 0.5 * (upper + lower), 0.5 * (upper - lower)
+        t = np.linspace(lower, upper, 9)
+        q = sum(Cb.coefs[i] * t ** i for i in range(order))
+        T = Chebyshev.basis(order)
+        assert np.abs((1.0 - t * q) - T((th - t) / de) / T(th / de)).max() < 1e-13
+        # the sweep: u1 = u0 + D^-1/2 q(D^-1/2 A D^-1/2) D^-1/2 (b - A u0)
+        u0 = np.linspace(0.0, 1.0, A.nrows)
+        Ss = (D @ S @ D).toarray()
+        Q = sum(Cb.coefs[i] * np.linalg.matrix_power(Ss, i) for i in range(order))
+        ref = u0 + D @ (Q @ (D @ (b - S @ u0)))
+        assert np.allclose(Cb.apply(b, u0), ref, rtol=1e-12, atol=1e-13)
+    G = orc.Cheby(A, eig_est=0)
+    assert G.max_eig >= lam[-1]
+    plain = orc.pcg(A, b, orc.Amg(A, orc.amg_params(True)))
+    cheb = orc.pcg(A, b, orc.Amg(A, orc.amg_params(True, relax_down=16, relax_up=16)))
+    assert cheb["converged"] and cheb["iters"] < plain["iters"]
