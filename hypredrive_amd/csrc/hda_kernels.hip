@@ -49,6 +49,14 @@ struct Pool {
 constexpr size_t kAlign = 512;
 } // namespace
 
+// HDA_POISON=1 (diagnostics): every block handed out is filled with 0xFF bytes (NaN as double, -1 as int) on the library
+// stream first, so a kernel that reads memory nobody wrote fails the tests instead of depending on what the block held before
+static void poison(void *p, size_t bytes)
+{
+   static const bool on = getenv("HDA_POISON") && *getenv("HDA_POISON") && *getenv("HDA_POISON") != '0';
+   if (on && p) (void)hipMemsetAsync(p, 0xFF, bytes, Context::get().stream);
+}
+
 void *pool_alloc(size_t bytes)
 {
    if (bytes == 0) return nullptr;
@@ -62,6 +70,7 @@ void *pool_alloc(size_t bytes)
       g_pool.in_use += it->first;
       g_pool.free_.erase(it);
       g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
+      poison(p, want);
       return p;
    }
    void      *p = nullptr;
@@ -81,6 +90,7 @@ void *pool_alloc(size_t bytes)
    g_pool.size_[p] = want;
    g_pool.in_use += want;
    g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
+   poison(p, want);
    return p;
 }
 
