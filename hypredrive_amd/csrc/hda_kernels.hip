@@ -57,10 +57,21 @@ static void poison(void *p, size_t bytes)
    if (on && p) (void)hipMemsetAsync(p, 0xFF, bytes, Context::get().stream);
 }
 
+// HDA_GUARD=1 (diagnostics): every block carries a 512-byte tail filled with 0xA5 that is checked when the block is
+// released; a kernel that writes past the end of its buffer aborts the process with a message instead of corrupting a neighbour
+static bool guard_on()
+{
+   static const bool on = getenv("HDA_GUARD") && *getenv("HDA_GUARD") && *getenv("HDA_GUARD") != '0';
+   return on;
+}
+constexpr size_t kGuardBytes = 512;
+static std::unordered_map<void *, size_t> g_guard_at; // block -> offset of its guard tail
+
 void *pool_alloc(size_t bytes)
 {
    if (bytes == 0) return nullptr;
-   const size_t want = (bytes + kAlign - 1) / kAlign * kAlign;
+   const size_t user = (bytes + kAlign - 1) / kAlign * kAlign;
+   const size_t want = user + (guard_on() ? kGuardBytes : 0);
    // best fit, but never waste more than 25 % (+64 KiB) of a cached block
    auto it = g_pool.free_.lower_bound(want);
    if (it != g_pool.free_.end() && it->first <= want + want / 4 + 65536)
@@ -71,6 +82,11 @@ void *pool_alloc(size_t bytes)
       g_pool.free_.erase(it);
       g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
       poison(p, want);
+      if (guard_on())
+      {
+         (void)hipMemsetAsync((char *)p + user, 0xA5, kGuardBytes, Context::get().stream);
+         g_guard_at[p] = user;
+      }
       return p;
    }
    void      *p = nullptr;
@@ -91,6 +107,11 @@ void *pool_alloc(size_t bytes)
    g_pool.in_use += want;
    g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
    poison(p, want);
+   if (guard_on())
+   {
+      (void)hipMemsetAsync((char *)p + user, 0xA5, kGuardBytes, Context::get().stream);
+      g_guard_at[p] = user;
+   }
    return p;
 }
 
@@ -99,6 +120,23 @@ void pool_free(void *p)
    if (!p) return;
    auto it = g_pool.size_.find(p);
    if (it == g_pool.size_.end()) return;
+   if (guard_on())
+   {
+      auto g = g_guard_at.find(p);
+      if (g != g_guard_at.end())
+      {
+         unsigned char tail[kGuardBytes];
+         (void)hipStreamSynchronize(Context::get().stream);
+         if (hipMemcpy(tail, (char *)p + g->second, kGuardBytes, hipMemcpyDeviceToHost) == hipSuccess)
+            for (size_t q = 0; q < kGuardBytes; q++)
+               if (tail[q] != 0xA5)
+               {
+                  fprintf(stderr, "HDA_GUARD: a kernel wrote %zu bytes past the end of a %zu-byte device buffer\n", q + 1, g->second);
+                  abort();
+               }
+         g_guard_at.erase(g);
+      }
+   }
    g_pool.in_use -= it->second;
    g_pool.cached += it->second;
    g_pool.free_.emplace(it->second, p);
