@@ -799,3 +799,26 @@ def test_chebyshev_variant_1_is_refused(hd):
     Ah = hd.lap7(6, 6, 6)
     with pytest.raises(hd.LibraryError, match="variant 0"):
         hd.Amg(Ah, hd.AmgParams.default(relax_down=16, relax_up=16, cheby_variant=1))
+
+
+@pytest.mark.parametrize("kind", ["amg-pcg", "amg-gmres", "mgr-gmres", "ilu-bicgstab", "cheby-pcg"])
+def test_runs_are_bitwise_reproducible(hd, kind):
+    """Two independent setups + solves of the same problem give bit-identical residual histories and solutions: reductions
+    are fixed trees over block partials, setup kernels have a fixed accumulation order, nothing uses floating-point atomics."""
+    def once():
+        if kind == "mgr-gmres":
+            S, labels = _three_field(12, seed=2)
+            A = hd.Csr.from_scipy(S)
+            M = hd.Mgr(A, labels, [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="l1-hsgs", restriction_type="columped")])
+            return hd.gmres(A, np.ones(S.shape[0]), M)
+        A = hd.lap7(20, 19, 18)
+        b = np.cos(np.arange(A.dims[0], dtype=np.float64))
+        if kind == "amg-pcg":
+            return hd.pcg(A, b, hd.Amg(A))
+        if kind == "amg-gmres":
+            return hd.gmres(A, b, hd.Amg(A), hd.KrylovParams.default(True, krylov_dim=5))
+        if kind == "cheby-pcg":
+            return hd.pcg(A, b, hd.Amg(A, hd.AmgParams.default(relax_down=16, relax_up=16)))
+        return hd.bicgstab(A, b, hd.Ilu(A, tri_solve=0))
+    r1, r2 = once(), once()
+    assert r1["iters"] == r2["iters"] and np.array_equal(r1["hist"], r2["hist"]) and np.array_equal(r1["x"], r2["x"])
