@@ -1390,6 +1390,31 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
    if (Comm::world().size > 1) s->mgr->setup_dist(A->A, A->halo, A->part, A->ghost_gids, labels);
    else s->mgr->setup(A->A, labels);
    hda_register_precond_veclen(s->mgr->vec_len0());
+   if (s->ap.print_level > 0)
+   { // the reduction hierarchy (global sizes), in the spirit of hypre's MGR setup printout
+      const int nl = s->mgr->num_reduction_levels();
+      std::vector<long long> sz((size_t)(2 * (nl + 1)));
+      for (int l = 0; l <= nl; l++)
+      {
+         const DCsr &M        = s->mgr->matrix(l, 0);
+         sz[(size_t)(2 * l)]     = M.nrows;
+         sz[(size_t)(2 * l + 1)] = M.nnz;
+      }
+      Comm::world().allreduce_host(sz.data(), (int)sz.size(), 0);
+      if (Comm::world().rank == 0)
+      {
+         printf("\n MGR (MI355X): %d reduction level%s + coarsest system\n   lev        rows     nonzeros   eliminated labels\n", nl, nl == 1 ? "" : "s");
+         for (int l = 0; l <= nl; l++)
+         {
+            printf("   %3d  %10lld  %11lld   ", l, sz[(size_t)(2 * l)], sz[(size_t)(2 * l + 1)]);
+            if (l < nl)
+               for (int f : p.levels[(size_t)l].f_labels) printf("%d ", f);
+            else printf("(%s)", p.coarse_is_ilu ? "ILU" : "BoomerAMG");
+            printf("\n");
+         }
+         printf("\n");
+      }
+   }
    HY_CATCH
 }
 
