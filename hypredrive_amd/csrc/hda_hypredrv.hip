@@ -175,6 +175,35 @@ struct hypredrv_struct {
    catch (const std::exception &e) { err_set(ERR_HYPRE_INTERNAL, e.what()); } \
    return g_err;
 
+// hypredrv_DistributedErrorStateSync (reference src/HYPREDRV.c:3101, :3279): at the end of Setup / Apply every rank
+// learns the error bits of all ranks, so that a failure on one rank is a failure of the collective call everywhere
+static void dist_error_sync()
+{
+   Comm &cm = Comm::world();
+   if (cm.size <= 1) return;
+   try
+   {
+      std::vector<long long> all;
+      cm.allgather_ll((long long)g_err, all);
+      uint32_t merged = 0;
+      for (long long v : all) merged |= (uint32_t)v;
+      if (merged & ~g_err)
+      {
+         g_err |= merged;
+         if (g_errmsg.empty()) g_errmsg = "an error was raised on another rank";
+      }
+   }
+   catch (const std::exception &e)
+   {
+      err_set(ERR_HYPRE_INTERNAL, e.what());
+   }
+}
+#define API_CATCH_SYNC                                                   \
+   }                                                                     \
+   catch (const std::exception &e) { err_set(ERR_HYPRE_INTERNAL, e.what()); } \
+   dist_error_sync();                                                    \
+   return g_err;
+
 static void stats_begin(Stats &s, const std::string &name) { s.open[name] = clk::now(); }
 static double stats_end(Stats &s, const std::string &name)
 {
@@ -1633,7 +1662,7 @@ extern "C" uint32_t HYPREDRV_LinearSolverSetup(HYPREDRV_t h)
    if (!skip_precon_setup) ops.setup(h->solver, M, h->vec_b, h->vec_x);
    h->last_setup_s = std::chrono::duration<double>(clk::now() - t0).count();
    consume_hypre_errors();
-   API_CATCH
+   API_CATCH_SYNC
 }
 
 static double residual_norm(hypredrv_struct *h)
@@ -1683,7 +1712,7 @@ extern "C" uint32_t HYPREDRV_LinearSolverApply(HYPREDRV_t h)
       h->stats.cur().rr = residual_norm(h) / (bn > 0.0 ? bn : 1.0);
    }
    consume_hypre_errors(); // non-convergence is not an error
-   API_CATCH
+   API_CATCH_SYNC
 }
 
 extern "C" uint32_t HYPREDRV_PreconApply(HYPREDRV_t h, HYPRE_Vector b, HYPRE_Vector x)
