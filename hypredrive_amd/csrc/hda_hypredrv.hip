@@ -522,23 +522,32 @@ extern "C" uint32_t HYPREDRV_InputArgsSetSolverPreset(HYPREDRV_t h, const char *
 
 // ------------------------------------------------------------- linear system
 
-static std::string ls_path(const hypredrv_struct *h, const std::string &fn)
+// LinearSystemDataFilenameResolve (reference src/internal/linsys.c:832-866): with a dirname the files of system k live in
+// "<dirname>_<suffix>/<filename>", suffix = init_suffix + k zero-padded to digits_suffix; a plain filename is used as it
+// is; a basename names "<basename>_<suffix>"
+static std::string ls_path(const hypredrv_struct *h, const std::string &fn, const std::string &base = std::string())
 {
-   if (fn.empty() || fn[0] == '/' || h->args.ls.dirname.empty()) return fn;
-   return h->args.ls.dirname + "/" + fn;
+   const LSArgs &l = h->args.ls;
+   char          suf[32];
+   snprintf(suf, sizeof suf, "_%0*d", std::max(l.digits_suffix, 1), std::max(l.init_suffix, 0) + std::max(h->current_system_index, 0));
+   if (!l.dirname.empty()) return l.dirname + suf + "/" + fn;
+   if (!fn.empty()) return fn;
+   if (!base.empty()) return base + suf;
+   return fn;
 }
 
 extern "C" uint32_t HYPREDRV_LinearSystemReadMatrix(HYPREDRV_t h)
 {
    CHECK_INIT_OBJ(h);
    API_TRY
-   if (h->args.ls.matrix_filename.empty()) return err_set(ERR_MISSING_KEY, "linear_system.matrix_filename is not set");
+   if (h->args.ls.matrix_filename.empty() && h->args.ls.matrix_basename.empty())
+      return err_set(ERR_MISSING_KEY, "linear_system.matrix_filename is not set");
    if (h->args.ls.type != 1 && h->args.ls.type != 3)
       return err_set(ERR_MISSING_LIB, "linear_system.type must be 'ij' (hypre ASCII or hypredrive multipart binary files) or 'mtx' (Matrix Market)");
    annotate(h, "matrix", true);
    if (h->owns_A && h->mat_A) HYPRE_IJMatrixDestroy(h->mat_A);
    h->mat_A = nullptr;
-   const std::string path = ls_path(h, h->args.ls.matrix_filename);
+   const std::string path = ls_path(h, h->args.ls.matrix_filename, h->args.ls.matrix_basename);
    // reference src/internal/linsys.c:946-1000: binary parts win over ASCII files of the same prefix
    HYPRE_Int rc;
    if (h->args.ls.type == 3) rc = HYPRE_IJMatrixReadMM(path.c_str(), h->comm, HYPRE_PARCSR, &h->mat_A);
@@ -616,9 +625,9 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetRHS(HYPREDRV_t h, HYPRE_Vector vec)
       if (!h->mat_A) return err_set(ERR_UNKNOWN, "SetRHS needs the matrix first");
       annotate(h, "rhs", true);
       const LSArgs &l = h->args.ls;
-      if (l.rhs_mode == 2 && !l.rhs_filename.empty())
+      if (l.rhs_mode == 2 && (!l.rhs_filename.empty() || !l.rhs_basename.empty()))
       {
-         const std::string path = ls_path(h, l.rhs_filename);
+         const std::string path = ls_path(h, l.rhs_filename, l.rhs_basename);
          if (read_vector_file(h, path, &h->vec_b))
          {
             annotate(h, "rhs", false);
@@ -1161,8 +1170,7 @@ extern "C" uint32_t HYPREDRV_LinearSystemReadDofmap(HYPREDRV_t h)
    // hypredrv_IntArrayParRead (reference src/internal/containers.c:443-620): parts prefix.%05d[.bin], a count then the labels
    // (ASCII), or a size_t count then int32 labels (binary); the parts are dealt to the ranks in order
    if (h->args.ls.dofmap_filename.empty()) return g_err;
-   std::string prefix = h->args.ls.dofmap_filename;
-   if (!h->args.ls.dirname.empty() && prefix[0] != '/') prefix = h->args.ls.dirname + "/" + prefix;
+   std::string prefix = ls_path(h, h->args.ls.dofmap_filename);
    auto exists = [](const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; };
    char buf[64];
    snprintf(buf, sizeof buf, ".%05d.bin", 0);

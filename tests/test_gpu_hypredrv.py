@@ -962,3 +962,42 @@ def test_row_partitioned_chebyshev(hd, tmp_path):
     assert res["converged"] and abs(res["iters"] - ref["iters"]) <= 1
     assert res["norm"] == pytest.approx(h.solution_norm("L2"), rel=1e-6)
     h.close()
+
+
+def test_cli_sequence_of_systems_with_reuse(tmp_path, orc):
+    """A sequence of linear systems in the reference's directory layout -- <dirname>_<suffix %05d>/<filename>
+    (src/internal/linsys.c:832-866), init_suffix .. last_suffix -- solved by hypredrive-cli with preconditioner.reuse
+    frequency 1: systems 0 and 2 rebuild the hierarchy, system 1 reuses it with its own matrix on level 0."""
+    import scipy.sparse as sp
+    Ao, b = orc.lap7(9, 8, 7)
+    S0 = Ao.to_scipy()
+    n = S0.shape[0]
+    mats = [(S0 + 0.4 * s * sp.identity(n)).tocsr() for s in range(3)]
+    for s, S in enumerate(mats):
+        d = tmp_path / f"ls_{s:05d}"
+        d.mkdir()
+        with open(d / "IJ.out.A.00000", "w") as f:
+            f.write(f"0 {n - 1} 0 {n - 1}\n")
+            C = S.tocoo()
+            for i, j, v in sorted(zip(C.row, C.col, C.data)):
+                f.write(f"{i} {j} {v:.17e}\n")
+        with open(d / "IJ.out.b.00000", "w") as f:
+            f.write(f"0 {n - 1}\n" + "".join(f"{i} {b[i]:.17e}\n" for i in range(n)))
+    cfg = tmp_path / "seq.yml"
+    cfg.write_text(f"general:\n  use_millisec: on\nlinear_system:\n  dirname: {tmp_path}/ls\n  init_suffix: 0\n  last_suffix: 2\n"
+                   "  matrix_filename: IJ.out.A\n  rhs_filename: IJ.out.b\nsolver: pcg\npreconditioner:\n  amg:\n    print_level: 0\n  reuse:\n    frequency: 1\n")
+    cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
+    r = subprocess.run([cli, "-q", str(cfg)], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = re.findall(r"^\|\s+(\d+) \|\s+([\d.]*) \|\s+([\d.]+) \|\s+([\d.]+) \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
+    assert len(rows) == 3, r.stdout
+    amg = None
+    for s, S in enumerate(mats):
+        A = orc.Csr.from_scipy(S)
+        if s % 2 == 0:
+            amg = orc.Amg(A, orc.amg_params(True))
+        else:
+            amg.rebind_level0(A)
+        ref = orc.pcg(A, b, amg)
+        assert int(rows[s][6]) == ref["iters"] and float(rows[s][5]) < 1e-6
+    assert float(rows[1][2]) < 0.2 < float(rows[0][2])   # setup time [ms]: nothing to set up on the reused system
