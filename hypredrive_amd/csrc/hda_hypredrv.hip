@@ -150,6 +150,7 @@ struct hypredrv_struct {
    InputArgs      args;
    YNode          tree;
    HYPRE_IJMatrix mat_A = nullptr, mat_M = nullptr;
+   bool           owns_M = false; // the preconditioning matrix was read from linear_system.precmat_filename
    HYPRE_IJVector vec_b = nullptr, vec_x = nullptr, vec_x0 = nullptr, vec_xref = nullptr;
    bool           owns_A = false, owns_b = false, owns_x = false, owns_x0 = false;
    HYPRE_Solver   solver = nullptr, precon = nullptr;
@@ -323,6 +324,8 @@ extern "C" uint32_t HYPREDRV_Create(MPI_Comm comm, HYPREDRV_t *out)
 
 static void destroy_system(hypredrv_struct *h)
 {
+   if (h->owns_M && h->mat_M && h->mat_M != h->mat_A) HYPRE_IJMatrixDestroy(h->mat_M);
+   h->owns_M = false;
    if (h->owns_A && h->mat_A) HYPRE_IJMatrixDestroy(h->mat_A);
    if (h->owns_b && h->vec_b) HYPRE_IJVectorDestroy(h->vec_b);
    if (h->owns_x && h->vec_x) HYPRE_IJVectorDestroy(h->vec_x);
@@ -601,11 +604,33 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetMatrix(HYPREDRV_t h, HYPRE_Matrix A)
    consume_hypre_errors();
    API_CATCH
 }
+// reference src/internal/linsys.c:2620-2660: a handle, else the file named by linear_system.precmat_filename, else A itself
 extern "C" uint32_t HYPREDRV_LinearSystemSetPrecMatrix(HYPREDRV_t h, HYPRE_Matrix M)
 {
    CHECK_INIT_OBJ(h);
-   h->mat_M = M ? M : h->mat_A;
-   return g_err;
+   API_TRY
+   if (h->owns_M && h->mat_M && h->mat_M != h->mat_A && h->mat_M != M) HYPRE_IJMatrixDestroy(h->mat_M);
+   h->owns_M = false;
+   if (M) h->mat_M = M;
+   else if (!h->args.ls.precmat_filename.empty() && h->args.ls.precmat_filename != h->args.ls.matrix_filename)
+   {
+      const std::string path = ls_path(h, h->args.ls.precmat_filename);
+      HYPRE_IJMatrix    P    = nullptr;
+      HYPRE_Int         rc;
+      if (h->args.ls.type == 3) rc = HYPRE_IJMatrixReadMM(path.c_str(), h->comm, HYPRE_PARCSR, &P);
+      else if (const int np = hda_count_binary_parts(path.c_str()); np > 0) rc = hda_IJMatrixReadMultipartBinary(path.c_str(), h->comm, np, &P);
+      else rc = HYPRE_IJMatrixRead(path.c_str(), h->comm, HYPRE_PARCSR, &P);
+      if (rc)
+      {
+         const std::string why = hypre_last_error();
+         HYPRE_ClearAllErrors();
+         return err_set(why.find("cannot open") != std::string::npos ? ERR_FILE_NOT_FOUND : ERR_FILE_UNEXPECTED_ENTRY, why);
+      }
+      h->mat_M  = P;
+      h->owns_M = true;
+   }
+   else h->mat_M = h->mat_A;
+   API_CATCH
 }
 
 extern "C" uint32_t HYPREDRV_LinearSystemSetRHS(HYPREDRV_t h, HYPRE_Vector vec)
