@@ -532,7 +532,9 @@ static std::string ls_path(const hypredrv_struct *h, const std::string &fn, cons
 {
    const LSArgs &l = h->args.ls;
    char          suf[32];
-   snprintf(suf, sizeof suf, "_%0*d", std::max(l.digits_suffix, 1), std::max(l.init_suffix, 0) + std::max(h->current_system_index, 0));
+   const int id  = std::max(h->current_system_index, 0);
+   const int num = (id >= 1 && (size_t)(id - 1) < l.set_suffix.size()) ? l.set_suffix[(size_t)(id - 1)] : std::max(l.init_suffix, 0) + id;
+   snprintf(suf, sizeof suf, "_%0*d", std::max(l.digits_suffix, 1), num);
    if (!l.dirname.empty()) return l.dirname + suf + "/" + fn;
    if (!fn.empty()) return fn;
    if (!base.empty()) return base + suf;
@@ -612,9 +614,10 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetPrecMatrix(HYPREDRV_t h, HYPRE_Matri
    if (h->owns_M && h->mat_M && h->mat_M != h->mat_A && h->mat_M != M) HYPRE_IJMatrixDestroy(h->mat_M);
    h->owns_M = false;
    if (M) h->mat_M = M;
-   else if (!h->args.ls.precmat_filename.empty() && h->args.ls.precmat_filename != h->args.ls.matrix_filename)
+   else if ((!h->args.ls.precmat_filename.empty() && h->args.ls.precmat_filename != h->args.ls.matrix_filename) ||
+            (h->args.ls.precmat_filename.empty() && !h->args.ls.precmat_basename.empty()))
    {
-      const std::string path = ls_path(h, h->args.ls.precmat_filename);
+      const std::string path = ls_path(h, h->args.ls.precmat_filename, h->args.ls.precmat_basename);
       HYPRE_IJMatrix    P    = nullptr;
       HYPRE_Int         rc;
       if (h->args.ls.type == 3) rc = HYPRE_IJMatrixReadMM(path.c_str(), h->comm, HYPRE_PARCSR, &P);
@@ -1194,8 +1197,8 @@ extern "C" uint32_t HYPREDRV_LinearSystemReadDofmap(HYPREDRV_t h)
    CHECK_INIT_OBJ(h);
    // hypredrv_IntArrayParRead (reference src/internal/containers.c:443-620): parts prefix.%05d[.bin], a count then the labels
    // (ASCII), or a size_t count then int32 labels (binary); the parts are dealt to the ranks in order
-   if (h->args.ls.dofmap_filename.empty()) return g_err;
-   std::string prefix = ls_path(h, h->args.ls.dofmap_filename);
+   if (h->args.ls.dofmap_filename.empty() && h->args.ls.dofmap_basename.empty()) return g_err;
+   std::string prefix = ls_path(h, h->args.ls.dofmap_filename, h->args.ls.dofmap_basename);
    auto exists = [](const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; };
    char buf[64];
    snprintf(buf, sizeof buf, ".%05d.bin", 0);

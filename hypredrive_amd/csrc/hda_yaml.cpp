@@ -862,13 +862,18 @@ uint32_t args_from_yaml(YNode &root, bool lib_mode, InputArgs &args, std::string
             else if (k->key == "rhs_mode") l.rhs_mode = to_int(c, *k, &kRhsMode);
             else if (k->key == "type") l.type = to_int(c, *k, &kLsType);
             else if (k->key == "exec_policy") (void)to_int(c, *k, &kExec);
+            else if (k->key == "precmat_basename") l.precmat_basename = k->val;
+            else if (k->key == "dofmap_basename") l.dofmap_basename = k->val;
+            else if (k->key == "set_suffix") l.set_suffix = int_list(c, *k, "set_suffix");
+            else if (k->key == "sequence_filename")
+               c.fail(ERR_INVALID_VAL, "linear_system.sequence_filename (single-file sequences) is not implemented on MI355X; use dirname / suffix directories");
             else if (k->key == "print_system" || k->key == "eigspec" || k->key == "dof_labels" || k->key == "timestep_filename" ||
-                     k->key == "sequence_filename" || k->key == "xref_basename" || k->key == "dofmap_basename" ||
-                     k->key == "precmat_basename" || k->key == "set_suffix")
-               ; // outside the solve path
+                     k->key == "xref_basename")
+               ; // diagnostics outside the solve path (dumps, spectra, reference solutions), symbolic label names
             else c.fail(ERR_INVALID_KEY, "unknown key '" + k->key + "' under 'linear_system'");
          }
          if (l.init_suffix >= 0 && l.last_suffix >= l.init_suffix) l.num_systems = l.last_suffix - l.init_suffix + 1;
+         if (!l.set_suffix.empty()) l.num_systems = (int)l.set_suffix.size() + 1;
       }
       else if (sec->key == "solver") parse_solver(c, *sec, args.solver);
       else if (sec->key == "preconditioner")

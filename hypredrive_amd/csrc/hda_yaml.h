@@ -48,8 +48,9 @@ struct GeneralArgs {
    int         warmup = 0, statistics = 1, print_config_params = 1, use_millisec = 0, num_repetitions = 1, exec_policy = 1;
 };
 struct LSArgs {
-   std::string dirname, matrix_filename, matrix_basename, precmat_filename, rhs_filename, rhs_basename, x0_filename,
-      xref_filename, dofmap_filename, sol_filename;
+   std::string dirname, matrix_filename, matrix_basename, precmat_filename, precmat_basename, rhs_filename, rhs_basename, x0_filename,
+      xref_filename, dofmap_filename, dofmap_basename, sol_filename;
+   std::vector<int> set_suffix; // explicit suffixes of systems 1, 2, ... (reference linsys.c:790-805)
    int digits_suffix = 5, init_suffix = -1, last_suffix = -1, init_guess_mode = 0, rhs_mode = 2, type = 1, num_systems = 1;
 };
 struct KrylovArgs {
