@@ -477,7 +477,7 @@ def _write_binary_parts(prefix_A, prefix_b, A, nparts, idx_bytes=8, val_bytes=8)
 
 
 def _solve_files(hd, tmp_path, extra=""):
-    h = hd.Hypredrv(f"linear_system:\n  dirname: {tmp_path}\n  matrix_filename: A\n  rhs_filename: b\n{extra}solver: pcg\npreconditioner: amg\n")
+    h = hd.Hypredrv(f"linear_system:\n  matrix_filename: {tmp_path}/A\n  rhs_filename: {tmp_path}/b\n{extra}solver: pcg\npreconditioner: amg\n")
     hd.check(hd.lib().HYPREDRV_LinearSystemBuild(h.h))
     r = h.solve()
     nrm = h.solution_norm("L2")
@@ -502,7 +502,7 @@ def test_multipart_binary_bad_files_are_errors(hd, tmp_path):
     """Truncated header / wrong index width -> ERROR_FILE_UNEXPECTED_ENTRY, as tests/test_vector.c:189-212
     and the validation in src/internal/matrix.c:36-131 demand; the handle stays usable."""
     (tmp_path / "A.00000.bin").write_bytes(np.zeros(4, dtype=np.uint64).tobytes())
-    h = hd.Hypredrv(f"linear_system:\n  dirname: {tmp_path}\n  matrix_filename: A\n  rhs_filename: b\nsolver: pcg\npreconditioner: amg\n")
+    h = hd.Hypredrv(f"linear_system:\n  matrix_filename: {tmp_path}/A\n  rhs_filename: {tmp_path}/b\nsolver: pcg\npreconditioner: amg\n")
     code = hd.lib().HYPREDRV_LinearSystemReadMatrix(h.h)
     assert code & hd.ERROR_FILE_UNEXPECTED_ENTRY
     hdr = np.zeros(11, dtype=np.uint64)
@@ -524,7 +524,7 @@ def test_matrix_market_file(hd, orc, tmp_path, symmetric):
         f.write(f"{A.shape[0]} {A.shape[1]} {M.nnz}\n")
         for i, j, v in zip(M.row, M.col, M.data):
             f.write(f"{i + 1} {j + 1} {v:.17g}\n")
-    h = hd.Hypredrv(f"linear_system:\n  type: mtx\n  dirname: {tmp_path}\n  matrix_filename: A\n  rhs_mode: ones\nsolver: pcg\npreconditioner: amg\n")
+    h = hd.Hypredrv(f"linear_system:\n  type: mtx\n  matrix_filename: {tmp_path}/A\n  rhs_mode: ones\nsolver: pcg\npreconditioner: amg\n")
     hd.check(hd.lib().HYPREDRV_LinearSystemBuild(h.h))
     r = h.solve()
     Ao, b = orc.lap7(10, 10, 10, b_mode=1)
