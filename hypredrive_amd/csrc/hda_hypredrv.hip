@@ -164,6 +164,14 @@ struct hypredrv_struct {
    int            current_system_index = -1;
    int            last_iters = 0, last_converged = 0;
    double         last_rel = 0.0, last_setup_s = 0.0, last_solve_s = 0.0;
+   // Scaling_context (reference include/internal/scaling.h:39-51): what of the caller's system is scaled right now
+   struct ScalingCtx {
+      bool           enabled = false, matrices_are_scaled = false, rhs_is_scaled = false, x_is_scaled = false;
+      int            type = 0;
+      double         scalar_factor = 1.0;       // rhs_l2
+      DArray<double> scaling, inverse_scaling;  // dofmap types: one weight per owned row, and its reciprocal
+      bool           is_applied() const { return matrices_are_scaled || rhs_is_scaled || x_is_scaled; }
+   } scal;
 };
 
 #define CHECK_INIT_OBJ(h)                                          \
@@ -749,6 +757,7 @@ extern "C" uint32_t HYPREDRV_LinearSystemBuild(HYPREDRV_t h)
    CHECK_INIT_OBJ(h);
    err_reset();
    h->current_system_index++;
+   h->scal.matrices_are_scaled = h->scal.rhs_is_scaled = h->scal.x_is_scaled = false; // src/HYPREDRV.c:1949-1956
    if (HYPREDRV_LinearSystemReadMatrix(h)) return g_err;
    if (HYPREDRV_LinearSystemSetRHS(h, nullptr)) return g_err;
    if (HYPREDRV_LinearSystemSetInitialGuess(h, nullptr)) return g_err;
@@ -1675,6 +1684,195 @@ extern "C" uint32_t HYPREDRV_PreconSetup(HYPREDRV_t h)
 }
 
 // reference src/HYPREDRV.c:3001-3119 -> hypredrv_SolverSetupWithReuse (src/internal/solver.c:457-546)
+// ------------------------------------------------------------------ scaling
+// solver.scaling (reference src/internal/scaling.c): the system is transformed in place before the preconditioner is
+// built, solved in the scaled variables and transformed back afterwards.  With D = diag(custom_values[dofmap]):
+//   rhs_l2                     s = 1/sqrt(||b||_2):  A <- s^2 A,      b <- s b,      x <- x / s      (scaling.c:246-262, :1050-1059)
+//   dofmap_custom              A <- D A D,           b <- D b,        x <- D^-1 x                    (:900-928 default branch)
+//   dofmap_row_custom          A <- D A,             b <- D b,        x unchanged
+//   dofmap_col_custom          A <- A D,             b unchanged,     x <- D^-1 x
+//   dofmap_similarity_custom   A <- D^-1 A D,        b <- D^-1 b,     x <- D^-1 x                    (:838-848)
+// The inverse transforms multiply by the reciprocals, as the reference does, so the caller's matrix comes back up to
+// rounding, not bit for bit.
+namespace {
+__global__ void k_scl_vals(int n, double s, double *v)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) v[i] *= s;
+}
+// a_ij <- left_i a_ij right_j (either side may be absent); one 64-lane wave per row
+__global__ void k_scl_diag(int nrows, const int *rowptr, const int *col, double *val, const double *left, const double *right)
+{
+   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+   if (row >= nrows) return;
+   const double l = left ? left[row] : 1.0;
+   for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 64) val[k] = l * val[k] * (right ? right[col[k]] : 1.0);
+}
+__global__ void k_scl_mul(int n, const double *d, double *v)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) v[i] = d[i] * v[i];
+}
+__global__ void k_scl_div(int n, const double *d, double *v)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) v[i] = v[i] / d[i];
+}
+__global__ void k_scl_inv(int n, const double *d, double *out)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) out[i] = 1.0 / d[i];
+}
+enum { SCL_RHS = 0, SCL_UNKNOWN = 1 };
+
+// hypredrv_ScalingCompute (scaling.c:577-660).  Collective; every rank leaves with the same verdict.
+void scaling_compute(hypredrv_struct *h)
+{
+   auto              &c = h->scal;
+   const ScalingArgs &a = h->args.solver.scaling;
+   c.enabled = a.enabled != 0;
+   c.type    = a.type;
+   if (!c.enabled) return;
+   if (a.type == 0)
+   { // ScalingComputeRHSL2 (:246-262)
+      double bb = 0.0;
+      HYPRE_ParVectorInnerProd(h->vec_b, h->vec_b, &bb);
+      const double bn = std::sqrt(bb);
+      c.scalar_factor = bn > 0.0 ? 1.0 / std::sqrt(bn) : 1.0;
+      return;
+   }
+   // ScalingComputeDofmapCustom (:388-560)
+   const int           n = h->mat_A->nloc;
+   uint32_t            bad = 0;
+   std::string         why;
+   std::vector<double> w((size_t)n, 1.0);
+   long long           max_tag = -1;
+   if (h->dofmap.empty() && n > 0) { bad = ERR_MISSING_DOFMAP; why = "custom dofmap scaling requires a dofmap to be set"; }
+   else if (a.custom_values.empty()) { bad = ERR_UNKNOWN; why = "custom dofmap scaling requires custom_values to be set"; }
+   else if ((int)h->dofmap.size() != n) { bad = ERR_UNKNOWN; why = "dofmap size (" + std::to_string(h->dofmap.size()) + ") does not match local matrix rows (" + std::to_string(n) + ")"; }
+   else
+   {
+      for (size_t i = 0; i < a.custom_values.size(); i++)
+         if (a.custom_values[i] == 0.0) { bad = ERR_INVALID_VAL; why = "custom dofmap scaling requires nonzero custom_values (entry " + std::to_string(i) + " is zero)"; }
+      for (int t : h->dofmap) max_tag = std::max<long long>(max_tag, t);
+   }
+   long long red[2] = {max_tag, (long long)bad};
+   if (Comm::world().size > 1) Comm::world().allreduce_host(red, 2, 1);
+   if (!red[1] && red[0] + 1 != (long long)a.custom_values.size())
+   {
+      bad = ERR_UNKNOWN;
+      why = "dofmap_custom: number of custom_values (" + std::to_string(a.custom_values.size()) + ") does not match number of unique dofmap tags (" + std::to_string(red[0] + 1) + ")";
+      red[1] = bad;
+   }
+   if (!red[1])
+      for (int i = 0; i < n; i++)
+      {
+         const int t = h->dofmap[(size_t)i];
+         if (t < 0) { bad = ERR_UNKNOWN; why = "dofmap_custom: invalid tag " + std::to_string(t) + " at local row " + std::to_string(i); break; }
+         w[(size_t)i] = a.custom_values[(size_t)t];
+      }
+   if (bad || red[1]) { err_set(bad ? bad : (uint32_t)red[1], why); return; }
+   c.scaling.alloc((size_t)std::max(n, 1));
+   c.inverse_scaling.alloc((size_t)std::max(n, 1));
+   c.scaling.upload(w.data(), (size_t)n);
+   if (n) k_scl_inv<<<ceil_div(n, 256), 256, 0, Context::get().stream>>>(n, c.scaling.data(), c.inverse_scaling.data());
+}
+
+// ScalingTransformVector (scaling.c:788-868)
+bool scaling_vector(hypredrv_struct *h, HYPRE_IJVector v, int kind, bool apply)
+{
+   auto &c = h->scal;
+   if (!c.enabled || !v) return false;
+   v->ensure_device();
+   const int n = v->nloc;
+   if (c.type == 0)
+   {
+      const double s = c.scalar_factor;
+      scale(n, kind == SCL_RHS ? (apply ? s : 1.0 / s) : (apply ? 1.0 / s : s), v->data());
+      return true;
+   }
+   if ((c.type == 3 && kind != SCL_RHS) || (c.type == 4 && kind != SCL_UNKNOWN)) return false;
+   if (c.type == 5 && kind == SCL_RHS) apply = !apply; // c = S^-1 b
+   const bool product = (kind == SCL_RHS && apply) || (kind == SCL_UNKNOWN && !apply);
+   if (n)
+   {
+      if (product) k_scl_mul<<<ceil_div(n, 256), 256, 0, Context::get().stream>>>(n, c.scaling.data(), v->data());
+      else k_scl_div<<<ceil_div(n, 256), 256, 0, Context::get().stream>>>(n, c.scaling.data(), v->data());
+   }
+   return true;
+}
+
+void scaling_matrix(hypredrv_struct *h, HYPRE_IJMatrix M, bool apply)
+{
+   auto &c = h->scal;
+   DCsr &A = M->A;
+   if (c.type == 0)
+   {
+      const double s2 = c.scalar_factor * c.scalar_factor;
+      if (A.nnz) k_scl_vals<<<ceil_div(A.nnz, 256), 256, 0, Context::get().stream>>>(A.nnz, apply ? s2 : 1.0 / s2, A.val.data());
+   }
+   else
+   { // ScalingDofmapMatrixFactors (:900-928)
+      const double *sc = c.scaling.data(), *inv = c.inverse_scaling.data(), *left = nullptr, *right = nullptr;
+      switch (c.type)
+      {
+         case 3: left = apply ? sc : inv; break;
+         case 4: right = apply ? sc : inv; break;
+         case 5: left = apply ? inv : sc; right = apply ? sc : inv; break;
+         default: left = right = apply ? sc : inv; break;
+      }
+      DArray<double> ext; // the column factor over [owned | ghost] columns
+      if (right)
+      {
+         ext.alloc((size_t)std::max(A.ncols, 1));
+         copy(M->nloc, right, ext.data());
+         if (A.ncols > M->nloc) halo_exchange(M->halo, ext.data());
+         right = ext.data();
+      }
+      if (A.nrows) k_scl_diag<<<ceil_div((long long)A.nrows * 64, 256), 256, 0, Context::get().stream>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data(), left, right);
+      Context::get().sync(); // ext is released on return
+   }
+   A.reset_plan(); // the streaming plan's stencil-coded shadow holds values
+}
+
+// hypredrv_ScalingApplyToSystem / UndoOnSystem (scaling.c:950-1205)
+void scaling_system(hypredrv_struct *h, bool apply)
+{
+   auto &c = h->scal;
+   if (!c.enabled || (!apply && !c.is_applied()) || (apply && c.is_applied())) return;
+   HYPRE_IJMatrix M = h->mat_M ? h->mat_M : h->mat_A;
+   if (apply)
+   {
+      scaling_matrix(h, h->mat_A, true);
+      if (M != h->mat_A) scaling_matrix(h, M, true);
+      c.matrices_are_scaled = true;
+      if (scaling_vector(h, h->vec_b, SCL_RHS, true)) c.rhs_is_scaled = true;
+      if (scaling_vector(h, h->vec_x, SCL_UNKNOWN, true)) c.x_is_scaled = true;
+   }
+   else
+   {
+      if (c.x_is_scaled && scaling_vector(h, h->vec_x, SCL_UNKNOWN, false)) c.x_is_scaled = false;
+      if (c.rhs_is_scaled && scaling_vector(h, h->vec_b, SCL_RHS, false)) c.rhs_is_scaled = false;
+      if (c.matrices_are_scaled)
+      {
+         scaling_matrix(h, h->mat_A, false);
+         if (M != h->mat_A) scaling_matrix(h, M, false);
+         c.matrices_are_scaled = false;
+      }
+   }
+}
+// RestoreScaledSystemState (src/HYPREDRV.c:141-158): keeps an error that is already raised
+void scaling_restore(hypredrv_struct *h, bool xref_scaled)
+{
+   try
+   {
+      scaling_system(h, false);
+      if (xref_scaled && h->vec_xref) scaling_vector(h, h->vec_xref, SCL_UNKNOWN, false);
+   }
+   catch (const std::exception &e) { err_set(ERR_HYPRE_INTERNAL, e.what()); }
+}
+} // namespace
+
 extern "C" uint32_t HYPREDRV_LinearSolverSetup(HYPREDRV_t h)
 {
    CHECK_INIT_OBJ(h);
@@ -1695,9 +1893,18 @@ extern "C" uint32_t HYPREDRV_LinearSolverSetup(HYPREDRV_t h)
    // reuse decision (src/HYPREDRV.c:3010-3020): a preconditioner that is set up is kept unless the policy asks
    // for a rebuild on this system; the Krylov setup has no other work, so it is skipped with it
    const bool skip_precon_setup = h->precon && h->precon_is_setup && !reuse_should_rebuild(h);
+   // src/HYPREDRV.c:3039-3072: the scaling is computed for every system and applied before the setup; the system
+   // stays scaled until the end of LinearSolverApply
+   if (h->args.solver.scaling.enabled)
+   {
+      scaling_compute(h);
+      if (!g_err) scaling_system(h, true);
+      if (g_err) { scaling_restore(h, false); dist_error_sync(); return g_err; }
+   }
    if (!skip_precon_setup) ops.setup(h->solver, M, h->vec_b, h->vec_x);
    h->last_setup_s = std::chrono::duration<double>(clk::now() - t0).count();
    consume_hypre_errors();
+   if (g_err && h->scal.is_applied()) scaling_restore(h, false);
    API_CATCH_SYNC
 }
 
@@ -1722,7 +1929,13 @@ extern "C" uint32_t HYPREDRV_LinearSolverApply(HYPREDRV_t h)
    if (h->args.precon().method != 99 && (!h->precon || !h->precon_is_setup))
       return err_set(ERR_INVALID_PRECON, "Linear solver apply requires a successfully set up preconditioner; check the preceding setup error");
    if (!h->mat_A || !h->vec_b || !h->vec_x) return err_set(ERR_UNKNOWN, "SolverApply: matrix or vector is NULL");
+   // src/HYPREDRV.c:3161-3200: a reused preconditioner skips Setup's transform, so it is applied here; r0 is
+   // measured on the system as the solver sees it
+   const bool scaled = h->args.solver.scaling.enabled && h->scal.enabled;
+   bool       xref_scaled = false;
+   if (scaled && !h->scal.is_applied()) scaling_system(h, true);
    const double r0 = residual_norm(h); // untimed (solver.c:666)
+   if (scaled && h->vec_xref) xref_scaled = scaling_vector(h, h->vec_xref, SCL_UNKNOWN, true);
    annotate(h, "solve", true);
    h->stats.cur().r0 = r0;
    const SolverOps &ops  = solver_ops(h->solver);
@@ -1740,6 +1953,7 @@ extern "C" uint32_t HYPREDRV_LinearSolverApply(HYPREDRV_t h)
    h->last_iters     = iters;
    h->last_converged = conv;
    h->last_rel       = frel;
+   if (scaled) scaling_restore(h, xref_scaled); // src/HYPREDRV.c:3246-3259: norms below are those of the caller's system
    if (!ierr)
    { // true relative residual, untimed (solver.c:686-690)
       double bn = 0.0;

@@ -548,15 +548,39 @@ static void parse_solver(Ctx &c, YNode &node, KrylovArgs &k)
       k.print_level = 0;
       return;
    }
-   bool seen = false;
+   bool        seen = false;
+   ScalingArgs sc;
    for (auto &ch : node.kids)
    {
       if (ch->key == "scaling")
-      { // solver.scaling (reference src/internal/scaling.c): off by default.  The scaled branch of
-        // LinearSolverSetup/Apply is not built here: asking for it is an error, not a silently unscaled solve
+      { // solver.scaling (reference src/internal/scaling.c:27-76, detached from the solver block in src/internal/args.c:314-410)
+         static const StrMap kScalingType = {{"rhs_l2", 0}, {"dofmap_mag", 1}, {"dofmap_custom", 2}, {"dofmap_row_custom", 3},
+                                             {"dofmap_col_custom", 4}, {"dofmap_similarity_custom", 5}};
          for (auto &q : ch->kids)
-            if (q->key == "enabled" && to_int(c, *q, &kOnOff) != 0)
-               c.fail(ERR_INVALID_VAL, "solver.scaling is not implemented on MI355X (set scaling.enabled: off)");
+         {
+            if (q->key == "enabled") sc.enabled = to_int(c, *q, &kOnOff);
+            else if (q->key == "type") sc.type = to_int(c, *q, &kScalingType);
+            else if (q->key == "custom_values")
+            {
+               std::string t = q->val;
+               for (auto &e : q->kids) t += " " + (e->val.empty() ? e->key : e->val);
+               for (char &x : t)
+                  if (x == '[' || x == ']' || x == ',') x = ' ';
+               std::istringstream is(t);
+               std::string        tok;
+               while (is >> tok)
+               {
+                  char  *end = nullptr;
+                  double v   = strtod(tok.c_str(), &end);
+                  if (!end || *end) { c.fail(ERR_INVALID_VAL, "scaling.custom_values: '" + tok + "' is not a number"); break; }
+                  sc.custom_values.push_back(v);
+               }
+            }
+            else c.fail(ERR_INVALID_KEY, "unknown key 'scaling." + q->key + "'");
+         }
+         // dofmap_mag is hypre's HYPRE_ParCSRMatrixComputeScalingTagged: not part of the reference sources, so there
+         // is nothing to restate it from -- refuse instead of guessing
+         if (sc.enabled && sc.type == 1) c.fail(ERR_INVALID_VAL, "solver.scaling.type dofmap_mag is not implemented on MI355X");
          continue;
       }
       int m = solver_method(ch->key);
@@ -566,6 +590,7 @@ static void parse_solver(Ctx &c, YNode &node, KrylovArgs &k)
       seen = true;
    }
    if (!seen) c.fail(ERR_MISSING_SOLVER, "solver section names no solver");
+   k.scaling = sc;
 }
 
 static void amg_fields(Ctx &c, YNode &sec, AmgArgs &a)

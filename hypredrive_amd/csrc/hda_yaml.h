@@ -53,7 +53,14 @@ struct LSArgs {
    std::vector<int> set_suffix; // explicit suffixes of systems 1, 2, ... (reference linsys.c:790-805)
    int digits_suffix = 5, init_suffix = -1, last_suffix = -1, init_guess_mode = 0, rhs_mode = 2, type = 1, num_systems = 1;
 };
+// solver.scaling (Scaling_args, reference include/internal/scaling.h:32-37, defaults src/internal/scaling.c:71-76)
+struct ScalingArgs {
+   int                 enabled = 0;
+   int                 type    = 0; // scaling_type_t order: rhs_l2, dofmap_mag, dofmap_custom, dofmap_row_custom, dofmap_col_custom, dofmap_similarity_custom
+   std::vector<double> custom_values;
+};
 struct KrylovArgs {
+   ScalingArgs scaling;
    int    method = 0; // 0 pcg, 1 gmres, 2 fgmres, 3 bicgstab (reference solver_t order)
    // PCG_args / GMRES_args union
    int    max_iter = 100, two_norm = 1, stop_crit = 0, rel_change = 0, print_level = 1, recompute_res = 0;

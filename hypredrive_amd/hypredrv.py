@@ -23,6 +23,7 @@ ERROR_MISSING_DOFMAP = 0x00010000
 ERROR_MISSING_KEY = 0x00001000
 ERROR_INVALID_KEY = 0x00000100
 ERROR_INVALID_VAL = 0x00000200
+ERROR_UNKNOWN = 0x80000000
 MPI_COMM_WORLD = 0x44000000
 
 ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_int, C.c_int)

@@ -125,6 +125,10 @@ def mode_csr(out, n, seed):
     h.set_matrix_csr(lo, hi - 1, blk.indptr, blk.indices, blk.data)
     h.set_rhs_array(lo, hi - 1, np.ones(hi - lo))
     h.finish_system()
+    if os.environ.get("HDA_TEST_DOFMAP_MOD"):  # label of global row i = i mod k
+        import ctypes as C
+        lab = np.ascontiguousarray(np.arange(lo, hi) % int(os.environ["HDA_TEST_DOFMAP_MOD"]), dtype=np.int32)
+        hd.check(hd.lib().HYPREDRV_LinearSystemSetDofmap(h.h, hi - lo, lab.ctypes.data_as(C.POINTER(C.c_int))))
     r = h.solve()
     nrm = h.solution_norm("L2")
     if rank == 0:

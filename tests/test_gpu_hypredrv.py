@@ -1033,3 +1033,122 @@ def test_cli_precmat_filename(tmp_path, orc):
     amg.rebind_level0(Ao)                                          # ... applied with the system matrix on level 0, as hypre's BoomerAMGSolve does
     ref = orc.pcg(Ao, b, amg)
     assert its["M"] == ref["iters"] and its["M"] > its["A"]
+
+
+# ------------------------------------------------------------------ solver.scaling
+
+def _scaled_oracle(orc, A, b, labels, kind, values, solver):
+    """The reference's scaled solve restated on the host (src/internal/scaling.c:246-262, :788-868, :900-928, :1050-1075 and the
+    scaled branch of src/HYPREDRV.c:3179-3259): transform the system, run the oracle's Krylov + AMG on it from x0 = 0, map the
+    solution back.  Also returns the caller's matrix and right-hand side as the inverse transforms leave them (products with
+    the reciprocal weights: equal to the originals only up to rounding, which is what the next solve starts from)."""
+    if kind == "rhs_l2":
+        s = 1.0 / np.sqrt(np.linalg.norm(b))
+        s2 = s * s
+        As, bs, back = (A * s2).tocsr(), s * b, lambda y: y * s
+        A_after, b_after = (As * (1.0 / s2)).tocsr(), bs * (1.0 / s)
+    else:
+        d = np.asarray(values)[labels]
+        inv = 1.0 / d
+        D, Di = sp.diags(d), sp.diags(inv)
+        if kind == "dofmap_custom":
+            As, bs, back = (D @ A @ D).tocsr(), d * b, lambda y: d * y
+            A_after, b_after = (Di @ As @ Di).tocsr(), bs / d
+        elif kind == "dofmap_row_custom":
+            As, bs, back = (D @ A).tocsr(), d * b, lambda y: y
+            A_after, b_after = (Di @ As).tocsr(), bs / d
+        elif kind == "dofmap_col_custom":
+            As, bs, back = (A @ D).tocsr(), b, lambda y: d * y
+            A_after, b_after = (As @ Di).tocsr(), b
+        else:
+            As, bs, back = (Di @ A @ D).tocsr(), b / d, lambda y: d * y
+            A_after, b_after = (D @ As @ Di).tocsr(), d * bs
+    As.sort_indices()
+    A_after.sort_indices()
+    Ao = orc.Csr.from_scipy(As)
+    amg = orc.Amg(Ao, orc.amg_params(True))
+    ref = orc.pcg(Ao, bs, amg) if solver == "pcg" else orc.gmres(Ao, bs, amg, orc.krylov_params(True))
+    return ref["iters"], back(ref["x"]), A_after, b_after
+
+
+@pytest.mark.parametrize("kind,solver", [("rhs_l2", "pcg"), ("dofmap_custom", "pcg"), ("dofmap_row_custom", "gmres"),
+                                         ("dofmap_col_custom", "gmres"), ("dofmap_similarity_custom", "gmres")])
+def test_solver_scaling_matches_scaled_oracle(hd, orc, kind, solver):
+    """solver.scaling of the reference (src/internal/scaling.c): the system is scaled in place before the AMG setup, solved in
+    the scaled variables, and handed back unscaled.  Iterations and solution of the oracle run on the explicitly scaled
+    system.  A second solve starts from the system as the inverse transform left it -- the reference multiplies by
+    reciprocals, so equal coefficients come back different in the last bit and the hierarchy built on them is another one;
+    the oracle is fed the same arithmetic.  rhs_l2 uses a right-hand side whose norm makes s a power of two."""
+    A = _lap_coo(16 if kind == "rhs_l2" else 12)
+    n = A.shape[0]
+    labels = np.arange(n) % 3
+    values = [2.0, 0.5, 3.0]
+    b = np.ones(n) if kind == "rhs_l2" else 7.0 * np.ones(n)
+    extra = "" if kind == "rhs_l2" else f"    custom_values: [{', '.join(str(v) for v in values)}]\n"
+    h = hd.Hypredrv(f"solver:\n  {solver}:\n    max_iter: 100\n  scaling:\n    enabled: on\n    type: {kind}\n{extra}preconditioner: amg\n")
+    h.set_matrix_csr(0, n - 1, A.indptr, A.indices, A.data)
+    h.set_rhs_array(0, n - 1, b)
+    h.finish_system()
+    if kind != "rhs_l2":
+        hd.check(hd.lib().HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, n // 3, 3))
+    A0, b0 = A, b
+    for _ in range(2):
+        its, xref, A, b = _scaled_oracle(orc, A, b, labels, kind, values, solver)
+        r = h.solve()
+        x = h.solution()
+        assert r["converged"] and r["iters"] == its
+        assert np.linalg.norm(x - xref) / np.linalg.norm(xref) < 1e-12
+        assert np.linalg.norm(b0 - A0 @ x) / np.linalg.norm(b0) < 1e-5
+    h.close()
+
+
+def test_solver_scaling_errors(hd):
+    """src/internal/scaling.c:400-470: custom scaling without a dofmap -> ERROR_MISSING_DOFMAP; a zero weight ->
+    ERROR_INVALID_VAL; a weight count that differs from the number of labels -> ERROR_UNKNOWN; the system is left as it was.
+    dofmap_mag (hypre's tagged scaling, not in the reference sources) is refused at parse time."""
+    A = _lap_coo(6)
+    n = A.shape[0]
+
+    def build(vals, dofmap=True):
+        h = hd.Hypredrv(f"solver:\n  pcg:\n    max_iter: 50\n  scaling:\n    enabled: on\n    type: dofmap_custom\n    custom_values: {vals}\npreconditioner: amg\n")
+        h.set_matrix_csr(0, n - 1, A.indptr, A.indices, A.data)
+        h.set_rhs_array(0, n - 1, np.ones(n))
+        h.finish_system()
+        if dofmap:
+            hd.check(hd.lib().HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, n // 3, 3))
+        hd.check(hd.lib().HYPREDRV_LinearSolverCreate(h.h))
+        code = hd.lib().HYPREDRV_LinearSolverSetup(h.h)
+        hd.lib().HYPREDRV_ErrorCodeClear()
+        return h, code
+
+    h, code = build("[1.0, 2.0, 3.0]", dofmap=False)
+    assert code & hd.ERROR_MISSING_DOFMAP
+    h.close()
+    h, code = build("[1.0, 0.0, 3.0]")
+    assert code & hd.ERROR_INVALID_VAL
+    h.close()
+    h, code = build("[1.0, 2.0]")
+    assert code & hd.ERROR_UNKNOWN
+    h.close()
+    with pytest.raises(hd.HypredrvError):
+        hd.Hypredrv("solver:\n  pcg:\n    max_iter: 50\n  scaling:\n    enabled: on\n    type: dofmap_mag\npreconditioner: amg\n")
+
+
+def test_row_partitioned_scaling(hd, orc, tmp_path):
+    """dofmap_custom on three row blocks: the column factor of ghost columns comes from their owners (halo exchange of
+    the weight vector); same iterations and solution norm as the oracle on the explicitly scaled system."""
+    n, seed, world = 3000, 33, 3
+    out = str(tmp_path / "res.json")
+    yaml = "solver:\n  pcg:\n    max_iter: 100\n  scaling:\n    enabled: on\n    type: dofmap_custom\n    custom_values: [2.0, 0.5, 3.0, 1.5]\npreconditioner: amg\n"
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS="400", HDA_TEST_YAML=yaml, HDA_TEST_DOFMAP_MOD="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", "29697", os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    res = json.load(open(out))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import random_mmatrix
+    A = random_mmatrix(seed, n)
+    its, xref, _A, _b = _scaled_oracle(orc, A, np.ones(n), np.arange(n) % 4, "dofmap_custom", [2.0, 0.5, 3.0, 1.5], "pcg")
+    assert res["converged"] and res["iters"] == its
+    assert res["norm"] == pytest.approx(np.linalg.norm(xref), rel=1e-7)

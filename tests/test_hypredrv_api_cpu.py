@@ -184,12 +184,16 @@ def test_precon_reuse_yaml(hd):
         hd.lib().HYPREDRV_ErrorCodeClear()
 
 
-def test_scaling_request_is_an_error(hd):
-    """solver.scaling (reference src/internal/scaling.c) is off by default; enabling it must not be ignored silently."""
+def test_scaling_block_parses(hd):
+    """solver.scaling (reference src/internal/scaling.c:27-76): enabled / type / custom_values parse, unknown keys and types are
+    errors, and dofmap_mag -- hypre's tagged scaling, whose algorithm is not in the reference sources -- is refused, not ignored."""
     hd.Hypredrv("solver:\n  pcg:\n    max_iter: 10\n  scaling:\n    enabled: off\npreconditioner: amg\n").close()
-    with pytest.raises(hd.HypredrvError, match="scaling is not implemented"):
-        hd.Hypredrv("solver:\n  pcg:\n    max_iter: 10\n  scaling:\n    enabled: yes\n    type: rhs_l2\npreconditioner: amg\n")
-    hd.lib().HYPREDRV_ErrorCodeClear()
+    hd.Hypredrv("solver:\n  pcg:\n    max_iter: 10\n  scaling:\n    enabled: yes\n    type: rhs_l2\npreconditioner: amg\n").close()
+    hd.Hypredrv("solver:\n  gmres:\n    max_iter: 10\n  scaling:\n    enabled: on\n    type: dofmap_row_custom\n    custom_values: [1.0, 2.5e-1]\npreconditioner: amg\n").close()
+    for bad in ("    type: dofmap_mag\n", "    type: nonsense\n", "    strength: 2\n", "    custom_values: [1.0, abc]\n"):
+        with pytest.raises(hd.HypredrvError):
+            hd.Hypredrv("solver:\n  pcg:\n    max_iter: 10\n  scaling:\n    enabled: on\n" + bad + "preconditioner: amg\n")
+        hd.lib().HYPREDRV_ErrorCodeClear()
 
 
 EX3_MGR = ("solver: gmres\npreconditioner:\n  mgr:\n    level:\n      0:\n        f_dofs: [2]\n        prolongation_type: jacobi\n"
