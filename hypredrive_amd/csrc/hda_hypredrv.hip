@@ -1961,6 +1961,24 @@ extern "C" uint32_t HYPREDRV_LinearSolverApply(HYPREDRV_t h)
       bn = std::sqrt(bn);
       h->stats.cur().rr = residual_norm(h) / (bn > 0.0 ? bn : 1.0);
    }
+   if (h->vec_xref && !ierr)
+   { // src/HYPREDRV.c:3310-3323: error against the reference solution, when one was set
+      double xx = 0.0, rr = 0.0, ee = 0.0;
+      h->vec_xref->ensure_device();
+      HYPRE_ParVectorInnerProd(h->vec_x, h->vec_x, &xx);
+      HYPRE_ParVectorInnerProd(h->vec_xref, h->vec_xref, &rr);
+      HYPRE_IJVector e = new_vector_like(h, 0.0);
+      HYPRE_ParVectorCopy(h->vec_xref, e);
+      axpy(e->nloc, -1.0, h->vec_x->data(), e->data());
+      HYPRE_ParVectorInnerProd(e, e, &ee);
+      HYPRE_IJVectorDestroy(e);
+      if (!h->mypid)
+      {
+         printf("L2 norm of error: %e\n", std::sqrt(ee));
+         printf("L2 norm of solution: %e\n", std::sqrt(xx));
+         printf("L2 norm of ref. solution: %e\n", std::sqrt(rr));
+      }
+   }
    consume_hypre_errors(); // non-convergence is not an error
    API_CATCH_SYNC
 }

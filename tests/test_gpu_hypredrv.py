@@ -1152,3 +1152,45 @@ def test_row_partitioned_scaling(hd, orc, tmp_path):
     its, xref, _A, _b = _scaled_oracle(orc, A, np.ones(n), np.arange(n) % 4, "dofmap_custom", [2.0, 0.5, 3.0, 1.5], "pcg")
     assert res["converged"] and res["iters"] == its
     assert res["norm"] == pytest.approx(np.linalg.norm(xref), rel=1e-7)
+
+
+def test_reference_solution_error_norms(hd, capfd):
+    """HYPREDRV_LinearSystemSetReferenceSolution + the tail of LinearSolverApply (src/HYPREDRV.c:3310-3323): rank 0 prints the
+    L2 norms of the error, the solution and the reference solution."""
+    import ctypes as C
+    import scipy.sparse.linalg as spla
+    A = _lap_coo(8)
+    n = A.shape[0]
+    xs = spla.spsolve(A.tocsc(), np.ones(n))
+    L = hd.lib()
+    v = C.c_void_p()
+    L.HYPRE_IJVectorCreate.argtypes = [C.c_int, C.c_longlong, C.c_longlong, C.POINTER(C.c_void_p)]
+    L.HYPRE_IJVectorSetObjectType.argtypes = [C.c_void_p, C.c_int]
+    L.HYPRE_IJVectorInitialize.argtypes = [C.c_void_p]
+    L.HYPRE_IJVectorSetValues.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+    L.HYPRE_IJVectorAssemble.argtypes = [C.c_void_p]
+    L.HYPRE_IJVectorDestroy.argtypes = [C.c_void_p]
+    assert L.HYPRE_IJVectorCreate(hd.MPI_COMM_WORLD, 0, n - 1, C.byref(v)) == 0
+    assert L.HYPRE_IJVectorSetObjectType(v, 5555) == 0 and L.HYPRE_IJVectorInitialize(v) == 0
+    idx = (C.c_longlong * n)(*range(n))
+    assert L.HYPRE_IJVectorSetValues(v, n, idx, xs.ctypes.data_as(C.POINTER(C.c_double))) == 0 and L.HYPRE_IJVectorAssemble(v) == 0
+    h = hd.Hypredrv("solver:\n  pcg:\n    relative_tol: 1.0e-10\npreconditioner: amg\n")
+    h.set_matrix_csr(0, n - 1, A.indptr, A.indices, A.data)
+    h.set_rhs_array(0, n - 1, np.ones(n))
+    h.finish_system()
+    L.HYPREDRV_LinearSystemSetReferenceSolution.argtypes = [C.c_void_p, C.c_void_p]
+    hd.check(L.HYPREDRV_LinearSystemSetReferenceSolution(h.h, v))
+    capfd.readouterr()
+    r = h.solve()
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)
+    out = capfd.readouterr().out
+    assert r["converged"]
+    err = float(re.search(r"L2 norm of error: (\S+)", out).group(1))
+    sol = float(re.search(r"L2 norm of solution: (\S+)", out).group(1))
+    ref = float(re.search(r"L2 norm of ref. solution: (\S+)", out).group(1))
+    assert ref == pytest.approx(np.linalg.norm(xs), rel=1e-6) and sol == pytest.approx(ref, rel=1e-6)
+    assert err < 1e-7 * ref
+    hd.check(L.HYPREDRV_LinearSystemSetReferenceSolution(h.h, None))
+    h.close()
+    L.HYPRE_IJVectorDestroy(v)
