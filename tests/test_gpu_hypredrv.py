@@ -1194,3 +1194,33 @@ def test_reference_solution_error_norms(hd, capfd):
     hd.check(L.HYPREDRV_LinearSystemSetReferenceSolution(h.h, None))
     h.close()
     L.HYPRE_IJVectorDestroy(v)
+
+
+@pytest.mark.parametrize("kind", ["rhs_l2", "dofmap_custom"])
+def test_scaling_is_reapplied_when_setup_is_skipped(hd, orc, kind):
+    """src/HYPREDRV.c:3161-3176: LinearSolverApply transforms the system itself when the preceding call left it unscaled
+    (second Apply after one Setup, or a reused preconditioner).  Weights that are powers of two make every transform exact,
+    so both applies must reproduce the oracle's solve of the scaled system and leave the caller's system untouched."""
+    A = _lap_coo(16 if kind == "rhs_l2" else 12)
+    n = A.shape[0]
+    values = [2.0, 0.5, 4.0]
+    b = np.ones(n)
+    if kind == "dofmap_custom":
+        b = b * 3.0
+    its, xref, A_after, b_after = _scaled_oracle(orc, A, b, np.arange(n) % 3, kind, values, "pcg")
+    assert (A_after != A).nnz == 0 and np.array_equal(b_after, b)  # exact round trip: the premise of this test
+    extra = "" if kind == "rhs_l2" else "    custom_values: [2.0, 0.5, 4.0]\n"
+    h = hd.Hypredrv(f"solver:\n  pcg:\n    max_iter: 100\n  scaling:\n    enabled: on\n    type: {kind}\n{extra}preconditioner: amg\n")
+    h.set_matrix_csr(0, n - 1, A.indptr, A.indices, A.data)
+    h.set_rhs_array(0, n - 1, b)
+    h.finish_system()
+    if kind != "rhs_l2":
+        hd.check(hd.lib().HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, n // 3, 3))
+    h.create_and_setup()
+    for _ in range(3):
+        r = h.apply()
+        x = h.solution()
+        assert r["converged"] and r["iters"] == its
+        assert np.linalg.norm(x - xref) / np.linalg.norm(xref) < 1e-12
+    h.destroy_solver()
+    h.close()
