@@ -136,7 +136,8 @@ def test_cli_runs_ex1_unchanged(orc, pins):
 
 @pytest.mark.parametrize("cfg", ["examples/ex1-preset.yml", "examples/ex1-gmres.yml", "examples/ex2-gpu.yml", "examples/ex1-jacobi.yml",
                                  "examples/ex1-gs.yml", "examples/ex2-hl1gs.yml", "examples/ex1-cpudefaults.yml",
-                                 "examples/ex1b-gmres-ilu.yml", "examples/ex8-ilu-smoother.yml", "examples/ex1a.yml", "examples/ex1b.yml", "examples/ex3-threefield.yml"])
+                                 "examples/ex1b-gmres-ilu.yml", "examples/ex8-ilu-smoother.yml", "examples/ex1a.yml", "examples/ex1b.yml", "examples/ex3-threefield.yml",
+                                 "examples/ex7-scaling-threefield.yml"])
 def test_cli_other_examples(cfg):
     cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
     r = subprocess.run([cli, "-q", cfg], capture_output=True, text=True, cwd=ROOT)
