@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- AMG-PCG solve of the 3-D 7-pt Laplacian on MI355X (BASELINE.json metric).
 
-One "step" = one solve phase of the reference's solve loop
-(examples/src/C_laplacian/laplacian.c:445-463: ResetInitialGuess + LinearSolverApply),
-i.e. BoomerAMG-preconditioned PCG from x0 = 0 to ||r||/||b|| < 1e-6 with the matrix,
-right-hand side and hierarchy already resident in HBM.  DOF/s = N / solve-phase time,
-exactly the reference's "solve" timer (src/internal/solver.c:668-683); AMG setup is the
-reference's separate "prec" timer and is reported beside it (setup_ms), not hidden.
+One "step" = one pass of the reference's solve loop (examples/src/C_laplacian/laplacian.c:445-463:
+HYPREDRV_LinearSystemResetInitialGuess + HYPREDRV_LinearSolverApply), i.e. BoomerAMG-preconditioned
+PCG from x0 = 0 to ||r||/||b|| < 1e-6 with the matrix, right-hand side and hierarchy already resident
+in HBM.  Every N runs the SAME code path: the HYPREDRV_* C API (include/HYPREDRV.h), one process per
+GPU.  AMG setup is the reference's separate "prec" timer, reported beside the metric (setup_ms).
 
-N = 1: BASELINE config 2 (256^3 on one MI355X).  N > 1: one 256^3 block per GPU, row
-partitioned (weak scaling; 8 GPUs = BASELINE config 3, 512^3), RCCL halo exchange + dot
-all-reduce.  --strong keeps the global problem at --grid^3 instead.
+N = 1: BASELINE config 2 (256^3 on one MI355X).  N > 1: one 256^3 block per GPU, row partitioned
+(weak scaling; 8 GPUs = BASELINE config 3, 512^3), RCCL halo exchange + dot all-reduce.  --strong
+keeps the global problem at --grid^3 instead.
+
+Launch: under torchrun (WORLD_SIZE set) this process is one rank.  `python bench.py --gpus N` with
+N > 1 and no WORLD_SIZE starts the N ranks itself as CHILD processes (reference:
+scripts/node_scaling.sh:1275-1292 `mpirun -np N`), before anything here touches the GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,11 +28,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+YAML = "solver: pcg\npreconditioner:\n  preset: poisson\n"
 
 
 def spmv_bytes(nrows, ncols, nnz):
     """CSR fp64 + int32, matrix once, x once, y once."""
     return 12.0 * nnz + 4.0 * (nrows + 1) + 8.0 * ncols + 8.0 * nrows
+
+
+def gbs(nbytes, ms):
+    return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
 
 def find_hypre():
@@ -43,8 +53,8 @@ def find_hypre():
     return None
 
 
-def cpu_baseline(sample_n):
-    """Time the CPU oracle (kind 'port') on a bounded sample of the same workload."""
+def cpu_baseline(sample_n, gpu_iters=None):
+    """Time the CPU oracle (kind 'port') on the benchmark's own configuration (or a smaller sample with --cpu-sample)."""
     from oracle import oracle_ffi as o
     # the GPU box shares its host: use the cores this process may run on, at most 16
     try:
@@ -59,128 +69,275 @@ def cpu_baseline(sample_n):
     amg = o.Amg(A, o.amg_params(True))
     t1 = time.perf_counter()
     times, r = [], None
-    for _ in range(5):  # the solve phase is short next to the (serial, uncounted) setup: repeat it
+    reps = 3 if sample_n >= 200 else 5
+    for _ in range(reps):  # the solve phase is short next to the setup: repeat it
         ts = time.perf_counter()
         r = o.pcg(A, b, amg)
         times.append(time.perf_counter() - ts)
     n = sample_n ** 3
     med = sorted(times)[len(times) // 2]
-    return {"value": n / med, "unit": "DOF/s", "cores": threads, "kind": "port",
-            "sample": f"lap7 {sample_n}^3 AMG-PCG solve phase (oracle/amg_oracle.c, OpenMP SpMV/Jacobi/dots on {threads} threads), "
-                      f"{r['iters']} iters, median of 5 solves {med:.3f} s (min {min(times):.3f}); serial oracle setup "
-                      f"{t1 - t0:.1f} s not counted",
-            "iters": r["iters"],
-            # a hypre install would allow the reference's own CPU path as a second baseline; none has been found on these boxes
-            "hypre_on_box": find_hypre()}
+    out = {"value": n / med, "unit": "DOF/s", "cores": threads, "kind": "port",
+           "sample": f"lap7 {sample_n}^3 AMG-PCG solve phase (oracle/amg_oracle.c, OpenMP SpMV/Jacobi/dots on {threads} threads), "
+                     f"{r['iters']} iters, median of {reps} solves {med:.3f} s (min {min(times):.3f}); oracle setup "
+                     f"{t1 - t0:.1f} s reported separately (setup_s), not counted in value",
+           "iters": r["iters"], "solve_s": med, "setup_s": t1 - t0, "grid": sample_n,
+           # a hypre install would allow the reference's own CPU path as a second baseline; none has been found on these boxes
+           "hypre_on_box": find_hypre()}
+    if gpu_iters is not None:
+        out["iters_match"] = (int(gpu_iters) == int(r["iters"]))
+    return out
 
 
-def run_single(args):
-    import hypredrive_amd as h
+# ------------------------------------------------------------------------------------------- launch
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (never re-exec: this
+    process has not touched the GPU and never will), forward rank 0's JSON line, return the children's status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    return r.returncode if (r.returncode or line) else 1
+
+
+# ------------------------------------------------------------------------------------------- one rank
+
+class World:
+    """torch.distributed (gloo) only carries the launcher's side: barriers and the reductions of the report."""
+
+    def __init__(self):
+        from hypredrive_amd import dist as hdist
+        self.hdist = hdist
+        self.rank, self.size = hdist.init()
+        self.dist = None
+        if self.size > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def reduce(self, values, op="sum"):
+        if not self.dist:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64)
+        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN}[op])
+        return t.tolist()
+
+
+def run(args):
+    import hypredrive_amd as hh
+    from hypredrive_amd import hypredrv as hd
+    w = World()
     n = args.n
-    A = h.lap7(n, n, n, want_rhs=False)
-    N, _, nnz = A.dims
-    # the reference's protocol is one warm-up run, then the timed ones (scripts/node_scaling.sh): the first
-    # setup of a process also pays for device-memory allocation (bimodal, 0.03-0.9 s on these boxes), the
-    # second one runs out of the library's caching allocator and is the "prec" timer proper
-    h.sync()
-    t0 = time.perf_counter()
-    amg = h.Amg(A)
-    h.sync()
-    setup_cold_ms = (time.perf_counter() - t0) * 1e3
-    del amg
-    h.sync()
-    t0 = time.perf_counter()
-    amg = h.Amg(A)
-    h.sync()
-    setup_ms = (time.perf_counter() - t0) * 1e3
-    kp = h.KrylovParams.default(False)
-    if args.warmup > 0:
-        h.solve_device(A, amg, kp, nsolves=args.warmup, profile_k1=False)
-    # the kernel with the largest share of the solve: the Jacobi sweep on the biggest operator
-    # of the hierarchy that is kept in plain CSR (level 1 for this workload -- level 0 is
-    # stencil-coded and cheaper); every one of its launches inside the timed solves is
-    # bracketed with HIP events on the library stream
+    P = w.hdist.factor3(w.size)
+    weak = not args.strong
+    gn = (n * P[0], n * P[1], n * P[2]) if weak else (n, n, n)
+    N = gn[0] * gn[1] * gn[2]
+    ndev = hh.device_count()
+    transport = hh._lib.comm_name()
+    if w.size > 1 and ndev >= w.size and transport != "rccl" and not os.environ.get("HDA_TRANSPORT"):
+        # one GPU per rank is there: a host-staged transport would be a silent fallback, not a measurement
+        raise SystemExit(f"bench.py: {w.size} ranks with {ndev} visible GPUs must run on RCCL, transport is '{transport}'")
+    h = hd.Hypredrv(YAML)
+    h.set_laplacian7(gn, P)
+    # the reference's protocol is one warm-up run, then the timed ones (scripts/node_scaling.sh): the first setup of a
+    # process also pays for device-memory allocation (bimodal, 0.03-0.9 s on these boxes), the second one runs out of the
+    # library's caching allocator and is the "prec" timer proper
+    setup = []
+    for _ in range(2):
+        hh.sync()
+        w.barrier()
+        t0 = time.perf_counter()
+        h.create_and_setup()
+        hh.sync()
+        w.barrier()
+        setup.append((time.perf_counter() - t0) * 1e3)
+        if len(setup) == 1:
+            h.destroy_solver()
+    setup = w.reduce(setup, "max")
+    A, amg = hh._lib.borrow(h)  # the objects HYPREDRV_LinearSolverSetup built, for the kernel-level measurement entries
+    for _ in range(args.warmup):
+        h.apply()
+    # probes: HIP events on the library stream around every launch of four kernels inside the timed solves.
+    # dominant = Jacobi sweep on the biggest operator of the hierarchy kept in plain CSR (level 1 for this workload:
+    # level 0 is stencil-coded and cheaper); k1 = the level-0 PCG product; P0 / R0 = level-0 prolongation / restriction
     lv_nnz = [amg.level_matrix(l, 0).dims[2] for l in range(amg.num_levels - 1)]
-    fb0 = h.format_bytes(A, amg)
-    dom = max(range(len(lv_nnz)), key=lambda l: (0 if (l == 0 and fb0["coded"]) else lv_nnz[l]))
+    fb0 = hh.format_bytes(A, amg)
+    dom = max(range(len(lv_nnz)), key=lambda l: (0 if (l == 0 and fb0["coded"]) else lv_nnz[l])) if lv_nnz else 0
     Ad = amg.level_matrix(dom, 0)
-    h.probe_spmv(Ad, 2)
-    h.sync()
+    hh.probe_spmv(None, 0)
+    probes = {"dom": hh._lib.probe_add(Ad, 2), "k1": hh._lib.probe_add(A, 0)}
+    if amg.num_levels > 1:
+        P0, R0 = amg.level_matrix(0, 1), amg.level_matrix(0, 2)
+        probes["P0"] = hh._lib.probe_add(P0, 0)
+        probes["R0"] = hh._lib.probe_add(R0, 0)
+    hh._lib.comm_stats(reset=True)
+    w.barrier()
+    hh.sync()
     t0 = time.perf_counter()
-    res = h.solve_device(A, amg, kp, nsolves=args.steps, profile_k1=True)
-    h.sync()
-    t1 = time.perf_counter()
-    dom_ms, dom_count = h.probe_read()
-    h.probe_spmv(None, 0)
-    ms_per_step = (t1 - t0) * 1e3 / args.steps
-    iters = res["iters"]
-    # bytes of one solve: iters PCG iterations + (iters + 1) V-cycles.  "algorithmic" = the CSR
-    # figures of SURVEY 8(d); "format" = what the kernels stream with coded operators
-    ncyc = res["precond_calls"]  # V-cycles really run: hypre's PCG runs iters + 1, the last one unused; here it is skipped
-    bytes_solve = iters * h.pcg_iteration_bytes(A) + ncyc * amg.vcycle_bytes
-    bytes_solve_fmt = iters * fb0["pcg_iteration"] + ncyc * fb0["vcycle"]
-    dn, dc, dnnz = Ad.dims
-    dom_bytes = spmv_bytes(dn, dc, dnnz) + 16.0 * dn          # + b, dinv of the sweep
-    dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    k1_bytes = spmv_bytes(N, N, nnz) + 8.0 * N                # + second operand of the fused dot
-    k1_fmt = fb0["spmv"] + 8.0 * N
-    k1_ms = res["k1_avg_ms"]
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath))
-        except Exception:
-            traffic = {}
-    g, o = amg.complexities
-    gbs = lambda by, ms: by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    out = {
-        "metric": "DOF/s, AMG-PCG solve phase, 3D 7-pt Laplacian",
-        "value": N / (ms_per_step * 1e-3),
-        "unit": "DOF/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"lap7 {n}^3 fp64 AMG-PCG (PMIS, ext+i Pmax 4, l1-Jacobi V(1,1), GE coarse), "
-                               f"BASELINE config 2", "rows": N, "nnz": nnz, "parallelism": "1 GPU",
-                   "rtol": 1e-6, "timed": "solve phase only (reference 'solve' timer); setup_ms is the 'prec' timer"},
-        "iters": iters, "vcycles": ncyc, "true_rel_res": res["true_rel"], "setup_ms": setup_ms, "setup_cold_ms": setup_cold_ms,
-        "solve_ms_each": [float(x) for x in res["solve_ms"]],
-        "num_levels": amg.num_levels, "operator_complexity": o, "grid_complexity": g,
-        "hbm_in_use_gb": h.memory_stats()[0] / 1e9, "hbm_peak_gb": h.memory_stats()[1] / 1e9,  # library allocator: resident after setup / peak during it
-        # CSR-equivalent rate (SURVEY 8(d) bytes / time) and the rate of bytes really streamed
-        "solve_phase_hbm_gbs": gbs(bytes_solve, ms_per_step),
-        "solve_phase_hbm_frac": gbs(bytes_solve, ms_per_step) / HBM_PEAK_GBS,
-        "solve_phase_format_gbs": gbs(bytes_solve_fmt, ms_per_step),
-        "solve_phase_format_frac": gbs(bytes_solve_fmt, ms_per_step) / HBM_PEAK_GBS,
-        "dof_iters_per_s": N * iters / (ms_per_step * 1e-3),
-        "roofline": {"kernel": f"k_spmv_stream<JACOBI> on the level-{dom} operator ({dn} rows, {dnnz} nnz, plain CSR): "
-                               f"largest share of the solve, {dom_count} launches timed inside it",
-                     "bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic.get(f"k_spmv_stream_jacobi_level{dom}_bytes_per_launch"),
-                     "bytes_per_launch": dom_bytes, "avg_ms": dom_ms},
-        # level-0 PCG product (the north-star SpMV).  The operator is stencil-coded (1 B/entry), so
-        # the CSR-equivalent rate exceeds what HBM can deliver; "format" is the honest HBM rate
-        "level0_spmv": {"kernel": "k_spmv_coded_row<PLAIN,DOT>" if fb0["coded"] else "k_spmv_stream<PLAIN,DOT>",
-                        "coded": fb0["coded"], "avg_ms": k1_ms,
-                        "csr_bytes_per_launch": k1_bytes, "csr_equiv_gbs": gbs(k1_bytes, k1_ms),
-                        "csr_equiv_frac": gbs(k1_bytes, k1_ms) / HBM_PEAK_GBS,
-                        "format_bytes_per_launch": k1_fmt, "format_gbs": gbs(k1_fmt, k1_ms),
-                        "format_frac": gbs(k1_fmt, k1_ms) / HBM_PEAK_GBS,
-                        "traffic": traffic.get("k_spmv_level0_bytes_per_launch")},
-    }
+    last, solve_timer, vcyc = None, [], 0
+    for _ in range(args.steps):
+        last = h.apply()
+        solve_timer.append(last["solve_s"] * 1e3)
+        vcyc = hh.load().hda_last_precond_calls()
+    hh.sync()
+    w.barrier()
+    dt = w.reduce([time.perf_counter() - t0], "max")[0]
+    ms_per_step = dt * 1e3 / args.steps
+    cs = hh._lib.comm_stats()
+    pr = {k: hh._lib.probe_read_id(v) for k, v in probes.items()}
+    hh.probe_spmv(None, 0)
+    iters = last["iters"]
+    # bytes of one solve on this rank: iters PCG iterations + the V-cycles really run (hypre's PCG runs iters + 1, the
+    # last one unused; here it is skipped).  "csr" = SURVEY 8(d) figures, "fmt" = what the kernels stream (coded operators)
+    (it_csr, it_fmt), (vc_csr, vc_fmt) = h.solve_phase_bytes()
+    by = w.reduce([iters * it_csr + vcyc * vc_csr, iters * it_fmt + vcyc * vc_fmt, 1.0], "sum")
+    ranks_seen = int(round(by[2]))
+    timer_ms = w.reduce([sorted(solve_timer)[len(solve_timer) // 2]], "max")[0]
+    out = None
+    if w.rank == 0:
+        dn, dc, dnnz = Ad.dims
+        dom_ms, dom_count = pr["dom"]
+        dom_bytes = spmv_bytes(dn, dc, dnnz) + 16.0 * dn  # + b, dinv of the sweep
+        a_n, a_c, a_nnz = A.dims
+        k1_ms, k1_count = pr["k1"]
+        k1_bytes = spmv_bytes(a_n, a_c, a_nnz) + 8.0 * a_n  # + second operand of the fused dot
+        k1_fmt = fb0["spmv"] + 8.0 * a_n
+        g, o = amg.complexities
+        traffic, traffic_src = {}, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))
+                traffic_src = f"profiles/traffic.json ({traffic.get('round', 'committed rocprofv3 --pmc run')}), not measured in this run"
+            except Exception:
+                traffic = {}
+        per_it = 1.0 / max(iters * args.steps, 1)
+        out = {
+            "metric": "DOF/s, AMG-PCG solve phase, 3D 7-pt Laplacian",
+            "value": N / (ms_per_step * 1e-3), "unit": "DOF/s",
+            "n_gpus": w.size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"lap7 {gn[0]}x{gn[1]}x{gn[2]} fp64 AMG-PCG (PMIS, ext+i Pmax 4, l1-Jacobi V(1,1), GE coarse), "
+                                   + ("BASELINE config 2" if (w.size == 1 and n == 256) else
+                                      "BASELINE config 3" if (w.size == 8 and weak and n == 256) else f"{n}^3 per rank" if weak else "fixed size"),
+                       "rows": N, "rows_per_rank": a_n, "parallelism": f"row blocks {P[0]}x{P[1]}x{P[2]}, one process per GPU",
+                       "rtol": 1e-6, "api": "HYPREDRV_LinearSystemResetInitialGuess + HYPREDRV_LinearSolverApply per step (every N)",
+                       "timed": "K steps between barrier + device sync; includes the reference's untimed r0 / final-residual evaluations "
+                                "(solve_timer_ms is the reference's 'solve' timer alone); setup_ms is the 'prec' timer"},
+            "ranks_seen": ranks_seen, "transport": transport,
+            # rank-to-rank operations rank 0 issued per PCG iteration (V-cycle included): all-reduces (<s,p>; <r,r> + <r,z> fused into one
+            # two-double reduction; restricted residual of the replicated tail) and neighbour halo exchanges
+            "allreduces_per_iter": cs["allreduce"] * per_it, "halo_exchanges_per_iter": cs["exchange"] * per_it,
+            "collectives_per_iter": (cs["allreduce"] + cs["exchange"]) * per_it,
+            "halo_exchanges_overlapped_per_iter": cs["overlapped"] * per_it,
+            "allreduce_doubles_per_iter": cs["allreduce_doubles"] * per_it, "halo_doubles_per_iter": cs["exchange_doubles"] * per_it,
+            "iters": iters, "vcycles": vcyc, "converged": last["converged"], "final_rel": last["final_rel"],
+            "solve_timer_ms": timer_ms, "setup_ms": setup[1], "setup_cold_ms": setup[0],
+            "num_levels": amg.num_levels, "operator_complexity": o, "grid_complexity": g,
+            "hbm_in_use_gb": hh.memory_stats()[0] / 1e9, "hbm_peak_gb": hh.memory_stats()[1] / 1e9,  # rank 0's allocator: resident / peak
+            # aggregate over the ranks; fractions against n_gpus x 8 TB/s.  CSR-equivalent rate (SURVEY 8(d) bytes / time) and
+            # the rate of bytes really streamed (level 0 is stencil-coded)
+            "solve_phase_hbm_gbs": gbs(by[0], ms_per_step), "solve_phase_hbm_frac": gbs(by[0], ms_per_step) / (HBM_PEAK_GBS * w.size),
+            "solve_phase_format_gbs": gbs(by[1], ms_per_step), "solve_phase_format_frac": gbs(by[1], ms_per_step) / (HBM_PEAK_GBS * w.size),
+            "dof_iters_per_s": N * iters / (ms_per_step * 1e-3),
+            "roofline": {"kernel": f"k_spmv_stream<JACOBI> on rank 0's block of the level-{dom} operator ({dn} rows, {dnnz} nnz, plain CSR): "
+                                   f"largest share of the solve, {dom_count} launches timed inside it",
+                         "bound": "hbm", "achieved": gbs(dom_bytes, dom_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs(dom_bytes, dom_ms) / HBM_PEAK_GBS,
+                         "traffic": traffic.get(f"k_spmv_stream_jacobi_level{dom}_bytes_per_launch") if w.size == 1 and n == 256 else None,
+                         "traffic_source": traffic_src if w.size == 1 and n == 256 else None,
+                         "bytes_per_launch": dom_bytes, "avg_ms": dom_ms},
+            # level-0 PCG product (the north-star SpMV).  The operator is stencil-coded (1 B/entry), so the CSR-equivalent
+            # rate exceeds what HBM can deliver; "format" is the honest HBM rate; plain_csr below is the uncoded kernel
+            "level0_spmv": {"kernel": "k_spmv_coded_row<PLAIN,DOT>" if fb0["coded"] else "k_spmv_stream<PLAIN,DOT>",
+                            "coded": fb0["coded"], "avg_ms": k1_ms, "launches": k1_count,
+                            "csr_bytes_per_launch": k1_bytes, "csr_equiv_gbs": gbs(k1_bytes, k1_ms),
+                            "csr_equiv_frac": gbs(k1_bytes, k1_ms) / HBM_PEAK_GBS,
+                            "format_bytes_per_launch": k1_fmt, "format_gbs": gbs(k1_fmt, k1_ms),
+                            "format_frac": gbs(k1_fmt, k1_ms) / HBM_PEAK_GBS,
+                            "traffic": traffic.get("k_spmv_level0_bytes_per_launch") if w.size == 1 and n == 256 else None},
+        }
+        if "P0" in pr:
+            for key, M, extra in (("level0_prolongation", P0, 8.0), ("level0_restriction", R0, 0.0)):
+                mn, mc, mnnz = M.dims
+                ms, cnt = pr["P0" if key.endswith("prolongation") else "R0"]
+                bts = spmv_bytes(mn, mc, mnnz) + extra * mn  # P: x += P e reads x too
+                out[key] = {"rows": mn, "cols": mc, "nnz": mnnz, "avg_ms": ms, "launches": cnt, "csr_bytes_per_launch": bts,
+                            "csr_equiv_gbs": gbs(bts, ms), "csr_equiv_frac": gbs(bts, ms) / HBM_PEAK_GBS}
+        if w.size == 1:
+            single_extras(args, out, hh, A, amg, fb0, iters)
+    del A, amg
+    h.destroy_solver()
+    h.close()
+    w.hdist.finalize()
+    return out
+
+
+def single_extras(args, out, hh, A, amg, fb0, iters):
+    """N = 1 only: the same solve through the kernel-level seam (extra field), the per-kernel table, the plain-CSR
+    child run and the CPU baseline."""
+    kp = hh.KrylovParams.default(False)
+    res = hh.solve_device(A, amg, kp, nsolves=args.steps, profile_k1=False)
+    sm = sorted(float(x) for x in res["solve_ms"])
+    out["seam"] = {"what": "hda_solve_device on the same operator and hierarchy: Krylov loop alone, reference 'solve' timer boundaries",
+                   "ms_per_step": sm[len(sm) // 2], "iters": res["iters"], "true_rel_res": res["true_rel"]}
     if not args.no_kernel_table:
         kt = {}
         for kind, name in ((0, "spmv"), (1, "l1_jacobi"), (2, "residual"), (3, "vcycle")):
-            ms, by = h.time_kernel(kind, A, amg if kind == 3 else None, 20)
+            ms, by = hh.time_kernel(kind, A, amg if kind == 3 else None, 20)
             kt[name] = {"ms": ms, "csr_equiv_GB/s": by / ms / 1e6, "csr_equiv_frac": by / ms / 1e6 / HBM_PEAK_GBS}
             if kind == 3:
                 kt[name]["format_GB/s"] = fb0["vcycle"] / ms / 1e6
         out["kernels"] = kt
+    if not args.no_plain_csr and fb0["coded"]:
+        out["plain_csr"] = plain_csr_child(args)
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
-    return out
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample or args.n, iters if (args.cpu_sample or args.n) == args.n else None)
+        if "iters_match" in out["cpu_baseline"]:
+            out["iters_match"] = out["cpu_baseline"]["iters_match"]
+
+
+def plain_csr_child(args):
+    """What a general matrix gets: the same bench in a child process with HDA_CODED=0 (no stencil / value coding), so the
+    level-0 product is the plain CSR stream kernel of the north-star 'CSR SpMV >= 40 % of roofline' claim."""
+    env = dict(os.environ, HDA_CODED="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--grid", str(args.n), "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            c = json.loads(ln)
+            k1 = c["level0_spmv"]
+            return {"what": "child run with HDA_CODED=0: every operator in plain CSR (int32 col + fp64 val)",
+                    "ms_per_step": c["ms_per_step"], "value": c["value"], "iters": c["iters"],
+                    "level0_spmv_kernel": k1["kernel"], "level0_spmv_ms": k1["avg_ms"], "level0_spmv_gbs": k1["csr_equiv_gbs"],
+                    "level0_spmv_frac": k1["csr_equiv_frac"], "solve_phase_hbm_frac": c["solve_phase_hbm_frac"],
+                    "level0_prolongation_ms": c.get("level0_prolongation", {}).get("avg_ms"),
+                    "level0_restriction_ms": c.get("level0_restriction", {}).get("avg_ms")}
+    return {"error": f"child exited {r.returncode}: {r.stderr[-500:]}"}
 
 
 def main():
@@ -188,24 +345,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per dimension (global)")
-    ap.add_argument("--cpu-sample", type=int, default=128, help="grid size of the CPU-baseline sample (about 20 s of CPU work)")
+    ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per dimension (per rank; global with --strong)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="grid size of the CPU-baseline run (default: the benchmark's own --grid; "
+                    "256^3 takes about 2 minutes of host time, most of it the oracle's setup)")
     ap.add_argument("--strong", action="store_true", help="N > 1: --grid is the GLOBAL problem, cut into N blocks (fixed-size series). Default is "
                     "weak scaling: --grid is the block of every rank (global grid = block x rank grid; 256 on 8 GPUs = "
                     "BASELINE config 3, 512^3)")
     ap.add_argument("--weak", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--no-plain-csr", action="store_true")
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
-        from hypredrive_amd import dist_bench
-        out = dist_bench.run(args)
-        if out is None:
-            return
-    else:
-        out = run_single(args)
-    print(json.dumps(out), flush=True)
+    world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world is None:
+        sys.exit(spawn_ranks(args))
+    if world is not None and int(world) != args.gpus:
+        print(f"bench.py: launcher started {world} ranks, --gpus says {args.gpus}: using {world}", file=sys.stderr)
+    out = run(args)
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

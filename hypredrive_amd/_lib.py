@@ -71,6 +71,7 @@ SYMBOLS = [
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
+    "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size",
 ]
 
 
@@ -131,6 +132,11 @@ def load():
     L.hda_format_bytes.argtypes = [vp, vp, dp, dp, dp, ip]
     L.hda_probe_spmv.argtypes = [vp, C.c_int]
     L.hda_probe_read.argtypes = [dp, ip]
+    L.hda_probe_add.argtypes = [vp, C.c_int, ip]
+    L.hda_probe_read_id.argtypes = [C.c_int, dp, ip]
+    L.hda_borrow_hypredrv.argtypes = [vp, P(vp), P(vp)]
+    L.hda_comm_stats.argtypes = [dp, C.c_int]
+    L.hda_comm_name.restype = C.c_char_p
     _L = L
     return L
 
@@ -483,6 +489,40 @@ def probe_read():
     ms, n = C.c_double(), C.c_int()
     _check(load().hda_probe_read(C.byref(ms), C.byref(n)))
     return ms.value, n.value
+
+
+def probe_add(A, mode):
+    """Arm one more probe (several may be armed at once); returns its id for probe_read_id."""
+    k = C.c_int()
+    _check(load().hda_probe_add(A.h, mode, C.byref(k)))
+    return k.value
+
+
+def probe_read_id(k):
+    ms, n = C.c_double(), C.c_int()
+    _check(load().hda_probe_read_id(k, C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+
+def borrow(hypredrv_obj):
+    """(Csr, Amg) views of what a hypredrv.Hypredrv object built (level-0 operator + hierarchy); borrowed, not copied."""
+    a, g = C.c_void_p(), C.c_void_p()
+    _check(load().hda_borrow_hypredrv(hypredrv_obj.h, C.byref(a), C.byref(g)))
+    A = Csr(a, owned=True, keep=hypredrv_obj)  # destroying the view does not touch the operator
+    amg = Amg.__new__(Amg)
+    amg.A, amg.params, amg.h = A, None, g
+    return A, amg
+
+
+def comm_stats(reset=False):
+    v = (C.c_double * 5)()
+    load().hda_comm_stats(v, 1 if reset else 0)
+    return dict(allreduce=v[0], exchange=v[1], allreduce_doubles=v[2], exchange_doubles=v[3], overlapped=v[4])
+
+
+def comm_name():
+    load().hda_comm_name.restype = C.c_char_p
+    return load().hda_comm_name().decode()
 
 
 def check_row_total(nrows, row_len):

@@ -2370,8 +2370,7 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
    }
    else
    {
-      halo_exchange(level_hA(l), cur);
-      jacobi(A, dinv, b, cur, alt, dot_slot);
+      jacobi(A, dinv, b, cur, alt, dot_slot, &level_hA(l)); // ghost refresh of cur runs under the sweep's owned-column part
       std::swap(cur, alt);
    }
 }
@@ -2441,11 +2440,9 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
          relax(l, prm.relax_down, lv.dinv_down.data(), f, cur, alt, zg, -1);
          zg = false;
       }
-      halo_exchange(level_hA(l), cur);
-      residual(A, cur, f, lv.t.data());
+      residual(A, cur, f, lv.t.data(), &level_hA(l));
       AmgLevel &nx = levels[l + 1];
-      halo_exchange(lv.hR, lv.t.data());
-      spmv(lv.R, 1.0, lv.t.data(), 0.0, nullptr, nx.f.data());
+      spmv(lv.R, 1.0, lv.t.data(), 0.0, nullptr, nx.f.data(), &lv.hR);
       sol[l] = cur;
       f      = nx.f.data();
       if (l + 1 < L - 1) { cur = nx.u.data(); alt = nx.u2.data(); }
@@ -2475,8 +2472,7 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
       if (l == 0) a = (c == x) ? levels[0].u2.data() : x;
       else a = (c == lv.u.data()) ? lv.u2.data() : lv.u.data();
       const double *fl = (l == 0) ? b : lv.f.data();
-      halo_exchange(lv.hP, sol[l + 1]);
-      spmv(lv.P, 1.0, sol[l + 1], 1.0, c, c);
+      spmv(lv.P, 1.0, sol[l + 1], 1.0, c, c, &lv.hP);
       for (int s = 0; s < prm.sweeps_up; s++)
       {
          const bool last = (l == 0) && (s == prm.sweeps_up - 1);

@@ -3,6 +3,7 @@
 
 #include "hda_krylov.h"
 #include "hda_comm.h"
+#include "hda_hypre.h"
 
 #include <chrono>
 #include <cmath>
@@ -15,10 +16,13 @@ struct hda_csr_s {
    DArray<double> rhs; // optional device rhs (generator)
    bool           borrowed = false;
    const DCsr    *ref      = nullptr; // for borrowed handles
+   const double  *rhs_ref  = nullptr; // device rhs of a handle borrowed from a HYPREDRV object
+   const HaloPlan *halo    = nullptr; // its ghost refresh plan (row-partitioned runs)
    const DCsr    &get() const { return ref ? *ref : m; }
 };
 struct hda_amg_s {
-   std::unique_ptr<Amg>                    amg;
+   Amg                                    *amg = nullptr; // the hierarchy: owned_amg.get(), or borrowed from a HYPREDRV object
+   std::unique_ptr<Amg>                    owned_amg;
    std::unique_ptr<Ilu>                    ilu; // handle made by hda_ilu_create: the preconditioner is one ILU solve
    std::unique_ptr<Mgr>                    mgr; // handle made by hda_mgr_create: the preconditioner is one MGR solve
    DArray<double>                          ilu_r, ilu_c;
@@ -356,8 +360,9 @@ extern "C" int hda_amg_create(const hda_amg_params *p, hda_csr_t A, hda_amg_t *o
 {
    HDA_TRY
    auto h = std::make_unique<hda_amg_s>();
-   h->amg = std::make_unique<Amg>(to_params(p));
-   h->A   = A;
+   h->owned_amg = std::make_unique<Amg>(to_params(p));
+   h->amg       = h->owned_amg.get();
+   h->A         = A;
    h->amg->setup(A->get());
    *out = h.release();
    HDA_CATCH
@@ -366,8 +371,9 @@ extern "C" int hda_amg_create_dof(const hda_amg_params *p, hda_csr_t A, const in
 {
    HDA_TRY
    auto h = std::make_unique<hda_amg_s>();
-   h->amg = std::make_unique<Amg>(to_params(p));
-   h->A   = A;
+   h->owned_amg = std::make_unique<Amg>(to_params(p));
+   h->amg       = h->owned_amg.get();
+   h->A         = A;
    if (dof_func) h->amg->dof_func0.assign(dof_func, dof_func + A->get().nrows);
    h->amg->setup(A->get());
    *out = h.release();
@@ -648,16 +654,22 @@ extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_par
    Context       &ctx = Context::get();
    const DCsr    &m   = A->get();
    const int      n   = m.nrows;
-   DArray<double> b, x((size_t)std::max(m.ncols, 1)), r((size_t)std::max(n, 1));
+   DArray<double> b, x(std::max<size_t>((size_t)std::max(m.ncols, 1), amg && amg->amg ? amg->amg->vec_len0() : 0)), r((size_t)std::max(n, 1));
    if (b_host) b.upload(b_host, (size_t)n);
+   else if (A->rhs_ref)
+   {
+      b.alloc((size_t)std::max(n, 1));
+      copy(n, A->rhs_ref, b.data());
+   }
    else
    {
       HDA_REQUIRE(A->rhs.size() == (size_t)n, "no right-hand side: pass b or build A with hda_lap7_create");
       b.copy_from(A->rhs);
    }
    x.zero();
+   const bool multi = A->halo && Comm::world().size > 1;
    // initial residual norm, untimed (solver.c:666)
-   residual(m, x.data(), b.data(), r.data());
+   residual(m, x.data(), b.data(), r.data()); // x = 0: no ghost refresh needed
    dot(n, r.data(), r.data(), 0);
    finalize(0, S_TMP);
    const double r0 = std::sqrt(read_scalar(S_TMP));
@@ -668,7 +680,7 @@ extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_par
    if (amg) M = [amg](const double *rr, double *zz, int slot) { amg->amg->apply(rr, zz, slot); };
    KrylovParams k = to_kparams(kp);
    k.profile_k1   = (k1_avg_ms != nullptr);
-   LinOp op(m, nullptr, amg ? amg->amg->vec_len0() : 0);
+   LinOp op(m, multi ? A->halo : nullptr, amg ? amg->amg->vec_len0() : 0);
    KrylovResult res;
    double       k1_sum = 0.0;
    long         k1_cnt = 0;
@@ -685,6 +697,7 @@ extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_par
       k1_cnt += res.k1_count;
    }
    // true relative residual, untimed (solver.c:686-690)
+   if (multi) halo_exchange(*A->halo, x.data());
    residual(m, x.data(), b.data(), r.data());
    dot(n, r.data(), r.data(), 0);
    finalize(0, S_TMP);
@@ -710,17 +723,78 @@ extern "C" int hda_format_bytes(hda_csr_t A, hda_amg_t amg, double *pcg_iteratio
    HDA_CATCH
 }
 
+// Borrowed seam views of a HYPREDRV object whose solver is set up: its level-0 operator (with the right-hand side and
+// the ghost refresh plan of a row block) and its BoomerAMG hierarchy.  bench.py measures the object the API
+// built, not a second copy.  Valid until LinearSolverDestroy / PreconDestroy; release with hda_csr_destroy / hda_amg_destroy.
+extern "C" int hda_borrow_hypredrv(void *hypredrv, hda_csr_t *A, hda_amg_t *amg)
+{
+   HDA_TRY
+   const DCsr     *m    = nullptr;
+   const HaloPlan *halo = nullptr;
+   const double   *rhs  = nullptr;
+   Amg            *g    = nullptr;
+   HDA_REQUIRE(hypredrv_peek(hypredrv, &m, &halo, &rhs, &g) && m, "hda_borrow_hypredrv: the object has no matrix yet");
+   if (A)
+   {
+      auto v      = std::make_unique<hda_csr_s>();
+      v->borrowed = true;
+      v->ref      = m;
+      v->rhs_ref  = rhs;
+      v->halo     = halo;
+      *A          = v.release();
+   }
+   if (amg)
+   {
+      HDA_REQUIRE(g, "hda_borrow_hypredrv: the preconditioner is not a set-up BoomerAMG hierarchy");
+      auto h = std::make_unique<hda_amg_s>();
+      h->amg = g;
+      *amg   = h.release();
+   }
+   HDA_CATCH
+}
+
+extern "C" int hda_probe_add(hda_csr_t A, int mode, int *id)
+{
+   HDA_TRY
+   HDA_REQUIRE(A && mode >= 0 && mode <= 2, "probe: matrix and mode 0 plain, 1 residual, 2 Jacobi");
+   const int k = spmv_probe_add(&A->get(), mode);
+   if (id) *id = k;
+   HDA_CATCH
+}
+extern "C" int hda_probe_read_id(int id, double *avg_ms, int *count)
+{
+   HDA_TRY
+   spmv_probe_read(id, avg_ms, count);
+   HDA_CATCH
+}
+// rank-to-rank traffic since the last reset: [0] device all-reduces, [1] halo exchanges (neighbour send/recv groups),
+// [2] doubles all-reduced, [3] doubles sent in halo exchanges, [4] exchanges whose transfer ran under a product kernel
+extern "C" int hda_comm_stats(double out[5], int reset)
+{
+   Comm &cm = Comm::world();
+   if (out)
+   {
+      out[0] = (double)cm.stats.allreduce; out[1] = (double)cm.stats.exchange; out[2] = (double)cm.stats.allreduce_doubles;
+      out[3] = (double)cm.stats.exchange_doubles; out[4] = (double)cm.stats.overlapped;
+   }
+   if (reset) cm.stats = Comm::Stats();
+   return HDA_OK;
+}
+extern "C" const char *hda_comm_name(void) { return Comm::world().name(); }
+extern "C" int hda_comm_size(void) { return Comm::world().size; }
+
 extern "C" int hda_probe_spmv(hda_csr_t A, int mode)
 {
    HDA_TRY
    HDA_REQUIRE(mode >= 0 && mode <= 2, "probe mode: 0 plain, 1 residual, 2 Jacobi");
-   spmv_probe_set(A ? &A->get() : nullptr, A ? mode : -1);
+   spmv_probe_clear();
+   if (A) spmv_probe_add(&A->get(), mode);
    HDA_CATCH
 }
 extern "C" int hda_probe_read(double *avg_ms, int *count)
 {
    HDA_TRY
-   spmv_probe_read(avg_ms, count);
+   spmv_probe_read(0, avg_ms, count);
    HDA_CATCH
 }
 

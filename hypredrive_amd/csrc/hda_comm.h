@@ -13,19 +13,33 @@
 namespace hda {
 
 // host callbacks of the staged transport (see include/HYPREDRV.h, HYPREDRV_AMD_CommInitCallbacks)
-typedef void (*hda_allreduce_cb)(void *buf, long count, int dtype /*0 f64, 1 i64*/, int op /*0 sum, 1 max*/);
+// Both return 0 on success; anything else makes the library raise an error on this rank (a callback that failed
+// silently would leave unfilled receive buffers behind: wrong halos and dot products, or deadlocked peers).
+typedef int (*hda_allreduce_cb)(void *buf, long count, int dtype /*0 f64, 1 i64*/, int op /*0 sum, 1 max*/);
 // send/recv are packed by ascending peer rank; counts in BYTES, arrays of length world_size
-typedef void (*hda_alltoallv_cb)(const void *send, const long *send_bytes, void *recv, const long *recv_bytes);
+typedef int (*hda_alltoallv_cb)(const void *send, const long *send_bytes, void *recv, const long *recv_bytes);
 
 class Comm {
  public:
    int rank = 0, size = 1;
+   // traffic counters of the solve path (bench.py: collectives per iteration)
+   struct Stats {
+      long allreduce = 0, exchange = 0, allreduce_doubles = 0, exchange_doubles = 0, overlapped = 0;
+   } stats;
    virtual ~Comm() = default;
    // in-place sum of n doubles living in HBM, ordered on the library stream
    virtual void allreduce_sum_dev(double *dbuf, int n) = 0;
    // neighbour exchange of doubles in HBM: send_dev is packed by ascending destination rank,
-   // recv_dev by ascending source rank; counts in elements, host arrays of length `size`
-   virtual void exchange_dev(const double *send_dev, const int *send_counts, double *recv_dev, const int *recv_counts) = 0;
+   // recv_dev by ascending source rank; counts in elements, host arrays of length `size`.
+   // Ordered on stream `s` (the library stream, or the communication stream of an overlapped exchange);
+   // the staged transport blocks the host until the messages have arrived.
+   virtual void exchange_dev(const double *send_dev, const int *send_counts, double *recv_dev, const int *recv_counts, hipStream_t s) = 0;
+   void exchange_dev(const double *send_dev, const int *send_counts, double *recv_dev, const int *recv_counts)
+   {
+      exchange_dev(send_dev, send_counts, recv_dev, recv_counts, Context::get().stream);
+   }
+   // true when exchange_dev only enqueues work (RCCL); false when it blocks the host (staged callbacks)
+   virtual bool async_exchange() const { return false; }
    // setup-time host collectives
    virtual void allreduce_host(long long *v, int n, int op /*0 sum 1 max*/) = 0;
    virtual void alltoallv_host(const void *send, const long *send_bytes, void *recv, const long *recv_bytes) = 0;

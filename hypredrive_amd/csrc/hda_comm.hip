@@ -48,7 +48,7 @@ namespace {
 class SelfComm : public Comm {
  public:
    void allreduce_sum_dev(double *, int) override {}
-   void exchange_dev(const double *, const int *, double *, const int *) override {}
+   void exchange_dev(const double *, const int *, double *, const int *, hipStream_t) override {}
    void allreduce_host(long long *, int, int) override {}
    void alltoallv_host(const void *send, const long *sb, void *recv, const long *rb) override
    {
@@ -131,21 +131,26 @@ class RcclComm : public Comm {
    }
    void allreduce_sum_dev(double *d, int n) override
    {
+      stats.allreduce++;
+      stats.allreduce_doubles += n;
       HDA_NCCL(rccl().AllReduce(d, d, (size_t)n, kF64, kSum, comm_, STREAM));
    }
-   void exchange_dev(const double *send, const int *sc, double *recv, const int *rc) override
+   void exchange_dev(const double *send, const int *sc, double *recv, const int *rc, hipStream_t st) override
    {
+      stats.exchange++;
       HDA_NCCL(rccl().GroupStart());
       size_t so = 0, ro = 0;
       for (int p = 0; p < size; p++)
       {
-         if (sc[p]) HDA_NCCL(rccl().Send(send + so, (size_t)sc[p], kF64, p, comm_, STREAM));
-         if (rc[p]) HDA_NCCL(rccl().Recv(recv + ro, (size_t)rc[p], kF64, p, comm_, STREAM));
+         if (sc[p]) HDA_NCCL(rccl().Send(send + so, (size_t)sc[p], kF64, p, comm_, st));
+         if (rc[p]) HDA_NCCL(rccl().Recv(recv + ro, (size_t)rc[p], kF64, p, comm_, st));
          so += (size_t)sc[p];
          ro += (size_t)rc[p];
       }
       HDA_NCCL(rccl().GroupEnd());
+      stats.exchange_doubles += (long)so;
    }
+   bool async_exchange() const override { return true; }
    void allreduce_host(long long *v, int n, int op) override
    {
       DArray<long long> d;
@@ -194,17 +199,25 @@ class CallbackComm : public Comm {
       rank = r;
       size = s;
    }
+   ~CallbackComm() override
+   {
+      for (double *p : pin_)
+         if (p) (void)hipHostFree(p);
+   }
    void allreduce_sum_dev(double *d, int n) override
    {
-      std::vector<double> h((size_t)n);
-      HDA_HIP(hipMemcpyAsync(h.data(), d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, STREAM));
+      stats.allreduce++;
+      stats.allreduce_doubles += n;
+      double *h = pinned(0, (size_t)std::max(n, 1));
+      HDA_HIP(hipMemcpyAsync(h, d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, STREAM));
       Context::get().sync();
-      ar_(h.data(), n, 0, 0);
-      HDA_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, STREAM));
+      check(ar_(h, n, 0, 0), "all-reduce");
+      HDA_HIP(hipMemcpyAsync(d, h, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, STREAM));
       Context::get().sync();
    }
-   void exchange_dev(const double *send, const int *sc, double *recv, const int *rc) override
+   void exchange_dev(const double *send, const int *sc, double *recv, const int *rc, hipStream_t strm) override
    {
+      stats.exchange++;
       long              st = 0, rt = 0;
       std::vector<long> sb((size_t)size), rb((size_t)size);
       for (int p = 0; p < size; p++)
@@ -214,18 +227,38 @@ class CallbackComm : public Comm {
          st += sc[p];
          rt += rc[p];
       }
-      std::vector<double> hs((size_t)std::max<long>(st, 1)), hr((size_t)std::max<long>(rt, 1));
-      if (st) HDA_HIP(hipMemcpyAsync(hs.data(), send, sizeof(double) * (size_t)st, hipMemcpyDeviceToHost, STREAM));
-      Context::get().sync();
-      a2a_(hs.data(), sb.data(), hr.data(), rb.data());
-      if (rt) HDA_HIP(hipMemcpyAsync(recv, hr.data(), sizeof(double) * (size_t)rt, hipMemcpyHostToDevice, STREAM));
-      Context::get().sync();
+      stats.exchange_doubles += st;
+      // pinned staging buffers: the copies go through the DMA engines and do not queue behind a product grid
+      double *hs = pinned(0, (size_t)std::max<long>(st, 1)), *hr = pinned(1, (size_t)std::max<long>(rt, 1));
+      if (st) HDA_HIP(hipMemcpyAsync(hs, send, sizeof(double) * (size_t)st, hipMemcpyDeviceToHost, strm));
+      HDA_HIP(hipStreamSynchronize(strm));
+      check(a2a_(hs, sb.data(), hr, rb.data()), "neighbour exchange");
+      if (rt) HDA_HIP(hipMemcpyAsync(recv, hr, sizeof(double) * (size_t)rt, hipMemcpyHostToDevice, strm));
+      HDA_HIP(hipStreamSynchronize(strm));
    }
-   void allreduce_host(long long *v, int n, int op) override { ar_(v, n, 1, op); }
-   void alltoallv_host(const void *send, const long *sb, void *recv, const long *rb) override { a2a_(send, sb, recv, rb); }
+   void allreduce_host(long long *v, int n, int op) override { check(ar_(v, n, 1, op), "host all-reduce"); }
+   void alltoallv_host(const void *send, const long *sb, void *recv, const long *rb) override { check(a2a_(send, sb, recv, rb), "host all-to-all"); }
    const char *name() const override { return "host-callbacks"; }
 
  private:
+   double *pinned(int which, size_t n)
+   {
+      if (pin_n_[which] < n)
+      {
+         if (pin_[which]) (void)hipHostFree(pin_[which]);
+         pin_[which] = nullptr;
+         const size_t m = std::max<size_t>(n + n / 2, 4096);
+         HDA_HIP(hipHostMalloc((void **)&pin_[which], sizeof(double) * m, hipHostMallocDefault));
+         pin_n_[which] = m;
+      }
+      return pin_[which];
+   }
+   double *pin_[2]   = {nullptr, nullptr};
+   size_t  pin_n_[2] = {0, 0};
+   static void check(int rc, const char *what)
+   {
+      if (rc != 0) throw Error(std::string("staged transport: the launcher's ") + what + " callback failed (code " + std::to_string(rc) + ")");
+   }
    hda_allreduce_cb ar_;
    hda_alltoallv_cb a2a_;
 };

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -49,6 +50,7 @@ constexpr int kRedThreads = 256;
 // One per process (per GPU): stream, reduction scratch, pinned scalars.
 struct Context {
    hipStream_t stream      = nullptr;
+   hipStream_t comm_stream = nullptr; // halo transfers that run under a product kernel (row-partitioned runs)
    double     *partials    = nullptr; // [kNumSlots][kRedBlocks] block partials
    double     *scalars     = nullptr; // device scalars (gamma, alpha, ...)
    double     *host_scalars = nullptr; // pinned host mirror for async read-back
@@ -141,6 +143,13 @@ class DArray {
    size_t n_ = 0;
 };
 
+// Ghost-column entries of a row block, by boundary row (built lazily by the first overlapped product; hda_kernels.hip)
+struct OffdPart {
+   int            nown = -1, nbrows = 0, nnz = 0; // columns >= nown are ghosts; rows with any; their entries
+   DArray<int>    brow, rp, col;
+   DArray<double> val;
+};
+
 // Local CSR block resident in HBM. int32 indices, fp64 values, rows column-sorted.
 // ncols may exceed nrows: columns >= nrows address the ghost tail of an extended vector
 // (row-partitioned case: [owned | halo]).
@@ -162,9 +171,10 @@ struct DCsr {
    mutable DArray<double>        dict_val;   // 256
    mutable DArray<int>           dict_delta; // 256
    mutable int                   coded = -1, escapes = 0; // -1 not examined, 0 plain, 1 coded; entries outside the dictionary
+   mutable std::unique_ptr<OffdPart> offd; // ghost-column part, for products overlapped with their halo exchange
    void reset_plan() const
    {
-      chunk_row.release(); code.release(); dict_val.release(); dict_delta.release();
+      chunk_row.release(); code.release(); dict_val.release(); dict_delta.release(); offd.reset();
       nchunks = 0; maxrow = -1; coded = -1;
    }
 };
@@ -185,6 +195,15 @@ inline bool verbose()
          fflush(stderr);                               \
       }                                                \
    } while (0)
+
+// Host read-back ordered on the library stream.  The stream is created non-blocking, so a
+// null-stream hipMemcpy does NOT wait for kernels enqueued on it: every device -> host copy
+// of data the library's kernels produce goes through here.
+inline void download_sync(void *host, const void *dev, size_t bytes)
+{
+   if (bytes) HDA_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, Context::get().stream));
+   Context::get().sync();
+}
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 

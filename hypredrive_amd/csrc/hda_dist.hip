@@ -92,7 +92,13 @@ HaloPlan make_halo_plan(int nloc, const std::vector<long long> &part, const std:
    h.nghost = (int)ghost_gids.size();
    h.send_counts.assign((size_t)cm.size, 0);
    h.recv_counts.assign((size_t)cm.size, 0);
-   if (cm.size == 1) return h;
+   if (cm.size == 1)
+   { // a matrix with off-rank columns on a one-rank communicator would read a ghost tail nobody ever writes (e.g. a
+     // driver started under mpiexec -n > 1 whose ranks never joined the library's communicator)
+      HDA_REQUIRE(ghost_gids.empty(), "matrix has off-rank columns but no communicator was joined (call HYPREDRV_AMD_CommInit / "
+                                      "HYPREDRV_AMD_CommInitCallbacks on every rank before assembling row blocks)");
+      return h;
+   }
    // who owns each ghost (ghost_gids ascending => grouped by ascending owner)
    for (long long g : ghost_gids)
    {
@@ -144,6 +150,29 @@ void halo_exchange(const HaloPlan &h, double *x_ext)
    if (h.send_total) k_pack<<<ceil_div(h.send_total, 256), 256, 0, STREAM>>>(h.send_total, h.send_idx.data(), x_ext, (double *)h.send_buf.data());
    cm.exchange_dev(h.send_buf.data(), h.send_counts.data(), x_ext + h.nloc, h.recv_counts.data());
 }
+
+bool halo_active(const HaloPlan &h) { return Comm::world().size > 1 && !h.send_counts.empty(); }
+
+static void halo_events(const HaloPlan &h)
+{
+   if (h.ev_packed) return;
+   HDA_HIP(hipEventCreateWithFlags(&h.ev_packed, hipEventDisableTiming));
+   HDA_HIP(hipEventCreateWithFlags(&h.ev_landed, hipEventDisableTiming));
+}
+void halo_pack(const HaloPlan &h, const double *x)
+{
+   halo_events(h);
+   if (h.send_total) k_pack<<<ceil_div(h.send_total, 256), 256, 0, STREAM>>>(h.send_total, h.send_idx.data(), x, (double *)h.send_buf.data());
+   HDA_HIP(hipEventRecord(h.ev_packed, STREAM));
+}
+void halo_transfer(const HaloPlan &h, double *x)
+{
+   Context &c = Context::get();
+   HDA_HIP(hipStreamWaitEvent(c.comm_stream, h.ev_packed, 0));
+   Comm::world().exchange_dev(h.send_buf.data(), h.send_counts.data(), x + h.nloc, h.recv_counts.data(), c.comm_stream);
+   HDA_HIP(hipEventRecord(h.ev_landed, c.comm_stream));
+}
+void halo_wait(const HaloPlan &h) { HDA_HIP(hipStreamWaitEvent(STREAM, h.ev_landed, 0)); }
 
 void gather_global(const DCsr &Aloc, const std::vector<long long> &part, const std::vector<long long> &ghost_gids, DCsr &G)
 {

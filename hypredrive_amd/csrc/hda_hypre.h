@@ -45,7 +45,18 @@ struct hypre_IJMatrix_struct {
 
 enum hda_solver_kind { HDA_SOLVER_PCG = 1, HDA_SOLVER_GMRES = 2, HDA_SOLVER_AMG = 3, HDA_SOLVER_ILU = 4, HDA_SOLVER_FGMRES = 5, HDA_SOLVER_BICGSTAB = 6, HDA_SOLVER_MGR = 7 };
 
+namespace hda {
+// addresses of the live solver objects THIS library created: an opaque HYPRE_Solver a caller installs with
+// HYPRE_PCGSetPrecond (hypredrive's cookie, a user's own struct) may only be looked into when it is one of them
+void solver_registry(const void *p, int op); // op: +1 insert, -1 erase
+bool is_live_solver(const void *p);
+} // namespace hda
+
 struct hypre_Solver_struct {
+   hypre_Solver_struct() { hda::solver_registry(this, +1); }
+   ~hypre_Solver_struct() { hda::solver_registry(this, -1); }
+   hypre_Solver_struct(const hypre_Solver_struct &) = delete;
+   hypre_Solver_struct &operator=(const hypre_Solver_struct &) = delete;
    int                       kind = 0;
    hda::KrylovParams         kp;
    hda::AmgParams            ap;
@@ -76,6 +87,8 @@ struct hypre_Solver_struct {
 };
 
 namespace hda {
+// what a HYPREDRV object holds (defined in hda_hypredrv.hip): level-0 operator, its halo plan, device rhs, hierarchy
+bool hypredrv_peek(void *hypredrv, const DCsr **A, const HaloPlan **halo, const double **rhs, Amg **amg);
 // error text of the last failed HYPRE_* call (HYPRE_GetError returns the code)
 const std::string &hypre_last_error();
 int                hypre_set_error(int code, const std::string &msg);

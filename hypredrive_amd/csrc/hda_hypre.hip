@@ -3,6 +3,8 @@
 // (src/internal/solver.c:204-253, src/internal/precon.c:106-157 in the reference) bind.
 #include "hda_hypre.h"
 
+#include <unordered_set>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -108,7 +110,7 @@ static HYPRE_Int vec_set(HYPRE_IJVector v, HYPRE_Int n, const HYPRE_BigInt *idx,
    if (v->assembled && v->stage.empty())
    { // re-open an assembled vector: pull the device values back into the stage
       v->stage.resize((size_t)v->nloc);
-      if (v->nloc) HDA_HIP(hipMemcpy(v->stage.data(), v->data(), sizeof(double) * (size_t)v->nloc, hipMemcpyDeviceToHost));
+      download_sync(v->stage.data(), v->data(), sizeof(double) * (size_t)v->nloc);
    }
    for (int q = 0; q < n; q++)
    {
@@ -151,7 +153,7 @@ extern "C" HYPRE_Int HYPRE_IJVectorGetValues(HYPRE_IJVector v, HYPRE_Int n, cons
    else
    {
       h.resize((size_t)std::max(v->nloc, 1));
-      if (v->nloc) HDA_HIP(hipMemcpy(h.data(), v->data(), sizeof(double) * (size_t)v->nloc, hipMemcpyDeviceToHost));
+      download_sync(h.data(), v->data(), sizeof(double) * (size_t)v->nloc);
       src = h.data();
    }
    for (int q = 0; q < n; q++)
@@ -293,7 +295,7 @@ extern "C" HYPRE_Int HYPRE_IJVectorPrint(HYPRE_IJVector v, const char *filename)
    FILE             *f  = fopen(fn.c_str(), "w");
    if (!f) return hypre_set_error(HYPRE_ERROR_ARG, "cannot write " + fn);
    std::vector<double> h((size_t)std::max(v->nloc, 1));
-   if (v->nloc) HDA_HIP(hipMemcpy(h.data(), v->data(), sizeof(double) * (size_t)v->nloc, hipMemcpyDeviceToHost));
+   download_sync(h.data(), v->data(), sizeof(double) * (size_t)v->nloc);
    fprintf(f, "%lld %lld\n", v->jlower, v->jupper);
    for (int i = 0; i < v->nloc; i++) fprintf(f, "%lld %.14e\n", v->jlower + i, h[(size_t)i]);
    fclose(f);
@@ -882,6 +884,20 @@ static size_t precond_veclen(HYPRE_Solver s)
    return 0;
 }
 
+namespace hda {
+static std::unordered_set<const void *> &live_solvers()
+{
+   static std::unordered_set<const void *> s;
+   return s;
+}
+void solver_registry(const void *p, int op)
+{
+   if (op > 0) live_solvers().insert(p);
+   else live_solvers().erase(p);
+}
+bool is_live_solver(const void *p) { return p && live_solvers().count(p) != 0; }
+} // namespace hda
+
 static thread_local size_t g_precond_veclen = 0;
 extern "C" void hda_register_precond_veclen(size_t n) { g_precond_veclen = n; }
 extern "C" void hda_reset_precond_veclen(void) { g_precond_veclen = 0; }
@@ -893,7 +909,7 @@ static HYPRE_Int krylov_solve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVec
    HDA_REQUIRE(A && A->assembled, "Krylov solve needs an assembled matrix");
    x->ensure_device();
    size_t veclen = std::max(g_precond_veclen, precond_veclen(s));
-   if (s->precond_solver && s->precond_solver->kind == HDA_SOLVER_AMG && s->precond_solver->amg)
+   if (is_live_solver(s->precond_solver) && s->precond_solver->kind == HDA_SOLVER_AMG && s->precond_solver->amg)
       veclen = std::max(veclen, s->precond_solver->amg->vec_len0());
    LinOp     op(A->A, Comm::world().size > 1 ? &A->halo : nullptr, veclen);
    PrecondFn M;

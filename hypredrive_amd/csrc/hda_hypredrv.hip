@@ -299,10 +299,7 @@ extern "C" uint32_t HYPREDRV_AMD_CommInit(int rank, int world, int device, const
    if (world > 1 || getenv("HDA_FORCE_RCCL")) Comm::set_world(make_rccl_comm(rank, world, uid));
    API_CATCH
 }
-typedef void (*hda_allreduce_cb_c)(void *, long, int, int);
-typedef void (*hda_alltoallv_cb_c)(const void *, const long *, void *, const long *);
-extern "C" HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_CommInitCallbacks(int rank, int world, int device, hda_allreduce_cb_c ar,
-                                                                          hda_alltoallv_cb_c a2a)
+extern "C" uint32_t HYPREDRV_AMD_CommInitCallbacks(int rank, int world, int device, HYPREDRV_AMD_AllreduceFn ar, HYPREDRV_AMD_AlltoallvFn a2a)
 {
    err_reset();
    API_TRY
@@ -596,7 +593,7 @@ static HYPRE_IJVector new_vector_like(hypredrv_struct *h, double value)
    HYPRE_IJVector v = nullptr;
    HYPRE_IJVectorCreate(h->comm, h->mat_A->ilower, h->mat_A->iupper, &v);
    HYPRE_IJVectorSetObjectType(v, HYPRE_PARCSR);
-   HYPRE_IJVectorInitialize(v);
+   v->initialized = true; // device resident from the start: HYPRE_IJVectorInitialize would zero a host staging copy first
    HYPRE_ParVectorSetConstantValues(v, value);
    return v;
 }
@@ -907,7 +904,7 @@ extern "C" uint32_t HYPREDRV_LinearSystemGetSolutionValues(HYPREDRV_t h, HYPRE_C
    if (!h->vec_x || !data) return err_set(ERR_UNKNOWN, "no solution vector");
    HYPRE_IJVector x = h->vec_x;
    x->host_mirror.resize((size_t)std::max(x->nloc, 1));
-   if (x->nloc) HDA_HIP(hipMemcpy(x->host_mirror.data(), x->data(), sizeof(double) * (size_t)x->nloc, hipMemcpyDeviceToHost));
+   download_sync(x->host_mirror.data(), x->data(), sizeof(double) * (size_t)x->nloc);
    *data = x->host_mirror.data();
    API_CATCH
 }
@@ -918,7 +915,7 @@ extern "C" uint32_t HYPREDRV_LinearSystemGetRHSValues(HYPREDRV_t h, HYPRE_Comple
    if (!h->vec_b || !data) return err_set(ERR_UNKNOWN, "no right-hand side");
    HYPRE_IJVector b = h->vec_b;
    b->host_mirror.resize((size_t)std::max(b->nloc, 1));
-   if (b->nloc) HDA_HIP(hipMemcpy(b->host_mirror.data(), b->data(), sizeof(double) * (size_t)b->nloc, hipMemcpyDeviceToHost));
+   download_sync(b->host_mirror.data(), b->data(), sizeof(double) * (size_t)b->nloc);
    *data = b->host_mirror.data();
    API_CATCH
 }
@@ -1101,7 +1098,7 @@ extern "C" uint32_t HYPREDRV_StateVectorApplyCorrection(HYPREDRV_t h, int state_
    if (!v) return err_set(ERR_INVALID_VAL, "StateVectorApplyCorrection: index outside the states set with StateVectorSet");
    if (!h->vec_x || h->vec_x->nloc != v->nloc) return err_set(ERR_UNKNOWN, "StateVectorApplyCorrection: no solution vector of matching size");
    std::vector<double> dx((size_t)std::max(v->nloc, 1));
-   if (v->nloc) HDA_HIP(hipMemcpy(dx.data(), h->vec_x->data(), sizeof(double) * (size_t)v->nloc, hipMemcpyDeviceToHost));
+   download_sync(dx.data(), h->vec_x->data(), sizeof(double) * (size_t)v->nloc);
    for (int i = 0; i < v->nloc; i++) v->stage[(size_t)i] += dx[(size_t)i];
    API_CATCH
 }
@@ -1243,6 +1240,19 @@ extern "C" uint32_t HYPREDRV_LinearSystemReadDofmap(HYPREDRV_t h)
    }
    return g_err;
 }
+// seam for bench.py (hda_borrow_hypredrv): the objects the API built, for the kernel-level measurement entries
+namespace hda {
+bool hypredrv_peek(void *obj, const DCsr **A, const HaloPlan **halo, const double **rhs, Amg **amg)
+{
+   hypredrv_struct *h = (hypredrv_struct *)obj;
+   if (!h || !h->mat_A) return false;
+   if (A) *A = &h->mat_A->A;
+   if (halo) *halo = &h->mat_A->halo;
+   if (rhs) *rhs = h->vec_b ? (h->vec_b->ensure_device(), h->vec_b->data()) : nullptr;
+   if (amg) *amg = (h->precon && h->precon_is_setup && h->precon->kind == HDA_SOLVER_AMG) ? h->precon->amg.get() : nullptr;
+   return true;
+}
+} // namespace hda
 // bytes THIS rank streams per Krylov iteration (operator product + vector updates) and per
 // V-cycle with the hierarchy that was set up: [0] CSR figures of SURVEY 8(d), [1] the formats
 // actually read (coded operators).  bench.py sums them over the ranks.
@@ -1754,7 +1764,13 @@ void scaling_compute(hypredrv_struct *h)
    {
       for (size_t i = 0; i < a.custom_values.size(); i++)
          if (a.custom_values[i] == 0.0) { bad = ERR_INVALID_VAL; why = "custom dofmap scaling requires nonzero custom_values (entry " + std::to_string(i) + " is zero)"; }
-      for (int t : h->dofmap) max_tag = std::max<long long>(max_tag, t);
+      for (size_t i = 0; i < h->dofmap.size(); i++)
+      {
+         const int t = h->dofmap[i];
+         // a negative tag is a local finding, but the verdict must be collective: it rides in the same all-reduce
+         if (t < 0 && !bad) { bad = ERR_UNKNOWN; why = "dofmap_custom: invalid tag " + std::to_string(t) + " at local row " + std::to_string(i); }
+         max_tag = std::max<long long>(max_tag, t);
+      }
    }
    long long red[2] = {max_tag, (long long)bad};
    if (Comm::world().size > 1) Comm::world().allreduce_host(red, 2, 1);
@@ -1767,11 +1783,9 @@ void scaling_compute(hypredrv_struct *h)
    if (!red[1])
       for (int i = 0; i < n; i++)
       {
-         const int t = h->dofmap[(size_t)i];
-         if (t < 0) { bad = ERR_UNKNOWN; why = "dofmap_custom: invalid tag " + std::to_string(t) + " at local row " + std::to_string(i); break; }
-         w[(size_t)i] = a.custom_values[(size_t)t];
+         w[(size_t)i] = a.custom_values[(size_t)h->dofmap[(size_t)i]]; // tags are in [0, custom_values.size()) on every rank here
       }
-   if (bad || red[1]) { err_set(bad ? bad : (uint32_t)red[1], why); return; }
+   if (bad || red[1]) { err_set(bad ? bad : (uint32_t)red[1], why.empty() ? std::string("custom dofmap scaling was rejected on another rank") : why); return; }
    c.scaling.alloc((size_t)std::max(n, 1));
    c.inverse_scaling.alloc((size_t)std::max(n, 1));
    c.scaling.upload(w.data(), (size_t)n);
@@ -1908,15 +1922,26 @@ extern "C" uint32_t HYPREDRV_LinearSolverSetup(HYPREDRV_t h)
    API_CATCH_SYNC
 }
 
+// ||b - A x||_2 (reference src/internal/linsys.c:2982-3067): the residual kernel on a work vector from the library's pool,
+// the ghost refresh of x under it on a row block
 static double residual_norm(hypredrv_struct *h)
 {
-   HYPRE_IJVector r = new_vector_like(h, 0.0);
-   HYPRE_ParVectorCopy(h->vec_b, r);
-   HYPRE_ParCSRMatrixMatvec(-1.0, h->mat_A, h->vec_x, 1.0, r);
-   double p = 0.0;
-   HYPRE_ParVectorInnerProd(r, r, &p);
-   HYPRE_IJVectorDestroy(r);
-   return std::sqrt(p);
+   hypre_IJMatrix_struct *A = h->mat_A;
+   const int              n = A->nloc;
+   h->vec_x->ensure_device();
+   h->vec_b->ensure_device();
+   DArray<double> r((size_t)std::max(n, 1)), xe;
+   double        *xin = h->vec_x->data();
+   if (A->A.ncols > n || h->vec_x->capacity < (size_t)A->A.ncols)
+   { // x has no room for the ghost tail: stage it
+      xe.alloc((size_t)std::max(A->A.ncols, 1));
+      copy(n, h->vec_x->data(), xe.data());
+      xin = xe.data();
+   }
+   residual(A->A, xin, h->vec_b->data(), r.data(), Comm::world().size > 1 ? &A->halo : nullptr);
+   dot(n, r.data(), r.data(), 0);
+   finalize(0, S_TMP);
+   return std::sqrt(read_scalar(S_TMP));
 }
 
 // reference src/HYPREDRV.c:3126-3338 -> hypredrv_SolverApply (src/internal/solver.c:627-693)

@@ -7,28 +7,37 @@
 
 namespace hda {
 
+struct HaloPlan; // hda_dist.h
+
+// Every product below takes an optional halo plan of its input vector (row-partitioned runs): the ghost tail of x
+// is then refreshed by the call itself and the transfer runs UNDER the product -- the rows' owned-column part is
+// computed while the ghost values travel on the communication stream, the ghost-column part is added afterwards
+// (SURVEY 2.4 C1).  With a plan, x must be writable up to [owned | ghosts].  halo == nullptr: x is used as it is.
+
 // ---- K1: CSR SpMV family (replaces HYPRE_ParCSRMatrixMatvec, reached from
 // src/internal/linsys.c:3031 and every PCG iteration via src/internal/solver.c:614).
 // y_out = alpha*A*x + beta*y_in   (y_in may alias y_out; beta==0 never reads y_in)
 void spmv(const DCsr &A, double alpha, const double *x, double beta, const double *y_in,
-          double *y_out);
+          double *y_out, const HaloPlan *halo = nullptr);
 // y = A*x and block partials of <y, w> into slot (fused dot, K9)
-void spmv_dot(const DCsr &A, const double *x, double *y, const double *w, int slot);
+void spmv_dot(const DCsr &A, const double *x, double *y, const double *w, int slot, const HaloPlan *halo = nullptr);
 // out = b - A*x
-void residual(const DCsr &A, const double *x, const double *b, double *out);
+void residual(const DCsr &A, const double *x, const double *b, double *out, const HaloPlan *halo = nullptr);
 
 // ---- K2: l1-Jacobi / weighted Jacobi sweep (hypre_BoomerAMGRelax types 18 / 0,7;
 // selected by src/internal/amg.c:183-186,360-375).  dinv = weight / l1 (or / a_ii).
 // x_out = x_in + dinv .* (b - A*x_in).  dot_slot >= 0 also emits partials of <b, x_out>.
 void jacobi(const DCsr &A, const double *dinv, const double *b, const double *x_in,
-            double *x_out, int dot_slot);
+            double *x_out, int dot_slot, const HaloPlan *halo = nullptr);
 // first sweep from a zero guess: x = dinv .* b
 void jacobi_zero_guess(int n, const double *dinv, const double *b, double *x);
 
 // ---- K9: fused BLAS-1 of the PCG recurrences (hypre_PCGSolve inner loop, reached from
 // solver_ops[SOLVER_PCG].solve src/internal/solver.c:211).
 enum Scalar : int {
-   S_GAMMA0 = 0, S_GAMMA1 = 1, S_SP = 2, S_RR = 3, S_BB = 4, S_TMP = 5, S_TMP2 = 6,
+   // PCG keeps <r,z> and <r,r> of an iteration side by side (pairs 0/1 and 2/3, alternating by iteration parity) so
+   // that one finalize_n + ONE two-double all-reduce serves both (C2 of SURVEY 2.4)
+   S_GAMMA0 = 0, S_RR0 = 1, S_GAMMA1 = 2, S_RR1 = 3, S_SP = 4, S_BB = 5, S_TMP = 6, S_TMP2 = 7,
    S_GMRES = 8 /* .. S_GMRES + krylov_dim + 1 */
 };
 void dot(int n, const double *x, const double *y, int slot);              // partials only
@@ -67,8 +76,12 @@ double matrix_stream_bytes(const DCsr &A, bool format);
 void spmv_prepare(const DCsr &A);
 // timing probe: bracket every launch of mode `mode` (0 plain, 1 residual, 2 Jacobi) on matrix A
 // with HIP events on the library stream; read returns the average launch duration
-void spmv_probe_set(const DCsr *A, int mode);
-void spmv_probe_read(double *avg_ms, int *count);
+void spmv_probe_set(const DCsr *A, int mode);   // clear, then arm one probe (A == nullptr: just clear)
+void spmv_probe_read(double *avg_ms, int *count); // probe 0
+// several probes at once (bench.py: dominant sweep, level-0 product, level-0 transfers)
+void spmv_probe_clear();
+int  spmv_probe_add(const DCsr *A, int mode);
+void spmv_probe_read(int id, double *avg_ms, int *count);
 void sort_rows(DCsr &A);                                    // column-sort every row in place
 void transpose(const DCsr &A, DCsr &T);                     // rows of T sorted
 // 7-pt Laplacian generator on device (examples/src/C_laplacian/laplacian.c:719-921),

@@ -8,7 +8,7 @@
 // fused into the kernel that already streams the operands.
 #include "hda_kernels.h"
 
-#include "hda_comm.h"
+#include "hda_dist.h"
 
 #include <algorithm>
 #include <cmath>
@@ -24,6 +24,15 @@ Context::Context()
 {
    HDA_HIP(hipGetDevice(&device));
    HDA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+   {
+      int lo = 0, hi = 0; // numerically lower = higher priority: the small transfer kernels should not queue behind product grids
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
+      if (hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, hi) != hipSuccess)
+      {
+         (void)hipGetLastError();
+         HDA_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+      }
+   }
    HDA_HIP(hipMalloc((void **)&partials, sizeof(double) * kNumSlots * kRedBlocks));
    HDA_HIP(hipMemset(partials, 0, sizeof(double) * kNumSlots * kRedBlocks));
    HDA_HIP(hipMalloc((void **)&scalars, sizeof(double) * kNumScalars));
@@ -360,7 +369,9 @@ static void ensure_plan(const DCsr &A)
 
 // VC: value-coded operator (see "value-coded SpMV" below) -- the 8-byte value stream is replaced by
 // one-byte codes into a 255-entry dictionary held in LDS; code 255 = read the value array
-template <int MODE, bool DOT, bool VC>
+// SPLIT: row-partitioned product overlapped with its halo exchange -- entries whose column is a ghost (>= nown)
+// contribute nothing here; k_offd_fix adds them once the ghost values have arrived
+template <int MODE, bool DOT, bool VC, bool SPLIT>
 __global__ __launch_bounds__(256) void k_spmv_stream(int nchunks, const int *__restrict__ chunk_row,
                                                      const int *__restrict__ rowptr, const int *__restrict__ col,
                                                      const double *__restrict__ val, const double *__restrict__ x,
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int nchunks, const int *__r
                                                      const double *__restrict__ b, const double *__restrict__ dinv,
                                                      const double *__restrict__ w, double *out,
                                                      double *__restrict__ partial, const unsigned char *__restrict__ code,
-                                                     const double *__restrict__ dval)
+                                                     const double *__restrict__ dval, int nown)
 {
    extern __shared__ double prod[];
    __shared__ double sdict[VC ? 256 : 1];
@@ -403,7 +414,13 @@ for (; k + 768 < k1; k += 1024)
          }
          else { v0 = val[k]; v1 = val[k + 256]; v2 = val[k + 512]; v3 = val[k + 768]; }
          const int    c0 = col[k], c1 = col[k + 256], c2 = col[k + 512], c3 = col[k + 768];
-         const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+         double x0, x1, x2, x3;
+         if (SPLIT)
+         {
+            x0 = (c0 < nown) ? x[c0] : 0.0; x1 = (c1 < nown) ? x[c1] : 0.0;
+            x2 = (c2 < nown) ? x[c2] : 0.0; x3 = (c3 < nown) ? x[c3] : 0.0;
+         }
+         else { x0 = x[c0]; x1 = x[c1]; x2 = x[c2]; x3 = x[c3]; }
          prod[k - k0]       = v0 * x0;
          prod[k - k0 + 256] = v1 * x1;
          prod[k - k0 + 512] = v2 * x2;
@@ -414,7 +431,8 @@ for (; k + 768 < k1; k += 1024)
          double vv;
          if (VC) { const int q0 = code[k]; vv = (q0 != 255) ? sdict[q0] : val[k]; }
          else vv = val[k];
-         prod[k - k0] = vv * x[col[k]];
+         const int cc = col[k];
+         prod[k - k0] = vv * ((!SPLIT || cc < nown) ? x[cc] : 0.0);
       }
       __syncthreads();
       // stage 2: L lanes per row, L = largest power of two with rows*L <= 256
@@ -452,7 +470,11 @@ for (; k + 768 < k1; k += 1024)
    if (DOT)
    {
       acc = block_sum(acc);
-      if (tid == 0) partial[blockIdx.x] = acc;
+      if (tid == 0)
+      {
+         partial[blockIdx.x] = acc;
+         if (blockIdx.x + gridDim.x < kRedBlocks) partial[blockIdx.x + gridDim.x] = 0.0; // reduced grid (>= kRedBlocks / 2)
+      }
    }
 }
 
@@ -635,13 +657,13 @@ __device__ __forceinline__ void coded_decode(CodedBatch &B, int r, int q, int e,
          if (B.cc[u] == 255) { B.j[u] = col[q + u]; B.v[u] = val[q + u]; }
    }
 }
-template <int MODE, bool DOT>
+template <int MODE, bool DOT, bool SPLIT>
 __global__ __launch_bounds__(256) void k_spmv_coded_row(int nrows, const int *__restrict__ rowptr, const unsigned char *__restrict__ code,
                                                         const double *__restrict__ dval, const int *__restrict__ ddelta,
                                                         const int *__restrict__ col, const double *__restrict__ val,
                                                         const double *__restrict__ x, double alpha, double beta, const double *yin,
                                                         const double *__restrict__ b, const double *__restrict__ dinv,
-                                                        const double *__restrict__ w, double *out, double *__restrict__ partial)
+                                                        const double *__restrict__ w, double *out, double *__restrict__ partial, int nown)
 {
    __shared__ double sv[256];
    __shared__ int    sd[256];
@@ -685,6 +707,14 @@ __global__ __launch_bounds__(256) void k_spmv_coded_row(int nrows, const int *__
          double xv[H][8];
 #pragma unroll
          for (int h = 0; h < H; h++) coded_decode(B[h], rr[h], q[h], e[h], cwords, sv, sd, col, val);
+         if (SPLIT)
+         { // ghost columns (always escapes: they have no fixed offset) wait for k_offd_fix
+#pragma unroll
+            for (int h = 0; h < H; h++)
+#pragma unroll
+               for (int u = 0; u < 8; u++)
+                  if (B[h].j[u] >= nown) { B[h].j[u] = 0; B[h].v[u] = 0.0; }
+         }
 #pragma unroll
          for (int h = 0; h < H; h++)
 #pragma unroll
@@ -724,10 +754,106 @@ __global__ __launch_bounds__(256) void k_spmv_coded_row(int nrows, const int *__
    if (DOT)
    {
       acc = block_sum(acc);
-      if (tid == 0) partial[blockIdx.x] = acc;
+      if (tid == 0)
+      {
+         partial[blockIdx.x] = acc;
+         if (blockIdx.x + gridDim.x < kRedBlocks) partial[blockIdx.x + gridDim.x] = 0.0;
+      }
    }
 }
 
+// ---- ghost-column part of a row-partitioned product ------------------------------------------------
+// The entries with ghost columns of the rows that have any ("boundary rows"), as a compressed-row list built
+// once per operator.  k_offd_fix runs after the halo exchange has landed and adds them to what the SPLIT
+// main kernel left: out_r (+)= the mode's linear function of sum_r = sum_k val_k * x_ghost[col_k]; fused dots
+// are linear in out, so their block partials get the matching correction (same slot, entries 0..grid-1).
+__global__ __launch_bounds__(256) void k_offd_count(int n, int nown, const int *__restrict__ rp, const int *__restrict__ cj, int *__restrict__ cnt,
+                                                    int *__restrict__ flag)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int c = 0;
+   for (int k = rp[i]; k < rp[i + 1]; k++) c += (cj[k] >= nown);
+   cnt[i]  = c;
+   flag[i] = c > 0;
+}
+__global__ __launch_bounds__(256) void k_offd_fill(int n, int nown, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                   const int *__restrict__ pos, const int *__restrict__ off, int *__restrict__ brow,
+                                                   int *__restrict__ orp, int *__restrict__ ocol, double *__restrict__ oval)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n || pos[i + 1] == pos[i]) return;
+   const int b = pos[i];
+   int       o = off[i];
+   brow[b]     = i;
+   orp[b]      = o;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (cj[k] >= nown) { ocol[o] = cj[k]; oval[o] = v[k]; o++; }
+}
+template <int MODE, bool DOT>
+__global__ __launch_bounds__(256) void k_offd_fix(int nb, const int *__restrict__ brow, const int *__restrict__ rp, const int *__restrict__ col,
+                                                  const double *__restrict__ val, const double *__restrict__ x, double alpha,
+                                                  const double *__restrict__ b, const double *__restrict__ dinv, const double *__restrict__ w,
+                                                  double *out, double *__restrict__ partial)
+{
+   double acc = 0.0;
+   for (int q = blockIdx.x * 256 + threadIdx.x; q < nb; q += gridDim.x * 256)
+   {
+      const int r   = brow[q];
+      double    sum = 0.0;
+      for (int k = rp[q]; k < rp[q + 1]; k++) sum += val[k] * x[col[k]];
+      if (MODE == MODE_PLAIN)
+      {
+         const double d = alpha * sum;
+         out[r] += d;
+         if (DOT) acc += d * w[r];
+      }
+      else if (MODE == MODE_RESID) out[r] -= sum;
+      else
+      {
+         const double d = dinv[r] * sum;
+         out[r] -= d;
+         if (DOT) acc -= b[r] * d;
+      }
+   }
+   if (DOT)
+   {
+      acc = block_sum(acc);
+      if (threadIdx.x == 0) partial[blockIdx.x] += acc;
+   }
+}
+
+static void ensure_offd(const DCsr &A, int nown)
+{
+   if (A.offd && A.offd->nown == nown) return;
+   auto        P = std::make_unique<OffdPart>();
+   const int   n = A.nrows;
+   DArray<int> cnt((size_t)n + 1), flag((size_t)n + 1), pos((size_t)n + 1), off((size_t)n + 1);
+   P->nown = nown;
+   if (n)
+   {
+      k_offd_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, nown, A.rowptr.data(), A.col.data(), cnt.data(), flag.data());
+      exclusive_scan(n, flag.data(), pos.data(), nullptr);
+      exclusive_scan(n, cnt.data(), off.data(), nullptr);
+      int tot[2] = {0, 0};
+      HDA_HIP(hipMemcpyAsync(&tot[0], pos.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+      HDA_HIP(hipMemcpyAsync(&tot[1], off.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+      Context::get().sync();
+      P->nbrows = tot[0];
+      P->nnz    = tot[1];
+      P->brow.alloc((size_t)std::max(P->nbrows, 1));
+      P->rp.alloc((size_t)P->nbrows + 1);
+      P->col.alloc((size_t)std::max(P->nnz, 1));
+      P->val.alloc((size_t)std::max(P->nnz, 1));
+      if (P->nbrows)
+         k_offd_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, nown, A.rowptr.data(), A.col.data(), A.val.data(), pos.data(), off.data(),
+                                                           P->brow.data(), P->rp.data(), P->col.data(), P->val.data());
+      HDA_HIP(hipMemcpyAsync(P->rp.data() + P->nbrows, &tot[1], 4, hipMemcpyHostToDevice, STREAM));
+      Context::get().sync();
+   }
+   else P->rp.alloc(1), P->rp.zero();
+   A.offd = std::move(P);
+}
 
 // ---- value-coded SpMV ----------------------------------------------------------------------
 // Interpolation operators of a constant-coefficient problem repeat their WEIGHTS even though the
@@ -858,34 +984,63 @@ static int spmv_mode()
    return m;
 }
 
-template <int MODE, bool DOT>
-static void launch_spmv_impl(const DCsr &A, const double *x, double alpha, double beta,
-                        const double *yin, const double *b, const double *dinv, const double *w,
-                        double *out, double *partial)
+// grid of a product that shares the chip with its own halo transfer: one workgroup slot per CU is left free
+// (7 of 8 resident 256-thread workgroups), or the transfer kernel would only start when the product ends
+static int overlap_grid()
 {
-   if (A.nrows == 0 && !DOT) return;
+   static const int g = [] {
+      const char *e = getenv("HDA_OVERLAP_GRID");
+      int         v = e ? atoi(e) : 1792;
+      v             = std::max(kRedBlocks / 2, std::min(kRedBlocks, v));
+      return v / 8 * 8;
+   }();
+   return g;
+}
+
+// nown < 0: the whole product.  nown >= 0: SPLIT -- entries with ghost columns (>= nown) are left to k_offd_fix
+template <int MODE, bool DOT>
+static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, double beta,
+                        const double *yin, const double *b, const double *dinv, const double *w,
+                        double *out, double *partial, int nown = -1)
+{
+   if (A.nrows == 0 && !DOT) return true;
    ensure_plan(A);
    ensure_coded(A);
+   const bool split = nown >= 0;
+   const int  gmax  = split ? overlap_grid() : kRedBlocks;
    if (A.coded == 1 && spmv_mode() == 0)
    {
       const int per  = (((A.nrows + 7) >> 3) + 255) / 256 * 256; // rows per XCD (as in the kernel)
-      const int grid = DOT ? kRedBlocks : std::min(kRedBlocks, 8 * (per / 256));
-      k_spmv_coded_row<MODE, DOT><<<grid, 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.code.data(), A.dict_val.data(), A.dict_delta.data(),
-                                                            A.col.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial);
-      return;
+      const int grid = DOT ? gmax : std::min(gmax, 8 * (per / 256));
+      if (split)
+         k_spmv_coded_row<MODE, DOT, true><<<grid, 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.code.data(), A.dict_val.data(), A.dict_delta.data(),
+                                                                     A.col.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown);
+      else
+         k_spmv_coded_row<MODE, DOT, false><<<grid, 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.code.data(), A.dict_val.data(), A.dict_delta.data(),
+                                                                      A.col.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, 0);
+      return true;
    }
    if (spmv_mode() == 0 && A.maxrow <= kMaxRowLds)
    {
-      const int    grid = DOT ? kRedBlocks : std::min(kRedBlocks, ((A.nchunks + 7) / 8) * 8);
+      const int    grid = DOT ? gmax : std::min(gmax, ((A.nchunks + 7) / 8) * 8);
       const size_t lds  = sizeof(double) * (size_t)(kChunk + A.maxrow);
+#define HDA_STREAM(VCF, SPF, CODE, DICT)                                                                                                  \
+   k_spmv_stream<MODE, DOT, VCF, SPF><<<grid, 256, lds, STREAM>>>(A.nchunks, A.chunk_row.data(), A.rowptr.data(), A.col.data(), A.val.data(), x, \
+                                                                  alpha, beta, yin, b, dinv, w, out, partial, CODE, DICT, nown)
       if (A.coded == 2)
-         k_spmv_stream<MODE, DOT, true><<<grid, 256, lds, STREAM>>>(A.nchunks, A.chunk_row.data(), A.rowptr.data(), A.col.data(), A.val.data(), x,
-                                                                    alpha, beta, yin, b, dinv, w, out, partial, A.code.data(), A.dict_val.data());
+      {
+         if (split) HDA_STREAM(true, true, A.code.data(), A.dict_val.data());
+         else HDA_STREAM(true, false, A.code.data(), A.dict_val.data());
+      }
       else
-         k_spmv_stream<MODE, DOT, false><<<grid, 256, lds, STREAM>>>(A.nchunks, A.chunk_row.data(), A.rowptr.data(), A.col.data(), A.val.data(), x,
-                                                                     alpha, beta, yin, b, dinv, w, out, partial, nullptr, nullptr);
-      return;
+      {
+         if (split) HDA_STREAM(false, true, nullptr, nullptr);
+         else HDA_STREAM(false, false, nullptr, nullptr);
+      }
+#undef HDA_STREAM
+      return true;
    }
+   if (split) return false; // the lane-group kernel (very long rows, HDA_SPMV=vector) has no split form: caller exchanges first
    const int lpr  = pick_lpr(A);
    long      need = ((long)A.nrows * lpr + 511) / 512; // two rows per group
    int       grid = DOT ? kRedBlocks : (int)std::min<long>(std::max<long>(need, 1), kRedBlocks);
@@ -902,6 +1057,49 @@ static void launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
       default: HDA_LAUNCH(64); break;
    }
 #undef HDA_LAUNCH
+   return true;
+}
+
+// HDA_OVERLAP=0: every ghost refresh completes before its product starts (the path the overlapped one is tested against)
+static bool overlap_enabled()
+{
+   static const bool on = !(getenv("HDA_OVERLAP") && atoi(getenv("HDA_OVERLAP")) == 0);
+   return on;
+}
+
+// Row-partitioned product with the ghost refresh of x under it (SURVEY 2.4 C1 "overlapped with the diag-block SpMV"):
+//   pack the send buffer | rows' owned-column part (SPLIT kernel) || transfer on the communication stream | ghost-column part
+// halo == nullptr or a one-rank run: the plain product.
+template <int MODE, bool DOT>
+static void launch_spmv_halo(const DCsr &A, const HaloPlan *halo, double *x, double alpha, double beta, const double *yin, const double *b,
+                             const double *dinv, const double *w, double *out, double *partial)
+{
+   const bool active = halo && halo_active(*halo);
+   if (active && overlap_enabled() && !(MODE == MODE_PLAIN && beta != 0.0 && out == x))
+   {
+      ensure_plan(A);
+      ensure_coded(A);
+      const bool splittable = spmv_mode() == 0 && (A.coded == 1 || A.maxrow <= kMaxRowLds);
+      if (splittable)
+      {
+         ensure_offd(A, halo->nloc);
+         const OffdPart &O = *A.offd;
+         halo_pack(*halo, x);
+         launch_spmv_impl<MODE, DOT>(A, x, alpha, beta, yin, b, dinv, w, out, partial, halo->nloc);
+         halo_transfer(*halo, x); // waits for the pack only; RCCL: enqueued, runs beside the kernel above; staged: host-side while it runs
+         halo_wait(*halo);
+         if (O.nbrows)
+         {
+            const int g = std::min(ceil_div(O.nbrows, 256), DOT ? kRedBlocks / 2 : 4096);
+            k_offd_fix<MODE, DOT><<<g, 256, 0, STREAM>>>(O.nbrows, O.brow.data(), O.rp.data(), O.col.data(), O.val.data(), x, alpha, b, dinv, w, out,
+                                                         partial);
+         }
+         Comm::world().stats.overlapped++;
+         return;
+      }
+   }
+   if (active) halo_exchange(*halo, x);
+   launch_spmv_impl<MODE, DOT>(A, x, alpha, beta, yin, b, dinv, w, out, partial);
 }
 
 namespace {
@@ -909,7 +1107,8 @@ struct SpmvProbe {
    const DCsr             *A    = nullptr;
    int                     mode = -1;
    std::vector<hipEvent_t> evs;
-} g_probe;
+};
+std::vector<SpmvProbe> g_probes;
 } // namespace
 void spmv_prepare(const DCsr &A)
 {
@@ -917,26 +1116,43 @@ void spmv_prepare(const DCsr &A)
    ensure_plan(A);
    ensure_coded(A);
 }
+void spmv_probe_clear()
+{
+   for (SpmvProbe &p : g_probes)
+      for (hipEvent_t e : p.evs) (void)hipEventDestroy(e);
+   g_probes.clear();
+}
+int spmv_probe_add(const DCsr *A, int mode)
+{
+   SpmvProbe p;
+   p.A    = A;
+   p.mode = mode;
+   g_probes.push_back(p);
+   return (int)g_probes.size() - 1;
+}
 void spmv_probe_set(const DCsr *A, int mode)
 {
-   for (hipEvent_t e : g_probe.evs) (void)hipEventDestroy(e);
-   g_probe.evs.clear();
-   g_probe.A    = A;
-   g_probe.mode = mode;
+   spmv_probe_clear();
+   if (A) spmv_probe_add(A, mode);
 }
-void spmv_probe_read(double *avg_ms, int *count)
+void spmv_probe_read(int id, double *avg_ms, int *count)
 {
    Context::get().sync();
    double s = 0.0;
    int    c = 0;
-   for (size_t e = 0; e + 1 < g_probe.evs.size(); e += 2)
+   if (id >= 0 && id < (int)g_probes.size())
    {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, g_probe.evs[e], g_probe.evs[e + 1]) == hipSuccess) { s += ms; c++; }
+      const SpmvProbe &p = g_probes[(size_t)id];
+      for (size_t e = 0; e + 1 < p.evs.size(); e += 2)
+      {
+         float ms = 0.f;
+         if (hipEventElapsedTime(&ms, p.evs[e], p.evs[e + 1]) == hipSuccess) { s += ms; c++; }
+      }
    }
    if (avg_ms) *avg_ms = c ? s / c : 0.0;
    if (count) *count = c;
 }
+void spmv_probe_read(double *avg_ms, int *count) { spmv_probe_read(0, avg_ms, count); }
 double matrix_stream_bytes(const DCsr &A, bool format)
 {
    if (format)
@@ -950,42 +1166,44 @@ double matrix_stream_bytes(const DCsr &A, bool format)
 }
 
 template <int MODE, bool DOT>
-static void launch_spmv(const DCsr &A, const double *x, double alpha, double beta, const double *yin, const double *b, const double *dinv,
-                        const double *w, double *out, double *partial)
+static void launch_spmv(const DCsr &A, const HaloPlan *halo, const double *x, double alpha, double beta, const double *yin, const double *b,
+                        const double *dinv, const double *w, double *out, double *partial)
 {
-   if (g_probe.A == &A && g_probe.mode == MODE && g_probe.evs.size() < 4096)
-   {
-      hipEvent_t e0, e1;
-      HDA_HIP(hipEventCreate(&e0));
-      HDA_HIP(hipEventCreate(&e1));
-      HDA_HIP(hipEventRecord(e0, STREAM));
-      launch_spmv_impl<MODE, DOT>(A, x, alpha, beta, yin, b, dinv, w, out, partial);
-      HDA_HIP(hipEventRecord(e1, STREAM));
-      g_probe.evs.push_back(e0);
-      g_probe.evs.push_back(e1);
-      return;
-   }
-   launch_spmv_impl<MODE, DOT>(A, x, alpha, beta, yin, b, dinv, w, out, partial);
+   double *xw = const_cast<double *>(x); // with a halo plan the ghost tail of x is refreshed (callers pass writable vectors there)
+   for (SpmvProbe &p : g_probes)
+      if (p.A == &A && p.mode == MODE && p.evs.size() < 8192)
+      {
+         hipEvent_t e0, e1;
+         HDA_HIP(hipEventCreate(&e0));
+         HDA_HIP(hipEventCreate(&e1));
+         HDA_HIP(hipEventRecord(e0, STREAM));
+         launch_spmv_halo<MODE, DOT>(A, halo, xw, alpha, beta, yin, b, dinv, w, out, partial);
+         HDA_HIP(hipEventRecord(e1, STREAM));
+         p.evs.push_back(e0);
+         p.evs.push_back(e1);
+         return;
+      }
+   launch_spmv_halo<MODE, DOT>(A, halo, xw, alpha, beta, yin, b, dinv, w, out, partial);
 }
 
-void spmv(const DCsr &A, double alpha, const double *x, double beta, const double *y_in, double *y_out)
+void spmv(const DCsr &A, double alpha, const double *x, double beta, const double *y_in, double *y_out, const HaloPlan *halo)
 {
-   launch_spmv<MODE_PLAIN, false>(A, x, alpha, beta, y_in, nullptr, nullptr, nullptr, y_out, nullptr);
+   launch_spmv<MODE_PLAIN, false>(A, halo, x, alpha, beta, y_in, nullptr, nullptr, nullptr, y_out, nullptr);
 }
-void spmv_dot(const DCsr &A, const double *x, double *y, const double *w, int slot)
+void spmv_dot(const DCsr &A, const double *x, double *y, const double *w, int slot, const HaloPlan *halo)
 {
-   launch_spmv<MODE_PLAIN, true>(A, x, 1.0, 0.0, nullptr, nullptr, nullptr, w, y, Context::get().slot(slot));
+   launch_spmv<MODE_PLAIN, true>(A, halo, x, 1.0, 0.0, nullptr, nullptr, nullptr, w, y, Context::get().slot(slot));
 }
-void residual(const DCsr &A, const double *x, const double *b, double *out)
+void residual(const DCsr &A, const double *x, const double *b, double *out, const HaloPlan *halo)
 {
-   launch_spmv<MODE_RESID, false>(A, x, 1.0, 0.0, nullptr, b, nullptr, nullptr, out, nullptr);
+   launch_spmv<MODE_RESID, false>(A, halo, x, 1.0, 0.0, nullptr, b, nullptr, nullptr, out, nullptr);
 }
-void jacobi(const DCsr &A, const double *dinv, const double *b, const double *x_in, double *x_out, int dot_slot)
+void jacobi(const DCsr &A, const double *dinv, const double *b, const double *x_in, double *x_out, int dot_slot, const HaloPlan *halo)
 {
    if (dot_slot >= 0)
-      launch_spmv<MODE_JACOBI, true>(A, x_in, 1.0, 0.0, nullptr, b, dinv, nullptr, x_out, Context::get().slot(dot_slot));
+      launch_spmv<MODE_JACOBI, true>(A, halo, x_in, 1.0, 0.0, nullptr, b, dinv, nullptr, x_out, Context::get().slot(dot_slot));
    else
-      launch_spmv<MODE_JACOBI, false>(A, x_in, 1.0, 0.0, nullptr, b, dinv, nullptr, x_out, nullptr);
+      launch_spmv<MODE_JACOBI, false>(A, halo, x_in, 1.0, 0.0, nullptr, b, dinv, nullptr, x_out, nullptr);
 }
 
 // ------------------------------------------------------------------ BLAS-1

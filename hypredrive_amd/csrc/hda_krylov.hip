@@ -26,7 +26,6 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
    KrylovResult res;
    const size_t vl = std::max<size_t>(op.veclen, 1);
    DArray<double> r(vl), p(vl), s(vl);
-   auto refresh = [&](double *v) { if (op.halo) halo_exchange(*op.halo, v); };
 
    auto precond = [&](const double *rr, double *zz, int slot) {
       res.precond_calls++;
@@ -65,46 +64,45 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
    }
    // r = b - A x ; p = C r ; gamma = <r,p>   (x has no ghost tail: stage it through p)
    copy(n, x, p.data());
-   refresh(p.data());
-   residual(A, p.data(), b, r.data());
+   residual(A, p.data(), b, r.data(), op.halo);
    precond(r.data(), p.data(), 2);
-   finalize(2, S_GAMMA0);
-   dot(n, r.data(), r.data(), 1);
-   finalize(1, S_RR);
-   read_scalars_async(S_GAMMA0, 4); // gamma0, gamma1, sp, rr
+   dot(n, r.data(), r.data(), 3);
+   finalize_n(2, 2, S_GAMMA0); // <r,z> -> S_GAMMA0, <r,r> -> S_RR0: one kernel, one all-reduce of two doubles
+   read_scalars_async(S_GAMMA0, 5);
    HDA_HIP(hipEventSynchronize(ctx.ev));
-   double i_prod = kp.two_norm ? ctx.host_scalars[S_RR] : ctx.host_scalars[S_GAMMA0];
+   double i_prod = kp.two_norm ? ctx.host_scalars[S_RR0] : ctx.host_scalars[S_GAMMA0];
    res.hist.push_back(std::sqrt(std::fabs(i_prod)));
    int it = 0;
    std::vector<hipEvent_t> evs;
+   // HDA_FUSE_DOTS=0: every inner product gets its own all-reduce (the unfused path the fused one is tested against)
+   static const bool fuse_dots = !(getenv("HDA_FUSE_DOTS") && atoi(getenv("HDA_FUSE_DOTS")) == 0);
    while (it + 1 <= kp.max_iter)
    {
       it++;
-      const int go = S_GAMMA0 + ((it - 1) & 1), gn = S_GAMMA0 + (it & 1);
-      refresh(p.data());
+      const int go = (it & 1) ? S_GAMMA0 : S_GAMMA1, gn = (it & 1) ? S_GAMMA1 : S_GAMMA0, rn = gn + 1;
       if (kp.profile_k1)
       {
          hipEvent_t e0, e1;
          HDA_HIP(hipEventCreate(&e0));
          HDA_HIP(hipEventCreate(&e1));
          HDA_HIP(hipEventRecord(e0, ctx.stream));
-         spmv_dot(A, p.data(), s.data(), p.data(), 0);
+         spmv_dot(A, p.data(), s.data(), p.data(), 0, op.halo); // row blocks: the ghost refresh of p runs under the product
          HDA_HIP(hipEventRecord(e1, ctx.stream));
          evs.push_back(e0);
          evs.push_back(e1);
       }
       else
-      spmv_dot(A, p.data(), s.data(), p.data(), 0);
+         spmv_dot(A, p.data(), s.data(), p.data(), 0, op.halo);
       finalize(0, S_SP);
-      cg_update(n, go, p.data(), s.data(), x, r.data(), 1);
-      finalize(1, S_RR);
-      read_scalars_async(S_GAMMA0, 4);
+      cg_update(n, go, p.data(), s.data(), x, r.data(), 3);
       // The stopping test of the two-norm variant needs only <r,r>.  hypre applies the preconditioner
       // before testing, so its last V-cycle is computed and thrown away; here, once the history says the
       // tolerance is within reach, the host waits for <r,r> BEFORE enqueueing that V-cycle and skips it
       // on convergence (same x, same iteration count, same history).  Far from convergence the
-      // V-cycle is enqueued first so the device never waits for the host.
-      bool tested = false, stop = false;
+      // V-cycle is enqueued first so the device never waits for the host, and <r,r> rides with <r,z> in
+      // one finalize kernel and one two-double all-reduce (row partitions: 2 all-reduces per iteration
+      // instead of 3).
+      bool stop = false;
       auto test = [&]() {
          HDA_HIP(hipEventSynchronize(ctx.ev));
          const double sp = ctx.host_scalars[S_SP];
@@ -114,7 +112,7 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
             stop = true;
             return;
          }
-         i_prod = kp.two_norm ? ctx.host_scalars[S_RR] : read_scalar(gn);
+         i_prod = kp.two_norm ? ctx.host_scalars[rn] : ctx.host_scalars[gn];
          res.hist.push_back(std::sqrt(std::fabs(i_prod)));
          if (kp.print_level >= 2)
             printf("%5d    %e    %f    %e\n", it, res.hist.back(),
@@ -126,25 +124,32 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
             stop          = true;
          }
       };
+      bool near = false;
       if (kp.two_norm && res.hist.size() >= 2)
       { // predicted <r,r> of this iteration from the last reduction factor, with a margin of 16
          const double h1 = res.hist.back(), h0 = res.hist[res.hist.size() - 2];
          const double rho2 = (h0 > 0.0) ? (h1 / h0) * (h1 / h0) : 1.0;
-         if (h1 * h1 * rho2 < 16.0 * eps * bi_prod)
-         {
-            test();
-            tested = true;
-            if (stop) break;
-         }
+         near = h1 * h1 * rho2 < 16.0 * eps * bi_prod;
       }
-      precond(r.data(), s.data(), 2);
-      finalize(2, gn);
-      cg_direction(n, go, gn, s.data(), p.data());
-      if (!tested)
+      if (near)
       {
+         finalize(3, rn);
+         read_scalars_async(S_GAMMA0, 5);
          test();
          if (stop) break;
+         precond(r.data(), s.data(), 2);
+         finalize(2, gn);
+         cg_direction(n, go, gn, s.data(), p.data());
+         continue;
       }
+      if (!fuse_dots) finalize(3, rn);
+      precond(r.data(), s.data(), 2);
+      if (fuse_dots) finalize_n(2, 2, gn);
+      else finalize(2, gn);
+      read_scalars_async(S_GAMMA0, 5);
+      cg_direction(n, go, gn, s.data(), p.data());
+      test();
+      if (stop) break;
    }
    ctx.sync();
    for (size_t e = 0; e + 1 < evs.size(); e += 2)

@@ -23,12 +23,27 @@ def env_rank():
 def _make_callbacks(dist, torch, rank, world):
     from . import hypredrv as hd
 
+    def guarded(fn):
+        # ctypes prints and swallows an exception raised inside a callback; the C side would then carry on with
+        # unfilled buffers.  Record it and hand the library a non-zero code instead: it raises hda::Error there.
+        def wrapper(*a):
+            try:
+                fn(*a)
+                return 0
+            except BaseException as e:  # noqa: BLE001 - anything here must reach the C caller as a failure
+                _keep["callback_error"] = e
+                print(f"[hypredrive_amd] rank {rank}: staged-transport callback failed: {e!r}", file=sys.stderr, flush=True)
+                return 1
+        return wrapper
+
+    @guarded
     def allreduce(buf, count, dtype, op):
         ct = C.c_double if dtype == 0 else C.c_int64
         arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(ct)), shape=(count,))
         t = torch.from_numpy(arr)
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
 
+    @guarded
     def alltoallv(send, sbytes, recv, rbytes):
         sb = [sbytes[p] for p in range(world)]
         rb = [rbytes[p] for p in range(world)]

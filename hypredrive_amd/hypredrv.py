@@ -26,8 +26,9 @@ ERROR_INVALID_VAL = 0x00000200
 ERROR_UNKNOWN = 0x80000000
 MPI_COMM_WORLD = 0x44000000
 
-ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_int, C.c_int)
-ALLTOALLV_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.POINTER(C.c_long))
+# staged-transport callbacks (include/HYPREDRV.h): return 0 on success, non-zero makes the library raise on this rank
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int)
+ALLTOALLV_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.POINTER(C.c_long))
 
 
 def lib():

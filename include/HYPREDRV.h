@@ -142,6 +142,16 @@ HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_CommGetUniqueId(void *unique_id_128
 HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_CommInit(int rank, int world_size, int local_device,
                                                       const void *unique_id_128);
 HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_CommFinalize(void);
+/* Second transport for launchers without one GPU per rank (several ranks sharing a device in tests, gloo-only
+ * hosts): the same messages staged through two host callbacks the launcher implements on whatever it has
+ * (torch.distributed gloo in hypredrive_amd/dist.py, MPI in a C driver).  Both return 0 on success; any other
+ * value raises an error on the calling rank.  allreduce: in place, count elements, dtype 0 = double / 1 = int64,
+ * op 0 = sum / 1 = max.  alltoallv: buffers packed by ascending peer rank, counts in BYTES, arrays of world_size. */
+typedef int (*HYPREDRV_AMD_AllreduceFn)(void *buf, long count, int dtype, int op);
+typedef int (*HYPREDRV_AMD_AlltoallvFn)(const void *send, const long *send_bytes, void *recv, const long *recv_bytes);
+HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_CommInitCallbacks(int rank, int world_size, int local_device,
+                                                               HYPREDRV_AMD_AllreduceFn allreduce,
+                                                               HYPREDRV_AMD_AlltoallvFn alltoallv);
 /* Build the benchmark system of examples/src/C_laplacian/laplacian.c:719-921 directly in HBM
  * (block pc of a P0 x P1 x P2 partition of an n0 x n1 x n2 grid) and attach it as
  * matrix + rhs of the object, as LinearSystemSetMatrix/SetRHS would. */

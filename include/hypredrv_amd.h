@@ -186,6 +186,21 @@ int hda_format_bytes(hda_csr_t A, hda_amg_t amg, double *pcg_iteration, double *
  * hda_probe_read synchronises and returns the average launch duration.  A = NULL disarms. */
 int hda_probe_spmv(hda_csr_t A, int mode);
 int hda_probe_read(double *avg_ms, int *count);
+/* Several probes at once (bench.py: dominant sweep, level-0 product, level-0 transfer operators): add returns the
+ * probe's id; hda_probe_spmv(NULL, 0) clears them all. */
+int hda_probe_add(hda_csr_t A, int mode, int *id);
+int hda_probe_read_id(int id, double *avg_ms, int *count);
+/* Borrowed seam views of a HYPREDRV_t whose solver is set up (include/HYPREDRV.h): its level-0 operator -- with the
+ * device right-hand side and, on a row block, the ghost refresh plan -- and its BoomerAMG hierarchy, so that the
+ * measurement entries above run on the very objects HYPREDRV_LinearSolverSetup built.  Valid until
+ * HYPREDRV_LinearSolverDestroy; release the views with hda_csr_destroy / hda_amg_destroy. */
+int hda_borrow_hypredrv(void *hypredrv, hda_csr_t *A, hda_amg_t *amg);
+/* rank-to-rank traffic of the solve path since the last reset: [0] device all-reduces, [1] halo exchanges (grouped
+ * neighbour send/recv), [2] doubles all-reduced, [3] doubles sent in halo exchanges, [4] exchanges that ran under a
+ * product kernel (interior rows computed while the ghost values travel) */
+int hda_comm_stats(double out[5], int reset);
+const char *hda_comm_name(void); /* "self", "rccl", "host-callbacks" */
+int         hda_comm_size(void);
 /* Exercises the active rank-to-rank transport (RCCL, staged callbacks or self): device
  * all-reduce, host all-reduce, host all-to-all.  Returns 0 when every result is right. */
 int hda_comm_selftest(void);

@@ -80,7 +80,15 @@ def mode_solve(out, n, solver):
     yaml = f"solver: {solver}\npreconditioner:\n  preset: poisson\n"
     h = hd.Hypredrv(yaml)
     h.set_laplacian7((n, n, n), P)
-    r = h.solve()
+    # rank-to-rank operations of the solve alone (Setup's are not counted): Create + Setup, reset the counters, Apply
+    hd.check(hd.lib().HYPREDRV_LinearSystemResetInitialGuess(h.h))
+    h.create_and_setup()
+    from hypredrive_amd import _lib
+    _lib.comm_stats(reset=True)
+    r = h.apply(reset=False)
+    cs = _lib.comm_stats()
+    vcycles = _lib.load().hda_last_precond_calls()
+    h.destroy_solver()
     x = h.solution()
     nrm = h.solution_norm("L2")
     l1 = h.solution_norm("L1")
@@ -88,7 +96,7 @@ def mode_solve(out, n, solver):
     np.save(f"{out}.x{rank}.npy", x)
     if rank == 0:
         json.dump({"iters": r["iters"], "converged": r["converged"], "final_rel": r["final_rel"], "norm": nrm,
-                   "l1": l1, "linf": linf, "world": world, "P": P}, open(out, "w"))
+                   "l1": l1, "linf": linf, "world": world, "P": P, "comm": cs, "vcycles": vcycles}, open(out, "w"))
     h.close()
     hdist.finalize()
 

@@ -203,6 +203,45 @@ def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solve
     assert np.linalg.norm(x) == pytest.approx(res["norm"], rel=1e-12)
 
 
+def _dist_solve(tmp_path, tag, world, n, port, **envx):
+    out = str(tmp_path / f"{tag}.json")
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_DIST_CHECK="0", **envx)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "solve", out, str(n), "pcg"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    return json.load(open(out)), np.concatenate([np.load(f"{out}.x{k}.npy") for k in range(world)])
+
+
+def test_fused_dot_allreduce_is_bitwise_the_unfused_one(tmp_path):
+    """C2 of SURVEY 2.4: <r,r> and <r,z> of a PCG iteration travel in ONE two-double all-reduce while the stopping
+    test is far away.  Same finalize kernel per slot, elementwise sum: on two ranks (a + b = b + a) the iterate is
+    bit-for-bit that of the path with one all-reduce per inner product (HDA_FUSE_DOTS=0)."""
+    a, xa = _dist_solve(tmp_path, "fused", 2, 24, 29671, HDA_REPLICATE_ROWS="300", HDA_OVERLAP="0")
+    b, xb = _dist_solve(tmp_path, "unfused", 2, 24, 29672, HDA_REPLICATE_ROWS="300", HDA_OVERLAP="0", HDA_FUSE_DOTS="0")
+    assert a["iters"] == b["iters"] and a["final_rel"] == b["final_rel"]
+    assert np.array_equal(xa, xb)
+    # all-reduces of the solve: <b,b>; <r0,z0> + <r0,r0>; per iteration <s,p> and the fused pair (the last iterations,
+    # tested before their V-cycle, keep three); one per V-cycle for the restricted residual of the replicated tail
+    it, vc = a["iters"], a["vcycles"]
+    assert a["comm"]["allreduce"] < b["comm"]["allreduce"]
+    assert a["comm"]["allreduce"] <= 2 + 3 * it + vc and b["comm"]["allreduce"] >= 3 * it + vc
+    assert a["comm"]["allreduce"] - (2 + 2 * it + vc) <= 4   # at most a few iterations near convergence are unfused
+
+
+def test_overlapped_halo_exchange_matches_the_serial_one(tmp_path):
+    """C1 of SURVEY 2.4: every product of the cycle and the PCG product start on the rows' owned columns while the ghost
+    values travel on the communication stream; the ghost-column part is added afterwards (k_offd_fix).  Against the
+    path that finishes every exchange first (HDA_OVERLAP=0): same iteration count, solution to rounding (the row sums
+    are split in two), and every exchange of the solve was an overlapped one."""
+    a, xa = _dist_solve(tmp_path, "ovl", 4, 24, 29673, HDA_REPLICATE_ROWS="700")
+    b, xb = _dist_solve(tmp_path, "ser", 4, 24, 29674, HDA_REPLICATE_ROWS="700", HDA_OVERLAP="0")
+    assert a["iters"] == b["iters"]
+    assert np.linalg.norm(xa - xb) <= 1e-12 * np.linalg.norm(xb)
+    assert a["comm"]["exchange"] == b["comm"]["exchange"] > 0
+    assert b["comm"]["overlapped"] == 0 and a["comm"]["overlapped"] >= a["comm"]["exchange"] - 2  # (untimed r0 / final residual products)
+
+
 @pytest.mark.parametrize("world,n,rep_rows,setup,port", [(4, 24, 700, "partitioned", 29655), (2, 20, 300, "partitioned", 29656),
                                                         (4, 24, 700, "replicated", 29657), (2, 32, 0, "partitioned", 29658)])
 def test_row_partitioned_with_renumbered_blocks(hd, tmp_path, world, n, rep_rows, setup, port):
