@@ -101,7 +101,12 @@ struct AmgLevel {
 
 class Amg {
  public:
-   explicit Amg(const AmgParams &p) : prm(p) {}
+   explicit Amg(const AmgParams &p) : prm(p)
+   { // relax type 89 ("l1sym-hgs", reference src/internal/amg.c:375) is hypre's second name for the symmetric hybrid l1
+     // Gauss-Seidel sweep (forward, then backward), type 8 here
+      for (int *t : {&prm.relax_down, &prm.relax_up, &prm.relax_coarse})
+         if (*t == 89) *t = 8;
+   }
    // systems AMG (prm.num_functions > 1): function of every level-0 unknown of the matrix handed to
    // setup() (for setup_dist: of this rank's rows); empty = (dof_row_offset + i) mod num_functions
    std::vector<int> dof_func0;

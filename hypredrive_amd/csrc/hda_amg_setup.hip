@@ -1774,7 +1774,10 @@ __global__ __launch_bounds__(256) void k_coarse_dof(int n, const int *__restrict
 void Amg::build_hierarchy(const DCsr &A)
 {
    HDA_REQUIRE(prm.coarsen_type == 8 || prm.coarsen_type == 10, "device AMG setup implements PMIS (8) and, on one rank, HMIS (10) coarsening");
-   HDA_REQUIRE(prm.interp_type == 6, "device AMG setup implements extended+i interpolation (type 6) only");
+   // 17 = "mm-ext+i" (reference src/internal/amg.c:266-268): hypre's matrix-matrix formulation of the SAME extended+i operator
+   // (its GPU interpolation); one algorithm serves both names here
+   HDA_REQUIRE(prm.interp_type == 6 || prm.interp_type == 17,
+               "interpolation type is not implemented on MI355X: extended+i (6) and its matrix-matrix form mm-ext+i (17) are");
    auto known = [](int t) { return is_jacobi_type(t) || is_gs_type(t) || t == 16; };
    HDA_REQUIRE(known(prm.relax_down) && known(prm.relax_up),
                "device V-cycle implements Jacobi (0, 7, 18), hybrid Gauss-Seidel (3, 4, 6, 8, 13, 14) and Chebyshev (16) smoothers");
@@ -3269,7 +3272,8 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
                                  const std::vector<long long> &ghost_gids0)
 {
    Comm &cm = Comm::world();
-   HDA_REQUIRE(prm.coarsen_type == 8 && prm.interp_type == 6 && prm.num_functions <= 1, "partitioned setup: scalar PMIS + extended+i only");
+   HDA_REQUIRE(prm.coarsen_type == 8 && (prm.interp_type == 6 || prm.interp_type == 17) && prm.num_functions <= 1,
+               "partitioned setup: scalar PMIS + extended+i only");
    static const long long rep_rows = getenv("HDA_REPLICATE_ROWS") ? atoll(getenv("HDA_REPLICATE_ROWS")) : 100000;
    const bool verbose = getenv("HDA_VERBOSE") != nullptr;
    auto tick = [&]() {

@@ -1337,8 +1337,8 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
    HDA_REQUIRE(s && s->kind == HDA_SOLVER_MGR, "MGRSetup: not an MGR handle");
    HDA_REQUIRE(A && A->assembled, "MGRSetup needs an assembled matrix");
    HDA_REQUIRE(s->mgr_levels > 0 && s->mgr_marker, "MGRSetup: no C points were set (HYPRE_MGRSetCpointsByPointMarkerArray)");
-   HDA_REQUIRE(s->mgr_cycle == 1, "MGR: only V-cycles (cycle 1) are implemented");
-   HDA_REQUIRE(s->mgr_frelax_cycle == 1 && s->mgr_gsmooth_cycle == 1, "MGR: only pre-smoothing (cycle_smooth_pos 1) is implemented");
+   HDA_REQUIRE(s->mgr_cycle == 1, "MGR: W-cycles (cycle: w) are not implemented on MI355X, only V-cycles");
+   HDA_REQUIRE(s->mgr_frelax_cycle == 1 && s->mgr_gsmooth_cycle == 1, "MGR: post-smoothing (cycle: v(0,1) / v(1,1)) is not implemented on MI355X, only pre-smoothing v(1,0)");
    HDA_REQUIRE(s->mgr_coarse_th == 0.0, "MGR: coarse_th (coarse grid truncation) is not implemented");
    HDA_REQUIRE(!s->mgr_csolver || s->mgr_csolver->kind == HDA_SOLVER_AMG || s->mgr_csolver->kind == HDA_SOLVER_ILU,
                "MGR coarsest_level: BoomerAMG and ILU are implemented");

@@ -1515,8 +1515,8 @@ static uint32_t mgr_create(hypredrv_struct *h, const MgrArgs &a)
    HYPRE_MGRSetTol(p, a.tolerance);
    HYPRE_MGRSetPrintLevel(p, a.print_level);
    HYPRE_MGRSetCycleType(p, a.cycle);
-   HYPRE_MGRSetFRelaxCycle(p, 1);
-   HYPRE_MGRSetGlobalSmoothCycle(p, 1);
+   HYPRE_MGRSetFRelaxCycle(p, a.cycle_smooth_pos); // reference src/internal/mgr.c:3792-3794
+   HYPRE_MGRSetGlobalSmoothCycle(p, a.cycle_smooth_pos);
    HYPRE_MGRSetTruncateCoarseGridThreshold(p, a.coarse_th);
    HYPRE_MGRSetRelaxType(p, a.relax_type);
    HYPRE_MGRSetLevelFRelaxType(p, frelax.data());

@@ -152,6 +152,26 @@ uint32_t yaml_parse(const std::string &text, YNode &root, std::string &message)
          content = trim(content.substr(1));
          if (content.empty()) continue;
          if (content.front() == '{') { parse_flow(*item, content); continue; }
+         // scalar item: "- file.yml", "- [0, 2]", "- \"quoted: text\"" (a list-valued include, a sequence of
+         // flow lists).  A ':' inside brackets or quotes does not make it a mapping.
+         {
+            bool   mapping = false;
+            int    depth   = 0;
+            char   quote   = 0;
+            for (char ch : content)
+            {
+               if (quote) { if (ch == quote) quote = 0; continue; }
+               if (ch == '"' || ch == '\'') quote = ch;
+               else if (ch == '[' || ch == '{') depth++;
+               else if (ch == ']' || ch == '}') depth--;
+               else if (ch == ':' && depth == 0) { mapping = true; break; }
+            }
+            if (!mapping)
+            {
+               item->val = unquote(content); // case kept: it may be a file name
+               continue;
+            }
+         }
          parent = item;
          level  = level + 1;
       }
@@ -185,6 +205,7 @@ static void print_node(const YNode &n, int indent, FILE *out)
 {
    if (n.seq_item)
    {
+      if (n.kids.empty() && !n.val.empty()) { fprintf(out, "%*s- %s\n", indent, "", n.val.c_str()); return; }
       bool first = true;
       for (auto &k : n.kids)
       {
@@ -349,6 +370,44 @@ static uint32_t expand_includes_rec(YNode &node, const std::string &base_dir, st
          i--;
          continue;
       }
+      if (k.key == "include" && k.val.empty() && !k.kids.empty())
+      { // list-valued include (reference src/internal/yaml.c:1863-2003): the top-level entries of every listed file become ONE
+        // sequence item appended to this node -- "amg: include: [a.yml, b.yml]" makes two preconditioner variants
+         std::vector<std::string> paths;
+         for (auto &q : k.kids)
+            if (q->seq_item && q->kids.empty() && !q->val.empty()) paths.push_back(q->val);
+            else { message = "include: expected a list of file names"; return ERR_YAML_TREE_INVALID; }
+         node.kids.erase(node.kids.begin() + (long)i);
+         for (const std::string &rel : paths)
+         {
+            std::string path = rel;
+            if (path[0] != '/' && !base_dir.empty()) path = base_dir + "/" + path;
+            if (stack.size() >= 10) { message = "YAML include depth exceeded max depth 10"; return ERR_YAML_TREE_INVALID; }
+            if (std::find(stack.begin(), stack.end(), path) != stack.end()) { message = "YAML include cycle detected at '" + path + "'"; return ERR_YAML_TREE_INVALID; }
+            FILE *f = fopen(path.c_str(), "r");
+            if (!f) { message = "cannot open included YAML file '" + path + "'"; return ERR_FILE_NOT_FOUND; }
+            std::string text;
+            char        buf[4096];
+            size_t      n;
+            while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+            fclose(f);
+            YNode    sub;
+            uint32_t e = yaml_parse(text, sub, message);
+            if (e) return e;
+            stack.push_back(path);
+            const size_t slash = path.find_last_of('/');
+            e                  = expand_includes_rec(sub, slash == std::string::npos ? std::string() : path.substr(0, slash), stack, message);
+            stack.pop_back();
+            if (e) return e;
+            node.kids.emplace_back(new YNode());
+            YNode *item    = node.kids.back().get();
+            item->key      = "-";
+            item->seq_item = true;
+            for (auto &q : sub.kids) item->kids.push_back(std::move(q));
+         }
+         i--; // the include node is gone: look at what now stands at its place
+         continue;
+      }
       uint32_t e = expand_includes_rec(k, base_dir, stack, message);
       if (e) return e;
    }
@@ -417,6 +476,9 @@ static std::vector<int> int_list(Ctx &c, YNode &k, const char *what)
    return out;
 }
 
+// nested Krylov components (reference src/internal/mgr.c:683-700 MGRIsNestedKrylovKey: any solver type name)
+static bool is_krylov_name(const std::string &k) { return k == "pcg" || k == "gmres" || k == "fgmres" || k == "bicgstab"; }
+
 // f_relaxation / g_relaxation: a flat name, or a block with type / num_sweeps / a nested solver
 static void ilu_fields(Ctx &c, YNode &sec, IluArgs &a);
 static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweeps, std::string &block, AmgArgs *amg = nullptr,
@@ -451,6 +513,8 @@ static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweep
          auto it = map.find(q->key);
          if (it != map.end()) type = it->second;
       }
+      else if (is_krylov_name(q->key))
+         c.fail(ERR_INVALID_VAL, "mgr: a nested Krylov solver ('" + q->key + "') as " + k.key + " is not implemented on MI355X");
       else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under '" + k.key + "'");
    }
 }
@@ -496,6 +560,8 @@ static void mgr_fields(Ctx &c, YNode &sec, MgrArgs &m)
                   auto it = kMgrCoarsest.find(q->key);
                   if (it != kMgrCoarsest.end()) m.coarsest_type = it->second;
                }
+               else if (is_krylov_name(q->key))
+                  c.fail(ERR_INVALID_VAL, "mgr: a nested Krylov solver ('" + q->key + "') on the coarsest level is not implemented on MI355X");
                else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under 'mgr.coarsest_level'");
             }
       }
@@ -510,8 +576,20 @@ static void mgr_fields(Ctx &c, YNode &sec, MgrArgs &m)
       else if (k->key == "coarse_th") m.coarse_th = to_double(c, *k);
       else if (k->key == "cycle")
       {
-         if (k->kids.empty()) m.cycle = to_int(c, *k, &kMgrCycle);
-         else c.fail(ERR_INVALID_VAL, "mgr.cycle blocks (smoothing positions) are not implemented on MI355X");
+         // MGRCycleSet (reference src/internal/mgr.c:614-675): 1 | 2 | v | w | v(1,0) | v(0,1) | v(1,1) | w(1,0) | w(0,1) | w(1,1)
+         static const std::map<std::string, std::pair<int, int>> names = {
+            {"v", {1, 1}}, {"v(1,0)", {1, 1}}, {"v(0,1)", {1, 2}}, {"v(1,1)", {1, 3}}, {"w", {2, 1}}, {"w(1,0)", {2, 1}},
+            {"w(0,1)", {2, 2}}, {"w(1,1)", {2, 3}}, {"1", {1, 1}}, {"2", {2, 1}}};
+         std::string v = k->val;
+         v.erase(std::remove_if(v.begin(), v.end(), [](char ch) { return isspace((unsigned char)ch); }), v.end());
+         auto it = names.find(v);
+         if (!k->kids.empty() || it == names.end())
+            c.fail(ERR_INVALID_VAL, "Invalid MGR cycle '" + k->val + "' (expected 1, 2, v, w, v(1,0), v(0,1), v(1,1), w(1,0), w(0,1), or w(1,1))");
+         else
+         {
+            m.cycle            = it->second.first;
+            m.cycle_smooth_pos = it->second.second;
+         }
       }
       else c.fail(ERR_INVALID_KEY, "unknown key '" + k->key + "' under 'mgr'");
    }
@@ -810,6 +888,11 @@ static void parse_precon_body(Ctx &c, YNode &node, std::vector<PreconArgs> &vari
          uint32_t    e = precon_from_text(t, p, m);
          if (e) c.fail(e, m);
          variants.push_back(p);
+         continue;
+      }
+      if (ch->seq_item)
+      { // "preconditioner: - amg: {...} - ilu: {...}" (what a list-valued include makes, examples/ex8-multi-2.yml): every item a full variant
+         parse_precon_body(c, *ch, variants);
          continue;
       }
       PreconArgs p;

@@ -119,7 +119,7 @@ struct MgrLevelArgs {
    bool        g_ilu_block = false; // g_relaxation came with its own ilu block (a smoother object, not hypre's built-in type 16)
 };
 struct MgrArgs {
-   int    non_c_to_f = 1, pmax = 0, max_iter = 1, num_levels = 0, relax_type = 7, print_level = 0, nonglk_max_elmts = 1, cycle = 1;
+   int    non_c_to_f = 1, pmax = 0, max_iter = 1, num_levels = 0, relax_type = 7, print_level = 0, nonglk_max_elmts = 1, cycle = 1, cycle_smooth_pos = 1; // cycle_smooth_pos: 1 pre, 2 post, 3 pre + post (mgr.h:160)
    double tolerance = 0.0, coarse_th = 0.0;
    std::vector<MgrLevelArgs> level;
    int         coarsest_type = -1; // -1 / 0: BoomerAMG

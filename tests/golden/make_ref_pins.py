@@ -64,6 +64,15 @@ def main():
     pins["elasticity"] = dict(source="examples/refOutput/elasticity.txt:9-16,37-41", stats=stats_rows(el),
                               config="30x10x10 nodes Q1 hexahedra, 3 dofs/node, presets pcg + elasticity_3D "
                                      "(num_functions 3, strong_th 0.8), CPU defaults")
+    # AMG variants on the 10^3 system (examples/ex8.yml as it stood when the output was made: the echoed input tree in the
+    # output itself, ex8.txt:26-78, names every variant; the initial residual 1.58e+01 = sqrt(250) against ex2's sqrt(1000) on
+    # the same np4 files says only the first of the four right-hand-side parts was read on one rank)
+    ex8 = open(os.path.join(ro, "ex8.txt")).read()
+    pins["ex8"] = dict(source="examples/refOutput/ex8.txt:26-78,92-96", stats=stats_rows(ex8),
+                       config="10^3 7-pt (np4 files on 1 rank), b = 1 on rows 0..249, PCG rtol 1e-9; variants: "
+                              "0 HMIS 0.25 + mm-ext+i + Chebyshev(2); 1 HMIS 0.5 + mm-ext+i + Chebyshev(4, fraction 0.1); "
+                              "2 HMIS 0.8 + mm-ext+i + l1sym-hgs; 3 HMIS 0.9 + mm-ext+i + Chebyshev(2) + ILU(0) level-0 smoother; "
+                              "4 PMIS 0.5 + standard interpolation + l1-hsgs x2 (not restated)")
     # analytic unit-test anchors (tests/test_linsys.c:4126-4155, tests/test_setmatrix_from_csr.c:397-417)
     pins["unit"] = dict(norms_of_1_m2_3=dict(L1=6.0, L2=14.0 ** 0.5, Linf=3.0),
                         one_by_one=dict(a=3.0, b=6.0, x_norm=2.0, tol=1e-6))

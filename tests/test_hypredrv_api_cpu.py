@@ -1,6 +1,7 @@
 """CPU-side tests of the reference-facing boundary: header/export agreement, YAML subset,
 error-code ABI (reference include/internal/error.h:16-48), guards that need no GPU."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -234,3 +235,45 @@ def test_mgr_yaml_and_create(hd):
     with pytest.raises(hd.HypredrvError, match="unknown key"):
         hd.Hypredrv(EX3_MGR.replace("prolongation_type: jacobi", "prolongation: jacobi"))
     L.HYPREDRV_ErrorCodeClear()
+
+
+REF_EXAMPLES = "/root/reference/examples"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference tree not present (it never travels to the GPU box)")
+def test_every_reference_example_parses_or_is_refused_by_name():
+    """the reference's own examples/*.yml, read in place, through HYPREDRV_InputArgsParse.  Expected outcome per
+    file in tests/golden/ref_examples_expect.json (names only, no reference text): "accepted"; "fragment" = an include file
+    without a preconditioner section, rejected by the reference too; "not implemented" = refused with a message that says so.
+    Never a grammar error: list-valued include, sequences of flow lists, quoted scalars and MGR cycle strings all parse."""
+    import ctypes as C
+    import glob
+    from hypredrive_amd import hypredrv as hd
+    expect = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_examples_expect.json")))
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(REF_EXAMPLES, "*.yml")))
+    assert names == sorted(expect), "examples added or removed upstream: regenerate the expectation list"
+    L = hd.lib()
+    cwd = os.getcwd()
+    os.chdir(REF_EXAMPLES)
+    try:
+        for name in names:
+            hd.check(L.HYPREDRV_Initialize())
+            h = C.c_void_p()
+            hd.check(L.HYPREDRV_Create(hd.MPI_COMM_WORLD, C.byref(h)))
+            hd.check(L.HYPREDRV_SetLibraryMode(h))
+            argv = (C.c_char_p * 1)(name.encode())
+            code = L.HYPREDRV_InputArgsParse(1, argv, h)
+            msg = L.HYPREDRV_AMD_LastErrorMessage().decode() if code else ""
+            L.HYPREDRV_ErrorCodeClear()
+            L.HYPREDRV_Destroy(C.byref(h))
+            want = expect[name]
+            if want == "accepted":
+                assert code == 0, f"{name}: {msg}"
+            elif want == "fragment":
+                assert code == hd.ERROR_MISSING_PRECON and "preconditioner" in msg, f"{name}: 0x{code:x} {msg}"
+            else:
+                assert code != 0 and "not implemented on MI355X" in msg, f"{name}: 0x{code:x} {msg}"
+            assert "expected 'key: value'" not in msg and "indentation" not in msg, f"{name}: grammar error: {msg}"
+    finally:
+        os.chdir(cwd)
+    assert sum(1 for v in expect.values() if v == "accepted") >= 43
