@@ -184,25 +184,53 @@ static std::string rank_file(const char *prefix, int rank)
    return std::string(prefix) + buf;
 }
 
-// hypre ASCII IJ vector file: "jlower jupper" then "j value" lines
+// Part files "<prefix>.%05d" present on disk, counted from 0 (reference src/internal/utils.c hypredrv_CountNumberOfPartitions)
+static int count_part_files(const char *prefix)
+{
+   int n = 0;
+   for (;; n++)
+   {
+      FILE *f = fopen(rank_file(prefix, n).c_str(), "r");
+      if (!f) break;
+      fclose(f);
+   }
+   return n;
+}
+static void my_parts(long long g_nparts, int &first, int &count);
+
+// hypre ASCII IJ vector file: "jlower jupper" then "j value" lines.  With more part files than ranks
+// (the np4 data set of examples/ex8.yml on one rank) a rank reads its contiguous group of parts, as the multipart binary
+// reader does (reference src/internal/linsys.c:872-903 takes that route whenever parts >= ranks).
 extern "C" HYPRE_Int HYPRE_IJVectorRead(const char *filename, MPI_Comm comm, HYPRE_Int, HYPRE_IJVector *vector)
 {
    HY_TRY
-   const std::string fn = rank_file(filename, Comm::world().rank);
-   FILE             *f  = fopen(fn.c_str(), "r");
-   if (!f) return hypre_set_error(HYPRE_ERROR_ARG, "cannot open " + fn);
-   long long jl, ju;
-   if (fscanf(f, "%lld %lld", &jl, &ju) != 2) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "bad IJ vector header in " + fn); }
-   HYPRE_IJVectorCreate(comm, jl, ju, vector);
-   HYPRE_IJVectorInitialize(*vector);
-   long long j;
-   double    val;
-   while (fscanf(f, "%lld %lf", &j, &val) == 2)
+   const int nparts = count_part_files(filename);
+   int       first = Comm::world().rank, count = 1;
+   if (nparts > Comm::world().size) my_parts(nparts, first, count);
+   std::vector<std::pair<long long, double>> ent;
+   long long lo = 0, hi = -1;
+   for (int p = first; p < first + count; p++)
    {
-      if (j < jl || j > ju) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "IJ vector entry outside its header range in " + fn); }
-      (*vector)->stage[(size_t)(j - jl)] = val;
+      const std::string fn = rank_file(filename, p);
+      FILE             *f  = fopen(fn.c_str(), "r");
+      if (!f) return hypre_set_error(HYPRE_ERROR_ARG, "cannot open " + fn);
+      long long jl, ju;
+      if (fscanf(f, "%lld %lld", &jl, &ju) != 2) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "bad IJ vector header in " + fn); }
+      if (p == first) lo = jl;
+      else if (jl != hi + 1) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "IJ vector parts are not contiguous at " + fn); }
+      hi = ju;
+      long long j;
+      double    val;
+      while (fscanf(f, "%lld %lf", &j, &val) == 2)
+      {
+         if (j < jl || j > ju) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "IJ vector entry outside its header range in " + fn); }
+         ent.emplace_back(j, val);
+      }
+      fclose(f);
    }
-   fclose(f);
+   HYPRE_IJVectorCreate(comm, lo, hi, vector);
+   HYPRE_IJVectorInitialize(*vector);
+   for (auto &e : ent) (*vector)->stage[(size_t)(e.first - lo)] = e.second;
    return HYPRE_IJVectorAssemble(*vector);
    HY_CATCH
 }
@@ -527,25 +555,46 @@ extern "C" HYPRE_Int HYPRE_ParCSRMatrixGetNumNonzeros(HYPRE_ParCSRMatrix A, HYPR
 extern "C" HYPRE_Int HYPRE_IJMatrixRead(const char *filename, MPI_Comm comm, HYPRE_Int, HYPRE_IJMatrix *matrix)
 {
    HY_TRY
-   const std::string fn = rank_file(filename, Comm::world().rank);
-   FILE             *f  = fopen(fn.c_str(), "r");
-   if (!f) return hypre_set_error(HYPRE_ERROR_ARG, "cannot open " + fn);
-   long long il, iu, jl, ju;
-   if (fscanf(f, "%lld %lld %lld %lld", &il, &iu, &jl, &ju) != 4) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "bad IJ matrix header in " + fn); }
-   HYPRE_IJMatrixCreate(comm, il, iu, jl, ju, matrix);
-   HYPRE_IJMatrixInitialize(*matrix);
-   long long i, j;
-   double    v;
-   auto     *m = *matrix;
-   while (fscanf(f, "%lld %lld %lf", &i, &j, &v) == 3)
+   // more part files than ranks: a rank reads its contiguous group of parts (see HYPRE_IJVectorRead)
+   const int nparts = count_part_files(filename);
+   int       first = Comm::world().rank, count = 1;
+   if (nparts > Comm::world().size) my_parts(nparts, first, count);
+   std::vector<long long> ti, tj;
+   std::vector<double>    tv;
+   long long              lo = 0, hi = -1, clo = 0, chi = -1;
+   for (int p = first; p < first + count; p++)
    {
-      if (i < il || i > iu) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "IJ matrix row outside its header range in " + fn); }
-      m->t_row.push_back((int)(i - il));
-      m->t_col.push_back(j);
-      m->t_val.push_back(v);
+      const std::string fn = rank_file(filename, p);
+      FILE             *f  = fopen(fn.c_str(), "r");
+      if (!f) return hypre_set_error(HYPRE_ERROR_ARG, "cannot open " + fn);
+      long long il, iu, jl, ju;
+      if (fscanf(f, "%lld %lld %lld %lld", &il, &iu, &jl, &ju) != 4) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "bad IJ matrix header in " + fn); }
+      if (p == first) { lo = il; clo = jl; }
+      else if (il != hi + 1) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "IJ matrix parts are not contiguous at " + fn); }
+      hi  = iu;
+      chi = ju;
+      long long i, j;
+      double    v;
+      while (fscanf(f, "%lld %lld %lf", &i, &j, &v) == 3)
+      {
+         if (i < il || i > iu) { fclose(f); return hypre_set_error(HYPRE_ERROR_GENERIC, "IJ matrix row outside its header range in " + fn); }
+         ti.push_back(i);
+         tj.push_back(j);
+         tv.push_back(v);
+      }
+      fclose(f);
+   }
+   HYPRE_IJMatrixCreate(comm, lo, hi, clo, chi, matrix);
+   HYPRE_IJMatrixInitialize(*matrix);
+   auto *m = *matrix;
+   m->t_row.reserve(ti.size());
+   for (size_t q = 0; q < ti.size(); q++)
+   {
+      m->t_row.push_back((int)(ti[q] - lo));
+      m->t_col.push_back(tj[q]);
+      m->t_val.push_back(tv[q]);
       m->t_add.push_back(0);
    }
-   fclose(f);
    return HYPRE_IJMatrixAssemble(m);
    HY_CATCH
 }
