@@ -2080,7 +2080,7 @@ double Amg::grid_complexity() const
    return s / std::max(stats_rows[0], 1.0);
 }
 
-static double spmv_bytes(const DCsr &M, bool format) { return matrix_stream_bytes(M, format) + 4.0 * (M.nrows + 1) + 8.0 * M.ncols + 8.0 * M.nrows; }
+static double spmv_bytes(const DCsr &M, bool format) { return matrix_stream_bytes(M, format) + rowptr_stream_bytes(M, format) + 8.0 * M.ncols + 8.0 * M.nrows; }
 
 // V(1,1) per level = smoothing sweeps + residual SpMV (+8n for b) + P^T apply
 // + P apply-add (+8n), on the actual hierarchy; the zero-guess first sweep is elementwise.

@@ -718,7 +718,7 @@ extern "C" int hda_format_bytes(hda_csr_t A, hda_amg_t amg, double *pcg_iteratio
    const DCsr &m = A->get();
    if (pcg_iteration) *pcg_iteration = pcg_iteration_bytes(m, true);
    if (vcycle) *vcycle = amg ? amg->amg->vcycle_bytes(true) : 0.0;
-   if (spmv) *spmv = matrix_stream_bytes(m, true) + 4.0 * (m.nrows + 1.0) + 8.0 * m.ncols + 8.0 * m.nrows;
+   if (spmv) *spmv = matrix_stream_bytes(m, true) + rowptr_stream_bytes(m, true) + 8.0 * m.ncols + 8.0 * m.nrows;
    if (coded) *coded = (m.coded == 1);
    HDA_CATCH
 }

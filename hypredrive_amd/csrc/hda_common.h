@@ -171,11 +171,18 @@ struct DCsr {
    mutable DArray<double>        dict_val;   // 256
    mutable DArray<int>           dict_delta; // 256
    mutable int                   coded = -1, escapes = 0; // -1 not examined, 0 plain, 1 coded; entries outside the dictionary
+   // row classes of a stencil-coded operator (coded == 1): rows that spell the same sequence of <= 8 entry codes share a
+   // class; one byte per ROW then replaces row pointer and entry codes (hda_kernels.hip "row-class coding")
+   mutable DArray<unsigned char>      rclass;  // nrows (+ padding); 255 = read the row from the CSR arrays
+   mutable DArray<unsigned long long> rc_keys; // 128 slots: the packed code sequence of every class
+   mutable int                        rowcoded = 0, rc_esc_rows = 0;
+   mutable long long                  rc_esc_entries = 0;
    mutable std::unique_ptr<OffdPart> offd; // ghost-column part, for products overlapped with their halo exchange
    void reset_plan() const
    {
       chunk_row.release(); code.release(); dict_val.release(); dict_delta.release(); offd.reset();
-      nchunks = 0; maxrow = -1; coded = -1;
+      rclass.release(); rc_keys.release();
+      nchunks = 0; maxrow = -1; coded = -1; rowcoded = 0; rc_esc_rows = 0; rc_esc_entries = 0;
    }
 };
 

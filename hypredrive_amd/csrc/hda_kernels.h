@@ -72,6 +72,8 @@ void make_dinv(int n, const double *d, double weight, double *dinv);
 // bytes of (col, val) one product streams: plain = 12 nnz; stencil-coded = 1 nnz (+ 12 per escape);
 // format = true asks for what the kernels really read, false for the CSR figure of SURVEY 8(d)
 double matrix_stream_bytes(const DCsr &A, bool format);
+// bytes of row pointers one product reads: 4 (n + 1), or -- format = true on a row-class coded operator -- only those of its CSR rows
+double rowptr_stream_bytes(const DCsr &A, bool format);
 // build the launch plans of A now (chunk plan, stencil coding attempt) instead of at its first product
 void spmv_prepare(const DCsr &A);
 // timing probe: bracket every launch of mode `mode` (0 plain, 1 residual, 2 Jacobi) on matrix A

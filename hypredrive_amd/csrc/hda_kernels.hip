@@ -571,9 +571,111 @@ static bool coded_enabled()
    return on;
 }
 
+// ---- row-class coding -----------------------------------------------------------------------------------
+// One step further for operators that are already stencil-coded: away from the boundary every row of a
+// constant-coefficient discretisation spells the SAME sequence of entry codes.  Rows with equal sequences (<= 8
+// entries, no escapes) share a class; the product then reads ONE byte per row instead of a row pointer and 7 entry
+// codes (11 -> 1 B per row of the 7-pt operator) and takes offsets and values of the whole row from a class table in
+// LDS.  Class 255 = the row is read from the CSR arrays (ghost columns of a row block, rows longer than 8).
+// Products and the order of additions are those of the CSR row: bit-identical results.
+constexpr int                kRcSlots  = 127;
+constexpr unsigned long long kRcNoKey  = 0xffffffffffffffffull; // also the key of an empty row: never a class
+
+__device__ __forceinline__ unsigned long long rc_row_key(int s, int e, const unsigned char *__restrict__ code)
+{
+   if (e - s > 8 || e == s) return kRcNoKey;
+   unsigned long long key = 0;
+   for (int u = 0; u < 8; u++)
+   {
+      const unsigned c = (s + u < e) ? code[s + u] : 254u; // 254 pads short rows ...
+      if (c == 255u || (c == 254u && s + u < e)) return kRcNoKey; // ... so a row that really uses dictionary slot 254 stays a CSR row
+      key |= (unsigned long long)c << (8 * u);
+   }
+   return key;
+}
+__global__ __launch_bounds__(256) void k_rc_collect(int n, int stride, const int *__restrict__ rp, const unsigned char *__restrict__ code,
+                                                    unsigned long long *keys, int *fails)
+{
+   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * stride;
+   if (i >= n || *(volatile int *)fails > 0) return;
+   const unsigned long long key = rc_row_key(rp[i], rp[i + 1], code);
+   if (key == kRcNoKey) return;
+   int s = (int)(key % kRcSlots);
+   for (int probe = 0; probe < kRcSlots; probe++)
+   {
+      unsigned long long cur = keys[s];
+      if (cur == kRcNoKey) cur = atomicCAS(&keys[s], kRcNoKey, key);
+      if (cur == kRcNoKey || cur == key) return;
+      s = (s + 1 == kRcSlots) ? 0 : s + 1;
+   }
+   atomicAdd(fails, 1); // more than 127 different rows: not a stencil operator in this sense
+}
+__global__ __launch_bounds__(256) void k_rc_encode(int n, const int *__restrict__ rp, const unsigned char *__restrict__ code,
+                                                   const unsigned long long *__restrict__ keys, unsigned char *__restrict__ rclass,
+                                                   unsigned long long *esc /* [0] rows, [1] entries */)
+{
+   __shared__ unsigned long long sk[128];
+   if (threadIdx.x < 128) sk[threadIdx.x] = threadIdx.x < kRcSlots ? keys[threadIdx.x] : kRcNoKey;
+   __syncthreads();
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   const int                s = rp[i], e = rp[i + 1];
+   const unsigned long long key = rc_row_key(s, e, code);
+   int                      c = 255;
+   if (key != kRcNoKey)
+   {
+      int q = (int)(key % kRcSlots);
+      for (int probe = 0; probe < kRcSlots; probe++)
+      {
+         if (sk[q] == key) { c = q; break; }
+         if (sk[q] == kRcNoKey) break;
+         q = (q + 1 == kRcSlots) ? 0 : q + 1;
+      }
+   }
+   rclass[i] = (unsigned char)c;
+   if (c == 255 && e > s)
+   {
+      atomicAdd(&esc[0], 1ull);
+      atomicAdd(&esc[1], (unsigned long long)(e - s));
+   }
+   else if (c == 255) rclass[i] = 254; // empty row: nothing to add, nothing to read
+}
+static void ensure_rowclass(const DCsr &A)
+{
+   A.rowcoded = 0;
+   const bool on = !(getenv("HDA_ROWCLASS") && atoi(getenv("HDA_ROWCLASS")) == 0); // read per matrix: the parity test builds both forms
+   if (!on || A.coded != 1 || A.nrows < 1) return;
+   A.rc_keys.alloc(128);
+   HDA_HIP(hipMemsetAsync(A.rc_keys.data(), 0xff, 128 * sizeof(unsigned long long), STREAM));
+   DArray<int>                fails(1);
+   DArray<unsigned long long> esc(2);
+   fails.zero();
+   esc.zero();
+   const int g = ceil_div(A.nrows, 256);
+   k_rc_collect<<<g, 256, 0, STREAM>>>(A.nrows, 1, A.rowptr.data(), A.code.data(), A.rc_keys.data(), fails.data());
+   int nf = 0;
+   fails.download(&nf, 1);
+   if (nf > 0) { A.rc_keys.release(); return; }
+   A.rclass.alloc(((size_t)A.nrows + 64 + 3) & ~(size_t)3);
+   k_rc_encode<<<g, 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.code.data(), A.rc_keys.data(), A.rclass.data(), esc.data());
+   unsigned long long he[2] = {0, 0};
+   esc.download(he, 2);
+   if (he[0] * 8 > (unsigned long long)A.nrows)
+   { // more than one row in eight falls back to CSR: the entry-coded kernel serves this operator better
+      A.rclass.release();
+      A.rc_keys.release();
+      return;
+   }
+   A.rowcoded       = 1;
+   A.rc_esc_rows    = (int)he[0];
+   A.rc_esc_entries = (long long)he[1];
+   HDA_TRACE("row-class coding for %d x %d: %d rows (%.3f %%) read from CSR", A.nrows, A.ncols, A.rc_esc_rows, 100.0 * A.rc_esc_rows / A.nrows);
+}
+
 // decide once per matrix whether the coded form pays: big enough to be bandwidth-bound and at
 // most 1 entry in 16 escaping
 static void ensure_vcoded(const DCsr &A);
+static void ensure_rowclass(const DCsr &A);
 static void ensure_coded(const DCsr &A)
 {
    if (A.coded >= 0) return;
@@ -622,6 +724,7 @@ static void ensure_coded(const DCsr &A)
    A.coded   = 1;
    A.escapes = e;
    HDA_TRACE("coded SpMV for %d x %d, nnz %d: %d escapes (%.3f %%)", A.nrows, A.ncols, A.nnz, e, 100.0 * e / std::max(A.nnz, 1));
+   ensure_rowclass(A);
 }
 
 // Row-per-lane kernel of the coded product: no LDS staging, no barriers.  A lane fetches the
@@ -747,6 +850,107 @@ __global__ __launch_bounds__(256) void k_spmv_coded_row(int nrows, const int *__
          {
             o0 = e2[h] + e1[h] * (e0[h] - sum[h]);
             if (DOT) acc += e0[h] * o0;
+         }
+         out[r] = o0;
+      }
+   }
+   if (DOT)
+   {
+      acc = block_sum(acc);
+      if (tid == 0)
+      {
+         partial[blockIdx.x] = acc;
+         if (blockIdx.x + gridDim.x < kRedBlocks) partial[blockIdx.x + gridDim.x] = 0.0;
+      }
+   }
+}
+
+// Row-per-lane product of a row-class coded operator: the lane reads its class byte (neighbouring lanes, neighbouring
+// bytes), takes the row's offsets and values from the class table in LDS (lanes of a wave mostly share a class: LDS
+// broadcasts) and keeps the row's <= 8 gathers in flight; x[r + offset] of 64 consecutive rows is a coalesced load.
+template <int MODE, bool DOT, bool SPLIT>
+__global__ __launch_bounds__(256) void k_spmv_rowclass(int nrows, const unsigned char *__restrict__ rclass,
+                                                       const unsigned long long *__restrict__ rc_keys, const double *__restrict__ dval,
+                                                       const int *__restrict__ ddelta, const int *__restrict__ rowptr,
+                                                       const int *__restrict__ col, const double *__restrict__ val,
+                                                       const double *__restrict__ x, double alpha, double beta, const double *yin,
+                                                       const double *__restrict__ b, const double *__restrict__ dinv,
+                                                       const double *__restrict__ w, double *out, double *__restrict__ partial, int nown)
+{
+   __shared__ double sv[128 * 8];
+   __shared__ int    sd[128 * 8];
+   __shared__ int    sn[128];
+   const int tid = threadIdx.x;
+   if (tid < 128)
+   {
+      const unsigned long long key = tid < kRcSlots ? rc_keys[tid] : kRcNoKey;
+      int                      n   = 0;
+      for (int u = 0; u < 8; u++)
+      {
+         const unsigned c = (unsigned)(key >> (8 * u)) & 255u;
+         const bool     on = key != kRcNoKey && c < 254u;
+         sv[tid * 8 + u]   = on ? dval[c] : 0.0;
+         sd[tid * 8 + u]   = on ? ddelta[c] : 0;
+         n += on;
+      }
+      sn[tid] = n;
+   }
+   __syncthreads();
+   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+   const int per = (((nrows + 7) >> 3) + 255) / 256 * 256; // rows per XCD, whole tiles
+   double    acc = 0.0;
+   for (int tile = slot; tile * 256 < per; tile += nslot)
+   {
+      const int  r    = xcd * per + tile * 256 + tid;
+      const bool live = r < nrows;
+      const int  cls  = live ? (int)rclass[r] : 254;
+      double     e0 = 0.0, e1 = 0.0, e2 = 0.0, sum = 0.0;
+      if (live)
+      {
+         if (MODE == MODE_PLAIN) { if (beta != 0.0) e0 = yin[r]; if (DOT) e1 = w[r]; }
+         else if (MODE == MODE_RESID) e0 = b[r];
+         else { e0 = b[r]; e1 = dinv[r]; e2 = x[r]; }
+      }
+      if (cls < 128)
+      {
+         const int     n  = sn[cls];
+         const double *cv = sv + cls * 8;
+         const int    *cd = sd + cls * 8;
+         double        xv[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++)
+         {
+            const int j = r + cd[u];
+            xv[u]       = (u < n && (!SPLIT || j < nown)) ? x[j] : 0.0;
+         }
+#pragma unroll
+         for (int u = 0; u < 8; u++)
+         {
+            const double t = sum + cv[u] * xv[u];
+            sum            = (u < n) ? t : sum;
+         }
+      }
+      else if (cls == 255)
+      { // CSR row (ghost columns, long rows): same products, same order
+         for (int k = rowptr[r]; k < rowptr[r + 1]; k++)
+         {
+            const int j = col[k];
+            if (!SPLIT || j < nown) sum += val[k] * x[j];
+         }
+      }
+      if (live)
+      {
+         double o0;
+         if (MODE == MODE_PLAIN)
+         {
+            o0 = (beta == 0.0) ? alpha * sum : alpha * sum + beta * e0;
+            if (DOT) acc += o0 * e1;
+         }
+         else if (MODE == MODE_RESID) o0 = e0 - sum;
+         else
+         {
+            o0 = e2 + e1 * (e0 - sum);
+            if (DOT) acc += e0 * o0;
          }
          out[r] = o0;
       }
@@ -1012,6 +1216,17 @@ static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
    {
       const int per  = (((A.nrows + 7) >> 3) + 255) / 256 * 256; // rows per XCD (as in the kernel)
       const int grid = DOT ? gmax : std::min(gmax, 8 * (per / 256));
+      if (A.rowcoded == 1)
+      {
+#define HDA_RC(SPF)                                                                                                                              \
+   k_spmv_rowclass<MODE, DOT, SPF><<<grid, 256, 0, STREAM>>>(A.nrows, A.rclass.data(), A.rc_keys.data(), A.dict_val.data(), A.dict_delta.data(),   \
+                                                             A.rowptr.data(), A.col.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out,    \
+                                                             partial, nown)
+         if (split) HDA_RC(true);
+         else HDA_RC(false);
+#undef HDA_RC
+         return true;
+      }
       if (split)
          k_spmv_coded_row<MODE, DOT, true><<<grid, 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.code.data(), A.dict_val.data(), A.dict_delta.data(),
                                                                      A.col.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown);
@@ -1153,12 +1368,23 @@ void spmv_probe_read(int id, double *avg_ms, int *count)
    if (count) *count = c;
 }
 void spmv_probe_read(double *avg_ms, int *count) { spmv_probe_read(0, avg_ms, count); }
+double rowptr_stream_bytes(const DCsr &A, bool format)
+{
+   if (format)
+   {
+      ensure_plan(A);
+      ensure_coded(A);
+      if (A.coded == 1 && A.rowcoded == 1) return 8.0 * A.rc_esc_rows; // class rows never touch the row pointer
+   }
+   return 4.0 * (A.nrows + 1.0);
+}
 double matrix_stream_bytes(const DCsr &A, bool format)
 {
    if (format)
    {
       ensure_plan(A);
       ensure_coded(A);
+      if (A.coded == 1 && A.rowcoded == 1) return 1.0 * A.nrows + 12.0 * (double)A.rc_esc_entries; // one class byte per row; CSR for the rest
       if (A.coded == 1) return 1.0 * A.nnz + 12.0 * A.escapes;
       if (A.coded == 2) return 5.0 * A.nnz + 8.0 * A.escapes;
    }

@@ -15,7 +15,7 @@ double pcg_iteration_bytes(const DCsr &A, bool format)
 {
    const double n = A.nrows;
    // SpMV + fused <s,p> (reads p again: 8n) ; x,r update + <r,r> : 48n ; p = z + beta p : 24n
-   return (matrix_stream_bytes(A, format) + 4.0 * (n + 1) + 8.0 * A.ncols + 8.0 * n) + 8.0 * n + 48.0 * n + 24.0 * n;
+   return (matrix_stream_bytes(A, format) + rowptr_stream_bytes(A, format) + 8.0 * A.ncols + 8.0 * n) + 8.0 * n + 48.0 * n + 24.0 * n;
 }
 
 KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)

@@ -72,6 +72,26 @@ def test_spmv_irregular(orc, hd, n, density):
     assert rel(Ah.spmv(x), orc.spmv(Ao, x)) < 1e-12
 
 
+@pytest.mark.parametrize("shape,c", [((64, 64, 64), (1.0, 1.0, 1.0)), ((80, 60, 56), (1.0, 0.5, 0.001))])
+def test_row_class_coding_is_bit_identical(hd, monkeypatch, shape, c):
+    """A stencil-coded operator read one class byte per row (row-class coding) performs the products and additions of the
+    entry-coded kernel -- and of the CSR row -- in the same order: bit-identical products, residuals and Jacobi sweeps, for
+    the isotropic benchmark operator and an anisotropic one (three distinct off-diagonal values, 27 boundary classes)."""
+    n = shape[0] * shape[1] * shape[2]
+    rng = np.random.default_rng(11)
+    x, b = rng.standard_normal(n), rng.standard_normal(n)
+    out = {}
+    for form in ("entry", "row"):
+        monkeypatch.setenv("HDA_ROWCLASS", "0" if form == "entry" else "1")
+        A = hd.lap7(*shape, c=c)
+        out[form] = (A.spmv(x), A.spmv(x, -1.0, 1.0, b), A.relax(b, x, 18, 1.0, sweeps=2), hd.format_bytes(A)["spmv"])
+    for a, q in zip(out["entry"][:3], out["row"][:3]):
+        assert np.array_equal(a, q)
+    assert out["row"][3] < 0.7 * out["entry"][3]  # and it does stream fewer bytes
+    S = hd.lap7(*shape, c=c).to_scipy()
+    assert rel(out["row"][0], S @ x) < 1e-13
+
+
 def test_spmv_rectangular(orc, hd):
     rng = np.random.default_rng(5)
     M = sp.random(123, 57, density=0.1, random_state=rng, format="csr")
