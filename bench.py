@@ -222,8 +222,8 @@ def run(args):
         dom_bytes = spmv_bytes(dn, dc, dnnz) + 16.0 * dn  # + b, dinv of the sweep
         a_n, a_c, a_nnz = A.dims
         k1_ms, k1_count = pr["k1"]
-        k1_bytes = spmv_bytes(a_n, a_c, a_nnz) + 8.0 * a_n  # + second operand of the fused dot
-        k1_fmt = fb0["spmv"] + 8.0 * a_n
+        k1_bytes = spmv_bytes(a_n, a_c, a_nnz)  # the second operand of the fused dot <Ap, p> is x itself: no further stream
+        k1_fmt = fb0["spmv"]
         g, o = amg.complexities
         traffic, traffic_src = {}, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -272,7 +272,8 @@ def run(args):
                          "bytes_per_launch": dom_bytes, "avg_ms": dom_ms},
             # level-0 PCG product (the north-star SpMV).  The operator is stencil-coded (1 B/entry), so the CSR-equivalent
             # rate exceeds what HBM can deliver; "format" is the honest HBM rate; plain_csr below is the uncoded kernel
-            "level0_spmv": {"kernel": "k_spmv_coded_row<PLAIN,DOT>" if fb0["coded"] else "k_spmv_stream<PLAIN,DOT>",
+            "level0_spmv": {"kernel": ("k_spmv_rowclass<PLAIN,DOT>" if fb0.get("row_coded") else "k_spmv_coded_row<PLAIN,DOT>") if fb0["coded"]
+                            else "k_spmv_stream<PLAIN,DOT>",
                             "coded": fb0["coded"], "avg_ms": k1_ms, "launches": k1_count,
                             "csr_bytes_per_launch": k1_bytes, "csr_equiv_gbs": gbs(k1_bytes, k1_ms),
                             "csr_equiv_frac": gbs(k1_bytes, k1_ms) / HBM_PEAK_GBS,

@@ -71,7 +71,7 @@ SYMBOLS = [
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
-    "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size",
+    "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
 ]
 
 
@@ -477,7 +477,7 @@ def format_bytes(A, amg=None):
     """Bytes really streamed when operators are stencil-coded: dict(pcg_iteration, vcycle, spmv, coded)."""
     a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_int()
     _check(load().hda_format_bytes(A.h, amg.h if amg is not None else None, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-    return {"pcg_iteration": a.value, "vcycle": b.value, "spmv": c.value, "coded": bool(d.value)}
+    return {"pcg_iteration": a.value, "vcycle": b.value, "spmv": c.value, "coded": bool(d.value), "row_coded": d.value == 2}
 
 
 def probe_spmv(A, mode):

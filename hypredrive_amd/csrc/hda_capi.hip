@@ -719,7 +719,7 @@ extern "C" int hda_format_bytes(hda_csr_t A, hda_amg_t amg, double *pcg_iteratio
    if (pcg_iteration) *pcg_iteration = pcg_iteration_bytes(m, true);
    if (vcycle) *vcycle = amg ? amg->amg->vcycle_bytes(true) : 0.0;
    if (spmv) *spmv = matrix_stream_bytes(m, true) + rowptr_stream_bytes(m, true) + 8.0 * m.ncols + 8.0 * m.nrows;
-   if (coded) *coded = (m.coded == 1);
+   if (coded) *coded = (m.coded == 1) ? (m.rowcoded == 1 ? 2 : 1) : 0; // 1 entry-coded stencil operator, 2 row-class coded
    HDA_CATCH
 }
 
@@ -751,6 +751,31 @@ extern "C" int hda_borrow_hypredrv(void *hypredrv, hda_csr_t *A, hda_amg_t *amg)
       *amg   = h.release();
    }
    HDA_CATCH
+}
+
+// The library's halo-plan construction without its device half, for the CPU (gloo) test of the N > 1 path: collective over the
+// communicator joined with HYPREDRV_AMD_CommInitCallbacks.  part: row starts of every rank (world + 1 entries); ghost_gids:
+// ascending global ids of this rank's ghost columns.  Outputs: send_counts / recv_counts (world entries each), send_idx (the
+// owned rows to pack, grouped by ascending destination; at most send_cap entries are written), *send_total.
+extern "C" int hda_halo_plan_host(int nloc, const long long *part, const long long *ghost_gids, int nghost, int *send_counts,
+                                  int *recv_counts, int *send_idx, int send_cap, int *send_total)
+{
+   try
+   {
+      Comm                  &cm = Comm::world();
+      std::vector<long long> pv(part, part + cm.size + 1), gv(ghost_gids, ghost_gids + std::max(nghost, 0));
+      std::vector<int>       sc, rc, idx;
+      halo_plan_host(nloc, pv, gv, sc, rc, idx);
+      for (int p = 0; p < cm.size; p++) { send_counts[p] = sc[(size_t)p]; recv_counts[p] = rc[(size_t)p]; }
+      for (size_t q = 0; q < idx.size() && (int)q < send_cap; q++) send_idx[q] = idx[q];
+      if (send_total) *send_total = (int)idx.size();
+   }
+   catch (const std::exception &e)
+   {
+      g_err = e.what();
+      return HDA_ERR_RUNTIME;
+   }
+   return HDA_OK;
 }
 
 extern "C" int hda_probe_add(hda_csr_t A, int mode, int *id)

@@ -48,6 +48,9 @@ void localize(const DCsr &G, long long row_lo, long long row_hi, long long col_l
 
 // part: row starts of every rank (length size+1) of the vector the plan exchanges.
 HaloPlan make_halo_plan(int nloc, const std::vector<long long> &part, const std::vector<long long> &ghost_gids);
+// its host half (collective over Comm::world(), no device call): per-peer counts and the owned rows to pack, by ascending destination
+void halo_plan_host(int nloc, const std::vector<long long> &part, const std::vector<long long> &ghost_gids, std::vector<int> &send_counts,
+                    std::vector<int> &recv_counts, std::vector<int> &send_idx);
 
 // x_ext[nloc .. nloc+nghost) <- owners' values.  Collective over Comm::world().
 void halo_exchange(const HaloPlan &h, double *x_ext);

@@ -84,55 +84,68 @@ void localize(const DCsr &G, long long row_lo, long long row_hi, long long col_l
    Context::get().sync();
 }
 
-HaloPlan make_halo_plan(int nloc, const std::vector<long long> &part, const std::vector<long long> &ghost_gids)
+// Host half of the plan (no device call: also driven on CPU by the gloo tests through hda_halo_plan_host): who owns every
+// ghost, how many entries every peer wants from this rank, and which owned rows they are (grouped by ascending destination).
+void halo_plan_host(int nloc, const std::vector<long long> &part, const std::vector<long long> &ghost_gids, std::vector<int> &send_counts,
+                    std::vector<int> &recv_counts, std::vector<int> &send_idx)
 {
-   Comm    &cm = Comm::world();
-   HaloPlan h;
-   h.nloc   = nloc;
-   h.nghost = (int)ghost_gids.size();
-   h.send_counts.assign((size_t)cm.size, 0);
-   h.recv_counts.assign((size_t)cm.size, 0);
+   Comm &cm = Comm::world();
+   send_counts.assign((size_t)cm.size, 0);
+   recv_counts.assign((size_t)cm.size, 0);
+   send_idx.clear();
    if (cm.size == 1)
    { // a matrix with off-rank columns on a one-rank communicator would read a ghost tail nobody ever writes (e.g. a
      // driver started under mpiexec -n > 1 whose ranks never joined the library's communicator)
       HDA_REQUIRE(ghost_gids.empty(), "matrix has off-rank columns but no communicator was joined (call HYPREDRV_AMD_CommInit / "
                                       "HYPREDRV_AMD_CommInitCallbacks on every rank before assembling row blocks)");
-      return h;
+      return;
    }
    // who owns each ghost (ghost_gids ascending => grouped by ascending owner)
    for (long long g : ghost_gids)
    {
       int owner = (int)(std::upper_bound(part.begin(), part.end(), g) - part.begin()) - 1;
       HDA_REQUIRE(owner >= 0 && owner < cm.size && owner != cm.rank, "ghost column without a remote owner");
-      h.recv_counts[(size_t)owner]++;
+      recv_counts[(size_t)owner]++;
    }
    // tell every owner how many (then which) entries are wanted
    std::vector<long>      eight((size_t)cm.size, 8);
    std::vector<long long> want((size_t)cm.size), asked((size_t)cm.size);
-   for (int p = 0; p < cm.size; p++) want[(size_t)p] = h.recv_counts[(size_t)p];
+   for (int p = 0; p < cm.size; p++) want[(size_t)p] = recv_counts[(size_t)p];
    cm.alltoallv_host(want.data(), eight.data(), asked.data(), eight.data());
    std::vector<long> sb((size_t)cm.size), rb((size_t)cm.size);
    long              tot = 0;
    for (int p = 0; p < cm.size; p++)
    {
-      h.send_counts[(size_t)p] = (int)asked[(size_t)p];
-      sb[(size_t)p]            = 8L * h.recv_counts[(size_t)p]; // my request lists go out
-      rb[(size_t)p]            = 8L * h.send_counts[(size_t)p]; // peers' request lists come in
-      tot += h.send_counts[(size_t)p];
+      send_counts[(size_t)p] = (int)asked[(size_t)p];
+      sb[(size_t)p]          = 8L * recv_counts[(size_t)p]; // my request lists go out
+      rb[(size_t)p]          = 8L * send_counts[(size_t)p]; // peers' request lists come in
+      tot += send_counts[(size_t)p];
    }
    std::vector<long long> req((size_t)std::max<long>(tot, 1));
    cm.alltoallv_host(ghost_gids.empty() ? (const void *)req.data() : (const void *)ghost_gids.data(), sb.data(), req.data(),
                      rb.data());
-   std::vector<int> idx((size_t)std::max<long>(tot, 1));
-   const long long  lo = part[(size_t)cm.rank];
+   send_idx.resize((size_t)tot);
+   const long long lo = part[(size_t)cm.rank];
    for (long q = 0; q < tot; q++)
    {
       const long long l = req[(size_t)q] - lo;
       HDA_REQUIRE(l >= 0 && l < nloc, "peer requested a row this rank does not own");
-      idx[(size_t)q] = (int)l;
+      send_idx[(size_t)q] = (int)l;
    }
+}
+
+HaloPlan make_halo_plan(int nloc, const std::vector<long long> &part, const std::vector<long long> &ghost_gids)
+{
+   HaloPlan h;
+   h.nloc   = nloc;
+   h.nghost = (int)ghost_gids.size();
+   std::vector<int> idx;
+   halo_plan_host(nloc, part, ghost_gids, h.send_counts, h.recv_counts, idx);
+   if (Comm::world().size == 1) return h;
+   const long tot = (long)idx.size();
+   if (idx.empty()) idx.push_back(0);
    h.send_total = (int)tot;
-   h.send_idx.upload(idx.data(), (size_t)std::max<long>(tot, 1));
+   h.send_idx.upload(idx.data(), idx.size());
    h.send_buf.alloc((size_t)std::max<long>(tot, 1));
    return h;
 }

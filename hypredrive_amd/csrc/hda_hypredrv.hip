@@ -162,6 +162,11 @@ struct hypredrv_struct {
    std::vector<HYPRE_IJVector> state; // borrowed time-level vectors (host resident), logical index i = state[(state_first + i) % n]
    int            state_first = 0;
    int            current_system_index = -1;
+   // exact null-space modes (HYPREDRV_LinearSystemSetNullSpace): orthonormalised, component-major, device resident,
+   // with the row range they were built for
+   DArray<double> ns_modes;
+   int            num_ns = 0, ns_nloc = 0;
+   long long      ns_lower = 0, ns_upper = -1;
    int            last_iters = 0, last_converged = 0;
    double         last_rel = 0.0, last_setup_s = 0.0, last_solve_s = 0.0;
    // Scaling_context (reference include/internal/scaling.h:39-51): what of the caller's system is scaled right now
@@ -1040,7 +1045,79 @@ extern "C" uint32_t HYPREDRV_LinearSystemPrintDofmap(HYPREDRV_t h, const char *f
 // which this build does not have: the call is accepted so drivers written for it run, the
 // vectors are not used
 extern "C" uint32_t HYPREDRV_LinearSystemSetNearNullSpace(HYPREDRV_t h, int, int, const HYPRE_Complex *) { CHECK_INIT_OBJ(h); return g_err; }
-UNSUPPORTED(HYPREDRV_LinearSystemSetNullSpace(HYPREDRV_t, int, int, const HYPRE_Complex *), "null-space projection")
+// Exact null-space modes (reference src/HYPREDRV.c:2281-2320 -> src/internal/linsys.c:533-625): modified Gram-Schmidt on the
+// component blocks, linear dependence refused at 1e-12 relative, num_components == 0 clears.  Here the modes live in HBM and
+// the inner products are the library's deterministic device reductions (all-reduced over the ranks of a row partition).
+extern "C" uint32_t HYPREDRV_LinearSystemSetNullSpace(HYPREDRV_t h, int num_entries, int num_components, const HYPRE_Complex *values)
+{
+   CHECK_INIT_OBJ(h);
+   API_TRY
+   if (num_components == 0)
+   {
+      h->ns_modes.release();
+      h->num_ns = 0;
+      return g_err;
+   }
+   if (!h->mat_A) return err_set(ERR_INVALID_VAL, "The matrix must be set before calling HYPREDRV_LinearSystemSetNullSpace");
+   if (num_components < 1 || num_entries < 0 || (!values && num_entries > 0))
+      return err_set(ERR_INVALID_VAL, "Invalid null space input: need num_components >= 1, num_entries >= 0, and non-NULL values when num_entries > 0");
+   if (num_entries != h->mat_A->nloc)
+      return err_set(ERR_INVALID_VAL, "Null space modes need one entry per locally owned row (" + std::to_string(h->mat_A->nloc) + "), got " + std::to_string(num_entries));
+   h->num_ns = 0;
+   const int      n = num_entries;
+   DArray<double> z((size_t)std::max((size_t)n * (size_t)num_components, (size_t)1));
+   if (n) z.upload(values, (size_t)n * (size_t)num_components);
+   auto ip = [&](const double *a, const double *b) {
+      dot(n, a, b, 0);
+      finalize(0, S_TMP);
+      return read_scalar(S_TMP);
+   };
+   for (int k = 0; k < num_components; k++)
+   {
+      double      *zk = z.data() + (size_t)k * (size_t)n;
+      const double norm_orig = std::sqrt(ip(zk, zk));
+      for (int j = 0; j < k; j++)
+      {
+         const double *zj = z.data() + (size_t)j * (size_t)n;
+         axpy(n, -ip(zk, zj), zj, zk);
+      }
+      const double nrm = std::sqrt(ip(zk, zk));
+      if (nrm <= 1.0e-12 * norm_orig) // HYPREDRV_NULLSPACE_DEP_TOL (linsys.c:32)
+      {
+         char buf[160];
+         snprintf(buf, sizeof(buf), "Null space modes must be linearly independent (mode %d has relative norm %e after orthogonalization)", k,
+                  norm_orig > 0.0 ? nrm / norm_orig : 0.0);
+         return err_set(ERR_INVALID_VAL, buf);
+      }
+      scale(n, 1.0 / nrm, zk);
+   }
+   h->ns_modes = std::move(z);
+   h->num_ns   = num_components;
+   h->ns_nloc  = n;
+   h->ns_lower = h->mat_A->ilower;
+   h->ns_upper = h->mat_A->iupper;
+   API_CATCH
+}
+// hypredrv_LinearSystemProjectOutNullSpace (src/internal/linsys.c:637-752): x -= sum_k <x, z_k> z_k with all inner products taken
+// of the solution as the solver left it; a system of another size or distribution is refused on every rank together
+static void project_out_null_space(hypredrv_struct *h)
+{
+   if (h->num_ns < 1 || !h->vec_x) return;
+   long long mismatch[1] = {(h->vec_x->jlower != h->ns_lower || h->vec_x->jupper != h->ns_upper || h->vec_x->nloc != h->ns_nloc) ? 1 : 0};
+   Comm::world().allreduce_host(mismatch, 1, 1);
+   if (mismatch[0])
+   {
+      err_set(ERR_INVALID_VAL, "Null space modes are incompatible with the current linear system; call HYPREDRV_LinearSystemSetNullSpace() again "
+                               "(or clear the modes with num_components = 0) after changing the system size or distribution");
+      return;
+   }
+   HDA_REQUIRE(h->num_ns <= Context::kNumSlots && S_GMRES + h->num_ns <= Context::kNumScalars, "too many null space modes for the reduction scratch");
+   h->vec_x->ensure_device();
+   const int n = h->ns_nloc;
+   for (int k = 0; k < h->num_ns; k++) dot(n, h->vec_x->data(), h->ns_modes.data() + (size_t)k * (size_t)n, k);
+   finalize_n(0, h->num_ns, S_GMRES);
+   for (int k = 0; k < h->num_ns; k++) axpy_dev(n, S_GMRES + k, -1.0, h->ns_modes.data() + (size_t)k * (size_t)n, h->vec_x->data());
+}
 // State vectors (reference src/HYPREDRV.c state-vector block, include/HYPREDRV.h:1521-1695): the
 // time levels of a nonlinear / transient driver.  The drivers create them HOST-initialised and
 // read and write them through raw pointers between solves, so they live in host memory here: the
@@ -1986,6 +2063,7 @@ extern "C" uint32_t HYPREDRV_LinearSolverApply(HYPREDRV_t h)
       bn = std::sqrt(bn);
       h->stats.cur().rr = residual_norm(h) / (bn > 0.0 ? bn : 1.0);
    }
+   if (!ierr) project_out_null_space(h); // src/HYPREDRV.c:3296-3300: fix the gauge of the solution (after the solver's own residual report)
    if (h->vec_xref && !ierr)
    { // src/HYPREDRV.c:3310-3323: error against the reference solution, when one was set
       double xx = 0.0, rr = 0.0, ee = 0.0;

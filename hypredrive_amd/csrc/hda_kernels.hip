@@ -899,18 +899,33 @@ __global__ __launch_bounds__(256) void k_spmv_rowclass(int nrows, const unsigned
    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
    const int per = (((nrows + 7) >> 3) + 255) / 256 * 256; // rows per XCD, whole tiles
    double    acc = 0.0;
+   // One row per lane and two dependent memory round trips per row (class byte, then the gathers it names) leave the
+   // kernel latency-bound (PMC: 2.5 TB/s of HBM traffic).  The class byte and the row's vector operands of the NEXT tile
+   // are therefore requested before the gathers of the current one: a tile then costs one round trip.
+   int    n_cls = 254;
+   double n_e0 = 0.0, n_e1 = 0.0, n_e2 = 0.0;
+   auto fetch = [&](int tile) {
+      const int r = xcd * per + tile * 256 + tid;
+      n_cls = 254;
+      n_e0 = n_e1 = n_e2 = 0.0;
+      if (tile * 256 < per && r < nrows)
+      {
+         n_cls = (int)rclass[r];
+         if (MODE == MODE_PLAIN) { if (beta != 0.0) n_e0 = yin[r]; if (DOT) n_e1 = w[r]; }
+         else if (MODE == MODE_RESID) n_e0 = b[r];
+         else { n_e0 = b[r]; n_e1 = dinv[r]; n_e2 = x[r]; }
+      }
+   };
+   // (runs of 2-16 consecutive tiles per workgroup, for L1 reuse of the neighbouring x lines, measured no faster)
+   fetch(slot);
    for (int tile = slot; tile * 256 < per; tile += nslot)
    {
-      const int  r    = xcd * per + tile * 256 + tid;
-      const bool live = r < nrows;
-      const int  cls  = live ? (int)rclass[r] : 254;
-      double     e0 = 0.0, e1 = 0.0, e2 = 0.0, sum = 0.0;
-      if (live)
-      {
-         if (MODE == MODE_PLAIN) { if (beta != 0.0) e0 = yin[r]; if (DOT) e1 = w[r]; }
-         else if (MODE == MODE_RESID) e0 = b[r];
-         else { e0 = b[r]; e1 = dinv[r]; e2 = x[r]; }
-      }
+      const int    r    = xcd * per + tile * 256 + tid;
+      const bool   live = r < nrows;
+      const int    cls  = n_cls;
+      const double e0 = n_e0, e1 = n_e1, e2 = n_e2;
+      double       sum = 0.0;
+      fetch(tile + nslot);
       if (cls < 128)
       {
          const int     n  = sn[cls];

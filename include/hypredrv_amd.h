@@ -195,6 +195,11 @@ int hda_probe_read_id(int id, double *avg_ms, int *count);
  * measurement entries above run on the very objects HYPREDRV_LinearSolverSetup built.  Valid until
  * HYPREDRV_LinearSolverDestroy; release the views with hda_csr_destroy / hda_amg_destroy. */
 int hda_borrow_hypredrv(void *hypredrv, hda_csr_t *A, hda_amg_t *amg);
+/* Host half of the library's halo plan (who owns every ghost column, what every peer wants from this rank), collective over
+ * the communicator joined with HYPREDRV_AMD_CommInitCallbacks; touches no device, so the world_size-2/3 gloo tests drive the
+ * library's own partition code on CPU.  part: world + 1 row starts; ghost_gids ascending. */
+int hda_halo_plan_host(int nloc, const long long *part, const long long *ghost_gids, int nghost, int *send_counts,
+                       int *recv_counts, int *send_idx, int send_cap, int *send_total);
 /* rank-to-rank traffic of the solve path since the last reset: [0] device all-reduces, [1] halo exchanges (grouped
  * neighbour send/recv), [2] doubles all-reduced, [3] doubles sent in halo exchanges, [4] exchanges that ran under a
  * product kernel (interior rows computed while the ghost values travel) */

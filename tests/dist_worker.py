@@ -26,44 +26,52 @@ def mode_transport(out):
     ar, a2a = hdist._make_callbacks(dist, torch, rank, world)
     # all-reduce: f64 sum and i64 max
     v = np.array([rank + 1.0, 2.0 * rank], dtype=np.float64)
-    ar(v.ctypes.data_as(C.c_void_p), 2, 0, 0)
+    assert ar(v.ctypes.data_as(C.c_void_p), 2, 0, 0) == 0
     assert np.allclose(v, [world * (world + 1) / 2, world * (world - 1)])
     w = np.array([rank, 7 - rank], dtype=np.int64)
-    ar(w.ctypes.data_as(C.c_void_p), 2, 1, 1)
+    assert ar(w.ctypes.data_as(C.c_void_p), 2, 1, 1) == 0
     assert list(w) == [world - 1, 7]
-    # row-partitioned SpMV on the generator's block numbering: ghost exchange through alltoallv
+    # row-partitioned SpMV on the generator's block numbering.  The PLAN comes from the library itself: its communicator is
+    # joined with these callbacks (no device needed) and hda_halo_plan_host runs the partition code of the GPU path -- owner
+    # lookup, count exchange, request lists -- collectively over gloo; only the local product is scipy's.
+    from hypredrive_amd import hypredrv as hd
+    import hypredrive_amd as hh
+    hdist._keep["cbs"] = (ar, a2a)
+    hd.check(hd.lib().HYPREDRV_AMD_CommInitCallbacks(rank, world, -1, ar, a2a))
     n, P = 6, (world, 1, 1)
     A, _ = o.lap7(n, n, n, P=P)
     S = A.to_scipy().tocsr()
     N = n ** 3
-    part = [o.lap7_partition(n, n, n, P, r)[0] for r in range(world)] + [N]
-    lo, hi = part[rank], part[rank + 1]
+    part = np.array([o.lap7_partition(n, n, n, P, r)[0] for r in range(world)] + [N], dtype=np.int64)
+    lo, hi = int(part[rank]), int(part[rank + 1])
     loc = S[lo:hi]
     cols = np.unique(loc.indices)
-    ghosts = cols[(cols < lo) | (cols >= hi)]
+    ghosts = np.ascontiguousarray(cols[(cols < lo) | (cols >= hi)], dtype=np.int64)
+    sc, rc = np.zeros(world, dtype=np.int32), np.zeros(world, dtype=np.int32)
+    idx = np.zeros(max(hi - lo, 1), dtype=np.int32)
+    tot = C.c_int()
+    L = hh.load()
+    ll, ip = C.POINTER(C.c_longlong), C.POINTER(C.c_int)
+    rcode = L.hda_halo_plan_host(hi - lo, part.ctypes.data_as(ll), ghosts.ctypes.data_as(ll), len(ghosts), sc.ctypes.data_as(ip),
+                                 rc.ctypes.data_as(ip), idx.ctypes.data_as(ip), len(idx), C.byref(tot))
+    assert rcode == 0, L.hda_last_error()
+    # the plan against an independent construction: ghosts grouped by owner, requests inside the owned range
     owner = np.searchsorted(part, ghosts, side="right") - 1
-    want = [ghosts[owner == p] for p in range(world)]
-    # exchange counts, then the id lists (the plan), then the values (the halo exchange)
-    cnt = np.array([len(x) for x in want], dtype=np.int64)
-    got = np.zeros(world, dtype=np.int64)
-    eight = (C.c_long * world)(*([8] * world))
-    a2a(cnt.ctypes.data_as(C.c_void_p), eight, got.ctypes.data_as(C.c_void_p), eight)
-    sb = (C.c_long * world)(*[8 * int(c) for c in cnt])
-    rb = (C.c_long * world)(*[8 * int(c) for c in got])
-    req = np.zeros(max(int(got.sum()), 1), dtype=np.int64)
-    flat = np.concatenate(want).astype(np.int64) if len(ghosts) else np.zeros(1, dtype=np.int64)
-    a2a(flat.ctypes.data_as(C.c_void_p), sb, req.ctypes.data_as(C.c_void_p), rb)
-    req = req[:int(got.sum())]
-    assert np.all((req >= lo) & (req < hi))
+    assert list(rc) == [int((owner == p).sum()) for p in range(world)] and rc[rank] == 0
+    assert tot.value == int(sc.sum()) and np.all((idx[:tot.value] >= 0) & (idx[:tot.value] < hi - lo))
+    # the halo exchange with the library's plan: pack by send_idx, one alltoallv, ghosts land in ascending global id
     x = np.sin(np.arange(N, dtype=np.float64))
-    sendv = x[req].copy() if len(req) else np.zeros(1)
+    sendv = np.ascontiguousarray(x[lo + idx[:tot.value]]) if tot.value else np.zeros(1)
     recvv = np.zeros(max(len(ghosts), 1))
-    a2a(sendv.ctypes.data_as(C.c_void_p), rb, recvv.ctypes.data_as(C.c_void_p), sb)
+    sb = (C.c_long * world)(*[8 * int(c) for c in sc])
+    rb = (C.c_long * world)(*[8 * int(c) for c in rc])
+    assert a2a(sendv.ctypes.data_as(C.c_void_p), sb, recvv.ctypes.data_as(C.c_void_p), rb) == 0
     xg = np.zeros(N)
     xg[lo:hi] = x[lo:hi]
     xg[ghosts] = recvv[:len(ghosts)]
     y = loc @ xg
     assert np.allclose(y, (S @ x)[lo:hi], rtol=1e-14)
+    hd.lib().HYPREDRV_AMD_CommFinalize()
     dist.barrier()
     if rank == 0:
         json.dump({"ok": True, "world": world}, open(out, "w"))

@@ -1,6 +1,7 @@
-"""N > 1 on CPU (gloo, world_size 2 and 3): the staged transport the multi-rank GPU tests and
-single-GPU rehearsals run on, driven with the exact message pattern of the row-partitioned
-SpMV (counts -> request lists -> halo values), checked against the oracle's global SpMV."""
+"""N > 1 on CPU (gloo, world_size 2 and 3): the staged transport the multi-rank GPU tests and single-GPU rehearsals run on.
+The library's communicator is joined with the gloo callbacks and the LIBRARY's own halo-plan code (hda_halo_plan_host: the
+host half of make_halo_plan, hda_dist.hip) builds the exchange plan collectively; the halo values then travel through the same
+callbacks and the row-partitioned SpMV is checked against the oracle's global one."""
 import json
 import os
 import subprocess

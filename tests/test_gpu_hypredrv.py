@@ -186,6 +186,59 @@ def test_cli_runs_ex8_multi_unchanged(orc, pins):
             assert abs(int(rows[k][3]) - pins["ex8"]["stats"][ref_entry[k]]["iters"]) <= 1
 
 
+def test_null_space_projection(hd):
+    """HYPREDRV_LinearSystemSetNullSpace + the projection at the end of LinearSolverApply, as the reference's own test drives them
+    (tests/test_hypredrv.c:4188-4350): modes before the matrix fail cleanly; two non-orthogonal modes are orthonormalised and the
+    computed solution is orthogonal to both INPUT modes; dependent modes are refused; modes of another system size make Apply fail
+    with ERROR_INVALID_VAL until they are cleared."""
+    import ctypes as C
+    L = hd.lib()
+
+    def lap1d(n):
+        import scipy.sparse as sp
+        return sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]).tocsr()
+
+    def set_ns(h, modes, ncomp):
+        m = np.ascontiguousarray(modes, dtype=np.float64)
+        return L.HYPREDRV_LinearSystemSetNullSpace(h.h, (m.size // ncomp) if ncomp else 0, ncomp, m.ctypes.data_as(C.POINTER(C.c_double)) if m.size else None)
+
+    def load(h, n):
+        A = lap1d(n)
+        h.set_matrix_csr(0, n - 1, A.indptr, A.indices, A.data)
+        h.set_rhs_array(0, n - 1, np.ones(n))
+        h.finish_system()
+
+    n = 8
+    h = hd.Hypredrv("solver: pcg\npreconditioner: amg\n")
+    assert set_ns(h, np.ones(1), 1) & hd.ERROR_INVALID_VAL  # no matrix yet
+    L.HYPREDRV_ErrorCodeClear()
+    load(h, n)
+    modes = np.r_[1.0 + (np.arange(n) % 2), np.arange(1, n + 1)].astype(float)
+    assert set_ns(h, modes, 2) == 0
+    r = h.solve()
+    assert r["converged"]
+    x = h.solution()
+    assert abs(x @ modes[:n]) < 1e-9 and abs(x @ modes[n:]) < 1e-9
+    # the unprojected solution is not orthogonal to them: the projection did the work
+    xf = np.linalg.solve(lap1d(n).toarray(), np.ones(n))
+    assert abs(xf @ modes[:n]) > 1.0
+    Q, _ = np.linalg.qr(modes.reshape(2, n).T)
+    assert np.allclose(x, xf - Q @ (Q.T @ xf), atol=1e-6)
+    assert set_ns(h, modes[:n], 1) == 0                           # replacing the modes
+    assert set_ns(h, np.r_[modes[:n], 2.0 * modes[:n]], 2) & hd.ERROR_INVALID_VAL  # linearly dependent
+    L.HYPREDRV_ErrorCodeClear()
+    assert set_ns(h, modes, 2) == 0
+    load(h, 4)                                                    # another system size: Apply must refuse, not corrupt
+    hd.check(L.HYPREDRV_LinearSystemResetInitialGuess(h.h))
+    h.create_and_setup()
+    assert L.HYPREDRV_LinearSolverApply(h.h) & hd.ERROR_INVALID_VAL
+    L.HYPREDRV_ErrorCodeClear()
+    h.destroy_solver()
+    assert set_ns(h, np.zeros(0), 0) == 0                         # cleared: solves succeed again
+    assert h.solve()["converged"]
+    h.close()
+
+
 def test_cli_overrides():
     cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
     r = subprocess.run([cli, "-q", "examples/ex1.yml", "-a", "--solver:pcg:max_iter", "3"], capture_output=True, text=True, cwd=ROOT)

@@ -1,0 +1,12 @@
+#!/bin/bash
+set -o pipefail
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
+O=$R/gpurun_out/r02h
+rm -rf $O; mkdir -p $O
+cd $R
+for w in 1 2 4 8 16; do
+HDA_RC_RUN=$w timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-plain-csr > $O/bench_run$w.json 2> $O/bench_run$w.err || { tail -30 $O/bench_run$w.err; exit 1; }
+python3 -c "
+import json; d=json.load(open('$O/bench_run$w.json'))
+print('run $w', {k:d[k] for k in ('value','ms_per_step','iters')}, 'k1', d['level0_spmv']['avg_ms'], 'kern', {k:round(v['ms'],4) for k,v in d['kernels'].items()})"
+done

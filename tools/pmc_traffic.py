@@ -70,7 +70,10 @@ def main():
             return None, None, None
         return fetch_factor * f * 1024 + write_factor * (w or 0.0) * 1024, f, w
 
-    for key, part, top in (("k_spmv_level0", "k_spmv_coded_row<0, true>", False), ("k_spmv_level0", "k_spmv_stream<0, true", False)):
+    names = "".join(byk.keys())
+    level0_coded = any(q in names for q in ("k_spmv_rowclass<0, true", "k_spmv_coded_row<0, true"))
+    for key, part, top in (("k_spmv_level0", "k_spmv_rowclass<0, true", False), ("k_spmv_level0", "k_spmv_coded_row<0, true", False),
+                           ("k_spmv_level0", "k_spmv_stream<0, true", True)):
         t, f, w = traffic(part, top)
         if t is not None and key + "_bytes_per_launch" not in out:
             out[key + "_bytes_per_launch"] = t
@@ -78,10 +81,27 @@ def main():
     # Jacobi sweep on the largest plain-CSR operator (bench.py's dominant kernel): level 1 when level 0 is coded
     t, f, w = traffic("k_spmv_stream<2, false", True)
     if t is not None:
-        lvl = 1 if "k_spmv_coded_row<0, true>" in "".join(byk.keys()) else 0
+        lvl = 1 if level0_coded else 0
         out[f"k_spmv_stream_jacobi_level{lvl}_bytes_per_launch"] = t
-        out[f"k_spmv_stream_jacobi_level{lvl}"] = {"kernel": "k_spmv_stream<2, false[, false]>, launches within 5 % of the largest FETCH_SIZE",
+        out[f"k_spmv_stream_jacobi_level{lvl}"] = {"kernel": "k_spmv_stream<2, false, ...>, launches within 5 % of the largest FETCH_SIZE",
                                                    "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
+    # level-0 transfer operators: the value-coded stream kernel in PLAIN mode without dot; P (x += P e) writes 8 B per fine row,
+    # R (f_c = R t) 8 B per coarse row -- told apart by WRITE_SIZE
+    pr = [k for k in byk if "k_spmv_stream<0, false, true" in k]
+    if pr and len(F) == len(W):
+        wmap = {d: v for d, _, v in W}
+        pairs = [(v, wmap.get(d)) for d, k, v in F if k in pr and wmap.get(d) is not None]
+        if pairs:
+            wmax = max(w for _, w in pairs)
+            Pp = [(f, w) for f, w in pairs if w >= 0.9 * wmax]
+            Rr = [(f, w) for f, w in pairs if 0.2 * wmax <= w <= 0.45 * wmax and f >= 0.5 * max(q for q, _ in pairs)]
+            for key, sel in (("level0_prolongation", Pp), ("level0_restriction", Rr)):
+                if sel:
+                    f, w = statistics.median([q for q, _ in sel]), statistics.median([q for _, q in sel])
+                    out[key + "_bytes_per_launch"] = fetch_factor * f * 1024 + write_factor * w * 1024
+                    out[key] = {"kernel": "k_spmv_stream<0, false, true, false> (value-coded level-0 transfer operator)", "launches": len(sel),
+                                "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
+    out["round"] = os.path.basename(tag)
     json.dump(out, open(os.path.join(os.path.dirname(tag) or ".", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
