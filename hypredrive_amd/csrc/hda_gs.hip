@@ -167,7 +167,10 @@ __global__ __launch_bounds__(1024) void k_gs_levels_fused(int l0, int l1, int ba
    }
 }
 
-template <int LPR>
+// LPR lanes per row in the per-level launches, FL in the single-workgroup runs of small levels: there a level is a few
+// hundred rows at most and every round of rows is a chain of dependent loads (permutation, row pointer, entries, x), so
+// the narrower group -- four times the rows in flight -- wins over the wider reduction
+template <int LPR, int FL>
 static void gs_sweep_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, double *x, bool forward)
 {
    const int ns = (int)p.segments.size();
@@ -181,7 +184,7 @@ static void gs_sweep_t(const DCsr &A, const GsPlan &p, const double *dinv, const
          k_gs_level<LPR><<<grid, 256, 0, STREAM>>>(first, count, p.perm.data(), A.rowptr.data(), A.col.data(), A.val.data(), dinv, b, x);
       }
       else
-         k_gs_levels_fused<LPR><<<1, 1024, 0, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
+         k_gs_levels_fused<FL><<<1, 1024, 0, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
                                                       A.rowptr.data(), A.col.data(), A.val.data(), dinv, b, x);
    }
 }
@@ -193,9 +196,9 @@ void gs_sweep(const DCsr &A, const GsPlan &plan, const double *dinv, const doubl
    HDA_REQUIRE(plan.built, "Gauss-Seidel plan missing");
    if (A.nrows == 0) return;
    const double a = A.avg_row();
-   if (a <= 10.0) gs_sweep_t<8>(A, plan, dinv, b, x, forward);
-   else if (a <= 40.0) gs_sweep_t<32>(A, plan, dinv, b, x, forward);
-   else gs_sweep_t<64>(A, plan, dinv, b, x, forward);
+   if (a <= 10.0) gs_sweep_t<8, 4>(A, plan, dinv, b, x, forward);
+   else if (a <= 40.0) gs_sweep_t<32, 8>(A, plan, dinv, b, x, forward);
+   else gs_sweep_t<64, 16>(A, plan, dinv, b, x, forward);
 }
 
 } // namespace hda
