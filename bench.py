@@ -29,6 +29,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 YAML = "solver: pcg\npreconditioner:\n  preset: poisson\n"
+# BASELINE config 5 (--workload aniso): GMRES(30) + BoomerAMG with the ILU(0) complex smoother on level 0, Jacobi-iterative
+# triangular solves (reference examples/ex8.yml variant 4 block; src/internal/amg.c:899-921, ilu.c:21-23)
+YAML_ANISO = ("solver:\n  gmres:\n    relative_tol: 1.0e-6\npreconditioner:\n  amg:\n    smoother:\n      type: ilu\n      num_levels: 1\n"
+              "      ilu:\n        type: bj-iluk\n        tri_solve: 0\n")
 
 
 def spmv_bytes(nrows, ncols, nnz):
@@ -159,8 +163,22 @@ def run(args):
     if w.size > 1 and ndev >= w.size and transport != "rccl" and not os.environ.get("HDA_TRANSPORT"):
         # one GPU per rank is there: a host-staged transport would be a silent fallback, not a measurement
         raise SystemExit(f"bench.py: {w.size} ranks with {ndev} visible GPUs must run on RCCL, transport is '{transport}'")
-    h = hd.Hypredrv(YAML)
-    h.set_laplacian7(gn, P)
+    aniso = args.workload == "aniso"
+    if aniso:
+        # a heterogeneous anisotropic reservoir operator (hypredrive_amd/synthetic.py; SPE10 itself is unreachable offline), the
+        # global n^3 system cut into contiguous row blocks (z slabs): every rank hands over its rows as CSR arrays
+        from hypredrive_amd.synthetic import spe10_like
+        weak, P, gn, N = False, (1, 1, w.size), (n, n, n), n ** 3
+        ip, ix, v, b = spe10_like(n)
+        lo, hi = w.rank * N // w.size, (w.rank + 1) * N // w.size
+        h = hd.Hypredrv(YAML_ANISO)
+        h.set_matrix_csr(lo, hi - 1, ip[lo:hi + 1] - ip[lo], ix[ip[lo]:ip[hi]], v[ip[lo]:ip[hi]])
+        h.set_rhs_array(lo, hi - 1, b[lo:hi])
+        h.finish_system()
+        del ip, ix, v, b
+    else:
+        h = hd.Hypredrv(YAML)
+        h.set_laplacian7(gn, P)
     # the reference's protocol is one warm-up run, then the timed ones (scripts/node_scaling.sh): the first setup of a
     # process also pays for device-memory allocation (bimodal, 0.03-0.9 s on these boxes), the second one runs out of the
     # library's caching allocator and is the "prec" timer proper
@@ -187,7 +205,15 @@ def run(args):
     dom = max(range(len(lv_nnz)), key=lambda l: (0 if (l == 0 and fb0["coded"]) else lv_nnz[l])) if lv_nnz else 0
     Ad = amg.level_matrix(dom, 0)
     hh.probe_spmv(None, 0)
-    probes = {"dom": hh._lib.probe_add(Ad, 2), "k1": hh._lib.probe_add(A, 0)}
+    dom_mode = 2
+    if aniso and amg.num_levels > 1:
+        # with ILU(0) on level 0 the largest l1-Jacobi sweep is the level-1 one; the level-0 operator is applied in the smoother's
+        # residuals and GMRES' products (k1)
+        dom = max(range(1, len(lv_nnz)), key=lambda l: lv_nnz[l]) if len(lv_nnz) > 1 else 0
+        Ad = amg.level_matrix(dom, 0)
+    probes = {"dom": hh._lib.probe_add(Ad, dom_mode), "k1": hh._lib.probe_add(A, 0)}
+    if aniso:
+        probes["res0"] = hh._lib.probe_add(A, 1)
     if amg.num_levels > 1:
         P0, R0 = amg.level_matrix(0, 1), amg.level_matrix(0, 2)
         probes["P0"] = hh._lib.probe_add(P0, 0)
@@ -235,12 +261,16 @@ def run(args):
                 traffic = {}
         per_it = 1.0 / max(iters * args.steps, 1)
         out = {
-            "metric": "DOF/s, AMG-PCG solve phase, 3D 7-pt Laplacian",
+            "metric": "DOF/s, GMRES+AMG(ILU0 smoother) solve phase, anisotropic heterogeneous diffusion" if aniso
+                      else "DOF/s, AMG-PCG solve phase, 3D 7-pt Laplacian",
             "value": N / (ms_per_step * 1e-3), "unit": "DOF/s",
             "n_gpus": w.size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"lap7 {gn[0]}x{gn[1]}x{gn[2]} fp64 AMG-PCG (PMIS, ext+i Pmax 4, l1-Jacobi V(1,1), GE coarse), "
+            "config": {"workload": (f"spe10-like {n}^3 fp64 (7-pt finite volumes, log-normal permeability over 3 decades, k_v/k_h 1e-3; "
+                                    "hypredrive_amd/synthetic.py), GMRES(30) + BoomerAMG (PMIS, ext+i Pmax 4, V(1,1): ILU(0) smoother on level 0 "
+                                    "with Jacobi-iterative triangular solves, l1-Jacobi below), BASELINE config 5 stand-in") if aniso else
+                                   f"lap7 {gn[0]}x{gn[1]}x{gn[2]} fp64 AMG-PCG (PMIS, ext+i Pmax 4, l1-Jacobi V(1,1), GE coarse), "
                                    + ("BASELINE config 2" if (w.size == 1 and n == 256) else
                                       "BASELINE config 3" if (w.size == 8 and weak and n == 256) else f"{n}^3 per rank" if weak else "fixed size"),
                        "rows": N, "rows_per_rank": a_n, "parallelism": f"row blocks {P[0]}x{P[1]}x{P[2]}, one process per GPU",
@@ -264,7 +294,7 @@ def run(args):
             "solve_phase_format_gbs": gbs(by[1], ms_per_step), "solve_phase_format_frac": gbs(by[1], ms_per_step) / (HBM_PEAK_GBS * w.size),
             "dof_iters_per_s": N * iters / (ms_per_step * 1e-3),
             "roofline": {"kernel": f"k_spmv_stream<JACOBI> on rank 0's block of the level-{dom} operator ({dn} rows, {dnnz} nnz, plain CSR): "
-                                   f"largest share of the solve, {dom_count} launches timed inside it",
+                                   + ("largest l1-Jacobi sweep of the cycle" if aniso else "largest share of the solve") + f", {dom_count} launches timed inside it",
                          "bound": "hbm", "achieved": gbs(dom_bytes, dom_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs(dom_bytes, dom_ms) / HBM_PEAK_GBS,
                          "traffic": traffic.get(f"k_spmv_stream_jacobi_level{dom}_bytes_per_launch") if w.size == 1 and n == 256 else None,
@@ -288,7 +318,16 @@ def run(args):
                 bts = spmv_bytes(mn, mc, mnnz) + extra * mn  # P: x += P e reads x too
                 out[key] = {"rows": mn, "cols": mc, "nnz": mnnz, "avg_ms": ms, "launches": cnt, "csr_bytes_per_launch": bts,
                             "csr_equiv_gbs": gbs(bts, ms), "csr_equiv_frac": gbs(bts, ms) / HBM_PEAK_GBS}
-        if w.size == 1:
+        if aniso:  # the byte model behind these four is the PCG iteration's: not quoted for GMRES
+            for k in ("solve_phase_hbm_gbs", "solve_phase_hbm_frac", "solve_phase_format_gbs", "solve_phase_format_frac"):
+                out[k] = None
+        if "res0" in pr:
+            ms, cnt = pr["res0"]
+            bts = spmv_bytes(a_n, a_c, a_nnz) + 8.0 * a_n
+            out["level0_residual"] = {"kernel": "k_spmv_stream<RESID> on the level-0 operator (plain CSR), inside the ILU(0) smoothing steps",
+                                      "avg_ms": ms, "launches": cnt, "csr_bytes_per_launch": bts, "csr_equiv_gbs": gbs(bts, ms),
+                                      "csr_equiv_frac": gbs(bts, ms) / HBM_PEAK_GBS}
+        if w.size == 1 and not aniso:
             single_extras(args, out, hh, A, amg, fb0, iters)
     del A, amg
     h.destroy_solver()
@@ -346,7 +385,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per dimension (per rank; global with --strong)")
+    ap.add_argument("--grid", dest="n", type=int, default=0, help="grid points per dimension (per rank; global with --strong or "
+                    "--workload aniso); default 256 (lap7) / 128 (aniso)")
+    ap.add_argument("--workload", choices=["lap7", "aniso"], default="lap7", help="lap7: BASELINE configs 2 / 3 (the headline metric). aniso: "
+                    "BASELINE config 5 stand-in, GMRES + AMG with the ILU(0) smoother on a heterogeneous anisotropic reservoir operator")
     ap.add_argument("--cpu-sample", type=int, default=0, help="grid size of the CPU-baseline run (default: the benchmark's own --grid; "
                     "256^3 takes about 2 minutes of host time, most of it the oracle's setup)")
     ap.add_argument("--strong", action="store_true", help="N > 1: --grid is the GLOBAL problem, cut into N blocks (fixed-size series). Default is "
@@ -357,6 +399,8 @@ def main():
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-plain-csr", action="store_true")
     args = ap.parse_args()
+    if args.n <= 0:
+        args.n = 128 if args.workload == "aniso" else 256
     world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world is None:
         sys.exit(spawn_ranks(args))

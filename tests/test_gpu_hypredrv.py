@@ -690,6 +690,51 @@ def test_yaml_amg_ilu_smoother_matches_oracle(hd, orc, nl, ns, ts):
     h.close()
 
 
+SPE10_YAML = ("solver:\n  gmres:\n    relative_tol: 1.0e-6\npreconditioner:\n  amg:\n    smoother:\n      type: ilu\n      num_levels: 1\n"
+              "      ilu:\n        type: bj-iluk\n        tri_solve: 0\n")
+
+
+@pytest.mark.parametrize("via", ["csr", "mtx"])
+def test_spe10_like_gmres_amg_ilu_matches_oracle(hd, orc, tmp_path, via):
+    """BASELINE config 5 in the small: a heterogeneous, anisotropic (k_v / k_h = 1e-3, three decades of log-normal
+    permeability) 7-point reservoir operator -- hypredrive_amd/synthetic.py stands in for SPE10, which is unreachable offline --
+    solved by GMRES(30) + BoomerAMG with the ILU(0) complex smoother on level 0 (Jacobi-iterative triangular solves).  Nothing in
+    this hierarchy is constant-coefficient, so every operator runs through the plain-CSR kernels.  Handed over as CSR arrays
+    (HYPREDRV_LinearSystemSetMatrixFromCSR) and as a Matrix Market file (linear_system.type mtx, reference linsys.c:986): the
+    oracle's iteration count and solution."""
+    import scipy.sparse as sp
+    from hypredrive_amd.synthetic import spe10_like
+    n = 40
+    N = n ** 3
+    ip, ix, v, b = spe10_like(n)
+    S = sp.csr_matrix((v, ix, ip), shape=(N, N))
+    Ao = orc.Csr.from_scipy(S)
+    ao = orc.Amg(Ao, orc.amg_params(True))
+    ao.set_ilu_smoother(num_levels=1, num_sweeps=1, tri_solve=0)
+    ref = orc.gmres(Ao, b, ao, orc.krylov_params(True))
+    plain = orc.gmres(Ao, b, orc.Amg(Ao, orc.amg_params(True)), orc.krylov_params(True))
+    assert ref["converged"] and ref["iters"] < plain["iters"]  # the smoother earns its keep on this operator
+    if via == "csr":
+        h = hd.Hypredrv(SPE10_YAML)
+        h.set_matrix_csr(0, N - 1, ip, ix, v)
+        h.set_rhs_array(0, N - 1, b)
+        h.finish_system()
+    else:
+        M = S.tocoo()
+        with open(tmp_path / "A", "w") as f:
+            f.write("%%MatrixMarket matrix coordinate real general\n")
+            f.write(f"{N} {N} {M.nnz}\n")
+            for i, j, q in zip(M.row, M.col, M.data):
+                f.write(f"{i + 1} {j + 1} {q:.17g}\n")
+        h = hd.Hypredrv(f"linear_system:\n  type: mtx\n  matrix_filename: {tmp_path}/A\n  rhs_mode: ones\n" + SPE10_YAML)
+        hd.check(hd.lib().HYPREDRV_LinearSystemBuild(h.h))
+        ref = orc.gmres(Ao, np.ones(N), ao, orc.krylov_params(True))
+    r = h.solve()
+    assert r["converged"] and r["iters"] == ref["iters"], (r["iters"], ref["iters"])
+    assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-7
+    h.close()
+
+
 def test_yaml_unimplemented_ilu_variants_fail_loudly(hd):
     for extra in ("type: bj-ilut", "fill_level: 1", "reordering: 1"):
         h = hd.Hypredrv("solver: gmres\npreconditioner:\n  ilu:\n    " + extra + "\n")
