@@ -124,9 +124,26 @@ class RcclComm : public Comm {
       memcpy(id.b, uid, 128);
       typedef int (*Init_t)(void **, int, Uid128, int);
       HDA_NCCL(((Init_t)rccl().CommInitRank)(&comm_, s, id, r));
+      // A second communicator carries the neighbour exchanges: they run on the communication stream beside product kernels
+      // and beside the all-reduces of the main stream.  Two communicators driven from two streams in the same order on every
+      // rank is the documented-safe way to have RCCL operations in flight concurrently.  Its id is made by rank 0 and handed
+      // round through the first communicator (a byte-wise sum with zeros from everybody else).
+      if (s > 1)
+      {
+         Uid128 id2;
+         memset(&id2, 0, sizeof(id2));
+         if (r == 0) HDA_NCCL(rccl().GetUniqueId(&id2));
+         DArray<char> d(128);
+         HDA_HIP(hipMemcpyAsync(d.data(), id2.b, 128, hipMemcpyHostToDevice, STREAM));
+         HDA_NCCL(rccl().AllReduce(d.data(), d.data(), 128, kInt8, kSum, comm_, STREAM));
+         HDA_HIP(hipMemcpyAsync(id2.b, d.data(), 128, hipMemcpyDeviceToHost, STREAM));
+         Context::get().sync();
+         HDA_NCCL(((Init_t)rccl().CommInitRank)(&halo_comm_, s, id2, r));
+      }
    }
    ~RcclComm() override
    {
+      if (halo_comm_) rccl().CommDestroy(halo_comm_);
       if (comm_) rccl().CommDestroy(comm_);
    }
    void allreduce_sum_dev(double *d, int n) override
@@ -138,12 +155,13 @@ class RcclComm : public Comm {
    void exchange_dev(const double *send, const int *sc, double *recv, const int *rc, hipStream_t st) override
    {
       stats.exchange++;
+      void *cm = halo_comm_ ? halo_comm_ : comm_;
       HDA_NCCL(rccl().GroupStart());
       size_t so = 0, ro = 0;
       for (int p = 0; p < size; p++)
       {
-         if (sc[p]) HDA_NCCL(rccl().Send(send + so, (size_t)sc[p], kF64, p, comm_, st));
-         if (rc[p]) HDA_NCCL(rccl().Recv(recv + ro, (size_t)rc[p], kF64, p, comm_, st));
+         if (sc[p]) HDA_NCCL(rccl().Send(send + so, (size_t)sc[p], kF64, p, cm, st));
+         if (rc[p]) HDA_NCCL(rccl().Recv(recv + ro, (size_t)rc[p], kF64, p, cm, st));
          so += (size_t)sc[p];
          ro += (size_t)rc[p];
       }
@@ -187,7 +205,7 @@ class RcclComm : public Comm {
    const char *name() const override { return "rccl"; }
 
  private:
-   void *comm_ = nullptr;
+   void *comm_ = nullptr, *halo_comm_ = nullptr; // collectives on the library stream / neighbour exchanges (any stream)
 };
 
 // ------------------------------------------------------------ host-staged callbacks

@@ -315,7 +315,7 @@ def test_overlapped_halo_exchange_matches_the_serial_one(tmp_path):
     values travel on the communication stream; the ghost-column part is added afterwards (k_offd_fix).  Against the
     path that finishes every exchange first (HDA_OVERLAP=0): same iteration count, solution to rounding (the row sums
     are split in two), and every exchange of the solve was an overlapped one."""
-    a, xa = _dist_solve(tmp_path, "ovl", 4, 24, 29673, HDA_REPLICATE_ROWS="700")
+    a, xa = _dist_solve(tmp_path, "ovl", 4, 24, 29673, HDA_REPLICATE_ROWS="700", HDA_OVERLAP="1")
     b, xb = _dist_solve(tmp_path, "ser", 4, 24, 29674, HDA_REPLICATE_ROWS="700", HDA_OVERLAP="0")
     assert a["iters"] == b["iters"]
     assert np.linalg.norm(xa - xb) <= 1e-12 * np.linalg.norm(xb)

@@ -113,7 +113,8 @@ def test_lifecycle_guards_and_error_bits(hd):
     assert L.HYPREDRV_LinearSolverApply(None) & hd.ERROR_UNKNOWN_HYPREDRV_OBJ
     L.HYPREDRV_ErrorCodeClear()
     # out-of-path entry points report instead of silently succeeding
-    assert L.HYPREDRV_LinearSystemSetNullSpace(h.h, 2, 1, None) & hd.ERROR_UNSUPPORTED_AMD
+    # null-space modes before a matrix is set: a clean ERROR_INVALID_VAL (reference tests/test_hypredrv.c:4224-4226)
+    assert L.HYPREDRV_LinearSystemSetNullSpace(h.h, 2, 1, None) & hd.ERROR_INVALID_VAL
     L.HYPREDRV_ErrorCodeClear()
     # dofmaps are host-side bookkeeping (they feed BoomerAMG's dof_func): valid without a GPU, validated
     dm = (C.c_int * 2)(0, 1)
