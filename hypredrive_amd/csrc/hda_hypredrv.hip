@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <csignal>
 #include <cstring>
@@ -2178,6 +2179,34 @@ extern "C" uint32_t HYPREDRV_StatsPrint(HYPREDRV_t h)
       else
          printf("| %*s | %*s | %*.*f | %*.*f | %*.*e | %*.*e | %*d |\n", w[0], label, w[1], "", w[2], 3, tf * e.prec, w[3], 3, tf * e.solve,
                 w[4], 2, e.r0, w[5], 2, e.rr, w[6], e.iters);
+   }
+   // general.statistics >= 2: aggregate rows inside the same table (reference src/internal/stats.c:1262-1358)
+   if (idx > 1 && h->args.general.statistics > 1)
+   {
+      struct Agg {
+         double mn = HUGE_VAL, mx = 0.0, sum = 0.0, ssq = 0.0;
+         void   add(double v) { mn = std::min(mn, v); mx = std::max(mx, v); sum += v; ssq += v * v; }
+         double avg(int n) const { return sum / n; }
+         double sd(int n) const { const double a = avg(n), var = ssq / n - a * a; return std::sqrt(var > 0.0 ? var : 0.0); } // clamped as StatsVarianceClamp does
+      } b, st, sv, r0, rr, it;
+      int imin = INT_MAX, imax = 0, isum = 0;
+      for (const StatEntry &e : s.entries)
+      {
+         if (!e.has_solve) continue;
+         b.add(tf * e.build); st.add(tf * e.prec); sv.add(tf * e.solve); r0.add(e.r0); rr.add(e.rr); it.add((double)e.iters);
+         imin = std::min(imin, e.iters); imax = std::max(imax, e.iters); isum += e.iters;
+      }
+      const int n = idx;
+      divisor();
+      printf("| %*s | %*.*f | %*.*f | %*.*f | %*.*e | %*.*e | %*d |\n", w[0], "Min.", w[1], 3, b.mn, w[2], 3, st.mn, w[3], 3, sv.mn, w[4], 2, r0.mn, w[5], 2, rr.mn,
+             w[6], imin);
+      printf("| %*s | %*.*f | %*.*f | %*.*f | %*.*e | %*.*e | %*d |\n", w[0], "Max.", w[1], 3, b.mx, w[2], 3, st.mx, w[3], 3, sv.mx, w[4], 2, r0.mx, w[5], 2, rr.mx,
+             w[6], imax);
+      printf("| %*s | %*.*f | %*.*f | %*.*f | %*.*e | %*.*e | %*.1f |\n", w[0], "Avg.", w[1], 3, b.avg(n), w[2], 3, st.avg(n), w[3], 3, sv.avg(n), w[4], 2,
+             r0.avg(n), w[5], 2, rr.avg(n), w[6], it.avg(n));
+      printf("| %*s | %*.*f | %*.*f | %*.*f | %*.*e | %*.*e | %*.1f |\n", w[0], "Std.", w[1], 3, b.sd(n), w[2], 3, st.sd(n), w[3], 3, sv.sd(n), w[4], 2,
+             r0.sd(n), w[5], 2, rr.sd(n), w[6], it.sd(n));
+      printf("| %*s | %*.*f | %*.*f | %*.*f | %*s | %*s | %*d |\n", w[0], "Total", w[1], 3, b.sum, w[2], 3, st.sum, w[3], 3, sv.sum, w[4], "", w[5], "", w[6], isum);
    }
    divisor();
    printf("\n");

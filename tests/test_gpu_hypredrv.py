@@ -239,6 +239,25 @@ def test_null_space_projection(hd):
     h.close()
 
 
+def test_cli_statistics_level_2_aggregate_rows():
+    """general.statistics: 2 appends Min. / Max. / Avg. / Std. / Total rows to the table (reference src/internal/stats.c:1262-1358):
+    same column widths and formats, Total leaves the residual columns blank and sums the iterations."""
+    cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
+    r = subprocess.run([cli, "-q", "examples/ex8-multi-1.yml", "-a", "--general:statistics", "2"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    its = [int(q) for q in re.findall(r"^\|\s+\d+ \|.*\|\s+(\d+) \|$", r.stdout, re.M)]
+    assert len(its) == 4
+    agg = dict(re.findall(r"^\|\s+(Min\.|Max\.|Avg\.|Std\.|Total) \|.*\|\s+(\S+) \|$", r.stdout, re.M))
+    assert set(agg) == {"Min.", "Max.", "Avg.", "Std.", "Total"}
+    assert int(agg["Min."]) == min(its) and int(agg["Max."]) == max(its) and int(agg["Total"]) == sum(its)
+    assert float(agg["Avg."]) == pytest.approx(sum(its) / 4, abs=0.05)
+    total = re.search(r"^\|\s+Total \|\s+[\d.]+ \|\s+[\d.]+ \|\s+[\d.]+ \|\s+\|\s+\|\s+\d+ \|$", r.stdout, re.M)
+    assert total, r.stdout
+    # level 1 (the default) prints none of them
+    r1 = subprocess.run([cli, "-q", "examples/ex8-multi-1.yml"], capture_output=True, text=True, cwd=ROOT)
+    assert "Total" not in r1.stdout
+
+
 def test_cli_overrides():
     cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
     r = subprocess.run([cli, "-q", "examples/ex1.yml", "-a", "--solver:pcg:max_iter", "3"], capture_output=True, text=True, cwd=ROOT)
