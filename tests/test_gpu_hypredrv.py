@@ -239,6 +239,27 @@ def test_null_space_projection(hd):
     h.close()
 
 
+def test_cli_output_matches_the_reference_golden_output(tmp_path):
+    """the reference keeps its drivers' outputs under examples/refOutput and compares them with
+    scripts/compare_output.sh.  The same comparison here (tools/compare_output.py: dates / versions / executable path normalised,
+    timing columns masked, the relative residual compared as a number within 2 %): `hypredrive-cli examples/ex1.yml` with the
+    reference's CPU-build defaults reproduces examples/refOutput/ex1.txt -- echoed input tree, banners, table frame, 1000 rows /
+    6400 nonzeros, r0 3.16e+01, 6 iterations -- line for line.  The golden file is the reference's own test fixture
+    (tests/golden/refOutput/ex1.txt)."""
+    cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
+    r = subprocess.run([cli, "examples/ex1.yml"], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, HYPREDRV_AMD_DEFAULTS="cpu"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    (tmp_path / "ex1.out").write_text(r.stdout)
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compare_output.py"), str(tmp_path / "ex1.out"),
+                        os.path.join(ROOT, "tests", "golden", "refOutput", "ex1.txt")], capture_output=True, text=True)
+    assert c.returncode == 0, c.stdout
+    # and it does catch a wrong iteration count
+    (tmp_path / "bad.out").write_text(re.sub(r"\|      6 \|", "|      7 |", r.stdout))
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compare_output.py"), str(tmp_path / "bad.out"),
+                        os.path.join(ROOT, "tests", "golden", "refOutput", "ex1.txt")], capture_output=True, text=True)
+    assert c.returncode == 1 and "iterations differ" in c.stdout
+
+
 def test_cli_statistics_level_2_aggregate_rows():
     """general.statistics: 2 appends Min. / Max. / Avg. / Std. / Total rows to the table (reference src/internal/stats.c:1262-1358):
     same column widths and formats, Total leaves the residual columns blank and sums the iterations."""
