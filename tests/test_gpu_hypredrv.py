@@ -253,6 +253,15 @@ def test_cli_output_matches_the_reference_golden_output(tmp_path):
     c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compare_output.py"), str(tmp_path / "ex1.out"),
                         os.path.join(ROOT, "tests", "golden", "refOutput", "ex1.txt")], capture_output=True, text=True)
     assert c.returncode == 0, c.stdout
+    # the reference's own driver, unmodified (oracle/_ref/laplacian_ref), against examples/refOutput/laplacian.txt: five solves, 5 iterations each
+    drv = os.path.join(ROOT, "oracle", "_ref", "laplacian_ref")
+    if os.path.exists(drv):
+        d = subprocess.run([drv], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, HYPREDRV_AMD_DEFAULTS="cpu"))
+        assert d.returncode == 0, d.stdout + d.stderr
+        (tmp_path / "lap.out").write_text(d.stdout)
+        c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compare_output.py"), str(tmp_path / "lap.out"),
+                            os.path.join(ROOT, "tests", "golden", "refOutput", "laplacian.txt")], capture_output=True, text=True)
+        assert c.returncode == 0, c.stdout
     # and it does catch a wrong iteration count
     (tmp_path / "bad.out").write_text(re.sub(r"\|      6 \|", "|      7 |", r.stdout))
     c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compare_output.py"), str(tmp_path / "bad.out"),
