@@ -52,6 +52,10 @@ struct AmgParams {
 // dependency levels of the local pattern for Gauss-Seidel sweeps (hda_gs.hip)
 struct GsPlan {
    DArray<int>                      perm;      // rows grouped by level, ascending inside a level
+   mutable const int               *span_rp = nullptr; // the row pointer array the spans below were read from (a reused hierarchy is
+   mutable int                      span_nnz = -1;     // applied with the level-0 matrix of the call: spans follow it, gs_sweep checks)
+   mutable DArray<int>              rbeg, rend; // first / past-the-end entry of the row at every sorted position (rowptr[perm[q]], rowptr[perm[q] + 1]):
+                                               // read coalesced with perm, so a sweep does not chase row id -> row pointer -> entries
    DArray<int>                      d_lvl_ptr; // device copy of lvl_ptr
    std::vector<int>                 lvl_ptr;   // nlev + 1 offsets into perm
    std::vector<std::pair<int, int>> segments;  // launch groups [first level, last level)

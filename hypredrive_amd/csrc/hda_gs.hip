@@ -68,6 +68,22 @@ __global__ __launch_bounds__(256) void k_gs_mark(int n, const int *__restrict__ 
    if (q < n) level_of_row[perm[q]] = lvl_of_pos[q];
 }
 
+__global__ __launch_bounds__(256) void k_gs_rowspan(int n, const int *__restrict__ perm, const int *__restrict__ rp, int *__restrict__ rbeg,
+                                                    int *__restrict__ rend)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) { rbeg[q] = rp[perm[q]]; rend[q] = rp[perm[q] + 1]; }
+}
+
+static void gs_row_spans(const DCsr &A, const GsPlan &plan)
+{
+   const int n = A.nrows;
+   if (plan.rbeg.size() != (size_t)n) { plan.rbeg.alloc((size_t)n); plan.rend.alloc((size_t)n); }
+   if (n) k_gs_rowspan<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), plan.rbeg.data(), plan.rend.data());
+   plan.span_rp  = A.rowptr.data();
+   plan.span_nnz = A.nnz;
+}
+
 void build_gs_plan(const DCsr &A, GsPlan &plan)
 {
    const int n = A.nrows;
@@ -122,21 +138,22 @@ void build_gs_plan(const DCsr &A, GsPlan &plan)
       L = E;
    }
    plan.d_lvl_ptr.upload(plan.lvl_ptr.data(), plan.lvl_ptr.size());
+   gs_row_spans(A, plan);
    Context::get().sync();
 }
 
 // x_i += dinv_i * (b_i - sum_j a_ij x_j) for the rows of one level; LPR lanes per row
 template <int LPR>
 __device__ __forceinline__ void gs_rows(int first, int count, int tid, int nthreads, const int *__restrict__ perm,
-                                        const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
-                                        const double *__restrict__ dinv, const double *__restrict__ b, double *x)
+                                        const int *__restrict__ rbeg, const int *__restrict__ rend, const int *__restrict__ cj,
+                                        const double *__restrict__ v, const double *__restrict__ dinv, const double *__restrict__ b, double *x)
 {
    const int lane = tid & (LPR - 1);
    for (int q = tid / LPR; q < count; q += nthreads / LPR)
    {
-      const int i = perm[first + q];
+      const int i = perm[first + q], k0 = rbeg[first + q], k1 = rend[first + q]; // three independent coalesced loads
       double    s = 0.0;
-      for (int k = rp[i] + lane; k < rp[i + 1]; k += LPR) s += v[k] * x[cj[k]];
+      for (int k = k0 + lane; k < k1; k += LPR) s += v[k] * x[cj[k]];
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
       if (lane == 0) x[i] += dinv[i] * (b[i] - s);
@@ -144,24 +161,25 @@ __device__ __forceinline__ void gs_rows(int first, int count, int tid, int nthre
 }
 
 template <int LPR>
-__global__ __launch_bounds__(256) void k_gs_level(int first, int count, const int *__restrict__ perm, const int *__restrict__ rp,
-                                                  const int *__restrict__ cj, const double *__restrict__ v,
+__global__ __launch_bounds__(256) void k_gs_level(int first, int count, const int *__restrict__ perm, const int *__restrict__ rbeg,
+                                                  const int *__restrict__ rend, const int *__restrict__ cj, const double *__restrict__ v,
                                                   const double *__restrict__ dinv, const double *__restrict__ b, double *x)
 {
-   gs_rows<LPR>(first, count, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, perm, rp, cj, v, dinv, b, x);
+   gs_rows<LPR>(first, count, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, perm, rbeg, rend, cj, v, dinv, b, x);
 }
 
 // levels [l0, l1) by ONE workgroup of 16 wavefronts, forward or backward, a barrier between levels
+// (requesting the next level's row ids, spans and first entries before the barrier was measured: no gain, 363 -> 372 ms at 128^3)
 template <int LPR>
 __global__ __launch_bounds__(1024) void k_gs_levels_fused(int l0, int l1, int backward, const int *__restrict__ lvl_ptr,
-                                                         const int *__restrict__ perm, const int *__restrict__ rp,
-                                                         const int *__restrict__ cj, const double *__restrict__ v,
+                                                         const int *__restrict__ perm, const int *__restrict__ rbeg,
+                                                         const int *__restrict__ rend, const int *__restrict__ cj, const double *__restrict__ v,
                                                          const double *__restrict__ dinv, const double *__restrict__ b, double *x)
 {
    for (int s = 0; s < l1 - l0; s++)
    {
       const int L = backward ? (l1 - 1 - s) : (l0 + s);
-      gs_rows<LPR>(lvl_ptr[L], lvl_ptr[L + 1] - lvl_ptr[L], threadIdx.x, blockDim.x, perm, rp, cj, v, dinv, b, x);
+      gs_rows<LPR>(lvl_ptr[L], lvl_ptr[L + 1] - lvl_ptr[L], threadIdx.x, blockDim.x, perm, rbeg, rend, cj, v, dinv, b, x);
       __threadfence_block();
       __syncthreads();
    }
@@ -181,11 +199,11 @@ static void gs_sweep_t(const DCsr &A, const GsPlan &p, const double *dinv, const
       {
          const int first = p.lvl_ptr[(size_t)sg.first], count = p.lvl_ptr[(size_t)sg.first + 1] - first;
          const int grid  = std::min(ceil_div((long long)count * LPR, 256), 2048);
-         k_gs_level<LPR><<<grid, 256, 0, STREAM>>>(first, count, p.perm.data(), A.rowptr.data(), A.col.data(), A.val.data(), dinv, b, x);
+         k_gs_level<LPR><<<grid, 256, 0, STREAM>>>(first, count, p.perm.data(), p.rbeg.data(), p.rend.data(), A.col.data(), A.val.data(), dinv, b, x);
       }
       else
          k_gs_levels_fused<FL><<<1, 1024, 0, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
-                                                      A.rowptr.data(), A.col.data(), A.val.data(), dinv, b, x);
+                                                      p.rbeg.data(), p.rend.data(), A.col.data(), A.val.data(), dinv, b, x);
    }
 }
 
@@ -195,6 +213,7 @@ void gs_sweep(const DCsr &A, const GsPlan &plan, const double *dinv, const doubl
 {
    HDA_REQUIRE(plan.built, "Gauss-Seidel plan missing");
    if (A.nrows == 0) return;
+   if (plan.span_rp != A.rowptr.data() || plan.span_nnz != A.nnz) gs_row_spans(A, plan); // another matrix behind a kept plan (preconditioner.reuse)
    const double a = A.avg_row();
    if (a <= 10.0) gs_sweep_t<8, 4>(A, plan, dinv, b, x, forward);
    else if (a <= 40.0) gs_sweep_t<32, 8>(A, plan, dinv, b, x, forward);
