@@ -178,11 +178,17 @@ struct DCsr {
    mutable int                        rowcoded = 0, rc_esc_rows = 0;
    mutable long long                  rc_esc_entries = 0;
    mutable std::unique_ptr<OffdPart> offd; // ghost-column part, for products overlapped with their halo exchange
+   // windowed form of the column indices (hda_kernels.hip "windowed CSR"): chunks of ~1024 entries (whole rows); per chunk the
+   // ascending list of its DISTINCT columns (ucol[uoff[c] .. uoff[c+1])) and per entry the 2-byte position of its column in it
+   mutable DArray<unsigned short> lidx;          // nnz
+   mutable DArray<int>            ucol, wmeta;   // distinct columns; 3 ints per chunk + sentinel: first row, first entry, first distinct
+   mutable int                    win = -1, nwin = 0, win_maxu = 0; // -1 not examined, 0 plain, 1 windowed; chunks; most distinct columns in a chunk
+   mutable long long              win_total = 0;
    void reset_plan() const
    {
       chunk_row.release(); code.release(); dict_val.release(); dict_delta.release(); offd.reset();
-      rclass.release(); rc_keys.release();
-      nchunks = 0; maxrow = -1; coded = -1; rowcoded = 0; rc_esc_rows = 0; rc_esc_entries = 0;
+      rclass.release(); rc_keys.release(); lidx.release(); ucol.release(); wmeta.release();
+      nchunks = 0; maxrow = -1; coded = -1; rowcoded = 0; rc_esc_rows = 0; rc_esc_entries = 0; win = -1; nwin = 0; win_maxu = 0; win_total = 0;
    }
 };
 

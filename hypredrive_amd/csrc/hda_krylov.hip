@@ -183,11 +183,9 @@ static KrylovResult gmres_core(bool flexible, const LinOp &op, const PrecondFn &
    // FlexGMRES keeps the preconditioned directions z_j = M^-1 v_j and updates x with them
    std::vector<DArray<double>> Z(flexible ? (size_t)k : 0);
    for (auto &z : Z) z.alloc(vlen);
-   auto refresh = [&](double *v) { if (op.halo) halo_exchange(*op.halo, v); };
    auto true_residual = [&](double *out) { // out = b - A x, x staged through w for its ghost tail
       copy(n, x, w.data());
-      refresh(w.data());
-      residual(A, w.data(), b, out);
+      residual(A, w.data(), b, out, op.halo); // row blocks: ghost refresh under the product
    };
    std::vector<double> H((size_t)(k + 1) * k, 0.0), cs((size_t)k), sn((size_t)k), rs((size_t)k + 1);
 
@@ -231,8 +229,7 @@ static KrylovResult gmres_core(bool flexible, const LinOp &op, const PrecondFn &
          iter++;
          double *zi = flexible ? Z[(size_t)i - 1].data() : r.data();
          precond(V[i - 1].data(), zi);
-         refresh(zi);
-         spmv(A, 1.0, zi, 0.0, nullptr, V[i].data());
+         spmv(A, 1.0, zi, 0.0, nullptr, V[i].data(), op.halo);
          // modified Gram-Schmidt with the coefficients kept on the device
          for (int j = 0; j < i; j++)
          {
@@ -319,11 +316,9 @@ KrylovResult bicgstab(const LinOp &op, const PrecondFn &M, const KrylovParams &k
    KrylovResult res;
    const size_t vlen = std::max<size_t>(op.veclen, 1);
    DArray<double> r0(vlen), r(vlen), p(vlen), v(vlen), q(vlen), s(vlen), w(vlen);
-   auto refresh = [&](double *y) { if (op.halo) halo_exchange(*op.halo, y); };
    auto true_residual = [&](double *out) {
       copy(n, x, w.data());
-      refresh(w.data());
-      residual(A, w.data(), b, out);
+      residual(A, w.data(), b, out, op.halo); // row blocks: ghost refresh under the product
    };
    auto precond = [&](const double *rr, double *zz) {
       if (M) M(rr, zz, -1);
@@ -353,16 +348,14 @@ KrylovResult bicgstab(const LinOp &op, const PrecondFn &M, const KrylovParams &k
    {
       iter++;
       precond(p.data(), v.data());
-      refresh(v.data());
-      spmv(A, 1.0, v.data(), 0.0, nullptr, q.data());
+      spmv(A, 1.0, v.data(), 0.0, nullptr, q.data(), op.halo);
       const double temp = inner(r0.data(), q.data());
       if (temp == 0.0) break; // breakdown
       const double alpha = rho / temp;
       axpy(n, alpha, v.data(), x);
       axpy(n, -alpha, q.data(), r.data());
       precond(r.data(), v.data());
-      refresh(v.data());
-      spmv(A, 1.0, v.data(), 0.0, nullptr, s.data());
+      spmv(A, 1.0, v.data(), 0.0, nullptr, s.data(), op.halo);
       const double gn = inner(r.data(), s.data()), gd = inner(s.data(), s.data());
       const double gamma = (gn == 0.0 && gd == 0.0) ? 0.0 : gn / gd;
       axpy(n, gamma, v.data(), x);
