@@ -1113,7 +1113,7 @@ static void ensure_window(const DCsr &A)
    A.win = 0;
    const bool on      = !(getenv("HDA_WINDOW") && atoi(getenv("HDA_WINDOW")) == 0); // read per matrix (the parity test builds both forms)
    const long min_nnz = getenv("HDA_WINDOW_MIN_NNZ") ? atol(getenv("HDA_WINDOW_MIN_NNZ")) : (1L << 20);
-   if (!on || A.coded != 0 || A.nnz < min_nnz || A.nnz < 1 || A.maxrow > kMaxRowLds) return;
+   if (!on || A.coded == 1 || A.coded < 0 || A.nnz < min_nnz || A.nnz < 1 || A.maxrow > kMaxRowLds) return;
    const int nw = std::max(1, ceil_div(A.nnz, kWChunk));
    A.wmeta.alloc(3 * ((size_t)nw + 2));
    A.wmeta.zero();
@@ -1146,16 +1146,26 @@ static void ensure_window(const DCsr &A)
    HDA_TRACE("windowed CSR for %d x %d, nnz %d: %.3f distinct columns per entry, at most %d in a chunk", A.nrows, A.ncols, A.nnz, ratio, m);
 }
 
-template <int MODE, bool DOT, bool SPLIT>
+template <int MODE, bool DOT, bool VC, bool SPLIT>
 __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict__ wmeta, const int *__restrict__ rowptr,
                                                   const unsigned short *__restrict__ lidx, const int *__restrict__ ucol,
                                                   const double *__restrict__ val, const double *__restrict__ x, double alpha, double beta,
                                                   const double *yin, const double *__restrict__ b, const double *__restrict__ dinv,
                                                   const double *__restrict__ w, double *out, double *__restrict__ partial, int nown,
-                                                  int prod_len)
+                                                  int prod_len, const unsigned char *__restrict__ code, const double *__restrict__ dval)
 {
    extern __shared__ double smem[];
    double *prod = smem, *xs = smem + prod_len;
+   __shared__ double sdict[VC ? 256 : 1];
+   if (VC)
+   {
+      sdict[threadIdx.x] = dval[threadIdx.x];
+      __syncthreads();
+   }
+   auto value = [&](int k) -> double { // value-coded operator: one-byte code into the dictionary, 255 = read the value array
+      if (VC) { const int q = code[k]; return (q != 255) ? sdict[q] : val[k]; }
+      return val[k];
+   };
    constexpr int E = 4, U = 3; // entries / distinct columns per thread requested one chunk ahead
    const int tid = threadIdx.x;
    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
@@ -1181,7 +1191,7 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
       for (int e = 0; e < E; e++)
       {
          const int k = c.k0 + tid + 256 * e;
-         pv[e]       = (k < c.k1) ? val[k] : 0.0;
+         pv[e]       = (k < c.k1) ? value(k) : 0.0;
          pl[e]       = (k < c.k1) ? (int)lidx[k] : 0;
       }
 #pragma unroll
@@ -1217,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
          const int k = tid + 256 * e;
          if (k < ne) prod[k] = pv[e] * xs[pl[e]];
       }
-      for (int k = tid + 256 * E; k < ne; k += 256) prod[k] = val[cur.k0 + k] * xs[lidx[cur.k0 + k]];
+      for (int k = tid + 256 * E; k < ne; k += 256) prod[k] = value(cur.k0 + k) * xs[lidx[cur.k0 + k]];
       // the next chunk's streams and distinct-column list leave now and travel during the reduction
       const Chunk nxt = meta(i + nslot);
       if (nxt.ok) request(nxt);
@@ -1544,11 +1554,20 @@ static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
          const int    plen = kWChunk + A.maxrow;
          const size_t wlds = sizeof(double) * (size_t)(plen + A.win_maxu);
          const int    wg   = DOT ? gmax : std::min(gmax, ((A.nwin + 7) / 8) * 8);
-#define HDA_WIN(SPF)                                                                                                                    \
-   k_spmv_win<MODE, DOT, SPF><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(),          \
-                                                         A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen)
-         if (split) { HDA_WIN(true); }
-         else { HDA_WIN(false); }
+#define HDA_WIN(VCF, SPF, CODE, DICT)                                                                                                   \
+   k_spmv_win<MODE, DOT, VCF, SPF><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(),     \
+                                                              A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen,  \
+                                                              CODE, DICT)
+         if (A.coded == 2)
+         {
+            if (split) { HDA_WIN(true, true, A.code.data(), A.dict_val.data()); }
+            else { HDA_WIN(true, false, A.code.data(), A.dict_val.data()); }
+         }
+         else
+         {
+            if (split) { HDA_WIN(false, true, nullptr, nullptr); }
+            else { HDA_WIN(false, false, nullptr, nullptr); }
+         }
 #undef HDA_WIN
          return true;
       }
@@ -1704,9 +1723,10 @@ double matrix_stream_bytes(const DCsr &A, bool format)
       ensure_coded(A);
       if (A.coded == 1 && A.rowcoded == 1) return 1.0 * A.nrows + 12.0 * (double)A.rc_esc_entries; // one class byte per row; CSR for the rest
       if (A.coded == 1) return 1.0 * A.nnz + 12.0 * A.escapes;
-      if (A.coded == 2) return 5.0 * A.nnz + 8.0 * A.escapes;
       if (spmv_mode() == 0) ensure_window(A);
-      if (A.win == 1) return 10.0 * A.nnz + 4.0 * (double)A.win_total + 12.0 * A.nwin; // value + 2-byte position, distinct columns, chunk table
+      const double idx = (A.win == 1) ? 2.0 * A.nnz + 4.0 * (double)A.win_total + 12.0 * A.nwin : 4.0 * A.nnz; // 2-byte positions + distinct columns + chunk table, or columns
+      if (A.coded == 2) return idx + 1.0 * A.nnz + 8.0 * A.escapes;
+      if (A.win == 1) return idx + 8.0 * A.nnz;
    }
    return 12.0 * A.nnz;
 }
