@@ -244,6 +244,7 @@ def run(args):
     out = None
     if w.rank == 0:
         dn, dc, dnnz = Ad.dims
+        fbd = hh.format_bytes(Ad)
         dom_ms, dom_count = pr["dom"]
         dom_bytes = spmv_bytes(dn, dc, dnnz) + 16.0 * dn  # + b, dinv of the sweep
         a_n, a_c, a_nnz = A.dims
@@ -293,13 +294,15 @@ def run(args):
             "solve_phase_hbm_gbs": gbs(by[0], ms_per_step), "solve_phase_hbm_frac": gbs(by[0], ms_per_step) / (HBM_PEAK_GBS * w.size),
             "solve_phase_format_gbs": gbs(by[1], ms_per_step), "solve_phase_format_frac": gbs(by[1], ms_per_step) / (HBM_PEAK_GBS * w.size),
             "dof_iters_per_s": N * iters / (ms_per_step * 1e-3),
-            "roofline": {"kernel": f"k_spmv_stream<JACOBI> on rank 0's block of the level-{dom} operator ({dn} rows, {dnnz} nnz, plain CSR): "
+            "roofline": {"kernel": (f"k_spmv_win<JACOBI> on rank 0's block of the level-{dom} operator ({dn} rows, {dnnz} nnz, windowed CSR: fp64 values, "
+                                    f"2-byte column positions, {fbd['spmv'] / max(dnnz, 1):.1f} B streamed per entry all told): " if fbd["windowed"] else
+                                    f"k_spmv_stream<JACOBI> on rank 0's block of the level-{dom} operator ({dn} rows, {dnnz} nnz, plain CSR): ")
                                    + ("largest l1-Jacobi sweep of the cycle" if aniso else "largest share of the solve") + f", {dom_count} launches timed inside it",
                          "bound": "hbm", "achieved": gbs(dom_bytes, dom_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs(dom_bytes, dom_ms) / HBM_PEAK_GBS,
                          "traffic": traffic.get(f"k_spmv_stream_jacobi_level{dom}_bytes_per_launch") if w.size == 1 and n == 256 else None,
                          "traffic_source": traffic_src if w.size == 1 and n == 256 else None,
-                         "bytes_per_launch": dom_bytes, "avg_ms": dom_ms},
+                         "bytes_per_launch": dom_bytes, "format_bytes_per_launch": fbd["spmv"] + 16.0 * dn, "avg_ms": dom_ms},
             # level-0 PCG product (the north-star SpMV).  The operator is stencil-coded (1 B/entry), so the CSR-equivalent
             # rate exceeds what HBM can deliver; "format" is the honest HBM rate; plain_csr below is the uncoded kernel
             "level0_spmv": {"kernel": ("k_spmv_rowclass<PLAIN,DOT>" if fb0.get("row_coded") else "k_spmv_coded_row<PLAIN,DOT>") if fb0["coded"]

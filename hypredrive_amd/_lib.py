@@ -477,7 +477,8 @@ def format_bytes(A, amg=None):
     """Bytes really streamed when operators are stencil-coded: dict(pcg_iteration, vcycle, spmv, coded)."""
     a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_int()
     _check(load().hda_format_bytes(A.h, amg.h if amg is not None else None, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-    return {"pcg_iteration": a.value, "vcycle": b.value, "spmv": c.value, "coded": bool(d.value), "row_coded": d.value == 2}
+    return {"pcg_iteration": a.value, "vcycle": b.value, "spmv": c.value, "coded": d.value in (1, 2), "row_coded": d.value == 2,
+            "windowed": d.value in (3, 5), "value_coded": d.value in (4, 5)}
 
 
 def probe_spmv(A, mode):

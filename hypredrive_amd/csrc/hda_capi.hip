@@ -719,7 +719,9 @@ extern "C" int hda_format_bytes(hda_csr_t A, hda_amg_t amg, double *pcg_iteratio
    if (pcg_iteration) *pcg_iteration = pcg_iteration_bytes(m, true);
    if (vcycle) *vcycle = amg ? amg->amg->vcycle_bytes(true) : 0.0;
    if (spmv) *spmv = matrix_stream_bytes(m, true) + rowptr_stream_bytes(m, true) + 8.0 * m.ncols + 8.0 * m.nrows;
-   if (coded) *coded = (m.coded == 1) ? (m.rowcoded == 1 ? 2 : 1) : 0; // 1 entry-coded stencil operator, 2 row-class coded
+   // storage form the products of A use: 0 plain CSR, 1 entry-coded stencil operator, 2 row-class coded, 3 windowed CSR,
+   // 4 value-coded, 5 value-coded + windowed
+   if (coded) *coded = (m.coded == 1) ? (m.rowcoded == 1 ? 2 : 1) : (m.coded == 2) ? (m.win == 1 ? 5 : 4) : (m.win == 1 ? 3 : 0);
    HDA_CATCH
 }
 

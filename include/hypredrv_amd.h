@@ -179,7 +179,8 @@ int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, in
 double hda_pcg_iteration_bytes(hda_csr_t A);
 /* Bytes the kernels really stream when operators are held in the stencil-coded form (1 B per
  * entry + dictionary instead of 12 B; DESIGN.md "coded operators"): one PCG iteration, one
- * V-cycle, one plain product with A.  Equal to the CSR figures when nothing is coded. */
+ * V-cycle, one plain product with A.  Equal to the CSR figures when nothing is coded.  *coded = storage form of A's products:
+ * 0 plain CSR, 1 entry-coded stencil operator, 2 row-class coded, 3 windowed CSR, 4 value-coded, 5 value-coded + windowed. */
 int hda_format_bytes(hda_csr_t A, hda_amg_t amg, double *pcg_iteration, double *vcycle, double *spmv, int *coded);
 /* Timing probe: bracket every product launch of `mode` (0 y=Ax, 1 residual, 2 Jacobi sweep) on
  * matrix A (e.g. a view from hda_amg_level_matrix) with HIP events on the library stream;

@@ -79,11 +79,15 @@ def main():
             out[key + "_bytes_per_launch"] = t
             out[key] = {"kernel": part, "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
     # Jacobi sweep on the largest plain-CSR operator (bench.py's dominant kernel): level 1 when level 0 is coded
-    t, f, w = traffic("k_spmv_stream<2, false", True)
+    t, f, w = traffic("k_spmv_win<2, false", True)
+    kname = "k_spmv_win<2, false, ...> (windowed CSR)"
+    if t is None:
+        t, f, w = traffic("k_spmv_stream<2, false", True)
+        kname = "k_spmv_stream<2, false, ...>"
     if t is not None:
         lvl = 1 if level0_coded else 0
         out[f"k_spmv_stream_jacobi_level{lvl}_bytes_per_launch"] = t
-        out[f"k_spmv_stream_jacobi_level{lvl}"] = {"kernel": "k_spmv_stream<2, false, ...>, launches within 5 % of the largest FETCH_SIZE",
+        out[f"k_spmv_stream_jacobi_level{lvl}"] = {"kernel": kname + ", launches within 5 % of the largest FETCH_SIZE",
                                                    "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
     # level-0 transfer operators: the value-coded stream kernel in PLAIN mode without dot; P (x += P e) writes 8 B per fine row,
     # R (f_c = R t) 8 B per coarse row -- told apart by WRITE_SIZE
