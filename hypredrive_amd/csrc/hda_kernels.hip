@@ -1057,7 +1057,9 @@ __device__ int win_sort_unique(const int *__restrict__ col, int k0, int n, int *
    __syncthreads();
    return total;
 }
-__global__ __launch_bounds__(256) void k_win_count(int nw, const int *__restrict__ wmeta, const int *__restrict__ col, int *__restrict__ ucount)
+// pass 1: sort a chunk's columns once; its distinct columns go to tcol[k0 ..) (scratch as long as the column array), their number to ucount
+__global__ __launch_bounds__(256) void k_win_count(int nw, const int *__restrict__ wmeta, const int *__restrict__ col, int *__restrict__ ucount,
+                                                   int *__restrict__ tcol)
 {
    __shared__ int keys[kWinSort];
    __shared__ int scan[256];
@@ -1065,36 +1067,39 @@ __global__ __launch_bounds__(256) void k_win_count(int nw, const int *__restrict
    {
       const int k0 = wmeta[3 * c + 1], n = wmeta[3 * c + 4] - k0;
       const int t  = (n > 0) ? win_sort_unique(col, k0, n, keys, scan) : 0;
+      for (int j = threadIdx.x; j < t; j += 256) tcol[k0 + j] = keys[j];
       if (threadIdx.x == 0) ucount[c] = t;
       __syncthreads();
    }
 }
+// pass 2: the distinct columns move to their final place; every entry gets the position of its column (binary search in LDS)
 __global__ __launch_bounds__(256) void k_win_fill(int nw, int *__restrict__ wmeta, const int *__restrict__ col, const int *__restrict__ uoff,
-                                                  int *__restrict__ ucol, unsigned short *__restrict__ lidx)
+                                                  const int *__restrict__ tcol, int *__restrict__ ucol, unsigned short *__restrict__ lidx)
 {
    __shared__ int keys[kWinSort];
-   __shared__ int scan[256];
    for (int c = blockIdx.x; c <= nw; c += gridDim.x)
    {
       if (threadIdx.x == 0) wmeta[3 * c + 2] = uoff[c];
       if (c == nw) break;
-      const int k0 = wmeta[3 * c + 1], n = wmeta[3 * c + 4] - k0;
-      if (n > 0)
+      const int k0 = wmeta[3 * c + 1], n = wmeta[3 * c + 4] - k0, u0 = uoff[c], t = uoff[c + 1] - u0;
+      for (int j = threadIdx.x; j < t; j += 256)
       {
-         const int t = win_sort_unique(col, k0, n, keys, scan), u0 = uoff[c];
-         for (int j = threadIdx.x; j < t; j += 256) ucol[u0 + j] = keys[j];
-         for (int i = threadIdx.x; i < n; i += 256)
+         const int v = tcol[k0 + j];
+         keys[j]     = v;
+         ucol[u0 + j] = v;
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += 256)
+      {
+         const int cc = col[k0 + i];
+         int       lo = 0, hi = t - 1;
+         while (lo < hi)
          {
-            const int cc = col[k0 + i];
-            int       lo = 0, hi = t - 1;
-            while (lo < hi)
-            {
-               const int mid = (lo + hi) >> 1;
-               if (keys[mid] < cc) lo = mid + 1;
-               else hi = mid;
-            }
-            lidx[k0 + i] = (unsigned short)lo;
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < cc) lo = mid + 1;
+            else hi = mid;
          }
+         lidx[k0 + i] = (unsigned short)lo;
       }
       __syncthreads();
    }
@@ -1118,9 +1123,9 @@ static void ensure_window(const DCsr &A)
    A.wmeta.alloc(3 * ((size_t)nw + 2));
    A.wmeta.zero();
    k_wchunk_rows<<<ceil_div(nw + 1, 256), 256, 0, STREAM>>>(nw, A.nrows, A.rowptr.data(), A.wmeta.data());
-   DArray<int> ucount((size_t)nw + 1), uoff((size_t)nw + 1), mx(1);
+   DArray<int> ucount((size_t)nw + 1), uoff((size_t)nw + 1), mx(1), tcol((size_t)A.nnz + 1);
    const int   g = std::min(nw, 256 * 8);
-   k_win_count<<<g, 256, 0, STREAM>>>(nw, A.wmeta.data(), A.col.data(), ucount.data());
+   k_win_count<<<g, 256, 0, STREAM>>>(nw, A.wmeta.data(), A.col.data(), ucount.data(), tcol.data());
    exclusive_scan(nw, ucount.data(), uoff.data(), nullptr);
    mx.zero();
    k_max_int<<<std::min(ceil_div(nw, 256), 256), 256, 0, STREAM>>>(nw, ucount.data(), mx.data());
@@ -1138,7 +1143,7 @@ static void ensure_window(const DCsr &A)
    }
    A.ucol.alloc((size_t)std::max(total, 1) + 1024); // the kernel's prefetch may read up to 768 entries past a chunk's list
    A.lidx.alloc((size_t)std::max(A.nnz, 1) + 1024);
-   k_win_fill<<<g, 256, 0, STREAM>>>(nw, A.wmeta.data(), A.col.data(), uoff.data(), A.ucol.data(), A.lidx.data());
+   k_win_fill<<<g, 256, 0, STREAM>>>(nw, A.wmeta.data(), A.col.data(), uoff.data(), tcol.data(), A.ucol.data(), A.lidx.data());
    A.win       = 1;
    A.nwin      = nw;
    A.win_maxu  = m;
