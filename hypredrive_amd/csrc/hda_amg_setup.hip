@@ -8,6 +8,7 @@
 // synchronous rounds.  The hierarchy is therefore bit-reproducible run to run and
 // independent of the launch geometry.
 #include "hda_amg.h"
+#include "hda_sort.h"
 
 #include <algorithm>
 #include <chrono>
@@ -55,11 +56,82 @@ __global__ __launch_bounds__(256) void k_strength(int n, const int *__restrict__
    ns[i] = cnt;
 }
 
+// The same classification with G lanes per row (coalesced reads of long rows).  The row sum keeps the sequential
+// order: the lanes hand their values round in ascending k and every lane adds them in that order; the scale is a
+// min/max, which no order changes.
+template <int G>
+__global__ __launch_bounds__(256) void k_strength_grp(int n, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                      const double *__restrict__ v, double theta, double mrs,
+                                                      unsigned char *__restrict__ smask, int *__restrict__ ns,
+                                                      const int *__restrict__ dof)
+{
+   const int  gl  = threadIdx.x & (G - 1);
+   const long row = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+   const bool in  = row < n;
+   const int  i   = in ? (int)row : 0;
+   const int  k0 = in ? rp[i] : 0, k1 = in ? rp[i + 1] : 0;
+   const int  fi = dof ? dof[i] : 0;
+   double     d  = 0.0;
+   for (int k = k0 + gl; k < k1; k += G)
+      if (cj[k] == i) d = v[k];
+   for (int o = G >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, G); // one lane holds the diagonal, the others 0
+   const double diag = d;
+   double       row_sum = 0.0, row_scale = 0.0;
+   for (int base = k0; base < k1; base += G)
+   {
+      const int k = base + gl;
+      double    a = 0.0;
+      bool      off = false; // an off-diagonal entry of the row's own function
+      if (k < k1)
+      {
+         const int c = cj[k];
+         if (!(dof && dof[c] != fi))
+         {
+            a   = v[k];
+            off = (c != i);
+         }
+      }
+      if (off)
+      {
+         if (diag < 0.0) row_scale = (a > row_scale) ? a : row_scale;
+         else row_scale = (a < row_scale) ? a : row_scale;
+      }
+      const int m = min(G, k1 - base);
+      for (int l = 0; l < m; l++) row_sum += __shfl(a, l, G); // skipped entries add 0.0
+   }
+   for (int o = G >> 1; o > 0; o >>= 1)
+   {
+      const double t = __shfl_xor(row_scale, o, G);
+      if (diag < 0.0) row_scale = (t > row_scale) ? t : row_scale;
+      else row_scale = (t < row_scale) ? t : row_scale;
+   }
+   const bool weak = (mrs < 1.0) && (diag != 0.0) && (fabs(row_sum / diag) > mrs);
+   int        cnt  = 0;
+   for (int k = k0 + gl; k < k1; k += G)
+   {
+      int       s = 0;
+      const int c = cj[k];
+      if (c != i && !weak && !(dof && dof[c] != fi)) s = (diag < 0.0) ? (v[k] > theta * row_scale) : (v[k] < theta * row_scale);
+      smask[k] = (unsigned char)s;
+      cnt += s;
+   }
+   for (int o = G >> 1; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, G);
+   if (in && gl == 0) ns[i] = cnt;
+}
+
 static void strength_ns(const DCsr &A, double theta, double mrs, unsigned char *smask, int *ns, const int *dof = nullptr)
 {
-   if (A.nrows)
-      k_strength<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data(),
-                                                             theta, mrs, smask, ns, dof);
+   if (!A.nrows) return;
+   const double avg = A.avg_row();
+   const int    n   = A.nrows;
+   if (avg <= 12.0)
+      k_strength<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), theta, mrs, smask, ns, dof);
+   else if (avg <= 24.0)
+      k_strength_grp<16><<<ceil_div((long long)n * 16, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), theta, mrs, smask, ns, dof);
+   else if (avg <= 48.0)
+      k_strength_grp<32><<<ceil_div((long long)n * 32, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), theta, mrs, smask, ns, dof);
+   else
+      k_strength_grp<64><<<ceil_div((long long)n * 64, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), theta, mrs, smask, ns, dof);
 }
 
 void amg_strength(const DCsr &A, double theta, double max_row_sum, unsigned char *smask, const int *dof)
@@ -168,6 +240,9 @@ static void pmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
    int left = 0;
    counter.download(&left, 1);
    HDA_TRACE("  pmis: init done, undecided=%d", left);
+   // (Measured at 256^3: rounds over a compacted worklist of the undecided rows are no faster -- 12.6 / 13.0 ms
+   // against 12.4 / 11.4 on levels 0 / 1 -- and several lanes per row are three times slower on level 1; the
+   // first two rounds, which touch nearly every row, carry the cost.)
    int rounds = 0;
    while (left > 0)
    {
@@ -414,9 +489,10 @@ struct PEnt {
 // Descending-|w| quicksort in the K&R form (pivot = middle element swapped to the front,
 // strict '>' partition) -- the tie order it produces decides which pmax of several equal
 // weights survive truncation, so it is part of the algorithm's definition (see oracle).
-__device__ void qsort_abs(int *L, double *W, int n)
+// stack: 64 ints of the caller's (the smaller partition is finished first, so the depth stays below 2 log2 n)
+__device__ void qsort_abs(int *L, double *W, int n, int *stack)
 {
-   int stack[64], sp = 0;
+   int sp = 0;
    stack[sp++] = 0;
    stack[sp++] = n - 1;
    while (sp > 0)
@@ -598,7 +674,8 @@ __global__ __launch_bounds__(256) void k_interp_build(
    {
       double tot = 0.0, kept = 0.0;
       for (int q = 0; q < cnt; q++) tot += W[q];
-      qsort_abs(L, W, cnt);
+      int stk[64];
+      qsort_abs(L, W, cnt, stk);
       cnt = pmax;
       for (int a = 1; a < cnt; a++) // kept set -> column order before summing (see oracle)
       {
@@ -676,19 +753,25 @@ __global__ __launch_bounds__(256) void k_max3(int n, const int *__restrict__ rp,
    if ((threadIdx.x & 63) == 0) { atomicMax(&mx[0], a); atomicMax(&mx[1], b); atomicMax(&mx[2], c); }
 }
 
+template <int G>
 __global__ __launch_bounds__(256, 3) void k_interp_wave(
    int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
    const unsigned char *__restrict__ smask, const int *__restrict__ cf, const int *__restrict__ nsC,
    const long long *__restrict__ uofs, int cap_row, int cap_ub, int cap_nbr, int pmax, double trunc_factor,
    const unsigned char *__restrict__ rowmode, int *__restrict__ lcol, double *__restrict__ lw, int *__restrict__ pcnt,
-   const int *__restrict__ dof)
+   const int *__restrict__ dof, int s3_scan, unsigned long long *__restrict__ prof)
 {
    extern __shared__ double ilds[];
-   const int    wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   constexpr int GPB = 256 / G;                    // row groups per workgroup
+   const int     grp = threadIdx.x / G, lane = threadIdx.x & (G - 1); // lane: position inside the row's group of G lanes
+   const int     gb  = (threadIdx.x & 63) & ~(G - 1); // first lane of the group inside its wavefront
+   const unsigned long long gmask = ~0ULL >> (64 - G);
+   auto gballot = [&](bool pr) -> unsigned long long { return (__ballot(pr) >> gb) & gmask; }; // votes of the group's lanes
    const size_t per  = interp_wave_doubles(cap_row, cap_ub, cap_nbr);
-   double      *rval = ilds + wave * per, *Wv = rval + cap_row, *nval = Wv + cap_ub, *misc = nval + cap_nbr;
-   int         *rcol = (int *)(misc + 2), *rtype = rcol + cap_row, *rofs = rtype + cap_row; // rofs: cap_row + 1
-   int         *noff = rofs + cap_row + 1, *nbeg = noff + cap_row + 1;                      // neighbour-row staging: offsets, global starts
+   double      *rval = ilds + grp * per, *Wv = rval + cap_row, *nval = Wv + cap_ub, *misc = nval + cap_nbr;
+   int         *rcol = (int *)(misc + 2), *rofs = rcol + cap_row, *rtype = rofs + cap_row + 1; // rofs: cap_row + 1
+   int         *noff = rtype + cap_row, *nbeg = noff + cap_row + 1;                         // neighbour-row staging: offsets, global starts
+   double      *ksum = (double *)rcol; // per-neighbour sums of a staged row: over rcol and rofs, both dead by then
    int         *craw = nbeg + cap_row, *ucol = craw + cap_ub, *htb = ucol + cap_ub;         // htb: 2*cap_ub slots, col -> pos+1
    int         *ncol = htb + 2 * cap_ub;                                                    // ncol: cap_nbr (bit 31 = strong C entry)
    const int    hmask = 2 * cap_ub - 1;
@@ -702,9 +785,19 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
          h = (h + 1) & (unsigned)hmask;
       }
    };
-   const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+   const unsigned long long lt = (1ULL << lane) - 1; // the group's lanes below this one
    enum { T_DIAG = 0, T_SC = 1, T_SF = 2, T_OTHER = 3 };
-   for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4)
+   // HDA_INTERP_PROF: shader-clock cycles per stage, summed over rows by every group's first lane (diagnostics)
+   unsigned long long tprev = 0;
+   auto stamp = [&](int st) {
+      if (prof)
+      {
+         const unsigned long long t = __builtin_readcyclecounter();
+         if (lane == 0 && st >= 0) atomicAdd(&prof[st], t - tprev);
+         tprev = t;
+      }
+   };
+   for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB)
    {
       if (rowmode[i]) continue;
       const int c = cf[i];
@@ -718,10 +811,11 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
          if (lane == 0) pcnt[i] = 0;
          continue;
       }
+      stamp(-1);
       const int k0 = rp[i], nk = rp[i + 1] - k0;
       // ---- 1. stage the row, classify entries, candidate offsets per entry
       int running = 0;
-      for (int base = 0; base < nk; base += 64)
+      for (int base = 0; base < nk; base += G)
       {
          const int k = base + lane;
          int       cntk = 0;
@@ -740,19 +834,20 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
             rtype[k] = t | ((cfj == -3 || (dof && dof[j] != dof[i])) ? 8 : 0) | (cfj == 1 ? 16 : 0);
          }
          int incl = cntk; // inclusive scan over the wave
-         for (int o = 1; o < 64; o <<= 1)
+         for (int o = 1; o < G; o <<= 1)
          {
-            const int up = __shfl_up(incl, o);
+            const int up = __shfl_up(incl, o, G);
             if (lane >= o) incl += up;
          }
          if (k < nk) rofs[k] = running + incl - cntk;
-         running += __shfl(incl, 63);
+         running += __shfl(incl, G - 1, G);
       }
       const int ncand = running;
       WAVE_SYNC();
+      stamp(0);
       // ---- 1b. stage the strong-F neighbour rows in LDS (one flat, fully parallel copy)
       int nrun = 0;
-      for (int base = 0; base < nk; base += 64)
+      for (int base = 0; base < nk; base += G)
       {
          const int k  = base + lane;
          int       ln = 0, js = 0;
@@ -763,13 +858,13 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
             ln          = rp[j + 1] - js;
          }
          int incl = ln;
-         for (int o = 1; o < 64; o <<= 1)
+         for (int o = 1; o < G; o <<= 1)
          {
-            const int up = __shfl_up(incl, o);
+            const int up = __shfl_up(incl, o, G);
             if (lane >= o) incl += up;
          }
          if (k < nk) { noff[k] = nrun + incl - ln; nbeg[k] = js; }
-         nrun += __shfl(incl, 63);
+         nrun += __shfl(incl, G - 1, G);
       }
       const int  nbr_total = nrun;
       const bool staged    = nbr_total <= cap_nbr; // otherwise neighbour rows are read from global memory
@@ -777,15 +872,15 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
       WAVE_SYNC();
       if (staged)
       {
-         for (int fb = 0; fb < nbr_total; fb += 256)
-         { // four independent 64-entry batches in flight
+         for (int fb = 0; fb < nbr_total; fb += 4 * G)
+         { // four independent batches in flight
             int g[4], m[4];
             double a[4];
             unsigned char sm[4];
 #pragma unroll
             for (int u = 0; u < 4; u++)
             {
-               const int f = fb + 64 * u + lane;
+               const int f = fb + G * u + lane;
                g[u]        = -1;
                if (f < nbr_total)
                {
@@ -806,13 +901,14 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
             for (int u = 0; u < 4; u++)
                if (g[u] >= 0)
                {
-                  const int f = fb + 64 * u + lane;
+                  const int f = fb + G * u + lane;
                   nval[f]     = a[u];
                   ncol[f]     = m[u] | ((sm[u] && cf[m[u]] == 1) ? (int)0x80000000 : 0);
                }
          }
       }
       WAVE_SYNC();
+      stamp(1);
       // neighbour-row entry e of neighbour k (e relative to the row): column, value, strong-C flag
       auto nb_col = [&](int k, int e) -> int { return staged ? (ncol[noff[k] + e] & 0x7FFFFFFF) : cj[nbeg[k] + e]; };
       auto nb_val = [&](int k, int e) -> double { return staged ? nval[noff[k] + e] : v[nbeg[k] + e]; };
@@ -821,7 +917,25 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
          const int g = nbeg[k] + e;
          return smask[g] && cf[cj[g]] == 1;
       };
-      // ---- 2. candidates in discovery order
+      // ---- 2. candidates in discovery order: entry k's candidates start at rofs[k]
+      if (staged)
+      { // one lane per row entry walks its staged neighbour row
+         for (int k = lane; k < nk; k += G)
+         {
+            const int t = rtype[k] & 7;
+            if (t == T_SC) craw[rofs[k]] = rcol[k];
+            else if (t == T_SF)
+            {
+               int q = rofs[k];
+               for (int f = noff[k]; f < noff[k + 1]; f++)
+               {
+                  const int w = ncol[f];
+                  if (w < 0) craw[q++] = w & 0x7FFFFFFF;
+               }
+            }
+         }
+      }
+      else
       for (int k = 0; k < nk; k++)
       {
          const int t = rtype[k] & 7;
@@ -830,7 +944,7 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
          {
             const int nj = noff[k + 1] - noff[k];
             int       q = rofs[k];
-            for (int base = 0; base < nj; base += 64)
+            for (int base = 0; base < nj; base += G)
             {
                const int kk = base + lane;
                bool      f  = false;
@@ -840,28 +954,85 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
                   m = nb_col(k, kk);
                   f = nb_sc(k, kk);
                }
-               const unsigned long long b = __ballot(f);
+               const unsigned long long b = gballot(f);
                if (f) craw[q + __popcll(b & lt)] = m;
                q += __popcll(b);
             }
          }
       }
       WAVE_SYNC();
-      // ---- 3. first occurrences -> C-hat_i in discovery order (ucol), accumulators to zero
+      stamp(2);
+      // ---- 3. first occurrences -> C-hat_i in discovery order (ucol), accumulators to zero.
+      // A hash table over the candidates keeps, per column, the smallest candidate index (+1); a candidate is a
+      // first occurrence when that index is its own.
       int cnt = 0;
-      for (int base = 0; base < ncand; base += 64)
+      if (ncand <= s3_scan)
+      { // few candidates: every lane scans the ones before its own
+         for (int base = 0; base < ncand; base += G)
+         {
+            const int ci = base + lane;
+            bool      uq = false;
+            int       m  = 0;
+            if (ci < ncand)
+            {
+               m  = craw[ci];
+               uq = true;
+               for (int e = 0; e < ci; e++)
+                  if (craw[e] == m) { uq = false; break; }
+            }
+            const unsigned long long b = gballot(uq);
+            if (uq)
+            {
+               const int pos = cnt + __popcll(b & lt);
+               ucol[pos]     = m;
+               Wv[pos]       = 0.0;
+            }
+            cnt += __popcll(b);
+         }
+      }
+      else
+      {
+      for (int q = lane; q <= hmask; q += G) htb[q] = 0;
+      WAVE_SYNC();
+      for (int ci = lane; ci < ncand; ci += G)
+      {
+         const int m = craw[ci];
+         unsigned  h = ((unsigned)m * 2654435761u) & (unsigned)hmask;
+         for (;;)
+         {
+            int e = htb[h];
+            if (e == 0)
+            {
+               e = atomicCAS(&htb[h], 0, ci + 1);
+               if (e == 0) break;
+            }
+            if (craw[e - 1] == m) // the slot is this column's (its index only ever moves to an equal column)
+            {
+               atomicMin(&htb[h], ci + 1);
+               break;
+            }
+            h = (h + 1) & (unsigned)hmask;
+         }
+      }
+      WAVE_SYNC();
+      for (int base = 0; base < ncand; base += G)
       {
          const int ci = base + lane;
          bool      uq = false;
          int       m  = 0;
          if (ci < ncand)
          {
-            m  = craw[ci];
-            uq = true;
-            for (int e = 0; e < ci; e++)
-               if (craw[e] == m) { uq = false; break; }
+            m          = craw[ci];
+            unsigned h = ((unsigned)m * 2654435761u) & (unsigned)hmask;
+            int      e = htb[h];
+            while (craw[e - 1] != m)
+            {
+               h = (h + 1) & (unsigned)hmask;
+               e = htb[h];
+            }
+            uq = (e == ci + 1);
          }
-         const unsigned long long b = __ballot(uq);
+         const unsigned long long b = gballot(uq);
          if (uq)
          {
             const int pos = cnt + __popcll(b & lt);
@@ -870,15 +1041,17 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
          }
          cnt += __popcll(b);
       }
+      }
       WAVE_SYNC();
-      for (int q = lane; q <= hmask; q += 64) htb[q] = 0;
+      for (int q = lane; q <= hmask; q += G) htb[q] = 0;
       WAVE_SYNC();
-      for (int q = lane; q < cnt; q += 64)
+      for (int q = lane; q < cnt; q += G)
       { // set semantics: any insertion order gives the same lookups
          unsigned h = ((unsigned)ucol[q] * 2654435761u) & (unsigned)hmask;
          while (atomicCAS(&htb[h], 0, q + 1) != 0) h = (h + 1) & (unsigned)hmask;
       }
       WAVE_SYNC();
+      stamp(3);
       // ---- 4. weights, neighbours visited in ascending k
       if (lane == 0)
       {
@@ -888,6 +1061,99 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
          misc[0] = d;
       }
       WAVE_SYNC();
+      if (staged)
+      {
+         // 4a. one lane per row entry: sign of a_jj for a strong-F neighbour (bit 5 of rtype), accumulator of a C point
+         for (int k = lane; k < nk; k += G)
+         {
+            const int t = rtype[k];
+            const int j = rcol[k];
+            if ((t & 7) == T_SF)
+            {
+               double ajj = 0.0;
+               for (int f = noff[k]; f < noff[k + 1]; f++)
+                  if ((ncol[f] & 0x7FFFFFFF) == j) { ajj = nval[f]; break; }
+               if (ajj < 0.0) rtype[k] = t | 32;
+            }
+            nbeg[k] = (t & 16) ? lookup(j) : -1; // the global row starts are not needed once the rows are staged
+         }
+         WAVE_SYNC();
+         // 4b. every staged entry: column -> accumulator position, -2 for column i, -1 for neither
+         for (int f = lane; f < nbr_total; f += G)
+         {
+            const int m = ncol[f] & 0x7FFFFFFF;
+            ncol[f]     = (m == i) ? -2 : lookup(m);
+         }
+         WAVE_SYNC();
+         // 4c. one lane per strong-F neighbour: the ordered sum over the qualifying entries of its row
+         for (int k = lane; k < nk; k += G)
+            if ((rtype[k] & 7) == T_SF)
+            {
+               const double sgn = (rtype[k] & 32) ? -1.0 : 1.0;
+               double       sum = 0.0;
+               for (int f = noff[k]; f < noff[k + 1]; f++)
+               {
+                  const double a = nval[f];
+                  if (sgn * a < 0.0 && ncol[f] != -1) sum += a;
+               }
+               ksum[k] = sum;
+            }
+         WAVE_SYNC();
+         stamp(4);
+         // 4d. accumulation, neighbours in ascending k (the order every accumulator sees its terms in)
+         for (int k = 0; k < nk; k++)
+         {
+            const int    t = rtype[k];
+            const double aij = rval[k];
+            if ((t & 7) == T_DIAG) continue;
+            if (t & 16)
+            {
+               const int pos = nbeg[k];
+               if (pos >= 0)
+               {
+                  if (lane == 0) Wv[pos] += aij;
+                  WAVE_SYNC();
+                  continue;
+               }
+            }
+            if ((t & 7) == T_SF)
+            {
+               const double sum = ksum[k];
+               if (sum != 0.0)
+               {
+                  const double distribute = aij / sum;
+                  const double sgn        = (t & 32) ? -1.0 : 1.0;
+                  const int    f1         = noff[k + 1];
+                  for (int f = noff[k] + lane; f - lane < f1; f += G)
+                  {
+                     if (f < f1)
+                     {
+                        const double a = nval[f];
+                        if (sgn * a < 0.0)
+                        {
+                           const int pos = ncol[f];
+                           if (pos >= 0) Wv[pos] += distribute * a;
+                           else if (pos == -2) misc[0] += distribute * a;
+                        }
+                     }
+                     WAVE_SYNC();
+                  }
+               }
+               else
+               {
+                  if (lane == 0) misc[0] += aij;
+                  WAVE_SYNC();
+               }
+               continue;
+            }
+            if (!(t & 8))
+            {
+               if (lane == 0) misc[0] += aij;
+               WAVE_SYNC();
+            }
+         }
+      }
+      else
       for (int k = 0; k < nk; k++)
       {
          const int    t = rtype[k];
@@ -909,18 +1175,18 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
             const int nj = noff[k + 1] - noff[k];
             // a_jj and its sign
             double ajj = 0.0;
-            for (int base = 0; base < nj; base += 64)
+            for (int base = 0; base < nj; base += G)
             {
                const int kk = base + lane;
                const bool hit = kk < nj && nb_col(k, kk) == j;
-               const unsigned long long b = __ballot(hit);
+               const unsigned long long b = gballot(hit);
                const double             a = hit ? nb_val(k, kk) : 0.0;
-               if (b) ajj = __shfl(a, __ffsll((long long)b) - 1);
+               if (b) ajj = __shfl(a, __ffsll((long long)b) - 1, G);
             }
             const double sgn = (ajj < 0.0) ? -1.0 : 1.0;
             // ordered sum over the qualifying entries of row j
             double sum = 0.0;
-            for (int base = 0; base < nj; base += 64)
+            for (int base = 0; base < nj; base += G)
             {
                const int kk = base + lane;
                bool      cond = false;
@@ -931,18 +1197,18 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
                   a           = nb_val(k, kk);
                   if (sgn * a < 0.0) cond = (m == i) || lookup(m) >= 0;
                }
-               unsigned long long bits = __ballot(cond);
+               unsigned long long bits = gballot(cond);
                while (bits)
                {
                   const int l = __ffsll((long long)bits) - 1;
-                  sum += __shfl(a, l);
+                  sum += __shfl(a, l, G);
                   bits &= bits - 1;
                }
             }
             if (sum != 0.0)
             {
                const double distribute = aij / sum;
-               for (int base = 0; base < nj; base += 64)
+               for (int base = 0; base < nj; base += G)
                {
                   const int kk = base + lane;
                   if (kk < nj)
@@ -975,8 +1241,9 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
       WAVE_SYNC();
       const double diagonal = misc[0];
       if (diagonal != 0.0)
-         for (int q = lane; q < cnt; q += 64) Wv[q] = Wv[q] / (-diagonal);
+         for (int q = lane; q < cnt; q += G) Wv[q] = Wv[q] / (-diagonal);
       WAVE_SYNC();
+      stamp(staged ? 5 : 6);
       // ---- 5. truncation and output (serial parts on lane 0, exactly the oracle's sequence)
       const long long o = uofs[i];
       int             out_cnt = cnt;
@@ -1013,7 +1280,7 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
       {
          // does a group of equal |w| straddle the cut?  If not the kept set is the top pmax.
          bool straddle = false;
-         for (int base = 0; base < cnt; base += 64)
+         for (int base = 0; base < cnt; base += G)
          {
             const int q = base + lane;
             bool      s = false;
@@ -1030,42 +1297,40 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
                s = gt < pmax && gt + eq > pmax;
                craw[q]  = gt; // rank by strict dominance
             }
-            straddle = straddle || __ballot(s) != 0ULL;
+            straddle = straddle || gballot(s) != 0ULL;
          }
          WAVE_SYNC();
          if (lane == 0)
          {
             double tot = 0.0, kept = 0.0;
             for (int q = 0; q < cnt; q++) tot += Wv[q];
-            int    kc[16];
-            double kw[16];
-            int    nkpt = 0;
+            // the kept entries are compacted to the front of ucol / Wv in place (LDS; private arrays would live in scratch memory)
+            int nkpt = 0;
             if (!straddle)
             {
-               for (int q = 0; q < cnt && nkpt < pmax && nkpt < 16; q++)
-                  if (craw[q] < pmax) { kc[nkpt] = ucol[q]; kw[nkpt] = Wv[q]; nkpt++; }
+               for (int q = 0; q < cnt && nkpt < pmax; q++)
+                  if (craw[q] < pmax) { ucol[nkpt] = ucol[q]; Wv[nkpt] = Wv[q]; nkpt++; }
             }
             else
             {
-               qsort_abs(ucol, Wv, cnt); // exact tie order of the reference algorithm
-               for (int q = 0; q < pmax && q < 16; q++) { kc[q] = ucol[q]; kw[q] = Wv[q]; }
-               nkpt = pmax < 16 ? pmax : 16;
+               qsort_abs(ucol, Wv, cnt, htb); // exact tie order of the reference algorithm; the hash table is dead, its slots hold the stack
+               nkpt = pmax;
             }
             for (int a = 1; a < nkpt; a++)
             {
-               const int    cc = kc[a];
-               const double ww = kw[a];
+               const int    cc = ucol[a];
+               const double ww = Wv[a];
                int          b  = a - 1;
-               while (b >= 0 && kc[b] > cc) { kc[b + 1] = kc[b]; kw[b + 1] = kw[b]; b--; }
-               kc[b + 1] = cc;
-               kw[b + 1] = ww;
+               while (b >= 0 && ucol[b] > cc) { ucol[b + 1] = ucol[b]; Wv[b + 1] = Wv[b]; b--; }
+               ucol[b + 1] = cc;
+               Wv[b + 1]   = ww;
             }
-            for (int q = 0; q < nkpt; q++) kept += kw[q];
+            for (int q = 0; q < nkpt; q++) kept += Wv[q];
             const double sc = (kept != 0.0) ? tot / kept : 1.0;
             for (int q = 0; q < nkpt; q++)
             {
-               lcol[o + q] = kc[q];
-               lw[o + q]   = (kept != 0.0) ? kw[q] * sc : kw[q];
+               lcol[o + q] = ucol[q];
+               lw[o + q]   = (kept != 0.0) ? Wv[q] * sc : Wv[q];
             }
             pcnt[i] = nkpt;
          }
@@ -1088,6 +1353,8 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
          }
       }
       WAVE_SYNC();
+      stamp(7);
+      if (prof && lane == 0) atomicAdd(&prof[staged ? 8 : 9], 1ULL);
    }
 }
 
@@ -1128,23 +1395,32 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    int hmx[3] = {0, 0, 0};
    mx.download(hmx, 3);
    static const char *imode = getenv("HDA_INTERP"); // "thread" / "wave" force one kernel (diagnostics)
-   // short rows (fine grids): one thread per row keeps 64 rows in flight per wave; long rows: one wave per row
-   bool use_wave = pmax > 0 && pmax <= 16 && hmx[0] > 16;
+   // G lanes share a row (8 for stencil rows, a whole wavefront for the long rows of coarse levels): the row, its
+   // candidates and its neighbour rows are staged in LDS by coalesced reads.  The thread-per-row kernel keeps the rows
+   // that exceed the LDS budget, and everything when pmax is outside the group kernel's range.
+   bool use_wave = pmax > 0 && pmax <= 16;
    if (imode && !strcmp(imode, "thread")) use_wave = false;
-   if (imode && !strcmp(imode, "wave")) use_wave = pmax > 0 && pmax <= 16;
+   static const int g_env = getenv("HDA_INTERP_LANES") ? atoi(getenv("HDA_INTERP_LANES")) : 0;
+   int G = 64; // (32 lanes for rows of ~30 entries measured twice as slow as 64: eight rows' staging areas leave one workgroup per CU)
+   if (hmx[0] <= 8) G = 8;
+   else if (hmx[0] <= 16) G = 16;
+   if (imode && !strcmp(imode, "wave")) G = 64;
+   if (g_env == 8 || g_env == 16 || g_env == 32 || g_env == 64) G = g_env;
+   const int gpb = 256 / G;
    int cap_row = 8, cap_ub = 16, cap_nbr = 64;
-   cap_row = std::min(256, std::max(8, (hmx[0] + 31) / 32 * 32)); // rows longer than 256 entries keep the thread kernel
+   cap_row = std::min(256, std::max(8, (hmx[0] + 7) / 8 * 8)); // rows longer than 256 entries keep the thread kernel
    while (cap_ub < hmx[1] && cap_ub < 1024) cap_ub <<= 1;
-   // Neighbour-row staging area per wave.  The kernel is held to 168 VGPRs (three waves per SIMD), so
+   // Neighbour-row staging area per row group.  The kernel is held to 168 VGPRs (three waves per SIMD), so
    // LDS decides the occupancy: where the neighbour rows of a typical row (about half of avg_row^2
-   // entries) fit 512 entries they are staged (level 1 of the 256^3 benchmark: 86 ms against 106 with
-   // 256); where they would not fit anyway the smaller area lets three workgroups share a CU (level 2:
-   // 38 ms against 50).  HDA_INTERP_NBR overrides.
+   // entries) fit 512 entries they are staged; where they would not fit anyway the smaller area lets three
+   // workgroups share a CU.  HDA_INTERP_NBR overrides.
    static const int nbr_env = getenv("HDA_INTERP_NBR") ? atoi(getenv("HDA_INTERP_NBR")) : 0;
    const double     est_nbr = 0.5 * A.avg_row() * A.avg_row();
    const int        nbr_cap_max = nbr_env > 0 ? nbr_env : (est_nbr <= 768.0 ? 512 : 256);
    while (cap_nbr < hmx[2] && cap_nbr < nbr_cap_max) cap_nbr <<= 1;
-   while (cap_nbr > 64 && interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * 4 > 150 * 1024) cap_nbr >>= 1; // four waves must fit the LDS budget
+   if (hmx[2] < cap_nbr) cap_nbr = std::max(8, (hmx[2] + 7) / 8 * 8); // every row's neighbourhood fits: no more than needed
+   while (cap_nbr > 64 && interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * gpb > 150 * 1024) cap_nbr >>= 1; // the workgroup's row groups must fit the LDS budget
+   if (interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * gpb > 150 * 1024) use_wave = false;
    if (use_wave)
       k_interp_rowmode<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), ub.data(), nt.data(), cap_row, cap_ub, cap_nbr, rowmode.data(), hsz.data());
    exclusive_scan64(n, ub.data(), uofs.data());
@@ -1160,19 +1436,37 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    if (tot_h) HDA_HIP(hipMemsetAsync(htab.data(), 0xFF, sizeof(int) * htab.size(), STREAM));
    DArray<int> pcnt((size_t)n + 1);
    pcnt.zero();
-   HDA_TRACE("  interp: build (tot_u=%lld tot_h=%lld nc=%d maxrow=%d maxub=%d maxnbr=%d wave=%d)", tot_u, tot_h, nc, hmx[0], hmx[1], hmx[2], (int)use_wave);
+   HDA_TRACE("  interp: build (tot_u=%lld tot_h=%lld nc=%d maxrow=%d maxub=%d maxnbr=%d lanes/row=%d caps %d %d %d)", tot_u, tot_h, nc, hmx[0], hmx[1], hmx[2], use_wave ? G : 1, cap_row, cap_ub, cap_nbr);
    if (use_wave)
    {
-      const size_t lds = interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * 4;
-      static bool  attr = false;
-      if (!attr)
+      const size_t lds = interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * gpb;
+      static const int s3_scan = getenv("HDA_INTERP_SCAN") ? atoi(getenv("HDA_INTERP_SCAN")) : 1 << 30; // candidates up to which duplicates are found by scanning
+      static const bool want_prof = getenv("HDA_INTERP_PROF") != nullptr;
+      DArray<unsigned long long> prof;
+      if (want_prof)
       {
-         HDA_HIP(hipFuncSetAttribute((const void *)k_interp_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-         attr = true;
+         prof.alloc(10);
+         prof.zero();
       }
-      k_interp_wave<<<std::min(ceil_div(n, 4), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf,
-                                                                          nsC.data(), uofs.data(), cap_row, cap_ub, cap_nbr, pmax, trunc_factor,
-                                                                          rowmode.data(), lcol.data(), lw.data(), pcnt.data(), dof);
+      auto launch = [&](auto kern) {
+         HDA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+         kern<<<std::min(ceil_div(n, gpb), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, nsC.data(),
+                                                                      uofs.data(), cap_row, cap_ub, cap_nbr, pmax, trunc_factor, rowmode.data(),
+                                                                      lcol.data(), lw.data(), pcnt.data(), dof, s3_scan, prof.data());
+      };
+      if (G == 8) launch(k_interp_wave<8>);
+      else if (G == 16) launch(k_interp_wave<16>);
+      else if (G == 32) launch(k_interp_wave<32>);
+      else launch(k_interp_wave<64>);
+      if (want_prof)
+      {
+         unsigned long long h[10];
+         prof.download(h, 10);
+         const double rows = (double)std::max<unsigned long long>(h[8] + h[9], 1);
+         fprintf(stderr, "[hda] interp stages, cycles per row (%llu staged, %llu unstaged rows): row %.0f nbr-stage %.0f cand %.0f dedupe %.0f prep %.0f "
+                         "accumulate(staged) %.0f accumulate(unstaged) %.0f output %.0f\n", h[8], h[9], h[0] / rows, h[1] / rows, h[2] / rows,
+                 h[3] / rows, h[4] / rows, h[5] / rows, h[6] / rows, h[7] / rows);
+      }
       // the rows the wave kernel left to the thread kernel (rowmode): also when none of them needs a hash table
       // (C points and non-interpolated F points among them still have to report their entry count)
       k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
@@ -1457,66 +1751,78 @@ __global__ __launch_bounds__(256) void k_esc_chunk_rows(int nchunks, int nrows, 
    chunk_row[c] = lo;
 }
 
-constexpr int kEscEntries = 640; // X entries of a chunk staged in LDS for the expansion
+constexpr int kEscEntries = 2048; // X entries of a chunk staged in LDS for the expansion
 
-// One pass: products -> LDS keys, sort, segment sums in enumeration order, results written to
-// a scratch CSR whose rows start at rowstart[i] (<= the row's first product index), counts in cnt.
-__global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, int cap, const int *__restrict__ chunk_row,
+// One pass: products -> keys in registers (values in LDS, indexed by p and never moved), sort, segment sums in
+// enumeration order, results written to a scratch CSR whose rows start at rowstart[i] (<= the row's first product
+// index), counts in cnt.  A chunk holds fewer than 256*PER products.
+template <int PER>
+__global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, const int *__restrict__ chunk_row,
                                                     const int *__restrict__ xrp, const int *__restrict__ xcj,
                                                     const double *__restrict__ xv, const int *__restrict__ yrp,
                                                     const int *__restrict__ ycj, const double *__restrict__ yv,
                                                     const long long *__restrict__ eoff, long long *__restrict__ rowstart,
-                                                    int *__restrict__ cnt, int *__restrict__ scol, double *__restrict__ sval)
+                                                    int *__restrict__ cnt, int *__restrict__ scol, double *__restrict__ sval,
+                                                    int *__restrict__ err)
 {
+   constexpr int cap = 256 * PER;
    extern __shared__ unsigned long long esc_lds[];
-   unsigned long long *keys = esc_lds;                   // cap keys
-   double             *vals = (double *)(esc_lds + cap); // cap products, indexed by p (never moved)
-   int                *eofs = (int *)(esc_lds + 2 * cap); // kEscEntries+1 entry offsets relative to p0
-   int                *erow = eofs + kEscEntries + 1;      // local row of every staged entry
+   unsigned long long *keys = esc_lds;                    // cap keys (after the sort); entry of every product before it
+   double             *vals = (double *)(esc_lds + cap);  // cap products, indexed by p
+   unsigned short     *ent  = (unsigned short *)keys;     // staged entry of product p (dead before the sort uses keys)
+   unsigned           *eofs = (unsigned *)(ent + cap);    // kEscEntries+1: (local row << 13) | entry offset relative to p0; dead likewise
    __shared__ int      scan[256];
    const int           tid = threadIdx.x;
    for (int c = blockIdx.x; c < nchunks; c += gridDim.x)
    {
       const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
       if (r0 == r1) continue;
+      if (r1 - r0 >= (1 << 19))
+      { // the local row does not fit its field: the caller repeats the product on the hash path
+         if (tid == 0) *err = 1;
+         continue;
+      }
       const int       e0 = xrp[r0], e1 = xrp[r1], ne = e1 - e0;
       const long long p0 = eoff[e0];
       const int       span = (int)(eoff[e1] - p0);
       if (span == 0) continue;
-      int S = 256;
-      while (S < span) S <<= 1;
       const bool staged = ne <= kEscEntries;
       if (staged)
-      { // entry offsets and entry -> local row, coalesced
-         for (int q = tid; q <= ne; q += 256) eofs[q] = (int)(eoff[e0 + q] - p0);
+      { // entry offsets and entry -> local row, coalesced; then the entry of every product
+         for (int q = tid; q <= ne; q += 256) eofs[q] = (unsigned)(eoff[e0 + q] - p0);
+         __syncthreads();
          for (int r = r0 + tid; r < r1; r += 256)
-            for (int e = xrp[r]; e < xrp[r + 1]; e++) erow[e - e0] = r - r0;
+            for (int e = xrp[r]; e < xrp[r + 1]; e++) eofs[e - e0] |= (unsigned)(r - r0) << 13;
+         __syncthreads();
+         for (int q = tid; q < ne; q += 256)
+         {
+            const int a = (int)(eofs[q] & 0x1FFFu), b = (int)(eofs[q + 1] & 0x1FFFu); // eofs[ne] = span carries no row tag
+            for (int p = a; p < b; p++) ent[p] = (unsigned short)q;
+         }
          __syncthreads();
       }
-      // ---- expand: one product per lane; its X entry by binary search (LDS when staged)
-      for (int p = tid; p < S; p += 256)
+      // ---- expand: lane-consecutive products, so the gathers of one Y row coalesce
+      unsigned long long k[PER];
+#pragma unroll
+      for (int m = 0; m < PER; m++)
       {
+         const int          p   = tid + 256 * m;
          unsigned long long key = ~0ULL;
          if (p < span)
          {
             int e, lrow, q;
             if (staged)
             {
-               int lo = 0, hi = ne - 1; // last entry with eofs <= p
-               while (lo < hi)
-               {
-                  const int mid = (lo + hi + 1) >> 1;
-                  if (eofs[mid] <= p) lo = mid;
-                  else hi = mid - 1;
-               }
+               const int      lo = ent[p];
+               const unsigned w  = eofs[lo];
                e    = e0 + lo;
-               lrow = erow[lo];
-               q    = p - eofs[lo];
+               lrow = (int)(w >> 13);
+               q    = p - (int)(w & 0x1FFFu);
             }
             else
             {
                const long long gp = p0 + p;
-               int             lo = e0, hi = e1 - 1;
+               int             lo = e0, hi = e1 - 1; // last entry with eoff <= gp
                while (lo < hi)
                {
                   const int mid = (lo + hi + 1) >> 1;
@@ -1538,26 +1844,17 @@ __global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, int cap, const 
             key          = ((unsigned long long)lrow << 44) | ((unsigned long long)(unsigned)ycj[yq] << 13) | (unsigned long long)p;
             vals[p]      = xv[e] * yv[yq];
          }
-         keys[p] = key;
+         k[m] = key;
       }
+      block_sort_regs<PER>(k, keys, tid); // its first LDS use is behind a barrier: ent is dead by then
       __syncthreads();
-      // ---- bitonic sort of S keys
-      for (int k = 2; k <= S; k <<= 1)
-         for (int j = k >> 1; j > 0; j >>= 1)
-         {
-            for (int t = tid; t < (S >> 1); t += 256)
-            {
-               const int i = ((t / j) * (j << 1)) + (t % j), q = i + j;
-               const unsigned long long a = keys[i], b = keys[q];
-               const bool up = ((i & k) == 0);
-               if ((a > b) == up) { keys[i] = b; keys[q] = a; }
-            }
-            __syncthreads();
-         }
+#pragma unroll
+      for (int r = 0; r < PER; r++) keys[tid * PER + r] = k[r];
+      __syncthreads();
       // ---- heads of (row, column) segments; inclusive head count per sorted position
-      const int per = S >> 8, t0 = tid * per;
+      const int t0 = tid * PER;
       int       local = 0;
-      for (int t = t0; t < t0 + per && t < span; t++) local += (t == 0) || ((keys[t] >> 13) != (keys[t - 1] >> 13));
+      for (int t = t0; t < t0 + PER && t < span; t++) local += (t == 0) || ((keys[t] >> 13) != (keys[t - 1] >> 13));
       scan[tid] = local;
       __syncthreads();
       for (int o = 1; o < 256; o <<= 1)
@@ -1568,7 +1865,7 @@ __global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, int cap, const 
          __syncthreads();
       }
       int incl = scan[tid] - local; // heads before this lane's range
-      for (int t = t0; t < t0 + per && t < span; t++)
+      for (int t = t0; t < t0 + PER && t < span; t++)
       {
          const unsigned long long kt = keys[t];
          const bool head = (t == 0) || ((kt >> 13) != (keys[t - 1] >> 13));
@@ -1657,10 +1954,12 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
    HDA_HIP(hipMemcpyAsync(&total, eoff.data() + X.nnz, 8, hipMemcpyDeviceToHost, STREAM));
    HDA_HIP(hipMemcpyAsync(&maxnp, mx.data(), 4, hipMemcpyDeviceToHost, STREAM));
    Context::get().sync();
-   // chunk target T and LDS capacity 2T: a chunk spans < T + maxnp <= 2T products
-   int T = 1024;
-   while (T < maxnp) T <<= 1;
-   HDA_TRACE("  spgemm(esc): n=%d products=%lld max/row=%d T=%d", n, total, maxnp, T);
+   // LDS capacity cap (a power of two, >= 2 maxnp) and chunk target T = cap - maxnp: a chunk spans < T + maxnp = cap
+   // products, and nearly all of them close to T, so the sort network runs almost full
+   int cap = 2048;
+   while (cap < 2 * maxnp && cap < 8192) cap <<= 1;
+   const int T = std::max(cap - maxnp, 1);
+   HDA_TRACE("  spgemm(esc): n=%d products=%lld max/row=%d cap=%d", n, total, maxnp, cap);
    // product scratch (12 B each) may take up to 30 % of the device memory: 7 G products on a 288 GB part,
    // enough for the 512^3 benchmark's largest Galerkin product (5 G); beyond it the hash path takes over
    static const long long scratch_cap = [] {
@@ -1669,8 +1968,7 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
       if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return 3LL << 30;
       return (long long)(0.3 * (double)totalb / 12.0);
    }(); // products
-   if (T > 4096 || total > scratch_cap) return spgemm_hash(X, Y, C); // outside the LDS path
-   const int cap     = 2 * T;
+   if (maxnp > 4096 || total > scratch_cap) return spgemm_hash(X, Y, C); // outside the LDS path
    const int nchunks = (int)std::max<long long>(1, (total + T - 1) / T);
    DArray<int>       chunk_row((size_t)nchunks + 1), cnt((size_t)n + 1);
    DArray<long long> rowstart((size_t)n + 1), chunkbase((size_t)n + 1);
@@ -1679,25 +1977,31 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
    k_esc_chunk_rows<<<ceil_div(nchunks + 1, 256), 256, 0, STREAM>>>(nchunks, n, T, X.rowptr.data(), eoff.data(), chunk_row.data());
    k_esc_chunkbase<<<nchunks, 256, 0, STREAM>>>(nchunks, chunk_row.data(), X.rowptr.data(), eoff.data(), chunkbase.data());
    cnt.zero();
-   const size_t lds  = (size_t)cap * 16 + (size_t)(2 * kEscEntries + 2) * 4;
-   const int    grid = std::min(nchunks, 256 * 8);
-   static bool  attr_done = false;
-   if (!attr_done)
-   {
-      HDA_HIP(hipFuncSetAttribute((const void *)k_spgemm_esc, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16 + (2 * kEscEntries + 2) * 4));
-      attr_done = true;
-   }
-   k_spgemm_esc<<<grid, 256, lds, STREAM>>>(nchunks, cap, chunk_row.data(), X.rowptr.data(), X.col.data(), X.val.data(),
-                                            Y.rowptr.data(), Y.col.data(), Y.val.data(), eoff.data(), rowstart.data(), cnt.data(),
-                                            scol.data(), sval.data());
+   mx.zero(); // reused as the kernel's "row field overflow" flag
+   static_assert(2048 * 2 + (kEscEntries + 1) * 4 <= 2048 * 8, "entry staging must fit the key area of the smallest chunk");
+   const size_t lds  = (size_t)cap * 16;
+   const int    grid = std::min(nchunks, 256 * std::max(1, (int)((160 * 1024) / (lds + 1024)))); // the resident workgroups: no tail wave
+
+   auto launch = [&](auto kern) {
+      HDA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      kern<<<grid, 256, lds, STREAM>>>(nchunks, chunk_row.data(), X.rowptr.data(), X.col.data(), X.val.data(), Y.rowptr.data(),
+                                       Y.col.data(), Y.val.data(), eoff.data(), rowstart.data(), cnt.data(), scol.data(), sval.data(),
+                                       mx.data());
+   };
+   if (cap == 2048) launch(k_spgemm_esc<8>);
+   else if (cap == 4096) launch(k_spgemm_esc<16>);
+   else launch(k_spgemm_esc<32>);
    k_esc_fix_counts<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, nullptr, nullptr, nullptr, rowstart.data(), chunkbase.data(), cnt.data());
    C.nrows = n;
    C.ncols = Y.ncols;
    C.rowptr.alloc((size_t)n + 1);
    require_int32_total(n, cnt.data(), "sparse product");
    exclusive_scan(n, cnt.data(), C.rowptr.data(), nullptr);
+   int overflow = 0;
    HDA_HIP(hipMemcpyAsync(&C.nnz, C.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   HDA_HIP(hipMemcpyAsync(&overflow, mx.data(), 4, hipMemcpyDeviceToHost, STREAM));
    Context::get().sync();
+   if (overflow) return spgemm_hash(X, Y, C); // a chunk spanned 2^19 rows or more (long runs of empty rows)
    C.col.alloc((size_t)std::max(C.nnz, 1));
    C.val.alloc((size_t)std::max(C.nnz, 1));
    k_esc_compact<<<std::min(ceil_div((long long)n * 8, 256), 1 << 16), 256, 0, STREAM>>>(n, C.rowptr.data(), rowstart.data(), scol.data(),

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -198,12 +199,18 @@ inline bool verbose()
    static const bool v = getenv("HDA_VERBOSE") != nullptr;
    return v;
 }
+inline double trace_ms() // milliseconds since the first trace point
+{
+   static const auto t0 = std::chrono::steady_clock::now();
+   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 #define HDA_TRACE(...)                                 \
    do {                                                \
       if (::hda::verbose())                            \
       {                                                \
          ::hda::Context::get().sync();                 \
-         fprintf(stderr, "[hda] " __VA_ARGS__);        \
+         fprintf(stderr, "[hda %9.2f] ", ::hda::trace_ms()); \
+         fprintf(stderr, __VA_ARGS__);                 \
          fprintf(stderr, "\n");                        \
          fflush(stderr);                               \
       }                                                \

@@ -7,6 +7,7 @@
 // dot product is produced as kRedBlocks block partials in a fixed tree (deterministic) and
 // fused into the kernel that already streams the operands.
 #include "hda_kernels.h"
+#include "hda_sort.h"
 
 #include "hda_dist.h"
 
@@ -1013,35 +1014,33 @@ __global__ __launch_bounds__(256) void k_wchunk_rows(int nw, int nrows, const in
    wmeta[3 * c]     = lo;
    wmeta[3 * c + 1] = rowptr[lo];
 }
-// sorts the columns of a chunk in LDS and leaves the distinct ones, ascending, in keys[0 .. return value)
+// sorts the columns of a chunk (in registers, hda_sort.h) and leaves the distinct ones, ascending, in keys[0 .. return value)
+template <int PER>
 __device__ int win_sort_unique(const int *__restrict__ col, int k0, int n, int *keys, int *scan)
 {
    const int tid = threadIdx.x;
-   int       m   = 256;
-   while (m < n) m <<= 1;
-   for (int i = tid; i < m; i += 256) keys[i] = (i < n) ? col[k0 + i] : 0x7fffffff;
-   __syncthreads();
-   for (int k = 2; k <= m; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1)
-      {
-         for (int i = tid; i < m; i += 256)
-         {
-            const int p = i ^ j;
-            if (p > i)
-            {
-               const int  a = keys[i], b = keys[p];
-               const bool up = ((i & k) == 0);
-               if ((a > b) == up) { keys[i] = b; keys[p] = a; }
-            }
-         }
-         __syncthreads();
-      }
-   const int per = m / 256;
-   int       cnt = 0, mine[kWinSort / 256], nm = 0;
-   for (int q = 0; q < per; q++)
+   int       k[PER];
+#pragma unroll
+   for (int m = 0; m < PER; m++)
    {
-      const int i = tid * per + q;
-      if (i < n && (i == 0 || keys[i] != keys[i - 1])) { cnt++; mine[nm++] = keys[i]; }
+      const int i = tid + 256 * m; // any initial placement will do: coalesced reads
+      k[m]        = (i < n) ? col[k0 + i] : 0x7fffffff;
+   }
+   block_sort_regs<PER>(k, keys, tid); // element tid*PER + r of the sorted sequence is now k[r]
+   __syncthreads();
+   scan[tid] = k[PER - 1];
+   __syncthreads();
+   int prev = (tid > 0) ? scan[tid - 1] : -1; // columns are non-negative
+   __syncthreads();
+   int      cnt   = 0;
+   unsigned heads = 0; // bit r: k[r] is the first of its value
+#pragma unroll
+   for (int r = 0; r < PER; r++)
+   {
+      const bool head = (tid * PER + r < n) && (k[r] != prev);
+      prev            = k[r];
+      heads |= (unsigned)head << r;
+      cnt += head;
    }
    scan[tid] = cnt;
    __syncthreads();
@@ -1052,8 +1051,11 @@ __device__ int win_sort_unique(const int *__restrict__ col, int k0, int n, int *
       scan[tid] += v;
       __syncthreads();
    }
-   const int total = scan[255], pos = scan[tid] - cnt;
-   for (int q = 0; q < nm; q++) keys[pos + q] = mine[q]; // (every thread holds its own elements in registers: no hazard)
+   const int total = scan[255];
+   int       pos   = scan[tid] - cnt;
+#pragma unroll
+   for (int r = 0; r < PER; r++)
+      if ((heads >> r) & 1u) keys[pos++] = k[r]; // the sort's exchange area is free again (barriers above)
    __syncthreads();
    return total;
 }
@@ -1066,7 +1068,7 @@ __global__ __launch_bounds__(256) void k_win_count(int nw, const int *__restrict
    for (int c = blockIdx.x; c < nw; c += gridDim.x)
    {
       const int k0 = wmeta[3 * c + 1], n = wmeta[3 * c + 4] - k0;
-      const int t  = (n > 0) ? win_sort_unique(col, k0, n, keys, scan) : 0;
+      const int t  = (n <= 0) ? 0 : (n <= 1024) ? win_sort_unique<4>(col, k0, n, keys, scan) : win_sort_unique<kWinSort / 256>(col, k0, n, keys, scan);
       for (int j = threadIdx.x; j < t; j += 256) tcol[k0 + j] = keys[j];
       if (threadIdx.x == 0) ucount[c] = t;
       __syncthreads();
