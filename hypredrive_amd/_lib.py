@@ -66,7 +66,7 @@ SYMBOLS = [
     "hda_last_error", "hda_device_count", "hda_device_name", "hda_device_sync",
     "hda_amg_default_params", "hda_krylov_default_params", "hda_csr_create", "hda_csr_destroy",
     "hda_csr_dims", "hda_csr_download", "hda_lap7_create", "hda_spmv", "hda_relax", "hda_dot",
-    "hda_l1_norms", "hda_strength", "hda_pmis", "hda_interp_extpi", "hda_rap", "hda_transpose",
+    "hda_l1_norms", "hda_strength", "hda_pmis", "hda_interp_extpi", "hda_interp_direct", "hda_rap", "hda_transpose",
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
@@ -105,6 +105,7 @@ def load():
     L.hda_strength.argtypes = [vp, C.c_double, C.c_double, P(C.c_ubyte)]
     L.hda_pmis.argtypes = [vp, P(C.c_ubyte), C.c_uint64, C.c_int, C.c_int64, ip]
     L.hda_interp_extpi.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
+    L.hda_interp_direct.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
     L.hda_rap.argtypes = [vp, vp, P(vp)]
     L.hda_transpose.argtypes = [vp, P(vp)]
     L.hda_spgemm.argtypes = [vp, vp, P(vp)]
@@ -251,6 +252,15 @@ class Csr:
         out = C.c_void_p()
         _check(load().hda_interp_extpi(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cfa), pmax,
                                        trunc_factor, C.byref(out)))
+        return Csr(out)
+
+    def interp_direct(self, smask, cf, pmax=4, trunc_factor=0.0):
+        """interpolation type 3 (direct_sep_weights)"""
+        sm = np.ascontiguousarray(np.concatenate([smask, np.zeros(1, np.uint8)]), dtype=np.uint8)
+        cfa = np.ascontiguousarray(np.concatenate([cf, np.zeros(1, np.int32)]), dtype=np.int32)
+        out = C.c_void_p()
+        _check(load().hda_interp_direct(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cfa), pmax,
+                                        trunc_factor, C.byref(out)))
         return Csr(out)
 
     def rap(self, P):

@@ -27,7 +27,7 @@ struct AmgParams {
    int    min_coarse_size = 0;
    int    max_levels      = 25;
    // interpolation (amg.c:120-128)
-   int    interp_type  = 6; // extended+i
+   int    interp_type  = 6; // extended+i (17: mm-ext+i, the same operator); 3: direct with separation of weights (one rank)
    int    pmax         = 4;
    double trunc_factor = 0.0;
    // relaxation (amg.c:178-199)
@@ -267,9 +267,10 @@ void amg_strength(const DCsr &A, double theta, double max_row_sum, unsigned char
 // hypre_BoomerAMGCoarsenPMIS: cf[i] = 1 C, -1 F, -3 special F. row_offset = global id of row 0.
 void amg_pmis(const DCsr &A, const unsigned char *smask, uint64_t seed, int level,
               long long row_offset, int *cf);
-// hypre_BoomerAMGBuildExtPIInterp + InterpTruncation: P (nrows x nc), rows column-sorted.
+// hypre_BoomerAMGBuildExtPIInterp (interp_type 6 / 17) or hypre_BoomerAMGBuildDirInterp with separation of weights (3),
+// then InterpTruncation: P (nrows x nc), rows column-sorted.
 void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax, // trailing dof: as amg_strength
-                      double trunc_factor, DCsr &P, const int *dof = nullptr);
+                      double trunc_factor, DCsr &P, const int *dof = nullptr, int interp_type = 6);
 // hypre_ParCSRMatMat-style product C = X*Y, deterministic accumulation order, rows sorted.
 void spgemm(const DCsr &X, const DCsr &Y, DCsr &C);
 // hypre_BoomerAMGBuildCoarseOperator: Ac = R*(A*P) with R = P^T

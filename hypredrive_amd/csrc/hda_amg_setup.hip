@@ -534,8 +534,8 @@ __global__ __launch_bounds__(256) void k_interp_build(
    const unsigned char *__restrict__ smask, const int *__restrict__ cf,
    const long long *__restrict__ uofs, const long long *__restrict__ hofs, int *__restrict__ lcol,
    double *__restrict__ lw, int *__restrict__ htab, int pmax, double trunc_factor, int *__restrict__ pcnt,
-   const unsigned char *__restrict__ rowmode, const int *__restrict__ dof)
-{
+   const unsigned char *__restrict__ rowmode, const int *__restrict__ dof, int itype)
+{ // itype 6: extended+i; 3: direct interpolation with separation of weights (strong C neighbours only)
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
    if (rowmode && !rowmode[i]) return; // handled by the wave-per-row kernel
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void k_interp_build(
       if (!smask[k]) continue;
       const int j = cj[k];
       if (cf[j] == 1) add(j);
-      else if (cf[j] == -1)
+      else if (cf[j] == -1 && itype != 3)
          for (int kk = rp[j]; kk < rp[j + 1]; kk++)
          {
             const int m = cj[kk];
@@ -605,6 +605,33 @@ __global__ __launch_bounds__(256) void k_interp_build(
    double diagonal = 0.0;
    for (int k = k0; k < k1; k++)
       if (cj[k] == i) diagonal = v[k];
+   if (itype == 3)
+   { // the oracle's orc_interp_direct_dof, entry for entry
+      double sum_N_pos = 0.0, sum_N_neg = 0.0, sum_P_pos = 0.0, sum_P_neg = 0.0;
+      for (int k = k0; k < k1; k++)
+      {
+         const int j = cj[k];
+         if (j == i) continue;
+         const double a = v[k];
+         if (!(dof && dof[j] != dof[i]))
+         {
+            if (a > 0.0) sum_N_pos += a;
+            else sum_N_neg += a;
+         }
+         if (smask[k] && cf[j] == 1)
+         {
+            W[find(j)] = a; // (a strong C neighbour occurs once in the row)
+            if (a > 0.0) sum_P_pos += a;
+            else sum_P_neg += a;
+         }
+      }
+      double alfa = 1.0, beta = 1.0;
+      if (sum_P_neg != 0.0) alfa = sum_N_neg / sum_P_neg / diagonal;
+      if (sum_P_pos != 0.0) beta = sum_N_pos / sum_P_pos / diagonal;
+      for (int q = 0; q < cnt; q++) W[q] *= (W[q] > 0.0) ? -beta : -alfa;
+      diagonal = 0.0; // nothing left to divide by below
+   }
+   else
    for (int k = k0; k < k1; k++)
    {
       const int j = cj[k];
@@ -1377,8 +1404,10 @@ __global__ __launch_bounds__(256) void k_interp_gather(int n, const long long *_
 }
 
 void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax,
-                      double trunc_factor, DCsr &P, const int *dof)
+                      double trunc_factor, DCsr &P, const int *dof, int interp_type)
 {
+   HDA_REQUIRE(interp_type == 6 || interp_type == 17 || interp_type == 3, "interpolation type not implemented");
+   const int itype = (interp_type == 3) ? 3 : 6;
    const int n = A.nrows;
    const int g = ceil_div(std::max(n, 1), 256);
    DArray<int>       nsC((size_t)n + 1), ub((size_t)n + 1), hsz((size_t)n + 1), cmark((size_t)n + 1), cidx((size_t)n + 1), nt((size_t)n + 1);
@@ -1398,7 +1427,7 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    // G lanes share a row (8 for stencil rows, a whole wavefront for the long rows of coarse levels): the row, its
    // candidates and its neighbour rows are staged in LDS by coalesced reads.  The thread-per-row kernel keeps the rows
    // that exceed the LDS budget, and everything when pmax is outside the group kernel's range.
-   bool use_wave = pmax > 0 && pmax <= 16;
+   bool use_wave = pmax > 0 && pmax <= 16 && itype == 6; // the group kernel is extended+i only
    if (imode && !strcmp(imode, "thread")) use_wave = false;
    static const int g_env = getenv("HDA_INTERP_LANES") ? atoi(getenv("HDA_INTERP_LANES")) : 0;
    int G = 64; // (32 lanes for rows of ~30 entries measured twice as slow as 64: eight rows' staging areas leave one workgroup per CU)
@@ -1470,11 +1499,11 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
       // the rows the wave kernel left to the thread kernel (rowmode): also when none of them needs a hash table
       // (C points and non-interpolated F points among them still have to report their entry count)
       k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
-                                            lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), rowmode.data(), dof);
+                                            lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), rowmode.data(), dof, itype);
    }
    else
       k_interp_build<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, uofs.data(), hofs.data(),
-                                            lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), nullptr, dof);
+                                            lcol.data(), lw.data(), htab.data(), pmax, trunc_factor, pcnt.data(), nullptr, dof, itype);
    HDA_TRACE("  interp: build done");
    P.nrows = n;
    P.ncols = nc;
@@ -2080,7 +2109,7 @@ void Amg::build_hierarchy(const DCsr &A)
    HDA_REQUIRE(prm.coarsen_type == 8 || prm.coarsen_type == 10, "device AMG setup implements PMIS (8) and, on one rank, HMIS (10) coarsening");
    // 17 = "mm-ext+i" (reference src/internal/amg.c:266-268): hypre's matrix-matrix formulation of the SAME extended+i operator
    // (its GPU interpolation); one algorithm serves both names here
-   HDA_REQUIRE(prm.interp_type == 6 || prm.interp_type == 17,
+   HDA_REQUIRE(prm.interp_type == 6 || prm.interp_type == 17 || prm.interp_type == 3,
                "interpolation type is not implemented on MI355X: extended+i (6) and its matrix-matrix form mm-ext+i (17) are");
    auto known = [](int t) { return is_jacobi_type(t) || is_gs_type(t) || t == 16; };
    HDA_REQUIRE(known(prm.relax_down) && known(prm.relax_up),
@@ -2134,7 +2163,7 @@ void Amg::build_hierarchy(const DCsr &A)
       HDA_TRACE("level %d: interp", lvl);
       auto t2 = tick();
       DCsr P;
-      amg_interp_extpi(Al, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, P, dof);
+      amg_interp_extpi(Al, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, P, dof, prm.interp_type);
       auto t3 = tick();
       const int nc = P.ncols;
       if (nc == 0 || nc == n || nc < prm.min_coarse_size) break;

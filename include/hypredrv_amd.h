@@ -96,6 +96,10 @@ int hda_pmis(hda_csr_t A, const unsigned char *smask, uint64_t seed, int level,
 /* hypre_BoomerAMGBuildExtPIInterp + hypre_BoomerAMGInterpTruncation */
 int hda_interp_extpi(hda_csr_t A, const unsigned char *smask, const int *cf, int pmax,
                      double trunc_factor, hda_csr_t *P);
+/* hypre_BoomerAMGBuildDirInterp with separation of weights (interpolation type 3, "direct_sep_weights",
+ * reference src/internal/amg.c:258-270) + hypre_BoomerAMGInterpTruncation */
+int hda_interp_direct(hda_csr_t A, const unsigned char *smask, const int *cf, int pmax,
+                      double trunc_factor, hda_csr_t *P);
 /* hypre_BoomerAMGBuildCoarseOperator (P^T A P) */
 int hda_rap(hda_csr_t A, hda_csr_t P, hda_csr_t *Ac);
 int hda_transpose(hda_csr_t A, hda_csr_t *T);

@@ -770,6 +770,36 @@ pent_qsort_abs(pent *v, int n)
    }
 }
 
+/* hypre_BoomerAMGInterpTruncation on one row (still in discovery order): relative threshold, then keep the
+ * pmax largest; each step rescales to preserve the row sum.  Returns the new entry count. */
+static int
+orc_truncate_row(pent *row, int cnt, int pmax, double trunc_factor)
+{
+   if (trunc_factor > 0.0 && cnt > 0)
+   {
+      double mx = 0.0, tot = 0.0, kept = 0.0;
+      for (int q = 0; q < cnt; q++) { if (fabs(row[q].w) > mx) mx = fabs(row[q].w); tot += row[q].w; }
+      int c2 = 0;
+      for (int q = 0; q < cnt; q++)
+         if (fabs(row[q].w) >= trunc_factor * mx) { row[c2++] = row[q]; kept += row[c2 - 1].w; }
+      cnt = c2;
+      if (kept != 0.0) { double sc = tot / kept; for (int q = 0; q < cnt; q++) row[q].w *= sc; }
+   }
+   if (pmax > 0 && cnt > pmax)
+   {
+      double tot = 0.0, kept = 0.0;
+      for (int q = 0; q < cnt; q++) tot += row[q].w;
+      pent_qsort_abs(row, cnt);
+      cnt = pmax;
+      /* the kept SET is what the sort decides; sums run in column order so that a
+       * data-parallel top-k selection gives bit-identical weights */
+      qsort(row, (size_t)cnt, sizeof(pent), pent_cmp_col);
+      for (int q = 0; q < cnt; q++) kept += row[q].w;
+      if (kept != 0.0) { double sc = tot / kept; for (int q = 0; q < cnt; q++) row[q].w *= sc; }
+   }
+   return cnt;
+}
+
 /* hypre_BoomerAMGBuildExtPIInterp + hypre_BoomerAMGInterpTruncation (interp type 6,
  * src/internal/amg.c:122-125,869,883-884), SURVEY App. A.6.  Rows column-sorted. */
 orc_csr *
@@ -893,30 +923,7 @@ orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf
          }
          if (diagonal != 0.0)
             for (int q = 0; q < cnt; q++) row[q].w = row[q].w / (-diagonal);
-         /* truncation (row still in discovery order): relative threshold, then keep the
-          * pmax largest; each step rescales to preserve the row sum */
-         if (trunc_factor > 0.0 && cnt > 0)
-         {
-            double mx = 0.0, tot = 0.0, kept = 0.0;
-            for (int q = 0; q < cnt; q++) { if (fabs(row[q].w) > mx) mx = fabs(row[q].w); tot += row[q].w; }
-            int c2 = 0;
-            for (int q = 0; q < cnt; q++)
-               if (fabs(row[q].w) >= trunc_factor * mx) { row[c2++] = row[q]; kept += row[c2 - 1].w; }
-            cnt = c2;
-            if (kept != 0.0) { double sc = tot / kept; for (int q = 0; q < cnt; q++) row[q].w *= sc; }
-         }
-         if (pmax > 0 && cnt > pmax)
-         {
-            double tot = 0.0, kept = 0.0;
-            for (int q = 0; q < cnt; q++) tot += row[q].w;
-            pent_qsort_abs(row, cnt);
-            cnt = pmax;
-            /* the kept SET is what the sort decides; sums run in column order so that a
-             * data-parallel top-k selection gives bit-identical weights */
-            qsort(row, (size_t)cnt, sizeof(pent), pent_cmp_col);
-            for (int q = 0; q < cnt; q++) kept += row[q].w;
-            if (kept != 0.0) { double sc = tot / kept; for (int q = 0; q < cnt; q++) row[q].w *= sc; }
-         }
+         cnt = orc_truncate_row(row, cnt, pmax, trunc_factor);
       }
       qsort(row, (size_t)cnt, sizeof(pent), pent_cmp_col); /* storage order: by column */
       if (pnnz + cnt > pcap)
@@ -933,6 +940,89 @@ orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf
    orc_csr *P = (orc_csr *)calloc(1, sizeof(orc_csr));
    P->nrows = n; P->ncols = nc; P->rowptr = prow; P->col = pcol; P->val = pval;
    free(cidx); free(pm); free(pst); free(sfm); free(row); free(rfine);
+   return P;
+}
+
+/* hypre_BoomerAMGBuildDirInterp with separation of weights (interp type 3, "direct_sep_weights" in
+ * src/internal/amg.c:258-270; examples/ex8-amg-5.yml, pinned by examples/refOutput/ex8.txt:96) followed by
+ * hypre_BoomerAMGInterpTruncation.  hypre itself is not in /root/reference: this restates the published
+ * algorithm -- an F point interpolates from its strong C neighbours only,
+ *    w_ij = -alpha a_ij / a_ii (a_ij < 0),  -beta a_ij / a_ii (a_ij > 0),
+ *    alpha = sum of the negative off-diagonals of row i / sum of the negative a_ij over the strong C neighbours,
+ *    beta likewise for the positive ones (1 when the interpolatory set has no entry of that sign).
+ * Other functions' unknowns take no part in the row sums (dof != NULL). */
+orc_csr *
+orc_interp_direct_dof(const orc_csr *A, const unsigned char *smask, const int *cf, int pmax,
+                      double trunc_factor, const int *dof)
+{
+   int  n    = A->nrows;
+   int *cidx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+   int  nc   = 0;
+   for (int i = 0; i < n; i++) cidx[i] = (cf[i] == ORC_C_PT) ? nc++ : -1;
+   int     cap = 64;
+   pent   *row = (pent *)malloc(sizeof(pent) * (size_t)cap);
+   int     pcap = 4 * n + 16, pnnz = 0;
+   int    *prow = (int *)calloc((size_t)n + 1, sizeof(int));
+   int    *pcol = (int *)malloc(sizeof(int) * (size_t)pcap);
+   double *pval = (double *)malloc(sizeof(double) * (size_t)pcap);
+   for (int i = 0; i < n; i++)
+   {
+      int cnt = 0;
+      if (cf[i] == ORC_C_PT)
+      {
+         row[0].c = cidx[i];
+         row[0].w = 1.0;
+         cnt      = 1;
+      }
+      else if (cf[i] == ORC_F_PT)
+      {
+         int    k0 = A->rowptr[i], k1 = A->rowptr[i + 1];
+         double diagonal = 0.0, sum_N_pos = 0.0, sum_N_neg = 0.0, sum_P_pos = 0.0, sum_P_neg = 0.0;
+         if (k1 - k0 >= cap)
+         {
+            cap = 2 * (k1 - k0) + 16;
+            row = (pent *)realloc(row, sizeof(pent) * (size_t)cap);
+         }
+         for (int k = k0; k < k1; k++)
+            if (A->col[k] == i) diagonal = A->val[k];
+         for (int k = k0; k < k1; k++)
+         {
+            int j = A->col[k];
+            if (j == i) continue;
+            double a = A->val[k];
+            if (!(dof && dof[j] != dof[i]))
+            {
+               if (a > 0.0) sum_N_pos += a;
+               else sum_N_neg += a;
+            }
+            if (smask[k] && cf[j] == ORC_C_PT)
+            {
+               row[cnt].c = cidx[j];
+               row[cnt].w = a;
+               cnt++;
+               if (a > 0.0) sum_P_pos += a;
+               else sum_P_neg += a;
+            }
+         }
+         double alfa = 1.0, beta = 1.0;
+         if (sum_P_neg != 0.0) alfa = sum_N_neg / sum_P_neg / diagonal;
+         if (sum_P_pos != 0.0) beta = sum_N_pos / sum_P_pos / diagonal;
+         for (int q = 0; q < cnt; q++) row[q].w *= (row[q].w > 0.0) ? -beta : -alfa;
+         cnt = orc_truncate_row(row, cnt, pmax, trunc_factor);
+      }
+      qsort(row, (size_t)cnt, sizeof(pent), pent_cmp_col); /* storage order: by column */
+      if (pnnz + cnt > pcap)
+      {
+         pcap = 2 * pcap + cnt;
+         pcol = (int *)realloc(pcol, sizeof(int) * (size_t)pcap);
+         pval = (double *)realloc(pval, sizeof(double) * (size_t)pcap);
+      }
+      for (int q = 0; q < cnt; q++) { pcol[pnnz] = row[q].c; pval[pnnz++] = row[q].w; }
+      prow[i + 1] = pnnz;
+   }
+   orc_csr *P = (orc_csr *)calloc(1, sizeof(orc_csr));
+   P->nrows = n; P->ncols = nc; P->rowptr = prow; P->col = pcol; P->val = pval;
+   free(cidx); free(row);
    return P;
 }
 
@@ -1388,7 +1478,8 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
          break;
       }
       h->cf[lvl] = cf;
-      h->P[lvl]  = orc_interp_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof);
+      h->P[lvl]  = (p->interp_type == 3) ? orc_interp_direct_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
+                                          : orc_interp_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof);
       if (dof)
       { /* coarse unknowns keep the function of their fine C point */
          int q = 0;

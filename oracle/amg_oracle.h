@@ -34,7 +34,7 @@ typedef struct {
  * defaults of src/internal/amg.c:120-238. */
 typedef struct {
    int    coarsen_type;    /* 8 PMIS (hypre-GPU default), 10 HMIS, 6 Falgout->RS pass */
-   int    interp_type;     /* 6 extended+i */
+   int    interp_type;     /* 6 extended+i (17: its matrix-matrix form, same operator), 3 direct with separation of weights */
    int    pmax;            /* interpolation.max_nnz_row = 4 */
    double trunc_factor;    /* 0.0 */
    double strong_th;       /* 0.25 */
@@ -112,6 +112,9 @@ orc_csr *orc_interp_extpi(const orc_csr *A, const unsigned char *smask, const in
                           int pmax, double trunc_factor);
 orc_csr *orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf,
                               int pmax, double trunc_factor, const int *dof);
+/* interp type 3: direct interpolation with separation of weights (strong C neighbours only) */
+orc_csr *orc_interp_direct_dof(const orc_csr *A, const unsigned char *smask, const int *cf,
+                               int pmax, double trunc_factor, const int *dof);
 orc_csr *orc_rap(const orc_csr *A, const orc_csr *P);
 
 /* Hierarchy */

@@ -186,6 +186,32 @@ def test_cli_runs_ex8_multi_unchanged(orc, pins):
             assert abs(int(rows[k][3]) - pins["ex8"]["stats"][ref_entry[k]]["iters"]) <= 1
 
 
+def test_cli_runs_ex8_unchanged(orc, pins):
+    """The reference's examples/ex8.yml UNCHANGED: five BoomerAMG variants as sequence items under `preconditioner: amg` -- the
+    fifth with `prolongation_type: direct_sep_weights` (interpolation type 3) and two l1 symmetric Gauss-Seidel sweeps.  Every
+    variant takes the oracle's iteration count; the reference's own counts (refOutput/ex8.txt:92-96, made from the first of the
+    four part files: half the right-hand side of this run) stay within one."""
+    cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
+    r = subprocess.run([cli, "-q", "examples/ex8.yml"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = re.findall(r"^\|\s+(\d+) \|\s+[\d.]* \|\s+[\d.]+ \|\s+[\d.]+ \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
+    assert [int(q[0]) for q in rows] == [0, 1, 2, 3, 4], r.stdout
+    assert all(q[1] == "3.16e+01" and float(q[2]) < 1e-9 for q in rows)
+    A, b = orc.lap7(10, 10, 10, b_mode=1)
+    variants = [dict(coarsen_type=10, strong_th=0.25, relax_down=16, relax_up=16),
+                dict(coarsen_type=10, strong_th=0.5, relax_down=16, relax_up=16, cheby_order=4, cheby_fraction=0.1),
+                dict(coarsen_type=10, strong_th=0.8, relax_down=8, relax_up=8),
+                dict(coarsen_type=10, strong_th=0.9, relax_down=16, relax_up=16),
+                dict(coarsen_type=8, interp_type=3, strong_th=0.5, relax_down=8, relax_up=8, sweeps_down=2, sweeps_up=2)]
+    for k, v in enumerate(variants):
+        amg = orc.Amg(A, orc.amg_params(False, **v))
+        if k == 3:
+            amg.set_ilu_smoother(1, 1)
+        ro = orc.pcg(A, b, amg, orc.krylov_params(False, rtol=1e-9, max_iter=500))
+        assert int(rows[k][3]) == ro["iters"], (k, rows[k], ro["iters"])
+        assert abs(int(rows[k][3]) - pins["ex8"]["stats"][k]["iters"]) <= 1
+
+
 def test_null_space_projection(hd):
     """HYPREDRV_LinearSystemSetNullSpace + the projection at the end of LinearSolverApply, as the reference's own test drives them
     (tests/test_hypredrv.c:4188-4350): modes before the matrix fail cleanly; two non-orthogonal modes are orthonormalised and the

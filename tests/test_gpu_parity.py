@@ -236,6 +236,53 @@ def test_interp_and_rap_bit_exact(orc, hd, shape, pmax, tf):
     assert np.array_equal(v, Aco.val), np.abs(v - Aco.val).max()
 
 
+@pytest.mark.parametrize("pmax,tf", [(4, 0.0), (0, 0.0), (2, 0.3)])
+def test_direct_interp_bit_exact(orc, hd, pmax, tf):
+    """Interpolation type 3 (`direct_sep_weights`, the fifth variant of the reference's examples/ex8.yml): strong C neighbours
+    only, negative and positive entries scaled separately.  Same pattern and the same bits as the oracle on a stencil operator
+    and on operators with off-diagonals of both signs (beta != 1), with and without truncation."""
+    mats = [both(orc, hd, orc.lap7(12, 11, 10)[0].to_scipy())]
+    for seed in (3, 4):
+        M = rand_spd(600, 0.02, seed)  # positive off-diagonals
+        mats.append(both(orc, hd, M))
+        rng = np.random.default_rng(seed)
+        M2 = M.copy()
+        M2.data = np.where(rng.random(M2.nnz) < 0.5, -1.0, 1.0) * M2.data
+        M2 = ((M2 + M2.T) * 0.5).tocsr()
+        M2.setdiag(np.asarray(abs(M2).sum(axis=1)).ravel() + 1.0)
+        M2.sort_indices()
+        mats.append(both(orc, hd, M2.tocsr()))
+    for Ao, Ah in mats:
+        sm = orc.strength(Ao, 0.25, 0.9)
+        cf = orc.pmis(Ao, sm)
+        Po = orc.interp_direct(Ao, sm, cf, pmax, tf)
+        rp, cj, v = Ah.interp_direct(sm, cf, pmax, tf).download()
+        assert np.array_equal(rp, Po.rowptr) and np.array_equal(cj, Po.col)
+        assert np.array_equal(v, Po.val), np.abs(v - Po.val).max()
+        if pmax:
+            assert np.diff(rp).max() <= pmax
+        F = np.flatnonzero(cf == -1)
+        assert np.all(np.diff(rp)[cf == 1] == 1) and (len(F) == 0 or np.diff(rp)[F].max() > 0)
+
+
+def test_direct_interp_hierarchy_and_pcg_match_oracle(orc, hd):
+    """The whole setup with interpolation type 3 (PMIS 0.5, two symmetric l1 Gauss-Seidel sweeps: examples/ex8.yml:69-79)."""
+    Ao, b = orc.lap7(14, 13, 12, b_mode=1)
+    Ah = hd.lap7(14, 13, 12)
+    kw = dict(coarsen_type=8, interp_type=3, strong_th=0.5, relax_down=8, relax_up=8, sweeps_down=2, sweeps_up=2)
+    ho = orc.Amg(Ao, orc.amg_params(False, **kw))
+    hh = hd.Amg(Ah, hd.AmgParams.default(relax_coarse=9, **kw))
+    assert hh.num_levels == ho.num_levels
+    for l in range(ho.num_levels - 1):
+        rp, cj, v = hh.level_matrix(l, 1).download()
+        Pl = ho.level_P(l)
+        assert np.array_equal(rp, Pl.rowptr) and np.array_equal(cj, Pl.col) and np.array_equal(v, Pl.val)
+    ro = orc.pcg(Ao, b, ho, orc.krylov_params(False, rtol=1e-9, max_iter=100))
+    rh = hd.pcg(Ah, b, hh, hd.KrylovParams.default(False, rtol=1e-9, max_iter=100))
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-9)
+
+
 def test_spgemm_and_transpose_vs_scipy(orc, hd, monkeypatch):
     rng = np.random.default_rng(11)
     X = sp.random(400, 300, density=0.03, random_state=rng, format="csr")

@@ -424,3 +424,26 @@ def test_pin_ex8_chebyshev_l1symgs_ilu_variants(orc, pins):
         assert abs(r["iters"] - ref[k]["iters"]) <= 1, (k, r["iters"], ref[k]["iters"])
         got.append(r["iters"])
     assert got == [6, 5, 6, 6]  # the oracle's own counts, so that a change of the restatement shows up here
+
+
+def test_pin_ex8_fifth_variant_direct_interpolation(orc, pins):
+    """examples/refOutput/ex8.txt:96 -- the fifth variant: PMIS 0.5, two l1 symmetric Gauss-Seidel sweeps (type 8) down and
+    up, 6 iterations.  That output echoes `prolongation_type: standard` (ex8.txt:74) while the examples/ex8.yml in the tree
+    says `direct_sep_weights` (ex8.yml:76): the pin constrains the restated direct interpolation (type 3) only as far as the
+    two operators agree on this grid -- SURVEY 8(c)'s +-1."""
+    A, b = ex8_system(orc)
+    ref = pins["ex8"]["stats"][4]
+    amg = orc.Amg(A, orc.amg_params(False, coarsen_type=8, interp_type=3, strong_th=0.5, relax_down=8, relax_up=8, sweeps_down=2, sweeps_up=2))
+    r = orc.pcg(A, b, amg, orc.krylov_params(False, rtol=1e-9, max_iter=500))
+    assert r["converged"] and abs(r["iters"] - ref["iters"]) <= 1, (r["iters"], ref["iters"])
+    assert r["iters"] == 6  # the oracle's own count
+    # direct interpolation: an F row names strong C neighbours only, rows sum to ~1 on this M-matrix interior
+    P = amg.level_P(0)
+    cf = amg.level_cf(0)
+    sm = orc.strength(A, 0.5, 0.9)
+    S = A.to_scipy().tocsr()
+    cidx = np.cumsum(cf == 1) - 1
+    for i in np.flatnonzero(cf == -1)[:200]:
+        strongC = {int(cidx[j]) for k, j in zip(range(S.indptr[i], S.indptr[i + 1]), S.indices[S.indptr[i]:S.indptr[i + 1]]) if sm[k] and cf[j] == 1}
+        assert set(P.col[P.rowptr[i]:P.rowptr[i + 1]]) <= strongC
+
