@@ -38,14 +38,6 @@ class AmgParams(C.Structure):
         return p
 
 
-class MgrLevelParams(C.Structure):
-    _fields_ = [("n_f_labels", C.c_int), ("f_labels", C.POINTER(C.c_int)), ("interp_type", C.c_int), ("restrict_type", C.c_int),
-                ("frelax_type", C.c_int), ("frelax_sweeps", C.c_int), ("grelax_type", C.c_int), ("grelax_sweeps", C.c_int),
-                ("frelax_amg", C.POINTER(AmgParams)),
-                ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int),
-                ("coarse_ilu_max_iter", C.c_int), ("coarse_ilu_tri_solve", C.c_int), ("coarse_ilu_lower_it", C.c_int), ("coarse_ilu_upper_it", C.c_int)]
-
-
 class KrylovParams(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
                 ("two_norm", C.c_int), ("krylov_dim", C.c_int)]
@@ -59,6 +51,16 @@ class KrylovParams(C.Structure):
                 raise KeyError(k)
             setattr(p, k, v)
         return p
+
+
+class MgrLevelParams(C.Structure):
+    _fields_ = [("n_f_labels", C.c_int), ("f_labels", C.POINTER(C.c_int)), ("interp_type", C.c_int), ("restrict_type", C.c_int),
+                ("frelax_type", C.c_int), ("frelax_sweeps", C.c_int), ("grelax_type", C.c_int), ("grelax_sweeps", C.c_int),
+                ("frelax_amg", C.POINTER(AmgParams)),
+                ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int),
+                ("coarse_ilu_max_iter", C.c_int), ("coarse_ilu_tri_solve", C.c_int), ("coarse_ilu_lower_it", C.c_int), ("coarse_ilu_upper_it", C.c_int),
+                ("frelax_krylov", C.c_int), ("frelax_krylov_precond", C.c_int), ("frelax_kp", KrylovParams),
+                ("coarse_krylov", C.c_int), ("coarse_krylov_precond", C.c_int), ("coarse_kp", KrylovParams)]
 
 
 # every symbol include/hypredrv_amd.h declares (checked by tests/test_cabi_symbols.py)
@@ -352,6 +354,22 @@ MGR_RESTRICT = {"injection": 0, "jacobi": 2, "columped": 14}
 MGR_FRELAX = {"jacobi": 7, "single": 7, "l1-jacobi": 18, "amg": 2, "ilu": 32}
 MGR_GRELAX = {"none": -1, "h-fgs": 3, "h-bgs": 4, "h-ssor": 6, "l1-hfgs": 13, "l1-hbgs": 14, "l1-hsgs": 88, "ilu": 16}
 
+MGR_KRYLOV = {"pcg": 1, "gmres": 2, "fgmres": 3, "bicgstab": 4}
+
+
+def _mgr_nested(entry, lv):
+    """nested Krylov components of a level dict: f_krylov / coarsest_krylov = dict(method=..., precond=True, **krylov params)"""
+    for key, pre in (("f_krylov", "frelax"), ("coarsest_krylov", "coarse")):
+        nk = lv.get(key)
+        if not nk:
+            continue
+        kw = {k: v for k, v in nk.items() if k not in ("method", "precond")}
+        kp = getattr(entry, pre + "_kp")
+        for k, v in {**dict(max_iter=100, rtol=1e-6, atol=0.0, two_norm=1, krylov_dim=30), **kw}.items():
+            setattr(kp, k, v)
+        setattr(entry, pre + "_krylov", MGR_KRYLOV[nk.get("method", "gmres")])
+        setattr(entry, pre + "_krylov_precond", 1 if nk.get("precond", True) else 0)
+
 
 class Mgr:
     """'preconditioner: mgr': multigrid reduction by dof labels; levels = list of dicts with the YAML keys of
@@ -383,6 +401,7 @@ class Mgr:
             cil = lv.get("coarsest_ilu", {})
             arr[k].coarse_ilu_max_iter, arr[k].coarse_ilu_tri_solve = cil.get("max_iter", 1), cil.get("tri_solve", 1)
             arr[k].coarse_ilu_lower_it, arr[k].coarse_ilu_upper_it = cil.get("lower_jac_iters", 5), cil.get("upper_jac_iters", 5)
+            _mgr_nested(arr[k], lv)
         self.nlevels = len(levels)
         self.h = C.c_void_p()
         _check(load().hda_mgr_create(A.h, _ip(self.labels), len(levels), arr, C.byref(self.params) if coarsest == "amg" else None,

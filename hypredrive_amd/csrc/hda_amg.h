@@ -193,6 +193,10 @@ void halo_reverse_add(const HaloPlan &h, double *x_ext);
 
 // ---- MGR (hda_mgr.hip): multigrid reduction by dof labels, BoomerAMG on the coarsest system.
 // Parameter contract: reference MGR_args / MGRlvl_args (include/internal/mgr.h:132-178), defaults src/internal/mgr.c:1226-1330.
+struct NestedKrylov { // the subset of KrylovParams a nested solve uses (hda_krylov.h includes this header)
+   int    max_iter = 100, krylov_dim = 30, min_iter = 0, two_norm = 1, skip_real_res_check = 0;
+   double rtol = 1.0e-6, atol = 0.0;
+};
 struct MgrLevelParams {
    std::vector<int> f_labels;          // level.N.f_dofs
    int interp_type = 0;                // prolongation_type: 0 injection, 1 l1-jacobi, 2 jacobi
@@ -202,6 +206,12 @@ struct MgrLevelParams {
    AmgParams frelax_amg;                     // f_relaxation.amg block
    IluParams ilu;                            // ILU arguments of this level's ILU components (f_relaxation 32, g_relaxation 16)
    int grelax_type = -1, grelax_sweeps = 1;  // g_relaxation: -1 none, 3/4/6/13/14 hybrid GS, 88 l1-hsgs, 16 ilu
+   // f_relaxation: {gmres: {..., preconditioner: {amg: ...}}} -- a nested Krylov solve on A_FF (reference src/internal/krylov.c,
+   // mgr.c:3938-3960).  method: -1 none, 0 pcg, 1 gmres, 2 fgmres, 3 bicgstab; its preconditioner is the level's amg / ilu
+   // component (frelax_type 2 / 32) or nothing (fkrylov_precond false).
+   int          fkrylov_method = -1;
+   NestedKrylov fkrylov;
+   bool         fkrylov_precond = true;
 };
 struct MgrParams {
    std::vector<MgrLevelParams> levels;
@@ -209,6 +219,10 @@ struct MgrParams {
    bool                        coarse_is_ilu = false; // coarsest_level: ilu
    IluParams                   coarse_ilu;
    int                         max_iter = 1;
+   // coarsest_level: {gmres: {..., preconditioner: ...}} -- a nested Krylov solve of the coarsest system (mgr.c:4253-4275)
+   int                         ckrylov_method = -1;
+   NestedKrylov                ckrylov;
+   bool                        ckrylov_precond = true;
 };
 class Mgr {
  public:

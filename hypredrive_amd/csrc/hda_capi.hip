@@ -442,6 +442,23 @@ extern "C" int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const
       q.grelax_type = levels[l].grelax_type; q.grelax_sweeps = levels[l].grelax_sweeps;
       if (levels[l].frelax_amg) q.frelax_amg = to_params(levels[l].frelax_amg);
       q.ilu.tri_solve = levels[l].ilu_tri_solve; q.ilu.lower_it = levels[l].ilu_lower_it; q.ilu.upper_it = levels[l].ilu_upper_it;
+      auto nested = [](const hda_krylov_params &k) {
+         NestedKrylov r;
+         r.max_iter = k.max_iter; r.rtol = k.rtol; r.atol = k.atol; r.two_norm = k.two_norm; r.krylov_dim = k.krylov_dim;
+         return r;
+      };
+      if (levels[l].frelax_krylov > 0)
+      {
+         q.fkrylov_method  = levels[l].frelax_krylov - 1;
+         q.fkrylov         = nested(levels[l].frelax_kp);
+         q.fkrylov_precond = levels[l].frelax_krylov_precond != 0;
+      }
+      if (l == nlevels - 1 && levels[l].coarse_krylov > 0)
+      {
+         p.ckrylov_method  = levels[l].coarse_krylov - 1;
+         p.ckrylov         = nested(levels[l].coarse_kp);
+         p.ckrylov_precond = levels[l].coarse_krylov_precond != 0;
+      }
       p.levels.push_back(q);
    }
    auto h = std::make_unique<hda_amg_s>();

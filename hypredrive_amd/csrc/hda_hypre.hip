@@ -1389,18 +1389,37 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
    HDA_REQUIRE(s->mgr_cycle == 1, "MGR: W-cycles (cycle: w) are not implemented on MI355X, only V-cycles");
    HDA_REQUIRE(s->mgr_frelax_cycle == 1 && s->mgr_gsmooth_cycle == 1, "MGR: post-smoothing (cycle: v(0,1) / v(1,1)) is not implemented on MI355X, only pre-smoothing v(1,0)");
    HDA_REQUIRE(s->mgr_coarse_th == 0.0, "MGR: coarse_th (coarse grid truncation) is not implemented");
-   HDA_REQUIRE(!s->mgr_csolver || s->mgr_csolver->kind == HDA_SOLVER_AMG || s->mgr_csolver->kind == HDA_SOLVER_ILU,
-               "MGR coarsest_level: BoomerAMG and ILU are implemented");
+   // a Krylov handle as component solver (the reference's nested Krylov wrapper, src/internal/krylov.c): its parameters and the
+   // BoomerAMG / ILU handle installed as its preconditioner
+   auto krylov_method = [](HYPRE_Solver q) {
+      return !q ? -1 : q->kind == HDA_SOLVER_PCG ? 0 : q->kind == HDA_SOLVER_GMRES ? 1 : q->kind == HDA_SOLVER_FGMRES ? 2 : q->kind == HDA_SOLVER_BICGSTAB ? 3 : -1;
+   };
+   auto nested = [](HYPRE_Solver q) {
+      NestedKrylov k;
+      k.max_iter = q->kp.max_iter; k.rtol = q->kp.rtol; k.atol = q->kp.atol; k.krylov_dim = q->kp.krylov_dim; k.min_iter = q->kp.min_iter;
+      k.two_norm = q->kp.two_norm; k.skip_real_res_check = q->kp.skip_real_res_check;
+      return k;
+   };
    auto ilu_ok = [](HYPRE_Solver q) { return q->ilu_type == 0 && q->ilu_fill == 0 && q->ilu_reordering == 0; };
-   MgrParams p;
-   p.max_iter = s->mgr_max_iter;
-   if (s->mgr_csolver && s->mgr_csolver->kind == HDA_SOLVER_ILU)
+   MgrParams    p;
+   HYPRE_Solver cs = s->mgr_csolver;
+   if (krylov_method(cs) >= 0)
    {
-      HDA_REQUIRE(ilu_ok(s->mgr_csolver), "MGR coarsest_level ilu: only type bj-iluk with fill_level 0 and reordering 0 is implemented");
-      p.coarse_is_ilu = true;
-      p.coarse_ilu    = s->mgr_csolver->ilup;
+      p.ckrylov_method  = krylov_method(cs);
+      p.ckrylov         = nested(cs);
+      p.ckrylov_precond = cs->precond_solver != nullptr;
+      cs                = cs->precond_solver; // what preconditions it; none: the coarse hierarchy below is built and left unused
    }
-   else if (s->mgr_csolver) p.coarse = s->mgr_csolver->ap;
+   HDA_REQUIRE(!cs || cs->kind == HDA_SOLVER_AMG || cs->kind == HDA_SOLVER_ILU,
+               "MGR coarsest_level: BoomerAMG, ILU and a Krylov solver preconditioned by one of them are implemented");
+   p.max_iter = s->mgr_max_iter;
+   if (cs && cs->kind == HDA_SOLVER_ILU)
+   {
+      HDA_REQUIRE(ilu_ok(cs), "MGR coarsest_level ilu: only type bj-iluk with fill_level 0 and reordering 0 is implemented");
+      p.coarse_is_ilu = true;
+      p.coarse_ilu    = cs->ilup;
+   }
+   else if (cs) p.coarse = cs->ap;
    else { AmgParams d; p.coarse = d; }
    p.coarse.max_iter = 1; // one V-cycle per MGR cycle (amg.c:224-226 defaults)
    // F labels of level l = C labels of level l-1 (all labels of the marker array for l = 0) that are no longer C
@@ -1424,9 +1443,22 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
       q.restrict_type = at(s->mgr_restrict, l, 0);
       q.coarse_type   = at(s->mgr_coarse_method, l, 0);
       q.frelax_type   = at(s->mgr_frelax, l, 7);
+      {
+         HYPRE_Solver fk = (size_t)l < s->mgr_fsolver.size() ? s->mgr_fsolver[(size_t)l] : nullptr;
+         if (krylov_method(fk) >= 0)
+         { // F-relaxation by a nested Krylov solve: the component underneath is its preconditioner (BoomerAMG when there is none to name)
+            q.fkrylov_method  = krylov_method(fk);
+            q.fkrylov         = nested(fk);
+            q.fkrylov_precond = fk->precond_solver != nullptr;
+            HDA_REQUIRE(!fk->precond_solver || fk->precond_solver->kind == HDA_SOLVER_AMG || fk->precond_solver->kind == HDA_SOLVER_ILU,
+                        "MGR f_relaxation: a nested Krylov solver takes BoomerAMG, ILU or no preconditioner");
+            q.frelax_type = (fk->precond_solver && fk->precond_solver->kind == HDA_SOLVER_ILU) ? 32 : 2;
+         }
+      }
       if (q.frelax_type == 2 || q.frelax_type == 32)
       {
          HYPRE_Solver fs = (size_t)l < s->mgr_fsolver.size() ? s->mgr_fsolver[(size_t)l] : nullptr;
+         if (krylov_method(fs) >= 0) fs = fs->precond_solver;
          HDA_REQUIRE(!fs || fs->kind == (q.frelax_type == 2 ? HDA_SOLVER_AMG : HDA_SOLVER_ILU), "MGR f_relaxation: the F-solver handle does not match its type (amg / ilu)");
          if (fs && q.frelax_type == 2) { q.frelax_amg = fs->ap; q.frelax_amg.num_functions = std::max(fs->num_functions, 1); }
          if (fs && q.frelax_type == 32)

@@ -1543,6 +1543,92 @@ static void amg_create(const AmgArgs &a, HYPRE_Solver *out)
 
 // hypredrv_MGRCreate (reference src/internal/mgr.c:3449-3900): C points of every reduction level by dof label, the
 // per-level option arrays, BoomerAMG as coarse solver -- handed over through hypre's own MGR calls
+// A Krylov solver handle from its arguments (hypredrv_PCGCreate / GMRESCreate / FGMRESCreate / BiCGSTABCreate, reference
+// src/internal/pcg.c, gmres.c, fgmres.c:36-48, bicgstab.c:41-55): the outer solver and the nested ones of MGR components
+static bool krylov_handle_create(MPI_Comm comm, const KrylovArgs &k, HYPRE_Solver *out)
+{
+   if (k.method == 0)
+   {
+      HYPRE_ParCSRPCGCreate(comm, out);
+      HYPRE_PCGSetMaxIter(*out, k.max_iter);
+      HYPRE_PCGSetTwoNorm(*out, k.two_norm);
+      HYPRE_PCGSetStopCrit(*out, k.stop_crit);
+      HYPRE_PCGSetRelChange(*out, k.rel_change);
+      HYPRE_PCGSetPrintLevel(*out, k.print_level);
+      HYPRE_PCGSetRecomputeResidual(*out, k.recompute_res);
+      HYPRE_PCGSetTol(*out, k.relative_tol);
+      HYPRE_PCGSetAbsoluteTol(*out, k.absolute_tol);
+      HYPRE_PCGSetResidualTol(*out, k.residual_tol);
+      HYPRE_PCGSetConvergenceFactorTol(*out, k.conv_fac_tol);
+   }
+   else if (k.method == 1)
+   {
+      HYPRE_ParCSRGMRESCreate(comm, out);
+      HYPRE_GMRESSetMinIter(*out, k.min_iter);
+      HYPRE_GMRESSetMaxIter(*out, k.max_iter);
+      HYPRE_GMRESSetStopCrit(*out, k.stop_crit);
+      HYPRE_GMRESSetSkipRealResidualCheck(*out, k.skip_real_res_check);
+      HYPRE_GMRESSetKDim(*out, k.krylov_dim);
+      HYPRE_GMRESSetRelChange(*out, k.rel_change);
+      HYPRE_GMRESSetLogging(*out, k.logging);
+      HYPRE_GMRESSetPrintLevel(*out, k.print_level);
+      HYPRE_GMRESSetTol(*out, k.relative_tol);
+      HYPRE_GMRESSetAbsoluteTol(*out, k.absolute_tol);
+      HYPRE_GMRESSetConvergenceFactorTol(*out, k.conv_fac_tol);
+   }
+   else if (k.method == 2)
+   { // hypredrv_FGMRESCreate (reference src/internal/fgmres.c:36-48)
+      HYPRE_ParCSRFlexGMRESCreate(comm, out);
+      HYPRE_FlexGMRESSetMinIter(*out, k.min_iter);
+      HYPRE_FlexGMRESSetMaxIter(*out, k.max_iter);
+      HYPRE_FlexGMRESSetKDim(*out, k.krylov_dim);
+      HYPRE_FlexGMRESSetLogging(*out, k.logging);
+      HYPRE_FlexGMRESSetPrintLevel(*out, k.print_level);
+      HYPRE_FlexGMRESSetTol(*out, k.relative_tol);
+      HYPRE_FlexGMRESSetAbsoluteTol(*out, k.absolute_tol);
+   }
+   else if (k.method == 3)
+   { // hypredrv_BiCGSTABCreate (reference src/internal/bicgstab.c:41-55)
+      HYPRE_ParCSRBiCGSTABCreate(comm, out);
+      HYPRE_BiCGSTABSetMinIter(*out, k.min_iter);
+      HYPRE_BiCGSTABSetMaxIter(*out, k.max_iter);
+      HYPRE_BiCGSTABSetStopCrit(*out, k.stop_crit);
+      HYPRE_BiCGSTABSetLogging(*out, k.logging);
+      HYPRE_BiCGSTABSetPrintLevel(*out, k.print_level);
+      HYPRE_BiCGSTABSetTol(*out, k.relative_tol);
+      HYPRE_BiCGSTABSetAbsoluteTol(*out, k.absolute_tol);
+      HYPRE_BiCGSTABSetConvergenceFactorTol(*out, k.conv_fac_tol);
+   }
+   else
+      return false;
+   return true;
+}
+
+// A nested Krylov component of MGR (reference hypredrv_NestedKrylovCreate, src/internal/krylov.c:418-505): the Krylov handle and, when
+// the block names one, the BoomerAMG / ILU handle installed as its preconditioner.  Both are owned by the HYPREDRV object.
+static HYPRE_Solver nested_krylov_create(hypredrv_struct *h, const NestedKrylovArgs &nk)
+{
+   HYPRE_Solver ks = nullptr, ps = nullptr;
+   krylov_handle_create(h->comm, nk.solver, &ks);
+   if (nk.precon == 0) amg_create(nk.amg, &ps);
+   else if (nk.precon == 2) ilu_create(nk.ilu, &ps);
+   if (ps)
+   {
+      h->precon_aux.push_back(ps);
+      HYPRE_PtrToSolverFcn solve = nk.precon == 0 ? (HYPRE_PtrToSolverFcn)HYPRE_BoomerAMGSolve : (HYPRE_PtrToSolverFcn)HYPRE_ILUSolve;
+      HYPRE_PtrToSolverFcn setup = nk.precon == 0 ? (HYPRE_PtrToSolverFcn)HYPRE_BoomerAMGSetup : (HYPRE_PtrToSolverFcn)HYPRE_ILUSetup;
+      switch (nk.solver.method)
+      {
+         case 0: HYPRE_PCGSetPrecond(ks, solve, setup, ps); break;
+         case 1: HYPRE_GMRESSetPrecond(ks, solve, setup, ps); break;
+         case 2: HYPRE_FlexGMRESSetPrecond(ks, solve, setup, ps); break;
+         default: HYPRE_BiCGSTABSetPrecond(ks, solve, setup, ps); break;
+      }
+   }
+   h->precon_aux.push_back(ks);
+   return ks;
+}
+
 static uint32_t mgr_create(hypredrv_struct *h, const MgrArgs &a)
 {
    if (h->dofmap.empty())
@@ -1608,7 +1694,11 @@ static uint32_t mgr_create(hypredrv_struct *h, const MgrArgs &a)
    for (int l = 0; l < nlev; l++)
    {
       const MgrLevelArgs &L = a.level[(size_t)l];
-      if (L.f_type == 2 || L.f_type == 32)
+      if (L.f_krylov.set)
+      { // f_relaxation by a nested Krylov solver (mgr.c:3938-3960): the handle goes in as the level's F-solver
+         HYPRE_MGRSetFSolverAtLevel(p, nested_krylov_create(h, L.f_krylov), l);
+      }
+      else if (L.f_type == 2 || L.f_type == 32)
       { // f_relaxation amg / ilu: a solver handle for A_FF (reference mgr.c:2594, HYPRE_MGRSetFSolverAtLevel)
          HYPRE_Solver fs = nullptr;
          if (L.f_type == 2) amg_create(L.f_amg, &fs);
@@ -1626,6 +1716,13 @@ static uint32_t mgr_create(hypredrv_struct *h, const MgrArgs &a)
       }
    }
    HYPRE_Solver cs = nullptr;
+   if (a.coarsest_krylov.set)
+   { // coarsest_level by a nested Krylov solver (mgr.c:4253-4275); its handles are already on the owned list
+      HYPRE_MGRSetCoarseSolver(p, HYPRE_ParCSRGMRESSolve, HYPRE_ParCSRGMRESSetup, nested_krylov_create(h, a.coarsest_krylov));
+      h->precon = p;
+      consume_hypre_errors();
+      return g_err;
+   }
    if (a.coarsest_type == 32)
    {
       ilu_create(a.coarsest_ilu, &cs);
@@ -1699,61 +1796,7 @@ extern "C" uint32_t HYPREDRV_LinearSolverCreate(HYPREDRV_t h)
       if (HYPREDRV_PreconCreate(h)) return g_err;
    }
    if (h->solver) { solver_ops(h->solver).destroy(h->solver); h->solver = nullptr; }
-   const KrylovArgs &k = h->args.solver;
-   if (k.method == 0)
-   {
-      HYPRE_ParCSRPCGCreate(h->comm, &h->solver);
-      HYPRE_PCGSetMaxIter(h->solver, k.max_iter);
-      HYPRE_PCGSetTwoNorm(h->solver, k.two_norm);
-      HYPRE_PCGSetStopCrit(h->solver, k.stop_crit);
-      HYPRE_PCGSetRelChange(h->solver, k.rel_change);
-      HYPRE_PCGSetPrintLevel(h->solver, k.print_level);
-      HYPRE_PCGSetRecomputeResidual(h->solver, k.recompute_res);
-      HYPRE_PCGSetTol(h->solver, k.relative_tol);
-      HYPRE_PCGSetAbsoluteTol(h->solver, k.absolute_tol);
-      HYPRE_PCGSetResidualTol(h->solver, k.residual_tol);
-      HYPRE_PCGSetConvergenceFactorTol(h->solver, k.conv_fac_tol);
-   }
-   else if (k.method == 1)
-   {
-      HYPRE_ParCSRGMRESCreate(h->comm, &h->solver);
-      HYPRE_GMRESSetMinIter(h->solver, k.min_iter);
-      HYPRE_GMRESSetMaxIter(h->solver, k.max_iter);
-      HYPRE_GMRESSetStopCrit(h->solver, k.stop_crit);
-      HYPRE_GMRESSetSkipRealResidualCheck(h->solver, k.skip_real_res_check);
-      HYPRE_GMRESSetKDim(h->solver, k.krylov_dim);
-      HYPRE_GMRESSetRelChange(h->solver, k.rel_change);
-      HYPRE_GMRESSetLogging(h->solver, k.logging);
-      HYPRE_GMRESSetPrintLevel(h->solver, k.print_level);
-      HYPRE_GMRESSetTol(h->solver, k.relative_tol);
-      HYPRE_GMRESSetAbsoluteTol(h->solver, k.absolute_tol);
-      HYPRE_GMRESSetConvergenceFactorTol(h->solver, k.conv_fac_tol);
-   }
-   else if (k.method == 2)
-   { // hypredrv_FGMRESCreate (reference src/internal/fgmres.c:36-48)
-      HYPRE_ParCSRFlexGMRESCreate(h->comm, &h->solver);
-      HYPRE_FlexGMRESSetMinIter(h->solver, k.min_iter);
-      HYPRE_FlexGMRESSetMaxIter(h->solver, k.max_iter);
-      HYPRE_FlexGMRESSetKDim(h->solver, k.krylov_dim);
-      HYPRE_FlexGMRESSetLogging(h->solver, k.logging);
-      HYPRE_FlexGMRESSetPrintLevel(h->solver, k.print_level);
-      HYPRE_FlexGMRESSetTol(h->solver, k.relative_tol);
-      HYPRE_FlexGMRESSetAbsoluteTol(h->solver, k.absolute_tol);
-   }
-   else if (k.method == 3)
-   { // hypredrv_BiCGSTABCreate (reference src/internal/bicgstab.c:41-55)
-      HYPRE_ParCSRBiCGSTABCreate(h->comm, &h->solver);
-      HYPRE_BiCGSTABSetMinIter(h->solver, k.min_iter);
-      HYPRE_BiCGSTABSetMaxIter(h->solver, k.max_iter);
-      HYPRE_BiCGSTABSetStopCrit(h->solver, k.stop_crit);
-      HYPRE_BiCGSTABSetLogging(h->solver, k.logging);
-      HYPRE_BiCGSTABSetPrintLevel(h->solver, k.print_level);
-      HYPRE_BiCGSTABSetTol(h->solver, k.relative_tol);
-      HYPRE_BiCGSTABSetAbsoluteTol(h->solver, k.absolute_tol);
-      HYPRE_BiCGSTABSetConvergenceFactorTol(h->solver, k.conv_fac_tol);
-   }
-   else
-      return err_set(ERR_INVALID_SOLVER, "unknown solver method");
+   if (!krylov_handle_create(h->comm, h->args.solver, &h->solver)) return err_set(ERR_INVALID_SOLVER, "unknown solver method");
    consume_hypre_errors();
    API_CATCH
 }

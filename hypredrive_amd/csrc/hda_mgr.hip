@@ -18,6 +18,7 @@
 // F-relaxation (a Jacobi sweep of the whole operator with divisors that vanish on C rows), residual,
 // restriction, recursion, prolongation: streaming kernels of the AMG solve.
 #include "hda_amg.h"
+#include "hda_krylov.h"
 
 #include <algorithm>
 #include <cstring>
@@ -418,6 +419,7 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
          { // block-Jacobi ILU(0) of this rank's diagonal block of A_FF
             L.filu = std::make_unique<Ilu>();
             L.filu->setup(L.Aff, p.ilu);
+            if (multi && p.fkrylov_method >= 0) L.hFF = make_halo_plan(nf, L.fpart, L.fghosts); // the nested solve's products need it
          }
          else
          {
@@ -546,13 +548,43 @@ const DCsr &Mgr::matrix(int level, int which) const
    return which == 0 ? *L.A : which == 1 ? L.P : L.R;
 }
 
+// A nested Krylov component (reference src/internal/krylov.c:557-603): the solver runs to its own max_iter / tolerance from the
+// guess it is given; not reaching the tolerance is no error (it is an inexact smoother / coarse solve).
+static void nested_krylov(int method, const NestedKrylov &k, const LinOp &op, const PrecondFn &M, const double *b, double *x)
+{
+   KrylovParams kp;
+   kp.max_iter = k.max_iter; kp.rtol = k.rtol; kp.atol = k.atol; kp.krylov_dim = k.krylov_dim; kp.min_iter = k.min_iter;
+   kp.two_norm = k.two_norm; kp.skip_real_res_check = k.skip_real_res_check; kp.print_level = 0;
+   switch (method)
+   {
+      case 0: pcg(op, M, kp, b, x); break;
+      case 1: gmres(op, M, kp, b, x); break;
+      case 2: fgmres(op, M, kp, b, x); break;
+      case 3: bicgstab(op, M, kp, b, x); break;
+      default: HDA_REQUIRE(false, "MGR: unknown nested Krylov method");
+   }
+}
+
 // one cycle on level l: u holds the current iterate (zero = it is known to be zero); returns where the result lives
 double *Mgr::cycle(int l, const double *f, double *u, bool zero)
 {
    if (l == (int)lv.size())
    {
-      if (camg) camg->apply(f, u, -1);
-      else ilu_solve(*cilu, Ac, Comm::world().size > 1 ? &hAc : nullptr, f, u, true, cilu_r, cilu_c);
+      const bool multi = Comm::world().size > 1;
+      if (prm.ckrylov_method >= 0)
+      {
+         fill((int)uc.size(), 0.0, u);
+         PrecondFn M;
+         if (prm.ckrylov_precond && camg) M = [this](const double *r, double *z, int slot) { camg->apply(r, z, -1); if (slot >= 0) dot(Ac.nrows, r, z, slot); };
+         else if (prm.ckrylov_precond && cilu)
+            M = [this, multi](const double *r, double *z, int slot) {
+               ilu_solve(*cilu, Ac, multi ? &hAc : nullptr, r, z, true, cilu_r, cilu_c);
+               if (slot >= 0) dot(Ac.nrows, r, z, slot);
+            };
+         nested_krylov(prm.ckrylov_method, prm.ckrylov, LinOp(Ac, multi ? &hAc : nullptr, uc.size()), M, f, u);
+      }
+      else if (camg) camg->apply(f, u, -1);
+      else ilu_solve(*cilu, Ac, multi ? &hAc : nullptr, f, u, true, cilu_r, cilu_c);
       return u;
    }
    Level                &L = lv[(size_t)l];
@@ -586,7 +618,16 @@ double *Mgr::cycle(int l, const double *f, double *u, bool zero)
          refresh(cur);
          residual(A, cur, f, L.t.data());
          if (n) k_mgr_gatherF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.t.data(), L.rF.data());
-         if (L.famg) L.famg->apply(L.rF.data(), L.eF.data(), -1);
+         if (p.fkrylov_method >= 0)
+         { // nested Krylov solve of A_FF e_F = r_F from a zero guess, preconditioned by the level's component
+            fill((int)L.eF.size(), 0.0, L.eF.data());
+            PrecondFn M;
+            // (a PCG caller hands over the slot it wants the block partials of <r, z> in)
+            if (p.fkrylov_precond && L.famg) M = [&L](const double *r, double *z, int slot) { L.famg->apply(r, z, -1); if (slot >= 0) dot(L.nf, r, z, slot); };
+            else if (p.fkrylov_precond && L.filu) M = [&L](const double *r, double *z, int slot) { L.filu->apply(r, z); if (slot >= 0) dot(L.nf, r, z, slot); };
+            nested_krylov(p.fkrylov_method, p.fkrylov, LinOp(L.Aff, multi ? &L.hFF : nullptr, L.eF.size()), M, L.rF.data(), L.eF.data());
+         }
+         else if (L.famg) L.famg->apply(L.rF.data(), L.eF.data(), -1);
          else L.filu->apply(L.rF.data(), L.eF.data());
          if (n) k_mgr_addF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.eF.data(), cur);
          continue;

@@ -479,10 +479,42 @@ static std::vector<int> int_list(Ctx &c, YNode &k, const char *what)
 // nested Krylov components (reference src/internal/mgr.c:683-700 MGRIsNestedKrylovKey: any solver type name)
 static bool is_krylov_name(const std::string &k) { return k == "pcg" || k == "gmres" || k == "fgmres" || k == "bicgstab"; }
 
-// f_relaxation / g_relaxation: a flat name, or a block with type / num_sweeps / a nested solver
 static void ilu_fields(Ctx &c, YNode &sec, IluArgs &a);
+static void krylov_fields(Ctx &c, YNode &sec, KrylovArgs &k);
+static int  solver_method(const std::string &name);
+// A nested Krylov block (reference hypredrv_NestedKrylovSetArgsFromYAML, src/internal/krylov.c:360-414): the node's key names the
+// method, `preconditioner:` is detached and parsed on its own, the rest are the method's solver keys.
+static void nested_krylov(Ctx &c, YNode &node, NestedKrylovArgs &nk, const std::string &where)
+{
+   nk.set = true;
+   nk.solver.defaults_for(solver_method(node.key));
+   std::unique_ptr<YNode> pre;
+   for (size_t i = 0; i < node.kids.size(); i++)
+      if (node.kids[i]->key == "preconditioner")
+      {
+         pre = std::move(node.kids[i]);
+         node.kids.erase(node.kids.begin() + (long)i);
+         break;
+      }
+   krylov_fields(c, node, nk.solver);
+   if (!pre) return;
+   auto named = [&](const std::string &name, YNode *block) {
+      if (name == "amg") { nk.precon = 0; if (block) amg_fields(c, *block, nk.amg); }
+      else if (name == "ilu") { nk.precon = 2; if (block) ilu_fields(c, *block, nk.ilu); }
+      else if (name == "none") nk.precon = 99;
+      else if (name == "mgr" || name == "fsai" || name == "schwarz")
+         c.fail(ERR_INVALID_VAL, "mgr: '" + name + "' as preconditioner of the nested " + node.key + " of " + where + " is not implemented on MI355X");
+      else c.fail(ERR_INVALID_VAL, "unknown nested preconditioner type: '" + name + "'");
+   };
+   if (pre->kids.empty()) named(pre->val, nullptr);
+   else
+      for (auto &q : pre->kids) named(q->key, q.get());
+   node.kids.push_back(std::move(pre)); // the tree is printed back by print_config_params
+}
+
+// f_relaxation / g_relaxation: a flat name, or a block with type / num_sweeps / a nested solver
 static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweeps, std::string &block, AmgArgs *amg = nullptr,
-                      IluArgs *ilu = nullptr, bool *ilu_block = nullptr)
+                      IluArgs *ilu = nullptr, bool *ilu_block = nullptr, NestedKrylovArgs *krylov = nullptr)
 {
    if (k.kids.empty())
    {
@@ -513,6 +545,7 @@ static void mgr_relax(Ctx &c, YNode &k, const StrMap &map, int &type, int &sweep
          auto it = map.find(q->key);
          if (it != map.end()) type = it->second;
       }
+      else if (is_krylov_name(q->key) && krylov) nested_krylov(c, *q, *krylov, k.key);
       else if (is_krylov_name(q->key))
          c.fail(ERR_INVALID_VAL, "mgr: a nested Krylov solver ('" + q->key + "') as " + k.key + " is not implemented on MI355X");
       else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under '" + k.key + "'");
@@ -538,7 +571,7 @@ static void mgr_fields(Ctx &c, YNode &sec, MgrArgs &m)
                else if (q->key == "prolongation_type") L.prolongation_type = to_int(c, *q, &kMgrInterp);
                else if (q->key == "restriction_type") L.restriction_type = to_int(c, *q, &kMgrRestrict);
                else if (q->key == "coarse_level_type") L.coarse_level_type = to_int(c, *q, &kMgrCoarse);
-               else if (q->key == "f_relaxation") mgr_relax(c, *q, kMgrFrelax, L.f_type, L.f_sweeps, L.f_block, &L.f_amg, &L.f_ilu);
+               else if (q->key == "f_relaxation") mgr_relax(c, *q, kMgrFrelax, L.f_type, L.f_sweeps, L.f_block, &L.f_amg, &L.f_ilu, nullptr, &L.f_krylov);
                else if (q->key == "g_relaxation") mgr_relax(c, *q, kMgrGrelax, L.g_type, L.g_sweeps, L.g_block, nullptr, &L.g_ilu, &L.g_ilu_block);
                else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under 'mgr.level." + lvn->key + "'");
             }
@@ -560,8 +593,7 @@ static void mgr_fields(Ctx &c, YNode &sec, MgrArgs &m)
                   auto it = kMgrCoarsest.find(q->key);
                   if (it != kMgrCoarsest.end()) m.coarsest_type = it->second;
                }
-               else if (is_krylov_name(q->key))
-                  c.fail(ERR_INVALID_VAL, "mgr: a nested Krylov solver ('" + q->key + "') on the coarsest level is not implemented on MI355X");
+               else if (is_krylov_name(q->key)) nested_krylov(c, *q, m.coarsest_krylov, "coarsest_level");
                else c.fail(ERR_INVALID_KEY, "unknown key '" + q->key + "' under 'mgr.coarsest_level'");
             }
       }

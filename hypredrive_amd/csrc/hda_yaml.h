@@ -107,6 +107,15 @@ struct AmgArgs { // AMG_args, GPU-branch defaults of src/internal/amg.c:120-238
       if (e && !strcmp(e, "cpu")) { type = 10; down_type = 13; up_type = 14; mod_rap2 = 0; keep_transpose = 0; }
    }
 };
+// NestedKrylov_args (reference include/internal/krylov.h, src/internal/krylov.c:336-414): a Krylov solver named inside an MGR
+// component, with an optional preconditioner block of its own
+struct NestedKrylovArgs {
+   bool       set = false;
+   KrylovArgs solver;
+   int        precon = 99; // 99 none, 0 amg, 2 ilu
+   AmgArgs    amg;
+   IluArgs    ilu;
+};
 // MGR_args / MGRlvl_args (reference include/internal/mgr.h:132-178; defaults src/internal/mgr.c:1226-1330)
 struct MgrLevelArgs {
    std::vector<int> f_dofs;
@@ -117,6 +126,7 @@ struct MgrLevelArgs {
    AmgArgs     f_amg;             // f_relaxation: {amg: {...}}
    IluArgs     f_ilu, g_ilu;      // f_relaxation / g_relaxation: {ilu: {...}}
    bool        g_ilu_block = false; // g_relaxation came with its own ilu block (a smoother object, not hypre's built-in type 16)
+   NestedKrylovArgs f_krylov;     // f_relaxation: {gmres: {...}}
 };
 struct MgrArgs {
    int    non_c_to_f = 1, pmax = 0, max_iter = 1, num_levels = 0, relax_type = 7, print_level = 0, nonglk_max_elmts = 1, cycle = 1, cycle_smooth_pos = 1; // cycle_smooth_pos: 1 pre, 2 post, 3 pre + post (mgr.h:160)
@@ -126,6 +136,7 @@ struct MgrArgs {
    std::string coarsest_block;     // anything but amg is not implemented
    AmgArgs     coarsest_amg;
    IluArgs     coarsest_ilu;
+   NestedKrylovArgs coarsest_krylov; // coarsest_level: {gmres: {...}}
 };
 struct PreconArgs {
    int         method = 0; // 0 boomeramg, 1 mgr, 2 ilu, 3 fsai, ... 99 none

@@ -131,6 +131,13 @@ typedef struct {
    int        ilu_tri_solve, ilu_lower_it, ilu_upper_it; /* ILU arguments of this level's ILU components (frelax 32, grelax 16) */
    /* coarsest_level: ilu -- read from the LAST level's entry when hda_mgr_create gets coarsest_amg == NULL */
    int        coarse_ilu_max_iter, coarse_ilu_tri_solve, coarse_ilu_lower_it, coarse_ilu_upper_it;
+   /* nested Krylov components (reference src/internal/krylov.c; mgr.c:3938-3960, 4253-4275): 0 none, 1 pcg, 2 gmres, 3 fgmres,
+    * 4 bicgstab.  f_relaxation: a solve of A_FF e = r_F from a zero guess, preconditioned by the level's amg / ilu component
+    * (frelax_type 2 / 32) when frelax_krylov_precond is set.  coarsest_level: read from the LAST level's entry. */
+   int               frelax_krylov, frelax_krylov_precond;
+   hda_krylov_params frelax_kp;
+   int               coarse_krylov, coarse_krylov_precond;
+   hda_krylov_params coarse_kp;
 } hda_mgr_level_params;
 int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const hda_mgr_level_params *levels,
                    const hda_amg_params *coarsest_amg, int max_iter, hda_amg_t *out);

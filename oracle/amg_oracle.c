@@ -1757,6 +1757,8 @@ typedef struct {
    int     *fidx, nf, frelax_type;
    double  *rF, *eF;
    int      frelax_sweeps, grelax_type, grelax_sweeps;
+   int      fkry, fkry_pre; /* nested Krylov F-relaxation: method + 1, preconditioned by famg */
+   orc_krylov_params fkp;
 } mgr_level;
 
 struct orc_mgr {
@@ -1769,7 +1771,27 @@ struct orc_mgr {
    double    *ct, *cc;
    double    *fc, *uc;
    int        max_iter;
+   int        ckry, ckry_pre; /* nested Krylov coarsest solve */
+   orc_krylov_params ckp;
 };
+
+/* A nested Krylov component: the solver runs to its own max_iter / tolerance from the guess it is given; missing the tolerance
+ * is no error (reference hypredrv_NestedKrylovSolve, src/internal/krylov.c:557-603). */
+static void
+nested_krylov(int method1, const orc_krylov_params *kp, const orc_csr *A, orc_amg *pre, const double *b, double *x)
+{
+   int     conv = 0;
+   double  rel  = 0.0;
+   double *hist = (double *)malloc(sizeof(double) * (size_t)(kp->max_iter + 2));
+   switch (method1)
+   {
+      case 1: orc_pcg(A, pre, kp, b, x, hist, &conv, &rel); break;
+      case 2: orc_gmres(A, pre, kp, b, x, hist, &conv, &rel); break;
+      case 3: orc_fgmres(A, pre, kp, b, x, hist, &conv, &rel); break;
+      default: orc_bicgstab(A, pre, kp, b, x, hist, &conv, &rel); break;
+   }
+   free(hist);
+}
 
 static int
 label_in(int lab, const int *set, int n)
@@ -1800,6 +1822,7 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
       const int  n = A->nrows;
       L->A = A; L->n = n; L->labels = labels;
       L->frelax_type   = lp[l].frelax_type;
+      L->fkry = lp[l].frelax_krylov; L->fkry_pre = lp[l].frelax_krylov_precond; L->fkp = lp[l].frelax_kp;
       L->frelax_sweeps = lp[l].frelax_sweeps; L->grelax_type = lp[l].grelax_type; L->grelax_sweeps = lp[l].grelax_sweeps;
       L->cf    = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
       L->cidx  = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
@@ -1939,6 +1962,7 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
    }
    M->Ac   = A;
    free(labels);
+   if (nlevels > 0) { M->ckry = lp[nlevels - 1].coarse_krylov; M->ckry_pre = lp[nlevels - 1].coarse_krylov_precond; M->ckp = lp[nlevels - 1].coarse_kp; }
    if (coarse_amg) M->camg = orc_amg_setup(A, coarse_amg);
    else
    { /* coarsest_level: ilu (the ILU arguments ride in the last level's slots) */
@@ -1961,7 +1985,8 @@ mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
    if (l == M->nlev)
    {
       memset(u, 0, sizeof(double) * (size_t)M->Ac->nrows);
-      if (M->camg) orc_amg_vcycle(M->camg, f, u);
+      if (M->ckry && M->camg) nested_krylov(M->ckry, &M->ckp, M->Ac, M->ckry_pre ? M->camg : NULL, f, u);
+      else if (M->camg) orc_amg_vcycle(M->camg, f, u);
       else ilu_iterate(M->cilu, M->Ac, M->cilu_iters, f, u, M->ct, M->cc);
       return;
    }
@@ -1980,7 +2005,8 @@ mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
          for (int i = 0; i < n; i++)
             if (L->cf[i] < 0) L->rF[L->fidx[i]] = L->t[i];
          memset(L->eF, 0, sizeof(double) * (size_t)L->nf);
-         if (L->frelax_type == 2) orc_amg_vcycle(L->famg, L->rF, L->eF);
+         if (L->fkry && L->frelax_type == 2) nested_krylov(L->fkry, &L->fkp, L->Aff, L->fkry_pre ? L->famg : NULL, L->rF, L->eF);
+         else if (L->frelax_type == 2) orc_amg_vcycle(L->famg, L->rF, L->eF);
          else orc_ilu_apply(L->filu, L->rF, L->eF);
          for (int i = 0; i < n; i++)
             if (L->cf[i] < 0) u[i] += L->eF[L->fidx[i]];

@@ -163,6 +163,14 @@ typedef struct {
    int        ilu_tri_solve, ilu_lower_it, ilu_upper_it;
    /* coarsest_level: ilu -- read from the LAST level's entry when orc_precond_mgr gets coarsest_amg == NULL */
    int        coarse_ilu_max_iter, coarse_ilu_tri_solve, coarse_ilu_lower_it, coarse_ilu_upper_it;
+   /* nested Krylov components (reference src/internal/krylov.c; mgr.c:3938-3960, 4253-4275): 0 none, 1 pcg, 2 gmres, 3 fgmres,
+    * 4 bicgstab.  f_relaxation: a solve of A_FF e = r_F from a zero guess, preconditioned by the level's amg component
+    * (frelax_type 2) when frelax_krylov_precond is set.  coarsest_level: read from the LAST level's entry, preconditioned by the
+    * coarsest BoomerAMG. */
+   int               frelax_krylov, frelax_krylov_precond;
+   orc_krylov_params frelax_kp;
+   int               coarse_krylov, coarse_krylov_precond;
+   orc_krylov_params coarse_kp;
 } orc_mgr_level_params;
 orc_amg *orc_precond_mgr(const orc_csr *A, const int *labels, int nlevels, const orc_mgr_level_params *levels,
                          const orc_amg_params *coarsest_amg, int max_iter);

@@ -212,6 +212,24 @@ def test_cli_runs_ex8_unchanged(orc, pins):
         assert abs(int(rows[k][3]) - pins["ex8"]["stats"][k]["iters"]) <= 1
 
 
+@pytest.mark.parametrize("cfg", ["examples/ex3-mgr_Frelax_gmres.yml", "examples/ex3-mgr_coarse_gmres_amg.yml"])
+def test_cli_runs_nested_krylov_mgr_examples(cfg):
+    """The reference's examples/ex3-mgr_Frelax_gmres.yml (F-relaxation of the second reduction level = GMRES(5) preconditioned by a
+    one-level BoomerAMG) and ex3-mgr_coarse_gmres_amg.yml (coarsest level = two GMRES iterations preconditioned by BoomerAMG), the
+    files UNCHANGED; their compflow6k data set is not in the tree, so the three file names are overridden on the command line
+    (`-a`, reference src/internal/yaml.c:2178) with the generated three-field stand-in of the same layout."""
+    cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
+    d = "data/threefield/np1/"
+    r = subprocess.run([cli, "-q", cfg, "-a", "--linear_system:rhs_filename", d + "IJ.out.b", "--linear_system:matrix_filename", d + "IJ.out.A",
+                        "--linear_system:dofmap_filename", d + "dofmap.out"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    row = re.search(r"^\|\s+0 \|.*\|\s+(\S+) \|\s+(\d+) \|$", r.stdout, re.M)
+    assert row and float(row.group(1)) < 1e-6 and 0 < int(row.group(2)) < 60, r.stdout
+    plain = subprocess.run([cli, "-q", "examples/ex3-threefield.yml"], capture_output=True, text=True, cwd=ROOT)
+    prow = re.search(r"^\|\s+0 \|.*\|\s+(\S+) \|\s+(\d+) \|$", plain.stdout, re.M)
+    assert int(row.group(2)) <= int(prow.group(2)) + 2  # a stronger component does not cost iterations
+
+
 def test_null_space_projection(hd):
     """HYPREDRV_LinearSystemSetNullSpace + the projection at the end of LinearSolverApply, as the reference's own test drives them
     (tests/test_hypredrv.c:4188-4350): modes before the matrix fail cleanly; two non-orthogonal modes are orthonormalised and the

@@ -888,6 +888,45 @@ def test_mgr_matches_oracle(orc, hd, levels):
     assert rel(rh["x"], ro["x"]) < 1e-8
 
 
+@pytest.mark.parametrize("case", ["frelax_gmres_amg", "coarse_gmres_amg", "frelax_gmres_plain", "both_fgmres"])
+def test_mgr_nested_krylov_matches_oracle(orc, hd, case):
+    """Nested Krylov components of MGR (reference src/internal/krylov.c; examples/ex3-mgr_Frelax_gmres.yml: GMRES(5, tol 1e-15)
+    preconditioned by a one-level BoomerAMG as F-relaxation of the second reduction level; ex3-mgr_coarse_gmres_amg.yml: two
+    GMRES iterations preconditioned by BoomerAMG on the coarsest system).  One MGR application against the oracle's, and the
+    outer FlexGMRES (the preconditioner is no longer a fixed operator) with the oracle's iteration count.  Parity unpinned:
+    compflow6k is not in the tree."""
+    S, labels = _three_field(11, seed=3)
+    Ao, Ah = both(orc, hd, S)
+
+    def levels(lib, amgp):
+        one = amgp(max_levels=1, relax_coarse=18)  # coarsening.max_levels: 1 -- the smoother alone
+        l0 = dict(f_dofs=[2], prolongation_type="jacobi")
+        l1 = dict(f_dofs=[1], restriction_type="columped")
+        if case == "frelax_gmres_amg":
+            l1.update(f_relaxation="amg", f_amg=one, f_krylov=dict(method="gmres", max_iter=5, rtol=1e-15))
+        elif case == "coarse_gmres_amg":
+            l1.update(f_relaxation="amg", f_amg=one, coarsest_krylov=dict(method="gmres", max_iter=2, rtol=0.0))
+        elif case == "frelax_gmres_plain":
+            l1.update(f_relaxation="amg", f_amg=one, f_krylov=dict(method="gmres", max_iter=3, rtol=1e-15, precond=False))
+        else:
+            l1.update(f_relaxation="amg", f_amg=one, f_krylov=dict(method="fgmres", max_iter=2, rtol=0.0),
+                      coarsest_krylov=dict(method="fgmres", max_iter=2, rtol=0.0))
+        return [l0, l1]
+
+    Mo = orc.MgrPrecond(Ao, labels, levels(orc, lambda **kw: orc.amg_params(True, **kw)))
+    Mh = hd.Mgr(Ah, labels, levels(hd, lambda **kw: hd.AmgParams.default(**kw)))
+    r = np.random.default_rng(6).standard_normal(S.shape[0])
+    assert rel(Mh.vcycle(r), Mo.vcycle(r)) < 1e-9
+    b = np.ones(S.shape[0])
+    ro, rh = orc.fgmres(Ao, b, Mo), hd.fgmres(Ah, b, Mh)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-6)
+    # the nested solve does something: the plain components give another preconditioner
+    plain = [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], restriction_type="columped", f_relaxation="amg",
+                                                                 f_amg=hd.AmgParams.default(max_levels=1, relax_coarse=18))]
+    assert rel(hd.Mgr(Ah, labels, plain).vcycle(r), Mh.vcycle(r)) > 1e-6
+
+
 def test_mgr_unimplemented_options_fail_loudly(hd):
     S, labels = _three_field(6)
     Ah = hd.Csr.from_scipy(S)
