@@ -219,6 +219,8 @@ struct MgrParams {
    bool                        coarse_is_ilu = false; // coarsest_level: ilu
    IluParams                   coarse_ilu;
    int                         max_iter = 1;
+   int                         cycle = 1;                      // 1 V, 2 W (mgr.c:614-675)
+   int                         frelax_pos = 1, gsmooth_pos = 1; // smoothing positions: 1 before the coarse correction, 2 after, 3 both
    // coarsest_level: {gmres: {..., preconditioner: ...}} -- a nested Krylov solve of the coarsest system (mgr.c:4253-4275)
    int                         ckrylov_method = -1;
    NestedKrylov                ckrylov;

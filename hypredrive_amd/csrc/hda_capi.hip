@@ -453,6 +453,12 @@ extern "C" int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const
          q.fkrylov         = nested(levels[l].frelax_kp);
          q.fkrylov_precond = levels[l].frelax_krylov_precond != 0;
       }
+      if (l == nlevels - 1)
+      {
+         if (levels[l].mgr_cycle > 0) p.cycle = levels[l].mgr_cycle;
+         if (levels[l].mgr_frelax_pos > 0) p.frelax_pos = levels[l].mgr_frelax_pos;
+         if (levels[l].mgr_gsmooth_pos > 0) p.gsmooth_pos = levels[l].mgr_gsmooth_pos;
+      }
       if (l == nlevels - 1 && levels[l].coarse_krylov > 0)
       {
          p.ckrylov_method  = levels[l].coarse_krylov - 1;

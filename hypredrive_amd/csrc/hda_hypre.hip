@@ -1386,8 +1386,9 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
    HDA_REQUIRE(s && s->kind == HDA_SOLVER_MGR, "MGRSetup: not an MGR handle");
    HDA_REQUIRE(A && A->assembled, "MGRSetup needs an assembled matrix");
    HDA_REQUIRE(s->mgr_levels > 0 && s->mgr_marker, "MGRSetup: no C points were set (HYPRE_MGRSetCpointsByPointMarkerArray)");
-   HDA_REQUIRE(s->mgr_cycle == 1, "MGR: W-cycles (cycle: w) are not implemented on MI355X, only V-cycles");
-   HDA_REQUIRE(s->mgr_frelax_cycle == 1 && s->mgr_gsmooth_cycle == 1, "MGR: post-smoothing (cycle: v(0,1) / v(1,1)) is not implemented on MI355X, only pre-smoothing v(1,0)");
+   HDA_REQUIRE(s->mgr_cycle == 1 || s->mgr_cycle == 2, "MGR cycle type: 1 (V) or 2 (W)");
+   HDA_REQUIRE(s->mgr_frelax_cycle >= 1 && s->mgr_frelax_cycle <= 3 && s->mgr_gsmooth_cycle >= 1 && s->mgr_gsmooth_cycle <= 3,
+               "MGR smoothing position: 1 (pre), 2 (post) or 3 (both)");
    HDA_REQUIRE(s->mgr_coarse_th == 0.0, "MGR: coarse_th (coarse grid truncation) is not implemented");
    // a Krylov handle as component solver (the reference's nested Krylov wrapper, src/internal/krylov.c): its parameters and the
    // BoomerAMG / ILU handle installed as its preconditioner
@@ -1413,6 +1414,7 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
    HDA_REQUIRE(!cs || cs->kind == HDA_SOLVER_AMG || cs->kind == HDA_SOLVER_ILU,
                "MGR coarsest_level: BoomerAMG, ILU and a Krylov solver preconditioned by one of them are implemented");
    p.max_iter = s->mgr_max_iter;
+   p.cycle = s->mgr_cycle; p.frelax_pos = s->mgr_frelax_cycle; p.gsmooth_pos = s->mgr_gsmooth_cycle;
    if (cs && cs->kind == HDA_SOLVER_ILU)
    {
       HDA_REQUIRE(ilu_ok(cs), "MGR coarsest_level ilu: only type bj-iluk with fill_level 0 and reordering 0 is implemented");

@@ -594,60 +594,76 @@ double *Mgr::cycle(int l, const double *f, double *u, bool zero)
    const bool            multi = Comm::world().size > 1;
    double               *cur = u, *alt = L.u2.data();
    auto refresh = [&](double *v) { if (multi) halo_exchange(*L.hA, v); };
-   if (p.grelax_type == 16)
-   {
-      ilu_solve(*L.gilu, A, multi ? L.hA : nullptr, f, cur, zero, L.ilu_r, L.ilu_c);
-      zero = false;
-   }
-   else if (p.grelax_type >= 0)
-   {
-      if (zero) fill((int)std::max(A.ncols, n), 0.0, cur);
-      zero = false;
-      for (int s = 0; s < std::max(p.grelax_sweeps, 1); s++)
+   // g_relaxation: sweeps over all points of the level
+   auto global_relax = [&]() {
+      if (p.grelax_type == 16)
       {
-         const int t = p.grelax_type;
-         if (t == 3 || t == 13 || t == 6 || t == 8 || t == 88) { refresh(cur); gs_sweep(A, L.gs, L.dinvG.data(), f, cur, true); }
-         if (t == 4 || t == 14 || t == 6 || t == 8 || t == 88) { refresh(cur); gs_sweep(A, L.gs, L.dinvG.data(), f, cur, false); }
+         ilu_solve(*L.gilu, A, multi ? L.hA : nullptr, f, cur, zero, L.ilu_r, L.ilu_c);
+         zero = false;
       }
-   }
-   for (int s = 0; s < p.frelax_sweeps; s++)
-   {
-      if (p.frelax_type == 2 || p.frelax_type == 32)
-      { // e_F = M_FF^-1 (f - A u)_F (one BoomerAMG cycle from a zero guess, or one ILU(0) solve), u_F += e_F
-         if (zero) { fill((int)std::max(A.ncols, n), 0.0, cur); zero = false; }
-         refresh(cur);
-         residual(A, cur, f, L.t.data());
-         if (n) k_mgr_gatherF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.t.data(), L.rF.data());
-         if (p.fkrylov_method >= 0)
-         { // nested Krylov solve of A_FF e_F = r_F from a zero guess, preconditioned by the level's component
-            fill((int)L.eF.size(), 0.0, L.eF.data());
-            PrecondFn M;
-            // (a PCG caller hands over the slot it wants the block partials of <r, z> in)
-            if (p.fkrylov_precond && L.famg) M = [&L](const double *r, double *z, int slot) { L.famg->apply(r, z, -1); if (slot >= 0) dot(L.nf, r, z, slot); };
-            else if (p.fkrylov_precond && L.filu) M = [&L](const double *r, double *z, int slot) { L.filu->apply(r, z); if (slot >= 0) dot(L.nf, r, z, slot); };
-            nested_krylov(p.fkrylov_method, p.fkrylov, LinOp(L.Aff, multi ? &L.hFF : nullptr, L.eF.size()), M, L.rF.data(), L.eF.data());
+      else if (p.grelax_type >= 0)
+      {
+         if (zero) fill((int)std::max(A.ncols, n), 0.0, cur);
+         zero = false;
+         for (int s = 0; s < std::max(p.grelax_sweeps, 1); s++)
+         {
+            const int t = p.grelax_type;
+            if (t == 3 || t == 13 || t == 6 || t == 8 || t == 88) { refresh(cur); gs_sweep(A, L.gs, L.dinvG.data(), f, cur, true); }
+            if (t == 4 || t == 14 || t == 6 || t == 8 || t == 88) { refresh(cur); gs_sweep(A, L.gs, L.dinvG.data(), f, cur, false); }
          }
-         else if (L.famg) L.famg->apply(L.rF.data(), L.eF.data(), -1);
-         else L.filu->apply(L.rF.data(), L.eF.data());
-         if (n) k_mgr_addF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.eF.data(), cur);
-         continue;
       }
-      if (zero) { jacobi_zero_guess(n, L.dinvF.data(), f, cur); zero = false; continue; } // u = dinvF .* f
-      refresh(cur);
-      jacobi(A, L.dinvF.data(), f, cur, alt, -1);
-      std::swap(cur, alt);
-   }
-   if (zero) { fill(n, 0.0, cur); zero = false; }
-   refresh(cur);
-   residual(A, cur, f, L.t.data());
+   };
+   // f_relaxation: sweeps on the F points of the level
+   auto f_relax = [&]() {
+      for (int s = 0; s < p.frelax_sweeps; s++)
+      {
+         if (p.frelax_type == 2 || p.frelax_type == 32)
+         { // e_F = M_FF^-1 (f - A u)_F (one BoomerAMG cycle from a zero guess, or one ILU(0) solve), u_F += e_F
+            if (zero) { fill((int)std::max(A.ncols, n), 0.0, cur); zero = false; }
+            refresh(cur);
+            residual(A, cur, f, L.t.data());
+            if (n) k_mgr_gatherF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.t.data(), L.rF.data());
+            if (p.fkrylov_method >= 0)
+            { // nested Krylov solve of A_FF e_F = r_F from a zero guess, preconditioned by the level's component
+               fill((int)L.eF.size(), 0.0, L.eF.data());
+               PrecondFn M;
+               // (a PCG caller hands over the slot it wants the block partials of <r, z> in)
+               if (p.fkrylov_precond && L.famg) M = [&L](const double *r, double *z, int slot) { L.famg->apply(r, z, -1); if (slot >= 0) dot(L.nf, r, z, slot); };
+               else if (p.fkrylov_precond && L.filu) M = [&L](const double *r, double *z, int slot) { L.filu->apply(r, z); if (slot >= 0) dot(L.nf, r, z, slot); };
+               nested_krylov(p.fkrylov_method, p.fkrylov, LinOp(L.Aff, multi ? &L.hFF : nullptr, L.eF.size()), M, L.rF.data(), L.eF.data());
+            }
+            else if (L.famg) L.famg->apply(L.rF.data(), L.eF.data(), -1);
+            else L.filu->apply(L.rF.data(), L.eF.data());
+            if (n) k_mgr_addF<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), L.fidx.data(), L.eF.data(), cur);
+            continue;
+         }
+         if (zero) { jacobi_zero_guess(n, L.dinvF.data(), f, cur); zero = false; continue; } // u = dinvF .* f
+         refresh(cur);
+         jacobi(A, L.dinvF.data(), f, cur, alt, -1);
+         std::swap(cur, alt);
+      }
+   };
+   // smoothing positions (reference mgr.c:614-675: v(1,0) pre, v(0,1) post, v(1,1) both; hypre's SetGlobalSmoothCycle /
+   // SetFRelaxCycle): before the coarse correction global relaxation then F-relaxation, after it the mirror image
+   if (prm.gsmooth_pos & 1) global_relax();
+   if (prm.frelax_pos & 1) f_relax();
    const bool last = (l + 1 == (int)lv.size());
    double    *fcl  = last ? fc.data() : lv[(size_t)l + 1].f.data();
    double    *ucl  = last ? uc.data() : lv[(size_t)l + 1].u.data();
-   refresh(L.t.data());
-   spmv(L.R, 1.0, L.t.data(), 0.0, nullptr, fcl);
-   double *ec = cycle(l + 1, fcl, ucl, true);
-   if (multi) halo_exchange(L.hP, ec);
-   spmv(L.P, 1.0, ec, 1.0, cur, cur);
+   // W-cycle (cycle 2): the coarser level is visited twice
+   for (int visit = 0; visit < (prm.cycle == 2 ? 2 : 1); visit++)
+   {
+      if (zero) { fill(n, 0.0, cur); zero = false; }
+      refresh(cur);
+      residual(A, cur, f, L.t.data());
+      refresh(L.t.data());
+      spmv(L.R, 1.0, L.t.data(), 0.0, nullptr, fcl);
+      double *ec = cycle(l + 1, fcl, ucl, true);
+      if (multi) halo_exchange(L.hP, ec);
+      spmv(L.P, 1.0, ec, 1.0, cur, cur);
+   }
+   if (prm.frelax_pos & 2) f_relax();
+   if (prm.gsmooth_pos & 2) global_relax();
    return cur;
 }
 

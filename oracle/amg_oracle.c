@@ -1771,6 +1771,7 @@ struct orc_mgr {
    double    *ct, *cc;
    double    *fc, *uc;
    int        max_iter;
+   int        cycle, fpos, gpos; /* 1 V / 2 W; smoothing positions 1 pre, 2 post, 3 both */
    int        ckry, ckry_pre; /* nested Krylov coarsest solve */
    orc_krylov_params ckp;
 };
@@ -1962,6 +1963,14 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
    }
    M->Ac   = A;
    free(labels);
+   M->cycle = 1; M->fpos = 1; M->gpos = 1;
+   if (nlevels > 0)
+   {
+      const orc_mgr_level_params *q = &lp[nlevels - 1];
+      if (q->mgr_cycle > 0) M->cycle = q->mgr_cycle;
+      if (q->mgr_frelax_pos > 0) M->fpos = q->mgr_frelax_pos;
+      if (q->mgr_gsmooth_pos > 0) M->gpos = q->mgr_gsmooth_pos;
+   }
    if (nlevels > 0) { M->ckry = lp[nlevels - 1].coarse_krylov; M->ckry_pre = lp[nlevels - 1].coarse_krylov_precond; M->ckp = lp[nlevels - 1].coarse_kp; }
    if (coarse_amg) M->camg = orc_amg_setup(A, coarse_amg);
    else
@@ -1980,22 +1989,18 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
 }
 
 static void
-mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
+mgr_global_relax(mgr_level *L, const double *f, double *u)
 {
-   if (l == M->nlev)
-   {
-      memset(u, 0, sizeof(double) * (size_t)M->Ac->nrows);
-      if (M->ckry && M->camg) nested_krylov(M->ckry, &M->ckp, M->Ac, M->ckry_pre ? M->camg : NULL, f, u);
-      else if (M->camg) orc_amg_vcycle(M->camg, f, u);
-      else ilu_iterate(M->cilu, M->Ac, M->cilu_iters, f, u, M->ct, M->cc);
-      return;
-   }
-   mgr_level *L = &M->lv[l];
-   const int  n = L->n;
    if (L->grelax_type == 16 && L->gilu) ilu_iterate(L->gilu, L->A, L->grelax_sweeps, f, u, L->t, L->cor);
    else if (L->grelax_type >= 0)
       for (int s = 0; s < L->grelax_sweeps; s++)
          orc_relax(L->A, L->l1g, L->grelax_type == 88 ? 8 : L->grelax_type, 1.0, f, u, L->t);
+}
+
+static void
+mgr_f_relax(mgr_level *L, const double *f, double *u)
+{
+   const int n = L->n;
    for (int s = 0; s < L->frelax_sweeps; s++)
    {
       memcpy(L->t, f, sizeof(double) * (size_t)n);
@@ -2014,14 +2019,38 @@ mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
       else
          for (int i = 0; i < n; i++) u[i] += L->dinvF[i] * L->t[i];
    }
-   memcpy(L->t, f, sizeof(double) * (size_t)n);
-   orc_spmv(L->A, -1.0, u, 1.0, L->t);
-   double *fc = (l + 1 < M->nlev) ? M->lv[l + 1].f : M->fc;
-   double *uc = (l + 1 < M->nlev) ? M->lv[l + 1].u : M->uc;
-   orc_spmv(L->R, 1.0, L->t, 0.0, fc);
-   memset(uc, 0, sizeof(double) * (size_t)L->nc);
-   mgr_cycle(M, l + 1, fc, uc);
-   orc_spmv(L->P, 1.0, uc, 1.0, u);
+}
+
+static void
+mgr_cycle(struct orc_mgr *M, int l, const double *f, double *u)
+{
+   if (l == M->nlev)
+   {
+      memset(u, 0, sizeof(double) * (size_t)M->Ac->nrows);
+      if (M->ckry && M->camg) nested_krylov(M->ckry, &M->ckp, M->Ac, M->ckry_pre ? M->camg : NULL, f, u);
+      else if (M->camg) orc_amg_vcycle(M->camg, f, u);
+      else ilu_iterate(M->cilu, M->Ac, M->cilu_iters, f, u, M->ct, M->cc);
+      return;
+   }
+   mgr_level *L = &M->lv[l];
+   /* smoothing positions (reference mgr.c:614-675): before the coarse correction global relaxation then F-relaxation, after it
+    * the mirror image; W-cycle: the coarser level is visited twice */
+   if (M->gpos & 1) mgr_global_relax(L, f, u);
+   if (M->fpos & 1) mgr_f_relax(L, f, u);
+   const int n   = L->n;
+   double   *fc = (l + 1 < M->nlev) ? M->lv[l + 1].f : M->fc;
+   double   *uc = (l + 1 < M->nlev) ? M->lv[l + 1].u : M->uc;
+   for (int visit = 0; visit < (M->cycle == 2 ? 2 : 1); visit++)
+   {
+      memcpy(L->t, f, sizeof(double) * (size_t)n);
+      orc_spmv(L->A, -1.0, u, 1.0, L->t);
+      orc_spmv(L->R, 1.0, L->t, 0.0, fc);
+      memset(uc, 0, sizeof(double) * (size_t)L->nc);
+      mgr_cycle(M, l + 1, fc, uc);
+      orc_spmv(L->P, 1.0, uc, 1.0, u);
+   }
+   if (M->fpos & 2) mgr_f_relax(L, f, u);
+   if (M->gpos & 2) mgr_global_relax(L, f, u);
 }
 
 static void

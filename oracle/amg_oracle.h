@@ -171,6 +171,9 @@ typedef struct {
    orc_krylov_params frelax_kp;
    int               coarse_krylov, coarse_krylov_precond;
    orc_krylov_params coarse_kp;
+   /* cycle shape, read from the LAST level's entry; 0 = default.  mgr_cycle: 1 V, 2 W; positions (reference mgr.c:614-675,
+    * hypre's SetFRelaxCycle / SetGlobalSmoothCycle): 1 before the coarse correction, 2 after it, 3 both */
+   int               mgr_cycle, mgr_frelax_pos, mgr_gsmooth_pos;
 } orc_mgr_level_params;
 orc_amg *orc_precond_mgr(const orc_csr *A, const int *labels, int nlevels, const orc_mgr_level_params *levels,
                          const orc_amg_params *coarsest_amg, int max_iter);

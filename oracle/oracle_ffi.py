@@ -43,7 +43,8 @@ class MgrLevelParams(C.Structure):
                 ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int),
                 ("coarse_ilu_max_iter", C.c_int), ("coarse_ilu_tri_solve", C.c_int), ("coarse_ilu_lower_it", C.c_int), ("coarse_ilu_upper_it", C.c_int),
                 ("frelax_krylov", C.c_int), ("frelax_krylov_precond", C.c_int), ("frelax_kp", KrylovParams),
-                ("coarse_krylov", C.c_int), ("coarse_krylov_precond", C.c_int), ("coarse_kp", KrylovParams)]
+                ("coarse_krylov", C.c_int), ("coarse_krylov_precond", C.c_int), ("coarse_kp", KrylovParams),
+                ("mgr_cycle", C.c_int), ("mgr_frelax_pos", C.c_int), ("mgr_gsmooth_pos", C.c_int)]
 
 
 def build(force=False):
@@ -468,6 +469,11 @@ def _mgr_nested(entry, lv):
             setattr(kp, k, v)
         setattr(entry, pre + "_krylov", MGR_KRYLOV[nk.get("method", "gmres")])
         setattr(entry, pre + "_krylov_precond", 1 if nk.get("precond", True) else 0)
+    cyc = lv.get("cycle")  # on the last level: "v(1,0)" (default), "v(0,1)", "v(1,1)", "w", "w(0,1)", "w(1,1)"
+    if cyc:
+        entry.mgr_cycle = 2 if cyc.startswith("w") else 1
+        pos = {"": 1, "(1,0)": 1, "(0,1)": 2, "(1,1)": 3}[cyc[1:]]
+        entry.mgr_frelax_pos = entry.mgr_gsmooth_pos = pos
 
 
 def mgr_level_list(levels):

@@ -230,6 +230,23 @@ def test_cli_runs_nested_krylov_mgr_examples(cfg):
     assert int(row.group(2)) <= int(prow.group(2)) + 2  # a stronger component does not cost iterations
 
 
+@pytest.mark.parametrize("cyc", ["v(1,1)", "v(0,1)", "w(1,1)"])
+def test_cli_mgr_cycle_strings(cyc):
+    """`preconditioner.mgr.cycle` through the YAML surface (the strings of the reference's examples/ex7-mgr-cycle-*.yml,
+    src/internal/mgr.c:614-675) on the three-field stand-in: every shape converges, the richer ones in no more iterations."""
+    cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
+    it = {}
+    for c in ("v(1,0)", cyc):
+        r = subprocess.run([cli, "-q", "examples/ex3-threefield.yml", "-a", "--preconditioner:mgr:cycle", c], capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 0, r.stdout + r.stderr
+        row = re.search(r"^\|\s+0 \|.*\|\s+(\S+) \|\s+(\d+) \|$", r.stdout, re.M)
+        assert row and float(row.group(1)) < 1e-6, r.stdout
+        it[c] = int(row.group(2))
+    if cyc != "v(0,1)":
+        assert it[cyc] <= it["v(1,0)"]
+    assert it[cyc] != it["v(1,0)"] or cyc == "v(0,1)"  # the option reaches the cycle
+
+
 def test_null_space_projection(hd):
     """HYPREDRV_LinearSystemSetNullSpace + the projection at the end of LinearSolverApply, as the reference's own test drives them
     (tests/test_hypredrv.c:4188-4350): modes before the matrix fail cleanly; two non-orthogonal modes are orthonormalised and the

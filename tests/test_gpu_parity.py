@@ -927,6 +927,25 @@ def test_mgr_nested_krylov_matches_oracle(orc, hd, case):
     assert rel(hd.Mgr(Ah, labels, plain).vcycle(r), Mh.vcycle(r)) > 1e-6
 
 
+@pytest.mark.parametrize("cyc", ["v(0,1)", "v(1,1)", "w", "w(1,1)"])
+def test_mgr_cycle_shapes_match_oracle(orc, hd, cyc):
+    """`mgr.cycle` (reference src/internal/mgr.c:614-675): smoothing after the coarse correction, on both sides of it, and W-cycles
+    (the coarser level visited twice), with global relaxation and F-relaxation on both reduction levels."""
+    S, labels = _three_field(11, seed=3)
+    Ao, Ah = both(orc, hd, S)
+    lev = [dict(f_dofs=[2], prolongation_type="jacobi", g_relaxation="l1-hsgs"),
+           dict(f_dofs=[1], g_relaxation="h-fgs", restriction_type="columped", f_relaxation="l1-jacobi", f_sweeps=2, cycle=cyc)]
+    Mo, Mh = orc.MgrPrecond(Ao, labels, lev), hd.Mgr(Ah, labels, lev)
+    r = np.random.default_rng(6).standard_normal(S.shape[0])
+    zh, zo = Mh.vcycle(r), Mo.vcycle(r)
+    assert rel(zh, zo) < 1e-11
+    base = [dict(lev[0]), {k: v for k, v in lev[1].items() if k != "cycle"}]
+    assert rel(hd.Mgr(Ah, labels, base).vcycle(r), zh) > 1e-6  # not the default v(1,0) cycle
+    b = np.ones(S.shape[0])
+    ro, rh = orc.gmres(Ao, b, Mo), hd.gmres(Ah, b, Mh)
+    assert rh["converged"] and rh["iters"] == ro["iters"] and np.allclose(rh["hist"], ro["hist"], rtol=1e-7)
+
+
 def test_mgr_unimplemented_options_fail_loudly(hd):
     S, labels = _three_field(6)
     Ah = hd.Csr.from_scipy(S)
