@@ -513,6 +513,12 @@ __global__ __launch_bounds__(256) void k_code_collect(int n, int stride, const i
    int bad = 0;
    for (int k = rp[i]; k < rp[i + 1]; k++)
    {
+      if (bad)
+      { // report at once: an operator that does not fit the table is given up as soon as the count passes the limit,
+        // not after every sampled row has walked the full table for each of its entries
+         if (atomicAdd(fails, bad) + bad > limit) return;
+         bad = 0;
+      }
       const double   val = v[k];
       const int      d   = cj[k] - (int)i;
       const uint64_t key = pair_key(val, d);
@@ -1401,7 +1407,8 @@ __global__ __launch_bounds__(256) void k_vhist(long nnz, int stride, const doubl
       if (*(volatile int *)distinct > kVHashSlots / 2) return; // too many different values: give up early
       const unsigned long long key = (unsigned long long)__double_as_longlong(v[k]);
       unsigned                 s   = vhash(key);
-      for (int probe = 0; probe < kVHashSlots; probe++)
+      bool placed = false;
+      for (int probe = 0; probe < 64; probe++)
       {
          unsigned long long cur = keys[s];
          if (cur == kEmptyKey)
@@ -1409,8 +1416,13 @@ __global__ __launch_bounds__(256) void k_vhist(long nnz, int stride, const doubl
             cur = atomicCAS(&keys[s], (unsigned long long)kEmptyKey, key);
             if (cur == kEmptyKey) { atomicAdd(distinct, 1); cur = key; }
          }
-         if (cur == key) { atomicAdd(&counts[s], 1); break; }
+         if (cur == key) { atomicAdd(&counts[s], 1); placed = true; break; }
          s = (s + 1) & (kVHashSlots - 1);
+      }
+      if (!placed)
+      { // 64 occupied slots in a row: the table is crowded, i.e. far more different values than a dictionary holds
+         atomicAdd(distinct, kVHashSlots);
+         return;
       }
    }
 }

@@ -1,0 +1,17 @@
+#!/bin/bash
+# kernel statistics of the config-5 stand-in (bench.py --workload aniso --grid 160)
+set -o pipefail
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
+O=$R/gpurun_out/r02ac
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python3 $R/bench.py --workload aniso --grid 160 --steps 5 --warmup 1 --no-cpu-baseline --no-kernel-table --no-plain-csr > $O/trace.log 2>&1 || { tail -20 $O/trace.log; exit 1; }
+find $O/trace -name "*kernel_trace.csv" -size +40M -delete
+python3 - <<PY
+import csv, glob
+f = glob.glob("$O/trace/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+for r in rows[:40]:
+    print(r["Name"][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"])
+PY
+tail -c 1500 $O/trace.log
