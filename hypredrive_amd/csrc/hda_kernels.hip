@@ -2197,9 +2197,56 @@ __global__ __launch_bounds__(256) void k_l1(int n, const int *__restrict__ rp, c
       l1[i] = (d < 0.0) ? -t : t;
    }
 }
+// G lanes per row (coalesced reads of long rows); the sums keep the sequential order: the lanes hand their terms round in
+// ascending k and every lane adds them in that order
+template <int G>
+__global__ __launch_bounds__(256) void k_l1_grp(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                int option, double *__restrict__ l1)
+{
+   const int  gl  = threadIdx.x & (G - 1);
+   const long row = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+   const bool in  = row < n;
+   const int  i   = in ? (int)row : 0;
+   const int  k0 = in ? rp[i] : 0, k1 = in ? rp[i + 1] : 0;
+   double     s = 0.0, d = 0.0, off = 0.0;
+   for (int base = k0; base < k1; base += G)
+   {
+      const int k = base + gl;
+      double    a = 0.0, o = 0.0;
+      if (k < k1)
+      {
+         const int    c  = cj[k];
+         const double vk = v[k];
+         a = fabs(vk);
+         if (c == i) d = vk;
+         if (c >= n) o = a;
+      }
+      const int m = min(G, k1 - base);
+      for (int l = 0; l < m; l++)
+      {
+         s += __shfl(a, l, G);
+         off += __shfl(o, l, G); // (entries that are not ghost columns add 0.0)
+      }
+   }
+   for (int o = G >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, G); // one lane holds the diagonal, the others 0
+   if (!in || gl) return;
+   if (option == 1) l1[i] = (d < 0.0) ? -s : s;
+   else
+   {
+      double t = fabs(d) + 0.5 * off;
+      if (t <= (4.0 / 3.0) * fabs(d)) t = fabs(d);
+      l1[i] = (d < 0.0) ? -t : t;
+   }
+}
 void l1_row_norms(const DCsr &A, int option, double *l1)
 {
-   if (A.nrows) k_l1<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
+   if (!A.nrows) return;
+   const int    n   = A.nrows;
+   const double avg = A.avg_row();
+   if (avg <= 12.0) k_l1<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
+   else if (avg <= 24.0) k_l1_grp<16><<<ceil_div((long long)n * 16, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
+   else if (avg <= 48.0) k_l1_grp<32><<<ceil_div((long long)n * 32, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
+   else k_l1_grp<64><<<ceil_div((long long)n * 64, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
 }
 void extract_diag(const DCsr &A, double *d) { l1_row_norms(A, 4, d); }
 
