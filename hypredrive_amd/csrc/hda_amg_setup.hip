@@ -451,6 +451,13 @@ __global__ __launch_bounds__(256) void k_count_strongC(int n, const int *__restr
    nsC[i] = c;
 }
 
+// per entry: strong connection to a C point (what C-hat_i is built from); the interpolation kernel reads it with the entry
+__global__ __launch_bounds__(256) void k_strongC_flag(int nnz, const int *__restrict__ cj, const unsigned char *__restrict__ smask,
+                                                      const int *__restrict__ cf, unsigned char *__restrict__ sc)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256) sc[k] = (smask[k] && cf[cj[k]] == 1) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void k_interp_ub(int n, const int *__restrict__ rp,
                                                    const int *__restrict__ cj,
                                                    const unsigned char *__restrict__ smask,
@@ -783,7 +790,7 @@ __global__ __launch_bounds__(256) void k_max3(int n, const int *__restrict__ rp,
 template <int G>
 __global__ __launch_bounds__(256, 3) void k_interp_wave(
    int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
-   const unsigned char *__restrict__ smask, const int *__restrict__ cf, const int *__restrict__ nsC,
+   const unsigned char *__restrict__ smask, const unsigned char *__restrict__ sc, const int *__restrict__ cf, const int *__restrict__ nsC,
    const long long *__restrict__ uofs, int cap_row, int cap_ub, int cap_nbr, int pmax, double trunc_factor,
    const unsigned char *__restrict__ rowmode, int *__restrict__ lcol, double *__restrict__ lw, int *__restrict__ pcnt,
    const int *__restrict__ dof, int s3_scan, unsigned long long *__restrict__ prof)
@@ -854,7 +861,13 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
             int t = T_OTHER;
             if (j == i) t = T_DIAG;
             else if (st && cfj == 1) { t = T_SC; cntk = 1; }
-            else if (st && cfj == -1) { t = T_SF; cntk = nsC[j]; }
+            else if (st && cfj == -1)
+            { // the neighbour row's extent travels with its candidate count: one round trip to memory, not two
+               t       = T_SF;
+               cntk    = nsC[j];
+               nbeg[k] = rp[j];
+               noff[k] = rp[j + 1]; // (its end, until the scan of stage 1b turns it into an offset)
+            }
             rcol[k]  = j;
             rval[k]  = v[k0 + k];
             // bit 8: never lumped into the diagonal (special F point, or another function's unknown)
@@ -880,9 +893,8 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
          int       ln = 0, js = 0;
          if (k < nk && (rtype[k] & 7) == T_SF)
          {
-            const int j = rcol[k];
-            js          = rp[j];
-            ln          = rp[j + 1] - js;
+            js = nbeg[k];
+            ln = noff[k] - js;
          }
          int incl = ln;
          for (int o = 1; o < G; o <<= 1)
@@ -923,14 +935,14 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
             }
 #pragma unroll
             for (int u = 0; u < 4; u++)
-               if (g[u] >= 0) { m[u] = cj[g[u]]; a[u] = v[g[u]]; sm[u] = smask[g[u]]; }
+               if (g[u] >= 0) { m[u] = cj[g[u]]; a[u] = v[g[u]]; sm[u] = sc[g[u]]; } // sc: strong entry whose column is a C point
 #pragma unroll
             for (int u = 0; u < 4; u++)
                if (g[u] >= 0)
                {
                   const int f = fb + G * u + lane;
                   nval[f]     = a[u];
-                  ncol[f]     = m[u] | ((sm[u] && cf[m[u]] == 1) ? (int)0x80000000 : 0);
+                  ncol[f]     = m[u] | (sm[u] ? (int)0x80000000 : 0);
                }
          }
       }
@@ -941,8 +953,7 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
       auto nb_val = [&](int k, int e) -> double { return staged ? nval[noff[k] + e] : v[nbeg[k] + e]; };
       auto nb_sc  = [&](int k, int e) -> bool {
          if (staged) return ncol[noff[k] + e] < 0;
-         const int g = nbeg[k] + e;
-         return smask[g] && cf[cj[g]] == 1;
+         return sc[nbeg[k] + e] != 0;
       };
       // ---- 2. candidates in discovery order: entry k's candidates start at rofs[k]
       if (staged)
@@ -1477,9 +1488,11 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
          prof.alloc(10);
          prof.zero();
       }
+      DArray<unsigned char> sc((size_t)std::max(A.nnz, 1));
+      if (A.nnz) k_strongC_flag<<<std::min(ceil_div(A.nnz, 256), 1 << 16), 256, 0, STREAM>>>(A.nnz, A.col.data(), smask, cf, sc.data());
       auto launch = [&](auto kern) {
          HDA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-         kern<<<std::min(ceil_div(n, gpb), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, nsC.data(),
+         kern<<<std::min(ceil_div(n, gpb), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, sc.data(), cf, nsC.data(),
                                                                       uofs.data(), cap_row, cap_ub, cap_nbr, pmax, trunc_factor, rowmode.data(),
                                                                       lcol.data(), lw.data(), pcnt.data(), dof, s3_scan, prof.data());
       };
