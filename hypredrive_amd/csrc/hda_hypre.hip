@@ -1402,14 +1402,24 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
       return k;
    };
    auto ilu_ok = [](HYPRE_Solver q) { return q->ilu_type == 0 && q->ilu_fill == 0 && q->ilu_reordering == 0; };
+   // component handles come through HYPRE_Solver-typed setters: anything that is not one of this library's live solver objects
+   // (a foreign cookie, a destroyed handle) is refused before it is looked into
+   auto ours = [](HYPRE_Solver q) { return !q || is_live_solver(q); };
+   HDA_REQUIRE(ours(s->mgr_csolver), "MGR coarsest_level: the solver handle is not a live solver object of this library");
+   for (HYPRE_Solver q : s->mgr_fsolver) HDA_REQUIRE(ours(q), "MGR f_relaxation: the F-solver handle is not a live solver object of this library");
+   for (HYPRE_Solver q : s->mgr_gsolver) HDA_REQUIRE(ours(q), "MGR g_relaxation: the smoother handle is not a live solver object of this library");
+   auto precond_of = [&](HYPRE_Solver q) -> HYPRE_Solver { // the preconditioner handle of a Krylov component
+      HDA_REQUIRE(ours(q->precond_solver), "MGR: the preconditioner of a nested Krylov solver is not a live solver object of this library");
+      return q->precond_solver;
+   };
    MgrParams    p;
    HYPRE_Solver cs = s->mgr_csolver;
    if (krylov_method(cs) >= 0)
    {
       p.ckrylov_method  = krylov_method(cs);
       p.ckrylov         = nested(cs);
-      p.ckrylov_precond = cs->precond_solver != nullptr;
-      cs                = cs->precond_solver; // what preconditions it; none: the coarse hierarchy below is built and left unused
+      p.ckrylov_precond = precond_of(cs) != nullptr;
+      cs                = precond_of(cs); // what preconditions it; none: the coarse hierarchy below is built and left unused
    }
    HDA_REQUIRE(!cs || cs->kind == HDA_SOLVER_AMG || cs->kind == HDA_SOLVER_ILU,
                "MGR coarsest_level: BoomerAMG, ILU and a Krylov solver preconditioned by one of them are implemented");
@@ -1451,16 +1461,17 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
          { // F-relaxation by a nested Krylov solve: the component underneath is its preconditioner (BoomerAMG when there is none to name)
             q.fkrylov_method  = krylov_method(fk);
             q.fkrylov         = nested(fk);
-            q.fkrylov_precond = fk->precond_solver != nullptr;
-            HDA_REQUIRE(!fk->precond_solver || fk->precond_solver->kind == HDA_SOLVER_AMG || fk->precond_solver->kind == HDA_SOLVER_ILU,
+            HYPRE_Solver fp   = precond_of(fk);
+            q.fkrylov_precond = fp != nullptr;
+            HDA_REQUIRE(!fp || fp->kind == HDA_SOLVER_AMG || fp->kind == HDA_SOLVER_ILU,
                         "MGR f_relaxation: a nested Krylov solver takes BoomerAMG, ILU or no preconditioner");
-            q.frelax_type = (fk->precond_solver && fk->precond_solver->kind == HDA_SOLVER_ILU) ? 32 : 2;
+            q.frelax_type = (fp && fp->kind == HDA_SOLVER_ILU) ? 32 : 2;
          }
       }
       if (q.frelax_type == 2 || q.frelax_type == 32)
       {
          HYPRE_Solver fs = (size_t)l < s->mgr_fsolver.size() ? s->mgr_fsolver[(size_t)l] : nullptr;
-         if (krylov_method(fs) >= 0) fs = fs->precond_solver;
+         if (krylov_method(fs) >= 0) fs = precond_of(fs);
          HDA_REQUIRE(!fs || fs->kind == (q.frelax_type == 2 ? HDA_SOLVER_AMG : HDA_SOLVER_ILU), "MGR f_relaxation: the F-solver handle does not match its type (amg / ilu)");
          if (fs && q.frelax_type == 2) { q.frelax_amg = fs->ap; q.frelax_amg.num_functions = std::max(fs->num_functions, 1); }
          if (fs && q.frelax_type == 32)

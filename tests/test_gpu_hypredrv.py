@@ -1098,8 +1098,18 @@ MGR_DIST_CASES["famg"] = ("solver:\n  gmres:\n    relative_tol: 1.0e-8\nprecondi
                           [dict(f_dofs=[0], prolongation_type="jacobi", f_relaxation="amg", f_amg_kw=dict(strong_th=0.3))], 1)
 
 
+# nested Krylov components on row partitions: GMRES(3) + BoomerAMG on A_FF, GMRES(2) + BoomerAMG on the coarsest system, FlexGMRES outside
+MGR_DIST_CASES["nested"] = ("solver:\n  fgmres:\n    relative_tol: 1.0e-8\npreconditioner:\n  mgr:\n    level:\n      0:\n        f_dofs: [0]\n"
+                            "        f_relaxation:\n          gmres:\n            max_iter: 3\n            relative_tol: 0.0\n            preconditioner:\n"
+                            "              amg:\n                coarsening:\n                  strong_th: 0.3\n"
+                            "        prolongation_type: jacobi\n    coarsest_level:\n      gmres:\n        max_iter: 2\n        relative_tol: 0.0\n"
+                            "        preconditioner: amg\n",
+                            [dict(f_dofs=[0], prolongation_type="jacobi", f_relaxation="amg", f_amg_kw=dict(strong_th=0.3),
+                                  f_krylov=dict(method="gmres", max_iter=3, rtol=0.0), coarsest_krylov=dict(method="gmres", max_iter=2, rtol=0.0))], 1)
+
+
 @pytest.mark.parametrize("world,case,rep_rows", [(2, "jacobi-columped", 0), (3, "jacobi-columped", 100000), (4, "ex3", 0), (3, "ex3", 100000),
-                                                 (3, "famg", 0), (2, "famg", 100000)])
+                                                 (3, "famg", 0), (2, "famg", 100000), (3, "nested", 0)])
 def test_row_partitioned_mgr(hd, orc, tmp_path, world, case, rep_rows):
     """MGR on a row-partitioned matrix (rows cut inside cells too): ghost labels / C-F marks / coarse ids through the halo plan,
     reduced operators by two row-partitioned products, BoomerAMG on the partitioned coarsest system.  Without global relaxation
@@ -1121,7 +1131,8 @@ def test_row_partitioned_mgr(hd, orc, tmp_path, world, case, rep_rows):
     for l in lev:
         if "f_amg_kw" in l:
             l["f_amg"] = orc.amg_params(True, **l.pop("f_amg_kw"))
-    ref = orc.gmres(Ao, np.ones(S.shape[0]), orc.MgrPrecond(Ao, labels, lev), orc.krylov_params(True, rtol=1e-8))
+    outer = orc.fgmres if case == "nested" else orc.gmres
+    ref = outer(Ao, np.ones(S.shape[0]), orc.MgrPrecond(Ao, labels, lev), orc.krylov_params(True, rtol=1e-8))
     assert res["converged"] and abs(res["iters"] - ref["iters"]) <= slack, (res["iters"], ref["iters"])
     assert res["norm"] == pytest.approx(np.linalg.norm(ref["x"]), rel=1e-6)
 
