@@ -439,6 +439,32 @@ def test_systems_amg_unknown_approach_identical_to_oracle(orc, hd, cpu_defaults,
     assert np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
 
 
+def test_systems_amg_with_direct_interpolation_identical_to_oracle(orc, hd):
+    """num_functions = 3 together with interpolation type 3: the direct weights' row sums leave other functions' couplings out
+    (positive off-diagonals here, so beta is exercised as well); hierarchy and PCG against the oracle."""
+    import scipy.sparse as sp
+    n = 7
+    I = sp.identity(n)
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n))
+    L = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)).tocsr()
+    B = np.array([[1.0, 0.85, 0.1], [0.85, 1.2, 0.25], [0.1, 0.25, 0.9]])
+    A = sp.kron(L, B).tocsr()
+    A.sort_indices()
+    N = A.shape[0]
+    Ao, Ah = orc.Csr.from_arrays(N, N, A.indptr, A.indices, A.data), hd.Csr.from_arrays(N, N, A.indptr, A.indices, A.data)
+    kw = dict(num_functions=3, strong_th=0.8, interp_type=3)
+    po = orc.amg_params(True, **kw)
+    ho, hh = orc.Amg(Ao, po), hd.Amg(Ah, hd.AmgParams.default(**kw))
+    assert hh.num_levels == ho.num_levels >= 2
+    for l in range(ho.num_levels - 1):
+        rp, cj, v = hh.level_matrix(l, 1).download()
+        Pl = ho.level_P(l)
+        assert np.array_equal(rp, Pl.rowptr) and np.array_equal(cj, Pl.col) and np.array_equal(v, Pl.val), f"P level {l}"
+    b = np.ones(N)
+    ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+    assert rh["converged"] and rh["iters"] == ro["iters"] and np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
+
+
 def _random_system(seed, kind):
     """Irregular test operators: weighted graph Laplacians (M-matrices), a version with positive
     off-diagonals mixed in, an unsymmetric convection-like one, and one with a negative diagonal."""
