@@ -153,7 +153,18 @@ __device__ __forceinline__ void gs_rows(int first, int count, int tid, int nthre
    {
       const int i = perm[first + q], k0 = rbeg[first + q], k1 = rend[first + q]; // three independent coalesced loads
       double    s = 0.0;
-      for (int k = k0 + lane; k < k1; k += LPR) s += v[k] * x[cj[k]];
+      int       k = k0 + lane;
+      for (; k + 3 * LPR < k1; k += 4 * LPR)
+      { // four entries in flight per lane (a level is a chain of dependent round trips: row -> entries -> x); same order of additions
+         const int    c0 = cj[k], c1 = cj[k + LPR], c2 = cj[k + 2 * LPR], c3 = cj[k + 3 * LPR];
+         const double a0 = v[k], a1 = v[k + LPR], a2 = v[k + 2 * LPR], a3 = v[k + 3 * LPR];
+         const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+         s += a0 * x0;
+         s += a1 * x1;
+         s += a2 * x2;
+         s += a3 * x3;
+      }
+      for (; k < k1; k += LPR) s += v[k] * x[cj[k]];
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
       if (lane == 0) x[i] += dinv[i] * (b[i] - s);
