@@ -196,6 +196,105 @@ __global__ __launch_bounds__(1024) void k_gs_levels_fused(int l0, int l1, int ba
    }
 }
 
+// The same run of small levels, software-pipelined.  A level is a chain of dependent round trips to memory (row ids and spans ->
+// entries -> x), and a run is a thousand levels of a few dozen rows: what it costs is that chain, not the arithmetic.  Here a
+// "pass" (the rows of a level the workgroup takes at once) goes through three stages, each one pass ahead of the next:
+//   A  row id and span                         (independent of x)
+//   B  the lane's first NPF entries, divisor, right-hand side   (independent of x)
+//   C  gather x, sum in entry order, update x  (needs every earlier level: the barrier)
+// so that between two barriers only the gather of x is waited for.  Same arithmetic, same order of additions.
+template <int LPR, int NPF>
+__global__ __launch_bounds__(1024) void k_gs_levels_pipe(int l0, int l1, int backward, const int *__restrict__ lvl_ptr,
+                                                         const int *__restrict__ perm, const int *__restrict__ rbeg,
+                                                         const int *__restrict__ rend, const int *__restrict__ cj, const double *__restrict__ v,
+                                                         const double *__restrict__ dinv, const double *__restrict__ b, double *x)
+{
+   extern __shared__ int slp[]; // lvl_ptr[l0 .. l1]
+   const int nl = l1 - l0, tid = threadIdx.x, lane = tid & (LPR - 1), q = tid / LPR;
+   constexpr int RP = 1024 / LPR; // rows per pass
+   for (int t = tid; t <= nl; t += 1024) slp[t] = lvl_ptr[l0 + t];
+   __syncthreads();
+   struct It { int s, p; }; // level of the run in sweep order, pass inside the level
+   auto level = [&](const It &it) { return backward ? nl - 1 - it.s : it.s; };
+   auto advance = [&](It it) {
+      if (it.s >= nl) return it; // past the end: stays there
+      const int L = level(it);
+      it.p++;
+      if (it.p * RP >= slp[L + 1] - slp[L]) { it.s++; it.p = 0; }
+      return it;
+   };
+   struct RowA { int i, k0, k1; bool has; };
+   struct RowB { int i, k0, k1; bool has; int c[NPF]; double a[NPF]; double d, rhs; };
+   auto stage_a = [&](const It &it) {
+      RowA r;
+      r.has = false; r.i = 0; r.k0 = 0; r.k1 = 0;
+      if (it.s < nl)
+      {
+         const int L = level(it), pos = slp[L] + it.p * RP + q;
+         if (pos < slp[L + 1])
+         {
+            r.has = true;
+            r.i   = perm[pos];
+            r.k0  = rbeg[pos];
+            r.k1  = rend[pos];
+         }
+      }
+      return r;
+   };
+   auto stage_b = [&](const RowA &ra) {
+      RowB r;
+      r.i = ra.i; r.k0 = ra.k0; r.k1 = ra.k1; r.has = ra.has; r.d = 0.0; r.rhs = 0.0;
+#pragma unroll
+      for (int u = 0; u < NPF; u++) { r.c[u] = -1; r.a[u] = 0.0; }
+      if (ra.has)
+      {
+#pragma unroll
+         for (int u = 0; u < NPF; u++)
+         {
+            const int k = ra.k0 + lane + u * LPR;
+            if (k < ra.k1) { r.c[u] = cj[k]; r.a[u] = v[k]; }
+         }
+         r.d   = dinv[ra.i];
+         r.rhs = b[ra.i];
+      }
+      return r;
+   };
+   It   itC = {0, 0}, itB = advance(itC), itA = advance(itB);
+   RowB cur = stage_b(stage_a(itC));
+   RowA nxa = stage_a(itB);
+   while (itC.s < nl)
+   {
+      const RowA nx2 = stage_a(itA); // two passes ahead
+      const RowB nxb = stage_b(nxa); // one pass ahead
+      if (cur.has)
+      {
+         double xs[NPF];
+#pragma unroll
+         for (int u = 0; u < NPF; u++) xs[u] = (cur.c[u] >= 0) ? x[cur.c[u]] : 0.0;
+         double sum = 0.0;
+#pragma unroll
+         for (int u = 0; u < NPF; u++)
+            if (cur.c[u] >= 0) sum += cur.a[u] * xs[u];
+         for (int k = cur.k0 + lane + NPF * LPR; k < cur.k1; k += LPR) sum += v[k] * x[cj[k]]; // rows longer than the prefetch
+#pragma unroll
+         for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+         if (lane == 0) x[cur.i] += cur.d * (cur.rhs - sum);
+      }
+      // (the lanes of a row group always agree on cur.has: the shuffles above stay matched)
+      const It nextC = itB;
+      if (nextC.s != itC.s)
+      { // the next pass belongs to another level: everything written so far must be visible
+         __threadfence_block();
+         __syncthreads();
+      }
+      itC = nextC;
+      itB = itA;
+      itA = advance(itA);
+      cur = nxb;
+      nxa = nx2;
+   }
+}
+
 // LPR lanes per row in the per-level launches, FL in the single-workgroup runs of small levels: there a level is a few
 // hundred rows at most and every round of rows is a chain of dependent loads (permutation, row pointer, entries, x), so
 // the narrower group -- four times the rows in flight -- wins over the wider reduction
@@ -213,8 +312,16 @@ static void gs_sweep_t(const DCsr &A, const GsPlan &p, const double *dinv, const
          k_gs_level<LPR><<<grid, 256, 0, STREAM>>>(first, count, p.perm.data(), p.rbeg.data(), p.rend.data(), A.col.data(), A.val.data(), dinv, b, x);
       }
       else
-         k_gs_levels_fused<FL><<<1, 1024, 0, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
-                                                      p.rbeg.data(), p.rend.data(), A.col.data(), A.val.data(), dinv, b, x);
+      {
+         static const int pipe = getenv("HDA_GS_PIPE") ? atoi(getenv("HDA_GS_PIPE")) : 1;
+         const size_t     lds  = sizeof(int) * (size_t)(sg.second - sg.first + 1);
+         if (pipe && lds <= 48 * 1024)
+            k_gs_levels_pipe<FL, (FL >= 8 ? 8 : 2)><<<1, 1024, lds, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
+                                                                          p.rbeg.data(), p.rend.data(), A.col.data(), A.val.data(), dinv, b, x);
+         else
+            k_gs_levels_fused<FL><<<1, 1024, 0, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
+                                                         p.rbeg.data(), p.rend.data(), A.col.data(), A.val.data(), dinv, b, x);
+      }
    }
 }
 
