@@ -215,6 +215,41 @@ def test_strength_pmis_irregular(orc, hd):
         assert np.array_equal(orc.pmis(Ao, so, 7, 2, 100), Ah.pmis(sh, 7, 2, 100))
 
 
+@pytest.mark.parametrize("avg", [18, 40, 90])
+def test_long_row_setup_kernels_bit_exact(orc, hd, avg):
+    """Rows of 18 / 40 / 90 entries on average (one of 400, one empty apart from its diagonal): the lanes-per-row forms of the
+    strength and l1-norm kernels (16 / 32 / 64 lanes; the row sums handed round in entry order), PMIS, the wavefront interpolation
+    kernel and the Galerkin product with its register sort, each bit for bit against the oracle on an operator with off-diagonals of
+    both signs."""
+    n = 1500
+    rng = np.random.default_rng(avg)
+    M = sp.random(n, n, density=avg / n, random_state=rng, format="lil")
+    M[3, rng.choice(n, size=400, replace=False)] = -0.25
+    M[9, :] = 0
+    M = M.tocsr()
+    M = (M + M.T) * 0.5
+    M.data = np.where(rng.random(M.nnz) < 0.7, -1.0, 0.3) * np.abs(M.data)
+    M = (M + M.T).tolil()
+    M.setdiag(np.asarray(abs(M.tocsr()).sum(axis=1)).ravel() * 0.6 + 0.5)
+    M = M.tocsr()
+    M.sort_indices()
+    Ao, Ah = both(orc, hd, M)
+    for opt in (1, 4):
+        assert np.array_equal(Ah.l1_norms(opt), orc.l1_norms(Ao, opt)), opt
+    for theta, mrs in ((0.25, 0.9), (0.6, 1.0)):
+        so, sh = orc.strength(Ao, theta, mrs), Ah.strength(theta, mrs)
+        assert np.array_equal(so, sh)
+    cf = orc.pmis(Ao, so)
+    assert np.array_equal(cf, Ah.pmis(sh))
+    Po = orc.interp_extpi(Ao, so, cf, 4, 0.0)
+    Ph = Ah.interp_extpi(sh, cf, 4, 0.0)
+    rp, cj, v = Ph.download()
+    assert np.array_equal(rp, Po.rowptr) and np.array_equal(cj, Po.col) and np.array_equal(v, Po.val)
+    Aco = orc.rap(Ao, Po)
+    rp, cj, v = Ah.rap(Ph).download()
+    assert np.array_equal(rp, Aco.rowptr) and np.array_equal(cj, Aco.col) and np.array_equal(v, Aco.val)
+
+
 # ------------------------------------------------------- K5 interpolation, K6 RAP
 
 @pytest.mark.parametrize("shape,pmax,tf", [((10, 10, 10), 4, 0.0), ((16, 9, 12), 4, 0.0),
