@@ -238,6 +238,32 @@ def test_mgr_yaml_and_create(hd):
     L.HYPREDRV_ErrorCodeClear()
 
 
+def test_mgr_nested_krylov_and_cycle_yaml(hd):
+    """Nested Krylov blocks inside MGR components (reference src/internal/krylov.c:360-414, mgr.c:1453-1470) and the cycle strings
+    (mgr.c:614-675): parsed and turned into solver handles without a GPU; what is not built is refused by name."""
+    L = hd.lib()
+    nested = (EX3_MGR.replace("prolongation_type: jacobi", "prolongation_type: jacobi\n        f_relaxation:\n          gmres:\n            max_iter: 5\n"
+                              "            relative_tol: 1e-15\n            preconditioner:\n              amg:\n                max_iter: 1\n"
+                              "                coarsening:\n                  max_levels: 1")
+              .replace("coarsest_level: amg", "coarsest_level:\n      fgmres:\n        max_iter: 2\n        relative_tol: 0.0\n        preconditioner: amg"))
+    for text in (nested, nested + "    cycle: w(1,1)\n", EX3_MGR + "    cycle: v(0,1)\n", EX3_MGR + "    cycle: 2\n"):
+        h = hd.Hypredrv(text)
+        assert L.HYPREDRV_LinearSystemSetInterleavedDofmap(h.h, 5, 3) == 0
+        assert L.HYPREDRV_PreconCreate(h.h) == 0, L.HYPREDRV_AMD_LastErrorMessage().decode()
+        assert L.HYPREDRV_PreconDestroy(h.h) == 0
+        h.close()
+    with pytest.raises(hd.HypredrvError, match="not implemented on MI355X"):  # an MGR nested inside the nested solver
+        hd.Hypredrv(nested.replace("preconditioner:\n              amg:\n                max_iter: 1\n                coarsening:\n                  max_levels: 1",
+                                   "preconditioner:\n              mgr:\n                max_iter: 1"))
+    L.HYPREDRV_ErrorCodeClear()
+    with pytest.raises(hd.HypredrvError, match="unknown nested preconditioner"):
+        hd.Hypredrv(nested.replace("preconditioner: amg", "preconditioner: multigrid"))
+    L.HYPREDRV_ErrorCodeClear()
+    with pytest.raises(hd.HypredrvError):
+        hd.Hypredrv(EX3_MGR + "    cycle: x(1,1)\n")
+    L.HYPREDRV_ErrorCodeClear()
+
+
 REF_EXAMPLES = "/root/reference/examples"
 
 
