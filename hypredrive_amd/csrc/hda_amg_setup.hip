@@ -2778,6 +2778,7 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
    if (zero_guess && (swaps0 & 1)) { cur = levels[0].u2.data(); alt = x; }
    else { cur = x; alt = levels[0].u2.data(); }
    const double *f = b;
+   bool first_sweep_done = false; // the level's zero-guess Jacobi sweep u = dinv .* f came out of the restriction above it
    for (int l = 0; l < L - 1; l++)
    {
       const DCsr &A  = level_A(l);
@@ -2786,12 +2787,19 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
       if (zg && prm.sweeps_down == 0) fill(A.nrows, 0.0, cur);
       for (int s = 0; s < prm.sweeps_down; s++)
       {
-         relax(l, prm.relax_down, lv.dinv_down.data(), f, cur, alt, zg, -1);
+         if (!(s == 0 && first_sweep_done)) relax(l, prm.relax_down, lv.dinv_down.data(), f, cur, alt, zg, -1);
          zg = false;
       }
       residual(A, cur, f, lv.t.data(), &level_hA(l));
       AmgLevel &nx = levels[l + 1];
-      spmv(lv.R, 1.0, lv.t.data(), 0.0, nullptr, nx.f.data(), &lv.hR);
+      // the next level starts from a zero guess: a Jacobi-type first sweep there is u = dinv .* f, one multiplication per row that
+      // the restriction kernel can do on the value it has just computed (one launch and one pass over f and dinv less per level)
+      first_sweep_done = false;
+      static const bool fuse_first = !(getenv("HDA_FUSE_FIRST_SWEEP") && atoi(getenv("HDA_FUSE_FIRST_SWEEP")) == 0);
+      if (fuse_first && l + 1 < L - 1 && prm.sweeps_down > 0 && is_jacobi_type(prm.relax_down) && !nx.ilu)
+         first_sweep_done = spmv_with_scaled_copy(lv.R, lv.t.data(), nx.f.data(), nx.dinv_down.data(), nx.u.data(), &lv.hR);
+      else
+         spmv(lv.R, 1.0, lv.t.data(), 0.0, nullptr, nx.f.data(), &lv.hR);
       sol[l] = cur;
       f      = nx.f.data();
       if (l + 1 < L - 1) { cur = nx.u.data(); alt = nx.u2.data(); }

@@ -20,6 +20,9 @@ struct HaloPlan; // hda_dist.h
 void spmv(const DCsr &A, double alpha, const double *x, double beta, const double *y_in,
           double *y_out, const HaloPlan *halo = nullptr);
 // y = A*x and block partials of <y, w> into slot (fused dot, K9)
+// y = A x and, when the operator's kernel can do it in the same pass (returns true), y2 = dinv2 .* y: the zero-guess Jacobi sweep
+// of the next coarser level fused into the restriction.  false: only y was written.
+bool spmv_with_scaled_copy(const DCsr &A, const double *x, double *y, const double *dinv2, double *y2, const HaloPlan *halo = nullptr);
 void spmv_dot(const DCsr &A, const double *x, double *y, const double *w, int slot, const HaloPlan *halo = nullptr);
 // out = b - A*x
 void residual(const DCsr &A, const double *x, const double *b, double *out, const HaloPlan *halo = nullptr);

@@ -380,8 +380,10 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int nchunks, const int *__r
                                                      const double *__restrict__ b, const double *__restrict__ dinv,
                                                      const double *__restrict__ w, double *out,
                                                      double *__restrict__ partial, const unsigned char *__restrict__ code,
-                                                     const double *__restrict__ dval, int nown)
-{
+                                                     const double *__restrict__ dval, int nown, const double *__restrict__ dinv2,
+                                                     double *__restrict__ out2)
+{ // out2 (MODE_PLAIN only): a second result out2 = dinv2 .* out -- the zero-guess Jacobi sweep of the next coarser level rides
+  // on the restriction that produces its right-hand side
    extern __shared__ double prod[];
    __shared__ double sdict[VC ? 256 : 1];
    const int tid  = threadIdx.x;
@@ -455,6 +457,7 @@ for (; k + 768 < k1; k += 1024)
             {
                o0 = (beta == 0.0) ? alpha * sum : alpha * sum + beta * yin[r];
                if (DOT) acc += o0 * w[r];
+               if (out2) out2[r] = dinv2[r] * o0;
             }
             else if (MODE == MODE_RESID) o0 = b[r] - sum;
             else
@@ -1532,6 +1535,15 @@ static int overlap_grid()
 }
 
 // nown < 0: the whole product.  nown >= 0: SPLIT -- entries with ghost columns (>= nown) are left to k_offd_fix
+// y = A x with a second result y2 = dinv2 .* y from the same kernel when the operator runs on the streaming kernel (else the
+// caller does the scaling itself): set by spmv_with_scaled_copy for the duration of one spmv() call
+struct SpmvEpilogue {
+   const double *dinv2 = nullptr;
+   double       *out2  = nullptr;
+   bool          done  = false;
+};
+static SpmvEpilogue g_epilogue;
+
 template <int MODE, bool DOT>
 static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, double beta,
                         const double *yin, const double *b, const double *dinv, const double *w,
@@ -1592,9 +1604,18 @@ static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
       }
       const int    grid = DOT ? gmax : std::min(gmax, ((A.nchunks + 7) / 8) * 8);
       const size_t lds  = sizeof(double) * (size_t)(kChunk + A.maxrow);
+      // a scaled second result asked for by spmv_with_scaled_copy: taken here (whole products only, not the owned-column half)
+      const double *epi_d = nullptr;
+      double       *epi_o = nullptr;
+      if (MODE == MODE_PLAIN && !DOT && !split && g_epilogue.out2)
+      {
+         epi_d = g_epilogue.dinv2;
+         epi_o = g_epilogue.out2;
+         g_epilogue.done = true;
+      }
 #define HDA_STREAM(VCF, SPF, CODE, DICT)                                                                                                  \
    k_spmv_stream<MODE, DOT, VCF, SPF><<<grid, 256, lds, STREAM>>>(A.nchunks, A.chunk_row.data(), A.rowptr.data(), A.col.data(), A.val.data(), x, \
-                                                                  alpha, beta, yin, b, dinv, w, out, partial, CODE, DICT, nown)
+                                                                  alpha, beta, yin, b, dinv, w, out, partial, CODE, DICT, nown, epi_d, epi_o)
       if (A.coded == 2)
       {
          if (split) HDA_STREAM(true, true, A.code.data(), A.dict_val.data());
@@ -1774,6 +1795,14 @@ static void launch_spmv(const DCsr &A, const HaloPlan *halo, const double *x, do
 void spmv(const DCsr &A, double alpha, const double *x, double beta, const double *y_in, double *y_out, const HaloPlan *halo)
 {
    launch_spmv<MODE_PLAIN, false>(A, halo, x, alpha, beta, y_in, nullptr, nullptr, nullptr, y_out, nullptr);
+}
+bool spmv_with_scaled_copy(const DCsr &A, const double *x, double *y, const double *dinv2, double *y2, const HaloPlan *halo)
+{
+   g_epilogue = SpmvEpilogue{dinv2, y2, false};
+   launch_spmv<MODE_PLAIN, false>(A, halo, x, 1.0, 0.0, nullptr, nullptr, nullptr, nullptr, y, nullptr);
+   const bool done = g_epilogue.done;
+   g_epilogue      = SpmvEpilogue{};
+   return done;
 }
 void spmv_dot(const DCsr &A, const double *x, double *y, const double *w, int slot, const HaloPlan *halo)
 {
