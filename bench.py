@@ -111,26 +111,54 @@ def spawn_ranks(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
+    line, errs = None, []
     for ln in r.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
+        elif ln.startswith("{") and '"error"' in ln and '"stage"' in ln:
+            errs.append(ln)
         else:
             print(ln, file=sys.stderr)
     if line:
         print(line, flush=True)
+    elif errs:
+        print(errs[0], flush=True)  # one line: the first rank that said where joining RCCL failed
     return r.returncode if (r.returncode or line) else 1
 
 
 # ------------------------------------------------------------------------------------------- one rank
 
+def error_line(stage, rank, msg):
+    """A first multi-GPU run that cannot join RCCL says where in ONE JSON line on stdout (stage: uid | init | halo_comm | selftest |
+    devices | peer | fallback | timeout:<stage>), then the process exits non-zero."""
+    print(json.dumps({"error": str(msg)[:600], "stage": stage, "rank": rank}), flush=True)
+
+
 class World:
     """torch.distributed (gloo) only carries the launcher's side: barriers and the reductions of the report."""
 
     def __init__(self):
+        import threading
         from hypredrive_amd import dist as hdist
         self.hdist = hdist
-        self.rank, self.size = hdist.init()
+        rank0 = int(os.environ.get("RANK", "0"))
+        limit = float(os.environ.get("HDA_BENCH_INIT_TIMEOUT", "300"))
+
+        def watchdog():  # a collective that never returns (a rank missing, a hung ncclCommInitRank) must not eat the driver's whole slot
+            error_line("timeout:" + str(hdist._keep.get("stage", "rendezvous")), rank0, f"joining the ranks did not finish within {limit:.0f} s")
+            os._exit(3)
+
+        t = threading.Timer(limit, watchdog)
+        t.daemon = True
+        t.start()
+        try:
+            # strict: N ranks with N GPUs on anything but RCCL is an error, not a measurement (no silent staged fallback)
+            self.rank, self.size = hdist.init(strict=not os.environ.get("HDA_TRANSPORT"))
+        except hdist.TransportError as e:
+            error_line(e.stage, e.rank, e)
+            raise SystemExit(2)
+        finally:
+            t.cancel()
         self.dist = None
         if self.size > 1:
             import torch
@@ -162,7 +190,8 @@ def run(args):
     transport = hh._lib.comm_name()
     if w.size > 1 and ndev >= w.size and transport != "rccl" and not os.environ.get("HDA_TRANSPORT"):
         # one GPU per rank is there: a host-staged transport would be a silent fallback, not a measurement
-        raise SystemExit(f"bench.py: {w.size} ranks with {ndev} visible GPUs must run on RCCL, transport is '{transport}'")
+        error_line("fallback", w.rank, f"{w.size} ranks with {ndev} visible GPUs must run on RCCL, transport is '{transport}'")
+        raise SystemExit(2)
     aniso = args.workload == "aniso"
     if aniso:
         # a heterogeneous anisotropic reservoir operator (hypredrive_amd/synthetic.py; SPE10 itself is unreachable offline), the
@@ -279,6 +308,9 @@ def run(args):
                        "timed": "K steps between barrier + device sync; includes the reference's untimed r0 / final-residual evaluations "
                                 "(solve_timer_ms is the reference's 'solve' timer alone); setup_ms is the 'prec' timer"},
             "ranks_seen": ranks_seen, "transport": transport,
+            # levels of the hierarchy cut into row blocks; the rest is the replicated tail every rank cycles redundantly (a level goes
+            # there once it has fewer than HDA_REPLICATE_ROWS_PER_RANK = 50 000 rows per rank, at least 100 000 in all)
+            "partitioned_levels": hh.load().hda_amd_partitioned_levels(h.h), "levels_total": hh.load().hda_amd_hierarchy_levels(h.h),
             # rank-to-rank operations rank 0 issued per PCG iteration (V-cycle included): all-reduces (<s,p>; <r,r> + <r,z> fused into one
             # two-double reduction; restricted residual of the replicated tail) and neighbour halo exchanges
             "allreduces_per_iter": cs["allreduce"] * per_it, "halo_exchanges_per_iter": cs["exchange"] * per_it,
@@ -383,6 +415,61 @@ def plain_csr_child(args):
     return {"error": f"child exited {r.returncode}: {r.stderr[-500:]}"}
 
 
+LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+              "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+              "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCHELASTIC_ERROR_FILE")
+
+
+def child_bench(extra, nranks, timeout_s):
+    """One more bench in a CHILD launch (never a re-exec: this process has used the GPU), outside this job's rendezvous; returns
+    its JSON line as a dict, or {"error": ...}.  nranks > 1: `python -m torch.distributed.run` like the driver's own launch."""
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    me = os.path.abspath(__file__)
+    cmd = [sys.executable, me] if nranks == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+                                                    "--master-addr", "127.0.0.1", "--master-port", str(free_port()), me]
+    cmd += ["--gpus", str(nranks), "--child", "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr"] + extra
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"child launch did not finish within {timeout_s} s"}
+    err = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            return json.loads(ln)
+        if ln.startswith("{") and '"error"' in ln and err is None:
+            err = json.loads(ln)
+    return err or {"error": f"child exited {r.returncode}: {r.stderr[-400:]}"}
+
+
+def multi_extras(args, out):
+    """N > 1, rank 0, after the timed weak-scaling run: the OTHER curve and the same-node N = 1 point, so that one driver invocation
+    per N yields both series BASELINE.md's >= 6x target can be read from (reference scripts/node_scaling.sh:1275-1292: the fixed-size
+    series 256^3 at P = 1 .. 2x2x2, partition examples/src/C_laplacian/laplacian.c:561-582).
+      strong_<n>:   the global <n>^3 problem (= one rank's block of the weak run) cut into N blocks, child launch of N ranks
+      n1_reference: <n>^3 on ONE GPU of this node (rank 0's), same run, same code
+    Failures of either child are recorded in their object and never touch the headline."""
+    n, N = args.n, out["n_gpus"]
+    base = ["--grid", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    keep = ("ms_per_step", "value", "iters", "converged", "setup_ms", "solve_timer_ms", "allreduces_per_iter", "halo_exchanges_per_iter",
+            "collectives_per_iter", "halo_exchanges_overlapped_per_iter", "partitioned_levels", "levels_total", "transport", "ranks_seen")
+    st = child_bench(base + ["--strong"], N, 900)
+    strong = {k: st.get(k) for k in keep if k in st} if "error" not in st else dict(st)
+    strong["what"] = (f"child launch of {N} ranks: lap7 {n}^3 GLOBAL cut into {N} blocks (strong scaling), same API path and timing as the headline")
+    if "config" in st:
+        strong["parallelism"] = st["config"].get("parallelism")
+    n1 = child_bench(base, 1, 900)
+    ref = {k: n1.get(k) for k in keep if k in n1} if "error" not in n1 else dict(n1)
+    ref["what"] = f"child run on ONE GPU of this node (rank 0's): lap7 {n}^3, the N = 1 point of both series, same run"
+    out[f"strong_{n}"] = strong
+    out["n1_reference"] = ref
+    if ref.get("value") and out.get("value") and out["scaling"] == "weak":
+        out["speedup_weak_dofs"] = out["value"] / ref["value"]  # DOF/s at N GPUs (N x the rows) over DOF/s at 1 GPU: ideal = N
+    if ref.get("ms_per_step") and strong.get("ms_per_step"):
+        out["speedup_strong"] = ref["ms_per_step"] / strong["ms_per_step"]  # same problem, N GPUs over 1: ideal = N
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -396,11 +483,14 @@ def main():
                     "256^3 takes about 2 minutes of host time, most of it the oracle's setup)")
     ap.add_argument("--strong", action="store_true", help="N > 1: --grid is the GLOBAL problem, cut into N blocks (fixed-size series). Default is "
                     "weak scaling: --grid is the block of every rank (global grid = block x rank grid; 256 on 8 GPUs = "
-                    "BASELINE config 3, 512^3)")
+                    "BASELINE config 3, 512^3); the weak line of N > 1 also carries the strong series' point (strong_<grid>) and the "
+                    "same-node N = 1 point (n1_reference) from child launches")
     ap.add_argument("--weak", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-plain-csr", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the strong_<grid> and n1_reference child launches")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # a launch made by another bench.py: no further children
     args = ap.parse_args()
     if args.n <= 0:
         args.n = 128 if args.workload == "aniso" else 256
@@ -411,6 +501,11 @@ def main():
         print(f"bench.py: launcher started {world} ranks, --gpus says {args.gpus}: using {world}", file=sys.stderr)
     out = run(args)
     if out is not None:
+        if out["n_gpus"] > 1 and not (args.child or args.no_extras or args.strong or args.workload != "lap7"):
+            try:
+                multi_extras(args, out)
+            except Exception as e:  # noqa: BLE001 - the headline is measured: extras must not lose it
+                out["extras_error"] = repr(e)[:400]
         print(json.dumps(out), flush=True)
 
 

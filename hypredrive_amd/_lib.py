@@ -75,6 +75,7 @@ SYMBOLS = [
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
+    "hda_thread_ranks_lap7", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
 ]
 
 
@@ -554,6 +555,31 @@ def comm_stats(reset=False):
     v = (C.c_double * 5)()
     load().hda_comm_stats(v, 1 if reset else 0)
     return dict(allreduce=v[0], exchange=v[1], allreduce_doubles=v[2], exchange_doubles=v[3], overlapped=v[4])
+
+
+def thread_ranks_lap7(nranks, n, P, yaml, nsolves=1, want_x=False):
+    """`nranks` ranks of a row partition as threads of this process (hda_thread_ranks.hip; test seam): AMG-Krylov on the
+    generator's 7-pt Laplacian, global grid n, rank grid P.  Returns the dict of one rank-0 result (+ "x" in block numbering)."""
+    L = load()
+    out = (C.c_double * 16)()
+    err = C.create_string_buffer(4096)
+    N = int(n[0]) * int(n[1]) * int(n[2])
+    x = np.zeros(N) if want_x else None
+    L.hda_thread_ranks_lap7.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int, C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.c_char_p, C.c_int]
+    rc = L.hda_thread_ranks_lap7(int(nranks), (C.c_int * 3)(*n), (C.c_int * 3)(*P), yaml.encode(), int(nsolves), out,
+                                 x.ctypes.data_as(C.POINTER(C.c_double)) if want_x else None, err, len(err))
+    if rc != 0:
+        raise LibraryError(f"hda_thread_ranks_lap7 failed ({rc}): {err.value.decode()}")
+    keys = ("iters", "converged", "final_rel", "norm", "l1", "linf", "allreduce", "exchange", "overlapped", "allreduce_doubles",
+            "exchange_doubles", "vcycles", "partitioned_levels", "iters_spread", "world")
+    res = {k: out[i] for i, k in enumerate(keys)}
+    for k in ("iters", "vcycles", "partitioned_levels", "iters_spread", "world"):
+        res[k] = int(res[k])
+    res["converged"] = bool(res["converged"])
+    if want_x:
+        res["x"] = x
+    return res
 
 
 def comm_name():

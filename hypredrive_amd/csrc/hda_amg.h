@@ -54,6 +54,7 @@ struct GsPlan {
    DArray<int>                      perm;      // rows grouped by level, ascending inside a level
    mutable const int               *span_rp = nullptr; // the row pointer array the spans below were read from (a reused hierarchy is
    mutable int                      span_nnz = -1;     // applied with the level-0 matrix of the call: spans follow it, gs_sweep checks)
+   mutable unsigned long long       span_gen = 0;      // DCsr::gen of that matrix (address + size alone can repeat after a re-assembly)
    mutable DArray<int>              rbeg, rend; // first / past-the-end entry of the row at every sorted position (rowptr[perm[q]], rowptr[perm[q] + 1]):
                                                // read coalesced with perm, so a sweep does not chase row id -> row pointer -> entries
    DArray<int>                      d_lvl_ptr; // device copy of lvl_ptr
@@ -88,6 +89,10 @@ void ilu_solve(Ilu &F, const DCsr &A, const HaloPlan *halo, const double *b, dou
 
 struct AmgLevel {
    DCsr           A, P, R;
+   // row partitions: the P rows of this rank's GHOST fine points (the ghost slots of hA, in their order; columns as P's), so that
+   // the prolongation updates the ghost copies of the iterate too and the first post-smoothing sweep needs no exchange
+   DCsr           Pg;
+   bool           pg_ready = false; // set by the setup on EVERY rank or on none (the exchange it saves is a collective)
    GsPlan         gs;
    std::unique_ptr<Ilu> ilu; // complex smoother of this level, if any
    // Chebyshev smoother (relax type 16): D^-1/2 scaling, polynomial coefficients, work vectors
@@ -139,6 +144,9 @@ class Amg {
    int    reordered_levels = 0;
    size_t vec_len0() const { return levels.empty() ? 0 : levels[0].ext; }
    bool   distributed() const { return dist; }
+   // row-partitioned runs: levels whose operator is cut into row blocks (the rest is the replicated tail every rank cycles redundantly)
+   int    partitioned_levels() const { return dist ? (int)levels.size() - (tail ? 1 : 0) : 0; }
+   int    total_levels() const { return (int)levels.size() + (tail ? tail->num_levels() - 1 : 0); } // partitioned levels + replicated tail
    // HYPRE_BoomerAMGSolve as a preconditioner (precon.c:108): one V(nu1,nu2) from x = 0.
    // dot_slot >= 0: also emit block partials of <b, x> (fuses PCG's <r, z>).
    void apply(const double *b, double *x, int dot_slot = -1);
@@ -162,7 +170,8 @@ class Amg {
    void build_hierarchy(const DCsr &A);
    void build_smoother_data(int l); // divisors (and Gauss-Seidel level sets) of level l on the matrix the cycle uses
    void build_cheby(int l);         // eigenvalue estimate and polynomial of the Chebyshev smoother
-   void cheby_sweep(int l, const double *b, double *u, bool zero_guess);
+   void cheby_sweep(int l, const double *b, double *u, bool zero_guess, bool ghosts_fresh = false);
+   bool ghosts_fresh_ = false; // cycle -> relax: the next sweep's input has fresh ghost copies (AmgLevel::Pg)
    void coarse_solve(const double *f, double *u);
    const HaloPlan &level_hA(int l) const { return (l == 0 && hA0) ? *hA0 : levels[l].hA; }
    const DCsr           *A0 = nullptr;

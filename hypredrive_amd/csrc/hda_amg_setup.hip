@@ -2107,6 +2107,7 @@ void Amg::build_smoother_data(int l)
    // part of the setup, not of the first solve
    spmv_prepare(Al);
    if (!last) { spmv_prepare(lv.P); spmv_prepare(lv.R); }
+   if (!last && lv.pg_ready && lv.Pg.nrows) spmv_prepare(lv.Pg);
 }
 
 __global__ __launch_bounds__(256) void k_cmark(int n, const int *__restrict__ cf, int *__restrict__ m);
@@ -2266,6 +2267,18 @@ __global__ __launch_bounds__(256) void k_cmark(int n, const int *__restrict__ cf
    if (i < n) m[i] = (cf[i] == 1);
 }
 
+// Row partitions: a level with this many GLOBAL rows or fewer is handed to the replicated tail (every rank cycles it redundantly
+// after one all-reduce of the restricted residual).  The criterion is rows PER RANK -- once a rank's block of a level is so small
+// that its kernels are shorter than a neighbour exchange, partitioning it only adds latency (hypre's analogue is seq_amg_th,
+// reference src/internal/amg.c:151,880): HDA_REPLICATE_ROWS_PER_RANK (default 50 000) x ranks, at least 100 000.
+// HDA_REPLICATE_ROWS, when set, is the global threshold itself (the tests move the split with it; 0 = partition everything).
+static long long replicate_rows(int nranks)
+{
+   if (const char *g = getenv("HDA_REPLICATE_ROWS")) return atoll(g);
+   const long long per = getenv("HDA_REPLICATE_ROWS_PER_RANK") ? atoll(getenv("HDA_REPLICATE_ROWS_PER_RANK")) : 50000;
+   return std::max(100000LL, per * std::max(nranks, 1));
+}
+
 void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<long long> &part0,
                      const std::vector<long long> &ghost_gids0)
 {
@@ -2309,7 +2322,7 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
    // cycle): keep them whole on every rank instead.  The restricted residual of the first such
    // level is summed into a replicated vector (one small all-reduce) and the rest of the
    // V-cycle runs redundantly on the replicated matrices this setup already holds.
-   static const long long rep_rows = getenv("HDA_REPLICATE_ROWS") ? atoll(getenv("HDA_REPLICATE_ROWS")) : 100000;
+   const long long rep_rows = replicate_rows(cm.size);
    int first_rep = L - 1;
    for (int l = 1; l < L; l++)
       if (level_A(l).nrows <= rep_rows) { first_rep = l; break; }
@@ -2641,7 +2654,7 @@ void Amg::build_cheby(int l)
 }
 
 // one Chebyshev sweep in place: u += D^-1/2 q(.) D^-1/2 (b - A u)
-void Amg::cheby_sweep(int l, const double *b, double *u, bool zero_guess)
+void Amg::cheby_sweep(int l, const double *b, double *u, bool zero_guess, bool ghosts_fresh)
 {
    const DCsr &A  = level_A(l);
    AmgLevel   &lv = levels[(size_t)l];
@@ -2655,7 +2668,7 @@ void Amg::cheby_sweep(int l, const double *b, double *u, bool zero_guess)
    }
    else
    {
-      halo_exchange(level_hA(l), u);
+      if (!ghosts_fresh) halo_exchange(level_hA(l), u);
       residual(A, u, b, r);
       k_cheb_scale<<<g, 256, 0, STREAM>>>(n, lv.cheb_ds.data(), r);
    }
@@ -2676,13 +2689,17 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
                 bool zero_guess, int dot_slot)
 {
    const DCsr &A = level_A(l);
+   // row partitions: the ghost copies of cur are already those of the owners (the prolongation updated them, AmgLevel::Pg):
+   // the first product of this sweep runs without its halo exchange
+   const bool fresh = ghosts_fresh_;
+   ghosts_fresh_    = false;
    if (levels[(size_t)l].ilu)
    { // complex smoother instead of the relaxation: max_iter iterations cur += M^-1 (b - A cur), in place
       AmgLevel &lv = levels[(size_t)l];
       for (int it = 0; it < lv.ilu->prm.max_iter; it++)
       {
          if (zero_guess && it == 0) { lv.ilu->apply(b, cur); continue; } // b - A*0 = b exactly
-         halo_exchange(level_hA(l), cur);
+         if (!(fresh && it == 0)) halo_exchange(level_hA(l), cur);
          residual(A, cur, b, lv.ilu_r.data());
          lv.ilu->apply(lv.ilu_r.data(), lv.ilu_c.data());
          axpy(A.nrows, 1.0, lv.ilu_c.data(), cur);
@@ -2692,14 +2709,14 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
    }
    if (type == 16)
    {
-      cheby_sweep(l, b, cur, zero_guess);
+      cheby_sweep(l, b, cur, zero_guess, fresh);
       if (dot_slot >= 0) dot(A.nrows, b, cur, dot_slot);
       return;
    }
    if (is_gs_type(type))
    { // in place; ghosts frozen for the sweep
       if (zero_guess) fill((int)levels[(size_t)l].ext, 0.0, cur);
-      else halo_exchange(level_hA(l), cur);
+      else if (!fresh) halo_exchange(level_hA(l), cur);
       const GsPlan &g = levels[(size_t)l].gs;
       if (type == 3 || type == 13) gs_sweep(A, g, dinv, b, cur, true);
       else if (type == 4 || type == 14) gs_sweep(A, g, dinv, b, cur, false);
@@ -2719,7 +2736,7 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
    }
    else
    {
-      jacobi(A, dinv, b, cur, alt, dot_slot, &level_hA(l)); // ghost refresh of cur runs under the sweep's owned-column part
+      jacobi(A, dinv, b, cur, alt, dot_slot, fresh ? nullptr : &level_hA(l)); // ghost refresh of cur runs under the sweep's owned-column part
       std::swap(cur, alt);
    }
 }
@@ -2830,11 +2847,18 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
       else a = (c == lv.u.data()) ? lv.u2.data() : lv.u.data();
       const double *fl = (l == 0) ? b : lv.f.data();
       spmv(lv.P, 1.0, sol[l + 1], 1.0, c, c, &lv.hP);
+      if (dist && lv.pg_ready)
+      { // the ghost copies of the iterate take the correction of their own P rows (the coarse ghosts have just been refreshed)
+         const int nown = level_A(l).nrows;
+         if (lv.Pg.nrows) spmv(lv.Pg, 1.0, sol[l + 1], 1.0, c + nown, c + nown);
+         ghosts_fresh_ = true;
+      }
       for (int s = 0; s < prm.sweeps_up; s++)
       {
          const bool last = (l == 0) && (s == prm.sweeps_up - 1);
          relax(l, prm.relax_up, lv.dinv_up.data(), fl, c, a, false, last ? dot_slot : -1);
       }
+      ghosts_fresh_ = false; // (no post-smoothing sweep consumed it)
       sol[l] = c;
    }
    if (sol[0] != x) copy(n0, sol[0], x);
@@ -3622,14 +3646,24 @@ void halo_reverse_add(const HaloPlan &h, double *x_ext)
    }
 }
 
+__global__ __launch_bounds__(256) void k_remap_ghost_cols(long nnz, int nown, const int *__restrict__ map, int *__restrict__ cj)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256)
+      if (cj[k] >= nown) cj[k] = map[cj[k] - nown];
+}
+
 void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<long long> &part0,
                                  const std::vector<long long> &ghost_gids0)
 {
    Comm &cm = Comm::world();
    HDA_REQUIRE(prm.coarsen_type == 8 && (prm.interp_type == 6 || prm.interp_type == 17) && prm.num_functions <= 1,
                "partitioned setup: scalar PMIS + extended+i only");
-   static const long long rep_rows = getenv("HDA_REPLICATE_ROWS") ? atoll(getenv("HDA_REPLICATE_ROWS")) : 100000;
+   const long long rep_rows = replicate_rows(cm.size);
    const bool verbose = getenv("HDA_VERBOSE") != nullptr;
+   // HDA_GHOST_PROLONG=0: the prolongation leaves ghost copies alone and the post-smoothing sweep refreshes them (4 exchanges per
+   // level and cycle instead of 3).  Off under HDA_DIST_CHECK, which compares P entry by entry with the replicated setup's.
+   const bool ghost_prolong = !(getenv("HDA_GHOST_PROLONG") && atoi(getenv("HDA_GHOST_PROLONG")) == 0) &&
+                              !(getenv("HDA_DIST_CHECK") && *getenv("HDA_DIST_CHECK") && *getenv("HDA_DIST_CHECK") != '0');
    auto tick = [&]() {
       if (verbose) Context::get().sync();
       return std::chrono::steady_clock::now();
@@ -3722,7 +3756,7 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
       AmgLevel              &lv = levels[(size_t)l];
       std::vector<long long> ghostc;
       localize_cols(Pown, C1, lv.P, ghostc);
-      lv.hP = make_halo_plan(ncl, partc, ghostc);
+      // (the halo plan of coarse vectors, lv.hP, is made below once the P rows of the ghost fine points are known: it may be widened)
       // ---- R: rows of P^T for the owned coarse points = local transpose + entries of fine rows owned elsewhere
       std::vector<Rec> recv_t;
       {
@@ -3771,6 +3805,43 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
          fetch_rows(hl.send_total, hl.send_idx.data(), hl.send_counts, (int)ghosts.size(), hl.recv_counts, Pown.rowptr.data(), gcolP.data(),
                     Pown.val.data(), H);
          gcolP.release();
+         // ---- ghost rows of P (C1 of SURVEY 2.4, one exchange less per level and cycle): with the P rows of this rank's ghost
+         // fine points at hand, the prolongation x += P e can update the ghost copies of x as well (their old values are the ones
+         // the residual's exchange brought in, and x has not changed since), so the first post-smoothing sweep finds fresh ghosts
+         // and needs no exchange of its own.  Price: the coarse halo grows by the coarse points only those rows name.
+         if (ghost_prolong)
+         {
+            std::vector<long long> wide = ghostc;
+            for (long long c : H.gcol)
+               if (c < clo || c >= chi) wide.push_back(c);
+            std::sort(wide.begin(), wide.end());
+            wide.erase(std::unique(wide.begin(), wide.end()), wide.end());
+            if (wide.size() != ghostc.size())
+            { // P's ghost columns move to their slots in the wider list
+               std::vector<int> mp(std::max<size_t>(ghostc.size(), 1), 0);
+               for (size_t k = 0; k < ghostc.size(); k++) mp[k] = ncl + (int)(std::lower_bound(wide.begin(), wide.end(), ghostc[k]) - wide.begin());
+               DArray<int> dmp;
+               dmp.upload(mp.data(), mp.size());
+               if (lv.P.nnz) k_remap_ghost_cols<<<std::min(ceil_div(lv.P.nnz, 256), 1 << 16), 256, 0, STREAM>>>(lv.P.nnz, ncl, dmp.data(), lv.P.col.data());
+               lv.P.ncols = ncl + (int)wide.size();
+               Context::get().sync();
+            }
+            HostRows G;
+            G.rp = H.rp;
+            G.row.resize(ghosts.size());
+            for (size_t g = 0; g < ghosts.size(); g++) G.row[g] = (int)g;
+            G.col.resize(H.gcol.size());
+            for (size_t k = 0; k < H.gcol.size(); k++)
+            {
+               const long long c = H.gcol[k];
+               G.col[k] = (c >= clo && c < chi) ? (int)(c - clo) : ncl + (int)(std::lower_bound(wide.begin(), wide.end(), c) - wide.begin());
+            }
+            G.val = H.val;
+            assemble_csr((int)ghosts.size(), ncl + (int)wide.size(), 0, DCsr(), nullptr, G, lv.Pg);
+            lv.pg_ready = true;
+            ghostc      = std::move(wide);
+         }
+         lv.hP = make_halo_plan(ncl, partc, ghostc);
          // coarse space C2 = C1 U columns of the fetched rows
          IdSpace C2;
          {

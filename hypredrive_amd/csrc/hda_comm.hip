@@ -3,14 +3,16 @@
 
 #include <dlfcn.h>
 
+#include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 namespace hda {
 
 #define STREAM (Context::get().stream)
 
-static std::unique_ptr<Comm> g_world;
+static thread_local std::unique_ptr<Comm> g_world; // per host thread, like the context (hda_kernels.hip Context::get)
 
 Comm &Comm::world()
 {
@@ -282,6 +284,144 @@ class CallbackComm : public Comm {
 };
 } // namespace
 
+// ------------------------------------------------------------ ranks as threads of one process
+//
+// Test transport: the ranks of a row partition are THREADS of one process (each with its own context, stream, allocator and
+// this communicator; hda_thread_ranks.hip).  It exists because a GPU box admits few processes on its card: the 2x2x2 layout
+// of BASELINE config 3 needs eight ranks.  Messages are staged through host memory like the callback transport; collectives
+// meet at a generation barrier; sums run in rank order on every rank (deterministic, identical everywhere).
+namespace {
+struct ThreadWorld {
+   explicit ThreadWorld(int n) : size(n), ptr((size_t)n, nullptr), cnt((size_t)n, nullptr) {}
+   int                       size;
+   std::mutex                mu;
+   std::condition_variable   cv;
+   int                       arrived = 0;
+   unsigned long             gen     = 0;
+   bool                      failed  = false; // a rank died: release everybody instead of deadlocking the process
+   std::vector<const void *> ptr;
+   std::vector<const long *> cnt;
+   void barrier()
+   {
+      std::unique_lock<std::mutex> lk(mu);
+      if (failed) throw Error("thread ranks: another rank failed");
+      const unsigned long g = gen;
+      if (++arrived == size)
+      {
+         arrived = 0;
+         gen++;
+         cv.notify_all();
+         return;
+      }
+      cv.wait(lk, [&] { return gen != g || failed; });
+      if (failed && gen == g) throw Error("thread ranks: another rank failed");
+   }
+   void fail()
+   {
+      std::lock_guard<std::mutex> lk(mu);
+      failed = true;
+      cv.notify_all();
+   }
+};
+
+class ThreadComm : public Comm {
+ public:
+   ThreadComm(int r, std::shared_ptr<ThreadWorld> w) : w_(std::move(w))
+   {
+      rank = r;
+      size = w_->size;
+   }
+   void allreduce_sum_dev(double *d, int n) override
+   {
+      stats.allreduce++;
+      stats.allreduce_doubles += n;
+      hbuf_.resize((size_t)std::max(n, 1));
+      HDA_HIP(hipMemcpyAsync(hbuf_.data(), d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, STREAM));
+      Context::get().sync();
+      reduce(hbuf_.data(), n, 0);
+      HDA_HIP(hipMemcpyAsync(d, hbuf_.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, STREAM));
+      Context::get().sync();
+   }
+   void exchange_dev(const double *send, const int *sc, double *recv, const int *rc, hipStream_t strm) override
+   {
+      stats.exchange++;
+      long              st = 0, rt = 0;
+      std::vector<long> sb((size_t)size), rb((size_t)size);
+      for (int p = 0; p < size; p++)
+      {
+         sb[(size_t)p] = 8L * sc[p];
+         rb[(size_t)p] = 8L * rc[p];
+         st += sc[p];
+         rt += rc[p];
+      }
+      stats.exchange_doubles += st;
+      hs_.resize((size_t)std::max<long>(st, 1));
+      hr_.resize((size_t)std::max<long>(rt, 1));
+      if (st) HDA_HIP(hipMemcpyAsync(hs_.data(), send, sizeof(double) * (size_t)st, hipMemcpyDeviceToHost, strm));
+      HDA_HIP(hipStreamSynchronize(strm));
+      alltoallv_host(hs_.data(), sb.data(), hr_.data(), rb.data());
+      if (rt) HDA_HIP(hipMemcpyAsync(recv, hr_.data(), sizeof(double) * (size_t)rt, hipMemcpyHostToDevice, strm));
+      HDA_HIP(hipStreamSynchronize(strm));
+   }
+   void allreduce_host(long long *v, int n, int op) override
+   {
+      std::vector<long long> t((size_t)std::max(n, 1));
+      w_->ptr[(size_t)rank] = v;
+      w_->barrier();
+      for (int i = 0; i < n; i++)
+      {
+         long long a = ((const long long *)w_->ptr[0])[i];
+         for (int p = 1; p < size; p++)
+         {
+            const long long b = ((const long long *)w_->ptr[(size_t)p])[i];
+            a = op ? std::max(a, b) : a + b;
+         }
+         t[(size_t)i] = a;
+      }
+      w_->barrier();
+      if (n) memcpy(v, t.data(), sizeof(long long) * (size_t)n);
+   }
+   void alltoallv_host(const void *send, const long *sb, void *recv, const long *rb) override
+   {
+      w_->ptr[(size_t)rank] = send;
+      w_->cnt[(size_t)rank] = sb;
+      w_->barrier();
+      long ro = 0;
+      for (int p = 0; p < size; p++)
+      {
+         const long *psb = w_->cnt[(size_t)p];
+         long        so  = 0;
+         for (int q = 0; q < rank; q++) so += psb[q];
+         const long nb = std::min(psb[rank], rb[p]);
+         if (nb) memcpy((char *)recv + ro, (const char *)w_->ptr[(size_t)p] + so, (size_t)nb);
+         ro += rb[p];
+      }
+      w_->barrier();
+   }
+   const char *name() const override { return "threads"; }
+
+ private:
+   void reduce(double *v, int n, int)
+   {
+      std::vector<double> t((size_t)std::max(n, 1));
+      w_->ptr[(size_t)rank] = v;
+      w_->barrier();
+      for (int i = 0; i < n; i++)
+      {
+         double a = ((const double *)w_->ptr[0])[i];
+         for (int p = 1; p < size; p++) a += ((const double *)w_->ptr[(size_t)p])[i];
+         t[(size_t)i] = a;
+      }
+      w_->barrier();
+      if (n) memcpy(v, t.data(), sizeof(double) * (size_t)n);
+   }
+   std::shared_ptr<ThreadWorld> w_;
+   std::vector<double>          hbuf_, hs_, hr_;
+};
+} // namespace
+std::shared_ptr<void> make_thread_world(int size) { return std::make_shared<ThreadWorld>(size); }
+Comm *make_thread_comm(int rank, const std::shared_ptr<void> &world) { return new ThreadComm(rank, std::static_pointer_cast<ThreadWorld>(world)); }
+void  thread_world_fail(const std::shared_ptr<void> &world) { std::static_pointer_cast<ThreadWorld>(world)->fail(); }
 Comm *make_rccl_comm(int rank, int size, const void *uid) { return new RcclComm(rank, size, uid); }
 Comm *make_callback_comm(int rank, int size, hda_allreduce_cb ar, hda_alltoallv_cb a2a)
 {

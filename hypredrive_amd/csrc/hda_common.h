@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,7 @@ struct Context {
    static constexpr int kNumScalars = 320; // recurrence scalars + GMRES Gram-Schmidt coefficients (krylov_dim up to ~300)
 
    static Context &get();
+   static void     release_thread();
    void            sync() { HDA_HIP(hipStreamSynchronize(stream)); }
    double         *slot(int s) { return partials + (size_t)s * kRedBlocks; }
 
@@ -151,11 +153,20 @@ struct OffdPart {
    DArray<double> val;
 };
 
+// identity stamp of a matrix's arrays: every DCsr is born with a fresh one and reset_plan() (arrays replaced) draws another, so
+// a cache keyed on it (the Gauss-Seidel row spans) cannot mistake a later matrix at the same address and size for its own
+inline unsigned long long next_csr_gen()
+{
+   static std::atomic<unsigned long long> g{1};
+   return g.fetch_add(1, std::memory_order_relaxed);
+}
+
 // Local CSR block resident in HBM. int32 indices, fp64 values, rows column-sorted.
 // ncols may exceed nrows: columns >= nrows address the ghost tail of an extended vector
 // (row-partitioned case: [owned | halo]).
 struct DCsr {
    int            nrows = 0, ncols = 0, nnz = 0;
+   mutable unsigned long long gen = next_csr_gen();
    DArray<int>    rowptr; // nrows+1
    DArray<int>    col;    // nnz
    DArray<double> val;    // nnz
@@ -189,6 +200,7 @@ struct DCsr {
    {
       chunk_row.release(); code.release(); dict_val.release(); dict_delta.release(); offd.reset();
       rclass.release(); rc_keys.release(); lidx.release(); ucol.release(); wmeta.release();
+      gen = next_csr_gen();
       nchunks = 0; maxrow = -1; coded = -1; rowcoded = 0; rc_esc_rows = 0; rc_esc_entries = 0; win = -1; nwin = 0; win_maxu = 0; win_total = 0;
    }
 };

@@ -82,6 +82,7 @@ static void gs_row_spans(const DCsr &A, const GsPlan &plan)
    if (n) k_gs_rowspan<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), plan.rbeg.data(), plan.rend.data());
    plan.span_rp  = A.rowptr.data();
    plan.span_nnz = A.nnz;
+   plan.span_gen = A.gen;
 }
 
 void build_gs_plan(const DCsr &A, GsPlan &plan)
@@ -331,7 +332,7 @@ void gs_sweep(const DCsr &A, const GsPlan &plan, const double *dinv, const doubl
 {
    HDA_REQUIRE(plan.built, "Gauss-Seidel plan missing");
    if (A.nrows == 0) return;
-   if (plan.span_rp != A.rowptr.data() || plan.span_nnz != A.nnz) gs_row_spans(A, plan); // another matrix behind a kept plan (preconditioner.reuse)
+   if (plan.span_rp != A.rowptr.data() || plan.span_nnz != A.nnz || plan.span_gen != A.gen) gs_row_spans(A, plan); // another matrix behind a kept plan (preconditioner.reuse)
    const double a = A.avg_row();
    if (a <= 10.0) gs_sweep_t<8, 4>(A, plan, dinv, b, x, forward);
    else if (a <= 40.0) gs_sweep_t<32, 8>(A, plan, dinv, b, x, forward);

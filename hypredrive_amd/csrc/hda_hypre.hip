@@ -936,7 +936,7 @@ static size_t precond_veclen(HYPRE_Solver s)
 namespace hda {
 static std::unordered_set<const void *> &live_solvers()
 {
-   static std::unordered_set<const void *> s;
+   static thread_local std::unordered_set<const void *> s;
    return s;
 }
 void solver_registry(const void *p, int op)

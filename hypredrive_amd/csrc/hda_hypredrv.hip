@@ -30,9 +30,10 @@ using namespace hda;
 
 // ------------------------------------------------------------------- errors
 
-static uint32_t    g_err = 0;
-static std::string g_errmsg;
-static bool        g_initialized = false;
+// (thread_local: one caller thread per process is the contract, HYPREDRV.h:66-70; the thread-rank harness runs one rank per thread)
+static thread_local uint32_t    g_err = 0;
+static thread_local std::string g_errmsg;
+static thread_local bool        g_initialized = false;
 
 static uint32_t err_set(uint32_t e, const std::string &msg = "")
 {
@@ -483,7 +484,7 @@ extern "C" uint32_t HYPREDRV_InputArgsSetPreconVariant(HYPREDRV_t h, int idx)
 
 static std::map<std::string, std::string> &user_presets(bool solver)
 {
-   static std::map<std::string, std::string> p[2];
+   static thread_local std::map<std::string, std::string> p[2];
    return p[solver ? 1 : 0];
 }
 extern "C" uint32_t HYPREDRV_PreconPresetRegister(const char *name, const char *yaml, const char *)
@@ -1331,6 +1332,19 @@ bool hypredrv_peek(void *obj, const DCsr **A, const HaloPlan **halo, const doubl
    return true;
 }
 } // namespace hda
+// levels of the set-up BoomerAMG hierarchy that are row partitioned (0 on one rank or before Setup): bench.py's line, thread-rank tests
+extern "C" int hda_amd_partitioned_levels(void *obj)
+{
+   hypredrv_struct *h = (hypredrv_struct *)obj;
+   if (!h || !h->precon || !h->precon_is_setup || !h->precon->amg) return 0;
+   return h->precon->amg->partitioned_levels();
+}
+extern "C" int hda_amd_hierarchy_levels(void *obj) // partitioned levels + the levels of the replicated tail
+{
+   hypredrv_struct *h = (hypredrv_struct *)obj;
+   if (!h || !h->precon || !h->precon_is_setup || !h->precon->amg) return 0;
+   return h->precon->amg->total_levels();
+}
 // bytes THIS rank streams per Krylov iteration (operator product + vector updates) and per
 // V-cycle with the hierarchy that was set up: [0] CSR figures of SURVEY 8(d), [1] the formats
 // actually read (coded operators).  bench.py sums them over the ranks.

@@ -42,10 +42,23 @@ Context::Context()
    HDA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 }
 
+// One context per host THREAD.  The library's contract is one caller thread per process (reference include/HYPREDRV.h:66-70), so a
+// process has exactly one; the thread-rank harness (hda_capi.hip hda_thread_ranks_*: several ranks of a row partition as threads
+// of one process, each with its own stream, allocator and communicator) is the only place where there are more.
 Context &Context::get()
 {
-   static Context ctx;
+   static thread_local Context ctx;
    return ctx;
+}
+void Context::release_thread()
+{ // the thread-rank harness: give back what this thread's context and allocator hold before the thread ends
+   Context &c = get();
+   (void)hipStreamSynchronize(c.stream);
+   (void)hipStreamSynchronize(c.comm_stream);
+   pool_trim();
+   (void)hipFree(c.partials); (void)hipFree(c.scalars); (void)hipHostFree(c.host_scalars);
+   (void)hipEventDestroy(c.ev); (void)hipStreamDestroy(c.comm_stream); (void)hipStreamDestroy(c.stream);
+   c.partials = c.scalars = c.host_scalars = nullptr; c.ev = nullptr; c.stream = c.comm_stream = nullptr;
 }
 
 // ---------------------------------------------------------------- allocator
@@ -55,7 +68,8 @@ struct Pool {
    std::multimap<size_t, void *>      free_;  // size -> block
    std::unordered_map<void *, size_t> size_;  // every block we own
    size_t                             in_use = 0, cached = 0, peak = 0;
-} g_pool;
+};
+thread_local Pool g_pool; // per thread like the context whose stream orders its blocks
 constexpr size_t kAlign = 512;
 } // namespace
 
@@ -75,7 +89,7 @@ static bool guard_on()
    return on;
 }
 constexpr size_t kGuardBytes = 512;
-static std::unordered_map<void *, size_t> g_guard_at; // block -> offset of its guard tail
+static thread_local std::unordered_map<void *, size_t> g_guard_at; // block -> offset of its guard tail
 
 void *pool_alloc(size_t bytes)
 {
@@ -821,7 +835,8 @@ __global__ __launch_bounds__(256) void k_spmv_coded_row(int nrows, const int *__
 #pragma unroll
          for (int h = 0; h < H; h++) coded_decode(B[h], rr[h], q[h], e[h], cwords, sv, sd, col, val);
          if (SPLIT)
-         { // ghost columns (always escapes: they have no fixed offset) wait for k_offd_fix
+         { // ghost columns wait for k_offd_fix.  (Usually escapes, but NOT always: on slab partitions a ghost column has a constant
+           // offset and gets a dictionary code -- the j >= nown test on every decoded entry is what keeps them out, keep it)
 #pragma unroll
             for (int h = 0; h < H; h++)
 #pragma unroll
@@ -1542,7 +1557,7 @@ struct SpmvEpilogue {
    double       *out2  = nullptr;
    bool          done  = false;
 };
-static SpmvEpilogue g_epilogue;
+static thread_local SpmvEpilogue g_epilogue;
 
 template <int MODE, bool DOT>
 static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, double beta,
@@ -1699,7 +1714,7 @@ struct SpmvProbe {
    int                     mode = -1;
    std::vector<hipEvent_t> evs;
 };
-std::vector<SpmvProbe> g_probes;
+thread_local std::vector<SpmvProbe> g_probes;
 } // namespace
 void spmv_prepare(const DCsr &A)
 {
@@ -1798,11 +1813,12 @@ void spmv(const DCsr &A, double alpha, const double *x, double beta, const doubl
 }
 bool spmv_with_scaled_copy(const DCsr &A, const double *x, double *y, const double *dinv2, double *y2, const HaloPlan *halo)
 {
-   g_epilogue = SpmvEpilogue{dinv2, y2, false};
+   struct Armed { // disarmed on every way out: a throwing launch must not leave a stale out2 behind for the next plain product
+      Armed(const double *d, double *o) { g_epilogue = SpmvEpilogue{d, o, false}; }
+      ~Armed() { g_epilogue = SpmvEpilogue{}; }
+   } armed(dinv2, y2);
    launch_spmv<MODE_PLAIN, false>(A, halo, x, 1.0, 0.0, nullptr, nullptr, nullptr, nullptr, y, nullptr);
-   const bool done = g_epilogue.done;
-   g_epilogue      = SpmvEpilogue{};
-   return done;
+   return g_epilogue.done;
 }
 void spmv_dot(const DCsr &A, const double *x, double *y, const double *w, int slot, const HaloPlan *halo)
 {

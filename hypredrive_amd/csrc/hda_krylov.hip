@@ -8,8 +8,39 @@
 
 namespace hda {
 
-static int g_last_precond_calls = 0;
+static thread_local int g_last_precond_calls = 0;
 int last_precond_calls() { return g_last_precond_calls; }
+
+// A Krylov solve that runs INSIDE the preconditioner call of another one (MGR's nested components, reference
+// src/internal/krylov.c, mgr.c:3938-3960, 4253-4275) shares the context's device scalars and block partials with its caller.
+// PCG keeps <r,r> partials (slot 3) and the gamma of the previous iteration alive across its preconditioner call (fused dots),
+// so the nested solve saves the caller's scalar block and partial slots on entry and puts them back on exit: two small
+// device copies per nested solve, nothing on the outermost one.
+namespace {
+struct NestedScope {
+   static thread_local int depth;
+   DArray<double>          save;
+   bool                    nested;
+   static constexpr size_t kScal = Context::kNumScalars, kPart = (size_t)Context::kNumSlots * kRedBlocks;
+   NestedScope() : nested(depth++ > 0)
+   {
+      if (!nested) return;
+      Context &ctx = Context::get();
+      save.alloc(kScal + kPart);
+      HDA_HIP(hipMemcpyAsync(save.data(), ctx.scalars, kScal * sizeof(double), hipMemcpyDeviceToDevice, ctx.stream));
+      HDA_HIP(hipMemcpyAsync(save.data() + kScal, ctx.partials, kPart * sizeof(double), hipMemcpyDeviceToDevice, ctx.stream));
+   }
+   ~NestedScope()
+   {
+      depth--;
+      if (!nested) return;
+      Context &ctx = Context::get();
+      (void)hipMemcpyAsync(ctx.scalars, save.data(), kScal * sizeof(double), hipMemcpyDeviceToDevice, ctx.stream);
+      (void)hipMemcpyAsync(ctx.partials, save.data() + kScal, kPart * sizeof(double), hipMemcpyDeviceToDevice, ctx.stream);
+   }
+};
+thread_local int NestedScope::depth = 0;
+} // namespace
 
 double pcg_iteration_bytes(const DCsr &A, bool format)
 {
@@ -20,6 +51,7 @@ double pcg_iteration_bytes(const DCsr &A, bool format)
 
 KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
 {
+   NestedScope  scope;
    Context     &ctx = Context::get();
    const DCsr  &A   = *op.A;
    const int    n   = A.nrows;
@@ -165,12 +197,13 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
    }
    res.iters     = it;
    res.final_rel = std::sqrt(std::fabs(i_prod) / bi_prod);
-   g_last_precond_calls = res.precond_calls;
+   if (!scope.nested) g_last_precond_calls = res.precond_calls;
    return res;
 }
 
 static KrylovResult gmres_core(bool flexible, const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
 {
+   NestedScope  scope;
    Context     &ctx = Context::get();
    const DCsr  &A   = *op.A;
    const int    n = A.nrows, k = std::max(kp.krylov_dim, 1);
@@ -311,6 +344,7 @@ KrylovResult fgmres(const LinOp &op, const PrecondFn &M, const KrylovParams &kp,
 // before the next kernel can be parameterised); everything else stays on the device.
 KrylovResult bicgstab(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
 {
+   NestedScope  scope;
    const DCsr  &A = *op.A;
    const int    n = A.nrows;
    KrylovResult res;

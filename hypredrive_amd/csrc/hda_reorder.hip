@@ -189,6 +189,7 @@ void Amg::reorder_levels()
       const int nl = nown(l), nn = nown(l + 1);
       permute_csr(lv.A, pl, rl, nl);                  // A_l: rows and owned columns
       permute_csr(lv.P, pl, rn, nn);                  // P_l: rows level l, columns level l+1
+      if (lv.pg_ready && lv.Pg.nrows && rn) permute_csr(lv.Pg, nullptr, rn, nn); // its ghost rows keep their slots, owned columns move
       permute_csr(lv.R, pn, rl, nl);                  // R_l: rows level l+1, columns level l
       if (dist)
       { // the owned unknowns the halo plans pack: inputs of A_l and R_l are level-l vectors, of P_l level l+1
@@ -199,6 +200,7 @@ void Amg::reorder_levels()
       if (l == 1)
       { // level 0 keeps the user's numbering: only the level-1 side of its transfer operators moves
          permute_csr(levels[0].P, nullptr, rl, nl);
+         if (levels[0].pg_ready && levels[0].Pg.nrows) permute_csr(levels[0].Pg, nullptr, rl, nl);
          permute_csr(levels[0].R, pl, nullptr, 0);
          if (dist) remap_halo(levels[0].hP, rl);
       }

@@ -1,0 +1,134 @@
+// hda_thread_ranks.hip -- test seam: the ranks of a row partition as THREADS of one process.
+//
+// Why it exists: BASELINE config 3 is a 2x2x2 rank grid (reference examples/src/C_laplacian/laplacian.c:561-582, `-P 2 2 2`),
+// whose coarse levels have edge and corner neighbours (7 peers) that no 1xPxQ layout produces -- and a GPU box admits at most
+// six processes on its card, so eight rank PROCESSES sharing the one GPU cannot be rehearsed there.  Every piece of per-rank
+// state of the library (context + stream, allocator, communicator, error state) is per host thread (hda_kernels.hip
+// Context::get), so eight ranks can run as eight threads of one process over the in-process transport of hda_comm.hip
+// (ThreadComm: host-staged messages, generation barrier).  Each thread drives the PUBLIC API exactly like one rank of
+// laplacian.c:331-468 does: Initialize, Create, InputArgsParse, (generator), ResetInitialGuess + LinearSolverCreate + Setup +
+// Apply + Destroy, getters.  Nothing here is on the product path.
+#include "HYPREDRV.h"
+#include "hda_comm.h"
+#include "hypredrv_amd.h"
+
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace hda;
+
+
+
+
+namespace {
+struct RankOut {
+   int         iters = 0, converged = 0, vcycles = 0, part_levels = 0;
+   double      final_rel = 0, l2 = 0, l1 = 0, linf = 0;
+   Comm::Stats comm;
+   std::string err;
+};
+
+void rank_body(int rank, int nranks, const std::shared_ptr<void> &world, const int n[3], const int P[3], const char *yaml, int nsolves, double *x_out,
+               const long long *row_start, RankOut &out)
+{
+   try
+   {
+      Comm::set_world(make_thread_comm(rank, world));
+      auto chk = [&](uint32_t code, const char *what) {
+         if (code) throw Error(std::string(what) + ": " + HYPREDRV_AMD_LastErrorMessage());
+      };
+      chk(HYPREDRV_Initialize(), "HYPREDRV_Initialize");
+      HYPREDRV_t h = nullptr;
+      chk(HYPREDRV_Create(MPI_COMM_WORLD, &h), "HYPREDRV_Create");
+      chk(HYPREDRV_SetLibraryMode(h), "HYPREDRV_SetLibraryMode");
+      std::string y(yaml);
+      char       *argv[1] = {y.data()};
+      chk(HYPREDRV_InputArgsParse(1, argv, h), "HYPREDRV_InputArgsParse");
+      const double c[3] = {1.0, 1.0, 1.0};
+      chk(HYPREDRV_AMD_LinearSystemSetLaplacian7pt(h, n, P, c), "HYPREDRV_AMD_LinearSystemSetLaplacian7pt");
+      for (int s = 0; s < std::max(nsolves, 1); s++)
+      {
+         chk(HYPREDRV_LinearSystemResetInitialGuess(h), "HYPREDRV_LinearSystemResetInitialGuess");
+         chk(HYPREDRV_LinearSolverCreate(h), "HYPREDRV_LinearSolverCreate");
+         chk(HYPREDRV_LinearSolverSetup(h), "HYPREDRV_LinearSolverSetup");
+         Comm::world().stats = Comm::Stats(); // rank-to-rank operations of the solve alone
+         chk(HYPREDRV_LinearSolverApply(h), "HYPREDRV_LinearSolverApply");
+         out.comm        = Comm::world().stats;
+         out.vcycles     = hda_last_precond_calls();
+         out.part_levels = hda_amd_partitioned_levels(h);
+         chk(HYPREDRV_LinearSolverGetNumIter(h, &out.iters), "HYPREDRV_LinearSolverGetNumIter");
+         chk(HYPREDRV_LinearSolverGetConverged(h, &out.converged), "HYPREDRV_LinearSolverGetConverged");
+         chk(HYPREDRV_LinearSolverGetFinalRelativeResidualNorm(h, &out.final_rel), "HYPREDRV_LinearSolverGetFinalRelativeResidualNorm");
+         chk(HYPREDRV_LinearSolverDestroy(h), "HYPREDRV_LinearSolverDestroy");
+      }
+      chk(HYPREDRV_LinearSystemGetSolutionNorm(h, "L2", &out.l2), "HYPREDRV_LinearSystemGetSolutionNorm");
+      chk(HYPREDRV_LinearSystemGetSolutionNorm(h, "L1", &out.l1), "HYPREDRV_LinearSystemGetSolutionNorm");
+      chk(HYPREDRV_LinearSystemGetSolutionNorm(h, "Linf", &out.linf), "HYPREDRV_LinearSystemGetSolutionNorm");
+      if (x_out)
+      {
+         HYPRE_Complex *xv  = nullptr;
+         HYPRE_BigInt   len = 0;
+         chk(HYPREDRV_LinearSystemGetSolutionValues(h, &xv), "HYPREDRV_LinearSystemGetSolutionValues");
+         chk(HYPREDRV_LinearSystemGetSolutionLength(h, &len), "HYPREDRV_LinearSystemGetSolutionLength");
+         if (len != row_start[rank + 1] - row_start[rank]) throw Error("thread ranks: local solution length differs from the generator's block");
+         memcpy(x_out + row_start[rank], xv, sizeof(double) * (size_t)len);
+      }
+      chk(HYPREDRV_Destroy(&h), "HYPREDRV_Destroy");
+      chk(HYPREDRV_Finalize(), "HYPREDRV_Finalize");
+   }
+   catch (const std::exception &e)
+   {
+      out.err = std::string("rank ") + std::to_string(rank) + ": " + e.what();
+      thread_world_fail(world); // release the ranks waiting for this one
+   }
+   Comm::set_world(make_self_comm());
+   Context::release_thread();
+   (void)nranks;
+}
+} // namespace
+
+// AMG-Krylov solve of the generator's 7-pt Laplacian (global grid n, rank grid P, P0*P1*P2 = nranks) on `nranks` thread ranks.
+// out16: iters, converged, final_rel, ||x||_2, ||x||_1, ||x||_inf, all-reduces / exchanges / overlapped exchanges / doubles
+// all-reduced / doubles exchanged of rank 0's last solve, V-cycles, partitioned levels, max |iters_r - iters_0|, ranks, 0.
+// x_global (may be null): the solution in the generator's block numbering (rank blocks in rank order), length n0*n1*n2.
+extern "C" int hda_thread_ranks_lap7(int nranks, const int n[3], const int P[3], const char *yaml, int nsolves, double out16[16], double *x_global,
+                                     char *errbuf, int errlen)
+{
+   if (nranks < 1 || P[0] * P[1] * P[2] != nranks) return 1;
+   // block sizes of the generator (laplacian.c:561-582): rows of rank r = product of its three extents
+   std::vector<long long> row_start((size_t)nranks + 1, 0);
+   for (int r = 0; r < nranks; r++)
+   {
+      const int pc[3] = {r / (P[1] * P[2]), (r / P[2]) % P[1], r % P[2]};
+      long long rows  = 1;
+      for (int d = 0; d < 3; d++)
+      {
+         const int size = n[d] / P[d], rest = n[d] - size * P[d];
+         rows *= size + (pc[d] < rest ? 1 : 0);
+      }
+      row_start[(size_t)r + 1] = row_start[(size_t)r] + rows;
+   }
+   std::shared_ptr<void>    world = make_thread_world(nranks);
+   std::vector<RankOut>     outs((size_t)nranks);
+   std::vector<std::thread> th;
+   for (int r = 0; r < nranks; r++) th.emplace_back(rank_body, r, nranks, std::cref(world), n, P, yaml, nsolves, x_global, row_start.data(), std::ref(outs[(size_t)r]));
+   for (auto &t : th) t.join();
+   std::string err;
+   for (auto &o : outs)
+      if (!o.err.empty()) err += o.err + "\n";
+   if (!err.empty())
+   {
+      if (errbuf && errlen > 0) { strncpy(errbuf, err.c_str(), (size_t)errlen - 1); errbuf[errlen - 1] = 0; }
+      return 2;
+   }
+   const RankOut &o = outs[0];
+   int            spread = 0;
+   for (auto &q : outs) spread = std::max(spread, std::abs(q.iters - o.iters));
+   const double v[16] = {(double)o.iters, (double)o.converged, o.final_rel, o.l2, o.l1, o.linf, (double)o.comm.allreduce, (double)o.comm.exchange,
+                         (double)o.comm.overlapped, (double)o.comm.allreduce_doubles, (double)o.comm.exchange_doubles, (double)o.vcycles,
+                         (double)o.part_levels, (double)spread, (double)nranks, 0.0};
+   memcpy(out16, v, sizeof(v));
+   return 0;
+}

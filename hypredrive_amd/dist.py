@@ -75,8 +75,18 @@ def _make_callbacks(dist, torch, rank, world):
     return hd.ALLREDUCE_CB(allreduce), hd.ALLTOALLV_CB(alltoallv)
 
 
-def init(transport="auto"):
-    """Join the world described by RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*; returns (rank, world)."""
+class TransportError(RuntimeError):
+    """RCCL could not be joined and falling back was not allowed.  stage: uid | init | halo_comm | selftest | devices | peer
+    (peer: this rank was fine, another one failed)."""
+
+    def __init__(self, stage, rank, msg):
+        super().__init__(msg)
+        self.stage, self.rank = stage, rank
+
+
+def init(transport="auto", strict=False):
+    """Join the world described by RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*; returns (rank, world).  strict: an RCCL failure raises
+    TransportError on every rank instead of falling back to the host-staged transport."""
     from . import hypredrv as hd
     rank, world, local = env_rank()
     if world == 1:
@@ -100,15 +110,19 @@ def init(transport="auto"):
         dist.all_gather_object(devs, (os.uname().nodename, mine))
         if len(set(devs)) < world:
             if forced == "rccl":
-                raise RuntimeError(f"RCCL needs one GPU per rank; ranks share devices: {devs}")
+                raise TransportError("devices", rank, f"RCCL needs one GPU per rank; ranks share devices: {devs}")
             if rank == 0:
                 print("[hypredrive_amd] several ranks share a GPU: using the host-staged transport", file=sys.stderr, flush=True)
             transport = "staged"
     if transport == "rccl":
         # join RCCL and prove the communicator works (all-reduce + neighbour exchange self-test);
         # if ANY rank fails, every rank falls back to the host-staged transport: slower
-        # messages, same kernels and results.  Set HDA_TRANSPORT=rccl to make this fatal.
-        err = None
+        # messages, same kernels and results.  Set HDA_TRANSPORT=rccl (or strict=True: bench.py) to make this fatal.
+        # `stage` names where it went wrong -- uid (rank 0's ncclGetUniqueId), init (ncclCommInitRank of the main communicator),
+        # halo_comm (the second communicator of the neighbour exchanges), selftest (first collectives on both) -- for the one-line
+        # diagnosis a first multi-GPU run needs
+        err, stage = None, None
+        _keep["stage"] = "uid"
         # rank 0's id (or its failure) reaches every rank in ONE collective, whatever happened on rank 0:
         # a rank that skipped the broadcast would leave the others waiting in it
         uid, box = (C.c_ubyte * 128)(), [None]
@@ -117,23 +131,33 @@ def init(transport="auto"):
                 hd.check(L.HYPREDRV_AMD_CommGetUniqueId(uid))
                 box = [bytes(uid)]
             except Exception as e:  # noqa: BLE001
-                err, box = e, [None]
+                err, stage, box = e, "uid", [None]
         dist.broadcast_object_list(box, src=0)
         try:
             if box[0] is None:
+                stage = "uid"
                 raise err or RuntimeError("rank 0 could not create an RCCL unique id")
             uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
-            hd.check(L.HYPREDRV_AMD_CommInit(rank, world, local, uid))
+            stage = _keep["stage"] = "init"  # (_keep["stage"]: what a watchdog reports when a call never returns)
+            try:
+                hd.check(L.HYPREDRV_AMD_CommInit(rank, world, local, uid))
+            except Exception as e:  # noqa: BLE001 - the library names the communicator that failed
+                if "halo_comm" in str(e):
+                    stage = "halo_comm"
+                raise
             from . import load
+            stage = _keep["stage"] = "selftest"
             if load().hda_comm_selftest() != 0:
                 raise RuntimeError("RCCL self-test failed: " + load().hda_last_error().decode())
+            stage = None
+            _keep["stage"] = "agree"
         except Exception as e:  # noqa: BLE001 - agreement below decides what happens
             err = e
         ok = torch.tensor([0 if err else 1], dtype=torch.int32)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0:
-            if forced == "rccl":
-                raise RuntimeError(f"RCCL transport unavailable on some rank (this rank: {err})")
+            if forced == "rccl" or strict:
+                raise TransportError(stage or "peer", rank, f"RCCL transport unavailable on some rank (this rank: {err})")
             if rank == 0:
                 print(f"[hypredrive_amd] RCCL transport unavailable ({err}); using the host-staged transport", file=sys.stderr, flush=True)
             L.HYPREDRV_AMD_CommFinalize()
@@ -143,6 +167,7 @@ def init(transport="auto"):
         _keep["cbs"] = (ar, a2a)  # keep the ctypes trampolines alive
         hd.check(L.HYPREDRV_AMD_CommInitCallbacks(rank, world, local if local < max(ndev, 1) else 0, ar, a2a))
     _keep["transport"] = transport
+    _keep["stage"] = "joined"
     return rank, world
 
 

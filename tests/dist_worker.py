@@ -181,8 +181,21 @@ def mode_mgr(out, n):
     hdist.finalize()
 
 
+def mode_threads(out, n, P, solver):
+    """ONE process, prod(P) thread ranks on the visible GPU (hypredrive_amd/csrc/hda_thread_ranks.hip): the public HYPREDRV_* sequence
+    on every rank, the in-process staged transport between them."""
+    from hypredrive_amd import _lib
+    P = tuple(int(v) for v in P.split(","))
+    yaml = f"solver: {solver}\npreconditioner:\n  preset: poisson\n"
+    r = _lib.thread_ranks_lap7(P[0] * P[1] * P[2], (n, n, n), P, yaml, want_x=True)
+    np.save(out + ".x.npy", r.pop("x"))
+    json.dump(r, open(out, "w"))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "transport":
+    if sys.argv[1] == "threads":
+        mode_threads(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
+    elif sys.argv[1] == "transport":
         mode_transport(sys.argv[2])
     elif sys.argv[1] == "mgr":
         mode_mgr(sys.argv[2], int(sys.argv[3]))

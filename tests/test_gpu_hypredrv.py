@@ -394,6 +394,42 @@ def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solve
     assert np.linalg.norm(x) == pytest.approx(res["norm"], rel=1e-12)
 
 
+def _thread_ranks(tmp_path, tag, n, P, solver="pcg", **envx):
+    """prod(P) ranks as THREADS of one child process (hda_thread_ranks.hip): a GPU box admits six processes on its card, so this is
+    how the eight ranks of BASELINE config 3's 2x2x2 layout share the one GPU."""
+    out = str(tmp_path / f"{tag}.json")
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", **envx)
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "threads", out, str(n), ",".join(str(v) for v in P), solver]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    return json.load(open(out)), np.load(out + ".x.npy"), r.stderr
+
+
+@pytest.mark.parametrize("n,rep_rows,check", [(40, 2000, "1"), (40, 2000, "0"), (32, 0, "0"), (48, 100000, "0")])
+def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check):
+    """BASELINE config 3's layout -- `-P 2 2 2` (reference examples/src/C_laplacian/laplacian.c:561-582, scripts/node_scaling.sh:1275-1292) --
+    with eight ranks: blocks have face, EDGE and CORNER neighbours (7 peers), which no 1xPxQ layout produces, on every partitioned
+    level.  rep_rows 2000 keeps three levels partitioned at 40^3 (64 000 / ~21 000 / ~4 500 rows) above the replicated tail; 0 keeps
+    every level partitioned; 100000 hands level 1 to the tail.  check = "1": HDA_DIST_CHECK, the partitioned setup compared level by
+    level with the replicated one inside the library.  Against one rank: iteration count within 1, every rank the same count,
+    solution norms to 1e-6 (the stopping tolerance), the gathered solution's norm to rounding."""
+    res, x, err = _thread_ranks(tmp_path, f"t{n}_{rep_rows}_{check}", n, (2, 2, 2), HDA_REPLICATE_ROWS=str(rep_rows), HDA_DIST_CHECK=check)
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  preset: poisson\n")
+    h.set_laplacian7((n, n, n))
+    ref = h.solve()
+    assert res["world"] == 8 and res["converged"] and res["iters_spread"] == 0
+    assert abs(res["iters"] - ref["iters"]) <= 1
+    assert res["norm"] == pytest.approx(h.solution_norm("L2"), rel=1e-6)
+    assert res["l1"] == pytest.approx(h.solution_norm("L1"), rel=1e-6)
+    assert res["linf"] == pytest.approx(h.solution_norm("Linf"), rel=1e-6)
+    assert np.linalg.norm(x) == pytest.approx(res["norm"], rel=1e-12)
+    if rep_rows == 2000:
+        assert res["partitioned_levels"] >= 2
+        assert res["exchange"] > 0 and res["allreduce"] > 0
+    if check == "1":
+        assert "dist check rank 7" in err  # every rank compared its levels
+
+
 def _dist_solve(tmp_path, tag, world, n, port, **envx):
     out = str(tmp_path / f"{tag}.json")
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_DIST_CHECK="0", **envx)

@@ -988,6 +988,36 @@ def test_mgr_nested_krylov_matches_oracle(orc, hd, case):
     assert rel(hd.Mgr(Ah, labels, plain).vcycle(r), Mh.vcycle(r)) > 1e-6
 
 
+@pytest.mark.parametrize("outer", ["pcg", "gmres"])
+def test_nested_pcg_inside_an_outer_krylov_matches_oracle(orc, hd, outer):
+    """A PCG nested inside the preconditioner call of an outer PCG (YAML `f_relaxation: pcg:` / `coarsest_level: pcg:` under
+    `solver: pcg`): the outer recurrence keeps <r,r> block partials and the previous gamma on the device across that call
+    (fused dots), the nested solve uses the same scalar block -- it saves and restores it (hda_krylov.hip NestedScope).  Without
+    that the outer search directions and stopping tests are silently wrong.  Compared step by step with the oracle, whose
+    nested solve has its own scalars by construction; a fixed number of outer iterations, convergence not required (the
+    preconditioner is not a fixed operator)."""
+    S, labels = _three_field(11, seed=3)
+    Ao, Ah = both(orc, hd, S)
+
+    def levels(amgp):
+        one = amgp(max_levels=1, relax_coarse=18)
+        return [dict(f_dofs=[2], prolongation_type="jacobi"),
+                dict(f_dofs=[1], restriction_type="columped", f_relaxation="amg", f_amg=one,
+                     f_krylov=dict(method="pcg", max_iter=3, rtol=0.0), coarsest_krylov=dict(method="pcg", max_iter=2, rtol=0.0))]
+
+    Mo = orc.MgrPrecond(Ao, labels, levels(lambda **kw: orc.amg_params(True, **kw)))
+    Mh = hd.Mgr(Ah, labels, levels(lambda **kw: hd.AmgParams.default(**kw)))
+    b = np.ones(S.shape[0])
+    if outer == "pcg":
+        ro = orc.pcg(Ao, b, Mo, orc.krylov_params(False, rtol=1e-8, max_iter=8))
+        rh = hd.pcg(Ah, b, Mh, hd.KrylovParams.default(False, rtol=1e-8, max_iter=8))
+    else:
+        ro, rh = orc.fgmres(Ao, b, Mo), hd.fgmres(Ah, b, Mh)
+    assert rh["iters"] == ro["iters"] and rh["iters"] >= 3
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-6)
+    assert rel(rh["x"], ro["x"]) < 1e-6
+
+
 @pytest.mark.parametrize("cyc", ["v(0,1)", "v(1,1)", "w", "w(1,1)"])
 def test_mgr_cycle_shapes_match_oracle(orc, hd, cyc):
     """`mgr.cycle` (reference src/internal/mgr.c:614-675): smoothing after the coarse correction, on both sides of it, and W-cycles
