@@ -443,6 +443,33 @@ def child_bench(extra, nranks, timeout_s):
     return err or {"error": f"child exited {r.returncode}: {r.stderr[-400:]}"}
 
 
+def wait_for_sibling_ranks(limit_s=120.0):
+    """Rank 0 starts child launches once its peers -- the other children of this job's launcher -- have exited and released their
+    GPUs (on a box where several ranks share one card, the old and the new ranks together would exceed what the card admits)."""
+    me, parent = os.getpid(), os.getppid()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < limit_s:
+        alive = 0
+        for d in os.listdir("/proc"):
+            if not d.isdigit() or int(d) == me:
+                continue
+            try:
+                with open(f"/proc/{d}/stat") as f:
+                    st = f.read()
+                ppid = int(st[st.rindex(")") + 2:].split()[1])
+                if ppid != parent:
+                    continue
+                with open(f"/proc/{d}/cmdline", "rb") as f:
+                    if b"bench.py" in f.read():
+                        alive += 1
+            except (OSError, ValueError):
+                continue
+        if alive == 0:
+            return True
+        time.sleep(0.5)
+    return False
+
+
 def multi_extras(args, out):
     """N > 1, rank 0, after the timed weak-scaling run: the OTHER curve and the same-node N = 1 point, so that one driver invocation
     per N yields both series BASELINE.md's >= 6x target can be read from (reference scripts/node_scaling.sh:1275-1292: the fixed-size
@@ -454,6 +481,7 @@ def multi_extras(args, out):
     base = ["--grid", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup)]
     keep = ("ms_per_step", "value", "iters", "converged", "setup_ms", "solve_timer_ms", "allreduces_per_iter", "halo_exchanges_per_iter",
             "collectives_per_iter", "halo_exchanges_overlapped_per_iter", "partitioned_levels", "levels_total", "transport", "ranks_seen")
+    wait_for_sibling_ranks()
     st = child_bench(base + ["--strong"], N, 900)
     strong = {k: st.get(k) for k in keep if k in st} if "error" not in st else dict(st)
     strong["what"] = (f"child launch of {N} ranks: lap7 {n}^3 GLOBAL cut into {N} blocks (strong scaling), same API path and timing as the headline")

@@ -87,6 +87,19 @@ class Ilu {
 void ilu_solve(Ilu &F, const DCsr &A, const HaloPlan *halo, const double *b, double *x, bool zero_guess, DArray<double> &r,
                DArray<double> &c); // max_iter iterations x += M^-1 (b - A x)
 
+// PCG <-> preconditioner: a V-cycle from a zero guess that opens with the Jacobi sweep z0 = dinv .* r on level 0 lets its caller do
+// that multiplication where r is produced (PCG's update kernel: one pass over r and one launch less per iteration).  Thread-local,
+// like the hints of the C callback seam (hda_hypre.h PrecondHints).  The callee publishes an offer after every application
+// (Amg::apply_offering); the caller that honours it writes dinv .* r into the offered vector and sets `done` before the next
+// application, which skips its first sweep and clears the flag -- a flag still set afterwards means the callee never looked.
+struct FirstSweepFusion {
+   bool          valid = false;   // offer: the next application from a zero guess may have its first sweep done by the caller
+   const double *dinv  = nullptr; //   divisors of that sweep
+   double       *dest  = nullptr; //   where the sweep's result is expected; nullptr = the application's output vector itself
+   bool          done  = false;   // caller -> callee: it has been done
+};
+FirstSweepFusion &first_sweep_fusion();
+
 struct AmgLevel {
    DCsr           A, P, R;
    // row partitions: the P rows of this rank's GHOST fine points (the ghost slots of hA, in their order; columns as P's), so that
@@ -150,6 +163,10 @@ class Amg {
    // HYPRE_BoomerAMGSolve as a preconditioner (precon.c:108): one V(nu1,nu2) from x = 0.
    // dot_slot >= 0: also emit block partials of <b, x> (fuses PCG's <r, z>).
    void apply(const double *b, double *x, int dot_slot = -1);
+   // the same, as the preconditioner of one of this library's Krylov loops: honours and renews the first-sweep offer (FirstSweepFusion)
+   void apply_offering(const double *b, double *x, int dot_slot = -1);
+   bool first_sweep_fusable() const;
+   double *first_sweep_dest(double *x); // where apply(b, x) puts its zero-guess first sweep: x or the level's second buffer
    // general solve entry: max_iter cycles starting from the x passed in
    void solve(const double *b, double *x);
 
@@ -164,7 +181,7 @@ class Amg {
    double        setup_times[8] = {0}; // strength, coarsen, interp, rap, misc (diagnostic)
 
  private:
-   void cycle(const double *b, double *x, bool zero_guess, int dot_slot);
+   void cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool first_sweep_given = false);
    void relax(int l, int type, const double *dinv, const double *b, double *&cur, double *&alt,
               bool zero_guess, int dot_slot);
    void build_hierarchy(const DCsr &A);

@@ -2765,7 +2765,40 @@ void Amg::coarse_solve(const double *f, double *u)
    if (coarse_nloc) k_place<<<ceil_div(coarse_nloc, 256), 256, 0, STREAM>>>(coarse_nloc, cbuf_u.data() + coarse_lo, u);
 }
 
-void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
+FirstSweepFusion &first_sweep_fusion()
+{
+   static thread_local FirstSweepFusion f;
+   return f;
+}
+bool Amg::first_sweep_fusable() const
+{
+   const char *e = getenv("HDA_FUSE_Z0"); // (read per call: the tests switch it inside one process)
+   return !(e && atoi(e) == 0) && num_levels() > 1 && prm.sweeps_down >= 1 && is_jacobi_type(prm.relax_down) && !levels[0].ilu;
+}
+// (the buffer choice of cycle() for zero_guess = true)
+double *Amg::first_sweep_dest(double *x)
+{
+   const int swaps0 = levels[0].ilu ? 0 : (is_jacobi_type(prm.relax_down) ? (prm.sweeps_down - (prm.sweeps_down > 0 ? 1 : 0)) : 0) +
+                                             (is_jacobi_type(prm.relax_up) ? prm.sweeps_up : 0);
+   return (swaps0 & 1) ? levels[0].u2.data() : x;
+}
+void Amg::apply_offering(const double *b, double *x, int dot_slot)
+{
+   FirstSweepFusion &fs = first_sweep_fusion();
+   const bool given = fs.done;
+   fs.done          = false;
+   HDA_REQUIRE(!given || first_sweep_fusable(), "first sweep handed to a cycle that does not open with one");
+   cycle(b, x, true, dot_slot, given);
+   fs.valid = first_sweep_fusable();
+   if (fs.valid)
+   {
+      double *d = first_sweep_dest(x);
+      fs.dinv   = levels[0].dinv_down.data();
+      fs.dest   = (d == x) ? nullptr : d;
+   }
+}
+
+void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool first_sweep_given)
 {
    const int L  = num_levels();
    const int n0 = level_A(0).nrows;
@@ -2795,7 +2828,7 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot)
    if (zero_guess && (swaps0 & 1)) { cur = levels[0].u2.data(); alt = x; }
    else { cur = x; alt = levels[0].u2.data(); }
    const double *f = b;
-   bool first_sweep_done = false; // the level's zero-guess Jacobi sweep u = dinv .* f came out of the restriction above it
+   bool first_sweep_done = first_sweep_given && zero_guess; // the level's zero-guess Jacobi sweep u = dinv .* f came out of the restriction above it (level 0: of the caller)
    for (int l = 0; l < L - 1; l++)
    {
       const DCsr &A  = level_A(l);

@@ -595,7 +595,7 @@ static int run_krylov(int kind, hda_csr_t A, hda_amg_t amg, const hda_krylov_par
          ilu_solve(*amg->ilu, m, nullptr, r, z, true, amg->ilu_r, amg->ilu_c);
          if (slot >= 0) dot(m.nrows, r, z, slot);
       };
-   else if (amg) M = [amg](const double *r, double *z, int slot) { amg->amg->apply(r, z, slot); };
+   else if (amg) M = [amg](const double *r, double *z, int slot) { amg->amg->apply_offering(r, z, slot); };
    KrylovParams  k   = to_kparams(kp);
    LinOp         op(m, nullptr, (amg && amg->amg) ? amg->amg->vec_len0() : 0);
    KrylovResult  res = kind == 1 ? gmres(op, M, k, db.data(), dx.data()) : kind == 2 ? fgmres(op, M, k, db.data(), dx.data())
@@ -716,7 +716,7 @@ extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_par
    finalize(0, S_TMP);
    const double bn = std::sqrt(read_scalar(S_TMP));
    PrecondFn M;
-   if (amg) M = [amg](const double *rr, double *zz, int slot) { amg->amg->apply(rr, zz, slot); };
+   if (amg) M = [amg](const double *rr, double *zz, int slot) { amg->amg->apply_offering(rr, zz, slot); };
    KrylovParams k = to_kparams(kp);
    k.profile_k1   = (k1_avg_ms != nullptr);
    LinOp op(m, multi ? A->halo : nullptr, amg ? amg->amg->vec_len0() : 0);

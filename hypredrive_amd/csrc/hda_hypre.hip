@@ -1196,7 +1196,7 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    }
    if (h.zero_guess && s->ap.max_iter == 1)
    {
-      s->amg->apply(b->data(), xp, h.dot_slot);
+      s->amg->apply_offering(b->data(), xp, h.dot_slot); // (honours and renews the first-sweep offer of PCG)
       if (h.dot_slot >= 0) h.dot_done = true;
       s->amg_iters = 1;
    }

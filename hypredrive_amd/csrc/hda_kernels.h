@@ -46,9 +46,13 @@ enum Scalar : int {
 void dot(int n, const double *x, const double *y, int slot);              // partials only
 void finalize(int slot, int scalar_idx);                                  // scalars[idx] = sum(slot)
 void finalize_n(int first_slot, int nslots, int first_scalar);            // several at once
-void cg_update(int n, int gamma_idx, const double *p, const double *s, double *x, double *r,
-               int rr_slot); // alpha = gamma/S_SP; x += alpha p; r -= alpha s; partials <r,r>
-void cg_direction(int n, int gamma_old_idx, int gamma_new_idx, const double *z, double *p);
+// alpha = gamma/S_SP; x += alpha p; r -= alpha s; partials <r,r>.  sp_slot >= 0 (one rank): <s,p> is finished from that slot of block
+// partials inside the kernel (no finalize launch; same bits).  z0 != null: also z0 = dinv0 .* r (the zero-guess first sweep of the cycle)
+void cg_update(int n, int gamma_idx, const double *p, const double *s, double *x, double *r, int rr_slot, int sp_slot = -1,
+               const double *dinv0 = nullptr, double *z0 = nullptr);
+// p = z + (gamma_new / gamma_old) p.  first_slot >= 0 (one rank): gamma_new and the scalar after it are finished here from the block
+// partials of slots first_slot, first_slot + 1 (no finalize launch; same bits)
+void cg_direction(int n, int gamma_old_idx, int gamma_new_idx, const double *z, double *p, int first_slot = -1);
 void axpy(int n, double a, const double *x, double *y);                   // y += a x
 void axpy_dev(int n, int scalar_idx, double sign, const double *x, double *y); // y += sign*scalars[idx]*x
 void scale(int n, double a, double *x);

@@ -1864,38 +1864,81 @@ void dot(int n, const double *x, const double *y, int slot)
    k_dot<<<kRedBlocks, 256, 0, STREAM>>>(n, x, y, Context::get().slot(slot));
 }
 
-__global__ __launch_bounds__(256) void k_cg_update(int n, const double *__restrict__ scalars,
-                                                   int gamma_idx, const double *__restrict__ p,
-                                                   const double *__restrict__ s, double *__restrict__ x,
-                                                   double *__restrict__ r, double *__restrict__ partial)
+// sum of one slot of block partials, every thread of a 256-thread block gets it: the arithmetic of k_finalize (same per-thread
+// strides, same block tree), so a kernel that finishes a dot product itself gets the bits the finalize kernel would have stored
+__device__ __forceinline__ double slot_sum_256(const double *__restrict__ p)
 {
-   const double alpha = scalars[gamma_idx] / scalars[S_SP];
+   double s = 0.0;
+   for (int i = threadIdx.x; i < kRedBlocks; i += kRedThreads) s += p[i];
+   return block_sum(s);
+}
+
+// FIN: one rank -- <s,p> is finished here from its block partials (sp_partials) instead of by a finalize launch of its own; every
+// block computes the same sum, block 0 stores it for the host's breakdown test.
+// Z0: the preconditioner's cycle opens with the zero-guess Jacobi sweep z0 = dinv0 .* r (Amg::first_sweep_*): written here, on
+// the r this kernel has just produced, instead of by a pass of its own over r and dinv0 (z0 may alias s: same index, read first)
+template <bool FIN, bool Z0>
+__global__ __launch_bounds__(256) void k_cg_update(int n, double *scalars, int gamma_idx, const double *__restrict__ p,
+                                                   const double *s, double *__restrict__ x, double *__restrict__ r,
+                                                   double *__restrict__ partial, const double *__restrict__ sp_partials,
+                                                   const double *__restrict__ dinv0, double *z0)
+{
+   double sp;
+   if (FIN)
+   {
+      sp = slot_sum_256(sp_partials);
+      if (blockIdx.x == 0 && threadIdx.x == 0) scalars[S_SP] = sp;
+   }
+   else sp = scalars[S_SP];
+   const double alpha = scalars[gamma_idx] / sp;
    double       acc   = 0.0;
    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
    {
       x[i] += alpha * p[i];
       const double ri = r[i] - alpha * s[i];
       r[i]            = ri;
+      if (Z0) z0[i] = dinv0[i] * ri;
       acc += ri * ri;
    }
    acc = block_sum(acc);
    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
-void cg_update(int n, int gamma_idx, const double *p, const double *s, double *x, double *r, int rr_slot)
+void cg_update(int n, int gamma_idx, const double *p, const double *s, double *x, double *r, int rr_slot, int sp_slot, const double *dinv0,
+               double *z0)
 {
    Context &c = Context::get();
-   k_cg_update<<<kRedBlocks, 256, 0, c.stream>>>(n, c.scalars, gamma_idx, p, s, x, r, c.slot(rr_slot));
+   const double *spp = sp_slot >= 0 ? c.slot(sp_slot) : nullptr;
+   if (spp && z0) k_cg_update<true, true><<<kRedBlocks, 256, 0, c.stream>>>(n, c.scalars, gamma_idx, p, s, x, r, c.slot(rr_slot), spp, dinv0, z0);
+   else if (spp) k_cg_update<true, false><<<kRedBlocks, 256, 0, c.stream>>>(n, c.scalars, gamma_idx, p, s, x, r, c.slot(rr_slot), spp, dinv0, z0);
+   else if (z0) k_cg_update<false, true><<<kRedBlocks, 256, 0, c.stream>>>(n, c.scalars, gamma_idx, p, s, x, r, c.slot(rr_slot), spp, dinv0, z0);
+   else k_cg_update<false, false><<<kRedBlocks, 256, 0, c.stream>>>(n, c.scalars, gamma_idx, p, s, x, r, c.slot(rr_slot), spp, dinv0, z0);
 }
 
-__global__ __launch_bounds__(256) void k_cg_dir(int n, const double *__restrict__ scalars, int go,
-                                                int gn, const double *__restrict__ z, double *__restrict__ p)
+// FIN: one rank -- gamma_new = <r,z> (and <r,r> beside it) are finished here from block partials slots first_slot, first_slot + 1
+// into scalars gn, gn + 1, instead of by a finalize launch
+template <bool FIN>
+__global__ __launch_bounds__(256) void k_cg_dir(int n, double *scalars, int go, int gn, const double *__restrict__ z, double *__restrict__ p,
+                                                const double *__restrict__ partials2)
 {
-   const double beta = scalars[gn] / scalars[go];
+   double g;
+   if (FIN)
+   {
+      g = slot_sum_256(partials2);
+      if (blockIdx.x == 0)
+      {
+         const double rr = slot_sum_256(partials2 + kRedBlocks);
+         if (threadIdx.x == 0) { scalars[gn] = g; scalars[gn + 1] = rr; }
+      }
+   }
+   else g = scalars[gn];
+   const double beta = g / scalars[go];
    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = z[i] + beta * p[i];
 }
-void cg_direction(int n, int gamma_old_idx, int gamma_new_idx, const double *z, double *p)
+void cg_direction(int n, int gamma_old_idx, int gamma_new_idx, const double *z, double *p, int first_slot)
 {
-   if (n) k_cg_dir<<<ew_grid(n), 256, 0, STREAM>>>(n, Context::get().scalars, gamma_old_idx, gamma_new_idx, z, p);
+   Context &c = Context::get();
+   if (first_slot >= 0) k_cg_dir<true><<<std::max(ew_grid(n), 1), 256, 0, STREAM>>>(n, c.scalars, gamma_old_idx, gamma_new_idx, z, p, c.slot(first_slot));
+   else if (n) k_cg_dir<false><<<ew_grid(n), 256, 0, STREAM>>>(n, c.scalars, gamma_old_idx, gamma_new_idx, z, p, nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_axpy(int n, double a, const double *__restrict__ x, double *__restrict__ y)

@@ -59,15 +59,30 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
    const size_t vl = std::max<size_t>(op.veclen, 1);
    DArray<double> r(vl), p(vl), s(vl);
 
+   // first-sweep offer of the preconditioner (hda_amg.h FirstSweepFusion): renewed by every application, used by the next update
+   FirstSweepFusion &fs = first_sweep_fusion();
+   fs                   = FirstSweepFusion();
+   const double *z0_dinv = nullptr;
+   double       *z0_dest = nullptr;
+   bool          z0_self = false; // the offered destination is the output vector of the next application
    auto precond = [&](const double *rr, double *zz, int slot) {
       res.precond_calls++;
+      fs.valid = false;
       if (M) M(rr, zz, slot);
       else
       {
          copy(n, rr, zz);
          if (slot >= 0) dot(n, rr, zz, slot);
       }
+      HDA_REQUIRE(!fs.done, "the preconditioner ignored a first sweep it had offered to take from the caller");
+      z0_dinv = fs.valid ? fs.dinv : nullptr;
+      z0_dest = fs.valid ? fs.dest : nullptr;
+      z0_self = fs.valid && fs.dest == nullptr;
+      fs.valid = false;
    };
+   // one rank: the finalize launches of <s,p> and of the <r,z>, <r,r> pair ride on the kernels that consume them (same bits)
+   const char *ffe = getenv("HDA_FUSE_FINALIZE"); // (read per solve: the tests switch it inside one process)
+   const bool  fin = !(ffe && atoi(ffe) == 0) && Comm::world().size == 1;
 
    // bi_prod = <b,b> (two_norm) or <C b, b>
    double bi_prod;
@@ -125,8 +140,9 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
       }
       else
          spmv_dot(A, p.data(), s.data(), p.data(), 0, op.halo);
-      finalize(0, S_SP);
-      cg_update(n, go, p.data(), s.data(), x, r.data(), 3);
+      if (!fin) finalize(0, S_SP);
+      double *z0 = z0_dinv ? (z0_self ? s.data() : z0_dest) : nullptr;
+      cg_update(n, go, p.data(), s.data(), x, r.data(), 3, fin ? 0 : -1, z0_dinv, z0);
       // The stopping test of the two-norm variant needs only <r,r>.  hypre applies the preconditioner
       // before testing, so its last V-cycle is computed and thrown away; here, once the history says the
       // tolerance is within reach, the host waits for <r,r> BEFORE enqueueing that V-cycle and skips it
@@ -169,20 +185,35 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
          read_scalars_async(S_GAMMA0, 5);
          test();
          if (stop) break;
+         fs.done = z0 != nullptr;
          precond(r.data(), s.data(), 2);
-         finalize(2, gn);
-         cg_direction(n, go, gn, s.data(), p.data());
+         if (fin) cg_direction(n, go, gn, s.data(), p.data(), 2); // (finishes slot 3 into rn once more: the same sum)
+         else
+         {
+            finalize(2, gn);
+            cg_direction(n, go, gn, s.data(), p.data());
+         }
          continue;
       }
       if (!fuse_dots) finalize(3, rn);
+      fs.done = z0 != nullptr;
       precond(r.data(), s.data(), 2);
-      if (fuse_dots) finalize_n(2, 2, gn);
-      else finalize(2, gn);
-      read_scalars_async(S_GAMMA0, 5);
-      cg_direction(n, go, gn, s.data(), p.data());
+      if (fin && fuse_dots)
+      {
+         cg_direction(n, go, gn, s.data(), p.data(), 2);
+         read_scalars_async(S_GAMMA0, 5);
+      }
+      else
+      {
+         if (fuse_dots) finalize_n(2, 2, gn);
+         else finalize(2, gn);
+         read_scalars_async(S_GAMMA0, 5);
+         cg_direction(n, go, gn, s.data(), p.data());
+      }
       test();
       if (stop) break;
    }
+   fs = FirstSweepFusion();
    ctx.sync();
    for (size_t e = 0; e + 1 < evs.size(); e += 2)
    {

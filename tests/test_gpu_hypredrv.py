@@ -430,6 +430,26 @@ def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check):
         assert "dist check rank 7" in err  # every rank compared its levels
 
 
+@pytest.mark.parametrize("reorder", [None, "150"])
+def test_prolongation_updates_ghost_copies_one_exchange_less_per_level(tmp_path, reorder):
+    """C1 of SURVEY 2.4, exchanges per cycle: the partitioned setup keeps the P rows of every rank's GHOST fine points
+    (AmgLevel::Pg), the prolongation updates the ghost copies of the iterate with them, and the first post-smoothing sweep runs
+    without a halo exchange of its own: 3 instead of 4 exchanges per partitioned level and V-cycle.  Same arithmetic on the owned
+    rows (the ghost copies hold what the owners hold, computed from the same P rows in the same order), so against
+    HDA_GHOST_PROLONG=0: same iterations, solution to rounding, and exactly vcycles x partitioned levels fewer exchanges.
+    2x2x2 thread ranks: corner and edge neighbours on every level; reorder = 150 forces the solve-phase renumbering onto these
+    small blocks (Pg's owned coarse columns are renamed with their level)."""
+    env = dict(HDA_REPLICATE_ROWS="2000", HDA_DIST_CHECK="0")
+    if reorder:
+        env["HDA_REORDER"] = reorder
+    a, xa, _ = _thread_ranks(tmp_path, "pg1", 40, (2, 2, 2), HDA_GHOST_PROLONG="1", **env)
+    b, xb, _ = _thread_ranks(tmp_path, "pg0", 40, (2, 2, 2), HDA_GHOST_PROLONG="0", **env)
+    assert a["converged"] and a["iters"] == b["iters"] and a["vcycles"] == b["vcycles"]
+    assert np.linalg.norm(xa - xb) <= 1e-10 * np.linalg.norm(xb)
+    assert a["partitioned_levels"] == b["partitioned_levels"] >= 2
+    assert b["exchange"] - a["exchange"] == a["vcycles"] * a["partitioned_levels"]
+
+
 def _dist_solve(tmp_path, tag, world, n, port, **envx):
     out = str(tmp_path / f"{tag}.json")
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_DIST_CHECK="0", **envx)
