@@ -266,8 +266,9 @@ __global__ __launch_bounds__(256) void k_spmv(int n, const int *__restrict__ row
                                               const double *__restrict__ b,
                                               const double *__restrict__ dinv,
                                               const double *__restrict__ w, double *out,
-                                              double *__restrict__ partial)
-{
+                                              double *__restrict__ partial, const double *__restrict__ dinv2 = nullptr,
+                                              double *__restrict__ out2 = nullptr)
+{ // out2 (MODE_PLAIN): a second result out2 = dinv2 .* out, as in k_spmv_stream
    const int  lane = threadIdx.x & (LPR - 1);
    const long G    = (long)gridDim.x * (256 / LPR);
    const long gid  = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256) void k_spmv(int n, const int *__restrict__ row
             o0 = (beta == 0.0) ? alpha * a0 : alpha * a0 + beta * yin[r0];
             if (h1) o1 = (beta == 0.0) ? alpha * a1 : alpha * a1 + beta * yin[r1];
             if (DOT) { acc += o0 * w[r0]; if (h1) acc += o1 * w[r1]; }
+            if (out2) { out2[r0] = dinv2[r0] * o0; if (h1) out2[r1] = dinv2[r1] * o1; }
          }
          else if (MODE == MODE_RESID)
          {
@@ -1183,7 +1185,7 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
                                                   const double *__restrict__ val, const double *__restrict__ x, double alpha, double beta,
                                                   const double *yin, const double *__restrict__ b, const double *__restrict__ dinv,
                                                   const double *__restrict__ w, double *out, double *__restrict__ partial, int nown,
-                                                  int prod_len, const unsigned char *__restrict__ code, const double *__restrict__ dval)
+                                                  int prod_len, const unsigned char *__restrict__ code, const double *__restrict__ dval, int pf)
 {
    extern __shared__ double smem[];
    double *prod = smem, *xs = smem + prod_len;
@@ -1217,7 +1219,30 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
    };
    double pv[E];
    int    pl[E], pu[U];
+   // per-row operands of the lane's FIRST row of a chunk, requested with the chunk's streams (one chunk ahead): the row reduction
+   // then starts on LDS products at once instead of on a round trip for its row pointers, and ends on registers instead of on a
+   // round trip for b, dinv and x[r]  (pf: HDA_WIN_PF, A/B)
+   int    ps = 0, pe = 0;
+   double pb = 0.0, pd = 0.0, px = 0.0;
+   auto lanes_per_row = [](int nr) {
+      int L = 1;
+      while (L < 64 && nr * (L << 1) <= 256) L <<= 1;
+      return L;
+   };
+   auto request_rows = [&](const Chunk &c) {
+      const int nr = c.r1 - c.r0, L = lanes_per_row(nr), rr = tid / L;
+      if (rr < nr)
+      {
+         const int r = c.r0 + rr;
+         ps          = rowptr[r] - c.k0;
+         pe          = rowptr[r + 1] - c.k0;
+         if (MODE == MODE_PLAIN) { if (beta != 0.0) pb = yin[r]; if (DOT) pd = w[r]; }
+         else if (MODE == MODE_RESID) pb = b[r];
+         else { pb = b[r]; pd = dinv[r]; px = x[r]; }
+      }
+   };
    auto request = [&](const Chunk &c) {
+      if (pf) request_rows(c);
 #pragma unroll
       for (int e = 0; e < E; e++)
       {
@@ -1235,6 +1260,8 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
    int   i   = slot;
    Chunk cur = meta(i);
    if (cur.ok) request(cur);
+   int    cps = ps, cpe = pe; // row operands of the chunk being reduced (the request for the next one overwrites ps .. px)
+   double cpb = pb, cpd = pd, cpx = px;
    while (cur.ok)
    {
       const int ne = cur.k1 - cur.k0;
@@ -1264,14 +1291,20 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
       if (nxt.ok) request(nxt);
       __syncthreads();
       // stage 2: L lanes per row, L = largest power of two with rows*L <= 256
+      // (the row operands prefetched for `cur` were overwritten by the request for `nxt` above: keep them)
+      const int    cs = cps, ce = cpe;
+      const double cb = cpb, cd = cpd, cx = cpx;
+      cps = ps; cpe = pe; cpb = pb; cpd = pd; cpx = px;
       const int nr = cur.r1 - cur.r0;
-      int       L  = 1;
-      while (L < 64 && nr * (L << 1) <= 256) L <<= 1;
+      const int L  = lanes_per_row(nr);
       const int lane = tid & (L - 1);
+      bool first = pf;
       for (int rr = tid / L; rr < nr; rr += 256 / L)
       {
          const int r = cur.r0 + rr;
-         const int s = rowptr[r] - cur.k0, e = rowptr[r + 1] - cur.k0;
+         int       s, e;
+         if (first) { s = cs; e = ce; }
+         else { s = rowptr[r] - cur.k0; e = rowptr[r + 1] - cur.k0; }
          double    sum = 0.0;
          for (int q = s + lane; q < e; q += L) sum += prod[q];
          for (int o = L >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -1280,18 +1313,19 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
             double o0;
             if (MODE == MODE_PLAIN)
             {
-               o0 = (beta == 0.0) ? alpha * sum : alpha * sum + beta * yin[r];
-               if (DOT) acc += o0 * w[r];
+               o0 = (beta == 0.0) ? alpha * sum : alpha * sum + beta * (first ? cb : yin[r]);
+               if (DOT) acc += o0 * (first ? cd : w[r]);
             }
-            else if (MODE == MODE_RESID) o0 = b[r] - sum;
+            else if (MODE == MODE_RESID) o0 = (first ? cb : b[r]) - sum;
             else
             {
-               const double br = b[r];
-               o0              = x[r] + dinv[r] * (br - sum);
+               const double br = first ? cb : b[r];
+               o0              = (first ? cx : x[r]) + (first ? cd : dinv[r]) * (br - sum);
                if (DOT) acc += br * o0;
             }
             out[r] = o0;
          }
+         first = false;
       }
       __syncthreads();
       cur = nxt;
@@ -1536,6 +1570,22 @@ static int spmv_mode()
    return m;
 }
 
+// row operands of the windowed kernel requested one chunk ahead (HDA_WIN_PF=0: loaded in the row reduction).  Same-box A/B, three
+// rounds (tools/gpurun/r03_f.sh): level-1 Jacobi sweep at 256^3 0.4562 -> 0.4512 ms (-1.1 %), solve 34.53 -> 34.40 ms.
+static int win_pf()
+{
+   static const int v = getenv("HDA_WIN_PF") ? atoi(getenv("HDA_WIN_PF")) : 1;
+   return v;
+}
+// entries below which a product runs on the lane-group kernel (HDA_SMALL_NNZ; 0 = never).  Same-box A/B, two rounds each
+// (tools/gpurun/r03_e.sh): 1 000 000 entries: 64^3 2.12 -> 1.96 ms per solve, 128^3 5.50 -> 5.25, 256^3 34.66 -> 34.33;
+// 100 000 and 4 000 000 both a little behind it.
+static long small_nnz()
+{
+   static const long v = getenv("HDA_SMALL_NNZ") ? atol(getenv("HDA_SMALL_NNZ")) : 1000000;
+   return v;
+}
+
 // grid of a product that shares the chip with its own halo transfer: one workgroup slot per CU is left free
 // (7 of 8 resident 256-thread workgroups), or the transfer kernel would only start when the product ends
 static int overlap_grid()
@@ -1592,7 +1642,12 @@ static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
                                                                       A.col.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, 0);
       return true;
    }
-   if (spmv_mode() == 0 && A.maxrow <= kMaxRowLds)
+   // Small operators (the coarse levels of a hierarchy; every level of a small problem) are latency-bound, not bandwidth-bound: what
+   // a product costs there is its chain of dependent memory round trips.  The lane-group kernel has three (row pointer -> entries ->
+   // x); the chunked LDS kernels five and two barriers (chunk table -> row pointers -> entries -> x -> products in LDS -> row
+   // pointers again).  Below small_nnz() entries the lane-group kernel runs (whole products only: it has no owned-column form).
+   const bool small = !split && A.coded != 1 && A.nnz <= small_nnz() && A.nnz > 0;
+   if (spmv_mode() == 0 && A.maxrow <= kMaxRowLds && !small)
    {
       ensure_window(A);
       if (A.win == 1)
@@ -1603,7 +1658,7 @@ static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
 #define HDA_WIN(VCF, SPF, CODE, DICT)                                                                                                   \
    k_spmv_win<MODE, DOT, VCF, SPF><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(),     \
                                                               A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen,  \
-                                                              CODE, DICT)
+                                                              CODE, DICT, win_pf())
          if (A.coded == 2)
          {
             if (split) { HDA_WIN(true, true, A.code.data(), A.dict_val.data()); }
@@ -1648,10 +1703,18 @@ static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
    const int lpr  = pick_lpr(A);
    long      need = ((long)A.nrows * lpr + 511) / 512; // two rows per group
    int       grid = DOT ? kRedBlocks : (int)std::min<long>(std::max<long>(need, 1), kRedBlocks);
+   const double *vepi_d = nullptr;
+   double       *vepi_o = nullptr;
+   if (MODE == MODE_PLAIN && !DOT && g_epilogue.out2)
+   { // the scaled second result of spmv_with_scaled_copy
+      vepi_d = g_epilogue.dinv2;
+      vepi_o = g_epilogue.out2;
+      g_epilogue.done = true;
+   }
 #define HDA_LAUNCH(L)                                                                         \
    k_spmv<L, MODE, DOT><<<grid, 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(),      \
                                                   A.val.data(), x, alpha, beta, yin, b, dinv,  \
-                                                  w, out, partial)
+                                                  w, out, partial, vepi_d, vepi_o)
    switch (lpr)
    {
       case 4: HDA_LAUNCH(4); break;

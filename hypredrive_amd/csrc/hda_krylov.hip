@@ -81,8 +81,12 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
       fs.valid = false;
    };
    // one rank: the finalize launches of <s,p> and of the <r,z>, <r,r> pair ride on the kernels that consume them (same bits)
+   // HDA_FUSE_FINALIZE: 0 none, 1 (default) <s,p> inside the update kernel, 2 also the <r,z>, <r,r> pair inside the direction kernel
+   // (measured slower: the host's read-back of <r,r> then waits for the direction kernel instead of running beside it, and the
+   // device idles while the host catches up -- 256^3: 33.9 vs 34.4 ms, 64^3: 2.02 vs 2.09 ms, profiles/r03_kernel_experiments.md)
    const char *ffe = getenv("HDA_FUSE_FINALIZE"); // (read per solve: the tests switch it inside one process)
-   const bool  fin = !(ffe && atoi(ffe) == 0) && Comm::world().size == 1;
+   const int   fl  = (Comm::world().size == 1) ? (ffe ? atoi(ffe) : 1) : 0;
+   const bool  fin = fl >= 1, fin2 = fl >= 2;
 
    // bi_prod = <b,b> (two_norm) or <C b, b>
    double bi_prod;
@@ -187,7 +191,7 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
          if (stop) break;
          fs.done = z0 != nullptr;
          precond(r.data(), s.data(), 2);
-         if (fin) cg_direction(n, go, gn, s.data(), p.data(), 2); // (finishes slot 3 into rn once more: the same sum)
+         if (fin2) cg_direction(n, go, gn, s.data(), p.data(), 2); // (finishes slot 3 into rn once more: the same sum)
          else
          {
             finalize(2, gn);
@@ -198,7 +202,7 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
       if (!fuse_dots) finalize(3, rn);
       fs.done = z0 != nullptr;
       precond(r.data(), s.data(), 2);
-      if (fin && fuse_dots)
+      if (fin2 && fuse_dots)
       {
          cg_direction(n, go, gn, s.data(), p.data(), 2);
          read_scalars_async(S_GAMMA0, 5);

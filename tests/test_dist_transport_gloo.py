@@ -9,6 +9,8 @@ import sys
 
 import pytest
 
+from conftest import free_port  # a port nobody listens on: two suites on one host do not collide
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -17,7 +19,7 @@ def test_staged_transport_partitioned_spmv(tmp_path, world, port):
     out = str(tmp_path / "res.json")
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "transport", out]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "transport", out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert json.load(open(out)) == {"ok": True, "world": world}

@@ -10,6 +10,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from conftest import free_port  # a port nobody listens on: two suites on one host do not collide
 import scipy.sparse as sp
 
 pytestmark = pytest.mark.gpu
@@ -377,7 +379,7 @@ def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solve
         env["HDA_REORDER"] = str(reorder)
         env["HDA_DIST_CHECK"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "solve", out, str(n), solver]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "solve", out, str(n), solver]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     res = json.load(open(out))
@@ -454,7 +456,7 @@ def _dist_solve(tmp_path, tag, world, n, port, **envx):
     out = str(tmp_path / f"{tag}.json")
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_DIST_CHECK="0", **envx)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "solve", out, str(n), "pcg"]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "solve", out, str(n), "pcg"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     return json.load(open(out)), np.concatenate([np.load(f"{out}.x{k}.npy") for k in range(world)])
@@ -515,7 +517,7 @@ def test_row_partitioned_irregular_csr(hd, tmp_path, world, n, seed, rep_rows):
     out = str(tmp_path / "res.json")
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS=str(rep_rows), HDA_DIST_CHECK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29660 + world), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     assert "dist check rank 0 level 0 P: identical pattern, max rel diff 0.00e+00" in r.stderr
@@ -927,7 +929,7 @@ def test_row_partitioned_ilu_is_block_jacobi(hd, orc, tmp_path, world, kind):
     yaml = ILU_YAML.format(mi=1, ts=1) if kind == "ilu" else AMG_ILU_YAML.format(nl=1, ns=1, ts=1)
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS="400", HDA_TEST_YAML=yaml)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29670 + world), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     res = json.load(open(out))
@@ -1175,7 +1177,7 @@ def test_row_partitioned_mgr(hd, orc, tmp_path, world, case, rep_rows):
     out = str(tmp_path / "res.json")
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS=str(rep_rows), HDA_TEST_YAML=yaml)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29680 + world), os.path.join(ROOT, "tests", "dist_worker.py"), "mgr", out, str(n)]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "mgr", out, str(n)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     res = json.load(open(out))
@@ -1290,7 +1292,7 @@ def test_row_partitioned_chebyshev(hd, tmp_path):
     yaml = "solver: pcg\npreconditioner:\n  amg:\n    relaxation:\n      down_type: 16\n      up_type: 16\n"
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS="500", HDA_TEST_YAML=yaml)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", "29691", os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     res = json.load(open(out))
@@ -1485,7 +1487,7 @@ def test_row_partitioned_scaling(hd, orc, tmp_path):
     yaml = "solver:\n  pcg:\n    max_iter: 100\n  scaling:\n    enabled: on\n    type: dofmap_custom\n    custom_values: [2.0, 0.5, 3.0, 1.5]\npreconditioner: amg\n"
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS="400", HDA_TEST_YAML=yaml, HDA_TEST_DOFMAP_MOD="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", "29697", os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(n), str(seed)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     res = json.load(open(out))

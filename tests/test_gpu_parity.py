@@ -130,7 +130,7 @@ def test_pcg_kernel_fusions_are_bitwise_neutral(hd, monkeypatch, sweeps):
     A = hd.lap7(n, n, n)
     b = np.random.default_rng(5).standard_normal(n ** 3)
     out = {}
-    for fin, z0 in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+    for fin, z0 in (("1", "1"), ("2", "1"), ("0", "1"), ("2", "0"), ("0", "0")):
         monkeypatch.setenv("HDA_FUSE_FINALIZE", fin)
         monkeypatch.setenv("HDA_FUSE_Z0", z0)
         amg = hd.Amg(A, hd.AmgParams.default(sweeps_down=sweeps[0], sweeps_up=sweeps[1]))
