@@ -25,7 +25,8 @@ class AmgParams(C.Structure):
                 ("cheby_order", C.c_int), ("cheby_eig_est", C.c_int), ("cheby_variant", C.c_int), ("cheby_scale", C.c_int),
                 ("cheby_fraction", C.c_double),
                 ("smooth_num_levels", C.c_int), ("smooth_num_sweeps", C.c_int),
-                ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int)]
+                ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int),
+                ("agg_num_levels", C.c_int), ("agg_num_paths", C.c_int), ("agg_interp_type", C.c_int)]
 
     @staticmethod
     def default(**kw):
@@ -76,6 +77,7 @@ SYMBOLS = [
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
     "hda_thread_ranks_lap7", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
+    "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass",
 ]
 
 
@@ -111,6 +113,9 @@ def load():
     L.hda_interp_extpi.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
     L.hda_interp_direct.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
     L.hda_rap.argtypes = [vp, vp, P(vp)]
+    L.hda_second_strength.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, P(vp)]
+    L.hda_coarsen_second_pass.argtypes = [vp, P(C.c_ubyte), C.c_int, C.c_uint64, C.c_int, ip]
+    L.hda_interp_multipass.argtypes = [vp, P(C.c_ubyte), ip, P(vp)]
     L.hda_transpose.argtypes = [vp, P(vp)]
     L.hda_spgemm.argtypes = [vp, vp, P(vp)]
     L.hda_amg_create.argtypes = [P(AmgParams), vp, P(vp)]
@@ -265,6 +270,29 @@ class Csr:
         out = C.c_void_p()
         _check(load().hda_interp_direct(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cfa), pmax,
                                         trunc_factor, C.byref(out)))
+        return Csr(out)
+
+    def second_strength(self, smask, cf, num_paths=1):
+        """aggressive coarsening: strong connections of distance <= 2 among the C points of cf (values = number of paths)"""
+        sm = np.ascontiguousarray(np.concatenate([smask, np.zeros(1, np.uint8)]), dtype=np.uint8)
+        cfa = np.ascontiguousarray(np.concatenate([cf, np.zeros(1, np.int32)]), dtype=np.int32)
+        out = C.c_void_p()
+        _check(load().hda_second_strength(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cfa), num_paths, C.byref(out)))
+        return Csr(out)
+
+    def coarsen_second_pass(self, smask, cf, num_paths=1, seed=2747, level=0):
+        """aggressive coarsening: the second PMIS pass; returns the updated C/F marker"""
+        sm = np.ascontiguousarray(np.concatenate([smask, np.zeros(1, np.uint8)]), dtype=np.uint8)
+        cfa = np.ascontiguousarray(np.concatenate([cf, np.zeros(1, np.int32)]), dtype=np.int32)
+        _check(load().hda_coarsen_second_pass(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), num_paths, seed, level, _ip(cfa)))
+        return cfa[:-1].copy()
+
+    def interp_multipass(self, smask, cf):
+        """aggressive coarsening: multipass interpolation (aggressive.prolongation_type 4)"""
+        sm = np.ascontiguousarray(np.concatenate([smask, np.zeros(1, np.uint8)]), dtype=np.uint8)
+        cfa = np.ascontiguousarray(np.concatenate([cf, np.zeros(1, np.int32)]), dtype=np.int32)
+        out = C.c_void_p()
+        _check(load().hda_interp_multipass(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cfa), C.byref(out)))
         return Csr(out)
 
     def rap(self, P):

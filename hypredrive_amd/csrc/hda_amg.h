@@ -47,6 +47,9 @@ struct AmgParams {
    // sweeps there; one smoothing step = smooth_num_sweeps iterations u += M^-1 (f - A u)
    int       smooth_type = 5, smooth_num_levels = 0, smooth_num_sweeps = 1;
    IluParams ilu;
+   // aggressive coarsening (AMGagg_args, amg.c:160-173, 938-944; hda_amg_agg.hip): on the first agg_num_levels levels a second PMIS
+   // pass over the distance-two strength graph (>= agg_num_paths paths of length <= 2) and multipass interpolation (type 4, untruncated)
+   int agg_num_levels = 0, agg_num_paths = 1, agg_interp_type = 4;
 };
 
 // dependency levels of the local pattern for Gauss-Seidel sweeps (hda_gs.hip)
@@ -313,6 +316,11 @@ void amg_pmis(const DCsr &A, const unsigned char *smask, uint64_t seed, int leve
 // then InterpTruncation: P (nrows x nc), rows column-sorted.
 void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax, // trailing dof: as amg_strength
                       double trunc_factor, DCsr &P, const int *dof = nullptr, int interp_type = 6);
+// aggressive coarsening (hda_amg_agg.hip): second strength graph among the C points of cf (c1: rank of every C point), second PMIS
+// pass folded into cf, multipass interpolation
+void amg_second_strength(const DCsr &A, const unsigned char *smask, const int *cf, int num_paths, DCsr &S2, DArray<int> &c1);
+void amg_coarsen_second_pass(const DCsr &A, const unsigned char *smask, int num_paths, uint64_t seed, int level, int *cf);
+void amg_interp_multipass(const DCsr &A, const unsigned char *smask, const int *cf, DCsr &P);
 // hypre_ParCSRMatMat-style product C = X*Y, deterministic accumulation order, rows sorted.
 void spgemm(const DCsr &X, const DCsr &Y, DCsr &C);
 // hypre_BoomerAMGBuildCoarseOperator: Ac = R*(A*P) with R = P^T

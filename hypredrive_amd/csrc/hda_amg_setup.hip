@@ -2131,6 +2131,8 @@ void Amg::build_hierarchy(const DCsr &A)
    HDA_REQUIRE(prm.relax_coarse == 9 || known(prm.relax_coarse), "coarse relaxation must be Gaussian elimination (9), Jacobi, hybrid Gauss-Seidel or Chebyshev");
    HDA_REQUIRE(prm.cheby_variant == 0 || (prm.relax_down != 16 && prm.relax_up != 16 && prm.relax_coarse != 16),
                "Chebyshev smoother: only variant 0 (the standard polynomial) is implemented");
+   HDA_REQUIRE(prm.agg_num_levels <= 0 || (prm.agg_interp_type == 4 && prm.num_functions <= 1),
+               "aggressive coarsening: multipass interpolation (aggressive.prolongation_type 4) on a scalar problem is what is implemented");
    A0 = &A;
    a0_dims[0] = A.nrows; a0_dims[1] = A.ncols; a0_dims[2] = A.nnz;
    levels.clear();
@@ -2174,10 +2176,13 @@ void Amg::build_hierarchy(const DCsr &A)
       auto t1 = tick();
       if (prm.coarsen_type == 10) amg_rs_first_pass(Al, sm.data(), ns.data(), cf.data());
       else pmis_core(Al, sm.data(), ns.data(), prm.seed, lvl + level0, 0, cf.data());
-      HDA_TRACE("level %d: interp", lvl);
+      const bool aggressive = lvl + level0 < prm.agg_num_levels;
+      if (aggressive) amg_coarsen_second_pass(Al, sm.data(), prm.agg_num_paths, prm.seed, lvl + level0, cf.data());
+      HDA_TRACE("level %d: interp%s", lvl, aggressive ? " (aggressive level: multipass)" : "");
       auto t2 = tick();
       DCsr P;
-      amg_interp_extpi(Al, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, P, dof, prm.interp_type);
+      if (aggressive) amg_interp_multipass(Al, sm.data(), cf.data(), P);
+      else amg_interp_extpi(Al, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, P, dof, prm.interp_type);
       auto t3 = tick();
       const int nc = P.ncols;
       if (nc == 0 || nc == n || nc < prm.min_coarse_size) break;
@@ -2283,6 +2288,7 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
                      const std::vector<long long> &ghost_gids0)
 {
    Comm &cm = Comm::world();
+   HDA_REQUIRE(prm.agg_num_levels <= 0, "aggressive coarsening is implemented on one rank only (the second strength graph reaches two ghost layers deep)");
    HDA_TRACE("setup_dist: gathering the operator on %d ranks (%s)", cm.size, cm.name());
    DCsr G0;
    gather_global(Aloc, part0, ghost_gids0, G0);
@@ -3691,6 +3697,7 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
    Comm &cm = Comm::world();
    HDA_REQUIRE(prm.coarsen_type == 8 && (prm.interp_type == 6 || prm.interp_type == 17) && prm.num_functions <= 1,
                "partitioned setup: scalar PMIS + extended+i only");
+   HDA_REQUIRE(prm.agg_num_levels <= 0, "aggressive coarsening is implemented on one rank only (the second strength graph reaches two ghost layers deep)");
    const long long rep_rows = replicate_rows(cm.size);
    const bool verbose = getenv("HDA_VERBOSE") != nullptr;
    // HDA_GHOST_PROLONG=0: the prolongation leaves ghost copies alone and the post-smoothing sweep refreshes them (4 exchanges per

@@ -87,6 +87,7 @@ extern "C" void hda_amg_default_params(hda_amg_params *p)
    p->cheby_fraction = d.cheby_fraction;
    p->smooth_num_levels = d.smooth_num_levels; p->smooth_num_sweeps = d.smooth_num_sweeps;
    p->ilu_tri_solve = d.ilu.tri_solve; p->ilu_lower_it = d.ilu.lower_it; p->ilu_upper_it = d.ilu.upper_it;
+   p->agg_num_levels = d.agg_num_levels; p->agg_num_paths = d.agg_num_paths; p->agg_interp_type = d.agg_interp_type;
 }
 extern "C" void hda_krylov_default_params(hda_krylov_params *p, int gmres)
 {
@@ -108,6 +109,7 @@ static AmgParams to_params(const hda_amg_params *p)
    a.cheby_fraction = p->cheby_fraction;
    a.smooth_num_levels = p->smooth_num_levels; a.smooth_num_sweeps = p->smooth_num_sweeps;
    a.ilu.tri_solve = p->ilu_tri_solve; a.ilu.lower_it = p->ilu_lower_it; a.ilu.upper_it = p->ilu_upper_it;
+   a.agg_num_levels = p->agg_num_levels; a.agg_num_paths = p->agg_num_paths; a.agg_interp_type = p->agg_interp_type;
    return a;
 }
 static KrylovParams to_kparams(const hda_krylov_params *p)
@@ -333,6 +335,48 @@ extern "C" int hda_interp_direct(hda_csr_t A, const unsigned char *smask, const 
    dcf.upload(cf, (size_t)std::max(m.nrows, 1));
    auto h = std::make_unique<hda_csr_s>();
    amg_interp_extpi(m, sm.data(), dcf.data(), pmax, trunc_factor, h->m, nullptr, 3);
+   Context::get().sync();
+   *P = h.release();
+   HDA_CATCH
+}
+
+// aggressive coarsening pieces (hda_amg_agg.hip), one entry per stage for the per-kernel parity tests
+extern "C" int hda_second_strength(hda_csr_t A, const unsigned char *smask, const int *cf, int num_paths, hda_csr_t *S2)
+{
+   HDA_TRY
+   const DCsr           &m = A->get();
+   DArray<unsigned char> sm;
+   DArray<int>           dcf, c1;
+   sm.upload(smask, (size_t)std::max(m.nnz, 1));
+   dcf.upload(cf, (size_t)std::max(m.nrows, 1));
+   auto h = std::make_unique<hda_csr_s>();
+   amg_second_strength(m, sm.data(), dcf.data(), num_paths, h->m, c1);
+   Context::get().sync();
+   *S2 = h.release();
+   HDA_CATCH
+}
+extern "C" int hda_coarsen_second_pass(hda_csr_t A, const unsigned char *smask, int num_paths, uint64_t seed, int level, int *cf)
+{
+   HDA_TRY
+   const DCsr           &m = A->get();
+   DArray<unsigned char> sm;
+   DArray<int>           dcf;
+   sm.upload(smask, (size_t)std::max(m.nnz, 1));
+   dcf.upload(cf, (size_t)std::max(m.nrows, 1));
+   amg_coarsen_second_pass(m, sm.data(), num_paths, seed, level, dcf.data());
+   dcf.download(cf, (size_t)m.nrows);
+   HDA_CATCH
+}
+extern "C" int hda_interp_multipass(hda_csr_t A, const unsigned char *smask, const int *cf, hda_csr_t *P)
+{
+   HDA_TRY
+   const DCsr           &m = A->get();
+   DArray<unsigned char> sm;
+   DArray<int>           dcf;
+   sm.upload(smask, (size_t)std::max(m.nnz, 1));
+   dcf.upload(cf, (size_t)std::max(m.nrows, 1));
+   auto h = std::make_unique<hda_csr_s>();
+   amg_interp_multipass(m, sm.data(), dcf.data(), h->m);
    Context::get().sync();
    *P = h.release();
    HDA_CATCH

@@ -1084,13 +1084,15 @@ HY_SETTER(HYPRE_BoomerAMGSetILUDroptol, HYPRE_Real, (void)v)   // threshold vari
 HY_SETTER(HYPRE_BoomerAMGSetILUMaxRowNnz, HYPRE_Int, (void)v)  // threshold variants only
 HY_SETTER(HYPRE_BoomerAMGSetILUMaxIter, HYPRE_Int, s->ap.smooth_num_sweeps = v) // amg.c:921 passes smoother.num_sweeps
 HY_SETTER(HYPRE_BoomerAMGSetSmoothNumLevels, HYPRE_Int, s->smooth_num_levels = v)
+// aggressive coarsening (reference src/internal/amg.c:938-944): levels, paths and the multipass interpolation are built
+// (hda_amg_agg.hip); a truncation of the aggressive levels' interpolation or a two-stage (P12) type is refused at Setup
 HY_SETTER(HYPRE_BoomerAMGSetAggNumLevels, HYPRE_Int, s->agg_num_levels = v)
-HY_SETTER(HYPRE_BoomerAMGSetAggInterpType, HYPRE_Int, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetAggTruncFactor, HYPRE_Real, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetAggP12TruncFactor, HYPRE_Real, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetAggPMaxElmts, HYPRE_Int, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetAggP12MaxElmts, HYPRE_Int, (void)v)
-HY_SETTER(HYPRE_BoomerAMGSetNumPaths, HYPRE_Int, (void)v)
+HY_SETTER(HYPRE_BoomerAMGSetAggInterpType, HYPRE_Int, s->ap.agg_interp_type = v)
+HY_SETTER(HYPRE_BoomerAMGSetAggTruncFactor, HYPRE_Real, s->agg_trunc[0] = v)
+HY_SETTER(HYPRE_BoomerAMGSetAggP12TruncFactor, HYPRE_Real, s->agg_trunc[1] = v)
+HY_SETTER(HYPRE_BoomerAMGSetAggPMaxElmts, HYPRE_Int, s->agg_trunc[2] = v)
+HY_SETTER(HYPRE_BoomerAMGSetAggP12MaxElmts, HYPRE_Int, s->agg_trunc[3] = v)
+HY_SETTER(HYPRE_BoomerAMGSetNumPaths, HYPRE_Int, s->ap.agg_num_paths = v)
 HY_SETTER(HYPRE_BoomerAMGSetRAP2, HYPRE_Int, (void)v)
 HY_SETTER(HYPRE_BoomerAMGSetModuleRAP2, HYPRE_Int, (void)v)
 HY_SETTER(HYPRE_BoomerAMGSetKeepTranspose, HYPRE_Int, (void)v)
@@ -1137,7 +1139,14 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    HDA_REQUIRE(s && s->kind == HDA_SOLVER_AMG, "BoomerAMGSetup: not a BoomerAMG handle");
    HDA_REQUIRE(A && A->assembled, "BoomerAMGSetup needs an assembled matrix");
    // features of the reference's parameter surface that this build does not implement
-   HDA_REQUIRE(s->agg_num_levels == 0, "aggressive coarsening (aggressive.num_levels > 0) is not implemented on MI355X yet");
+   s->ap.agg_num_levels = std::max(s->agg_num_levels, 0);
+   if (s->ap.agg_num_levels > 0)
+   {
+      HDA_REQUIRE(s->ap.agg_interp_type == 4, "aggressive coarsening: only multipass interpolation (aggressive.prolongation_type 4 / multipass) is implemented on MI355X");
+      HDA_REQUIRE(s->agg_trunc[0] == 0.0 && s->agg_trunc[1] == 0.0 && s->agg_trunc[2] == 0.0 && s->agg_trunc[3] == 0.0,
+                  "aggressive coarsening: truncation of the aggressive levels' interpolation (aggressive.max_nnz_row / trunc_factor / P12_*) is not implemented on MI355X");
+      HDA_REQUIRE(Comm::world().size == 1, "aggressive coarsening is implemented on one rank only");
+   }
    if (s->smooth_num_levels > 0)
    {
       HDA_REQUIRE(s->smooth_type == 5, "complex smoother: only ILU (smoother.type ilu) is implemented on MI355X; FSAI, Schwarz, Pilut, ParaSails, Euclid are not");

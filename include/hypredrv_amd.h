@@ -46,6 +46,9 @@ typedef struct {
    /* complex smoother (src/internal/amg.c:899-921), ILU only: bj-iluk, fill 0, natural order on levels < smooth_num_levels */
    int      smooth_num_levels, smooth_num_sweeps;
    int      ilu_tri_solve, ilu_lower_it, ilu_upper_it; /* ILU_args tri_solve / lower_jac_iters / upper_jac_iters (ilu.c:21-23) */
+   /* AMGagg_args (src/internal/amg.c:160-173, forwarded at :938-944): aggressive coarsening on the first agg_num_levels levels
+    * (second PMIS pass over the graph of >= agg_num_paths paths of length <= 2), multipass interpolation (agg_interp_type 4) there */
+   int      agg_num_levels, agg_num_paths, agg_interp_type;
 } hda_amg_params;
 
 /* PCG_args src/internal/pcg.c:15-25 / GMRES_args src/internal/gmres.c:16-27 */
@@ -102,6 +105,12 @@ int hda_interp_direct(hda_csr_t A, const unsigned char *smask, const int *cf, in
                       double trunc_factor, hda_csr_t *P);
 /* hypre_BoomerAMGBuildCoarseOperator (P^T A P) */
 int hda_rap(hda_csr_t A, hda_csr_t P, hda_csr_t *Ac);
+/* aggressive coarsening, stage by stage (HYPRE_BoomerAMGSetAggNumLevels / SetNumPaths / SetAggInterpType 4; hypre_BoomerAMGCreate2ndS,
+ * second PMIS pass, hypre_BoomerAMGBuildMultipass): S2 = strong connections of distance <= 2 among the C points of cf (values = number
+ * of paths); the second pass updates cf in place; multipass P for a given splitting */
+int hda_second_strength(hda_csr_t A, const unsigned char *smask, const int *cf, int num_paths, hda_csr_t *S2);
+int hda_coarsen_second_pass(hda_csr_t A, const unsigned char *smask, int num_paths, uint64_t seed, int level, int *cf);
+int hda_interp_multipass(hda_csr_t A, const unsigned char *smask, const int *cf, hda_csr_t *P);
 int hda_transpose(hda_csr_t A, hda_csr_t *T);
 int hda_spgemm(hda_csr_t X, hda_csr_t Y, hda_csr_t *C);
 

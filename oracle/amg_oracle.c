@@ -45,6 +45,7 @@ orc_amg_default_params(orc_amg_params *p, int gpu_defaults)
    p->seed            = 2747;
    p->cheby_order = 2; p->cheby_eig_est = 10; p->cheby_variant = 0; p->cheby_scale = 1; p->cheby_fraction = 0.3;
    p->num_functions   = 1;
+   p->agg_num_levels = 0; p->agg_num_paths = 1; p->agg_interp_type = 4; /* amg.c:164-171 */
 }
 
 /* src/internal/pcg.c:15-25, src/internal/gmres.c:16-27 */
@@ -1090,6 +1091,184 @@ orc_rap(const orc_csr *A, const orc_csr *P)
 }
 
 
+/* ------------------------------------------------------------------ aggressive coarsening
+ * HYPRE_BoomerAMGSetAggNumLevels / SetNumPaths / SetAggInterpType as forwarded by src/internal/amg.c:938-944.  hypre is not in the
+ * reference tree and no checked-in output uses these options: restated from the published method (Stueben 1999, "aggressive
+ * coarsening" A1 / A2 and "multipass interpolation"; Yang 2010, "On long-range interpolation operators for aggressive coarsening").
+ * PARITY UNPINNED.
+ *
+ * Second strength graph: C points i, j of a first coarsening are strongly n-connected when at least num_paths paths of length <= 2
+ * lead from i to j along strong connections (the direct connection counts as one path, every intermediate point k with i -> k -> j
+ * as one).  A second PMIS pass over that graph keeps a subset of the first pass's C points. */
+orc_csr *
+orc_second_strength(const orc_csr *A, const unsigned char *smask, const int *cf, int num_paths)
+{
+   const int n = A->nrows;
+   int *c1 = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+   int  n1 = 0;
+   for (int i = 0; i < n; i++) c1[i] = (cf[i] == ORC_C_PT) ? n1++ : -1;
+   /* S restricted to C rows (n1 x n, unit values) and S restricted to C columns (n x n1): paths of length two = their product */
+   int nsr = 0, nsc = 0;
+   for (int i = 0; i < n; i++)
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         if (smask[k]) { nsr += (c1[i] >= 0); nsc += (c1[A->col[k]] >= 0); }
+   orc_csr *Sr = orc_csr_alloc(n1, n, nsr), *Sc = orc_csr_alloc(n, n1, nsc), *D = orc_csr_alloc(n1, n1, nsr);
+   int a = 0, b = 0, d = 0;
+   for (int i = 0; i < n; i++)
+   {
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+      {
+         if (!smask[k]) continue;
+         const int j = A->col[k];
+         if (c1[i] >= 0) { Sr->col[a] = j; Sr->val[a++] = 1.0; }
+         if (c1[j] >= 0) { Sc->col[b] = c1[j]; Sc->val[b++] = 1.0; }
+         if (c1[i] >= 0 && c1[j] >= 0) { D->col[d] = c1[j]; D->val[d++] = 1.0; }
+      }
+      if (c1[i] >= 0) { Sr->rowptr[c1[i] + 1] = a; D->rowptr[c1[i] + 1] = d; }
+      Sc->rowptr[i + 1] = b;
+   }
+   orc_csr *T = spgemm(Sr, Sc); /* n1 x n1: number of two-step paths */
+   /* S2 = entries of T + D with at least num_paths paths, diagonal dropped; rows column-sorted (both operands are) */
+   int cap = T->rowptr[n1] + D->rowptr[n1];
+   orc_csr *S2 = orc_csr_alloc(n1, n1, cap);
+   int q = 0;
+   for (int i = 0; i < n1; i++)
+   {
+      int t = T->rowptr[i], te = T->rowptr[i + 1], e = D->rowptr[i], ee = D->rowptr[i + 1];
+      while (t < te || e < ee)
+      {
+         const int jt = (t < te) ? T->col[t] : 0x7fffffff, jd = (e < ee) ? D->col[e] : 0x7fffffff, j = jt < jd ? jt : jd;
+         double cnt = 0.0;
+         if (jt == j) cnt += T->val[t++];
+         if (jd == j) cnt += D->val[e++];
+         if (j != i && cnt >= (double)num_paths) { S2->col[q] = j; S2->val[q++] = cnt; }
+      }
+      S2->rowptr[i + 1] = q;
+   }
+   orc_csr_free(Sr); orc_csr_free(Sc); orc_csr_free(D); orc_csr_free(T);
+   free(c1);
+   return S2;
+}
+
+/* second coarsening of an aggressive level: PMIS over the second strength graph of cf's C points (every entry strong; tie-break
+ * weights hash the C point's rank among them under the level salt + 64); C points that become F there become F points of the level.
+ * A C point without any second-graph neighbour stays C. */
+void
+orc_coarsen_second_pass(const orc_csr *A, const unsigned char *smask, int num_paths, uint64_t seed, int level, int *cf)
+{
+   const int n = A->nrows;
+   orc_csr  *S2 = orc_second_strength(A, smask, cf, num_paths);
+   const int n1 = S2->nrows, nnz2 = S2->rowptr[n1];
+   unsigned char *all = (unsigned char *)malloc((size_t)(nnz2 > 0 ? nnz2 : 1));
+   memset(all, 1, (size_t)(nnz2 > 0 ? nnz2 : 1));
+   int *cf2 = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1));
+   orc_pmis(S2, all, seed, level + 64, 0, cf2);
+   int q = 0;
+   for (int i = 0; i < n; i++)
+      if (cf[i] == ORC_C_PT)
+      {
+         if (cf2[q] == ORC_F_PT) cf[i] = ORC_F_PT;
+         q++;
+      }
+   free(all); free(cf2);
+   orc_csr_free(S2);
+}
+
+/* Multipass interpolation (hypre agg_interp_type 4).  Pass 0: C points (identity).  Pass 1: F points with a strong C neighbour,
+ * direct interpolation w_ij = alfa_i a_ij over the strong C neighbours, alfa_i = -(sum of ALL off-diagonals of row i) /
+ * (a_ii * sum over those neighbours) -- constants are reproduced.  Pass p >= 2: F points with a strong neighbour of pass p - 1
+ * interpolate THROUGH those neighbours' rows: w_i = alfa_i sum_k a_ik w_k with the same alfa over the pass-(p-1) strong neighbours.
+ * Points no pass reaches (and special F points) get empty rows.  Passes >= 2 are formed as sparse products M_p W (M_p: the scaled
+ * strong pass-(p-1) entries of the pass-p rows) with the Galerkin product's own row-wise accumulation order, so that a device
+ * implementation built on its SpGEMM kernel is bit-comparable. */
+orc_csr *
+orc_interp_multipass(const orc_csr *A, const unsigned char *smask, const int *cf)
+{
+   const int n = A->nrows;
+   int *cidx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)), *pass = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+   double *alfa = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+   int nc = 0;
+   for (int i = 0; i < n; i++) { cidx[i] = (cf[i] == ORC_C_PT) ? nc++ : -1; pass[i] = (cf[i] == ORC_C_PT) ? 0 : -1; }
+   /* pass numbers */
+   int npass = 0;
+   for (int p = 1;; p++)
+   {
+      int found = 0;
+      for (int i = 0; i < n; i++)
+      {
+         if (pass[i] >= 0 || cf[i] != ORC_F_PT) continue;
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+            if (smask[k] && pass[A->col[k]] == p - 1) { pass[i] = -2; found++; break; } /* marked; committed below (synchronous rounds) */
+      }
+      for (int i = 0; i < n; i++)
+         if (pass[i] == -2) pass[i] = p;
+      if (!found) break;
+      npass = p;
+   }
+   /* alfa_i for every interpolated F point */
+   for (int i = 0; i < n; i++)
+   {
+      if (pass[i] < 1) continue;
+      double diag = 0.0, sum_n = 0.0, sum_c = 0.0;
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+      {
+         const int j = A->col[k];
+         if (j == i) { diag = A->val[k]; continue; }
+         sum_n += A->val[k];
+         if (smask[k] && pass[j] == pass[i] - 1) sum_c += A->val[k];
+      }
+      alfa[i] = (sum_c * diag != 0.0) ? -sum_n / (sum_c * diag) : 0.0;
+   }
+   /* W after pass 1: identity rows of the C points, direct rows of the pass-1 points */
+   int nnz = 0;
+   for (int i = 0; i < n; i++)
+   {
+      if (pass[i] == 0) nnz++;
+      else if (pass[i] == 1)
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) nnz += (smask[k] && pass[A->col[k]] == 0);
+   }
+   orc_csr *W = orc_csr_alloc(n, nc, nnz);
+   int q = 0;
+   for (int i = 0; i < n; i++)
+   {
+      if (pass[i] == 0) { W->col[q] = cidx[i]; W->val[q++] = 1.0; }
+      else if (pass[i] == 1)
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+            if (smask[k] && pass[A->col[k]] == 0) { W->col[q] = cidx[A->col[k]]; W->val[q++] = alfa[i] * A->val[k]; }
+      W->rowptr[i + 1] = q;
+   }
+   for (int p = 2; p <= npass; p++)
+   {
+      int mnz = 0;
+      for (int i = 0; i < n; i++)
+         if (pass[i] == p)
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) mnz += (smask[k] && pass[A->col[k]] == p - 1);
+      orc_csr *M = orc_csr_alloc(n, n, mnz);
+      int m = 0;
+      for (int i = 0; i < n; i++)
+      {
+         if (pass[i] == p)
+            for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+               if (smask[k] && pass[A->col[k]] == p - 1) { M->col[m] = A->col[k]; M->val[m++] = alfa[i] * A->val[k]; }
+         M->rowptr[i + 1] = m;
+      }
+      orc_csr *T = spgemm(M, W);
+      /* W := W + T (the rows of T are rows W does not have yet) */
+      orc_csr *W2 = orc_csr_alloc(n, nc, W->rowptr[n] + T->rowptr[n]);
+      int z = 0;
+      for (int i = 0; i < n; i++)
+      {
+         const orc_csr *src = (pass[i] == p) ? T : W;
+         for (int k = src->rowptr[i]; k < src->rowptr[i + 1]; k++) { W2->col[z] = src->col[k]; W2->val[z++] = src->val[k]; }
+         W2->rowptr[i + 1] = z;
+      }
+      orc_csr_free(M); orc_csr_free(T); orc_csr_free(W);
+      W = W2;
+   }
+   free(cidx); free(pass); free(alfa);
+   return W;
+}
+
 /* ------------------------------------------------------------------ Chebyshev smoother (relax type 16)
  * hypre_ParCSRRelax_Cheby_Setup / _Solve and hypre_ParCSRMaxEigEstimateCG as configured by
  * HYPRE_BoomerAMGSetCheby{Order,Fraction,EigEst,Variant,Scale} (reference src/internal/amg.c:886-890, cheby.c:15-20).
@@ -1470,6 +1649,8 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
          orc_pmis(A, sm, p->seed, lvl, 0, cf);
       else
          orc_rs_first_pass(A, sm, cf);
+      const int aggressive = lvl < p->agg_num_levels;
+      if (aggressive) orc_coarsen_second_pass(A, sm, p->agg_num_paths > 0 ? p->agg_num_paths : 1, p->seed, lvl, cf);
       int nc = 0;
       for (int i = 0; i < n; i++) nc += (cf[i] == ORC_C_PT);
       if (nc == 0 || nc == n || nc < p->min_coarse_size)
@@ -1478,7 +1659,8 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
          break;
       }
       h->cf[lvl] = cf;
-      h->P[lvl]  = (p->interp_type == 3) ? orc_interp_direct_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
+      h->P[lvl]  = aggressive ? orc_interp_multipass(A, sm, cf)
+                   : (p->interp_type == 3) ? orc_interp_direct_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
                                           : orc_interp_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof);
       if (dof)
       { /* coarse unknowns keep the function of their fine C point */

@@ -55,6 +55,11 @@ typedef struct {
    /* relaxation.chebyshev (relax type 16; reference src/internal/cheby.c:15-20): order 2, eig_est 10, variant 0, scale 1, fraction 0.3 */
    int    cheby_order, cheby_eig_est, cheby_variant, cheby_scale;
    double cheby_fraction;
+   /* aggressive coarsening (reference AMGagg_args, src/internal/amg.c:160-173, forwarded at :938-944): on the first agg_num_levels
+    * levels a second coarsening runs over the distance-two strength graph of the first one's C points (at least agg_num_paths paths of
+    * length <= 2) and the interpolation is multipass (agg_interp_type 4, the only one restated; no truncation: the reference's defaults
+    * max_nnz_row 0 / trunc_factor 0).  PARITY UNPINNED: no reference output uses it. */
+   int    agg_num_levels, agg_num_paths, agg_interp_type;
 } orc_amg_params;
 
 typedef struct orc_amg orc_amg; /* hierarchy handle */
@@ -116,6 +121,11 @@ orc_csr *orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, cons
 orc_csr *orc_interp_direct_dof(const orc_csr *A, const unsigned char *smask, const int *cf,
                                int pmax, double trunc_factor, const int *dof);
 orc_csr *orc_rap(const orc_csr *A, const orc_csr *P);
+/* aggressive coarsening pieces (see orc_amg_params.agg_*): distance-two strength among the C points of cf (n1 x n1, value = number
+ * of paths, entries with fewer than num_paths dropped, no diagonal); second PMIS pass folded into cf; multipass interpolation */
+orc_csr *orc_second_strength(const orc_csr *A, const unsigned char *smask, const int *cf, int num_paths);
+void     orc_coarsen_second_pass(const orc_csr *A, const unsigned char *smask, int num_paths, uint64_t seed, int level, int *cf);
+orc_csr *orc_interp_multipass(const orc_csr *A, const unsigned char *smask, const int *cf);
 
 /* Hierarchy */
 orc_amg *orc_amg_setup(const orc_csr *A, const orc_amg_params *p);

@@ -28,7 +28,8 @@ class AmgParams(C.Structure):
                 ("relax_weight", C.c_double), ("outer_weight", C.c_double),
                 ("seed", C.c_uint64), ("num_functions", C.c_int),
                 ("cheby_order", C.c_int), ("cheby_eig_est", C.c_int), ("cheby_variant", C.c_int), ("cheby_scale", C.c_int),
-                ("cheby_fraction", C.c_double)]
+                ("cheby_fraction", C.c_double),
+                ("agg_num_levels", C.c_int), ("agg_num_paths", C.c_int), ("agg_interp_type", C.c_int)]
 
 
 class KrylovParams(C.Structure):
@@ -96,6 +97,11 @@ def lib():
     L.orc_interp_extpi.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double]
     L.orc_rap.restype = cp
     L.orc_rap.argtypes = [cp, cp]
+    L.orc_second_strength.restype = cp
+    L.orc_second_strength.argtypes = [cp, P(C.c_ubyte), ip, C.c_int]
+    L.orc_coarsen_second_pass.argtypes = [cp, P(C.c_ubyte), C.c_int, C.c_uint64, C.c_int, ip]
+    L.orc_interp_multipass.restype = cp
+    L.orc_interp_multipass.argtypes = [cp, P(C.c_ubyte), ip]
     L.orc_amg_setup.restype = C.c_void_p
     L.orc_amg_setup.argtypes = [cp, P(AmgParams)]
     L.orc_amg_setup_dof.restype = C.c_void_p
@@ -308,6 +314,28 @@ def interp_direct(A, smask, cf, pmax=4, trunc_factor=0.0, dof=None):
     d = None if dof is None else np.ascontiguousarray(dof, dtype=np.int32)
     return Csr(lib().orc_interp_direct_dof(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), cfa.ctypes.data_as(C.POINTER(C.c_int)), pmax,
                                            trunc_factor, None if d is None else d.ctypes.data_as(C.POINTER(C.c_int))))
+
+
+def second_strength(A, smask, cf, num_paths=1):
+    """aggressive coarsening: strong connections of distance <= 2 among the C points of cf (values = number of paths)"""
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    cfa = np.ascontiguousarray(cf, dtype=np.int32)
+    return Csr(lib().orc_second_strength(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), cfa.ctypes.data_as(C.POINTER(C.c_int)), num_paths))
+
+
+def coarsen_second_pass(A, smask, cf, num_paths=1, seed=2747, level=0):
+    """aggressive coarsening: the second PMIS pass; returns the updated C/F marker"""
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    cfa = np.ascontiguousarray(cf, dtype=np.int32).copy()
+    lib().orc_coarsen_second_pass(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), num_paths, seed, level, cfa.ctypes.data_as(C.POINTER(C.c_int)))
+    return cfa
+
+
+def interp_multipass(A, smask, cf):
+    """aggressive coarsening: multipass interpolation (aggressive.prolongation_type 4)"""
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    cfa = np.ascontiguousarray(cf, dtype=np.int32)
+    return Csr(lib().orc_interp_multipass(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), cfa.ctypes.data_as(C.POINTER(C.c_int))))
 
 
 def rap(A, P):

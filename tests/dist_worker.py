@@ -181,20 +181,21 @@ def mode_mgr(out, n):
     hdist.finalize()
 
 
-def mode_threads(out, n, P, solver):
+def mode_threads(out, n, P, solver, want_x=True):
     """ONE process, prod(P) thread ranks on the visible GPU (hypredrive_amd/csrc/hda_thread_ranks.hip): the public HYPREDRV_* sequence
     on every rank, the in-process staged transport between them."""
     from hypredrive_amd import _lib
     P = tuple(int(v) for v in P.split(","))
     yaml = f"solver: {solver}\npreconditioner:\n  preset: poisson\n"
-    r = _lib.thread_ranks_lap7(P[0] * P[1] * P[2], (n, n, n), P, yaml, want_x=True)
-    np.save(out + ".x.npy", r.pop("x"))
+    r = _lib.thread_ranks_lap7(P[0] * P[1] * P[2], (n, n, n), P, yaml, want_x=want_x)
+    if want_x:
+        np.save(out + ".x.npy", r.pop("x"))
     json.dump(r, open(out, "w"))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "threads":
-        mode_threads(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
+        mode_threads(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5], want_x=(len(sys.argv) < 7 or sys.argv[6] == "1"))
     elif sys.argv[1] == "transport":
         mode_transport(sys.argv[2])
     elif sys.argv[1] == "mgr":

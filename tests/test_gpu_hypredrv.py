@@ -396,15 +396,15 @@ def test_row_partitioned_solve_matches_single_rank(hd, tmp_path, world, n, solve
     assert np.linalg.norm(x) == pytest.approx(res["norm"], rel=1e-12)
 
 
-def _thread_ranks(tmp_path, tag, n, P, solver="pcg", **envx):
+def _thread_ranks(tmp_path, tag, n, P, solver="pcg", want_x="1", **envx):
     """prod(P) ranks as THREADS of one child process (hda_thread_ranks.hip): a GPU box admits six processes on its card, so this is
     how the eight ranks of BASELINE config 3's 2x2x2 layout share the one GPU."""
     out = str(tmp_path / f"{tag}.json")
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", **envx)
-    cmd = [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "threads", out, str(n), ",".join(str(v) for v in P), solver]
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "threads", out, str(n), ",".join(str(v) for v in P), solver, want_x]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
-    return json.load(open(out)), np.load(out + ".x.npy"), r.stderr
+    return json.load(open(out)), (np.load(out + ".x.npy") if want_x == "1" else None), r.stderr
 
 
 @pytest.mark.parametrize("n,rep_rows,check", [(40, 2000, "1"), (40, 2000, "0"), (32, 0, "0"), (48, 100000, "0")])
@@ -430,6 +430,26 @@ def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check):
         assert res["exchange"] > 0 and res["allreduce"] > 0
     if check == "1":
         assert "dist check rank 7" in err  # every rank compared its levels
+
+
+def test_config3_full_size_512_cubed_on_eight_thread_ranks(hd, tmp_path):
+    """BASELINE config 3 AS NAMED -- the 3-D 7-pt Laplacian 512^3 (134 217 728 rows), fp64, AMG-PCG, row-partitioned 2x2x2 over eight
+    ranks, a 256^3 block each (`-n 512 512 512 -P 2 2 2`, reference examples/src/C_laplacian/laplacian.c:561-582) -- on ONE MI355X:
+    the eight ranks are threads of one process (hda_thread_ranks.hip) and their messages are host-staged, so this says nothing about
+    speed; it says that the partitioned setup, the halo plans with face / edge / corner neighbours on every level and the solve are
+    right at the full size: converged, the same iteration count on every rank and within 1 of ONE rank solving the same 512^3
+    system on the same GPU (16), the same solution norms.  (What stays unmeasured is RCCL between eight GPUs.)"""
+    n = 512
+    res, _, err = _thread_ranks(tmp_path, "cfg3", n, (2, 2, 2), want_x="0")
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  preset: poisson\n")
+    h.set_laplacian7((n, n, n))
+    ref = h.solve()
+    assert res["world"] == 8 and res["converged"] and res["iters_spread"] == 0
+    assert ref["converged"] and abs(res["iters"] - ref["iters"]) <= 1, (res["iters"], ref["iters"])
+    assert res["norm"] == pytest.approx(h.solution_norm("L2"), rel=1e-6)
+    assert res["linf"] == pytest.approx(h.solution_norm("Linf"), rel=1e-6)
+    assert res["partitioned_levels"] >= 3
+    h.close()
 
 
 @pytest.mark.parametrize("reorder", [None, "150"])
@@ -901,6 +921,39 @@ def test_spe10_like_gmres_amg_ilu_matches_oracle(hd, orc, tmp_path, via):
     assert r["converged"] and r["iters"] == ref["iters"], (r["iters"], ref["iters"])
     assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-7
     h.close()
+
+
+def test_yaml_aggressive_coarsening_matches_oracle(hd, orc, tmp_path):
+    """`preconditioner: amg: aggressive: {num_levels: 1}` (reference AMGagg_args, src/internal/amg.c:160-173 -> HYPRE_BoomerAMGSetAgg*
+    at :938-944) through the HYPREDRV_* API: the oracle's iteration count and solution; `num_paths: 2` likewise; what is not built
+    (a two-stage interpolation type, a truncation of the aggressive levels' interpolation, row partitions) is refused by name."""
+    n = 20
+    Ao, b = orc.lap7(n, n, n)
+    for paths in (1, 2):
+        ref = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True, agg_num_levels=1, agg_num_paths=paths)))
+        h = hd.Hypredrv(f"solver: pcg\npreconditioner:\n  amg:\n    aggressive:\n      num_levels: 1\n      num_paths: {paths}\n")
+        h.set_laplacian7((n, n, n))
+        r = h.solve()
+        assert r["converged"] and r["iters"] == ref["iters"], (r["iters"], ref["iters"])
+        assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-10
+        h.close()
+    plain = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True)))
+    assert ref["iters"] > plain["iters"]  # the cheaper hierarchy costs iterations
+    for extra, what in (("prolongation_type: 2_stage_extended+i", "multipass"), ("max_nnz_row: 4", "truncation"), ("trunc_factor: 0.1", "truncation")):
+        h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    aggressive:\n      num_levels: 1\n      " + extra + "\n")
+        h.set_laplacian7((8, 8, 8))
+        with pytest.raises(hd.HypredrvError, match=what):
+            h.solve()
+        hd.lib().HYPREDRV_ErrorCodeClear()
+        h.close()
+    # two ranks: refused on every rank, not silently solved with another hierarchy
+    out = str(tmp_path / "agg2.json")
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1",
+               HDA_TEST_YAML="solver: pcg\npreconditioner:\n  amg:\n    aggressive:\n      num_levels: 1\n")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, "2000", "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "one rank only" in (r.stdout + r.stderr)
 
 
 def test_yaml_unimplemented_ilu_variants_fail_loudly(hd):

@@ -384,6 +384,94 @@ def test_hierarchy_identical_to_oracle(orc, hd, shape):
     assert rel(hh.vcycle(r), ho.vcycle(r)) < 1e-12
 
 
+def _agg_mats(orc, hd):
+    """A stencil operator, an anisotropic one (strong connections along two axes only) and irregular M-matrices."""
+    mats = [both(orc, hd, orc.lap7(12, 11, 10)[0].to_scipy()), both(orc, hd, hd.lap7(14, 12, 10, c=(1.0, 1.0, 0.01)).to_scipy())]
+    for seed in (5, 6):
+        M = rand_spd(900, 0.01, seed)
+        M.data = -np.abs(M.data)
+        M.setdiag(0.0)
+        M.eliminate_zeros()
+        M = (M + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel() + 0.1)).tocsr()
+        M.sort_indices()
+        mats.append(both(orc, hd, M))
+    return mats
+
+
+@pytest.mark.parametrize("num_paths", [1, 2])
+def test_aggressive_coarsening_stages_bit_exact(orc, hd, num_paths):
+    """Aggressive coarsening (reference AMGagg_args src/internal/amg.c:160-173, forwarded at :938-944; hda_amg_agg.hip), stage by
+    stage against the oracle: the second strength graph among the first pass's C points (pattern AND path counts), the C/F
+    marker after the second PMIS pass, and the multipass interpolation -- same pattern, same bits (sums in the oracle's order; the
+    pass products on the deterministic SpGEMM).  Parity unpinned upstream: no reference output uses these options."""
+    for Ao, Ah in _agg_mats(orc, hd):
+        sm = orc.strength(Ao, 0.25, 0.9)
+        cf1 = orc.pmis(Ao, sm)
+        S2o = orc.second_strength(Ao, sm, cf1, num_paths)
+        rp, cj, v = Ah.second_strength(sm, cf1, num_paths).download()
+        assert np.array_equal(rp, S2o.rowptr) and np.array_equal(cj, S2o.col) and np.array_equal(v, S2o.val)
+        assert S2o.nrows == int((cf1 == 1).sum()) and (v >= num_paths).all()
+        cfo = orc.coarsen_second_pass(Ao, sm, cf1, num_paths, 2747, 0)
+        cfh = Ah.coarsen_second_pass(sm, cf1, num_paths, 2747, 0)
+        assert np.array_equal(cfo, cfh)
+        assert (cfo == 1).sum() < (cf1 == 1).sum() and set(np.flatnonzero(cfo == 1)) <= set(np.flatnonzero(cf1 == 1))
+        Po = orc.interp_multipass(Ao, sm, cfo)
+        rp, cj, v = Ah.interp_multipass(sm, cfo).download()
+        assert np.array_equal(rp, Po.rowptr) and np.array_equal(cj, Po.col)
+        assert np.array_equal(v, Po.val), np.abs(v - Po.val).max()
+        # what multipass interpolation promises: C rows are identity rows; a row sums to (a_ii - rowsum_i) / a_ii times the mean row
+        # sum of the rows it interpolates through -- exactly 1 everywhere on an operator whose rows all sum to zero (below)
+        P = Po.to_scipy().tocsr()
+        prs = np.asarray(P.sum(axis=1)).ravel()
+        assert np.allclose(prs[cfo == 1], 1.0) and (np.diff(P.indptr)[cfo == 1] == 1).all()
+        assert (prs[np.diff(P.indptr) > 0] <= 1.0 + 1e-12).all()
+    # a graph Laplacian (every row sums to zero): constants are interpolated exactly by every pass
+    W = rand_spd(700, 0.012, 9)
+    W.setdiag(0.0)
+    W.eliminate_zeros()
+    W.data = np.abs(W.data)
+    L = (sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W).tocsr()
+    L.sort_indices()
+    Ao, Ah = both(orc, hd, L)
+    sm = orc.strength(Ao, 0.25, 2.0)  # (max_row_sum 2: the row-sum test must not weaken rows here)
+    cfo = orc.coarsen_second_pass(Ao, sm, orc.pmis(Ao, sm), num_paths, 2747, 0)
+    Po = orc.interp_multipass(Ao, sm, cfo)
+    rp, cj, v = Ah.interp_multipass(sm, cfo).download()
+    assert np.array_equal(rp, Po.rowptr) and np.array_equal(cj, Po.col) and np.array_equal(v, Po.val)
+    P = Po.to_scipy().tocsr()
+    filled = np.diff(P.indptr) > 0
+    assert filled.sum() > 0.9 * L.shape[0]
+    assert np.allclose(np.asarray(P.sum(axis=1)).ravel()[filled], 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape,agg", [((16, 16, 16), 1), ((20, 18, 16), 2), ((24, 24, 24), 1)])
+def test_aggressive_hierarchy_and_pcg_match_oracle(orc, hd, shape, agg):
+    """`aggressive.num_levels` 1 and 2: every operator and interpolation of the hierarchy bit-identical to the oracle's, the coarsening
+    really is aggressive (first level coarsens by more than 8 where PMIS + extended+i coarsens by about 3; operator complexity below
+    1.5 against 2.6), PCG takes the oracle's iterations with the oracle's history."""
+    Ao, b = orc.lap7(*shape)
+    Ah = hd.lap7(*shape)
+    ho = orc.Amg(Ao, orc.amg_params(True, agg_num_levels=agg))
+    hh = hd.Amg(Ah, hd.AmgParams.default(agg_num_levels=agg))
+    assert hh.num_levels == ho.num_levels
+    for l in range(ho.num_levels):
+        rp, cj, v = hh.level_matrix(l, 0).download()
+        Al = ho.level_A(l)
+        assert np.array_equal(rp, Al.rowptr) and np.array_equal(cj, Al.col) and np.array_equal(v, Al.val), f"A level {l}"
+        if l < ho.num_levels - 1:
+            assert np.array_equal(hh.level_cf(l), ho.level_cf(l)), f"C/F level {l}"
+            rp, cj, v = hh.level_matrix(l, 1).download()
+            Pl = ho.level_P(l)
+            assert np.array_equal(rp, Pl.rowptr) and np.array_equal(cj, Pl.col) and np.array_equal(v, Pl.val), f"P level {l}"
+    assert ho.level_A(0).nrows > 8 * ho.level_A(1).nrows and ho.operator_complexity < 1.5
+    plain = orc.Amg(Ao, orc.amg_params(True))
+    assert plain.operator_complexity > 2.0
+    ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
+    assert rel(rh["x"], ro["x"]) < 1e-10
+
+
 @pytest.mark.parametrize("n", [128, 256])
 def test_parity_at_128_and_256_cubed(orc, hd, n):
     """The benchmark workload itself -- BASELINE config 2, 256^3 = 16.8 M rows (oracle setup about 45 s on the box's host cores) --
