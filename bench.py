@@ -389,10 +389,49 @@ def single_extras(args, out, hh, A, amg, fb0, iters):
         out["kernels"] = kt
     if not args.no_plain_csr and fb0["coded"]:
         out["plain_csr"] = plain_csr_child(args)
+    if not args.no_aggressive:
+        out["aggressive_1"] = aggressive_run(args, hh)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample or args.n, iters if (args.cpu_sample or args.n) == args.n else None)
         if "iters_match" in out["cpu_baseline"]:
             out["iters_match"] = out["cpu_baseline"]["iters_match"]
+
+
+def aggressive_run(args, hh):
+    """The same system and API path with ONE aggressive-coarsening level (reference option `preconditioner: amg: aggressive: num_levels: 1`,
+    src/internal/amg.c:160-173, 938-944; NOT the benchmark's configuration, which is the reference's default preset): what the option
+    buys on this workload -- a hierarchy of operator complexity ~1.33 instead of ~2.77, more iterations, each much cheaper."""
+    from hypredrive_amd import hypredrv as hd
+    n = args.n
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    aggressive:\n      num_levels: 1\n")
+    h.set_laplacian7((n, n, n))
+    ts = []
+    for rep in range(2):
+        hh.sync()
+        t0 = time.perf_counter()
+        h.create_and_setup()
+        hh.sync()
+        ts.append((time.perf_counter() - t0) * 1e3)
+        if rep == 0:
+            h.destroy_solver()
+    A, amg = hh._lib.borrow(h)
+    g, o = amg.complexities
+    for _ in range(args.warmup):
+        h.apply()
+    hh.sync()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = h.apply()
+    hh.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)
+    res = {"what": "same system, same API path, `aggressive: num_levels: 1` (multipass interpolation on level 0): a reference OPTION, not the "
+                   "benchmark's configuration", "ms_per_step": ms, "value": n ** 3 / (ms * 1e-3), "iters": last["iters"], "converged": last["converged"],
+           "setup_ms": ts[1], "operator_complexity": o, "grid_complexity": g, "num_levels": amg.num_levels}
+    del A, amg
+    h.destroy_solver()
+    h.close()
+    return res
 
 
 def plain_csr_child(args):
@@ -400,7 +439,7 @@ def plain_csr_child(args):
     the level-0 product is the plain CSR stream kernel of the north-star 'CSR SpMV >= 40 % of roofline' claim."""
     env = dict(os.environ, HDA_CODED="0", HDA_WINDOW="0")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--grid", str(args.n), "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr"]
+           "--grid", str(args.n), "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     for ln in r.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
@@ -429,7 +468,7 @@ def child_bench(extra, nranks, timeout_s):
     me = os.path.abspath(__file__)
     cmd = [sys.executable, me] if nranks == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
                                                     "--master-addr", "127.0.0.1", "--master-port", str(free_port()), me]
-    cmd += ["--gpus", str(nranks), "--child", "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr"] + extra
+    cmd += ["--gpus", str(nranks), "--child", "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive"] + extra
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired:
@@ -517,6 +556,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-plain-csr", action="store_true")
+    ap.add_argument("--no-aggressive", action="store_true", help="N = 1: skip the side run with one aggressive-coarsening level")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the strong_<grid> and n1_reference child launches")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # a launch made by another bench.py: no further children
     args = ap.parse_args()

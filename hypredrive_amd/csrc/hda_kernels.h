@@ -53,6 +53,10 @@ void cg_update(int n, int gamma_idx, const double *p, const double *s, double *x
 // p = z + (gamma_new / gamma_old) p.  first_slot >= 0 (one rank): gamma_new and the scalar after it are finished here from the block
 // partials of slots first_slot, first_slot + 1 (no finalize launch; same bits)
 void cg_direction(int n, int gamma_old_idx, int gamma_new_idx, const double *z, double *p, int first_slot = -1);
+// one step of the single-reduction (Chronopoulos-Gear) PCG: p = u + beta p; s = w + beta s; x += alpha p; r -= alpha s; partials <r,r>
+// with beta, alpha formed on the device from scalars[t_new] = <r,u>, [t_new + 2] = <w,u>, [t_old] = the previous <r,u>, [alpha_idx]
+void cg_single_step(int n, int t_new, int t_old, int alpha_idx, bool first, const double *u, const double *w, double *p, double *s, double *x,
+                    double *r, int rr_slot);
 void axpy(int n, double a, const double *x, double *y);                   // y += a x
 void axpy_dev(int n, int scalar_idx, double sign, const double *x, double *y); // y += sign*scalars[idx]*x
 void scale(int n, double a, double *x);

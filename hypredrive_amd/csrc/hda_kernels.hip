@@ -2004,6 +2004,55 @@ void cg_direction(int n, int gamma_old_idx, int gamma_new_idx, const double *z, 
    else if (n) k_cg_dir<false><<<ew_grid(n), 256, 0, STREAM>>>(n, c.scalars, gamma_old_idx, gamma_new_idx, z, p, nullptr);
 }
 
+// One step of the single-reduction (Chronopoulos-Gear) form of PCG, all vector work of an iteration in one pass:
+//   beta = gamma_new / gamma_old (0 on the first step);  alpha = gamma_new / (delta - beta gamma_new / alpha_old)
+//   p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  partials of <r,r>
+// scalars[t_new + {0, 2}] = gamma_new = <r,u>, delta = <w,u>; scalars[t_old] = gamma_old; scalars[alpha_idx] = the previous alpha
+__global__ __launch_bounds__(256) void k_cg_single(int n, double *scalars, int t_new, int t_old, int alpha_idx, int first, const double *__restrict__ u,
+                                                   const double *__restrict__ w, double *__restrict__ p, double *__restrict__ s,
+                                                   double *__restrict__ x, double *__restrict__ r, double *__restrict__ partial)
+{
+   const double gn = scalars[t_new], delta = scalars[t_new + 2];
+   double       beta = 0.0, alpha;
+   if (first) alpha = gn / delta;
+   else
+   {
+      beta  = gn / scalars[t_old];
+      alpha = gn / (delta - beta * gn / scalars[alpha_idx]);
+   }
+   double acc = 0.0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+   {
+      const double pi = u[i] + beta * p[i], si = w[i] + beta * s[i];
+      p[i]            = pi;
+      s[i]            = si;
+      x[i] += alpha * pi;
+      const double ri = r[i] - alpha * si;
+      r[i]            = ri;
+      acc += ri * ri;
+   }
+   acc = block_sum(acc);
+   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+// (alpha of the step is published by a one-thread kernel AFTER the step, so that no block of the step can read the new value)
+__global__ void k_cg_single_alpha(double *scalars, int t_new, int t_old, int alpha_idx, int first)
+{
+   const double gn = scalars[t_new], delta = scalars[t_new + 2];
+   if (first) scalars[alpha_idx] = gn / delta;
+   else
+   {
+      const double beta   = gn / scalars[t_old];
+      scalars[alpha_idx] = gn / (delta - beta * gn / scalars[alpha_idx]);
+   }
+}
+void cg_single_step(int n, int t_new, int t_old, int alpha_idx, bool first, const double *u, const double *w, double *p, double *s, double *x,
+                    double *r, int rr_slot)
+{
+   Context &c = Context::get();
+   k_cg_single<<<kRedBlocks, 256, 0, c.stream>>>(n, c.scalars, t_new, t_old, alpha_idx, first ? 1 : 0, u, w, p, s, x, r, c.slot(rr_slot));
+   k_cg_single_alpha<<<1, 1, 0, c.stream>>>(c.scalars, t_new, t_old, alpha_idx, first ? 1 : 0);
+}
+
 __global__ __launch_bounds__(256) void k_axpy(int n, double a, const double *__restrict__ x, double *__restrict__ y)
 {
    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];

@@ -49,9 +49,115 @@ double pcg_iteration_bytes(const DCsr &A, bool format)
    return (matrix_stream_bytes(A, format) + rowptr_stream_bytes(A, format) + 8.0 * A.ncols + 8.0 * n) + 8.0 * n + 48.0 * n + 24.0 * n;
 }
 
+// Single-reduction PCG (Chronopoulos & Gear 1989), opt-in: HDA_PCG_SINGLE_REDUCE=1.  hypre's recurrence needs three global sums per
+// iteration at two points (<s,p> before the update; <r,z> and <r,r> after the preconditioner); here gamma = <r,u>, delta = <w,u>
+// (w = A u, u = M^-1 r) and <r,r> are formed together and travel in ONE all-reduce of three doubles (C2 of SURVEY 2.4), alpha comes
+// from the recurrence alpha = gamma / (delta - beta gamma / alpha_old).  Price: a second vector recurrence (s = w + beta s, +24 B per
+// row) and a different rounding -- iteration counts within 1 of the standard loop, not bit-equal histories; which is why it is off
+// until a measurement on several GPUs says the latency of an all-reduce matters.  Two-norm stopping test only.
+static KrylovResult pcg_single_reduction(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
+{
+   Context     &ctx = Context::get();
+   const DCsr  &A   = *op.A;
+   const int    n   = A.nrows;
+   KrylovResult res;
+   const size_t vl = std::max<size_t>(op.veclen, 1);
+   DArray<double> r(vl), u(vl), w(vl), p(vl), s(vl);
+   constexpr int T0 = S_GMRES, T1 = S_GMRES + 3, S_ALPHA = S_GMRES + 6; // (gamma, <r,r>, delta) triples of alternating iterations
+   auto precond = [&](const double *rr, double *zz, int slot) {
+      res.precond_calls++;
+      if (M) M(rr, zz, slot);
+      else
+      {
+         copy(n, rr, zz);
+         if (slot >= 0) dot(n, rr, zz, slot);
+      }
+   };
+   dot(n, b, b, 0);
+   finalize(0, S_BB);
+   const double bi_prod = read_scalar(S_BB);
+   if (bi_prod == 0.0)
+   {
+      copy(n, b, x);
+      ctx.sync();
+      res.hist.push_back(0.0);
+      return res;
+   }
+   double eps = kp.rtol * kp.rtol;
+   if (kp.atol * kp.atol / bi_prod > eps) eps = kp.atol * kp.atol / bi_prod;
+   copy(n, x, p.data()); // (x has no ghost tail: stage it)
+   residual(A, p.data(), b, r.data(), op.halo);
+   fill((int)vl, 0.0, p.data());
+   fill((int)vl, 0.0, s.data());
+   dot(n, r.data(), r.data(), 3);
+   precond(r.data(), u.data(), 2);
+   spmv_dot(A, u.data(), w.data(), u.data(), 4, op.halo);
+   finalize_n(2, 3, T0);
+   read_scalars_async(T0, 3);
+   HDA_HIP(hipEventSynchronize(ctx.ev));
+   double i_prod = ctx.host_scalars[T0 + 1];
+   res.hist.push_back(std::sqrt(std::fabs(i_prod)));
+   int it = 0;
+   while (it + 1 <= kp.max_iter)
+   {
+      it++;
+      const int tn = (it & 1) ? T0 : T1, tnext = (it & 1) ? T1 : T0; // the triple this step consumes / the one it produces
+      const double delta = ctx.host_scalars[tn + 2];
+      if (delta == 0.0 || !std::isfinite(delta)) { it--; break; } // breakdown, as hypre's <s,p> == 0
+      cg_single_step(n, tn, tnext, S_ALPHA, it == 1, u.data(), w.data(), p.data(), s.data(), x, r.data(), 3);
+      // near the tolerance <r,r> is reduced and tested first, so that the V-cycle and the product that would only serve the next step
+      // are not run (one extra small all-reduce in the last iteration or two)
+      bool near = false;
+      if (res.hist.size() >= 2)
+      {
+         const double h1 = res.hist.back(), h0 = res.hist[res.hist.size() - 2];
+         const double rho2 = (h0 > 0.0) ? (h1 / h0) * (h1 / h0) : 1.0;
+         near = h1 * h1 * rho2 < 16.0 * eps * bi_prod;
+      }
+      if (near)
+      {
+         finalize(3, tnext + 1);
+         read_scalars_async(tnext, 3);
+         HDA_HIP(hipEventSynchronize(ctx.ev));
+         i_prod = ctx.host_scalars[tnext + 1];
+         if (i_prod / bi_prod < eps)
+         {
+            res.hist.push_back(std::sqrt(std::fabs(i_prod)));
+            res.converged = true;
+            break;
+         }
+      }
+      precond(r.data(), u.data(), 2);
+      spmv_dot(A, u.data(), w.data(), u.data(), 4, op.halo);
+      finalize_n(2, 3, tnext); // <r,u>, <r,r>, <w,u>: one kernel, ONE all-reduce of three doubles
+      read_scalars_async(tnext, 3);
+      HDA_HIP(hipEventSynchronize(ctx.ev));
+      i_prod = ctx.host_scalars[tnext + 1];
+      res.hist.push_back(std::sqrt(std::fabs(i_prod)));
+      if (kp.print_level >= 2)
+         printf("%5d    %e    %f    %e\n", it, res.hist.back(),
+                res.hist[res.hist.size() - 2] > 0 ? res.hist.back() / res.hist[res.hist.size() - 2] : 0.0, std::sqrt(i_prod / bi_prod));
+      if (i_prod / bi_prod < eps) { res.converged = true; break; }
+   }
+   ctx.sync();
+   res.iters     = it;
+   res.final_rel = std::sqrt(std::fabs(i_prod) / bi_prod);
+   return res;
+}
+
 KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, const double *b, double *x)
 {
    NestedScope  scope;
+   if (kp.two_norm && !scope.nested)
+   {
+      const char *sr = getenv("HDA_PCG_SINGLE_REDUCE");
+      if (sr && atoi(sr) != 0)
+      {
+         KrylovResult r1 = pcg_single_reduction(op, M, kp, b, x);
+         g_last_precond_calls = r1.precond_calls;
+         return r1;
+      }
+   }
    Context     &ctx = Context::get();
    const DCsr  &A   = *op.A;
    const int    n   = A.nrows;

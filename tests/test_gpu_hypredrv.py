@@ -498,6 +498,21 @@ def test_fused_dot_allreduce_is_bitwise_the_unfused_one(tmp_path):
     assert a["comm"]["allreduce"] - (2 + 2 * it + vc) <= 4   # at most a few iterations near convergence are unfused
 
 
+def test_single_reduction_pcg_one_allreduce_per_iteration(tmp_path):
+    """C2 of SURVEY 2.4 with HDA_PCG_SINGLE_REDUCE=1 (opt-in): the three inner products of an iteration travel in ONE all-reduce of
+    three doubles; with the replicated tail's restricted residual that is 2 all-reduces per iteration instead of 3 (plus the few
+    iterations near convergence that test <r,r> first).  Same iteration count within 1, same solution to the stopping tolerance."""
+    a, xa = _dist_solve(tmp_path, "sr1", 4, 24, 0, HDA_REPLICATE_ROWS="700", HDA_PCG_SINGLE_REDUCE="1")
+    b, xb = _dist_solve(tmp_path, "sr0", 4, 24, 0, HDA_REPLICATE_ROWS="700")
+    assert a["converged"] and abs(a["iters"] - b["iters"]) <= 1
+    assert np.linalg.norm(xa - xb) <= 1e-5 * np.linalg.norm(xb)
+    it, vc = a["iters"], a["vcycles"]
+    # the untimed r0 and final-residual norms of Apply (2); <b,b> and the first triple (2); one triple per iteration; one per V-cycle
+    # (the tail's restricted residual); up to three <r,r>-first tests near convergence
+    assert a["comm"]["allreduce"] <= 4 + it + vc + 3
+    assert a["comm"]["allreduce"] < b["comm"]["allreduce"] - (it - 3)
+
+
 def test_overlapped_halo_exchange_matches_the_serial_one(tmp_path):
     """C1 of SURVEY 2.4: every product of the cycle and the PCG product start on the rows' owned columns while the ghost
     values travel on the communication stream; the ghost-column part is added afterwards (k_offd_fix).  Against the

@@ -141,6 +141,26 @@ def test_pcg_kernel_fusions_are_bitwise_neutral(hd, monkeypatch, sweeps):
         assert r["iters"] == ref["iters"] and np.array_equal(r["hist"], ref["hist"]) and np.array_equal(r["x"], ref["x"]), k
 
 
+@pytest.mark.parametrize("shape", [(24, 24, 24), (40, 32, 20)])
+def test_single_reduction_pcg_is_the_same_iteration(hd, monkeypatch, shape):
+    """HDA_PCG_SINGLE_REDUCE=1 (opt-in): the Chronopoulos-Gear form of PCG -- <r,u>, <w,u> and <r,r> in ONE reduction per iteration,
+    alpha from the recurrence -- is the same Krylov iteration in exact arithmetic: iteration count within 1 of hypre's recurrence,
+    residual history within 1e-6 relative step by step while both run, the same solution to the stopping tolerance."""
+    A = hd.lap7(*shape)
+    b = np.random.default_rng(7).standard_normal(shape[0] * shape[1] * shape[2])
+    out = {}
+    for sr in ("0", "1"):
+        monkeypatch.setenv("HDA_PCG_SINGLE_REDUCE", sr)
+        out[sr] = hd.pcg(A, b, hd.Amg(A), hd.KrylovParams.default(False, rtol=1e-9))
+    a, c = out["0"], out["1"]
+    assert a["converged"] and c["converged"] and abs(a["iters"] - c["iters"]) <= 1
+    m = min(len(a["hist"]), len(c["hist"]))
+    assert np.allclose(a["hist"][:m], c["hist"][:m], rtol=1e-6)
+    assert rel(c["x"], a["x"]) < 1e-7
+    S = A.to_scipy()
+    assert np.linalg.norm(b - S @ c["x"]) / np.linalg.norm(b) < 2e-9
+
+
 def test_spmv_rectangular(orc, hd):
     rng = np.random.default_rng(5)
     M = sp.random(123, 57, density=0.1, random_state=rng, format="csr")
