@@ -91,19 +91,21 @@ def main():
                                                    "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
     # level-0 transfer operators: the value-coded stream kernel in PLAIN mode without dot; P (x += P e) writes 8 B per fine row,
     # R (f_c = R t) 8 B per coarse row -- told apart by WRITE_SIZE
-    pr = [k for k in byk if "k_spmv_stream<0, false, true" in k]
+    # (since round 2 one of the two runs on the windowed kernel, and the restriction also writes the next level's first sweep:
+    # 2 x 8 B per coarse row)
+    pr = [k for k in byk if "k_spmv_stream<0, false, true" in k or "k_spmv_win<0, false, true" in k]
     if pr and len(F) == len(W):
         wmap = {d: v for d, _, v in W}
         pairs = [(v, wmap.get(d)) for d, k, v in F if k in pr and wmap.get(d) is not None]
         if pairs:
             wmax = max(w for _, w in pairs)
             Pp = [(f, w) for f, w in pairs if w >= 0.9 * wmax]
-            Rr = [(f, w) for f, w in pairs if 0.2 * wmax <= w <= 0.45 * wmax and f >= 0.5 * max(q for q, _ in pairs)]
+            Rr = [(f, w) for f, w in pairs if 0.2 * wmax <= w <= 0.75 * wmax and f >= 0.5 * max(q for q, _ in pairs)]
             for key, sel in (("level0_prolongation", Pp), ("level0_restriction", Rr)):
                 if sel:
                     f, w = statistics.median([q for q, _ in sel]), statistics.median([q for _, q in sel])
                     out[key + "_bytes_per_launch"] = fetch_factor * f * 1024 + write_factor * w * 1024
-                    out[key] = {"kernel": "k_spmv_stream<0, false, true, false> (value-coded level-0 transfer operator)", "launches": len(sel),
+                    out[key] = {"kernel": "k_spmv_stream / k_spmv_win <0, false, true, false> (value-coded level-0 transfer operator)", "launches": len(sel),
                                 "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
     out["round"] = os.path.basename(tag)
     json.dump(out, open(os.path.join(os.path.dirname(tag) or ".", "traffic.json"), "w"), indent=1)
