@@ -26,7 +26,8 @@ class AmgParams(C.Structure):
                 ("cheby_fraction", C.c_double),
                 ("smooth_num_levels", C.c_int), ("smooth_num_sweeps", C.c_int),
                 ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int),
-                ("agg_num_levels", C.c_int), ("agg_num_paths", C.c_int), ("agg_interp_type", C.c_int)]
+                ("agg_num_levels", C.c_int), ("agg_num_paths", C.c_int), ("agg_interp_type", C.c_int),
+                ("agg_pmax", C.c_int), ("agg_trunc_factor", C.c_double)]
 
     @staticmethod
     def default(**kw):
@@ -77,7 +78,7 @@ SYMBOLS = [
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
     "hda_thread_ranks_lap7", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
-    "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass",
+    "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass", "hda_truncate_rows",
 ]
 
 
@@ -116,6 +117,7 @@ def load():
     L.hda_second_strength.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, P(vp)]
     L.hda_coarsen_second_pass.argtypes = [vp, P(C.c_ubyte), C.c_int, C.c_uint64, C.c_int, ip]
     L.hda_interp_multipass.argtypes = [vp, P(C.c_ubyte), ip, P(vp)]
+    L.hda_truncate_rows.argtypes = [vp, C.c_int, C.c_double]
     L.hda_transpose.argtypes = [vp, P(vp)]
     L.hda_spgemm.argtypes = [vp, vp, P(vp)]
     L.hda_amg_create.argtypes = [P(AmgParams), vp, P(vp)]
@@ -294,6 +296,11 @@ class Csr:
         out = C.c_void_p()
         _check(load().hda_interp_multipass(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cfa), C.byref(out)))
         return Csr(out)
+
+    def truncate_rows(self, pmax=0, trunc_factor=0.0):
+        """hypre_BoomerAMGInterpTruncation on the finished rows of this interpolation matrix, in place"""
+        _check(load().hda_truncate_rows(self.h, pmax, trunc_factor))
+        return self
 
     def rap(self, P):
         out = C.c_void_p()

@@ -50,6 +50,8 @@ struct AmgParams {
    // aggressive coarsening (AMGagg_args, amg.c:160-173, 938-944; hda_amg_agg.hip): on the first agg_num_levels levels a second PMIS
    // pass over the distance-two strength graph (>= agg_num_paths paths of length <= 2) and multipass interpolation (type 4, untruncated)
    int agg_num_levels = 0, agg_num_paths = 1, agg_interp_type = 4;
+   int    agg_pmax = 0;           // aggressive.max_nnz_row (HYPRE_BoomerAMGSetAggPMaxElmts): 0 = no limit
+   double agg_trunc_factor = 0.0; // aggressive.trunc_factor (HYPRE_BoomerAMGSetAggTruncFactor)
 };
 
 // dependency levels of the local pattern for Gauss-Seidel sweeps (hda_gs.hip)
@@ -321,6 +323,7 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
 void amg_second_strength(const DCsr &A, const unsigned char *smask, const int *cf, int num_paths, DCsr &S2, DArray<int> &c1);
 void amg_coarsen_second_pass(const DCsr &A, const unsigned char *smask, int num_paths, uint64_t seed, int level, int *cf);
 void amg_interp_multipass(const DCsr &A, const unsigned char *smask, const int *cf, DCsr &P);
+void amg_truncate_rows(DCsr &P, int pmax, double trunc_factor); // hypre_BoomerAMGInterpTruncation on finished, column-sorted rows
 // hypre_ParCSRMatMat-style product C = X*Y, deterministic accumulation order, rows sorted.
 void spgemm(const DCsr &X, const DCsr &Y, DCsr &C);
 // hypre_BoomerAMGBuildCoarseOperator: Ac = R*(A*P) with R = P^T

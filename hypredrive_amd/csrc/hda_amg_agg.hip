@@ -200,6 +200,113 @@ __global__ __launch_bounds__(256) void k_mp_take(int n, int p, const int *__rest
    for (int k = s; k < e; k++, q++) { ocj[q] = scj[k]; ov[q] = sv[k]; }
 }
 
+// hypre_BoomerAMGInterpTruncation on a finished row, in place in the CSR arrays (thread per row; the same steps, sums and tie order
+// as the truncation inside the extended+i kernels and as the oracle's orc_truncate_row): relative threshold, the pmax largest,
+// row sum kept; the survivors are left column-sorted at the front of the row's slice.  cnt[i] = entries kept.
+__device__ void agg_qsort_abs(int *L, double *W, int n, int *stack)
+{ // descending |w|, K&R form: pivot = middle element swapped to the front, strict '>' partition, smaller partition first
+   int sp = 0;
+   stack[sp++] = 0;
+   stack[sp++] = n - 1;
+   while (sp > 0)
+   {
+      int right = stack[--sp], left = stack[--sp];
+      while (left < right)
+      {
+         const int mid = (left + right) / 2;
+         int       last = left, ti;
+         double    td;
+         ti = L[left]; L[left] = L[mid]; L[mid] = ti;
+         td = W[left]; W[left] = W[mid]; W[mid] = td;
+         const double piv = fabs(W[left]);
+         for (int i = left + 1; i <= right; i++)
+            if (fabs(W[i]) > piv)
+            {
+               ++last;
+               ti = L[last]; L[last] = L[i]; L[i] = ti;
+               td = W[last]; W[last] = W[i]; W[i] = td;
+            }
+         ti = L[left]; L[left] = L[last]; L[last] = ti;
+         td = W[left]; W[left] = W[last]; W[last] = td;
+         if (last - left < right - last)
+         {
+            stack[sp++] = last + 1; stack[sp++] = right;
+            right = last - 1;
+         }
+         else
+         {
+            stack[sp++] = left; stack[sp++] = last - 1;
+            left = last + 1;
+         }
+      }
+   }
+}
+__global__ __launch_bounds__(256) void k_agg_truncate(int n, const int *__restrict__ rp, int *cj, double *v, int pmax, double trunc_factor,
+                                                      int *__restrict__ cnt_out)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int    *L   = cj + rp[i];
+   double *W   = v + rp[i];
+   int     cnt = rp[i + 1] - rp[i];
+   if (trunc_factor > 0.0 && cnt > 0)
+   {
+      double mx = 0.0, tot = 0.0, kept = 0.0;
+      for (int q = 0; q < cnt; q++)
+      {
+         if (fabs(W[q]) > mx) mx = fabs(W[q]);
+         tot += W[q];
+      }
+      int c2 = 0;
+      for (int q = 0; q < cnt; q++)
+         if (fabs(W[q]) >= trunc_factor * mx)
+         {
+            L[c2] = L[q];
+            W[c2] = W[q];
+            kept += W[c2];
+            c2++;
+         }
+      cnt = c2;
+      if (kept != 0.0)
+      {
+         const double sc = tot / kept;
+         for (int q = 0; q < cnt; q++) W[q] *= sc;
+      }
+   }
+   if (pmax > 0 && cnt > pmax)
+   {
+      double tot = 0.0, kept = 0.0;
+      for (int q = 0; q < cnt; q++) tot += W[q];
+      int stk[64];
+      agg_qsort_abs(L, W, cnt, stk);
+      cnt = pmax;
+      for (int a = 1; a < cnt; a++) // kept set -> column order before summing
+      {
+         const int    cc = L[a];
+         const double ww = W[a];
+         int          b  = a - 1;
+         while (b >= 0 && L[b] > cc) { L[b + 1] = L[b]; W[b + 1] = W[b]; b--; }
+         L[b + 1] = cc;
+         W[b + 1] = ww;
+      }
+      for (int q = 0; q < cnt; q++) kept += W[q];
+      if (kept != 0.0)
+      {
+         const double sc = tot / kept;
+         for (int q = 0; q < cnt; q++) W[q] *= sc;
+      }
+   }
+   cnt_out[i] = cnt;
+}
+__global__ __launch_bounds__(256) void k_agg_compact(int n, const int *__restrict__ srp, const int *__restrict__ scj, const double *__restrict__ sv,
+                                                     const int *__restrict__ drp, int *__restrict__ dcj, double *__restrict__ dv)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   const int s = srp[i], d = drp[i], c = drp[i + 1] - d;
+   for (int k = 0; k < c; k++) { dcj[d + k] = scj[s + k]; dv[d + k] = sv[s + k]; }
+}
+
 // rowptr = exclusive scan of cnt; allocates col / val; returns nnz
 int finish_rows(int nrows, int ncols, DArray<int> &cnt, DCsr &M)
 {
@@ -216,6 +323,20 @@ int finish_rows(int nrows, int ncols, DArray<int> &cnt, DCsr &M)
 }
 
 } // namespace
+
+void amg_truncate_rows(DCsr &P, int pmax, double trunc_factor)
+{
+   if ((pmax <= 0 && trunc_factor <= 0.0) || P.nrows == 0) return;
+   const int   n = P.nrows, g = ceil_div(n, 256);
+   DArray<int> cnt((size_t)n + 1);
+   cnt.zero();
+   k_agg_truncate<<<g, 256, 0, STREAM>>>(n, P.rowptr.data(), P.col.data(), P.val.data(), pmax, trunc_factor, cnt.data());
+   DCsr Q;
+   finish_rows(n, P.ncols, cnt, Q);
+   k_agg_compact<<<g, 256, 0, STREAM>>>(n, P.rowptr.data(), P.col.data(), P.val.data(), Q.rowptr.data(), Q.col.data(), Q.val.data());
+   P = std::move(Q);
+   P.reset_plan();
+}
 
 void amg_second_strength(const DCsr &A, const unsigned char *smask, const int *cf, int num_paths, DCsr &S2, DArray<int> &c1)
 {

@@ -2181,7 +2181,11 @@ void Amg::build_hierarchy(const DCsr &A)
       HDA_TRACE("level %d: interp%s", lvl, aggressive ? " (aggressive level: multipass)" : "");
       auto t2 = tick();
       DCsr P;
-      if (aggressive) amg_interp_multipass(Al, sm.data(), cf.data(), P);
+      if (aggressive)
+      {
+         amg_interp_multipass(Al, sm.data(), cf.data(), P);
+         amg_truncate_rows(P, prm.agg_pmax, prm.agg_trunc_factor);
+      }
       else amg_interp_extpi(Al, sm.data(), cf.data(), prm.pmax, prm.trunc_factor, P, dof, prm.interp_type);
       auto t3 = tick();
       const int nc = P.ncols;
@@ -2288,7 +2292,8 @@ void Amg::setup_dist(const DCsr &Aloc, const HaloPlan &hA0_, const std::vector<l
                      const std::vector<long long> &ghost_gids0)
 {
    Comm &cm = Comm::world();
-   HDA_REQUIRE(prm.agg_num_levels <= 0, "aggressive coarsening is implemented on one rank only (the second strength graph reaches two ghost layers deep)");
+   // (aggressive coarsening runs here, on the gathered operator, like every option the partitioned setup does not build: its
+   // second strength graph reaches two ghost layers deep)
    HDA_TRACE("setup_dist: gathering the operator on %d ranks (%s)", cm.size, cm.name());
    DCsr G0;
    gather_global(Aloc, part0, ghost_gids0, G0);
@@ -3697,7 +3702,7 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
    Comm &cm = Comm::world();
    HDA_REQUIRE(prm.coarsen_type == 8 && (prm.interp_type == 6 || prm.interp_type == 17) && prm.num_functions <= 1,
                "partitioned setup: scalar PMIS + extended+i only");
-   HDA_REQUIRE(prm.agg_num_levels <= 0, "aggressive coarsening is implemented on one rank only (the second strength graph reaches two ghost layers deep)");
+   HDA_REQUIRE(prm.agg_num_levels <= 0, "partitioned setup: aggressive coarsening needs the replicated setup (the second strength graph reaches two ghost layers deep)");
    const long long rep_rows = replicate_rows(cm.size);
    const bool verbose = getenv("HDA_VERBOSE") != nullptr;
    // HDA_GHOST_PROLONG=0: the prolongation leaves ghost copies alone and the post-smoothing sweep refreshes them (4 exchanges per

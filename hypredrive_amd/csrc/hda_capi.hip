@@ -88,6 +88,7 @@ extern "C" void hda_amg_default_params(hda_amg_params *p)
    p->smooth_num_levels = d.smooth_num_levels; p->smooth_num_sweeps = d.smooth_num_sweeps;
    p->ilu_tri_solve = d.ilu.tri_solve; p->ilu_lower_it = d.ilu.lower_it; p->ilu_upper_it = d.ilu.upper_it;
    p->agg_num_levels = d.agg_num_levels; p->agg_num_paths = d.agg_num_paths; p->agg_interp_type = d.agg_interp_type;
+   p->agg_pmax = d.agg_pmax; p->agg_trunc_factor = d.agg_trunc_factor;
 }
 extern "C" void hda_krylov_default_params(hda_krylov_params *p, int gmres)
 {
@@ -110,6 +111,7 @@ static AmgParams to_params(const hda_amg_params *p)
    a.smooth_num_levels = p->smooth_num_levels; a.smooth_num_sweeps = p->smooth_num_sweeps;
    a.ilu.tri_solve = p->ilu_tri_solve; a.ilu.lower_it = p->ilu_lower_it; a.ilu.upper_it = p->ilu_upper_it;
    a.agg_num_levels = p->agg_num_levels; a.agg_num_paths = p->agg_num_paths; a.agg_interp_type = p->agg_interp_type;
+   a.agg_pmax = p->agg_pmax; a.agg_trunc_factor = p->agg_trunc_factor;
    return a;
 }
 static KrylovParams to_kparams(const hda_krylov_params *p)
@@ -379,6 +381,14 @@ extern "C" int hda_interp_multipass(hda_csr_t A, const unsigned char *smask, con
    amg_interp_multipass(m, sm.data(), dcf.data(), h->m);
    Context::get().sync();
    *P = h.release();
+   HDA_CATCH
+}
+
+extern "C" int hda_truncate_rows(hda_csr_t P, int pmax, double trunc_factor)
+{
+   HDA_TRY
+   amg_truncate_rows(const_cast<DCsr &>(P->get()), pmax, trunc_factor);
+   Context::get().sync();
    HDA_CATCH
 }
 

@@ -1143,9 +1143,9 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    if (s->ap.agg_num_levels > 0)
    {
       HDA_REQUIRE(s->ap.agg_interp_type == 4, "aggressive coarsening: only multipass interpolation (aggressive.prolongation_type 4 / multipass) is implemented on MI355X");
-      HDA_REQUIRE(s->agg_trunc[0] == 0.0 && s->agg_trunc[1] == 0.0 && s->agg_trunc[2] == 0.0 && s->agg_trunc[3] == 0.0,
-                  "aggressive coarsening: truncation of the aggressive levels' interpolation (aggressive.max_nnz_row / trunc_factor / P12_*) is not implemented on MI355X");
-      HDA_REQUIRE(Comm::world().size == 1, "aggressive coarsening is implemented on one rank only");
+      s->ap.agg_trunc_factor = s->agg_trunc[0];
+      s->ap.agg_pmax         = (int)s->agg_trunc[2];
+      // (P12_* concern the two-stage interpolation types only, which are refused above: accepted and unused, as in hypre with type 4)
    }
    if (s->smooth_num_levels > 0)
    {
@@ -1174,7 +1174,8 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
       // the specification the partitioned setup is checked against (HDA_DIST_CHECK=1)
       const char *mode = getenv("HDA_DIST_SETUP");
       // (HMIS = sequential Ruge pass: only the replicated scheme can run it, on the gathered operator)
-      if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8 || s->ap.num_functions > 1 || s->ap.smooth_num_levels > 1) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+      // (aggressive levels: their second strength graph reaches two ghost layers deep -- built on the gathered operator too)
+      if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8 || s->ap.num_functions > 1 || s->ap.smooth_num_levels > 1 || s->ap.agg_num_levels > 0) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
       else s->amg->setup_dist_partitioned(A->A, A->halo, A->part, A->ghost_gids);
    }
    else s->amg->setup(A->A);

@@ -49,6 +49,8 @@ typedef struct {
    /* AMGagg_args (src/internal/amg.c:160-173, forwarded at :938-944): aggressive coarsening on the first agg_num_levels levels
     * (second PMIS pass over the graph of >= agg_num_paths paths of length <= 2), multipass interpolation (agg_interp_type 4) there */
    int      agg_num_levels, agg_num_paths, agg_interp_type;
+   int      agg_pmax;         /* aggressive.max_nnz_row (0: no limit) */
+   double   agg_trunc_factor; /* aggressive.trunc_factor */
 } hda_amg_params;
 
 /* PCG_args src/internal/pcg.c:15-25 / GMRES_args src/internal/gmres.c:16-27 */
@@ -111,6 +113,8 @@ int hda_rap(hda_csr_t A, hda_csr_t P, hda_csr_t *Ac);
 int hda_second_strength(hda_csr_t A, const unsigned char *smask, const int *cf, int num_paths, hda_csr_t *S2);
 int hda_coarsen_second_pass(hda_csr_t A, const unsigned char *smask, int num_paths, uint64_t seed, int level, int *cf);
 int hda_interp_multipass(hda_csr_t A, const unsigned char *smask, const int *cf, hda_csr_t *P);
+/* hypre_BoomerAMGInterpTruncation on the finished rows of P, in place (HYPRE_BoomerAMGSetAggPMaxElmts / SetAggTruncFactor) */
+int hda_truncate_rows(hda_csr_t P, int pmax, double trunc_factor);
 int hda_transpose(hda_csr_t A, hda_csr_t *T);
 int hda_spgemm(hda_csr_t X, hda_csr_t Y, hda_csr_t *C);
 

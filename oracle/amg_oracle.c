@@ -46,6 +46,7 @@ orc_amg_default_params(orc_amg_params *p, int gpu_defaults)
    p->cheby_order = 2; p->cheby_eig_est = 10; p->cheby_variant = 0; p->cheby_scale = 1; p->cheby_fraction = 0.3;
    p->num_functions   = 1;
    p->agg_num_levels = 0; p->agg_num_paths = 1; p->agg_interp_type = 4; /* amg.c:164-171 */
+   p->agg_pmax = 0; p->agg_trunc_factor = 0.0;
 }
 
 /* src/internal/pcg.c:15-25, src/internal/gmres.c:16-27 */
@@ -1269,6 +1270,31 @@ orc_interp_multipass(const orc_csr *A, const unsigned char *smask, const int *cf
    return W;
 }
 
+/* hypre_BoomerAMGInterpTruncation applied to a finished interpolation (the aggressive levels' multipass rows): every row, in its
+ * stored (column) order, goes through orc_truncate_row -- the same threshold / keep-the-largest / rescale steps and the same tie
+ * order as the truncation inside the extended+i routine. */
+void
+orc_truncate_rows(orc_csr *P, int pmax, double trunc_factor)
+{
+   if (pmax <= 0 && trunc_factor <= 0.0) return;
+   const int n = P->nrows;
+   int cap = 64, q = 0;
+   pent *row = (pent *)malloc(sizeof(pent) * (size_t)cap);
+   int *nrp = (int *)calloc((size_t)n + 1, sizeof(int));
+   for (int i = 0; i < n; i++)
+   {
+      int cnt = P->rowptr[i + 1] - P->rowptr[i];
+      if (cnt > cap) { cap = 2 * cnt; row = (pent *)realloc(row, sizeof(pent) * (size_t)cap); }
+      for (int k = 0; k < cnt; k++) { row[k].c = P->col[P->rowptr[i] + k]; row[k].w = P->val[P->rowptr[i] + k]; }
+      cnt = orc_truncate_row(row, cnt, pmax, trunc_factor);
+      qsort(row, (size_t)cnt, sizeof(pent), pent_cmp_col);
+      for (int k = 0; k < cnt; k++) { P->col[q] = row[k].c; P->val[q++] = row[k].w; } /* (q never passes the read position) */
+      nrp[i + 1] = q;
+   }
+   memcpy(P->rowptr, nrp, sizeof(int) * (size_t)(n + 1));
+   free(nrp); free(row);
+}
+
 /* ------------------------------------------------------------------ Chebyshev smoother (relax type 16)
  * hypre_ParCSRRelax_Cheby_Setup / _Solve and hypre_ParCSRMaxEigEstimateCG as configured by
  * HYPRE_BoomerAMGSetCheby{Order,Fraction,EigEst,Variant,Scale} (reference src/internal/amg.c:886-890, cheby.c:15-20).
@@ -1659,9 +1685,10 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
          break;
       }
       h->cf[lvl] = cf;
-      h->P[lvl]  = aggressive ? orc_interp_multipass(A, sm, cf)
+      h->P[lvl]  = aggressive ? orc_interp_multipass(A, sm, cf)  /* (truncated below) */
                    : (p->interp_type == 3) ? orc_interp_direct_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
                                           : orc_interp_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof);
+      if (aggressive) orc_truncate_rows(h->P[lvl], p->agg_pmax, p->agg_trunc_factor);
       if (dof)
       { /* coarse unknowns keep the function of their fine C point */
          int q = 0;

@@ -60,6 +60,10 @@ typedef struct {
     * length <= 2) and the interpolation is multipass (agg_interp_type 4, the only one restated; no truncation: the reference's defaults
     * max_nnz_row 0 / trunc_factor 0).  PARITY UNPINNED: no reference output uses it. */
    int    agg_num_levels, agg_num_paths, agg_interp_type;
+   /* truncation of the aggressive levels' interpolation (aggressive.max_nnz_row / trunc_factor -> HYPRE_BoomerAMGSetAggPMaxElmts /
+    * SetAggTruncFactor, amg.c:940-942; both 0 = none by default): hypre_BoomerAMGInterpTruncation on the finished multipass rows */
+   int    agg_pmax;
+   double agg_trunc_factor;
 } orc_amg_params;
 
 typedef struct orc_amg orc_amg; /* hierarchy handle */
@@ -126,6 +130,8 @@ orc_csr *orc_rap(const orc_csr *A, const orc_csr *P);
 orc_csr *orc_second_strength(const orc_csr *A, const unsigned char *smask, const int *cf, int num_paths);
 void     orc_coarsen_second_pass(const orc_csr *A, const unsigned char *smask, int num_paths, uint64_t seed, int level, int *cf);
 orc_csr *orc_interp_multipass(const orc_csr *A, const unsigned char *smask, const int *cf);
+/* hypre_BoomerAMGInterpTruncation on finished (column-sorted) rows, in place: relative threshold, then the pmax largest, row sums kept */
+void     orc_truncate_rows(orc_csr *P, int pmax, double trunc_factor);
 
 /* Hierarchy */
 orc_amg *orc_amg_setup(const orc_csr *A, const orc_amg_params *p);

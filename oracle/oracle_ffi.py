@@ -29,7 +29,8 @@ class AmgParams(C.Structure):
                 ("seed", C.c_uint64), ("num_functions", C.c_int),
                 ("cheby_order", C.c_int), ("cheby_eig_est", C.c_int), ("cheby_variant", C.c_int), ("cheby_scale", C.c_int),
                 ("cheby_fraction", C.c_double),
-                ("agg_num_levels", C.c_int), ("agg_num_paths", C.c_int), ("agg_interp_type", C.c_int)]
+                ("agg_num_levels", C.c_int), ("agg_num_paths", C.c_int), ("agg_interp_type", C.c_int),
+                ("agg_pmax", C.c_int), ("agg_trunc_factor", C.c_double)]
 
 
 class KrylovParams(C.Structure):
@@ -102,6 +103,7 @@ def lib():
     L.orc_coarsen_second_pass.argtypes = [cp, P(C.c_ubyte), C.c_int, C.c_uint64, C.c_int, ip]
     L.orc_interp_multipass.restype = cp
     L.orc_interp_multipass.argtypes = [cp, P(C.c_ubyte), ip]
+    L.orc_truncate_rows.argtypes = [cp, C.c_int, C.c_double]
     L.orc_amg_setup.restype = C.c_void_p
     L.orc_amg_setup.argtypes = [cp, P(AmgParams)]
     L.orc_amg_setup_dof.restype = C.c_void_p
@@ -336,6 +338,12 @@ def interp_multipass(A, smask, cf):
     sm = np.ascontiguousarray(smask, dtype=np.uint8)
     cfa = np.ascontiguousarray(cf, dtype=np.int32)
     return Csr(lib().orc_interp_multipass(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), cfa.ctypes.data_as(C.POINTER(C.c_int))))
+
+
+def truncate_rows(P, pmax=0, trunc_factor=0.0):
+    """hypre_BoomerAMGInterpTruncation on finished rows, in place (the aggressive levels' multipass interpolation)"""
+    lib().orc_truncate_rows(P.ptr, pmax, trunc_factor)
+    return P
 
 
 def rap(A, P):

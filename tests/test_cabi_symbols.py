@@ -40,10 +40,10 @@ def test_param_struct_layout_matches_oracle(orc):
         assert getattr(hp, name) == getattr(op, name), name
         assert getattr(h.AmgParams, name).offset == getattr(orc.AmgParams, name).offset, name
     # the aggressive-coarsening fields close both structs (AMGagg_args defaults of src/internal/amg.c:164-171: 0 levels, 1 path, multipass)
-    assert every[len(shared):] == ["agg_num_levels", "agg_num_paths", "agg_interp_type"] == [n for (n, _t) in h.AmgParams._fields_][-3:]
+    assert every[len(shared):] == ["agg_num_levels", "agg_num_paths", "agg_interp_type", "agg_pmax", "agg_trunc_factor"] == [n for (n, _t) in h.AmgParams._fields_][-5:]
     for name in every[len(shared):]:
         assert getattr(hp, name) == getattr(op, name), name
-    assert (hp.agg_num_levels, hp.agg_num_paths, hp.agg_interp_type) == (0, 1, 4)
+    assert (hp.agg_num_levels, hp.agg_num_paths, hp.agg_interp_type, hp.agg_pmax, hp.agg_trunc_factor) == (0, 1, 4, 0, 0.0)
     # ILU_args defaults of src/internal/ilu.c:21-23 and smoother off (amg.c:237)
     assert (hp.smooth_num_levels, hp.smooth_num_sweeps, hp.ilu_tri_solve, hp.ilu_lower_it, hp.ilu_upper_it) == (0, 1, 1, 5, 5)
     assert (hp.coarsen_type, hp.relax_down, hp.relax_up, hp.relax_coarse) == (8, 18, 18, 9)

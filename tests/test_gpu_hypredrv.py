@@ -941,7 +941,8 @@ def test_spe10_like_gmres_amg_ilu_matches_oracle(hd, orc, tmp_path, via):
 def test_yaml_aggressive_coarsening_matches_oracle(hd, orc, tmp_path):
     """`preconditioner: amg: aggressive: {num_levels: 1}` (reference AMGagg_args, src/internal/amg.c:160-173 -> HYPRE_BoomerAMGSetAgg*
     at :938-944) through the HYPREDRV_* API: the oracle's iteration count and solution; `num_paths: 2` likewise; what is not built
-    (a two-stage interpolation type, a truncation of the aggressive levels' interpolation, row partitions) is refused by name."""
+    (a two-stage interpolation type) is refused by name; `max_nnz_row` / `trunc_factor` truncate the aggressive levels' interpolation as in
+    the oracle; on row partitions the aggressive levels come from the replicated setup."""
     n = 20
     Ao, b = orc.lap7(n, n, n)
     for paths in (1, 2):
@@ -954,21 +955,43 @@ def test_yaml_aggressive_coarsening_matches_oracle(hd, orc, tmp_path):
         h.close()
     plain = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True)))
     assert ref["iters"] > plain["iters"]  # the cheaper hierarchy costs iterations
-    for extra, what in (("prolongation_type: 2_stage_extended+i", "multipass"), ("max_nnz_row: 4", "truncation"), ("trunc_factor: 0.1", "truncation")):
+    # truncation of the aggressive levels' interpolation (aggressive.max_nnz_row / trunc_factor -> SetAggPMaxElmts / SetAggTruncFactor)
+    for extra, kw in (("max_nnz_row: 2", dict(agg_pmax=2)), ("trunc_factor: 0.3", dict(agg_trunc_factor=0.3))):
+        ref2 = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True, agg_num_levels=1, **kw)))
         h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    aggressive:\n      num_levels: 1\n      " + extra + "\n")
-        h.set_laplacian7((8, 8, 8))
-        with pytest.raises(hd.HypredrvError, match=what):
-            h.solve()
-        hd.lib().HYPREDRV_ErrorCodeClear()
+        h.set_laplacian7((n, n, n))
+        r = h.solve()
+        assert r["converged"] and r["iters"] == ref2["iters"], (extra, r["iters"], ref2["iters"])
         h.close()
-    # two ranks: refused on every rank, not silently solved with another hierarchy
-    out = str(tmp_path / "agg2.json")
-    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1",
-               HDA_TEST_YAML="solver: pcg\npreconditioner:\n  amg:\n    aggressive:\n      num_levels: 1\n")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, "2000", "3"]
+    # the two-stage interpolation types are not built: refused by name
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    aggressive:\n      num_levels: 1\n      prolongation_type: 2_stage_extended+i\n")
+    h.set_laplacian7((8, 8, 8))
+    with pytest.raises(hd.HypredrvError, match="multipass"):
+        h.solve()
+    hd.lib().HYPREDRV_ErrorCodeClear()
+    h.close()
+    # row partitions (three ranks, irregular matrix): the aggressive levels are built on the gathered operator (the replicated setup,
+    # like HMIS and systems AMG) and cut into row blocks -- the single-rank hierarchy, so the single-rank iteration count
+    nn, seed = 4000, 3
+    yaml = "solver: pcg\npreconditioner:\n  amg:\n    aggressive:\n      num_levels: 1\n"
+    out = str(tmp_path / "agg3.json")
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", HDA_REPLICATE_ROWS="300", HDA_TEST_YAML=yaml)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "csr", out, str(nn), str(seed)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and "one rank only" in (r.stdout + r.stderr)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    res = json.load(open(out))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import random_mmatrix
+    M = random_mmatrix(seed, nn)
+    h = hd.Hypredrv(yaml)
+    h.set_matrix_csr(0, nn - 1, M.indptr, M.indices, M.data)
+    h.set_rhs_array(0, nn - 1, np.ones(nn))
+    h.finish_system()
+    one = h.solve()
+    assert res["converged"] and res["iters"] == one["iters"]
+    assert res["norm"] == pytest.approx(h.solution_norm("L2"), rel=1e-8)
+    h.close()
 
 
 def test_yaml_unimplemented_ilu_variants_fail_loudly(hd):

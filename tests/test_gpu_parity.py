@@ -439,6 +439,15 @@ def test_aggressive_coarsening_stages_bit_exact(orc, hd, num_paths):
         rp, cj, v = Ah.interp_multipass(sm, cfo).download()
         assert np.array_equal(rp, Po.rowptr) and np.array_equal(cj, Po.col)
         assert np.array_equal(v, Po.val), np.abs(v - Po.val).max()
+        # truncation of the finished rows (aggressive.max_nnz_row / trunc_factor): same survivors, same rescaled weights, row sums kept
+        for pmax, tf in ((2, 0.0), (0, 0.4), (3, 0.2)):
+            Pt_o = orc.truncate_rows(orc.interp_multipass(Ao, sm, cfo), pmax, tf)
+            rp2, cj2, v2 = Ah.interp_multipass(sm, cfo).truncate_rows(pmax, tf).download()
+            assert np.array_equal(rp2, Pt_o.rowptr) and np.array_equal(cj2, Pt_o.col) and np.array_equal(v2, Pt_o.val), (pmax, tf)
+            if pmax:
+                assert np.diff(rp2).max() <= pmax
+            full, cut = Po.to_scipy().tocsr(), Pt_o.to_scipy().tocsr()
+            assert np.allclose(np.asarray(cut.sum(axis=1)).ravel(), np.asarray(full.sum(axis=1)).ravel(), rtol=1e-12, atol=1e-14)
         # what multipass interpolation promises: C rows are identity rows; a row sums to (a_ii - rowsum_i) / a_ii times the mean row
         # sum of the rows it interpolates through -- exactly 1 everywhere on an operator whose rows all sum to zero (below)
         P = Po.to_scipy().tocsr()
@@ -464,15 +473,17 @@ def test_aggressive_coarsening_stages_bit_exact(orc, hd, num_paths):
     assert np.allclose(np.asarray(P.sum(axis=1)).ravel()[filled], 1.0, atol=1e-12)
 
 
-@pytest.mark.parametrize("shape,agg", [((16, 16, 16), 1), ((20, 18, 16), 2), ((24, 24, 24), 1)])
-def test_aggressive_hierarchy_and_pcg_match_oracle(orc, hd, shape, agg):
+@pytest.mark.parametrize("shape,agg,trunc", [((16, 16, 16), 1, None), ((20, 18, 16), 2, None), ((24, 24, 24), 1, None), ((20, 20, 20), 1, (2, 0.0)),
+                                             ((18, 18, 18), 2, (0, 0.3))])
+def test_aggressive_hierarchy_and_pcg_match_oracle(orc, hd, shape, agg, trunc):
     """`aggressive.num_levels` 1 and 2: every operator and interpolation of the hierarchy bit-identical to the oracle's, the coarsening
     really is aggressive (first level coarsens by more than 8 where PMIS + extended+i coarsens by about 3; operator complexity below
     1.5 against 2.6), PCG takes the oracle's iterations with the oracle's history."""
     Ao, b = orc.lap7(*shape)
     Ah = hd.lap7(*shape)
-    ho = orc.Amg(Ao, orc.amg_params(True, agg_num_levels=agg))
-    hh = hd.Amg(Ah, hd.AmgParams.default(agg_num_levels=agg))
+    extra = dict(agg_pmax=trunc[0], agg_trunc_factor=trunc[1]) if trunc else {}
+    ho = orc.Amg(Ao, orc.amg_params(True, agg_num_levels=agg, **extra))
+    hh = hd.Amg(Ah, hd.AmgParams.default(agg_num_levels=agg, **extra))
     assert hh.num_levels == ho.num_levels
     for l in range(ho.num_levels):
         rp, cj, v = hh.level_matrix(l, 0).download()
