@@ -407,15 +407,18 @@ def _thread_ranks(tmp_path, tag, n, P, solver="pcg", want_x="1", **envx):
     return json.load(open(out)), (np.load(out + ".x.npy") if want_x == "1" else None), r.stderr
 
 
-@pytest.mark.parametrize("n,rep_rows,check", [(40, 2000, "1"), (40, 2000, "0"), (32, 0, "0"), (48, 100000, "0")])
-def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check):
+@pytest.mark.parametrize("n,rep_rows,check,extra", [(40, 2000, "1", {}), (40, 2000, "0", {}), (32, 0, "0", {}), (48, 100000, "0", {}),
+                                                    (40, 2000, "0", {"HDA_OVERLAP": "1"}), (36, 1500, "0", {"HDA_PCG_SINGLE_REDUCE": "1"})])
+def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check, extra):
     """BASELINE config 3's layout -- `-P 2 2 2` (reference examples/src/C_laplacian/laplacian.c:561-582, scripts/node_scaling.sh:1275-1292) --
     with eight ranks: blocks have face, EDGE and CORNER neighbours (7 peers), which no 1xPxQ layout produces, on every partitioned
     level.  rep_rows 2000 keeps three levels partitioned at 40^3 (64 000 / ~21 000 / ~4 500 rows) above the replicated tail; 0 keeps
     every level partitioned; 100000 hands level 1 to the tail.  check = "1": HDA_DIST_CHECK, the partitioned setup compared level by
     level with the replicated one inside the library.  Against one rank: iteration count within 1, every rank the same count,
     solution norms to 1e-6 (the stopping tolerance), the gathered solution's norm to rounding."""
-    res, x, err = _thread_ranks(tmp_path, f"t{n}_{rep_rows}_{check}", n, (2, 2, 2), HDA_REPLICATE_ROWS=str(rep_rows), HDA_DIST_CHECK=check)
+    # extra: HDA_OVERLAP=1 -- every product runs its owned-column part while the ghosts travel and adds the ghost-column part afterwards
+    # (the RCCL default), here with 7 peers per block; HDA_PCG_SINGLE_REDUCE=1 -- the opt-in one-reduction PCG
+    res, x, err = _thread_ranks(tmp_path, f"t{n}_{rep_rows}_{check}", n, (2, 2, 2), HDA_REPLICATE_ROWS=str(rep_rows), HDA_DIST_CHECK=check, **extra)
     h = hd.Hypredrv("solver: pcg\npreconditioner:\n  preset: poisson\n")
     h.set_laplacian7((n, n, n))
     ref = h.solve()
