@@ -22,6 +22,9 @@ for seed in seeds:
     M = M.tocsr(); M.eliminate_zeros(); M.sort_indices()
     Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
     kw = dict(strong_th=float(rng.choice([0.25, 0.5, 0.7])), pmax=int(rng.choice([0, 2, 4, 6])), interp_type=int(rng.choice([6, 6, 3])))
+    if os.environ.get("FUZZ_AGG", "1") != "0":  # round 3: aggressive levels (second PMIS pass, multipass interpolation, its truncation)
+        kw.update(agg_num_levels=int(rng.choice([0, 0, 1, 2])), agg_num_paths=int(rng.choice([1, 1, 2])), agg_pmax=int(rng.choice([0, 0, 3])),
+                  agg_trunc_factor=float(rng.choice([0.0, 0.0, 0.2])))
     try:
         ho, hh = orc.Amg(Ao, orc.amg_params(True, **kw)), hd.Amg(Ah, hd.AmgParams.default(**kw))
         ok = hh.num_levels == ho.num_levels
