@@ -168,6 +168,9 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
    // first-sweep offer of the preconditioner (hda_amg.h FirstSweepFusion): renewed by every application, used by the next update
    FirstSweepFusion &fs = first_sweep_fusion();
    fs                   = FirstSweepFusion();
+   struct FsReset { // also on the way out through an exception: a flag left set would make the next solver's first cycle skip its sweep
+      ~FsReset() { first_sweep_fusion() = FirstSweepFusion(); }
+   } fs_reset;
    const double *z0_dinv = nullptr;
    double       *z0_dest = nullptr;
    bool          z0_self = false; // the offered destination is the output vector of the next application
