@@ -398,14 +398,20 @@ __global__ __launch_bounds__(256) void k_strong_fill(int n, const int *__restric
    for (int k = rp[i]; k < rp[i + 1]; k++)
       if (sm[k]) { scj[d] = cj[k]; sv[d] = 1.0; d++; }
 }
-constexpr int kRsMaxRows = 200000; // one device thread: ~1 us per dependent access
+// one device thread: about 8.5 us per row of a hierarchy's setup (58^3: 1.7 s, measured round 3), so 2.5 M rows -- a 128^3 grid, where a
+// run with the reference's CPU defaults is still a sensible parity check -- cost about 20 s.  HDA_HMIS_MAX_ROWS moves the limit.
+static int rs_max_rows()
+{
+   static const int v = getenv("HDA_HMIS_MAX_ROWS") ? atoi(getenv("HDA_HMIS_MAX_ROWS")) : 2500000;
+   return v;
+}
 
 void amg_rs_first_pass(const DCsr &A, const unsigned char *smask, const int *ns, int *cf)
 {
    const int n = A.nrows;
    if (!n) return;
-   HDA_REQUIRE(n <= kRsMaxRows, "HMIS / Ruge first pass runs as one device thread (parity with the reference's CPU defaults on small "
-                                "systems); use PMIS (coarsening type pmis) above 200000 rows");
+   HDA_REQUIRE(n <= rs_max_rows(), "HMIS / Ruge first pass runs as one device thread (parity with the reference's CPU defaults, about 8.5 us "
+                                   "per row); use PMIS (coarsening type pmis) above 2500000 rows, or raise HDA_HMIS_MAX_ROWS and wait");
    DCsr S, T;
    S.nrows = n;
    S.ncols = A.ncols;

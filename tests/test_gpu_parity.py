@@ -568,9 +568,27 @@ def test_pin_ex1_reference_cpu_defaults_on_gpu(hd, pins):
 
 
 def test_hmis_refuses_large_systems(hd):
-    A = hd.lap7(64, 64, 64)  # 262144 rows > the one-thread limit
+    A = hd.lap7(140, 140, 140)  # 2 744 000 rows > the one-thread limit of 2 500 000
     with pytest.raises(hd.LibraryError, match="HMIS"):
         hd.Amg(A, hd.AmgParams.default(coarsen_type=10))
+
+
+def test_hmis_cpu_defaults_at_64_cubed_match_oracle(orc, hd):
+    """The reference's CPU-build defaults (HMIS + hybrid l1 Gauss-Seidel 13 / 14, src/internal/amg.c:138-146,183-189) one size above
+    what round 2 allowed (262 144 rows; the Ruge first pass is one device thread, 2.5 M rows is the limit now): same C/F splitting
+    on every level, PCG with the oracle's iterations and history."""
+    n = 64
+    Ao, b = orc.lap7(n, n, n)
+    Ah = hd.lap7(n, n, n)
+    po = orc.amg_params(False)
+    ph = hd.AmgParams.default(coarsen_type=po.coarsen_type, relax_down=po.relax_down, relax_up=po.relax_up, relax_coarse=po.relax_coarse)
+    ho, hh = orc.Amg(Ao, po), hd.Amg(Ah, ph)
+    assert hh.num_levels == ho.num_levels
+    for l in range(ho.num_levels - 1):
+        assert np.array_equal(hh.level_cf(l), ho.level_cf(l)), f"C/F level {l}"
+    ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
 
 
 @pytest.mark.parametrize("cpu_defaults,layout", [(False, "interleaved"), (True, "interleaved"), (False, "contiguous")])
