@@ -128,6 +128,9 @@ def spawn_ranks(args):
 
 # ------------------------------------------------------------------------------------------- one rank
 
+PHASE = {"name": "start"}  # where a multi-rank run is: what the watchdog of main() reports when the run never finishes
+
+
 def error_line(stage, rank, msg):
     """A first multi-GPU run that cannot join RCCL says where in ONE JSON line on stdout (stage: uid | init | halo_comm | selftest |
     devices | peer | fallback | timeout:<stage>), then the process exits non-zero."""
@@ -211,6 +214,7 @@ def run(args):
     # the reference's protocol is one warm-up run, then the timed ones (scripts/node_scaling.sh): the first setup of a
     # process also pays for device-memory allocation (bimodal, 0.03-0.9 s on these boxes), the second one runs out of the
     # library's caching allocator and is the "prec" timer proper
+    PHASE["name"] = "setup"
     setup = []
     for _ in range(2):
         hh.sync()
@@ -224,6 +228,7 @@ def run(args):
             h.destroy_solver()
     setup = w.reduce(setup, "max")
     A, amg = hh._lib.borrow(h)  # the objects HYPREDRV_LinearSolverSetup built, for the kernel-level measurement entries
+    PHASE["name"] = "warmup"
     for _ in range(args.warmup):
         h.apply()
     # probes: HIP events on the library stream around every launch of four kernels inside the timed solves.
@@ -248,6 +253,7 @@ def run(args):
         probes["P0"] = hh._lib.probe_add(P0, 0)
         probes["R0"] = hh._lib.probe_add(R0, 0)
     hh._lib.comm_stats(reset=True)
+    PHASE["name"] = "timed solves"
     w.barrier()
     hh.sync()
     t0 = time.perf_counter()
@@ -259,6 +265,7 @@ def run(args):
     hh.sync()
     w.barrier()
     dt = w.reduce([time.perf_counter() - t0], "max")[0]
+    PHASE["name"] = "report"
     ms_per_step = dt * 1e3 / args.steps
     cs = hh._lib.comm_stats()
     pr = {k: hh._lib.probe_read_id(v) for k, v in probes.items()}
@@ -567,8 +574,25 @@ def main():
         sys.exit(spawn_ranks(args))
     if world is not None and int(world) != args.gpus:
         print(f"bench.py: launcher started {world} ranks, --gpus says {args.gpus}: using {world}", file=sys.stderr)
+    if world is not None and int(world) > 1:
+        # a multi-rank run that hangs (a collective one rank never enters) must say where before the launcher's own limit ends it silently
+        import threading
+        limit = float(os.environ.get("HDA_BENCH_TIMEOUT", "900"))
+
+        def hang():
+            error_line("hang:" + PHASE["name"], int(os.environ.get("RANK", "0")), f"bench.py did not finish within {limit:.0f} s")
+            os._exit(4)
+
+        wd = threading.Timer(limit, hang)
+        wd.daemon = True
+        wd.start()
+    else:
+        wd = None
     out = run(args)
+    if wd is not None:
+        wd.cancel()  # (the child launches below have limits of their own)
     if out is not None:
+        PHASE["name"] = "extras (strong / n1 child launches)"
         if out["n_gpus"] > 1 and not (args.child or args.no_extras or args.strong or args.workload != "lap7"):
             try:
                 multi_extras(args, out)
