@@ -396,6 +396,23 @@ def single_extras(args, out, hh, A, amg, fb0, iters):
         out["kernels"] = kt
     if not args.no_plain_csr and fb0["coded"]:
         out["plain_csr"] = plain_csr_child(args)
+    if not args.no_traffic and args.n == 256:
+        t, why = measure_traffic(args)
+        rf = out["roofline"]
+        if t is not None:
+            dom_key = [k for k in t if k.startswith("k_spmv_stream_jacobi_level") and k.endswith("_bytes_per_launch")]
+            if dom_key:
+                rf["traffic"] = t[dom_key[0]]
+                rf["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over a one-solve child "
+                                        f"({t['seconds']:.0f} s), tools/pmc_traffic.py; FETCH_SIZE unit calibrated on k_cg_dir: x{t['calibration']['fetch_factor']:.3f}")
+                rf["traffic_over_format_bytes"] = rf["traffic"] / rf["format_bytes_per_launch"]
+            if t.get("k_spmv_level0_bytes_per_launch"):
+                out["level0_spmv"]["traffic"] = t["k_spmv_level0_bytes_per_launch"]
+            for key in ("level0_prolongation", "level0_restriction"):
+                if key in out and t.get(key + "_bytes_per_launch"):
+                    out[key]["traffic"] = t[key + "_bytes_per_launch"]
+        else:
+            rf["traffic_source"] = (rf.get("traffic_source") or "no committed profile") + f"; live counter passes failed: {why}"
     if not args.no_aggressive:
         out["aggressive_1"] = aggressive_run(args, hh)
     if not args.no_cpu_baseline:
@@ -446,7 +463,7 @@ def plain_csr_child(args):
     the level-0 product is the plain CSR stream kernel of the north-star 'CSR SpMV >= 40 % of roofline' claim."""
     env = dict(os.environ, HDA_CODED="0", HDA_WINDOW="0")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--grid", str(args.n), "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive"]
+           "--grid", str(args.n), "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     for ln in r.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
@@ -459,6 +476,49 @@ def plain_csr_child(args):
                     "level0_prolongation_ms": c.get("level0_prolongation", {}).get("avg_ms"),
                     "level0_restriction_ms": c.get("level0_restriction", {}).get("avg_ms")}
     return {"error": f"child exited {r.returncode}: {r.stderr[-500:]}"}
+
+
+def measure_traffic(args, limit_s=240):
+    """HBM bytes per launch of the kernels the line quotes, measured NOW: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE:
+    separate runs, counters only, as MI355X_MICROARCH.md's HBM section prescribes) over a one-solve child of this script, reduced by
+    tools/pmc_traffic.py (its k_cg_dir calibration of the gfx950 FETCH_SIZE unit included).  Returns (dict, None) or (None, why)."""
+    import importlib.util
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    if any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, "this run is itself being profiled"
+    tmp = tempfile.mkdtemp(prefix="hda_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV}
+    env["TMPDIR"] = "/tmp"
+    try:
+        t0 = time.perf_counter()
+        for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            # the program itself after `--`: no env / shell hop between the profiler's preloaded library and python
+            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, sub), "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--grid", str(args.n), "--child",
+                   "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic"]
+            left = limit_s - (time.perf_counter() - t0)
+            if left < 20:
+                return None, f"counter passes exceeded {limit_s} s"
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {ctr} pass did not finish within {left:.0f} s"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} pass exited {r.returncode}: {r.stderr[-300:]}"
+        spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(ROOT, "tools", "pmc_traffic.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        t = mod.compute(os.path.join(tmp, "fetch"), os.path.join(tmp, "write"), "live")
+        t["seconds"] = time.perf_counter() - t0
+        return t, None
+    except Exception as e:  # noqa: BLE001 - the committed profile stays as the fallback
+        return None, repr(e)[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 LAUNCH_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
@@ -475,7 +535,7 @@ def child_bench(extra, nranks, timeout_s):
     me = os.path.abspath(__file__)
     cmd = [sys.executable, me] if nranks == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
                                                     "--master-addr", "127.0.0.1", "--master-port", str(free_port()), me]
-    cmd += ["--gpus", str(nranks), "--child", "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive"] + extra
+    cmd += ["--gpus", str(nranks), "--child", "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic"] + extra
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired:
@@ -564,6 +624,8 @@ def main():
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-plain-csr", action="store_true")
     ap.add_argument("--no-aggressive", action="store_true", help="N = 1: skip the side run with one aggressive-coarsening level")
+    ap.add_argument("--no-traffic", action="store_true", help="N = 1, 256^3: skip the two rocprofv3 --pmc passes behind roofline.traffic "
+                    "(the committed profiles/traffic.json is quoted instead)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the strong_<grid> and n1_reference child launches")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # a launch made by another bench.py: no further children
     args = ap.parse_args()

@@ -936,6 +936,8 @@ extern "C" int hda_memory_stats(double *in_use, double *peak)
    return HDA_OK;
 }
 
+extern "C" double hda_memory_cached(void) { return (double)pool_bytes_cached(); }
+
 extern "C" int hda_comm_selftest(void)
 {
    HDA_TRY

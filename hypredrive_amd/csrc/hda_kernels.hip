@@ -64,10 +64,15 @@ void Context::release_thread()
 // ---------------------------------------------------------------- allocator
 
 namespace {
+struct Cached {
+   void    *p;
+   uint64_t stamp; // release order: the oldest blocks go first when the cache is over its limit
+};
 struct Pool {
-   std::multimap<size_t, void *>      free_;  // size -> block
+   std::multimap<size_t, Cached>      free_;  // size -> block
    std::unordered_map<void *, size_t> size_;  // every block we own
    size_t                             in_use = 0, cached = 0, peak = 0;
+   uint64_t                           clock = 0;
 };
 thread_local Pool g_pool; // per thread like the context whose stream orders its blocks
 constexpr size_t kAlign = 512;
@@ -100,7 +105,7 @@ void *pool_alloc(size_t bytes)
    auto it = g_pool.free_.lower_bound(want);
    if (it != g_pool.free_.end() && it->first <= want + want / 4 + 65536)
    {
-      void *p = it->second;
+      void *p = it->second.p;
       g_pool.cached -= it->first;
       g_pool.in_use += it->first;
       g_pool.free_.erase(it);
@@ -163,7 +168,30 @@ void pool_free(void *p)
    }
    g_pool.in_use -= it->second;
    g_pool.cached += it->second;
-   g_pool.free_.emplace(it->second, p);
+   g_pool.free_.emplace(it->second, Cached{p, ++g_pool.clock});
+   // Released blocks are kept for the next setup / solve of the same shape (a warm AMG setup is half the cold one), but never more
+   // than this thread ever had in use at once (at least HDA_POOL_CACHE_MIN_GB, default 4): a long-lived process that has solved many
+   // differently sized systems must not sit on the whole of HBM -- other processes and other rank threads allocate from it too
+   static const size_t floor_bytes = [] {
+      const char *e = getenv("HDA_POOL_CACHE_MIN_GB");
+      return (size_t)((e && *e ? atof(e) : 4.0) * (double)(1ull << 30));
+   }();
+   const size_t cap = std::max(floor_bytes, g_pool.peak);
+   if (g_pool.cached > cap)
+   {
+      std::vector<std::multimap<size_t, Cached>::iterator> by_age;
+      for (auto q = g_pool.free_.begin(); q != g_pool.free_.end(); ++q) by_age.push_back(q);
+      std::sort(by_age.begin(), by_age.end(), [](auto a, auto b) { return a->second.stamp < b->second.stamp; });
+      // (hipFree waits for the device, so a block a queued kernel still uses is safe to return)
+      for (auto q : by_age)
+      {
+         if (g_pool.cached <= cap - cap / 4) break; // some slack: not one hipFree per release from here on
+         g_pool.cached -= q->first;
+         g_pool.size_.erase(q->second.p);
+         (void)hipFree(q->second.p);
+         g_pool.free_.erase(q);
+      }
+   }
 }
 
 void pool_trim()
@@ -171,14 +199,15 @@ void pool_trim()
    (void)hipStreamSynchronize(Context::get().stream);
    for (auto &kv : g_pool.free_)
    {
-      g_pool.size_.erase(kv.second);
-      (void)hipFree(kv.second);
+      g_pool.size_.erase(kv.second.p);
+      (void)hipFree(kv.second.p);
    }
    g_pool.free_.clear();
    g_pool.cached = 0;
 }
 size_t pool_bytes_in_use() { return g_pool.in_use; }
 size_t pool_bytes_peak() { return g_pool.peak; }
+size_t pool_bytes_cached() { return g_pool.cached; }
 
 #define STREAM (Context::get().stream)
 

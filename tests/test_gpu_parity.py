@@ -940,6 +940,44 @@ def test_full_size_spmv_properties(hd):
     assert abs(A.spmv(u) @ v - u @ A.spmv(v)) / abs(u @ A.spmv(v)) < 1e-12
 
 
+def test_allocator_cache_is_bounded_by_the_peak():
+    """Released device blocks are kept for the next setup of the same shape, but a process that has solved many differently sized
+    systems must not end up holding all of HBM (that starved a child process of scratch memory in the round-3 suite): the cache never
+    exceeds max(peak in use, HDA_POOL_CACHE_MIN_GB), oldest blocks are returned first, and results do not depend on it."""
+    import json
+    import subprocess
+    import sys
+    code = """
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import hypredrive_amd as hd
+from hypredrive_amd import _lib
+seen, its = [], []
+for n in (24, 40, 28, 44, 32, 36, 48, 26, 30, 34, 38, 42, 46, 24):
+    A = hd.lap7(n, n, n)
+    amg = hd.Amg(A)
+    b = np.zeros(n ** 3); b[:n * n] = 1.0
+    r = hd.pcg(A, b, amg)
+    its.append([n, int(r["iters"]), float(r["hist"][-1])])
+    del A, amg
+    iu, pk = _lib.memory_stats()
+    seen.append([iu, pk, _lib.memory_cached()])
+print(json.dumps(dict(seen=seen, its=its)))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for floor in ("0.001", "64"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, HDA_POOL_CACHE_MIN_GB=floor), timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    small, big = outs
+    assert small["its"] == big["its"]                                  # same iterations and residuals, bit for bit
+    for iu, pk, cached in small["seen"]:
+        assert cached <= max(pk, 0.001 * 2 ** 30)
+    assert small["seen"][-1][2] < big["seen"][-1][2]                   # without the bound the cache only grows
+    tot_small = small["seen"][-1][0] + small["seen"][-1][2]
+    assert tot_small <= 2 * small["seen"][-1][1] + 0.001 * 2 ** 30
+
+
 def test_int32_size_guard(hd):
     """Operators are int32-indexed (HYPRE_Int in hypre's default build): a setup stage whose output
     would pass 2^31-1 entries must stop with an error, never wrap around."""

@@ -31,15 +31,16 @@ def load(d, counter):
     return rows
 
 
-def main():
-    fdir, wdir, tag = sys.argv[1:4]
+def compute(fdir, wdir, tag, summary_csv=None):
+    """The traffic dictionary of one pair of counter passes (bench.py calls this on passes it has just run itself); tag names the
+    round / run; summary_csv: where to write the per-kernel table, if anywhere."""
     F, W = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
     byk = defaultdict(lambda: {"F": [], "W": []})
     for _, k, v in F:
         byk[k]["F"].append(v)
     for _, k, v in W:
         byk[k]["W"].append(v)
-    with open(tag + "_pmc_summary.csv", "w") as o:
+    with open(summary_csv or os.devnull, "w") as o:
         o.write("kernel,calls,FETCH_SIZE_max_KB,FETCH_SIZE_median_KB,WRITE_SIZE_max_KB,WRITE_SIZE_median_KB\n")
         for k, d in sorted(byk.items(), key=lambda kv: -sum(kv[1]["F"])):
             f, w = d["F"] or [0.0], d["W"] or [0.0]
@@ -108,6 +109,12 @@ def main():
                     out[key] = {"kernel": "k_spmv_stream / k_spmv_win <0, false, true, false> (value-coded level-0 transfer operator)", "launches": len(sel),
                                 "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
     out["round"] = os.path.basename(tag)
+    return out
+
+
+def main():
+    fdir, wdir, tag = sys.argv[1:4]
+    out = compute(fdir, wdir, tag, tag + "_pmc_summary.csv")
     json.dump(out, open(os.path.join(os.path.dirname(tag) or ".", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
