@@ -77,7 +77,7 @@ SYMBOLS = [
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_memory_cached", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
-    "hda_thread_ranks_lap7", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
+    "hda_thread_ranks_lap7", "hda_thread_world_create", "hda_thread_world_join", "hda_thread_world_leave", "hda_thread_world_destroy", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
     "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass", "hda_truncate_rows",
 ]
 
@@ -615,6 +615,46 @@ def thread_ranks_lap7(nranks, n, P, yaml, nsolves=1, want_x=False):
     res["converged"] = bool(res["converged"])
     if want_x:
         res["x"] = x
+    return res
+
+
+def run_thread_ranks(nranks, body):
+    """Test seam: `nranks` Python threads, each joined to one in-process world as its rank (hda_thread_world_*), run
+    body(rank, nranks) -- which drives the public API like one rank of an MPI job would -- and return the list of results in rank
+    order.  ctypes releases the interpreter lock inside library calls, so ranks blocked in a collective do not stall the others.
+    A rank that raises releases its peers with an error; the first exception is re-raised here."""
+    import threading
+    L = load()
+    L.hda_thread_world_create.restype = C.c_void_p
+    L.hda_thread_world_join.argtypes = [C.c_void_p, C.c_int]
+    L.hda_thread_world_leave.argtypes = [C.c_void_p, C.c_int]
+    L.hda_thread_world_destroy.argtypes = [C.c_void_p]
+    L.hda_thread_world_destroy.restype = None
+    world = L.hda_thread_world_create(int(nranks))
+    if not world:
+        raise LibraryError("hda_thread_world_create failed")
+    res, errs = [None] * nranks, [None] * nranks
+
+    def run(rank):
+        failed = 0
+        try:
+            if L.hda_thread_world_join(world, rank) != 0:
+                raise LibraryError(f"rank {rank} could not join the thread world")
+            res[rank] = body(rank, nranks)
+        except BaseException as e:  # noqa: BLE001 - reported by the caller's thread below
+            errs[rank], failed = e, 1
+        finally:
+            L.hda_thread_world_leave(world, failed)
+
+    th = [threading.Thread(target=run, args=(r,), name=f"hda-rank-{r}") for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    L.hda_thread_world_destroy(world)
+    first = [e for e in errs if e is not None and "another rank failed" not in str(e)] or [e for e in errs if e is not None]
+    if first:
+        raise first[0]
     return res
 
 

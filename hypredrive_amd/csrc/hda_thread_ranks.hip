@@ -132,3 +132,40 @@ extern "C" int hda_thread_ranks_lap7(int nranks, const int n[3], const int P[3],
    memcpy(out16, v, sizeof(v));
    return 0;
 }
+
+// ---- the same thing with the caller's own threads: a host thread joins an in-process world as one rank and then drives the public API
+// itself (tests: Python threads, each handing over its row block of an arbitrary CSR matrix).  world: hda_thread_world_create's handle.
+extern "C" void *hda_thread_world_create(int nranks)
+{
+   if (nranks < 1) return nullptr;
+   return new std::shared_ptr<void>(make_thread_world(nranks));
+}
+extern "C" int hda_thread_world_join(void *world, int rank)
+{
+   if (!world) return 1;
+   try
+   {
+      Comm::set_world(make_thread_comm(rank, *(std::shared_ptr<void> *)world));
+   }
+   catch (const std::exception &)
+   {
+      return 2;
+   }
+   return 0;
+}
+// failed != 0: this rank gives up -- the ranks waiting for it in a collective are released with an error instead of hanging
+extern "C" int hda_thread_world_leave(void *world, int failed)
+{
+   if (world && failed) thread_world_fail(*(std::shared_ptr<void> *)world);
+   try
+   {
+      Comm::set_world(make_self_comm());
+      Context::release_thread();
+   }
+   catch (const std::exception &)
+   {
+      return 2;
+   }
+   return 0;
+}
+extern "C" void hda_thread_world_destroy(void *world) { delete (std::shared_ptr<void> *)world; }

@@ -243,6 +243,13 @@ const char *hda_comm_name(void); /* "self", "rccl", "host-callbacks", "threads" 
  * x_global (may be NULL): the solution in the generator's block numbering.  Returns 0, or 2 with the ranks' messages in errbuf. */
 int hda_thread_ranks_lap7(int nranks, const int n[3], const int P[3], const char *yaml, int nsolves, double out16[16], double *x_global,
                           char *errbuf, int errlen);
+/* The same seam for a caller that brings its own threads (tests: Python threads, one per rank, each handing over its row block of an
+ * arbitrary CSR matrix through the public API): create a world of nranks, let every thread join as its rank BEFORE its first
+ * HYPREDRV_* call, leave when done (failed != 0 releases ranks blocked in a collective with an error), destroy after all have left. */
+void *hda_thread_world_create(int nranks);
+int hda_thread_world_join(void *world, int rank);
+int hda_thread_world_leave(void *world, int failed);
+void hda_thread_world_destroy(void *world);
 /* levels of the set-up BoomerAMG hierarchy behind an HYPREDRV_t that are row partitioned (0: one rank, or not set up) */
 int hda_amd_partitioned_levels(void *hypredrv);
 int hda_amd_hierarchy_levels(void *hypredrv); /* all levels: the partitioned ones + those of the replicated tail */

@@ -1289,6 +1289,131 @@ def test_row_partitioned_mgr(hd, orc, tmp_path, world, case, rep_rows):
     assert res["norm"] == pytest.approx(np.linalg.norm(ref["x"]), rel=1e-6)
 
 
+def _solve_on_thread_ranks(hd, cuts, S, b, yaml, labels=None):
+    """len(cuts) - 1 ranks as threads of this process (hypredrive_amd/_lib.py run_thread_ranks): rank r hands over rows cuts[r] .. cuts[r + 1] - 1
+    of the global matrix S through the public API (HYPREDRV_LinearSystemSetMatrixFromCSR / SetRHSFromArray / SetDofmap), solves, and
+    returns its block of the solution.  Returns (rank 0's result dict, the gathered solution, rank 0's partitioned levels)."""
+    import ctypes as C
+    from hypredrive_amd import _lib
+
+    def body(rank, world):
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+        blk = S[lo:hi]
+        h = hd.Hypredrv(yaml)
+        try:
+            h.set_matrix_csr(lo, hi - 1, blk.indptr, blk.indices, blk.data)
+            h.set_rhs_array(lo, hi - 1, b[lo:hi])
+            h.finish_system()
+            if labels is not None:
+                lab = np.ascontiguousarray(labels[lo:hi], dtype=np.int32)
+                hd.check(hd.lib().HYPREDRV_LinearSystemSetDofmap(h.h, hi - lo, lab.ctypes.data_as(C.POINTER(C.c_int))))
+            L = hd.lib()
+            hd.check(L.HYPREDRV_LinearSystemResetInitialGuess(h.h))
+            hd.check(L.HYPREDRV_LinearSolverCreate(h.h))
+            hd.check(L.HYPREDRV_LinearSolverSetup(h.h))
+            part = _lib.load().hda_amd_partitioned_levels(h.h)
+            hd.check(L.HYPREDRV_LinearSolverApply(h.h))
+            r = h.last()
+            hd.check(L.HYPREDRV_LinearSolverDestroy(h.h))
+            return r, np.array(h.solution(), copy=True), part
+        finally:
+            h.close()
+
+    outs = _lib.run_thread_ranks(len(cuts) - 1, body)
+    assert len({o[0]["iters"] for o in outs}) == 1                      # every rank stopped at the same iteration
+    return outs[0][0], np.concatenate([o[1] for o in outs]), outs[0][2]
+
+
+@pytest.mark.parametrize("rep_rows", [0, 1500])
+def test_eight_thread_ranks_irregular_csr_match_oracle(hd, orc, monkeypatch, rep_rows):
+    """Eight ranks, an IRREGULAR matrix (tests/dist_worker.py random_mmatrix: mostly local couplings plus long-range ones, so a block's
+    peers and ghost layers are whatever the matrix says), row blocks of very different sizes -- one of them 7 rows -- handed over
+    through HYPREDRV_LinearSystemSetMatrixFromCSR like reference tests/test_setmatrix_from_csr_mpi.c does per rank.  The partitioned
+    setup must build the ORACLE's hierarchy (same PMIS draw per global row): AMG-PCG iteration count within 1 of the oracle's, the gathered
+    solution its solution to the stopping tolerance, the true residual of the gathered solution below it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import random_mmatrix
+    n = 9000
+    S = random_mmatrix(5, n)
+    b = np.ones(n)
+    cuts = np.array([0, 1400, 1407, 3000, 3900, 5200, 6100, 8000, n])
+    monkeypatch.setenv("HDA_REPLICATE_ROWS", str(rep_rows))
+    res, x, part = _solve_on_thread_ranks(hd, cuts, S, b, "solver: pcg\npreconditioner: amg\n")
+    Ao = orc.Csr.from_scipy(S)
+    ref = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True)))
+    assert part >= 2                                                      # the hierarchy really is cut into row blocks
+    assert res["converged"] and abs(res["iters"] - ref["iters"]) <= 1, (res["iters"], ref["iters"])
+    assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-5
+    assert np.linalg.norm(b - S @ x) / np.linalg.norm(b) < 2e-6
+
+
+def test_config5_standin_on_eight_thread_ranks(hd, orc, monkeypatch):
+    """BASELINE config 5's shape -- GMRES(30) + BoomerAMG with the ILU(0) smoother on level 0, heterogeneous anisotropic reservoir
+    operator (hypredrive_amd/synthetic.py) -- on EIGHT row blocks (slabs of the 40^3 grid, the last two uneven).  The level-0 ILU is
+    block Jacobi by rank (`bj-iluk`, reference src/internal/ilu.c), so the preconditioner is not the one-rank one: the bar is convergence
+    to the same tolerance within a few iterations of the oracle's one-rank count and the true residual of the gathered solution."""
+    import scipy.sparse as sp
+    from hypredrive_amd.synthetic import spe10_like
+    n = 40
+    N = n ** 3
+    ip, ix, v, b = spe10_like(n)
+    S = sp.csr_matrix((v, ix, ip), shape=(N, N))
+    cuts = np.array([0, 8000, 16000, 24000, 32000, 40000, 48000, 59000, N])
+    monkeypatch.setenv("HDA_REPLICATE_ROWS", "3000")
+    res, x, part = _solve_on_thread_ranks(hd, cuts, S, b, SPE10_YAML)
+    Ao = orc.Csr.from_scipy(S)
+    ao = orc.Amg(Ao, orc.amg_params(True))
+    ao.set_ilu_smoother(num_levels=1, num_sweeps=1, tri_solve=0)
+    ref = orc.gmres(Ao, b, ao, orc.krylov_params(True))
+    assert part >= 2
+    assert res["converged"] and abs(res["iters"] - ref["iters"]) <= 3, (res["iters"], ref["iters"])
+    assert np.linalg.norm(b - S @ x) / np.linalg.norm(b) < 2e-6
+    assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-4
+
+
+@pytest.mark.parametrize("case", ["ex3", "jacobi-columped", "famg"])
+def test_mgr_on_eight_thread_ranks(hd, orc, monkeypatch, case):
+    """BASELINE config 4's shape (GMRES + MGR by dof labels, examples/ex3.yml on the three-field stand-in) on eight row blocks cut
+    anywhere, also inside a cell: the oracle's one-rank iteration count (+- the slack of the hybrid smoother) and solution."""
+    yaml, lev, slack = MGR_DIST_CASES[case]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_pins import three_field_system
+    S, labels = three_field_system(14, seed=4)
+    N = S.shape[0]
+    cuts = np.array([0, N // 9, N // 9 + 4] + [N * k // 8 for k in range(3, 8)] + [N])
+    assert len(cuts) == 9 and np.all(np.diff(cuts) > 0)
+    monkeypatch.setenv("HDA_REPLICATE_ROWS", "0")
+    b = np.ones(N)
+    res, x, _ = _solve_on_thread_ranks(hd, cuts, S, b, yaml, labels=labels)
+    Ao = orc.Csr.from_scipy(S)
+    lev = [dict(l) for l in lev]
+    for l in lev:
+        if "f_amg_kw" in l:
+            l["f_amg"] = orc.amg_params(True, **l.pop("f_amg_kw"))
+    ref = orc.gmres(Ao, b, orc.MgrPrecond(Ao, labels, lev), orc.krylov_params(True, rtol=1e-8))
+    assert res["converged"] and abs(res["iters"] - ref["iters"]) <= slack, (res["iters"], ref["iters"])
+    assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-6
+
+
+def test_a_failing_thread_rank_releases_its_peers(hd):
+    """A rank that raises must not leave the other ranks blocked in a collective: they get an error, and the first real error surfaces."""
+    from hypredrive_amd import _lib
+
+    def body(rank, world):
+        if rank == 2:
+            raise ValueError("rank 2 gives up")
+        h = hd.Hypredrv("solver: pcg\npreconditioner: amg\n")
+        try:
+            h.set_laplacian7((12, 12, 12), (1, 1, 4))
+            return h.solve()
+        finally:
+            hd.lib().HYPREDRV_ErrorCodeClear()
+            h.close()
+
+    with pytest.raises(ValueError, match="rank 2 gives up"):
+        _lib.run_thread_ranks(4, body)
+
+
 def test_precon_reuse_with_mgr(hd, orc):
     """preconditioner.reuse with MGR: a kept MGR is applied to the next system with level 0 taken from the new matrix."""
     import scipy.sparse as sp
