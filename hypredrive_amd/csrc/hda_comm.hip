@@ -293,6 +293,7 @@ class CallbackComm : public Comm {
 namespace {
 struct ThreadWorld {
    explicit ThreadWorld(int n) : size(n), ptr((size_t)n, nullptr), cnt((size_t)n, nullptr) {}
+   virtual ~ThreadWorld() = default;
    int                       size;
    std::mutex                mu;
    std::condition_variable   cv;
@@ -400,7 +401,7 @@ class ThreadComm : public Comm {
    }
    const char *name() const override { return "threads"; }
 
- private:
+ protected:
    void reduce(double *v, int n, int)
    {
       std::vector<double> t((size_t)std::max(n, 1));
@@ -418,9 +419,122 @@ class ThreadComm : public Comm {
    std::shared_ptr<ThreadWorld> w_;
    std::vector<double>          hbuf_, hs_, hr_;
 };
+
+// The same ranks-as-threads world with a transport that behaves like RCCL towards the caller (HDA_THREAD_TRANSPORT=device): an
+// exchange or a device all-reduce only ENQUEUES work on the caller's stream -- device-to-device copies straight out of the peers'
+// buffers, ordered by events -- and returns; nothing waits for the GPU on the host.  (The host threads still meet at the world's barrier
+// while they enqueue, which RCCL does not need; what matters is that the DEVICE side is asynchronous.)  This is the one-GPU rehearsal
+// of everything the library does around an asynchronous transport: the overlapped products (pack | owned-column part || transfer |
+// ghost-column part, hda_kernels.hip launch_spmv_halo), buffers reused while a peer may still read them, results read back by the host
+// without a transport-side synchronisation to lean on.
+constexpr int kMaxThreadRanks = 64;
+struct PtrTable {
+   const double *p[kMaxThreadRanks];
+};
+__global__ __launch_bounds__(256) void k_sum_ranks(int n, int nranks, PtrTable t, double *__restrict__ out)
+{
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+   {
+      double a = t.p[0][i];
+      for (int r = 1; r < nranks; r++) a += t.p[r][i]; // rank order on every rank: identical, deterministic sums
+      out[i] = a;
+   }
+}
+struct DeviceThreadWorld : ThreadWorld {
+   explicit DeviceThreadWorld(int n)
+      : ThreadWorld(n), xsend((size_t)n, nullptr), xcnt((size_t)n, nullptr), arptr((size_t)n, nullptr), ev_ready((size_t)n, nullptr),
+        ev_done((size_t)n, nullptr), ar_ready((size_t)n, nullptr), ar_done((size_t)n, nullptr)
+   {
+   }
+   std::vector<const double *> xsend;  // rank -> its packed send buffer (device)
+   std::vector<const int *>    xcnt;   // rank -> its send counts by destination (host, valid between the two barriers of a call)
+   std::vector<const double *> arptr;  // rank -> its staged all-reduce operand (device)
+   std::vector<hipEvent_t>     ev_ready, ev_done, ar_ready, ar_done;
+};
+
+class DeviceThreadComm : public ThreadComm {
+ public:
+   DeviceThreadComm(int r, std::shared_ptr<DeviceThreadWorld> w) : ThreadComm(r, w), d_(std::move(w))
+   {
+      HDA_REQUIRE(size <= kMaxThreadRanks, "thread ranks: the device transport handles at most 64 ranks");
+      for (hipEvent_t *e : {&d_->ev_ready[(size_t)r], &d_->ev_done[(size_t)r], &d_->ar_ready[(size_t)r], &d_->ar_done[(size_t)r]})
+         HDA_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      d_->barrier(); // every rank's events exist before anybody waits on one
+   }
+   ~DeviceThreadComm() override
+   {
+      (void)hipDeviceSynchronize(); // peers may still be reading this rank's buffers
+      for (hipEvent_t e : {d_->ev_ready[(size_t)rank], d_->ev_done[(size_t)rank], d_->ar_ready[(size_t)rank], d_->ar_done[(size_t)rank]})
+         if (e) (void)hipEventDestroy(e);
+   }
+   bool async_exchange() const override { return true; }
+   const char *name() const override { return "threads-device"; }
+   void exchange_dev(const double *send, const int *sc, double *recv, const int *rc, hipStream_t st) override
+   {
+      stats.exchange++;
+      for (int p = 0; p < size; p++) stats.exchange_doubles += sc[p];
+      d_->xsend[(size_t)rank] = send;
+      d_->xcnt[(size_t)rank]  = sc;
+      HDA_HIP(hipEventRecord(d_->ev_ready[(size_t)rank], st)); // my send buffer is packed once `st` gets here
+      d_->barrier();
+      size_t ro = 0;
+      for (int p = 0; p < size; p++)
+      {
+         if (!rc[p]) continue;
+         const int *pc = d_->xcnt[(size_t)p];
+         size_t     so = 0;
+         for (int q = 0; q < rank; q++) so += (size_t)pc[q];
+         HDA_REQUIRE(pc[rank] == rc[p], "thread ranks: send and receive counts of a neighbour exchange disagree");
+         HDA_HIP(hipStreamWaitEvent(st, d_->ev_ready[(size_t)p], 0));
+         HDA_HIP(hipMemcpyAsync(recv + ro, d_->xsend[(size_t)p] + so, sizeof(double) * (size_t)rc[p], hipMemcpyDeviceToDevice, st));
+         ro += (size_t)rc[p];
+      }
+      HDA_HIP(hipEventRecord(d_->ev_done[(size_t)rank], st)); // I have read what I needed from my peers
+      d_->barrier();
+      for (int p = 0; p < size; p++) // like a send that has completed: later work on `st` may overwrite the send buffer
+         if (sc[p]) HDA_HIP(hipStreamWaitEvent(st, d_->ev_done[(size_t)p], 0));
+   }
+   void allreduce_sum_dev(double *d, int n) override
+   {
+      stats.allreduce++;
+      stats.allreduce_doubles += n;
+      if (n <= 0) return;
+      hipStream_t st = STREAM;
+      for (int p = 0; p < size; p++) // peers have finished reading my previous operand (recorded before the last barrier of that call)
+         if (p != rank) HDA_HIP(hipStreamWaitEvent(st, d_->ar_done[(size_t)p], 0));
+      if (stage_.size() < (size_t)n) stage_.alloc((size_t)n);
+      HDA_HIP(hipMemcpyAsync(stage_.data(), d, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+      HDA_HIP(hipEventRecord(d_->ar_ready[(size_t)rank], st));
+      d_->arptr[(size_t)rank] = stage_.data();
+      d_->barrier();
+      PtrTable t;
+      for (int p = 0; p < size; p++)
+      {
+         t.p[p] = d_->arptr[(size_t)p];
+         if (p != rank) HDA_HIP(hipStreamWaitEvent(st, d_->ar_ready[(size_t)p], 0));
+      }
+      k_sum_ranks<<<std::min(ceil_div(n, 256), 1024), 256, 0, st>>>(n, size, t, d);
+      HDA_HIP(hipEventRecord(d_->ar_done[(size_t)rank], st));
+      d_->barrier();
+   }
+
+ private:
+   std::shared_ptr<DeviceThreadWorld> d_;
+   DArray<double>                     stage_;
+};
 } // namespace
-std::shared_ptr<void> make_thread_world(int size) { return std::make_shared<ThreadWorld>(size); }
-Comm *make_thread_comm(int rank, const std::shared_ptr<void> &world) { return new ThreadComm(rank, std::static_pointer_cast<ThreadWorld>(world)); }
+std::shared_ptr<void> make_thread_world(int size)
+{
+   const char *t = getenv("HDA_THREAD_TRANSPORT");
+   if (t && !strcmp(t, "device")) return std::static_pointer_cast<ThreadWorld>(std::make_shared<DeviceThreadWorld>(size));
+   return std::make_shared<ThreadWorld>(size);
+}
+Comm *make_thread_comm(int rank, const std::shared_ptr<void> &world)
+{
+   auto w = std::static_pointer_cast<ThreadWorld>(world);
+   if (auto d = std::dynamic_pointer_cast<DeviceThreadWorld>(w)) return new DeviceThreadComm(rank, d);
+   return new ThreadComm(rank, w);
+}
 void  thread_world_fail(const std::shared_ptr<void> &world) { std::static_pointer_cast<ThreadWorld>(world)->fail(); }
 Comm *make_rccl_comm(int rank, int size, const void *uid) { return new RcclComm(rank, size, uid); }
 Comm *make_callback_comm(int rank, int size, hda_allreduce_cb ar, hda_alltoallv_cb a2a)

@@ -408,7 +408,10 @@ def _thread_ranks(tmp_path, tag, n, P, solver="pcg", want_x="1", **envx):
 
 
 @pytest.mark.parametrize("n,rep_rows,check,extra", [(40, 2000, "1", {}), (40, 2000, "0", {}), (32, 0, "0", {}), (48, 100000, "0", {}),
-                                                    (40, 2000, "0", {"HDA_OVERLAP": "1"}), (36, 1500, "0", {"HDA_PCG_SINGLE_REDUCE": "1"})])
+                                                    (40, 2000, "0", {"HDA_OVERLAP": "1"}), (36, 1500, "0", {"HDA_PCG_SINGLE_REDUCE": "1"}),
+                                                    (40, 2000, "0", {"HDA_THREAD_TRANSPORT": "device"}), (32, 0, "0", {"HDA_THREAD_TRANSPORT": "device"}),
+                                                    (36, 1500, "0", {"HDA_THREAD_TRANSPORT": "device", "HDA_PCG_SINGLE_REDUCE": "1"}),
+                                                    (40, 2000, "0", {"HDA_THREAD_TRANSPORT": "device", "HDA_OVERLAP": "0"})])
 def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check, extra):
     """BASELINE config 3's layout -- `-P 2 2 2` (reference examples/src/C_laplacian/laplacian.c:561-582, scripts/node_scaling.sh:1275-1292) --
     with eight ranks: blocks have face, EDGE and CORNER neighbours (7 peers), which no 1xPxQ layout produces, on every partitioned
@@ -417,7 +420,9 @@ def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check, e
     level with the replicated one inside the library.  Against one rank: iteration count within 1, every rank the same count,
     solution norms to 1e-6 (the stopping tolerance), the gathered solution's norm to rounding."""
     # extra: HDA_OVERLAP=1 -- every product runs its owned-column part while the ghosts travel and adds the ghost-column part afterwards
-    # (the RCCL default), here with 7 peers per block; HDA_PCG_SINGLE_REDUCE=1 -- the opt-in one-reduction PCG
+    # (the RCCL default), here with 7 peers per block; HDA_PCG_SINGLE_REDUCE=1 -- the opt-in one-reduction PCG;
+    # HDA_THREAD_TRANSPORT=device -- the thread transport that, like RCCL, only ENQUEUES exchanges and all-reduces on the caller's stream
+    # (device-to-device copies ordered by events, hda_comm.hip DeviceThreadComm): overlapped products on by default, nothing waits on the host
     res, x, err = _thread_ranks(tmp_path, f"t{n}_{rep_rows}_{check}", n, (2, 2, 2), HDA_REPLICATE_ROWS=str(rep_rows), HDA_DIST_CHECK=check, **extra)
     h = hd.Hypredrv("solver: pcg\npreconditioner:\n  preset: poisson\n")
     h.set_laplacian7((n, n, n))
@@ -1324,8 +1329,8 @@ def _solve_on_thread_ranks(hd, cuts, S, b, yaml, labels=None):
     return outs[0][0], np.concatenate([o[1] for o in outs]), outs[0][2]
 
 
-@pytest.mark.parametrize("rep_rows", [0, 1500])
-def test_eight_thread_ranks_irregular_csr_match_oracle(hd, orc, monkeypatch, rep_rows):
+@pytest.mark.parametrize("rep_rows,transport", [(0, "host"), (1500, "host"), (0, "device"), (1500, "device")])
+def test_eight_thread_ranks_irregular_csr_match_oracle(hd, orc, monkeypatch, rep_rows, transport):
     """Eight ranks, an IRREGULAR matrix (tests/dist_worker.py random_mmatrix: mostly local couplings plus long-range ones, so a block's
     peers and ghost layers are whatever the matrix says), row blocks of very different sizes -- one of them 7 rows -- handed over
     through HYPREDRV_LinearSystemSetMatrixFromCSR like reference tests/test_setmatrix_from_csr_mpi.c does per rank.  The partitioned
@@ -1338,6 +1343,7 @@ def test_eight_thread_ranks_irregular_csr_match_oracle(hd, orc, monkeypatch, rep
     b = np.ones(n)
     cuts = np.array([0, 1400, 1407, 3000, 3900, 5200, 6100, 8000, n])
     monkeypatch.setenv("HDA_REPLICATE_ROWS", str(rep_rows))
+    monkeypatch.setenv("HDA_THREAD_TRANSPORT", transport)  # device: exchanges and all-reduces are only enqueued, as with RCCL
     res, x, part = _solve_on_thread_ranks(hd, cuts, S, b, "solver: pcg\npreconditioner: amg\n")
     Ao = orc.Csr.from_scipy(S)
     ref = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True)))
@@ -1347,7 +1353,8 @@ def test_eight_thread_ranks_irregular_csr_match_oracle(hd, orc, monkeypatch, rep
     assert np.linalg.norm(b - S @ x) / np.linalg.norm(b) < 2e-6
 
 
-def test_config5_standin_on_eight_thread_ranks(hd, orc, monkeypatch):
+@pytest.mark.parametrize("transport", ["host", "device"])
+def test_config5_standin_on_eight_thread_ranks(hd, orc, monkeypatch, transport):
     """BASELINE config 5's shape -- GMRES(30) + BoomerAMG with the ILU(0) smoother on level 0, heterogeneous anisotropic reservoir
     operator (hypredrive_amd/synthetic.py) -- on EIGHT row blocks (slabs of the 40^3 grid, the last two uneven).  The level-0 ILU is
     block Jacobi by rank (`bj-iluk`, reference src/internal/ilu.c), so the preconditioner is not the one-rank one: the bar is convergence
@@ -1360,6 +1367,7 @@ def test_config5_standin_on_eight_thread_ranks(hd, orc, monkeypatch):
     S = sp.csr_matrix((v, ix, ip), shape=(N, N))
     cuts = np.array([0, 8000, 16000, 24000, 32000, 40000, 48000, 59000, N])
     monkeypatch.setenv("HDA_REPLICATE_ROWS", "3000")
+    monkeypatch.setenv("HDA_THREAD_TRANSPORT", transport)
     res, x, part = _solve_on_thread_ranks(hd, cuts, S, b, SPE10_YAML)
     Ao = orc.Csr.from_scipy(S)
     ao = orc.Amg(Ao, orc.amg_params(True))
@@ -1371,8 +1379,8 @@ def test_config5_standin_on_eight_thread_ranks(hd, orc, monkeypatch):
     assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-4
 
 
-@pytest.mark.parametrize("case", ["ex3", "jacobi-columped", "famg"])
-def test_mgr_on_eight_thread_ranks(hd, orc, monkeypatch, case):
+@pytest.mark.parametrize("case,transport", [("ex3", "host"), ("jacobi-columped", "host"), ("famg", "host"), ("ex3", "device"), ("famg", "device")])
+def test_mgr_on_eight_thread_ranks(hd, orc, monkeypatch, case, transport):
     """BASELINE config 4's shape (GMRES + MGR by dof labels, examples/ex3.yml on the three-field stand-in) on eight row blocks cut
     anywhere, also inside a cell: the oracle's one-rank iteration count (+- the slack of the hybrid smoother) and solution."""
     yaml, lev, slack = MGR_DIST_CASES[case]
@@ -1383,6 +1391,7 @@ def test_mgr_on_eight_thread_ranks(hd, orc, monkeypatch, case):
     cuts = np.array([0, N // 9, N // 9 + 4] + [N * k // 8 for k in range(3, 8)] + [N])
     assert len(cuts) == 9 and np.all(np.diff(cuts) > 0)
     monkeypatch.setenv("HDA_REPLICATE_ROWS", "0")
+    monkeypatch.setenv("HDA_THREAD_TRANSPORT", transport)
     b = np.ones(N)
     res, x, _ = _solve_on_thread_ranks(hd, cuts, S, b, yaml, labels=labels)
     Ao = orc.Csr.from_scipy(S)
