@@ -440,6 +440,22 @@ __global__ __launch_bounds__(256) void k_sum_ranks(int n, int nranks, PtrTable t
       out[i] = a;
    }
 }
+// HDA_THREAD_JITTER=<max microseconds>: a rank-and-call dependent delay in front of every send-ready / operand-ready event, so the
+// ranks' device timelines drift apart the way eight GPUs' do; results must not depend on it (a missing event wait would)
+__global__ void k_spin(long long cycles)
+{
+   const long long t0 = wall_clock64();
+   while (wall_clock64() - t0 < cycles) {}
+}
+static void jitter(hipStream_t st, int rank, unsigned long &calls)
+{
+   static const int max_us = getenv("HDA_THREAD_JITTER") ? atoi(getenv("HDA_THREAD_JITTER")) : 0;
+   if (max_us <= 0) return;
+   unsigned long long h = (unsigned long long)(rank + 1) * 0x9E3779B97F4A7C15ull + (++calls) * 0xC2B2AE3D27D4EB4Full;
+   h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+   const long long us = (long long)(h % (unsigned long long)(max_us + 1));
+   if (us) k_spin<<<1, 1, 0, st>>>(us * 100); // wall_clock64 ticks at 100 MHz on gfx950
+}
 struct DeviceThreadWorld : ThreadWorld {
    explicit DeviceThreadWorld(int n)
       : ThreadWorld(n), xsend((size_t)n, nullptr), xcnt((size_t)n, nullptr), arptr((size_t)n, nullptr), ev_ready((size_t)n, nullptr),
@@ -475,6 +491,7 @@ class DeviceThreadComm : public ThreadComm {
       for (int p = 0; p < size; p++) stats.exchange_doubles += sc[p];
       d_->xsend[(size_t)rank] = send;
       d_->xcnt[(size_t)rank]  = sc;
+      jitter(st, rank, calls_);
       HDA_HIP(hipEventRecord(d_->ev_ready[(size_t)rank], st)); // my send buffer is packed once `st` gets here
       d_->barrier();
       size_t ro = 0;
@@ -504,6 +521,7 @@ class DeviceThreadComm : public ThreadComm {
          if (p != rank) HDA_HIP(hipStreamWaitEvent(st, d_->ar_done[(size_t)p], 0));
       if (stage_.size() < (size_t)n) stage_.alloc((size_t)n);
       HDA_HIP(hipMemcpyAsync(stage_.data(), d, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+      jitter(st, rank, calls_);
       HDA_HIP(hipEventRecord(d_->ar_ready[(size_t)rank], st));
       d_->arptr[(size_t)rank] = stage_.data();
       d_->barrier();
@@ -521,6 +539,7 @@ class DeviceThreadComm : public ThreadComm {
  private:
    std::shared_ptr<DeviceThreadWorld> d_;
    DArray<double>                     stage_;
+   unsigned long                      calls_ = 0;
 };
 } // namespace
 std::shared_ptr<void> make_thread_world(int size)

@@ -440,6 +440,22 @@ def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check, e
         assert "dist check rank 7" in err  # every rank compared its levels
 
 
+@pytest.mark.parametrize("extra", [{}, {"HDA_PCG_SINGLE_REDUCE": "1"}, {"HDA_OVERLAP": "0"}])
+def test_asynchronous_transport_results_do_not_depend_on_timing(tmp_path, extra):
+    """The device-direct thread transport only enqueues exchanges and all-reduces (like RCCL), so the ranks' device timelines are held
+    together by events alone.  HDA_THREAD_JITTER delays every rank's send-ready / operand-ready events by a rank-and-call dependent
+    0-300 us, which pulls the eight timelines apart the way eight GPUs' drift: a missing wait (a ghost tail read before it landed, a send
+    buffer repacked while a peer still reads it, a scalar read before its all-reduce) would change the numbers.  They must be
+    bit-identical with and without it, 2x2x2 ranks, every level partitioned."""
+    base = dict(HDA_REPLICATE_ROWS="0", HDA_DIST_CHECK="0", HDA_THREAD_TRANSPORT="device", **extra)
+    r0, x0, _ = _thread_ranks(tmp_path, "calm", 32, (2, 2, 2), **base)
+    r1, x1, _ = _thread_ranks(tmp_path, "jitter", 32, (2, 2, 2), HDA_THREAD_JITTER="300", **base)
+    assert r0["converged"] and r1["converged"] and r0["iters"] == r1["iters"]
+    assert r0["overlapped"] == r1["overlapped"] and (r0["overlapped"] > 0) == (extra.get("HDA_OVERLAP") != "0")
+    assert np.array_equal(x0, x1)
+    assert r0["final_rel"] == r1["final_rel"]
+
+
 def test_config3_full_size_512_cubed_on_eight_thread_ranks(hd, tmp_path):
     """BASELINE config 3 AS NAMED -- the 3-D 7-pt Laplacian 512^3 (134 217 728 rows), fp64, AMG-PCG, row-partitioned 2x2x2 over eight
     ranks, a 256^3 block each (`-n 512 512 512 -P 2 2 2`, reference examples/src/C_laplacian/laplacian.c:561-582) -- on ONE MI355X:
