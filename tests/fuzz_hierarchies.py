@@ -1,6 +1,6 @@
 """Random operators of every row length through the AMG setup, device against oracle, bit for bit (run under HDA_GUARD=1 HDA_POISON=1)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
 import hypredrive_amd as hd
 from oracle import oracle_ffi as orc

@@ -1420,6 +1420,18 @@ def test_mgr_on_eight_thread_ranks(hd, orc, monkeypatch, case, transport):
     assert np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-6
 
 
+def test_random_partitions_of_random_matrices_match_oracle():
+    """tests/fuzz_ranks.py, 32 cases: random irregular M-matrices (400-7000 rows) cut into 2-8 row blocks at random -- blocks of a few
+    rows, EMPTY blocks -- on thread ranks, host-staged or asynchronous device transport, every level partitioned or a replicated tail at a
+    random depth, HDA_DIST_CHECK on a third; PCG / GMRES with the default, Chebyshev, aggressive, truncated-interpolation hierarchies (the
+    oracle's iteration count +-1 and its solution to 1e-5: observed 0 and 1e-15) and the rank-dependent hybrid GS / ILU smoothers
+    (convergence, true residual).  (180 cases ran clean in tools/gpurun/r03_zc.sh.)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_ranks.py"), "32", "9000"], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=ROOT), timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"cases": 32, "failed": 0}
+
+
 def test_a_failing_thread_rank_releases_its_peers(hd):
     """A rank that raises must not leave the other ranks blocked in a collective: they get an error, and the first real error surfaces."""
     from hypredrive_amd import _lib

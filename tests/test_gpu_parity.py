@@ -978,6 +978,18 @@ print(json.dumps(dict(seen=seen, its=its)))
     assert tot_small <= 2 * small["seen"][-1][1] + 0.001 * 2 ** 30
 
 
+def test_random_hierarchies_bit_identical_to_oracle():
+    """tests/fuzz_hierarchies.py, 40 random operators (40-3000 rows, 2-70 entries a row, both signs, empty rows; theta 0.25-0.7, Pmax 0-6,
+    ext+i / direct interpolation, 0-2 aggressive levels) through the whole setup under HDA_GUARD=1 HDA_POISON=1: every operator, C/F
+    marker and interpolation of every hierarchy bit-identical to the oracle's (200 of them ran clean in tools/gpurun/r03_m.sh)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_hierarchies.py"), "40"], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=root, HDA_GUARD="1", HDA_POISON="1"), timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_int32_size_guard(hd):
     """Operators are int32-indexed (HYPRE_Int in hypre's default build): a setup stage whose output
     would pass 2^31-1 entries must stop with an error, never wrap around."""

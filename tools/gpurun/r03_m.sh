@@ -5,6 +5,6 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 O=$R/gpurun_out/${1:-r03m}
 rm -rf $O; mkdir -p $O
 cd $R
-HDA_GUARD=1 HDA_POISON=1 timeout -k 10 1000 python tools/gpurun/gpurun_fuzz.py 200 > $O/fuzz.log 2>&1; rc=$?
+HDA_GUARD=1 HDA_POISON=1 timeout -k 10 1000 python tests/fuzz_hierarchies.py 200 > $O/fuzz.log 2>&1; rc=$?
 tail -15 $O/fuzz.log
 exit $rc
