@@ -794,12 +794,12 @@ __global__ __launch_bounds__(256) void k_max3(int n, const int *__restrict__ rp,
 }
 
 template <int G>
-__global__ __launch_bounds__(256, 3) void k_interp_wave(
+__global__ __launch_bounds__(256, 5) void k_interp_wave(
    int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
    const unsigned char *__restrict__ smask, const unsigned char *__restrict__ sc, const int *__restrict__ cf, const int *__restrict__ nsC,
    const long long *__restrict__ uofs, int cap_row, int cap_ub, int cap_nbr, int pmax, double trunc_factor,
    const unsigned char *__restrict__ rowmode, int *__restrict__ lcol, double *__restrict__ lw, int *__restrict__ pcnt,
-   const int *__restrict__ dof, int s3_scan, unsigned long long *__restrict__ prof)
+   const int *__restrict__ dof, int s3_scan, unsigned long long *__restrict__ prof, int reg_nbr)
 {
    extern __shared__ double ilds[];
    constexpr int GPB = 256 / G;                    // row groups per workgroup
@@ -1214,6 +1214,68 @@ __global__ __launch_bounds__(256, 3) void k_interp_wave(
                continue;
             }
          }
+         if (reg_nbr && (t & 7) == T_SF && noff[k + 1] - noff[k] <= 4 * G)
+         { // the neighbour row fits four entries per lane: ONE pass over memory and one lookup per entry, the three sweeps below
+           // (a_jj, ordered sum, distribution) run on registers.  Same terms, same order as the general form that follows.
+            const int nj = noff[k + 1] - noff[k];
+            int       mm[4], pp[4];
+            double    aa[4];
+            double    ajj = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+               const int kk = u * G + lane;
+               mm[u]        = -1;
+               aa[u]        = 0.0;
+               if (u * G < nj)
+               {
+                  if (kk < nj) { mm[u] = nb_col(k, kk); aa[u] = nb_val(k, kk); }
+                  const unsigned long long b = gballot(kk < nj && mm[u] == j);
+                  if (b) ajj = __shfl(aa[u], __ffsll((long long)b) - 1, G);
+               }
+            }
+            const double sgn = (ajj < 0.0) ? -1.0 : 1.0;
+            double       sum = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+               pp[u] = -1;
+               if (u * G < nj)
+               {
+                  bool cond = false;
+                  if (mm[u] >= 0 && sgn * aa[u] < 0.0)
+                  {
+                     pp[u] = (mm[u] == i) ? -2 : lookup(mm[u]);
+                     cond  = pp[u] != -1;
+                  }
+                  unsigned long long bits = gballot(cond);
+                  while (bits)
+                  {
+                     const int l = __ffsll((long long)bits) - 1;
+                     sum += __shfl(aa[u], l, G);
+                     bits &= bits - 1;
+                  }
+               }
+            }
+            if (sum != 0.0)
+            {
+               const double distribute = aij / sum;
+#pragma unroll
+               for (int u = 0; u < 4; u++)
+                  if (u * G < nj)
+                  {
+                     if (pp[u] >= 0) Wv[pp[u]] += distribute * aa[u];
+                     else if (pp[u] == -2) misc[0] += distribute * aa[u];
+                     WAVE_SYNC();
+                  }
+            }
+            else
+            {
+               if (lane == 0) misc[0] += aij;
+               WAVE_SYNC();
+            }
+            continue;
+         }
          if ((t & 7) == T_SF)
          {
             const int nj = noff[k + 1] - noff[k];
@@ -1456,15 +1518,17 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    int cap_row = 8, cap_ub = 16, cap_nbr = 64;
    cap_row = std::min(256, std::max(8, (hmx[0] + 7) / 8 * 8)); // rows longer than 256 entries keep the thread kernel
    while (cap_ub < hmx[1] && cap_ub < 1024) cap_ub <<= 1;
-   // Neighbour-row staging area per row group.  The kernel is held to 168 VGPRs (three waves per SIMD), so
-   // LDS decides the occupancy: where the neighbour rows of a typical row (about half of avg_row^2
-   // entries) fit 512 entries they are staged; where they would not fit anyway the smaller area lets three
-   // workgroups share a CU.  HDA_INTERP_NBR overrides.
+   // Neighbour-row staging area per row group.  Since round 3 neighbour rows of up to four entries per lane are read ONCE from memory
+   // and swept on registers (reg_nbr below), which beat the LDS-staged form on every level of the 256^3 hierarchy (level 1: 70 -> 59 ms,
+   // level 2: 36 -> 20, levels 0 / 3: 23.3 -> 22.2 / 5.0 -> 3.0, tools/gpurun/r03_zg.sh ... r03_zi.sh) because the small area lets more
+   // rows be in flight per CU: the default area is 8 entries, i.e. staging is off in practice.  HDA_INTERP_NBR=<entries> brings it back.
    static const int nbr_env = getenv("HDA_INTERP_NBR") ? atoi(getenv("HDA_INTERP_NBR")) : 0;
-   const double     est_nbr = 0.5 * A.avg_row() * A.avg_row();
-   const int        nbr_cap_max = nbr_env > 0 ? nbr_env : (est_nbr <= 768.0 ? 512 : 256);
-   while (cap_nbr < hmx[2] && cap_nbr < nbr_cap_max) cap_nbr <<= 1;
-   if (hmx[2] < cap_nbr) cap_nbr = std::max(8, (hmx[2] + 7) / 8 * 8); // every row's neighbourhood fits: no more than needed
+   cap_nbr = 8;
+   if (nbr_env > 8)
+   {
+      while (cap_nbr < hmx[2] && cap_nbr < nbr_env) cap_nbr <<= 1;
+      if (hmx[2] < cap_nbr) cap_nbr = std::max(8, (hmx[2] + 7) / 8 * 8); // every row's neighbourhood fits: no more than needed
+   }
    while (cap_nbr > 64 && interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * gpb > 150 * 1024) cap_nbr >>= 1; // the workgroup's row groups must fit the LDS budget
    if (interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * gpb > 150 * 1024) use_wave = false;
    if (use_wave)
@@ -1488,6 +1552,8 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
       const size_t lds = interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * gpb;
       static const int s3_scan = getenv("HDA_INTERP_SCAN") ? atoi(getenv("HDA_INTERP_SCAN")) : 1 << 30; // candidates up to which duplicates are found by scanning
       static const bool want_prof = getenv("HDA_INTERP_PROF") != nullptr;
+      // neighbour rows read from memory, at most four entries per lane: one pass, the sweeps on registers (HDA_INTERP_REG=0: three passes)
+      static const int reg_nbr = !(getenv("HDA_INTERP_REG") && atoi(getenv("HDA_INTERP_REG")) == 0);
       DArray<unsigned long long> prof;
       if (want_prof)
       {
@@ -1500,7 +1566,7 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
          HDA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
          kern<<<std::min(ceil_div(n, gpb), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, sc.data(), cf, nsC.data(),
                                                                       uofs.data(), cap_row, cap_ub, cap_nbr, pmax, trunc_factor, rowmode.data(),
-                                                                      lcol.data(), lw.data(), pcnt.data(), dof, s3_scan, prof.data());
+                                                                      lcol.data(), lw.data(), pcnt.data(), dof, s3_scan, prof.data(), reg_nbr);
       };
       if (G == 8) launch(k_interp_wave<8>);
       else if (G == 16) launch(k_interp_wave<16>);

@@ -80,7 +80,7 @@ void  pool_free(void *p);
 void  pool_trim(); // sync + return all cached blocks to the driver
 size_t pool_bytes_in_use();
 size_t pool_bytes_peak();
-size_t pool_bytes_cached(); // released blocks kept for reuse: at most max(peak, HDA_POOL_CACHE_MIN_GB)
+size_t pool_bytes_cached(); // released blocks kept for reuse: at most max(2 x peak, HDA_POOL_CACHE_MIN_GB)
 
 // Stream-ordered device array.
 template <class T>

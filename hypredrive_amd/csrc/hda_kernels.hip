@@ -169,14 +169,16 @@ void pool_free(void *p)
    g_pool.in_use -= it->second;
    g_pool.cached += it->second;
    g_pool.free_.emplace(it->second, Cached{p, ++g_pool.clock});
-   // Released blocks are kept for the next setup / solve of the same shape (a warm AMG setup is half the cold one), but never more
-   // than this thread ever had in use at once (at least HDA_POOL_CACHE_MIN_GB, default 4): a long-lived process that has solved many
-   // differently sized systems must not sit on the whole of HBM -- other processes and other rank threads allocate from it too
+   // Released blocks are kept for the next setup / solve of the same shape (on boxes with a slow hipMalloc a cold AMG setup takes three
+   // times the warm one), but never more than TWICE what this thread ever had in use at once (at least HDA_POOL_CACHE_MIN_GB, default 4):
+   // a long-lived process that has solved many differently sized systems must not sit on the whole of HBM -- other processes and other
+   // rank threads allocate from it too.  (Twice, not once: after a setup the allocator owns about 1.2x the peak -- temporaries freed
+   // early cannot all be reused later -- and a bound of 1x evicted exactly the big level-0 temporaries the next setup asks for first.)
    static const size_t floor_bytes = [] {
       const char *e = getenv("HDA_POOL_CACHE_MIN_GB");
       return (size_t)((e && *e ? atof(e) : 4.0) * (double)(1ull << 30));
    }();
-   const size_t cap = std::max(floor_bytes, g_pool.peak);
+   const size_t cap = std::max(floor_bytes, 2 * g_pool.peak);
    if (g_pool.cached > cap)
    {
       std::vector<std::multimap<size_t, Cached>::iterator> by_age;

@@ -259,7 +259,7 @@ int         hda_comm_size(void);
 int hda_comm_selftest(void);
 /* allocator statistics (bytes) */
 int hda_memory_stats(double *in_use, double *peak);
-/* bytes of released device blocks the calling thread's allocator keeps for reuse: never more than the thread's peak in use
+/* bytes of released device blocks the calling thread's allocator keeps for reuse: never more than twice the thread's peak in use
  * (or HDA_POOL_CACHE_MIN_GB, default 4, if that is larger); older blocks go back to the driver first */
 double hda_memory_cached(void);
 /* Matrices are int32-indexed (hypre's HYPRE_Int in its default build, HYPRE_config.h).  Every setup

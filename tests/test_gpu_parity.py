@@ -943,7 +943,7 @@ def test_full_size_spmv_properties(hd):
 def test_allocator_cache_is_bounded_by_the_peak():
     """Released device blocks are kept for the next setup of the same shape, but a process that has solved many differently sized
     systems must not end up holding all of HBM (that starved a child process of scratch memory in the round-3 suite): the cache never
-    exceeds max(peak in use, HDA_POOL_CACHE_MIN_GB), oldest blocks are returned first, and results do not depend on it."""
+    exceeds max(twice the peak in use, HDA_POOL_CACHE_MIN_GB), oldest blocks are returned first, and results do not depend on it."""
     import json
     import subprocess
     import sys
@@ -972,10 +972,10 @@ print(json.dumps(dict(seen=seen, its=its)))
     small, big = outs
     assert small["its"] == big["its"]                                  # same iterations and residuals, bit for bit
     for iu, pk, cached in small["seen"]:
-        assert cached <= max(pk, 0.001 * 2 ** 30)
+        assert cached <= max(2 * pk, 0.001 * 2 ** 30)
     assert small["seen"][-1][2] < big["seen"][-1][2]                   # without the bound the cache only grows
     tot_small = small["seen"][-1][0] + small["seen"][-1][2]
-    assert tot_small <= 2 * small["seen"][-1][1] + 0.001 * 2 ** 30
+    assert tot_small <= 3 * small["seen"][-1][1] + 0.001 * 2 ** 30
 
 
 def test_random_hierarchies_bit_identical_to_oracle():
