@@ -464,6 +464,21 @@ __global__ __launch_bounds__(256) void k_strongC_flag(int nnz, const int *__rest
    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256) sc[k] = (smask[k] && cf[cj[k]] == 1) ? 1 : 0;
 }
 
+// the strong C columns of every row, side by side in row order (offsets: scan of k_count_strongC's counts): what a row's candidate
+// set C-hat_i is gathered from without walking its neighbours' full rows
+__global__ __launch_bounds__(256) void k_fill_strongC(int n, const int *__restrict__ rp, const int *__restrict__ cj, const unsigned char *__restrict__ smask,
+                                                      const int *__restrict__ cf, const int *__restrict__ scofs, int *__restrict__ scc)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int q = scofs[i];
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+   {
+      const int j = cj[k];
+      if (smask[k] && cf[j] == 1) scc[q++] = j;
+   }
+}
+
 __global__ __launch_bounds__(256) void k_interp_ub(int n, const int *__restrict__ rp,
                                                    const int *__restrict__ cj,
                                                    const unsigned char *__restrict__ smask,
@@ -760,8 +775,8 @@ __global__ __launch_bounds__(256) void k_interp_build(
 // 64 lanes of a batch update distinct accumulators while batches and neighbours are visited
 // in order.  Rows that do not fit the LDS budget are flagged for k_interp_build.
 __host__ __device__ inline size_t interp_wave_doubles(int cap_row, int cap_ub, int cap_nbr)
-{ // doubles: rval[cap_row] Wv[cap_ub] nval[cap_nbr] misc[2]; ints: 5*cap_row + 2 + 4*cap_ub + cap_nbr
-   return (size_t)cap_row + cap_ub + cap_nbr + 2 + ((size_t)cap_row * 5 + 2 + (size_t)cap_ub * 4 + cap_nbr + 1) / 2 + 1;
+{ // doubles: rval[cap_row] Wv[cap_ub] nval[cap_nbr] misc[2]; ints: 6*cap_row + 2 + 4*cap_ub + cap_nbr
+   return (size_t)cap_row + cap_ub + cap_nbr + 2 + ((size_t)cap_row * 6 + 2 + (size_t)cap_ub * 4 + cap_nbr + 1) / 2 + 1;
 }
 #define WAVE_SYNC()                                         \
    do {                                                     \
@@ -799,7 +814,8 @@ __global__ __launch_bounds__(256, 5) void k_interp_wave(
    const unsigned char *__restrict__ smask, const unsigned char *__restrict__ sc, const int *__restrict__ cf, const int *__restrict__ nsC,
    const long long *__restrict__ uofs, int cap_row, int cap_ub, int cap_nbr, int pmax, double trunc_factor,
    const unsigned char *__restrict__ rowmode, int *__restrict__ lcol, double *__restrict__ lw, int *__restrict__ pcnt,
-   const int *__restrict__ dof, int s3_scan, unsigned long long *__restrict__ prof, int reg_nbr)
+   const int *__restrict__ dof, int s3_scan, unsigned long long *__restrict__ prof, int reg_nbr, const int *__restrict__ scofs,
+   const int *__restrict__ scc)
 {
    extern __shared__ double ilds[];
    constexpr int GPB = 256 / G;                    // row groups per workgroup
@@ -814,6 +830,7 @@ __global__ __launch_bounds__(256, 5) void k_interp_wave(
    double      *ksum = (double *)rcol; // per-neighbour sums of a staged row: over rcol and rofs, both dead by then
    int         *craw = nbeg + cap_row, *ucol = craw + cap_ub, *htb = ucol + cap_ub;         // htb: 2*cap_ub slots, col -> pos+1
    int         *ncol = htb + 2 * cap_ub;                                                    // ncol: cap_nbr (bit 31 = strong C entry)
+   int         *sbeg = ncol + cap_nbr;                                                      // sbeg: cap_row, start of a strong-F neighbour's strong-C list
    const int    hmask = 2 * cap_ub - 1;
    auto lookup = [&](int m) -> int { // position of column m in C-hat_i or -1
       unsigned h = ((unsigned)m * 2654435761u) & (unsigned)hmask;
@@ -873,6 +890,7 @@ __global__ __launch_bounds__(256, 5) void k_interp_wave(
                cntk    = nsC[j];
                nbeg[k] = rp[j];
                noff[k] = rp[j + 1]; // (its end, until the scan of stage 1b turns it into an offset)
+               if (scc) sbeg[k] = scofs[j];
             }
             rcol[k]  = j;
             rval[k]  = v[k0 + k];
@@ -977,6 +995,21 @@ __global__ __launch_bounds__(256, 5) void k_interp_wave(
                   if (w < 0) craw[q++] = w & 0x7FFFFFFF;
                }
             }
+         }
+      }
+      else if (scc)
+      { // one flat gather: candidate f belongs to the last row entry whose offset is <= f (entries without candidates share offsets);
+        // a strong C neighbour is its own candidate, a strong F neighbour contributes its list of strong C columns
+         for (int f = lane; f < ncand; f += G)
+         {
+            int lo = 0, hi = nk - 1;
+            while (lo < hi)
+            {
+               const int mid = (lo + hi + 1) >> 1;
+               if (rofs[mid] <= f) lo = mid;
+               else hi = mid - 1;
+            }
+            craw[f] = ((rtype[lo] & 7) == T_SC) ? rcol[lo] : scc[sbeg[lo] + (f - rofs[lo])];
          }
       }
       else
@@ -1562,11 +1595,26 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
       }
       DArray<unsigned char> sc((size_t)std::max(A.nnz, 1));
       if (A.nnz) k_strongC_flag<<<std::min(ceil_div(A.nnz, 256), 1 << 16), 256, 0, STREAM>>>(A.nnz, A.col.data(), smask, cf, sc.data());
+      // compact lists of every row's strong C columns: a row gathers its candidates from them in one flat pass instead of walking the
+      // full rows of its strong F neighbours one after the other (HDA_INTERP_SCLIST=0: the walk)
+      static const bool sclist = !(getenv("HDA_INTERP_SCLIST") && atoi(getenv("HDA_INTERP_SCLIST")) == 0);
+      DArray<int> scofs, scc;
+      if (sclist && cap_nbr <= 8)
+      {
+         scofs.alloc((size_t)n + 1);
+         exclusive_scan(n, nsC.data(), scofs.data(), nullptr);
+         int tot_sc = 0;
+         HDA_HIP(hipMemcpyAsync(&tot_sc, scofs.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+         Context::get().sync();
+         scc.alloc((size_t)std::max(tot_sc, 1));
+         k_fill_strongC<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, scofs.data(), scc.data());
+      }
       auto launch = [&](auto kern) {
          HDA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
          kern<<<std::min(ceil_div(n, gpb), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, sc.data(), cf, nsC.data(),
                                                                       uofs.data(), cap_row, cap_ub, cap_nbr, pmax, trunc_factor, rowmode.data(),
-                                                                      lcol.data(), lw.data(), pcnt.data(), dof, s3_scan, prof.data(), reg_nbr);
+                                                                      lcol.data(), lw.data(), pcnt.data(), dof, s3_scan, prof.data(), reg_nbr,
+                                                                      scc.data() ? scofs.data() : nullptr, scc.data());
       };
       if (G == 8) launch(k_interp_wave<8>);
       else if (G == 16) launch(k_interp_wave<16>);
