@@ -808,6 +808,20 @@ __global__ __launch_bounds__(256) void k_max3(int n, const int *__restrict__ rp,
    if ((threadIdx.x & 63) == 0) { atomicMax(&mx[0], a); atomicMax(&mx[1], b); atomicMax(&mx[2], c); }
 }
 
+// value of lane l of the row's lane group.  With a whole wavefront per row l is wave-uniform (it comes out of a ballot), so the value
+// travels through two v_readlane instead of two ds_bpermute round trips: the ordered sums below read one lane per term.
+template <int G>
+__device__ __forceinline__ double group_lane_value(double v, int l)
+{
+   if constexpr (G == 64)
+   {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+      return __hiloint2double(hi, lo);
+   }
+   else return __shfl(v, l, G);
+}
+
 template <int G>
 __global__ __launch_bounds__(256, 5) void k_interp_wave(
    int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
@@ -1264,7 +1278,7 @@ __global__ __launch_bounds__(256, 5) void k_interp_wave(
                {
                   if (kk < nj) { mm[u] = nb_col(k, kk); aa[u] = nb_val(k, kk); }
                   const unsigned long long b = gballot(kk < nj && mm[u] == j);
-                  if (b) ajj = __shfl(aa[u], __ffsll((long long)b) - 1, G);
+                  if (b) ajj = group_lane_value<G>(aa[u], __ffsll((long long)b) - 1);
                }
             }
             const double sgn = (ajj < 0.0) ? -1.0 : 1.0;
@@ -1285,7 +1299,7 @@ __global__ __launch_bounds__(256, 5) void k_interp_wave(
                   while (bits)
                   {
                      const int l = __ffsll((long long)bits) - 1;
-                     sum += __shfl(aa[u], l, G);
+                     sum += group_lane_value<G>(aa[u], l);
                      bits &= bits - 1;
                   }
                }
@@ -1320,7 +1334,7 @@ __global__ __launch_bounds__(256, 5) void k_interp_wave(
                const bool hit = kk < nj && nb_col(k, kk) == j;
                const unsigned long long b = gballot(hit);
                const double             a = hit ? nb_val(k, kk) : 0.0;
-               if (b) ajj = __shfl(a, __ffsll((long long)b) - 1, G);
+               if (b) ajj = group_lane_value<G>(a, __ffsll((long long)b) - 1);
             }
             const double sgn = (ajj < 0.0) ? -1.0 : 1.0;
             // ordered sum over the qualifying entries of row j
@@ -1340,7 +1354,7 @@ __global__ __launch_bounds__(256, 5) void k_interp_wave(
                while (bits)
                {
                   const int l = __ffsll((long long)bits) - 1;
-                  sum += __shfl(a, l, G);
+                  sum += group_lane_value<G>(a, l);
                   bits &= bits - 1;
                }
             }
