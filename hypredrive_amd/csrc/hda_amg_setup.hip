@@ -1932,8 +1932,8 @@ constexpr int kEscEntries = 2048; // X entries of a chunk staged in LDS for the 
 // One pass: products -> keys in registers (values in LDS, indexed by p and never moved), sort, segment sums in
 // enumeration order, results written to a scratch CSR whose rows start at rowstart[i] (<= the row's first product
 // index), counts in cnt.  A chunk holds fewer than 256*PER products.
-template <int PER>
-__global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, const int *__restrict__ chunk_row,
+template <int PER, int NT>
+__global__ __launch_bounds__(NT) void k_spgemm_esc(int nchunks, const int *__restrict__ chunk_row,
                                                     const int *__restrict__ xrp, const int *__restrict__ xcj,
                                                     const double *__restrict__ xv, const int *__restrict__ yrp,
                                                     const int *__restrict__ ycj, const double *__restrict__ yv,
@@ -1941,13 +1941,13 @@ __global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, const int *__re
                                                     int *__restrict__ cnt, int *__restrict__ scol, double *__restrict__ sval,
                                                     int *__restrict__ err)
 {
-   constexpr int cap = 256 * PER;
+   constexpr int cap = NT * PER;
    extern __shared__ unsigned long long esc_lds[];
    unsigned long long *keys = esc_lds;                    // cap keys (after the sort); entry of every product before it
    double             *vals = (double *)(esc_lds + cap);  // cap products, indexed by p
    unsigned short     *ent  = (unsigned short *)keys;     // staged entry of product p (dead before the sort uses keys)
    unsigned           *eofs = (unsigned *)(ent + cap);    // kEscEntries+1: (local row << 13) | entry offset relative to p0; dead likewise
-   __shared__ int      scan[256];
+   __shared__ int      scan[NT];
    const int           tid = threadIdx.x;
    for (int c = blockIdx.x; c < nchunks; c += gridDim.x)
    {
@@ -1965,12 +1965,12 @@ __global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, const int *__re
       const bool staged = ne <= kEscEntries;
       if (staged)
       { // entry offsets and entry -> local row, coalesced; then the entry of every product
-         for (int q = tid; q <= ne; q += 256) eofs[q] = (unsigned)(eoff[e0 + q] - p0);
+         for (int q = tid; q <= ne; q += NT) eofs[q] = (unsigned)(eoff[e0 + q] - p0);
          __syncthreads();
-         for (int r = r0 + tid; r < r1; r += 256)
+         for (int r = r0 + tid; r < r1; r += NT)
             for (int e = xrp[r]; e < xrp[r + 1]; e++) eofs[e - e0] |= (unsigned)(r - r0) << 13;
          __syncthreads();
-         for (int q = tid; q < ne; q += 256)
+         for (int q = tid; q < ne; q += NT)
          {
             const int a = (int)(eofs[q] & 0x1FFFu), b = (int)(eofs[q + 1] & 0x1FFFu); // eofs[ne] = span carries no row tag
             for (int p = a; p < b; p++) ent[p] = (unsigned short)q;
@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, const int *__re
 #pragma unroll
       for (int m = 0; m < PER; m++)
       {
-         const int          p   = tid + 256 * m;
+         const int          p   = tid + NT * m;
          unsigned long long key = ~0ULL;
          if (p < span)
          {
@@ -2022,7 +2022,7 @@ __global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, const int *__re
          }
          k[m] = key;
       }
-      block_sort_regs<PER>(k, keys, tid); // its first LDS use is behind a barrier: ent is dead by then
+      block_sort_regs<PER, unsigned long long, NT>(k, keys, tid); // its first LDS use is behind a barrier: ent is dead by then
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < PER; r++) keys[tid * PER + r] = k[r];
@@ -2033,7 +2033,7 @@ __global__ __launch_bounds__(256) void k_spgemm_esc(int nchunks, const int *__re
       for (int t = t0; t < t0 + PER && t < span; t++) local += (t == 0) || ((keys[t] >> 13) != (keys[t - 1] >> 13));
       scan[tid] = local;
       __syncthreads();
-      for (int o = 1; o < 256; o <<= 1)
+      for (int o = 1; o < NT; o <<= 1)
       {
          const int add = (tid >= o) ? scan[tid - o] : 0;
          __syncthreads();
@@ -2156,17 +2156,22 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
    mx.zero(); // reused as the kernel's "row field overflow" flag
    static_assert(2048 * 2 + (kEscEntries + 1) * 4 <= 2048 * 8, "entry staging must fit the key area of the smallest chunk");
    const size_t lds  = (size_t)cap * 16;
-   const int    grid = std::min(nchunks, 256 * std::max(1, (int)((160 * 1024) / (lds + 1024)))); // the resident workgroups: no tail wave
+   // Eight keys per thread whatever the chunk capacity: a 4096 / 8192-product chunk gets 512 / 1024 threads, so that the two / one
+   // workgroups a CU has LDS for still put 16 wavefronts on it (with 256 threads they left the CU at 8 / 4 and ran 1.5 - 3x slower per
+   // product, profiles/r03_kernel_experiments.md).  HDA_ESC_THREADS=256: the round-2 shape.
+   static const bool wide = !(getenv("HDA_ESC_THREADS") && atoi(getenv("HDA_ESC_THREADS")) == 256);
+   const int    nt   = wide ? cap / 8 : 256; // (four keys per thread -- twice the threads again -- lost 10-20 %: more cross-wave stages)
+   const int    grid = std::min(nchunks, 256 * std::max(1, (int)((160 * 1024) / (lds + 4 * nt + 1024)))); // the resident workgroups: no tail wave
 
    auto launch = [&](auto kern) {
       HDA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      kern<<<grid, 256, lds, STREAM>>>(nchunks, chunk_row.data(), X.rowptr.data(), X.col.data(), X.val.data(), Y.rowptr.data(),
+      kern<<<grid, nt, lds, STREAM>>>(nchunks, chunk_row.data(), X.rowptr.data(), X.col.data(), X.val.data(), Y.rowptr.data(),
                                        Y.col.data(), Y.val.data(), eoff.data(), rowstart.data(), cnt.data(), scol.data(), sval.data(),
                                        mx.data());
    };
-   if (cap == 2048) launch(k_spgemm_esc<8>);
-   else if (cap == 4096) launch(k_spgemm_esc<16>);
-   else launch(k_spgemm_esc<32>);
+   if (cap == 2048) launch(k_spgemm_esc<8, 256>);
+   else if (cap == 4096) { if (wide) launch(k_spgemm_esc<8, 512>); else launch(k_spgemm_esc<16, 256>); }
+   else { if (wide) launch(k_spgemm_esc<8, 1024>); else launch(k_spgemm_esc<32, 256>); }
    k_esc_fix_counts<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, nullptr, nullptr, nullptr, rowstart.data(), chunkbase.data(), cnt.data());
    C.nrows = n;
    C.ncols = Y.ncols;

@@ -1,4 +1,4 @@
-// hda_sort.h -- workgroup-wide bitonic sort with the keys in registers (256 threads, PER keys each).
+// hda_sort.h -- workgroup-wide bitonic sort with the keys in registers (NT threads, 256 by default, PER keys each).
 // Used by the expand/sort/compress SpGEMM (64-bit keys) and the windowed-CSR plan (32-bit column indices).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,11 +15,11 @@ __device__ __forceinline__ void sort_cex(K &a, K &b, const bool up)
    b = sw ? x : y;
 }
 
-// Bitonic sort of 256*PER keys, PER per lane in registers: element i = tid*PER + r lives in k[r] of lane tid.
+// Bitonic sort of NT*PER keys, PER per lane in registers: element i = tid*PER + r lives in k[r] of lane tid.
 // Stage (kk, j) compares elements i and i^j, ascending where (i & kk) == 0.  j < PER stays inside a lane's
-// registers, j < 64*PER is a lane exchange inside the wave (no LDS traffic, no barrier), and only the three stages
-// with j >= 64*PER cross waves through xch (256*PER keys of LDS).
-template <int PER, typename K>
+// registers, j < 64*PER is a lane exchange inside the wave (no LDS traffic, no barrier), and only the stages
+// with j >= 64*PER (three of them with four waves) cross waves through xch (NT*PER keys of LDS).
+template <int PER, typename K, int NT = 256>
 __device__ __forceinline__ void block_sort_regs(K (&k)[PER], K *xch, const int tid)
 {
 #pragma unroll
@@ -29,7 +29,7 @@ __device__ __forceinline__ void block_sort_regs(K (&k)[PER], K *xch, const int t
 #pragma unroll
          for (int r = 0; r < PER; r++)
             if ((r & j) == 0) sort_cex(k[r], k[r | j], ((tid * PER + r) & kk) == 0);
-   for (int kk = 2 * PER; kk <= 256 * PER; kk <<= 1)
+   for (int kk = 2 * PER; kk <= NT * PER; kk <<= 1)
    {
       const bool up = ((tid * PER) & kk) == 0;
       for (int j = kk >> 1; j >= PER; j >>= 1)
@@ -40,12 +40,12 @@ __device__ __forceinline__ void block_sort_regs(K (&k)[PER], K *xch, const int t
          {
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < PER; r++) xch[r * 256 + tid] = k[r];
+            for (int r = 0; r < PER; r++) xch[r * NT + tid] = k[r];
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < PER; r++)
             {
-               const K o = xch[r * 256 + (tid ^ m)];
+               const K o = xch[r * NT + (tid ^ m)];
                k[r]                       = ((o < k[r]) == keepmin) ? o : k[r];
             }
          }
