@@ -360,7 +360,8 @@ def run(args):
             # level-0 PCG product (the north-star SpMV).  The operator is stencil-coded (1 B/entry), so the CSR-equivalent
             # rate exceeds what HBM can deliver; "format" is the honest HBM rate; plain_csr below is the uncoded kernel
             "level0_spmv": {"kernel": ("k_spmv_rowclass<PLAIN,DOT>" if fb0.get("row_coded") else "k_spmv_coded_row<PLAIN,DOT>") if fb0["coded"]
-                            else "k_spmv_stream<PLAIN,DOT>",
+                            else ("k_spmv_win<PLAIN,DOT> (windowed CSR: 2-byte column positions; run form on a structured grid)" if fb0.get("windowed")
+                                  else "k_spmv_stream<PLAIN,DOT>"),
                             "coded": fb0["coded"], "avg_ms": k1_ms, "launches": k1_count,
                             "csr_bytes_per_launch": k1_bytes, "csr_equiv_gbs": gbs(k1_bytes, k1_ms),
                             "csr_equiv_frac": gbs(k1_bytes, k1_ms) / HBM_PEAK_GBS,

@@ -197,12 +197,16 @@ struct DCsr {
    mutable DArray<int>            ucol, wmeta;   // distinct columns; 3 ints per chunk + sentinel: first row, first entry, first distinct
    mutable int                    win = -1, nwin = 0, win_maxu = 0; // -1 not examined, 0 plain, 1 windowed; chunks; most distinct columns in a chunk
    mutable long long              win_total = 0;
+   // run form of the windowed operator: where every chunk's distinct columns are at most kWinRuns runs of consecutive indices (a
+   // structured-grid operator in lexicographic order) ucol holds, per chunk, 2 * kWinRuns ints (first position, first column of
+   // every run; unused runs start at INT_MAX) instead of the list: the kernel computes a position's column instead of loading it
+   mutable bool                   win_runs = false;
    void reset_plan() const
    {
       chunk_row.release(); code.release(); dict_val.release(); dict_delta.release(); offd.reset();
       rclass.release(); rc_keys.release(); lidx.release(); ucol.release(); wmeta.release();
       gen = next_csr_gen();
-      nchunks = 0; maxrow = -1; coded = -1; rowcoded = 0; rc_esc_rows = 0; rc_esc_entries = 0; win = -1; nwin = 0; win_maxu = 0; win_total = 0;
+      nchunks = 0; maxrow = -1; coded = -1; rowcoded = 0; rc_esc_rows = 0; rc_esc_entries = 0; win = -1; nwin = 0; win_maxu = 0; win_total = 0; win_runs = false;
    }
 };
 

@@ -1163,6 +1163,54 @@ __global__ __launch_bounds__(256) void k_win_fill(int nw, int *__restrict__ wmet
       __syncthreads();
    }
 }
+// run form: number of runs of consecutive indices among a chunk's distinct columns (tcol[k0 .. k0 + ucount))
+constexpr int kWinRuns = 16;
+__global__ __launch_bounds__(256) void k_win_run_count(int nw, const int *__restrict__ wmeta, const int *__restrict__ ucount, const int *__restrict__ tcol,
+                                                       int *__restrict__ rcount)
+{
+   __shared__ int cnt;
+   for (int c = blockIdx.x; c < nw; c += gridDim.x)
+   {
+      if (threadIdx.x == 0) cnt = 0;
+      __syncthreads();
+      const int k0 = wmeta[3 * c + 1], t = ucount[c];
+      int       mine = 0;
+      for (int j = threadIdx.x; j < t; j += 256) mine += (j == 0) || (tcol[k0 + j] != tcol[k0 + j - 1] + 1);
+      if (mine) atomicAdd(&cnt, mine);
+      __syncthreads();
+      if (threadIdx.x == 0) rcount[c] = cnt;
+      __syncthreads();
+   }
+}
+// the run table of every chunk: (first position, first column) of its runs in ascending order, INT_MAX beyond the last
+__global__ __launch_bounds__(64) void k_win_run_fill(int nw, const int *__restrict__ wmeta, const int *__restrict__ ucount, const int *__restrict__ tcol,
+                                                     int *__restrict__ wrun)
+{
+   const int lane = threadIdx.x;
+   for (int c = blockIdx.x; c < nw; c += gridDim.x)
+   {
+      const int k0 = wmeta[3 * c + 1], t = ucount[c];
+      if (lane < 2 * kWinRuns) wrun[(size_t)c * 2 * kWinRuns + lane] = 0x7fffffff;
+      int nr = 0;
+      for (int base = 0; base < t; base += 64)
+      {
+         const int  j    = base + lane;
+         const int  v    = (j < t) ? tcol[k0 + j] : 0;
+         const bool head = (j < t) && (j == 0 || v != tcol[k0 + j - 1] + 1);
+         const unsigned long long bal = __ballot(head);
+         if (head)
+         {
+            const int r = nr + __popcll(bal & ((1ULL << lane) - 1));
+            if (r < kWinRuns)
+            {
+               wrun[(size_t)c * 2 * kWinRuns + 2 * r]     = j;
+               wrun[(size_t)c * 2 * kWinRuns + 2 * r + 1] = v;
+            }
+         }
+         nr += __popcll(bal);
+      }
+   }
+}
 __global__ __launch_bounds__(256) void k_max_int(int n, const int *__restrict__ v, int *mx)
 {
    int m = 0;
@@ -1197,6 +1245,37 @@ static void ensure_window(const DCsr &A)
    // operands one chunk ahead it gains 8 % (0.228 -> 0.210 ms per apply, solve 34.25 -> 33.6 ms; tools/gpurun/r03_q.sh, three rounds;
    // 0.65 and 0.8 no better: a 7-point operator in lexicographic order, 0.71, does not profit)
    const double limit = getenv("HDA_WINDOW_RATIO") ? atof(getenv("HDA_WINDOW_RATIO")) : 0.6;
+   // Run form (round 3): an operator on a structured grid in lexicographic order names, per chunk, a handful of RUNS of consecutive
+   // columns (a 7-point operator: the lines below, beside and above a chunk's rows -- 5 to 10 runs, 0.71 distinct columns per entry, which
+   // is why the list form does not pay for it).  With at most kWinRuns runs in every chunk the list is replaced by a 128-byte run table per
+   // chunk: 8 + 2 bytes per entry instead of 12, and the gather of the chunk's x values becomes a few contiguous reads.  HDA_WINDOW_RUNS=0: off.
+   const bool runs_on = !(getenv("HDA_WINDOW_RUNS") && atoi(getenv("HDA_WINDOW_RUNS")) == 0);
+   if (runs_on && A.coded != 2)
+   {
+      DArray<int> rcount((size_t)nw + 1);
+      k_win_run_count<<<g, 256, 0, STREAM>>>(nw, A.wmeta.data(), ucount.data(), tcol.data(), rcount.data());
+      mx.zero();
+      k_max_int<<<std::min(ceil_div(nw, 256), 256), 256, 0, STREAM>>>(nw, rcount.data(), mx.data());
+      int mr = 0;
+      HDA_HIP(hipMemcpyAsync(&mr, mx.data(), 4, hipMemcpyDeviceToHost, STREAM));
+      Context::get().sync();
+      if (mr <= kWinRuns)
+      {
+         A.ucol.alloc((size_t)nw * 2 * kWinRuns + 64);
+         k_win_run_fill<<<g, 64, 0, STREAM>>>(nw, A.wmeta.data(), ucount.data(), tcol.data(), A.ucol.data());
+         // positions: k_win_fill's second half (it also writes a list, into scratch here)
+         DArray<int> scratch((size_t)std::max(total, 1) + 1024);
+         A.lidx.alloc((size_t)std::max(A.nnz, 1) + 1024);
+         k_win_fill<<<g, 256, 0, STREAM>>>(nw, A.wmeta.data(), A.col.data(), uoff.data(), tcol.data(), scratch.data(), A.lidx.data());
+         A.win       = 1;
+         A.win_runs  = true;
+         A.nwin      = nw;
+         A.win_maxu  = m;
+         A.win_total = total;
+         HDA_TRACE("windowed CSR (run form) for %d x %d, nnz %d: %.3f distinct columns per entry in at most %d runs per chunk", A.nrows, A.ncols, A.nnz, ratio, mr);
+         return;
+      }
+   }
    if (ratio > limit)
    {
       A.wmeta.release();
@@ -1213,7 +1292,7 @@ static void ensure_window(const DCsr &A)
    HDA_TRACE("windowed CSR for %d x %d, nnz %d: %.3f distinct columns per entry, at most %d in a chunk", A.nrows, A.ncols, A.nnz, ratio, m);
 }
 
-template <int MODE, bool DOT, bool VC, bool SPLIT>
+template <int MODE, bool DOT, bool VC, bool SPLIT, bool RUNS = false>
 __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict__ wmeta, const int *__restrict__ rowptr,
                                                   const unsigned short *__restrict__ lidx, const int *__restrict__ ucol,
                                                   const double *__restrict__ val, const double *__restrict__ x, double alpha, double beta,
@@ -1238,10 +1317,11 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
    const int nper = (nw + 7) >> 3;
    double    acc  = 0.0;
-   struct Chunk { int r0, r1, k0, k1, u0, nu; bool ok; };
+   struct Chunk { int r0, r1, k0, k1, u0, nu, q; bool ok; };
    auto meta = [&](int i) {
       Chunk     c;
       const int q = xcd * nper + i;
+      c.q         = q;
       c.ok        = i < nper && q < nw;
       if (c.ok)
       {
@@ -1284,12 +1364,28 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
          pv[e]       = (k < c.k1) ? value(k) : 0.0;
          pl[e]       = (k < c.k1) ? (int)lidx[k] : 0;
       }
-#pragma unroll
-      for (int u = 0; u < U; u++)
+      if (RUNS) pu[0] = ((tid & 63) < 2 * kWinRuns) ? ucol[(size_t)c.q * 2 * kWinRuns + (tid & 63)] : 0x7fffffff; // the chunk's run table, once per wave
+      else
       {
-         const int j = tid + 256 * u;
-         pu[u]       = (j < c.nu) ? ucol[c.u0 + j] : 0;
+#pragma unroll
+         for (int u = 0; u < U; u++)
+         {
+            const int j = tid + 256 * u;
+            pu[u]       = (j < c.nu) ? ucol[c.u0 + j] : 0;
+         }
       }
+   };
+   // run form: column of the distinct-column position j = first column of its run + distance from the run's first position; the table
+   // (lanes 2r, 2r + 1 of every wave: first position and first column of run r, ascending, INT_MAX beyond the last) is searched by shuffles
+   auto run_col = [&](int j) {
+      int lo = 0;
+#pragma unroll
+      for (int step = kWinRuns / 2; step > 0; step >>= 1)
+      {
+         const int p = __shfl(pu[0], 2 * (lo + step));
+         if (p <= j) lo += step;
+      }
+      return __shfl(pu[0], 2 * lo + 1) + (j - __shfl(pu[0], 2 * lo));
    };
    int   i   = slot;
    Chunk cur = meta(i);
@@ -1300,16 +1396,28 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
    {
       const int ne = cur.k1 - cur.k0;
       // stage 0: every distinct x of the chunk once, ascending addresses
-#pragma unroll
-      for (int u = 0; u < U; u++)
+      if (RUNS)
       {
-         const int j = tid + 256 * u;
-         if (j < cur.nu) xs[j] = (SPLIT && pu[u] >= nown) ? 0.0 : x[pu[u]];
+         for (int base = 0; base < cur.nu; base += 256) // (uniform trip count: the shuffles of run_col need whole waves)
+         {
+            const int j  = base + tid;
+            const int uc = run_col(j);
+            if (j < cur.nu) xs[j] = (SPLIT && uc >= nown) ? 0.0 : x[uc];
+         }
       }
-      for (int j = tid + 256 * U; j < cur.nu; j += 256)
+      else
       {
-         const int uc = ucol[cur.u0 + j];
-         xs[j]        = (SPLIT && uc >= nown) ? 0.0 : x[uc];
+#pragma unroll
+         for (int u = 0; u < U; u++)
+         {
+            const int j = tid + 256 * u;
+            if (j < cur.nu) xs[j] = (SPLIT && pu[u] >= nown) ? 0.0 : x[pu[u]];
+         }
+         for (int j = tid + 256 * U; j < cur.nu; j += 256)
+         {
+            const int uc = ucol[cur.u0 + j];
+            xs[j]        = (SPLIT && uc >= nown) ? 0.0 : x[uc];
+         }
       }
       __syncthreads();
       // stage 1: products -> LDS
@@ -1693,7 +1801,12 @@ static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
    k_spmv_win<MODE, DOT, VCF, SPF><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(),     \
                                                               A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen,  \
                                                               CODE, DICT, win_pf())
-         if (A.coded == 2)
+         if (A.win_runs)
+         { // run form (never value-coded)
+            if (split) k_spmv_win<MODE, DOT, false, true, true><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen, nullptr, nullptr, win_pf());
+            else k_spmv_win<MODE, DOT, false, false, true><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen, nullptr, nullptr, win_pf());
+         }
+         else if (A.coded == 2)
          {
             if (split) { HDA_WIN(true, true, A.code.data(), A.dict_val.data()); }
             else { HDA_WIN(true, false, A.code.data(), A.dict_val.data()); }
@@ -1876,7 +1989,8 @@ double matrix_stream_bytes(const DCsr &A, bool format)
       if (A.coded == 1 && A.rowcoded == 1) return 1.0 * A.nrows + 12.0 * (double)A.rc_esc_entries; // one class byte per row; CSR for the rest
       if (A.coded == 1) return 1.0 * A.nnz + 12.0 * A.escapes;
       if (spmv_mode() == 0) ensure_window(A);
-      const double idx = (A.win == 1) ? 2.0 * A.nnz + 4.0 * (double)A.win_total + 12.0 * A.nwin : 4.0 * A.nnz; // 2-byte positions + distinct columns + chunk table, or columns
+      const double idx = (A.win == 1) ? 2.0 * A.nnz + (A.win_runs ? 8.0 * kWinRuns * A.nwin : 4.0 * (double)A.win_total) + 12.0 * A.nwin
+                                      : 4.0 * A.nnz; // 2-byte positions + distinct columns (or run tables) + chunk table, or columns
       if (A.coded == 2) return idx + 1.0 * A.nnz + 8.0 * A.escapes;
       if (A.win == 1) return idx + 8.0 * A.nnz;
    }

@@ -940,6 +940,41 @@ def test_full_size_spmv_properties(hd):
     assert abs(A.spmv(u) @ v - u @ A.spmv(v)) / abs(u @ A.spmv(v)) < 1e-12
 
 
+def test_run_form_of_windowed_csr_changes_no_result():
+    """Run form of the windowed CSR (round 3): an uncoded structured-grid operator names a handful of runs of consecutive columns per
+    1024-entry chunk, so its column indices shrink to 2-byte positions plus a 128-byte run table per chunk.  HDA_CODED=0 (the general-matrix
+    path) with and without it (HDA_WINDOW_RUNS=0), 72^3: the level-0 operator takes the run form, same iterations, histories and solutions
+    to rounding; and as a bare product against the plain kernel on a random vector."""
+    import json
+    import subprocess
+    import sys
+    code = """
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import hypredrive_amd as hd
+n = 72
+A = hd.lap7(n, n, n)
+x = np.random.default_rng(3).standard_normal(n ** 3)
+y = A.spmv(x)
+amg = hd.Amg(A)
+b = np.zeros(n ** 3); b[:n * n] = 1.0
+r = hd.pcg(A, b, amg)
+fb = hd.format_bytes(A, amg)
+print(json.dumps(dict(it=r["iters"], hist=list(map(float, r["hist"])), xn=float(np.linalg.norm(r["x"])), yn=float(np.linalg.norm(y)),
+                      y0=[float(v) for v in y[::40009]], spmv_bytes=fb["spmv"], windowed=bool(fb["windowed"]))))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for env in ({"HDA_CODED": "0"}, {"HDA_CODED": "0", "HDA_WINDOW_RUNS": "0"}, {"HDA_CODED": "0", "HDA_WINDOW": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    runs, lists, plain = out
+    assert runs["spmv_bytes"] < 0.9 * lists["spmv_bytes"]          # fewer bytes streamed by the level-0 product
+    assert runs["it"] == lists["it"] == plain["it"]
+    assert np.allclose(runs["hist"], plain["hist"], rtol=1e-9) and runs["xn"] == pytest.approx(plain["xn"], rel=1e-10)
+    assert np.allclose(runs["y0"], plain["y0"], rtol=1e-13, atol=1e-13) and runs["yn"] == pytest.approx(plain["yn"], rel=1e-13)
+
+
 def test_allocator_cache_is_bounded_by_the_peak():
     """Released device blocks are kept for the next setup of the same shape, but a process that has solved many differently sized
     systems must not end up holding all of HBM (that starved a child process of scratch memory in the round-3 suite): the cache never
