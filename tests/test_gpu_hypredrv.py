@@ -411,7 +411,9 @@ def _thread_ranks(tmp_path, tag, n, P, solver="pcg", want_x="1", **envx):
                                                     (40, 2000, "0", {"HDA_OVERLAP": "1"}), (36, 1500, "0", {"HDA_PCG_SINGLE_REDUCE": "1"}),
                                                     (40, 2000, "0", {"HDA_THREAD_TRANSPORT": "device"}), (32, 0, "0", {"HDA_THREAD_TRANSPORT": "device"}),
                                                     (36, 1500, "0", {"HDA_THREAD_TRANSPORT": "device", "HDA_PCG_SINGLE_REDUCE": "1"}),
-                                                    (40, 2000, "0", {"HDA_THREAD_TRANSPORT": "device", "HDA_OVERLAP": "0"})])
+                                                    (40, 2000, "0", {"HDA_THREAD_TRANSPORT": "device", "HDA_OVERLAP": "0"}),
+                                                    (40, 2000, "0", {"HDA_THREAD_TRANSPORT": "device", "HDA_CODED": "0", "HDA_WINDOW_MIN_NNZ": "1000"}),
+                                                    (40, 2000, "0", {"HDA_THREAD_TRANSPORT": "device", "HDA_CODED": "0", "HDA_WINDOW_MIN_NNZ": "1000", "HDA_WINDOW_RUNS": "0"})])
 def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check, extra):
     """BASELINE config 3's layout -- `-P 2 2 2` (reference examples/src/C_laplacian/laplacian.c:561-582, scripts/node_scaling.sh:1275-1292) --
     with eight ranks: blocks have face, EDGE and CORNER neighbours (7 peers), which no 1xPxQ layout produces, on every partitioned
@@ -422,7 +424,9 @@ def test_eight_ranks_2x2x2_match_single_rank(hd, tmp_path, n, rep_rows, check, e
     # extra: HDA_OVERLAP=1 -- every product runs its owned-column part while the ghosts travel and adds the ghost-column part afterwards
     # (the RCCL default), here with 7 peers per block; HDA_PCG_SINGLE_REDUCE=1 -- the opt-in one-reduction PCG;
     # HDA_THREAD_TRANSPORT=device -- the thread transport that, like RCCL, only ENQUEUES exchanges and all-reduces on the caller's stream
-    # (device-to-device copies ordered by events, hda_comm.hip DeviceThreadComm): overlapped products on by default, nothing waits on the host
+    # (device-to-device copies ordered by events, hda_comm.hip DeviceThreadComm): overlapped products on by default, nothing waits on the host;
+    # HDA_CODED=0 HDA_WINDOW_MIN_NNZ=1000 -- uncoded blocks small enough to be windowed: the owned-column halves of the overlapped products
+    # run on the windowed kernel in its run form (ghost columns = further runs) or, with HDA_WINDOW_RUNS=0, its list form
     res, x, err = _thread_ranks(tmp_path, f"t{n}_{rep_rows}_{check}", n, (2, 2, 2), HDA_REPLICATE_ROWS=str(rep_rows), HDA_DIST_CHECK=check, **extra)
     h = hd.Hypredrv("solver: pcg\npreconditioner:\n  preset: poisson\n")
     h.set_laplacian7((n, n, n))
