@@ -27,7 +27,8 @@ class AmgParams(C.Structure):
                 ("smooth_num_levels", C.c_int), ("smooth_num_sweeps", C.c_int),
                 ("ilu_tri_solve", C.c_int), ("ilu_lower_it", C.c_int), ("ilu_upper_it", C.c_int),
                 ("agg_num_levels", C.c_int), ("agg_num_paths", C.c_int), ("agg_interp_type", C.c_int),
-                ("agg_pmax", C.c_int), ("agg_trunc_factor", C.c_double)]
+                ("agg_pmax", C.c_int), ("agg_trunc_factor", C.c_double),
+                ("blocks", C.c_int), ("block_part", C.POINTER(C.c_int64)), ("struct_size", C.c_int)]
 
     @staticmethod
     def default(**kw):
@@ -36,6 +37,13 @@ class AmgParams(C.Structure):
         for k, v in kw.items():
             if not hasattr(p, k):
                 raise KeyError(k)
+            if k == "block_part":
+                if v is None:
+                    continue
+                keep = np.ascontiguousarray(v, dtype=np.int64)
+                p._block_part_keep = keep  # (borrowed until the setup has read it)
+                p.block_part = keep.ctypes.data_as(C.POINTER(C.c_int64))
+                continue
             setattr(p, k, v)
         return p
 
@@ -79,6 +87,7 @@ SYMBOLS = [
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
     "hda_thread_ranks_lap7", "hda_thread_world_create", "hda_thread_world_join", "hda_thread_world_leave", "hda_thread_world_destroy", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
     "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass", "hda_truncate_rows",
+    "hda_relax_blocks", "hda_l1_norms_blocks", "hda_hmis_blocks", "hda_amg_blocks", "hda_amg_level_blocks",
 ]
 
 
@@ -109,6 +118,11 @@ def load():
     L.hda_relax.argtypes = [vp, C.c_int, C.c_double, C.c_int, dp, dp]
     L.hda_dot.argtypes = [C.c_int, dp, dp, dp]
     L.hda_l1_norms.argtypes = [vp, C.c_int, dp]
+    L.hda_relax_blocks.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_int, P(C.c_int64), dp, dp]
+    L.hda_l1_norms_blocks.argtypes = [vp, C.c_int, C.c_int, P(C.c_int64), dp]
+    L.hda_hmis_blocks.argtypes = [vp, P(C.c_ubyte), C.c_int, P(C.c_int64), C.c_uint64, C.c_int, ip]
+    L.hda_amg_blocks.argtypes = [vp]
+    L.hda_amg_level_blocks.argtypes = [vp, C.c_int, P(C.c_int64)]
     L.hda_strength.argtypes = [vp, C.c_double, C.c_double, P(C.c_ubyte)]
     L.hda_pmis.argtypes = [vp, P(C.c_ubyte), C.c_uint64, C.c_int, C.c_int64, ip]
     L.hda_interp_extpi.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
@@ -247,6 +261,28 @@ class Csr:
         _check(load().hda_l1_norms(self.h, option, _dp(out)))
         return out
 
+    # the row-block forms (part: V + 1 row starts) = the reference at np = V
+    def relax_blocks(self, b, x, part, relax_type=13, weight=1.0, sweeps=1):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        pt = np.ascontiguousarray(part, dtype=np.int64)
+        _check(load().hda_relax_blocks(self.h, relax_type, weight, sweeps, len(pt) - 1, pt.ctypes.data_as(C.POINTER(C.c_int64)), _dp(b), _dp(x)))
+        return x
+
+    def l1_norms_blocks(self, option, part):
+        out = np.zeros(max(self.nrows, 1))
+        pt = np.ascontiguousarray(part, dtype=np.int64)
+        _check(load().hda_l1_norms_blocks(self.h, option, len(pt) - 1, pt.ctypes.data_as(C.POINTER(C.c_int64)), _dp(out)))
+        return out[:self.nrows]
+
+    def hmis_blocks(self, smask, part, seed=2747, level=0):
+        sm = np.ascontiguousarray(np.concatenate([smask, np.zeros(1, np.uint8)]), dtype=np.uint8)
+        cf = np.zeros(max(self.nrows, 1), dtype=np.int32)
+        pt = np.ascontiguousarray(part, dtype=np.int64)
+        _check(load().hda_hmis_blocks(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), len(pt) - 1, pt.ctypes.data_as(C.POINTER(C.c_int64)),
+                                      seed, level, _ip(cf)))
+        return cf[:self.nrows]
+
     def strength(self, theta=0.25, max_row_sum=0.9):
         sm = np.zeros(max(self.nnz, 1), dtype=np.uint8)
         _check(load().hda_strength(self.h, theta, max_row_sum, sm.ctypes.data_as(C.POINTER(C.c_ubyte))))
@@ -369,6 +405,16 @@ class Amg:
         cf = np.zeros(n, dtype=np.int32)
         _check(load().hda_amg_level_cf(self.h, level, _ip(cf)))
         return cf
+
+    @property
+    def blocks(self):
+        """row blocks the setup worked with (AmgParams.blocks resolved; 1 = none)"""
+        return load().hda_amg_blocks(self.h)
+
+    def level_blocks(self, level):
+        out = np.zeros(max(self.blocks, 1) + 1, dtype=np.int64)
+        _check(load().hda_amg_level_blocks(self.h, level, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
 
     @property
     def complexities(self):

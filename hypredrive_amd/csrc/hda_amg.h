@@ -52,7 +52,16 @@ struct AmgParams {
    int agg_num_levels = 0, agg_num_paths = 1, agg_interp_type = 4;
    int    agg_pmax = 0;           // aggressive.max_nnz_row (HYPRE_BoomerAMGSetAggPMaxElmts): 0 = no limit
    double agg_trunc_factor = 0.0; // aggressive.trunc_factor (HYPRE_BoomerAMGSetAggTruncFactor)
+   // V contiguous row blocks on one GPU = the reference at np = V (its CPU defaults, amg.c:141-146 HMIS and :182-189 hybrid l1
+   // Gauss-Seidel, are rank-block algorithms): the hybrid Gauss-Seidel sweeps (3/4/6/8/13/14) are Gauss-Seidel inside a block and
+   // Jacobi across blocks with hypre's option-4 l1 divisor, HMIS is a Ruge first pass per block + PMIS on what it leaves; coarse
+   // levels inherit the blocks through their C points.  1 = one block (the sequential algorithms), 0 = chosen by the setup from
+   // the operator's size and bandwidth (amg_auto_blocks), V > 1 = hypre's even split into V blocks unless block_part names the
+   // V + 1 row starts.
+   int                    blocks = 1;
+   std::vector<long long> block_part;
 };
+int amg_auto_blocks(const DCsr &A); // the setup's choice for blocks = 0
 
 // dependency levels of the local pattern for Gauss-Seidel sweeps (hda_gs.hip)
 struct GsPlan {
@@ -67,10 +76,23 @@ struct GsPlan {
    std::vector<std::pair<int, int>> segments;  // launch groups [first level, last level)
    int                              nlev  = 0;
    bool                             built = false;
+   // row-block form (nblk > 1): Gauss-Seidel inside a block, Jacobi across blocks.  perm lists block after block (block q owns the
+   // positions [part[q], part[q + 1])), inside a block dependency level after level of the block's OWN pattern; one workgroup
+   // sweeps one block
+   int         nblk = 0;
+   DArray<int> blk_part;    // nblk + 1 row starts
+   DArray<int> blk_lvl_ptr; // nblk + 1: block q's levels are blk_lvl[blk_lvl_ptr[q] .. blk_lvl_ptr[q + 1]]
+   DArray<int> blk_lvl;     // first position of every (block, level); one past the end = nrows
+   int         blk_max_levels = 0;
 };
 void build_gs_plan(const DCsr &A, GsPlan &plan);
+void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &plan);
 // one hybrid Gauss-Seidel sweep in place: x_i += dinv_i (b_i - A_i x), rows in sequential order
 void gs_sweep(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, double *x, bool forward);
+// row-block form: xout = sweep(xin); the other blocks' values are read from xin, which the sweep leaves alone (xin != xout).
+// zero_in: the input is the zero vector and is not read (xin may be null or xout)
+void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, const double *xin, double *xout,
+                     bool forward, bool zero_in);
 
 // block-Jacobi ILU(0) of a rank's diagonal block (hda_ilu.hip)
 class Ilu {
@@ -118,6 +140,7 @@ struct AmgLevel {
    double         cheb_coef[5] = {0, 0, 0, 0, 0}, cheb_max_eig = 0.0, cheb_min_eig = 0.0;
    DArray<double> ilu_r, ilu_c;
    DArray<int>    cf;
+   std::vector<int> blk_part; // row blocks of this level (AmgParams::blocks): V + 1 row starts; empty = one block
    DArray<double> dinv_down, dinv_up; // relax_weight / l1 (or / a_ii), per cycle direction
    DArray<double> f, u, u2, t;
    // row-partitioned runs: ghost refresh plans for the inputs of A_l, P_l, R_l and the
@@ -183,6 +206,8 @@ class Amg {
    // algorithmic HBM bytes of one V-cycle (SURVEY 8(d) formulas on the built hierarchy)
    double        vcycle_bytes(bool format = false) const; // format: bytes the kernels read (coded operators), else the CSR figure
    AmgParams     prm;
+   int           blocks_used = 1;      // row blocks the setup worked with (AmgParams::blocks resolved)
+   const std::vector<int> &level_blocks(int l) const { return levels[(size_t)l].blk_part; }
    double        setup_times[8] = {0}; // strength, coarsen, interp, rap, misc (diagnostic)
 
  private:
@@ -314,6 +339,9 @@ void amg_strength(const DCsr &A, double theta, double max_row_sum, unsigned char
 // hypre_BoomerAMGCoarsenPMIS: cf[i] = 1 C, -1 F, -3 special F. row_offset = global id of row 0.
 void amg_pmis(const DCsr &A, const unsigned char *smask, uint64_t seed, int level,
               long long row_offset, int *cf);
+// hypre_BoomerAMGCoarsenHMIS (coarsen type 10) on the row blocks part (V + 1 row starts; empty = one block): Ruge first pass per
+// block, interior C points kept, PMIS from there
+void amg_hmis(const DCsr &A, const unsigned char *smask, const std::vector<int> &part, uint64_t seed, int level, int *cf);
 // hypre_BoomerAMGBuildExtPIInterp (interp_type 6 / 17) or hypre_BoomerAMGBuildDirInterp with separation of weights (3),
 // then InterpTruncation: P (nrows x nc), rows column-sorted.
 void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax, // trailing dof: as amg_strength

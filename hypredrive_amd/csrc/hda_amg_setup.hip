@@ -303,24 +303,36 @@ __device__ inline void bk_remove(RsBuckets &b, int i)
    else b.tail[key] = b.prev[i];
    b.prev[i] = b.next[i] = -1;
 }
-// S = strong entries of A (CSR, rp/cj), T = its transpose (tp/tj, ascending); work arrays sized n+1 / nb
-__global__ void k_rs_first_pass(int n, const int *__restrict__ rp, const int *__restrict__ cj, const int *__restrict__ tp,
-                                const int *__restrict__ tj, int nb, int *head, int *tail, int *prev, int *next, int *key, int *meas, int *cf)
+// S = strong entries of A (CSR, rp/cj), T = its transpose (tp/tj, ascending).  One wavefront per row block (lane 0 works; the
+// pass is sequential by definition), all blocks at once: block q = rows [part[q], part[q + 1]), connections that leave the block
+// ignored (a rank's S_diag), measures = in-block dependants.  Work arrays: prev/next/key/meas indexed by row; block q's bucket
+// heads and tails at 2 * part[q] + 2 * q, 2 * rows + 2 of them (a measure never exceeds twice the in-block dependants: each
+// dependant counts once as such and once more when it turns F).
+__global__ __launch_bounds__(64) void k_rs_first_pass(int nblk, const int *__restrict__ part, const int *__restrict__ rp,
+                                                      const int *__restrict__ cj, const int *__restrict__ tp, const int *__restrict__ tj,
+                                                      int *head_all, int *tail_all, int *prev, int *next, int *key, int *meas, int *cf)
 {
-   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+   if (threadIdx.x != 0) return;
+   const int q = blockIdx.x;
+   if (q >= nblk) return;
+   const int lo = part[q], hi = part[q + 1], nbk = 2 * (hi - lo) + 2;
+   int      *head = head_all + 2 * (size_t)lo + 2 * (size_t)q, *tail = tail_all + 2 * (size_t)lo + 2 * (size_t)q;
    RsBuckets B{head, tail, prev, next, key, 0};
-   for (int q = 0; q < nb; q++) head[q] = tail[q] = -1;
-   for (int i = 0; i < n; i++)
+   auto      in = [&](int j) { return j >= lo && j < hi; };
+   for (int t = 0; t < nbk; t++) head[t] = tail[t] = -1;
+   for (int i = lo; i < hi; i++)
    {
-      meas[i] = tp[i + 1] - tp[i];
+      int nt = 0;
+      for (int k = tp[i]; k < tp[i + 1]; k++) nt += in(tj[k]);
+      meas[i] = nt;
       prev[i] = next[i] = -1;
       key[i]  = 0;
-      cf[i]   = (rp[i + 1] == rp[i]) ? -3 : 0; // no strong dependence: special F, never interpolated
+      cf[i]   = (rp[i + 1] == rp[i]) ? -3 : 0; // no strong dependence at all: special F, never interpolated
       if (cf[i] == -3) meas[i] = 0;
    }
    // ascending-index insertion; measure-0 points become F and the points they depend on gain
    // weight (re-listed at the tail when already listed)
-   for (int j = 0; j < n; j++)
+   for (int j = lo; j < hi; j++)
    {
       if (cf[j] == -3) continue;
       if (meas[j] > 0) { bk_enter(B, j, meas[j]); continue; }
@@ -328,7 +340,7 @@ __global__ void k_rs_first_pass(int n, const int *__restrict__ rp, const int *__
       for (int k = rp[j]; k < rp[j + 1]; k++)
       {
          const int m = cj[k];
-         if (cf[m] == -3) continue;
+         if (!in(m) || cf[m] == -3) continue;
          if (m < j)
          {
             if (cf[m] != 0) { meas[m]++; continue; }
@@ -350,13 +362,13 @@ __global__ void k_rs_first_pass(int n, const int *__restrict__ rp, const int *__
       for (int k = tp[i]; k < tp[i + 1]; k++)
       { // everything that strongly depends on i becomes F
          const int j = tj[k];
-         if (cf[j] != 0) continue;
+         if (!in(j) || cf[j] != 0) continue;
          cf[j] = -1;
          bk_remove(B, j);
          for (int kk = rp[j]; kk < rp[j + 1]; kk++)
          {
             const int m = cj[kk];
-            if (cf[m] == 0)
+            if (in(m) && cf[m] == 0)
             {
                bk_remove(B, m);
                meas[m]++;
@@ -367,7 +379,7 @@ __global__ void k_rs_first_pass(int n, const int *__restrict__ rp, const int *__
       for (int k = rp[i]; k < rp[i + 1]; k++)
       { // points i depends on lose one potential dependant
          const int j = cj[k];
-         if (cf[j] != 0) continue;
+         if (!in(j) || cf[j] != 0) continue;
          bk_remove(B, j);
          meas[j]--;
          if (meas[j] > 0) bk_enter(B, j, meas[j]);
@@ -377,7 +389,7 @@ __global__ void k_rs_first_pass(int n, const int *__restrict__ rp, const int *__
             for (int kk = rp[j]; kk < rp[j + 1]; kk++)
             {
                const int m = cj[kk];
-               if (cf[m] == 0)
+               if (in(m) && cf[m] == 0)
                {
                   bk_remove(B, m);
                   meas[m]++;
@@ -387,6 +399,34 @@ __global__ void k_rs_first_pass(int n, const int *__restrict__ rp, const int *__
          }
       }
    }
+}
+// after the first pass: only the C points of interior rows (no strong connection leaving the block) stay decided
+__global__ __launch_bounds__(256) void k_hmis_keep(int n, int nblk, const int *__restrict__ part, const int *__restrict__ rp,
+                                                   const int *__restrict__ cj, const unsigned char *__restrict__ sm, int *__restrict__ cf)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n || cf[i] == -3) return;
+   int a = 0, b = nblk;
+   while (b - a > 1)
+   {
+      const int m = (a + b) >> 1;
+      if (part[m] <= i) a = m;
+      else b = m;
+   }
+   const int lo = part[a], hi = part[a + 1];
+   bool      boundary = false;
+   for (int k = rp[i]; k < rp[i + 1] && !boundary; k++) boundary = sm[k] && (cj[k] < lo || cj[k] >= hi);
+   if (boundary || cf[i] != 1) cf[i] = 0;
+}
+// PMIS started from a given first independent set: measures as k_pmis_init, special F and C points kept
+__global__ __launch_bounds__(256) void k_pmis_init_from(int n, const int *__restrict__ indeg, unsigned long long seed, int level,
+                                                        double *__restrict__ meas, int *__restrict__ cf)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   const int nt = indeg[i];
+   meas[i]      = (double)nt + pmis_rand(seed, level, i);
+   if (cf[i] == 0 && nt == 0) cf[i] = -1; // measure < 1: nobody depends on it
 }
 __global__ __launch_bounds__(256) void k_strong_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj,
                                                      const unsigned char *__restrict__ sm, const int *__restrict__ srp, int *__restrict__ scj,
@@ -398,20 +438,29 @@ __global__ __launch_bounds__(256) void k_strong_fill(int n, const int *__restric
    for (int k = rp[i]; k < rp[i + 1]; k++)
       if (sm[k]) { scj[d] = cj[k]; sv[d] = 1.0; d++; }
 }
-// one device thread: about 8.5 us per row of a hierarchy's setup (58^3: 1.7 s, measured round 3), so 2.5 M rows -- a 128^3 grid, where a
-// run with the reference's CPU defaults is still a sensible parity check -- cost about 20 s.  HDA_HMIS_MAX_ROWS moves the limit.
+// one device thread per block: about 8.5 us per row (58^3 in one block: 1.7 s, measured round 3), so a block of 2.5 M rows -- a
+// 128^3 grid, where a run with the reference's CPU defaults is still a sensible parity check -- costs about 20 s.
+// HDA_HMIS_MAX_ROWS moves the limit; more blocks (AmgParams::blocks) shorten the pass in proportion.
 static int rs_max_rows()
 {
    static const int v = getenv("HDA_HMIS_MAX_ROWS") ? atoi(getenv("HDA_HMIS_MAX_ROWS")) : 2500000;
    return v;
 }
 
-void amg_rs_first_pass(const DCsr &A, const unsigned char *smask, const int *ns, int *cf)
+static void hmis_core(const DCsr &A, const unsigned char *smask, const int *ns, const std::vector<int> &part_in, uint64_t seed, int level,
+                      int *cf)
 {
    const int n = A.nrows;
    if (!n) return;
-   HDA_REQUIRE(n <= rs_max_rows(), "HMIS / Ruge first pass runs as one device thread (parity with the reference's CPU defaults, about 8.5 us "
-                                   "per row); use PMIS (coarsening type pmis) above 2500000 rows, or raise HDA_HMIS_MAX_ROWS and wait");
+   std::vector<int> part = part_in;
+   if (part.size() < 2) part = {0, n};
+   const int nblk = (int)part.size() - 1;
+   HDA_REQUIRE(part.front() == 0 && part.back() == n, "row blocks must cover the rows of the operator");
+   int longest = 0;
+   for (int q = 0; q < nblk; q++) longest = std::max(longest, part[(size_t)q + 1] - part[(size_t)q]);
+   HDA_REQUIRE(longest <= rs_max_rows(), "HMIS: the Ruge first pass of a row block runs as one device thread (parity with the reference's CPU "
+                                         "defaults, about 8.5 us per row); use more row blocks (HDA_BLOCKS), PMIS (coarsening type pmis), or raise "
+                                         "HDA_HMIS_MAX_ROWS and wait");
    DCsr S, T;
    S.nrows = n;
    S.ncols = A.ncols;
@@ -423,13 +472,45 @@ void amg_rs_first_pass(const DCsr &A, const unsigned char *smask, const int *ns,
    S.val.alloc((size_t)std::max(S.nnz, 1));
    k_strong_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, S.rowptr.data(), S.col.data(), S.val.data());
    transpose(S, T);
-   // a measure never exceeds the number of points that can still come to depend on a point
-   // plus the increments it receives: both bounded by its degree in S u S^T
-   const int   nb = n + 2;
-   DArray<int> head((size_t)nb), tail((size_t)nb), prev((size_t)n + 1), next((size_t)n + 1), key((size_t)n + 1), meas((size_t)n + 1);
-   k_rs_first_pass<<<1, 1, 0, STREAM>>>(n, S.rowptr.data(), S.col.data(), T.rowptr.data(), T.col.data(), nb, head.data(), tail.data(), prev.data(),
-                                        next.data(), key.data(), meas.data(), cf);
-   Context::get().sync();
+   DArray<int> dpart;
+   dpart.upload(part.data(), part.size());
+   {
+      const size_t nbk = 2 * (size_t)n + 2 * (size_t)nblk;
+      DArray<int>  head(nbk), tail(nbk), prev((size_t)n + 1), next((size_t)n + 1), key((size_t)n + 1), meas((size_t)n + 1);
+      k_rs_first_pass<<<nblk, 64, 0, STREAM>>>(nblk, dpart.data(), S.rowptr.data(), S.col.data(), T.rowptr.data(), T.col.data(), head.data(),
+                                              tail.data(), prev.data(), next.data(), key.data(), meas.data(), cf);
+      Context::get().sync();
+   }
+   // hypre_BoomerAMGCoarsenPMIS with CF_init 1: interior C points are the first independent set, everything else is decided again
+   const int g = ceil_div(n, 256);
+   k_hmis_keep<<<g, 256, 0, STREAM>>>(n, nblk, dpart.data(), A.rowptr.data(), A.col.data(), smask, cf);
+   DArray<int>           indeg((size_t)n), counter(1);
+   DArray<double>        meas((size_t)n);
+   DArray<unsigned char> notmax((size_t)n);
+   indeg.zero();
+   notmax.zero();
+   if (A.nnz) k_indeg<<<std::min(ceil_div(A.nnz, 256), 1 << 16), 256, 0, STREAM>>>(A.nnz, A.col.data(), smask, indeg.data());
+   k_pmis_init_from<<<g, 256, 0, STREAM>>>(n, indeg.data(), seed, level, meas.data(), cf);
+   counter.zero();
+   k_pmis_setF<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data(), 0); // dependants of the kept C points
+   int left = 0, rounds = 0;
+   counter.download(&left, 1);
+   while (left > 0)
+   {
+      counter.zero();
+      k_pmis_mark<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, meas.data(), notmax.data(), 0);
+      k_pmis_setC<<<g, 256, 0, STREAM>>>(n, cf, notmax.data(), 0);
+      k_pmis_setF<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data(), 0);
+      counter.download(&left, 1);
+      HDA_REQUIRE(++rounds < 10000, "HMIS: the trailing PMIS did not terminate");
+   }
+}
+
+void amg_hmis(const DCsr &A, const unsigned char *smask, const std::vector<int> &part, uint64_t seed, int level, int *cf)
+{
+   DArray<int> ns((size_t)A.nrows + 1);
+   if (A.nrows) k_count_strong<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), smask, ns.data());
+   hmis_core(A, smask, ns.data(), part, seed, level, cf);
 }
 
 // ------------------------------------------------------------ interpolation
@@ -2206,26 +2287,66 @@ static bool is_l1_gs_type(int t) { return t == 8 || t == 13 || t == 14; }
 // divisor of the sweep: l1 row sums (18), hypre's "option 4" l1 (13/14/8: a_ii plus half the
 // off-rank row sum) or the plain diagonal (0/7/3/4/6).  Extracting the diagonal is option 4
 // with the ghost part ignored, which is what columns < nrows give.
-static void build_dinv(const DCsr &A, int relax_type, double weight, DArray<double> &dinv)
+static void build_dinv(const DCsr &A, int relax_type, double weight, DArray<double> &dinv, const int *d_part = nullptr, int nblk = 0)
 {
    DArray<double> d((size_t)std::max(A.nrows, 1));
    dinv.alloc((size_t)std::max(A.nrows, 1));
    if (relax_type == 18) l1_row_norms(A, 1, d.data());
-   else if (is_l1_gs_type(relax_type)) l1_row_norms(A, 4, d.data());
+   else if (is_l1_gs_type(relax_type)) l1_row_norms(A, 4, d.data(), d_part, nblk); // entries that leave the row's block count as off-rank
    else extract_diag(A, d.data());
    make_dinv(A.nrows, d.data(), weight, dinv.data());
+}
+
+// blocks = 0: the sequential algorithms (one block) while they are affordable, beyond that blocks of at least four times the
+// operator's bandwidth -- on a grid in lexicographic order four planes, thick enough for most rows to have all their neighbours
+// inside the block, which is what keeps the hybrid sweep and HMIS within an iteration of their one-block forms
+__global__ __launch_bounds__(256) void k_bandwidth(int n, const int *__restrict__ rp, const int *__restrict__ cj, int *bw)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   int       m = 0;
+   if (i < n)
+      for (int k = rp[i]; k < rp[i + 1]; k++)
+         if (cj[k] < n) m = max(m, abs(cj[k] - i));
+   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+   if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(bw, m);
+}
+int amg_auto_blocks(const DCsr &A)
+{
+   static const long long min_rows  = getenv("HDA_BLOCKS_MIN_ROWS") ? atoll(getenv("HDA_BLOCKS_MIN_ROWS")) : 500000;
+   static const long long min_block = getenv("HDA_BLOCK_ROWS") ? atoll(getenv("HDA_BLOCK_ROWS")) : 32768;
+   const int n = A.nrows;
+   if (n <= min_rows) return 1;
+   DArray<int> bw(1);
+   bw.zero();
+   k_bandwidth<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), bw.data());
+   int h = 0;
+   bw.download(&h, 1);
+   const long long m = std::max(4LL * h, min_block);
+   return (int)std::max(1LL, std::min(1024LL, (long long)n / m));
 }
 
 void Amg::build_smoother_data(int l)
 {
    const DCsr &Al = level_A(l);
    AmgLevel   &lv = levels[(size_t)l];
-   build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down);
-   if (prm.relax_up == prm.relax_down) lv.dinv_up.copy_from(lv.dinv_down); // same divisors: a copy, not a second pass over A
-   else build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up);
    const bool last = (l == num_levels() - 1);
    const bool gs   = is_gs_type(prm.relax_down) || is_gs_type(prm.relax_up) || (last && is_gs_type(prm.relax_coarse));
-   if (gs && !lv.gs.built) build_gs_plan(Al, lv.gs);
+   const int  nblk = (int)lv.blk_part.size() - 1; // row blocks of this level (> 1: the hybrid sweeps are block sweeps)
+   HDA_REQUIRE(nblk <= 1 || !dist, "row blocks (AmgParams::blocks) are a one-rank feature: across ranks the rank blocks are the blocks");
+   if (gs && nblk > 1)
+   {
+      if (!lv.gs.built) build_gs_plan_blocks(Al, lv.blk_part, lv.gs);
+      build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down, lv.gs.blk_part.data(), nblk);
+      if (prm.relax_up == prm.relax_down) lv.dinv_up.copy_from(lv.dinv_down);
+      else build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up, lv.gs.blk_part.data(), nblk);
+   }
+   else
+   {
+      build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down);
+      if (prm.relax_up == prm.relax_down) lv.dinv_up.copy_from(lv.dinv_down); // same divisors: a copy, not a second pass over A
+      else build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up);
+      if (gs && !lv.gs.built) build_gs_plan(Al, lv.gs);
+   }
    if (prm.relax_down == 16 || prm.relax_up == 16 || (last && prm.relax_coarse == 16)) build_cheby(l);
    // complex smoother (amg.c:899-921): ILU(0) of the rank's diagonal block on the first smooth_num_levels
    // levels (counted from the finest level of the whole hierarchy), never on the coarsest
@@ -2288,6 +2409,27 @@ void Amg::build_hierarchy(const DCsr &A)
    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double, std::milli>(b - a).count();
    };
+   // row blocks of level 0 (AmgParams::blocks): the caller's starts, hypre's even split, or the setup's own choice
+   {
+      const bool uses = prm.coarsen_type == 10 || is_gs_type(prm.relax_down) || is_gs_type(prm.relax_up) || is_gs_type(prm.relax_coarse);
+      int        V    = prm.blocks;
+      if (V == 0) V = uses ? amg_auto_blocks(A) : 1;
+      if (!prm.block_part.empty())
+      {
+         HDA_REQUIRE((int)prm.block_part.size() == V + 1 && prm.block_part.front() == 0 && prm.block_part.back() == A.nrows,
+                     "block_part must hold blocks + 1 ascending row starts from 0 to the number of rows");
+         levels[0].blk_part.assign(prm.block_part.begin(), prm.block_part.end());
+      }
+      else if (V > 1)
+      {
+         levels[0].blk_part.resize((size_t)V + 1);
+         for (int q = 0; q <= V; q++) levels[0].blk_part[(size_t)q] = (int)(((long long)q * A.nrows) / V); // hypre_GeneratePartitioning
+      }
+      if (V > 1 && (verbose || prm.print_level > 0))
+         fprintf(stderr, "[hda] BoomerAMG setup: %d row blocks of about %d rows (hybrid Gauss-Seidel / HMIS as the reference computes them on %d ranks)\n",
+                 V, A.nrows / V, V);
+      blocks_used = V > 1 ? V : 1;
+   }
    // function of every unknown on the current level (systems AMG): the user's dof_func or i mod nf
    DArray<int> dof_cur;
    if (prm.num_functions > 1)
@@ -2313,7 +2455,7 @@ void Amg::build_hierarchy(const DCsr &A)
       strength_ns(Al, prm.strong_th, prm.max_row_sum, sm.data(), ns.data(), dof);
       HDA_TRACE("level %d: pmis", lvl);
       auto t1 = tick();
-      if (prm.coarsen_type == 10) amg_rs_first_pass(Al, sm.data(), ns.data(), cf.data());
+      if (prm.coarsen_type == 10) hmis_core(Al, sm.data(), ns.data(), levels[lvl].blk_part, prm.seed, lvl + level0, cf.data());
       else pmis_core(Al, sm.data(), ns.data(), prm.seed, lvl + level0, 0, cf.data());
       const bool aggressive = lvl + level0 < prm.agg_num_levels;
       if (aggressive) amg_coarsen_second_pass(Al, sm.data(), prm.agg_num_paths, prm.seed, lvl + level0, cf.data());
@@ -2342,9 +2484,20 @@ void Amg::build_hierarchy(const DCsr &A)
       }
       HDA_TRACE("level %d: transpose", lvl);
       transpose(L.P, L.R);
+      std::vector<int> next_part;
+      if (L.blk_part.size() > 1)
+      { // coarse ids ascend with the fine ids of the C points: a block's coarse rows are a contiguous range (a rank's coarse rows)
+         DArray<int> m((size_t)n + 1), cidx((size_t)n + 1);
+         k_cmark<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, L.cf.data(), m.data());
+         exclusive_scan(n, m.data(), cidx.data(), nullptr);
+         const std::vector<int> hc = cidx.to_host();
+         next_part.resize(L.blk_part.size());
+         for (size_t q = 0; q < L.blk_part.size(); q++) next_part[q] = hc[(size_t)L.blk_part[q]];
+      }
       HDA_TRACE("level %d: rap", lvl);
       auto t4 = tick();
       levels.emplace_back();
+      levels[lvl + 1].blk_part = std::move(next_part);
       amg_rap(Al, levels[lvl].P, levels[lvl].R, levels[lvl + 1].A);
       auto t5 = tick();
       if (verbose)
@@ -2865,9 +3018,28 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
    }
    if (is_gs_type(type))
    { // in place; ghosts frozen for the sweep
-      if (zero_guess) fill((int)levels[(size_t)l].ext, 0.0, cur);
-      else if (!fresh) halo_exchange(level_hA(l), cur);
       const GsPlan &g = levels[(size_t)l].gs;
+      if (zero_guess) { if (g.nblk == 0) fill((int)levels[(size_t)l].ext, 0.0, cur); } // (a block sweep zeroes its own rows)
+      else if (!fresh) halo_exchange(level_hA(l), cur);
+      if (g.nblk > 0)
+      { // row blocks: the sweep reads the other blocks' old values from its input and writes its output elsewhere; from a zero
+        // guess nothing is read and the result can land in cur itself
+         if (type == 3 || type == 13 || type == 4 || type == 14)
+         {
+            const bool fwd = (type == 3 || type == 13);
+            if (zero_guess) gs_sweep_blocks(A, g, dinv, b, nullptr, cur, fwd, true);
+            else { gs_sweep_blocks(A, g, dinv, b, cur, alt, fwd, false); std::swap(cur, alt); }
+         }
+         else
+         { // symmetric: forward, then backward
+            if (zero_guess) { gs_sweep_blocks(A, g, dinv, b, nullptr, cur, true, true); }
+            else { gs_sweep_blocks(A, g, dinv, b, cur, alt, true, false); std::swap(cur, alt); }
+            gs_sweep_blocks(A, g, dinv, b, cur, alt, false, false);
+            std::swap(cur, alt);
+         }
+         if (dot_slot >= 0) dot(A.nrows, b, cur, dot_slot);
+         return;
+      }
       if (type == 3 || type == 13) gs_sweep(A, g, dinv, b, cur, true);
       else if (type == 4 || type == 14) gs_sweep(A, g, dinv, b, cur, false);
       else
@@ -2928,8 +3100,9 @@ bool Amg::first_sweep_fusable() const
 // (the buffer choice of cycle() for zero_guess = true)
 double *Amg::first_sweep_dest(double *x)
 {
-   const int swaps0 = levels[0].ilu ? 0 : (is_jacobi_type(prm.relax_down) ? (prm.sweeps_down - (prm.sweeps_down > 0 ? 1 : 0)) : 0) +
-                                             (is_jacobi_type(prm.relax_up) ? prm.sweeps_up : 0);
+   auto oop = [&](int t) { return is_jacobi_type(t) || (levels[0].gs.nblk > 0 && (t == 3 || t == 4 || t == 13 || t == 14)); }; // as in cycle()
+   const int swaps0 = levels[0].ilu ? 0 : (oop(prm.relax_down) ? (prm.sweeps_down - (prm.sweeps_down > 0 ? 1 : 0)) : 0) +
+                                             (oop(prm.relax_up) ? prm.sweeps_up : 0);
    return (swaps0 & 1) ? levels[0].u2.data() : x;
 }
 void Amg::apply_offering(const double *b, double *x, int dot_slot)
@@ -2971,9 +3144,11 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool 
    }
    std::vector<double *> sol((size_t)L, nullptr);
    // level-0 buffer choice so the last out-of-place sweep lands in x
+   // (a one-directional hybrid Gauss-Seidel sweep over row blocks is out of place like a Jacobi sweep, and in place from a zero guess)
+   auto oop = [&](int t) { return is_jacobi_type(t) || (levels[0].gs.nblk > 0 && (t == 3 || t == 4 || t == 13 || t == 14)); };
    const int swaps0 = levels[0].ilu ? 0 : // the complex smoother works in place
-                      (is_jacobi_type(prm.relax_down) ? (prm.sweeps_down - (zero_guess && prm.sweeps_down > 0 ? 1 : 0)) : 0) +
-                      (is_jacobi_type(prm.relax_up) ? prm.sweeps_up : 0); // out-of-place sweeps on level 0
+                      (oop(prm.relax_down) ? (prm.sweeps_down - (zero_guess && prm.sweeps_down > 0 ? 1 : 0)) : 0) +
+                      (oop(prm.relax_up) ? prm.sweeps_up : 0); // out-of-place sweeps on level 0
    double   *cur, *alt;
    if (zero_guess && (swaps0 & 1)) { cur = levels[0].u2.data(); alt = x; }
    else { cur = x; alt = levels[0].u2.data(); }

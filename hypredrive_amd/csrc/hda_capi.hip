@@ -89,6 +89,8 @@ extern "C" void hda_amg_default_params(hda_amg_params *p)
    p->ilu_tri_solve = d.ilu.tri_solve; p->ilu_lower_it = d.ilu.lower_it; p->ilu_upper_it = d.ilu.upper_it;
    p->agg_num_levels = d.agg_num_levels; p->agg_num_paths = d.agg_num_paths; p->agg_interp_type = d.agg_interp_type;
    p->agg_pmax = d.agg_pmax; p->agg_trunc_factor = d.agg_trunc_factor;
+   p->blocks = d.blocks; p->block_part = nullptr;
+   p->struct_size = (int)sizeof(hda_amg_params);
 }
 extern "C" void hda_krylov_default_params(hda_krylov_params *p, int gmres)
 {
@@ -99,6 +101,9 @@ static AmgParams to_params(const hda_amg_params *p)
 {
    AmgParams a;
    if (!p) return a;
+   // a caller compiled against an older, shorter struct passes garbage (or another field) where the size sits
+   HDA_REQUIRE(p->struct_size == (int)sizeof(hda_amg_params),
+               "hda_amg_params: struct_size does not match this library (start from hda_amg_default_params; rebuild against include/hypredrv_amd.h)");
    a.coarsen_type = p->coarsen_type; a.interp_type = p->interp_type; a.pmax = p->pmax;
    a.trunc_factor = p->trunc_factor; a.strong_th = p->strong_th; a.max_row_sum = p->max_row_sum;
    a.max_coarse_size = p->max_coarse_size; a.min_coarse_size = p->min_coarse_size; a.max_levels = p->max_levels;
@@ -112,7 +117,17 @@ static AmgParams to_params(const hda_amg_params *p)
    a.ilu.tri_solve = p->ilu_tri_solve; a.ilu.lower_it = p->ilu_lower_it; a.ilu.upper_it = p->ilu_upper_it;
    a.agg_num_levels = p->agg_num_levels; a.agg_num_paths = p->agg_num_paths; a.agg_interp_type = p->agg_interp_type;
    a.agg_pmax = p->agg_pmax; a.agg_trunc_factor = p->agg_trunc_factor;
+   a.blocks = p->blocks;
+   if (p->block_part && p->blocks > 1) a.block_part.assign(p->block_part, p->block_part + p->blocks + 1);
    return a;
+}
+static std::vector<int> to_part(int nblk, const int64_t *part, int nrows)
+{
+   HDA_REQUIRE(nblk >= 1 && part, "row blocks: nblk + 1 row starts expected");
+   std::vector<int> v((size_t)nblk + 1);
+   for (int q = 0; q <= nblk; q++) v[(size_t)q] = (int)part[q];
+   HDA_REQUIRE(v.front() == 0 && v.back() == nrows, "row blocks must cover the rows of the operator");
+   return v;
 }
 static KrylovParams to_kparams(const hda_krylov_params *p)
 {
@@ -260,6 +275,67 @@ extern "C" int hda_relax(hda_csr_t A, int relax_type, double weight, int sweeps,
    }
    HDA_HIP(hipMemcpyAsync(x, cur, sizeof(double) * (size_t)m.nrows, hipMemcpyDeviceToHost, Context::get().stream));
    Context::get().sync();
+   HDA_CATCH
+}
+
+extern "C" int hda_relax_blocks(hda_csr_t A, int relax_type, double weight, int sweeps, int nblk, const int64_t *part, const double *b, double *x)
+{
+   HDA_TRY
+   const DCsr &m    = A->get();
+   const bool  gs_t = relax_type == 3 || relax_type == 4 || relax_type == 6 || relax_type == 8 || relax_type == 13 || relax_type == 14;
+   HDA_REQUIRE(gs_t, "row-block relax: hybrid Gauss-Seidel (3/4/6/8/13/14)");
+   const std::vector<int> hp = to_part(nblk, part, m.nrows);
+   GsPlan plan;
+   build_gs_plan_blocks(m, hp, plan);
+   DArray<double> d((size_t)std::max(m.nrows, 1)), dinv((size_t)std::max(m.nrows, 1)), db, x0, x1;
+   if (relax_type == 13 || relax_type == 14 || relax_type == 8) l1_row_norms(m, 4, d.data(), plan.blk_part.data(), nblk);
+   else extract_diag(m, d.data());
+   make_dinv(m.nrows, d.data(), weight, dinv.data());
+   db.upload(b, (size_t)m.nrows);
+   x0.upload(x, (size_t)std::max(m.ncols, m.nrows));
+   x1.alloc((size_t)std::max(m.ncols, m.nrows));
+   double *cur = x0.data(), *alt = x1.data();
+   for (int s = 0; s < sweeps; s++)
+   {
+      if (relax_type == 3 || relax_type == 13 || relax_type == 6 || relax_type == 8)
+      {
+         gs_sweep_blocks(m, plan, dinv.data(), db.data(), cur, alt, true, false);
+         std::swap(cur, alt);
+      }
+      if (relax_type == 4 || relax_type == 14 || relax_type == 6 || relax_type == 8)
+      {
+         gs_sweep_blocks(m, plan, dinv.data(), db.data(), cur, alt, false, false);
+         std::swap(cur, alt);
+      }
+   }
+   HDA_HIP(hipMemcpyAsync(x, cur, sizeof(double) * (size_t)m.nrows, hipMemcpyDeviceToHost, Context::get().stream));
+   Context::get().sync();
+   HDA_CATCH
+}
+
+extern "C" int hda_l1_norms_blocks(hda_csr_t A, int option, int nblk, const int64_t *part, double *l1)
+{
+   HDA_TRY
+   const DCsr            &m  = A->get();
+   const std::vector<int> hp = to_part(nblk, part, m.nrows);
+   DArray<int>            dp;
+   dp.upload(hp.data(), hp.size());
+   DArray<double> d((size_t)std::max(m.nrows, 1));
+   l1_row_norms(m, option, d.data(), dp.data(), nblk);
+   if (m.nrows) d.download(l1, (size_t)m.nrows);
+   HDA_CATCH
+}
+
+extern "C" int hda_hmis_blocks(hda_csr_t A, const unsigned char *smask, int nblk, const int64_t *part, uint64_t seed, int level, int *cf)
+{
+   HDA_TRY
+   const DCsr            &m  = A->get();
+   const std::vector<int> hp = to_part(nblk, part, m.nrows);
+   DArray<unsigned char>  sm((size_t)std::max(m.nnz, 1));
+   if (m.nnz) sm.upload(smask, (size_t)m.nnz);
+   DArray<int> dcf((size_t)std::max(m.nrows, 1));
+   amg_hmis(m, sm.data(), hp, seed, level, dcf.data());
+   if (m.nrows) dcf.download(cf, (size_t)m.nrows);
    HDA_CATCH
 }
 
@@ -585,6 +661,16 @@ extern "C" int hda_amg_level_cf(hda_amg_t h, int level, int *cf)
    HDA_REQUIRE(level >= 0 && level < h->amg->num_levels() - 1, "level has no C/F splitting");
    auto &L = h->amg->level(level);
    L.cf.download(cf, L.cf.size());
+   HDA_CATCH
+}
+extern "C" int hda_amg_blocks(hda_amg_t h) { return (h && h->amg) ? h->amg->blocks_used : 0; }
+extern "C" int hda_amg_level_blocks(hda_amg_t h, int level, int64_t *part)
+{
+   HDA_TRY
+   HDA_REQUIRE(h && h->amg && level >= 0 && level < h->amg->num_levels(), "no such level");
+   const std::vector<int> &bp = h->amg->level_blocks(level);
+   if (bp.size() < 2) { part[0] = 0; part[1] = h->amg->level_A(level).nrows; }
+   else for (size_t q = 0; q < bp.size(); q++) part[q] = bp[q];
    HDA_CATCH
 }
 extern "C" int hda_amg_complexities(hda_amg_t h, double *grid, double *op)

@@ -20,9 +20,11 @@ namespace hda {
 
 // distinct neighbours of row i in pattern(A) U pattern(A^T), restricted to owned columns,
 // visited in ascending order; f(j) is called once per neighbour j != i
+// (lo, hi: only neighbours in [lo, hi) count -- the row's own block in the row-block form, [0, n) otherwise)
 template <class F>
 __device__ __forceinline__ void for_each_sym_neighbour(int i, int n, const int *__restrict__ rp, const int *__restrict__ cj,
-                                                       const int *__restrict__ trp, const int *__restrict__ tcj, F f)
+                                                       const int *__restrict__ trp, const int *__restrict__ tcj, F f, int lo = 0,
+                                                       int hi = 0x7fffffff)
 {
    int a = rp[i], ae = rp[i + 1], t = trp[i], te = trp[i + 1];
    while (a < ae || t < te)
@@ -31,33 +33,54 @@ __device__ __forceinline__ void for_each_sym_neighbour(int i, int n, const int *
       const int j  = min(ja, jt);
       if (ja == j) a++;
       if (jt == j) t++;
-      if (j >= n) break; // ghost columns sort last
-      if (j != i) f(j);
+      if (j >= n || j >= hi) break; // ghost columns sort last
+      if (j != i && j >= lo) f(j);
    }
+}
+
+// first row and past-the-end row of the block that holds row i (part: nb + 1 row starts; nullptr = one block)
+__device__ __forceinline__ void gs_block_of(const int *__restrict__ part, int nb, int i, int n, int &lo, int &hi)
+{
+   lo = 0;
+   hi = n;
+   if (!part) return;
+   int a = 0, b = nb;
+   while (b - a > 1)
+   {
+      const int m = (a + b) >> 1;
+      if (part[m] <= i) a = m;
+      else b = m;
+   }
+   lo = part[a];
+   hi = part[a + 1];
 }
 
 __global__ __launch_bounds__(256) void k_gs_indeg(int n, const int *__restrict__ rp, const int *__restrict__ cj,
                                                   const int *__restrict__ trp, const int *__restrict__ tcj, int *__restrict__ indeg,
-                                                  int *__restrict__ perm, int *counter)
+                                                  int *__restrict__ perm, int *counter, const int *__restrict__ part, int nb)
 {
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
-   int d = 0;
-   for_each_sym_neighbour(i, n, rp, cj, trp, tcj, [&](int j) { d += (j < i); });
+   int d = 0, lo, hi;
+   gs_block_of(part, nb, i, n, lo, hi);
+   for_each_sym_neighbour(i, n, rp, cj, trp, tcj, [&](int j) { d += (j < i); }, lo, hi);
    indeg[i] = d;
    if (d == 0) perm[atomicAdd(counter, 1)] = i;
 }
 
 __global__ __launch_bounds__(256) void k_gs_expand(int nf, const int *__restrict__ frontier, int n, const int *__restrict__ rp,
                                                    const int *__restrict__ cj, const int *__restrict__ trp,
-                                                   const int *__restrict__ tcj, int *indeg, int *__restrict__ next, int *counter)
+                                                   const int *__restrict__ tcj, int *indeg, int *__restrict__ next, int *counter,
+                                                   const int *__restrict__ part, int nb)
 {
    const int q = blockIdx.x * 256 + threadIdx.x;
    if (q >= nf) return;
    const int i = frontier[q];
+   int       lo, hi;
+   gs_block_of(part, nb, i, n, lo, hi);
    for_each_sym_neighbour(i, n, rp, cj, trp, tcj, [&](int j) {
       if (j > i && atomicSub(&indeg[j], 1) == 1) next[atomicAdd(counter, 1)] = j;
-   });
+   }, lo, hi);
 }
 
 // ascending row ids inside every level: deterministic launch contents and better locality
@@ -85,20 +108,17 @@ static void gs_row_spans(const DCsr &A, const GsPlan &plan)
    plan.span_gen = A.gen;
 }
 
-void build_gs_plan(const DCsr &A, GsPlan &plan)
+// dependency levels of the symmetrised pattern (restricted to the row blocks of part when given): rows in discovery order in
+// plan.perm, level offsets in plan.lvl_ptr; returns the level of every row (host)
+static std::vector<int> gs_levels(const DCsr &A, GsPlan &plan, const int *d_part, int nb)
 {
    const int n = A.nrows;
-   plan        = GsPlan();
-   plan.built  = true;
-   plan.perm.alloc((size_t)std::max(n, 1));
-   plan.lvl_ptr.assign(1, 0);
-   if (n == 0) return;
    DCsr T;
    transpose(A, T); // rows of T = columns of A; only rows < n are consulted
    DArray<int> indeg((size_t)n), counter(1);
    counter.zero();
    k_gs_indeg<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(),
-                                                   plan.perm.data(), counter.data());
+                                                   plan.perm.data(), counter.data(), d_part, nb);
    int done = 0, nf = 0;
    counter.download(&nf, 1);
    while (nf > 0)
@@ -109,20 +129,31 @@ void build_gs_plan(const DCsr &A, GsPlan &plan)
       if (done >= n) break;
       counter.zero();
       k_gs_expand<<<ceil_div(nf, 256), 256, 0, STREAM>>>(nf, cur, n, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(),
-                                                        indeg.data(), plan.perm.data() + done, counter.data());
+                                                        indeg.data(), plan.perm.data() + done, counter.data(), d_part, nb);
       counter.download(&nf, 1);
    }
    HDA_REQUIRE(done == n, "Gauss-Seidel level scheduling did not reach every row");
    plan.nlev = (int)plan.lvl_ptr.size() - 1;
+   std::vector<int> lvl_of_pos((size_t)n);
+   for (int L = 0; L < plan.nlev; L++)
+      for (int q = plan.lvl_ptr[(size_t)L]; q < plan.lvl_ptr[(size_t)L + 1]; q++) lvl_of_pos[(size_t)q] = L;
+   DArray<int> dpos, lrow((size_t)n);
+   dpos.upload(lvl_of_pos.data(), (size_t)n);
+   k_gs_mark<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), dpos.data(), lrow.data());
+   return lrow.to_host();
+}
+
+void build_gs_plan(const DCsr &A, GsPlan &plan)
+{
+   const int n = A.nrows;
+   plan        = GsPlan();
+   plan.built  = true;
+   plan.perm.alloc((size_t)std::max(n, 1));
+   plan.lvl_ptr.assign(1, 0);
+   if (n == 0) return;
    // level of every row -> stable counting order = ascending rows inside each level
    {
-      std::vector<int> lvl_of_pos((size_t)n);
-      for (int L = 0; L < plan.nlev; L++)
-         for (int q = plan.lvl_ptr[(size_t)L]; q < plan.lvl_ptr[(size_t)L + 1]; q++) lvl_of_pos[(size_t)q] = L;
-      DArray<int> dpos, lrow((size_t)n);
-      dpos.upload(lvl_of_pos.data(), (size_t)n);
-      k_gs_mark<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), dpos.data(), lrow.data());
-      std::vector<int> hl = lrow.to_host(), cursor(plan.lvl_ptr.begin(), plan.lvl_ptr.end() - 1), hp((size_t)n);
+      std::vector<int> hl = gs_levels(A, plan, nullptr, 0), cursor(plan.lvl_ptr.begin(), plan.lvl_ptr.end() - 1), hp((size_t)n);
       for (int i = 0; i < n; i++) hp[(size_t)cursor[(size_t)hl[(size_t)i]]++] = i;
       plan.perm.upload(hp.data(), (size_t)n);
    }
@@ -139,6 +170,53 @@ void build_gs_plan(const DCsr &A, GsPlan &plan)
       L = E;
    }
    plan.d_lvl_ptr.upload(plan.lvl_ptr.data(), plan.lvl_ptr.size());
+   gs_row_spans(A, plan);
+   Context::get().sync();
+}
+
+// Row-block form (hypre's hybrid sweep at np = V on one GPU): the dependency levels of every block's OWN pattern -- connections
+// that leave a block carry the values of the sweep's start, so they order nothing -- and the rows sorted by (block, level, row).
+void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &plan)
+{
+   const int n = A.nrows, nb = (int)part.size() - 1;
+   HDA_REQUIRE(nb >= 1 && part.front() == 0 && part.back() == n, "row blocks must cover the rows of the operator");
+   plan       = GsPlan();
+   plan.built = true;
+   plan.nblk  = nb;
+   plan.perm.alloc((size_t)std::max(n, 1));
+   plan.lvl_ptr.assign(1, 0);
+   plan.blk_part.upload(part.data(), part.size());
+   std::vector<int> bl_ptr((size_t)nb + 1, 0), bl;
+   if (n == 0)
+   {
+      bl.push_back(0);
+      plan.blk_lvl_ptr.upload(bl_ptr.data(), bl_ptr.size());
+      plan.blk_lvl.upload(bl.data(), bl.size());
+      return;
+   }
+   const std::vector<int> hl = gs_levels(A, plan, plan.blk_part.data(), nb);
+   std::vector<int>       hp((size_t)n), cnt;
+   for (int q = 0; q < nb; q++)
+   {
+      const int lo = part[(size_t)q], hi = part[(size_t)q + 1];
+      HDA_REQUIRE(lo <= hi, "row blocks must ascend");
+      int nl = 0;
+      for (int i = lo; i < hi; i++) nl = std::max(nl, hl[(size_t)i] + 1);
+      cnt.assign((size_t)nl + 1, 0);
+      for (int i = lo; i < hi; i++) cnt[(size_t)hl[(size_t)i] + 1]++;
+      for (int L = 0; L < nl; L++)
+      {
+         cnt[(size_t)L + 1] += cnt[(size_t)L];
+         bl.push_back(lo + cnt[(size_t)L]);
+      }
+      for (int i = lo; i < hi; i++) hp[(size_t)(lo + cnt[(size_t)hl[(size_t)i]]++)] = i; // ascending rows inside a level
+      bl_ptr[(size_t)q + 1]  = (int)bl.size();
+      plan.blk_max_levels = std::max(plan.blk_max_levels, nl);
+   }
+   bl.push_back(n);
+   plan.perm.upload(hp.data(), (size_t)n);
+   plan.blk_lvl_ptr.upload(bl_ptr.data(), bl_ptr.size());
+   plan.blk_lvl.upload(bl.data(), bl.size());
    gs_row_spans(A, plan);
    Context::get().sync();
 }
@@ -294,6 +372,138 @@ __global__ __launch_bounds__(1024) void k_gs_levels_pipe(int l0, int l1, int bac
       cur = nxb;
       nxa = nx2;
    }
+}
+
+// Row-block form: workgroup q sweeps block q -- the levels of the block's own pattern one after the other, a barrier between two
+// levels, the same three-stage pipeline as above -- while every other block is swept by its own workgroup at the same time.  A
+// column inside the block is read from xout (the block's rows are copied there first and updated in place), a column outside from
+// xin, which nobody writes during the sweep: the values the other blocks held when the sweep began (hypre's hybrid sweep with the
+// blocks in the role of ranks).  zero_in: the input is the zero vector and is not read.
+template <int LPR, int NPF>
+__global__ __launch_bounds__(1024) void k_gs_blocks(int backward, int zero_in, int lds_levels, const int *__restrict__ part,
+                                                    const int *__restrict__ blk_lvl_ptr, const int *__restrict__ blk_lvl,
+                                                    const int *__restrict__ perm, const int *__restrict__ rbeg, const int *__restrict__ rend,
+                                                    const int *__restrict__ cj, const double *__restrict__ v, const double *__restrict__ dinv,
+                                                    const double *__restrict__ b, const double *xin, double *xout)
+{
+   extern __shared__ int slp_lds[];
+   const int blk = blockIdx.x, lo = part[blk], hi = part[blk + 1];
+   const int L0 = blk_lvl_ptr[blk], nl = blk_lvl_ptr[blk + 1] - L0;
+   const int tid = threadIdx.x, lane = tid & (LPR - 1), q = tid / LPR;
+   constexpr int RP = 1024 / LPR; // rows per pass
+   const int *slp = blk_lvl + L0; // level offsets of this block: in LDS when they fit
+   if (nl + 1 <= lds_levels)
+   {
+      for (int t = tid; t <= nl; t += 1024) slp_lds[t] = blk_lvl[L0 + t];
+      slp = slp_lds;
+   }
+   if (zero_in) { for (int i = lo + tid; i < hi; i += 1024) xout[i] = 0.0; }
+   else { for (int i = lo + tid; i < hi; i += 1024) xout[i] = xin[i]; }
+   __threadfence_block();
+   __syncthreads();
+   struct It { int s, p; }; // level of the block in sweep order, pass inside the level
+   auto level = [&](const It &it) { return backward ? nl - 1 - it.s : it.s; };
+   auto advance = [&](It it) {
+      if (it.s >= nl) return it; // past the end: stays there
+      const int L = level(it);
+      it.p++;
+      if (it.p * RP >= slp[L + 1] - slp[L]) { it.s++; it.p = 0; }
+      return it;
+   };
+   struct RowA { int i, k0, k1; bool has; };
+   struct RowB { int i, k0, k1; bool has; int c[NPF]; double a[NPF]; double d, rhs; };
+   auto stage_a = [&](const It &it) {
+      RowA r;
+      r.has = false; r.i = 0; r.k0 = 0; r.k1 = 0;
+      if (it.s < nl)
+      {
+         const int L = level(it), pos = slp[L] + it.p * RP + q;
+         if (pos < slp[L + 1])
+         {
+            r.has = true;
+            r.i   = perm[pos];
+            r.k0  = rbeg[pos];
+            r.k1  = rend[pos];
+         }
+      }
+      return r;
+   };
+   auto stage_b = [&](const RowA &ra) {
+      RowB r;
+      r.i = ra.i; r.k0 = ra.k0; r.k1 = ra.k1; r.has = ra.has; r.d = 0.0; r.rhs = 0.0;
+#pragma unroll
+      for (int u = 0; u < NPF; u++) { r.c[u] = -1; r.a[u] = 0.0; }
+      if (ra.has)
+      {
+#pragma unroll
+         for (int u = 0; u < NPF; u++)
+         {
+            const int k = ra.k0 + lane + u * LPR;
+            if (k < ra.k1) { r.c[u] = cj[k]; r.a[u] = v[k]; }
+         }
+         r.d   = dinv[ra.i];
+         r.rhs = b[ra.i];
+      }
+      return r;
+   };
+   auto value = [&](int c) { return (c >= lo && c < hi) ? xout[c] : (zero_in ? 0.0 : xin[c]); };
+   It   itC = {0, 0}, itB = advance(itC), itA = advance(itB);
+   RowB cur = stage_b(stage_a(itC));
+   RowA nxa = stage_a(itB);
+   while (itC.s < nl)
+   {
+      const RowA nx2 = stage_a(itA); // two passes ahead
+      const RowB nxb = stage_b(nxa); // one pass ahead
+      if (cur.has)
+      {
+         double xs[NPF];
+#pragma unroll
+         for (int u = 0; u < NPF; u++) xs[u] = (cur.c[u] >= 0) ? value(cur.c[u]) : 0.0;
+         double sum = 0.0;
+#pragma unroll
+         for (int u = 0; u < NPF; u++)
+            if (cur.c[u] >= 0) sum += cur.a[u] * xs[u];
+         for (int k = cur.k0 + lane + NPF * LPR; k < cur.k1; k += LPR) sum += v[k] * value(cj[k]); // rows longer than the prefetch
+#pragma unroll
+         for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+         if (lane == 0) xout[cur.i] += cur.d * (cur.rhs - sum);
+      }
+      const It nextC = itB;
+      if (nextC.s != itC.s)
+      { // the next pass belongs to another level: everything written so far must be visible
+         __threadfence_block();
+         __syncthreads();
+      }
+      itC = nextC;
+      itB = itA;
+      itA = advance(itA);
+      cur = nxb;
+      nxa = nx2;
+   }
+}
+
+template <int LPR, int NPF>
+static void gs_blocks_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
+                        bool zero_in)
+{
+   const int    lds_levels = std::min(p.blk_max_levels + 1, 12 * 1024); // (48 KB of level offsets at most; longer blocks read them from memory)
+   const size_t lds        = sizeof(int) * (size_t)lds_levels;
+   k_gs_blocks<LPR, NPF><<<p.nblk, 1024, lds, STREAM>>>(forward ? 0 : 1, zero_in ? 1 : 0, lds_levels, p.blk_part.data(), p.blk_lvl_ptr.data(),
+                                                       p.blk_lvl.data(), p.perm.data(), p.rbeg.data(), p.rend.data(), A.col.data(), A.val.data(),
+                                                       dinv, b, xin, xout);
+}
+
+void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
+                     bool zero_in)
+{
+   HDA_REQUIRE(plan.built && plan.nblk > 0, "row-block Gauss-Seidel plan missing");
+   HDA_REQUIRE(zero_in || (xin && xin != xout), "row-block Gauss-Seidel sweeps out of place");
+   if (A.nrows == 0) return;
+   if (plan.span_rp != A.rowptr.data() || plan.span_nnz != A.nnz || plan.span_gen != A.gen) gs_row_spans(A, plan);
+   const double a = A.avg_row();
+   if (a <= 10.0) gs_blocks_t<4, 2>(A, plan, dinv, b, xin, xout, forward, zero_in);
+   else if (a <= 40.0) gs_blocks_t<8, 8>(A, plan, dinv, b, xin, xout, forward, zero_in);
+   else gs_blocks_t<16, 8>(A, plan, dinv, b, xin, xout, forward, zero_in);
 }
 
 // LPR lanes per row in the per-level launches, FL in the single-workgroup runs of small levels: there a level is a few

@@ -1161,7 +1161,10 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    HDA_REQUIRE(s->restriction == 0, "only P^T restriction (restriction_type 0) is implemented");
    HDA_REQUIRE(s->relax_order == 0, "only lexicographic relaxation order (relaxation.order 0) is implemented");
    s->ap.num_functions = std::max(s->num_functions, 1);
-   s->amg              = std::make_unique<Amg>(s->ap);
+   // row blocks (the reference's hybrid Gauss-Seidel / HMIS at np = V on one GPU): HDA_BLOCKS = V, 1 = the sequential algorithms,
+   // unset = the setup's own choice (one block up to HDA_BLOCKS_MIN_ROWS rows); across ranks the rank blocks are the blocks
+   s->ap.blocks = (Comm::world().size > 1) ? 1 : (getenv("HDA_BLOCKS") ? std::max(atoi(getenv("HDA_BLOCKS")), 0) : 0);
+   s->amg       = std::make_unique<Amg>(s->ap);
    if (s->ap.num_functions > 1)
    {
       if (s->dof_func_ptr) s->amg->dof_func0.assign(s->dof_func_ptr, s->dof_func_ptr + A->nloc);
@@ -1181,8 +1184,12 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
    else s->amg->setup(A->A);
    hda_register_precond_veclen(s->amg->vec_len0());
    if (s->ap.print_level > 0 && Comm::world().rank == 0)
-      printf("\n BoomerAMG (MI355X): %d levels, grid complexity %.6f, operator complexity %.6f\n\n", s->amg->num_levels(),
+   {
+      printf("\n BoomerAMG (MI355X): %d levels, grid complexity %.6f, operator complexity %.6f\n", s->amg->num_levels(),
              s->amg->grid_complexity(), s->amg->operator_complexity());
+      if (s->amg->blocks_used > 1) printf(" %d row blocks (hybrid Gauss-Seidel / HMIS as on %d ranks)\n", s->amg->blocks_used, s->amg->blocks_used);
+      printf("\n");
+   }
    HY_CATCH
 }
 

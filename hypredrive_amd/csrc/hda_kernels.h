@@ -77,7 +77,8 @@ void csr_to_dense(const DCsr &A, double *dense);
 // ---- utilities
 void exclusive_scan(int n, const int *in, int *out, int *total_out_dev); // out[i] = sum_{j<i} in[j]; out[n] = total
 void require_int32_total(long n, const int *counts, const char *what);  // throws when sum(counts) >= 2^31
-void l1_row_norms(const DCsr &A, int option, double *l1);   // hypre_ParCSRComputeL1Norms opt 1 / 4
+// hypre_ParCSRComputeL1Norms option 1 / 4 (0: the plain diagonal); part (device, nb + 1 row starts): row blocks whose outside counts as off-rank
+void l1_row_norms(const DCsr &A, int option, double *l1, const int *part = nullptr, int nb = 0);
 void extract_diag(const DCsr &A, double *d);
 void make_dinv(int n, const double *d, double weight, double *dinv);
 // bytes of (col, val) one product streams: plain = 12 nnz; stencil-coded = 1 nnz (+ 12 per escape);

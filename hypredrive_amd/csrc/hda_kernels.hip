@@ -2523,21 +2523,42 @@ void require_int32_total(long n, const int *counts, const char *what)
 
 // ------------------------------------------------------------- row utilities
 
-// hypre_ParCSRComputeL1Norms: option 1 = sum_j |a_ij| (sign of a_ii), option 4 = a_ii on
-// a single rank.  One thread per row, ascending k: bit-identical to the oracle.
+// hypre_ParCSRComputeL1Norms: option 1 = sum_j |a_ij| (sign of a_ii); option 4 = |a_ii| + half the absolute sum of the entries that
+// leave the row's block, truncated to |a_ii| when within 4/3 of it -- "leaving" = ghost (off-rank) columns and, with row blocks
+// (part != nullptr: nb + 1 row starts), the columns outside the row's own block; option 0 = the plain diagonal.  One thread per
+// row, ascending k: bit-identical to the oracle.
+__device__ __forceinline__ void l1_block_range(const int *__restrict__ part, int nb, int i, int n, int &lo, int &hi)
+{
+   lo = 0;
+   hi = n;
+   if (!part) return;
+   int a = 0, b = nb; // part[a] <= i < part[b]
+   while (b - a > 1)
+   {
+      const int m = (a + b) >> 1;
+      if (part[m] <= i) a = m;
+      else b = m;
+   }
+   lo = part[a];
+   hi = part[a + 1];
+}
 __global__ __launch_bounds__(256) void k_l1(int n, const int *__restrict__ rp, const int *__restrict__ cj,
-                                            const double *__restrict__ v, int option, double *__restrict__ l1)
+                                            const double *__restrict__ v, int option, double *__restrict__ l1,
+                                            const int *__restrict__ part, int nb)
 {
    int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
+   int lo, hi;
+   l1_block_range(part, nb, i, n, lo, hi);
    double s = 0.0, d = 0.0, off = 0.0;
    for (int k = rp[i]; k < rp[i + 1]; k++)
    {
       s += fabs(v[k]);
       if (cj[k] == i) d = v[k];
-      if (cj[k] >= n) off += fabs(v[k]); // ghost (off-rank) columns
+      if (cj[k] < lo || cj[k] >= hi) off += fabs(v[k]); // ghost (off-rank) and off-block columns
    }
    if (option == 1) l1[i] = (d < 0.0) ? -s : s;
+   else if (option == 0) l1[i] = d;
    else
    { // option 4: a_ii + 0.5 * sum_offd |a_ij|, truncated to a_ii when within 4/3 of it
       double t = fabs(d) + 0.5 * off;
@@ -2549,13 +2570,15 @@ __global__ __launch_bounds__(256) void k_l1(int n, const int *__restrict__ rp, c
 // ascending k and every lane adds them in that order
 template <int G>
 __global__ __launch_bounds__(256) void k_l1_grp(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
-                                                int option, double *__restrict__ l1)
+                                                int option, double *__restrict__ l1, const int *__restrict__ part, int nb)
 {
    const int  gl  = threadIdx.x & (G - 1);
    const long row = ((long)blockIdx.x * 256 + threadIdx.x) / G;
    const bool in  = row < n;
    const int  i   = in ? (int)row : 0;
    const int  k0 = in ? rp[i] : 0, k1 = in ? rp[i + 1] : 0;
+   int        lo, hi;
+   l1_block_range(part, nb, i, n, lo, hi);
    double     s = 0.0, d = 0.0, off = 0.0;
    for (int base = k0; base < k1; base += G)
    {
@@ -2567,18 +2590,19 @@ __global__ __launch_bounds__(256) void k_l1_grp(int n, const int *__restrict__ r
          const double vk = v[k];
          a = fabs(vk);
          if (c == i) d = vk;
-         if (c >= n) o = a;
+         if (c < lo || c >= hi) o = a;
       }
       const int m = min(G, k1 - base);
       for (int l = 0; l < m; l++)
       {
          s += __shfl(a, l, G);
-         off += __shfl(o, l, G); // (entries that are not ghost columns add 0.0)
+         off += __shfl(o, l, G); // (entries that stay inside the block add 0.0)
       }
    }
    for (int o = G >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, G); // one lane holds the diagonal, the others 0
    if (!in || gl) return;
    if (option == 1) l1[i] = (d < 0.0) ? -s : s;
+   else if (option == 0) l1[i] = d;
    else
    {
       double t = fabs(d) + 0.5 * off;
@@ -2586,17 +2610,19 @@ __global__ __launch_bounds__(256) void k_l1_grp(int n, const int *__restrict__ r
       l1[i] = (d < 0.0) ? -t : t;
    }
 }
-void l1_row_norms(const DCsr &A, int option, double *l1)
+void l1_row_norms(const DCsr &A, int option, double *l1, const int *part, int nb)
 {
    if (!A.nrows) return;
    const int    n   = A.nrows;
    const double avg = A.avg_row();
-   if (avg <= 12.0) k_l1<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
-   else if (avg <= 24.0) k_l1_grp<16><<<ceil_div((long long)n * 16, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
-   else if (avg <= 48.0) k_l1_grp<32><<<ceil_div((long long)n * 32, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
-   else k_l1_grp<64><<<ceil_div((long long)n * 64, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1);
+   if (nb <= 1) part = nullptr;
+   if (avg <= 12.0) k_l1<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1, part, nb);
+   else if (avg <= 24.0) k_l1_grp<16><<<ceil_div((long long)n * 16, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1, part, nb);
+   else if (avg <= 48.0) k_l1_grp<32><<<ceil_div((long long)n * 32, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1, part, nb);
+   else k_l1_grp<64><<<ceil_div((long long)n * 64, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), option, l1, part, nb);
 }
-void extract_diag(const DCsr &A, double *d) { l1_row_norms(A, 4, d); }
+// the plain diagonal (hypre's Jacobi / Gauss-Seidel types 0, 7, 3, 4, 6 divide by a_ii whatever leaves the rank)
+void extract_diag(const DCsr &A, double *d) { l1_row_norms(A, 0, d); }
 
 __global__ __launch_bounds__(256) void k_dinv(int n, const double *__restrict__ d, double w, double *__restrict__ o)
 {

@@ -51,6 +51,12 @@ typedef struct {
    int      agg_num_levels, agg_num_paths, agg_interp_type;
    int      agg_pmax;         /* aggressive.max_nnz_row (0: no limit) */
    double   agg_trunc_factor; /* aggressive.trunc_factor */
+   /* V contiguous row blocks on one GPU = the reference at np = V (its CPU defaults, src/internal/amg.c:141-146 HMIS and :182-189
+    * hybrid l1 Gauss-Seidel, are rank-block algorithms): 1 one block, 0 chosen by the setup, V > 1 hypre's even split unless
+    * block_part names the V + 1 row starts */
+   int            blocks;
+   const int64_t *block_part;
+   int            struct_size; /* sizeof(hda_amg_params) as the caller was compiled; set by hda_amg_default_params, checked on entry */
 } hda_amg_params;
 
 /* PCG_args src/internal/pcg.c:15-25 / GMRES_args src/internal/gmres.c:16-27 */
@@ -91,6 +97,12 @@ int hda_relax(hda_csr_t A, int relax_type, double weight, int sweeps, const doub
 int hda_dot(int n, const double *x, const double *y, double *result);
 /* hypre_ParCSRComputeL1Norms option 1 / 4 */
 int hda_l1_norms(hda_csr_t A, int option, double *l1);
+/* the same three on nblk contiguous row blocks (part: nblk + 1 row starts) = what the reference computes at np = nblk: hybrid
+ * Gauss-Seidel inside a block / Jacobi across blocks (hypre_BoomerAMGRelax types 3, 4, 6, 8, 13, 14), the option-4 l1 divisor with
+ * the other blocks in the role of the off-processor part, and hypre_BoomerAMGCoarsenHMIS (Ruge first pass per block + PMIS) */
+int hda_relax_blocks(hda_csr_t A, int relax_type, double weight, int sweeps, int nblk, const int64_t *part, const double *b, double *x);
+int hda_l1_norms_blocks(hda_csr_t A, int option, int nblk, const int64_t *part, double *l1);
+int hda_hmis_blocks(hda_csr_t A, const unsigned char *smask, int nblk, const int64_t *part, uint64_t seed, int level, int *cf);
 
 /* ---- K4 / K5 / K6 ------------------------------------------------------------------ */
 /* hypre_BoomerAMGCreateS */
@@ -166,6 +178,9 @@ int hda_amg_num_levels(hda_amg_t h);
 /* which: 0 = A_l, 1 = P_l, 2 = R_l; returns a borrowed handle (do not destroy) */
 int hda_amg_level_matrix(hda_amg_t h, int level, int which, hda_csr_t *out);
 int hda_amg_level_cf(hda_amg_t h, int level, int *cf);
+/* row blocks the setup worked with (hda_amg_params.blocks resolved; 1 = none) and a level's block starts (blocks + 1 values) */
+int hda_amg_blocks(hda_amg_t h);
+int hda_amg_level_blocks(hda_amg_t h, int level, int64_t *part);
 int hda_amg_complexities(hda_amg_t h, double *grid, double *op);
 double hda_amg_vcycle_bytes(hda_amg_t h);
 /* HYPRE_BoomerAMGSolve as preconditioner (src/internal/precon.c:108): x = V-cycle(b) from 0 */

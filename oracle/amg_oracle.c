@@ -47,6 +47,7 @@ orc_amg_default_params(orc_amg_params *p, int gpu_defaults)
    p->num_functions   = 1;
    p->agg_num_levels = 0; p->agg_num_paths = 1; p->agg_interp_type = 4; /* amg.c:164-171 */
    p->agg_pmax = 0; p->agg_trunc_factor = 0.0;
+   p->blocks = 1; p->block_part = NULL;
 }
 
 /* src/internal/pcg.c:15-25, src/internal/gmres.c:16-27 */
@@ -374,6 +375,100 @@ orc_relax(const orc_csr *A, const double *l1, int type, double w, const double *
    }
 }
 
+/* ---- V contiguous row blocks on one rank = what the reference computes at np = V.
+ * hypre's hybrid smoothers are Gauss-Seidel inside a rank's rows and Jacobi across ranks, its option-4 l1 divisor adds half the
+ * absolute sum of the entries that leave the rank, and HMIS is a Ruge first pass per rank followed by PMIS on
+ * everything that pass did not fix (App. A.5).  part = nb+1 ascending row starts, part[0] = 0, part[nb] = nrows. */
+static inline int
+blk_find(const int64_t *part, int nb, int i)
+{
+   int lo = 0, hi = nb; /* part[lo] <= i < part[hi] */
+   while (hi - lo > 1)
+   {
+      int mid = (lo + hi) / 2;
+      if (part[mid] <= i) lo = mid;
+      else hi = mid;
+   }
+   return lo;
+}
+
+/* hypre_ParCSRComputeL1Norms with the rows outside i's block in the role of the off-processor part.  option 1: full-row sum
+ * (blocks make no difference); option 4: |a_ii| + 0.5 * sum over entries leaving the block, truncated to |a_ii| when that is
+ * <= 4/3 |a_ii|; sign of a_ii restored.  nb <= 1 gives orc_l1_norms bit for bit. */
+void
+orc_l1_norms_blocks(const orc_csr *A, int option, int nb, const int64_t *part, double *l1)
+{
+   if (nb <= 1 || !part || option == 1)
+   {
+      orc_l1_norms(A, option, l1);
+      return;
+   }
+   for (int b = 0; b < nb; b++)
+   {
+      const int lo = (int)part[b], hi = (int)part[b + 1];
+      for (int i = lo; i < hi; i++)
+      {
+         double d = 0.0, off = 0.0;
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         {
+            const int j = A->col[k];
+            if (j == i) d = A->val[k];
+            else if (j < lo || j >= hi) off += fabs(A->val[k]);
+         }
+         const double ad = fabs(d);
+         double       v  = ad + 0.5 * off;
+         if (v <= 4.0 / 3.0 * ad) v = ad;
+         l1[i] = (d < 0.0) ? -v : v;
+      }
+   }
+}
+
+/* orc_relax on V row blocks: the Gauss-Seidel family (3/4/6/8/13/14) sees the values the OTHER blocks held when the sweep
+ * began (tmp keeps them), its own block's values as they are updated; the Jacobi family is what it was.  nb <= 1 gives
+ * orc_relax bit for bit (same products, same order). */
+void
+orc_relax_blocks(const orc_csr *A, const double *l1, int type, double w, const double *b, double *x, double *tmp, int nb,
+                 const int64_t *part)
+{
+   const int n = A->nrows;
+   if (nb <= 1 || !part || type == 0 || type == 7 || type == 18)
+   {
+      orc_relax(A, l1, type, w, b, x, tmp);
+      return;
+   }
+   if (type == 6 || type == 8)
+   {
+      orc_relax_blocks(A, l1, type == 6 ? 3 : 13, w, b, x, tmp, nb, part);
+      orc_relax_blocks(A, l1, type == 6 ? 4 : 14, w, b, x, tmp, nb, part);
+      return;
+   }
+   if (type != 3 && type != 13 && type != 4 && type != 14)
+   {
+      fprintf(stderr, "orc_relax_blocks: unsupported relax type %d\n", type);
+      abort();
+   }
+   const int fwd = (type == 3 || type == 13), use_l1 = (type == 13 || type == 14);
+   memcpy(tmp, x, sizeof(double) * (size_t)n);
+#pragma omp parallel for schedule(dynamic, 1)
+   for (int q = 0; q < nb; q++)
+   {
+      const int lo = (int)part[q], hi = (int)part[q + 1];
+      for (int s = 0; s < hi - lo; s++)
+      {
+         const int i = fwd ? lo + s : hi - 1 - s;
+         double    r = b[i], d = 0.0;
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         {
+            const int j = A->col[k];
+            r -= A->val[k] * ((j >= lo && j < hi) ? x[j] : tmp[j]);
+            if (j == i) d = A->val[k];
+         }
+         if (use_l1) d = l1[i];
+         x[i] += w * r / d;
+      }
+   }
+}
+
 /* hypre relax type 9 (coarse_type ge, src/internal/amg.c:190): hypre_gselim, no pivoting */
 int
 orc_gselim(double *a, double *x, int n)
@@ -617,29 +712,30 @@ bk_top(rsbuckets *b)
    return (b->maxkey > 0) ? b->head[b->maxkey] : -1;
 }
 
-/* hypre_BoomerAMGCoarsenRuge first pass == HMIS (type 10) on a single rank, where the
- * "interior" is the whole grid and the trailing PMIS finds nothing left (SURVEY App. A.5). */
-void
-orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
+/* hypre_BoomerAMGCoarsenRuge first pass on the rows [lo, hi) of A with every connection that leaves the range ignored (a rank's
+ * S_diag): measures count in-range dependants only (measure_type 0), a row is "special F" only when its FULL row has no strong
+ * entry.  tp/tj = strong transpose of the whole matrix; prev/next/key/meas are indexed by row, so disjoint ranges may run
+ * concurrently. */
+static void
+rs_pass_range(const orc_csr *A, const unsigned char *smask, const int *tp, const int *tj, int lo, int hi, int *cf, int *prev,
+              int *next, int *key, int *meas)
 {
-   int       n = A->nrows;
-   int      *tp, *tj;
    rsbuckets B;
-   strong_transpose(A, smask, &tp, &tj);
    B.nb     = 64;
    B.maxkey = 0;
    B.head   = (int *)malloc(sizeof(int) * (size_t)B.nb);
    B.tail   = (int *)malloc(sizeof(int) * (size_t)B.nb);
    for (int q = 0; q < B.nb; q++) B.head[q] = B.tail[q] = -1;
-   B.prev = (int *)malloc(sizeof(int) * (size_t)(n + 1));
-   B.next = (int *)malloc(sizeof(int) * (size_t)(n + 1));
-   B.key  = (int *)malloc(sizeof(int) * (size_t)(n + 1));
-   int *meas = (int *)malloc(sizeof(int) * (size_t)(n + 1));
-   for (int i = 0; i < n; i++)
+   B.prev = prev;
+   B.next = next;
+   B.key  = key;
+#define IN_RANGE(j) ((j) >= lo && (j) < hi)
+   for (int i = lo; i < hi; i++)
    {
-      int ns = 0;
+      int ns = 0, nt = 0;
       for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) ns += smask[k];
-      meas[i]   = tp[i + 1] - tp[i];
+      for (int k = tp[i]; k < tp[i + 1]; k++) nt += IN_RANGE(tj[k]);
+      meas[i]   = nt;
       B.prev[i] = B.next[i] = -1;
       B.key[i]  = 0;
       cf[i]     = (ns == 0) ? ORC_SF_PT : 0;
@@ -647,7 +743,7 @@ orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
    }
    /* ascending-index insertion; measure-0 points become F and the points they depend on
     * gain weight (re-listed at the tail when already listed) */
-   for (int j = 0; j < n; j++)
+   for (int j = lo; j < hi; j++)
    {
       if (cf[j] == ORC_SF_PT) continue;
       if (meas[j] > 0) { bk_enter(&B, j, meas[j]); continue; }
@@ -655,7 +751,7 @@ orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
       for (int k = A->rowptr[j]; k < A->rowptr[j + 1]; k++)
       {
          int nb = A->col[k];
-         if (!smask[k] || cf[nb] == ORC_SF_PT) continue;
+         if (!smask[k] || !IN_RANGE(nb) || cf[nb] == ORC_SF_PT) continue;
          if (nb < j)
          {
             if (cf[nb] != 0) { meas[nb]++; continue; }
@@ -678,13 +774,13 @@ orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
       for (int k = tp[i]; k < tp[i + 1]; k++)
       {
          int j = tj[k];
-         if (cf[j] != 0) continue;
+         if (!IN_RANGE(j) || cf[j] != 0) continue;
          cf[j] = ORC_F_PT;
          bk_remove(&B, j);
          for (int kk = A->rowptr[j]; kk < A->rowptr[j + 1]; kk++)
          {
             int m = A->col[kk];
-            if (smask[kk] && cf[m] == 0)
+            if (smask[kk] && IN_RANGE(m) && cf[m] == 0)
             {
                bk_remove(&B, m);
                meas[m]++;
@@ -696,7 +792,7 @@ orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
       for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
       {
          int j = A->col[k];
-         if (!smask[k] || cf[j] != 0) continue;
+         if (!smask[k] || !IN_RANGE(j) || cf[j] != 0) continue;
          bk_remove(&B, j);
          meas[j]--;
          if (meas[j] > 0)
@@ -707,7 +803,7 @@ orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
             for (int kk = A->rowptr[j]; kk < A->rowptr[j + 1]; kk++)
             {
                int m = A->col[kk];
-               if (smask[kk] && cf[m] == 0)
+               if (smask[kk] && IN_RANGE(m) && cf[m] == 0)
                {
                   bk_remove(&B, m);
                   meas[m]++;
@@ -717,8 +813,120 @@ orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
          }
       }
    }
-   free(tp); free(tj); free(B.head); free(B.tail); free(B.prev); free(B.next); free(B.key);
-   free(meas);
+#undef IN_RANGE
+   free(B.head); free(B.tail);
+}
+
+/* hypre_BoomerAMGCoarsenRuge first pass == HMIS (type 10) on a single rank, where the
+ * "interior" is the whole grid and the trailing PMIS finds nothing left (SURVEY App. A.5). */
+void
+orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
+{
+   int  n = A->nrows;
+   int *tp, *tj;
+   strong_transpose(A, smask, &tp, &tj);
+   int *w = (int *)malloc(sizeof(int) * 4 * (size_t)(n + 1));
+   rs_pass_range(A, smask, tp, tj, 0, n, cf, w, w + (n + 1), w + 2 * (size_t)(n + 1), w + 3 * (size_t)(n + 1));
+   free(tp); free(tj); free(w);
+}
+
+/* HMIS (coarsen type 10, the reference's CPU default src/internal/amg.c:141-146) on V row blocks = hypre at np = V (De Sterck,
+ * Yang, Heys 2006, "HMIS"; hypre_BoomerAMGCoarsenHMIS = CoarsenRuge(type 10) + CoarsenPMIS(CF_init 1)): a Ruge first pass inside
+ * every block on the block's own connections; of its result only the C points of INTERIOR rows (rows without a strong connection
+ * leaving the block) are kept, every other point goes back to undecided; PMIS then starts from those C points as its first
+ * independent set, with measures counted over the whole matrix.  One block: every C point of the first pass is interior. */
+void
+orc_hmis_blocks(const orc_csr *A, const unsigned char *smask, int nb, const int64_t *part, uint64_t seed, int level, int *cf)
+{
+   const int     n      = A->nrows;
+   const int64_t one[2] = {0, n};
+   if (nb <= 1 || !part) { nb = 1; part = one; }
+   int *tp, *tj;
+   strong_transpose(A, smask, &tp, &tj);
+   int *w = (int *)malloc(sizeof(int) * 4 * (size_t)(n + 1));
+#pragma omp parallel for schedule(dynamic, 1)
+   for (int q = 0; q < nb; q++)
+      rs_pass_range(A, smask, tp, tj, (int)part[q], (int)part[q + 1], cf, w, w + (n + 1), w + 2 * (size_t)(n + 1),
+                    w + 3 * (size_t)(n + 1));
+   free(w);
+   /* keep the interior C points; the trailing PMIS decides the rest */
+   for (int q = 0; q < nb; q++)
+   {
+      const int lo = (int)part[q], hi = (int)part[q + 1];
+      for (int i = lo; i < hi; i++)
+      {
+         if (cf[i] == ORC_SF_PT) continue;
+         int boundary = 0;
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1] && !boundary; k++)
+            boundary = smask[k] && (A->col[k] < lo || A->col[k] >= hi);
+         if (boundary || cf[i] != ORC_C_PT) cf[i] = 0;
+      }
+   }
+   /* PMIS with the kept C points as first independent set (orc_pmis's synchronous rounds) */
+   double *meas = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+   char   *newc = (char *)malloc((size_t)(n > 0 ? n : 1));
+   int     undecided = 0;
+   for (int i = 0; i < n; i++)
+   {
+      const int nt = tp[i + 1] - tp[i];
+      meas[i]      = (double)nt + pmis_rand(seed, level, i);
+      if (cf[i] != 0) continue; /* special F, kept C */
+      if (nt == 0) cf[i] = ORC_F_PT; /* measure < 1 */
+      else undecided++;
+   }
+   /* points that depend on a kept C point are F before the first round */
+   for (int i = 0; i < n; i++)
+   {
+      if (cf[i] != 0) continue;
+      for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         if (smask[k] && cf[A->col[k]] == ORC_C_PT)
+         {
+            cf[i] = ORC_F_PT;
+            undecided--;
+            break;
+         }
+   }
+   while (undecided > 0)
+   {
+      for (int i = 0; i < n; i++)
+      {
+         newc[i] = 0;
+         if (cf[i] != 0) continue;
+         int    is_max = 1;
+         double mi     = meas[i];
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1] && is_max; k++)
+         {
+            int j = A->col[k];
+            if (!smask[k] || cf[j] != 0) continue;
+            if (meas[j] > mi || (meas[j] == mi && j > i)) is_max = 0;
+         }
+         for (int k = tp[i]; k < tp[i + 1] && is_max; k++)
+         {
+            int j = tj[k];
+            if (cf[j] != 0) continue;
+            if (meas[j] > mi || (meas[j] == mi && j > i)) is_max = 0;
+         }
+         newc[i] = (char)is_max;
+      }
+      for (int i = 0; i < n; i++)
+         if (newc[i])
+         {
+            cf[i] = ORC_C_PT;
+            undecided--;
+         }
+      for (int i = 0; i < n; i++)
+      {
+         if (cf[i] != 0) continue;
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+            if (smask[k] && cf[A->col[k]] == ORC_C_PT)
+            {
+               cf[i] = ORC_F_PT;
+               undecided--;
+               break;
+            }
+      }
+   }
+   free(tp); free(tj); free(meas); free(newc);
 }
 
 typedef struct {
@@ -1607,6 +1815,8 @@ struct orc_amg {
    /* complex smoother (src/internal/amg.c:899-921): ILU on the first smooth_levels levels */
    orc_ilu      **ilu;
    int            smooth_levels, smooth_sweeps;
+   int            nblk;       /* row blocks (orc_amg_params.blocks); 1 = none */
+   int64_t      **bpart;      /* per level: nblk+1 row starts (coarse levels: through the C points) */
    struct orc_mgr *mgr;       /* handle made by orc_precond_mgr: the "hierarchy" is one MGR cycle */
    orc_ilu       *ilu_only;   /* handle made by orc_precond_ilu: the "hierarchy" is one ILU solve */
    const orc_csr *ilu_A;
@@ -1646,6 +1856,15 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
    h->cheb_w2   = (double **)calloc((size_t)maxl, sizeof(void *));
    h->cheb_w3   = (double **)calloc((size_t)maxl, sizeof(void *));
    h->cheb_coef = (double (*)[5])calloc((size_t)maxl, sizeof(double[5]));
+   h->nblk  = p->blocks > 1 ? p->blocks : 1;
+   h->bpart = (int64_t **)calloc((size_t)maxl, sizeof(void *));
+   if (h->nblk > 1)
+   { /* level 0: the caller's starts, or hypre's even split (hypre_GeneratePartitioning) */
+      h->bpart[0] = (int64_t *)malloc(sizeof(int64_t) * (size_t)(h->nblk + 1));
+      for (int q = 0; q <= h->nblk; q++)
+         h->bpart[0][q] = p->block_part ? p->block_part[q] : (int64_t)(((__int128)q * A0->nrows) / h->nblk);
+   }
+   h->p.block_part = NULL; /* (the caller's array is not kept) */
    /* own copy of level 0 */
    {
       int nnz = A0->rowptr[A0->nrows];
@@ -1674,7 +1893,7 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
       if (p->coarsen_type == 8)
          orc_pmis(A, sm, p->seed, lvl, 0, cf);
       else
-         orc_rs_first_pass(A, sm, cf);
+         orc_hmis_blocks(A, sm, h->nblk, h->bpart[lvl], p->seed, lvl, cf);
       const int aggressive = lvl < p->agg_num_levels;
       if (aggressive) orc_coarsen_second_pass(A, sm, p->agg_num_paths > 0 ? p->agg_num_paths : 1, p->seed, lvl, cf);
       int nc = 0;
@@ -1697,6 +1916,18 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
       }
       h->R[lvl]  = orc_csr_transpose(h->P[lvl]);
       free(sm);
+      if (h->nblk > 1)
+      { /* coarse ids ascend with the fine ids of the C points: block q keeps a contiguous range (a rank's coarse rows) */
+         int64_t *np_ = (int64_t *)malloc(sizeof(int64_t) * (size_t)(h->nblk + 1));
+         int64_t  c = 0;
+         int      q = 0;
+         for (int64_t i = 0; i <= n; i++)
+         {
+            while (q <= h->nblk && h->bpart[lvl][q] == i) np_[q++] = c;
+            if (i < n && cf[i] == ORC_C_PT) c++;
+         }
+         h->bpart[lvl + 1] = np_;
+      }
       h->A[lvl + 1] = orc_rap(A, h->P[lvl]);
       lvl++;
       if (lvl >= maxl - 1 || nc <= p->max_coarse_size) not_finished = 0;
@@ -1708,8 +1939,8 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
       int n     = h->A[l]->nrows;
       h->l1d[l] = (double *)malloc(sizeof(double) * (size_t)n);
       h->l1u[l] = (double *)malloc(sizeof(double) * (size_t)n);
-      orc_l1_norms(h->A[l], l1_option_for(p->relax_down), h->l1d[l]);
-      orc_l1_norms(h->A[l], l1_option_for(p->relax_up), h->l1u[l]);
+      orc_l1_norms_blocks(h->A[l], l1_option_for(p->relax_down), h->nblk, h->bpart[l], h->l1d[l]);
+      orc_l1_norms_blocks(h->A[l], l1_option_for(p->relax_up), h->nblk, h->bpart[l], h->l1u[l]);
       h->f[l]   = (double *)calloc((size_t)n, sizeof(double));
       h->u[l]   = (double *)calloc((size_t)n, sizeof(double));
       h->tmp[l] = (double *)calloc((size_t)n, sizeof(double));
@@ -1756,7 +1987,9 @@ orc_amg_free(orc_amg *h)
       free(h->cf[l]); free(h->l1d[l]); free(h->l1u[l]);
       free(h->f[l]); free(h->u[l]); free(h->tmp[l]);
       free(h->cheb_ds[l]); free(h->cheb_w2[l]); free(h->cheb_w3[l]);
+      if (h->bpart) free(h->bpart[l]);
    }
+   free(h->bpart);
    free(h->A); free(h->P); free(h->R); free(h->cf); free(h->l1d); free(h->l1u);
    free(h->f); free(h->u); free(h->tmp); free(h->dense);
    free(h->ilu); free(h->cor);
@@ -1833,6 +2066,7 @@ const orc_csr *orc_amg_A(const orc_amg *h, int l) { return h->A[l]; }
 const orc_csr *orc_amg_P(const orc_amg *h, int l) { return h->P[l]; }
 const int     *orc_amg_cf(const orc_amg *h, int l) { return h->cf[l]; }
 const double  *orc_amg_l1(const orc_amg *h, int l, int which) { return which ? h->l1u[l] : h->l1d[l]; }
+const int64_t *orc_amg_block_part(const orc_amg *h, int l) { return h->bpart ? h->bpart[l] : NULL; } /* NULL: one block */
 
 double
 orc_amg_operator_complexity(const orc_amg *h)
@@ -1856,7 +2090,7 @@ level_relax(orc_amg *h, int l, int type, const double *l1, const double *b, doub
 {
    if (type == 16)
       orc_cheby_apply(h->A[l], h->p.cheby_order, h->p.cheby_scale, h->cheb_ds[l], h->cheb_coef[l], b, x, h->tmp[l], h->cheb_w2[l], h->cheb_w3[l]);
-   else orc_relax(h->A[l], l1, type, h->p.relax_weight, b, x, h->tmp[l]);
+   else orc_relax_blocks(h->A[l], l1, type, h->p.relax_weight, b, x, h->tmp[l], h->nblk, h->bpart[l]);
 }
 
 static void

@@ -64,6 +64,12 @@ typedef struct {
     * SetAggTruncFactor, amg.c:940-942; both 0 = none by default): hypre_BoomerAMGInterpTruncation on the finished multipass rows */
    int    agg_pmax;
    double agg_trunc_factor;
+   /* V contiguous row blocks on one rank = the reference at np = V: hybrid Gauss-Seidel (relax 3/4/6/8/13/14) is Gauss-Seidel
+    * inside a block and Jacobi across blocks with hypre's option-4 l1 divisor, HMIS (coarsen 10) a Ruge first pass per block +
+    * PMIS on the rest; coarse levels inherit the blocks through their C points.  blocks <= 1: one block.  block_part: blocks+1
+    * row starts of level 0 (NULL: hypre's even split, start q = floor(q * n / blocks)). */
+   int            blocks;
+   const int64_t *block_part;
 } orc_amg_params;
 
 typedef struct orc_amg orc_amg; /* hierarchy handle */
@@ -117,6 +123,11 @@ void orc_strength_dof(const orc_csr *A, double theta, double max_row_sum, const 
 void orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
               int64_t row_offset, int *cf); /* cf: 1 C, -1 F, -3 special F */
 void orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf);
+/* the row-block forms (see orc_amg_params.blocks); part = nb+1 ascending row starts */
+void orc_hmis_blocks(const orc_csr *A, const unsigned char *smask, int nb, const int64_t *part, uint64_t seed, int level, int *cf);
+void orc_l1_norms_blocks(const orc_csr *A, int option, int nb, const int64_t *part, double *l1);
+void orc_relax_blocks(const orc_csr *A, const double *l1, int type, double weight, const double *b, double *x, double *tmp,
+                      int nb, const int64_t *part);
 orc_csr *orc_interp_extpi(const orc_csr *A, const unsigned char *smask, const int *cf,
                           int pmax, double trunc_factor);
 orc_csr *orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf,
@@ -143,6 +154,7 @@ const orc_csr *orc_amg_A(const orc_amg *h, int lvl);
 const orc_csr *orc_amg_P(const orc_amg *h, int lvl); /* NULL on coarsest */
 const int     *orc_amg_cf(const orc_amg *h, int lvl);
 const double  *orc_amg_l1(const orc_amg *h, int lvl, int which); /* 0 down, 1 up */
+const int64_t *orc_amg_block_part(const orc_amg *h, int level); /* nblk+1 row starts of the level's blocks; NULL: one block */
 double   orc_amg_operator_complexity(const orc_amg *h);
 double   orc_amg_grid_complexity(const orc_amg *h);
 void     orc_amg_vcycle(orc_amg *h, const double *b, double *x); /* x must hold the initial guess */

@@ -30,7 +30,8 @@ class AmgParams(C.Structure):
                 ("cheby_order", C.c_int), ("cheby_eig_est", C.c_int), ("cheby_variant", C.c_int), ("cheby_scale", C.c_int),
                 ("cheby_fraction", C.c_double),
                 ("agg_num_levels", C.c_int), ("agg_num_paths", C.c_int), ("agg_interp_type", C.c_int),
-                ("agg_pmax", C.c_int), ("agg_trunc_factor", C.c_double)]
+                ("agg_pmax", C.c_int), ("agg_trunc_factor", C.c_double),
+                ("blocks", C.c_int), ("block_part", C.POINTER(C.c_int64))]
 
 
 class KrylovParams(C.Structure):
@@ -94,6 +95,11 @@ def lib():
     L.orc_strength.argtypes = [cp, C.c_double, C.c_double, P(C.c_ubyte)]
     L.orc_pmis.argtypes = [cp, P(C.c_ubyte), C.c_uint64, C.c_int, C.c_int64, ip]
     L.orc_rs_first_pass.argtypes = [cp, P(C.c_ubyte), ip]
+    L.orc_hmis_blocks.argtypes = [cp, P(C.c_ubyte), C.c_int, P(C.c_int64), C.c_uint64, C.c_int, ip]
+    L.orc_l1_norms_blocks.argtypes = [cp, C.c_int, C.c_int, P(C.c_int64), dp]
+    L.orc_relax_blocks.argtypes = [cp, dp, C.c_int, C.c_double, dp, dp, dp, C.c_int, P(C.c_int64)]
+    L.orc_amg_block_part.restype = P(C.c_int64)
+    L.orc_amg_block_part.argtypes = [C.c_void_p, C.c_int]
     L.orc_interp_extpi.restype = cp
     L.orc_interp_extpi.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double]
     L.orc_rap.restype = cp
@@ -229,12 +235,29 @@ def lap7_partition(nx, ny, nz, P, rank):
     return lo.value, hi.value
 
 
+def _bpart(part):
+    a = np.ascontiguousarray(part, dtype=np.int64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def even_blocks(n, blocks):
+    """hypre's even split of n rows into `blocks` contiguous blocks (start q = floor(q * n / blocks))."""
+    return np.array([(q * n) // blocks for q in range(blocks + 1)], dtype=np.int64)
+
+
 def amg_params(gpu_defaults=True, **kw):
     p = AmgParams()
     lib().orc_amg_default_params(C.byref(p), 1 if gpu_defaults else 0)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise KeyError(k)
+        if k == "block_part":
+            if v is None:
+                continue
+            keep, ptr = _bpart(v)
+            p._block_part_keep = keep  # (the struct borrows the array until the setup has read it)
+            p.block_part = ptr
+            continue
         setattr(p, k, v)
     return p
 
@@ -269,6 +292,32 @@ def relax(A, l1, rtype, weight, b, x):
     l1 = np.ascontiguousarray(l1, dtype=np.float64)
     lib().orc_relax(A.ptr, _dp(l1), rtype, weight, _dp(b), _dp(x), _dp(tmp))
     return x
+
+
+def l1_norms_blocks(A, option, part):
+    out = np.zeros(A.nrows)
+    keep, ptr = _bpart(part)
+    lib().orc_l1_norms_blocks(A.ptr, option, len(keep) - 1, ptr, _dp(out))
+    return out
+
+
+def relax_blocks(A, l1, rtype, weight, b, x, part):
+    x = np.ascontiguousarray(x, dtype=np.float64).copy()
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    tmp = np.zeros(A.nrows)
+    l1 = np.ascontiguousarray(l1, dtype=np.float64)
+    keep, ptr = _bpart(part)
+    lib().orc_relax_blocks(A.ptr, _dp(l1), rtype, weight, _dp(b), _dp(x), _dp(tmp), len(keep) - 1, ptr)
+    return x
+
+
+def hmis_blocks(A, smask, part, seed=2747, level=0):
+    cf = np.zeros(A.nrows, dtype=np.int32)
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    keep, ptr = _bpart(part)
+    lib().orc_hmis_blocks(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), len(keep) - 1, ptr, seed, level,
+                          cf.ctypes.data_as(C.POINTER(C.c_int)))
+    return cf
 
 
 def strength(A, theta=0.25, max_row_sum=0.9, dof=None):
@@ -380,6 +429,10 @@ class Amg:
         n = self.level_A(l).nrows
         p = lib().orc_amg_cf(self.h, l)
         return np.ctypeslib.as_array(p, shape=(n,)).copy() if p else None
+
+    def level_block_part(self, l):
+        p = lib().orc_amg_block_part(self.h, l)
+        return np.ctypeslib.as_array(p, shape=(self.params.blocks + 1,)).copy() if p else None
 
     def level_l1(self, l, which=0):
         n = self.level_A(l).nrows

@@ -40,9 +40,13 @@ def test_param_struct_layout_matches_oracle(orc):
         assert getattr(hp, name) == getattr(op, name), name
         assert getattr(h.AmgParams, name).offset == getattr(orc.AmgParams, name).offset, name
     # the aggressive-coarsening fields close both structs (AMGagg_args defaults of src/internal/amg.c:164-171: 0 levels, 1 path, multipass)
-    assert every[len(shared):] == ["agg_num_levels", "agg_num_paths", "agg_interp_type", "agg_pmax", "agg_trunc_factor"] == [n for (n, _t) in h.AmgParams._fields_][-5:]
-    for name in every[len(shared):]:
+    # ... then the row blocks (the reference at np = V); the product's struct ends with its own size, which hda_amg_create checks
+    tail = ["agg_num_levels", "agg_num_paths", "agg_interp_type", "agg_pmax", "agg_trunc_factor", "blocks", "block_part"]
+    assert every[len(shared):] == tail == [n for (n, _t) in h.AmgParams._fields_][-8:-1]
+    assert h.AmgParams._fields_[-1][0] == "struct_size" and hp.struct_size == C.sizeof(h.AmgParams)
+    for name in tail[:-1]:
         assert getattr(hp, name) == getattr(op, name), name
+    assert hp.blocks == 1 and not hp.block_part and not op.block_part
     assert (hp.agg_num_levels, hp.agg_num_paths, hp.agg_interp_type, hp.agg_pmax, hp.agg_trunc_factor) == (0, 1, 4, 0, 0.0)
     # ILU_args defaults of src/internal/ilu.c:21-23 and smoother off (amg.c:237)
     assert (hp.smooth_num_levels, hp.smooth_num_sweeps, hp.ilu_tri_solve, hp.ilu_lower_it, hp.ilu_upper_it) == (0, 1, 1, 5, 5)

@@ -1,0 +1,193 @@
+"""GPU parity tests of the row-block forms: V contiguous row blocks on one GPU = what the reference computes at np = V
+(its CPU-build defaults, /root/reference/src/internal/amg.c:141-146 HMIS and :182-189 hybrid l1 Gauss-Seidel 13 / 14, are
+rank-block algorithms; pins examples/refOutput/ex1.txt:27, laplacian.txt:34-38 were made with them at np 1).
+
+Bars: C/F splittings, block starts and l1 divisors bit-exact; sweeps 1e-13 (wave-parallel row sums); identical iteration counts
+and residual histories to 1e-10 on identical hierarchies.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+GS_TYPES = [3, 4, 6, 13, 14, 8]
+
+
+@pytest.fixture(scope="module")
+def hd():
+    import hypredrive_amd as h
+    assert h.device_count() >= 1, "no HIP device"
+    return h
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def mmatrix(n, density, seed, unsym=False):
+    rng = np.random.default_rng(seed)
+    M = sp.random(n, n, density=density, random_state=rng, format="csr")
+    if not unsym:
+        M = M + M.T
+    M = sp.csr_matrix(M)
+    M.data = -np.abs(M.data)
+    M.setdiag(0)
+    M.eliminate_zeros()
+    d = np.asarray(abs(M).sum(axis=1)).ravel() * rng.uniform(0.7, 1.3, n) + 0.05
+    return (M + sp.diags(d)).tocsr()
+
+
+def parts_for(n, kind, seed=0):
+    rng = np.random.default_rng(seed)
+    if kind == "one":
+        return np.array([0, n])
+    if kind == "even4":
+        return np.array([(q * n) // 4 for q in range(5)])
+    if kind == "even37":
+        return np.array([(q * n) // 37 for q in range(38)])
+    if kind == "ragged":  # blocks of very different sizes, two of them empty
+        cuts = np.sort(rng.choice(np.arange(1, n), size=min(9, n - 1), replace=False))
+        p = np.concatenate([[0], cuts[:3], [cuts[3], cuts[3]], cuts[4:], [n, n]])
+        return np.sort(p)
+    if kind == "rows":  # every row its own block: the hybrid sweep is a Jacobi sweep with the option-4 divisor
+        return np.arange(n + 1)
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["one", "even4", "even37", "ragged", "rows"])
+def test_block_l1_divisors_bit_exact(orc, hd, kind):
+    """hypre_ParCSRComputeL1Norms option 4 with the other blocks in the role of the off-processor part"""
+    for M in (mmatrix(900, 0.01, 3), mmatrix(400, 0.12, 4), orc.lap7(12, 9, 7)[0].to_scipy()):
+        Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+        part = parts_for(M.shape[0], kind, 5)
+        for option in (1, 4):
+            assert np.array_equal(Ah.l1_norms_blocks(option, part), orc.l1_norms_blocks(Ao, option, part))
+
+
+@pytest.mark.parametrize("rtype", GS_TYPES)
+@pytest.mark.parametrize("kind", ["one", "even4", "even37", "ragged", "rows"])
+def test_block_hybrid_gauss_seidel_matches_oracle(orc, hd, rtype, kind):
+    """Gauss-Seidel inside a block, Jacobi across blocks: every block's workgroup reproduces the sequential sweep of its rows on
+    the values the other blocks held when the sweep began"""
+    cases = [(orc.lap7(13, 11, 9, b_mode=1)[0].to_scipy(), 1.0), (mmatrix(1200, 0.008, 11), 0.9), (mmatrix(300, 0.2, 12), 1.0),
+             (mmatrix(500, 0.03, 13, unsym=True), 1.0)]
+    for M, w in cases:
+        n = M.shape[0]
+        Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+        part = parts_for(n, kind, 7)
+        rng = np.random.default_rng(rtype)
+        b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+        l1 = orc.l1_norms_blocks(Ao, 4, part)
+        xo = x0
+        for _ in range(2):
+            xo = orc.relax_blocks(Ao, l1, rtype, w, b, xo, part)
+        assert rel(Ah.relax_blocks(b, x0, part, rtype, w, sweeps=2), xo) < 1e-12
+
+
+def test_one_block_is_the_sequential_sweep(orc, hd):
+    M = mmatrix(800, 0.01, 21)
+    Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+    rng = np.random.default_rng(1)
+    b, x0 = rng.standard_normal(800), rng.standard_normal(800)
+    for rtype in (13, 14, 8):
+        seq = orc.relax(Ao, orc.l1_norms(Ao, 4), rtype, 1.0, b, x0)
+        assert np.array_equal(orc.relax_blocks(Ao, orc.l1_norms(Ao, 4), rtype, 1.0, b, x0, [0, 800]), seq)
+        assert rel(Ah.relax_blocks(b, x0, [0, 800], rtype, 1.0), seq) < 1e-13
+        assert rel(Ah.relax(b, x0, rtype, 1.0), seq) < 1e-13
+
+
+@pytest.mark.parametrize("kind", ["one", "even4", "even37", "ragged"])
+@pytest.mark.parametrize("theta", [0.25, 0.6])
+def test_block_hmis_bit_exact(orc, hd, kind, theta):
+    """hypre_BoomerAMGCoarsenHMIS at np = V: Ruge first pass per block, interior C points kept, PMIS from there"""
+    for M in (orc.lap7(14, 12, 10)[0].to_scipy(), mmatrix(1500, 0.006, 31), mmatrix(600, 0.05, 32), mmatrix(700, 0.02, 33, unsym=True)):
+        Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+        part = parts_for(M.shape[0], kind, 9)
+        sm = orc.strength(Ao, theta)
+        assert np.array_equal(Ah.strength(theta), sm)
+        assert np.array_equal(Ah.hmis_blocks(sm, part), orc.hmis_blocks(Ao, sm, part))
+
+
+@pytest.mark.parametrize("shape,V", [((12, 12, 12), 1), ((16, 16, 16), 4), ((20, 18, 16), 7), ((24, 24, 24), 12), ((16, 16, 16), 64)])
+def test_block_hierarchy_and_pcg_match_oracle(orc, hd, shape, V):
+    """the reference's CPU defaults (HMIS, hybrid l1 Gauss-Seidel 13 / 14) on V row blocks: same block starts, C/F splittings and
+    operators on every level, PCG with the oracle's iterations and history"""
+    Ao, b = orc.lap7(*shape)
+    Ah = hd.lap7(*shape)
+    po = orc.amg_params(False, blocks=V)
+    ph = hd.AmgParams.default(coarsen_type=10, relax_down=13, relax_up=14, relax_coarse=9, blocks=V)
+    ho, hh = orc.Amg(Ao, po), hd.Amg(Ah, ph)
+    assert hh.num_levels == ho.num_levels and hh.blocks == max(V, 1)
+    for l in range(ho.num_levels):
+        if V > 1:
+            assert np.array_equal(hh.level_blocks(l), ho.level_block_part(l)), f"block starts level {l}"
+        if l < ho.num_levels - 1:
+            assert np.array_equal(hh.level_cf(l), ho.level_cf(l)), f"C/F level {l}"
+            rp, cj, v = hh.level_matrix(l + 1, 0).download()
+            Al = ho.level_A(l + 1)
+            assert np.array_equal(rp, Al.rowptr) and np.array_equal(cj, Al.col) and np.array_equal(v, Al.val)
+    ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
+    assert rel(rh["x"], ro["x"]) < 1e-9
+
+
+def test_block_part_given_by_the_caller(orc, hd):
+    """uneven blocks named by their row starts (what a reference run on ranks of different sizes computes)"""
+    shape = (14, 14, 14)
+    Ao, b = orc.lap7(*shape)
+    Ah = hd.lap7(*shape)
+    n = Ao.nrows
+    part = np.array([0, 300, 301, 1500, 1500, n])
+    po = orc.amg_params(False, blocks=5, block_part=part)
+    ph = hd.AmgParams.default(coarsen_type=10, relax_down=13, relax_up=14, relax_coarse=9, blocks=5, block_part=part)
+    ho, hh = orc.Amg(Ao, po), hd.Amg(Ah, ph)
+    assert hh.num_levels == ho.num_levels
+    for l in range(ho.num_levels - 1):
+        assert np.array_equal(hh.level_blocks(l), ho.level_block_part(l))
+        assert np.array_equal(hh.level_cf(l), ho.level_cf(l))
+    ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+    assert rh["iters"] == ro["iters"] and np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("down,up", [(3, 4), (6, 6), (8, 8)])
+def test_block_sweeps_with_pmis_grids(orc, hd, down, up):
+    """row blocks with the GPU build's coarsening (PMIS is block independent): only the sweeps and their divisors change"""
+    Ao, b = orc.lap7(18, 18, 18, b_mode=1)
+    Ah = hd.lap7(18, 18, 18)
+    ro = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(True, relax_down=down, relax_up=up, blocks=9)))
+    rh = hd.pcg(Ah, b, hd.Amg(Ah, hd.AmgParams.default(relax_down=down, relax_up=up, blocks=9)))
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-9)
+
+
+def test_blocks_stay_within_one_iteration_of_one_block_at_64_cubed(orc, hd):
+    """Blocks four grid planes thick (what the setup chooses by itself above HDA_BLOCKS_MIN_ROWS rows: blocks of four times the
+    operator's bandwidth) keep the CPU-default preconditioner within one PCG iteration of its one-block form; device = oracle(V)."""
+    n = 64
+    Ao, b = orc.lap7(n, n, n)
+    Ah = hd.lap7(n, n, n)
+    iters = {}
+    for V in (1, 16):
+        ph = hd.AmgParams.default(coarsen_type=10, relax_down=13, relax_up=14, relax_coarse=9, blocks=V)
+        rh = hd.pcg(Ah, b, hd.Amg(Ah, ph))
+        ro = orc.pcg(Ao, b, orc.Amg(Ao, orc.amg_params(False, blocks=V)))
+        assert rh["converged"] and rh["iters"] == ro["iters"], V
+        assert np.allclose(rh["hist"], ro["hist"], rtol=1e-9, atol=0)
+        iters[V] = rh["iters"]
+    assert abs(iters[16] - iters[1]) <= 1, iters
+
+
+def test_automatic_blocks(hd, monkeypatch):
+    """blocks = 0: one block up to HDA_BLOCKS_MIN_ROWS rows, beyond that blocks of at least four times the bandwidth"""
+    A = hd.lap7(40, 40, 40)
+    p = hd.AmgParams.default(coarsen_type=10, relax_down=13, relax_up=14, relax_coarse=9, blocks=0)
+    assert hd.Amg(A, p).blocks == 1  # 64 000 rows: the sequential algorithms
+    B = hd.lap7(96, 96, 96)  # 884 736 rows, bandwidth 9216: 24 blocks of four planes
+    h = hd.Amg(B, p)
+    assert h.blocks == 24
+    part = h.level_blocks(0)
+    assert part[0] == 0 and part[-1] == B.nrows and np.all(np.diff(part) == 96 * 96 * 4)
+    # Jacobi smoothing + PMIS never asks for blocks
+    assert hd.Amg(B, hd.AmgParams.default(blocks=0)).blocks == 1

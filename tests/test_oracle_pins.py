@@ -447,3 +447,137 @@ def test_pin_ex8_fifth_variant_direct_interpolation(orc, pins):
         strongC = {int(cidx[j]) for k, j in zip(range(S.indptr[i], S.indptr[i + 1]), S.indices[S.indptr[i]:S.indptr[i + 1]]) if sm[k] and cf[j] == 1}
         assert set(P.col[P.rowptr[i]:P.rowptr[i + 1]]) <= strongC
 
+
+
+# ---- row blocks: V contiguous row blocks on one rank = the reference at np = V (orc_amg_params.blocks) -------------------------
+
+def _mmat(n, density, seed):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    M = sp.random(n, n, density=density, random_state=rng, format="csr")
+    M = sp.csr_matrix(M + M.T)
+    M.data = -np.abs(M.data)
+    M.setdiag(0)
+    M.eliminate_zeros()
+    return (M + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel() + 0.1)).tocsr()
+
+
+def test_block_forms_with_one_block_are_the_sequential_forms(orc):
+    """blocks <= 1 must reproduce the one-rank restatement bit for bit (the ex1 / laplacian pins above run through it)"""
+    M = _mmat(600, 0.01, 3)
+    A = orc.Csr.from_scipy(M)
+    rng = np.random.default_rng(0)
+    b, x = rng.standard_normal(600), rng.standard_normal(600)
+    for opt in (1, 4):
+        assert np.array_equal(orc.l1_norms_blocks(A, opt, [0, 600]), orc.l1_norms(A, opt))
+    for t in (3, 4, 6, 8, 13, 14, 18, 0):
+        l1 = orc.l1_norms(A, 1 if t == 18 else 4)
+        assert np.array_equal(orc.relax_blocks(A, l1, t, 0.9, b, x, [0, 600]), orc.relax(A, l1, t, 0.9, b, x))
+    # a hierarchy with blocks = 1 is the hierarchy without the parameter
+    Al, bl = orc.lap7(9, 8, 7)
+    h0, h1 = orc.Amg(Al, orc.amg_params(False)), orc.Amg(Al, orc.amg_params(False, blocks=1))
+    assert h0.num_levels == h1.num_levels
+    for l in range(h0.num_levels - 1):
+        assert np.array_equal(h0.level_cf(l), h1.level_cf(l))
+    assert np.allclose(orc.pcg(Al, bl, h0)["hist"], orc.pcg(Al, bl, h1)["hist"], rtol=1e-12, atol=0)  # (threaded inner products)
+
+
+def test_block_l1_divisor_formula(orc):
+    """hypre_ParCSRComputeL1Norms option 4: |a_ii| + half the absolute sum of the entries leaving the block, truncated to |a_ii|
+    when within 4/3 of it"""
+    M = _mmat(300, 0.03, 5)
+    A = orc.Csr.from_scipy(M)
+    part = np.array([0, 70, 70, 190, 300])
+    got = orc.l1_norms_blocks(A, 4, part)
+    Mc = M.tocoo()
+    blk = np.searchsorted(part, np.arange(300), side="right") - 1
+    # (searchsorted with the empty block: rows 70..189 belong to block 2)
+    off = np.zeros(300)
+    for i, j, v in zip(Mc.row, Mc.col, Mc.data):
+        if i != j and not (part[blk[i]] <= j < part[blk[i] + 1]):
+            off[i] += abs(v)
+    d = M.diagonal()
+    want = d + 0.5 * off
+    want[want <= 4.0 / 3.0 * d] = d[want <= 4.0 / 3.0 * d]
+    assert np.allclose(got, want, rtol=1e-15)
+    assert (got > d).any() and (got == d).any()  # both branches of the truncation are exercised
+
+
+def test_block_gauss_seidel_limits(orc):
+    """every row its own block = a Jacobi sweep with the option-4 divisor; blocks that do not couple = independent sequential
+    sweeps; a sweep over V blocks never reads a value another block wrote in the same sweep"""
+    M = _mmat(250, 0.04, 7)
+    A = orc.Csr.from_scipy(M)
+    rng = np.random.default_rng(2)
+    b, x = rng.standard_normal(250), rng.standard_normal(250)
+    rows = np.arange(251)
+    l1 = orc.l1_norms_blocks(A, 4, rows)
+    jac = x + (b - M @ x) / l1
+    for t in (13, 14):
+        assert np.allclose(orc.relax_blocks(A, l1, t, 1.0, b, x, rows), jac, rtol=1e-13, atol=1e-14)
+    # block-diagonal operator: blocks = components, the hybrid sweep is the sequential sweep
+    import scipy.sparse as sp
+    B = sp.block_diag([_mmat(80, 0.1, 8), _mmat(50, 0.1, 9), _mmat(120, 0.05, 10)]).tocsr()
+    Bo = orc.Csr.from_scipy(B)
+    bb, xx = rng.standard_normal(250), rng.standard_normal(250)
+    part = [0, 80, 130, 250]
+    l1b = orc.l1_norms_blocks(Bo, 4, part)
+    assert np.array_equal(l1b, orc.l1_norms(Bo, 4))
+    for t in (3, 4, 6, 13, 14, 8):
+        assert np.array_equal(orc.relax_blocks(Bo, l1b, t, 1.0, bb, xx, part), orc.relax(Bo, l1b, t, 1.0, bb, xx))
+    # two blocks: the second block's forward sweep sees the OLD first block
+    part2 = [0, 100, 250]
+    l12 = orc.l1_norms_blocks(A, 4, part2)
+    got = orc.relax_blocks(A, l12, 13, 1.0, b, x, part2)
+    want = x.copy()
+    Ml = M.tolil()
+    for lo, hi in ((0, 100), (100, 250)):
+        cur = x.copy()
+        for i in range(lo, hi):
+            r = b[i] - sum(v * (cur[j] if lo <= j < hi else x[j]) for j, v in zip(Ml.rows[i], Ml.data[i]))
+            cur[i] += r / l12[i]
+        want[lo:hi] = cur[lo:hi]
+    assert np.allclose(got, want, rtol=1e-13, atol=1e-14)
+
+
+def test_block_hmis_properties(orc):
+    """HMIS on V blocks (De Sterck / Yang / Heys: Ruge first pass per block, interior C points kept, PMIS on the rest): components
+    as blocks = the first pass of every component; every F point ends up with a strong C neighbour or without dependants; the C points
+    are an independent set of the strength graph wherever PMIS placed them; thin blocks (every row on a block boundary) = PMIS"""
+    import scipy.sparse as sp
+    B = sp.block_diag([orc.lap7(6, 5, 4)[0].to_scipy(), orc.lap7(5, 5, 5)[0].to_scipy()]).tocsr()
+    Bo = orc.Csr.from_scipy(B)
+    sm = orc.strength(Bo, 0.25)
+    cf = orc.hmis_blocks(Bo, sm, [0, 120, 245])
+    a = orc.lap7(6, 5, 4)[0]
+    c = orc.lap7(5, 5, 5)[0]
+    assert np.array_equal(cf[:120], orc.hmis_blocks(a, orc.strength(a, 0.25), [0, 120]))
+    assert np.array_equal(cf[120:], orc.hmis_blocks(c, orc.strength(c, 0.25), [0, 125]))
+    # structure of the result on a coupled problem
+    A, _ = orc.lap7(12, 10, 8)
+    n = A.nrows
+    sm = orc.strength(A, 0.25)
+    S = sp.csr_matrix((sm.astype(float), A.col, A.rowptr), shape=(n, n))
+    S.eliminate_zeros()
+    for part in ([0, n], [0, n // 3, n], [(q * n) // 8 for q in range(9)]):
+        cf = orc.hmis_blocks(A, sm, part)
+        assert set(np.unique(cf)) <= {1, -1, -3}
+        C = (cf == 1).astype(float)
+        has_c = (S @ C) > 0
+        dependants = np.asarray(S.sum(axis=0)).ravel() > 0
+        assert np.all(has_c[cf == -1] | ~dependants[cf == -1])
+    thin = [(q * n) // 80 for q in range(81)]  # blocks of one x-line ... 1.2 lines: every row has a strong neighbour outside
+    assert np.array_equal(orc.hmis_blocks(A, sm, thin), orc.pmis(A, sm))
+
+
+def test_block_hierarchy_partitions_follow_the_c_points(orc):
+    A, b = orc.lap7(12, 12, 12)
+    h = orc.Amg(A, orc.amg_params(False, blocks=6))
+    p0 = h.level_block_part(0)
+    assert np.array_equal(p0, orc.even_blocks(A.nrows, 6))
+    for l in range(h.num_levels - 1):
+        cf = h.level_cf(l)
+        p, pn = h.level_block_part(l), h.level_block_part(l + 1)
+        assert np.array_equal(pn, np.concatenate([[0], np.cumsum(cf == 1)])[p])
+    r1, r6 = orc.pcg(A, b, orc.Amg(A, orc.amg_params(False))), orc.pcg(A, b, h)
+    assert r6["converged"] and abs(r6["iters"] - r1["iters"]) <= 2
