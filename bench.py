@@ -18,6 +18,7 @@ scripts/node_scaling.sh:1275-1292 `mpirun -np N`), before anything here touches 
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -27,7 +28,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# RCCL / device-memory sharing across processes needs dmabuf IPC on this driver: must be in the environment before the first HIP call
+# of the process, whoever launched it (the driver's torchrun, bench.py's own spawn, a child bench)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# The headline is measured first and published at once (stderr + gpurun_out/bench_headline.json; printed to stdout by the SIGTERM handler
+# if the job is ended during the extras); the extras that follow share ONE time budget and are skipped, by name, once it is spent.
+STATE = {"headline": None, "printed": False, "deadline": None}
+
+
+def publish_headline(out):
+    STATE["headline"] = out
+    STATE["deadline"] = time.time() + float(os.environ.get("HDA_BENCH_EXTRAS_BUDGET", "600"))
+    line = json.dumps(out)
+    print("[bench] headline (extras follow): " + line, file=sys.stderr, flush=True)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_headline.json"), "w") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def budget_left():
+    return 1e9 if STATE["deadline"] is None else STATE["deadline"] - time.time()
+
+
+def print_line(out):
+    if not STATE["printed"]:
+        STATE["printed"] = True
+        print(json.dumps(out), flush=True)
+
+
+def _on_term(signum, frame):  # ended from outside during the extras: the measured headline must not be lost
+    if STATE["headline"] is not None and not STATE["printed"]:
+        STATE["headline"]["extras_interrupted"] = f"signal {signum} during the extras"
+        print_line(STATE["headline"])
+    os._exit(143)
+
 YAML = "solver: pcg\npreconditioner:\n  preset: poisson\n"
 # BASELINE config 5 (--workload aniso): GMRES(30) + BoomerAMG with the ILU(0) complex smoother on level 0, Jacobi-iterative
 # triangular solves (reference examples/ex8.yml variant 4 block; src/internal/amg.c:899-921, ilu.c:21-23)
@@ -131,10 +171,14 @@ def spawn_ranks(args):
 PHASE = {"name": "start"}  # where a multi-rank run is: what the watchdog of main() reports when the run never finishes
 
 
-def error_line(stage, rank, msg):
+def error_line(stage, rank, msg, nccl_debug=None):
     """A first multi-GPU run that cannot join RCCL says where in ONE JSON line on stdout (stage: uid | init | halo_comm | selftest |
-    devices | peer | fallback | timeout:<stage>), then the process exits non-zero."""
-    sys.stdout.write(json.dumps({"error": str(msg)[:600], "stage": stage, "rank": rank}) + "\n")  # one write: ranks share the pipe
+    devices | peer | fallback | timeout:<stage>), with what RCCL itself logged on that rank (NCCL_DEBUG=WARN, hypredrive_amd/dist.py),
+    then the process exits non-zero."""
+    rec = {"error": str(msg)[:600], "stage": stage, "rank": rank}
+    if nccl_debug:
+        rec["nccl_debug"] = nccl_debug[-1500:]
+    sys.stdout.write(json.dumps(rec) + "\n")  # one write: ranks share the pipe
     sys.stdout.flush()
 
 
@@ -149,7 +193,8 @@ class World:
         limit = float(os.environ.get("HDA_BENCH_INIT_TIMEOUT", "300"))
 
         def watchdog():  # a collective that never returns (a rank missing, a hung ncclCommInitRank) must not eat the driver's whole slot
-            error_line("timeout:" + str(hdist._keep.get("stage", "rendezvous")), rank0, f"joining the ranks did not finish within {limit:.0f} s")
+            error_line("timeout:" + str(hdist._keep.get("stage", "rendezvous")), rank0, f"joining the ranks did not finish within {limit:.0f} s",
+                       hdist.rccl_debug_tail())
             os._exit(3)
 
         t = threading.Timer(limit, watchdog)
@@ -163,10 +208,10 @@ class World:
             # every rank gets here together (dist.init agrees on the failure before raising).  The error line comes first; then, unless
             # HDA_BENCH_NO_FALLBACK is set, the same job is measured over the host-staged transport so that the run still says whether
             # the partitioned solve works across these GPUs -- labelled (`transport`, `rccl_error`), and the process still exits non-zero.
-            error_line(e.stage, e.rank, e)
+            error_line(e.stage, e.rank, e, getattr(e, "nccl_debug", None))
             if os.environ.get("HDA_BENCH_NO_FALLBACK"):
                 raise SystemExit(2)
-            self.rccl_error = {"stage": e.stage, "rank": e.rank, "error": str(e)[:400]}
+            self.rccl_error = {"stage": e.stage, "rank": e.rank, "error": str(e)[:400], "nccl_debug": (getattr(e, "nccl_debug", None) or "")[-600:]}
             try:
                 from hypredrive_amd import hypredrv as hd
                 hd.lib().HYPREDRV_AMD_CommFinalize()
@@ -271,12 +316,14 @@ def run(args):
     PHASE["name"] = "timed solves"
     w.barrier()
     hh.sync()
+    hh.load().hda_marker(1)  # (an empty kernel: the solve phase's boundary in traces and counter passes, tools/pmc_traffic.py)
     t0 = time.perf_counter()
     last, solve_timer, vcyc = None, [], 0
     for _ in range(args.steps):
         last = h.apply()
         solve_timer.append(last["solve_s"] * 1e3)
         vcyc = hh.load().hda_last_precond_calls()
+    hh.load().hda_marker(2)
     hh.sync()
     w.barrier()
     dt = w.reduce([time.perf_counter() - t0], "max")[0]
@@ -343,10 +390,13 @@ def run(args):
             "solve_timer_ms": timer_ms, "setup_ms": setup[1], "setup_cold_ms": setup[0],
             "num_levels": amg.num_levels, "operator_complexity": o, "grid_complexity": g,
             "hbm_in_use_gb": hh.memory_stats()[0] / 1e9, "hbm_peak_gb": hh.memory_stats()[1] / 1e9,  # rank 0's allocator: resident / peak
-            # aggregate over the ranks; fractions against n_gpus x 8 TB/s.  CSR-equivalent rate (SURVEY 8(d) bytes / time) and
-            # the rate of bytes really streamed (level 0 is stencil-coded)
-            "solve_phase_hbm_gbs": gbs(by[0], ms_per_step), "solve_phase_hbm_frac": gbs(by[0], ms_per_step) / (HBM_PEAK_GBS * w.size),
-            "solve_phase_format_gbs": gbs(by[1], ms_per_step), "solve_phase_format_frac": gbs(by[1], ms_per_step) / (HBM_PEAK_GBS * w.size),
+            # aggregate over the ranks; fractions against n_gpus x 8 TB/s.  solve_phase_hbm_* = the bytes the kernels really stream (the
+            # formats in HBM: level 0 is stencil-coded, the Galerkin levels windowed) per solve / time; solve_phase_csr_equiv_* = the SURVEY
+            # 8(d) CSR figure of the same solve / time (exceeds what HBM delivers where a format is smaller than CSR: not a bandwidth).
+            # N = 1 at 256^3 adds solve_phase_traffic_gb: FETCH_SIZE / WRITE_SIZE summed over every kernel of one solve
+            "solve_phase_hbm_gbs": gbs(by[1], ms_per_step), "solve_phase_hbm_frac": gbs(by[1], ms_per_step) / (HBM_PEAK_GBS * w.size),
+            "solve_phase_csr_equiv_gbs": gbs(by[0], ms_per_step), "solve_phase_csr_equiv_frac": gbs(by[0], ms_per_step) / (HBM_PEAK_GBS * w.size),
+            "solve_phase_bytes_per_solve": {"format": by[1], "csr_equiv": by[0]},
             "dof_iters_per_s": N * iters / (ms_per_step * 1e-3),
             "roofline": {"kernel": (f"k_spmv_win<JACOBI> on rank 0's block of the level-{dom} operator ({dn} rows, {dnnz} nnz, windowed CSR: fp64 values, "
                                     f"2-byte column positions, {fbd['spmv'] / max(dnnz, 1):.1f} B streamed per entry all told): " if fbd["windowed"] else
@@ -377,7 +427,7 @@ def run(args):
                 out[key] = {"rows": mn, "cols": mc, "nnz": mnnz, "avg_ms": ms, "launches": cnt, "csr_bytes_per_launch": bts,
                             "csr_equiv_gbs": gbs(bts, ms), "csr_equiv_frac": gbs(bts, ms) / HBM_PEAK_GBS}
         if aniso:  # the byte model behind these four is the PCG iteration's: not quoted for GMRES
-            for k in ("solve_phase_hbm_gbs", "solve_phase_hbm_frac", "solve_phase_format_gbs", "solve_phase_format_frac"):
+            for k in ("solve_phase_hbm_gbs", "solve_phase_hbm_frac", "solve_phase_csr_equiv_gbs", "solve_phase_csr_equiv_frac", "solve_phase_bytes_per_solve"):
                 out[k] = None
         if "res0" in pr:
             ms, cnt = pr["res0"]
@@ -385,6 +435,8 @@ def run(args):
             out["level0_residual"] = {"kernel": "k_spmv_stream<RESID> on the level-0 operator (plain CSR), inside the ILU(0) smoothing steps",
                                       "avg_ms": ms, "launches": cnt, "csr_bytes_per_launch": bts, "csr_equiv_gbs": gbs(bts, ms),
                                       "csr_equiv_frac": gbs(bts, ms) / HBM_PEAK_GBS}
+        if not args.child:
+            publish_headline(out)
         if w.size == 1 and not aniso:
             single_extras(args, out, hh, A, amg, fb0, iters)
     del A, amg
@@ -395,8 +447,47 @@ def run(args):
 
 
 def single_extras(args, out, hh, A, amg, fb0, iters):
-    """N = 1 only: the same solve through the kernel-level seam (extra field), the per-kernel table, the plain-CSR
-    child run and the CPU baseline."""
+    """N = 1 only, after the headline has been published: the CPU baseline (part of the line's contract: first), the counter passes
+    behind roofline.traffic and solve_phase_traffic_gb, the same solve through the kernel-level seam, the per-kernel table, the
+    plain-CSR / uncoded child runs, the reference's CPU-build defaults (cpu_defaults) and the aggressive-coarsening option.  All of
+    them share the budget of publish_headline(); one that does not fit is recorded as skipped, by name."""
+    skipped = []
+
+    def fits(name, need_s):
+        if budget_left() >= need_s:
+            return True
+        skipped.append(f"{name} (needs ~{need_s:.0f} s, {max(budget_left(), 0):.0f} s of HDA_BENCH_EXTRAS_BUDGET left)")
+        return False
+
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample or args.n, iters if (args.cpu_sample or args.n) == args.n else None)
+        if "iters_match" in out["cpu_baseline"]:
+            out["iters_match"] = out["cpu_baseline"]["iters_match"]
+    if not args.no_traffic and args.n == 256 and fits("traffic", 30):
+        t, why = measure_traffic(args, limit_s=min(240, budget_left()))
+        rf = out["roofline"]
+        if t is not None:
+            dom_key = [k for k in t if k.startswith("k_spmv_stream_jacobi_level") and k.endswith("_bytes_per_launch")]
+            if dom_key:
+                rf["traffic"] = t[dom_key[0]]
+                rf["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over a one-solve child "
+                                        f"({t['seconds']:.0f} s), tools/pmc_traffic.py; FETCH_SIZE unit calibrated on k_cg_dir: x{t['calibration']['fetch_factor']:.3f}")
+                rf["traffic_over_format_bytes"] = rf["traffic"] / rf["format_bytes_per_launch"]
+            if t.get("k_spmv_level0_bytes_per_launch"):
+                out["level0_spmv"]["traffic"] = t["k_spmv_level0_bytes_per_launch"]
+            for key in ("level0_prolongation", "level0_restriction"):
+                if key in out and t.get(key + "_bytes_per_launch"):
+                    out[key]["traffic"] = t[key + "_bytes_per_launch"]
+            if t.get("solve_phase_traffic_bytes"):
+                # every kernel of ONE solve (the child's --steps 1), counters summed between the two marker kernels; against the format bytes
+                # of the same solve: > 1 = re-reads that missed the caches (FETCH_SIZE counts Infinity-Cache hits too: fabric traffic)
+                fmt = out["solve_phase_bytes_per_solve"]["format"]
+                out["solve_phase_traffic_gb"] = t["solve_phase_traffic_bytes"] / 1e9
+                out["traffic_over_format"] = t["solve_phase_traffic_bytes"] / fmt if fmt else None
+                out["solve_phase_traffic_gbs"] = gbs(t["solve_phase_traffic_bytes"], out["ms_per_step"])
+                out["solve_phase_traffic"] = t.get("solve_phase")
+        else:
+            rf["traffic_source"] = (rf.get("traffic_source") or "no committed profile") + f"; live counter passes failed: {why}"
     kp = hh.KrylovParams.default(False)
     res = hh.solve_device(A, amg, kp, nsolves=args.steps, profile_k1=False)
     sm = sorted(float(x) for x in res["solve_ms"])
@@ -411,31 +502,32 @@ def single_extras(args, out, hh, A, amg, fb0, iters):
                 kt[name]["format_GB/s"] = fb0["vcycle"] / ms / 1e6
         out["kernels"] = kt
     if not args.no_plain_csr and fb0["coded"]:
-        out["plain_csr"] = plain_csr_child(args)
-        out["uncoded"] = plain_csr_child(args, window="1")
-    if not args.no_traffic and args.n == 256:
-        t, why = measure_traffic(args)
-        rf = out["roofline"]
-        if t is not None:
-            dom_key = [k for k in t if k.startswith("k_spmv_stream_jacobi_level") and k.endswith("_bytes_per_launch")]
-            if dom_key:
-                rf["traffic"] = t[dom_key[0]]
-                rf["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over a one-solve child "
-                                        f"({t['seconds']:.0f} s), tools/pmc_traffic.py; FETCH_SIZE unit calibrated on k_cg_dir: x{t['calibration']['fetch_factor']:.3f}")
-                rf["traffic_over_format_bytes"] = rf["traffic"] / rf["format_bytes_per_launch"]
-            if t.get("k_spmv_level0_bytes_per_launch"):
-                out["level0_spmv"]["traffic"] = t["k_spmv_level0_bytes_per_launch"]
-            for key in ("level0_prolongation", "level0_restriction"):
-                if key in out and t.get(key + "_bytes_per_launch"):
-                    out[key]["traffic"] = t[key + "_bytes_per_launch"]
-        else:
-            rf["traffic_source"] = (rf.get("traffic_source") or "no committed profile") + f"; live counter passes failed: {why}"
-    if not args.no_aggressive:
+        if fits("plain_csr", 40):
+            out["plain_csr"] = plain_csr_child(args)
+        if fits("uncoded", 40):
+            out["uncoded"] = plain_csr_child(args, window="1")
+    if not args.no_cpu_defaults and fits("cpu_defaults", 40):
+        out["cpu_defaults"] = cpu_defaults_run(args)
+    if not args.no_aggressive and fits("aggressive_1", 20):
         out["aggressive_1"] = aggressive_run(args, hh)
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample or args.n, iters if (args.cpu_sample or args.n) == args.n else None)
-        if "iters_match" in out["cpu_baseline"]:
-            out["iters_match"] = out["cpu_baseline"]["iters_match"]
+    if skipped:
+        out["extras_skipped"] = skipped
+
+
+def cpu_defaults_run(args):
+    """SURVEY 8(d)'s second series: the same system and API path with the reference's CPU-build defaults (HMIS coarsening, hybrid l1
+    Gauss-Seidel 13 / 14; src/internal/amg.c:141-146, 182-189 -- the configuration its exact pins examples/refOutput/ex1.txt:27 and
+    laplacian.txt:34-38 were made with) on V row blocks = the reference at np = V (V: the setup's own choice, in the object), and the
+    oracle doing the same on the same V (iters_match) when the budget allows its serial setup."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("series_b", os.path.join(ROOT, "tools", "series_b.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        need = 200 if args.n >= 200 else 40  # the oracle's serial setup at 256^3 is about a minute, its block sweeps run on the host threads
+        return mod.run(args.n, steps=max(min(args.steps, 3), 1), warmup=1, oracle=(not args.no_cpu_defaults_oracle) and budget_left() >= need)
+    except Exception as e:  # noqa: BLE001 - an extra must not lose the headline
+        return {"error": repr(e)[:400]}
 
 
 def aggressive_run(args, hh):
@@ -481,8 +573,11 @@ def plain_csr_child(args, window="0"):
     codings are off -- what a variable-coefficient operator of the same sparsity gets with default settings."""
     env = dict(os.environ, HDA_CODED="0", HDA_WINDOW=window)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--grid", str(args.n), "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic"]
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+           "--grid", str(args.n), "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic", "--no-cpu-defaults", "--child"]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=max(min(300.0, budget_left()), 30.0))
+    except subprocess.TimeoutExpired:
+        return {"error": "child run did not finish within its share of the extras budget"}
     for ln in r.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             c = json.loads(ln)
@@ -519,7 +614,7 @@ def measure_traffic(args, limit_s=240):
             # the program itself after `--`: no env / shell hop between the profiler's preloaded library and python
             cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, sub), "-o", "run", "--",
                    sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--grid", str(args.n), "--child",
-                   "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic"]
+                   "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic", "--no-cpu-defaults"]
             left = limit_s - (time.perf_counter() - t0)
             if left < 20:
                 return None, f"counter passes exceeded {limit_s} s"
@@ -555,7 +650,7 @@ def child_bench(extra, nranks, timeout_s):
     me = os.path.abspath(__file__)
     cmd = [sys.executable, me] if nranks == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
                                                     "--master-addr", "127.0.0.1", "--master-port", str(free_port()), me]
-    cmd += ["--gpus", str(nranks), "--child", "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic"] + extra
+    cmd += ["--gpus", str(nranks), "--child", "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic", "--no-cpu-defaults"] + extra
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired:
@@ -618,6 +713,22 @@ def multi_extras(args, out):
     ref["what"] = f"child run on ONE GPU of this node (rank 0's): lap7 {n}^3, the N = 1 point of both series, same run"
     out[f"strong_{n}"] = strong
     out["n1_reference"] = ref
+    # the model the first measured curve is to be read against: what one PCG iteration of the weak run exchanges (counted by the library,
+    # rank 0), priced with DESIGN section 5's assumptions, next to the measured kernel time of the same block on one GPU
+    if ref.get("ms_per_step") and out.get("iters"):
+        lat_x, lat_ar, link = 30.0, 25.0, 153.0  # us per grouped send/recv, us per small all-reduce, GB/s per xGMI link (MI355X_MICROARCH.md)
+        xb = 8.0 * out["halo_doubles_per_iter"]
+        hidden = out["halo_exchanges_overlapped_per_iter"]
+        exposed_us = (out["halo_exchanges_per_iter"] - hidden) * lat_x + out["allreduces_per_iter"] * lat_ar + xb / (link * 1e3)
+        out["comm_model"] = {
+            "per_iteration": {"halo_exchanges": out["halo_exchanges_per_iter"], "of_them_under_a_product_kernel": hidden, "halo_bytes": xb,
+                              "allreduces": out["allreduces_per_iter"], "allreduce_doubles": out["allreduce_doubles_per_iter"]},
+            "assumed": {"exchange_latency_us": lat_x, "allreduce_latency_us": lat_ar, "xgmi_link_GBs": link,
+                        "note": "design estimates (DESIGN section 5), never measured: this run is their first measurement"},
+            "projected_exposed_comm_ms_per_solve": exposed_us * out["iters"] * 1e-3,
+            "n1_kernel_ms_per_solve": ref["ms_per_step"],
+            "projected_weak_ms_per_solve": ref["ms_per_step"] + exposed_us * out["iters"] * 1e-3,
+            "measured_weak_ms_per_solve": out["ms_per_step"]}
     if ref.get("value") and out.get("value") and out["scaling"] == "weak":
         out["speedup_weak_dofs"] = out["value"] / ref["value"]  # DOF/s at N GPUs (N x the rows) over DOF/s at 1 GPU: ideal = N
     if ref.get("ms_per_step") and strong.get("ms_per_step"):
@@ -644,11 +755,14 @@ def main():
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-plain-csr", action="store_true")
     ap.add_argument("--no-aggressive", action="store_true", help="N = 1: skip the side run with one aggressive-coarsening level")
+    ap.add_argument("--no-cpu-defaults", action="store_true", help="N = 1: skip the side run with the reference's CPU-build defaults (HMIS, hybrid l1 Gauss-Seidel)")
+    ap.add_argument("--no-cpu-defaults-oracle", action="store_true", help="cpu_defaults without the oracle's run on the same row blocks (iters_match)")
     ap.add_argument("--no-traffic", action="store_true", help="N = 1, 256^3: skip the two rocprofv3 --pmc passes behind roofline.traffic "
                     "(the committed profiles/traffic.json is quoted instead)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the strong_<grid> and n1_reference child launches")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # a launch made by another bench.py: no further children
     args = ap.parse_args()
+    signal.signal(signal.SIGTERM, _on_term)
     if args.n <= 0:
         args.n = 128 if args.workload == "aniso" else 256
     world = os.environ.get("WORLD_SIZE")
@@ -680,7 +794,7 @@ def main():
                 multi_extras(args, out)
             except Exception as e:  # noqa: BLE001 - the headline is measured: extras must not lose it
                 out["extras_error"] = repr(e)[:400]
-        print(json.dumps(out), flush=True)
+        print_line(out)
         if out.get("rccl_error"):
             sys.exit(2)  # measured over the host-staged transport because RCCL could not be joined: a result line, and a failure
 

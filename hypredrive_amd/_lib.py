@@ -87,7 +87,7 @@ SYMBOLS = [
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
     "hda_thread_ranks_lap7", "hda_thread_world_create", "hda_thread_world_join", "hda_thread_world_leave", "hda_thread_world_destroy", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
     "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass", "hda_truncate_rows",
-    "hda_relax_blocks", "hda_l1_norms_blocks", "hda_hmis_blocks", "hda_amg_blocks", "hda_amg_level_blocks",
+    "hda_marker", "hda_relax_blocks", "hda_l1_norms_blocks", "hda_hmis_blocks", "hda_amg_blocks", "hda_amg_level_blocks",
 ]
 
 
@@ -122,6 +122,7 @@ def load():
     L.hda_l1_norms_blocks.argtypes = [vp, C.c_int, C.c_int, P(C.c_int64), dp]
     L.hda_hmis_blocks.argtypes = [vp, P(C.c_ubyte), C.c_int, P(C.c_int64), C.c_uint64, C.c_int, ip]
     L.hda_amg_blocks.argtypes = [vp]
+    L.hda_marker.argtypes = [C.c_int]
     L.hda_amg_level_blocks.argtypes = [vp, C.c_int, P(C.c_int64)]
     L.hda_strength.argtypes = [vp, C.c_double, C.c_double, P(C.c_ubyte)]
     L.hda_pmis.argtypes = [vp, P(C.c_ubyte), C.c_uint64, C.c_int, C.c_int64, ip]

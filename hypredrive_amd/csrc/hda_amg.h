@@ -84,6 +84,13 @@ struct GsPlan {
    DArray<int> blk_lvl_ptr; // nblk + 1: block q's levels are blk_lvl[blk_lvl_ptr[q] .. blk_lvl_ptr[q + 1]]
    DArray<int> blk_lvl;     // first position of every (block, level); one past the end = nrows
    int         blk_max_levels = 0;
+   // sweep-order copy of the operator (big levels): the rows in perm order, entries contiguous, a column inside the row's block named
+   // by its POSITION in perm, a column outside by ~column -- a level's rows, their entries and (on a grid) their neighbours' values
+   // then sit next to each other, where the row-ordered arrays give every row cache lines of its own
+   mutable DArray<int>    s_rowptr, s_col;
+   mutable DArray<double> s_val;
+   mutable DArray<double> s_x, s_b, s_d; // the sweep's iterate, right-hand side and divisors in sweep order
+   mutable bool           sorted = false;
 };
 void build_gs_plan(const DCsr &A, GsPlan &plan);
 void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &plan);

@@ -3089,8 +3089,7 @@ void Amg::coarse_solve(const double *f, double *u)
 
 FirstSweepFusion &first_sweep_fusion()
 {
-   static thread_local FirstSweepFusion f;
-   return f;
+   return RankState<FirstSweepFusion>::get();
 }
 bool Amg::first_sweep_fusable() const
 {

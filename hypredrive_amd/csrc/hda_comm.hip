@@ -8,11 +8,18 @@
 #include <memory>
 #include <mutex>
 
+// The host driver of this pool supports dmabuf IPC only: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL (and any device memory shared
+// across processes) fails with hipIpcGetMemHandle: invalid argument.  The HIP runtime reads it when it starts, so it goes into the
+// environment when this library is loaded -- before any GPU call of ours -- unless the caller has chosen a value (C callers such
+// as hypredrive-cli and the reference's drivers have no other place to do it; bench.py and hypredrive_amd/dist.py also set it).
+__attribute__((constructor)) static void hda_default_environment() { setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); }
+
 namespace hda {
 
 #define STREAM (Context::get().stream)
 
-static thread_local std::unique_ptr<Comm> g_world; // per host thread, like the context (hda_kernels.hip Context::get)
+// the process's communicator (a thread rank of the test seam has its own, like its context: hda_common.h RankState)
+#define g_world (RankState<std::unique_ptr<Comm>>::get())
 
 Comm &Comm::world()
 {

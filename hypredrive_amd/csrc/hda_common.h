@@ -49,6 +49,43 @@ struct Error : std::runtime_error {
 constexpr int kRedBlocks  = 2048; // 8 blocks (32 waves) per CU on 256 CUs
 constexpr int kRedThreads = 256;
 
+// ---- where the library's state lives.  It is PROCESS-global: the reference's contract (include/HYPREDRV.h:66-70) is "one thread at a
+// time", so initialising on one thread and solving on another is legal, and a handle freed by a finalizer thread must find its
+// allocator.  The thread-rank test seam (hda_thread_ranks.hip: the ranks of a row partition as threads of one process) is the one
+// place where a thread owns state: a thread that has joined a thread world gets private instances of everything below, installed by
+// enter_thread_rank() and destroyed by leave_thread_rank().
+bool in_thread_rank();
+void enter_thread_rank();
+void leave_thread_rank();                     // releases this thread's context, allocator, communicator and the rest of its private state
+void thread_rank_on_leave(void (*drop)());    // (RankState registers the destruction of a private instance)
+template <class T, int Tag = 0>
+struct RankState {
+   static T &get()
+   {
+      if (!in_thread_rank())
+      {
+         static T global;
+         return global;
+      }
+      if (!mine_)
+      {
+         mine_ = new T();
+         thread_rank_on_leave(&drop);
+      }
+      return *mine_;
+   }
+
+ private:
+   static void drop()
+   {
+      delete mine_;
+      mine_ = nullptr;
+   }
+   static thread_local T *mine_;
+};
+template <class T, int Tag>
+thread_local T *RankState<T, Tag>::mine_ = nullptr;
+
 // One per process (per GPU): stream, reduction scratch, pinned scalars.
 struct Context {
    hipStream_t stream      = nullptr;
@@ -62,7 +99,7 @@ struct Context {
    static constexpr int kNumScalars = 320; // recurrence scalars + GMRES Gram-Schmidt coefficients (krylov_dim up to ~300)
 
    static Context &get();
-   static void     release_thread();
+   static void     release_thread(); // (thread ranks: called by leave_thread_rank)
    void            sync() { HDA_HIP(hipStreamSynchronize(stream)); }
    double         *slot(int s) { return partials + (size_t)s * kRedBlocks; }
 

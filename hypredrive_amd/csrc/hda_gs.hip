@@ -108,6 +108,49 @@ static void gs_row_spans(const DCsr &A, const GsPlan &plan)
    plan.span_gen = A.gen;
 }
 
+// ---- sweep-order copy of the operator for the row-block sweeps of big levels
+__global__ __launch_bounds__(256) void k_gs_inverse(int n, const int *__restrict__ perm, const int *__restrict__ rp, int *__restrict__ pos_of,
+                                                    int *__restrict__ len)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q >= n) return;
+   const int i = perm[q];
+   pos_of[i]   = q;
+   len[q]      = rp[i + 1] - rp[i];
+}
+__global__ __launch_bounds__(256) void k_gs_sorted_fill(int n, int nb, const int *__restrict__ part, const int *__restrict__ perm,
+                                                        const int *__restrict__ pos_of, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                        const double *__restrict__ v, const int *__restrict__ srp, int *__restrict__ scj,
+                                                        double *__restrict__ sv)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q >= n) return;
+   const int i = perm[q];
+   int       lo, hi;
+   gs_block_of(part, nb, i, n, lo, hi);
+   int d = srp[q];
+   for (int k = rp[i]; k < rp[i + 1]; k++, d++)
+   { // same entry order as the row: same order of additions as the row-ordered kernel
+      const int c = cj[k];
+      scj[d]      = (c >= lo && c < hi) ? pos_of[c] : ~c;
+      sv[d]       = v[k];
+   }
+}
+static void gs_sorted_copy(const DCsr &A, const GsPlan &plan)
+{
+   const int n = A.nrows;
+   DArray<int> pos_of((size_t)n), len((size_t)n + 1);
+   k_gs_inverse<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), pos_of.data(), len.data());
+   plan.s_rowptr.alloc((size_t)n + 1);
+   exclusive_scan(n, len.data(), plan.s_rowptr.data(), nullptr);
+   plan.s_col.alloc((size_t)std::max(A.nnz, 1));
+   plan.s_val.alloc((size_t)std::max(A.nnz, 1));
+   k_gs_sorted_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.nblk, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
+                                                         A.col.data(), A.val.data(), plan.s_rowptr.data(), plan.s_col.data(), plan.s_val.data());
+   if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); }
+   plan.sorted = true;
+}
+
 // dependency levels of the symmetrised pattern (restricted to the row blocks of part when given): rows in discovery order in
 // plan.perm, level offsets in plan.lvl_ptr; returns the level of every row (host)
 static std::vector<int> gs_levels(const DCsr &A, GsPlan &plan, const int *d_part, int nb)
@@ -218,6 +261,8 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
    plan.blk_lvl_ptr.upload(bl_ptr.data(), bl_ptr.size());
    plan.blk_lvl.upload(bl.data(), bl.size());
    gs_row_spans(A, plan);
+   const int sorted_min = getenv("HDA_GS_SORTED_MIN") ? atoi(getenv("HDA_GS_SORTED_MIN")) : 50000; // (read per plan: the tests move it)
+   if (n >= sorted_min) gs_sorted_copy(A, plan);
    Context::get().sync();
 }
 
@@ -482,6 +527,145 @@ __global__ __launch_bounds__(1024) void k_gs_blocks(int backward, int zero_in, i
    }
 }
 
+// The same sweep on the sweep-order copy (GsPlan::s_*): before it, every unknown's iterate, right-hand side and divisor are brought
+// into sweep order by a kernel of the whole chip; after it the iterate goes back.  Position q of the copy is the row perm[q].
+__global__ __launch_bounds__(256) void k_gs_to_sweep_order(int n, int zero_in, const int *__restrict__ perm, const double *__restrict__ xin,
+                                                           const double *__restrict__ b, const double *__restrict__ dinv,
+                                                           double *__restrict__ sx, double *__restrict__ sb, double *__restrict__ sd)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q >= n) return;
+   const int i = perm[q];
+   sx[q]       = zero_in ? 0.0 : xin[i];
+   sb[q]       = b[i];
+   sd[q]       = dinv[i];
+}
+__global__ __launch_bounds__(256) void k_gs_from_sweep_order(int n, const int *__restrict__ perm, const double *__restrict__ sx, double *__restrict__ xout)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) xout[perm[q]] = sx[q];
+}
+template <int LPR, int NPF>
+__global__ __launch_bounds__(1024) void k_gs_blocks_sorted(int backward, int zero_in, int lds_levels, const int *__restrict__ blk_lvl_ptr,
+                                                           const int *__restrict__ blk_lvl, const int *__restrict__ srp,
+                                                           const int *__restrict__ scj, const double *__restrict__ sv,
+                                                           const double *__restrict__ sd, const double *__restrict__ sb, const double *xin,
+                                                           double *sx)
+{
+   extern __shared__ int slp_lds[];
+   const int blk = blockIdx.x;
+   const int L0 = blk_lvl_ptr[blk], nl = blk_lvl_ptr[blk + 1] - L0;
+   const int tid = threadIdx.x, lane = tid & (LPR - 1), q = tid / LPR;
+   constexpr int RP = 1024 / LPR; // rows per pass
+   const int *slp = blk_lvl + L0;
+   if (nl + 1 <= lds_levels)
+   {
+      for (int t = tid; t <= nl; t += 1024) slp_lds[t] = blk_lvl[L0 + t];
+      slp = slp_lds;
+      __syncthreads();
+   }
+   struct It { int s, p; };
+   auto level = [&](const It &it) { return backward ? nl - 1 - it.s : it.s; };
+   auto advance = [&](It it) {
+      if (it.s >= nl) return it;
+      const int L = level(it);
+      it.p++;
+      if (it.p * RP >= slp[L + 1] - slp[L]) { it.s++; it.p = 0; }
+      return it;
+   };
+   struct RowA { int pos, k0, k1; bool has; };
+   struct RowB { int pos, k0, k1; bool has; int c[NPF]; double a[NPF]; double d, rhs; };
+   auto stage_a = [&](const It &it) {
+      RowA r;
+      r.has = false; r.pos = 0; r.k0 = 0; r.k1 = 0;
+      if (it.s < nl)
+      {
+         const int L = level(it), pos = slp[L] + it.p * RP + q;
+         if (pos < slp[L + 1])
+         {
+            r.has = true;
+            r.pos = pos;
+            r.k0  = srp[pos];
+            r.k1  = srp[pos + 1];
+         }
+      }
+      return r;
+   };
+   auto stage_b = [&](const RowA &ra) {
+      RowB r;
+      r.pos = ra.pos; r.k0 = ra.k0; r.k1 = ra.k1; r.has = ra.has; r.d = 0.0; r.rhs = 0.0;
+#pragma unroll
+      for (int u = 0; u < NPF; u++) { r.c[u] = 0; r.a[u] = 0.0; }
+      if (ra.has)
+      {
+#pragma unroll
+         for (int u = 0; u < NPF; u++)
+         {
+            const int k = ra.k0 + lane + u * LPR;
+            if (k < ra.k1) { r.c[u] = scj[k]; r.a[u] = sv[k]; }
+            else r.a[u] = 0.0; // (c = 0 with a = 0: the value read for it never reaches the sum, see below)
+         }
+         r.d   = sd[ra.pos];
+         r.rhs = sb[ra.pos];
+      }
+      return r;
+   };
+   auto value = [&](int c) { return (c >= 0) ? sx[c] : (zero_in ? 0.0 : xin[~c]); };
+   It   itC = {0, 0}, itB = advance(itC), itA = advance(itB);
+   RowB cur = stage_b(stage_a(itC));
+   RowA nxa = stage_a(itB);
+   while (itC.s < nl)
+   {
+      // the gathers of this pass go out FIRST: loads return in issue order, so requests made before them would have to land before them
+      double xs[NPF];
+      bool   used[NPF];
+#pragma unroll
+      for (int u = 0; u < NPF; u++)
+      {
+         used[u] = cur.has && (cur.k0 + lane + u * LPR < cur.k1);
+         xs[u]   = used[u] ? value(cur.c[u]) : 0.0;
+      }
+      const RowA nx2 = stage_a(itA); // two passes ahead
+      const RowB nxb = stage_b(nxa); // one pass ahead
+      if (cur.has)
+      {
+         double sum = 0.0;
+#pragma unroll
+         for (int u = 0; u < NPF; u++)
+            if (used[u]) sum += cur.a[u] * xs[u];
+         for (int k = cur.k0 + lane + NPF * LPR; k < cur.k1; k += LPR) sum += sv[k] * value(scj[k]); // rows longer than the prefetch
+#pragma unroll
+         for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+         if (lane == 0) sx[cur.pos] += cur.d * (cur.rhs - sum);
+      }
+      const It nextC = itB;
+      if (nextC.s != itC.s)
+      {
+         __threadfence_block();
+         __syncthreads();
+      }
+      itC = nextC;
+      itB = itA;
+      itA = advance(itA);
+      cur = nxb;
+      nxa = nx2;
+   }
+}
+
+template <int LPR, int NPF>
+static void gs_blocks_sorted_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
+                               bool zero_in)
+{
+   const int    n          = A.nrows;
+   const int    lds_levels = std::min(p.blk_max_levels + 1, 12 * 1024);
+   const size_t lds        = sizeof(int) * (size_t)lds_levels;
+   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data());
+   k_gs_blocks_sorted<LPR, NPF><<<p.nblk, 1024, lds, STREAM>>>(forward ? 0 : 1, zero_in ? 1 : 0, lds_levels, p.blk_lvl_ptr.data(), p.blk_lvl.data(),
+                                                              p.s_rowptr.data(), p.s_col.data(), p.s_val.data(), p.s_d.data(), p.s_b.data(), xin,
+                                                              p.s_x.data());
+   k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
+}
+
 template <int LPR, int NPF>
 static void gs_blocks_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
                         bool zero_in)
@@ -499,8 +683,20 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
    HDA_REQUIRE(plan.built && plan.nblk > 0, "row-block Gauss-Seidel plan missing");
    HDA_REQUIRE(zero_in || (xin && xin != xout), "row-block Gauss-Seidel sweeps out of place");
    if (A.nrows == 0) return;
-   if (plan.span_rp != A.rowptr.data() || plan.span_nnz != A.nnz || plan.span_gen != A.gen) gs_row_spans(A, plan);
+   if (plan.span_rp != A.rowptr.data() || plan.span_nnz != A.nnz || plan.span_gen != A.gen)
+   { // another matrix behind a kept plan (preconditioner.reuse)
+      gs_row_spans(A, plan);
+      if (plan.sorted) gs_sorted_copy(A, plan);
+   }
    const double a = A.avg_row();
+   const bool use_sorted = !(getenv("HDA_GS_SORTED") && atoi(getenv("HDA_GS_SORTED")) == 0);
+   if (plan.sorted && use_sorted)
+   {
+      if (a <= 10.0) gs_blocks_sorted_t<2, 4>(A, plan, dinv, b, xin, xout, forward, zero_in); // (two lanes per row: 42.7 -> 41.1 ms per 128^3 solve against four, eight 48.2)
+      else if (a <= 40.0) gs_blocks_sorted_t<8, 8>(A, plan, dinv, b, xin, xout, forward, zero_in);
+      else gs_blocks_sorted_t<16, 8>(A, plan, dinv, b, xin, xout, forward, zero_in);
+      return;
+   }
    if (a <= 10.0) gs_blocks_t<4, 2>(A, plan, dinv, b, xin, xout, forward, zero_in);
    else if (a <= 40.0) gs_blocks_t<8, 8>(A, plan, dinv, b, xin, xout, forward, zero_in);
    else gs_blocks_t<16, 8>(A, plan, dinv, b, xin, xout, forward, zero_in);

@@ -14,8 +14,8 @@ using namespace hda;
 #define STREAM (Context::get().stream)
 
 namespace hda {
-static thread_local std::string g_herr;
-static thread_local int         g_hcode = 0;
+#define g_herr (RankState<std::string, 2>::get())
+#define g_hcode (RankState<int, 2>::get())
 const std::string &hypre_last_error() { return g_herr; }
 int hypre_set_error(int code, const std::string &msg)
 {
@@ -25,7 +25,7 @@ int hypre_set_error(int code, const std::string &msg)
 }
 PrecondHints &precond_hints()
 {
-   static thread_local PrecondHints h;
+   PrecondHints &h = RankState<PrecondHints>::get();
    return h;
 }
 } // namespace hda
@@ -936,7 +936,7 @@ static size_t precond_veclen(HYPRE_Solver s)
 namespace hda {
 static std::unordered_set<const void *> &live_solvers()
 {
-   static thread_local std::unordered_set<const void *> s;
+   std::unordered_set<const void *> &s = RankState<std::unordered_set<const void *>>::get();
    return s;
 }
 void solver_registry(const void *p, int op)
@@ -947,7 +947,7 @@ void solver_registry(const void *p, int op)
 bool is_live_solver(const void *p) { return p && live_solvers().count(p) != 0; }
 } // namespace hda
 
-static thread_local size_t g_precond_veclen = 0;
+#define g_precond_veclen (RankState<size_t, 3>::get())
 extern "C" void hda_register_precond_veclen(size_t n) { g_precond_veclen = n; }
 extern "C" void hda_reset_precond_veclen(void) { g_precond_veclen = 0; }
 

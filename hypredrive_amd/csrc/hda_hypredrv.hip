@@ -30,10 +30,11 @@ using namespace hda;
 
 // ------------------------------------------------------------------- errors
 
-// (thread_local: one caller thread per process is the contract, HYPREDRV.h:66-70; the thread-rank harness runs one rank per thread)
-static thread_local uint32_t    g_err = 0;
-static thread_local std::string g_errmsg;
-static thread_local bool        g_initialized = false;
+// (process-global, as in the reference: the contract of HYPREDRV.h:66-70 is one thread AT A TIME, any thread may make the next call;
+// a thread rank of the test seam has its own copy, hda_common.h RankState)
+#define g_err (RankState<uint32_t, 4>::get())
+#define g_errmsg (RankState<std::string, 4>::get())
+#define g_initialized (RankState<bool, 4>::get())
 
 static uint32_t err_set(uint32_t e, const std::string &msg = "")
 {
@@ -51,6 +52,16 @@ static void err_reset()
    g_errmsg.clear();
    HYPRE_ClearAllErrors();
 }
+// The code-level half of the reference's error state (include/internal/error.h:56-62, src/internal/error.c:920-984): not part of the
+// public header, but the reference's own unit tests (tests/test_setmatrix_from_csr.c:255-459, tests/test_helpers.h) call it between
+// their negative cases, so a drop-in boundary exports it.  Same sticky bits as every HYPREDRV_* call returns.
+extern "C" void     hypredrv_ErrorCodeSet(uint32_t code) { err_set(code); }
+extern "C" uint32_t hypredrv_ErrorCodeGet(void) { return g_err; }
+extern "C" bool     hypredrv_ErrorCodeActive(void) { return g_err != 0; }
+extern "C" void     hypredrv_ErrorCodeReset(uint32_t bits) { g_err &= ~bits; }
+extern "C" void     hypredrv_ErrorCodeResetAll(void) { g_err = 0; }
+extern "C" void     hypredrv_ErrorStateReset(void) { err_reset(); }
+
 // hypredrv_HypreConsumeErrors (reference src/internal/utils.c:33-79): HYPRE_ERROR_CONV and
 // HYPRE_ERROR_ARG are soft, anything else becomes ERROR_HYPRE_INTERNAL
 static void consume_hypre_errors()
@@ -484,8 +495,7 @@ extern "C" uint32_t HYPREDRV_InputArgsSetPreconVariant(HYPREDRV_t h, int idx)
 
 static std::map<std::string, std::string> &user_presets(bool solver)
 {
-   static thread_local std::map<std::string, std::string> p[2];
-   return p[solver ? 1 : 0];
+   return solver ? RankState<std::map<std::string, std::string>, 6>::get() : RankState<std::map<std::string, std::string>, 7>::get();
 }
 extern "C" uint32_t HYPREDRV_PreconPresetRegister(const char *name, const char *yaml, const char *)
 {
@@ -696,8 +706,9 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetInitialGuess(HYPREDRV_t h, HYPRE_Vec
    API_TRY
    if (!h->mat_A) return err_set(ERR_UNKNOWN, "SetInitialGuess needs the matrix first");
    if (h->owns_x0 && h->vec_x0 && h->vec_x0 != vec) HYPRE_IJVectorDestroy(h->vec_x0);
-   if (h->owns_x && h->vec_x) HYPRE_IJVectorDestroy(h->vec_x);
    h->owns_x0 = false;
+   // (the working solution is recreated only at the END: init_guess_mode "previous" reads the last solve's values from it while x0
+   // is built -- reference src/internal/linsys.c:1999-2003, 2046-2068; asserted by its tests/test_init_guess.c:170-199)
    if (vec)
    {
       h->vec_x0 = vec;
@@ -717,10 +728,17 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetInitialGuess(HYPREDRV_t h, HYPRE_Vec
          }
       }
       else if (l.init_guess_mode == 1) h->vec_x0 = new_vector_like(h, 1.0);
-      else if (l.init_guess_mode == 0 || l.init_guess_mode == 2 || l.init_guess_mode == 4) h->vec_x0 = new_vector_like(h, 0.0);
+      else if (l.init_guess_mode == 0 || l.init_guess_mode == 2) h->vec_x0 = new_vector_like(h, 0.0);
+      else if (l.init_guess_mode == 4)
+      { // previous: the last solve's solution when its row range is this system's, zeros otherwise
+         h->vec_x0 = new_vector_like(h, 0.0);
+         if (h->vec_x && h->vec_x->assembled && h->vec_x->jlower == h->vec_x0->jlower && h->vec_x->jupper == h->vec_x0->jupper)
+            HYPRE_ParVectorCopy(h->vec_x, h->vec_x0);
+      }
       else return err_set(ERR_MISSING_LIB, "init_guess_mode random is not supported by this build");
       h->owns_x0 = true;
    }
+   if (h->owns_x && h->vec_x) HYPRE_IJVectorDestroy(h->vec_x);
    h->vec_x  = new_vector_like(h, 0.0);
    h->owns_x = true;
    HYPRE_ParVectorCopy(h->vec_x0, h->vec_x);
@@ -779,26 +797,42 @@ extern "C" uint32_t HYPREDRV_LinearSystemBuild(HYPREDRV_t h)
 
 // CSR ingestion (reference src/internal/linsys.c:1190-1405): buffers are copied, the
 // resulting objects are always owned (include/HYPREDRV.h:830-834 there)
-extern "C" uint32_t HYPREDRV_LinearSystemSetMatrixFromCSR(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_BigInt row_end,
-                                                          const HYPRE_BigInt *indptr, const HYPRE_BigInt *cols,
-                                                          const HYPRE_Real *data)
+// HYPREDRV_LinearSystemSetMatrixFromCSR / SetRHSFromArray (reference src/HYPREDRV.c:2139-2190, 2197-2254 over
+// src/internal/linsys.c:1190-1405, 1412-1491): same order of events and the same refusals, each with ERROR_INVALID_VAL -- the old
+// matrix is released first (a failed build leaves NO matrix behind), row_end < row_start, a negative indptr[0], counts outside
+// HYPRE_Int, a decreasing indptr, missing column / value arrays for a non-empty block; the right-hand side needs a matrix and its
+// exact row range.  The reference's own tests/test_setmatrix_from_csr.c runs against these (oracle/Makefile ref_tests).
+// allow_empty: an EMPTY row block (row_end == row_start - 1), which hypre's IJ layer represents and the reference's entry refuses --
+// only reachable through HYPREDRV_AMD_LinearSystemSetEmptyBlock (row partitions with a rank that owns nothing).
+static uint32_t set_matrix_from_csr(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_BigInt row_end, const HYPRE_BigInt *indptr,
+                                    const HYPRE_BigInt *cols, const HYPRE_Real *data, bool allow_empty)
 {
-   CHECK_INIT_OBJ(h);
-   err_reset();
-   API_TRY
-   if (row_end < row_start - 1 || !indptr) return err_set(ERR_INVALID_VAL, "SetMatrixFromCSR: bad row range or null indptr");
-   const int n = (int)(row_end - row_start + 1);
-   if (n > 0 && (!cols || !data)) return err_set(ERR_INVALID_VAL, "SetMatrixFromCSR: null column or data array");
-   for (int i = 0; i < n; i++)
-      if (indptr[i + 1] < indptr[i]) return err_set(ERR_INVALID_VAL, "SetMatrixFromCSR: indptr must be non-decreasing");
-   annotate(h, "matrix", true);
    if (h->owns_A && h->mat_A) HYPRE_IJMatrixDestroy(h->mat_A);
+   if (h->owns_M && h->mat_M && h->mat_M != h->mat_A) HYPRE_IJMatrixDestroy(h->mat_M);
+   h->mat_A = h->mat_M = nullptr;
+   h->owns_A = h->owns_M = false;
+   if (!indptr) return err_set(ERR_INVALID_VAL, "BuildMatrixFromCSR: mat_ptr and indptr must be non-NULL");
+   if (row_end < row_start && !(allow_empty && row_end == row_start - 1))
+      return err_set(ERR_INVALID_VAL, "BuildMatrixFromCSR: row_end (" + std::to_string((long long)row_end) + ") < row_start (" +
+                                          std::to_string((long long)row_start) + ")");
+   const long long nrows_big = (long long)row_end - (long long)row_start + 1;
+   if (nrows_big > 2147483647LL) return err_set(ERR_INVALID_VAL, "BuildMatrixFromCSR: local row count is out of HYPRE_Int range");
+   const int n = (int)nrows_big;
+   if (indptr[0] < 0) return err_set(ERR_INVALID_VAL, "BuildMatrixFromCSR: indptr[0] must be nonnegative");
+   const long long nnz_big = (long long)indptr[n] - (long long)indptr[0];
+   if (nnz_big < 0) return err_set(ERR_INVALID_VAL, "BuildMatrixFromCSR: indptr[nrows] < indptr[0]");
+   if (nnz_big > 2147483647LL) return err_set(ERR_INVALID_VAL, "BuildMatrixFromCSR: local nonzero count exceeds HYPRE_Int range");
+   if (nnz_big > 0 && (!cols || !data)) return err_set(ERR_INVALID_VAL, "BuildMatrixFromCSR: col_indices/data must be non-NULL when nnz > 0");
+   for (int i = 0; i < n; i++)
+      if (indptr[i + 1] < indptr[i])
+         return err_set(ERR_INVALID_VAL, "BuildMatrixFromCSR: indptr is not monotonically non-decreasing at row " + std::to_string(i));
+   annotate(h, "matrix", true);
    HYPRE_IJMatrix A = nullptr;
    HYPRE_IJMatrixCreate(h->comm, row_start, row_end, row_start, row_end, &A);
    HYPRE_IJMatrixSetObjectType(A, HYPRE_PARCSR);
    HYPRE_IJMatrixInitialize(A);
    const HYPRE_BigInt base = indptr[0];
-   const size_t       nnz  = (size_t)(indptr[n] - base);
+   const size_t       nnz  = (size_t)nnz_big;
    A->t_row.resize(nnz); A->t_col.resize(nnz); A->t_val.resize(nnz); A->t_add.assign(nnz, 0);
    for (int i = 0; i < n; i++)
       for (HYPRE_BigInt k = indptr[i]; k < indptr[i + 1]; k++)
@@ -817,19 +851,23 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetMatrixFromCSR(HYPREDRV_t h, HYPRE_Bi
    h->mat_A = h->mat_M = A;
    h->owns_A           = true;
    annotate(h, "matrix", false);
-   API_CATCH
+   return g_err;
 }
 
-extern "C" uint32_t HYPREDRV_LinearSystemSetRHSFromArray(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_BigInt row_end,
-                                                         const HYPRE_Real *values)
+static uint32_t set_rhs_from_array(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_BigInt row_end, const HYPRE_Real *values, bool allow_empty)
 {
-   CHECK_INIT_OBJ(h);
-   err_reset();
-   API_TRY
-   const int n = (int)(row_end - row_start + 1);
-   if (n < 0 || (n > 0 && !values)) return err_set(ERR_INVALID_VAL, "SetRHSFromArray: bad range or null values");
-   annotate(h, "rhs", true);
+   if (!h->mat_A) return err_set(ERR_INVALID_VAL, "HYPREDRV_LinearSystemSetRHSFromArray: matrix must be set before RHS");
+   if (row_start != h->mat_A->ilower || row_end != h->mat_A->iupper)
+      return err_set(ERR_INVALID_VAL, "HYPREDRV_LinearSystemSetRHSFromArray: RHS row range [" + std::to_string((long long)row_start) + ", " +
+                                          std::to_string((long long)row_end) + "] does not match matrix row range [" +
+                                          std::to_string((long long)h->mat_A->ilower) + ", " + std::to_string((long long)h->mat_A->iupper) + "]");
    if (h->owns_b && h->vec_b) HYPRE_IJVectorDestroy(h->vec_b);
+   h->vec_b  = nullptr;
+   h->owns_b = false;
+   if (row_end < row_start && !(allow_empty && row_end == row_start - 1)) return err_set(ERR_INVALID_VAL, "BuildRHSFromArray: row_end < row_start");
+   const int n = (int)(row_end - row_start + 1);
+   if (!values && !(allow_empty && n == 0)) return err_set(ERR_INVALID_VAL, "BuildRHSFromArray: values must be non-NULL");
+   annotate(h, "rhs", true);
    HYPRE_IJVector b = nullptr;
    HYPRE_IJVectorCreate(h->comm, row_start, row_end, &b);
    HYPRE_IJVectorInitialize(b);
@@ -839,6 +877,40 @@ extern "C" uint32_t HYPREDRV_LinearSystemSetRHSFromArray(HYPREDRV_t h, HYPRE_Big
    h->owns_b = true;
    annotate(h, "rhs", false);
    consume_hypre_errors();
+   return g_err;
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemSetMatrixFromCSR(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_BigInt row_end,
+                                                          const HYPRE_BigInt *indptr, const HYPRE_BigInt *cols,
+                                                          const HYPRE_Real *data)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   return set_matrix_from_csr(h, row_start, row_end, indptr, cols, data, false);
+   API_CATCH
+}
+
+extern "C" uint32_t HYPREDRV_LinearSystemSetRHSFromArray(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_BigInt row_end,
+                                                         const HYPRE_Real *values)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   return set_rhs_from_array(h, row_start, row_end, values, false);
+   API_CATCH
+}
+
+// A rank that owns NO rows of a row-partitioned system: empty matrix block and empty right-hand side at row_start (hypre's IJ layer
+// represents such a rank as [row_start, row_start - 1]; the reference's CSR entry refuses the range, src/internal/linsys.c:1220-1226).
+extern "C" uint32_t HYPREDRV_AMD_LinearSystemSetEmptyBlock(HYPREDRV_t h, HYPRE_BigInt row_start)
+{
+   CHECK_INIT_OBJ(h);
+   err_reset();
+   API_TRY
+   const HYPRE_BigInt ip[1] = {0};
+   if (set_matrix_from_csr(h, row_start, row_start - 1, ip, nullptr, nullptr, true)) return g_err;
+   return set_rhs_from_array(h, row_start, row_start - 1, nullptr, true);
    API_CATCH
 }
 

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <unordered_map>
 
 namespace hda {
@@ -42,16 +43,53 @@ Context::Context()
    HDA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 }
 
-// One context per host THREAD.  The library's contract is one caller thread per process (reference include/HYPREDRV.h:66-70), so a
-// process has exactly one; the thread-rank harness (hda_capi.hip hda_thread_ranks_*: several ranks of a row partition as threads
-// of one process, each with its own stream, allocator and communicator) is the only place where there are more.
+// ---- process-global state with a private copy per thread rank (hda_common.h)
+namespace {
+thread_local bool                        tl_rank = false;
+thread_local std::vector<void (*)()>    *tl_drops = nullptr;
+thread_local Context                    *tl_ctx  = nullptr;
+} // namespace
+bool in_thread_rank() { return tl_rank; }
+void enter_thread_rank()
+{
+   tl_rank = true;
+   if (!tl_drops) tl_drops = new std::vector<void (*)()>();
+}
+void thread_rank_on_leave(void (*drop)())
+{
+   if (tl_drops) tl_drops->push_back(drop);
+}
+void leave_thread_rank()
+{
+   if (!tl_rank) return;
+   Comm::set_world(nullptr);   // this thread's communicator
+   Context::release_thread();  // stream syncs, cached blocks back to the driver, reduction scratch
+   if (tl_drops)
+   {
+      for (size_t q = tl_drops->size(); q-- > 0;) (*tl_drops)[q](); // (a dropper must not create state)
+      delete tl_drops;
+      tl_drops = nullptr;
+   }
+   delete tl_ctx;
+   tl_ctx  = nullptr;
+   tl_rank = false;
+}
+
+// One context per PROCESS (the reference's contract is one thread at a time, include/HYPREDRV.h:66-70: any thread may make the next
+// call); a thread rank of the test seam has its own -- stream, reduction scratch, allocator, communicator.
 Context &Context::get()
 {
-   static thread_local Context ctx;
-   return ctx;
+   if (!tl_rank)
+   {
+      static Context ctx;
+      return ctx;
+   }
+   if (!tl_ctx) tl_ctx = new Context();
+   return *tl_ctx;
 }
 void Context::release_thread()
 { // the thread-rank harness: give back what this thread's context and allocator hold before the thread ends
+   if (!tl_rank || !tl_ctx) return;
    Context &c = get();
    (void)hipStreamSynchronize(c.stream);
    (void)hipStreamSynchronize(c.comm_stream);
@@ -68,15 +106,64 @@ struct Cached {
    void    *p;
    uint64_t stamp; // release order: the oldest blocks go first when the cache is over its limit
 };
+struct Pool;
+// every live block's pool: a block may be released by another thread than the one that asked for it (a finalizer thread of the
+// caller's language runtime; a thread rank's object destroyed after its thread has left) and must find its way home
+std::mutex                          g_pool_mutex; // guards every Pool and the two maps below
+std::unordered_map<void *, Pool *> &block_owner()
+{
+   static std::unordered_map<void *, Pool *> m;
+   return m;
+}
 struct Pool {
    std::multimap<size_t, Cached>      free_;  // size -> block
    std::unordered_map<void *, size_t> size_;  // every block we own
    size_t                             in_use = 0, cached = 0, peak = 0;
    uint64_t                           clock = 0;
+   ~Pool();
 };
-thread_local Pool g_pool; // per thread like the context whose stream orders its blocks
+Pool &process_pool()
+{
+   static Pool *p = new Pool(); // (never destroyed: blocks are released by static destructors of other translation units)
+   return *p;
+}
+thread_local Pool *tl_pool = nullptr; // a thread rank's own pool, like its context whose stream orders its blocks
+void drop_tl_pool()
+{
+   delete tl_pool;
+   tl_pool = nullptr;
+}
+Pool &current_pool()
+{
+   if (!in_thread_rank()) return process_pool();
+   if (!tl_pool)
+   {
+      tl_pool = new Pool();
+      thread_rank_on_leave(&drop_tl_pool);
+   }
+   return *tl_pool;
+}
+Pool::~Pool()
+{ // a thread rank leaves: cached blocks go back to the driver, blocks still in use move to the process's pool
+   std::lock_guard<std::mutex> lk(g_pool_mutex);
+   for (auto &kv : free_)
+   {
+      size_.erase(kv.second.p);
+      block_owner().erase(kv.second.p);
+      (void)hipFree(kv.second.p);
+   }
+   Pool &g = process_pool();
+   if (&g == this) return;
+   for (auto &kv : size_)
+   {
+      g.size_[kv.first] = kv.second;
+      g.in_use += kv.second;
+      block_owner()[kv.first] = &g;
+   }
+}
 constexpr size_t kAlign = 512;
 } // namespace
+#define g_pool (current_pool())
 
 // HDA_POISON=1 (diagnostics): every block handed out is filled with 0xFF bytes (NaN as double, -1 as int) on the library
 // stream first, so a kernel that reads memory nobody wrote fails the tests instead of depending on what the block held before
@@ -94,11 +181,12 @@ static bool guard_on()
    return on;
 }
 constexpr size_t kGuardBytes = 512;
-static thread_local std::unordered_map<void *, size_t> g_guard_at; // block -> offset of its guard tail
+static std::unordered_map<void *, size_t> g_guard_at; // block -> offset of its guard tail (under g_pool_mutex)
 
 void *pool_alloc(size_t bytes)
 {
    if (bytes == 0) return nullptr;
+   std::unique_lock<std::mutex> lk(g_pool_mutex);
    const size_t user = (bytes + kAlign - 1) / kAlign * kAlign;
    const size_t want = user + (guard_on() ? kGuardBytes : 0);
    // best fit, but never waste more than 25 % (+64 KiB) of a cached block
@@ -123,7 +211,9 @@ void *pool_alloc(size_t bytes)
    if (e != hipSuccess)
    {
       (void)hipGetLastError();
+      lk.unlock();
       pool_trim(); // give cached blocks back and retry once
+      lk.lock();
       e = hipMalloc(&p, want);
    }
    if (e != hipSuccess)
@@ -133,6 +223,7 @@ void *pool_alloc(size_t bytes)
       throw Error(buf);
    }
    g_pool.size_[p] = want;
+   block_owner()[p] = &g_pool;
    g_pool.in_use += want;
    g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
    poison(p, want);
@@ -144,10 +235,19 @@ void *pool_alloc(size_t bytes)
    return p;
 }
 
+#undef g_pool
 void pool_free(void *p)
 {
    if (!p) return;
-   auto it = g_pool.size_.find(p);
+   std::lock_guard<std::mutex> lk(g_pool_mutex);
+   auto ow = block_owner().find(p);
+   if (ow == block_owner().end())
+   { // not a block of this allocator (or released twice): say so instead of leaking or corrupting quietly
+      fprintf(stderr, "[hda] pool_free: %p is not a live block of the device allocator (ignored)\n", p);
+      return;
+   }
+   Pool &g_pool = *ow->second; // the pool the block came from, whichever thread releases it
+   auto  it     = g_pool.size_.find(p);
    if (it == g_pool.size_.end()) return;
    if (guard_on())
    {
@@ -190,26 +290,31 @@ void pool_free(void *p)
          if (g_pool.cached <= cap - cap / 4) break; // some slack: not one hipFree per release from here on
          g_pool.cached -= q->first;
          g_pool.size_.erase(q->second.p);
+         block_owner().erase(q->second.p);
          (void)hipFree(q->second.p);
          g_pool.free_.erase(q);
       }
    }
 }
+#define g_pool (current_pool())
 
 void pool_trim()
 {
    (void)hipStreamSynchronize(Context::get().stream);
+   std::lock_guard<std::mutex> lk(g_pool_mutex);
    for (auto &kv : g_pool.free_)
    {
       g_pool.size_.erase(kv.second.p);
+      block_owner().erase(kv.second.p);
       (void)hipFree(kv.second.p);
    }
    g_pool.free_.clear();
    g_pool.cached = 0;
 }
-size_t pool_bytes_in_use() { return g_pool.in_use; }
-size_t pool_bytes_peak() { return g_pool.peak; }
-size_t pool_bytes_cached() { return g_pool.cached; }
+size_t pool_bytes_in_use() { std::lock_guard<std::mutex> lk(g_pool_mutex); return g_pool.in_use; }
+size_t pool_bytes_peak() { std::lock_guard<std::mutex> lk(g_pool_mutex); return g_pool.peak; }
+size_t pool_bytes_cached() { std::lock_guard<std::mutex> lk(g_pool_mutex); return g_pool.cached; }
+#undef g_pool
 
 #define STREAM (Context::get().stream)
 
@@ -1749,7 +1854,7 @@ struct SpmvEpilogue {
    double       *out2  = nullptr;
    bool          done  = false;
 };
-static thread_local SpmvEpilogue g_epilogue;
+#define g_epilogue (RankState<SpmvEpilogue>::get())
 
 template <int MODE, bool DOT>
 static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, double beta,
@@ -1924,7 +2029,7 @@ struct SpmvProbe {
    int                     mode = -1;
    std::vector<hipEvent_t> evs;
 };
-thread_local std::vector<SpmvProbe> g_probes;
+#define g_probes (RankState<std::vector<SpmvProbe>>::get())
 } // namespace
 void spmv_prepare(const DCsr &A)
 {

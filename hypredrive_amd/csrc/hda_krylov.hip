@@ -8,7 +8,7 @@
 
 namespace hda {
 
-static thread_local int g_last_precond_calls = 0;
+#define g_last_precond_calls (RankState<int, 5>::get())
 int last_precond_calls() { return g_last_precond_calls; }
 
 // A Krylov solve that runs INSIDE the preconditioner call of another one (MGR's nested components, reference
@@ -390,8 +390,9 @@ static KrylovResult gmres_core(bool flexible, const LinOp &op, const PrecondFn &
    while (iter < kp.max_iter)
    {
       rs[0] = r_norm;
-      if (r_norm <= epsilon && iter >= kp.min_iter && iter > 0)
-      {
+      if (r_norm <= epsilon && iter >= kp.min_iter)
+      { // (also before the first iteration: hypre_GMRESSolve accepts an initial guess that already meets the tolerance with 0
+        // iterations -- asserted by the reference's own tests/test_init_guess.c:170-199, 247-270)
          true_residual(r.data());
          r_norm = norm2(r.data());
          if (r_norm <= epsilon) { res.converged = true; break; }

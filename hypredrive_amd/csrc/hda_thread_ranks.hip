@@ -2,9 +2,10 @@
 //
 // Why it exists: BASELINE config 3 is a 2x2x2 rank grid (reference examples/src/C_laplacian/laplacian.c:561-582, `-P 2 2 2`),
 // whose coarse levels have edge and corner neighbours (7 peers) that no 1xPxQ layout produces -- and a GPU box admits at most
-// six processes on its card, so eight rank PROCESSES sharing the one GPU cannot be rehearsed there.  Every piece of per-rank
-// state of the library (context + stream, allocator, communicator, error state) is per host thread (hda_kernels.hip
-// Context::get), so eight ranks can run as eight threads of one process over the in-process transport of hda_comm.hip
+// six processes on its card, so eight rank PROCESSES sharing the one GPU cannot be rehearsed there.  The library's state is
+// process-global (hda_common.h); a thread that enters this seam (enter_thread_rank) gets a private copy of every piece of it
+// (context + stream, allocator, communicator, API and error state) until it leaves, so eight ranks can run as eight threads of
+// one process over the in-process transport of hda_comm.hip
 // (ThreadComm: host-staged messages, generation barrier).  Each thread drives the PUBLIC API exactly like one rank of
 // laplacian.c:331-468 does: Initialize, Create, InputArgsParse, (generator), ResetInitialGuess + LinearSolverCreate + Setup +
 // Apply + Destroy, getters.  Nothing here is on the product path.
@@ -33,6 +34,7 @@ struct RankOut {
 void rank_body(int rank, int nranks, const std::shared_ptr<void> &world, const int n[3], const int P[3], const char *yaml, int nsolves, double *x_out,
                const long long *row_start, RankOut &out)
 {
+   enter_thread_rank(); // this thread is one rank: context, allocator, communicator and API state of its own (hda_common.h)
    try
    {
       Comm::set_world(make_thread_comm(rank, world));
@@ -83,8 +85,7 @@ void rank_body(int rank, int nranks, const std::shared_ptr<void> &world, const i
       out.err = std::string("rank ") + std::to_string(rank) + ": " + e.what();
       thread_world_fail(world); // release the ranks waiting for this one
    }
-   Comm::set_world(make_self_comm());
-   Context::release_thread();
+   leave_thread_rank();
    (void)nranks;
 }
 } // namespace
@@ -145,6 +146,7 @@ extern "C" int hda_thread_world_join(void *world, int rank)
    if (!world) return 1;
    try
    {
+      enter_thread_rank();
       Comm::set_world(make_thread_comm(rank, *(std::shared_ptr<void> *)world));
    }
    catch (const std::exception &)
@@ -159,8 +161,7 @@ extern "C" int hda_thread_world_leave(void *world, int failed)
    if (world && failed) thread_world_fail(*(std::shared_ptr<void> *)world);
    try
    {
-      Comm::set_world(make_self_comm());
-      Context::release_thread();
+      leave_thread_rank(); // (blocks this rank still holds move to the process's allocator: whoever releases them later finds them)
    }
    catch (const std::exception &)
    {

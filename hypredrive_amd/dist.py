@@ -77,11 +77,25 @@ def _make_callbacks(dist, torch, rank, world):
 
 class TransportError(RuntimeError):
     """RCCL could not be joined and falling back was not allowed.  stage: uid | init | halo_comm | selftest | devices | peer
-    (peer: this rank was fine, another one failed)."""
+    (peer: this rank was fine, another one failed).  nccl_debug: what RCCL itself logged on this rank (NCCL_DEBUG=WARN)."""
 
-    def __init__(self, stage, rank, msg):
+    def __init__(self, stage, rank, msg, nccl_debug=None):
         super().__init__(msg)
-        self.stage, self.rank = stage, rank
+        self.stage, self.rank, self.nccl_debug = stage, rank, nccl_debug
+
+
+def _rccl_log_path():
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"hda_rccl_{os.getpid()}.log")
+
+
+def rccl_debug_tail(limit=1500):
+    """the tail of this process's RCCL log (NCCL_DEBUG_FILE, set by init() unless the caller chose one); '' when there is none"""
+    path = _keep.get("nccl_debug_file")
+    try:
+        with open(path, errors="replace") as f:
+            return f.read()[-limit:]
+    except (OSError, TypeError):
+        return ""
 
 
 def init(transport="auto", strict=False):
@@ -91,6 +105,14 @@ def init(transport="auto", strict=False):
     rank, world, local = env_rank()
     if world == 1:
         return rank, world
+    # RCCL / device-memory sharing across processes needs dmabuf IPC on this driver, whoever launched the ranks; it is read when the
+    # HIP runtime starts, so it has to be in the environment before the first GPU call of the process (nothing here has made one)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # a first contact that fails should say why: RCCL's own warnings go to a per-process file whose tail joins the error
+    if "NCCL_DEBUG" not in os.environ:
+        os.environ["NCCL_DEBUG"] = "WARN"
+        os.environ.setdefault("NCCL_DEBUG_FILE", _rccl_log_path())
+    _keep["nccl_debug_file"] = os.environ.get("NCCL_DEBUG_FILE")
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -157,7 +179,7 @@ def init(transport="auto", strict=False):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0:
             if forced == "rccl" or strict:
-                raise TransportError(stage or "peer", rank, f"RCCL transport unavailable on some rank (this rank: {err})")
+                raise TransportError(stage or "peer", rank, f"RCCL transport unavailable on some rank (this rank: {err})", rccl_debug_tail())
             if rank == 0:
                 print(f"[hypredrive_amd] RCCL transport unavailable ({err}); using the host-staged transport", file=sys.stderr, flush=True)
             L.HYPREDRV_AMD_CommFinalize()

@@ -65,6 +65,7 @@ def lib():
         "HYPREDRV_AMD_CommInitCallbacks": [C.c_int, C.c_int, C.c_int, ALLREDUCE_CB, ALLTOALLV_CB],
         "HYPREDRV_AMD_CommFinalize": [],
         "HYPREDRV_AMD_LinearSystemSetLaplacian7pt": [vp, ip, ip, dp],
+        "HYPREDRV_AMD_LinearSystemSetEmptyBlock": [vp, C.c_longlong],
         "HYPREDRV_LinearSystemSetDofmap": [vp, C.c_int, ip],
         "HYPREDRV_LinearSystemSetInterleavedDofmap": [vp, C.c_int, C.c_int],
         "HYPREDRV_LinearSystemSetContiguousDofmap": [vp, C.c_int, C.c_int],
@@ -126,6 +127,11 @@ class Hypredrv:
         check(lib().HYPREDRV_InputArgsSetPreconPreset(self.h, precon.encode()))
 
     def set_matrix_csr(self, row_start, row_end, indptr, cols, data):
+        if row_end == row_start - 1:  # a rank that owns nothing: the reference's entry refuses the range, the extension sets matrix AND rhs
+            self._empty_block = True
+            check(lib().HYPREDRV_AMD_LinearSystemSetEmptyBlock(self.h, row_start))
+            return
+        self._empty_block = False
         ip = np.ascontiguousarray(indptr, dtype=np.int64)
         cj = np.ascontiguousarray(cols, dtype=np.int64)
         v = np.ascontiguousarray(data, dtype=np.float64)
@@ -134,6 +140,8 @@ class Hypredrv:
                                                           cj.ctypes.data_as(ll), v.ctypes.data_as(C.POINTER(C.c_double))))
 
     def set_rhs_array(self, row_start, row_end, values):
+        if row_end == row_start - 1 and getattr(self, "_empty_block", False):
+            return  # (set together with the empty matrix block)
         v = np.ascontiguousarray(values, dtype=np.float64)
         check(lib().HYPREDRV_LinearSystemSetRHSFromArray(self.h, row_start, row_end, v.ctypes.data_as(C.POINTER(C.c_double))))
 

@@ -158,6 +158,10 @@ HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_CommInitCallbacks(int rank, int wor
 HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_LinearSystemSetLaplacian7pt(HYPREDRV_t hypredrv, const int n[3],
                                                                          const int P[3], const double c[3]);
 /* Last error text of the MI355X backend (the reference prints through ErrorCodeDescribe). */
+/* A rank that owns no rows of a row-partitioned system: empty matrix block and right-hand side at row_start.  (hypre's IJ layer
+ * represents such a rank; HYPREDRV_LinearSystemSetMatrixFromCSR refuses row_end < row_start like the reference,
+ * src/internal/linsys.c:1220-1226.) */
+HYPREDRV_EXPORT_SYMBOL uint32_t HYPREDRV_AMD_LinearSystemSetEmptyBlock(HYPREDRV_t hypredrv, HYPRE_BigInt row_start);
 HYPREDRV_EXPORT_SYMBOL const char *HYPREDRV_AMD_LastErrorMessage(void);
 /* measurement hook of bench.py: bytes this rank streams per Krylov iteration and per V-cycle,
  * [0] as CSR, [1] in the formats actually read */

@@ -70,6 +70,8 @@ const char *hda_last_error(void);
 int         hda_device_count(void);           /* 0 when no HIP device is visible */
 int         hda_device_name(char *buf, int len);
 int         hda_device_sync(void);
+/* launches the empty kernel hda::k_marker on the library's stream: a boundary that shows in kernel traces and counter passes */
+int         hda_marker(int id);
 
 void hda_amg_default_params(hda_amg_params *p);           /* amg.c:120-238, GPU branch */
 void hda_krylov_default_params(hda_krylov_params *p, int gmres);
@@ -248,8 +250,8 @@ int hda_halo_plan_host(int nloc, const long long *part, const long long *ghost_g
  * product kernel (interior rows computed while the ghost values travel) */
 int hda_comm_stats(double out[5], int reset);
 const char *hda_comm_name(void); /* "self", "rccl", "host-callbacks", "threads" */
-/* Test seam (hda_thread_ranks.hip): `nranks` ranks of a row partition as THREADS of this process -- every piece of per-rank
- * library state is per host thread -- each driving the public HYPREDRV_* sequence of one rank of the reference's
+/* Test seam (hda_thread_ranks.hip): `nranks` ranks of a row partition as THREADS of this process -- the library's state is
+ * process-global, a thread that joins a thread world gets a private copy until it leaves -- each driving the public HYPREDRV_* sequence of one rank of the reference's
  * examples/src/C_laplacian/laplacian.c:331-468 on the generator's 7-pt Laplacian (global grid n, rank grid P with
  * P[0]*P[1]*P[2] == nranks, `-P 2 2 2` = BASELINE config 3's layout, laplacian.c:561-582).  A GPU box admits six processes
  * on its card, so this is how eight ranks are rehearsed on one GPU.  out16: iterations, converged, final relative residual,

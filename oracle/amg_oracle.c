@@ -2674,8 +2674,9 @@ gmres_core(int flexible, const orc_csr *A, orc_amg *h, const orc_krylov_params *
    while (iter < kp->max_iter)
    {
       rs[0] = r_norm;
-      if (r_norm <= epsilon && iter > 0)
-      {
+      if (r_norm <= epsilon)
+      { /* (also before the first iteration: hypre_GMRESSolve accepts an initial guess that already meets the tolerance with 0
+         * iterations -- what the reference's tests/test_init_guess.c:170-199,247-270 assert) */
          /* true residual check */
          memcpy(r, b, sizeof(double) * (size_t)n);
          orc_spmv(A, -1.0, x, 1.0, r);

@@ -67,9 +67,12 @@ def test_block_l1_divisors_bit_exact(orc, hd, kind):
 
 @pytest.mark.parametrize("rtype", GS_TYPES)
 @pytest.mark.parametrize("kind", ["one", "even4", "even37", "ragged", "rows"])
-def test_block_hybrid_gauss_seidel_matches_oracle(orc, hd, rtype, kind):
+@pytest.mark.parametrize("sweep_order_copy", [False, True])
+def test_block_hybrid_gauss_seidel_matches_oracle(orc, hd, monkeypatch, rtype, kind, sweep_order_copy):
     """Gauss-Seidel inside a block, Jacobi across blocks: every block's workgroup reproduces the sequential sweep of its rows on
-    the values the other blocks held when the sweep began"""
+    the values the other blocks held when the sweep began.  sweep_order_copy: the kernel big levels get (operator, iterate,
+    right-hand side and divisors copied into sweep order, HDA_GS_SORTED_MIN rows and more), forced on these small operators."""
+    monkeypatch.setenv("HDA_GS_SORTED_MIN", "0" if sweep_order_copy else "1000000000")
     cases = [(orc.lap7(13, 11, 9, b_mode=1)[0].to_scipy(), 1.0), (mmatrix(1200, 0.008, 11), 0.9), (mmatrix(300, 0.2, 12), 1.0),
              (mmatrix(500, 0.03, 13, unsym=True), 1.0)]
     for M, w in cases:

@@ -47,6 +47,32 @@ def test_pmc_traffic_calibrates_on_cg_dir_and_reports_the_quoted_launches(tmp_pa
     assert out["round"] == "unit" and os.path.exists(tmp_path / "summary.csv")
 
 
+def test_pmc_traffic_sums_the_solve_phase_between_the_markers(tmp_path):
+    """solve_phase_traffic_bytes = calibrated FETCH + WRITE of EVERY dispatch between the two hda::k_marker launches bench.py puts around
+    its timed solve; what runs before the first marker (setup) and after the last one (probe read-outs) does not count."""
+    mod = _load()
+    n = 256 ** 3
+    dir_k = "void hda::k_cg_dir<false>(int, double*, int, int, double const*, double*, double const*)"
+    mark = "hda::k_marker(int, int*)"
+    setup = "void hda::k_spgemm_esc<8, 256>(int)"
+    a, b = "void hda::k_spmv_win<2, false, false, false, false>(int, int const*)", "void hda::k_cg_update<true, true>(int)"
+    seq = [setup, setup, mark, a, dir_k, b, a, mark, setup]
+    fetch = {setup: 5e6, mark: 0.0, a: 900000.0, b: 200000.0, dir_k: 8.0 * n / 1024}
+    write = {setup: 3e6, mark: 0.0, a: 40000.0, b: 260000.0, dir_k: 8.0 * n / 1024}
+    _write(tmp_path / "f", "FETCH_SIZE", [(k, fetch[k]) for k in seq])
+    _write(tmp_path / "w", "WRITE_SIZE", [(k, write[k]) for k in seq])
+    out = mod.compute(str(tmp_path / "f"), str(tmp_path / "w"), "unit")
+    inside = [a, dir_k, b, a]
+    want = sum(2.0 * fetch[k] + write[k] for k in inside) * 1024
+    assert out["solve_phase_traffic_bytes"] == pytest.approx(want)
+    assert out["solve_phase"]["dispatches"] == 4
+    assert out["solve_phase"]["top_kernels"][0]["kernel"].endswith("k_spmv_win<2, false, false, false, false>")
+    # without markers the whole-solve figure is absent rather than guessed
+    _write(tmp_path / "f2", "FETCH_SIZE", [(k, fetch[k]) for k in seq if k != mark])
+    _write(tmp_path / "w2", "WRITE_SIZE", [(k, write[k]) for k in seq if k != mark])
+    assert "solve_phase_traffic_bytes" not in mod.compute(str(tmp_path / "f2"), str(tmp_path / "w2"), "unit")
+
+
 def test_bench_skips_its_counter_passes_when_it_is_being_profiled(monkeypatch):
     """bench.py's own rocprofv3 children must not start under a profiler (a profiler inside a profiler): the committed profile is quoted."""
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))

@@ -108,8 +108,42 @@ def compute(fdir, wdir, tag, summary_csv=None):
                     out[key + "_bytes_per_launch"] = fetch_factor * f * 1024 + write_factor * w * 1024
                     out[key] = {"kernel": "k_spmv_stream / k_spmv_win <0, false, true, false> (value-coded level-0 transfer operator)", "launches": len(sel),
                                 "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w}
+    # the whole solve phase: every dispatch between the two hda::k_marker launches bench.py puts around its timed solves, both counters
+    # summed with the calibrated factors (setup kernels, uploads and the probes' own launches stay outside the markers)
+    sp = solve_phase(F, W, fetch_factor, write_factor)
+    if sp:
+        out.update(sp)
     out["round"] = os.path.basename(tag)
     return out
+
+
+def between_markers(rows):
+    """(dispatch id, kernel, value) rows of the dispatches strictly between the first and the last hda::k_marker launch; None without two markers"""
+    marks = [d for d, k, _ in rows if "k_marker" in k]
+    if len(marks) < 2:
+        return None
+    lo, hi = marks[0], marks[-1]
+    return [(d, k, v) for d, k, v in rows if lo < d < hi]
+
+
+def solve_phase(F, W, fetch_factor, write_factor):
+    f, w = between_markers(F), between_markers(W)
+    if f is None or w is None:
+        return None
+    fk, wk = sum(v for _, _, v in f), sum(v for _, _, v in w)
+    per = defaultdict(lambda: [0, 0.0, 0.0])
+    for _, k, v in f:
+        per[k][0] += 1
+        per[k][1] += v
+    for _, k, v in w:
+        per[k][2] += v
+    top = sorted(per.items(), key=lambda kv: -(fetch_factor * kv[1][1] + write_factor * kv[1][2]))[:8]
+    return {"solve_phase_traffic_bytes": fetch_factor * fk * 1024 + write_factor * wk * 1024,
+            "solve_phase": {"what": "sum over every dispatch between the two hda::k_marker launches around the timed solve(s): "
+                                    "fetch_factor * FETCH_SIZE + write_factor * WRITE_SIZE",
+                            "dispatches": len(f), "FETCH_SIZE_KB_sum": fk, "WRITE_SIZE_KB_sum": wk,
+                            "top_kernels": [{"kernel": k.split("(")[0][-60:], "calls": c, "bytes": fetch_factor * a * 1024 + write_factor * b * 1024}
+                                            for k, (c, a, b) in top]}}
 
 
 def main():
