@@ -84,6 +84,7 @@ struct GsPlan {
    DArray<int> blk_lvl_ptr; // nblk + 1: block q's levels are blk_lvl[blk_lvl_ptr[q] .. blk_lvl_ptr[q + 1]]
    DArray<int> blk_lvl;     // first position of every (block, level); one past the end = nrows
    int         blk_max_levels = 0;
+   double      blk_mean_rows_per_level = 0.0;
    // sweep-order copy of the operator (big levels): the rows in perm order, entries contiguous, a column inside the row's block named
    // by its POSITION in perm, a column outside by ~column -- a level's rows, their entries and (on a grid) their neighbours' values
    // then sit next to each other, where the row-ordered arrays give every row cache lines of its own
@@ -91,6 +92,13 @@ struct GsPlan {
    mutable DArray<double> s_val;
    mutable DArray<double> s_x, s_b, s_d; // the sweep's iterate, right-hand side and divisors in sweep order
    mutable bool           sorted = false;
+   // level-wise form of that copy (k_gs_blocks_ring): the rows of one (block, level) all take the level's widest row's number of
+   // 4-entry chunks, so a row's chunks sit at first chunk of the level + row * width -- no row pointer to chase; r_cb / r_w per
+   // (block, level) in the order of blk_lvl
+   mutable DArray<int>    r_cb, r_w, r_col;
+   mutable DArray<double> r_val;
+   mutable bool           ring = false;
+   std::vector<int>       h_blk_lvl, h_blk_lvl_ptr; // host copies of blk_lvl / blk_lvl_ptr (the copies are rebuilt when a kept plan meets another matrix)
 };
 void build_gs_plan(const DCsr &A, GsPlan &plan);
 void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &plan);

@@ -108,19 +108,23 @@ static void gs_row_spans(const DCsr &A, const GsPlan &plan)
    plan.span_gen = A.gen;
 }
 
-// ---- sweep-order copy of the operator for the row-block sweeps of big levels
+// ---- sweep-order copy of the operator for the row-block sweeps of big levels.  A row is stored as whole CHUNKS of four entries
+// (padded with zero-valued entries that name the row itself), 16-byte aligned: a lane reads a chunk with one 16-byte load of columns
+// and two of values, and the lanes of a wave read neighbouring chunks -- where one entry per lane per load makes every load
+// instruction touch every cache line of the wave's rows (18 line look-ups per load instruction and the address unit 60 % busy in
+// the first form of this kernel, profiles/r04_gs_blocks.md).
 __global__ __launch_bounds__(256) void k_gs_inverse(int n, const int *__restrict__ perm, const int *__restrict__ rp, int *__restrict__ pos_of,
-                                                    int *__restrict__ len)
+                                                    int *__restrict__ len4)
 {
    const int q = blockIdx.x * 256 + threadIdx.x;
    if (q >= n) return;
    const int i = perm[q];
    pos_of[i]   = q;
-   len[q]      = rp[i + 1] - rp[i];
+   len4[q]     = (rp[i + 1] - rp[i] + 3) >> 2;
 }
 __global__ __launch_bounds__(256) void k_gs_sorted_fill(int n, int nb, const int *__restrict__ part, const int *__restrict__ perm,
                                                         const int *__restrict__ pos_of, const int *__restrict__ rp, const int *__restrict__ cj,
-                                                        const double *__restrict__ v, const int *__restrict__ srp, int *__restrict__ scj,
+                                                        const double *__restrict__ v, const int *__restrict__ srp4, int *__restrict__ scj,
                                                         double *__restrict__ sv)
 {
    const int q = blockIdx.x * 256 + threadIdx.x;
@@ -128,27 +132,110 @@ __global__ __launch_bounds__(256) void k_gs_sorted_fill(int n, int nb, const int
    const int i = perm[q];
    int       lo, hi;
    gs_block_of(part, nb, i, n, lo, hi);
-   int d = srp[q];
+   int d = 4 * srp4[q];
+   const int e = 4 * srp4[q + 1];
    for (int k = rp[i]; k < rp[i + 1]; k++, d++)
-   { // same entry order as the row: same order of additions as the row-ordered kernel
+   { // same entry order as the row
       const int c = cj[k];
       scj[d]      = (c >= lo && c < hi) ? pos_of[c] : ~c;
       sv[d]       = v[k];
    }
+   for (; d < e; d++) { scj[d] = q; sv[d] = 0.0; } // padding: 0 * (the row's own value)
 }
 static void gs_sorted_copy(const DCsr &A, const GsPlan &plan)
 {
    const int n = A.nrows;
-   DArray<int> pos_of((size_t)n), len((size_t)n + 1);
-   k_gs_inverse<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), pos_of.data(), len.data());
+   DArray<int> pos_of((size_t)n), len4((size_t)n + 1);
+   k_gs_inverse<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), pos_of.data(), len4.data());
    plan.s_rowptr.alloc((size_t)n + 1);
-   exclusive_scan(n, len.data(), plan.s_rowptr.data(), nullptr);
-   plan.s_col.alloc((size_t)std::max(A.nnz, 1));
-   plan.s_val.alloc((size_t)std::max(A.nnz, 1));
+   exclusive_scan(n, len4.data(), plan.s_rowptr.data(), nullptr);
+   int chunks = 0;
+   HDA_HIP(hipMemcpyAsync(&chunks, plan.s_rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   HDA_REQUIRE(chunks < (1 << 29), "sweep-order copy: too many entries for 32-bit offsets");
+   plan.s_col.alloc((size_t)4 * chunks + 4); // (one spare chunk: the kernel reads a row's first chunk unconditionally)
+   plan.s_val.alloc((size_t)4 * chunks + 4);
+   plan.s_col.zero();
+   plan.s_val.zero();
    k_gs_sorted_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.nblk, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
                                                          A.col.data(), A.val.data(), plan.s_rowptr.data(), plan.s_col.data(), plan.s_val.data());
    if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); }
    plan.sorted = true;
+}
+
+// ---- level-wise sweep-order copy (GsPlan::r_*) for k_gs_blocks_ring
+constexpr int kGsRing = 4096; // doubles of LDS that hold the iterate of the level just swept (and of the one being swept)
+__global__ __launch_bounds__(256) void k_gs_len4(int n, const int *__restrict__ perm, const int *__restrict__ rp, int *__restrict__ len4)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) len4[q] = (rp[perm[q] + 1] - rp[perm[q]] + 3) >> 2;
+}
+__global__ __launch_bounds__(256) void k_gs_ring_fill(int n, int nb, int nlev_total, const int *__restrict__ part, const int *__restrict__ perm,
+                                                      const int *__restrict__ pos_of, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                      const double *__restrict__ v, const int *__restrict__ lvl_first,
+                                                      const int *__restrict__ lvl_cb, const int *__restrict__ lvl_w, int *__restrict__ rcj,
+                                                      double *__restrict__ rv)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q >= n) return;
+   int a = 0, b = nlev_total; // the (block, level) that holds position q: lvl_first[a] <= q < lvl_first[b]
+   while (b - a > 1)
+   {
+      const int m = (a + b) >> 1;
+      if (lvl_first[m] <= q) a = m;
+      else b = m;
+   }
+   const int i = perm[q], w = lvl_w[a];
+   int       lo, hi;
+   gs_block_of(part, nb, i, n, lo, hi);
+   long      d = 4L * (lvl_cb[a] + (long)(q - lvl_first[a]) * w);
+   const long e = d + 4L * w;
+   for (int k = rp[i]; k < rp[i + 1]; k++, d++)
+   {
+      const int c = cj[k];
+      rcj[d]      = (c >= lo && c < hi) ? pos_of[c] : ~c;
+      rv[d]       = v[k];
+   }
+   for (; d < e; d++) { rcj[d] = q; rv[d] = 0.0; }
+}
+static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
+{
+   plan.ring = false;
+   const int n = A.nrows, ng = (int)plan.h_blk_lvl.size() - 1; // (block, level) pairs
+   if (n == 0 || ng <= 0) return;
+   // the ring must hold two consecutive levels of a block, the three per-level tables and the ring must fit the LDS budget
+   for (int q = 0; q < plan.nblk; q++)
+      for (int g = plan.h_blk_lvl_ptr[(size_t)q]; g + 1 < plan.h_blk_lvl_ptr[(size_t)q + 1]; g++)
+         if (plan.h_blk_lvl[(size_t)g + 2] - plan.h_blk_lvl[(size_t)g] > kGsRing) return;
+   if (plan.blk_max_levels + 1 > 2700) return; // (three tables of that length + the ring within 64 KB of LDS)
+   DArray<int> len4((size_t)n), pos_of((size_t)n), dummy((size_t)n);
+   k_gs_inverse<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), pos_of.data(), len4.data());
+   const std::vector<int> hl = len4.to_host();
+   std::vector<int>       cb((size_t)ng + 1, 0), w((size_t)ng, 0);
+   long long              total = 0;
+   for (int g = 0; g < ng; g++)
+   {
+      int mx = 0;
+      for (int q = plan.h_blk_lvl[(size_t)g]; q < plan.h_blk_lvl[(size_t)g + 1]; q++) mx = std::max(mx, hl[(size_t)q]);
+      w[(size_t)g]  = mx;
+      cb[(size_t)g] = (int)total;
+      total += (long long)mx * (plan.h_blk_lvl[(size_t)g + 1] - plan.h_blk_lvl[(size_t)g]);
+      if (total >= (1LL << 29)) return; // 32-bit chunk offsets
+   }
+   cb[(size_t)ng] = (int)total;
+   plan.r_cb.upload(cb.data(), cb.size());
+   plan.r_w.upload(w.data(), w.size());
+   plan.r_col.alloc((size_t)4 * total + 4); // (one spare chunk: a lane without a chunk of its own reads the level's first one)
+   plan.r_val.alloc((size_t)4 * total + 4);
+   plan.r_col.zero();
+   plan.r_val.zero();
+   k_gs_ring_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.nblk, ng, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
+                                                       A.col.data(), A.val.data(), plan.blk_lvl.data(), plan.r_cb.data(), plan.r_w.data(),
+                                                       plan.r_col.data(), plan.r_val.data());
+   if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); }
+   plan.ring = true;
+   if (getenv("HDA_VERBOSE"))
+      fprintf(stderr, "[hda] block Gauss-Seidel plan: level-wise copy, %.2f padded entries per entry\n", 4.0 * (double)total / std::max(A.nnz, 1));
 }
 
 // dependency levels of the symmetrised pattern (restricted to the row blocks of part when given): rows in discovery order in
@@ -257,12 +344,20 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
       plan.blk_max_levels = std::max(plan.blk_max_levels, nl);
    }
    bl.push_back(n);
+   plan.blk_mean_rows_per_level = (double)n / (double)std::max<size_t>(bl.size() - 1, 1);
    plan.perm.upload(hp.data(), (size_t)n);
    plan.blk_lvl_ptr.upload(bl_ptr.data(), bl_ptr.size());
    plan.blk_lvl.upload(bl.data(), bl.size());
+   plan.h_blk_lvl     = bl;
+   plan.h_blk_lvl_ptr = bl_ptr;
    gs_row_spans(A, plan);
    const int sorted_min = getenv("HDA_GS_SORTED_MIN") ? atoi(getenv("HDA_GS_SORTED_MIN")) : 50000; // (read per plan: the tests move it)
-   if (n >= sorted_min) gs_sorted_copy(A, plan);
+   if (n >= sorted_min && plan.blk_max_levels + 1 <= 12 * 1024) gs_sorted_copy(A, plan); // (the kernel keeps a block's level offsets in LDS: 48 KB)
+   if (plan.sorted && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0)) gs_ring_copy(A, plan);
+   if (getenv("HDA_VERBOSE"))
+      fprintf(stderr, "[hda] block Gauss-Seidel plan: n=%d nnz=%d (%.1f per row), %d blocks, dependency levels per block: max %d, mean %.0f (%.0f rows per level)%s\n",
+              n, A.nnz, A.avg_row(), nb, plan.blk_max_levels, (double)(bl.size() - 1) / nb, (double)n / std::max<size_t>(bl.size() - 1, 1),
+              plan.sorted ? ", sweep-order copy" : "");
    Context::get().sync();
 }
 
@@ -545,124 +640,322 @@ __global__ __launch_bounds__(256) void k_gs_from_sweep_order(int n, const int *_
    const int q = blockIdx.x * 256 + threadIdx.x;
    if (q < n) xout[perm[q]] = sx[q];
 }
-template <int LPR, int NPF>
-__global__ __launch_bounds__(1024) void k_gs_blocks_sorted(int backward, int zero_in, int lds_levels, const int *__restrict__ blk_lvl_ptr,
-                                                           const int *__restrict__ blk_lvl, const int *__restrict__ srp,
-                                                           const int *__restrict__ scj, const double *__restrict__ sv,
+// LPR lanes per row, one 4-entry chunk per lane and pass (rows longer than 4 * LPR entries: further chunks in a loop).
+// The loop body is STRAIGHT-LINE code: every load of a pass is issued unconditionally at a clamped, always valid address and its
+// result masked afterwards.  The first form of this kernel wrapped each load in the branch of its condition, and the level offsets
+// sat behind a generic pointer (LDS or memory): the compiler then cannot count the loads in flight and drains ALL of them
+// (s_waitcnt vmcnt(0), flat loads on both counters) at every use -- four to six full memory round trips per pass where one is
+// needed (disassembly in profiles/r04_gs_blocks.md).  Here the level offsets are always in LDS, the gathers of a pass go out first,
+// the requests for the next two passes behind them, and the two software-pipeline stages alternate between two sets of registers
+// (no copies at the end of a pass, which would wait for the loads they copy).
+template <int LPR, int NT>
+__global__ __launch_bounds__(NT) void k_gs_blocks_sorted(int backward, int zero_in, const int *__restrict__ blk_lvl_ptr,
+                                                           const int *__restrict__ blk_lvl, const int *__restrict__ srp4,
+                                                           const int4 *__restrict__ scj4, const double2 *__restrict__ sv2,
                                                            const double *__restrict__ sd, const double *__restrict__ sb, const double *xin,
-                                                           double *sx)
+                                                           double *sx, unsigned long long *diag)
 {
-   extern __shared__ int slp_lds[];
+   extern __shared__ int slp[]; // level offsets of this block (nl + 1 of them)
+   unsigned long long tG = 0, tF = 0, tB = 0, tN = 0, t0 = 0, t1 = 0, tU = 0, tI = 0, tE = 0; // diag: shader-clock sums per phase, passes
    const int blk = blockIdx.x;
    const int L0 = blk_lvl_ptr[blk], nl = blk_lvl_ptr[blk + 1] - L0;
    const int tid = threadIdx.x, lane = tid & (LPR - 1), q = tid / LPR;
-   constexpr int RP = 1024 / LPR; // rows per pass
-   const int *slp = blk_lvl + L0;
-   if (nl + 1 <= lds_levels)
-   {
-      for (int t = tid; t <= nl; t += 1024) slp_lds[t] = blk_lvl[L0 + t];
-      slp = slp_lds;
-      __syncthreads();
-   }
+   constexpr int RP = NT / LPR; // rows per pass
+   for (int t = tid; t <= nl; t += NT) slp[t] = blk_lvl[L0 + t];
+   __syncthreads();
+   if (nl == 0) return;
    struct It { int s, p; };
-   auto level = [&](const It &it) { return backward ? nl - 1 - it.s : it.s; };
+   auto level = [&](const It &it) { const int sc = min(it.s, nl - 1); return backward ? nl - 1 - sc : sc; }; // (clamped past the end)
    auto advance = [&](It it) {
-      if (it.s >= nl) return it;
       const int L = level(it);
       it.p++;
-      if (it.p * RP >= slp[L + 1] - slp[L]) { it.s++; it.p = 0; }
+      if (it.s < nl && it.p * RP >= slp[L + 1] - slp[L]) { it.s++; it.p = 0; }
       return it;
    };
-   struct RowA { int pos, k0, k1; bool has; };
-   struct RowB { int pos, k0, k1; bool has; int c[NPF]; double a[NPF]; double d, rhs; };
+   struct RowA { int pos, c0, c1; bool has; };
+   struct RowB { int pos, c0, c1; bool has, mine; int4 c; double2 a01, a23; double d, rhs; };
    auto stage_a = [&](const It &it) {
       RowA r;
-      r.has = false; r.pos = 0; r.k0 = 0; r.k1 = 0;
-      if (it.s < nl)
-      {
-         const int L = level(it), pos = slp[L] + it.p * RP + q;
-         if (pos < slp[L + 1])
-         {
-            r.has = true;
-            r.pos = pos;
-            r.k0  = srp[pos];
-            r.k1  = srp[pos + 1];
-         }
-      }
+      const int L = level(it), pos = slp[L] + it.p * RP + q;
+      r.has = (it.s < nl) && (pos < slp[L + 1]);
+      r.pos = r.has ? pos : slp[L]; // a valid row either way: the loads below are unconditional
+      r.c0  = srp4[r.pos];
+      r.c1  = srp4[r.pos + 1];
       return r;
    };
    auto stage_b = [&](const RowA &ra) {
       RowB r;
-      r.pos = ra.pos; r.k0 = ra.k0; r.k1 = ra.k1; r.has = ra.has; r.d = 0.0; r.rhs = 0.0;
-#pragma unroll
-      for (int u = 0; u < NPF; u++) { r.c[u] = 0; r.a[u] = 0.0; }
-      if (ra.has)
-      {
-#pragma unroll
-         for (int u = 0; u < NPF; u++)
-         {
-            const int k = ra.k0 + lane + u * LPR;
-            if (k < ra.k1) { r.c[u] = scj[k]; r.a[u] = sv[k]; }
-            else r.a[u] = 0.0; // (c = 0 with a = 0: the value read for it never reaches the sum, see below)
-         }
-         r.d   = sd[ra.pos];
-         r.rhs = sb[ra.pos];
-      }
+      r.pos = ra.pos; r.c0 = ra.c0; r.c1 = ra.c1; r.has = ra.has;
+      const int ch = ra.c0 + lane;
+      r.mine       = ra.has && (ch < ra.c1);
+      const int cc = r.mine ? ch : ra.c0; // (the copy ends with a spare chunk: c0 of an empty last row is still readable)
+      r.c   = scj4[cc];
+      r.a01 = sv2[2 * cc];
+      r.a23 = sv2[2 * cc + 1];
+      r.d   = sd[ra.pos];
+      r.rhs = sb[ra.pos];
       return r;
    };
-   auto value = [&](int c) { return (c >= 0) ? sx[c] : (zero_in ? 0.0 : xin[~c]); };
-   It   itC = {0, 0}, itB = advance(itC), itA = advance(itB);
-   RowB cur = stage_b(stage_a(itC));
-   RowA nxa = stage_a(itB);
-   while (itC.s < nl)
-   {
+   // value of column c: inside the block sx[position], outside it the other blocks' old value xin[~c] (zero_in: 0) -- ONE load
+   auto address = [&](int c, int self) -> const double * { return (c >= 0) ? sx + c : (zero_in ? sx + self : xin + ~c); };
+   auto masked  = [&](int c, double v) { return (c < 0 && zero_in) ? 0.0 : v; };
+   auto pass = [&](const RowB &cur, const RowA &nxa, RowB &nxb, RowA &nx2, const It &itA) {
       // the gathers of this pass go out FIRST: loads return in issue order, so requests made before them would have to land before them
-      double xs[NPF];
-      bool   used[NPF];
-#pragma unroll
-      for (int u = 0; u < NPF; u++)
-      {
-         used[u] = cur.has && (cur.k0 + lane + u * LPR < cur.k1);
-         xs[u]   = used[u] ? value(cur.c[u]) : 0.0;
-      }
-      const RowA nx2 = stage_a(itA); // two passes ahead
-      const RowB nxb = stage_b(nxa); // one pass ahead
+      const double x0 = *address(cur.c.x, cur.pos), x1 = *address(cur.c.y, cur.pos), x2 = *address(cur.c.z, cur.pos),
+                   x3 = *address(cur.c.w, cur.pos);
+      if (diag) { t0 = __builtin_amdgcn_s_memtime(); if (tE) tU += t0 - tE; }
+      nx2 = stage_a(itA); // two passes ahead
+      nxb = stage_b(nxa); // one pass ahead
+      if (diag) { const unsigned long long ti = __builtin_amdgcn_s_memtime(); tI += ti - t0; }
+      double sum = 0.0;
+      sum += cur.a01.x * masked(cur.c.x, x0);
+      sum += cur.a01.y * masked(cur.c.y, x1);
+      sum += cur.a23.x * masked(cur.c.z, x2);
+      sum += cur.a23.y * masked(cur.c.w, x3);
+      if (!cur.mine) sum = 0.0;
       if (cur.has)
+         for (int ch = cur.c0 + lane + LPR; ch < cur.c1; ch += LPR)
+         { // rows longer than 4 * LPR entries
+            const int4    c = scj4[ch];
+            const double2 a = sv2[2 * ch], b2 = sv2[2 * ch + 1];
+            const double  y0 = *address(c.x, cur.pos), y1 = *address(c.y, cur.pos), y2 = *address(c.z, cur.pos), y3 = *address(c.w, cur.pos);
+            sum += a.x * masked(c.x, y0);
+            sum += a.y * masked(c.y, y1);
+            sum += b2.x * masked(c.z, y2);
+            sum += b2.y * masked(c.w, y3);
+         }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      if (lane == 0 && cur.has) sx[cur.pos] += cur.d * (cur.rhs - sum);
+      if (diag)
       {
-         double sum = 0.0;
-#pragma unroll
-         for (int u = 0; u < NPF; u++)
-            if (used[u]) sum += cur.a[u] * xs[u];
-         for (int k = cur.k0 + lane + NPF * LPR; k < cur.k1; k += LPR) sum += sv[k] * value(scj[k]); // rows longer than the prefetch
-#pragma unroll
-         for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-         if (lane == 0) sx[cur.pos] += cur.d * (cur.rhs - sum);
+         t1 = __builtin_amdgcn_s_memtime();
+         tG += t1 - t0 + (unsigned long long)(sum == 12345.678); // (the sum is needed here: the gathers have landed)
+         tN++;
       }
-      const It nextC = itB;
-      if (nextC.s != itC.s)
+   };
+   It   itC = {0, 0}, itB = advance(itC), itA = advance(itB);
+   RowB B0 = stage_b(stage_a(itC)), B1;
+   RowA A1 = stage_a(itB), A0;
+   auto step = [&]() { // after a pass: a barrier when the next one belongs to another level, then the iterators move on
+      if (itB.s != itC.s)
       {
          __threadfence_block();
+         if (diag) { t0 = __builtin_amdgcn_s_memtime(); tF += t0 - t1; }
          __syncthreads();
+         if (diag) { t1 = __builtin_amdgcn_s_memtime(); tB += t1 - t0; }
       }
-      itC = nextC;
+      if (diag) tE = t1;
+      itC = itB;
       itB = itA;
       itA = advance(itA);
-      cur = nxb;
-      nxa = nx2;
+   };
+   while (true)
+   {
+      pass(B0, A1, B1, A0, itA);
+      step();
+      if (itC.s >= nl) break;
+      pass(B1, A0, B0, A1, itA);
+      step();
+      if (itC.s >= nl) break;
+   }
+   if (diag && blk == 0 && (tid & 63) == 0)
+   {
+      unsigned long long *o = diag + 4 * (tid >> 6);
+      o[0] = tG; o[1] = tF; o[2] = tB; o[3] = tN; diag[64 + 2 * (tid >> 6)] = tU; diag[65 + 2 * (tid >> 6)] = tI;
    }
 }
 
-template <int LPR, int NPF>
+// The row-block sweep with the iterate of the level just swept in LDS.  What bounds the kernel above is not bandwidth but the chain
+// of dependent steps per level -- barrier, gather of the values the previous level wrote (a trip to L2 behind the streaming loads of
+// sixteen wavefronts: 1 700-2 000 cycles measured with the shader clock, profiles/r04_gs_blocks.md), arithmetic, store, fence.  Here
+// a row goes through three stages in three consecutive passes:
+//   B  its chunk of the level-wise copy (columns, values), divisor, right-hand side, own old value      (streams, two passes ahead)
+//   X  the values of its columns that are NOT in the level being swept right now -- older levels' stores were fenced before this
+//      pass began, later levels and other blocks still hold the values of the sweep's start: all safe to read one pass early
+//   C  the values of the columns in the level just swept, from the LDS ring where that level's rows left them; sum; update; the new
+//      value goes to the ring and to memory
+// so between two barriers the dependent work is an LDS read, the arithmetic and the stores.  Three register sets rotate (no copies).
+template <int LPR, int NT>
+__global__ __launch_bounds__(NT) void k_gs_blocks_ring(int backward, int zero_in, int lds_levels, const int *__restrict__ blk_lvl_ptr,
+                                                       const int *__restrict__ blk_lvl, const int *__restrict__ lvl_cb,
+                                                       const int *__restrict__ lvl_w, const int4 *__restrict__ rcj4,
+                                                       const double2 *__restrict__ rv2, const double *__restrict__ sd,
+                                                       const double *__restrict__ sb, const double *xin, double *sx)
+{
+   extern __shared__ int lds_i[];
+   int    *lp = lds_i, *cb = lds_i + lds_levels, *wl = lds_i + 2 * lds_levels;
+   double *ring = (double *)(lds_i + 3 * lds_levels + ((3 * lds_levels) & 1));
+   const int blk = blockIdx.x;
+   const int L0 = blk_lvl_ptr[blk], nl = blk_lvl_ptr[blk + 1] - L0;
+   const int tid = threadIdx.x, lane = tid & (LPR - 1), q = tid / LPR;
+   constexpr int RP = NT / LPR; // rows per pass
+   for (int t = tid; t <= nl; t += NT) lp[t] = blk_lvl[L0 + t];
+   for (int t = tid; t < nl; t += NT) { cb[t] = lvl_cb[L0 + t]; wl[t] = lvl_w[L0 + t]; }
+   __syncthreads();
+   if (nl == 0) return;
+   struct It { int s, p; };
+   auto level = [&](const It &it) { const int sc = min(it.s, nl - 1); return backward ? nl - 1 - sc : sc; }; // (clamped past the end)
+   auto advance = [&](It it) {
+      const int L = level(it);
+      it.p++;
+      if (it.s < nl && it.p * RP >= lp[L + 1] - lp[L]) { it.s++; it.p = 0; }
+      return it;
+   };
+   struct Row {
+      int     pos, chunk0, w, ulo, uhi; // position, first chunk, chunks per row of its level, positions of the level swept during its stage X
+      bool    has, mine;
+      int4    c;
+      double2 a01, a23;
+      double  d, rhs, xown, x0, x1, x2, x3;
+   };
+   auto stage_b = [&](Row &r, const It &it) {
+      const int L = level(it), j = it.p * RP + q;
+      r.has       = (it.s < nl) && (j < lp[L + 1] - lp[L]);
+      r.pos       = lp[L] + (r.has ? j : 0);
+      r.w         = wl[L];
+      r.chunk0    = cb[L] + (r.has ? j : 0) * r.w;
+      r.mine      = r.has && (lane < r.w);
+      const int cc = r.mine ? r.chunk0 + lane : cb[L]; // (always readable: the copy ends with a spare chunk)
+      r.c    = rcj4[cc];
+      r.a01  = rv2[2 * cc];
+      r.a23  = rv2[2 * cc + 1];
+      r.d    = sd[r.pos];
+      r.rhs  = sb[r.pos];
+      r.xown = sx[r.pos];
+   };
+   // column c of a row at position self: where its value is read EARLY (stage X) -- a dummy, always valid address when it must wait for the ring
+   auto early = [&](int c, int self, int ulo, int uhi) -> const double * {
+      const bool in_ring = (c >= ulo) && (c < uhi);
+      return (c >= 0) ? sx + (in_ring ? self : c) : (zero_in ? sx + self : xin + ~c);
+   };
+   auto stage_x = [&](Row &r, int ulo, int uhi) {
+      r.ulo = ulo;
+      r.uhi = uhi;
+      r.x0  = *early(r.c.x, r.pos, ulo, uhi);
+      r.x1  = *early(r.c.y, r.pos, ulo, uhi);
+      r.x2  = *early(r.c.z, r.pos, ulo, uhi);
+      r.x3  = *early(r.c.w, r.pos, ulo, uhi);
+   };
+   auto late = [&](int c, double xe, int ulo, int uhi) { // the value used in stage C
+      const double xr = ring[c & (kGsRing - 1)];
+      return (c >= ulo && c < uhi) ? xr : ((c < 0 && zero_in) ? 0.0 : xe);
+   };
+   auto stage_c = [&](const Row &r) {
+      double sum = 0.0;
+      sum += r.a01.x * late(r.c.x, r.x0, r.ulo, r.uhi);
+      sum += r.a01.y * late(r.c.y, r.x1, r.ulo, r.uhi);
+      sum += r.a23.x * late(r.c.z, r.x2, r.ulo, r.uhi);
+      sum += r.a23.y * late(r.c.w, r.x3, r.ulo, r.uhi);
+      if (!r.mine) sum = 0.0;
+      if (r.has)
+         for (int ch = lane + LPR; ch < r.w; ch += LPR)
+         { // rows of a level wider than 4 * LPR entries: the remaining chunks, read now
+            const int4    c = rcj4[r.chunk0 + ch];
+            const double2 a = rv2[2 * (r.chunk0 + ch)], b2 = rv2[2 * (r.chunk0 + ch) + 1];
+            const double  y0 = *early(c.x, r.pos, r.ulo, r.uhi), y1 = *early(c.y, r.pos, r.ulo, r.uhi), y2 = *early(c.z, r.pos, r.ulo, r.uhi),
+                          y3 = *early(c.w, r.pos, r.ulo, r.uhi);
+            sum += a.x * late(c.x, y0, r.ulo, r.uhi);
+            sum += a.y * late(c.y, y1, r.ulo, r.uhi);
+            sum += b2.x * late(c.z, y2, r.ulo, r.uhi);
+            sum += b2.y * late(c.w, y3, r.ulo, r.uhi);
+         }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      if (lane == 0 && r.has)
+      {
+         const double nv           = r.xown + r.d * (r.rhs - sum);
+         ring[r.pos & (kGsRing - 1)] = nv;
+         sx[r.pos]                 = nv;
+      }
+   };
+   It  it0 = {0, 0}, it1 = advance(it0), it2 = advance(it1);
+   Row S0, S1, S2;
+   stage_b(S0, it0);
+   stage_x(S0, 0, 0); // nothing has been swept yet: every value is read from memory
+   stage_b(S1, it1);
+   // one pass: C of this pass's rows first (LDS reads, arithmetic, the stores), then X of the next pass's rows and B of the rows after
+   // them go out -- ten loads per lane, unconditional, in program order behind the store.  Before the barrier a wavefront waits until
+   // at most those ten are outstanding (memory operations retire in issue order: the store has then landed) and for its LDS writes;
+   // the loads stay in flight across the barrier and are consumed one and two passes later.  (__syncthreads' own fence would drain
+   // them: 1 500-2 000 cycles per level, profiles/r04_gs_blocks.md.)
+   auto pass = [&](const Row &c, Row &x, Row &b) {
+      const int Lc = level(it0);
+      stage_c(c);
+      asm volatile("" ::: "memory"); // (no memory operation of X / B may be scheduled above the store)
+      stage_x(x, (it1.s != it0.s) ? lp[Lc] : 0, (it1.s != it0.s) ? lp[Lc + 1] : 0); // (a pass of the SAME level has no column in it)
+      stage_b(b, it2);
+      if (it1.s != it0.s)
+      { // the next pass belongs to another level: this level's stores and ring writes must have landed
+         asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+         __builtin_amdgcn_s_barrier();
+         asm volatile("" ::: "memory");
+      }
+      it0 = it1;
+      it1 = it2;
+      it2 = advance(it2);
+   };
+   while (true)
+   {
+      pass(S0, S1, S2);
+      if (it0.s >= nl) break;
+      pass(S1, S2, S0);
+      if (it0.s >= nl) break;
+      pass(S2, S0, S1);
+      if (it0.s >= nl) break;
+   }
+}
+
+template <int LPR, int NT>
+static void gs_blocks_ring_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
+                             bool zero_in)
+{
+   const int    n          = A.nrows;
+   const int    lds_levels = p.blk_max_levels + 1;
+   const size_t lds        = sizeof(int) * (size_t)(3 * lds_levels + 2) + sizeof(double) * (size_t)kGsRing;
+   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data());
+   k_gs_blocks_ring<LPR, NT><<<p.nblk, NT, lds, STREAM>>>(forward ? 0 : 1, zero_in ? 1 : 0, lds_levels, p.blk_lvl_ptr.data(), p.blk_lvl.data(),
+                                                       p.r_cb.data(), p.r_w.data(), (const int4 *)p.r_col.data(), (const double2 *)p.r_val.data(),
+                                                       p.s_d.data(), p.s_b.data(), xin, p.s_x.data());
+   k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
+}
+
+// HDA_GS_DIAG=1: wave 0..15 of block 0 time their passes with the shader clock (gathers + arithmetic / fence / barrier)
+static unsigned long long *gs_diag_buffer()
+{
+   static const bool        on = getenv("HDA_GS_DIAG") != nullptr;
+   static DArray<unsigned long long> buf;
+   if (!on) return nullptr;
+   if (buf.size() == 0) { buf.alloc(128); buf.zero(); }
+   return buf.data();
+}
+static void gs_diag_report(int lpr, int n)
+{
+   unsigned long long *d = gs_diag_buffer();
+   if (!d) return;
+   static int calls = 0;
+   if (calls++ % 16 > 2) return;
+   unsigned long long h[128];
+   Context::get().sync();
+   HDA_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+   for (int w : {0, 1, 7, 15})
+      fprintf(stderr, "[hda] gs diag n=%d lanes/row=%d wave %2d: passes %llu, cycles per pass: top-of-pass (iterators, addresses, gather issue) %.0f, prefetch issue %.0f, "
+                      "gathers+arithmetic+store %.0f, fence %.0f, barrier %.0f\n", n, lpr, w, h[4 * w + 3], (double)h[64 + 2 * w] / std::max(h[4 * w + 3], 1ull),
+              (double)h[65 + 2 * w] / std::max(h[4 * w + 3], 1ull), (double)(h[4 * w] - h[65 + 2 * w]) / std::max(h[4 * w + 3], 1ull),
+              (double)h[4 * w + 1] / std::max(h[4 * w + 3], 1ull), (double)h[4 * w + 2] / std::max(h[4 * w + 3], 1ull));
+}
+
+template <int LPR, int NT>
 static void gs_blocks_sorted_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
                                bool zero_in)
 {
-   const int    n          = A.nrows;
-   const int    lds_levels = std::min(p.blk_max_levels + 1, 12 * 1024);
-   const size_t lds        = sizeof(int) * (size_t)lds_levels;
+   const int    n   = A.nrows;
+   const size_t lds = sizeof(int) * (size_t)(p.blk_max_levels + 1);
    k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data());
-   k_gs_blocks_sorted<LPR, NPF><<<p.nblk, 1024, lds, STREAM>>>(forward ? 0 : 1, zero_in ? 1 : 0, lds_levels, p.blk_lvl_ptr.data(), p.blk_lvl.data(),
-                                                              p.s_rowptr.data(), p.s_col.data(), p.s_val.data(), p.s_d.data(), p.s_b.data(), xin,
-                                                              p.s_x.data());
+   k_gs_blocks_sorted<LPR, NT><<<p.nblk, NT, lds, STREAM>>>(forward ? 0 : 1, zero_in ? 1 : 0, p.blk_lvl_ptr.data(), p.blk_lvl.data(),
+                                                         p.s_rowptr.data(), (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(),
+                                                         p.s_d.data(), p.s_b.data(), xin, p.s_x.data(), gs_diag_buffer());
+   gs_diag_report(LPR, n);
    k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
 }
 
@@ -687,14 +980,39 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
    { // another matrix behind a kept plan (preconditioner.reuse)
       gs_row_spans(A, plan);
       if (plan.sorted) gs_sorted_copy(A, plan);
+      if (plan.ring) gs_ring_copy(A, plan);
    }
    const double a = A.avg_row();
    const bool use_sorted = !(getenv("HDA_GS_SORTED") && atoi(getenv("HDA_GS_SORTED")) == 0);
    if (plan.sorted && use_sorted)
    {
-      if (a <= 10.0) gs_blocks_sorted_t<2, 4>(A, plan, dinv, b, xin, xout, forward, zero_in); // (two lanes per row: 42.7 -> 41.1 ms per 128^3 solve against four, eight 48.2)
-      else if (a <= 40.0) gs_blocks_sorted_t<8, 8>(A, plan, dinv, b, xin, xout, forward, zero_in);
-      else gs_blocks_sorted_t<16, 8>(A, plan, dinv, b, xin, xout, forward, zero_in);
+      static const int l0 = getenv("HDA_GS_LPR0") ? atoi(getenv("HDA_GS_LPR0")) : 2, l1 = getenv("HDA_GS_LPR1") ? atoi(getenv("HDA_GS_LPR1")) : 8,
+                       l2 = getenv("HDA_GS_LPR2") ? atoi(getenv("HDA_GS_LPR2")) : 16;
+      const int lpr = (a <= 10.0) ? l0 : (a <= 40.0) ? l1 : l2; // lanes per row: 4 entries each per pass
+      // workgroup size: what a typical level of a block keeps busy (every wavefront of the workgroup runs every pass and meets every
+      // barrier, rows or not: idle ones only take issue slots and queue loads in front of the busy ones')
+      static const int nt_env = getenv("HDA_GS_NT") ? atoi(getenv("HDA_GS_NT")) : 0;
+      const double     lanes  = plan.blk_mean_rows_per_level * std::min(std::max(lpr, 2), 16);
+      const int        nt     = nt_env ? nt_env : (lanes <= 192.0 ? 256 : lanes <= 640.0 ? 512 : 1024);
+      const bool ring = plan.ring && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0);
+#define HDA_GS_DISPATCH(L)                                                                              \
+   do                                                                                                   \
+   {                                                                                                    \
+      if (ring)                                                                                         \
+      {                                                                                                 \
+         if (nt <= 256) gs_blocks_ring_t<L, 256>(A, plan, dinv, b, xin, xout, forward, zero_in);        \
+         else if (nt <= 512) gs_blocks_ring_t<L, 512>(A, plan, dinv, b, xin, xout, forward, zero_in);   \
+         else gs_blocks_ring_t<L, 1024>(A, plan, dinv, b, xin, xout, forward, zero_in);                 \
+      }                                                                                                 \
+      else if (nt <= 256) gs_blocks_sorted_t<L, 256>(A, plan, dinv, b, xin, xout, forward, zero_in);    \
+      else if (nt <= 512) gs_blocks_sorted_t<L, 512>(A, plan, dinv, b, xin, xout, forward, zero_in);    \
+      else gs_blocks_sorted_t<L, 1024>(A, plan, dinv, b, xin, xout, forward, zero_in);                  \
+   } while (0)
+      if (lpr <= 2) HDA_GS_DISPATCH(2);
+      else if (lpr <= 4) HDA_GS_DISPATCH(4);
+      else if (lpr <= 8) HDA_GS_DISPATCH(8);
+      else HDA_GS_DISPATCH(16);
+#undef HDA_GS_DISPATCH
       return;
    }
    if (a <= 10.0) gs_blocks_t<4, 2>(A, plan, dinv, b, xin, xout, forward, zero_in);
