@@ -96,8 +96,12 @@ struct GsPlan {
    // 4-entry chunks, so a row's chunks sit at first chunk of the level + row * width -- no row pointer to chase; r_cb / r_w per
    // (block, level) in the order of blk_lvl
    mutable DArray<int>    r_cb, r_w, r_col;
-   mutable DArray<double> r_val;
+   mutable DArray<double> r_val, s_x0; // (s_x0: the iterate at the start of the sweep in sweep order -- what the other blocks' columns read)
    mutable bool           ring = false;
+   // the sweep as a list of PASSES per block and direction (8 ints each: first position, rows, first chunk, chunks per row, the
+   // positions whose values come from the LDS ring, barrier-after flag), so that the kernel's control flow is one scalar load
+   mutable DArray<int>    r_pass[2], r_pass_ptr; // [0] forward, [1] backward; r_pass_ptr: nblk + 1 offsets (in passes, 2 spare ones per block)
+   mutable int            ring_lpr = 0, ring_nt = 0;
    std::vector<int>       h_blk_lvl, h_blk_lvl_ptr; // host copies of blk_lvl / blk_lvl_ptr (the copies are rebuilt when a kept plan meets another matrix)
 };
 void build_gs_plan(const DCsr &A, GsPlan &plan);

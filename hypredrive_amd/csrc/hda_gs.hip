@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_gs_ring_fill(int n, int nb, int nlev_to
    for (int k = rp[i]; k < rp[i + 1]; k++, d++)
    {
       const int c = cj[k];
-      rcj[d]      = (c >= lo && c < hi) ? pos_of[c] : ~c;
+      rcj[d]      = (c >= lo && c < hi) ? pos_of[c] : ~pos_of[c]; // (another block's column: its position in the sweep-START copy)
       rv[d]       = v[k];
    }
    for (; d < e; d++) { rcj[d] = q; rv[d] = 0.0; }
@@ -206,7 +206,10 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
    // the ring must hold two consecutive levels of a block, the three per-level tables and the ring must fit the LDS budget
    for (int q = 0; q < plan.nblk; q++)
       for (int g = plan.h_blk_lvl_ptr[(size_t)q]; g + 1 < plan.h_blk_lvl_ptr[(size_t)q + 1]; g++)
-         if (plan.h_blk_lvl[(size_t)g + 2] - plan.h_blk_lvl[(size_t)g] > kGsRing) return;
+      { // three consecutive levels of a block: the two just swept and the one being swept
+         const int g3 = std::min(g + 3, plan.h_blk_lvl_ptr[(size_t)q + 1]);
+         if (plan.h_blk_lvl[(size_t)g3] - plan.h_blk_lvl[(size_t)g] > kGsRing) return;
+      }
    if (plan.blk_max_levels + 1 > 2700) return; // (three tables of that length + the ring within 64 KB of LDS)
    DArray<int> len4((size_t)n), pos_of((size_t)n), dummy((size_t)n);
    k_gs_inverse<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), pos_of.data(), len4.data());
@@ -233,9 +236,67 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
                                                        A.col.data(), A.val.data(), plan.blk_lvl.data(), plan.r_cb.data(), plan.r_w.data(),
                                                        plan.r_col.data(), plan.r_val.data());
    if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); }
+   plan.s_x0.alloc((size_t)n);
+   // lanes per row and workgroup size of this level's sweeps: what a typical level of a block keeps busy (every wavefront of the
+   // workgroup runs every pass and meets every barrier, rows or not)
+   {
+      const double a  = A.avg_row();
+      const int    l0 = getenv("HDA_GS_LPR0") ? atoi(getenv("HDA_GS_LPR0")) : 2, l1 = getenv("HDA_GS_LPR1") ? atoi(getenv("HDA_GS_LPR1")) : 8,
+                l2 = getenv("HDA_GS_LPR2") ? atoi(getenv("HDA_GS_LPR2")) : 16;
+      int lpr = (a <= 10.0) ? l0 : (a <= 40.0) ? l1 : l2;
+      lpr     = lpr <= 2 ? 2 : lpr <= 4 ? 4 : lpr <= 8 ? 8 : 16;
+      const double lanes = plan.blk_mean_rows_per_level * lpr;
+      const int    nt_e  = getenv("HDA_GS_NT") ? atoi(getenv("HDA_GS_NT")) : 0;
+      int          nt    = nt_e ? nt_e : (lanes <= 192.0 ? 256 : 512); // (1024 threads leave a wavefront 128 registers: 35.0 against 32.7 ms per 128^3 solve)
+      nt                 = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;
+      plan.ring_lpr      = lpr;
+      plan.ring_nt       = nt;
+   }
+   // the pass lists
+   {
+      const int        RP = plan.ring_nt / plan.ring_lpr;
+      std::vector<int> pp((size_t)plan.nblk + 1, 0), rec[2];
+      for (int dir = 0; dir < 2; dir++)
+      {
+         rec[dir].clear();
+         for (int q = 0; q < plan.nblk; q++)
+         {
+            const int g0 = plan.h_blk_lvl_ptr[(size_t)q], g1 = plan.h_blk_lvl_ptr[(size_t)q + 1];
+            if (dir == 0) pp[(size_t)q] = (int)(rec[0].size() / 8);
+            // positions of the TWO levels swept before a level: what its rows read from the ring (contiguous: levels follow each other)
+            int r1lo = 0, r1hi = 0, r2lo = 0, r2hi = 0; // the level before (r1) and the one before that (r2)
+            for (int s2 = 0; s2 < g1 - g0; s2++)
+            {
+               const int g = dir == 0 ? g0 + s2 : g1 - 1 - s2;
+               const int first = plan.h_blk_lvl[(size_t)g], rows = plan.h_blk_lvl[(size_t)g + 1] - first, wg = w[(size_t)g];
+               const int np = std::max((rows + RP - 1) / RP, 1);
+               int       ulo = 0, uhi = 0;
+               if (r1hi > r1lo) { ulo = r1lo; uhi = r1hi; }
+               if (r2hi > r2lo) { ulo = std::min(ulo, r2lo); uhi = std::max(uhi, r2hi); }
+               for (int p2 = 0; p2 < np; p2++)
+               {
+                  const int j0 = p2 * RP, r = std::min(rows - j0, RP);
+                  const int last = (p2 == np - 1);
+                  const int v8[8] = {first + j0, std::max(r, 0), cb[(size_t)g] + j0 * wg, wg, ulo, uhi, last, 0};
+                  rec[dir].insert(rec[dir].end(), v8, v8 + 8);
+               }
+               r2lo = r1lo; r2hi = r1hi;
+               r1lo = first; r1hi = first + rows;
+            }
+            // three spare passes without rows behind every block: the pipeline reads three passes ahead
+            const int safe_pos = std::min(plan.h_blk_lvl[(size_t)g0 < plan.h_blk_lvl.size() ? (size_t)g0 : 0], std::max(n - 1, 0));
+            const int v8[8]    = {safe_pos, 0, (int)total, 0, 0, 0, 0, 0};
+            for (int k2 = 0; k2 < 3; k2++) rec[dir].insert(rec[dir].end(), v8, v8 + 8);
+         }
+         if (dir == 0) pp[(size_t)plan.nblk] = (int)(rec[0].size() / 8);
+         plan.r_pass[dir].upload(rec[dir].data(), rec[dir].size());
+      }
+      plan.r_pass_ptr.upload(pp.data(), pp.size());
+   }
    plan.ring = true;
    if (getenv("HDA_VERBOSE"))
-      fprintf(stderr, "[hda] block Gauss-Seidel plan: level-wise copy, %.2f padded entries per entry\n", 4.0 * (double)total / std::max(A.nnz, 1));
+      fprintf(stderr, "[hda] block Gauss-Seidel plan: level-wise copy, %.2f padded entries per entry, %d lanes per row, workgroups of %d\n",
+              4.0 * (double)total / std::max(A.nnz, 1), plan.ring_lpr, plan.ring_nt);
 }
 
 // dependency levels of the symmetrised pattern (restricted to the row blocks of part when given): rows in discovery order in
@@ -351,7 +412,7 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
    plan.h_blk_lvl     = bl;
    plan.h_blk_lvl_ptr = bl_ptr;
    gs_row_spans(A, plan);
-   const int sorted_min = getenv("HDA_GS_SORTED_MIN") ? atoi(getenv("HDA_GS_SORTED_MIN")) : 50000; // (read per plan: the tests move it)
+   const int sorted_min = getenv("HDA_GS_SORTED_MIN") ? atoi(getenv("HDA_GS_SORTED_MIN")) : 2000; // (read per plan: the tests move it)
    if (n >= sorted_min && plan.blk_max_levels + 1 <= 12 * 1024) gs_sorted_copy(A, plan); // (the kernel keeps a block's level offsets in LDS: 48 KB)
    if (plan.sorted && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0)) gs_ring_copy(A, plan);
    if (getenv("HDA_VERBOSE"))
@@ -626,12 +687,15 @@ __global__ __launch_bounds__(1024) void k_gs_blocks(int backward, int zero_in, i
 // into sweep order by a kernel of the whole chip; after it the iterate goes back.  Position q of the copy is the row perm[q].
 __global__ __launch_bounds__(256) void k_gs_to_sweep_order(int n, int zero_in, const int *__restrict__ perm, const double *__restrict__ xin,
                                                            const double *__restrict__ b, const double *__restrict__ dinv,
-                                                           double *__restrict__ sx, double *__restrict__ sb, double *__restrict__ sd)
+                                                           double *__restrict__ sx, double *__restrict__ sb, double *__restrict__ sd,
+                                                           double *__restrict__ sx0 = nullptr)
 {
    const int q = blockIdx.x * 256 + threadIdx.x;
    if (q >= n) return;
-   const int i = perm[q];
-   sx[q]       = zero_in ? 0.0 : xin[i];
+   const int    i = perm[q];
+   const double x = zero_in ? 0.0 : xin[i];
+   sx[q]          = x;
+   if (sx0) sx0[q] = x; // (the ring kernel reads the other blocks' columns from this copy, which the sweep leaves alone)
    sb[q]       = b[i];
    sd[q]       = dinv[i];
 }
@@ -766,57 +830,52 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_sorted(int backward, int zero_
    }
 }
 
-// The row-block sweep with the iterate of the level just swept in LDS.  What bounds the kernel above is not bandwidth but the chain
+// The row-block sweep with the iterate of the level just swept in LDS.  What bounds the kernels above is not bandwidth but the chain
 // of dependent steps per level -- barrier, gather of the values the previous level wrote (a trip to L2 behind the streaming loads of
-// sixteen wavefronts: 1 700-2 000 cycles measured with the shader clock, profiles/r04_gs_blocks.md), arithmetic, store, fence.  Here
-// a row goes through three stages in three consecutive passes:
+// sixteen wavefronts: 1 700-2 000 cycles measured with the shader clock), arithmetic, store, fence -- and, once those are shortened,
+// the number of INSTRUCTIONS a wavefront issues per pass (450 in the first form of this kernel: iterators over LDS tables, address
+// selects for three kinds of columns; profiles/r04_gs_blocks.md).  Here a row goes through three stages in three consecutive passes:
 //   B  its chunk of the level-wise copy (columns, values), divisor, right-hand side, own old value      (streams, two passes ahead)
-//   X  the values of its columns that are NOT in the level being swept right now -- older levels' stores were fenced before this
-//      pass began, later levels and other blocks still hold the values of the sweep's start: all safe to read one pass early
+//   X  the values of its columns that are NOT in the level being swept right now -- older levels' stores have landed before this
+//      pass began, later levels still hold the values of the sweep's start, other blocks' columns name the sweep-start copy: all
+//      safe to read one pass early
 //   C  the values of the columns in the level just swept, from the LDS ring where that level's rows left them; sum; update; the new
 //      value goes to the ring and to memory
-// so between two barriers the dependent work is an LDS read, the arithmetic and the stores.  Three register sets rotate (no copies).
+// so between two barriers the dependent work is an LDS read, the arithmetic and the stores.  B runs three passes ahead of C and X two:
+// a value requested in one pass is not needed before the pass after the next (a request made in the pass before its use waited out
+// its whole latency at the top of that pass: 33.6 ms per 128^3 solve either way).  The ring therefore holds the TWO levels swept
+// last, and the plan keeps three consecutive levels of a block within its kGsRing slots.  Four register sets rotate (no copies).
+// The control flow is a LIST OF PASSES made at plan time (GsPlan::r_pass): one scalar load per pass.
+struct GsPass { int pos0, rows, chunk0, w, ulo, uhi, last, pad; };
 template <int LPR, int NT>
-__global__ __launch_bounds__(NT) void k_gs_blocks_ring(int backward, int zero_in, int lds_levels, const int *__restrict__ blk_lvl_ptr,
-                                                       const int *__restrict__ blk_lvl, const int *__restrict__ lvl_cb,
-                                                       const int *__restrict__ lvl_w, const int4 *__restrict__ rcj4,
-                                                       const double2 *__restrict__ rv2, const double *__restrict__ sd,
-                                                       const double *__restrict__ sb, const double *xin, double *sx)
+__global__ __launch_bounds__(NT) void k_gs_blocks_ring(const int *__restrict__ pass_ptr, const GsPass *__restrict__ passes,
+                                                       const int4 *__restrict__ rcj4, const double2 *__restrict__ rv2,
+                                                       const double *__restrict__ sd, const double *__restrict__ sb,
+                                                       const double *__restrict__ sx0, double *sx, unsigned long long *diag)
 {
-   extern __shared__ int lds_i[];
-   int    *lp = lds_i, *cb = lds_i + lds_levels, *wl = lds_i + 2 * lds_levels;
-   double *ring = (double *)(lds_i + 3 * lds_levels + ((3 * lds_levels) & 1));
-   const int blk = blockIdx.x;
-   const int L0 = blk_lvl_ptr[blk], nl = blk_lvl_ptr[blk + 1] - L0;
-   const int tid = threadIdx.x, lane = tid & (LPR - 1), q = tid / LPR;
-   constexpr int RP = NT / LPR; // rows per pass
-   for (int t = tid; t <= nl; t += NT) lp[t] = blk_lvl[L0 + t];
-   for (int t = tid; t < nl; t += NT) { cb[t] = lvl_cb[L0 + t]; wl[t] = lvl_w[L0 + t]; }
-   __syncthreads();
-   if (nl == 0) return;
-   struct It { int s, p; };
-   auto level = [&](const It &it) { const int sc = min(it.s, nl - 1); return backward ? nl - 1 - sc : sc; }; // (clamped past the end)
-   auto advance = [&](It it) {
-      const int L = level(it);
-      it.p++;
-      if (it.s < nl && it.p * RP >= lp[L + 1] - lp[L]) { it.s++; it.p = 0; }
-      return it;
-   };
+   __shared__ double ring[kGsRing];
+   unsigned long long tc = 0, ti = 0, tw = 0, tb = 0, tn = 0, ta = 0, tz = 0;
+   const int      blk = blockIdx.x, np = pass_ptr[blk + 1] - pass_ptr[blk] - 3; // (three spare passes close every block's list)
+   const GsPass  *pl  = passes + pass_ptr[blk];
+   const int      tid = threadIdx.x, lane = tid & (LPR - 1), q = tid / LPR;
+   if (np <= 0) return;
    struct Row {
-      int     pos, chunk0, w, ulo, uhi; // position, first chunk, chunks per row of its level, positions of the level swept during its stage X
-      bool    has, mine;
+      int     pos, chunk0, w, ulo, uhi;
+      bool    has, mine, r0, r1, r2, r3; // (r_u: column u is read from the ring)
       int4    c;
       double2 a01, a23;
       double  d, rhs, xown, x0, x1, x2, x3;
    };
-   auto stage_b = [&](Row &r, const It &it) {
-      const int L = level(it), j = it.p * RP + q;
-      r.has       = (it.s < nl) && (j < lp[L + 1] - lp[L]);
-      r.pos       = lp[L] + (r.has ? j : 0);
-      r.w         = wl[L];
-      r.chunk0    = cb[L] + (r.has ? j : 0) * r.w;
-      r.mine      = r.has && (lane < r.w);
-      const int cc = r.mine ? r.chunk0 + lane : cb[L]; // (always readable: the copy ends with a spare chunk)
+   auto stage_b = [&](Row &r, const GsPass &p) {
+      r.has       = q < p.rows;
+      const int j = r.has ? q : 0;
+      r.pos       = p.pos0 + j;
+      r.w         = p.w;
+      r.ulo       = p.ulo;
+      r.uhi       = p.uhi;
+      r.chunk0    = p.chunk0 + j * p.w;
+      r.mine      = r.has && (lane < p.w);
+      const int cc = r.mine ? r.chunk0 + lane : p.chunk0; // (always readable: the copy ends with a spare chunk)
       r.c    = rcj4[cc];
       r.a01  = rv2[2 * cc];
       r.a23  = rv2[2 * cc + 1];
@@ -824,110 +883,144 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_ring(int backward, int zero_in
       r.rhs  = sb[r.pos];
       r.xown = sx[r.pos];
    };
-   // column c of a row at position self: where its value is read EARLY (stage X) -- a dummy, always valid address when it must wait for the ring
-   auto early = [&](int c, int self, int ulo, int uhi) -> const double * {
-      const bool in_ring = (c >= ulo) && (c < uhi);
-      return (c >= 0) ? sx + (in_ring ? self : c) : (zero_in ? sx + self : xin + ~c);
-   };
-   auto stage_x = [&](Row &r, int ulo, int uhi) {
-      r.ulo = ulo;
-      r.uhi = uhi;
-      r.x0  = *early(r.c.x, r.pos, ulo, uhi);
-      r.x1  = *early(r.c.y, r.pos, ulo, uhi);
-      r.x2  = *early(r.c.z, r.pos, ulo, uhi);
-      r.x3  = *early(r.c.w, r.pos, ulo, uhi);
-   };
-   auto late = [&](int c, double xe, int ulo, int uhi) { // the value used in stage C
-      const double xr = ring[c & (kGsRing - 1)];
-      return (c >= ulo && c < uhi) ? xr : ((c < 0 && zero_in) ? 0.0 : xe);
+   // where column c is read early: its own position (sweep-order iterate), ~position of another block's column (sweep-start copy), or
+   // -- when its value must wait for the ring -- the row's own slot, which is always valid
+   auto early = [&](int c, int self, bool in_ring) -> const double * { return (c >= 0) ? sx + (in_ring ? self : c) : sx0 + ~c; };
+   auto stage_x = [&](Row &r) {
+      r.r0 = (r.c.x >= r.ulo) && (r.c.x < r.uhi);
+      r.r1 = (r.c.y >= r.ulo) && (r.c.y < r.uhi);
+      r.r2 = (r.c.z >= r.ulo) && (r.c.z < r.uhi);
+      r.r3 = (r.c.w >= r.ulo) && (r.c.w < r.uhi);
+      r.x0 = *early(r.c.x, r.pos, r.r0);
+      r.x1 = *early(r.c.y, r.pos, r.r1);
+      r.x2 = *early(r.c.z, r.pos, r.r2);
+      r.x3 = *early(r.c.w, r.pos, r.r3);
    };
    auto stage_c = [&](const Row &r) {
+      const double y0 = ring[r.c.x & (kGsRing - 1)], y1 = ring[r.c.y & (kGsRing - 1)], y2 = ring[r.c.z & (kGsRing - 1)],
+                   y3 = ring[r.c.w & (kGsRing - 1)];
       double sum = 0.0;
-      sum += r.a01.x * late(r.c.x, r.x0, r.ulo, r.uhi);
-      sum += r.a01.y * late(r.c.y, r.x1, r.ulo, r.uhi);
-      sum += r.a23.x * late(r.c.z, r.x2, r.ulo, r.uhi);
-      sum += r.a23.y * late(r.c.w, r.x3, r.ulo, r.uhi);
+      sum += r.a01.x * (r.r0 ? y0 : r.x0);
+      sum += r.a01.y * (r.r1 ? y1 : r.x1);
+      sum += r.a23.x * (r.r2 ? y2 : r.x2);
+      sum += r.a23.y * (r.r3 ? y3 : r.x3);
       if (!r.mine) sum = 0.0;
       if (r.has)
          for (int ch = lane + LPR; ch < r.w; ch += LPR)
          { // rows of a level wider than 4 * LPR entries: the remaining chunks, read now
             const int4    c = rcj4[r.chunk0 + ch];
             const double2 a = rv2[2 * (r.chunk0 + ch)], b2 = rv2[2 * (r.chunk0 + ch) + 1];
-            const double  y0 = *early(c.x, r.pos, r.ulo, r.uhi), y1 = *early(c.y, r.pos, r.ulo, r.uhi), y2 = *early(c.z, r.pos, r.ulo, r.uhi),
-                          y3 = *early(c.w, r.pos, r.ulo, r.uhi);
-            sum += a.x * late(c.x, y0, r.ulo, r.uhi);
-            sum += a.y * late(c.y, y1, r.ulo, r.uhi);
-            sum += b2.x * late(c.z, y2, r.ulo, r.uhi);
-            sum += b2.y * late(c.w, y3, r.ulo, r.uhi);
+            const bool    i0 = (c.x >= r.ulo) && (c.x < r.uhi), i1 = (c.y >= r.ulo) && (c.y < r.uhi), i2 = (c.z >= r.ulo) && (c.z < r.uhi),
+                       i3 = (c.w >= r.ulo) && (c.w < r.uhi);
+            const double  e0 = *early(c.x, r.pos, i0), e1 = *early(c.y, r.pos, i1), e2 = *early(c.z, r.pos, i2), e3 = *early(c.w, r.pos, i3);
+            sum += a.x * (i0 ? ring[c.x & (kGsRing - 1)] : e0);
+            sum += a.y * (i1 ? ring[c.y & (kGsRing - 1)] : e1);
+            sum += b2.x * (i2 ? ring[c.z & (kGsRing - 1)] : e2);
+            sum += b2.y * (i3 ? ring[c.w & (kGsRing - 1)] : e3);
          }
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
       if (lane == 0 && r.has)
       {
-         const double nv           = r.xown + r.d * (r.rhs - sum);
+         const double nv             = r.xown + r.d * (r.rhs - sum);
          ring[r.pos & (kGsRing - 1)] = nv;
-         sx[r.pos]                 = nv;
+         sx[r.pos]                   = nv;
       }
    };
-   It  it0 = {0, 0}, it1 = advance(it0), it2 = advance(it1);
-   Row S0, S1, S2;
-   stage_b(S0, it0);
-   stage_x(S0, 0, 0); // nothing has been swept yet: every value is read from memory
-   stage_b(S1, it1);
-   // one pass: C of this pass's rows first (LDS reads, arithmetic, the stores), then X of the next pass's rows and B of the rows after
-   // them go out -- ten loads per lane, unconditional, in program order behind the store.  Before the barrier a wavefront waits until
-   // at most those ten are outstanding (memory operations retire in issue order: the store has then landed) and for its LDS writes;
-   // the loads stay in flight across the barrier and are consumed one and two passes later.  (__syncthreads' own fence would drain
-   // them: 1 500-2 000 cycles per level, profiles/r04_gs_blocks.md.)
+   Row S0, S1, S2, S3;
+   stage_b(S0, pl[0]);
+   stage_b(S1, pl[1]);
+   stage_b(S2, pl[2]);
+   stage_x(S0); // (the first pass's ring range is empty, the second's names the first level: its values come from the ring later)
+   stage_x(S1);
+   int  t = 0;
+   bool last = pl[0].last != 0;
+   // one pass: C of this pass's rows first (LDS reads, arithmetic, the stores), then X of the rows two passes on and B of the rows three
+   // passes on go out -- ten loads per lane, unconditional, in program order behind the store.  Before the barrier a wavefront waits
+   // until at most those ten are outstanding (memory operations retire in issue order: the store has then landed) and for its LDS
+   // writes; the loads stay in flight across the barrier.  (__syncthreads' own fence would drain them.)
    auto pass = [&](const Row &c, Row &x, Row &b) {
-      const int Lc = level(it0);
+      const GsPass pb    = pl[t + 3];
+      const bool   lnext = pl[t + 1].last != 0;
+      if (diag) { ta = __builtin_amdgcn_s_memtime(); if (tz) tn += ta - tz; }
       stage_c(c);
       asm volatile("" ::: "memory"); // (no memory operation of X / B may be scheduled above the store)
-      stage_x(x, (it1.s != it0.s) ? lp[Lc] : 0, (it1.s != it0.s) ? lp[Lc + 1] : 0); // (a pass of the SAME level has no column in it)
-      stage_b(b, it2);
-      if (it1.s != it0.s)
+      if (diag) { const unsigned long long u = __builtin_amdgcn_s_memtime(); tc += u - ta; ta = u; }
+      stage_x(x);
+      stage_b(b, pb);
+      if (diag) { const unsigned long long u = __builtin_amdgcn_s_memtime(); ti += u - ta; ta = u; }
+      if (last)
       { // the next pass belongs to another level: this level's stores and ring writes must have landed
          asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+         if (diag) { const unsigned long long u = __builtin_amdgcn_s_memtime(); tw += u - ta; ta = u; }
          __builtin_amdgcn_s_barrier();
          asm volatile("" ::: "memory");
+         if (diag) { const unsigned long long u = __builtin_amdgcn_s_memtime(); tb += u - ta; ta = u; }
       }
-      it0 = it1;
-      it1 = it2;
-      it2 = advance(it2);
+      tz = ta;
+      last = lnext;
+      t++;
    };
    while (true)
    {
-      pass(S0, S1, S2);
-      if (it0.s >= nl) break;
-      pass(S1, S2, S0);
-      if (it0.s >= nl) break;
+      pass(S0, S2, S3);
+      if (t >= np) break;
+      pass(S1, S3, S0);
+      if (t >= np) break;
       pass(S2, S0, S1);
-      if (it0.s >= nl) break;
+      if (t >= np) break;
+      pass(S3, S1, S2);
+      if (t >= np) break;
+   }
+   if (diag && blk == 0 && (tid & 63) == 0)
+   {
+      unsigned long long *o = diag + 8 * (tid >> 6);
+      o[0] = tc; o[1] = ti; o[2] = tw; o[3] = tb; o[4] = tn; o[5] = (unsigned long long)t;
    }
 }
 
+static unsigned long long *gs_diag_buffer();
+static void                gs_ring_diag_report(int lpr, int nt, int n);
 template <int LPR, int NT>
 static void gs_blocks_ring_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
                              bool zero_in)
 {
-   const int    n          = A.nrows;
-   const int    lds_levels = p.blk_max_levels + 1;
-   const size_t lds        = sizeof(int) * (size_t)(3 * lds_levels + 2) + sizeof(double) * (size_t)kGsRing;
-   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data());
-   k_gs_blocks_ring<LPR, NT><<<p.nblk, NT, lds, STREAM>>>(forward ? 0 : 1, zero_in ? 1 : 0, lds_levels, p.blk_lvl_ptr.data(), p.blk_lvl.data(),
-                                                       p.r_cb.data(), p.r_w.data(), (const int4 *)p.r_col.data(), (const double2 *)p.r_val.data(),
-                                                       p.s_d.data(), p.s_b.data(), xin, p.s_x.data());
+   const int n = A.nrows;
+   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data(),
+                                                            p.s_x0.data());
+   k_gs_blocks_ring<LPR, NT><<<p.nblk, NT, 0, STREAM>>>(p.r_pass_ptr.data(), (const GsPass *)p.r_pass[forward ? 0 : 1].data(),
+                                                      (const int4 *)p.r_col.data(), (const double2 *)p.r_val.data(), p.s_d.data(), p.s_b.data(),
+                                                      p.s_x0.data(), p.s_x.data(), gs_diag_buffer());
+   gs_ring_diag_report(LPR, NT, n);
    k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
 }
 
 // HDA_GS_DIAG=1: wave 0..15 of block 0 time their passes with the shader clock (gathers + arithmetic / fence / barrier)
-static unsigned long long *gs_diag_buffer()
+static unsigned long long *gs_diag_buffer_impl()
 {
    static const bool        on = getenv("HDA_GS_DIAG") != nullptr;
    static DArray<unsigned long long> buf;
    if (!on) return nullptr;
    if (buf.size() == 0) { buf.alloc(128); buf.zero(); }
    return buf.data();
+}
+static unsigned long long *gs_diag_buffer() { return gs_diag_buffer_impl(); }
+static void gs_ring_diag_report(int lpr, int nt, int n)
+{
+   unsigned long long *d = gs_diag_buffer();
+   if (!d) return;
+   static int calls = 0;
+   if (calls++ % 16 > 2) return;
+   unsigned long long h[128];
+   Context::get().sync();
+   HDA_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+   for (int w : {0, 1, nt / 64 - 1})
+   {
+      const double np = (double)std::max(h[8 * w + 5], 1ull);
+      fprintf(stderr, "[hda] gs ring diag n=%d lanes/row=%d threads=%d wave %2d: passes %.0f, cycles per pass: C (ring reads, sum, stores) %.0f, X+B issue %.0f, "
+                      "wait for the store %.0f, barrier %.0f, pass records / loop %.0f\n", n, lpr, nt, w, np, h[8 * w] / np, h[8 * w + 1] / np, h[8 * w + 2] / np,
+              h[8 * w + 3] / np, h[8 * w + 4] / np);
+   }
 }
 static void gs_diag_report(int lpr, int n)
 {
@@ -984,6 +1077,22 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
    }
    const double a = A.avg_row();
    const bool use_sorted = !(getenv("HDA_GS_SORTED") && atoi(getenv("HDA_GS_SORTED")) == 0);
+   if (plan.ring && use_sorted && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0))
+   { // (lanes per row and workgroup size were fixed when the pass lists were made)
+#define HDA_GS_RING_NT(L)                                                                                      \
+   do                                                                                                          \
+   {                                                                                                           \
+      if (plan.ring_nt == 256) gs_blocks_ring_t<L, 256>(A, plan, dinv, b, xin, xout, forward, zero_in);        \
+      else if (plan.ring_nt == 512) gs_blocks_ring_t<L, 512>(A, plan, dinv, b, xin, xout, forward, zero_in);   \
+      else gs_blocks_ring_t<L, 1024>(A, plan, dinv, b, xin, xout, forward, zero_in);                           \
+   } while (0)
+      if (plan.ring_lpr == 2) HDA_GS_RING_NT(2);
+      else if (plan.ring_lpr == 4) HDA_GS_RING_NT(4);
+      else if (plan.ring_lpr == 8) HDA_GS_RING_NT(8);
+      else HDA_GS_RING_NT(16);
+#undef HDA_GS_RING_NT
+      return;
+   }
    if (plan.sorted && use_sorted)
    {
       static const int l0 = getenv("HDA_GS_LPR0") ? atoi(getenv("HDA_GS_LPR0")) : 2, l1 = getenv("HDA_GS_LPR1") ? atoi(getenv("HDA_GS_LPR1")) : 8,
@@ -994,17 +1103,10 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
       static const int nt_env = getenv("HDA_GS_NT") ? atoi(getenv("HDA_GS_NT")) : 0;
       const double     lanes  = plan.blk_mean_rows_per_level * std::min(std::max(lpr, 2), 16);
       const int        nt     = nt_env ? nt_env : (lanes <= 192.0 ? 256 : lanes <= 640.0 ? 512 : 1024);
-      const bool ring = plan.ring && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0);
 #define HDA_GS_DISPATCH(L)                                                                              \
    do                                                                                                   \
    {                                                                                                    \
-      if (ring)                                                                                         \
-      {                                                                                                 \
-         if (nt <= 256) gs_blocks_ring_t<L, 256>(A, plan, dinv, b, xin, xout, forward, zero_in);        \
-         else if (nt <= 512) gs_blocks_ring_t<L, 512>(A, plan, dinv, b, xin, xout, forward, zero_in);   \
-         else gs_blocks_ring_t<L, 1024>(A, plan, dinv, b, xin, xout, forward, zero_in);                 \
-      }                                                                                                 \
-      else if (nt <= 256) gs_blocks_sorted_t<L, 256>(A, plan, dinv, b, xin, xout, forward, zero_in);    \
+      if (nt <= 256) gs_blocks_sorted_t<L, 256>(A, plan, dinv, b, xin, xout, forward, zero_in);         \
       else if (nt <= 512) gs_blocks_sorted_t<L, 512>(A, plan, dinv, b, xin, xout, forward, zero_in);    \
       else gs_blocks_sorted_t<L, 1024>(A, plan, dinv, b, xin, xout, forward, zero_in);                  \
    } while (0)
