@@ -27,7 +27,7 @@ struct AmgParams {
    int    min_coarse_size = 0;
    int    max_levels      = 25;
    // interpolation (amg.c:120-128)
-   int    interp_type  = 6; // extended+i (17: mm-ext+i, the same operator); 3: direct with separation of weights (one rank)
+   int    interp_type  = 6; // extended+i; 17: mm-ext+i, its matrix-matrix form (an operator of its own, one rank); 3: direct with separation of weights (one rank)
    int    pmax         = 4;
    double trunc_factor = 0.0;
    // relaxation (amg.c:178-199)
@@ -371,6 +371,9 @@ void amg_second_strength(const DCsr &A, const unsigned char *smask, const int *c
 void amg_coarsen_second_pass(const DCsr &A, const unsigned char *smask, int num_paths, uint64_t seed, int level, int *cf);
 void amg_interp_multipass(const DCsr &A, const unsigned char *smask, const int *cf, DCsr &P);
 void amg_truncate_rows(DCsr &P, int pmax, double trunc_factor); // hypre_BoomerAMGInterpTruncation on finished, column-sorted rows
+// mm-ext+i (interp type 17): the matrix-matrix form of extended+i, W = -D^-1 (I + B) A^s_FC, + InterpTruncation (hda_amg_agg.hip)
+void amg_interp_mm_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor, DCsr &P,
+                         const int *dof = nullptr);
 // hypre_ParCSRMatMat-style product C = X*Y, deterministic accumulation order, rows sorted.
 void spgemm(const DCsr &X, const DCsr &Y, DCsr &C);
 // hypre_BoomerAMGBuildCoarseOperator: Ac = R*(A*P) with R = P^T

@@ -322,6 +322,104 @@ int finish_rows(int nrows, int ncols, DArray<int> &cnt, DCsr &M)
    return M.nnz;
 }
 
+// ---- mm-ext+i (interpolation type 17): W = -D^-1 (I + B) A^s_FC as sparse products (oracle: orc_interp_mm_extpi_dof)
+// q_k = sum of the strong C entries of row k (F rows; column order)
+__global__ __launch_bounds__(256) void k_mm_q(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                              const unsigned char *__restrict__ sm, const int *__restrict__ cf, double *__restrict__ q,
+                                              int *__restrict__ nsc)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   double s = 0.0;
+   int    c = 0;
+   if (cf[i] == kF)
+      for (int k = rp[i]; k < rp[i + 1]; k++)
+         if (sm[k] && cf[cj[k]] == kC) { s += v[k]; c++; }
+   q[i]   = s;
+   nsc[i] = c; // entries of row i of A^s_FC
+}
+// one walk over row i in column order (FILL = false: counts only): the entries of row i of I + B -- (i, 1) and (k, b_ik) for the
+// strong F neighbours with a non-zero denominator -- and d_i
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_mm_rows(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                 const unsigned char *__restrict__ sm, const int *__restrict__ cf, const int *__restrict__ dof,
+                                                 const double *__restrict__ q, int *__restrict__ cnt, const int *__restrict__ brp,
+                                                 int *__restrict__ bcj, double *__restrict__ bv, double *__restrict__ dd)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   if (cf[i] != kF)
+   {
+      if (!FILL) cnt[i] = 0;
+      return;
+   }
+   double d = 0.0;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (cj[k] == i) d = v[k];
+   int o = FILL ? brp[i] : 0, c = 0;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+   {
+      const int    j   = cj[k];
+      const double aij = v[k];
+      if (j == i)
+      {
+         if (FILL) { bcj[o] = i; bv[o] = 1.0; o++; }
+         c++;
+      }
+      else if (sm[k] && cf[j] == kF)
+      {
+         double ski = 0.0;
+         for (int kk = rp[j]; kk < rp[j + 1]; kk++)
+            if (cj[kk] == i && sm[kk]) ski = v[kk];
+         const double den = q[j] + ski;
+         if (den != 0.0)
+         {
+            const double coef = aij / den;
+            d += coef * ski;
+            if (FILL) { bcj[o] = j; bv[o] = coef; o++; }
+            c++;
+         }
+         else d += aij;
+      }
+      else if (sm[k] && cf[j] == kC) {}
+      else if (cf[j] != -3 && !(dof && dof[j] != dof[i])) d += aij; // weak (or strong towards a point that is neither C nor F): lumped
+   }
+   if (FILL) dd[i] = d;
+   else cnt[i] = c;
+}
+// A^s_FC: row k = the strong C entries of row k (F rows), columns renumbered to coarse ids
+__global__ __launch_bounds__(256) void k_mm_fc_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
+                                                    const unsigned char *__restrict__ sm, const int *__restrict__ cf, const int *__restrict__ cidx,
+                                                    const int *__restrict__ frp, int *__restrict__ fcj, double *__restrict__ fv)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n || cf[i] != kF) return;
+   int o = frp[i];
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (sm[k] && cf[cj[k]] == kC) { fcj[o] = cidx[cj[k]]; fv[o] = v[k]; o++; }
+}
+__global__ __launch_bounds__(256) void k_mm_p_count(int n, const int *__restrict__ cf, const int *__restrict__ trp, int *__restrict__ cnt)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) cnt[i] = (cf[i] == kC) ? 1 : (cf[i] == kF ? trp[i + 1] - trp[i] : 0);
+}
+__global__ __launch_bounds__(256) void k_mm_p_fill(int n, const int *__restrict__ cf, const int *__restrict__ cidx, const int *__restrict__ trp,
+                                                   const int *__restrict__ tcj, const double *__restrict__ tv, const double *__restrict__ dd,
+                                                   const int *__restrict__ prp, int *__restrict__ pcj, double *__restrict__ pv)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int o = prp[i];
+   if (cf[i] == kC) { pcj[o] = cidx[i]; pv[o] = 1.0; return; }
+   if (cf[i] != kF) return;
+   const double d = dd[i];
+   for (int k = trp[i]; k < trp[i + 1]; k++, o++)
+   {
+      pcj[o] = tcj[k];
+      pv[o]  = (d != 0.0) ? tv[k] / (-d) : tv[k];
+   }
+}
+
 } // namespace
 
 void amg_truncate_rows(DCsr &P, int pmax, double trunc_factor)
@@ -431,6 +529,42 @@ void amg_interp_multipass(const DCsr &A, const unsigned char *smask, const int *
    HDA_TRACE("  multipass interpolation: %d passes, %d x %d, %d entries", npass, n, nc, W.nnz);
    P = std::move(W);
    P.reset_plan();
+}
+
+// hypre's mm-ext+i (interpolation type 17, reference src/internal/amg.c:267-268): W = -D^-1 (I + B) A^s_FC, the product on the
+// deterministic SpGEMM of the Galerkin operator, then InterpTruncation on the finished rows.  Bit-identical to
+// orc_interp_mm_extpi_dof (same order of every sum).
+void amg_interp_mm_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor, DCsr &P, const int *dof)
+{
+   const int n = A.nrows, g = ceil_div(std::max(n, 1), 256);
+   DArray<int> m((size_t)n + 1), cidx((size_t)n + 1), nsc((size_t)n + 1), cb((size_t)n + 1);
+   DArray<double> q((size_t)std::max(n, 1)), dd((size_t)std::max(n, 1));
+   k_agg_cmark<<<g, 256, 0, STREAM>>>(n, cf, m.data());
+   exclusive_scan(n, m.data(), cidx.data(), nullptr);
+   int nc = 0;
+   HDA_HIP(hipMemcpyAsync(&nc, cidx.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   nsc.zero();
+   cb.zero();
+   k_mm_q<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, q.data(), nsc.data());
+   k_mm_rows<false><<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, dof, q.data(), cb.data(), nullptr, nullptr,
+                                          nullptr, nullptr);
+   Context::get().sync();
+   DCsr B, FC, T;
+   finish_rows(n, n, cb, B);
+   finish_rows(n, nc, nsc, FC);
+   k_mm_rows<true><<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, dof, q.data(), nullptr, B.rowptr.data(),
+                                         B.col.data(), B.val.data(), dd.data());
+   k_mm_fc_fill<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, cf, cidx.data(), FC.rowptr.data(), FC.col.data(),
+                                      FC.val.data());
+   spgemm(B, FC, T); // rows column-sorted, every output entry summed in the order the product enumerates its terms (k ascending)
+   DArray<int> pc((size_t)n + 1);
+   pc.zero();
+   k_mm_p_count<<<g, 256, 0, STREAM>>>(n, cf, T.rowptr.data(), pc.data());
+   finish_rows(n, nc, pc, P);
+   k_mm_p_fill<<<g, 256, 0, STREAM>>>(n, cf, cidx.data(), T.rowptr.data(), T.col.data(), T.val.data(), dd.data(), P.rowptr.data(), P.col.data(),
+                                     P.val.data());
+   P.reset_plan();
+   amg_truncate_rows(P, pmax, trunc_factor);
 }
 
 } // namespace hda

@@ -1614,6 +1614,11 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
                       double trunc_factor, DCsr &P, const int *dof, int interp_type)
 {
    HDA_REQUIRE(interp_type == 6 || interp_type == 17 || interp_type == 3, "interpolation type not implemented");
+   if (interp_type == 17)
+   { // mm-ext+i is an operator of its own, built from sparse products (hda_amg_agg.hip)
+      amg_interp_mm_extpi(A, smask, cf, pmax, trunc_factor, P, dof);
+      return;
+   }
    const int itype = (interp_type == 3) ? 3 : 6;
    const int n = A.nrows;
    const int g = ceil_div(std::max(n, 1), 256);
@@ -2381,8 +2386,8 @@ __global__ __launch_bounds__(256) void k_coarse_dof(int n, const int *__restrict
 void Amg::build_hierarchy(const DCsr &A)
 {
    HDA_REQUIRE(prm.coarsen_type == 8 || prm.coarsen_type == 10, "device AMG setup implements PMIS (8) and, on one rank, HMIS (10) coarsening");
-   // 17 = "mm-ext+i" (reference src/internal/amg.c:266-268): hypre's matrix-matrix formulation of the SAME extended+i operator
-   // (its GPU interpolation); one algorithm serves both names here
+   // 17 = "mm-ext+i" (reference src/internal/amg.c:266-268): hypre's matrix-matrix formulation of extended+i -- an operator of its
+   // own (denominators over the strong C neighbours of the intermediate point, no sign filter), built from sparse products
    HDA_REQUIRE(prm.interp_type == 6 || prm.interp_type == 17 || prm.interp_type == 3,
                "interpolation type is not implemented on MI355X: extended+i (6) and its matrix-matrix form mm-ext+i (17) are");
    auto known = [](int t) { return is_jacobi_type(t) || is_gs_type(t) || t == 16; };
@@ -4013,7 +4018,7 @@ void Amg::setup_dist_partitioned(const DCsr &Aloc, const HaloPlan &hA0_, const s
                                  const std::vector<long long> &ghost_gids0)
 {
    Comm &cm = Comm::world();
-   HDA_REQUIRE(prm.coarsen_type == 8 && (prm.interp_type == 6 || prm.interp_type == 17) && prm.num_functions <= 1,
+   HDA_REQUIRE(prm.coarsen_type == 8 && prm.interp_type == 6 && prm.num_functions <= 1,
                "partitioned setup: scalar PMIS + extended+i only");
    HDA_REQUIRE(prm.agg_num_levels <= 0, "partitioned setup: aggressive coarsening needs the replicated setup (the second strength graph reaches two ghost layers deep)");
    const long long rep_rows = replicate_rows(cm.size);

@@ -1178,7 +1178,10 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
       const char *mode = getenv("HDA_DIST_SETUP");
       // (HMIS = sequential Ruge pass: only the replicated scheme can run it, on the gathered operator)
       // (aggressive levels: their second strength graph reaches two ghost layers deep -- built on the gathered operator too)
-      if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8 || s->ap.num_functions > 1 || s->ap.smooth_num_levels > 1 || s->ap.agg_num_levels > 0) s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
+      // (mm-ext+i, type 17: its sparse products are formed on the gathered operator as well)
+      if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8 || s->ap.num_functions > 1 || s->ap.smooth_num_levels > 1 || s->ap.agg_num_levels > 0 ||
+          s->ap.interp_type == 17)
+         s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
       else s->amg->setup_dist_partitioned(A->A, A->halo, A->part, A->ghost_gids);
    }
    else s->amg->setup(A->A);

@@ -1153,6 +1153,125 @@ orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf
    return P;
 }
 
+/* Interpolation type 17, "mm-ext+i" (reference name map src/internal/amg.c:267-268; the interpolation of all four pinned variants
+ * of examples/refOutput/ex8.txt:26-78): hypre's matrix-matrix form of extended+i (Li, Sjogreen, Yang 2021, "A new class of AMG
+ * interpolation methods based on matrix-matrix multiplications"; hypre par_mod_lr_interp.c, which is not in the reference tree).  It is
+ * a DIFFERENT operator from the classical formula above: the weight a strong F neighbour k passes on is normalised over k's OWN strong C
+ * neighbours (plus i), not over the interpolatory set of i, and entries are not filtered by sign -- which is what lets the whole
+ * operator be written as sparse products:
+ *    q_k    = sum of a_kl over the strong C neighbours l of k
+ *    b_ik   = a_ik / (q_k + s_ki),  s_ki = a_ki when k depends strongly on i, else 0        (k a strong F neighbour of i)
+ *    d_i    = a_ii + sum of the weak a_in + sum_k b_ik s_ki      (a strong F neighbour with q_k + s_ki = 0 is lumped like a weak one)
+ *    W      = -D^-1 (I + B) A^s_FC                                (A^s_FC: the strong F-to-C entries)
+ * then hypre_BoomerAMGInterpTruncation on the finished, column-sorted rows.  Order of every sum (the device reproduces it bit for bit):
+ * d_i in the column order of row i; an output entry over k ascending (i itself in its place), i.e. the order in which the product
+ * (I + B) A^s_FC enumerates its terms.  Entries towards special F points and other functions' unknowns are neither strong nor lumped. */
+orc_csr *
+orc_interp_mm_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor, const int *dof)
+{
+   const int n    = A->nrows;
+   int      *cidx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+   int       nc   = 0;
+   for (int i = 0; i < n; i++) cidx[i] = (cf[i] == ORC_C_PT) ? nc++ : -1;
+   double *qk = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+   for (int k = 0; k < n; k++)
+   {
+      double s = 0.0;
+      if (cf[k] == ORC_F_PT)
+         for (int kk = A->rowptr[k]; kk < A->rowptr[k + 1]; kk++)
+            if (smask[kk] && cf[A->col[kk]] == ORC_C_PT) s += A->val[kk];
+      qk[k] = s;
+   }
+   double *acc   = (double *)calloc((size_t)(nc > 0 ? nc : 1), sizeof(double));
+   int    *stamp = (int *)malloc(sizeof(int) * (size_t)(nc > 0 ? nc : 1));
+   int    *list  = (int *)malloc(sizeof(int) * (size_t)(nc > 0 ? nc : 1));
+   for (int j = 0; j < nc; j++) stamp[j] = -1;
+   int     pcap = 8 * n + 16, pnnz = 0;
+   int    *prow = (int *)calloc((size_t)n + 1, sizeof(int));
+   int    *pcol = (int *)malloc(sizeof(int) * (size_t)pcap);
+   double *pval = (double *)malloc(sizeof(double) * (size_t)pcap);
+   for (int i = 0; i < n; i++)
+   {
+      int cnt = 0;
+      if (cf[i] == ORC_C_PT)
+      {
+         list[0]      = cidx[i];
+         acc[cidx[i]] = 1.0;
+         cnt          = 1;
+      }
+      else if (cf[i] == ORC_F_PT)
+      {
+         double d = 0.0;
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+            if (A->col[k] == i) d = A->val[k];
+         for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++)
+         { /* one pass in column order: the row's own strong C entries when the walk reaches i, a strong F neighbour's when it reaches it */
+            const int    j   = A->col[k];
+            const double aij = A->val[k];
+            double       coef = 0.0;
+            int          src  = -1;
+            if (j == i) { coef = 1.0; src = i; }
+            else if (smask[k] && cf[j] == ORC_F_PT)
+            {
+               double ski = 0.0;
+               for (int kk = A->rowptr[j]; kk < A->rowptr[j + 1]; kk++)
+                  if (A->col[kk] == i && smask[kk]) ski = A->val[kk];
+               const double den = qk[j] + ski;
+               if (den != 0.0)
+               {
+                  coef = aij / den;
+                  src  = j;
+                  d += coef * ski;
+               }
+               else
+                  d += aij;
+            }
+            else if (smask[k] && cf[j] == ORC_C_PT) { /* reaches the row through src == i */ }
+            else if (cf[j] != ORC_SF_PT && !(dof && dof[j] != dof[i]))
+               d += aij; /* weak connection (or a strong one to a point that is neither C nor F): lumped */
+            if (src < 0) continue;
+            for (int kk = A->rowptr[src]; kk < A->rowptr[src + 1]; kk++)
+            {
+               const int l = A->col[kk];
+               if (!smask[kk] || cf[l] != ORC_C_PT) continue;
+               const int    c = cidx[l];
+               const double t = coef * A->val[kk];
+               if (stamp[c] != i)
+               {
+                  stamp[c]    = i;
+                  acc[c]      = t;
+                  list[cnt++] = c;
+               }
+               else
+                  acc[c] += t;
+            }
+         }
+         if (d != 0.0)
+            for (int q = 0; q < cnt; q++) acc[list[q]] = acc[list[q]] / (-d);
+      }
+      /* storage order: by column */
+      for (int a = 1; a < cnt; a++)
+      {
+         int v = list[a], b = a - 1;
+         while (b >= 0 && list[b] > v) { list[b + 1] = list[b]; b--; }
+         list[b + 1] = v;
+      }
+      if (pnnz + cnt > pcap)
+      {
+         pcap = 2 * pcap + cnt;
+         pcol = (int *)realloc(pcol, sizeof(int) * (size_t)pcap);
+         pval = (double *)realloc(pval, sizeof(double) * (size_t)pcap);
+      }
+      for (int q = 0; q < cnt; q++) { pcol[pnnz] = list[q]; pval[pnnz++] = acc[list[q]]; }
+      prow[i + 1] = pnnz;
+   }
+   orc_csr *P = (orc_csr *)calloc(1, sizeof(orc_csr));
+   P->nrows = n; P->ncols = nc; P->rowptr = prow; P->col = pcol; P->val = pval;
+   free(cidx); free(qk); free(acc); free(stamp); free(list);
+   orc_truncate_rows(P, pmax, trunc_factor);
+   return P;
+}
+
 /* hypre_BoomerAMGBuildDirInterp with separation of weights (interp type 3, "direct_sep_weights" in
  * src/internal/amg.c:258-270; examples/ex8-amg-5.yml, pinned by examples/refOutput/ex8.txt:96) followed by
  * hypre_BoomerAMGInterpTruncation.  hypre itself is not in /root/reference: this restates the published
@@ -1905,8 +2024,9 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
       }
       h->cf[lvl] = cf;
       h->P[lvl]  = aggressive ? orc_interp_multipass(A, sm, cf)  /* (truncated below) */
-                   : (p->interp_type == 3) ? orc_interp_direct_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
-                                          : orc_interp_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof);
+                   : (p->interp_type == 3)  ? orc_interp_direct_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
+                   : (p->interp_type == 17) ? orc_interp_mm_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
+                                            : orc_interp_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof);
       if (aggressive) orc_truncate_rows(h->P[lvl], p->agg_pmax, p->agg_trunc_factor);
       if (dof)
       { /* coarse unknowns keep the function of their fine C point */

@@ -34,7 +34,7 @@ typedef struct {
  * defaults of src/internal/amg.c:120-238. */
 typedef struct {
    int    coarsen_type;    /* 8 PMIS (hypre-GPU default), 10 HMIS, 6 Falgout->RS pass */
-   int    interp_type;     /* 6 extended+i (17: its matrix-matrix form, same operator), 3 direct with separation of weights */
+   int    interp_type;     /* 6 extended+i, 17 mm-ext+i (its matrix-matrix form: a different operator), 3 direct with separation of weights */
    int    pmax;            /* interpolation.max_nnz_row = 4 */
    double trunc_factor;    /* 0.0 */
    double strong_th;       /* 0.25 */
@@ -132,6 +132,9 @@ orc_csr *orc_interp_extpi(const orc_csr *A, const unsigned char *smask, const in
                           int pmax, double trunc_factor);
 orc_csr *orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf,
                               int pmax, double trunc_factor, const int *dof);
+/* interp type 17 (mm-ext+i): the matrix-matrix form of extended+i, W = -D^-1 (I + B) A^s_FC -- its own operator, see amg_oracle.c */
+orc_csr *orc_interp_mm_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor,
+                                 const int *dof);
 /* interp type 3: direct interpolation with separation of weights (strong C neighbours only) */
 orc_csr *orc_interp_direct_dof(const orc_csr *A, const unsigned char *smask, const int *cf,
                                int pmax, double trunc_factor, const int *dof);

@@ -117,6 +117,8 @@ def lib():
     L.orc_strength_dof.argtypes = [cp, C.c_double, C.c_double, ip, P(C.c_ubyte)]
     L.orc_interp_extpi_dof.restype = cp
     L.orc_interp_extpi_dof.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double, ip]
+    L.orc_interp_mm_extpi_dof.restype = cp
+    L.orc_interp_mm_extpi_dof.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double, ip]
     L.orc_interp_direct_dof.restype = cp
     L.orc_interp_direct_dof.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double, ip]
     L.orc_amg_free.argtypes = [C.c_void_p]
@@ -356,6 +358,15 @@ def interp_extpi(A, smask, cf, pmax=4, trunc_factor=0.0, dof=None):
     return Csr(lib().orc_interp_extpi(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)),
                                       cfa.ctypes.data_as(C.POINTER(C.c_int)), pmax,
                                       trunc_factor))
+
+
+def interp_mm_extpi(A, smask, cf, pmax=4, trunc_factor=0.0, dof=None):
+    """interp type 17 (mm-ext+i): W = -D^-1 (I + B) A^s_FC, truncated"""
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    cfa = np.ascontiguousarray(cf, dtype=np.int32)
+    d = None if dof is None else np.ascontiguousarray(dof, dtype=np.int32)
+    return Csr(lib().orc_interp_mm_extpi_dof(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), cfa.ctypes.data_as(C.POINTER(C.c_int)), pmax,
+                                             trunc_factor, None if d is None else d.ctypes.data_as(C.POINTER(C.c_int))))
 
 
 def interp_direct(A, smask, cf, pmax=4, trunc_factor=0.0, dof=None):

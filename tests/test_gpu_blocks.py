@@ -194,3 +194,46 @@ def test_automatic_blocks(hd, monkeypatch):
     assert part[0] == 0 and part[-1] == B.nrows and np.all(np.diff(part) == 96 * 96 * 4)
     # Jacobi smoothing + PMIS never asks for blocks
     assert hd.Amg(B, hd.AmgParams.default(blocks=0)).blocks == 1
+
+
+# ---- mm-ext+i (interpolation type 17) as its own operator, from sparse products ---------------------------------------------------
+
+@pytest.mark.parametrize("pmax,tf", [(4, 0.0), (0, 0.0), (3, 0.2)])
+def test_mm_extpi_bit_exact(orc, hd, pmax, tf):
+    """hypre's mm-ext+i (/root/reference/src/internal/amg.c:267-268; every pinned variant of examples/refOutput/ex8.txt:26-78):
+    W = -D^-1 (I + B) A^s_FC on the deterministic SpGEMM, then InterpTruncation -- pattern and weights bit for bit the oracle's"""
+    mats = [orc.lap7(12, 10, 9)[0].to_scipy(), mmatrix(900, 0.01, 41), mmatrix(500, 0.04, 42), mmatrix(600, 0.02, 43, unsym=True)]
+    M = mmatrix(400, 0.05, 44).tolil()
+    M[7, :] = 0
+    M[7, 7] = 1.0  # a row without connections (special F)
+    mats.append(M.tocsr())
+    for M in mats:
+        Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+        for theta in (0.25, 0.6):
+            sm = orc.strength(Ao, theta)
+            for cf in (orc.pmis(Ao, sm), orc.hmis_blocks(Ao, sm, [0, Ao.nrows])):
+                Po, Ph = orc.interp_mm_extpi(Ao, sm, cf, pmax, tf), Ah.interp_mm_extpi(sm, cf, pmax, tf)
+                rp, cj, v = Ph.download()
+                assert np.array_equal(rp, Po.rowptr) and np.array_equal(cj, Po.col)
+                assert np.array_equal(v, Po.val)
+
+
+@pytest.mark.parametrize("shape,coarsen", [((12, 12, 12), 10), ((20, 16, 14), 8), ((24, 24, 24), 10)])
+def test_mm_extpi_hierarchy_and_pcg_match_oracle(orc, hd, shape, coarsen):
+    Ao, b = orc.lap7(*shape)
+    Ah = hd.lap7(*shape)
+    po = orc.amg_params(coarsen == 8, coarsen_type=coarsen, interp_type=17)
+    ph = hd.AmgParams.default(coarsen_type=coarsen, interp_type=17, relax_down=po.relax_down, relax_up=po.relax_up, relax_coarse=9)
+    ho, hh = orc.Amg(Ao, po), hd.Amg(Ah, ph)
+    assert hh.num_levels == ho.num_levels
+    for l in range(ho.num_levels - 1):
+        assert np.array_equal(hh.level_cf(l), ho.level_cf(l))
+        for which, Mo in ((1, ho.level_P(l)), (0, ho.level_A(l + 1))):
+            rp, cj, v = hh.level_matrix(l + (0 if which else 1), which).download()
+            assert np.array_equal(rp, Mo.rowptr) and np.array_equal(cj, Mo.col) and np.array_equal(v, Mo.val)
+    ro, rh = orc.pcg(Ao, b, ho), hd.pcg(Ah, b, hh)
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-10, atol=0)
+    # the operator differs from classical extended+i (type 6): same C/F splitting on level 0, other weights
+    h6 = hd.Amg(Ah, hd.AmgParams.default(coarsen_type=coarsen, interp_type=6, relax_down=po.relax_down, relax_up=po.relax_up, relax_coarse=9))
+    assert np.array_equal(h6.level_cf(0), hh.level_cf(0))

@@ -173,10 +173,10 @@ def test_cli_runs_ex8_multi_unchanged(orc, pins):
     assert [int(q[0]) for q in rows] == [0, 1, 2, 3], r.stdout
     assert all(q[1] == "3.16e+01" and float(q[2]) < 1e-9 for q in rows)
     A, b = orc.lap7(10, 10, 10, b_mode=1)
-    variants = [dict(coarsen_type=10, strong_th=0.8, relax_down=8, relax_up=8),                                              # ex8-amg-3.yml
-                dict(coarsen_type=8, strong_th=0.5, relax_down=16, relax_up=16, cheby_order=4, cheby_fraction=0.1),          # ex8-amg-2.yml
-                dict(coarsen_type=10, strong_th=0.25, relax_down=16, relax_up=16),                                           # ex8-amg-1.yml
-                dict(coarsen_type=10, strong_th=0.9, relax_down=16, relax_up=16)]                                            # ex8-amg-4.yml (+ ILU)
+    variants = [dict(coarsen_type=10, interp_type=17, strong_th=0.8, relax_down=8, relax_up=8),                                      # ex8-amg-3.yml
+                dict(coarsen_type=8, interp_type=17, strong_th=0.5, relax_down=16, relax_up=16, cheby_order=4, cheby_fraction=0.1),  # ex8-amg-2.yml
+                dict(coarsen_type=10, interp_type=17, strong_th=0.25, relax_down=16, relax_up=16),                                   # ex8-amg-1.yml
+                dict(coarsen_type=10, interp_type=17, strong_th=0.9, relax_down=16, relax_up=16)]                                    # ex8-amg-4.yml (+ ILU)
     ref_entry = [2, None, 0, 3]  # rows of examples/refOutput/ex8.txt made with the same options (its variant 1 used HMIS, not PMIS)
     for k, v in enumerate(variants):
         amg = orc.Amg(A, orc.amg_params(False, **v))
@@ -200,10 +200,10 @@ def test_cli_runs_ex8_unchanged(orc, pins):
     assert [int(q[0]) for q in rows] == [0, 1, 2, 3, 4], r.stdout
     assert all(q[1] == "3.16e+01" and float(q[2]) < 1e-9 for q in rows)
     A, b = orc.lap7(10, 10, 10, b_mode=1)
-    variants = [dict(coarsen_type=10, strong_th=0.25, relax_down=16, relax_up=16),
-                dict(coarsen_type=10, strong_th=0.5, relax_down=16, relax_up=16, cheby_order=4, cheby_fraction=0.1),
-                dict(coarsen_type=10, strong_th=0.8, relax_down=8, relax_up=8),
-                dict(coarsen_type=10, strong_th=0.9, relax_down=16, relax_up=16),
+    variants = [dict(coarsen_type=10, interp_type=17, strong_th=0.25, relax_down=16, relax_up=16),
+                dict(coarsen_type=10, interp_type=17, strong_th=0.5, relax_down=16, relax_up=16, cheby_order=4, cheby_fraction=0.1),
+                dict(coarsen_type=10, interp_type=17, strong_th=0.8, relax_down=8, relax_up=8),
+                dict(coarsen_type=10, interp_type=17, strong_th=0.9, relax_down=16, relax_up=16),
                 dict(coarsen_type=8, interp_type=3, strong_th=0.5, relax_down=8, relax_up=8, sweeps_down=2, sweeps_up=2)]
     for k, v in enumerate(variants):
         amg = orc.Amg(A, orc.amg_params(False, **v))
