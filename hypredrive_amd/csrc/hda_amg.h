@@ -142,7 +142,11 @@ struct FirstSweepFusion {
    bool          valid = false;   // offer: the next application from a zero guess may have its first sweep done by the caller
    const double *dinv  = nullptr; //   divisors of that sweep
    double       *dest  = nullptr; //   where the sweep's result is expected; nullptr = the application's output vector itself
-   bool          done  = false;   // caller -> callee: it has been done
+   int           n     = 0;       //   rows of the operator the offer is about (a caller iterating on another system must not take it)
+   const void   *owner = nullptr; //   the preconditioner that made the offer
+   bool          done  = false;   // caller -> callee: it has been done ...
+   const double *in    = nullptr; //   ... for the application that gets THIS right-hand side
+   double       *out   = nullptr; //   ... and THIS output vector: any other application runs its own sweep
 };
 FirstSweepFusion &first_sweep_fusion();
 

@@ -3112,7 +3112,9 @@ double *Amg::first_sweep_dest(double *x)
 void Amg::apply_offering(const double *b, double *x, int dot_slot)
 {
    FirstSweepFusion &fs = first_sweep_fusion();
-   const bool given = fs.done;
+   // the caller's sweep counts only for the application it was promised to: this preconditioner, this right-hand side, this output
+   // (an application on another system or vector in between -- a composite preconditioner, a user callback -- runs its own sweep)
+   const bool given = fs.done && fs.owner == this && fs.in == b && fs.out == x;
    fs.done          = false;
    HDA_REQUIRE(!given || first_sweep_fusable(), "first sweep handed to a cycle that does not open with one");
    cycle(b, x, true, dot_slot, given);
@@ -3122,6 +3124,8 @@ void Amg::apply_offering(const double *b, double *x, int dot_slot)
       double *d = first_sweep_dest(x);
       fs.dinv   = levels[0].dinv_down.data();
       fs.dest   = (d == x) ? nullptr : d;
+      fs.n      = level_A(0).nrows;
+      fs.owner  = this;
    }
 }
 

@@ -62,7 +62,7 @@ struct hypre_Solver_struct {
    hda::AmgParams            ap;
    // values of setters whose feature is not implemented (checked at Setup)
    const int                *dof_func_ptr = nullptr; // HYPRE_BoomerAMGSetDofFunc (borrowed until Setup)
-   double                    agg_trunc[4] = {0.0, 0.0, 0.0, 0.0}; // AggTruncFactor, AggP12TruncFactor, AggPMaxElmts, AggP12MaxElmts (refused when non-zero)
+   double                    agg_trunc[4] = {0.0, 0.0, 0.0, 0.0}; // AggTruncFactor, AggP12TruncFactor, AggPMaxElmts, AggP12MaxElmts: [0] / [2] go to the multipass rows' truncation; the P12 pair belongs to the two-stage interpolation types, which are refused by name
    int                       smooth_type = 5, smooth_num_levels = 0, agg_num_levels = 0, num_functions = 1, cycle_type = 1,
                              restriction = 0, relax_order = 0, sabs = 0, seq_threshold = 0, relax_type_all = -1, filter_functions = 0;
    HYPRE_PtrToSolverFcn      precond = nullptr, precond_setup = nullptr;

@@ -184,9 +184,10 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
          if (slot >= 0) dot(n, rr, zz, slot);
       }
       HDA_REQUIRE(!fs.done, "the preconditioner ignored a first sweep it had offered to take from the caller");
-      z0_dinv = fs.valid ? fs.dinv : nullptr;
-      z0_dest = fs.valid ? fs.dest : nullptr;
-      z0_self = fs.valid && fs.dest == nullptr;
+      const bool mine = fs.valid && fs.n == n; // (an offer about an operator of another size is not for this loop)
+      z0_dinv = mine ? fs.dinv : nullptr;
+      z0_dest = mine ? fs.dest : nullptr;
+      z0_self = mine && fs.dest == nullptr;
       fs.valid = false;
    };
    // one rank: the finalize launches of <s,p> and of the <r,z>, <r,r> pair ride on the kernels that consume them (same bits)
@@ -299,6 +300,8 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
          test();
          if (stop) break;
          fs.done = z0 != nullptr;
+         fs.in   = r.data();
+         fs.out  = s.data();
          precond(r.data(), s.data(), 2);
          if (fin2) cg_direction(n, go, gn, s.data(), p.data(), 2); // (finishes slot 3 into rn once more: the same sum)
          else
@@ -310,6 +313,8 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
       }
       if (!fuse_dots) finalize(3, rn);
       fs.done = z0 != nullptr;
+      fs.in   = r.data();
+      fs.out  = s.data();
       precond(r.data(), s.data(), 2);
       if (fin2 && fuse_dots)
       {
