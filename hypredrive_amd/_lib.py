@@ -87,7 +87,7 @@ SYMBOLS = [
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
     "hda_thread_ranks_lap7", "hda_thread_world_create", "hda_thread_world_join", "hda_thread_world_leave", "hda_thread_world_destroy", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
     "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass", "hda_truncate_rows",
-    "hda_interp_mm_extpi", "hda_marker", "hda_relax_blocks", "hda_l1_norms_blocks", "hda_hmis_blocks", "hda_amg_blocks", "hda_amg_level_blocks",
+    "hda_interp_mm_extpi", "hda_interp_standard", "hda_marker", "hda_relax_blocks", "hda_l1_norms_blocks", "hda_hmis_blocks", "hda_amg_blocks", "hda_amg_level_blocks",
 ]
 
 
@@ -129,6 +129,7 @@ def load():
     L.hda_interp_extpi.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
     L.hda_interp_direct.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
     L.hda_interp_mm_extpi.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
+    L.hda_interp_standard.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, C.c_double, P(vp)]
     L.hda_rap.argtypes = [vp, vp, P(vp)]
     L.hda_second_strength.argtypes = [vp, P(C.c_ubyte), ip, C.c_int, P(vp)]
     L.hda_coarsen_second_pass.argtypes = [vp, P(C.c_ubyte), C.c_int, C.c_uint64, C.c_int, ip]
@@ -310,6 +311,14 @@ class Csr:
         cfa = np.ascontiguousarray(np.concatenate([cf, np.zeros(1, np.int32)]), dtype=np.int32)
         out = C.c_void_p()
         _check(load().hda_interp_mm_extpi(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cfa), pmax, trunc_factor, C.byref(out)))
+        return Csr(out)
+
+    def interp_standard(self, smask, cf, pmax=4, trunc_factor=0.0):
+        """interpolation type 8 (standard): strong F neighbours eliminated through their own rows, direct interpolation on the result"""
+        sm = np.ascontiguousarray(np.concatenate([smask, np.zeros(1, np.uint8)]), dtype=np.uint8)
+        cfa = np.ascontiguousarray(np.concatenate([cf, np.zeros(1, np.int32)]), dtype=np.int32)
+        out = C.c_void_p()
+        _check(load().hda_interp_standard(self.h, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(cfa), pmax, trunc_factor, C.byref(out)))
         return Csr(out)
 
     def interp_direct(self, smask, cf, pmax=4, trunc_factor=0.0):

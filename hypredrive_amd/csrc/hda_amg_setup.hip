@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void k_interp_build(
    const long long *__restrict__ uofs, const long long *__restrict__ hofs, int *__restrict__ lcol,
    double *__restrict__ lw, int *__restrict__ htab, int pmax, double trunc_factor, int *__restrict__ pcnt,
    const unsigned char *__restrict__ rowmode, const int *__restrict__ dof, int itype)
-{ // itype 6: extended+i; 3: direct interpolation with separation of weights (strong C neighbours only)
+{ // itype 6: extended+i; 3: direct interpolation with separation of weights (strong C neighbours only); 8: standard
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
    if (rowmode && !rowmode[i]) return; // handled by the wave-per-row kernel
@@ -739,6 +739,47 @@ __global__ __launch_bounds__(256) void k_interp_build(
       if (sum_P_pos != 0.0) beta = sum_N_pos / sum_P_pos / diagonal;
       for (int q = 0; q < cnt; q++) W[q] *= (W[q] > 0.0) ? -beta : -alfa;
       diagonal = 0.0; // nothing left to divide by below
+   }
+   else if (itype == 8)
+   { // the oracle's orc_interp_standard_dof, entry for entry: strong F neighbours eliminated through their own rows, then direct
+     // interpolation on the widened stencil (no separation of weights)
+      double other = 0.0;
+      for (int k = k0; k < k1; k++)
+      {
+         const int j = cj[k];
+         if (j == i) continue;
+         const double aij = v[k];
+         if (smask[k] && cf[j] == -1 && !(dof && dof[j] != dof[i]))
+         {
+            const int j0 = rp[j], j1 = rp[j + 1];
+            double    ajj = 0.0;
+            for (int kk = j0; kk < j1; kk++)
+               if (cj[kk] == j) ajj = v[kk];
+            const double distribute = aij / ajj;
+            for (int kk = j0; kk < j1; kk++)
+            {
+               const int m = cj[kk];
+               if (m == j) continue;
+               const double t  = v[kk] * distribute;
+               const int    em = find(m);
+               if (em >= 0) W[em] -= t;
+               else if (m == i) diagonal -= t;
+               else other -= t;
+            }
+         }
+         else
+         {
+            const int e = find(j);
+            if (e >= 0) W[e] += aij;
+            else other += aij;
+         }
+      }
+      double sum_C = 0.0, alfa = 1.0;
+      for (int q = 0; q < cnt; q++) sum_C += W[q];
+      const double sum = sum_C + other;
+      if (sum_C * diagonal != 0.0) alfa = sum / sum_C / diagonal;
+      for (int q = 0; q < cnt; q++) W[q] = -alfa * W[q];
+      diagonal = 0.0;
    }
    else
    for (int k = k0; k < k1; k++)
@@ -1613,13 +1654,13 @@ __global__ __launch_bounds__(256) void k_interp_gather(int n, const long long *_
 void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, int pmax,
                       double trunc_factor, DCsr &P, const int *dof, int interp_type)
 {
-   HDA_REQUIRE(interp_type == 6 || interp_type == 17 || interp_type == 3, "interpolation type not implemented");
+   HDA_REQUIRE(interp_type == 6 || interp_type == 17 || interp_type == 3 || interp_type == 8, "interpolation type not implemented");
    if (interp_type == 17)
    { // mm-ext+i is an operator of its own, built from sparse products (hda_amg_agg.hip)
       amg_interp_mm_extpi(A, smask, cf, pmax, trunc_factor, P, dof);
       return;
    }
-   const int itype = (interp_type == 3) ? 3 : 6;
+   const int itype = (interp_type == 3 || interp_type == 8) ? interp_type : 6;
    const int n = A.nrows;
    const int g = ceil_div(std::max(n, 1), 256);
    DArray<int>       nsC((size_t)n + 1), ub((size_t)n + 1), hsz((size_t)n + 1), cmark((size_t)n + 1), cidx((size_t)n + 1), nt((size_t)n + 1);
@@ -2388,8 +2429,8 @@ void Amg::build_hierarchy(const DCsr &A)
    HDA_REQUIRE(prm.coarsen_type == 8 || prm.coarsen_type == 10, "device AMG setup implements PMIS (8) and, on one rank, HMIS (10) coarsening");
    // 17 = "mm-ext+i" (reference src/internal/amg.c:266-268): hypre's matrix-matrix formulation of extended+i -- an operator of its
    // own (denominators over the strong C neighbours of the intermediate point, no sign filter), built from sparse products
-   HDA_REQUIRE(prm.interp_type == 6 || prm.interp_type == 17 || prm.interp_type == 3,
-               "interpolation type is not implemented on MI355X: extended+i (6) and its matrix-matrix form mm-ext+i (17) are");
+   HDA_REQUIRE(prm.interp_type == 6 || prm.interp_type == 17 || prm.interp_type == 3 || prm.interp_type == 8,
+               "interpolation type is not implemented on MI355X: extended+i (6), its matrix-matrix form mm-ext+i (17), direct_sep_weights (3) and standard (8) are");
    auto known = [](int t) { return is_jacobi_type(t) || is_gs_type(t) || t == 16; };
    HDA_REQUIRE(known(prm.relax_down) && known(prm.relax_up),
                "device V-cycle implements Jacobi (0, 7, 18), hybrid Gauss-Seidel (3, 4, 6, 8, 13, 14) and Chebyshev (16) smoothers");

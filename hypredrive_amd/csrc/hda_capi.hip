@@ -431,6 +431,21 @@ extern "C" int hda_interp_direct(hda_csr_t A, const unsigned char *smask, const 
    HDA_CATCH
 }
 
+extern "C" int hda_interp_standard(hda_csr_t A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor, hda_csr_t *P)
+{
+   HDA_TRY
+   const DCsr           &m = A->get();
+   DArray<unsigned char> sm;
+   DArray<int>           dcf;
+   sm.upload(smask, (size_t)std::max(m.nnz, 1));
+   dcf.upload(cf, (size_t)std::max(m.nrows, 1));
+   auto h = std::make_unique<hda_csr_s>();
+   amg_interp_extpi(m, sm.data(), dcf.data(), pmax, trunc_factor, h->m, nullptr, 8);
+   Context::get().sync();
+   *P = h.release();
+   HDA_CATCH
+}
+
 extern "C" int hda_interp_mm_extpi(hda_csr_t A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor, hda_csr_t *P)
 {
    HDA_TRY

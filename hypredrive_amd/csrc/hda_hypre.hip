@@ -1178,9 +1178,10 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
       const char *mode = getenv("HDA_DIST_SETUP");
       // (HMIS = sequential Ruge pass: only the replicated scheme can run it, on the gathered operator)
       // (aggressive levels: their second strength graph reaches two ghost layers deep -- built on the gathered operator too)
-      // (mm-ext+i, type 17: its sparse products are formed on the gathered operator as well)
+      // (mm-ext+i, type 17: its sparse products are formed on the gathered operator as well; direct (3) and standard (8) interpolation:
+      //  options beside the path, one-rank kernels)
       if ((mode && !strcmp(mode, "replicated")) || s->ap.coarsen_type != 8 || s->ap.num_functions > 1 || s->ap.smooth_num_levels > 1 || s->ap.agg_num_levels > 0 ||
-          s->ap.interp_type == 17)
+          s->ap.interp_type != 6)
          s->amg->setup_dist(A->A, A->halo, A->part, A->ghost_gids);
       else s->amg->setup_dist_partitioned(A->A, A->halo, A->part, A->ghost_gids);
    }

@@ -122,6 +122,9 @@ int hda_interp_direct(hda_csr_t A, const unsigned char *smask, const int *cf, in
 /* hypre's mm-ext+i (interpolation type 17, "mm-ext+i" in reference src/internal/amg.c:267-268; the interpolation of
  * examples/refOutput/ex8.txt:26-78): the matrix-matrix form of extended+i, W = -D^-1 (I + B) A^s_FC, + InterpTruncation */
 int hda_interp_mm_extpi(hda_csr_t A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor, hda_csr_t *P);
+/* hypre_BoomerAMGBuildStdInterp without separation of weights (interpolation type 8, "standard" in reference
+ * src/internal/amg.c:258; the configuration examples/refOutput/ex8.txt:74 echoes for its fifth variant) + InterpTruncation */
+int hda_interp_standard(hda_csr_t A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor, hda_csr_t *P);
 /* hypre_BoomerAMGBuildCoarseOperator (P^T A P) */
 int hda_rap(hda_csr_t A, hda_csr_t P, hda_csr_t *Ac);
 /* aggressive coarsening, stage by stage (HYPRE_BoomerAMGSetAggNumLevels / SetNumPaths / SetAggInterpType 4; hypre_BoomerAMGCreate2ndS,

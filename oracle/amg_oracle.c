@@ -1153,6 +1153,123 @@ orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf
    return P;
 }
 
+/* Interpolation type 8, "standard" (reference name map src/internal/amg.c:258; the configuration examples/refOutput/ex8.txt:74 echoes
+ * for its fifth variant, pinned at 6 iterations by ex8.txt:96).  hypre_BoomerAMGBuildStdInterp is not in the reference tree: this
+ * restates the published algorithm (De Sterck, Falgout, Nolting, Yang, "Distance-two interpolation for parallel algebraic multigrid",
+ * 2008, section 4.1) in the form without separation of weights.  The interpolatory set is the extended one,
+ * C-hat_i = C_i U (U_{j in F_i^s} C_j); every strong F neighbour j of i is eliminated through its OWN equation,
+ *    e_j = -sum_{m != j} a_jm e_m / a_jj,
+ * which turns row i into a wider stencil a-hat (entries to C-hat_i, to i itself, and to points outside both), and direct
+ * interpolation is applied to that stencil:
+ *    w_ic = -alfa a-hat_ic / a-hat_ii,   alfa = (sum of a-hat_im over all m != i) / (sum of a-hat_ic over C-hat_i)   (1 if that is 0).
+ * Order of the sums (part of the definition, the device kernel follows it): row i in storage order; a strong F neighbour's row in
+ * storage order; the C-hat sum in discovery order of C-hat_i.  Truncation as for the other operators. */
+orc_csr *
+orc_interp_standard_dof(const orc_csr *A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor, const int *dof)
+{
+   int  n    = A->nrows;
+   int *cidx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+   int  nc   = 0;
+   for (int i = 0; i < n; i++) cidx[i] = (cf[i] == ORC_C_PT) ? nc++ : -1;
+   int *pm  = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)); /* position in current row */
+   int *pst = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)); /* stamp for pm */
+   for (int i = 0; i < n; i++) pst[i] = -1;
+   int     cap  = 64;
+   pent   *row  = (pent *)malloc(sizeof(pent) * (size_t)cap);
+   int     pcap = 4 * n + 16, pnnz = 0;
+   int    *prow = (int *)calloc((size_t)n + 1, sizeof(int));
+   int    *pcol = (int *)malloc(sizeof(int) * (size_t)pcap);
+   double *pval = (double *)malloc(sizeof(double) * (size_t)pcap);
+#define ADD_CHAT(j)                                             \
+   if (pst[j] != i)                                             \
+   {                                                            \
+      if (cnt >= cap)                                           \
+      {                                                         \
+         cap *= 2;                                              \
+         row = (pent *)realloc(row, sizeof(pent) * (size_t)cap); \
+      }                                                         \
+      pst[j]     = i;                                           \
+      pm[j]      = cnt;                                         \
+      row[cnt].c = cidx[j];                                     \
+      row[cnt].w = 0.0;                                         \
+      cnt++;                                                    \
+   }
+   for (int i = 0; i < n; i++)
+   {
+      int cnt = 0;
+      if (cf[i] == ORC_C_PT)
+      {
+         row[0].c = cidx[i];
+         row[0].w = 1.0;
+         cnt      = 1;
+      }
+      else if (cf[i] == ORC_F_PT)
+      {
+         int k0 = A->rowptr[i], k1 = A->rowptr[i + 1];
+         for (int k = k0; k < k1; k++)
+         {
+            if (!smask[k]) continue;
+            int j = A->col[k];
+            if (cf[j] == ORC_C_PT) { ADD_CHAT(j); }
+            else if (cf[j] == ORC_F_PT)
+               for (int kk = A->rowptr[j]; kk < A->rowptr[j + 1]; kk++)
+               {
+                  int m = A->col[kk];
+                  if (smask[kk] && cf[m] == ORC_C_PT) { ADD_CHAT(m); }
+               }
+         }
+         double diagonal = 0.0, other = 0.0;
+         for (int k = k0; k < k1; k++)
+            if (A->col[k] == i) diagonal = A->val[k];
+         for (int k = k0; k < k1; k++)
+         {
+            int j = A->col[k];
+            if (j == i) continue;
+            double aij = A->val[k];
+            if (smask[k] && cf[j] == ORC_F_PT && !(dof && dof[j] != dof[i]))
+            { /* a strong F neighbour: replaced by the rest of its own row */
+               int    j0 = A->rowptr[j], j1 = A->rowptr[j + 1];
+               double ajj = 0.0;
+               for (int kk = j0; kk < j1; kk++)
+                  if (A->col[kk] == j) ajj = A->val[kk];
+               double distribute = aij / ajj;
+               for (int kk = j0; kk < j1; kk++)
+               {
+                  int m = A->col[kk];
+                  if (m == j) continue;
+                  double t = A->val[kk] * distribute;
+                  if (pst[m] == i) row[pm[m]].w -= t;
+                  else if (m == i) diagonal -= t;
+                  else other -= t;
+               }
+            }
+            else if (pst[j] == i) row[pm[j]].w += aij;
+            else other += aij;
+         }
+         double sum_C = 0.0, alfa = 1.0;
+         for (int q = 0; q < cnt; q++) sum_C += row[q].w;
+         double sum = sum_C + other;
+         if (sum_C * diagonal != 0.0) alfa = sum / sum_C / diagonal;
+         for (int q = 0; q < cnt; q++) row[q].w = -alfa * row[q].w;
+         cnt = orc_truncate_row(row, cnt, pmax, trunc_factor);
+      }
+      qsort(row, (size_t)cnt, sizeof(pent), pent_cmp_col); /* storage order: by column */
+      if (pnnz + cnt > pcap)
+      {
+         pcap = 2 * pcap + cnt;
+         pcol = (int *)realloc(pcol, sizeof(int) * (size_t)pcap);
+         pval = (double *)realloc(pval, sizeof(double) * (size_t)pcap);
+      }
+      for (int q = 0; q < cnt; q++) { pcol[pnnz] = row[q].c; pval[pnnz++] = row[q].w; }
+      prow[i + 1] = pnnz;
+   }
+#undef ADD_CHAT
+   orc_csr *P = (orc_csr *)calloc(1, sizeof(orc_csr));
+   P->nrows = n; P->ncols = nc; P->rowptr = prow; P->col = pcol; P->val = pval;
+   free(cidx); free(pm); free(pst); free(row);
+   return P;
+}
+
 /* Interpolation type 17, "mm-ext+i" (reference name map src/internal/amg.c:267-268; the interpolation of all four pinned variants
  * of examples/refOutput/ex8.txt:26-78): hypre's matrix-matrix form of extended+i (Li, Sjogreen, Yang 2021, "A new class of AMG
  * interpolation methods based on matrix-matrix multiplications"; hypre par_mod_lr_interp.c, which is not in the reference tree).  It is
@@ -2025,6 +2142,7 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
       h->cf[lvl] = cf;
       h->P[lvl]  = aggressive ? orc_interp_multipass(A, sm, cf)  /* (truncated below) */
                    : (p->interp_type == 3)  ? orc_interp_direct_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
+                   : (p->interp_type == 8)  ? orc_interp_standard_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
                    : (p->interp_type == 17) ? orc_interp_mm_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof)
                                             : orc_interp_extpi_dof(A, sm, cf, p->pmax, p->trunc_factor, dof);
       if (aggressive) orc_truncate_rows(h->P[lvl], p->agg_pmax, p->agg_trunc_factor);

@@ -136,6 +136,8 @@ orc_csr *orc_interp_extpi_dof(const orc_csr *A, const unsigned char *smask, cons
 orc_csr *orc_interp_mm_extpi_dof(const orc_csr *A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor,
                                  const int *dof);
 /* interp type 3: direct interpolation with separation of weights (strong C neighbours only) */
+orc_csr *orc_interp_standard_dof(const orc_csr *A, const unsigned char *smask, const int *cf, int pmax, double trunc_factor,
+                                 const int *dof); /* interp type 8 ("standard") */
 orc_csr *orc_interp_direct_dof(const orc_csr *A, const unsigned char *smask, const int *cf,
                                int pmax, double trunc_factor, const int *dof);
 orc_csr *orc_rap(const orc_csr *A, const orc_csr *P);

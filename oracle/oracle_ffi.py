@@ -119,6 +119,8 @@ def lib():
     L.orc_interp_extpi_dof.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double, ip]
     L.orc_interp_mm_extpi_dof.restype = cp
     L.orc_interp_mm_extpi_dof.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double, ip]
+    L.orc_interp_standard_dof.restype = cp
+    L.orc_interp_standard_dof.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double, ip]
     L.orc_interp_direct_dof.restype = cp
     L.orc_interp_direct_dof.argtypes = [cp, P(C.c_ubyte), ip, C.c_int, C.c_double, ip]
     L.orc_amg_free.argtypes = [C.c_void_p]
@@ -376,6 +378,15 @@ def interp_direct(A, smask, cf, pmax=4, trunc_factor=0.0, dof=None):
     d = None if dof is None else np.ascontiguousarray(dof, dtype=np.int32)
     return Csr(lib().orc_interp_direct_dof(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), cfa.ctypes.data_as(C.POINTER(C.c_int)), pmax,
                                            trunc_factor, None if d is None else d.ctypes.data_as(C.POINTER(C.c_int))))
+
+
+def interp_standard(A, smask, cf, pmax=4, trunc_factor=0.0, dof=None):
+    """interp type 8 (standard)"""
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    cfa = np.ascontiguousarray(cf, dtype=np.int32)
+    d = None if dof is None else np.ascontiguousarray(dof, dtype=np.int32)
+    return Csr(lib().orc_interp_standard_dof(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), cfa.ctypes.data_as(C.POINTER(C.c_int)), pmax,
+                                             trunc_factor, None if d is None else d.ctypes.data_as(C.POINTER(C.c_int))))
 
 
 def second_strength(A, smask, cf, num_paths=1):

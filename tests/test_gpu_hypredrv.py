@@ -214,6 +214,25 @@ def test_cli_runs_ex8_unchanged(orc, pins):
         assert abs(int(rows[k][3]) - pins["ex8"]["stats"][k]["iters"]) <= 1
 
 
+def test_cli_runs_ex8_with_the_standard_interpolation_its_golden_output_echoes(orc, pins, tmp_path):
+    """examples/refOutput/ex8.txt:74 echoes `prolongation_type: standard` for the fifth variant (the ex8.yml in the tree says
+    direct_sep_weights today): the same file with that one word put back runs through the CLI, takes the oracle's count with
+    interpolation type 8, and stays within one of the reference's 6 (refOutput/ex8.txt:96)."""
+    cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
+    text = open(os.path.join(ROOT, "examples", "ex8.yml")).read()
+    assert text.count("direct_sep_weights") == 1
+    cfg = tmp_path / "ex8-standard.yml"
+    cfg.write_text(text.replace("direct_sep_weights", "standard"))
+    r = subprocess.run([cli, "-q", str(cfg)], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = re.findall(r"^\|\s+(\d+) \|\s+[\d.]* \|\s+[\d.]+ \|\s+[\d.]+ \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
+    assert [int(q[0]) for q in rows] == [0, 1, 2, 3, 4], r.stdout
+    A, b = orc.lap7(10, 10, 10, b_mode=1)
+    amg = orc.Amg(A, orc.amg_params(False, coarsen_type=8, interp_type=8, strong_th=0.5, relax_down=8, relax_up=8, sweeps_down=2, sweeps_up=2))
+    ro = orc.pcg(A, b, amg, orc.krylov_params(False, rtol=1e-9, max_iter=500))
+    assert int(rows[4][3]) == ro["iters"] and abs(int(rows[4][3]) - pins["ex8"]["stats"][4]["iters"]) <= 1, (rows[4], ro["iters"])
+
+
 @pytest.mark.parametrize("cfg", ["examples/ex3-mgr_Frelax_gmres.yml", "examples/ex3-mgr_coarse_gmres_amg.yml"])
 def test_cli_runs_nested_krylov_mgr_examples(cfg):
     """The reference's examples/ex3-mgr_Frelax_gmres.yml (F-relaxation of the second reduction level = GMRES(5) preconditioned by a

@@ -360,6 +360,56 @@ def test_direct_interp_hierarchy_and_pcg_match_oracle(orc, hd):
     assert np.allclose(rh["hist"], ro["hist"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("pmax,tf", [(4, 0.0), (0, 0.0), (3, 0.2)])
+def test_standard_interp_bit_exact(orc, hd, pmax, tf):
+    """Interpolation type 8 (`standard`, what examples/refOutput/ex8.txt:74 echoes for the fifth ex8 variant): the extended
+    interpolatory set, strong F neighbours eliminated through their own rows, direct interpolation on the widened stencil.  Same
+    pattern and the same bits as the oracle on a stencil operator, an anisotropic one and random operators with off-diagonals
+    of both signs, with and without truncation."""
+    mats = [both(orc, hd, orc.lap7(12, 11, 10)[0].to_scipy()), both(orc, hd, orc.lap7(9, 10, 11, c=(1.0, 0.1, 10.0))[0].to_scipy())]
+    for seed in (5, 6):
+        M = rand_spd(500, 0.02, seed)
+        rng = np.random.default_rng(seed)
+        M2 = M.copy()
+        M2.data = np.where(rng.random(M2.nnz) < 0.3, -1.0, 1.0) * M2.data
+        M2 = ((M2 + M2.T) * 0.5).tocsr()
+        M2.setdiag(np.asarray(abs(M2).sum(axis=1)).ravel() + 1.0)
+        M2.sort_indices()
+        mats += [both(orc, hd, M), both(orc, hd, M2.tocsr())]
+    for Ao, Ah in mats:
+        sm = orc.strength(Ao, 0.25, 0.9)
+        cf = orc.pmis(Ao, sm)
+        Po = orc.interp_standard(Ao, sm, cf, pmax, tf)
+        rp, cj, v = Ah.interp_standard(sm, cf, pmax, tf).download()
+        assert np.array_equal(rp, Po.rowptr) and np.array_equal(cj, Po.col)
+        assert np.array_equal(v, Po.val), np.abs(v - Po.val).max()
+        if pmax:
+            assert np.diff(rp).max() <= pmax
+        # the pattern is the extended one: without truncation the same entries as extended+i names
+        if pmax == 0 and tf == 0.0:
+            Pe = orc.interp_extpi(Ao, sm, cf, 0, 0.0)
+            assert np.array_equal(Pe.rowptr, Po.rowptr) and np.array_equal(Pe.col, Po.col)
+
+
+def test_standard_interp_hierarchy_and_pcg_match_oracle(orc, hd):
+    """The whole setup with interpolation type 8 in the configuration examples/refOutput/ex8.txt:63-79 echoes (PMIS 0.5, two
+    symmetric l1 Gauss-Seidel sweeps): identical transfer operators on every level, the oracle's iteration count and history."""
+    Ao, b = orc.lap7(14, 13, 12, b_mode=1)
+    Ah = hd.lap7(14, 13, 12)
+    kw = dict(coarsen_type=8, interp_type=8, strong_th=0.5, relax_down=8, relax_up=8, sweeps_down=2, sweeps_up=2)
+    ho = orc.Amg(Ao, orc.amg_params(False, **kw))
+    hh = hd.Amg(Ah, hd.AmgParams.default(relax_coarse=9, **kw))
+    assert hh.num_levels == ho.num_levels
+    for l in range(ho.num_levels - 1):
+        rp, cj, v = hh.level_matrix(l, 1).download()
+        Pl = ho.level_P(l)
+        assert np.array_equal(rp, Pl.rowptr) and np.array_equal(cj, Pl.col) and np.array_equal(v, Pl.val)
+    ro = orc.pcg(Ao, b, ho, orc.krylov_params(False, rtol=1e-9, max_iter=100))
+    rh = hd.pcg(Ah, b, hh, hd.KrylovParams.default(False, rtol=1e-9, max_iter=100))
+    assert rh["converged"] and rh["iters"] == ro["iters"]
+    assert np.allclose(rh["hist"], ro["hist"], rtol=1e-9)
+
+
 def test_spgemm_and_transpose_vs_scipy(orc, hd, monkeypatch):
     rng = np.random.default_rng(11)
     X = sp.random(400, 300, density=0.03, random_state=rng, format="csr")
