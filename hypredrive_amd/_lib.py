@@ -83,7 +83,7 @@ SYMBOLS = [
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
-    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_memory_cached", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
+    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_memory_cached", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_create_blocks", "hda_ilu_blocks", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
     "hda_thread_ranks_lap7", "hda_thread_world_create", "hda_thread_world_join", "hda_thread_world_leave", "hda_thread_world_destroy", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
     "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass", "hda_truncate_rows",
@@ -143,6 +143,8 @@ def load():
     L.hda_mgr_matrix.argtypes = [vp, C.c_int, C.c_int, P(vp)]
     L.hda_ilu_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(vp)]
     L.hda_ilu_factors.argtypes = [vp, C.c_int, P(vp)]
+    L.hda_ilu_create_blocks.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int64), P(vp)]
+    L.hda_ilu_blocks.argtypes = [vp, C.c_int]
     L.hda_amg_num_levels.argtypes = [vp]
     L.hda_amg_level_matrix.argtypes = [vp, C.c_int, C.c_int, P(vp)]
     L.hda_amg_level_cf.argtypes = [vp, C.c_int, ip]
@@ -535,10 +537,23 @@ class Mgr:
 class Ilu:
     """'preconditioner: ilu': block-Jacobi ILU(0) of A's diagonal block; usable as amg= in pcg()/gmres()."""
 
-    def __init__(self, A, max_iter=1, tri_solve=1, lower_it=5, upper_it=5):
+    def __init__(self, A, max_iter=1, tri_solve=1, lower_it=5, upper_it=5, blocks=1, block_part=None):
+        """blocks: V contiguous row blocks = bj-iluk at np = V (1 one block, 0 the setup's choice); block_part: V + 1 row starts"""
         self.A = A
         self.h = C.c_void_p()
-        _check(load().hda_ilu_create(A.h, max_iter, tri_solve, lower_it, upper_it, C.byref(self.h)))
+        if blocks == 1 and block_part is None:
+            _check(load().hda_ilu_create(A.h, max_iter, tri_solve, lower_it, upper_it, C.byref(self.h)))
+        else:
+            bp = None
+            if block_part is not None:
+                bp = np.ascontiguousarray(block_part, dtype=np.int64)
+                blocks = len(bp) - 1
+            _check(load().hda_ilu_create_blocks(A.h, max_iter, tri_solve, lower_it, upper_it, blocks,
+                                                None if bp is None else bp.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(self.h)))
+
+    @property
+    def blocks(self):
+        return load().hda_ilu_blocks(self.h, -1)
 
     def __del__(self):
         if getattr(self, "h", None):

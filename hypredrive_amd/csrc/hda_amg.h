@@ -16,6 +16,11 @@ struct IluParams {
    int tri_solve = 1;              // 1 exact substitutions (level scheduled), 0 Jacobi iterations on L and U
    int lower_it = 5, upper_it = 5; // lower_jac_iters / upper_jac_iters
    int max_iter = 1;               // iterations x += M^-1 (b - A x) per solve
+   // V contiguous row blocks on one GPU = bj-iluk at np = V: the factorisation drops the entries that leave a row's block, and
+   // the exact substitutions (tri_solve 1) run block-parallel on the block Gauss-Seidel kernels.  1 = one block, 0 = chosen from
+   // the operator's size and bandwidth (amg_auto_blocks), V > 1 = hypre's even split unless block_part names the V + 1 row starts
+   int                    blocks = 1;
+   std::vector<long long> block_part;
 };
 
 struct AmgParams {
@@ -128,6 +133,14 @@ class Ilu {
    DArray<int>    diag;
    GsPlan         plan;
    DArray<double> work, dinv;
+   // row blocks (IluParams::blocks): the substitutions as two zero-guess block sweeps over LU -- forward with unit divisors
+   // (the upper part multiplies the zero guess), backward with 1 / u_ii (the lower part does)
+   std::vector<int> bpart;
+   GsPlan           bplan;
+   DArray<double>   ones, udinv;
+
+ public:
+   int blocks_used() const { return bpart.empty() ? 1 : (int)bpart.size() - 1; }
 };
 
 void ilu_solve(Ilu &F, const DCsr &A, const HaloPlan *halo, const double *b, double *x, bool zero_guess, DArray<double> &r,

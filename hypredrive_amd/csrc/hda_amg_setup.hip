@@ -2404,6 +2404,12 @@ void Amg::build_smoother_data(int l)
          lv.ilu = std::make_unique<Ilu>();
          IluParams ip = prm.ilu;
          ip.max_iter  = std::max(prm.smooth_num_sweeps, 1);
+         ip.blocks    = 1;
+         if (nblk > 1)
+         { // the hierarchy's row blocks are the ILU's: at np = V the reference's complex smoother is block-Jacobi over the same ranks
+            ip.blocks = nblk;
+            ip.block_part.assign(lv.blk_part.begin(), lv.blk_part.end());
+         }
          lv.ilu->setup(Al, ip);
          lv.ilu_r.alloc((size_t)std::max(Al.nrows, 1));
          lv.ilu_c.alloc((size_t)std::max(Al.nrows, 1));
@@ -2457,7 +2463,8 @@ void Amg::build_hierarchy(const DCsr &A)
    };
    // row blocks of level 0 (AmgParams::blocks): the caller's starts, hypre's even split, or the setup's own choice
    {
-      const bool uses = prm.coarsen_type == 10 || is_gs_type(prm.relax_down) || is_gs_type(prm.relax_up) || is_gs_type(prm.relax_coarse);
+      const bool uses = prm.coarsen_type == 10 || is_gs_type(prm.relax_down) || is_gs_type(prm.relax_up) || is_gs_type(prm.relax_coarse) ||
+                        (prm.smooth_num_levels > 0 && prm.ilu.tri_solve); // (exact ILU substitutions: block-parallel as the hybrid sweeps)
       int        V    = prm.blocks;
       if (V == 0) V = uses ? amg_auto_blocks(A) : 1;
       if (!prm.block_part.empty())

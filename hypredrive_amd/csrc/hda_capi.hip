@@ -590,6 +590,29 @@ extern "C" int hda_ilu_create(hda_csr_t A, int max_iter, int tri_solve, int lowe
    *out = h.release();
    HDA_CATCH
 }
+// the same on V row blocks (IluParams::blocks: bj-iluk at np = V; block_part = V + 1 row starts or NULL for hypre's even split)
+extern "C" int hda_ilu_create_blocks(hda_csr_t A, int max_iter, int tri_solve, int lower_it, int upper_it, int blocks, const int64_t *block_part,
+                                     hda_amg_t *out)
+{
+   HDA_TRY
+   auto h = std::make_unique<hda_amg_s>();
+   h->A   = A;
+   h->ilu = std::make_unique<Ilu>();
+   IluParams p;
+   p.max_iter = max_iter; p.tri_solve = tri_solve; p.lower_it = lower_it; p.upper_it = upper_it;
+   p.blocks   = blocks;
+   if (block_part && blocks > 1) p.block_part.assign(block_part, block_part + blocks + 1);
+   h->ilu->setup(A->get(), p);
+   *out = h.release();
+   HDA_CATCH
+}
+extern "C" int hda_ilu_blocks(hda_amg_t h, int level)
+{
+   if (!h) return 0;
+   if (level < 0) return h->ilu ? h->ilu->blocks_used() : 0;
+   if (!h->amg || level >= h->amg->num_levels() || !h->amg->level(level).ilu) return 0;
+   return h->amg->level(level).ilu->blocks_used();
+}
 // "preconditioner: mgr" (reference src/internal/mgr.c): multigrid reduction by dof labels
 extern "C" int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const hda_mgr_level_params *levels,
                               const hda_amg_params *coarsest_amg, int max_iter, hda_amg_t *out)

@@ -27,27 +27,47 @@ namespace {
 enum { OP_FACTOR = 0, OP_LOWER = 1, OP_UPPER = 2 };
 constexpr int kLanes = 8; // lanes per row in the substitutions
 
-__global__ __launch_bounds__(256) void k_ilu_count(int n, const int *__restrict__ rp, const int *__restrict__ cj, int *__restrict__ cnt)
+// the row block of row i: [lo, hi) (part == nullptr: the whole diagonal block [0, n))
+__device__ __forceinline__ void ilu_block_of(int i, int n, const int *__restrict__ part, int nb, int &lo, int &hi)
+{
+   lo = 0;
+   hi = n;
+   if (!part) return;
+   int a = 0, b = nb; // part[a] <= i < part[b]
+   while (b - a > 1)
+   {
+      const int m = (a + b) >> 1;
+      if (part[m] <= i) a = m;
+      else b = m;
+   }
+   lo = part[a];
+   hi = part[b];
+}
+
+__global__ __launch_bounds__(256) void k_ilu_count(int n, const int *__restrict__ rp, const int *__restrict__ cj, const int *__restrict__ part,
+                                                   int nb, int *__restrict__ cnt)
 {
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
-   int c = 0;
-   for (int k = rp[i]; k < rp[i + 1]; k++) c += (cj[k] < n);
+   int lo, hi, c = 0;
+   ilu_block_of(i, n, part, nb, lo, hi);
+   for (int k = rp[i]; k < rp[i + 1]; k++) c += (cj[k] >= lo && cj[k] < hi);
    cnt[i] = c;
 }
 
 // copy the diagonal block; flag bit 0: a row without diagonal entry, bit 1: a row that is not column-sorted
 __global__ __launch_bounds__(256) void k_ilu_fill(int n, const int *__restrict__ rp, const int *__restrict__ cj, const double *__restrict__ v,
-                                                  const int *__restrict__ orp, int *__restrict__ ocj, double *__restrict__ ov,
-                                                  int *__restrict__ diag, int *flag)
+                                                  const int *__restrict__ part, int nb, const int *__restrict__ orp, int *__restrict__ ocj,
+                                                  double *__restrict__ ov, int *__restrict__ diag, int *flag)
 {
    const int i = blockIdx.x * 256 + threadIdx.x;
    if (i >= n) return;
-   int q = orp[i], d = -1, prev = -1, bad = 0;
+   int q = orp[i], d = -1, prev = -1, bad = 0, lo, hi;
+   ilu_block_of(i, n, part, nb, lo, hi);
    for (int k = rp[i]; k < rp[i + 1]; k++)
    {
       const int j = cj[k];
-      if (j >= n) continue;
+      if (j < lo || j >= hi) continue;
       if (j <= prev) bad = 2;
       prev = j;
       if (j == i) d = q;
@@ -158,6 +178,15 @@ void run_levels(const DCsr &LU, const GsPlan &p, const int *dg, double *x, int *
    }
 }
 
+__global__ __launch_bounds__(256) void k_ilu_block_divisors(int n, const double *__restrict__ v, const int *__restrict__ dg, double *__restrict__ ones,
+                                                            double *__restrict__ udinv)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   ones[i]  = 1.0;
+   udinv[i] = 1.0 / v[dg[i]];
+}
+
 // split the factors for the Jacobi-iterative solves: Ls = strict lower part, Us = diagonal + strict upper part
 __global__ __launch_bounds__(256) void k_ilu_split_count(int n, const int *__restrict__ rp, const int *__restrict__ dg, int *__restrict__ nl,
                                                          int *__restrict__ nu)
@@ -196,7 +225,31 @@ void Ilu::setup(const DCsr &A, const IluParams &p)
    DArray<int> cnt((size_t)n + 1), flag(1);
    cnt.zero();
    flag.zero();
-   if (n) k_ilu_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), cnt.data());
+   // row blocks: the caller's starts, hypre's even split into V, or the setup's own choice (blocks = 0)
+   bpart.clear();
+   bplan = GsPlan();
+   {
+      int V = prm.blocks;
+      if (V == 0) V = amg_auto_blocks(A);
+      V = std::min(std::max(V, 1), std::max(n, 1));
+      if (!prm.block_part.empty())
+      {
+         HDA_REQUIRE((int)prm.block_part.size() == V + 1 && prm.block_part.front() == 0 && prm.block_part.back() == n,
+                     "ILU: block_part must hold blocks + 1 ascending row starts from 0 to the number of rows");
+         bpart.assign(prm.block_part.begin(), prm.block_part.end());
+      }
+      else if (V > 1)
+      {
+         bpart.resize((size_t)V + 1);
+         for (int q = 0; q <= V; q++) bpart[(size_t)q] = (int)(((__int128)q * n) / V);
+      }
+      if (bpart.size() <= 2) bpart.clear();
+   }
+   const int   nb = bpart.empty() ? 0 : (int)bpart.size() - 1;
+   DArray<int> dpart;
+   if (nb) dpart.upload(bpart.data(), bpart.size());
+   const int *pp = nb ? dpart.data() : nullptr;
+   if (n) k_ilu_count<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), pp, nb, cnt.data());
    require_int32_total(n, cnt.data(), "ILU factor");
    exclusive_scan(n, cnt.data(), LU.rowptr.data(), nullptr);
    HDA_HIP(hipMemcpyAsync(&LU.nnz, LU.rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
@@ -204,7 +257,7 @@ void Ilu::setup(const DCsr &A, const IluParams &p)
    LU.col.alloc((size_t)std::max(LU.nnz, 1));
    LU.val.alloc((size_t)std::max(LU.nnz, 1));
    if (n)
-      k_ilu_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), LU.rowptr.data(), LU.col.data(),
+      k_ilu_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), pp, nb, LU.rowptr.data(), LU.col.data(),
                                                       LU.val.data(), diag.data(), flag.data());
    int f = 0;
    flag.download(&f, 1);
@@ -222,6 +275,13 @@ void Ilu::setup(const DCsr &A, const IluParams &p)
    work.alloc((size_t)std::max(n, 1) * 2);
    Ls = DCsr();
    Us = DCsr();
+   if (prm.tri_solve && nb && n)
+   { // the substitutions on the block kernels: the plan copies the FINISHED factors into sweep order
+      build_gs_plan_blocks(LU, bpart, bplan);
+      ones.alloc((size_t)n);
+      udinv.alloc((size_t)n);
+      k_ilu_block_divisors<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, LU.val.data(), diag.data(), ones.data(), udinv.data());
+   }
    if (!prm.tri_solve && n)
    { // the iterations are plain products with the two triangles: keep each in its own CSR so that a pass
      // streams only its half, through the same kernels (and launch plans) as every other operator
@@ -255,6 +315,14 @@ void Ilu::apply(const double *r, double *z)
 {
    const int n = LU.nrows;
    if (n == 0) return;
+   if (prm.tri_solve && bplan.built)
+   { // row blocks: y = L^-1 r is a forward block sweep over LU from the zero guess with unit divisors (y_i = r_i - sum_{j<i} l_ij y_j:
+     // the diagonal and the upper entries multiply zeros), z = U^-1 y a backward one with 1 / u_ii (the lower entries do)
+      double *y = work.data();
+      gs_sweep_blocks(LU, bplan, ones.data(), r, nullptr, y, true, true);
+      gs_sweep_blocks(LU, bplan, udinv.data(), y, nullptr, z, false, true);
+      return;
+   }
    if (prm.tri_solve)
    {
       copy(n, r, z);

@@ -149,6 +149,12 @@ int hda_amg_destroy(hda_amg_t h);
  * diagonal block; the handle is accepted by hda_pcg / hda_gmres / hda_amg_vcycle (= one application from a zero guess)
  * in place of a hierarchy.  max_iter iterations x += M^-1 (b - A x) per application. */
 int hda_ilu_create(hda_csr_t A, int max_iter, int tri_solve, int lower_it, int upper_it, hda_amg_t *out);
+/* the same on V contiguous row blocks of one GPU = bj-iluk at np = V (hypre factors every rank's diagonal block on its own): entries
+ * that leave a row's block are dropped, the exact substitutions (tri_solve 1) run block-parallel.  blocks: 1 one block, 0 chosen from
+ * the operator's size and bandwidth, V > 1 with block_part = V + 1 row starts (NULL: hypre's even split, floor(q n / V)). */
+int hda_ilu_create_blocks(hda_csr_t A, int max_iter, int tri_solve, int lower_it, int upper_it, int blocks, const int64_t *block_part,
+                          hda_amg_t *out);
+int hda_ilu_blocks(hda_amg_t h, int level); /* row blocks in use: level < 0 a handle of hda_ilu_create*, else that AMG level's smoother */
 /* "preconditioner: mgr" (reference src/internal/mgr.c; MGRlvl_args include/internal/mgr.h:132-147): multigrid reduction
  * by dof labels with BoomerAMG on the coarsest system.  labels = dofmap of A's rows.  Implemented per level:
  * prolongation injection (0) / l1-jacobi (1) / jacobi (2); restriction injection (0) / jacobi (2) / columped (14);

@@ -237,3 +237,86 @@ def test_mm_extpi_hierarchy_and_pcg_match_oracle(orc, hd, shape, coarsen):
     # the operator differs from classical extended+i (type 6): same C/F splitting on level 0, other weights
     h6 = hd.Amg(Ah, hd.AmgParams.default(coarsen_type=coarsen, interp_type=6, relax_down=po.relax_down, relax_up=po.relax_up, relax_coarse=9))
     assert np.array_equal(h6.level_cf(0), hh.level_cf(0))
+
+
+# ---- block-Jacobi ILU(0) on row blocks: bj-iluk at np = V (reference src/internal/ilu.c:63-115; hypre factors every rank's diagonal block)
+
+
+@pytest.mark.parametrize("form", ["plain", "sorted", "ring"])
+@pytest.mark.parametrize("kind", ["even4", "even37", "ragged"])
+def test_block_ilu_factors_bit_exact_and_exact_substitutions_match(orc, hd, monkeypatch, kind, form):
+    """ILU(0) of the diagonal blocks of a row partition: the factors carry the oracle's bits (entries leaving a block dropped, updates
+    in ascending pivot order), and the exact substitutions -- two zero-guess block sweeps over LU, forward with unit divisors and
+    backward with 1 / u_ii -- give the oracle's z = U^-1 L^-1 r to 1e-13 on every form of the block kernel."""
+    monkeypatch.setenv("HDA_GS_SORTED_MIN", "100000000" if form == "plain" else "0")
+    monkeypatch.setenv("HDA_GS_RING", "1" if form == "ring" else "0")
+    cases = [orc.lap7(13, 11, 9, b_mode=1)[0].to_scipy(), mmatrix(900, 0.01, 3), mmatrix(700, 0.012, 4, unsym=True)]
+    for M in cases:
+        n = M.shape[0]
+        part = parts_for(n, kind, seed=n)
+        Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+        Fo, Fh = orc.Ilu(Ao, part=part), hd.Ilu(Ah, block_part=part)
+        assert Fh.blocks == len(part) - 1
+        lo, lh = Fo.factors.to_scipy(), Fh.factors.to_scipy()
+        assert np.array_equal(lo.indptr, lh.indptr) and np.array_equal(lo.indices, lh.indices)
+        assert np.array_equal(lo.data, lh.data)
+        # block-diagonal pattern: no entry leaves its block
+        blk = np.searchsorted(part, np.arange(n), side="right")
+        rows = np.repeat(np.arange(n), np.diff(lh.indptr))
+        assert np.all(blk[rows] == blk[lh.indices])
+        r = np.random.default_rng(7).standard_normal(n)
+        assert rel(Fh.apply(r), Fo.apply(r)) < 1e-13
+        # and it IS the exact solve with the block factors
+        L = sp.tril(lh, -1).tocsr() + sp.identity(n)
+        U = sp.triu(lh, 0).tocsr()
+        assert rel((L @ (U @ Fh.apply(r))), r) < 1e-11
+
+
+def test_block_ilu_even_split_and_jacobi_iterations(orc, hd):
+    """blocks = V without starts = hypre's even split floor(q n / V); the Jacobi-iterative substitutions (tri_solve 0) run on the
+    block factors through the streaming kernels as before."""
+    M = orc.lap7(12, 12, 12, b_mode=1)[0].to_scipy()
+    n = M.shape[0]
+    Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+    part = np.array([(q * n) // 5 for q in range(6)])
+    r = np.random.default_rng(1).standard_normal(n)
+    for ts in (1, 0):
+        Fo, Fh = orc.Ilu(Ao, part=part, tri_solve=ts), hd.Ilu(Ah, blocks=5, tri_solve=ts)
+        assert Fh.blocks == 5 and np.array_equal(Fo.factors.to_scipy().data, Fh.factors.to_scipy().data)
+        assert rel(Fh.apply(r), Fo.apply(r)) < 1e-13
+
+
+@pytest.mark.parametrize("max_iter", [1, 2])
+def test_block_ilu_preconditioned_krylov_matches_oracle(orc, hd, max_iter):
+    """'preconditioner: ilu' on four row blocks under PCG / GMRES: the oracle's iteration counts and histories (the oracle at np = 4)."""
+    Ao, b = orc.lap7(16, 15, 14, b_mode=1)
+    Ah = hd.lap7(16, 15, 14)
+    n = Ao.nrows
+    part = np.array([(q * n) // 4 for q in range(5)])
+    po, ph = orc.IluPrecond(Ao, max_iter=max_iter, part=part), hd.Ilu(Ah, max_iter=max_iter, blocks=4)
+    if max_iter == 1:
+        ro, rh = orc.pcg(Ao, b, po), hd.pcg(Ah, b, ph)
+        assert rh["converged"] and rh["iters"] == ro["iters"] and np.allclose(rh["hist"], ro["hist"], rtol=1e-9)
+        one = orc.pcg(Ao, b, orc.IluPrecond(Ao, max_iter=1))
+        assert ro["iters"] >= one["iters"]  # dropping the couplings between blocks does not help
+    ro, rh = orc.gmres(Ao, b, po), hd.gmres(Ah, b, ph)
+    assert rh["converged"] and rh["iters"] == ro["iters"] and np.allclose(rh["hist"], ro["hist"], rtol=1e-8)
+
+
+def test_amg_ilu_smoother_on_the_hierarchy_blocks(orc, hd):
+    """BoomerAMG's complex smoother on a hierarchy with row blocks: the ILU of a level is block-Jacobi over THAT level's blocks
+    (at np = V the reference's smoother factors every rank's diagonal block), coarse levels through their C points."""
+    Ao, b = orc.lap7(18, 16, 14, b_mode=1)
+    Ah = hd.lap7(18, 16, 14)
+    kw = dict(coarsen_type=10, strong_th=0.5, relax_down=13, relax_up=14, blocks=4)
+    ao = orc.Amg(Ao, orc.amg_params(False, **kw))
+    ao.set_ilu_smoother(num_levels=2, num_sweeps=1, part=ao.level_block_part(0))
+    ah = hd.Amg(Ah, hd.AmgParams.default(smooth_num_levels=2, smooth_num_sweeps=1, relax_coarse=9, **kw))
+    assert ah.num_levels == ao.num_levels
+    for l in (0, 1):
+        Fo = orc.Ilu(ao.level_A(l), part=ao.level_block_part(l))
+        assert np.array_equal(Fo.factors.to_scipy().data, ah.ilu_factors(l).to_scipy().data)
+    r = np.random.default_rng(4).standard_normal(Ao.nrows)
+    assert rel(ah.vcycle(r), ao.vcycle(r)) < 1e-12
+    ro, rh = orc.pcg(Ao, b, ao), hd.pcg(Ah, b, ah)
+    assert rh["converged"] and rh["iters"] == ro["iters"] and np.allclose(rh["hist"], ro["hist"], rtol=1e-9)
