@@ -85,10 +85,28 @@ SYMBOLS = [
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_memory_cached", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_create_blocks", "hda_ilu_blocks", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
-    "hda_thread_ranks_lap7", "hda_thread_world_create", "hda_thread_world_join", "hda_thread_world_leave", "hda_thread_world_destroy", "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
+    "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
     "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass", "hda_truncate_rows",
     "hda_interp_mm_extpi", "hda_interp_standard", "hda_marker", "hda_relax_blocks", "hda_l1_norms_blocks", "hda_hmis_blocks", "hda_amg_blocks", "hda_amg_level_blocks",
 ]
+
+
+TESTRANKS_SYMBOLS = ["hda_thread_ranks_lap7", "hda_thread_world_create", "hda_thread_world_join", "hda_thread_world_leave",
+                     "hda_thread_world_destroy"]
+_TESTRANKS_PATH = os.path.join(os.path.dirname(_LIBPATH), "libhypredrv_amd_testranks.so")
+_T = None
+
+
+def load_testranks():
+    """The test seam "ranks as threads of one process" (include/hypredrv_amd_testranks.h): its own small library on top of the
+    product library, which is loaded first so that both share one instance of it."""
+    global _T
+    if _T is None:
+        load()
+        if not os.path.exists(_TESTRANKS_PATH):
+            raise LibraryError(f"{_TESTRANKS_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _T = C.CDLL(_TESTRANKS_PATH)
+    return _T
 
 
 def load():
@@ -676,7 +694,7 @@ def comm_stats(reset=False):
 def thread_ranks_lap7(nranks, n, P, yaml, nsolves=1, want_x=False):
     """`nranks` ranks of a row partition as threads of this process (hda_thread_ranks.hip; test seam): AMG-Krylov on the
     generator's 7-pt Laplacian, global grid n, rank grid P.  Returns the dict of one rank-0 result (+ "x" in block numbering)."""
-    L = load()
+    L = load_testranks()
     out = (C.c_double * 16)()
     err = C.create_string_buffer(4096)
     N = int(n[0]) * int(n[1]) * int(n[2])
@@ -704,7 +722,7 @@ def run_thread_ranks(nranks, body):
     order.  ctypes releases the interpreter lock inside library calls, so ranks blocked in a collective do not stall the others.
     A rank that raises releases its peers with an error; the first exception is re-raised here."""
     import threading
-    L = load()
+    L = load_testranks()
     L.hda_thread_world_create.restype = C.c_void_p
     L.hda_thread_world_join.argtypes = [C.c_void_p, C.c_int]
     L.hda_thread_world_leave.argtypes = [C.c_void_p, C.c_int]

@@ -58,9 +58,5 @@ Comm *make_self_comm();
 Comm *make_rccl_comm(int rank, int size, const void *unique_id_128);
 Comm *make_callback_comm(int rank, int size, hda_allreduce_cb ar, hda_alltoallv_cb a2a);
 void  rccl_get_unique_id(void *out_128);
-// test transport "ranks as threads of one process" (hda_comm.hip ThreadComm, hda_thread_ranks.hip)
-std::shared_ptr<void> make_thread_world(int size);
-Comm                 *make_thread_comm(int rank, const std::shared_ptr<void> &world);
-void                  thread_world_fail(const std::shared_ptr<void> &world);
 
 } // namespace hda

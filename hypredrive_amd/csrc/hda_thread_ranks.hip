@@ -5,12 +5,12 @@
 // six processes on its card, so eight rank PROCESSES sharing the one GPU cannot be rehearsed there.  The library's state is
 // process-global (hda_common.h); a thread that enters this seam (enter_thread_rank) gets a private copy of every piece of it
 // (context + stream, allocator, communicator, API and error state) until it leaves, so eight ranks can run as eight threads of
-// one process over the in-process transport of hda_comm.hip
+// one process over the in-process transport of hda_testranks_comm.hip
 // (ThreadComm: host-staged messages, generation barrier).  Each thread drives the PUBLIC API exactly like one rank of
 // laplacian.c:331-468 does: Initialize, Create, InputArgsParse, (generator), ResetInitialGuess + LinearSolverCreate + Setup +
-// Apply + Destroy, getters.  Nothing here is on the product path.
+// Apply + Destroy, getters.  Nothing here is on the product path: this file and the transport are built into libhypredrv_amd_testranks.so, not the product library.
 #include "HYPREDRV.h"
-#include "hda_comm.h"
+#include "hda_testranks.h"
 #include "hypredrv_amd.h"
 
 #include <cstring>

@@ -262,23 +262,7 @@ int hda_halo_plan_host(int nloc, const long long *part, const long long *ghost_g
  * product kernel (interior rows computed while the ghost values travel) */
 int hda_comm_stats(double out[5], int reset);
 const char *hda_comm_name(void); /* "self", "rccl", "host-callbacks", "threads" */
-/* Test seam (hda_thread_ranks.hip): `nranks` ranks of a row partition as THREADS of this process -- the library's state is
- * process-global, a thread that joins a thread world gets a private copy until it leaves -- each driving the public HYPREDRV_* sequence of one rank of the reference's
- * examples/src/C_laplacian/laplacian.c:331-468 on the generator's 7-pt Laplacian (global grid n, rank grid P with
- * P[0]*P[1]*P[2] == nranks, `-P 2 2 2` = BASELINE config 3's layout, laplacian.c:561-582).  A GPU box admits six processes
- * on its card, so this is how eight ranks are rehearsed on one GPU.  out16: iterations, converged, final relative residual,
- * |x|_2, |x|_1, |x|_inf, then rank 0's all-reduces / halo exchanges / overlapped exchanges / doubles all-reduced / doubles
- * exchanged of the last solve, V-cycles, partitioned levels, largest difference of the ranks' iteration counts, ranks, 0.
- * x_global (may be NULL): the solution in the generator's block numbering.  Returns 0, or 2 with the ranks' messages in errbuf. */
-int hda_thread_ranks_lap7(int nranks, const int n[3], const int P[3], const char *yaml, int nsolves, double out16[16], double *x_global,
-                          char *errbuf, int errlen);
-/* The same seam for a caller that brings its own threads (tests: Python threads, one per rank, each handing over its row block of an
- * arbitrary CSR matrix through the public API): create a world of nranks, let every thread join as its rank BEFORE its first
- * HYPREDRV_* call, leave when done (failed != 0 releases ranks blocked in a collective with an error), destroy after all have left. */
-void *hda_thread_world_create(int nranks);
-int hda_thread_world_join(void *world, int rank);
-int hda_thread_world_leave(void *world, int failed);
-void hda_thread_world_destroy(void *world);
+/* (the test seam "ranks as threads of one process" is declared in hypredrv_amd_testranks.h and built into its own library) */
 /* levels of the set-up BoomerAMG hierarchy behind an HYPREDRV_t that are row partitioned (0: one rank, or not set up) */
 int hda_amd_partitioned_levels(void *hypredrv);
 int hda_amd_hierarchy_levels(void *hypredrv); /* all levels: the partitioned ones + those of the replicated tail */

@@ -26,6 +26,24 @@ def test_kernel_abi_exports_every_declared_symbol():
     assert sorted(names) == sorted(h._lib.SYMBOLS)
 
 
+def test_test_seam_is_a_library_of_its_own():
+    """The test transport "ranks as threads of one process" is not in the product library: libhypredrv_amd_testranks.so exports what
+    include/hypredrv_amd_testranks.h declares, libhypredrv_amd.so exports none of it and does not depend on it."""
+    import subprocess
+    import hypredrive_amd as h
+    L, T = h.load(), h._lib.load_testranks()
+    names = [n for n in _declared("hypredrv_amd_testranks.h") if n.startswith("hda_")]
+    assert sorted(names) == sorted(h._lib.TESTRANKS_SYMBOLS) and len(names) == 5
+    for n in names:
+        assert hasattr(T, n), f"{n} declared in include/hypredrv_amd_testranks.h but not exported by the test library"
+        assert not hasattr(L, n), f"{n} (test seam) is exported by the product library"
+    lib = os.path.join(ROOT, "hypredrive_amd", "lib", "libhypredrv_amd.so")
+    needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+    assert "testranks" not in needed
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+    assert "ThreadComm" not in syms and "thread_world" not in syms
+
+
 def test_param_struct_layout_matches_oracle(orc):
     """hda_amg_params starts with the oracle's orc_amg_params (same fields, order and GPU defaults of
     src/internal/amg.c:120-238); the complex-smoother fields follow (the oracle takes them through

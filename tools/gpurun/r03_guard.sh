@@ -2,7 +2,7 @@
 # the GPU suite and the benches with guard tails on every device block and poisoned allocations
 set -o pipefail
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
-O=$R/gpurun_out/r03guard
+O=$R/gpurun_out/${1:-r03guard}
 rm -rf $O; mkdir -p $O
 cd $R
 export HDA_GUARD=1 HDA_POISON=1
