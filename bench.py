@@ -288,9 +288,64 @@ def run(args):
             h.destroy_solver()
     setup = w.reduce(setup, "max")
     A, amg = hh._lib.borrow(h)  # the objects HYPREDRV_LinearSolverSetup built, for the kernel-level measurement entries
+    # First contact with an asynchronous transport (RCCL): the same W + K solves are run FIRST with every halo exchange ahead of its
+    # product on the library stream (hda_set_overlap(0): one communicator in use at a time, nothing concurrent), and only then as
+    # designed -- exchanges on the communication stream under the owned-column part of the product.  The headline is the overlapped
+    # form; `serial_exchange` carries the other.  If the overlapped phase raises or does not finish, the line is written from the serial
+    # measurement and says so (`overlap_error`): a complete measurement of this job on RCCL either way.
+    serial, guard = None, None
+    two_phase = w.size > 1 and (transport == "rccl" or os.environ.get("HDA_BENCH_SERIAL_FIRST"))
+    if two_phase:
+        PHASE["name"] = "serial-exchange rehearsal"
+        hh.load().hda_set_overlap(0)
+        for _ in range(args.warmup):
+            h.apply()
+        w.barrier()
+        hh.sync()
+        t0 = time.perf_counter()
+        st, lst = [], None
+        for _ in range(args.steps):
+            lst = h.apply()
+            st.append(lst["solve_s"] * 1e3)
+        hh.sync()
+        w.barrier()
+        dts = w.reduce([time.perf_counter() - t0], "max")[0]
+        serial = {"what": "the same W + K solves with every halo exchange ahead of its product on the library stream (hda_set_overlap(0)), run "
+                          "before the overlapped ones", "ms_per_step": dts * 1e3 / args.steps, "value": N / (dts / args.steps),
+                  "iters": lst["iters"], "converged": lst["converged"], "final_rel": lst["final_rel"],
+                  "solve_timer_ms": w.reduce([sorted(st)[len(st) // 2]], "max")[0]}
+        hh.load().hda_set_overlap(-1)
+        import threading
+        limit = float(os.environ.get("HDA_BENCH_OVERLAP_TIMEOUT", str(max(60.0, 50.0 * dts))))
+
+        def give_up(why):
+            if w.rank == 0:
+                line = {"metric": "DOF/s, AMG-PCG solve phase, 3D 7-pt Laplacian", "value": serial["value"], "unit": "DOF/s", "n_gpus": w.size,
+                        "steps": args.steps, "warmup": args.warmup, "ms_per_step": serial["ms_per_step"], "higher_is_better": True,
+                        "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                        "config": {"workload": f"lap7 {gn[0]}x{gn[1]}x{gn[2]} fp64 AMG-PCG (PMIS, ext+i Pmax 4, l1-Jacobi V(1,1), GE coarse), "
+                                               + (f"{n}^3 per rank" if weak else "fixed size"), "rows": N, "parallelism": f"row blocks {P[0]}x{P[1]}x{P[2]}, one process per GPU",
+                                   "exchanges": "ahead of their products on the library stream (HDA_OVERLAP=0): the overlapped form failed, see overlap_error"},
+                        "transport": transport, "iters": serial["iters"], "converged": serial["converged"], "final_rel": serial["final_rel"],
+                        "solve_timer_ms": serial["solve_timer_ms"], "setup_ms": setup[1], "setup_cold_ms": setup[0],
+                        "overlap_error": why, "serial_exchange": serial}
+                sys.stdout.write(json.dumps(line) + "\n")
+                sys.stdout.flush()
+            os._exit(0)  # (every rank: kernels of the overlapped phase may never finish; the measurement above is complete)
+
+        guard = threading.Timer(limit, give_up, args=(f"the overlapped phase did not finish within {limit:.0f} s (phase: see stderr)",))
+        guard.daemon = True
+        guard.start()
+        if os.environ.get("HDA_BENCH_TEST_OVERLAP_HANG"):  # (test hook: the overlapped phase never returns)
+            time.sleep(1e6)
     PHASE["name"] = "warmup"
-    for _ in range(args.warmup):
-        h.apply()
+    try:
+        for _ in range(args.warmup):
+            h.apply()
+    except Exception as e:  # noqa: BLE001 - an RCCL error inside the overlapped products: the serial measurement stands
+        if serial is None:
+            raise
+        give_up(f"the overlapped phase raised: {e!r}"[:600])
     # probes: HIP events on the library stream around every launch of four kernels inside the timed solves.
     # dominant = Jacobi sweep on the biggest operator of the hierarchy kept in plain CSR (level 1 for this workload:
     # level 0 is stencil-coded and cheaper); k1 = the level-0 PCG product; P0 / R0 = level-0 prolongation / restriction
@@ -319,14 +374,21 @@ def run(args):
     hh.load().hda_marker(1)  # (an empty kernel: the solve phase's boundary in traces and counter passes, tools/pmc_traffic.py)
     t0 = time.perf_counter()
     last, solve_timer, vcyc = None, [], 0
-    for _ in range(args.steps):
-        last = h.apply()
-        solve_timer.append(last["solve_s"] * 1e3)
-        vcyc = hh.load().hda_last_precond_calls()
+    try:
+        for _ in range(args.steps):
+            last = h.apply()
+            solve_timer.append(last["solve_s"] * 1e3)
+            vcyc = hh.load().hda_last_precond_calls()
+    except Exception as e:  # noqa: BLE001
+        if serial is None:
+            raise
+        give_up(f"the overlapped phase raised: {e!r}"[:600])
     hh.load().hda_marker(2)
     hh.sync()
     w.barrier()
     dt = w.reduce([time.perf_counter() - t0], "max")[0]
+    if guard is not None:
+        guard.cancel()
     PHASE["name"] = "report"
     ms_per_step = dt * 1e3 / args.steps
     cs = hh._lib.comm_stats()
@@ -376,7 +438,7 @@ def run(args):
                        "rtol": 1e-6, "api": "HYPREDRV_LinearSystemResetInitialGuess + HYPREDRV_LinearSolverApply per step (every N)",
                        "timed": "K steps between barrier + device sync; includes the reference's untimed r0 / final-residual evaluations "
                                 "(solve_timer_ms is the reference's 'solve' timer alone); setup_ms is the 'prec' timer"},
-            "ranks_seen": ranks_seen, "transport": transport, "rccl_error": w.rccl_error,
+            "ranks_seen": ranks_seen, "transport": transport, "rccl_error": w.rccl_error, "serial_exchange": serial,
             # levels of the hierarchy cut into row blocks; the rest is the replicated tail every rank cycles redundantly (a level goes
             # there once it has fewer than HDA_REPLICATE_ROWS_PER_RANK = 50 000 rows per rank, at least 100 000 in all)
             "partitioned_levels": hh.load().hda_amd_partitioned_levels(h.h), "levels_total": hh.load().hda_amd_hierarchy_levels(h.h),

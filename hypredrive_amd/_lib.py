@@ -87,7 +87,7 @@ SYMBOLS = [
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
     "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
     "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass", "hda_truncate_rows",
-    "hda_interp_mm_extpi", "hda_interp_standard", "hda_marker", "hda_relax_blocks", "hda_l1_norms_blocks", "hda_hmis_blocks", "hda_amg_blocks", "hda_amg_level_blocks",
+    "hda_interp_mm_extpi", "hda_interp_standard", "hda_set_overlap", "hda_marker", "hda_relax_blocks", "hda_l1_norms_blocks", "hda_hmis_blocks", "hda_amg_blocks", "hda_amg_level_blocks",
 ]
 
 
@@ -163,6 +163,8 @@ def load():
     L.hda_ilu_factors.argtypes = [vp, C.c_int, P(vp)]
     L.hda_ilu_create_blocks.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int64), P(vp)]
     L.hda_ilu_blocks.argtypes = [vp, C.c_int]
+    L.hda_set_overlap.argtypes = [C.c_int]
+    L.hda_set_overlap.restype = None
     L.hda_amg_num_levels.argtypes = [vp]
     L.hda_amg_level_matrix.argtypes = [vp, C.c_int, C.c_int, P(vp)]
     L.hda_amg_level_cf.argtypes = [vp, C.c_int, ip]

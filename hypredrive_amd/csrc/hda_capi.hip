@@ -888,6 +888,7 @@ extern "C" int hda_time_kernel(int kind, hda_csr_t A, hda_amg_t amg, int reps, d
    HDA_CATCH
 }
 
+extern "C" void hda_set_overlap(int mode) { set_overlap_mode(mode); }
 extern "C" int hda_last_precond_calls(void) { return last_precond_calls(); }
 
 extern "C" int hda_solve_device(hda_csr_t A, hda_amg_t amg, const hda_krylov_params *kp, int solver,

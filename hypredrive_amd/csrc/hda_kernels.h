@@ -104,4 +104,7 @@ void lap7_generate(const int n[3], const int P[3], const int pc[3], const double
                    int rowptr_out[], long long cols_out[], double vals_out[], double rhs_out[],
                    int local_n);
 
+// products of a row partition overlap their ghost refresh (1), run it first (0), or decide by the transport / HDA_OVERLAP (-1: default)
+void set_overlap_mode(int mode);
+
 } // namespace hda

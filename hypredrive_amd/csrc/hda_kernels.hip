@@ -1982,10 +1982,12 @@ static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
 // Default: products overlap their ghost refresh on transports whose exchange only ENQUEUES work (RCCL).  On the host-staged
 // transport the exchange blocks the host and several ranks share one GPU: measured 17 % slower with the split (4 ranks x 128^3 on
 // one MI355X: 124.1 vs 106.6 ms per solve, gpurun_out/r02c), so it stays serial there.  HDA_OVERLAP=1 / 0 forces either (tests).
+static int g_overlap_forced = -2; // -2: not read yet; -1: by transport; 0 / 1: forced (HDA_OVERLAP, or set_overlap_mode below)
+void set_overlap_mode(int mode) { g_overlap_forced = (mode == 0 || mode == 1) ? mode : (getenv("HDA_OVERLAP") ? (atoi(getenv("HDA_OVERLAP")) != 0 ? 1 : 0) : -1); }
 static bool overlap_enabled()
 {
-   static const int forced = getenv("HDA_OVERLAP") ? (atoi(getenv("HDA_OVERLAP")) != 0 ? 1 : 0) : -1;
-   return forced >= 0 ? forced == 1 : Comm::world().async_exchange();
+   if (g_overlap_forced == -2) set_overlap_mode(-1);
+   return g_overlap_forced >= 0 ? g_overlap_forced == 1 : Comm::world().async_exchange();
 }
 
 // Row-partitioned product with the ghost refresh of x under it (SURVEY 2.4 C1 "overlapped with the diag-block SpMV"):

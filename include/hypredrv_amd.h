@@ -261,6 +261,10 @@ int hda_halo_plan_host(int nloc, const long long *part, const long long *ghost_g
  * neighbour send/recv), [2] doubles all-reduced, [3] doubles sent in halo exchanges, [4] exchanges that ran under a
  * product kernel (interior rows computed while the ghost values travel) */
 int hda_comm_stats(double out[5], int reset);
+/* row-partitioned products: 1 = overlap the ghost refresh of x with the owned-column part (the default on RCCL), 0 = exchange first,
+ * then the whole product (the default on host-staged transports), -1 = back to the default (transport, or HDA_OVERLAP).  bench.py
+ * measures both on a first multi-GPU run, the serial form first. */
+void hda_set_overlap(int mode);
 const char *hda_comm_name(void); /* "self", "rccl", "host-callbacks", "threads" */
 /* (the test seam "ranks as threads of one process" is declared in hypredrv_amd_testranks.h and built into its own library) */
 /* levels of the set-up BoomerAMG hierarchy behind an HYPREDRV_t that are row partitioned (0: one rank, or not set up) */

@@ -1900,3 +1900,32 @@ def test_reference_unit_tests_unmodified(name):
         pytest.skip(f"oracle/_ref/{name}_ref not built (needs /root/reference + MPICH at build time)")
     r = subprocess.run([exe], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+
+
+def _bench_two_ranks(extra_env, timeout=300):
+    env = dict(os.environ, HDA_TRANSPORT="staged", HDA_BENCH_SERIAL_FIRST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "40", "--steps", "2", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    return r, lines
+
+
+def test_bench_measures_serial_exchanges_before_overlapped_ones():
+    """bench.py on N > 1 ranks over an asynchronous transport (forced here on the staged one: two ranks share the GPU) runs the W + K
+    solves with every exchange ahead of its product first (hda_set_overlap(0)) and reports them as `serial_exchange` beside the headline."""
+    r, lines = _bench_two_ranks({})
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["converged"] and "overlap_error" not in d
+    se = d["serial_exchange"]
+    assert se["converged"] and se["iters"] == d["iters"] and se["ms_per_step"] > 0 and abs(se["final_rel"] - d["final_rel"]) < 1e-9
+
+
+def test_bench_reports_the_serial_measurement_when_the_overlapped_phase_hangs():
+    """...and if the overlapped phase never returns (test hook), the guard writes the line from the serial measurement, labelled, and
+    every rank leaves with status 0: a first contact with RCCL still ends with a measurement of the job."""
+    r, lines = _bench_two_ranks({"HDA_BENCH_TEST_OVERLAP_HANG": "1", "HDA_BENCH_OVERLAP_TIMEOUT": "4"})
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = lines[0]
+    assert "did not finish" in d["overlap_error"] and d["value"] == d["serial_exchange"]["value"] and d["ms_per_step"] == d["serial_exchange"]["ms_per_step"]
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["converged"] and d["scaling"] == "weak"
