@@ -639,6 +639,20 @@ def test_reference_laplacian_driver_unmodified(orc):
     assert row and float(row.group(1)) < 1e-6
 
 
+def test_reference_laplacian_driver_unmodified_at_benchmark_size():
+    """The same unmodified binary on BASELINE config 2 (`-n 256 256 256`, reference scripts/node_scaling.sh's one-GPU point): six
+    solves, r0 = 256 = sqrt(65 536 ones), 13 iterations each -- the oracle's count at 256^3 (test_parity_at_128_and_256_cubed,
+    bench.py's cpu_baseline.iters_match) -- and the reference's own 'solve' column under 0.05 s."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "laplacian_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/laplacian_ref not built (needs /root/reference + MPICH at build time)")
+    r = subprocess.run([exe, "-v", "1", "-n", "256", "256", "256", "-ns", "6"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rows = re.findall(r"^\|\s+(\d+) \|\s+([\d.]*) \|\s+([\d.]+) \|\s+([\d.]+) \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|", r.stdout, re.M)
+    assert len(rows) == 6 and all(x[4] == "2.56e+02" and int(x[6]) == 13 and float(x[5]) < 1e-6 for x in rows), r.stdout[-2000:]
+    assert all(float(x[3]) < 0.05 for x in rows[1:]) and all(float(x[2]) < 1.0 for x in rows[1:])
+
+
 def _run_convdif(cfg):
     exe = os.path.join(ROOT, "oracle", "_ref", "convdif_ref")
     if not os.path.exists(exe):
