@@ -22,11 +22,21 @@ for seed in seeds:
     M = M.tocsr(); M.eliminate_zeros(); M.sort_indices()
     Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
     kw = dict(strong_th=float(rng.choice([0.25, 0.5, 0.7])), pmax=int(rng.choice([0, 2, 4, 6])), interp_type=int(rng.choice([6, 6, 3])))
-    if os.environ.get("FUZZ_AGG", "1") != "0":  # round 3: aggressive levels (second PMIS pass, multipass interpolation, its truncation)
+    r4 = os.environ.get("FUZZ_R4", "1") != "0" and seed % 2 == 1
+    if r4:  # round 4: standard and mm-ext+i interpolation, HMIS and hybrid Gauss-Seidel on row blocks (the reference at np = V)
+        kw["interp_type"] = int(rng.choice([6, 8, 17, 3]))
+        kw["coarsen_type"] = int(rng.choice([8, 10, 10]))
+        gs = [(18, 18), (13, 14), (3, 4), (8, 8), (6, 6)][int(rng.integers(0, 5))]
+        kw["relax_down"], kw["relax_up"] = gs
+        kw["blocks"] = int(rng.choice([1, 1, 3, 7])) if (kw["coarsen_type"] == 10 or gs[0] != 18) else 1
+    if os.environ.get("FUZZ_AGG", "1") != "0" and not r4:  # round 3: aggressive levels (second PMIS pass, multipass interpolation, its truncation)
         kw.update(agg_num_levels=int(rng.choice([0, 0, 1, 2])), agg_num_paths=int(rng.choice([1, 1, 2])), agg_pmax=int(rng.choice([0, 0, 3])),
                   agg_trunc_factor=float(rng.choice([0.0, 0.0, 0.2])))
     try:
         ho, hh = orc.Amg(Ao, orc.amg_params(True, **kw)), hd.Amg(Ah, hd.AmgParams.default(**kw))
+        if r4 and kw["blocks"] > 1:
+            for l in range(min(ho.num_levels, hh.num_levels)):
+                if not np.array_equal(hh.level_blocks(l), ho.level_block_part(l)): raise AssertionError("block starts differ on level %d" % l)
         ok = hh.num_levels == ho.num_levels
         why = [] if ok else ["levels %d vs %d" % (hh.num_levels, ho.num_levels)]
         for l in range(min(ho.num_levels, hh.num_levels)):

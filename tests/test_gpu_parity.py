@@ -1065,8 +1065,10 @@ print(json.dumps(dict(seen=seen, its=its)))
 
 def test_random_hierarchies_bit_identical_to_oracle():
     """tests/fuzz_hierarchies.py, 40 random operators (40-3000 rows, 2-70 entries a row, both signs, empty rows; theta 0.25-0.7, Pmax 0-6,
-    ext+i / direct interpolation, 0-2 aggressive levels) through the whole setup under HDA_GUARD=1 HDA_POISON=1: every operator, C/F
-    marker and interpolation of every hierarchy bit-identical to the oracle's (200 of them ran clean in tools/gpurun/r03_m.sh)."""
+    ext+i / direct interpolation, 0-2 aggressive levels; every other seed since round 4: standard / mm-ext+i / direct / ext+i
+    interpolation, PMIS or HMIS, Jacobi or a hybrid Gauss-Seidel pair, on 1 / 3 / 7 row blocks) through the whole setup under
+    HDA_GUARD=1 HDA_POISON=1: every operator, C/F marker, block start and interpolation of every hierarchy bit-identical to the oracle's
+    (240 of them ran clean in round 4, gpurun_out/r04fuzz)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
