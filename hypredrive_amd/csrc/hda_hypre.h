@@ -40,7 +40,12 @@ struct hypre_IJMatrix_struct {
    long long              global_rows = 0, global_nnz = 0;
    void                   assemble();
    // adopt a block that was built directly in HBM with global column ids (generator path)
-   void adopt_device(int nloc, int nnz, hda::DArray<int> &rowptr, hda::DArray<long long> &gcols, hda::DArray<double> &vals);
+   // (refuse_duplicates: returns false -- nothing adopted -- when a row names a column twice; the caller then stages triplets instead)
+   bool adopt_device(int nloc, int nnz, hda::DArray<int> &rowptr, hda::DArray<long long> &gcols, hda::DArray<double> &vals,
+                     bool refuse_duplicates = false);
+   // a host CSR block with global column ids (HYPREDRV_LinearSystemSetMatrixFromCSR): uploaded as it is, columns mapped, rows sorted
+   // and checked on the device; false = a row has a duplicate column (the staged path defines what that means)
+   bool assemble_csr(const long long *indptr, const long long *cols, const double *data);
 };
 
 enum hda_solver_kind { HDA_SOLVER_PCG = 1, HDA_SOLVER_GMRES = 2, HDA_SOLVER_AMG = 3, HDA_SOLVER_ILU = 4, HDA_SOLVER_FGMRES = 5, HDA_SOLVER_BICGSTAB = 6, HDA_SOLVER_MGR = 7 };

@@ -498,7 +498,76 @@ void hypre_IJMatrix_struct::assemble()
    adopt_device(nloc, (int)nnz, drp, dgc, dv);
 }
 
-void hypre_IJMatrix_struct::adopt_device(int nl, int nnz, DArray<int> &rowptr, DArray<long long> &gcols, DArray<double> &vals)
+// entries of a block whose global column lies outside [jlo, jhi]: counted, and (second launch) written side by side
+__global__ __launch_bounds__(256) void k_ghost_cols(long nnz, const long long *__restrict__ gc, long long jlo, long long jhi, unsigned long long *count,
+                                                    long long *__restrict__ out)
+{
+   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (long)gridDim.x * 256)
+   {
+      const long long c = gc[k];
+      if (c < jlo || c > jhi)
+      {
+         const unsigned long long q = atomicAdd(count, 1ull);
+         if (out) out[q] = c;
+      }
+   }
+}
+__global__ __launch_bounds__(256) void k_indptr_to_rowptr(int n, const long long *__restrict__ ip, int *__restrict__ rp)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i <= n) rp[i] = (int)(ip[i] - ip[0]);
+}
+__global__ __launch_bounds__(256) void k_row_has_duplicate(int n, const int *__restrict__ rp, const int *__restrict__ cj, int *flag)
+{ // rows are column-sorted: a duplicate is two equal neighbours
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   for (int k = rp[i] + 1; k < rp[i + 1]; k++)
+      if (cj[k] == cj[k - 1]) { *flag = 1; return; }
+}
+
+bool hypre_IJMatrix_struct::assemble_csr(const long long *indptr, const long long *cols, const double *data)
+{
+   const long long nnz = indptr[nloc] - indptr[0];
+   DArray<long long> dip, dgc;
+   DArray<double>    dv;
+   DArray<int>       drp((size_t)nloc + 1);
+   dip.upload(indptr, (size_t)nloc + 1);
+   if (nnz)
+   {
+      dgc.upload(cols + indptr[0], (size_t)nnz);
+      dv.upload(data + indptr[0], (size_t)nnz);
+   }
+   else
+   { // a block without entries (cols / data may be NULL: reference tests/test_setmatrix_from_csr.c:483)
+      dgc.alloc(1);
+      dv.alloc(1);
+   }
+   k_indptr_to_rowptr<<<ceil_div(nloc + 1, 256), 256, 0, STREAM>>>(nloc, dip.data(), drp.data());
+   // ghost columns: the few entries that leave [jlower, jupper] are collected on the device, sorted and made unique on the host
+   ghost_gids.clear();
+   if (nnz)
+   {
+      DArray<unsigned long long> cnt(1);
+      cnt.zero();
+      const int g = std::min(ceil_div(nnz, 256), 1 << 16);
+      k_ghost_cols<<<g, 256, 0, STREAM>>>((long)nnz, dgc.data(), jlower, jupper, cnt.data(), nullptr);
+      unsigned long long ng = 0;
+      cnt.download(&ng, 1);
+      if (ng)
+      {
+         DArray<long long> out((size_t)ng);
+         cnt.zero();
+         k_ghost_cols<<<g, 256, 0, STREAM>>>((long)nnz, dgc.data(), jlower, jupper, cnt.data(), out.data());
+         std::vector<long long> gh = out.to_host();
+         std::sort(gh.begin(), gh.end());
+         gh.erase(std::unique(gh.begin(), gh.end()), gh.end());
+         ghost_gids = gh;
+      }
+   }
+   return adopt_device(nloc, (int)nnz, drp, dgc, dv, true);
+}
+
+bool hypre_IJMatrix_struct::adopt_device(int nl, int nnz, DArray<int> &rowptr, DArray<long long> &gcols, DArray<double> &vals, bool refuse_duplicates)
 {
    // ghost list must already be in ghost_gids (ascending); single-rank callers leave it empty
    const int ncol_loc = (int)(jupper - jlower + 1);
@@ -514,9 +583,24 @@ void hypre_IJMatrix_struct::adopt_device(int nl, int nnz, DArray<int> &rowptr, D
       k_map_gcols<<<std::min(ceil_div(nnz, 256), 1 << 16), 256, 0, STREAM>>>(nnz, gcols.data(), jlower, jupper, ncol_loc,
                                                                            dgh.data(), (int)ghost_gids.size(), A.col.data());
    sort_rows(A);
+   if (refuse_duplicates && nnz)
+   {
+      DArray<int> flag(1);
+      flag.zero();
+      k_row_has_duplicate<<<ceil_div(nl, 256), 256, 0, STREAM>>>(nl, A.rowptr.data(), A.col.data(), flag.data());
+      int f = 0;
+      flag.download(&f, 1);
+      if (f)
+      {
+         A = DCsr();
+         ghost_gids.clear();
+         return false;
+      }
+   }
    Context::get().sync();
    finish_partition(this);
    assembled = true;
+   return true;
 }
 
 extern "C" HYPRE_Int HYPRE_IJMatrixAssemble(HYPRE_IJMatrix m)

@@ -833,6 +833,31 @@ static uint32_t set_matrix_from_csr(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_
    HYPRE_IJMatrixInitialize(A);
    const HYPRE_BigInt base = indptr[0];
    const size_t       nnz  = (size_t)nnz_big;
+   // the caller's arrays go to the device as they are (columns mapped, rows sorted and checked there); only a block with a column
+   // named twice in a row takes the staged path below, which defines what that means (the later value wins)
+   const bool direct = !(getenv("HDA_CSR_DIRECT") && atoi(getenv("HDA_CSR_DIRECT")) == 0);
+   int ndev = 0;
+   if (direct && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) // (no device: the staged path reports it through HYPRE_IJMatrixAssemble)
+   {
+      bool done = false;
+      try
+      {
+         done = A->assemble_csr((const long long *)indptr, (const long long *)cols, data);
+      }
+      catch (...)
+      {
+         HYPRE_IJMatrixDestroy(A);
+         annotate(h, "matrix", false);
+         throw;
+      }
+      if (done)
+      {
+         h->mat_A = h->mat_M = A;
+         h->owns_A           = true;
+         annotate(h, "matrix", false);
+         return g_err;
+      }
+   }
    A->t_row.resize(nnz); A->t_col.resize(nnz); A->t_val.resize(nnz); A->t_add.assign(nnz, 0);
    for (int i = 0; i < n; i++)
       for (HYPRE_BigInt k = indptr[i]; k < indptr[i + 1]; k++)
@@ -870,9 +895,21 @@ static uint32_t set_rhs_from_array(HYPREDRV_t h, HYPRE_BigInt row_start, HYPRE_B
    annotate(h, "rhs", true);
    HYPRE_IJVector b = nullptr;
    HYPRE_IJVectorCreate(h->comm, row_start, row_end, &b);
-   HYPRE_IJVectorInitialize(b);
-   if (n) memcpy(b->stage.data(), values, sizeof(double) * (size_t)n);
-   HYPRE_IJVectorAssemble(b);
+   int ndev = 0;
+   if (n > 0 && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0)
+   { // the caller's array goes to the device as it is (no host staging copy)
+      b->initialized = true;
+      b->d.alloc((size_t)n);
+      b->capacity = b->d.size();
+      b->d.upload(values, (size_t)n);
+      b->assembled = true;
+   }
+   else
+   {
+      HYPRE_IJVectorInitialize(b);
+      if (n) memcpy(b->stage.data(), values, sizeof(double) * (size_t)n);
+      HYPRE_IJVectorAssemble(b);
+   }
    h->vec_b  = b;
    h->owns_b = true;
    annotate(h, "rhs", false);

@@ -54,6 +54,50 @@ def test_csr_offset_one_by_one(hd, pins):
     assert h.solution_norm("bad") == -1.0  # tests/test_linsys.c:4126-4155
 
 
+def test_csr_direct_device_assembly_equals_the_staged_one(hd, monkeypatch):
+    """HYPREDRV_LinearSystemSetMatrixFromCSR uploads the caller's arrays as they are and maps columns / sorts rows on the device
+    (round 4; the staged host path took 0.65 s for 49 M entries).  Rows in any column order and an offset indptr give the operator the
+    staged path builds (HDA_CSR_DIRECT=0), entry for entry; a row that names a column twice is handed to the staged path, whose rule
+    (the later value wins) therefore still holds."""
+    import hypredrive_amd as hh
+    rng = np.random.default_rng(5)
+    n = 400
+    M = sp.random(n, n, density=0.03, random_state=rng, format="csr")
+    M = (M + M.T + sp.diags(np.full(n, 5.0))).tocsr()
+    M.sort_indices()
+    ip, ix, v = M.indptr.astype(np.int64), M.indices.astype(np.int64).copy(), M.data.copy()
+    for i in range(n):  # shuffle every row's entries
+        q = rng.permutation(ip[i + 1] - ip[i]) + ip[i]
+        ix[ip[i]:ip[i + 1]], v[ip[i]:ip[i + 1]] = ix[q], v[q]
+    pad = 7  # offset CSR: indptr[0] = 7, seven unused leading entries
+    ip2, ix2, v2 = ip + pad, np.r_[np.full(pad, 3), ix], np.r_[np.full(pad, 9.0), v]
+    # a duplicate: row 11 names its first column again, with another value
+    k0 = ip2[11]
+    ipd = ip2.copy()
+    ipd[12:] += 1
+    ixd, vd = np.insert(ix2, ip2[12], ix2[k0]), np.insert(v2, ip2[12], 123.0)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HDA_CSR_DIRECT", mode)
+        for tag, (a, b, c) in (("plain", (ip2, ix2, v2)), ("dup", (ipd, ixd, vd))):
+            h = hd.Hypredrv(YAML_PCG_AMG)
+            h.set_matrix_csr(0, n - 1, a, b, c)
+            h.set_rhs_array(0, n - 1, np.ones(n))
+            h.finish_system()
+            h.create_and_setup()
+            A, amg = hh._lib.borrow(h)
+            got[mode, tag] = A.to_scipy().copy()
+            del A, amg
+            h.destroy_solver()
+            h.close()
+    for tag in ("plain", "dup"):
+        a, b = got["1", tag], got["0", tag]
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data), tag
+    assert abs(got["1", "plain"] - M).max() == 0.0
+    D = got["1", "dup"]
+    assert D[11, ix2[k0]] == 123.0 and D.nnz == M.nnz  # the later value won, one entry
+
+
 def test_norms_known_answer(hd, pins):
     """tests/test_linsys.c:4126-4155 on the solution of I x = [1,-2,3]."""
     k = pins["unit"]["norms_of_1_m2_3"]
