@@ -442,6 +442,29 @@ static void finish_partition(hypre_IJMatrix_struct *m)
 void hypre_IJMatrix_struct::assemble()
 {
    const size_t T = t_row.size();
+   // Rows handed over in order with plain "set" semantics (every row-at-a-time driver: reference examples/src/C_laplacian/laplacian.c:
+   // 734-914) are a CSR block already: count the rows, upload the staged columns and values as they are and let the device map, sort
+   // and check them (assemble_csr); a block with a column named twice in a row comes back and takes the general path below.
+   if (T > 0 && T < (1ULL << 31) && !(getenv("HDA_CSR_DIRECT") && atoi(getenv("HDA_CSR_DIRECT")) == 0))
+   {
+      bool ordered = true;
+      for (size_t q = 1; q < T && ordered; q++) ordered = t_row[q] >= t_row[q - 1];
+      for (size_t q = 0; q < T && ordered; q++) ordered = !t_add[q];
+      if (ordered)
+      {
+         std::vector<long long> ip((size_t)nloc + 1, 0);
+         for (size_t q = 0; q < T; q++) ip[(size_t)t_row[q] + 1]++;
+         for (int i = 0; i < nloc; i++) ip[(size_t)i + 1] += ip[(size_t)i];
+         if (assemble_csr(ip.data(), t_col.data(), t_val.data()))
+         {
+            std::vector<int>().swap(t_row);
+            std::vector<long long>().swap(t_col);
+            std::vector<double>().swap(t_val);
+            std::vector<char>().swap(t_add);
+            return;
+         }
+      }
+   }
    // stable counting sort of the triplets by row
    std::vector<int> rp((size_t)nloc + 1, 0);
    for (size_t q = 0; q < T; q++) rp[(size_t)t_row[q] + 1]++;
