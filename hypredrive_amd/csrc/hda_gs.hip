@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_gs_sorted_fill(int n, int nb, const int
    for (int k = rp[i]; k < rp[i + 1]; k++, d++)
    { // same entry order as the row
       const int c = cj[k];
-      scj[d]      = (c >= lo && c < hi) ? pos_of[c] : ~c;
+      scj[d]      = (c >= lo && c < hi) ? pos_of[c] : ~pos_of[c]; // (another block's column: its position in the sweep-START copy)
       sv[d]       = v[k];
    }
    for (; d < e; d++) { scj[d] = q; sv[d] = 0.0; } // padding: 0 * (the row's own value)
@@ -160,6 +160,7 @@ static void gs_sorted_copy(const DCsr &A, const GsPlan &plan)
    k_gs_sorted_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.nblk, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
                                                          A.col.data(), A.val.data(), plan.s_rowptr.data(), plan.s_col.data(), plan.s_val.data());
    if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); }
+   if (plan.s_x0.size() != (size_t)n) plan.s_x0.alloc((size_t)n);
    plan.sorted = true;
 }
 
@@ -367,6 +368,7 @@ void build_gs_plan(const DCsr &A, GsPlan &plan)
 
 // Row-block form (hypre's hybrid sweep at np = V on one GPU): the dependency levels of every block's OWN pattern -- connections
 // that leave a block carry the values of the sweep's start, so they order nothing -- and the rows sorted by (block, level, row).
+static void gs_free_plan(const GsPlan &plan, int n);
 void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &plan)
 {
    const int n = A.nrows, nb = (int)part.size() - 1;
@@ -377,6 +379,7 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
    plan.perm.alloc((size_t)std::max(n, 1));
    plan.lvl_ptr.assign(1, 0);
    plan.blk_part.upload(part.data(), part.size());
+   plan.h_part = part;
    std::vector<int> bl_ptr((size_t)nb + 1, 0), bl;
    if (n == 0)
    {
@@ -415,6 +418,11 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
    const int sorted_min = getenv("HDA_GS_SORTED_MIN") ? atoi(getenv("HDA_GS_SORTED_MIN")) : 2000; // (read per plan: the tests move it)
    if (n >= sorted_min && plan.blk_max_levels + 1 <= 12 * 1024) gs_sorted_copy(A, plan); // (the kernel keeps a block's level offsets in LDS: 48 KB)
    if (plan.sorted && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0)) gs_ring_copy(A, plan);
+   if (plan.sorted)
+   {
+      if (!plan.s_x0.size()) plan.s_x0.alloc((size_t)n);
+      gs_free_plan(plan, n);
+   }
    if (getenv("HDA_VERBOSE"))
       fprintf(stderr, "[hda] block Gauss-Seidel plan: n=%d nnz=%d (%.1f per row), %d blocks, dependency levels per block: max %d, mean %.0f (%.0f rows per level)%s\n",
               n, A.nnz, A.avg_row(), nb, plan.blk_max_levels, (double)(bl.size() - 1) / nb, (double)n / std::max<size_t>(bl.size() - 1, 1),
@@ -716,8 +724,8 @@ template <int LPR, int NT>
 __global__ __launch_bounds__(NT) void k_gs_blocks_sorted(int backward, int zero_in, const int *__restrict__ blk_lvl_ptr,
                                                            const int *__restrict__ blk_lvl, const int *__restrict__ srp4,
                                                            const int4 *__restrict__ scj4, const double2 *__restrict__ sv2,
-                                                           const double *__restrict__ sd, const double *__restrict__ sb, const double *xin,
-                                                           double *sx, unsigned long long *diag)
+                                                           const double *__restrict__ sd, const double *__restrict__ sb,
+                                                           const double *__restrict__ sx0, double *sx, unsigned long long *diag)
 {
    extern __shared__ int slp[]; // level offsets of this block (nl + 1 of them)
    unsigned long long tG = 0, tF = 0, tB = 0, tN = 0, t0 = 0, t1 = 0, tU = 0, tI = 0, tE = 0; // diag: shader-clock sums per phase, passes
@@ -760,9 +768,10 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_sorted(int backward, int zero_
       r.rhs = sb[ra.pos];
       return r;
    };
-   // value of column c: inside the block sx[position], outside it the other blocks' old value xin[~c] (zero_in: 0) -- ONE load
-   auto address = [&](int c, int self) -> const double * { return (c >= 0) ? sx + c : (zero_in ? sx + self : xin + ~c); };
-   auto masked  = [&](int c, double v) { return (c < 0 && zero_in) ? 0.0 : v; };
+   // value of column c: inside the block sx[position], outside it the other blocks' value at the sweep's start, sx0[~c] (zeros from a
+   // zero guess) -- ONE load
+   auto address = [&](int c, int) -> const double * { return (c >= 0) ? sx + c : sx0 + ~c; };
+   auto masked  = [&](int, double v) { return v; };
    auto pass = [&](const RowB &cur, const RowA &nxa, RowB &nxb, RowA &nx2, const It &itA) {
       // the gathers of this pass go out FIRST: loads return in issue order, so requests made before them would have to land before them
       const double x0 = *address(cur.c.x, cur.pos), x1 = *address(cur.c.y, cur.pos), x2 = *address(cur.c.z, cur.pos),
@@ -1044,12 +1053,360 @@ static void gs_blocks_sorted_t(const DCsr &A, const GsPlan &p, const double *din
 {
    const int    n   = A.nrows;
    const size_t lds = sizeof(int) * (size_t)(p.blk_max_levels + 1);
-   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data());
+   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data(),
+                                                          p.s_x0.data());
    k_gs_blocks_sorted<LPR, NT><<<p.nblk, NT, lds, STREAM>>>(forward ? 0 : 1, zero_in ? 1 : 0, p.blk_lvl_ptr.data(), p.blk_lvl.data(),
                                                          p.s_rowptr.data(), (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(),
-                                                         p.s_d.data(), p.s_b.data(), xin, p.s_x.data(), gs_diag_buffer());
+                                                         p.s_d.data(), p.s_b.data(), p.s_x0.data(), p.s_x.data(), gs_diag_buffer());
    gs_diag_report(LPR, n);
    k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
+}
+
+// ---- the row-block sweep WITHOUT level barriers ("sync-free": every row waits for its own dependencies) ---------------------------------
+// The kernels above pay a workgroup barrier and a full software-pipeline stage per dependency level (~2 800 cycles measured).  Here the
+// rows of a block are dealt round-robin, in sweep order, to the G = NT / LPR lane groups of the block's workgroup; a group finishes
+// sweep index t (row of position lo + t, or hi - 1 - t backwards), leaves the new value in an LDS ring (slot t mod RING) and then
+// publishes t in done[group] (LDS; the two writes of one lane stay in order), and a row whose column is an EARLIER sweep index t' polls
+// done[t' mod G] >= t' before it takes the value from the ring.  Columns later in the sweep (and the row's own) come from the
+// sweep-start copy, other blocks' columns from the input vector: neither depends on the sweep, both are requested before the wait.
+// What bounds a level is then two LDS round trips and the arithmetic.  A group may run at most RING - W - G sweep indices ahead of the
+// slowest wavefront (wdone[]), so that a ring slot is never overwritten while a row W = RING / 4 indices back may still read it; the
+// plan guarantees that no dependency reaches further back than W (else this kernel is not used).  Rows take one 4-entry chunk per lane:
+// LPR >= chunks of the longest row.  Progress: the smallest unfinished sweep index never waits for the guard and all its dependencies
+// are smaller, so some row can always finish; a spin limit turns a protocol error into an error flag instead of a hang.
+// sum / conjunction over the LPR lanes of a row with every lane receiving the result: data-parallel-primitive moves inside a row of
+// sixteen lanes (quad permutes, half-row and row mirrors: no LDS traffic, unlike ds_bpermute), shuffles beyond.  The pairing differs from
+// the xor butterfly only in which lane adds which partner: a + b and b + a, the same bits.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double x)
+{
+   const int lo = dpp_i<CTRL>(__double2loint(x)), hi = dpp_i<CTRL>(__double2hiint(x));
+   return __hiloint2double(hi, lo);
+}
+template <int LPR>
+__device__ __forceinline__ double group_sum(double x)
+{
+   if (LPR >= 2) x += dpp_d<0xB1>(x);  // quad_perm [1,0,3,2]
+   if (LPR >= 4) x += dpp_d<0x4E>(x);  // quad_perm [2,3,0,1]
+   if (LPR >= 8) x += dpp_d<0x141>(x); // row_half_mirror
+   if (LPR >= 16) x += dpp_d<0x140>(x); // row_mirror
+   if (LPR >= 32) x += __shfl_xor(x, 16);
+   if (LPR >= 64) x += __shfl_xor(x, 32);
+   return x;
+}
+template <int LPR>
+__device__ __forceinline__ int group_and(int x)
+{
+   if (LPR >= 2) x &= dpp_i<0xB1>(x);
+   if (LPR >= 4) x &= dpp_i<0x4E>(x);
+   if (LPR >= 8) x &= dpp_i<0x141>(x);
+   if (LPR >= 16) x &= dpp_i<0x140>(x);
+   if (LPR >= 32) x &= __shfl_xor(x, 16);
+   if (LPR >= 64) x &= __shfl_xor(x, 32);
+   return x;
+}
+template <int LPR, int MAXC, int NT, bool BACKWARD>
+__global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int *__restrict__ part, const int *__restrict__ srp4,
+                                                       const int4 *__restrict__ scj4, const double2 *__restrict__ sv2,
+                                                       const double *__restrict__ sd, const double *__restrict__ sb,
+                                                       const double *__restrict__ sx0, double *sx, int *err)
+{
+   constexpr int G = NT / LPR, NW = NT / 64, GPW = 64 / LPR, NE = 4 * MAXC; // groups, wavefronts, groups per wavefront, entries per lane
+   extern __shared__ long long free_ring[];   // ring_mask + 1 values (the bits of a double each)
+   __shared__ int              done_s[G];     // last sweep index every group has finished
+   __shared__ int              wdone_s[NW];   // last sweep index of the last round every wavefront has finished
+   // (relaxed atomic accesses of the NAMED shared arrays: they stay LDS instructions and are re-read in every turn of a waiting loop;
+   //  a volatile pointer to them becomes a generic pointer -- flat loads with system scope and a wait for every counter after each)
+#define RING_LD(i) __longlong_as_double(__atomic_load_n(&free_ring[i], __ATOMIC_RELAXED))
+#define RING_ST(i, x) __atomic_store_n(&free_ring[i], __double_as_longlong(x), __ATOMIC_RELAXED)
+#define DONE_LD(i) __atomic_load_n(&done_s[i], __ATOMIC_RELAXED)
+#define DONE_ST(i, x) __atomic_store_n(&done_s[i], x, __ATOMIC_RELAXED)
+#define WDONE_LD(i) __atomic_load_n(&wdone_s[i], __ATOMIC_RELAXED)
+#define WDONE_ST(i, x) __atomic_store_n(&wdone_s[i], x, __ATOMIC_RELAXED)
+   constexpr bool backward = BACKWARD;
+   const int blk = blockIdx.x, lo = part[blk], hi = part[blk + 1], nb = hi - lo;
+   const int tid = threadIdx.x, lane = tid & (LPR - 1), g = tid / LPR, wave = tid >> 6;
+   if (lane == 0) DONE_ST(g, -1);
+   if ((tid & 63) == 0) WDONE_ST(wave, -1);
+   __syncthreads();
+   const int  rounds = (nb + G - 1) / G, W = (ring_mask + 1) >> 2;
+   const bool whole  = (ring_mask + 1) >= nb; // every value of the block has a slot of its own: nothing is ever overwritten, no guard
+   int        KG     = 8;
+   while (KG > 1 && KG * G > (ring_mask + 1) - W - G - 1) KG >>= 1;
+   // A row goes through four stages in four consecutive rounds, so that nothing the sweep does not produce is waited for when the row's
+   // turn comes: A its chunk range (three rounds ahead), B its chunks, divisor, right-hand side and own old value (two ahead), X the
+   // values that do not depend on the sweep -- other blocks' columns, columns later in the sweep (one ahead) --, C the wait for its
+   // dependencies, the sum and the update.  Four NAMED register sets per stage rotate and the loop is unrolled by four: plain values
+   // the compiler keeps in registers (arrays of these structs went to scratch memory), never a copy of a value still in flight.
+   // (Deeper pipelines -- leads of 5 / 3 / 1 and 6 / 4 / 2 rounds -- measured the same: a round costs the instructions its eight
+   //  wavefronts issue, two to a SIMD, not a memory latency.)
+   struct RowA { int t, p, c0, c1; bool has; };
+   struct RowB { int t, p; bool has, mine[MAXC]; int4 c[MAXC]; double2 a01[MAXC], a23[MAXC]; double d, rhs, own; };
+   struct RowX { int t, p; bool has, mine[MAXC]; double a[NE], v[NE], d, rhs, own; int dep[NE]; };
+   auto stage_a = [&](int r) {
+      RowA ra;
+      ra.t   = r * G + g;
+      ra.has = ra.t < nb;
+      ra.p   = ra.has ? (backward ? hi - 1 - ra.t : lo + ra.t) : lo;
+      ra.c0  = srp4[ra.p];
+      ra.c1  = srp4[ra.p + 1];
+      return ra;
+   };
+   auto stage_b = [&](const RowA &ra) {
+      RowB rb;
+      rb.t = ra.t; rb.p = ra.p; rb.has = ra.has;
+#pragma unroll
+      for (int m = 0; m < MAXC; m++)
+      {
+         const int  ch   = ra.c0 + lane + m * LPR;
+         const bool mine = ra.has && ch < ra.c1;
+         const int  cc   = mine ? ch : ra.c0; // (always a readable chunk: the copy ends with a spare one)
+         rb.c[m]    = scj4[cc];
+         rb.a01[m]  = sv2[2 * cc];
+         rb.a23[m]  = sv2[2 * cc + 1];
+         rb.mine[m] = mine; // (a lane without a chunk of its own carries the row's first one: real dependencies of the row, a sum that is dropped)
+      }
+      rb.d   = sd[ra.p];
+      rb.rhs = sb[ra.p];
+      rb.own = sx0[ra.p];
+      return rb;
+   };
+   auto stage_x = [&](const RowB &rb) {
+      RowX rx;
+      rx.t = rb.t; rx.p = rb.p; rx.has = rb.has; rx.d = rb.d; rx.rhs = rb.rhs; rx.own = rb.own;
+#pragma unroll
+      for (int m = 0; m < MAXC; m++)
+      {
+         rx.mine[m]           = rb.mine[m];
+         const int    cols[4] = {rb.c[m].x, rb.c[m].y, rb.c[m].z, rb.c[m].w};
+         const double as[4]   = {rb.a01[m].x, rb.a01[m].y, rb.a23[m].x, rb.a23[m].y};
+#pragma unroll
+         for (int e = 0; e < 4; e++)
+         { // every load unconditional, at an always valid address; what it is worth is decided afterwards
+            const int  col   = cols[e];
+            const int  pos   = col ^ (col >> 31); // (another block's column is stored as ~position: the sweep-start copy serves both)
+            const bool isdep = col >= 0 && (backward ? col > rb.p : col < rb.p);
+            const double val = sx0[pos];
+            rx.a[4 * m + e]   = as[e];
+            rx.dep[4 * m + e] = isdep ? (backward ? hi - 1 - col : col - lo) : -1;
+            rx.v[4 * m + e]   = isdep ? 0.0 : val;
+         }
+      }
+      return rx;
+   };
+   int  bad = 0; // (a spin limit was hit: reported once, after the sweep -- no memory operation inside the waiting loops)
+   auto stage_c = [&](RowX &rx, int r) {
+      // guard of the ring (looked at every KG-th round, for the KG rounds ahead; KG G <= RING - W - G - 1, or round 0 could never start):
+      // nobody more than RING - W - G sweep indices behind
+      const int need = (r + KG) * G - (ring_mask + 1) + W + G;
+      if (!whole && (r & (KG - 1)) == 0 && need >= 0)
+      {
+         int spins = 0;
+         while (true)
+         {
+            int m = WDONE_LD(tid & (NW - 1));
+#pragma unroll
+            for (int o = NW / 2; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+            if (m >= need) break;
+            if (++spins > (1 << 22)) { bad = 2; break; }
+         }
+      }
+      double xn = 0.0;
+      auto look = [&]() { // are this lane's dependencies done?  (every read unconditional: dep = -1 names the last slot, then ignored)
+         int ok = 1;
+#pragma unroll
+         for (int e = 0; e < NE; e++)
+         {
+            const int dn = DONE_LD(rx.dep[e] & (G - 1));
+            ok &= (rx.dep[e] < 0) | (dn >= rx.dep[e]);
+         }
+         return group_and<LPR>(ok);
+      };
+      auto finish = [&]() { // the row's sum with the ring's values, the update, the new value into the ring and then the flag
+         asm volatile("" ::: "memory");
+         double rv[NE];
+#pragma unroll
+         for (int e = 0; e < NE; e++) rv[e] = RING_LD(rx.dep[e] & ring_mask);
+         double sum = 0.0;
+#pragma unroll
+         for (int m = 0; m < MAXC; m++)
+         {
+            double sm = 0.0;
+#pragma unroll
+            for (int e = 4 * m; e < 4 * m + 4; e++) sm += rx.a[e] * (rx.dep[e] >= 0 ? rv[e] : rx.v[e]);
+            sum += rx.mine[m] ? sm : 0.0;
+         }
+         sum = group_sum<LPR>(sum);
+         xn  = rx.own + rx.d * (rx.rhs - sum);
+         if (lane == 0 && rx.has)
+         {
+            RING_ST(rx.t & ring_mask, xn);
+            asm volatile("" ::: "memory");
+            DONE_ST(g, rx.t);
+         }
+      };
+      // the common case first, without a diverging branch: every row of this wavefront's round finds its dependencies done at the first
+      // look (a round is a level's worth of rows; the level before it was finished a round ago)
+      if (__builtin_amdgcn_ballot_w64(rx.has && !look()) == 0ull) finish();
+      else
+      { // rows of this round that wait for each other (a round across a level's end) or for a slower wavefront
+         bool fin   = !rx.has;
+         int  spins = 0;
+         while (true)
+         {
+            if (!fin && look())
+            {
+               finish();
+               fin = true;
+            }
+            if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
+            if (++spins > (1 << 22)) { bad = 1; break; }
+         }
+      }
+      if (lane == 0 && rx.has) sx[rx.p] = xn; // (after the loop: a memory operation inside it would make the compiler wait for every prefetch)
+      if ((tid & 63) == 0) WDONE_ST(wave, r * G + wave * GPW + GPW - 1);
+   };
+   RowA A0 = stage_a(0), A1 = stage_a(1), A2 = stage_a(2), A3;
+   RowB B0 = stage_b(A0), B1 = stage_b(A1), B2, B3;
+   RowX X0 = stage_x(B0), X1, X2, X3;
+   for (int r = 0; r < rounds && !bad; r += 4)
+   {
+      A3 = stage_a(r + 3); B2 = stage_b(A2); X1 = stage_x(B1); stage_c(X0, r);
+      if (r + 1 >= rounds) break;
+      A0 = stage_a(r + 4); B3 = stage_b(A3); X2 = stage_x(B2); stage_c(X1, r + 1);
+      if (r + 2 >= rounds) break;
+      A1 = stage_a(r + 5); B0 = stage_b(A0); X3 = stage_x(B3); stage_c(X2, r + 2);
+      if (r + 3 >= rounds) break;
+      A2 = stage_a(r + 6); B1 = stage_b(A1); X0 = stage_x(B0); stage_c(X3, r + 3);
+   }
+   if (bad) *err = bad;
+}
+#undef RING_LD
+#undef RING_ST
+#undef DONE_LD
+#undef DONE_ST
+#undef WDONE_LD
+#undef WDONE_ST
+
+// TIMING PROBE (HDA_GS_PROBE=1): what one workgroup per block can stream when nothing depends on anything -- the block's chunks, divisors,
+// right-hand sides and sweep-start values read once with 16-byte loads, summed, one store per lane
+__global__ __launch_bounds__(512) void k_gs_stream_probe(const int *__restrict__ part, const int *__restrict__ srp4, const int4 *__restrict__ scj4,
+                                                         const double2 *__restrict__ sv2, const double *__restrict__ sd,
+                                                         const double *__restrict__ sb, const double *__restrict__ sx0, double *out)
+{
+   const int blk = blockIdx.x, lo = part[blk], hi = part[blk + 1];
+   const int c0 = srp4[lo], c1 = srp4[hi];
+   double acc = 0.0;
+   for (int ch = c0 + threadIdx.x; ch < c1; ch += 512)
+   {
+      const int4    c = scj4[ch];
+      const double2 a = sv2[2 * ch], b = sv2[2 * ch + 1];
+      acc += a.x + a.y + b.x + b.y + (double)(c.x + c.y + c.z + c.w);
+   }
+   for (int p = lo + threadIdx.x; p < hi; p += 512) acc += sd[p] + sb[p] + sx0[p];
+   out[blk * 512 + threadIdx.x] = acc;
+}
+
+// longest distance, in sweep positions, between a row and an in-block column of it (the reach of a dependency in either direction)
+__global__ __launch_bounds__(256) void k_gs_reach(int n, const int *__restrict__ srp4, const int *__restrict__ scj, int *reach, int *maxchunks)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   int       m = 0, k = 0;
+   if (q < n)
+   {
+      k = srp4[q + 1] - srp4[q];
+      for (int e = 4 * srp4[q]; e < 4 * srp4[q + 1]; e++)
+         if (scj[e] >= 0) m = max(m, abs(scj[e] - q));
+   }
+   for (int o = 32; o > 0; o >>= 1) { m = max(m, __shfl_xor(m, o)); k = max(k, __shfl_xor(k, o)); }
+   if ((threadIdx.x & 63) == 0) { if (m) atomicMax(reach, m); if (k) atomicMax(maxchunks, k); }
+}
+static void gs_free_plan(const GsPlan &plan, int n)
+{ // can the barrier-free kernel take this operator?  ring size, lanes per row and chunks per lane if so
+   plan.free_lpr = 0;
+   if (!plan.sorted || !plan.s_x0.size()) return;
+   DArray<int> two(2);
+   two.zero();
+   k_gs_reach<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), two.data(), two.data() + 1);
+   int h[2] = {0, 0};
+   two.download(h, 2);
+   int maxblock = 0;
+   for (size_t q = 0; q + 1 < plan.h_part.size(); q++) maxblock = std::max(maxblock, plan.h_part[q + 1] - plan.h_part[q]);
+   int ring = 1024;
+   if (maxblock > 0 && maxblock <= 16384)
+      while (ring < maxblock) ring <<= 1; // the whole block in the ring: nothing is overwritten, any reach
+   else
+      while (ring < 4 * (h[0] + 1)) ring <<= 1; // W = ring / 4 must cover the longest reach
+   // one chunk per lane wherever 64 lanes cover the longest row (two chunks per lane and half the rounds measured slower: 0.41 against
+   // 0.29 ms on the 128^3 level 0, 0.80 against 0.58 on level 1 -- the sweep costs instructions, and eight entries per lane issue more
+   // of them per row than two lanes with four each)
+   const int maxc = h[1] > 64 ? 2 : 1;
+   int       lpr  = 1;
+   while (lpr * maxc < h[1]) lpr <<= 1;
+   if (ring > 16384 || lpr > 64)
+   {
+      if (getenv("HDA_VERBOSE"))
+         fprintf(stderr, "[hda] block Gauss-Seidel plan: barrier-free kernel not used (dependency reach %d positions, %d chunks in the longest row)\n", h[0], h[1]);
+      return;
+   }
+   plan.free_ring = ring;
+   plan.free_lpr  = lpr;
+   plan.free_maxc = maxc;
+   if (getenv("HDA_VERBOSE"))
+      fprintf(stderr, "[hda] block Gauss-Seidel plan: barrier-free kernel, dependency reach %d positions, largest block %d rows (ring %d), %d lanes per row, %d chunks per lane\n",
+              h[0], maxblock, ring, lpr, maxc);
+}
+template <int LPR, int MAXC>
+static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
+                             bool zero_in)
+{
+   const int n = A.nrows;
+   constexpr int NT = 512; // (1024 threads leave a lane 128 registers: the four rows in flight spill)
+   static DArray<int> err; // (one flag per process: the kernel raises it instead of spinning forever)
+   if (!err.size()) { err.alloc(1); err.zero(); }
+   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data(),
+                                                          p.s_x0.data());
+   if (getenv("HDA_GS_PROBE"))
+   {
+      DArray<double> sink((size_t)p.nblk * 512);
+      hipEvent_t e0, e1;
+      HDA_HIP(hipEventCreate(&e0));
+      HDA_HIP(hipEventCreate(&e1));
+      for (int rep = 0; rep < 2; rep++)
+      {
+         HDA_HIP(hipEventRecord(e0, STREAM));
+         k_gs_stream_probe<<<p.nblk, 512, 0, STREAM>>>(p.blk_part.data(), p.s_rowptr.data(), (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(),
+                                                       p.s_d.data(), p.s_b.data(), p.s_x0.data(), sink.data());
+         HDA_HIP(hipEventRecord(e1, STREAM));
+         HDA_HIP(hipEventSynchronize(e1));
+         float ms = 0.f;
+         HDA_HIP(hipEventElapsedTime(&ms, e0, e1));
+         if (rep) fprintf(stderr, "[hda] stream probe: n=%d nnz=%d %d blocks: %.3f ms for %.1f MB (%.2f TB/s, %.1f B/clk per CU at 2.4 GHz)\n", n, A.nnz, p.nblk, ms,
+                          (12.0 * 4 * p.s_col.size() / 4 / 1 + 24.0 * n) / 1e6 * 0 + (12.0 * p.s_col.size() + 24.0 * n) / 1e6,
+                          (12.0 * p.s_col.size() + 24.0 * n) / ms / 1e9, (12.0 * p.s_col.size() + 24.0 * n) / (ms * 1e-3) / p.nblk / 2.4e9);
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+   }
+   const size_t lds = sizeof(double) * (size_t)p.free_ring;
+#define HDA_GS_FREE_LAUNCH(BW)                                                                                                               \
+   HDA_HIP(hipFuncSetAttribute((const void *)k_gs_blocks_free<LPR, MAXC, NT, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));  \
+   k_gs_blocks_free<LPR, MAXC, NT, BW><<<p.nblk, NT, lds, STREAM>>>(p.free_ring - 1, p.blk_part.data(), p.s_rowptr.data(),                   \
+                                                                    (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(), p.s_d.data(), \
+                                                                    p.s_b.data(), p.s_x0.data(), p.s_x.data(), err.data())
+   if (forward) { HDA_GS_FREE_LAUNCH(false); }
+   else { HDA_GS_FREE_LAUNCH(true); }
+#undef HDA_GS_FREE_LAUNCH
+   k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
+   static const bool check = getenv("HDA_GS_FREE_CHECK") != nullptr;
+   if (check)
+   {
+      int e = 0;
+      err.download(&e, 1);
+      HDA_REQUIRE(e == 0, "barrier-free Gauss-Seidel sweep: a row waited beyond the spin limit (protocol error)");
+   }
 }
 
 template <int LPR, int NPF>
@@ -1074,9 +1431,43 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
       gs_row_spans(A, plan);
       if (plan.sorted) gs_sorted_copy(A, plan);
       if (plan.ring) gs_ring_copy(A, plan);
+      if (plan.sorted) gs_free_plan(plan, A.nrows);
    }
    const double a = A.avg_row();
    const bool use_sorted = !(getenv("HDA_GS_SORTED") && atoi(getenv("HDA_GS_SORTED")) == 0);
+   // barrier-free kernel or ring kernel: both cost about a microsecond per step (round of 512 / LPR rows, pass of a dependency level);
+   // the one with fewer steps runs -- HDA_GS_FREE=1 / 0 force either
+   bool use_free = plan.free_lpr > 0 && use_sorted;
+   if (use_free && plan.ring && !getenv("HDA_GS_FREE"))
+   {
+      int maxblock = 0;
+      for (size_t q = 0; q + 1 < plan.h_part.size(); q++) maxblock = std::max(maxblock, plan.h_part[q + 1] - plan.h_part[q]);
+      const double rounds = std::ceil((double)maxblock / (512 / plan.free_lpr));
+      const double passes = (double)plan.r_pass[0].size() / 8.0 / std::max(plan.nblk, 1) - 3.0; // (mean over the blocks; three spare records each)
+      use_free            = rounds <= 1.3 * passes; // (measured: 1.06 us per round, 1.42 us per pass on the 128^3 series-B levels)
+   }
+   if (getenv("HDA_GS_FREE")) use_free = use_free && atoi(getenv("HDA_GS_FREE")) != 0;
+   if (use_free)
+   {
+#define HDA_GS_FREE(L)                                                                                      \
+   do                                                                                                       \
+   {                                                                                                        \
+      if (plan.free_maxc == 2) gs_blocks_free_t<L, 2>(A, plan, dinv, b, xin, xout, forward, zero_in);       \
+      else gs_blocks_free_t<L, 1>(A, plan, dinv, b, xin, xout, forward, zero_in);                           \
+   } while (0)
+      switch (plan.free_lpr)
+      {
+         case 1: HDA_GS_FREE(1); break;
+         case 2: HDA_GS_FREE(2); break;
+         case 4: HDA_GS_FREE(4); break;
+         case 8: HDA_GS_FREE(8); break;
+         case 16: HDA_GS_FREE(16); break;
+         case 32: HDA_GS_FREE(32); break;
+         default: HDA_GS_FREE(64); break;
+      }
+#undef HDA_GS_FREE
+      return;
+   }
    if (plan.ring && use_sorted && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0))
    { // (lanes per row and workgroup size were fixed when the pass lists were made)
 #define HDA_GS_RING_NT(L)                                                                                      \
