@@ -117,6 +117,7 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
 void gs_sweep(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, double *x, bool forward);
 // row-block form: xout = sweep(xin); the other blocks' values are read from xin, which the sweep leaves alone (xin != xout).
 // zero_in: the input is the zero vector and is not read (xin may be null or xout)
+void gs_free_check(); // throws if a barrier-free block sweep hit its spin limit since the last call (Krylov solves call it at their end)
 void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, const double *xin, double *xout,
                      bool forward, bool zero_in);
 

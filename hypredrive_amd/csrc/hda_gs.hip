@@ -1358,14 +1358,37 @@ static void gs_free_plan(const GsPlan &plan, int n)
       fprintf(stderr, "[hda] block Gauss-Seidel plan: barrier-free kernel, dependency reach %d positions, largest block %d rows (ring %d), %d lanes per row, %d chunks per lane\n",
               h[0], maxblock, ring, lpr, maxc);
 }
+static int *g_free_err = nullptr;
+static int *gs_free_error_flag()
+{
+   if (!g_free_err)
+   {
+      HDA_HIP(hipMalloc((void **)&g_free_err, sizeof(int)));
+      HDA_HIP(hipMemset(g_free_err, 0, sizeof(int)));
+   }
+   return g_free_err;
+}
+// did a barrier-free sweep run into its spin limit since the last look?  (one 4-byte read-back; the callers are at a host sync anyway)
+void gs_free_check()
+{
+   if (!g_free_err) return;
+   int e = 0;
+   HDA_HIP(hipMemcpyAsync(&e, g_free_err, sizeof(int), hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   if (e)
+   {
+      HDA_HIP(hipMemsetAsync(g_free_err, 0, sizeof(int), STREAM));
+      throw Error("barrier-free Gauss-Seidel sweep: a row waited beyond the spin limit (protocol error " + std::to_string(e) + ")");
+   }
+}
+
 template <int LPR, int MAXC>
 static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
                              bool zero_in)
 {
    const int n = A.nrows;
    constexpr int NT = 512; // (1024 threads leave a lane 128 registers: the four rows in flight spill)
-   static DArray<int> err; // (one flag per process: the kernel raises it instead of spinning forever)
-   if (!err.size()) { err.alloc(1); err.zero(); }
+   int *err = gs_free_error_flag(); // (one flag per process: the kernel raises it instead of spinning forever; read by gs_free_check)
    k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data(),
                                                           p.s_x0.data());
    if (getenv("HDA_GS_PROBE"))
@@ -1395,18 +1418,13 @@ static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv,
    HDA_HIP(hipFuncSetAttribute((const void *)k_gs_blocks_free<LPR, MAXC, NT, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));  \
    k_gs_blocks_free<LPR, MAXC, NT, BW><<<p.nblk, NT, lds, STREAM>>>(p.free_ring - 1, p.blk_part.data(), p.s_rowptr.data(),                   \
                                                                     (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(), p.s_d.data(), \
-                                                                    p.s_b.data(), p.s_x0.data(), p.s_x.data(), err.data())
+                                                                    p.s_b.data(), p.s_x0.data(), p.s_x.data(), err)
    if (forward) { HDA_GS_FREE_LAUNCH(false); }
    else { HDA_GS_FREE_LAUNCH(true); }
 #undef HDA_GS_FREE_LAUNCH
    k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
-   static const bool check = getenv("HDA_GS_FREE_CHECK") != nullptr;
-   if (check)
-   {
-      int e = 0;
-      err.download(&e, 1);
-      HDA_REQUIRE(e == 0, "barrier-free Gauss-Seidel sweep: a row waited beyond the spin limit (protocol error)");
-   }
+   static const bool check = getenv("HDA_GS_FREE_CHECK") != nullptr; // (tests: after every sweep; otherwise at the end of every Krylov solve)
+   if (check) gs_free_check();
 }
 
 template <int LPR, int NPF>

@@ -140,6 +140,7 @@ static KrylovResult pcg_single_reduction(const LinOp &op, const PrecondFn &M, co
       if (i_prod / bi_prod < eps) { res.converged = true; break; }
    }
    ctx.sync();
+   gs_free_check();
    res.iters     = it;
    res.final_rel = std::sqrt(std::fabs(i_prod) / bi_prod);
    return res;
@@ -333,6 +334,7 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
    }
    fs = FirstSweepFusion();
    ctx.sync();
+   gs_free_check();
    for (size_t e = 0; e + 1 < evs.size(); e += 2)
    {
       float ms = 0.f;
@@ -474,6 +476,7 @@ static KrylovResult gmres_core(bool flexible, const LinOp &op, const PrecondFn &
          r_norm = true_norm;
    }
    ctx.sync();
+   gs_free_check();
    res.iters     = iter;
    res.final_rel = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
    return res;
@@ -563,6 +566,7 @@ KrylovResult bicgstab(const LinOp &op, const PrecondFn &M, const KrylovParams &k
       axpy(n, 1.0, r.data(), p.data());
    }
    Context::get().sync();
+   gs_free_check();
    res.iters     = iter;
    res.final_rel = (b_norm > 0.0) ? r_norm / b_norm : r_norm;
    return res;
