@@ -94,6 +94,7 @@ struct GsPlan {
    // by its POSITION in perm, a column outside by ~column -- a level's rows, their entries and (on a grid) their neighbours' values
    // then sit next to each other, where the row-ordered arrays give every row cache lines of its own
    mutable DArray<int>    s_rowptr, s_col;
+   mutable DArray<double> s_aii; // diagonal entries in sweep order (the sweep-order copy keeps them apart from the rows' chunks)
    mutable DArray<double> s_val;
    mutable DArray<double> s_x, s_b, s_d; // the sweep's iterate, right-hand side and divisors in sweep order
    mutable bool           sorted = false;

@@ -122,6 +122,23 @@ __global__ __launch_bounds__(256) void k_gs_inverse(int n, const int *__restrict
    pos_of[i]   = q;
    len4[q]     = (rp[i + 1] - rp[i] + 3) >> 2;
 }
+// the sweep-order copy keeps the diagonal entry apart (s_aii): a 17-entry row of a coarse level is then four chunks, not five, and the
+// barrier-free kernel gives it four lanes instead of eight
+__global__ __launch_bounds__(256) void k_gs_inverse_nodiag(int n, const int *__restrict__ perm, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                           const double *__restrict__ v, int *__restrict__ pos_of, int *__restrict__ len4,
+                                                           double *__restrict__ aii)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q >= n) return;
+   const int i = perm[q];
+   pos_of[i]   = q;
+   int    len = rp[i + 1] - rp[i];
+   double d   = 0.0;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+      if (cj[k] == i) { d = v[k]; len--; break; } // (the first diagonal entry; a second one stays an ordinary entry)
+   aii[q]  = d;
+   len4[q] = (len + 3) >> 2;
+}
 __global__ __launch_bounds__(256) void k_gs_sorted_fill(int n, int nb, const int *__restrict__ part, const int *__restrict__ perm,
                                                         const int *__restrict__ pos_of, const int *__restrict__ rp, const int *__restrict__ cj,
                                                         const double *__restrict__ v, const int *__restrict__ srp4, int *__restrict__ scj,
@@ -134,11 +151,14 @@ __global__ __launch_bounds__(256) void k_gs_sorted_fill(int n, int nb, const int
    gs_block_of(part, nb, i, n, lo, hi);
    int d = 4 * srp4[q];
    const int e = 4 * srp4[q + 1];
-   for (int k = rp[i]; k < rp[i + 1]; k++, d++)
-   { // same entry order as the row
+   bool skipped = false;
+   for (int k = rp[i]; k < rp[i + 1]; k++)
+   { // same entry order as the row, without its (first) diagonal entry: that one is in s_aii
       const int c = cj[k];
-      scj[d]      = (c >= lo && c < hi) ? pos_of[c] : ~pos_of[c]; // (another block's column: its position in the sweep-START copy)
-      sv[d]       = v[k];
+      if (c == i && !skipped) { skipped = true; continue; }
+      scj[d] = (c >= lo && c < hi) ? pos_of[c] : ~pos_of[c]; // (another block's column: its position in the sweep-START copy)
+      sv[d]  = v[k];
+      d++;
    }
    for (; d < e; d++) { scj[d] = q; sv[d] = 0.0; } // padding: 0 * (the row's own value)
 }
@@ -146,7 +166,9 @@ static void gs_sorted_copy(const DCsr &A, const GsPlan &plan)
 {
    const int n = A.nrows;
    DArray<int> pos_of((size_t)n), len4((size_t)n + 1);
-   k_gs_inverse<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), pos_of.data(), len4.data());
+   if (plan.s_aii.size() != (size_t)n) plan.s_aii.alloc((size_t)n);
+   k_gs_inverse_nodiag<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), A.col.data(), A.val.data(), pos_of.data(), len4.data(),
+                                                           plan.s_aii.data());
    plan.s_rowptr.alloc((size_t)n + 1);
    exclusive_scan(n, len4.data(), plan.s_rowptr.data(), nullptr);
    int chunks = 0;
@@ -725,7 +747,8 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_sorted(int backward, int zero_
                                                            const int *__restrict__ blk_lvl, const int *__restrict__ srp4,
                                                            const int4 *__restrict__ scj4, const double2 *__restrict__ sv2,
                                                            const double *__restrict__ sd, const double *__restrict__ sb,
-                                                           const double *__restrict__ sx0, double *sx, unsigned long long *diag)
+                                                           const double *__restrict__ saii, const double *__restrict__ sx0, double *sx,
+                                                           unsigned long long *diag)
 {
    extern __shared__ int slp[]; // level offsets of this block (nl + 1 of them)
    unsigned long long tG = 0, tF = 0, tB = 0, tN = 0, t0 = 0, t1 = 0, tU = 0, tI = 0, tE = 0; // diag: shader-clock sums per phase, passes
@@ -745,7 +768,7 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_sorted(int backward, int zero_
       return it;
    };
    struct RowA { int pos, c0, c1; bool has; };
-   struct RowB { int pos, c0, c1; bool has, mine; int4 c; double2 a01, a23; double d, rhs; };
+   struct RowB { int pos, c0, c1; bool has, mine; int4 c; double2 a01, a23; double d, rhs, aii; };
    auto stage_a = [&](const It &it) {
       RowA r;
       const int L = level(it), pos = slp[L] + it.p * RP + q;
@@ -766,6 +789,7 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_sorted(int backward, int zero_
       r.a23 = sv2[2 * cc + 1];
       r.d   = sd[ra.pos];
       r.rhs = sb[ra.pos];
+      r.aii = saii[ra.pos];
       return r;
    };
    // value of column c: inside the block sx[position], outside it the other blocks' value at the sweep's start, sx0[~c] (zeros from a
@@ -799,7 +823,11 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_sorted(int backward, int zero_
          }
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-      if (lane == 0 && cur.has) sx[cur.pos] += cur.d * (cur.rhs - sum);
+      if (lane == 0 && cur.has)
+      { // (the diagonal entry is kept apart: s_aii)
+         const double xo = sx[cur.pos];
+         sx[cur.pos]     = xo + cur.d * (cur.rhs - (sum + cur.aii * xo));
+      }
       if (diag)
       {
          t1 = __builtin_amdgcn_s_memtime();
@@ -1057,7 +1085,7 @@ static void gs_blocks_sorted_t(const DCsr &A, const GsPlan &p, const double *din
                                                           p.s_x0.data());
    k_gs_blocks_sorted<LPR, NT><<<p.nblk, NT, lds, STREAM>>>(forward ? 0 : 1, zero_in ? 1 : 0, p.blk_lvl_ptr.data(), p.blk_lvl.data(),
                                                          p.s_rowptr.data(), (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(),
-                                                         p.s_d.data(), p.s_b.data(), p.s_x0.data(), p.s_x.data(), gs_diag_buffer());
+                                                         p.s_d.data(), p.s_b.data(), p.s_aii.data(), p.s_x0.data(), p.s_x.data(), gs_diag_buffer());
    gs_diag_report(LPR, n);
    k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
 }
@@ -1111,7 +1139,7 @@ template <int LPR, int MAXC, int NT, bool BACKWARD>
 __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int *__restrict__ part, const int *__restrict__ srp4,
                                                        const int4 *__restrict__ scj4, const double2 *__restrict__ sv2,
                                                        const double *__restrict__ sd, const double *__restrict__ sb,
-                                                       const double *__restrict__ sx0, double *sx, int *err)
+                                                       const double *__restrict__ saii, const double *__restrict__ sx0, double *sx, int *err)
 {
    constexpr int G = NT / LPR, NW = NT / 64, GPW = 64 / LPR, NE = 4 * MAXC; // groups, wavefronts, groups per wavefront, entries per lane
    extern __shared__ long long free_ring[];   // ring_mask + 1 values (the bits of a double each)
@@ -1143,8 +1171,8 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
    // (Deeper pipelines -- leads of 5 / 3 / 1 and 6 / 4 / 2 rounds -- measured the same: a round costs the instructions its eight
    //  wavefronts issue, two to a SIMD, not a memory latency.)
    struct RowA { int t, p, c0, c1; bool has; };
-   struct RowB { int t, p; bool has, mine[MAXC]; int4 c[MAXC]; double2 a01[MAXC], a23[MAXC]; double d, rhs, own; };
-   struct RowX { int t, p; bool has, mine[MAXC]; double a[NE], v[NE], d, rhs, own; int dep[NE]; };
+   struct RowB { int t, p; bool has, mine[MAXC]; int4 c[MAXC]; double2 a01[MAXC], a23[MAXC]; double d, rhs, own, aii; };
+   struct RowX { int t, p; bool has, mine[MAXC]; double a[NE], v[NE], d, rhs, own, aii; int dep[NE]; };
    auto stage_a = [&](int r) {
       RowA ra;
       ra.t   = r * G + g;
@@ -1171,11 +1199,12 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
       rb.d   = sd[ra.p];
       rb.rhs = sb[ra.p];
       rb.own = sx0[ra.p];
+      rb.aii = saii[ra.p];
       return rb;
    };
    auto stage_x = [&](const RowB &rb) {
       RowX rx;
-      rx.t = rb.t; rx.p = rb.p; rx.has = rb.has; rx.d = rb.d; rx.rhs = rb.rhs; rx.own = rb.own;
+      rx.t = rb.t; rx.p = rb.p; rx.has = rb.has; rx.d = rb.d; rx.rhs = rb.rhs; rx.own = rb.own; rx.aii = rb.aii;
 #pragma unroll
       for (int m = 0; m < MAXC; m++)
       {
@@ -1239,7 +1268,7 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
             sum += rx.mine[m] ? sm : 0.0;
          }
          sum = group_sum<LPR>(sum);
-         xn  = rx.own + rx.d * (rx.rhs - sum);
+         xn  = rx.own + rx.d * (rx.rhs - (sum + rx.aii * rx.own)); // (the diagonal entry is kept apart: s_aii)
          if (lane == 0 && rx.has)
          {
             RING_ST(rx.t & ring_mask, xn);
@@ -1418,7 +1447,7 @@ static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv,
    HDA_HIP(hipFuncSetAttribute((const void *)k_gs_blocks_free<LPR, MAXC, NT, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));  \
    k_gs_blocks_free<LPR, MAXC, NT, BW><<<p.nblk, NT, lds, STREAM>>>(p.free_ring - 1, p.blk_part.data(), p.s_rowptr.data(),                   \
                                                                     (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(), p.s_d.data(), \
-                                                                    p.s_b.data(), p.s_x0.data(), p.s_x.data(), err)
+                                                                    p.s_b.data(), p.s_aii.data(), p.s_x0.data(), p.s_x.data(), err)
    if (forward) { HDA_GS_FREE_LAUNCH(false); }
    else { HDA_GS_FREE_LAUNCH(true); }
 #undef HDA_GS_FREE_LAUNCH
