@@ -88,6 +88,25 @@ def test_block_hybrid_gauss_seidel_matches_oracle(orc, hd, monkeypatch, rtype, k
         assert rel(Ah.relax_blocks(b, x0, part, rtype, w, sweeps=2), xo) < 1e-12
 
 
+@pytest.mark.parametrize("kind", ["one", "even4", "ragged"])
+def test_block_gauss_seidel_on_long_rows(orc, hd, monkeypatch, kind):
+    """Rows of several hundred entries: the barrier-free kernel gives a row 64 lanes and, beyond 256 entries, two chunks per lane;
+    rows longer still leave it to the ring / sorted kernels.  Forward, backward and symmetric sweeps against the oracle."""
+    monkeypatch.setenv("HDA_GS_SORTED_MIN", "0")
+    monkeypatch.setenv("HDA_GS_FREE_CHECK", "1")
+    for n, dens in ((500, 0.35), (640, 0.6), (900, 0.75)):
+        M = mmatrix(n, dens, 40 + n)
+        assert np.diff(M.indptr).max() > 4 * 40
+        Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+        part = parts_for(n, kind, 3)
+        rng = np.random.default_rng(n)
+        b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+        l1 = orc.l1_norms_blocks(Ao, 4, part)
+        for rtype in (13, 14, 8):
+            xo = orc.relax_blocks(Ao, l1, rtype, 1.0, b, x0, part)
+            assert rel(Ah.relax_blocks(b, x0, part, rtype, 1.0), xo) < 1e-12, (n, rtype)
+
+
 def test_one_block_is_the_sequential_sweep(orc, hd):
     M = mmatrix(800, 0.01, 21)
     Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
