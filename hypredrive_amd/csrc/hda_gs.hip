@@ -1368,10 +1368,14 @@ static void gs_free_plan(const GsPlan &plan, int n)
       while (ring < maxblock) ring <<= 1; // the whole block in the ring: nothing is overwritten, any reach
    else
       while (ring < 4 * (h[0] + 1)) ring <<= 1; // W = ring / 4 must cover the longest reach
-   // one chunk per lane wherever 64 lanes cover the longest row (two chunks per lane and half the rounds measured slower: 0.41 against
-   // 0.29 ms on the 128^3 level 0, 0.80 against 0.58 on level 1 -- the sweep costs instructions, and eight entries per lane issue more
-   // of them per row than two lanes with four each)
-   const int maxc = h[1] > 64 ? 2 : 1;
+   // one chunk per lane for short rows (two chunks per lane and half the rounds measured slower there: 0.41 against 0.29 ms on the
+   // 128^3 level 0, 0.80 against 0.58 on level 1 -- the sweep costs instructions, and eight entries per lane issue more of them per row
+   // than two lanes with four each); two where a row would otherwise take 32 or 64 lanes and the blocks are long enough for the halved
+   // number of rounds to count (128^3 level 2, rows of up to 69 entries, 7 000 rows per block: 0.47 -> 0.41 ms; level 3, 730 rows per
+   // block: 0.079 -> 0.083, left at one)
+   // (HDA_GS_FREE_MAXC2_FROM=<chunks>: the shortest "longest row" that gets two chunks per lane -- experiments)
+   static const int maxc2_from = getenv("HDA_GS_FREE_MAXC2_FROM") ? atoi(getenv("HDA_GS_FREE_MAXC2_FROM")) : 17;
+   const int maxc = (h[1] > 64 || (h[1] >= maxc2_from && maxblock >= 2048)) ? 2 : 1;
    int       lpr  = 1;
    while (lpr * maxc < h[1]) lpr <<= 1;
    if (ring > 16384 || lpr > 64)
