@@ -2358,7 +2358,7 @@ __global__ __launch_bounds__(256) void k_bandwidth(int n, const int *__restrict_
 }
 int amg_auto_blocks(const DCsr &A)
 {
-   static const long long min_rows  = getenv("HDA_BLOCKS_MIN_ROWS") ? atoll(getenv("HDA_BLOCKS_MIN_ROWS")) : 500000;
+   static const long long min_rows  = getenv("HDA_BLOCKS_MIN_ROWS") ? atoll(getenv("HDA_BLOCKS_MIN_ROWS")) : 100000;
    static const long long min_block = getenv("HDA_BLOCK_ROWS") ? atoll(getenv("HDA_BLOCK_ROWS")) : 32768;
    const int n = A.nrows;
    if (n <= min_rows) return 1;
