@@ -1095,13 +1095,17 @@ static void gs_blocks_sorted_t(const DCsr &A, const GsPlan &p, const double *din
 // rows of a block are dealt round-robin, in sweep order, to the G = NT / LPR lane groups of the block's workgroup; a group finishes
 // sweep index t (row of position lo + t, or hi - 1 - t backwards), leaves the new value in an LDS ring (slot t mod RING) and then
 // publishes t in done[group] (LDS; the two writes of one lane stay in order), and a row whose column is an EARLIER sweep index t' polls
-// done[t' mod G] >= t' before it takes the value from the ring.  Columns later in the sweep (and the row's own) come from the
-// sweep-start copy, other blocks' columns from the input vector: neither depends on the sweep, both are requested before the wait.
-// What bounds a level is then two LDS round trips and the arithmetic.  A group may run at most RING - W - G sweep indices ahead of the
-// slowest wavefront (wdone[]), so that a ring slot is never overwritten while a row W = RING / 4 indices back may still read it; the
-// plan guarantees that no dependency reaches further back than W (else this kernel is not used).  Rows take one 4-entry chunk per lane:
-// LPR >= chunks of the longest row.  Progress: the smallest unfinished sweep index never waits for the guard and all its dependencies
-// are smaller, so some row can always finish; a spin limit turns a protocol error into an error flag instead of a hang.
+// done[t' mod G] >= t' before it takes the value from the ring.  Columns later in the sweep, the row's own value and other blocks'
+// columns all come from the sweep-start copy (s_x0): none depends on the sweep, all are requested a round before the wait.
+// What a round costs turned out to be the instructions the workgroup's eight wavefronts issue for it (two wavefronts to a SIMD; about
+// 1.06 us), not the LDS round trips, the memory latency or the bandwidth: profiles/r04_gs_blocks.md.  A group may run at most
+// RING - W - G sweep indices ahead of the slowest wavefront (wdone[]), so that a ring slot is never overwritten while a row W = RING / 4
+// indices back may still read it; the plan guarantees that no dependency reaches further back than W, or gives every row of the block a
+// slot of its own (blocks of up to 16 384 rows: no guard at all), else this kernel is not used.  A lane takes MAXC 4-entry chunks of its
+// row (one; two for rows that would otherwise need 32 or 64 lanes): LPR x MAXC >= chunks of the longest row, the diagonal entry is kept
+// apart (s_aii).  Progress: the smallest unfinished sweep index never waits for the guard and all its dependencies are smaller, so some
+// row can always finish; a spin limit turns a protocol error into an error flag (gs_free_check) instead of a hang.
+
 // sum / conjunction over the LPR lanes of a row with every lane receiving the result: data-parallel-primitive moves inside a row of
 // sixteen lanes (quad permutes, half-row and row mirrors: no LDS traffic, unlike ds_bpermute), shuffles beyond.  The pairing differs from
 // the xor butterfly only in which lane adds which partner: a + b and b + a, the same bits.
