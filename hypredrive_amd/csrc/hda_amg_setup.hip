@@ -312,15 +312,17 @@ __global__ __launch_bounds__(64) void k_rs_first_pass(int nblk, const int *__res
                                                       const int *__restrict__ cj, const int *__restrict__ tp, const int *__restrict__ tj,
                                                       int *head_all, int *tail_all, int *prev, int *next, int *key, int *meas, int *cf)
 {
-   if (threadIdx.x != 0) return;
    const int q = blockIdx.x;
    if (q >= nblk) return;
    const int lo = part[q], hi = part[q + 1], nbk = 2 * (hi - lo) + 2;
    int      *head = head_all + 2 * (size_t)lo + 2 * (size_t)q, *tail = tail_all + 2 * (size_t)lo + 2 * (size_t)q;
    RsBuckets B{head, tail, prev, next, key, 0};
    auto      in = [&](int j) { return j >= lo && j < hi; };
-   for (int t = 0; t < nbk; t++) head[t] = tail[t] = -1;
-   for (int i = lo; i < hi; i++)
+   // the initial state has no order in it: all 64 lanes write it (a tenth of the pass when one lane did), then lane 0 goes on alone.
+   // (Reading the rows the main loop walks 64 entries at a time and handing them over by readlane was tried and measured the same:
+   //  what the loop costs is the chain of dependent list operations, not the row reads.)
+   for (int t = threadIdx.x; t < nbk; t += 64) head[t] = tail[t] = -1;
+   for (int i = lo + threadIdx.x; i < hi; i += 64)
    {
       int nt = 0;
       for (int k = tp[i]; k < tp[i + 1]; k++) nt += in(tj[k]);
@@ -330,6 +332,9 @@ __global__ __launch_bounds__(64) void k_rs_first_pass(int nblk, const int *__res
       cf[i]   = (rp[i + 1] == rp[i]) ? -3 : 0; // no strong dependence at all: special F, never interpolated
       if (cf[i] == -3) meas[i] = 0;
    }
+   __threadfence_block();
+   __syncthreads();
+   if (threadIdx.x != 0) return;
    // ascending-index insertion; measure-0 points become F and the points they depend on gain
    // weight (re-listed at the tail when already listed)
    for (int j = lo; j < hi; j++)
