@@ -1090,6 +1090,12 @@ extern "C" int hda_memory_stats(double *in_use, double *peak)
 }
 
 extern "C" double hda_memory_cached(void) { return (double)pool_bytes_cached(); }
+extern "C" int    hda_memory_trim(void)
+{
+   HDA_TRY
+   pool_trim();
+   HDA_CATCH
+}
 
 extern "C" int hda_comm_selftest(void)
 {

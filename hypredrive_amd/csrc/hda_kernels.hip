@@ -115,12 +115,29 @@ std::unordered_map<void *, Pool *> &block_owner()
    static std::unordered_map<void *, Pool *> m;
    return m;
 }
+std::vector<Pool *> &all_pools() // the process's pool and every thread rank's (under g_pool_mutex)
+{
+   static std::vector<Pool *> v;
+   return v;
+}
 struct Pool {
    std::multimap<size_t, Cached>      free_;  // size -> block
    std::unordered_map<void *, size_t> size_;  // every block we own
    size_t                             in_use = 0, cached = 0, peak = 0;
    uint64_t                           clock = 0;
+   Pool() { all_pools().push_back(this); } // (made by current_pool() only, whose callers hold g_pool_mutex)
    ~Pool();
+   void drop_cached() // caller holds g_pool_mutex; hipFree waits for the device, so a block a queued kernel still reads is safe to return
+   {
+      for (auto &kv : free_)
+      {
+         size_.erase(kv.second.p);
+         block_owner().erase(kv.second.p);
+         (void)hipFree(kv.second.p);
+      }
+      free_.clear();
+      cached = 0;
+   }
 };
 Pool &process_pool()
 {
@@ -146,12 +163,9 @@ Pool &current_pool()
 Pool::~Pool()
 { // a thread rank leaves: cached blocks go back to the driver, blocks still in use move to the process's pool
    std::lock_guard<std::mutex> lk(g_pool_mutex);
-   for (auto &kv : free_)
-   {
-      size_.erase(kv.second.p);
-      block_owner().erase(kv.second.p);
-      (void)hipFree(kv.second.p);
-   }
+   drop_cached();
+   auto &all = all_pools();
+   all.erase(std::remove(all.begin(), all.end(), this), all.end());
    Pool &g = process_pool();
    if (&g == this) return;
    for (auto &kv : size_)
@@ -214,6 +228,12 @@ void *pool_alloc(size_t bytes)
       lk.unlock();
       pool_trim(); // give cached blocks back and retry once
       lk.lock();
+      e = hipMalloc(&p, want);
+   }
+   if (e != hipSuccess)
+   { // thread ranks share the device: what is short may sit in the caches of the other ranks' pools (each keeps up to twice its peak)
+      (void)hipGetLastError();
+      for (Pool *q : all_pools()) q->drop_cached();
       e = hipMalloc(&p, want);
    }
    if (e != hipSuccess)
@@ -302,14 +322,7 @@ void pool_trim()
 {
    (void)hipStreamSynchronize(Context::get().stream);
    std::lock_guard<std::mutex> lk(g_pool_mutex);
-   for (auto &kv : g_pool.free_)
-   {
-      g_pool.size_.erase(kv.second.p);
-      block_owner().erase(kv.second.p);
-      (void)hipFree(kv.second.p);
-   }
-   g_pool.free_.clear();
-   g_pool.cached = 0;
+   g_pool.drop_cached();
 }
 size_t pool_bytes_in_use() { std::lock_guard<std::mutex> lk(g_pool_mutex); return g_pool.in_use; }
 size_t pool_bytes_peak() { std::lock_guard<std::mutex> lk(g_pool_mutex); return g_pool.peak; }

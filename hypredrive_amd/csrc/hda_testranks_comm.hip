@@ -20,7 +20,7 @@ namespace hda {
 // meet at a generation barrier; sums run in rank order on every rank (deterministic, identical everywhere).
 namespace {
 struct ThreadWorld {
-   explicit ThreadWorld(int n) : size(n), ptr((size_t)n, nullptr), cnt((size_t)n, nullptr) {}
+   explicit ThreadWorld(int n) : size(n), ptr((size_t)n, nullptr), cnt((size_t)n, nullptr), kind((size_t)n, 0), len((size_t)n, 0) {}
    virtual ~ThreadWorld() = default;
    int                       size;
    std::mutex                mu;
@@ -30,6 +30,17 @@ struct ThreadWorld {
    bool                      failed  = false; // a rank died: release everybody instead of deadlocking the process
    std::vector<const void *> ptr;
    std::vector<const long *> cnt;
+   std::vector<int>          kind; // which collective a rank has entered (checked by all after the first barrier of a call:
+   std::vector<long>         len;  //  ranks that disagree would read each other's stale pointers) and its operand's length
+   // called between the two barriers of a collective, before anybody dereferences a peer's pointers
+   void same_call(int rank, int k, long n, const char *what) const
+   {
+      for (int p = 0; p < size; p++)
+         if (kind[(size_t)p] != k || (n >= 0 && len[(size_t)p] != n))
+            throw Error(std::string("thread ranks: ranks are in different collectives: rank ") + std::to_string(rank) + " in " + what + "(" +
+                        std::to_string(n) + "), rank " + std::to_string(p) + " in kind " + std::to_string(kind[(size_t)p]) + "(" +
+                        std::to_string(len[(size_t)p]) + ")");
+   }
    void barrier()
    {
       std::unique_lock<std::mutex> lk(mu);
@@ -95,8 +106,11 @@ class ThreadComm : public Comm {
    void allreduce_host(long long *v, int n, int op) override
    {
       std::vector<long long> t((size_t)std::max(n, 1));
-      w_->ptr[(size_t)rank] = v;
+      w_->ptr[(size_t)rank]  = v;
+      w_->kind[(size_t)rank] = 2;
+      w_->len[(size_t)rank]  = n;
       w_->barrier();
+      w_->same_call(rank, 2, n, "allreduce_host");
       for (int i = 0; i < n; i++)
       {
          long long a = ((const long long *)w_->ptr[0])[i];
@@ -112,16 +126,21 @@ class ThreadComm : public Comm {
    }
    void alltoallv_host(const void *send, const long *sb, void *recv, const long *rb) override
    {
-      w_->ptr[(size_t)rank] = send;
-      w_->cnt[(size_t)rank] = sb;
+      w_->ptr[(size_t)rank]  = send;
+      w_->cnt[(size_t)rank]  = sb;
+      w_->kind[(size_t)rank] = 3;
       w_->barrier();
+      w_->same_call(rank, 3, -1, "alltoallv_host");
       long ro = 0;
       for (int p = 0; p < size; p++)
       {
          const long *psb = w_->cnt[(size_t)p];
          long        so  = 0;
          for (int q = 0; q < rank; q++) so += psb[q];
-         const long nb = std::min(psb[rank], rb[p]);
+         const long nb = psb[rank];
+         if (nb != rb[p])
+            throw Error("thread ranks: alltoallv_host: rank " + std::to_string(p) + " sends " + std::to_string(nb) + " bytes to rank " +
+                        std::to_string(rank) + ", which expects " + std::to_string(rb[p]));
          if (nb) memcpy((char *)recv + ro, (const char *)w_->ptr[(size_t)p] + so, (size_t)nb);
          ro += rb[p];
       }
@@ -133,8 +152,11 @@ class ThreadComm : public Comm {
    void reduce(double *v, int n, int)
    {
       std::vector<double> t((size_t)std::max(n, 1));
-      w_->ptr[(size_t)rank] = v;
+      w_->ptr[(size_t)rank]  = v;
+      w_->kind[(size_t)rank] = 1;
+      w_->len[(size_t)rank]  = n;
       w_->barrier();
+      w_->same_call(rank, 1, n, "allreduce_sum_dev");
       for (int i = 0; i < n; i++)
       {
          double a = ((const double *)w_->ptr[0])[i];
@@ -219,9 +241,11 @@ class DeviceThreadComm : public ThreadComm {
       for (int p = 0; p < size; p++) stats.exchange_doubles += sc[p];
       d_->xsend[(size_t)rank] = send;
       d_->xcnt[(size_t)rank]  = sc;
+      d_->kind[(size_t)rank]  = 4;
       jitter(st, rank, calls_);
       HDA_HIP(hipEventRecord(d_->ev_ready[(size_t)rank], st)); // my send buffer is packed once `st` gets here
       d_->barrier();
+      d_->same_call(rank, 4, -1, "exchange_dev");
       size_t ro = 0;
       for (int p = 0; p < size; p++)
       {
@@ -252,7 +276,10 @@ class DeviceThreadComm : public ThreadComm {
       jitter(st, rank, calls_);
       HDA_HIP(hipEventRecord(d_->ar_ready[(size_t)rank], st));
       d_->arptr[(size_t)rank] = stage_.data();
+      d_->kind[(size_t)rank]  = 5;
+      d_->len[(size_t)rank]   = n;
       d_->barrier();
+      d_->same_call(rank, 5, n, "allreduce_sum_dev");
       PtrTable t;
       for (int p = 0; p < size; p++)
       {

@@ -279,6 +279,10 @@ int hda_memory_stats(double *in_use, double *peak);
 /* bytes of released device blocks the calling thread's allocator keeps for reuse: never more than twice the thread's peak in use
  * (or HDA_POOL_CACHE_MIN_GB, default 4, if that is larger); older blocks go back to the driver first */
 double hda_memory_cached(void);
+/* gives the calling thread's cached blocks back to the driver (after the library stream has drained): for a host application that
+ * shares the device with other processes and is about to sit idle.  The allocator does this by itself when an allocation fails --
+ * its own cache first, then the caches of the process's other rank threads -- but it cannot reach another PROCESS's cache. */
+int hda_memory_trim(void);
 /* Matrices are int32-indexed (hypre's HYPRE_Int in its default build, HYPRE_config.h).  Every setup
  * stage that sizes an operator (interpolation, sparse products, routed row blocks) checks the 64-bit
  * sum of its row lengths first and returns HDA_ERR with a message instead of wrapping around.  This

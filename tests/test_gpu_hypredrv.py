@@ -523,15 +523,20 @@ def test_asynchronous_transport_results_do_not_depend_on_timing(tmp_path, extra)
     assert r0["final_rel"] == r1["final_rel"]
 
 
-def test_config3_full_size_512_cubed_on_eight_thread_ranks(hd, tmp_path):
-    """BASELINE config 3 AS NAMED -- the 3-D 7-pt Laplacian 512^3 (134 217 728 rows), fp64, AMG-PCG, row-partitioned 2x2x2 over eight
+@pytest.mark.parametrize("transport", ["host", "device"])
+def test_config3_full_size_512_cubed_on_eight_thread_ranks(hd, tmp_path, transport):
+    """(transport "device": the enqueue-only, event-ordered thread transport that behaves like RCCL towards the library, so the products
+    overlap their halo exchanges exactly as they will between GPUs -- at the full size of the configuration.)
+    BASELINE config 3 AS NAMED -- the 3-D 7-pt Laplacian 512^3 (134 217 728 rows), fp64, AMG-PCG, row-partitioned 2x2x2 over eight
     ranks, a 256^3 block each (`-n 512 512 512 -P 2 2 2`, reference examples/src/C_laplacian/laplacian.c:561-582) -- on ONE MI355X:
     the eight ranks are threads of one process (hda_thread_ranks.hip) and their messages are host-staged, so this says nothing about
     speed; it says that the partitioned setup, the halo plans with face / edge / corner neighbours on every level and the solve are
     right at the full size: converged, the same iteration count on every rank and within 1 of ONE rank solving the same 512^3
     system on the same GPU (16), the same solution norms.  (What stays unmeasured is RCCL between eight GPUs.)"""
     n = 512
-    res, _, err = _thread_ranks(tmp_path, "cfg3", n, (2, 2, 2), want_x="0")
+    from hypredrive_amd import _lib
+    _lib.memory_trim()  # the eight ranks need most of the 288 GB: nothing of this process's earlier tests may sit cached on the device
+    res, _, err = _thread_ranks(tmp_path, "cfg3" + transport, n, (2, 2, 2), want_x="0", **({"HDA_THREAD_TRANSPORT": "device"} if transport == "device" else {}))
     h = hd.Hypredrv("solver: pcg\npreconditioner:\n  preset: poisson\n")
     h.set_laplacian7((n, n, n))
     ref = h.solve()
