@@ -405,6 +405,146 @@ __global__ __launch_bounds__(64) void k_rs_first_pass(int nblk, const int *__res
       }
    }
 }
+// The same pass with the state of a row in ONE 16-byte record {prev, next, measure, cf} (one load where the version above makes
+// four dependent ones; a listed point's bucket key IS its measure) and the bucket heads / tails in LDS when twice the largest
+// in-degree fits (they are the hottest words of the pass).  What the pass costs is the chain of dependent memory round trips of its
+// one working lane, so it is those that are cut: per list operation one record load (stores are not waited for), against the
+// record's three or four loads plus the bucket's before.  Same order of operations, same result bit for bit.
+__device__ __forceinline__ int4 rs_load(const int4 *rec, int p) { return rec[p]; }
+#define RS_F(p, f) (((int *)(rec + (p)))[f]) // field f of row p's record: 0 prev, 1 next, 2 measure, 3 cf
+template <bool LDSHT>
+__global__ __launch_bounds__(64) void k_rs_first_pass_rec(int nblk, const int *__restrict__ part, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                          const int *__restrict__ tp, const int *__restrict__ tj, int *head_all, int *tail_all,
+                                                          int4 *rec, int *__restrict__ cf, int kcap)
+{
+   extern __shared__ int s_ht[]; // LDSHT: heads [0, kcap), tails [kcap, 2 kcap)
+   const int q = blockIdx.x;
+   if (q >= nblk) return;
+   const int lo = part[q], hi = part[q + 1];
+   int      *head, *tail;
+   int       nbk;
+   if constexpr (LDSHT)
+   {
+      head = s_ht;
+      tail = s_ht + kcap;
+      nbk  = kcap;
+   }
+   else
+   {
+      head = head_all + 2 * (size_t)lo + 2 * (size_t)q;
+      tail = tail_all + 2 * (size_t)lo + 2 * (size_t)q;
+      nbk  = 2 * (hi - lo) + 2;
+   }
+   auto in = [&](int j) { return j >= lo && j < hi; };
+   for (int t = threadIdx.x; t < nbk; t += 64) head[t] = tail[t] = -1;
+   for (int i = lo + threadIdx.x; i < hi; i += 64)
+   {
+      int nt = 0;
+      for (int k = tp[i]; k < tp[i + 1]; k++) nt += in(tj[k]);
+      const bool special = (rp[i + 1] == rp[i]); // no strong dependence at all: special F, never interpolated
+      rec[i] = make_int4(-1, -1, special ? 0 : nt, special ? -3 : 0);
+      cf[i]  = special ? -3 : 0;
+   }
+   __threadfence_block();
+   __syncthreads();
+   if (threadIdx.x != 0) return;
+   int  maxkey = 0;
+   auto unlink = [&](const int4 &R) { // R: the record of a listed point (key = its measure)
+      if (R.x >= 0) RS_F(R.x, 1) = R.y;
+      else head[R.z] = R.y;
+      if (R.y >= 0) RS_F(R.y, 0) = R.x;
+      else tail[R.z] = R.x;
+   };
+   auto enter = [&](int p, int key) { // at the tail of bucket `key`; the point is undecided
+      const int t = tail[key];
+      rec[p]      = make_int4(t, -1, key, 0);
+      if (t >= 0) RS_F(t, 1) = p;
+      else head[key] = p;
+      tail[key] = p;
+      if (key > maxkey) maxkey = key;
+   };
+   auto bump = [&](int m) { // an undecided listed point gains one: to the tail of the next bucket
+      const int4 R = rs_load(rec, m);
+      if (R.w != 0) return;
+      unlink(R);
+      enter(m, R.z + 1);
+   };
+   // ascending-index insertion; measure-0 points become F and the points they depend on gain weight (re-listed at the tail when
+   // already listed)
+   for (int j = lo; j < hi; j++)
+   {
+      const int4 Rj = rs_load(rec, j);
+      if (Rj.w == -3) continue;
+      if (Rj.z > 0) { enter(j, Rj.z); continue; }
+      RS_F(j, 3) = -1;
+      cf[j]      = -1;
+      for (int k = rp[j]; k < rp[j + 1]; k++)
+      {
+         const int m = cj[k];
+         if (!in(m)) continue;
+         const int4 R = rs_load(rec, m);
+         if (R.w != 0) continue; // special, or decided (a decided point's measure is never read again)
+         if (m < j)
+         {
+            if (R.z > 0) unlink(R);
+            enter(m, R.z + 1);
+         }
+         else RS_F(m, 2) = R.z + 1; // not listed yet
+      }
+   }
+   for (;;)
+   {
+      while (maxkey > 0 && head[maxkey] < 0) maxkey--;
+      if (maxkey <= 0) break;
+      const int  i  = head[maxkey];
+      const int4 Ri = rs_load(rec, i);
+      unlink(Ri);
+      rec[i] = make_int4(-1, -1, 0, 1);
+      cf[i]  = 1;
+      for (int k = tp[i]; k < tp[i + 1]; k++)
+      { // everything that strongly depends on i becomes F
+         const int j = tj[k];
+         if (!in(j)) continue;
+         const int4 Rj = rs_load(rec, j);
+         if (Rj.w != 0) continue;
+         unlink(Rj);
+         rec[j] = make_int4(-1, -1, Rj.z, -1);
+         cf[j]  = -1;
+         for (int kk = rp[j]; kk < rp[j + 1]; kk++)
+         {
+            const int m = cj[kk];
+            if (in(m)) bump(m);
+         }
+      }
+      for (int k = rp[i]; k < rp[i + 1]; k++)
+      { // points i depends on lose one potential dependant
+         const int j = cj[k];
+         if (!in(j)) continue;
+         const int4 Rj = rs_load(rec, j);
+         if (Rj.w != 0) continue;
+         unlink(Rj);
+         if (Rj.z - 1 > 0) enter(j, Rj.z - 1);
+         else
+         {
+            rec[j] = make_int4(-1, -1, 0, -1);
+            cf[j]  = -1;
+            for (int kk = rp[j]; kk < rp[j + 1]; kk++)
+            {
+               const int m = cj[kk];
+               if (in(m)) bump(m);
+            }
+         }
+      }
+   }
+}
+#undef RS_F
+__global__ __launch_bounds__(256) void k_max_row_len(int n, const int *__restrict__ rp, int *mx)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   int       m = (i < n) ? rp[i + 1] - rp[i] : 0;
+   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+   if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(mx, m);
+}
 // after the first pass: only the C points of interior rows (no strong connection leaving the block) stay decided
 __global__ __launch_bounds__(256) void k_hmis_keep(int n, int nblk, const int *__restrict__ part, const int *__restrict__ rp,
                                                    const int *__restrict__ cj, const unsigned char *__restrict__ sm, int *__restrict__ cf)
@@ -479,11 +619,35 @@ static void hmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
    transpose(S, T);
    DArray<int> dpart;
    dpart.upload(part.data(), part.size());
+   static const bool legacy = getenv("HDA_RS_LEGACY") && atoi(getenv("HDA_RS_LEGACY")) != 0; // the round-3 kernel (A/B)
+   if (legacy)
    {
       const size_t nbk = 2 * (size_t)n + 2 * (size_t)nblk;
       DArray<int>  head(nbk), tail(nbk), prev((size_t)n + 1), next((size_t)n + 1), key((size_t)n + 1), meas((size_t)n + 1);
       k_rs_first_pass<<<nblk, 64, 0, STREAM>>>(nblk, dpart.data(), S.rowptr.data(), S.col.data(), T.rowptr.data(), T.col.data(), head.data(),
                                               tail.data(), prev.data(), next.data(), key.data(), meas.data(), cf);
+      Context::get().sync();
+   }
+   else
+   {
+      // a measure never exceeds twice the in-block dependants: bucket keys stay below 2 * (largest in-degree) + 2
+      DArray<int> mx(1);
+      mx.zero();
+      k_max_row_len<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, T.rowptr.data(), mx.data());
+      int maxin = 0;
+      mx.download(&maxin, 1);
+      const int         kcap = 2 * maxin + 2;
+      const bool        lds  = (size_t)kcap * 8 <= 64 * 1024;
+      const size_t      nbk  = lds ? 1 : 2 * (size_t)n + 2 * (size_t)nblk;
+      DArray<int>       head(nbk), tail(nbk);
+      DArray<long long> recs(2 * ((size_t)n + 1)); // int4 records
+      int4             *rec = reinterpret_cast<int4 *>(recs.data());
+      if (lds)
+         k_rs_first_pass_rec<true><<<nblk, 64, (size_t)kcap * 8, STREAM>>>(nblk, dpart.data(), S.rowptr.data(), S.col.data(), T.rowptr.data(), T.col.data(),
+                                                                          head.data(), tail.data(), rec, cf, kcap);
+      else
+         k_rs_first_pass_rec<false><<<nblk, 64, 0, STREAM>>>(nblk, dpart.data(), S.rowptr.data(), S.col.data(), T.rowptr.data(), T.col.data(), head.data(),
+                                                            tail.data(), rec, cf, kcap);
       Context::get().sync();
    }
    // hypre_BoomerAMGCoarsenPMIS with CF_init 1: interior C points are the first independent set, everything else is decided again
