@@ -570,14 +570,20 @@ def single_extras(args, out, hh, A, amg, fb0, iters):
             out["uncoded"] = plain_csr_child(args, window="1")
     if not args.no_cpu_defaults and fits("cpu_defaults", 40):
         out["cpu_defaults"] = cpu_defaults_run(args)
+    if not args.no_cpu_defaults and args.n % 32 == 0 and args.n >= 64 and fits("cpu_defaults_rank_blocks", 60):
+        out["cpu_defaults_rank_blocks"] = cpu_defaults_run(args, rank_grid=args.n // 32)
     if not args.no_aggressive and fits("aggressive_1", 20):
         out["aggressive_1"] = aggressive_run(args, hh)
     if skipped:
         out["extras_skipped"] = skipped
 
 
-def cpu_defaults_run(args):
-    """SURVEY 8(d)'s second series: the same system and API path with the reference's CPU-build defaults (HMIS coarsening, hybrid l1
+def cpu_defaults_run(args, rank_grid=None):
+    """(rank_grid = p: the same PDE in the numbering the reference's generator gives it at np = p^3, `-P p p p` -- laplacian.c:504-520 --
+    handed over through HYPREDRV_LinearSystemSetMatrixFromCSR; row block q is then rank q's 32^3 sub-cube, which is what the reference's
+    HMIS and hybrid sweeps see on p^3 ranks: blocks with an interior however many there are, where slabs of a lexicographic numbering
+    lose theirs.)
+    SURVEY 8(d)'s second series: the same system and API path with the reference's CPU-build defaults (HMIS coarsening, hybrid l1
     Gauss-Seidel 13 / 14; src/internal/amg.c:141-146, 182-189 -- the configuration its exact pins examples/refOutput/ex1.txt:27 and
     laplacian.txt:34-38 were made with) on V row blocks = the reference at np = V (V: the setup's own choice, in the object), and the
     oracle doing the same on the same V (iters_match) when the budget allows its serial setup."""
@@ -587,7 +593,8 @@ def cpu_defaults_run(args):
     spec.loader.exec_module(mod)
     try:
         need = 200 if args.n >= 200 else 40  # the oracle's serial setup at 256^3 is about a minute, its block sweeps run on the host threads
-        return mod.run(args.n, steps=max(min(args.steps, 3), 1), warmup=1, oracle=(not args.no_cpu_defaults_oracle) and budget_left() >= need)
+        return mod.run(args.n, steps=max(min(args.steps, 3), 1), warmup=1, oracle=(not args.no_cpu_defaults_oracle) and budget_left() >= need,
+                       rank_grid=rank_grid)
     except Exception as e:  # noqa: BLE001 - an extra must not lose the headline
         return {"error": repr(e)[:400]}
 

@@ -85,3 +85,27 @@ def test_bench_skips_its_counter_passes_when_it_is_being_profiled(monkeypatch):
         n = 256
     t, why = bench.measure_traffic(A())
     assert t is None and "profiled" in why
+
+
+def test_series_b_rank_block_numbering_is_the_generators():
+    """tools/series_b.py --rank-grid p hands the library the n^3 Laplacian in the numbering the reference's generator produces at
+    np = p^3 (`-P p p p`, examples/src/C_laplacian/laplacian.c:504-520 grid2idx; rhs :898-905): the oracle's restatement of that
+    generator (pinned by laplacian.txt) must give the same matrix and right-hand side, entry for entry."""
+    import importlib.util
+    import numpy as np
+    import scipy.sparse as sp
+    from oracle import oracle_ffi as orc
+    spec = importlib.util.spec_from_file_location("series_b", os.path.join(ROOT, "tools", "series_b.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for n, p in ((8, 2), (12, 3), (8, 1)):
+        ip, cj, v, b = mod.lap7_rank_blocks(n, p)
+        A, bo = orc.lap7(n, n, n, P=(p, p, p))
+        M = sp.csr_matrix((v, cj, ip), shape=(n ** 3, n ** 3))
+        Mo = sp.csr_matrix((np.array(A.val), np.array(A.col), np.array(A.rowptr)), shape=(n ** 3, n ** 3))
+        assert M.nnz == Mo.nnz and abs(M - Mo).max() == 0.0
+        assert np.array_equal(b, bo)
+        # block q of n^3 / p^3 consecutive rows is a sub-cube: its rows couple to at most 6 (n/p)^2 rows outside
+        nl3 = (n // p) ** 3
+        q = np.repeat(np.arange(n ** 3) // nl3, np.diff(ip))
+        assert (q != cj // nl3).sum() == 6 * (n // p) ** 2 * p ** 3 - 6 * n * n
