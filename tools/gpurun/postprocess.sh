@@ -7,6 +7,7 @@ cp $O/trace/run_kernel_stats.csv profiles/${T}_bench_kernel_stats.csv
 python3 tools/trace_by_operator.py $O/trace/run_kernel_trace.csv profiles/${T}_kernel_by_operator.csv
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write profiles/$T > /dev/null
 cp $O/series_b.jsonl profiles/${T}_series_b.jsonl
+[ -f $O/series_b_rank_blocks.jsonl ] && cp $O/series_b_rank_blocks.jsonl profiles/${T}_series_b_rank_blocks.jsonl
 cp $O/series_b_kernel_by_operator.csv profiles/${T}_series_b_kernel_by_operator.csv
 cp $O/trace_b/run_kernel_stats.csv profiles/${T}_series_b_kernel_stats.csv
 tail -3 gpurun_out/${T}_suite/t_all.log | head -1
@@ -25,5 +26,10 @@ print("cpu_defaults", {k: cd.get(k) for k in ("V", "iters", "iters_match")}, rou
 for l in open(f"profiles/{T}_series_b.jsonl"):
     q = json.loads(l)
     print("series B", q["grid"], "V", q["V"], "iters", q["iters"], round(q["ms_per_step"], 2), "ms, setup", round(q["setup_ms"], 0))
+import os
+if os.path.exists(f"profiles/{T}_series_b_rank_blocks.jsonl"):
+    for l in open(f"profiles/{T}_series_b_rank_blocks.jsonl"):
+        q = json.loads(l)
+        print("series B rank blocks", q["grid"], "V", q["V"], "iters", q["iters"], round(q["ms_per_step"], 2), "ms, setup", round(q["setup_ms"], 0))
 PYEOF
 grep 'k_spmv_win<2, false, false, false, false>",0' profiles/${T}_kernel_by_operator.csv
