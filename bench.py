@@ -807,8 +807,8 @@ def multi_extras(args, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)  # (a solve is 34 ms: ten of them average out a one-off host hiccup that five do not)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", dest="n", type=int, default=0, help="grid points per dimension (per rank; global with --strong or "
                     "--workload aniso); default 256 (lap7) / 128 (aniso)")
     ap.add_argument("--workload", choices=["lap7", "aniso"], default="lap7", help="lap7: BASELINE configs 2 / 3 (the headline metric). aniso: "
