@@ -92,7 +92,7 @@ SYMBOLS = [
 
 
 TESTRANKS_SYMBOLS = ["hda_thread_ranks_lap7", "hda_thread_world_create", "hda_thread_world_join", "hda_thread_world_leave",
-                     "hda_thread_world_destroy"]
+                     "hda_thread_world_destroy", "hda_testranks_selftest"]
 _TESTRANKS_PATH = os.path.join(os.path.dirname(_LIBPATH), "libhypredrv_amd_testranks.so")
 _T = None
 
@@ -107,6 +107,15 @@ def load_testranks():
             raise LibraryError(f"{_TESTRANKS_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         _T = C.CDLL(_TESTRANKS_PATH)
     return _T
+
+
+def testranks_selftest(what, cache_gb=8.0):
+    """include/hypredrv_amd_testranks.h hda_testranks_selftest: (ok, the ranks' messages)"""
+    T = load_testranks()
+    T.hda_testranks_selftest.argtypes = [C.c_int, C.c_double, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(4096)
+    rc = T.hda_testranks_selftest(int(what), float(cache_gb), buf, 4096)
+    return rc == 0, buf.value.decode(errors="replace")
 
 
 def load():

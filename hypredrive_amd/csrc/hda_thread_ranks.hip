@@ -13,7 +13,9 @@
 #include "hda_testranks.h"
 #include "hypredrv_amd.h"
 
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -170,3 +172,109 @@ extern "C" int hda_thread_world_leave(void *world, int failed)
    return 0;
 }
 extern "C" void hda_thread_world_destroy(void *world) { delete (std::shared_ptr<void> *)world; }
+
+// ---- self tests of the seam itself (tests/test_gpu_hypredrv.py)
+// what = 0: two thread ranks enter DIFFERENT collectives (an all-reduce against an all-to-all).  Both must come back with an error that
+//           names the disagreement -- before round 4's end this read a stale pointer of the other rank and crashed the process.
+// what = 1: the device allocator when the device is full of OTHER rank threads' cached blocks: a second rank allocates `cache_gb` and
+//           releases it (the block stays cached in that rank's pool), then this rank asks for more than the driver has left -- the
+//           request must be served by giving the other rank's cache back, not fail.
+// Returns 0 when the behaviour is as described, 1 otherwise; the ranks' messages in errbuf.
+extern "C" int hda_testranks_selftest(int what, double cache_gb, char *errbuf, int errlen)
+{
+   std::string report;
+   int         rc = 1;
+   if (what == 0)
+   {
+      std::shared_ptr<void>    world = make_thread_world(2);
+      std::string              msg[2];
+      std::vector<std::thread> th;
+      for (int r = 0; r < 2; r++)
+         th.emplace_back([&, r] {
+            enter_thread_rank();
+            try
+            {
+               Comm::set_world(make_thread_comm(r, world));
+               long long v[2] = {1, 2};
+               long      eight[2] = {8, 8};
+               long long out[2]   = {0, 0};
+               if (r == 0) Comm::world().allreduce_host(v, 2, 0);
+               else Comm::world().alltoallv_host(v, eight, out, eight);
+               msg[r] = "no error";
+            }
+            catch (const std::exception &e)
+            {
+               msg[r] = e.what();
+               thread_world_fail(world);
+            }
+            leave_thread_rank();
+         });
+      for (auto &t : th) t.join();
+      report = "rank 0: " + msg[0] + "\nrank 1: " + msg[1];
+      const bool named = msg[0].find("different collectives") != std::string::npos || msg[1].find("different collectives") != std::string::npos;
+      rc = (named && msg[0] != "no error" && msg[1] != "no error") ? 0 : 1;
+   }
+   else if (what == 1)
+   {
+      std::mutex              mu;
+      std::condition_variable cv;
+      int                     stage = 0; // 1: the other rank's block is cached; 2: this rank is done
+      std::string             other;
+      std::thread             t([&] {
+         enter_thread_rank();
+         try
+         {
+            {
+               DArray<char> big((size_t)(cache_gb * (double)(1ull << 30)));
+               HDA_HIP(hipMemsetAsync(big.data(), 0, 4096, Context::get().stream));
+               Context::get().sync();
+            } // released: cached in this rank's pool
+            other = "cached " + std::to_string(hda_memory_cached() / (double)(1ull << 30)) + " GB";
+         }
+         catch (const std::exception &e)
+         {
+            other = std::string("error: ") + e.what();
+         }
+         {
+            std::unique_lock<std::mutex> lk(mu);
+            stage = 1;
+            cv.notify_all();
+            cv.wait(lk, [&] { return stage == 2; });
+         }
+         leave_thread_rank();
+      });
+      {
+         std::unique_lock<std::mutex> lk(mu);
+         cv.wait(lk, [&] { return stage == 1; });
+      }
+      std::string mine;
+      try
+      {
+         (void)hda_memory_trim(); // nothing cached on this thread: what is short can only come from the other rank's pool
+         size_t freeb = 0, totalb = 0;
+         HDA_HIP(hipMemGetInfo(&freeb, &totalb));
+         const size_t want = freeb + (size_t)(0.5 * cache_gb * (double)(1ull << 30)); // more than the driver has, less than free + the other rank's cache
+         {
+            DArray<char> big(want);
+            HDA_HIP(hipMemsetAsync(big.data(), 0, 4096, Context::get().stream));
+            Context::get().sync();
+         }
+         (void)hda_memory_trim();
+         mine = "served " + std::to_string((double)want / (double)(1ull << 30)) + " GB with " + std::to_string((double)freeb / (double)(1ull << 30)) + " GB free";
+         rc   = other.rfind("cached", 0) == 0 ? 0 : 1;
+      }
+      catch (const std::exception &e)
+      {
+         mine = std::string("error: ") + e.what();
+      }
+      {
+         std::lock_guard<std::mutex> lk(mu);
+         stage = 2;
+         cv.notify_all();
+      }
+      t.join();
+      report = "other rank: " + other + "\nthis rank: " + mine;
+   }
+   if (errbuf && errlen > 0) { strncpy(errbuf, report.c_str(), (size_t)errlen - 1); errbuf[errlen - 1] = 0; }
+   return rc;
+}

@@ -33,7 +33,7 @@ def test_test_seam_is_a_library_of_its_own():
     import hypredrive_amd as h
     L, T = h.load(), h._lib.load_testranks()
     names = [n for n in _declared("hypredrv_amd_testranks.h") if n.startswith("hda_")]
-    assert sorted(names) == sorted(h._lib.TESTRANKS_SYMBOLS) and len(names) == 5
+    assert sorted(names) == sorted(h._lib.TESTRANKS_SYMBOLS) and len(names) == 6
     for n in names:
         assert hasattr(T, n), f"{n} declared in include/hypredrv_amd_testranks.h but not exported by the test library"
         assert not hasattr(L, n), f"{n} (test seam) is exported by the product library"

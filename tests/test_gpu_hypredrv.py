@@ -1992,3 +1992,19 @@ def test_bench_reports_the_serial_measurement_when_the_overlapped_phase_hangs():
     d = lines[0]
     assert "did not finish" in d["overlap_error"] and d["value"] == d["serial_exchange"]["value"] and d["ms_per_step"] == d["serial_exchange"]["ms_per_step"]
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["converged"] and d["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("what", [0, 1])
+def test_thread_rank_seam_selftests(what):
+    """include/hypredrv_amd_testranks.h hda_testranks_selftest, in a child process (what = 1 asks the driver for nearly all of HBM).
+    0: two thread ranks in DIFFERENT collectives get an error that names the disagreement -- the full-size config-3 run once crashed
+       there, reading a stale pointer of a rank that had left the setup with an out-of-memory error.
+    1: an allocation larger than the driver's free memory is served by returning ANOTHER rank thread's cached blocks -- the cause of
+       that out-of-memory error: eight ranks' caches (up to twice each rank's peak) filled the device."""
+    code = ("import sys; from hypredrive_amd import _lib; ok, msg = _lib.testranks_selftest(%d, 8.0); print(msg); sys.exit(0 if ok else 1)" % what)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    if what == 0:
+        assert "different collectives" in r.stdout
+    else:
+        assert "served" in r.stdout and "cached 8." in r.stdout
