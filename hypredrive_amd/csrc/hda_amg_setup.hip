@@ -619,7 +619,7 @@ static void hmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
    transpose(S, T);
    DArray<int> dpart;
    dpart.upload(part.data(), part.size());
-   static const bool legacy = getenv("HDA_RS_LEGACY") && atoi(getenv("HDA_RS_LEGACY")) != 0; // the round-3 kernel (A/B)
+   const bool legacy = getenv("HDA_RS_LEGACY") && atoi(getenv("HDA_RS_LEGACY")) != 0; // the round-3 kernel (A/B; read per setup: the tests switch it)
    if (legacy)
    {
       const size_t nbk = 2 * (size_t)n + 2 * (size_t)nblk;
@@ -637,7 +637,8 @@ static void hmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
       int maxin = 0;
       mx.download(&maxin, 1);
       const int         kcap = 2 * maxin + 2;
-      const bool        lds  = (size_t)kcap * 8 <= 64 * 1024;
+      const char       *le   = getenv("HDA_RS_LDS"); // 0: bucket heads / tails in global memory whatever their number (tests: the form for in-degrees beyond 4095)
+      const bool        lds  = (size_t)kcap * 8 <= 64 * 1024 && !(le && atoi(le) == 0);
       const size_t      nbk  = lds ? 1 : 2 * (size_t)n + 2 * (size_t)nblk;
       DArray<int>       head(nbk), tail(nbk);
       DArray<long long> recs(2 * ((size_t)n + 1)); // int4 records
