@@ -76,7 +76,7 @@ class MgrLevelParams(C.Structure):
 
 # every symbol include/hypredrv_amd.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
-    "hda_last_error", "hda_device_count", "hda_device_name", "hda_device_sync",
+    "hda_last_error", "hda_device_count", "hda_device_name", "hda_device_pci_bus_id", "hda_device_sync",
     "hda_amg_default_params", "hda_krylov_default_params", "hda_csr_create", "hda_csr_destroy",
     "hda_csr_dims", "hda_csr_download", "hda_lap7_create", "hda_spmv", "hda_relax", "hda_dot",
     "hda_l1_norms", "hda_strength", "hda_pmis", "hda_interp_extpi", "hda_interp_direct", "hda_rap", "hda_transpose",
@@ -132,6 +132,7 @@ def load():
     dp, ip, vp = P(C.c_double), P(C.c_int), C.c_void_p
     L.hda_last_error.restype = C.c_char_p
     L.hda_device_name.argtypes = [C.c_char_p, C.c_int]
+    L.hda_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.hda_amg_default_params.argtypes = [P(AmgParams)]
     L.hda_amg_default_params.restype = None
     L.hda_krylov_default_params.argtypes = [P(KrylovParams), C.c_int]

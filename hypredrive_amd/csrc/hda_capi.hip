@@ -67,6 +67,20 @@ extern "C" int hda_device_name(char *buf, int len)
    HDA_CATCH
 }
 
+// PCI bus id of visible device `dev` ("0000:c1:00.0"): the identity of the physical GPU, which an index is not once a launcher has
+// narrowed every rank's view to its own device (HIP_VISIBLE_DEVICES per rank: all indices are 0).  Touches no context of the library.
+extern "C" int hda_device_pci_bus_id(int dev, char *buf, int len)
+{
+   if (!buf || len < 16) return HDA_ERR_RUNTIME;
+   if (hipDeviceGetPCIBusId(buf, len, dev) != hipSuccess)
+   {
+      (void)hipGetLastError();
+      g_err = "hipDeviceGetPCIBusId failed";
+      return HDA_ERR_RUNTIME;
+   }
+   return HDA_OK;
+}
+
 extern "C" int hda_device_sync(void)
 {
    HDA_TRY

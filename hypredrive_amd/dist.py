@@ -122,14 +122,19 @@ def init(transport="auto", strict=False):
     if forced:
         transport = forced
     if transport == "auto":
-        transport = "rccl" if ndev >= world or (ndev > 1 and local < ndev) else "staged"
+        transport = "rccl" if ndev >= 1 else "staged"  # (decided for good below: one PHYSICAL GPU per rank, or the staged transport)
     L = hd.lib()
     if transport == "rccl":
         # RCCL refuses two ranks on one device, and the refusing rank leaves its peers blocked inside
-        # ncclCommInitRank: find that out BEFORE touching RCCL (single node: the device index is the identity)
+        # ncclCommInitRank: find that out BEFORE touching RCCL.  The identity of a device is its PCI bus id, not its index: a launcher
+        # that narrows every rank's view to its own GPU (HIP_VISIBLE_DEVICES per rank) makes every index 0.
         mine = local if local < max(ndev, 1) else 0
+        ident = mine
+        buf = C.create_string_buffer(64)
+        if L.hda_device_pci_bus_id(mine, buf, 64) == 0:
+            ident = buf.value.decode(errors="replace")
         devs = [None] * world
-        dist.all_gather_object(devs, (os.uname().nodename, mine))
+        dist.all_gather_object(devs, (os.uname().nodename, ident))
         if len(set(devs)) < world:
             if forced == "rccl":
                 raise TransportError("devices", rank, f"RCCL needs one GPU per rank; ranks share devices: {devs}")

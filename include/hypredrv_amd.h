@@ -69,6 +69,9 @@ typedef struct {
 const char *hda_last_error(void);
 int         hda_device_count(void);           /* 0 when no HIP device is visible */
 int         hda_device_name(char *buf, int len);
+/* PCI bus id of visible device dev (len >= 16): which physical GPU an index means (launchers that give every rank its own
+ * HIP_VISIBLE_DEVICES make all indices 0; hypredrive_amd/dist.py decides "one GPU per rank" on this) */
+int         hda_device_pci_bus_id(int dev, char *buf, int len);
 int         hda_device_sync(void);
 /* launches the empty kernel hda::k_marker on the library's stream: a boundary that shows in kernel traces and counter passes */
 int         hda_marker(int id);
