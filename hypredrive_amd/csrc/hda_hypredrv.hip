@@ -312,6 +312,11 @@ extern "C" uint32_t HYPREDRV_AMD_CommInit(int rank, int world, int device, const
 {
    err_reset();
    API_TRY
+   if (device > 0)
+   { // a launcher that shows every rank exactly one device (HIP_VISIBLE_DEVICES per rank): LOCAL_RANK is not an index then
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) == hipSuccess && ndev == 1) device = 0;
+   }
    if (device >= 0) HDA_HIP(hipSetDevice(device));
    // HDA_FORCE_RCCL: build a 1-rank RCCL communicator too (transport self-test on a single GPU)
    if (world > 1 || getenv("HDA_FORCE_RCCL")) Comm::set_world(make_rccl_comm(rank, world, uid));

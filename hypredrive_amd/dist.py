@@ -167,7 +167,7 @@ def init(transport="auto", strict=False):
             uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
             stage = _keep["stage"] = "init"  # (_keep["stage"]: what a watchdog reports when a call never returns)
             try:
-                hd.check(L.HYPREDRV_AMD_CommInit(rank, world, local, uid))
+                hd.check(L.HYPREDRV_AMD_CommInit(rank, world, mine, uid))  # (mine: LOCAL_RANK, or 0 when the launcher shows this rank one device)
             except Exception as e:  # noqa: BLE001 - the library names the communicator that failed
                 if "halo_comm" in str(e):
                     stage = "halo_comm"
