@@ -116,6 +116,10 @@ def init(transport="auto", strict=False):
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
+        # a one-node world that meets on the loopback address needs no other interface: gloo otherwise looks its interface up through the
+        # host NAME, which containers do not always resolve
+        if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     ndev = torch.cuda.device_count()
     forced = os.environ.get("HDA_TRANSPORT")  # "rccl" | "staged": overrides the choice below
