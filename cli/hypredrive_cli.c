@@ -28,7 +28,10 @@ static void join_world(void)
    int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), local = env_int("LOCAL_RANK", rank);
    if (world <= 1) return;
    char path[256], tmp[300];
-   snprintf(path, sizeof(path), "/tmp/hypredrv_amd_uid_%s", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+   /* one file per LAUNCH: the ranks of a launch are children of one launcher process (torchrun's agent, mpirun's daemon, a shell), so its
+    * pid tells this launch's id file from one a crashed earlier launch on the same port left behind (reading that would hang every rank
+    * inside ncclCommInitRank) */
+   snprintf(path, sizeof(path), "/tmp/hypredrv_amd_uid_%s_%ld", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0", (long)getppid());
    unsigned char uid[128];
    if (rank == 0)
    {
