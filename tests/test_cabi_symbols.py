@@ -98,3 +98,15 @@ def test_product_never_imports_oracle():
                     if re.search(r"oracle_ffi|amg_oracle|liboracle|from oracle|import oracle", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_thread_transport_reports_ranks_in_different_collectives():
+    """Host-only part of the thread-rank seam (no GPU call): two thread ranks that enter DIFFERENT collectives both come back with an
+    error naming the disagreement instead of reading each other's stale pointers (include/hypredrv_amd_testranks.h
+    hda_testranks_selftest, what = 0)."""
+    import subprocess
+    import sys
+    code = "import sys; from hypredrive_amd import _lib; ok, msg = _lib.testranks_selftest(0); print(msg); sys.exit(0 if ok else 1)"
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("different collectives") == 2
