@@ -176,6 +176,7 @@ extern "C" void hda_thread_world_destroy(void *world) { delete (std::shared_ptr<
 // ---- self tests of the seam itself (tests/test_gpu_hypredrv.py)
 // what = 0: two thread ranks enter DIFFERENT collectives (an all-reduce against an all-to-all).  Both must come back with an error that
 //           names the disagreement -- before round 4's end this read a stale pointer of the other rank and crashed the process.
+// what = 2: the same collective with send and receive counts that disagree: an error naming the two ranks and the byte counts.
 // what = 1: the device allocator when the device is full of OTHER rank threads' cached blocks: a second rank allocates `cache_gb` and
 //           releases it (the block stays cached in that rank's pool), then this rank asks for more than the driver has left -- the
 //           request must be served by giving the other rank's cache back, not fail.
@@ -184,7 +185,7 @@ extern "C" int hda_testranks_selftest(int what, double cache_gb, char *errbuf, i
 {
    std::string report;
    int         rc = 1;
-   if (what == 0)
+   if (what == 0 || what == 2)
    {
       std::shared_ptr<void>    world = make_thread_world(2);
       std::string              msg[2];
@@ -198,7 +199,14 @@ extern "C" int hda_testranks_selftest(int what, double cache_gb, char *errbuf, i
                long long v[2] = {1, 2};
                long      eight[2] = {8, 8};
                long long out[2]   = {0, 0};
-               if (r == 0) Comm::world().allreduce_host(v, 2, 0);
+               long      sixteen[2] = {16, 16};
+               long long out4[4]    = {0, 0, 0, 0};
+               if (what == 2) // same collective, but rank 1 expects 16 bytes from everybody where 8 are sent
+               {
+                  if (r == 0) Comm::world().alltoallv_host(v, eight, out, eight);
+                  else Comm::world().alltoallv_host(v, eight, out4, sixteen);
+               }
+               else if (r == 0) Comm::world().allreduce_host(v, 2, 0);
                else Comm::world().alltoallv_host(v, eight, out, eight);
                msg[r] = "no error";
             }
@@ -211,7 +219,8 @@ extern "C" int hda_testranks_selftest(int what, double cache_gb, char *errbuf, i
          });
       for (auto &t : th) t.join();
       report = "rank 0: " + msg[0] + "\nrank 1: " + msg[1];
-      const bool named = msg[0].find("different collectives") != std::string::npos || msg[1].find("different collectives") != std::string::npos;
+      const char *needle = what == 2 ? "which expects 16" : "different collectives";
+      const bool  named  = msg[0].find(needle) != std::string::npos || msg[1].find(needle) != std::string::npos;
       rc = (named && msg[0] != "no error" && msg[1] != "no error") ? 0 : 1;
    }
    else if (what == 1)

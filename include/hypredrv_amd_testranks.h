@@ -27,7 +27,7 @@ int hda_thread_world_leave(void *world, int failed);
 void hda_thread_world_destroy(void *world);
 /* Self tests of the seam (returns 0 when the behaviour is as described; the ranks' messages in errbuf).
  * what 0: two thread ranks enter different collectives -- both must return with an error naming the disagreement (not read each other's
- *         stale pointers).  what 1: the device allocator serves a request larger than the driver's free memory by returning the cached
+ *         stale pointers).  what 2: the same collective with send / receive byte counts that disagree -- an error naming both.  what 1: the device allocator serves a request larger than the driver's free memory by returning the cached
  *         blocks of ANOTHER rank thread (which has cached cache_gb GiB) to the driver. */
 int hda_testranks_selftest(int what, double cache_gb, char *errbuf, int errlen);
 

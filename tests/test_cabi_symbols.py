@@ -106,7 +106,11 @@ def test_thread_transport_reports_ranks_in_different_collectives():
     hda_testranks_selftest, what = 0)."""
     import subprocess
     import sys
-    code = "import sys; from hypredrive_amd import _lib; ok, msg = _lib.testranks_selftest(0); print(msg); sys.exit(0 if ok else 1)"
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=120)
+    code = "import sys; from hypredrive_amd import _lib; ok, msg = _lib.testranks_selftest(%d); print(msg); sys.exit(0 if ok else 1)"
+    r = subprocess.run([sys.executable, "-c", code % 0], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("different collectives") == 2
+    # what = 2: the same collective, but one rank expects 16 bytes where 8 are sent
+    r = subprocess.run([sys.executable, "-c", code % 2], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "sends 8 bytes" in r.stdout and "which expects 16" in r.stdout
