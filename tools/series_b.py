@@ -4,6 +4,8 @@
 (HDA_BLOCKS; unset = the setup's own choice).  Prints one JSON line per run.
 
     python tools/series_b.py --grid 128 [--blocks 32] [--steps 5] [--oracle]
+    python tools/series_b.py --grid 256 --rank-grid 8      # the system numbered as the reference's generator numbers it at np = 8^3
+                                                           # (-P 8 8 8): one row block per rank = a 32^3 sub-cube
 """
 import argparse
 import json
