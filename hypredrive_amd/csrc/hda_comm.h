@@ -52,6 +52,9 @@ class Comm {
 
    static Comm &world();
    static void  set_world(Comm *c); // takes ownership
+   // true once the launcher has called HYPREDRV_AMD_CommInit / CommInitCallbacks: the MPI join (hda_mpi.cpp) then stays out
+   static bool  explicitly_joined();
+   static void  set_explicitly_joined(bool v);
 };
 
 Comm *make_self_comm();

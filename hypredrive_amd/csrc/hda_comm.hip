@@ -27,6 +27,9 @@ Comm &Comm::world()
    return *g_world;
 }
 void Comm::set_world(Comm *c) { g_world.reset(c); }
+#define g_explicit (RankState<bool, 41>::get())
+bool Comm::explicitly_joined() { return g_explicit; }
+void Comm::set_explicitly_joined(bool v) { g_explicit = v; }
 
 void Comm::allgather_ll(long long mine, std::vector<long long> &all)
 {
@@ -258,10 +261,10 @@ class CallbackComm : public Comm {
       // pinned staging buffers: the copies go through the DMA engines and do not queue behind a product grid
       double *hs = pinned(0, (size_t)std::max<long>(st, 1)), *hr = pinned(1, (size_t)std::max<long>(rt, 1));
       if (st) HDA_HIP(hipMemcpyAsync(hs, send, sizeof(double) * (size_t)st, hipMemcpyDeviceToHost, strm));
-      HDA_HIP(hipStreamSynchronize(strm));
+      wait_stream(strm);
       check(a2a_(hs, sb.data(), hr, rb.data()), "neighbour exchange");
       if (rt) HDA_HIP(hipMemcpyAsync(recv, hr, sizeof(double) * (size_t)rt, hipMemcpyHostToDevice, strm));
-      HDA_HIP(hipStreamSynchronize(strm));
+      wait_stream(strm);
    }
    void allreduce_host(long long *v, int n, int op) override { check(ar_(v, n, 1, op), "host all-reduce"); }
    void alltoallv_host(const void *send, const long *sb, void *recv, const long *rb) override { check(a2a_(send, sb, recv, rb), "host all-to-all"); }

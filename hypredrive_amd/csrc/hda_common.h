@@ -86,6 +86,16 @@ struct RankState {
 template <class T, int Tag>
 thread_local T *RankState<T, Tag>::mine_ = nullptr;
 
+// Host waits of the library.  With HDA_COMM_TIMEOUT_S=<seconds> (default: none, the wait blocks as hipStreamSynchronize does) a wait
+// that does not end in time -- a peer rank that failed or left the collective sequence leaves RCCL / the staged transport waiting
+// silently -- reports rank and stage and ends the job non-zero (MPI_Abort under MPI, _exit(86) otherwise); nothing is re-exec'd.
+void        wait_stream(hipStream_t s);
+void        wait_event(hipEvent_t e);
+double      wait_limit_s();
+void        set_stage(const char *stage); // what the library is doing, for that report ("matrix assembly", "preconditioner setup", ...)
+const char *current_stage();
+[[noreturn]] void abort_job(int status);  // MPI_Abort when the process runs under MPI (hda_mpi.cpp), else _exit
+
 // One per process (per GPU): stream, reduction scratch, pinned scalars.
 struct Context {
    hipStream_t stream      = nullptr;
@@ -100,7 +110,7 @@ struct Context {
 
    static Context &get();
    static void     release_thread(); // (thread ranks: called by leave_thread_rank)
-   void            sync() { HDA_HIP(hipStreamSynchronize(stream)); }
+   void            sync() { wait_stream(stream); }
    double         *slot(int s) { return partials + (size_t)s * kRedBlocks; }
 
  private:

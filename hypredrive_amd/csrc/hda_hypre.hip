@@ -2,6 +2,7 @@
 // This is the lower seam of the drop-in boundary: the functions hypredrive's op tables
 // (src/internal/solver.c:204-253, src/internal/precon.c:106-157 in the reference) bind.
 #include "hda_hypre.h"
+#include "hda_mpi_join.h"
 
 #include <unordered_set>
 
@@ -47,7 +48,11 @@ static bool have_device()
 // ------------------------------------------------------------------ utilities
 
 extern "C" HYPRE_Int HYPRE_Initialize(void) { return 0; }
-extern "C" HYPRE_Int HYPRE_Finalize(void) { return 0; }
+extern "C" HYPRE_Int HYPRE_Finalize(void)
+{
+   mpi_leave(); // lower-seam callers (an unmodified libHYPREDRV on top of this library) end here, before MPI_Finalize
+   return 0;
+}
 extern "C" HYPRE_Int HYPRE_SetMemoryLocation(HYPRE_MemoryLocation) { return 0; }
 extern "C" HYPRE_Int HYPRE_SetExecutionPolicy(HYPRE_ExecutionPolicy) { return 0; }
 extern "C" HYPRE_Int HYPRE_GetError(void) { return g_hcode; }
@@ -75,6 +80,7 @@ void hypre_IJVector_struct::ensure_device()
 extern "C" HYPRE_Int HYPRE_IJVectorCreate(MPI_Comm comm, HYPRE_BigInt jlower, HYPRE_BigInt jupper, HYPRE_IJVector *vector)
 {
    HY_TRY
+   mpi_autojoin((int)comm); // lower-seam callers hand their communicator over here (hda_mpi.cpp)
    auto *v   = new hypre_IJVector_struct();
    v->comm   = comm;
    v->jlower = jlower;
@@ -204,6 +210,7 @@ static void my_parts(long long g_nparts, int &first, int &count);
 extern "C" HYPRE_Int HYPRE_IJVectorRead(const char *filename, MPI_Comm comm, HYPRE_Int, HYPRE_IJVector *vector)
 {
    HY_TRY
+   mpi_autojoin((int)comm);
    const int nparts = count_part_files(filename);
    int       first = Comm::world().rank, count = 1;
    if (nparts > Comm::world().size) my_parts(nparts, first, count);
@@ -272,6 +279,7 @@ static bool all_ok(bool mine)
 extern "C" HYPRE_Int hda_IJVectorReadMultipartBinary(const char *prefix, MPI_Comm comm, long long g_nparts, HYPRE_IJVector *vector)
 {
    HY_TRY
+   mpi_autojoin((int)comm);
    *vector = nullptr;
    Comm &cm = Comm::world();
    if (g_nparts < cm.size) return hypre_set_error(HYPRE_ERROR_GENERIC, "Invalid number of parts!");
@@ -336,6 +344,7 @@ extern "C" HYPRE_Int HYPRE_IJMatrixCreate(MPI_Comm comm, HYPRE_BigInt ilower, HY
                                           HYPRE_BigInt jupper, HYPRE_IJMatrix *matrix)
 {
    HY_TRY
+   mpi_autojoin((int)comm);
    auto *m   = new hypre_IJMatrix_struct();
    m->comm   = comm;
    m->ilower = ilower; m->iupper = iupper; m->jlower = jlower; m->jupper = jupper;
@@ -630,6 +639,7 @@ extern "C" HYPRE_Int HYPRE_IJMatrixAssemble(HYPRE_IJMatrix m)
 {
    HY_NEED_DEVICE;
    HY_TRY
+   set_stage("matrix assembly (HYPRE_IJMatrixAssemble)");
    if (m->assembled && m->t_row.empty()) return 0;
    HDA_REQUIRE(!m->assembled || m->t_row.empty(), "re-assembly of an assembled IJMatrix with new values is not supported");
    m->assemble();
@@ -662,6 +672,7 @@ extern "C" HYPRE_Int HYPRE_ParCSRMatrixGetNumNonzeros(HYPRE_ParCSRMatrix A, HYPR
 extern "C" HYPRE_Int HYPRE_IJMatrixRead(const char *filename, MPI_Comm comm, HYPRE_Int, HYPRE_IJMatrix *matrix)
 {
    HY_TRY
+   mpi_autojoin((int)comm);
    // more part files than ranks: a rank reads its contiguous group of parts (see HYPRE_IJVectorRead)
    const int nparts = count_part_files(filename);
    int       first = Comm::world().rank, count = 1;
@@ -710,6 +721,7 @@ extern "C" HYPRE_Int HYPRE_IJMatrixRead(const char *filename, MPI_Comm comm, HYP
 extern "C" HYPRE_Int hda_IJMatrixReadMultipartBinary(const char *prefix, MPI_Comm comm, long long g_nparts, HYPRE_IJMatrix *matrix)
 {
    HY_TRY
+   mpi_autojoin((int)comm);
    *matrix = nullptr;
    Comm &cm = Comm::world();
    if (g_nparts < cm.size) return hypre_set_error(HYPRE_ERROR_GENERIC, "Invalid number of parts!");
@@ -789,6 +801,7 @@ extern "C" HYPRE_Int hda_IJMatrixReadMultipartBinary(const char *prefix, MPI_Com
 extern "C" HYPRE_Int HYPRE_IJMatrixReadMM(const char *filename, MPI_Comm comm, HYPRE_Int, HYPRE_IJMatrix *matrix)
 {
    HY_TRY
+   mpi_autojoin((int)comm);
    *matrix = nullptr;
    FILE *f = fopen(filename, "r");
    if (!f) return hypre_set_error(HYPRE_ERROR_ARG, std::string("cannot open ") + filename);
@@ -1062,6 +1075,7 @@ static HYPRE_Int krylov_solve(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_ParVec
 {
    HY_NEED_DEVICE;
    HY_TRY
+   set_stage("Krylov solve");
    HDA_REQUIRE(A && A->assembled, "Krylov solve needs an assembled matrix");
    x->ensure_device();
    size_t veclen = std::max(g_precond_veclen, precond_veclen(s));
@@ -1243,6 +1257,7 @@ extern "C" HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, 
 {
    HY_NEED_DEVICE;
    HY_TRY
+   set_stage("preconditioner setup (HYPRE_BoomerAMGSetup)");
    HDA_REQUIRE(s && s->kind == HDA_SOLVER_AMG, "BoomerAMGSetup: not a BoomerAMG handle");
    HDA_REQUIRE(A && A->assembled, "BoomerAMGSetup needs an assembled matrix");
    // features of the reference's parameter surface that this build does not implement

@@ -12,6 +12,7 @@
 
 #include "hda_hypre.h"
 #include "hda_yaml.h"
+#include "hda_mpi_join.h"
 
 #include <sys/stat.h>
 #include <unistd.h>
@@ -96,7 +97,7 @@ extern "C" void HYPREDRV_ErrorCodeDescribe(uint32_t code)
 }
 extern "C" void HYPREDRV_ErrorCodeClear(void) { err_reset(); }
 extern "C" uint32_t HYPREDRV_ErrorInvalidValue(const char *message) { return err_set(ERR_INVALID_VAL, message ? message : ""); }
-extern "C" void HYPREDRV_SafeCallHandleError(uint32_t code, MPI_Comm, const char *file, int line, const char *func)
+extern "C" void HYPREDRV_SafeCallHandleError(uint32_t code, MPI_Comm comm, const char *file, int line, const char *func)
 {
    if (!code) return;
    fprintf(stderr, "At %s:%d in %s():\n", file, line, func);
@@ -104,7 +105,9 @@ extern "C" void HYPREDRV_SafeCallHandleError(uint32_t code, MPI_Comm, const char
    const char *dbg = getenv("HYPREDRV_DEBUG");
    if (dbg && !strcmp(dbg, "1")) raise(SIGTRAP);
    fflush(nullptr);
-   _exit((int)(code & 0x7F) ? (int)(code & 0x7F) : 1); // the reference calls MPI_Abort
+   const int status = (int)(code & 0x7F) ? (int)(code & 0x7F) : 1;
+   mpi_abort((int)comm, status); // the reference calls MPI_Abort (include/HYPREDRV_utils.h:50-80): the peers of a failed rank end with it
+   _exit(status);
 }
 
 // -------------------------------------------------------------------- stats
@@ -295,6 +298,7 @@ extern "C" uint32_t HYPREDRV_Finalize(void)
 {
    if (g_initialized)
    {
+      mpi_leave(); // ranks joined through an MPI communicator hand back the duplicate while MPI is alive
       HYPRE_Finalize();
       g_initialized = false;
    }
@@ -320,6 +324,7 @@ extern "C" uint32_t HYPREDRV_AMD_CommInit(int rank, int world, int device, const
    if (device >= 0) HDA_HIP(hipSetDevice(device));
    // HDA_FORCE_RCCL: build a 1-rank RCCL communicator too (transport self-test on a single GPU)
    if (world > 1 || getenv("HDA_FORCE_RCCL")) Comm::set_world(make_rccl_comm(rank, world, uid));
+   Comm::set_explicitly_joined(true);
    API_CATCH
 }
 extern "C" uint32_t HYPREDRV_AMD_CommInitCallbacks(int rank, int world, int device, HYPREDRV_AMD_AllreduceFn ar, HYPREDRV_AMD_AlltoallvFn a2a)
@@ -328,11 +333,13 @@ extern "C" uint32_t HYPREDRV_AMD_CommInitCallbacks(int rank, int world, int devi
    API_TRY
    if (device >= 0 && hipSetDevice(device) != hipSuccess) (void)hipGetLastError();
    if (world > 1) Comm::set_world(make_callback_comm(rank, world, ar, a2a));
+   Comm::set_explicitly_joined(true);
    API_CATCH
 }
 extern "C" uint32_t HYPREDRV_AMD_CommFinalize(void)
 {
    Comm::set_world(make_self_comm());
+   Comm::set_explicitly_joined(false);
    return HYPREDRV_SUCCESS;
 }
 
@@ -340,6 +347,21 @@ extern "C" uint32_t HYPREDRV_Create(MPI_Comm comm, HYPREDRV_t *out)
 {
    if (!g_initialized) return err_set(ERR_HYPREDRV_NOT_INITIALIZED);
    if (!out) return err_set(ERR_UNKNOWN_HYPREDRV_OBJ);
+   // an MPI program hands its communicator over here (reference: rank and size come from it, src/HYPREDRV.c:1014-1041): unless the
+   // launcher has joined the ranks itself (HYPREDRV_AMD_CommInit*), they are joined now -- RCCL with one GPU per rank, the
+   // host-staged transport over MPI for ranks that share one (hda_mpi.cpp)
+   try
+   {
+      mpi_autojoin((int)comm);
+      int cr = 0, cs = 1;
+      if (mpi_comm_size((int)comm, &cr, &cs) && cs != Comm::world().size && (mpi_joined() || Comm::explicitly_joined()))
+         return err_set(ERR_UNKNOWN, "HYPREDRV_Create: the communicator has " + std::to_string(cs) + " ranks but the library is joined on " +
+                                        std::to_string(Comm::world().size) + " (one communicator per process; HYPREDRV_Finalize leaves it)");
+   }
+   catch (const std::exception &e)
+   {
+      return err_set(ERR_UNKNOWN, std::string("HYPREDRV_Create: joining the MPI ranks failed: ") + e.what());
+   }
    auto *h      = new hypredrv_struct();
    h->comm      = comm;
    h->mypid     = Comm::world().rank;
@@ -2141,6 +2163,7 @@ extern "C" uint32_t HYPREDRV_LinearSolverSetup(HYPREDRV_t h)
    CHECK_INIT_OBJ(h);
    err_reset();
    API_TRY
+   set_stage("HYPREDRV_LinearSolverSetup");
    if (!h->solver) return err_set(ERR_INVALID_SOLVER, "LinearSolverSetup: solver is NULL (call LinearSolverCreate)");
    if (!h->mat_A || !h->vec_b || !h->vec_x) return err_set(ERR_UNKNOWN, "LinearSolverSetup: matrix, rhs or solution vector is missing");
    h->stats.next_entry_if_used();
@@ -2199,6 +2222,7 @@ extern "C" uint32_t HYPREDRV_LinearSolverApply(HYPREDRV_t h)
    CHECK_INIT_OBJ(h);
    err_reset();
    API_TRY
+   set_stage("HYPREDRV_LinearSolverApply");
    if (!h->solver) return err_set(ERR_INVALID_SOLVER, "LinearSolverApply: solver is NULL");
    if (h->args.precon().method != 99 && (!h->precon || !h->precon_is_setup))
       return err_set(ERR_INVALID_PRECON, "Linear solver apply requires a successfully set up preconditioner; check the preceding setup error");

@@ -10,6 +10,8 @@
 #include "hda_sort.h"
 
 #include "hda_dist.h"
+#include "hda_mpi_join.h"
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -41,6 +43,55 @@ Context::Context()
    HDA_HIP(hipMemset(scalars, 0, sizeof(double) * kNumScalars));
    HDA_HIP(hipHostMalloc((void **)&host_scalars, sizeof(double) * kNumScalars, hipHostMallocDefault));
    HDA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+}
+
+// ---- host waits with an optional limit (hda_common.h)
+namespace {
+const char *g_stage_name = "idle";
+template <class Query>
+void wait_limited(Query done, const char *what)
+{
+   const double lim = wait_limit_s();
+   const auto   t0  = std::chrono::steady_clock::now();
+   for (long spin = 0;; spin++)
+   {
+      hipError_t e = done();
+      if (e == hipSuccess) return;
+      if (e != hipErrorNotReady) HDA_HIP(e);
+      (void)hipGetLastError();
+      if (spin > 2000) usleep(20);
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > lim)
+      {
+         fprintf(stderr, "[hypredrv_amd] rank %d of %d (%s transport): a %s wait did not end within %.1f s (HDA_COMM_TIMEOUT_S) during %s: a peer "
+                         "rank has failed or left the collective sequence, or a kernel hangs; ending the job\n", Comm::world().rank, Comm::world().size,
+                 Comm::world().name(), what, lim, g_stage_name);
+         abort_job(86);
+      }
+   }
+}
+} // namespace
+double wait_limit_s()
+{
+   static const double t = [] { const char *e = getenv("HDA_COMM_TIMEOUT_S"); return e ? atof(e) : 0.0; }();
+   return t;
+}
+void set_stage(const char *stage) { g_stage_name = stage; }
+const char *current_stage() { return g_stage_name; }
+void wait_stream(hipStream_t s)
+{
+   if (wait_limit_s() <= 0.0) { HDA_HIP(hipStreamSynchronize(s)); return; }
+   wait_limited([s] { return hipStreamQuery(s); }, "stream");
+}
+void wait_event(hipEvent_t e)
+{
+   if (wait_limit_s() <= 0.0) { HDA_HIP(hipEventSynchronize(e)); return; }
+   wait_limited([e] { return hipEventQuery(e); }, "event");
+}
+void abort_job(int status)
+{
+   fflush(nullptr);
+   mpi_abort(0x44000000 /* MPI_COMM_WORLD of the MPICH ABI; the joined duplicate is used when there is one */, status);
+   _exit(status);
 }
 
 // ---- process-global state with a private copy per thread rank (hda_common.h)

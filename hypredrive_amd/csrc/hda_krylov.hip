@@ -94,7 +94,7 @@ static KrylovResult pcg_single_reduction(const LinOp &op, const PrecondFn &M, co
    spmv_dot(A, u.data(), w.data(), u.data(), 4, op.halo);
    finalize_n(2, 3, T0);
    read_scalars_async(T0, 3);
-   HDA_HIP(hipEventSynchronize(ctx.ev));
+   wait_event(ctx.ev);
    double i_prod = ctx.host_scalars[T0 + 1];
    res.hist.push_back(std::sqrt(std::fabs(i_prod)));
    int it = 0;
@@ -118,7 +118,7 @@ static KrylovResult pcg_single_reduction(const LinOp &op, const PrecondFn &M, co
       {
          finalize(3, tnext + 1);
          read_scalars_async(tnext, 3);
-         HDA_HIP(hipEventSynchronize(ctx.ev));
+         wait_event(ctx.ev);
          i_prod = ctx.host_scalars[tnext + 1];
          if (i_prod / bi_prod < eps)
          {
@@ -131,7 +131,7 @@ static KrylovResult pcg_single_reduction(const LinOp &op, const PrecondFn &M, co
       spmv_dot(A, u.data(), w.data(), u.data(), 4, op.halo);
       finalize_n(2, 3, tnext); // <r,u>, <r,r>, <w,u>: one kernel, ONE all-reduce of three doubles
       read_scalars_async(tnext, 3);
-      HDA_HIP(hipEventSynchronize(ctx.ev));
+      wait_event(ctx.ev);
       i_prod = ctx.host_scalars[tnext + 1];
       res.hist.push_back(std::sqrt(std::fabs(i_prod)));
       if (kp.print_level >= 2)
@@ -231,7 +231,7 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
    dot(n, r.data(), r.data(), 3);
    finalize_n(2, 2, S_GAMMA0); // <r,z> -> S_GAMMA0, <r,r> -> S_RR0: one kernel, one all-reduce of two doubles
    read_scalars_async(S_GAMMA0, 5);
-   HDA_HIP(hipEventSynchronize(ctx.ev));
+   wait_event(ctx.ev);
    double i_prod = kp.two_norm ? ctx.host_scalars[S_RR0] : ctx.host_scalars[S_GAMMA0];
    res.hist.push_back(std::sqrt(std::fabs(i_prod)));
    int it = 0;
@@ -267,7 +267,7 @@ KrylovResult pcg(const LinOp &op, const PrecondFn &M, const KrylovParams &kp, co
       // instead of 3).
       bool stop = false;
       auto test = [&]() {
-         HDA_HIP(hipEventSynchronize(ctx.ev));
+         wait_event(ctx.ev);
          const double sp = ctx.host_scalars[S_SP];
          if (sp == 0.0 || !std::isfinite(sp))
          {
@@ -426,7 +426,7 @@ static KrylovResult gmres_core(bool flexible, const LinOp &op, const PrecondFn &
          finalize(0, S_GMRES + i);
          scale_inv_sqrt_dev(n, S_GMRES + i, V[i].data());
          read_scalars_async(S_GMRES, i + 1);
-         HDA_HIP(hipEventSynchronize(ctx.ev));
+         wait_event(ctx.ev);
          for (int j = 0; j < i; j++) H[(size_t)j * k + (i - 1)] = ctx.host_scalars[S_GMRES + j];
          H[(size_t)i * k + (i - 1)] = std::sqrt(ctx.host_scalars[S_GMRES + i]);
          for (int j = 1; j < i; j++)
