@@ -47,7 +47,7 @@ orc_amg_default_params(orc_amg_params *p, int gpu_defaults)
    p->num_functions   = 1;
    p->agg_num_levels = 0; p->agg_num_paths = 1; p->agg_interp_type = 4; /* amg.c:164-171 */
    p->agg_pmax = 0; p->agg_trunc_factor = 0.0;
-   p->blocks = 1; p->block_part = NULL;
+   p->blocks = 1; p->block_part = NULL; p->pmis_rng = 0;
 }
 
 /* src/internal/pcg.c:15-25, src/internal/gmres.c:16-27 */
@@ -596,14 +596,69 @@ strong_transpose(const orc_csr *A, const unsigned char *smask, int **tp_out, int
 
 /* hypre_BoomerAMGCoarsenPMIS (coarsen type 8, src/internal/amg.c:303-308), SURVEY App. A.5,
  * written as synchronous rounds so a data-parallel implementation gives the same split. */
+/* hypre's own tie-break stream (hypre_BoomerAMGIndepSetInit with seq_rand 0): every rank seeds hypre_Rand --
+ * the Park-Miller minimal standard generator, seed <- 16807 * seed mod (2^31 - 1), value seed / (2^31 - 1) -- with 2747 + rank and
+ * draws once per local row in row order, on every level anew.  Row blocks are the ranks (orc_amg_params.blocks).  PARITY: this is
+ * the published generator and the upstream convention as SURVEY records it; hypre is not in the reference tree, so whether it
+ * reproduces a checked-in hierarchy is an experiment (tests/test_oracle_pins.py). */
+static int pmis_stream_rank_offset = 1; /* experiment switch (tools/pmis_rng_experiment.py): 0 = every rank seeded 2747 */
+void orc_pmis_stream_rank_offset(int on) { pmis_stream_rank_offset = on; }
+void
+orc_pmis_hypre_stream(int n, int nb, const int64_t *part, double *rnd)
+{
+   const int64_t one[2] = {0, n};
+   if (nb <= 1 || !part) { nb = 1; part = one; }
+   for (int q = 0; q < nb; q++)
+   {
+      int64_t seed = 2747 + (pmis_stream_rank_offset ? q : 0);
+      for (int64_t i = part[q]; i < part[q + 1]; i++)
+      {
+         seed = (16807 * seed) % 2147483647LL;
+         rnd[i] = (double)seed / 2147483647.0;
+      }
+   }
+}
+
+static void pmis_core(const orc_csr *A, const unsigned char *smask, const double *rnd, int *cf);
+
 void
 orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
          int64_t row_offset, int *cf)
+{
+   const int n   = A->nrows;
+   double   *rnd = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+   for (int i = 0; i < n; i++) rnd[i] = pmis_rand(seed, level, row_offset + i);
+   pmis_core(A, smask, rnd, cf);
+   free(rnd);
+}
+
+/* the same with caller-supplied tie-break values in [0, 1) */
+void
+orc_pmis_weights(const orc_csr *A, const unsigned char *smask, const double *rnd, int *cf)
+{
+   pmis_core(A, smask, rnd, cf);
+}
+
+/* nb > 1 with part: hypre's PARALLEL rounds on nb ranks (= row blocks).  A rank learns that a remote point became F one round late:
+ * the C/F markers of the ghost points are exchanged right after the independent set is picked and before the F points of the round
+ * are set, and a ghost's measure is zeroed only on a non-zero marker -- so in the following round's independent-set pass a local
+ * row still sees such a ghost column with its full measure and is kept out of the set by it when the ghost's measure is larger
+ * (upstream behaviour of hypre_BoomerAMGCoarsenPMIS / hypre_BoomerAMGIndepSet).  nb <= 1: the global rounds. */
+static void
+pmis_core_ranks(const orc_csr *A, const unsigned char *smask, const double *rnd, int *cf, int nb, const int64_t *part)
 {
    int     n = A->nrows;
    int    *tp, *tj;
    double *meas = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
    char   *newc = (char *)malloc((size_t)(n > 0 ? n : 1));
+   int    *blk = NULL, *fround = NULL;
+   if (nb > 1 && part)
+   {
+      blk    = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+      fround = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+      for (int q = 0; q < nb; q++)
+         for (int64_t i = part[q]; i < part[q + 1]; i++) { blk[i] = q; fround[i] = -2; }
+   }
    strong_transpose(A, smask, &tp, &tj);
    int undecided = 0;
    for (int i = 0; i < n; i++)
@@ -611,7 +666,7 @@ orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
       int ns = 0;
       for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) ns += smask[k];
       int nt  = tp[i + 1] - tp[i];
-      meas[i] = (double)nt + pmis_rand(seed, level, row_offset + i);
+      meas[i] = (double)nt + rnd[i];
       if (ns == 0)
          cf[i] = ORC_SF_PT; /* no strong dependence: special F, never interpolated */
       else if (nt == 0)
@@ -622,7 +677,7 @@ orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
          undecided++;
       }
    }
-   while (undecided > 0)
+   for (int round = 0; undecided > 0; round++)
    {
       for (int i = 0; i < n; i++)
       {
@@ -633,7 +688,10 @@ orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
          for (int k = A->rowptr[i]; k < A->rowptr[i + 1] && is_max; k++)
          {
             int j = A->col[k];
-            if (!smask[k] || cf[j] != 0) continue;
+            if (!smask[k]) continue;
+            /* a column counts while it is undecided -- or, on another rank, while this rank has not yet heard that it became F */
+            const int stale = blk && blk[j] != blk[i] && cf[j] == ORC_F_PT && fround[j] == round - 1;
+            if (cf[j] != 0 && !stale) continue;
             if (meas[j] > mi || (meas[j] == mi && j > i)) is_max = 0;
          }
          for (int k = tp[i]; k < tp[i + 1] && is_max; k++)
@@ -657,6 +715,7 @@ orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
             if (smask[k] && cf[A->col[k]] == ORC_C_PT)
             {
                cf[i] = ORC_F_PT;
+               if (fround) fround[i] = round;
                undecided--;
                break;
             }
@@ -666,6 +725,13 @@ orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
    free(tj);
    free(meas);
    free(newc);
+   free(blk);
+   free(fround);
+}
+static void
+pmis_core(const orc_csr *A, const unsigned char *smask, const double *rnd, int *cf)
+{
+   pmis_core_ranks(A, smask, rnd, cf, 1, NULL);
 }
 
 /* Measure buckets as FIFO doubly-linked lists: the structure hypre's Ruge first pass
@@ -835,8 +901,18 @@ orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf)
  * every block on the block's own connections; of its result only the C points of INTERIOR rows (rows without a strong connection
  * leaving the block) are kept, every other point goes back to undecided; PMIS then starts from those C points as its first
  * independent set, with measures counted over the whole matrix.  One block: every C point of the first pass is interior. */
+static void hmis_core(const orc_csr *A, const unsigned char *smask, int nb, const int64_t *part, const double *rnd, int *cf);
 void
 orc_hmis_blocks(const orc_csr *A, const unsigned char *smask, int nb, const int64_t *part, uint64_t seed, int level, int *cf)
+{
+   const int n   = A->nrows;
+   double   *rnd = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+   for (int i = 0; i < n; i++) rnd[i] = pmis_rand(seed, level, i);
+   hmis_core(A, smask, nb, part, rnd, cf);
+   free(rnd);
+}
+static void
+hmis_core(const orc_csr *A, const unsigned char *smask, int nb, const int64_t *part, const double *rnd, int *cf)
 {
    const int     n      = A->nrows;
    const int64_t one[2] = {0, n};
@@ -869,7 +945,7 @@ orc_hmis_blocks(const orc_csr *A, const unsigned char *smask, int nb, const int6
    for (int i = 0; i < n; i++)
    {
       const int nt = tp[i + 1] - tp[i];
-      meas[i]      = (double)nt + pmis_rand(seed, level, i);
+      meas[i]      = (double)nt + rnd[i];
       if (cf[i] != 0) continue; /* special F, kept C */
       if (nt == 0) cf[i] = ORC_F_PT; /* measure < 1 */
       else undecided++;
@@ -2126,7 +2202,15 @@ orc_amg_setup_dof(const orc_csr *A0, const orc_amg_params *p, const int *dof0)
       unsigned char *sm  = (unsigned char *)malloc((size_t)(nnz > 0 ? nnz : 1));
       int           *cf  = (int *)malloc(sizeof(int) * (size_t)n);
       orc_strength_dof(A, p->strong_th, p->max_row_sum, dof, sm);
-      if (p->coarsen_type == 8)
+      if (p->pmis_rng == 1)
+      { /* hypre's per-rank Park-Miller stream, the row blocks being the ranks */
+         double *rnd = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+         orc_pmis_hypre_stream(n, h->nblk, h->bpart[lvl], rnd);
+         if (p->coarsen_type == 8) pmis_core_ranks(A, sm, rnd, cf, p->pmis_rng == 1 ? h->nblk : 1, h->bpart[lvl]);
+         else hmis_core(A, sm, h->nblk, h->bpart[lvl], rnd, cf);
+         free(rnd);
+      }
+      else if (p->coarsen_type == 8)
          orc_pmis(A, sm, p->seed, lvl, 0, cf);
       else
          orc_hmis_blocks(A, sm, h->nblk, h->bpart[lvl], p->seed, lvl, cf);

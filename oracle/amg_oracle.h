@@ -70,6 +70,9 @@ typedef struct {
     * row starts of level 0 (NULL: hypre's even split, start q = floor(q * n / blocks)). */
    int            blocks;
    const int64_t *block_part;
+   /* PMIS tie-break values: 0 = hash of the global row id (partition independent; the default), 1 = hypre's own stream -- per
+    * row block (= rank) Park-Miller seeded 2747 + rank, one draw per row in row order, every level anew (orc_pmis_hypre_stream) */
+   int            pmis_rng;
 } orc_amg_params;
 
 typedef struct orc_amg orc_amg; /* hierarchy handle */
@@ -122,6 +125,8 @@ void orc_strength(const orc_csr *A, double theta, double max_row_sum, unsigned c
 void orc_strength_dof(const orc_csr *A, double theta, double max_row_sum, const int *dof, unsigned char *smask);
 void orc_pmis(const orc_csr *A, const unsigned char *smask, uint64_t seed, int level,
               int64_t row_offset, int *cf); /* cf: 1 C, -1 F, -3 special F */
+void orc_pmis_weights(const orc_csr *A, const unsigned char *smask, const double *rnd, int *cf); /* caller's tie-break values */
+void orc_pmis_hypre_stream(int n, int nb, const int64_t *part, double *rnd);                      /* hypre_Rand seeded 2747 + rank */
 void orc_rs_first_pass(const orc_csr *A, const unsigned char *smask, int *cf);
 /* the row-block forms (see orc_amg_params.blocks); part = nb+1 ascending row starts */
 void orc_hmis_blocks(const orc_csr *A, const unsigned char *smask, int nb, const int64_t *part, uint64_t seed, int level, int *cf);

@@ -31,7 +31,7 @@ class AmgParams(C.Structure):
                 ("cheby_fraction", C.c_double),
                 ("agg_num_levels", C.c_int), ("agg_num_paths", C.c_int), ("agg_interp_type", C.c_int),
                 ("agg_pmax", C.c_int), ("agg_trunc_factor", C.c_double),
-                ("blocks", C.c_int), ("block_part", C.POINTER(C.c_int64))]
+                ("blocks", C.c_int), ("block_part", C.POINTER(C.c_int64)), ("pmis_rng", C.c_int)]
 
 
 class KrylovParams(C.Structure):
@@ -340,6 +340,28 @@ def pmis(A, smask, seed=2747, level=0, row_offset=0):
     lib().orc_pmis(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), seed, level, row_offset,
                    cf.ctypes.data_as(C.POINTER(C.c_int)))
     return cf
+
+
+def pmis_weights(A, smask, rnd):
+    """PMIS with the caller's tie-break values in [0, 1)."""
+    cf = np.zeros(A.nrows, dtype=np.int32)
+    sm = np.ascontiguousarray(smask, dtype=np.uint8)
+    r = np.ascontiguousarray(rnd, dtype=np.float64)
+    lib().orc_pmis_weights.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib().orc_pmis_weights(A.ptr, sm.ctypes.data_as(C.POINTER(C.c_ubyte)), _dp(r), cf.ctypes.data_as(C.POINTER(C.c_int)))
+    return cf
+
+
+def pmis_hypre_stream(n, part=None):
+    """hypre_Rand seeded 2747 + rank, one draw per row of every row block (orc_pmis_hypre_stream)."""
+    out = np.zeros(max(n, 1))
+    lib().orc_pmis_hypre_stream.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    if part is None:
+        lib().orc_pmis_hypre_stream(n, 1, None, _dp(out))
+    else:
+        keep, ptr = _bpart(part)
+        lib().orc_pmis_hypre_stream(n, len(keep) - 1, ptr, _dp(out))
+    return out[:n]
 
 
 def rs_first_pass(A, smask):

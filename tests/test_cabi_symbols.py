@@ -60,7 +60,9 @@ def test_param_struct_layout_matches_oracle(orc):
     # the aggressive-coarsening fields close both structs (AMGagg_args defaults of src/internal/amg.c:164-171: 0 levels, 1 path, multipass)
     # ... then the row blocks (the reference at np = V); the product's struct ends with its own size, which hda_amg_create checks
     tail = ["agg_num_levels", "agg_num_paths", "agg_interp_type", "agg_pmax", "agg_trunc_factor", "blocks", "block_part"]
-    assert every[len(shared):] == tail == [n for (n, _t) in h.AmgParams._fields_][-8:-1]
+    # (the oracle alone ends with pmis_rng: hypre's own tie-break stream, an oracle-side experiment -- tests/test_oracle_pins.py)
+    assert every[len(shared):] == tail + ["pmis_rng"] and tail == [n for (n, _t) in h.AmgParams._fields_][-8:-1]
+    assert op.pmis_rng == 0
     assert h.AmgParams._fields_[-1][0] == "struct_size" and hp.struct_size == C.sizeof(h.AmgParams)
     for name in tail[:-1]:
         assert getattr(hp, name) == getattr(op, name), name

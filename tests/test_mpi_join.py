@@ -134,3 +134,27 @@ def test_reference_laplacian_driver_on_four_mpi_ranks():
         assert one.returncode == 0 and r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         a, b = re.findall(ROW, one.stdout, re.M), re.findall(ROW, r.stdout, re.M)
         assert a[0][4] == b[0][4] and abs(int(a[0][6]) - int(b[0][6])) <= 1 and float(b[0][5]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_cli_under_mpiexec_on_the_four_part_files():
+    """The reference's own multi-rank CLI launch (cmake/HYPREDRV_Testing.cmake:938 "ex2_4proc": mpiexec -n 4 hypredrive <ex2.yml>,
+    four ranks reading the four part files of data/ps3d10pt7/np4).  ex2.yml's FSAI smoother is outside SURVEY §8 (refused by name),
+    so the input is ex2-hl1gs.yml = ex2.yml without it, pointed at the np4 files: same rows / nonzeros / r0 as refOutput/ex2.txt,
+    and the iteration count of the same input on one rank +-1."""
+    cli = os.path.join(ROOT, "hypredrive_amd", "bin", "hypredrive-cli")
+    _need(cli)
+    args = ["-q", "examples/ex2-hl1gs.yml", "-a", "--linear_system:matrix_filename", "data/ps3d10pt7/np4/IJ.out.A",
+            "--linear_system:rhs_filename", "data/ps3d10pt7/np4/IJ.out.b"]
+    one = subprocess.run([cli] + args, capture_output=True, text=True, cwd=ROOT)
+    assert one.returncode == 0, one.stdout + one.stderr
+    r = _mpirun(4, [cli] + args, env={"HDA_MPI_VERBOSE": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stderr.count("joined through the MPI communicator") == 4
+    pat = r"^\|\s+0 \|\s+[\d.]* \|\s+[\d.]+ \|\s+[\d.]+ \|\s+(\S+) \|\s+(\S+) \|\s+(\d+) \|"
+    a, b = re.search(pat, one.stdout, re.M), re.search(pat, r.stdout, re.M)
+    assert a and b, r.stdout
+    assert len(re.findall(pat, r.stdout, re.M)) == 1                      # the table is printed once, by rank 0
+    assert b.group(1) == a.group(1) == "3.16e+01"                         # ||b|| = sqrt(1000): every part was read exactly once
+    assert abs(int(a.group(3)) - int(b.group(3))) <= 1 and float(b.group(2)) < 1e-6
+    assert "Solving linear system #0 with 1000 rows and 6400 nonzeros" in r.stdout
