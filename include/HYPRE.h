@@ -333,6 +333,39 @@ HYPRE_Int HYPRE_BoomerAMGGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE
 HYPRE_Int HYPRE_BoomerAMGGetNumLevels(HYPRE_Solver solver, HYPRE_Int *num_levels);
 HYPRE_Int HYPRE_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);
 
+/* ---- the rest of the names the reference files of SURVEY 8(a) call (round 5), so that an unmodified libHYPREDRV links as it is.
+ * FSAI parameter setters (src/internal/amg.c:924-932 calls them for every BoomerAMG): accepted, nothing recorded -- choosing the FSAI
+ * smoother itself (HYPRE_BoomerAMGSetSmoothType 4) is refused by HYPRE_BoomerAMGSetup. */
+HYPRE_Int HYPRE_BoomerAMGSetFSAIAlgoType(HYPRE_Solver solver, HYPRE_Int v);
+HYPRE_Int HYPRE_BoomerAMGSetFSAILocalSolveType(HYPRE_Solver solver, HYPRE_Int v);
+HYPRE_Int HYPRE_BoomerAMGSetFSAIMaxSteps(HYPRE_Solver solver, HYPRE_Int v);
+HYPRE_Int HYPRE_BoomerAMGSetFSAIMaxStepSize(HYPRE_Solver solver, HYPRE_Int v);
+HYPRE_Int HYPRE_BoomerAMGSetFSAIMaxNnzRow(HYPRE_Solver solver, HYPRE_Int v);
+HYPRE_Int HYPRE_BoomerAMGSetFSAINumLevels(HYPRE_Solver solver, HYPRE_Int v);
+HYPRE_Int HYPRE_BoomerAMGSetFSAIThreshold(HYPRE_Solver solver, HYPRE_Real v);
+HYPRE_Int HYPRE_BoomerAMGSetFSAIEigMaxIters(HYPRE_Solver solver, HYPRE_Int v);
+HYPRE_Int HYPRE_BoomerAMGSetFSAIKapTolerance(HYPRE_Solver solver, HYPRE_Real v);
+/* REFUSED BY NAME (outside SURVEY 8): each sets hypre's error flag with a message and returns non-zero.  amg.c:988-1032
+ * (relaxation.points, coarsening.nodal + rigid-body modes), gmres.c:86-98 (reference-solution tracking), precon.c:138-154 (destroy
+ * entries of preconditioners this library never creates: NULL is accepted). */
+HYPRE_Int HYPRE_BoomerAMGSetGridRelaxPoints(HYPRE_Solver solver, HYPRE_Int **grid_relax_points);
+HYPRE_Int HYPRE_BoomerAMGSetNodal(HYPRE_Solver solver, HYPRE_Int nodal);
+HYPRE_Int HYPRE_BoomerAMGSetNodalDiag(HYPRE_Solver solver, HYPRE_Int nodal_diag);
+HYPRE_Int HYPRE_BoomerAMGSetInterpVecVariant(HYPRE_Solver solver, HYPRE_Int var);
+HYPRE_Int HYPRE_BoomerAMGSetInterpVecQMax(HYPRE_Solver solver, HYPRE_Int q_max);
+HYPRE_Int HYPRE_BoomerAMGSetSmoothInterpVectors(HYPRE_Solver solver, HYPRE_Int smooth);
+HYPRE_Int HYPRE_BoomerAMGSetInterpVectors(HYPRE_Solver solver, HYPRE_Int num_vectors, HYPRE_ParVector *interp_vectors);
+HYPRE_Int HYPRE_ParCSRGMRESSetRefSolution(HYPRE_Solver solver, HYPRE_ParVector xref);
+HYPRE_Int HYPRE_FSAIDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_AMSDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_ADSDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_SchwarzDestroy(HYPRE_Solver solver);
+/* amg.c:557, precon.c:770-783: a ParVector is this library's IJ vector; partitioning = {first row, one past the last} of the
+ * calling rank, NULL = hypre's even split */
+HYPRE_Int HYPRE_ParVectorCreate(MPI_Comm comm, HYPRE_BigInt global_size, HYPRE_BigInt *partitioning, HYPRE_ParVector *vector);
+HYPRE_Int HYPRE_ParVectorInitialize(HYPRE_ParVector vector);
+HYPRE_Int HYPRE_ParVectorDestroy(HYPRE_ParVector vector);
+
 #ifdef __cplusplus
 }
 #endif
