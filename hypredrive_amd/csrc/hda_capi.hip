@@ -302,6 +302,7 @@ extern "C" int hda_relax(hda_csr_t A, int relax_type, double weight, int sweeps,
    }
    HDA_HIP(hipMemcpyAsync(x, cur, sizeof(double) * (size_t)m.nrows, hipMemcpyDeviceToHost, Context::get().stream));
    Context::get().sync();
+   gs_free_check(); // (an aborted barrier-free sweep is reported by the call that ran it, not by a later solve)
    HDA_CATCH
 }
 
@@ -337,6 +338,7 @@ extern "C" int hda_relax_blocks(hda_csr_t A, int relax_type, double weight, int 
    }
    HDA_HIP(hipMemcpyAsync(x, cur, sizeof(double) * (size_t)m.nrows, hipMemcpyDeviceToHost, Context::get().stream));
    Context::get().sync();
+   gs_free_check();
    HDA_CATCH
 }
 
@@ -772,6 +774,7 @@ extern "C" int hda_amg_vcycle(hda_amg_t h, const double *b, double *x)
       db.upload(b, (size_t)m.nrows);
       h->mgr->solve(db.data(), dx.data(), true);
       dx.download(x, (size_t)m.nrows);
+      gs_free_check();
       return HDA_OK;
    }
    if (h->ilu)
@@ -781,6 +784,7 @@ extern "C" int hda_amg_vcycle(hda_amg_t h, const double *b, double *x)
       db.upload(b, (size_t)m.nrows);
       ilu_solve(*h->ilu, m, nullptr, db.data(), dx.data(), true, h->ilu_r, h->ilu_c);
       dx.download(x, (size_t)m.nrows);
+      gs_free_check();
       return HDA_OK;
    }
    const int      n = h->amg->level_A(0).nrows;
@@ -788,6 +792,7 @@ extern "C" int hda_amg_vcycle(hda_amg_t h, const double *b, double *x)
    db.upload(b, (size_t)n);
    h->amg->apply(db.data(), dx.data(), -1);
    dx.download(x, (size_t)n);
+   gs_free_check();
    HDA_CATCH
 }
 

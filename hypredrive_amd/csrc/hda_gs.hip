@@ -13,6 +13,7 @@
 #include "hda_amg.h"
 
 #include <algorithm>
+#include <mutex>
 
 namespace hda {
 
@@ -1167,6 +1168,11 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
    const bool whole  = (ring_mask + 1) >= nb; // every value of the block has a slot of its own: nothing is ever overwritten, no guard
    int        KG     = 8;
    while (KG > 1 && KG * G > (ring_mask + 1) - W - G - 1) KG >>= 1;
+   if (!whole && KG * G > (ring_mask + 1) - W - G - 1)
+   { // the plan broke the guard's invariant (gs_free_plan sizes the ring for it): say so instead of waiting for a progress nobody can make
+      if (tid == 0) atomicMax(err, 3);
+      return;
+   }
    // A row goes through four stages in four consecutive rounds, so that nothing the sweep does not produce is waited for when the row's
    // turn comes: A its chunk range (three rounds ahead), B its chunks, divisor, right-hand side and own old value (two ahead), X the
    // values that do not depend on the sweep -- other blocks' columns, columns later in the sweep (one ahead) --, C the wait for its
@@ -1382,6 +1388,12 @@ static void gs_free_plan(const GsPlan &plan, int n)
    const int maxc = (h[1] > 64 || (h[1] >= maxc2_from && maxblock >= 2048)) ? 2 : 1;
    int       lpr  = 1;
    while (lpr * maxc < h[1]) lpr <<= 1;
+   // the ring's guard (k_gs_blocks_free stage C): round 0 can start only if G = 512 / lpr groups fit twice into what the guard leaves
+   // free, G <= RING - RING / 4 - G - 1 -- with one lane per row (rows of <= 4 off-diagonal entries: a 2-D five-point or tridiagonal
+   // operator on blocks of more than 16384 rows) that needs 2048 slots where 1024 cover the reach (round-4 ADVICE: every wavefront
+   // waited for a progress nobody could make, and the sweep ended in its spin limit)
+   if (!(maxblock > 0 && maxblock <= 16384))
+      while (lpr <= 64 && ring <= 16384 && 2 * (512 / lpr) > ring - ring / 4 - 1) ring <<= 1;
    if (ring > 16384 || lpr > 64)
    {
       if (getenv("HDA_VERBOSE"))
@@ -1395,14 +1407,16 @@ static void gs_free_plan(const GsPlan &plan, int n)
       fprintf(stderr, "[hda] block Gauss-Seidel plan: barrier-free kernel, dependency reach %d positions, largest block %d rows (ring %d), %d lanes per row, %d chunks per lane\n",
               h[0], maxblock, ring, lpr, maxc);
 }
-static int *g_free_err = nullptr;
+static int           *g_free_err = nullptr;
+static std::once_flag g_free_err_once;
 static int *gs_free_error_flag()
-{
-   if (!g_free_err)
-   {
-      HDA_HIP(hipMalloc((void **)&g_free_err, sizeof(int)));
-      HDA_HIP(hipMemset(g_free_err, 0, sizeof(int)));
-   }
+{ // (one flag per process, shared by the rank threads of the test seam: allocated once, under a lock)
+   std::call_once(g_free_err_once, [] {
+      int *p = nullptr;
+      HDA_HIP(hipMalloc((void **)&p, sizeof(int)));
+      HDA_HIP(hipMemset(p, 0, sizeof(int)));
+      g_free_err = p;
+   });
    return g_free_err;
 }
 // did a barrier-free sweep run into its spin limit since the last look?  (one 4-byte read-back; the callers are at a host sync anyway)

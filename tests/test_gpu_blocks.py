@@ -109,6 +109,35 @@ def test_block_gauss_seidel_on_long_rows(orc, hd, monkeypatch, kind):
             assert rel(Ah.relax_blocks(b, x0, part, rtype, 1.0), xo) < 1e-12, (n, rtype)
 
 
+@pytest.mark.parametrize("case", ["five_point_200x600", "tridiagonal"])
+def test_block_gauss_seidel_short_rows_on_blocks_beyond_16384_rows(orc, hd, monkeypatch, case):
+    """Round-4 ADVICE (high): rows of <= 4 off-diagonal entries get one lane each -- G = 512 groups -- and on blocks of more than
+    16 384 rows the ring was sized for the dependency reach alone (1024 slots), which broke the guard's invariant
+    KG G <= RING - RING / 4 - G - 1: round 0 waited for a progress nobody could make and the sweep ended in its spin limit.  The plan
+    now grows the ring (2048 for one lane per row), the kernel asserts the invariant, and the sweep equals the oracle's."""
+    monkeypatch.setenv("HDA_GS_SORTED_MIN", "0")
+    monkeypatch.setenv("HDA_GS_FREE_CHECK", "1")
+    if case == "tridiagonal":
+        n = 70000
+        M = sp.diags([-np.ones(n - 1), 2.5 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]).tocsr()
+        parts = [np.array([0, n]), np.array([0, 20000, 50000, n])]
+    else:
+        nx, ny = 200, 600
+        T = lambda m: sp.diags([-np.ones(m - 1), 2.0 * np.ones(m), -np.ones(m - 1)], [-1, 0, 1])
+        M = (sp.kron(sp.eye(ny), T(nx)) + sp.kron(T(ny), sp.eye(nx))).tocsr()
+        n = nx * ny
+        parts = [np.array([0, n]), np.array([0, 40000, 80000, n])]
+    Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+    rng = np.random.default_rng(5)
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    for part in parts:
+        assert np.diff(part).max() > 16384
+        l1 = orc.l1_norms_blocks(Ao, 4, part)
+        for rtype in (13, 14):
+            xo = orc.relax_blocks(Ao, l1, rtype, 1.0, b, x0, part)
+            assert rel(Ah.relax_blocks(b, x0, part, rtype, 1.0), xo) < 1e-12, (case, list(part), rtype)
+
+
 def test_one_block_is_the_sequential_sweep(orc, hd):
     M = mmatrix(800, 0.01, 21)
     Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
