@@ -141,6 +141,45 @@ def test_pcg_kernel_fusions_are_bitwise_neutral(hd, monkeypatch, sweeps):
         assert r["iters"] == ref["iters"] and np.array_equal(r["hist"], ref["hist"]) and np.array_equal(r["x"], ref["x"]), k
 
 
+@pytest.mark.parametrize("case", ["lap7_40", "lap7_24_nofirst", "aniso_48x30x20", "theta_0.6", "relax_7"])
+def test_cycle_tail_is_bitwise_neutral(hd, monkeypatch, case):
+    """Round 5: the coarse levels of the cycle -- residual, restriction + first sweep, dense coarse solve, prolongation, Jacobi sweep on
+    every level whose operators fit one workgroup -- run in ONE launch (k_cycle_tail, HDA_TAIL_NNZ entries per operator).  Every row sum
+    is formed as the lane-group kernel forms it, so V-cycles, PCG iterates, histories and iteration counts are bit-identical with the
+    tail kernel off (HDA_TAIL=0), with a small cap (fewer levels inside) and with every coarse level inside."""
+    kw = {}
+    shape = (40, 40, 40)
+    c = (1.0, 1.0, 1.0)
+    if case == "lap7_24_nofirst":
+        shape = (24, 24, 24)
+        monkeypatch.setenv("HDA_FUSE_FIRST_SWEEP", "0")   # level T's first sweep is then made inside the tail kernel
+    elif case == "aniso_48x30x20":
+        shape, c = (48, 30, 20), (1.0, 0.1, 10.0)
+    elif case == "theta_0.6":
+        kw = dict(strong_th=0.6)
+    elif case == "relax_7":
+        kw = dict(relax_down=7, relax_up=7, relax_weight=0.8)
+    A = hd.lap7(*shape, c=c)
+    n = shape[0] * shape[1] * shape[2]
+    b = np.random.default_rng(9).standard_normal(n)
+    out, lv = {}, {}
+    for tail, cap in (("0", "60000"), ("1", "2000"), ("1", "60000"), ("1", "1000000")):
+        monkeypatch.setenv("HDA_TAIL", tail)
+        monkeypatch.setenv("HDA_TAIL_NNZ", cap)
+        amg = hd.Amg(A, hd.AmgParams.default(**kw))
+        z = amg.vcycle(b)
+        r = hd.pcg(A, b, amg, hd.KrylovParams.default(False, rtol=1e-10))
+        out[(tail, cap)] = (z, r)
+        lv[(tail, cap)] = hd.load().hda_amg_tail_from(amg.h)
+    assert lv[("0", "60000")] == -1 and lv[("1", "1000000")] >= 1                 # off; on with every small level inside
+    assert lv[("1", "1000000")] <= lv[("1", "60000")] <= max(lv[("1", "2000")], lv[("1", "60000")])
+    zr, rr = out[("0", "60000")]
+    assert rr["converged"]
+    for k, (z, r) in out.items():
+        assert np.array_equal(z, zr), k
+        assert r["iters"] == rr["iters"] and np.array_equal(r["hist"], rr["hist"]) and np.array_equal(r["x"], rr["x"]), k
+
+
 @pytest.mark.parametrize("shape", [(24, 24, 24), (40, 32, 20)])
 def test_single_reduction_pcg_is_the_same_iteration(hd, monkeypatch, shape):
     """HDA_PCG_SINGLE_REDUCE=1 (opt-in): the Chronopoulos-Gear form of PCG -- <r,u>, <w,u> and <r,r> in ONE reduction per iteration,
