@@ -574,6 +574,11 @@ def single_extras(args, out, hh, A, amg, fb0, iters):
         out["cpu_defaults_rank_blocks"] = cpu_defaults_run(args, rank_grid=args.n // 32)
     if not args.no_aggressive and fits("aggressive_1", 20):
         out["aggressive_1"] = aggressive_run(args, hh)
+    # BASELINE.json configs 4 and 5 on stand-in data (tools/side_configs.py), each with its oracle iteration check at a small size
+    if not args.no_side_configs:
+        for name, need in (("gmres_amg_ilu0", 60), ("gmres_mgr", 60)):
+            if fits(name, need):
+                out[name] = side_config_run(name, hh)
     if skipped:
         out["extras_skipped"] = skipped
 
@@ -595,6 +600,19 @@ def cpu_defaults_run(args, rank_grid=None):
         need = 200 if args.n >= 200 else 40  # the oracle's serial setup at 256^3 is about a minute, its block sweeps run on the host threads
         return mod.run(args.n, steps=max(min(args.steps, 3), 1), warmup=1, oracle=(not args.no_cpu_defaults_oracle) and budget_left() >= need,
                        rank_grid=rank_grid)
+    except Exception as e:  # noqa: BLE001 - an extra must not lose the headline
+        return {"error": repr(e)[:400]}
+
+
+def side_config_run(name, hh):
+    """BASELINE.json configs[3] (GMRES + MGR, examples/ex3.yml:11-23) and configs[4] (GMRES + AMG with the ILU(0) smoother,
+    src/internal/ilu.c:15-28) through the same API path as the headline, on stand-in data (tools/side_configs.py says which and why)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("side_configs", os.path.join(ROOT, "tools", "side_configs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        return getattr(mod, name)(hh)
     except Exception as e:  # noqa: BLE001 - an extra must not lose the headline
         return {"error": repr(e)[:400]}
 
@@ -642,7 +660,7 @@ def plain_csr_child(args, window="0"):
     codings are off -- what a variable-coefficient operator of the same sparsity gets with default settings."""
     env = dict(os.environ, HDA_CODED="0", HDA_WINDOW=window)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--grid", str(args.n), "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic", "--no-cpu-defaults", "--child"]
+           "--grid", str(args.n), "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic", "--no-cpu-defaults", "--no-side-configs", "--child"]
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=max(min(300.0, budget_left()), 30.0))
     except subprocess.TimeoutExpired:
@@ -683,7 +701,7 @@ def measure_traffic(args, limit_s=240):
             # the program itself after `--`: no env / shell hop between the profiler's preloaded library and python
             cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, sub), "-o", "run", "--",
                    sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--grid", str(args.n), "--child",
-                   "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic", "--no-cpu-defaults"]
+                   "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic", "--no-cpu-defaults", "--no-side-configs"]
             left = limit_s - (time.perf_counter() - t0)
             if left < 20:
                 return None, f"counter passes exceeded {limit_s} s"
@@ -719,7 +737,7 @@ def child_bench(extra, nranks, timeout_s):
     me = os.path.abspath(__file__)
     cmd = [sys.executable, me] if nranks == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
                                                     "--master-addr", "127.0.0.1", "--master-port", str(free_port()), me]
-    cmd += ["--gpus", str(nranks), "--child", "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic", "--no-cpu-defaults"] + extra
+    cmd += ["--gpus", str(nranks), "--child", "--no-cpu-baseline", "--no-kernel-table", "--no-plain-csr", "--no-aggressive", "--no-traffic", "--no-cpu-defaults", "--no-side-configs"] + extra
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired:
@@ -826,6 +844,7 @@ def main():
     ap.add_argument("--no-aggressive", action="store_true", help="N = 1: skip the side run with one aggressive-coarsening level")
     ap.add_argument("--no-cpu-defaults", action="store_true", help="N = 1: skip the side run with the reference's CPU-build defaults (HMIS, hybrid l1 Gauss-Seidel)")
     ap.add_argument("--no-cpu-defaults-oracle", action="store_true", help="cpu_defaults without the oracle's run on the same row blocks (iters_match)")
+    ap.add_argument("--no-side-configs", action="store_true", help="N = 1: skip gmres_amg_ilu0 / gmres_mgr (BASELINE configs 5 and 4 on stand-in data)")
     ap.add_argument("--no-traffic", action="store_true", help="N = 1, 256^3: skip the two rocprofv3 --pmc passes behind roofline.traffic "
                     "(the committed profiles/traffic.json is quoted instead)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the strong_<grid> and n1_reference child launches")

@@ -698,6 +698,13 @@ def borrow(hypredrv_obj):
     return A, amg
 
 
+def borrow_matrix(hypredrv_obj):
+    """Csr view of the level-0 operator of a hypredrv.Hypredrv object whatever its preconditioner is (MGR, ILU, ...)."""
+    a = C.c_void_p()
+    _check(load().hda_borrow_hypredrv(hypredrv_obj.h, C.byref(a), None))
+    return Csr(a, owned=True, keep=hypredrv_obj)
+
+
 def comm_stats(reset=False):
     v = (C.c_double * 5)()
     load().hda_comm_stats(v, 1 if reset else 0)

@@ -2008,3 +2008,21 @@ def test_thread_rank_seam_selftests(what):
         assert "different collectives" in r.stdout
     else:
         assert "served" in r.stdout and "cached 8." in r.stdout
+
+
+def test_bench_side_configs_on_small_sizes():
+    """BASELINE.json configs 4 and 5 as bench.py carries them (tools/side_configs.py, stand-in data): GMRES + MGR with examples/ex3.yml's
+    block on the three-field system, GMRES + BoomerAMG with the ILU(0) smoother on the anisotropic reservoir operator -- through
+    HYPREDRV_LinearSolverSetup / Apply, with the oracle's iteration count on a size it finishes in seconds."""
+    import importlib.util
+    import hypredrive_amd as hh
+    spec = importlib.util.spec_from_file_location("side_configs", os.path.join(ROOT, "tools", "side_configs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    m = mod.gmres_mgr(hh, cells=64, steps=2, warmup=1, oracle_cells=16)
+    assert m["converged"] and m["iters_match"] and m["rows"] == 3 * 64 * 64 and m["final_rel"] < 1e-6
+    assert m["dominant_kernel"]["launches"] >= m["iters"] and m["dominant_kernel"]["avg_ms"] > 0
+    a = mod.gmres_amg_ilu0(hh, n=32, steps=2, warmup=1, oracle_n=14)
+    assert a["converged"] and a["iters_match"] and a["rows"] == 32 ** 3 and a["final_rel"] < 1e-6
+    assert a["dominant_kernel"]["launches"] > 0 and a["level0_residual"]["launches"] > 0
+    assert "STAND-IN DATA" in m["what"] and "STAND-IN DATA" in a["what"]

@@ -13,7 +13,7 @@ for f in $FORMS; do
 done
 for rep in 1 2; do
   for f in $FORMS; do
-    env $f timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-traffic --no-plain-csr --no-cpu-defaults --no-aggressive --no-kernel-table \
+    env $f timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-traffic --no-plain-csr --no-cpu-defaults --no-side-configs --no-aggressive --no-kernel-table \
         > $O/bench_$f.$rep.json 2> $O/bench_$f.$rep.err || { tail -30 $O/bench_$f.$rep.err; exit 1; }
     python3 - $O/bench_$f.$rep.json $f <<'PYEOF'
 import json, sys

@@ -9,7 +9,7 @@ mkdir -p $O
 cd $R
 timeout -k 10 300 python tools/hierarchy_dims.py 256 > $O/dims.txt 2>&1 || { tail -5 $O/dims.txt; exit 1; }
 cat $O/dims.txt
-FLAGS="--no-cpu-baseline --no-kernel-table --no-plain-csr --no-aggressive --no-traffic --no-cpu-defaults"
+FLAGS="--no-cpu-baseline --no-kernel-table --no-plain-csr --no-aggressive --no-traffic --no-cpu-defaults --no-side-configs"
 timeout -k 10 300 python bench.py --steps 10 --warmup 2 $FLAGS > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 cut -c1-700 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
