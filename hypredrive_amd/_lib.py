@@ -80,7 +80,7 @@ SYMBOLS = [
     "hda_amg_default_params", "hda_krylov_default_params", "hda_csr_create", "hda_csr_destroy",
     "hda_csr_dims", "hda_csr_download", "hda_lap7_create", "hda_spmv", "hda_relax", "hda_dot",
     "hda_l1_norms", "hda_strength", "hda_pmis", "hda_interp_extpi", "hda_interp_direct", "hda_rap", "hda_transpose",
-    "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels", "hda_amg_tail_from",
+    "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
     "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_memory_cached", "hda_memory_trim", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_create_blocks", "hda_ilu_blocks", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
@@ -176,7 +176,6 @@ def load():
     L.hda_set_overlap.argtypes = [C.c_int]
     L.hda_set_overlap.restype = None
     L.hda_amg_num_levels.argtypes = [vp]
-    L.hda_amg_tail_from.argtypes = [vp]
     L.hda_amg_level_matrix.argtypes = [vp, C.c_int, C.c_int, P(vp)]
     L.hda_amg_level_cf.argtypes = [vp, C.c_int, ip]
     L.hda_amg_complexities.argtypes = [vp, dp, dp]

@@ -239,7 +239,6 @@ class Amg {
    void solve(const double *b, double *x);
 
    int           num_levels() const { return (int)levels.size(); }
-   int           cycle_tail_from() { return tail_from(); } // first level of the one-launch tail of the cycle (-1: none)
    const DCsr   &level_A(int l) const { return l == 0 ? *A0 : levels[l].A; }
    AmgLevel     &level(int l) { return levels[l]; }
    double        operator_complexity() const;
@@ -261,11 +260,6 @@ class Amg {
    void cheby_sweep(int l, const double *b, double *u, bool zero_guess, bool ghosts_fresh = false);
    bool ghosts_fresh_ = false; // cycle -> relax: the next sweep's input has fresh ghost copies (AmgLevel::Pg)
    void coarse_solve(const double *f, double *u);
-   // one launch for the tail of the cycle (hda_kernels.h TailArgs): first level the tail kernel takes over, -1 = none; planned at
-   // the first cycle after a setup / rebind / renumbering (the operators' arrays must be final)
-   int      tail_from();
-   int      tail_from_ = -2;
-   TailArgs tail_args_;
    const HaloPlan &level_hA(int l) const { return (l == 0 && hA0) ? *hA0 : levels[l].hA; }
    const DCsr           *A0 = nullptr;
    int                   a0_dims[3] = {0, 0, 0}; // rows, columns, entries of the level-0 operator when it was bound

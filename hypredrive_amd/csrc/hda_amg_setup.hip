@@ -2762,7 +2762,6 @@ void Amg::setup(const DCsr &A)
 {
    dist = false;
    hA0  = nullptr;
-   tail_from_ = -2; // (planned again at the first cycle: the arrays below are new)
    build_hierarchy(A);
    reorder_levels(); // solve-phase numbering of the big coarse levels (the setup above stays in natural order)
    const int L = (int)levels.size();
@@ -2788,7 +2787,6 @@ void Amg::rebind(const DCsr &A, const HaloPlan *hA)
    A0 = &A;
    a0_dims[0] = A.nrows; a0_dims[1] = A.ncols; a0_dims[2] = A.nnz;
    if (dist) hA0 = hA;
-   tail_from_ = -2;
    spmv_prepare(A);
 }
 
@@ -3354,47 +3352,6 @@ void Amg::apply_offering(const double *b, double *x, int dot_slot)
    }
 }
 
-// Which levels the one-workgroup tail kernel (hda_kernels.h k_cycle_tail) takes over: the longest run of levels at the bottom of the
-// hierarchy -- never level 0, at least one level above the coarsest -- whose A, P and R all run on the lane-group kernel today (the
-// only form it reproduces bit for bit) and are small enough for one workgroup (HDA_TAIL_NNZ entries per operator, default 60 000:
-// one CU passes over that in 2-3 us).  V(1,1) with Jacobi-type sweeps and the dense coarse solve only; one rank (the replicated
-// tail of a row-partitioned hierarchy is a one-rank hierarchy of its own).  HDA_TAIL=0 switches it off (A/B, bitwise test).
-int Amg::tail_from()
-{
-   if (tail_from_ != -2) return tail_from_;
-   tail_from_ = -1;
-   const bool off = getenv("HDA_TAIL") && atoi(getenv("HDA_TAIL")) == 0; // (read per plan: the tests switch it inside one process)
-   const long cap = getenv("HDA_TAIL_NNZ") ? atol(getenv("HDA_TAIL_NNZ")) : 60000;
-   const int L = num_levels();
-   if (off || dist || L < 3 || !coarse_dense || coarse_n < 1 || coarse_n > kTailDenseMax) return tail_from_;
-   if (prm.sweeps_down != 1 || prm.sweeps_up != 1 || !is_jacobi_type(prm.relax_down) || !is_jacobi_type(prm.relax_up)) return tail_from_;
-   int T = L - 1;
-   while (T - 1 >= 1)
-   { // may level T - 1 join?
-      AmgLevel &lv = levels[(size_t)(T - 1)];
-      if (lv.ilu || lv.gs.built || lv.A.nnz > cap || lv.P.nnz > cap || lv.R.nnz > cap) break;
-      if (!spmv_lane_group_lpr(lv.A) || !spmv_lane_group_lpr(lv.P) || !spmv_lane_group_lpr(lv.R)) break;
-      T--;
-   }
-   if (T > L - 2 || L - 1 - T > kTailMaxLevels) return tail_from_;
-   TailArgs &a = tail_args_;
-   a           = TailArgs();
-   a.nlev      = L - 1 - T;
-   a.coarse_n  = coarse_n;
-   a.invT      = coarse_invT.data();
-   a.fc        = levels[(size_t)(L - 1)].f.data();
-   a.uc        = levels[(size_t)(L - 1)].u.data();
-   auto op = [](const DCsr &M) { return TailOp{M.rowptr.data(), M.col.data(), M.val.data(), M.nrows, spmv_lane_group_lpr(M)}; };
-   for (int q = 0; q < a.nlev; q++)
-   {
-      AmgLevel &lv = levels[(size_t)(T + q)];
-      a.lv[q]      = TailLevel{op(lv.A), op(lv.R), op(lv.P), lv.dinv_down.data(), lv.dinv_up.data(), lv.f.data(), lv.u.data(), lv.u2.data(), lv.t.data()};
-   }
-   tail_from_ = T;
-   if (getenv("HDA_VERBOSE")) fprintf(stderr, "[hda] cycle tail: levels %d .. %d (of %d) in one launch\n", T, L - 1, L);
-   return tail_from_;
-}
-
 void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool first_sweep_given)
 {
    const int L  = num_levels();
@@ -3428,10 +3385,8 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool 
    else { cur = x; alt = levels[0].u2.data(); }
    const double *f = b;
    bool first_sweep_done = first_sweep_given && zero_guess; // the level's zero-guess Jacobi sweep u = dinv .* f came out of the restriction above it (level 0: of the caller)
-   const int T = tail_from(); // >= 1: levels T .. L - 1 run in one launch (k_cycle_tail)
    for (int l = 0; l < L - 1; l++)
    {
-      if (l == T) break;
       const DCsr &A  = level_A(l);
       AmgLevel   &lv = levels[l];
       bool        zg = zero_guess || l > 0;
@@ -3455,14 +3410,8 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool 
       f      = nx.f.data();
       if (l + 1 < L - 1) { cur = nx.u.data(); alt = nx.u2.data(); }
    }
-   if (T >= 1)
-   { // the rest of the way down, the coarse solve and the way back up to level T: one workgroup, one launch
-      tail_args_.first_given = first_sweep_done ? 1 : 0;
-      cycle_tail(tail_args_);
-      sol[(size_t)T] = levels[(size_t)T].u2.data(); // (where the post-smoothing sweep of level T leaves its result)
-   }
-   else
-   { // coarsest
+   // coarsest
+   {
       AmgLevel &lc = levels[L - 1];
       if (coarse_dense) coarse_solve(lc.f.data(), lc.u.data());
       else
@@ -3478,7 +3427,7 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool 
       }
       sol[L - 1] = lc.u.data();
    }
-   for (int l = (T >= 1 ? T - 1 : L - 2); l >= 0; l--)
+   for (int l = L - 2; l >= 0; l--)
    {
       AmgLevel &lv = levels[l];
       double   *c  = sol[l];

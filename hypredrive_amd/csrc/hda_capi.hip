@@ -592,7 +592,6 @@ extern "C" int hda_amg_destroy(hda_amg_t h)
    return HDA_OK;
 }
 extern "C" int hda_amg_num_levels(hda_amg_t h) { return (h && h->amg) ? h->amg->num_levels() : 0; }
-extern "C" int hda_amg_tail_from(hda_amg_t h) { return (h && h->amg) ? h->amg->cycle_tail_from() : -1; }
 
 // "preconditioner: ilu" (reference src/internal/ilu.c): a handle the Krylov entry points accept in place of a hierarchy
 extern "C" int hda_ilu_create(hda_csr_t A, int max_iter, int tri_solve, int lower_it, int upper_it, hda_amg_t *out)

@@ -265,13 +265,10 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
    // workgroup runs every pass and meets every barrier, rows or not)
    {
       const double a  = A.avg_row();
-      const int    l0 = getenv("HDA_GS_LPR0") ? atoi(getenv("HDA_GS_LPR0")) : 2, l1 = getenv("HDA_GS_LPR1") ? atoi(getenv("HDA_GS_LPR1")) : 8,
-                l2 = getenv("HDA_GS_LPR2") ? atoi(getenv("HDA_GS_LPR2")) : 16;
-      int lpr = (a <= 10.0) ? l0 : (a <= 40.0) ? l1 : l2;
+      int lpr = (a <= 10.0) ? 2 : (a <= 40.0) ? 8 : 16;
       lpr     = lpr <= 2 ? 2 : lpr <= 4 ? 4 : lpr <= 8 ? 8 : 16;
       const double lanes = plan.blk_mean_rows_per_level * lpr;
-      const int    nt_e  = getenv("HDA_GS_NT") ? atoi(getenv("HDA_GS_NT")) : 0;
-      int          nt    = nt_e ? nt_e : (lanes <= 192.0 ? 256 : 512); // (1024 threads leave a wavefront 128 registers: 35.0 against 32.7 ms per 128^3 solve)
+      int          nt    = lanes <= 192.0 ? 256 : 512; // (1024 threads leave a wavefront 128 registers: 35.0 against 32.7 ms per 128^3 solve)
       nt                 = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;
       plan.ring_lpr      = lpr;
       plan.ring_nt       = nt;
@@ -1033,48 +1030,11 @@ static void gs_blocks_ring_t(const DCsr &A, const GsPlan &p, const double *dinv,
    k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
 }
 
-// HDA_GS_DIAG=1: wave 0..15 of block 0 time their passes with the shader clock (gathers + arithmetic / fence / barrier)
-static unsigned long long *gs_diag_buffer_impl()
-{
-   static const bool        on = getenv("HDA_GS_DIAG") != nullptr;
-   static DArray<unsigned long long> buf;
-   if (!on) return nullptr;
-   if (buf.size() == 0) { buf.alloc(128); buf.zero(); }
-   return buf.data();
-}
-static unsigned long long *gs_diag_buffer() { return gs_diag_buffer_impl(); }
-static void gs_ring_diag_report(int lpr, int nt, int n)
-{
-   unsigned long long *d = gs_diag_buffer();
-   if (!d) return;
-   static int calls = 0;
-   if (calls++ % 16 > 2) return;
-   unsigned long long h[128];
-   Context::get().sync();
-   HDA_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
-   for (int w : {0, 1, nt / 64 - 1})
-   {
-      const double np = (double)std::max(h[8 * w + 5], 1ull);
-      fprintf(stderr, "[hda] gs ring diag n=%d lanes/row=%d threads=%d wave %2d: passes %.0f, cycles per pass: C (ring reads, sum, stores) %.0f, X+B issue %.0f, "
-                      "wait for the store %.0f, barrier %.0f, pass records / loop %.0f\n", n, lpr, nt, w, np, h[8 * w] / np, h[8 * w + 1] / np, h[8 * w + 2] / np,
-              h[8 * w + 3] / np, h[8 * w + 4] / np);
-   }
-}
-static void gs_diag_report(int lpr, int n)
-{
-   unsigned long long *d = gs_diag_buffer();
-   if (!d) return;
-   static int calls = 0;
-   if (calls++ % 16 > 2) return;
-   unsigned long long h[128];
-   Context::get().sync();
-   HDA_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
-   for (int w : {0, 1, 7, 15})
-      fprintf(stderr, "[hda] gs diag n=%d lanes/row=%d wave %2d: passes %llu, cycles per pass: top-of-pass (iterators, addresses, gather issue) %.0f, prefetch issue %.0f, "
-                      "gathers+arithmetic+store %.0f, fence %.0f, barrier %.0f\n", n, lpr, w, h[4 * w + 3], (double)h[64 + 2 * w] / std::max(h[4 * w + 3], 1ull),
-              (double)h[65 + 2 * w] / std::max(h[4 * w + 3], 1ull), (double)(h[4 * w] - h[65 + 2 * w]) / std::max(h[4 * w + 3], 1ull),
-              (double)h[4 * w + 1] / std::max(h[4 * w + 3], 1ull), (double)h[4 * w + 2] / std::max(h[4 * w + 3], 1ull));
-}
+// (the shader-clock instrumentation of the ring / sorted kernels -- their `diag` argument -- is switched off in product builds: the
+//  measurements it made are in profiles/r04_gs_blocks.md)
+static unsigned long long *gs_diag_buffer() { return nullptr; }
+static void gs_ring_diag_report(int, int, int) {}
+static void gs_diag_report(int, int) {}
 
 template <int LPR, int NT>
 static void gs_blocks_sorted_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
@@ -1329,25 +1289,6 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
 #undef WDONE_LD
 #undef WDONE_ST
 
-// TIMING PROBE (HDA_GS_PROBE=1): what one workgroup per block can stream when nothing depends on anything -- the block's chunks, divisors,
-// right-hand sides and sweep-start values read once with 16-byte loads, summed, one store per lane
-__global__ __launch_bounds__(512) void k_gs_stream_probe(const int *__restrict__ part, const int *__restrict__ srp4, const int4 *__restrict__ scj4,
-                                                         const double2 *__restrict__ sv2, const double *__restrict__ sd,
-                                                         const double *__restrict__ sb, const double *__restrict__ sx0, double *out)
-{
-   const int blk = blockIdx.x, lo = part[blk], hi = part[blk + 1];
-   const int c0 = srp4[lo], c1 = srp4[hi];
-   double acc = 0.0;
-   for (int ch = c0 + threadIdx.x; ch < c1; ch += 512)
-   {
-      const int4    c = scj4[ch];
-      const double2 a = sv2[2 * ch], b = sv2[2 * ch + 1];
-      acc += a.x + a.y + b.x + b.y + (double)(c.x + c.y + c.z + c.w);
-   }
-   for (int p = lo + threadIdx.x; p < hi; p += 512) acc += sd[p] + sb[p] + sx0[p];
-   out[blk * 512 + threadIdx.x] = acc;
-}
-
 // longest distance, in sweep positions, between a row and an in-block column of it (the reach of a dependency in either direction)
 __global__ __launch_bounds__(256) void k_gs_reach(int n, const int *__restrict__ srp4, const int *__restrict__ scj, int *reach, int *maxchunks)
 {
@@ -1383,8 +1324,7 @@ static void gs_free_plan(const GsPlan &plan, int n)
    // than two lanes with four each); two where a row would otherwise take 32 or 64 lanes and the blocks are long enough for the halved
    // number of rounds to count (128^3 level 2, rows of up to 69 entries, 7 000 rows per block: 0.47 -> 0.41 ms; level 3, 730 rows per
    // block: 0.079 -> 0.083, left at one)
-   // (HDA_GS_FREE_MAXC2_FROM=<chunks>: the shortest "longest row" that gets two chunks per lane -- experiments)
-   static const int maxc2_from = getenv("HDA_GS_FREE_MAXC2_FROM") ? atoi(getenv("HDA_GS_FREE_MAXC2_FROM")) : 17;
+   constexpr int maxc2_from = 17;
    const int maxc = (h[1] > 64 || (h[1] >= maxc2_from && maxblock >= 2048)) ? 2 : 1;
    int       lpr  = 1;
    while (lpr * maxc < h[1]) lpr <<= 1;
@@ -1442,28 +1382,6 @@ static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv,
    int *err = gs_free_error_flag(); // (one flag per process: the kernel raises it instead of spinning forever; read by gs_free_check)
    k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data(),
                                                           p.s_x0.data());
-   if (getenv("HDA_GS_PROBE"))
-   {
-      DArray<double> sink((size_t)p.nblk * 512);
-      hipEvent_t e0, e1;
-      HDA_HIP(hipEventCreate(&e0));
-      HDA_HIP(hipEventCreate(&e1));
-      for (int rep = 0; rep < 2; rep++)
-      {
-         HDA_HIP(hipEventRecord(e0, STREAM));
-         k_gs_stream_probe<<<p.nblk, 512, 0, STREAM>>>(p.blk_part.data(), p.s_rowptr.data(), (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(),
-                                                       p.s_d.data(), p.s_b.data(), p.s_x0.data(), sink.data());
-         HDA_HIP(hipEventRecord(e1, STREAM));
-         HDA_HIP(hipEventSynchronize(e1));
-         float ms = 0.f;
-         HDA_HIP(hipEventElapsedTime(&ms, e0, e1));
-         if (rep) fprintf(stderr, "[hda] stream probe: n=%d nnz=%d %d blocks: %.3f ms for %.1f MB (%.2f TB/s, %.1f B/clk per CU at 2.4 GHz)\n", n, A.nnz, p.nblk, ms,
-                          (12.0 * 4 * p.s_col.size() / 4 / 1 + 24.0 * n) / 1e6 * 0 + (12.0 * p.s_col.size() + 24.0 * n) / 1e6,
-                          (12.0 * p.s_col.size() + 24.0 * n) / ms / 1e9, (12.0 * p.s_col.size() + 24.0 * n) / (ms * 1e-3) / p.nblk / 2.4e9);
-      }
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
-   }
    const size_t lds = sizeof(double) * (size_t)p.free_ring;
 #define HDA_GS_FREE_LAUNCH(BW)                                                                                                               \
    HDA_HIP(hipFuncSetAttribute((const void *)k_gs_blocks_free<LPR, MAXC, NT, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));  \
@@ -1503,7 +1421,7 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
       if (plan.sorted) gs_free_plan(plan, A.nrows);
    }
    const double a = A.avg_row();
-   const bool use_sorted = !(getenv("HDA_GS_SORTED") && atoi(getenv("HDA_GS_SORTED")) == 0);
+   constexpr bool use_sorted = true;
    // barrier-free kernel or ring kernel: both cost about a microsecond per step (round of 512 / LPR rows, pass of a dependency level);
    // the one with fewer steps runs -- HDA_GS_FREE=1 / 0 force either
    bool use_free = plan.free_lpr > 0 && use_sorted;
@@ -1555,14 +1473,11 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
    }
    if (plan.sorted && use_sorted)
    {
-      static const int l0 = getenv("HDA_GS_LPR0") ? atoi(getenv("HDA_GS_LPR0")) : 2, l1 = getenv("HDA_GS_LPR1") ? atoi(getenv("HDA_GS_LPR1")) : 8,
-                       l2 = getenv("HDA_GS_LPR2") ? atoi(getenv("HDA_GS_LPR2")) : 16;
-      const int lpr = (a <= 10.0) ? l0 : (a <= 40.0) ? l1 : l2; // lanes per row: 4 entries each per pass
+      const int lpr = (a <= 10.0) ? 2 : (a <= 40.0) ? 8 : 16; // lanes per row: 4 entries each per pass
       // workgroup size: what a typical level of a block keeps busy (every wavefront of the workgroup runs every pass and meets every
       // barrier, rows or not: idle ones only take issue slots and queue loads in front of the busy ones')
-      static const int nt_env = getenv("HDA_GS_NT") ? atoi(getenv("HDA_GS_NT")) : 0;
       const double     lanes  = plan.blk_mean_rows_per_level * std::min(std::max(lpr, 2), 16);
-      const int        nt     = nt_env ? nt_env : (lanes <= 192.0 ? 256 : lanes <= 640.0 ? 512 : 1024);
+      const int        nt     = lanes <= 192.0 ? 256 : lanes <= 640.0 ? 512 : 1024;
 #define HDA_GS_DISPATCH(L)                                                                              \
    do                                                                                                   \
    {                                                                                                    \
@@ -1600,9 +1515,8 @@ static void gs_sweep_t(const DCsr &A, const GsPlan &p, const double *dinv, const
       }
       else
       {
-         static const int pipe = getenv("HDA_GS_PIPE") ? atoi(getenv("HDA_GS_PIPE")) : 1;
          const size_t     lds  = sizeof(int) * (size_t)(sg.second - sg.first + 1);
-         if (pipe && lds <= 48 * 1024)
+         if (lds <= 48 * 1024)
             k_gs_levels_pipe<FL, (FL >= 8 ? 8 : 2)><<<1, 1024, lds, STREAM>>>(sg.first, sg.second, forward ? 0 : 1, p.d_lvl_ptr.data(), p.perm.data(),
                                                                           p.rbeg.data(), p.rend.data(), A.col.data(), A.val.data(), dinv, b, x);
          else

@@ -74,37 +74,6 @@ void dense_apply(int n, const double *inv, const double *b, double *x);
 void dense_invert(int n, double *a, double *inv);
 void csr_to_dense(const DCsr &A, double *dense);
 
-// ---- one launch for the tail of a V(1,1) cycle (round 5).  The coarse levels of a hierarchy are bound by the latency of their tiny
-// kernels -- at 256^3 about 24 dispatches of 5-6 us per cycle below level 3 -- not by bandwidth.  Levels whose operators are small
-// enough for ONE workgroup run their whole part of the cycle in a single kernel: residual, restriction (with the next level's
-// zero-guess Jacobi sweep), ..., dense coarse solve, ..., prolongation, Jacobi sweep, with workgroup barriers in place of kernel
-// boundaries.  Every row sum is formed exactly as the lane-group kernel k_spmv<LPR> forms it (same lanes per row, same strides, same
-// shuffle tree), so the cycle's result is bit-identical to the unfused one (tests/test_gpu_parity.py::test_cycle_tail_is_bitwise_neutral).
-// Reference: the cycle of HYPRE_BoomerAMGSolve, src/internal/precon.c:108.
-constexpr int kTailMaxLevels = 12;
-struct TailOp {
-   const int    *rp, *col;
-   const double *val;
-   int           n, lpr; // rows; lanes per row of the lane-group kernel
-};
-struct TailLevel {
-   TailOp        A, R, P; // operator, restriction onto the next level, prolongation from it
-   const double *dinv_down, *dinv_up;
-   double       *f, *u, *u2, *t;
-};
-struct TailArgs {
-   int           nlev = 0;        // levels ABOVE the coarsest that the kernel cycles through (lv[0 .. nlev))
-   int           coarse_n = 0;    // rows of the coarsest operator (dense inverse, column-major)
-   int           first_given = 0; // lv[0].u already holds the zero-guess sweep dinv_down .* f (fused into the restriction above it)
-   const double *invT = nullptr;
-   double       *fc = nullptr, *uc = nullptr;
-   TailLevel     lv[kTailMaxLevels];
-};
-constexpr int kTailDenseMax = 1024; // largest coarsest system the kernel stages in LDS
-// lanes per row when a whole product of A runs on the lane-group kernel k_spmv<LPR> (the only form the tail kernel reproduces), else 0
-int  spmv_lane_group_lpr(const DCsr &A);
-void cycle_tail(const TailArgs &a); // on return (stream order) lv[0].u2 holds level lv[0]'s part of the cycle's result
-
 // ---- utilities
 void exclusive_scan(int n, const int *in, int *out, int *total_out_dev); // out[i] = sum_{j<i} in[j]; out[n] = total
 void require_int32_total(long n, const int *counts, const char *what);  // throws when sum(counts) >= 2^31

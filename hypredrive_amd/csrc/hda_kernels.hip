@@ -1467,8 +1467,9 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
                                                   const double *__restrict__ val, const double *__restrict__ x, double alpha, double beta,
                                                   const double *yin, const double *__restrict__ b, const double *__restrict__ dinv,
                                                   const double *__restrict__ w, double *out, double *__restrict__ partial, int nown,
-                                                  int prod_len, const unsigned char *__restrict__ code, const double *__restrict__ dval, int pf)
-{
+                                                  int prod_len, const unsigned char *__restrict__ code, const double *__restrict__ dval, int pf,
+                                                  const double *__restrict__ dinv2 = nullptr, double *__restrict__ out2 = nullptr)
+{ // out2 (MODE_PLAIN only): a second result out2 = dinv2 .* out, as in k_spmv_stream (the next level's zero-guess Jacobi sweep)
    extern __shared__ double smem[];
    double *prod = smem, *xs = smem + prod_len;
    __shared__ double sdict[VC ? 256 : 1];
@@ -1626,6 +1627,7 @@ __global__ __launch_bounds__(256) void k_spmv_win(int nw, const int *__restrict_
             {
                o0 = (beta == 0.0) ? alpha * sum : alpha * sum + beta * (first ? cb : yin[r]);
                if (DOT) acc += o0 * (first ? cd : w[r]);
+               if (out2) out2[r] = dinv2[r] * o0;
             }
             else if (MODE == MODE_RESID) o0 = (first ? cb : b[r]) - sum;
             else
@@ -1966,14 +1968,23 @@ static bool launch_spmv_impl(const DCsr &A, const double *x, double alpha, doubl
          const int    plen = kWChunk + A.maxrow;
          const size_t wlds = sizeof(double) * (size_t)(plen + A.win_maxu);
          const int    wg   = DOT ? gmax : std::min(gmax, ((A.nwin + 7) / 8) * 8);
+         // a scaled second result asked for by spmv_with_scaled_copy (whole products only, not the owned-column half)
+         const double *wepi_d = nullptr;
+         double       *wepi_o = nullptr;
+         if (MODE == MODE_PLAIN && !DOT && !split && g_epilogue.out2)
+         {
+            wepi_d = g_epilogue.dinv2;
+            wepi_o = g_epilogue.out2;
+            g_epilogue.done = true;
+         }
 #define HDA_WIN(VCF, SPF, CODE, DICT)                                                                                                   \
    k_spmv_win<MODE, DOT, VCF, SPF><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(),     \
                                                               A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen,  \
-                                                              CODE, DICT, win_pf())
+                                                              CODE, DICT, win_pf(), wepi_d, wepi_o)
          if (A.win_runs)
          { // run form (never value-coded)
             if (split) k_spmv_win<MODE, DOT, false, true, true><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen, nullptr, nullptr, win_pf());
-            else k_spmv_win<MODE, DOT, false, false, true><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen, nullptr, nullptr, win_pf());
+            else k_spmv_win<MODE, DOT, false, false, true><<<wg, 256, wlds, STREAM>>>(A.nwin, A.wmeta.data(), A.rowptr.data(), A.lidx.data(), A.ucol.data(), A.val.data(), x, alpha, beta, yin, b, dinv, w, out, partial, nown, plen, nullptr, nullptr, win_pf(), wepi_d, wepi_o);
          }
          else if (A.coded == 2)
          {
@@ -2444,107 +2455,6 @@ __global__ __launch_bounds__(256) void k_dense_apply(int n, const double *__rest
 void dense_apply(int n, const double *invT, const double *b, double *x)
 {
    if (n) k_dense_apply<<<ceil_div(n, 256), 256, sizeof(double) * (size_t)n, STREAM>>>(n, invT, b, x);
-}
-
-// ---- one launch for the tail of a cycle (hda_kernels.h)
-constexpr int kTailThreads = 1024;
-enum { TAIL_RESID = 0, TAIL_RESTRICT = 1, TAIL_PROLONG = 2, TAIL_JACOBI = 3 };
-// rows of op dealt to lane groups of LPR lanes; the sum of a row as in k_spmv<LPR>: lane q takes entries q, q + LPR, ... in order,
-// then group_sum<LPR>.  Vectors are NOT restrict / read-only here: they are written by earlier steps of the same kernel.
-template <int LPR, int MODE>
-__device__ __forceinline__ void tail_rows(const TailOp &op, const double *x, const double *b, const double *dinv, double *out, const double *dinv2,
-                                          double *out2)
-{
-   const int lane = threadIdx.x & (LPR - 1), g = threadIdx.x / LPR;
-   constexpr int G = kTailThreads / LPR;
-   for (int r = g; r < op.n; r += G)
-   {
-      const int s = op.rp[r], e = op.rp[r + 1];
-      int       k = s + lane;
-      double    a = 0.0;
-      if (k < e) a = op.val[k] * x[op.col[k]];
-      for (k += LPR; k < e; k += LPR) a += op.val[k] * x[op.col[k]];
-      a = group_sum<LPR>(a);
-      if (lane == 0)
-      {
-         if (MODE == TAIL_RESID) out[r] = b[r] - a;
-         else if (MODE == TAIL_RESTRICT)
-         { // MODE_PLAIN with alpha 1, beta 0 (+ the scaled second result of spmv_with_scaled_copy)
-            const double o = 1.0 * a;
-            out[r]         = o;
-            if (out2) out2[r] = dinv2[r] * o;
-         }
-         else if (MODE == TAIL_PROLONG) out[r] = 1.0 * a + 1.0 * b[r]; // MODE_PLAIN with alpha 1, beta 1, yin = b
-         else out[r] = x[r] + dinv[r] * (b[r] - a);                      // MODE_JACOBI
-      }
-   }
-}
-template <int MODE>
-__device__ __forceinline__ void tail_step(const TailOp &op, const double *x, const double *b, const double *dinv, double *out,
-                                          const double *dinv2 = nullptr, double *out2 = nullptr)
-{
-   switch (op.lpr)
-   {
-      case 4: tail_rows<4, MODE>(op, x, b, dinv, out, dinv2, out2); break;
-      case 8: tail_rows<8, MODE>(op, x, b, dinv, out, dinv2, out2); break;
-      case 16: tail_rows<16, MODE>(op, x, b, dinv, out, dinv2, out2); break;
-      case 32: tail_rows<32, MODE>(op, x, b, dinv, out, dinv2, out2); break;
-      default: tail_rows<64, MODE>(op, x, b, dinv, out, dinv2, out2); break;
-   }
-   __syncthreads(); // the step's results are the next step's inputs (one workgroup: one CU, one vector L1)
-}
-__global__ __launch_bounds__(kTailThreads) void k_cycle_tail(const TailArgs a)
-{
-   __shared__ double sb[kTailDenseMax];
-   const int tid = threadIdx.x;
-   if (!a.first_given)
-   { // the zero-guess Jacobi sweep of the first tail level, u = dinv .* f (k_mul)
-      const TailLevel &l0 = a.lv[0];
-      for (int i = tid; i < l0.A.n; i += kTailThreads) l0.u[i] = l0.dinv_down[i] * l0.f[i];
-      __syncthreads();
-   }
-   for (int q = 0; q < a.nlev; q++)
-   { // down: residual, restriction (+ the next level's first sweep unless that level is the coarsest)
-      const TailLevel &lv   = a.lv[q];
-      const bool       last = q + 1 == a.nlev;
-      tail_step<TAIL_RESID>(lv.A, lv.u, lv.f, nullptr, lv.t);
-      if (last) tail_step<TAIL_RESTRICT>(lv.R, lv.t, nullptr, nullptr, a.fc);
-      else tail_step<TAIL_RESTRICT>(lv.R, lv.t, nullptr, nullptr, a.lv[q + 1].f, a.lv[q + 1].dinv_down, a.lv[q + 1].u);
-   }
-   { // coarsest: x = inverse * f (k_dense_apply: column-major inverse, the sum in column order)
-      const int n = a.coarse_n;
-      for (int j = tid; j < n; j += kTailThreads) sb[j] = a.fc[j];
-      __syncthreads();
-      for (int i = tid; i < n; i += kTailThreads)
-      {
-         double s = 0.0;
-         for (int j = 0; j < n; j++) s += a.invT[(size_t)j * n + i] * sb[j];
-         a.uc[i] = s;
-      }
-      __syncthreads();
-   }
-   for (int q = a.nlev - 1; q >= 0; q--)
-   { // up: u += P e, then the Jacobi sweep u2 = u + dinv (f - A u)
-      const TailLevel &lv = a.lv[q];
-      const double    *e  = (q + 1 == a.nlev) ? a.uc : a.lv[q + 1].u2;
-      tail_step<TAIL_PROLONG>(lv.P, e, lv.u, nullptr, lv.u);
-      tail_step<TAIL_JACOBI>(lv.A, lv.u, lv.f, lv.dinv_up, lv.u2);
-   }
-}
-int spmv_lane_group_lpr(const DCsr &A)
-{ // the condition under which launch_spmv_impl sends a whole product to k_spmv<LPR> (one rank)
-   if (A.nrows == 0 || A.nnz <= 0) return 0;
-   ensure_plan(A);
-   ensure_coded(A);
-   if (A.coded == 1 && spmv_mode() == 0) return 0;
-   const bool small = A.nnz <= small_nnz();
-   if (spmv_mode() == 0 && A.maxrow <= kMaxRowLds && !small) return 0;
-   return pick_lpr(A);
-}
-void cycle_tail(const TailArgs &a)
-{
-   HDA_REQUIRE(a.nlev >= 1 && a.nlev <= kTailMaxLevels && a.coarse_n >= 1 && a.coarse_n <= kTailDenseMax, "cycle tail: plan out of range");
-   k_cycle_tail<<<1, kTailThreads, 0, STREAM>>>(a);
 }
 
 __global__ void k_csr_to_dense(int n, const int *__restrict__ rp, const int *__restrict__ cj,

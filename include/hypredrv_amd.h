@@ -192,9 +192,6 @@ int hda_mgr_matrix(hda_amg_t h, int level, int which, hda_csr_t *out);
  * hda_ilu_create; level >= 0: the complex smoother of that AMG level. */
 int hda_ilu_factors(hda_amg_t h, int level, hda_csr_t *out);
 int hda_amg_num_levels(hda_amg_t h);
-/* first level of the hierarchy that the one-launch tail of the cycle takes over (k_cycle_tail: the levels from there to the coarsest
- * run in a single workgroup), -1 = none (HDA_TAIL=0, other smoothers than Jacobi-type V(1,1), a row-partitioned hierarchy) */
-int hda_amg_tail_from(hda_amg_t h);
 /* which: 0 = A_l, 1 = P_l, 2 = R_l; returns a borrowed handle (do not destroy) */
 int hda_amg_level_matrix(hda_amg_t h, int level, int which, hda_csr_t *out);
 int hda_amg_level_cf(hda_amg_t h, int level, int *cf);

@@ -141,43 +141,25 @@ def test_pcg_kernel_fusions_are_bitwise_neutral(hd, monkeypatch, sweeps):
         assert r["iters"] == ref["iters"] and np.array_equal(r["hist"], ref["hist"]) and np.array_equal(r["x"], ref["x"]), k
 
 
-@pytest.mark.parametrize("case", ["lap7_40", "lap7_24_nofirst", "aniso_48x30x20", "theta_0.6", "relax_7"])
-def test_cycle_tail_is_bitwise_neutral(hd, monkeypatch, case):
-    """Round 5: the coarse levels of the cycle -- residual, restriction + first sweep, dense coarse solve, prolongation, Jacobi sweep on
-    every level whose operators fit one workgroup -- run in ONE launch (k_cycle_tail, HDA_TAIL_NNZ entries per operator).  Every row sum
-    is formed as the lane-group kernel forms it, so V-cycles, PCG iterates, histories and iteration counts are bit-identical with the
-    tail kernel off (HDA_TAIL=0), with a small cap (fewer levels inside) and with every coarse level inside."""
-    kw = {}
-    shape = (40, 40, 40)
-    c = (1.0, 1.0, 1.0)
-    if case == "lap7_24_nofirst":
-        shape = (24, 24, 24)
-        monkeypatch.setenv("HDA_FUSE_FIRST_SWEEP", "0")   # level T's first sweep is then made inside the tail kernel
-    elif case == "aniso_48x30x20":
-        shape, c = (48, 30, 20), (1.0, 0.1, 10.0)
-    elif case == "theta_0.6":
-        kw = dict(strong_th=0.6)
-    elif case == "relax_7":
-        kw = dict(relax_down=7, relax_up=7, relax_weight=0.8)
-    A = hd.lap7(*shape, c=c)
-    n = shape[0] * shape[1] * shape[2]
-    b = np.random.default_rng(9).standard_normal(n)
-    out, lv = {}, {}
-    for tail, cap in (("0", "60000"), ("1", "2000"), ("1", "60000"), ("1", "1000000")):
-        monkeypatch.setenv("HDA_TAIL", tail)
-        monkeypatch.setenv("HDA_TAIL_NNZ", cap)
-        amg = hd.Amg(A, hd.AmgParams.default(**kw))
-        z = amg.vcycle(b)
-        r = hd.pcg(A, b, amg, hd.KrylovParams.default(False, rtol=1e-10))
-        out[(tail, cap)] = (z, r)
-        lv[(tail, cap)] = hd.load().hda_amg_tail_from(amg.h)
-    assert lv[("0", "60000")] == -1 and lv[("1", "1000000")] >= 1                 # off; on with every small level inside
-    assert lv[("1", "1000000")] <= lv[("1", "60000")] <= max(lv[("1", "2000")], lv[("1", "60000")])
-    zr, rr = out[("0", "60000")]
-    assert rr["converged"]
-    for k, (z, r) in out.items():
-        assert np.array_equal(z, zr), k
-        assert r["iters"] == rr["iters"] and np.array_equal(r["hist"], rr["hist"]) and np.array_equal(r["x"], rr["x"]), k
+@pytest.mark.parametrize("coded", ["1", "0"])
+def test_first_sweep_fusion_on_the_windowed_restriction_is_bitwise_neutral(hd, monkeypatch, coded):
+    """The zero-guess Jacobi sweep u = dinv .* f of a coarse level rides on the restriction kernel that produces f (spmv_with_scaled_copy);
+    since round 5 also when the restriction runs on the WINDOWED kernel -- the level-0 restriction of a large problem (value-coded with
+    HDA_CODED=1, plain values without): at 96^3 R0 has 1.4 M entries, above the lane-group and window thresholds.  One multiplication per
+    row either way: V-cycles, PCG iterates and histories are bit-identical with HDA_FUSE_FIRST_SWEEP=0 (a separate k_mul launch).
+    (profiles/r05_cycle_tail.md: what else was tried on the small-kernel tail of the cycle, and why it was removed.)"""
+    monkeypatch.setenv("HDA_CODED", coded)
+    n = 96
+    A = hd.lap7(n, n, n)
+    b = np.random.default_rng(9).standard_normal(n ** 3)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("HDA_FUSE_FIRST_SWEEP", fuse)
+        amg = hd.Amg(A)
+        out[fuse] = (amg.vcycle(b), hd.pcg(A, b, amg, hd.KrylovParams.default(False, rtol=1e-10)))
+    (z1, r1), (z0, r0) = out["1"], out["0"]
+    assert r0["converged"] and np.array_equal(z1, z0)
+    assert r1["iters"] == r0["iters"] and np.array_equal(r1["hist"], r0["hist"]) and np.array_equal(r1["x"], r0["x"])
 
 
 @pytest.mark.parametrize("shape", [(24, 24, 24), (40, 32, 20)])
