@@ -3385,6 +3385,7 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool 
    else { cur = x; alt = levels[0].u2.data(); }
    const double *f = b;
    bool first_sweep_done = first_sweep_given && zero_guess; // the level's zero-guess Jacobi sweep u = dinv .* f came out of the restriction above it (level 0: of the caller)
+   const bool fuse_first = !(getenv("HDA_FUSE_FIRST_SWEEP") && atoi(getenv("HDA_FUSE_FIRST_SWEEP")) == 0); // (read per cycle: the tests switch it inside one process)
    for (int l = 0; l < L - 1; l++)
    {
       const DCsr &A  = level_A(l);
@@ -3401,7 +3402,6 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool 
       // the next level starts from a zero guess: a Jacobi-type first sweep there is u = dinv .* f, one multiplication per row that
       // the restriction kernel can do on the value it has just computed (one launch and one pass over f and dinv less per level)
       first_sweep_done = false;
-      static const bool fuse_first = !(getenv("HDA_FUSE_FIRST_SWEEP") && atoi(getenv("HDA_FUSE_FIRST_SWEEP")) == 0);
       if (fuse_first && l + 1 < L - 1 && prm.sweeps_down > 0 && is_jacobi_type(prm.relax_down) && !nx.ilu)
          first_sweep_done = spmv_with_scaled_copy(lv.R, lv.t.data(), nx.f.data(), nx.dinv_down.data(), nx.u.data(), &lv.hR);
       else
