@@ -163,6 +163,16 @@ __global__ __launch_bounds__(256) void k_indeg(int nnz, const int *__restrict__ 
       if (smask[k]) atomicAdd(&indeg[cj[k]], 1);
 }
 
+// counter += number of lanes of the wavefront for which pred holds: ONE atomic per wavefront.  (One atomicAdd per undecided row --
+// 16.7 M of them on one address in the first PMIS round at 256^3 -- serialised in the memory system: k_pmis_init and k_pmis_setF took
+// 2.9 ms each on level 0 where their loads need 0.3 ms; round-5 setup accounting, profiles/r05_setup_accounting.md.)  Every lane of the
+// wavefront that is still running must call it.
+__device__ __forceinline__ void wave_count_add(int *counter, bool pred)
+{
+   const unsigned long long m = __ballot(pred);
+   if (pred && (int)(__lane_id()) == __ffsll((unsigned long long)m) - 1) atomicAdd(counter, (int)__popcll(m));
+}
+
 // rows [r0, r0 + n); global id of row i = gid[i] when a table is given, else row_offset + i
 __global__ __launch_bounds__(256) void k_pmis_init(int r0, int n, const int *__restrict__ ns,
                                                    const int *__restrict__ indeg,
@@ -170,15 +180,19 @@ __global__ __launch_bounds__(256) void k_pmis_init(int r0, int n, const int *__r
                                                    long long row_offset, const long long *__restrict__ gid,
                                                    double *__restrict__ meas, int *__restrict__ cf, int *counter)
 {
-   const int i = r0 + blockIdx.x * 256 + threadIdx.x;
-   if (i >= r0 + n) return;
-   const int nt = indeg[i];
-   meas[i]      = (double)nt + pmis_rand(seed, level, gid ? gid[i] : row_offset + i);
-   int c;
-   if (ns[i] == 0) c = -3;      // no strong dependence: special F, never interpolated
-   else if (nt == 0) c = -1;    // measure < 1: nobody depends on it
-   else { c = 0; atomicAdd(counter, 1); }
-   cf[i] = c;
+   const int  i  = r0 + blockIdx.x * 256 + threadIdx.x;
+   const bool in = i < r0 + n;
+   int        c  = -1;
+   if (in)
+   {
+      const int nt = indeg[i];
+      meas[i]      = (double)nt + pmis_rand(seed, level, gid ? gid[i] : row_offset + i);
+      if (ns[i] == 0) c = -3;      // no strong dependence: special F, never interpolated
+      else if (nt == 0) c = -1;    // measure < 1: nobody depends on it
+      else c = 0;
+      cf[i] = c;
+   }
+   wave_count_add(counter, in && c == 0);
 }
 
 // one edge visit decides both endpoints (hypre's IndepSet loop): the neighbourhood is S u S^T
@@ -212,15 +226,17 @@ __global__ __launch_bounds__(256) void k_pmis_setF(int n, const int *__restrict_
                                                    const int *__restrict__ cj,
                                                    const unsigned char *__restrict__ smask, int *cf, int *counter, int r0)
 {
-   const int i = r0 + blockIdx.x * 256 + threadIdx.x;
-   if (i >= r0 + n || cf[i] != 0) return;
-   for (int k = rp[i]; k < rp[i + 1]; k++)
-      if (smask[k] && cf[cj[k]] == 1)
-      {
-         cf[i] = -1;
-         return;
-      }
-   atomicAdd(counter, 1);
+   const int i    = r0 + blockIdx.x * 256 + threadIdx.x;
+   bool      left = i < r0 + n && cf[i] == 0; // still undecided after this round?
+   if (left)
+      for (int k = rp[i]; k < rp[i + 1]; k++)
+         if (smask[k] && cf[cj[k]] == 1)
+         {
+            cf[i] = -1;
+            left  = false;
+            break;
+         }
+   wave_count_add(counter, left);
 }
 
 static void pmis_core(const DCsr &A, const unsigned char *smask, const int *ns, uint64_t seed, int level,
@@ -280,132 +296,12 @@ void amg_pmis(const DCsr &A, const unsigned char *smask, uint64_t seed, int leve
 // bucket, buckets are FIFO lists.  That order is the algorithm, so it runs as ONE device thread
 // (kept on the device so the setup never leaves HBM).  Meant for parity runs on the
 // reference's small examples; PMIS is the coarsening for large problems.
-struct RsBuckets {
-   int *head, *tail, *prev, *next, *key;
-   int  maxkey;
-};
-__device__ inline void bk_enter(RsBuckets &b, int i, int key)
-{
-   b.key[i]  = key;
-   b.next[i] = -1;
-   b.prev[i] = b.tail[key];
-   if (b.tail[key] >= 0) b.next[b.tail[key]] = i;
-   else b.head[key] = i;
-   b.tail[key] = i;
-   if (key > b.maxkey) b.maxkey = key;
-}
-__device__ inline void bk_remove(RsBuckets &b, int i)
-{
-   const int key = b.key[i];
-   if (b.prev[i] >= 0) b.next[b.prev[i]] = b.next[i];
-   else b.head[key] = b.next[i];
-   if (b.next[i] >= 0) b.prev[b.next[i]] = b.prev[i];
-   else b.tail[key] = b.prev[i];
-   b.prev[i] = b.next[i] = -1;
-}
-// S = strong entries of A (CSR, rp/cj), T = its transpose (tp/tj, ascending).  One wavefront per row block (lane 0 works; the
-// pass is sequential by definition), all blocks at once: block q = rows [part[q], part[q + 1]), connections that leave the block
-// ignored (a rank's S_diag), measures = in-block dependants.  Work arrays: prev/next/key/meas indexed by row; block q's bucket
-// heads and tails at 2 * part[q] + 2 * q, 2 * rows + 2 of them (a measure never exceeds twice the in-block dependants: each
-// dependant counts once as such and once more when it turns F).
-__global__ __launch_bounds__(64) void k_rs_first_pass(int nblk, const int *__restrict__ part, const int *__restrict__ rp,
-                                                      const int *__restrict__ cj, const int *__restrict__ tp, const int *__restrict__ tj,
-                                                      int *head_all, int *tail_all, int *prev, int *next, int *key, int *meas, int *cf)
-{
-   const int q = blockIdx.x;
-   if (q >= nblk) return;
-   const int lo = part[q], hi = part[q + 1], nbk = 2 * (hi - lo) + 2;
-   int      *head = head_all + 2 * (size_t)lo + 2 * (size_t)q, *tail = tail_all + 2 * (size_t)lo + 2 * (size_t)q;
-   RsBuckets B{head, tail, prev, next, key, 0};
-   auto      in = [&](int j) { return j >= lo && j < hi; };
-   // the initial state has no order in it: all 64 lanes write it (a tenth of the pass when one lane did), then lane 0 goes on alone.
-   // (Reading the rows the main loop walks 64 entries at a time and handing them over by readlane was tried and measured the same:
-   //  what the loop costs is the chain of dependent list operations, not the row reads.)
-   for (int t = threadIdx.x; t < nbk; t += 64) head[t] = tail[t] = -1;
-   for (int i = lo + threadIdx.x; i < hi; i += 64)
-   {
-      int nt = 0;
-      for (int k = tp[i]; k < tp[i + 1]; k++) nt += in(tj[k]);
-      meas[i] = nt;
-      prev[i] = next[i] = -1;
-      key[i]  = 0;
-      cf[i]   = (rp[i + 1] == rp[i]) ? -3 : 0; // no strong dependence at all: special F, never interpolated
-      if (cf[i] == -3) meas[i] = 0;
-   }
-   __threadfence_block();
-   __syncthreads();
-   if (threadIdx.x != 0) return;
-   // ascending-index insertion; measure-0 points become F and the points they depend on gain
-   // weight (re-listed at the tail when already listed)
-   for (int j = lo; j < hi; j++)
-   {
-      if (cf[j] == -3) continue;
-      if (meas[j] > 0) { bk_enter(B, j, meas[j]); continue; }
-      cf[j] = -1;
-      for (int k = rp[j]; k < rp[j + 1]; k++)
-      {
-         const int m = cj[k];
-         if (!in(m) || cf[m] == -3) continue;
-         if (m < j)
-         {
-            if (cf[m] != 0) { meas[m]++; continue; }
-            if (meas[m] > 0) bk_remove(B, m);
-            meas[m]++;
-            bk_enter(B, m, meas[m]);
-         }
-         else meas[m]++;
-      }
-   }
-   for (;;)
-   {
-      while (B.maxkey > 0 && head[B.maxkey] < 0) B.maxkey--;
-      if (B.maxkey <= 0) break;
-      const int i = head[B.maxkey];
-      bk_remove(B, i);
-      cf[i]   = 1;
-      meas[i] = 0;
-      for (int k = tp[i]; k < tp[i + 1]; k++)
-      { // everything that strongly depends on i becomes F
-         const int j = tj[k];
-         if (!in(j) || cf[j] != 0) continue;
-         cf[j] = -1;
-         bk_remove(B, j);
-         for (int kk = rp[j]; kk < rp[j + 1]; kk++)
-         {
-            const int m = cj[kk];
-            if (in(m) && cf[m] == 0)
-            {
-               bk_remove(B, m);
-               meas[m]++;
-               bk_enter(B, m, meas[m]);
-            }
-         }
-      }
-      for (int k = rp[i]; k < rp[i + 1]; k++)
-      { // points i depends on lose one potential dependant
-         const int j = cj[k];
-         if (!in(j) || cf[j] != 0) continue;
-         bk_remove(B, j);
-         meas[j]--;
-         if (meas[j] > 0) bk_enter(B, j, meas[j]);
-         else
-         {
-            cf[j] = -1;
-            for (int kk = rp[j]; kk < rp[j + 1]; kk++)
-            {
-               const int m = cj[kk];
-               if (in(m) && cf[m] == 0)
-               {
-                  bk_remove(B, m);
-                  meas[m]++;
-                  bk_enter(B, m, meas[m]);
-               }
-            }
-         }
-      }
-   }
-}
-// The same pass with the state of a row in ONE 16-byte record {prev, next, measure, cf} (one load where the version above makes
+// Ruge first pass of HMIS.  S = strong entries of A (CSR, rp/cj), T = its transpose (tp/tj, ascending).  One wavefront per row block
+// (lane 0 works; the pass is sequential by definition), all blocks at once: block q = rows [part[q], part[q + 1]), connections that
+// leave the block ignored (a rank's S_diag), measures = in-block dependants (a measure never exceeds twice the in-block dependants:
+// each dependant counts once as such and once more when it turns F).  (The round-3 form with one array per field was removed in
+// round 5: same result bit for bit, 25 % slower, profiles/r04_gs_blocks.md.)
+// The state of a row is ONE 16-byte record {prev, next, measure, cf} (one load where one array per field makes
 // four dependent ones; a listed point's bucket key IS its measure) and the bucket heads / tails in LDS when twice the largest
 // in-degree fits (they are the hottest words of the pass).  What the pass costs is the chain of dependent memory round trips of its
 // one working lane, so it is those that are cut: per list operation one record load (stores are not waited for), against the
@@ -588,7 +484,7 @@ __global__ __launch_bounds__(256) void k_strong_fill(int n, const int *__restric
 // HDA_HMIS_MAX_ROWS moves the limit; more blocks (AmgParams::blocks) shorten the pass in proportion.
 static int rs_max_rows()
 {
-   static const int v = getenv("HDA_HMIS_MAX_ROWS") ? atoi(getenv("HDA_HMIS_MAX_ROWS")) : 2500000;
+   static const int v = 2500000;
    return v;
 }
 
@@ -619,16 +515,6 @@ static void hmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
    transpose(S, T);
    DArray<int> dpart;
    dpart.upload(part.data(), part.size());
-   const bool legacy = getenv("HDA_RS_LEGACY") && atoi(getenv("HDA_RS_LEGACY")) != 0; // the round-3 kernel (A/B; read per setup: the tests switch it)
-   if (legacy)
-   {
-      const size_t nbk = 2 * (size_t)n + 2 * (size_t)nblk;
-      DArray<int>  head(nbk), tail(nbk), prev((size_t)n + 1), next((size_t)n + 1), key((size_t)n + 1), meas((size_t)n + 1);
-      k_rs_first_pass<<<nblk, 64, 0, STREAM>>>(nblk, dpart.data(), S.rowptr.data(), S.col.data(), T.rowptr.data(), T.col.data(), head.data(),
-                                              tail.data(), prev.data(), next.data(), key.data(), meas.data(), cf);
-      Context::get().sync();
-   }
-   else
    {
       // a measure never exceeds twice the in-block dependants: bucket keys stay below 2 * (largest in-degree) + 2
       DArray<int> mx(1);
@@ -1846,13 +1732,13 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    k_max3<<<std::min(g, 1024), 256, 0, STREAM>>>(n, A.rowptr.data(), ub.data(), nt.data(), mx.data());
    int hmx[3] = {0, 0, 0};
    mx.download(hmx, 3);
-   static const char *imode = getenv("HDA_INTERP"); // "thread" / "wave" force one kernel (diagnostics)
+   const char *imode = nullptr; // ("thread" / "wave" forced one kernel: diagnostics of rounds 1-3)
    // G lanes share a row (8 for stencil rows, a whole wavefront for the long rows of coarse levels): the row, its
    // candidates and its neighbour rows are staged in LDS by coalesced reads.  The thread-per-row kernel keeps the rows
    // that exceed the LDS budget, and everything when pmax is outside the group kernel's range.
    bool use_wave = pmax > 0 && pmax <= 16 && itype == 6; // the group kernel is extended+i only
    if (imode && !strcmp(imode, "thread")) use_wave = false;
-   static const int g_env = getenv("HDA_INTERP_LANES") ? atoi(getenv("HDA_INTERP_LANES")) : 0;
+   constexpr int g_env = 0;
    int G = 64; // (32 lanes for rows of ~30 entries measured twice as slow as 64: eight rows' staging areas leave one workgroup per CU)
    if (hmx[0] <= 8) G = 8;
    else if (hmx[0] <= 16) G = 16;
@@ -1866,7 +1752,7 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    // and swept on registers (reg_nbr below), which beat the LDS-staged form on every level of the 256^3 hierarchy (level 1: 70 -> 59 ms,
    // level 2: 36 -> 20, levels 0 / 3: 23.3 -> 22.2 / 5.0 -> 3.0, tools/gpurun/r03_zg.sh ... r03_zi.sh) because the small area lets more
    // rows be in flight per CU: the default area is 8 entries, i.e. staging is off in practice.  HDA_INTERP_NBR=<entries> brings it back.
-   static const int nbr_env = getenv("HDA_INTERP_NBR") ? atoi(getenv("HDA_INTERP_NBR")) : 0;
+   constexpr int nbr_env = 0; // (the LDS staging of neighbour rows lost to the register sweeps on every level: closed in round 3)
    cap_nbr = 8;
    if (nbr_env > 8)
    {
@@ -1894,10 +1780,10 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
    if (use_wave)
    {
       const size_t lds = interp_wave_doubles(cap_row, cap_ub, cap_nbr) * 8 * gpb;
-      static const int s3_scan = getenv("HDA_INTERP_SCAN") ? atoi(getenv("HDA_INTERP_SCAN")) : 1 << 30; // candidates up to which duplicates are found by scanning
-      static const bool want_prof = getenv("HDA_INTERP_PROF") != nullptr;
+      constexpr int s3_scan = 1 << 30; // candidates up to which duplicates are found by scanning
+      constexpr bool want_prof = false; // (shader-clock stage profile of rounds 2-3)
       // neighbour rows read from memory, at most four entries per lane: one pass, the sweeps on registers (HDA_INTERP_REG=0: three passes)
-      static const int reg_nbr = !(getenv("HDA_INTERP_REG") && atoi(getenv("HDA_INTERP_REG")) == 0);
+      constexpr int reg_nbr = 1;
       DArray<unsigned long long> prof;
       if (want_prof)
       {
@@ -1908,7 +1794,7 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
       if (A.nnz) k_strongC_flag<<<std::min(ceil_div(A.nnz, 256), 1 << 16), 256, 0, STREAM>>>(A.nnz, A.col.data(), smask, cf, sc.data());
       // compact lists of every row's strong C columns: a row gathers its candidates from them in one flat pass instead of walking the
       // full rows of its strong F neighbours one after the other (HDA_INTERP_SCLIST=0: the walk)
-      static const bool sclist = !(getenv("HDA_INTERP_SCLIST") && atoi(getenv("HDA_INTERP_SCLIST")) == 0);
+      constexpr bool sclist = true;
       DArray<int> scofs, scc;
       if (sclist && cap_nbr <= 8)
       {
@@ -2405,8 +2291,7 @@ static bool use_hash_spgemm()
    static int m = -1;
    if (m < 0)
    {
-      const char *e = getenv("HDA_SPGEMM");
-      m             = (e && !strcmp(e, "hash")) ? 1 : 0;
+      m = 0; // (the hash product stays the fallback for rows beyond the sort network and products beyond the scratch budget)
    }
    return m == 1;
 }
@@ -2436,7 +2321,6 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
    // product scratch (12 B each) may take up to 30 % of the device memory: 7 G products on a 288 GB part,
    // enough for the 512^3 benchmark's largest Galerkin product (5 G); beyond it the hash path takes over
    static const long long scratch_cap = [] {
-      if (getenv("HDA_ESC_SCRATCH")) return atoll(getenv("HDA_ESC_SCRATCH"));
       size_t freeb = 0, totalb = 0;
       if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return 3LL << 30;
       return (long long)(0.3 * (double)totalb / 12.0);
@@ -2456,7 +2340,7 @@ void spgemm(const DCsr &X, const DCsr &Y, DCsr &C)
    // Eight keys per thread whatever the chunk capacity: a 4096 / 8192-product chunk gets 512 / 1024 threads, so that the two / one
    // workgroups a CU has LDS for still put 16 wavefronts on it (with 256 threads they left the CU at 8 / 4 and ran 1.5 - 3x slower per
    // product, profiles/r03_kernel_experiments.md).  HDA_ESC_THREADS=256: the round-2 shape.
-   static const bool wide = !(getenv("HDA_ESC_THREADS") && atoi(getenv("HDA_ESC_THREADS")) == 256);
+   constexpr bool wide = true;
    const int    nt   = wide ? cap / 8 : 256; // (four keys per thread -- twice the threads again -- lost 10-20 %: more cross-wave stages)
    const int    grid = std::min(nchunks, 256 * std::max(1, (int)((160 * 1024) / (lds + 4 * nt + 1024)))); // the resident workgroups: no tail wave
 
@@ -2529,7 +2413,7 @@ __global__ __launch_bounds__(256) void k_bandwidth(int n, const int *__restrict_
 int amg_auto_blocks(const DCsr &A)
 {
    static const long long min_rows  = getenv("HDA_BLOCKS_MIN_ROWS") ? atoll(getenv("HDA_BLOCKS_MIN_ROWS")) : 100000;
-   static const long long min_block = getenv("HDA_BLOCK_ROWS") ? atoll(getenv("HDA_BLOCK_ROWS")) : 32768;
+   constexpr long long min_block = 32768;
    const int n = A.nrows;
    if (n <= min_rows) return 1;
    DArray<int> bw(1);

@@ -1877,8 +1877,7 @@ static int spmv_mode()
    static int m = -1;
    if (m < 0)
    {
-      const char *e = getenv("HDA_SPMV");
-      m             = (e && !strcmp(e, "vector")) ? 1 : 0;
+      m = 0; // (1 forced the lane-group kernel everywhere: rounds 1-2)
    }
    return m;
 }
@@ -1887,7 +1886,7 @@ static int spmv_mode()
 // rounds (tools/gpurun/r03_f.sh): level-1 Jacobi sweep at 256^3 0.4562 -> 0.4512 ms (-1.1 %), solve 34.53 -> 34.40 ms.
 static int win_pf()
 {
-   static const int v = getenv("HDA_WIN_PF") ? atoi(getenv("HDA_WIN_PF")) : 1;
+   constexpr int v = 1;
    return v;
 }
 // entries below which a product runs on the lane-group kernel (HDA_SMALL_NNZ; 0 = never).  Same-box A/B, two rounds each
@@ -1895,7 +1894,7 @@ static int win_pf()
 // 100 000 and 4 000 000 both a little behind it.
 static long small_nnz()
 {
-   static const long v = getenv("HDA_SMALL_NNZ") ? atol(getenv("HDA_SMALL_NNZ")) : 1000000;
+   constexpr long v = 1000000;
    return v;
 }
 
@@ -1904,8 +1903,7 @@ static long small_nnz()
 static int overlap_grid()
 {
    static const int g = [] {
-      const char *e = getenv("HDA_OVERLAP_GRID");
-      int         v = e ? atoi(e) : 1792;
+      int         v = 1792;
       v             = std::max(kRedBlocks / 2, std::min(kRedBlocks, v));
       return v / 8 * 8;
    }();

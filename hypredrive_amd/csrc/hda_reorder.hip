@@ -119,7 +119,7 @@ void permute_csr(DCsr &M, const int *perm, const int *col_rank, int nown)
    }
    // Column-sorting the renamed rows again costs 50-80 ms of setup at 256^3 and buys 1.6 % of solve time
    // (39.4 vs 40.0 ms): off unless asked for.  Nothing in the solve phase needs sorted rows.
-   static const bool resort = getenv("HDA_REORDER_SORT") && atoi(getenv("HDA_REORDER_SORT")) != 0;
+   constexpr bool resort = false;
    if (col_rank && resort) sort_rows(out);
    M = std::move(out);
    M.reset_plan();

@@ -150,17 +150,15 @@ def test_one_block_is_the_sequential_sweep(orc, hd):
         assert rel(Ah.relax(b, x0, rtype, 1.0), seq) < 1e-13
 
 
-@pytest.mark.parametrize("form", ["lds", "global", "round3"])
+@pytest.mark.parametrize("form", ["lds", "global"])
 @pytest.mark.parametrize("kind", ["one", "even4", "even37", "ragged"])
 @pytest.mark.parametrize("theta", [0.25, 0.6])
 def test_block_hmis_bit_exact(orc, hd, kind, theta, form, monkeypatch):
     """hypre_BoomerAMGCoarsenHMIS at np = V: Ruge first pass per block, interior C points kept, PMIS from there.
-    form: the first pass's bucket heads / tails in LDS (default), in global memory (what in-degrees beyond 4095 get, HDA_RS_LDS=0),
-    and the round-3 kernel with one array per field (HDA_RS_LEGACY=1, kept for A/B timing)."""
+    form: the first pass's bucket heads / tails in LDS (default) or in global memory (what in-degrees beyond 4095 get; HDA_RS_LDS=0
+    forces it here)."""
     if form == "global":
         monkeypatch.setenv("HDA_RS_LDS", "0")
-    elif form == "round3":
-        monkeypatch.setenv("HDA_RS_LEGACY", "1")
     for M in (orc.lap7(14, 12, 10)[0].to_scipy(), mmatrix(1500, 0.006, 31), mmatrix(600, 0.05, 32), mmatrix(700, 0.02, 33, unsym=True)):
         Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
         part = parts_for(M.shape[0], kind, 9)
