@@ -331,7 +331,9 @@ def run(args):
                         "overlap_error": why, "serial_exchange": serial}
                 sys.stdout.write(json.dumps(line) + "\n")
                 sys.stdout.flush()
-            os._exit(0)  # (every rank: kernels of the overlapped phase may never finish; the measurement above is complete)
+            # every rank: kernels of the overlapped phase may never finish.  The line above is a complete measurement of the job with serial
+            # exchanges -- and the designed (overlapped) path FAILED: "a result line, and a failure", as for the staged fallback (exit 2)
+            os._exit(2)
 
         guard = threading.Timer(limit, give_up, args=(f"the overlapped phase did not finish within {limit:.0f} s (phase: see stderr)",))
         guard.daemon = True

@@ -163,14 +163,17 @@ __global__ __launch_bounds__(256) void k_indeg(int nnz, const int *__restrict__ 
       if (smask[k]) atomicAdd(&indeg[cj[k]], 1);
 }
 
-// counter += number of lanes of the wavefront for which pred holds: ONE atomic per wavefront.  (One atomicAdd per undecided row --
-// 16.7 M of them on one address in the first PMIS round at 256^3 -- serialised in the memory system: k_pmis_init and k_pmis_setF took
-// 2.9 ms each on level 0 where their loads need 0.3 ms; round-5 setup accounting, profiles/r05_setup_accounting.md.)  Every lane of the
-// wavefront that is still running must call it.
-__device__ __forceinline__ void wave_count_add(int *counter, bool pred)
+// counter += the wavefront's sum of cnt: ONE atomic per wavefront and launch.  Atomics on one address are serialised at the L2
+// (~10 ns each): one per undecided row -- 16.7 M in the first PMIS round at 256^3 -- or even one per wavefront of a thread-per-row
+// grid (262 144) made k_pmis_init and k_pmis_setF take 2.9 ms each on level 0 where their loads need 0.1-0.3 ms (round-5 setup
+// accounting, profiles/r05_setup_accounting.md).  The kernels below walk the rows with a grid-stride loop on at most kPmisGrid
+// workgroups and count in a register.
+constexpr int kPmisGrid = 2048;
+__device__ __forceinline__ void wave_sum_add(int *counter, int cnt)
 {
-   const unsigned long long m = __ballot(pred);
-   if (pred && (int)(__lane_id()) == __ffsll((unsigned long long)m) - 1) atomicAdd(counter, (int)__popcll(m));
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(counter, cnt);
 }
 
 // rows [r0, r0 + n); global id of row i = gid[i] when a table is given, else row_offset + i
@@ -180,19 +183,19 @@ __global__ __launch_bounds__(256) void k_pmis_init(int r0, int n, const int *__r
                                                    long long row_offset, const long long *__restrict__ gid,
                                                    double *__restrict__ meas, int *__restrict__ cf, int *counter)
 {
-   const int  i  = r0 + blockIdx.x * 256 + threadIdx.x;
-   const bool in = i < r0 + n;
-   int        c  = -1;
-   if (in)
+   int left = 0;
+   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long)gridDim.x * 256)
    {
+      const int i  = r0 + (int)q;
       const int nt = indeg[i];
       meas[i]      = (double)nt + pmis_rand(seed, level, gid ? gid[i] : row_offset + i);
+      int c;
       if (ns[i] == 0) c = -3;      // no strong dependence: special F, never interpolated
       else if (nt == 0) c = -1;    // measure < 1: nobody depends on it
-      else c = 0;
+      else { c = 0; left++; }
       cf[i] = c;
    }
-   wave_count_add(counter, in && c == 0);
+   wave_sum_add(counter, left);
 }
 
 // one edge visit decides both endpoints (hypre's IndepSet loop): the neighbourhood is S u S^T
@@ -226,17 +229,17 @@ __global__ __launch_bounds__(256) void k_pmis_setF(int n, const int *__restrict_
                                                    const int *__restrict__ cj,
                                                    const unsigned char *__restrict__ smask, int *cf, int *counter, int r0)
 {
-   const int i    = r0 + blockIdx.x * 256 + threadIdx.x;
-   bool      left = i < r0 + n && cf[i] == 0; // still undecided after this round?
-   if (left)
-      for (int k = rp[i]; k < rp[i + 1]; k++)
-         if (smask[k] && cf[cj[k]] == 1)
-         {
-            cf[i] = -1;
-            left  = false;
-            break;
-         }
-   wave_count_add(counter, left);
+   int left = 0; // rows of this lane that are still undecided after this round
+   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long)gridDim.x * 256)
+   {
+      const int i = r0 + (int)q;
+      if (cf[i] != 0) continue;
+      bool f = false;
+      for (int k = rp[i]; k < rp[i + 1] && !f; k++) f = smask[k] && cf[cj[k]] == 1;
+      if (f) cf[i] = -1;
+      else left++;
+   }
+   wave_sum_add(counter, left);
 }
 
 static void pmis_core(const DCsr &A, const unsigned char *smask, const int *ns, uint64_t seed, int level,
@@ -252,7 +255,7 @@ static void pmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
    counter.zero();
    const int g = ceil_div(n, 256);
    if (A.nnz) k_indeg<<<std::min(ceil_div(A.nnz, 256), 1 << 16), 256, 0, STREAM>>>(A.nnz, A.col.data(), smask, indeg.data());
-   k_pmis_init<<<g, 256, 0, STREAM>>>(0, n, ns, indeg.data(), seed, level, row_offset, nullptr, meas.data(), cf, counter.data());
+   k_pmis_init<<<std::min(g, kPmisGrid), 256, 0, STREAM>>>(0, n, ns, indeg.data(), seed, level, row_offset, nullptr, meas.data(), cf, counter.data());
    int left = 0;
    counter.download(&left, 1);
    HDA_TRACE("  pmis: init done, undecided=%d", left);
@@ -265,7 +268,7 @@ static void pmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
       counter.zero();
       k_pmis_mark<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, meas.data(), notmax.data(), 0);
       k_pmis_setC<<<g, 256, 0, STREAM>>>(n, cf, notmax.data(), 0);
-      k_pmis_setF<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data(), 0);
+      k_pmis_setF<<<std::min(g, kPmisGrid), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data(), 0);
       counter.download(&left, 1);
       HDA_REQUIRE(++rounds < 10000, "PMIS did not terminate");
    }
@@ -548,7 +551,7 @@ static void hmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
    if (A.nnz) k_indeg<<<std::min(ceil_div(A.nnz, 256), 1 << 16), 256, 0, STREAM>>>(A.nnz, A.col.data(), smask, indeg.data());
    k_pmis_init_from<<<g, 256, 0, STREAM>>>(n, indeg.data(), seed, level, meas.data(), cf);
    counter.zero();
-   k_pmis_setF<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data(), 0); // dependants of the kept C points
+   k_pmis_setF<<<std::min(g, kPmisGrid), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data(), 0); // dependants of the kept C points
    int left = 0, rounds = 0;
    counter.download(&left, 1);
    while (left > 0)
@@ -556,7 +559,7 @@ static void hmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
       counter.zero();
       k_pmis_mark<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, meas.data(), notmax.data(), 0);
       k_pmis_setC<<<g, 256, 0, STREAM>>>(n, cf, notmax.data(), 0);
-      k_pmis_setF<<<g, 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data(), 0);
+      k_pmis_setF<<<std::min(g, kPmisGrid), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), smask, cf, counter.data(), 0);
       counter.download(&left, 1);
       HDA_REQUIRE(++rounds < 10000, "HMIS: the trailing PMIS did not terminate");
    }
@@ -3822,7 +3825,7 @@ void pmis_dist(ExtLevel &X, const unsigned char *smask, const int *ns, uint64_t 
    k_i2d<<<gn, 256, 0, STREAM>>>(n, indeg.data(), tmp.data());
    ext_reverse_add(X.plan, tmp.data());
    k_d2i<<<gn, 256, 0, STREAM>>>(n, tmp.data(), indeg.data());
-   if (X.nloc) k_pmis_init<<<g, 256, 0, STREAM>>>(X.off, X.nloc, ns, indeg.data(), seed, level, 0, X.gid_dev.data(), meas.data(), cf, counter.data());
+   if (X.nloc) k_pmis_init<<<std::min(g, kPmisGrid), 256, 0, STREAM>>>(X.off, X.nloc, ns, indeg.data(), seed, level, 0, X.gid_dev.data(), meas.data(), cf, counter.data());
    ext_exchange(X.plan, meas.data());
    ext_exchange_int(X.plan, n, cf, tmp);
    long long left = 0;
@@ -3843,7 +3846,7 @@ void pmis_dist(ExtLevel &X, const unsigned char *smask, const int *ns, uint64_t 
       notmax.zero();
       ext_exchange_int(X.plan, n, cf, tmp);
       counter.zero();
-      if (X.nloc) k_pmis_setF<<<g, 256, 0, STREAM>>>(X.nloc, X.E.rowptr.data(), X.E.col.data(), smask, cf, counter.data(), X.off);
+      if (X.nloc) k_pmis_setF<<<std::min(g, kPmisGrid), 256, 0, STREAM>>>(X.nloc, X.E.rowptr.data(), X.E.col.data(), smask, cf, counter.data(), X.off);
       ext_exchange_int(X.plan, n, cf, tmp);
       int c = 0;
       counter.download(&c, 1);

@@ -1986,9 +1986,10 @@ def test_bench_measures_serial_exchanges_before_overlapped_ones():
 
 def test_bench_reports_the_serial_measurement_when_the_overlapped_phase_hangs():
     """...and if the overlapped phase never returns (test hook), the guard writes the line from the serial measurement, labelled, and
-    every rank leaves with status 0: a first contact with RCCL still ends with a measurement of the job."""
+    every rank leaves with a NON-ZERO status (round-4 ADVICE: the designed path failed -- "a result line, and a failure", as for the staged
+    fallback): a first contact with RCCL still ends with a measurement of the job, and nobody reads it as a success of the overlap."""
     r, lines = _bench_two_ranks({"HDA_BENCH_TEST_OVERLAP_HANG": "1", "HDA_BENCH_OVERLAP_TIMEOUT": "4"})
-    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode != 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     d = lines[0]
     assert "did not finish" in d["overlap_error"] and d["value"] == d["serial_exchange"]["value"] and d["ms_per_step"] == d["serial_exchange"]["ms_per_step"]
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["converged"] and d["scaling"] == "weak"

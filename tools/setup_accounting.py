@@ -18,6 +18,14 @@ from collections import defaultdict
 FETCH_FACTOR = 2.0  # gfx950: FETCH_SIZE reports half the bytes of a streamed read (MI355X_MICROARCH.md, HBM section; pmc_traffic.py re-derives 1.9-2.0)
 
 
+def short(name):
+    k = name.split("(")[0]
+    for pre in ("void ", "hda::"):
+        if k.startswith(pre):
+            k = k[len(pre):]
+    return k.replace("hda::", "")
+
+
 def between_markers(rows, name_key):
     idx = [i for i, r in enumerate(rows) if "k_marker" in r[name_key]]
     return rows[idx[0] + 1:idx[1]] if len(idx) >= 2 else rows
@@ -26,7 +34,7 @@ def between_markers(rows, name_key):
 def load_trace(path):
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     rows = between_markers(rows, "Kernel_Name")
-    return [(r["Kernel_Name"].split("(")[0], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows]
+    return [(short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows]
 
 
 def load_pmc(d, counter):
@@ -35,7 +43,7 @@ def load_pmc(d, counter):
     for f in files:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0], float(r["Counter_Value"])))
+                rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), float(r["Counter_Value"])))
     rows.sort()
     rows = [{"k": k, "v": v} for _, k, v in rows]
     idx = [i for i, r in enumerate(rows) if "k_marker" in r["k"]]
