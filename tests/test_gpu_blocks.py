@@ -375,3 +375,35 @@ def test_amg_ilu_smoother_on_the_hierarchy_blocks(orc, hd):
     assert rel(ah.vcycle(r), ao.vcycle(r)) < 1e-12
     ro, rh = orc.pcg(Ao, b, ao), hd.pcg(Ah, b, ah)
     assert rh["converged"] and rh["iters"] == ro["iters"] and np.allclose(rh["hist"], ro["hist"], rtol=1e-9)
+
+
+def test_row_block_announcement(tmp_path):
+    """Round-4 review (weak #2) and ADVICE: from 100 000 rows the rank-block algorithms (HMIS, hybrid Gauss-Seidel) run on V row blocks =
+    the reference at np = V, not np = 1 -- the setup must SAY so, whatever the print level; HDA_QUIET=1 silences the line; and
+    `preconditioner: ilu` keeps the whole matrix in one block unless HDA_BLOCKS asks for blocks (block-Jacobi ILU drops couplings)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ilu_code = ("from hypredrive_amd import hypredrv as hd\n"
+                "d = hd.Hypredrv('solver: gmres\\npreconditioner: ilu\\n'); d.set_laplacian7((48, 48, 48)); r = d.solve(); print('ilu', r['converged'])\n")
+    code = ("import hypredrive_amd as h\n"
+            "A = h.lap7(48, 48, 48)\n"                      # 110 592 rows > HDA_BLOCKS_MIN_ROWS
+            "amg = h.Amg(A, h.AmgParams.default(coarsen_type=10, relax_down=13, relax_up=14, blocks=0))\n"
+            "print('blocks', h.load().hda_amg_blocks(amg.h))\n" + ilu_code)
+    out = {}
+    for quiet in ("0", "1"):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("HDA_BLOCKS", None)
+        if quiet == "1":
+            env["HDA_QUIET"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        out[quiet] = r
+    loud, silent = out["0"], out["1"]
+    assert "blocks 1" not in loud.stdout and "ilu True" in loud.stdout
+    assert "[hypredrv_amd] BoomerAMG setup:" in loud.stderr and "row blocks" in loud.stderr and "chosen by the setup" in loud.stderr
+    assert "[hypredrv_amd]" not in silent.stderr
+    assert "ILU(0):" not in loud.stderr                     # the ILU preconditioner stayed one block: nothing to announce
+    env = dict(os.environ, PYTHONPATH=root, HDA_BLOCKS="8")
+    r = subprocess.run([sys.executable, "-c", ilu_code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ILU(0): 8 row blocks" in r.stderr and "couplings between blocks are dropped" in r.stderr, r.stderr[-2000:]
