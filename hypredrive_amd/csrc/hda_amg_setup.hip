@@ -1049,7 +1049,18 @@ __global__ __launch_bounds__(256, 5) void k_interp_wave(
          tprev = t;
       }
    };
-   for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB)
+   // XCD-aware dealing of the rows (round 5): workgroups b, b + 8, ... share an XCD and its L2; they walk ONE contiguous eighth of the rows
+   // instead of every eighth group of four.  A row reads the rows of its strong F neighbours -- the level-1 launch at 256^3 fetched 58 GB for
+   // 2.2 GB of operator (profiles/r05f_setup_accounting.md) -- and rows that share neighbours (the same grid line, the next one) now meet in
+   // the same L2.  Rows are independent of one another: same results.  (xcd_rows = 0: the plain grid-stride walk, for grids below 8.)
+   // Same-box A/B at 256^3 (tools/gpurun/r05_interp_ab.sh): level 1 fetches 26 % less (28.1 -> 20.7 M KB) in the same 39.5 ms -- that launch is
+   // bound by its LDS / instruction work, not by the fetches --, level 0 runs 20.7 -> 18.4 ms; setup 242.7 -> 238.3 ms.
+   const int  nslots   = (int)gridDim.x >> 3;
+   const int  xcd_rows = (gridDim.x >= 8 && (gridDim.x & 7) == 0) ? (((n + 7) / 8 + GPB - 1) / GPB) * GPB : 0;
+   const int  r_first  = xcd_rows ? ((int)blockIdx.x & 7) * xcd_rows + ((int)blockIdx.x >> 3) * GPB + grp : (int)blockIdx.x * GPB + grp;
+   const int  r_end    = xcd_rows ? min(n, (((int)blockIdx.x & 7) + 1) * xcd_rows) : n;
+   const int  r_step   = xcd_rows ? nslots * GPB : (int)gridDim.x * GPB;
+   for (int i = r_first; i < r_end; i += r_step)
    {
       if (rowmode[i]) continue;
       const int c = cf[i];
@@ -1811,7 +1822,7 @@ void amg_interp_extpi(const DCsr &A, const unsigned char *smask, const int *cf, 
       }
       auto launch = [&](auto kern) {
          HDA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-         kern<<<std::min(ceil_div(n, gpb), 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, sc.data(), cf, nsC.data(),
+         kern<<<std::min((ceil_div(n, gpb) + 7) / 8 * 8, 256 * 16), 256, lds, STREAM>>>(n, A.rowptr.data(), A.col.data(), A.val.data(), smask, sc.data(), cf, nsC.data(),
                                                                       uofs.data(), cap_row, cap_ub, cap_nbr, pmax, trunc_factor, rowmode.data(),
                                                                       lcol.data(), lw.data(), pcnt.data(), dof, s3_scan, prof.data(), reg_nbr,
                                                                       scc.data() ? scofs.data() : nullptr, scc.data());
