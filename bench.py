@@ -275,15 +275,17 @@ def run(args):
     # process also pays for device-memory allocation (bimodal, 0.03-0.9 s on these boxes), the second one runs out of the
     # library's caching allocator and is the "prec" timer proper
     PHASE["name"] = "setup"
-    setup = []
+    setup, setup_alloc = [], []
     for _ in range(2):
         hh.sync()
         w.barrier()
+        hh._lib.memory_driver_stats(reset=True)
         t0 = time.perf_counter()
         h.create_and_setup()
         hh.sync()
         w.barrier()
         setup.append((time.perf_counter() - t0) * 1e3)
+        setup_alloc.append(hh._lib.memory_driver_stats())  # what of it the driver's hipMalloc took (this rank)
         if len(setup) == 1:
             h.destroy_solver()
     setup = w.reduce(setup, "max")
@@ -452,6 +454,9 @@ def run(args):
             "allreduce_doubles_per_iter": cs["allreduce_doubles"] * per_it, "halo_doubles_per_iter": cs["exchange_doubles"] * per_it,
             "iters": iters, "vcycles": vcyc, "converged": last["converged"], "final_rel": last["final_rel"],
             "solve_timer_ms": timer_ms, "setup_ms": setup[1], "setup_cold_ms": setup[0],
+            # the first setup of a process pays the driver's allocator (the second runs out of the library's cache): how much of the
+            # difference that is on THIS box (bimodal over the pool: tens of ms here, several hundred on other boxes)
+            "setup_cold_alloc": setup_alloc[0], "setup_alloc": setup_alloc[1],
             "num_levels": amg.num_levels, "operator_complexity": o, "grid_complexity": g,
             "hbm_in_use_gb": hh.memory_stats()[0] / 1e9, "hbm_peak_gb": hh.memory_stats()[1] / 1e9,  # rank 0's allocator: resident / peak
             # aggregate over the ranks; fractions against n_gpus x 8 TB/s.  solve_phase_hbm_* = the bytes the kernels really stream (the

@@ -83,7 +83,7 @@ SYMBOLS = [
     "hda_spgemm", "hda_amg_create", "hda_amg_destroy", "hda_amg_num_levels",
     "hda_last_precond_calls", "hda_amg_create_dof", "hda_format_bytes", "hda_probe_spmv", "hda_probe_read", "hda_amg_level_matrix", "hda_amg_level_cf", "hda_amg_complexities", "hda_amg_vcycle_bytes",
     "hda_amg_vcycle", "hda_pcg", "hda_gmres", "hda_time_kernel", "hda_solve_device",
-    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_memory_cached", "hda_memory_trim", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_create_blocks", "hda_ilu_blocks", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
+    "hda_pcg_iteration_bytes", "hda_memory_stats", "hda_memory_cached", "hda_memory_driver_stats", "hda_memory_trim", "hda_comm_selftest", "hda_check_row_total", "hda_ilu_create", "hda_ilu_create_blocks", "hda_ilu_blocks", "hda_ilu_factors", "hda_fgmres", "hda_bicgstab", "hda_mgr_create", "hda_mgr_matrix",
     "hda_probe_add", "hda_probe_read_id", "hda_borrow_hypredrv", "hda_comm_stats", "hda_comm_name", "hda_comm_size", "hda_halo_plan_host",
     "hda_amd_partitioned_levels", "hda_amd_hierarchy_levels",
     "hda_second_strength", "hda_coarsen_second_pass", "hda_interp_multipass", "hda_truncate_rows",
@@ -190,6 +190,7 @@ def load():
     L.hda_pcg_iteration_bytes.restype = C.c_double
     L.hda_memory_stats.argtypes = [dp, dp]
     L.hda_memory_cached.restype = C.c_double
+    L.hda_memory_driver_stats.argtypes = [C.POINTER(C.c_double), C.c_int]
     L.hda_check_row_total.argtypes = [C.c_longlong, C.c_int]
     L.hda_format_bytes.argtypes = [vp, vp, dp, dp, dp, ip]
     L.hda_probe_spmv.argtypes = [vp, C.c_int]
@@ -793,6 +794,13 @@ def memory_stats():
 
 def memory_cached():
     return load().hda_memory_cached()
+
+
+def memory_driver_stats(reset=False):
+    """hipMalloc calls that reached the driver since the last reset, host ms spent in them, bytes they returned."""
+    v = (C.c_double * 3)()
+    load().hda_memory_driver_stats(v, 1 if reset else 0)
+    return {"hipmalloc_calls": int(v[0]), "hipmalloc_ms": v[1], "hipmalloc_gb": v[2] / 1e9}
 
 
 def memory_trim():

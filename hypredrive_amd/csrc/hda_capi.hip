@@ -1109,6 +1109,12 @@ extern "C" int hda_memory_stats(double *in_use, double *peak)
 }
 
 extern "C" double hda_memory_cached(void) { return (double)pool_bytes_cached(); }
+extern "C" int    hda_memory_driver_stats(double out[3], int reset)
+{
+   HDA_TRY
+   pool_driver_stats(out, reset != 0);
+   HDA_CATCH
+}
 extern "C" int    hda_memory_trim(void)
 {
    HDA_TRY

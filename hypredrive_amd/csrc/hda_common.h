@@ -128,6 +128,7 @@ void  pool_trim(); // sync + return all cached blocks to the driver
 size_t pool_bytes_in_use();
 size_t pool_bytes_peak();
 size_t pool_bytes_cached(); // released blocks kept for reuse: at most max(2 x peak, HDA_POOL_CACHE_MIN_GB)
+void   pool_driver_stats(double out[3], bool reset); // hipMalloc calls that reached the driver, host ms spent in them, bytes they returned
 
 // Stream-ordered device array.
 template <class T>

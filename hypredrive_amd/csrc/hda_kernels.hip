@@ -227,7 +227,26 @@ Pool::~Pool()
    }
 }
 constexpr size_t kAlign = 512;
+// what the driver's allocator cost: calls of hipMalloc that reached the driver and the host time spent in them (bench.py reports both
+// for the first and the second setup of a process: on some boxes of the pool the first setup pays several hundred ms here)
+std::atomic<long long> g_malloc_calls{0}, g_malloc_ns{0}, g_malloc_bytes{0};
+hipError_t timed_hipMalloc(void **p, size_t bytes)
+{
+   const auto       t0 = std::chrono::steady_clock::now();
+   const hipError_t e  = hipMalloc(p, bytes);
+   g_malloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+   g_malloc_calls++;
+   if (e == hipSuccess) g_malloc_bytes += (long long)bytes;
+   return e;
+}
 } // namespace
+void pool_driver_stats(double out[3], bool reset)
+{
+   out[0] = (double)g_malloc_calls.load();
+   out[1] = (double)g_malloc_ns.load() * 1e-6;
+   out[2] = (double)g_malloc_bytes.load();
+   if (reset) { g_malloc_calls = 0; g_malloc_ns = 0; g_malloc_bytes = 0; }
+}
 #define g_pool (current_pool())
 
 // HDA_POISON=1 (diagnostics): every block handed out is filled with 0xFF bytes (NaN as double, -1 as int) on the library
@@ -272,14 +291,14 @@ void *pool_alloc(size_t bytes)
       return p;
    }
    void      *p = nullptr;
-   hipError_t e = hipMalloc(&p, want);
+   hipError_t e = timed_hipMalloc(&p, want);
    if (e != hipSuccess)
    {
       (void)hipGetLastError();
       lk.unlock();
       pool_trim(); // give cached blocks back and retry once
       lk.lock();
-      e = hipMalloc(&p, want);
+      e = timed_hipMalloc(&p, want);
    }
    if (e != hipSuccess)
    { // thread ranks share the device: what is short may sit in the caches of the other ranks' pools (each keeps up to twice its peak)

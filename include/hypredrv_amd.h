@@ -282,6 +282,10 @@ int hda_memory_stats(double *in_use, double *peak);
 /* bytes of released device blocks the calling thread's allocator keeps for reuse: never more than twice the thread's peak in use
  * (or HDA_POOL_CACHE_MIN_GB, default 4, if that is larger); older blocks go back to the driver first */
 double hda_memory_cached(void);
+/* what the DRIVER's allocator cost since the last reset: out[0] hipMalloc calls that reached the driver (the caching allocator missed),
+ * out[1] host milliseconds spent inside them, out[2] bytes they returned.  bench.py quotes it for the first (cold) and the second (warm)
+ * setup of its process. */
+int hda_memory_driver_stats(double out[3], int reset);
 /* gives the calling thread's cached blocks back to the driver (after the library stream has drained): for a host application that
  * shares the device with other processes and is about to sit idle.  The allocator does this by itself when an allocation fails --
  * its own cache first, then the caches of the process's other rank threads -- but it cannot reach another PROCESS's cache. */
