@@ -302,6 +302,7 @@ struct MgrLevelParams {
    AmgParams frelax_amg;                     // f_relaxation.amg block
    IluParams ilu;                            // ILU arguments of this level's ILU components (f_relaxation 32, g_relaxation 16)
    int grelax_type = -1, grelax_sweeps = 1;  // g_relaxation: -1 none, 3/4/6/13/14 hybrid GS, 88 l1-hsgs, 16 ilu
+   int grelax_blocks = 1;                    // row blocks of the hybrid GS global relaxation (as AmgParams::blocks: 1 one block, 0 the setup's choice, V even split)
    // f_relaxation: {gmres: {..., preconditioner: {amg: ...}}} -- a nested Krylov solve on A_FF (reference src/internal/krylov.c,
    // mgr.c:3938-3960).  method: -1 none, 0 pcg, 1 gmres, 2 fgmres, 3 bicgstab; its preconditioner is the level's amg / ilu
    // component (frelax_type 2 / 32) or nothing (fkrylov_precond false).

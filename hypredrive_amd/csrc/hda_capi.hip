@@ -652,6 +652,7 @@ extern "C" int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const
       q.interp_type = levels[l].interp_type; q.restrict_type = levels[l].restrict_type;
       q.frelax_type = levels[l].frelax_type; q.frelax_sweeps = levels[l].frelax_sweeps;
       q.grelax_type = levels[l].grelax_type; q.grelax_sweeps = levels[l].grelax_sweeps;
+      q.grelax_blocks = levels[l].grelax_blocks;
       if (levels[l].frelax_amg) q.frelax_amg = to_params(levels[l].frelax_amg);
       q.ilu.tri_solve = levels[l].ilu_tri_solve; q.ilu.lower_it = levels[l].ilu_lower_it; q.ilu.upper_it = levels[l].ilu_upper_it;
       auto nested = [](const hda_krylov_params &k) {

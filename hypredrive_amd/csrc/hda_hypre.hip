@@ -1635,6 +1635,9 @@ extern "C" HYPRE_Int HYPRE_MGRSetup(HYPRE_Solver s, HYPRE_ParCSRMatrix A, HYPRE_
       q.grelax_type   = at(s->mgr_gsmooth, l, -1);
       q.grelax_sweeps = at(s->mgr_giters, l, 1);
       if (q.grelax_sweeps <= 0) q.grelax_type = -1; // hypre: no global smoothing without sweeps
+      // row blocks of a hybrid Gauss-Seidel global relaxation, as for BoomerAMG's sweeps: HDA_BLOCKS = V, 1 = one block (np = 1), unset = the
+      // setup's choice (one block up to 100 000 rows; announced); across ranks the rank blocks are the blocks
+      q.grelax_blocks = (Comm::world().size > 1) ? 1 : (getenv("HDA_BLOCKS") ? std::max(atoi(getenv("HDA_BLOCKS")), 0) : 0);
       if ((size_t)l < s->mgr_gsolver.size() && s->mgr_gsolver[(size_t)l])
       { // a smoother object handed over with HYPRE_MGRSetGlobalSmootherAtLevel (mgr.c: ILU with its own arguments)
          HYPRE_Solver gs = s->mgr_gsolver[(size_t)l];

@@ -451,11 +451,31 @@ void Mgr::setup_dist(const DCsr &A0, const HaloPlan &hA0, const std::vector<long
       {
          DArray<double> d((size_t)std::max(n, 1));
          const int      t = p.grelax_type == 88 ? 8 : p.grelax_type;
-         if (t == 8 || t == 13 || t == 14) l1_row_norms(*A, 4, d.data());
-         else extract_diag(*A, d.data());
+         // Row blocks (MgrLevelParams::grelax_blocks, as AmgParams::blocks): hypre's hybrid sweep is Gauss-Seidel over a RANK's rows, so V
+         // contiguous blocks on one GPU are what the reference computes at np = V; one block is the sequential sweep (np = 1), level
+         // scheduled -- 2 n^(1/2) .. 3 n^(1/3) launches per sweep, which is what bound BASELINE config 4's stand-in (round 5: 39 ms per
+         // solve at 786 k rows, the level-0 product 0.02 ms).  0 = the setup's choice, announced like BoomerAMG's.
+         int V = multi ? 1 : p.grelax_blocks;
+         if (V == 0) V = amg_auto_blocks(*A);
+         if (V > 1 && n >= V)
+         {
+            std::vector<int> part((size_t)V + 1);
+            for (int q = 0; q <= V; q++) part[(size_t)q] = (int)(((long long)q * n) / V); // hypre_GeneratePartitioning
+            build_gs_plan_blocks(*A, part, L.gs);
+            if (t == 8 || t == 13 || t == 14) l1_row_norms(*A, 4, d.data(), L.gs.blk_part.data(), V);
+            else extract_diag(*A, d.data());
+            if (p.grelax_blocks == 0 && !getenv("HDA_QUIET"))
+               fprintf(stderr, "[hypredrv_amd] MGR setup, level %d: %d row blocks of about %d rows chosen by the setup: the hybrid Gauss-Seidel global relaxation "
+                               "runs as the reference computes it on %d ranks (HDA_BLOCKS=1: one block, the np = 1 sweep)\n", (int)l, V, n / V, V);
+         }
+         else
+         {
+            if (t == 8 || t == 13 || t == 14) l1_row_norms(*A, 4, d.data());
+            else extract_diag(*A, d.data());
+            build_gs_plan(*A, L.gs);
+         }
          L.dinvG.alloc((size_t)std::max(n, 1));
          make_dinv(n, d.data(), 1.0, L.dinvG.data());
-         build_gs_plan(*A, L.gs);
       }
       // coarse operator A_c = R (A P), its ghost list and halo plan, the labels of its rows
       Level                  *next = (l + 1 < prm.levels.size()) ? &lv[l + 1] : nullptr;
@@ -603,11 +623,24 @@ double *Mgr::cycle(int l, const double *f, double *u, bool zero)
       }
       else if (p.grelax_type >= 0)
       {
+         const int t = p.grelax_type;
+         if (L.gs.nblk > 0)
+         { // row blocks (one rank): out of place, the other blocks' values are those of the sweep's start; from a zero guess nothing is read
+            for (int s = 0; s < std::max(p.grelax_sweeps, 1); s++)
+               for (int dir = 0; dir < 2; dir++)
+               {
+                  const bool fwd = dir == 0;
+                  if (fwd ? !(t == 3 || t == 13 || t == 6 || t == 8 || t == 88) : !(t == 4 || t == 14 || t == 6 || t == 8 || t == 88)) continue;
+                  if (zero) gs_sweep_blocks(A, L.gs, L.dinvG.data(), f, nullptr, cur, fwd, true);
+                  else { gs_sweep_blocks(A, L.gs, L.dinvG.data(), f, cur, alt, fwd, false); std::swap(cur, alt); }
+                  zero = false;
+               }
+            return;
+         }
          if (zero) fill((int)std::max(A.ncols, n), 0.0, cur);
          zero = false;
          for (int s = 0; s < std::max(p.grelax_sweeps, 1); s++)
          {
-            const int t = p.grelax_type;
             if (t == 3 || t == 13 || t == 6 || t == 8 || t == 88) { refresh(cur); gs_sweep(A, L.gs, L.dinvG.data(), f, cur, true); }
             if (t == 4 || t == 14 || t == 6 || t == 8 || t == 88) { refresh(cur); gs_sweep(A, L.gs, L.dinvG.data(), f, cur, false); }
          }

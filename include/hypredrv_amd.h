@@ -183,6 +183,9 @@ typedef struct {
    /* cycle shape, read from the LAST level's entry; 0 = default.  mgr_cycle: 1 V, 2 W; positions (reference mgr.c:614-675,
     * hypre's SetFRelaxCycle / SetGlobalSmoothCycle): 1 before the coarse correction, 2 after it, 3 both */
    int               mgr_cycle, mgr_frelax_pos, mgr_gsmooth_pos;
+   /* row blocks of the hybrid Gauss-Seidel global relaxation (g_relaxation 3/4/6/13/14/88) = the reference at np = V (as hda_amg_params.blocks):
+    * 1 = one block (the sequential sweep), V > 1 = hypre's even split of the level's rows, 0 = the setup's choice (one block up to 100 000 rows) */
+   int               grelax_blocks;
 } hda_mgr_level_params;
 int hda_mgr_create(hda_csr_t A, const int *labels, int nlevels, const hda_mgr_level_params *levels,
                    const hda_amg_params *coarsest_amg, int max_iter, hda_amg_t *out);

@@ -2522,6 +2522,8 @@ typedef struct {
    int     *fidx, nf, frelax_type;
    double  *rF, *eF;
    int      frelax_sweeps, grelax_type, grelax_sweeps;
+   int      gnb;      /* row blocks of the global relaxation (orc_mgr_level_params.grelax_blocks), 1 = one block */
+   int64_t *gpart;    /* gnb + 1 row starts */
    int      fkry, fkry_pre; /* nested Krylov F-relaxation: method + 1, preconditioned by famg */
    orc_krylov_params fkp;
 } mgr_level;
@@ -2711,7 +2713,14 @@ orc_precond_mgr(const orc_csr *A0, const int *labels0, int nlevels, const orc_mg
       else if (L->grelax_type >= 0)
       {
          L->l1g = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-         orc_l1_norms(A, (L->grelax_type == 18) ? 1 : 4, L->l1g);
+         L->gnb = lp[l].grelax_blocks > 1 ? lp[l].grelax_blocks : 1;
+         if (L->gnb > 1)
+         { /* hypre_GeneratePartitioning of this level's rows */
+            L->gpart = (int64_t *)malloc(sizeof(int64_t) * (size_t)(L->gnb + 1));
+            for (int q = 0; q <= L->gnb; q++) L->gpart[q] = (int64_t)(((__int128)q * n) / L->gnb);
+            orc_l1_norms_blocks(A, (L->grelax_type == 18) ? 1 : 4, L->gnb, L->gpart, L->l1g);
+         }
+         else orc_l1_norms(A, (L->grelax_type == 18) ? 1 : 4, L->l1g);
       }
       L->f = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
       L->u = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
@@ -2759,7 +2768,10 @@ mgr_global_relax(mgr_level *L, const double *f, double *u)
    if (L->grelax_type == 16 && L->gilu) ilu_iterate(L->gilu, L->A, L->grelax_sweeps, f, u, L->t, L->cor);
    else if (L->grelax_type >= 0)
       for (int s = 0; s < L->grelax_sweeps; s++)
-         orc_relax(L->A, L->l1g, L->grelax_type == 88 ? 8 : L->grelax_type, 1.0, f, u, L->t);
+      {
+         if (L->gnb > 1) orc_relax_blocks(L->A, L->l1g, L->grelax_type == 88 ? 8 : L->grelax_type, 1.0, f, u, L->t, L->gnb, L->gpart);
+         else orc_relax(L->A, L->l1g, L->grelax_type == 88 ? 8 : L->grelax_type, 1.0, f, u, L->t);
+      }
 }
 
 static void
@@ -2836,7 +2848,7 @@ mgr_free(struct orc_mgr *M)
       if (L->famg) orc_amg_free(L->famg);
       if (L->filu) orc_ilu_free(L->filu);
       if (L->Aff) orc_csr_free(L->Aff);
-      free(L->fidx); free(L->rF); free(L->eF);
+      free(L->fidx); free(L->rF); free(L->eF); free(L->gpart);
    }
    orc_csr_free(M->Ac);
    orc_amg_free(M->camg);

@@ -212,6 +212,10 @@ typedef struct {
    /* cycle shape, read from the LAST level's entry; 0 = default.  mgr_cycle: 1 V, 2 W; positions (reference mgr.c:614-675,
     * hypre's SetFRelaxCycle / SetGlobalSmoothCycle): 1 before the coarse correction, 2 after it, 3 both */
    int               mgr_cycle, mgr_frelax_pos, mgr_gsmooth_pos;
+   /* row blocks of the hybrid Gauss-Seidel global relaxation (g_relaxation 3/4/6/13/14/88) = the reference at np = V: Gauss-Seidel inside
+    * a block, Jacobi across blocks with hypre's option-4 l1 divisor; V <= 1: one block (the sequential sweep, np = 1); V > 1: hypre's
+    * even split of the level's rows (start q = floor(q n / V)) */
+   int               grelax_blocks;
 } orc_mgr_level_params;
 orc_amg *orc_precond_mgr(const orc_csr *A, const int *labels, int nlevels, const orc_mgr_level_params *levels,
                          const orc_amg_params *coarsest_amg, int max_iter);

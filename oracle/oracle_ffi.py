@@ -47,7 +47,7 @@ class MgrLevelParams(C.Structure):
                 ("coarse_ilu_max_iter", C.c_int), ("coarse_ilu_tri_solve", C.c_int), ("coarse_ilu_lower_it", C.c_int), ("coarse_ilu_upper_it", C.c_int),
                 ("frelax_krylov", C.c_int), ("frelax_krylov_precond", C.c_int), ("frelax_kp", KrylovParams),
                 ("coarse_krylov", C.c_int), ("coarse_krylov_precond", C.c_int), ("coarse_kp", KrylovParams),
-                ("mgr_cycle", C.c_int), ("mgr_frelax_pos", C.c_int), ("mgr_gsmooth_pos", C.c_int)]
+                ("mgr_cycle", C.c_int), ("mgr_frelax_pos", C.c_int), ("mgr_gsmooth_pos", C.c_int), ("grelax_blocks", C.c_int)]
 
 
 def build(force=False):
@@ -625,6 +625,7 @@ def mgr_level_list(levels):
         arr[k].frelax_sweeps = lv.get("f_sweeps", 1)
         arr[k].grelax_type = MGR_GRELAX[lv.get("g_relaxation", "none")]
         arr[k].grelax_sweeps = lv.get("g_sweeps", 1)
+        arr[k].grelax_blocks = lv.get("g_blocks", 1)   # row blocks of the hybrid Gauss-Seidel global relaxation (the reference at np = V)
         if lv.get("f_amg") is not None:   # AmgParams of 'f_relaxation: {amg: {...}}'
             keep.append(lv["f_amg"])
             arr[k].frelax_amg = C.pointer(lv["f_amg"])

@@ -1224,6 +1224,9 @@ MGR_CASES = [
     [dict(f_dofs=[2], prolongation_type="l1-jacobi", restriction_type="columped", f_relaxation="l1-jacobi", f_sweeps=2)],
     [dict(f_dofs=[2])],
     [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="l1-hsgs", restriction_type="columped")],   # ex3.yml
+    # the same with the global relaxation on row blocks (round 5): hybrid l1 Gauss-Seidel as the reference computes it at np = 3 / 5
+    [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="l1-hsgs", restriction_type="columped", g_blocks=3)],
+    [dict(f_dofs=[2], prolongation_type="jacobi", g_relaxation="l1-hfgs", g_blocks=5), dict(f_dofs=[1], g_relaxation="h-bgs", g_sweeps=2, g_blocks=2)],
     [dict(f_dofs=[1, 2], prolongation_type="jacobi", g_relaxation="h-fgs", g_sweeps=2)],
     [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="ilu", restriction_type="columped")],       # ex4.yml / ex5-mgr.yml
     [dict(f_dofs=[0], prolongation_type="jacobi", f_relaxation="amg")],                                                      # AMG on A_FF (diffusive field eliminated first)

@@ -734,3 +734,24 @@ def test_standard_interp_properties(orc):
     # row 1: a-hat_11 = 2 - (-1)(-1)/2 = 1.5, a-hat_10 = -1, a-hat_13 = -(-1/2)(-1) = -0.5; all of the stencil is in C-hat: alfa = 1/1.5
     assert np.allclose(Pt.val[Pt.rowptr[1]:Pt.rowptr[2]], [1.0 / 1.5, 0.5 / 1.5])
     assert np.allclose(Pt.val[Pt.rowptr[2]:Pt.rowptr[3]], [0.5 / 1.5, 1.0 / 1.5])
+
+
+def test_mgr_global_relaxation_on_row_blocks(orc):
+    """orc_mgr_level_params.grelax_blocks (round 5): the hybrid Gauss-Seidel global relaxation of an MGR level on V row blocks = the
+    reference at np = V.  One block is the sequential sweep bit for bit; with every row a block of its own the sweep is the Jacobi sweep
+    with hypre's option-4 l1 divisor (what orc_relax_blocks is anchored on), a different -- still convergent -- preconditioner."""
+    S, labels = three_field_system(9, seed=2)
+    A = orc.Csr.from_scipy(S)
+    b = np.ones(S.shape[0])
+    base = [dict(f_dofs=[2], prolongation_type="jacobi"), dict(f_dofs=[1], g_relaxation="l1-hsgs", restriction_type="columped")]
+    r = np.random.default_rng(3).standard_normal(S.shape[0])
+    z0 = orc.MgrPrecond(A, labels, base).vcycle(r)
+    one = [dict(base[0]), dict(base[1], g_blocks=1)]
+    assert np.array_equal(orc.MgrPrecond(A, labels, one).vcycle(r), z0)
+    nrows1 = int((np.asarray(labels) != 2).sum())   # rows of the second reduction level
+    for V in (3, nrows1):
+        lev = [dict(base[0]), dict(base[1], g_blocks=V)]
+        M = orc.MgrPrecond(A, labels, lev)
+        assert not np.array_equal(M.vcycle(r), z0)
+        res = orc.gmres(A, b, M)
+        assert res["converged"] and res["iters"] <= 3 * orc.gmres(A, b, orc.MgrPrecond(A, labels, base))["iters"]
