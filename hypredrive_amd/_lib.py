@@ -534,7 +534,7 @@ class Mgr:
             arr[k].frelax_sweeps = lv.get("f_sweeps", 1)
             arr[k].grelax_type = MGR_GRELAX[lv.get("g_relaxation", "none")]
             arr[k].grelax_sweeps = lv.get("g_sweeps", 1)
-        arr[k].grelax_blocks = lv.get("g_blocks", 1)   # row blocks of the hybrid Gauss-Seidel global relaxation (the reference at np = V)
+            arr[k].grelax_blocks = lv.get("g_blocks", 1)   # row blocks of the hybrid Gauss-Seidel global relaxation (the reference at np = V)
             if lv.get("f_amg") is not None:   # AmgParams of 'f_relaxation: {amg: {...}}'
                 self._keep.append(lv["f_amg"])
                 arr[k].frelax_amg = C.pointer(lv["f_amg"])
