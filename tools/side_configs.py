@@ -84,7 +84,8 @@ def gmres_mgr(hh, cells=512, steps=3, warmup=1, oracle_cells=24, with_oracle=Tru
     by = 12.0 * nnz + 4.0 * (N + 1) + 16.0 * N
     out = {"what": "BASELINE config 4 on STAND-IN DATA: GMRES(30) + MGR with the solver / preconditioner block of examples/ex3.yml:11-23 on the "
                    f"three-field model system of tools/make_threefield.py at {cells} x {cells} cells (compflow6k is not in the reference tree); "
-                   "parity unpinned (device == oracle only)",
+                   "the l1-hsgs global relaxation runs on the row blocks the setup announces on stderr (the reference at np = V, as BoomerAMG's "
+                   "hybrid sweeps; HDA_BLOCKS=1: the sequential np = 1 sweep, 39 ms per solve); parity unpinned (device == oracle only)",
            "rows": N, "nnz": nnz, "iters": last["iters"], "converged": last["converged"], "final_rel": last["final_rel"],
            "ms_per_step": ms, "value": N / (ms * 1e-3), "unit": "DOF/s", "setup_ms": setup[1], "setup_cold_ms": setup[0],
            "dominant_kernel": {"kernel": "level-0 product of the GMRES iteration (K1)", "bytes_per_launch": by, "avg_ms": k1_ms, "launches": k1_n,
