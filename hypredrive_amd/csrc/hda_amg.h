@@ -88,6 +88,7 @@ struct GsPlan {
    DArray<int> blk_part;    // nblk + 1 row starts
    DArray<int> blk_lvl_ptr; // nblk + 1: block q's levels are blk_lvl[blk_lvl_ptr[q] .. blk_lvl_ptr[q + 1]]
    DArray<int> blk_lvl;     // first position of every (block, level); one past the end = nrows
+   DArray<int> group_of_pos; // exclusive scan of the (block, level) group starts over the positions (n + 1): position q is in group [q + 1] - 1
    int         blk_max_levels = 0;
    double      blk_mean_rows_per_level = 0.0;
    // sweep-order copy of the operator (big levels): the rows in perm order, entries contiguous, a column inside the row's block named

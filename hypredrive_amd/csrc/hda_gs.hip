@@ -12,6 +12,9 @@
 // ramp-up/ramp-down of the wavefront (and whole coarse grids) do not pay one launch per level.
 #include "hda_amg.h"
 
+#include <cstring> // rocprim's texture iterator calls memset on the host
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <algorithm>
 #include <mutex>
 
@@ -85,11 +88,85 @@ __global__ __launch_bounds__(256) void k_gs_expand(int nf, const int *__restrict
 }
 
 // ascending row ids inside every level: deterministic launch contents and better locality
-__global__ __launch_bounds__(256) void k_gs_mark(int n, const int *__restrict__ perm, const int *__restrict__ lvl_of_pos,
+// (the level of a frontier position = the interval of lvl_ptr it lies in: nlev + 1 offsets, found by bisection)
+__global__ __launch_bounds__(256) void k_gs_mark(int n, const int *__restrict__ perm, const int *__restrict__ lvl_ptr, int nlev,
                                                  int *__restrict__ level_of_row)
 {
    const int q = blockIdx.x * 256 + threadIdx.x;
-   if (q < n) level_of_row[perm[q]] = lvl_of_pos[q];
+   if (q >= n) return;
+   int a = 0, b = nlev;
+   while (b - a > 1)
+   {
+      const int m = (a + b) >> 1;
+      if (lvl_ptr[m] <= q) a = m;
+      else b = m;
+   }
+   level_of_row[perm[q]] = a;
+}
+// rows in the order (block, level, row): 64-bit keys for a stable radix sort, then the boundaries of the (block, level) groups
+__global__ __launch_bounds__(256) void k_gs_keys(int n, const int *__restrict__ level_of_row, const int *__restrict__ part, int nb, int nlev,
+                                                 unsigned long long *__restrict__ keys, int *__restrict__ rows)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   int q = 0;
+   if (part)
+   {
+      int a = 0, b = nb;
+      while (b - a > 1)
+      {
+         const int m = (a + b) >> 1;
+         if (part[m] <= i) a = m;
+         else b = m;
+      }
+      q = a;
+   }
+   keys[i] = (unsigned long long)q * (unsigned long long)nlev + (unsigned long long)level_of_row[i];
+   rows[i] = i;
+}
+__global__ __launch_bounds__(256) void k_gs_group_flags(int n, const unsigned long long *__restrict__ keys, int *__restrict__ flag)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) flag[q] = (q == 0 || keys[q] != keys[q - 1]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_gs_group_starts(int n, const int *__restrict__ flag, const int *__restrict__ gidx,
+                                                         const unsigned long long *__restrict__ keys, int *__restrict__ start,
+                                                         unsigned long long *__restrict__ gkey)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n && flag[q]) { start[gidx[q]] = q; gkey[gidx[q]] = keys[q]; }
+}
+// perm <- the rows sorted by (block, level, row) (part == nullptr: by (level, row)); gstart / gkey: first position and key of every
+// non-empty (block, level) group, on the host (their number is levels x blocks, small); gidx (device, n): group of every position
+static void gs_order_rows(int n, const DArray<int> &level_of_row, const int *d_part, int nb, int nlev, DArray<int> &perm, std::vector<int> &gstart,
+                          std::vector<unsigned long long> &gkey, DArray<int> *gidx_out = nullptr)
+{
+   DArray<unsigned long long> keys((size_t)n), skeys((size_t)n);
+   DArray<int>                rows((size_t)n), flag((size_t)n + 1), gidx((size_t)n + 1);
+   k_gs_keys<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, level_of_row.data(), d_part, nb, std::max(nlev, 1), keys.data(), rows.data());
+   int bits = 1;
+   while (bits < 64 && ((unsigned long long)std::max(nb, 1) * (unsigned long long)std::max(nlev, 1)) >> bits) bits++;
+   size_t tmp_bytes = 0;
+   HDA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.data(), skeys.data(), rows.data(), perm.data(), (size_t)n, 0, bits, STREAM));
+   DArray<char> tmp(std::max<size_t>(tmp_bytes, 1));
+   HDA_HIP(rocprim::radix_sort_pairs(tmp.data(), tmp_bytes, keys.data(), skeys.data(), rows.data(), perm.data(), (size_t)n, 0, bits, STREAM));
+   flag.zero();
+   k_gs_group_flags<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, skeys.data(), flag.data());
+   exclusive_scan(n, flag.data(), gidx.data(), nullptr);
+   int ng = 0;
+   HDA_HIP(hipMemcpyAsync(&ng, gidx.data() + n, sizeof(int), hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   DArray<int>                dstart((size_t)std::max(ng, 1));
+   DArray<unsigned long long> dkey((size_t)std::max(ng, 1));
+   k_gs_group_starts<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, flag.data(), gidx.data(), skeys.data(), dstart.data(), dkey.data());
+   gstart.resize((size_t)ng);
+   gkey.resize((size_t)ng);
+   if (ng)
+   {
+      dstart.download(gstart.data(), (size_t)ng);
+      dkey.download(gkey.data(), (size_t)ng);
+   }
+   if (gidx_out) *gidx_out = std::move(gidx); // (exclusive scan of the flags: position q belongs to group gidx[q + 1] - 1)
 }
 
 __global__ __launch_bounds__(256) void k_gs_rowspan(int n, const int *__restrict__ perm, const int *__restrict__ rp, int *__restrict__ rbeg,
@@ -122,6 +199,12 @@ __global__ __launch_bounds__(256) void k_gs_inverse(int n, const int *__restrict
    const int i = perm[q];
    pos_of[i]   = q;
    len4[q]     = (rp[i + 1] - rp[i] + 3) >> 2;
+}
+// w[g] = max over the positions q of group g of len[q]; gscan = exclusive scan of the group-start flags (position q is in group gscan[q + 1] - 1)
+__global__ __launch_bounds__(256) void k_gs_group_max(int n, const int *__restrict__ gscan, const int *__restrict__ len, int *__restrict__ w)
+{
+   const int q = blockIdx.x * 256 + threadIdx.x;
+   if (q < n) atomicMax(&w[gscan[q + 1] - 1], len[q]);
 }
 // the sweep-order copy keeps the diagonal entry apart (s_aii): a 17-entry row of a coarse level is then four chunks, not five, and the
 // barrier-free kernel gives it four lanes instead of eight
@@ -237,14 +320,20 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
    if (plan.blk_max_levels + 1 > 2700) return; // (three tables of that length + the ring within 64 KB of LDS)
    DArray<int> len4((size_t)n), pos_of((size_t)n), dummy((size_t)n);
    k_gs_inverse<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), A.rowptr.data(), pos_of.data(), len4.data());
-   const std::vector<int> hl = len4.to_host();
-   std::vector<int>       cb((size_t)ng + 1, 0), w((size_t)ng, 0);
-   long long              total = 0;
+   // widest row of every (block, level) group: a segmented maximum on the device (the groups of the positions come with the plan)
+   std::vector<int> w((size_t)ng, 0);
+   {
+      HDA_REQUIRE(plan.group_of_pos.size() >= (size_t)n + 1, "Gauss-Seidel plan: group table missing");
+      DArray<int> dw((size_t)ng);
+      dw.zero();
+      k_gs_group_max<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.group_of_pos.data(), len4.data(), dw.data());
+      dw.download(w.data(), (size_t)ng);
+   }
+   std::vector<int> cb((size_t)ng + 1, 0);
+   long long        total = 0;
    for (int g = 0; g < ng; g++)
    {
-      int mx = 0;
-      for (int q = plan.h_blk_lvl[(size_t)g]; q < plan.h_blk_lvl[(size_t)g + 1]; q++) mx = std::max(mx, hl[(size_t)q]);
-      w[(size_t)g]  = mx;
+      const int mx = w[(size_t)g];
       cb[(size_t)g] = (int)total;
       total += (long long)mx * (plan.h_blk_lvl[(size_t)g + 1] - plan.h_blk_lvl[(size_t)g]);
       if (total >= (1LL << 29)) return; // 32-bit chunk offsets
@@ -322,7 +411,9 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
 
 // dependency levels of the symmetrised pattern (restricted to the row blocks of part when given): rows in discovery order in
 // plan.perm, level offsets in plan.lvl_ptr; returns the level of every row (host)
-static std::vector<int> gs_levels(const DCsr &A, GsPlan &plan, const int *d_part, int nb)
+// dependency level of every row (device array); plan.lvl_ptr gets the global level sizes (Kahn's algorithm, one launch and one
+// counter read-back per level; everything of size n stays on the device since round 5)
+static DArray<int> gs_levels(const DCsr &A, GsPlan &plan, const int *d_part, int nb)
 {
    const int n = A.nrows;
    DCsr T;
@@ -346,13 +437,10 @@ static std::vector<int> gs_levels(const DCsr &A, GsPlan &plan, const int *d_part
    }
    HDA_REQUIRE(done == n, "Gauss-Seidel level scheduling did not reach every row");
    plan.nlev = (int)plan.lvl_ptr.size() - 1;
-   std::vector<int> lvl_of_pos((size_t)n);
-   for (int L = 0; L < plan.nlev; L++)
-      for (int q = plan.lvl_ptr[(size_t)L]; q < plan.lvl_ptr[(size_t)L + 1]; q++) lvl_of_pos[(size_t)q] = L;
-   DArray<int> dpos, lrow((size_t)n);
-   dpos.upload(lvl_of_pos.data(), (size_t)n);
-   k_gs_mark<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), dpos.data(), lrow.data());
-   return lrow.to_host();
+   DArray<int> dptr, lrow((size_t)n);
+   dptr.upload(plan.lvl_ptr.data(), plan.lvl_ptr.size());
+   k_gs_mark<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.perm.data(), dptr.data(), plan.nlev, lrow.data());
+   return lrow;
 }
 
 void build_gs_plan(const DCsr &A, GsPlan &plan)
@@ -363,11 +451,13 @@ void build_gs_plan(const DCsr &A, GsPlan &plan)
    plan.perm.alloc((size_t)std::max(n, 1));
    plan.lvl_ptr.assign(1, 0);
    if (n == 0) return;
-   // level of every row -> stable counting order = ascending rows inside each level
+   // level of every row -> rows sorted by (level, row): ascending rows inside each level (stable radix sort on the device)
    {
-      std::vector<int> hl = gs_levels(A, plan, nullptr, 0), cursor(plan.lvl_ptr.begin(), plan.lvl_ptr.end() - 1), hp((size_t)n);
-      for (int i = 0; i < n; i++) hp[(size_t)cursor[(size_t)hl[(size_t)i]]++] = i;
-      plan.perm.upload(hp.data(), (size_t)n);
+      const DArray<int>               lrow = gs_levels(A, plan, nullptr, 0);
+      std::vector<int>                gstart;
+      std::vector<unsigned long long> gkey;
+      gs_order_rows(n, lrow, nullptr, 0, plan.nlev, plan.perm, gstart, gkey);
+      HDA_REQUIRE((int)gstart.size() == plan.nlev, "Gauss-Seidel plan: a dependency level without rows");
    }
    // launch segments: big levels alone, runs of small levels fused into one workgroup
    const int small = 512;
@@ -408,28 +498,33 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
       plan.blk_lvl.upload(bl.data(), bl.size());
       return;
    }
-   const std::vector<int> hl = gs_levels(A, plan, plan.blk_part.data(), nb);
-   std::vector<int>       hp((size_t)n), cnt;
-   for (int q = 0; q < nb; q++)
+   for (int q = 0; q < nb; q++) HDA_REQUIRE(part[(size_t)q] <= part[(size_t)q + 1], "row blocks must ascend");
+   // rows sorted by (block, level, row) on the device (round 5: the host made this order from downloaded level numbers, O(n) loops at
+   // 16.7 M rows); what comes back are the first positions of the (block, level) groups -- blocks x levels of them
    {
-      const int lo = part[(size_t)q], hi = part[(size_t)q + 1];
-      HDA_REQUIRE(lo <= hi, "row blocks must ascend");
-      int nl = 0;
-      for (int i = lo; i < hi; i++) nl = std::max(nl, hl[(size_t)i] + 1);
-      cnt.assign((size_t)nl + 1, 0);
-      for (int i = lo; i < hi; i++) cnt[(size_t)hl[(size_t)i] + 1]++;
-      for (int L = 0; L < nl; L++)
-      {
-         cnt[(size_t)L + 1] += cnt[(size_t)L];
-         bl.push_back(lo + cnt[(size_t)L]);
+      const DArray<int>               lrow = gs_levels(A, plan, plan.blk_part.data(), nb);
+      std::vector<int>                gstart;
+      std::vector<unsigned long long> gkey;
+      gs_order_rows(n, lrow, plan.blk_part.data(), nb, plan.nlev, plan.perm, gstart, gkey, &plan.group_of_pos);
+      const unsigned long long nl = (unsigned long long)std::max(plan.nlev, 1);
+      size_t                   g  = 0;
+      for (int q = 0; q < nb; q++)
+      { // a block's levels 0 .. nl_q - 1 are all present (a row of level L has a neighbour of level L - 1 in its block)
+         int nlq = 0;
+         while (g < gstart.size() && (int)(gkey[g] / nl) == q)
+         {
+            HDA_REQUIRE((int)(gkey[g] % nl) == nlq, "Gauss-Seidel plan: a block skips a dependency level");
+            bl.push_back(gstart[g]);
+            nlq++;
+            g++;
+         }
+         bl_ptr[(size_t)q + 1] = (int)bl.size();
+         plan.blk_max_levels   = std::max(plan.blk_max_levels, nlq);
       }
-      for (int i = lo; i < hi; i++) hp[(size_t)(lo + cnt[(size_t)hl[(size_t)i]]++)] = i; // ascending rows inside a level
-      bl_ptr[(size_t)q + 1]  = (int)bl.size();
-      plan.blk_max_levels = std::max(plan.blk_max_levels, nl);
+      HDA_REQUIRE(g == gstart.size(), "Gauss-Seidel plan: (block, level) groups out of order");
    }
    bl.push_back(n);
    plan.blk_mean_rows_per_level = (double)n / (double)std::max<size_t>(bl.size() - 1, 1);
-   plan.perm.upload(hp.data(), (size_t)n);
    plan.blk_lvl_ptr.upload(bl_ptr.data(), bl_ptr.size());
    plan.blk_lvl.upload(bl.data(), bl.size());
    plan.h_blk_lvl     = bl;
