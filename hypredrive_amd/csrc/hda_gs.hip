@@ -409,15 +409,70 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
               4.0 * (double)total / std::max(A.nnz, 1), plan.ring_lpr, plan.ring_nt);
 }
 
-// dependency levels of the symmetrised pattern (restricted to the row blocks of part when given): rows in discovery order in
-// plan.perm, level offsets in plan.lvl_ptr; returns the level of every row (host)
-// dependency level of every row (device array); plan.lvl_ptr gets the global level sizes (Kahn's algorithm, one launch and one
-// counter read-back per level; everything of size n stays on the device since round 5)
+// Row blocks: the dependency levels of a block concern that block alone, so ONE workgroup runs Kahn's algorithm for its block from
+// start to end -- frontier after frontier with workgroup barriers, no launch and no host read-back per level (round 5: the global
+// level loop below made ~900 launch + read-back round trips over the series-B hierarchy at 256^3, 30-70 ms per operator level
+// whatever its size).  lvl[i] = dependency level of row i inside its block; nlev[b] = levels of block b.  fr0 / fr1: frontier
+// ping-pong, a block uses the slice [part[b], part[b + 1]) of each.
+__global__ __launch_bounds__(1024) void k_gs_levels_blocks(int n, const int *__restrict__ part, const int *__restrict__ rp, const int *__restrict__ cj,
+                                                           const int *__restrict__ trp, const int *__restrict__ tcj, int *indeg, int *fr0, int *fr1,
+                                                           int *__restrict__ lvl, int *__restrict__ nlev)
+{
+   __shared__ int cnt[2];
+   const int b = blockIdx.x, lo = part[b], hi = part[b + 1], tid = threadIdx.x;
+   if (tid < 2) cnt[tid] = 0;
+   __syncthreads();
+   int *cur = fr0 + lo, *nxt = fr1 + lo;
+   for (int i = lo + tid; i < hi; i += 1024)
+   {
+      int d = 0;
+      for_each_sym_neighbour(i, n, rp, cj, trp, tcj, [&](int j) { d += (j < i); }, lo, hi);
+      indeg[i] = d;
+      if (d == 0) cur[atomicAdd(&cnt[0], 1)] = i;
+   }
+   __syncthreads();
+   int level = 0, c = 0;
+   for (;;)
+   {
+      const int nf = cnt[c];
+      if (nf == 0) break;
+      for (int q = tid; q < nf; q += 1024)
+      {
+         const int i = cur[q];
+         lvl[i]      = level;
+         for_each_sym_neighbour(i, n, rp, cj, trp, tcj, [&](int j) {
+            if (j > i && atomicSub(&indeg[j], 1) == 1) nxt[atomicAdd(&cnt[c ^ 1], 1)] = j;
+         }, lo, hi);
+      }
+      __syncthreads();           // the next frontier is complete (and visible: one workgroup, one CU)
+      if (tid == 0) cnt[c] = 0;  // (this counter is the one the level after next fills)
+      c ^= 1;
+      int *t = cur; cur = nxt; nxt = t;
+      level++;
+      __syncthreads();
+   }
+   if (tid == 0) nlev[b] = level;
+}
+
+// dependency levels of the symmetrised pattern (restricted to the row blocks of part when given): dependency level of every row
+// (device array); one block: plan.lvl_ptr gets the level sizes (Kahn's algorithm with one launch and one counter read-back per level);
+// row blocks: one workgroup per block (k_gs_levels_blocks), plan.nlev = the most levels any block has.  Everything of size n stays on
+// the device since round 5.
 static DArray<int> gs_levels(const DCsr &A, GsPlan &plan, const int *d_part, int nb)
 {
    const int n = A.nrows;
    DCsr T;
    transpose(A, T); // rows of T = columns of A; only rows < n are consulted
+   if (d_part && nb > 0)
+   {
+      DArray<int> indeg((size_t)n), fr0((size_t)n), fr1((size_t)n), lrow((size_t)n), dnl((size_t)nb);
+      k_gs_levels_blocks<<<nb, 1024, 0, STREAM>>>(n, d_part, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(), fr0.data(),
+                                                  fr1.data(), lrow.data(), dnl.data());
+      const std::vector<int> hn = dnl.to_host();
+      plan.nlev = 0;
+      for (int v : hn) plan.nlev = std::max(plan.nlev, v);
+      return lrow;
+   }
    DArray<int> indeg((size_t)n), counter(1);
    counter.zero();
    k_gs_indeg<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(),
