@@ -10,8 +10,6 @@
 #include "hda_amg.h"
 #include "hda_sort.h"
 
-#include <cstring> // rocprim's texture iterator calls memset on the host
-#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -1962,24 +1960,6 @@ __global__ __launch_bounds__(256) void k_spgemm_gather(int r0, int r1, const lon
       cv[w]  = hval[o + h];
       w++;
    }
-}
-
-// every row of C column-sorted, whatever its length: one segmented radix sort (columns of a row are distinct: the order is unique)
-static void sort_rows_segmented(DCsr &C)
-{
-   if (C.nrows == 0 || C.nnz == 0) return;
-   DArray<int>    k2((size_t)C.nnz);
-   DArray<double> v2((size_t)C.nnz);
-   int            bits = 1;
-   while (bits < 31 && (C.ncols >> bits)) bits++;
-   size_t tmp_bytes = 0;
-   HDA_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, C.col.data(), k2.data(), C.val.data(), v2.data(), (unsigned)C.nnz, (unsigned)C.nrows,
-                                               C.rowptr.data(), C.rowptr.data() + 1, 0, bits, STREAM));
-   DArray<char> tmp(std::max<size_t>(tmp_bytes, 1));
-   HDA_HIP(rocprim::segmented_radix_sort_pairs(tmp.data(), tmp_bytes, C.col.data(), k2.data(), C.val.data(), v2.data(), (unsigned)C.nnz, (unsigned)C.nrows,
-                                               C.rowptr.data(), C.rowptr.data() + 1, 0, bits, STREAM));
-   C.col = std::move(k2);
-   C.val = std::move(v2);
 }
 
 static long long spgemm_slot_budget()
