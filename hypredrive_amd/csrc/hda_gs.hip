@@ -557,10 +557,13 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
    // rows sorted by (block, level, row) on the device (round 5: the host made this order from downloaded level numbers, O(n) loops at
    // 16.7 M rows); what comes back are the first positions of the (block, level) groups -- blocks x levels of them
    {
+      HDA_TRACE("  gs plan: start n=%d", n);
       const DArray<int>               lrow = gs_levels(A, plan, plan.blk_part.data(), nb);
+      HDA_TRACE("  gs plan: levels done");
       std::vector<int>                gstart;
       std::vector<unsigned long long> gkey;
       gs_order_rows(n, lrow, plan.blk_part.data(), nb, plan.nlev, plan.perm, gstart, gkey, &plan.group_of_pos);
+      HDA_TRACE("  gs plan: rows ordered");
       const unsigned long long nl = (unsigned long long)std::max(plan.nlev, 1);
       size_t                   g  = 0;
       for (int q = 0; q < nb; q++)
@@ -585,14 +588,18 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
    plan.h_blk_lvl     = bl;
    plan.h_blk_lvl_ptr = bl_ptr;
    gs_row_spans(A, plan);
+   HDA_TRACE("  gs plan: tables uploaded");
    const int sorted_min = getenv("HDA_GS_SORTED_MIN") ? atoi(getenv("HDA_GS_SORTED_MIN")) : 2000; // (read per plan: the tests move it)
    if (n >= sorted_min && plan.blk_max_levels + 1 <= 12 * 1024) gs_sorted_copy(A, plan); // (the kernel keeps a block's level offsets in LDS: 48 KB)
+   HDA_TRACE("  gs plan: sweep-order copy");
    if (plan.sorted && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0)) gs_ring_copy(A, plan);
+   HDA_TRACE("  gs plan: level-wise copy");
    if (plan.sorted)
    {
       if (!plan.s_x0.size()) plan.s_x0.alloc((size_t)n);
       gs_free_plan(plan, n);
    }
+   HDA_TRACE("  gs plan: barrier-free plan");
    if (getenv("HDA_VERBOSE"))
       fprintf(stderr, "[hda] block Gauss-Seidel plan: n=%d nnz=%d (%.1f per row), %d blocks, dependency levels per block: max %d, mean %.0f (%.0f rows per level)%s\n",
               n, A.nnz, A.avg_row(), nb, plan.blk_max_levels, (double)(bl.size() - 1) / nb, (double)n / std::max<size_t>(bl.size() - 1, 1),
