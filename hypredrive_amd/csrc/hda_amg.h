@@ -98,6 +98,10 @@ struct GsPlan {
    mutable DArray<double> s_aii; // diagonal entries in sweep order (the sweep-order copy keeps them apart from the rows' chunks)
    mutable DArray<double> s_val;
    mutable DArray<double> s_x, s_b, s_d; // the sweep's iterate, right-hand side and divisors in sweep order
+   // what s_d / s_b hold (round 5): the divisors of a level do not change between sweeps and the right-hand side of a level is the same
+   // for every sweep of one cycle, so their sweep-order copies are made once (per divisor array / per cycle) instead of per sweep
+   mutable const double  *sd_src = nullptr, *sb_src = nullptr;
+   mutable const double  *to_b = nullptr, *to_d = nullptr; // what the next k_gs_to_sweep_order gathers (nullptr: s_b / s_d are current)
    mutable bool           sorted = false;
    // level-wise form of that copy (k_gs_blocks_ring): the rows of one (block, level) all take the level's widest row's number of
    // 4-entry chunks, so a row's chunks sit at first chunk of the level + row * width -- no row pointer to chase; r_cb / r_w per
@@ -120,8 +124,9 @@ void gs_sweep(const DCsr &A, const GsPlan &plan, const double *dinv, const doubl
 // row-block form: xout = sweep(xin); the other blocks' values are read from xin, which the sweep leaves alone (xin != xout).
 // zero_in: the input is the zero vector and is not read (xin may be null or xout)
 void gs_free_check(); // throws if a barrier-free block sweep hit its spin limit since the last call (Krylov solves call it at their end)
+// b_unchanged: the caller vouches that b (the same array, the same contents) was the right-hand side of the previous sweep on this plan
 void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, const double *xin, double *xout,
-                     bool forward, bool zero_in);
+                     bool forward, bool zero_in, bool b_unchanged = false);
 
 // block-Jacobi ILU(0) of a rank's diagonal block (hda_ilu.hip)
 class Ilu {
@@ -184,6 +189,7 @@ struct AmgLevel {
    std::vector<int> blk_part; // row blocks of this level (AmgParams::blocks): V + 1 row starts; empty = one block
    DArray<double> dinv_down, dinv_up; // relax_weight / l1 (or / a_ii), per cycle direction
    DArray<double> f, u, u2, t;
+   bool           gs_b_seen = false; // a block sweep of this cycle has already put this level's right-hand side into sweep order
    // row-partitioned runs: ghost refresh plans for the inputs of A_l, P_l, R_l and the
    // length every level-l work vector needs ([owned | largest ghost tail])
    HaloPlan hA, hP, hR;

@@ -2396,6 +2396,13 @@ static bool is_l1_gs_type(int t) { return t == 8 || t == 13 || t == 14; }
 // divisor of the sweep: l1 row sums (18), hypre's "option 4" l1 (13/14/8: a_ii plus half the
 // off-rank row sum) or the plain diagonal (0/7/3/4/6).  Extracting the diagonal is option 4
 // with the ghost part ignored, which is what columns < nrows give.
+// two relaxation types with the same divisors (build_dinv below): the up sweep then uses the down sweep's array -- one pass over A
+// less per level in the setup, and on row blocks one sweep-order copy of the divisors serves both (GsPlan::sd_src)
+static bool same_divisors(int t1, int t2)
+{
+   auto cls = [](int t) { return t == 18 ? 1 : is_l1_gs_type(t) ? 2 : 0; };
+   return cls(t1) == cls(t2);
+}
 static void build_dinv(const DCsr &A, int relax_type, double weight, DArray<double> &dinv, const int *d_part = nullptr, int nblk = 0)
 {
    DArray<double> d((size_t)std::max(A.nrows, 1));
@@ -2446,13 +2453,14 @@ void Amg::build_smoother_data(int l)
    {
       if (!lv.gs.built) build_gs_plan_blocks(Al, lv.blk_part, lv.gs);
       build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down, lv.gs.blk_part.data(), nblk);
-      if (prm.relax_up == prm.relax_down) lv.dinv_up.copy_from(lv.dinv_down);
+      if (same_divisors(prm.relax_up, prm.relax_down)) lv.dinv_up.copy_from(lv.dinv_down);
       else build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up, lv.gs.blk_part.data(), nblk);
+      lv.gs.sd_src = lv.gs.sb_src = nullptr; // new divisors, perhaps at the old address
    }
    else
    {
       build_dinv(Al, prm.relax_down, prm.relax_weight, lv.dinv_down);
-      if (prm.relax_up == prm.relax_down) lv.dinv_up.copy_from(lv.dinv_down); // same divisors: a copy, not a second pass over A
+      if (same_divisors(prm.relax_up, prm.relax_down)) lv.dinv_up.copy_from(lv.dinv_down); // same divisors: a copy, not a second pass over A
       else build_dinv(Al, prm.relax_up, prm.relax_weight, lv.dinv_up);
       if (gs && !lv.gs.built) build_gs_plan(Al, lv.gs);
    }
@@ -3145,17 +3153,22 @@ void Amg::relax(int l, int type, const double *dinv, const double *b, double *&c
       if (g.nblk > 0)
       { // row blocks: the sweep reads the other blocks' old values from its input and writes its output elsewhere; from a zero
         // guess nothing is read and the result can land in cur itself
+         // (the level's right-hand side is the same array with the same contents for every sweep of one cycle: its sweep-order copy
+         //  is made by the first of them only -- cycle() clears the flags)
+         AmgLevel  &lvb  = levels[(size_t)l];
+         const bool same = lvb.gs_b_seen;
+         lvb.gs_b_seen   = true;
          if (type == 3 || type == 13 || type == 4 || type == 14)
          {
             const bool fwd = (type == 3 || type == 13);
-            if (zero_guess) gs_sweep_blocks(A, g, dinv, b, nullptr, cur, fwd, true);
-            else { gs_sweep_blocks(A, g, dinv, b, cur, alt, fwd, false); std::swap(cur, alt); }
+            if (zero_guess) gs_sweep_blocks(A, g, dinv, b, nullptr, cur, fwd, true, same);
+            else { gs_sweep_blocks(A, g, dinv, b, cur, alt, fwd, false, same); std::swap(cur, alt); }
          }
          else
          { // symmetric: forward, then backward
-            if (zero_guess) { gs_sweep_blocks(A, g, dinv, b, nullptr, cur, true, true); }
-            else { gs_sweep_blocks(A, g, dinv, b, cur, alt, true, false); std::swap(cur, alt); }
-            gs_sweep_blocks(A, g, dinv, b, cur, alt, false, false);
+            if (zero_guess) { gs_sweep_blocks(A, g, dinv, b, nullptr, cur, true, true, same); }
+            else { gs_sweep_blocks(A, g, dinv, b, cur, alt, true, false, same); std::swap(cur, alt); }
+            gs_sweep_blocks(A, g, dinv, b, cur, alt, false, false, true);
             std::swap(cur, alt);
          }
          if (dot_slot >= 0) dot(A.nrows, b, cur, dot_slot);
@@ -3249,6 +3262,7 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool 
 {
    const int L  = num_levels();
    const int n0 = level_A(0).nrows;
+   for (AmgLevel &lv : levels) lv.gs_b_seen = false; // (row-block Gauss-Seidel: every level's right-hand side is new in this cycle)
    if (L == 1)
    {
       if (coarse_dense) coarse_solve(b, x);
@@ -3338,7 +3352,8 @@ void Amg::cycle(const double *b, double *x, bool zero_guess, int dot_slot, bool 
       for (int s = 0; s < prm.sweeps_up; s++)
       {
          const bool last = (l == 0) && (s == prm.sweeps_up - 1);
-         relax(l, prm.relax_up, lv.dinv_up.data(), fl, c, a, false, last ? dot_slot : -1);
+         // (same smoother both ways: the same divisors, and on row blocks the same sweep-order copy of them)
+         relax(l, prm.relax_up, (same_divisors(prm.relax_up, prm.relax_down) ? lv.dinv_down : lv.dinv_up).data(), fl, c, a, false, last ? dot_slot : -1);
       }
       ghosts_fresh_ = false; // (no post-smoothing sweep consumed it)
       sol[l] = c;

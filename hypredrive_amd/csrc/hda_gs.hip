@@ -265,7 +265,7 @@ static void gs_sorted_copy(const DCsr &A, const GsPlan &plan)
    plan.s_val.zero();
    k_gs_sorted_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.nblk, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
                                                          A.col.data(), A.val.data(), plan.s_rowptr.data(), plan.s_col.data(), plan.s_val.data());
-   if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); }
+   if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); plan.sd_src = plan.sb_src = nullptr; }
    if (plan.s_x0.size() != (size_t)n) plan.s_x0.alloc((size_t)n);
    plan.sorted = true;
 }
@@ -348,7 +348,7 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
    k_gs_ring_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.nblk, ng, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
                                                        A.col.data(), A.val.data(), plan.blk_lvl.data(), plan.r_cb.data(), plan.r_w.data(),
                                                        plan.r_col.data(), plan.r_val.data());
-   if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); }
+   if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); plan.sd_src = plan.sb_src = nullptr; }
    plan.s_x0.alloc((size_t)n);
    // lanes per row and workgroup size of this level's sweeps: what a typical level of a block keeps busy (every wavefront of the
    // workgroup runs every pass and meets every barrier, rows or not)
@@ -868,6 +868,13 @@ __global__ __launch_bounds__(1024) void k_gs_blocks(int backward, int zero_in, i
    }
 }
 
+// Workgroups w, w + 8, w + 16, ... run on the same XCD (MI355X_MICROARCH: round-robin dispatch over the 8 XCDs, one L2 each).  The two
+// kernels below gather / scatter 8-byte values whose 128-byte lines are shared by the positions of ONE row block, which are contiguous
+// in q: with workgroup w on positions [256 w, 256 w + 256) every XCD touched every line of x (8 fetches of each line from memory,
+// 340 us for the 16.7 M unknowns of 256^3 = 1 TB/s of useful bytes, round-5 trace).  Dealt in chunks instead -- XCD k takes the k-th
+// eighth of the positions -- a line is fetched by one L2 only.  The launch is rounded up to a multiple of 8 workgroups.
+__device__ __forceinline__ int xcd_chunk_block() { return (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3); }
+static inline int xcd_chunk_grid(int n) { return 8 * ceil_div(ceil_div(n, 256), 8); }
 // The same sweep on the sweep-order copy (GsPlan::s_*): before it, every unknown's iterate, right-hand side and divisor are brought
 // into sweep order by a kernel of the whole chip; after it the iterate goes back.  Position q of the copy is the row perm[q].
 __global__ __launch_bounds__(256) void k_gs_to_sweep_order(int n, int zero_in, const int *__restrict__ perm, const double *__restrict__ xin,
@@ -875,18 +882,18 @@ __global__ __launch_bounds__(256) void k_gs_to_sweep_order(int n, int zero_in, c
                                                            double *__restrict__ sx, double *__restrict__ sb, double *__restrict__ sd,
                                                            double *__restrict__ sx0 = nullptr)
 {
-   const int q = blockIdx.x * 256 + threadIdx.x;
+   const int q = xcd_chunk_block() * 256 + threadIdx.x;
    if (q >= n) return;
    const int    i = perm[q];
    const double x = zero_in ? 0.0 : xin[i];
    sx[q]          = x;
    if (sx0) sx0[q] = x; // (the ring kernel reads the other blocks' columns from this copy, which the sweep leaves alone)
-   sb[q]       = b[i];
-   sd[q]       = dinv[i];
+   if (b) sb[q] = b[i];       // (nullptr: the sweep-order copy is current -- GsPlan::sb_src / sd_src)
+   if (dinv) sd[q] = dinv[i];
 }
 __global__ __launch_bounds__(256) void k_gs_from_sweep_order(int n, const int *__restrict__ perm, const double *__restrict__ sx, double *__restrict__ xout)
 {
-   const int q = blockIdx.x * 256 + threadIdx.x;
+   const int q = xcd_chunk_block() * 256 + threadIdx.x;
    if (q < n) xout[perm[q]] = sx[q];
 }
 // LPR lanes per row, one 4-entry chunk per lane and pass (rows longer than 4 * LPR entries: further chunks in a loop).
@@ -1178,13 +1185,13 @@ static void gs_blocks_ring_t(const DCsr &A, const GsPlan &p, const double *dinv,
                              bool zero_in)
 {
    const int n = A.nrows;
-   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data(),
+   k_gs_to_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, p.to_b, p.to_d, p.s_x.data(), p.s_b.data(), p.s_d.data(),
                                                             p.s_x0.data());
    k_gs_blocks_ring<LPR, NT><<<p.nblk, NT, 0, STREAM>>>(p.r_pass_ptr.data(), (const GsPass *)p.r_pass[forward ? 0 : 1].data(),
                                                       (const int4 *)p.r_col.data(), (const double2 *)p.r_val.data(), p.s_d.data(), p.s_b.data(),
                                                       p.s_x0.data(), p.s_x.data(), gs_diag_buffer());
    gs_ring_diag_report(LPR, NT, n);
-   k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
+   k_gs_from_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
 }
 
 // (the shader-clock instrumentation of the ring / sorted kernels -- their `diag` argument -- is switched off in product builds: the
@@ -1199,13 +1206,13 @@ static void gs_blocks_sorted_t(const DCsr &A, const GsPlan &p, const double *din
 {
    const int    n   = A.nrows;
    const size_t lds = sizeof(int) * (size_t)(p.blk_max_levels + 1);
-   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data(),
+   k_gs_to_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, p.to_b, p.to_d, p.s_x.data(), p.s_b.data(), p.s_d.data(),
                                                           p.s_x0.data());
    k_gs_blocks_sorted<LPR, NT><<<p.nblk, NT, lds, STREAM>>>(forward ? 0 : 1, zero_in ? 1 : 0, p.blk_lvl_ptr.data(), p.blk_lvl.data(),
                                                          p.s_rowptr.data(), (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(),
                                                          p.s_d.data(), p.s_b.data(), p.s_aii.data(), p.s_x0.data(), p.s_x.data(), gs_diag_buffer());
    gs_diag_report(LPR, n);
-   k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
+   k_gs_from_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
 }
 
 // ---- the row-block sweep WITHOUT level barriers ("sync-free": every row waits for its own dependencies) ---------------------------------
@@ -1537,7 +1544,7 @@ static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv,
    const int n = A.nrows;
    constexpr int NT = 512; // (1024 threads leave a lane 128 registers: the four rows in flight spill)
    int *err = gs_free_error_flag(); // (one flag per process: the kernel raises it instead of spinning forever; read by gs_free_check)
-   k_gs_to_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, b, dinv, p.s_x.data(), p.s_b.data(), p.s_d.data(),
+   k_gs_to_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, p.to_b, p.to_d, p.s_x.data(), p.s_b.data(), p.s_d.data(),
                                                           p.s_x0.data());
    const size_t lds = sizeof(double) * (size_t)p.free_ring;
 #define HDA_GS_FREE_LAUNCH(BW)                                                                                                               \
@@ -1548,7 +1555,7 @@ static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv,
    if (forward) { HDA_GS_FREE_LAUNCH(false); }
    else { HDA_GS_FREE_LAUNCH(true); }
 #undef HDA_GS_FREE_LAUNCH
-   k_gs_from_sweep_order<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
+   k_gs_from_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, p.perm.data(), p.s_x.data(), xout);
    static const bool check = getenv("HDA_GS_FREE_CHECK") != nullptr; // (tests: after every sweep; otherwise at the end of every Krylov solve)
    if (check) gs_free_check();
 }
@@ -1565,11 +1572,17 @@ static void gs_blocks_t(const DCsr &A, const GsPlan &p, const double *dinv, cons
 }
 
 void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
-                     bool zero_in)
+                     bool zero_in, bool b_unchanged)
 {
    HDA_REQUIRE(plan.built && plan.nblk > 0, "row-block Gauss-Seidel plan missing");
    HDA_REQUIRE(zero_in || (xin && xin != xout), "row-block Gauss-Seidel sweeps out of place");
    if (A.nrows == 0) return;
+   // the sweep-order copies of the divisors and of the right-hand side are reused where they are current (round-5 series-B trace:
+   // k_gs_to_sweep_order / k_gs_from_sweep_order were 18.5 of 80 ms per solve, two thirds of the gathers of the first for b and dinv)
+   plan.to_d   = (plan.sd_src == dinv && plan.s_d.size() == (size_t)A.nrows) ? nullptr : dinv;
+   plan.to_b   = (b_unchanged && plan.sb_src == b && plan.s_b.size() == (size_t)A.nrows) ? nullptr : b;
+   plan.sd_src = dinv;
+   plan.sb_src = b;
    if (plan.span_rp != A.rowptr.data() || plan.span_nnz != A.nnz || plan.span_gen != A.gen)
    { // another matrix behind a kept plan (preconditioner.reuse)
       gs_row_spans(A, plan);
