@@ -347,8 +347,14 @@ __global__ __launch_bounds__(64) void k_rs_first_pass_rec(int nblk, const int *_
    }
    __threadfence_block();
    __syncthreads();
-   if (threadIdx.x != 0) return;
-   int  maxkey = 0;
+   // From here on ONE lane (lane 0) does every list operation, in the order of the sequential pass; the other 63 stay in the loop
+   // with it and do the reads that do NOT depend on the lists, a whole row of them per load instruction: the neighbour indices of a
+   // row, and for each neighbour its record (decided or not -- which only the neighbour's own turn changes, never the turns of the
+   // others of the same row -- and a first touch of the line the working lane reads next) and its row bounds.  The working lane then
+   // visits the undecided neighbours only.  What the pass costs is its chain of dependent round trips to memory (round 4: 2.7 us
+   // per row); the chain loses the reads of the decided neighbours and every index read.
+   const int lane   = threadIdx.x;
+   int       maxkey = 0; // (lane 0's)
    auto unlink = [&](const int4 &R) { // R: the record of a listed point (key = its measure)
       if (R.x >= 0) RS_F(R.x, 1) = R.y;
       else head[R.z] = R.y;
@@ -369,70 +375,149 @@ __global__ __launch_bounds__(64) void k_rs_first_pass_rec(int nblk, const int *_
       unlink(R);
       enter(m, R.z + 1);
    };
-   // ascending-index insertion; measure-0 points become F and the points they depend on gain weight (re-listed at the tail when
-   // already listed)
-   for (int j = lo; j < hi; j++)
-   {
-      const int4 Rj = rs_load(rec, j);
-      if (Rj.w == -3) continue;
-      if (Rj.z > 0) { enter(j, Rj.z); continue; }
-      RS_F(j, 3) = -1;
-      cf[j]      = -1;
-      for (int k = rp[j]; k < rp[j + 1]; k++)
+   auto first_set = [](unsigned long long &mask) { // lowest set lane of a (uniform) vote, cleared
+      const int t = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mask));
+      mask &= mask - 1;
+      return t;
+   };
+   // the strong neighbours [a, b) of a point that has just become F: the undecided ones of its block gain one
+   auto bump_row = [&](int a, int b) {
+      for (int base = a; base < b; base += 64)
       {
-         const int m = cj[k];
-         if (!in(m)) continue;
-         const int4 R = rs_load(rec, m);
-         if (R.w != 0) continue; // special, or decided (a decided point's measure is never read again)
-         if (m < j)
+         const int k = base + lane;
+         int       m = -1, w = 1;
+         if (k < b)
          {
-            if (R.z > 0) unlink(R);
-            enter(m, R.z + 1);
+            m = cj[k];
+            if (in(m)) w = rs_load(rec, m).w;
+            else m = -1;
          }
-         else RS_F(m, 2) = R.z + 1; // not listed yet
+         unsigned long long mask = __ballot(m >= 0 && w == 0);
+         while (mask)
+         {
+            const int mm = __builtin_amdgcn_readlane(m, first_set(mask));
+            if (lane == 0) bump(mm);
+         }
+      }
+   };
+   // ascending-index insertion; measure-0 points become F and the points they depend on gain weight (re-listed at the tail when
+   // already listed).  64 records per load; a measure-0 point may change the measures of later points: the working lane then reads
+   // the rest of its batch again, one by one
+   for (int base = lo; base < hi; base += 64)
+   {
+      const int  jv    = base + lane;
+      const int4 Rv    = jv < hi ? rs_load(rec, jv) : make_int4(-1, -1, 0, -3);
+      const int  cnt   = min(64, hi - base);
+      bool       dirty = false; // (lane 0's)
+      for (int t = 0; t < cnt; t++)
+      {
+         const int j = base + t;
+         const int z = __builtin_amdgcn_readlane(Rv.z, t), w = __builtin_amdgcn_readlane(Rv.w, t);
+         if (lane != 0) continue;
+         int4 Rj = make_int4(-1, -1, z, w);
+         if (dirty) Rj = rs_load(rec, j);
+         if (Rj.w == -3) continue;
+         if (Rj.z > 0) { enter(j, Rj.z); continue; }
+         RS_F(j, 3) = -1;
+         cf[j]      = -1;
+         dirty      = true;
+         for (int k = rp[j]; k < rp[j + 1]; k++)
+         {
+            const int m = cj[k];
+            if (!in(m)) continue;
+            const int4 R = rs_load(rec, m);
+            if (R.w != 0) continue; // special, or decided (a decided point's measure is never read again)
+            if (m < j)
+            {
+               if (R.z > 0) unlink(R);
+               enter(m, R.z + 1);
+            }
+            else RS_F(m, 2) = R.z + 1; // not listed yet
+         }
       }
    }
    for (;;)
    {
-      while (maxkey > 0 && head[maxkey] < 0) maxkey--;
-      if (maxkey <= 0) break;
-      const int  i  = head[maxkey];
-      const int4 Ri = rs_load(rec, i);
-      unlink(Ri);
-      rec[i] = make_int4(-1, -1, 0, 1);
-      cf[i]  = 1;
-      for (int k = tp[i]; k < tp[i + 1]; k++)
-      { // everything that strongly depends on i becomes F
-         const int j = tj[k];
-         if (!in(j)) continue;
-         const int4 Rj = rs_load(rec, j);
-         if (Rj.w != 0) continue;
-         unlink(Rj);
-         rec[j] = make_int4(-1, -1, Rj.z, -1);
-         cf[j]  = -1;
-         for (int kk = rp[j]; kk < rp[j + 1]; kk++)
+      int i = -1;
+      if (lane == 0)
+      {
+         while (maxkey > 0 && head[maxkey] < 0) maxkey--;
+         if (maxkey > 0)
          {
-            const int m = cj[kk];
-            if (in(m)) bump(m);
+            i             = head[maxkey];
+            const int4 Ri = rs_load(rec, i);
+            unlink(Ri);
+            rec[i] = make_int4(-1, -1, 0, 1);
+            cf[i]  = 1;
          }
       }
-      for (int k = rp[i]; k < rp[i + 1]; k++)
-      { // points i depends on lose one potential dependant
-         const int j = cj[k];
-         if (!in(j)) continue;
-         const int4 Rj = rs_load(rec, j);
-         if (Rj.w != 0) continue;
-         unlink(Rj);
-         if (Rj.z - 1 > 0) enter(j, Rj.z - 1);
-         else
+      i = __builtin_amdgcn_readfirstlane(i);
+      if (i < 0) break;
+      const int t0 = tp[i], t1 = tp[i + 1], s0 = rp[i], s1 = rp[i + 1];
+      for (int base = t0; base < t1; base += 64)
+      { // everything that strongly depends on i becomes F
+         const int k = base + lane;
+         int       j = -1, w = 1, a = 0, b = 0;
+         if (k < t1)
          {
-            rec[j] = make_int4(-1, -1, 0, -1);
-            cf[j]  = -1;
-            for (int kk = rp[j]; kk < rp[j + 1]; kk++)
+            j = tj[k];
+            if (in(j))
             {
-               const int m = cj[kk];
-               if (in(m)) bump(m);
+               w = rs_load(rec, j).w;
+               a = rp[j];
+               b = rp[j + 1];
             }
+            else j = -1;
+         }
+         unsigned long long mask = __ballot(j >= 0 && w == 0);
+         while (mask)
+         {
+            const int t  = first_set(mask);
+            const int jj = __builtin_amdgcn_readlane(j, t), ja = __builtin_amdgcn_readlane(a, t), jb = __builtin_amdgcn_readlane(b, t);
+            if (lane == 0)
+            {
+               const int4 Rj = rs_load(rec, jj); // (its measure may have grown since the batch was read: an earlier F point of the batch)
+               unlink(Rj);
+               rec[jj] = make_int4(-1, -1, Rj.z, -1);
+               cf[jj]  = -1;
+            }
+            bump_row(ja, jb);
+         }
+      }
+      for (int base = s0; base < s1; base += 64)
+      { // points i depends on lose one potential dependant
+         const int k = base + lane;
+         int       j = -1, w = 1, a = 0, b = 0;
+         if (k < s1)
+         {
+            j = cj[k];
+            if (in(j))
+            {
+               w = rs_load(rec, j).w;
+               a = rp[j];
+               b = rp[j + 1];
+            }
+            else j = -1;
+         }
+         unsigned long long mask = __ballot(j >= 0 && w == 0);
+         while (mask)
+         {
+            const int t  = first_set(mask);
+            const int jj = __builtin_amdgcn_readlane(j, t), ja = __builtin_amdgcn_readlane(a, t), jb = __builtin_amdgcn_readlane(b, t);
+            int       nowF = 0;
+            if (lane == 0)
+            {
+               const int4 Rj = rs_load(rec, jj);
+               unlink(Rj);
+               if (Rj.z - 1 > 0) enter(jj, Rj.z - 1);
+               else
+               {
+                  rec[jj] = make_int4(-1, -1, 0, -1);
+                  cf[jj]  = -1;
+                  nowF    = 1;
+               }
+            }
+            if (__builtin_amdgcn_readfirstlane(nowF)) bump_row(ja, jb);
          }
       }
    }
