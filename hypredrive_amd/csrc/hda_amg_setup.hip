@@ -525,8 +525,8 @@ __global__ __launch_bounds__(64) void k_rs_first_pass_rec(int nblk, const int *_
 #undef RS_F
 __global__ __launch_bounds__(256) void k_max_row_len(int n, const int *__restrict__ rp, int *mx)
 {
-   const int i = blockIdx.x * 256 + threadIdx.x;
-   int       m = (i < n) ? rp[i + 1] - rp[i] : 0;
+   int m = 0; // (grid-stride: one atomic per wavefront of a SMALL grid -- atomics on one address are serialised at the L2, 10 ns each)
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = max(m, rp[i + 1] - rp[i]);
    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(mx, m);
 }
@@ -608,7 +608,7 @@ static void hmis_core(const DCsr &A, const unsigned char *smask, const int *ns, 
       // a measure never exceeds twice the in-block dependants: bucket keys stay below 2 * (largest in-degree) + 2
       DArray<int> mx(1);
       mx.zero();
-      k_max_row_len<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, T.rowptr.data(), mx.data());
+      k_max_row_len<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, T.rowptr.data(), mx.data());
       int maxin = 0;
       mx.download(&maxin, 1);
       const int         kcap = 2 * maxin + 2;
@@ -2503,11 +2503,10 @@ static void build_dinv(const DCsr &A, int relax_type, double weight, DArray<doub
 // inside the block, which is what keeps the hybrid sweep and HMIS within an iteration of their one-block forms
 __global__ __launch_bounds__(256) void k_bandwidth(int n, const int *__restrict__ rp, const int *__restrict__ cj, int *bw)
 {
-   const int i = blockIdx.x * 256 + threadIdx.x;
-   int       m = 0;
-   if (i < n)
+   int m = 0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
       for (int k = rp[i]; k < rp[i + 1]; k++)
-         if (cj[k] < n) m = max(m, abs(cj[k] - i));
+         if (cj[k] < n) m = max(m, abs(cj[k] - (int)i));
    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(bw, m);
 }
@@ -2519,7 +2518,7 @@ int amg_auto_blocks(const DCsr &A)
    if (n <= min_rows) return 1;
    DArray<int> bw(1);
    bw.zero();
-   k_bandwidth<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), bw.data());
+   k_bandwidth<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), bw.data());
    int h = 0;
    bw.download(&h, 1);
    const long long m = std::max(4LL * h, min_block);

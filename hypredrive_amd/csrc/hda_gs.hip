@@ -25,6 +25,13 @@ namespace hda {
 // distinct neighbours of row i in pattern(A) U pattern(A^T), restricted to owned columns,
 // visited in ascending order; f(j) is called once per neighbour j != i
 // (lo, hi: only neighbours in [lo, hi) count -- the row's own block in the row-block form, [0, n) otherwise)
+// Workgroups w, w + 8, w + 16, ... run on the same XCD (MI355X_MICROARCH: round-robin dispatch over the 8 XCDs, one L2 each).  The two
+// kernels below gather / scatter 8-byte values whose 128-byte lines are shared by the positions of ONE row block, which are contiguous
+// in q: with workgroup w on positions [256 w, 256 w + 256) every XCD touched every line of x (8 fetches of each line from memory,
+// 340 us for the 16.7 M unknowns of 256^3 = 1 TB/s of useful bytes, round-5 trace).  Dealt in chunks instead -- XCD k takes the k-th
+// eighth of the positions -- a line is fetched by one L2 only.  The launch is rounded up to a multiple of 8 workgroups.
+__device__ __forceinline__ int xcd_chunk_block() { return (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3); }
+static inline int xcd_chunk_grid(int n) { return 8 * ceil_div(ceil_div(n, 256), 8); }
 template <class F>
 __device__ __forceinline__ void for_each_sym_neighbour(int i, int n, const int *__restrict__ rp, const int *__restrict__ cj,
                                                        const int *__restrict__ trp, const int *__restrict__ tcj, F f, int lo = 0,
@@ -228,23 +235,28 @@ __global__ __launch_bounds__(256) void k_gs_sorted_fill(int n, int nb, const int
                                                         const double *__restrict__ v, const int *__restrict__ srp4, int *__restrict__ scj,
                                                         double *__restrict__ sv)
 {
-   const int q = blockIdx.x * 256 + threadIdx.x;
+   // eight lanes to a row (its entries are read and written side by side), 32 rows to a workgroup; the rows of a block are gathered
+   // by one XCD (xcd_chunk_block: their lines are fetched once)
+   constexpr int G = 8;
+   const int     q = xcd_chunk_block() * (256 / G) + (int)threadIdx.x / G, gl = (int)threadIdx.x % G;
    if (q >= n) return;
    const int i = perm[q];
    int       lo, hi;
    gs_block_of(part, nb, i, n, lo, hi);
-   int d = 4 * srp4[q];
-   const int e = 4 * srp4[q + 1];
-   bool skipped = false;
-   for (int k = rp[i]; k < rp[i + 1]; k++)
-   { // same entry order as the row, without its (first) diagonal entry: that one is in s_aii
-      const int c = cj[k];
-      if (c == i && !skipped) { skipped = true; continue; }
-      scj[d] = (c >= lo && c < hi) ? pos_of[c] : ~pos_of[c]; // (another block's column: its position in the sweep-START copy)
-      sv[d]  = v[k];
-      d++;
+   const int r0 = rp[i], r1 = rp[i + 1];
+   int       kd = 0x7fffffff; // the row's first diagonal entry: that one is in s_aii, the others keep their order
+   for (int k = r0 + gl; k < r1; k += G)
+      if (cj[k] == i) { kd = k; break; }
+   for (int o = 1; o < G; o <<= 1) kd = min(kd, __shfl_xor(kd, o));
+   const int d0 = 4 * srp4[q], e = 4 * srp4[q + 1];
+   for (int k = r0 + gl; k < r1; k += G)
+   {
+      if (k == kd) continue;
+      const int c = cj[k], d = d0 + (k - r0) - (k > kd ? 1 : 0);
+      scj[d]      = (c >= lo && c < hi) ? pos_of[c] : ~pos_of[c]; // (another block's column: its position in the sweep-START copy)
+      sv[d]       = v[k];
    }
-   for (; d < e; d++) { scj[d] = q; sv[d] = 0.0; } // padding: 0 * (the row's own value)
+   for (int d = d0 + (r1 - r0) - (kd != 0x7fffffff ? 1 : 0) + gl; d < e; d += G) { scj[d] = q; sv[d] = 0.0; } // padding: 0 * (the row's own value)
 }
 static void gs_sorted_copy(const DCsr &A, const GsPlan &plan)
 {
@@ -263,7 +275,7 @@ static void gs_sorted_copy(const DCsr &A, const GsPlan &plan)
    plan.s_val.alloc((size_t)4 * chunks + 4);
    plan.s_col.zero();
    plan.s_val.zero();
-   k_gs_sorted_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.nblk, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
+   k_gs_sorted_fill<<<8 * ceil_div(ceil_div(n, 32), 8), 256, 0, STREAM>>>(n, plan.nblk, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
                                                          A.col.data(), A.val.data(), plan.s_rowptr.data(), plan.s_col.data(), plan.s_val.data());
    if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); plan.sd_src = plan.sb_src = nullptr; }
    if (plan.s_x0.size() != (size_t)n) plan.s_x0.alloc((size_t)n);
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(256) void k_gs_ring_fill(int n, int nb, int nlev_to
                                                       const int *__restrict__ lvl_cb, const int *__restrict__ lvl_w, int *__restrict__ rcj,
                                                       double *__restrict__ rv)
 {
-   const int q = blockIdx.x * 256 + threadIdx.x;
+   const int q = xcd_chunk_block() * 256 + threadIdx.x;
    if (q >= n) return;
    int a = 0, b = nlev_total; // the (block, level) that holds position q: lvl_first[a] <= q < lvl_first[b]
    while (b - a > 1)
@@ -304,6 +316,30 @@ __global__ __launch_bounds__(256) void k_gs_ring_fill(int n, int nb, int nlev_to
       rv[d]       = v[k];
    }
    for (; d < e; d++) { rcj[d] = q; rv[d] = 0.0; }
+}
+static void gs_ring_shape(const DCsr &A, const GsPlan &plan, int &lpr, int &nt)
+{
+   const double a     = A.avg_row();
+   lpr                = (a <= 10.0) ? 2 : (a <= 40.0) ? 8 : 16;
+   const double lanes = plan.blk_mean_rows_per_level * lpr;
+   nt                 = lanes <= 192.0 ? 256 : 512; // (1024 threads leave a wavefront 128 registers: 35.0 against 32.7 ms per 128^3 solve)
+}
+// passes of the level-wise (ring) kernel, mean over the blocks: every dependency level of a block takes ceil(rows / rows per pass)
+static double gs_ring_mean_passes(const GsPlan &plan, int rows_per_pass)
+{
+   long long np = 0;
+   for (size_t g = 0; g + 1 < plan.h_blk_lvl.size(); g++)
+      np += std::max((plan.h_blk_lvl[g + 1] - plan.h_blk_lvl[g] + rows_per_pass - 1) / rows_per_pass, 1);
+   return (double)np / std::max(plan.nblk, 1);
+}
+// barrier-free kernel or ring kernel: both cost about a microsecond per step (round of 512 / LPR rows, pass of a dependency level);
+// the one with fewer steps runs (measured: 1.06 us per round, 1.42 us per pass on the 128^3 series-B levels)
+static bool gs_free_beats_ring(const GsPlan &plan, double ring_passes)
+{
+   int maxblock = 0;
+   for (size_t q = 0; q + 1 < plan.h_part.size(); q++) maxblock = std::max(maxblock, plan.h_part[q + 1] - plan.h_part[q]);
+   const double rounds = std::ceil((double)maxblock / (512 / std::max(plan.free_lpr, 1)));
+   return rounds <= 1.3 * ring_passes;
 }
 static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
 {
@@ -345,23 +381,14 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
    plan.r_val.alloc((size_t)4 * total + 4);
    plan.r_col.zero();
    plan.r_val.zero();
-   k_gs_ring_fill<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.nblk, ng, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
+   k_gs_ring_fill<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, plan.nblk, ng, plan.blk_part.data(), plan.perm.data(), pos_of.data(), A.rowptr.data(),
                                                        A.col.data(), A.val.data(), plan.blk_lvl.data(), plan.r_cb.data(), plan.r_w.data(),
                                                        plan.r_col.data(), plan.r_val.data());
    if (plan.s_x.size() != (size_t)n) { plan.s_x.alloc((size_t)n); plan.s_b.alloc((size_t)n); plan.s_d.alloc((size_t)n); plan.sd_src = plan.sb_src = nullptr; }
    plan.s_x0.alloc((size_t)n);
    // lanes per row and workgroup size of this level's sweeps: what a typical level of a block keeps busy (every wavefront of the
    // workgroup runs every pass and meets every barrier, rows or not)
-   {
-      const double a  = A.avg_row();
-      int lpr = (a <= 10.0) ? 2 : (a <= 40.0) ? 8 : 16;
-      lpr     = lpr <= 2 ? 2 : lpr <= 4 ? 4 : lpr <= 8 ? 8 : 16;
-      const double lanes = plan.blk_mean_rows_per_level * lpr;
-      int          nt    = lanes <= 192.0 ? 256 : 512; // (1024 threads leave a wavefront 128 registers: 35.0 against 32.7 ms per 128^3 solve)
-      nt                 = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;
-      plan.ring_lpr      = lpr;
-      plan.ring_nt       = nt;
-   }
+   gs_ring_shape(A, plan, plan.ring_lpr, plan.ring_nt);
    // the pass lists
    {
       const int        RP = plan.ring_nt / plan.ring_lpr;
@@ -414,20 +441,39 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
 // level loop below made ~900 launch + read-back round trips over the series-B hierarchy at 256^3, 30-70 ms per operator level
 // whatever its size).  lvl[i] = dependency level of row i inside its block; nlev[b] = levels of block b.  fr0 / fr1: frontier
 // ping-pong, a block uses the slice [part[b], part[b + 1]) of each.
+// Kahn's algorithm on one row block per workgroup.  A row's predecessors are its in-block neighbours of smaller index, in A's row or
+// in A^T's: each ENTRY counts (a pair present both ways counts twice and is taken off twice), so the two rows are walked one after
+// the other with independent loads -- the round-4 form merged them into one sorted walk, two dependent loads per step, and kept the
+// counters in memory (returned global atomics, one round trip each): 122 us per level on the 256^3 level 0.  LDSDEG: the counters of
+// a block of up to 32768 rows as 16-bit halves of LDS words (a count is below twice the block size; a half never borrows: every decrement
+// takes off a unit that was counted).
+template <bool LDSDEG>
 __global__ __launch_bounds__(1024) void k_gs_levels_blocks(int n, const int *__restrict__ part, const int *__restrict__ rp, const int *__restrict__ cj,
                                                            const int *__restrict__ trp, const int *__restrict__ tcj, int *indeg, int *fr0, int *fr1,
                                                            int *__restrict__ lvl, int *__restrict__ nlev)
 {
-   __shared__ int cnt[2];
+   __shared__ int               cnt[2];
+   extern __shared__ unsigned int sdeg[];
    const int b = blockIdx.x, lo = part[b], hi = part[b + 1], tid = threadIdx.x;
    if (tid < 2) cnt[tid] = 0;
+   if constexpr (LDSDEG)
+      for (int w = tid; w < (hi - lo + 1) / 2; w += 1024) sdeg[w] = 0u;
    __syncthreads();
    int *cur = fr0 + lo, *nxt = fr1 + lo;
-   for (int i = lo + tid; i < hi; i += 1024)
+   // G lanes to a row, one entry each per step: a level of a block is a few hundred rows, and what a level costs is the chain
+   // row number -> row bounds -> entries -> counter, not the entries themselves
+   constexpr int G = 8, NG = 1024 / G;
+   const int     grp = tid / G, gl = tid % G;
+   for (int i = lo + grp; i < hi; i += NG)
    {
-      int d = 0;
-      for_each_sym_neighbour(i, n, rp, cj, trp, tcj, [&](int j) { d += (j < i); }, lo, hi);
-      indeg[i] = d;
+      int       d  = 0;
+      const int a0 = rp[i], a1 = rp[i + 1], t0 = trp[i], t1 = trp[i + 1];
+      for (int k = a0 + gl; k < a1; k += G) d += (cj[k] >= lo && cj[k] < i);
+      for (int k = t0 + gl; k < t1; k += G) d += (tcj[k] >= lo && tcj[k] < i);
+      for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
+      if (gl != 0) continue;
+      if constexpr (LDSDEG) { if (d) atomicAdd(&sdeg[(i - lo) >> 1], (unsigned)d << (16 * ((i - lo) & 1))); }
+      else indeg[i] = d;
       if (d == 0) cur[atomicAdd(&cnt[0], 1)] = i;
    }
    __syncthreads();
@@ -436,13 +482,32 @@ __global__ __launch_bounds__(1024) void k_gs_levels_blocks(int n, const int *__r
    {
       const int nf = cnt[c];
       if (nf == 0) break;
-      for (int q = tid; q < nf; q += 1024)
+      auto take = [&](int j) { // one predecessor of j is done
+         bool last;
+         if constexpr (LDSDEG)
+         {
+            const int      sh  = 16 * ((j - lo) & 1);
+            const unsigned old = atomicSub(&sdeg[(j - lo) >> 1], 1u << sh);
+            last               = ((old >> sh) & 0xffffu) == 1u;
+         }
+         else last = atomicSub(&indeg[j], 1) == 1;
+         if (last) nxt[atomicAdd(&cnt[c ^ 1], 1)] = j;
+      };
+      for (int q = grp; q < nf; q += NG)
       {
          const int i = cur[q];
-         lvl[i]      = level;
-         for_each_sym_neighbour(i, n, rp, cj, trp, tcj, [&](int j) {
-            if (j > i && atomicSub(&indeg[j], 1) == 1) nxt[atomicAdd(&cnt[c ^ 1], 1)] = j;
-         }, lo, hi);
+         if (gl == 0) lvl[i] = level;
+         const int a0 = rp[i], a1 = rp[i + 1], t0 = trp[i], t1 = trp[i + 1];
+         for (int k = a0 + gl; k < a1; k += G)
+         {
+            const int j = cj[k];
+            if (j > i && j < hi) take(j); // (ghost columns are >= n >= hi)
+         }
+         for (int k = t0 + gl; k < t1; k += G)
+         {
+            const int j = tcj[k];
+            if (j > i && j < hi) take(j);
+         }
       }
       __syncthreads();           // the next frontier is complete (and visible: one workgroup, one CU)
       if (tid == 0) cnt[c] = 0;  // (this counter is the one the level after next fills)
@@ -461,18 +526,30 @@ __global__ __launch_bounds__(1024) void k_gs_levels_blocks(int n, const int *__r
 static DArray<int> gs_levels(const DCsr &A, GsPlan &plan, const int *d_part, int nb)
 {
    const int n = A.nrows;
-   DCsr T;
-   transpose(A, T); // rows of T = columns of A; only rows < n are consulted
    if (d_part && nb > 0)
-   {
+   { // (the block kernel only enumerates a column's rows: the pattern of A^T, unsorted, without values)
+      struct { DArray<int> rowptr, col; } T;
+      transpose_pattern_unsorted(A, T.rowptr, T.col);
       DArray<int> indeg((size_t)n), fr0((size_t)n), fr1((size_t)n), lrow((size_t)n), dnl((size_t)nb);
-      k_gs_levels_blocks<<<nb, 1024, 0, STREAM>>>(n, d_part, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(), fr0.data(),
-                                                  fr1.data(), lrow.data(), dnl.data());
+      int maxblock = 0;
+      for (size_t q = 0; q + 1 < plan.h_part.size(); q++) maxblock = std::max(maxblock, plan.h_part[q + 1] - plan.h_part[q]);
+      HDA_REQUIRE((int)plan.h_part.size() == nb + 1, "Gauss-Seidel plan: row blocks of the host and of the device differ");
+      if (maxblock <= 32768) // (a count is below twice the block size -- entries of both rows: 16 bits; 64 KB of LDS, two workgroups to a CU)
+      {
+         HDA_HIP(hipFuncSetAttribute((const void *)k_gs_levels_blocks<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+         k_gs_levels_blocks<true><<<nb, 1024, sizeof(unsigned) * (size_t)((maxblock + 1) / 2), STREAM>>>(
+            n, d_part, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(), fr0.data(), fr1.data(), lrow.data(), dnl.data());
+      }
+      else
+         k_gs_levels_blocks<false><<<nb, 1024, 0, STREAM>>>(n, d_part, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(),
+                                                           fr0.data(), fr1.data(), lrow.data(), dnl.data());
       const std::vector<int> hn = dnl.to_host();
       plan.nlev = 0;
       for (int v : hn) plan.nlev = std::max(plan.nlev, v);
       return lrow;
    }
+   DCsr T;
+   transpose(A, T); // rows of T = columns of A (sorted: the kernels below walk a row and its column together); only rows < n are consulted
    DArray<int> indeg((size_t)n), counter(1);
    counter.zero();
    k_gs_indeg<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(),
@@ -592,14 +669,23 @@ void build_gs_plan_blocks(const DCsr &A, const std::vector<int> &part, GsPlan &p
    const int sorted_min = getenv("HDA_GS_SORTED_MIN") ? atoi(getenv("HDA_GS_SORTED_MIN")) : 2000; // (read per plan: the tests move it)
    if (n >= sorted_min && plan.blk_max_levels + 1 <= 12 * 1024) gs_sorted_copy(A, plan); // (the kernel keeps a block's level offsets in LDS: 48 KB)
    HDA_TRACE("  gs plan: sweep-order copy");
-   if (plan.sorted && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0)) gs_ring_copy(A, plan);
-   HDA_TRACE("  gs plan: level-wise copy");
    if (plan.sorted)
    {
       if (!plan.s_x0.size()) plan.s_x0.alloc((size_t)n);
       gs_free_plan(plan, n);
    }
    HDA_TRACE("  gs plan: barrier-free plan");
+   // the level-wise copy (a second padded copy of the operator, 6 - 9 ms to fill at 256^3) only where its kernel will run: not where
+   // the barrier-free kernel takes fewer steps -- the same rule gs_sweep_blocks applies (HDA_GS_FREE set: both, the tests force either)
+   bool want_ring = plan.sorted && !(getenv("HDA_GS_RING") && atoi(getenv("HDA_GS_RING")) == 0);
+   if (want_ring && plan.free_lpr > 0 && !getenv("HDA_GS_FREE"))
+   {
+      int lpr = 2, nt = 256;
+      gs_ring_shape(A, plan, lpr, nt);
+      if (gs_free_beats_ring(plan, gs_ring_mean_passes(plan, nt / lpr))) want_ring = false;
+   }
+   if (want_ring) gs_ring_copy(A, plan);
+   HDA_TRACE("  gs plan: level-wise copy");
    if (getenv("HDA_VERBOSE"))
       fprintf(stderr, "[hda] block Gauss-Seidel plan: n=%d nnz=%d (%.1f per row), %d blocks, dependency levels per block: max %d, mean %.0f (%.0f rows per level)%s\n",
               n, A.nnz, A.avg_row(), nb, plan.blk_max_levels, (double)(bl.size() - 1) / nb, (double)n / std::max<size_t>(bl.size() - 1, 1),
@@ -868,13 +954,6 @@ __global__ __launch_bounds__(1024) void k_gs_blocks(int backward, int zero_in, i
    }
 }
 
-// Workgroups w, w + 8, w + 16, ... run on the same XCD (MI355X_MICROARCH: round-robin dispatch over the 8 XCDs, one L2 each).  The two
-// kernels below gather / scatter 8-byte values whose 128-byte lines are shared by the positions of ONE row block, which are contiguous
-// in q: with workgroup w on positions [256 w, 256 w + 256) every XCD touched every line of x (8 fetches of each line from memory,
-// 340 us for the 16.7 M unknowns of 256^3 = 1 TB/s of useful bytes, round-5 trace).  Dealt in chunks instead -- XCD k takes the k-th
-// eighth of the positions -- a line is fetched by one L2 only.  The launch is rounded up to a multiple of 8 workgroups.
-__device__ __forceinline__ int xcd_chunk_block() { return (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3); }
-static inline int xcd_chunk_grid(int n) { return 8 * ceil_div(ceil_div(n, 256), 8); }
 // The same sweep on the sweep-order copy (GsPlan::s_*): before it, every unknown's iterate, right-hand side and divisor are brought
 // into sweep order by a kernel of the whole chip; after it the iterate goes back.  Position q of the copy is the row perm[q].
 __global__ __launch_bounds__(256) void k_gs_to_sweep_order(int n, int zero_in, const int *__restrict__ perm, const double *__restrict__ xin,
@@ -1456,11 +1535,11 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
 // longest distance, in sweep positions, between a row and an in-block column of it (the reach of a dependency in either direction)
 __global__ __launch_bounds__(256) void k_gs_reach(int n, const int *__restrict__ srp4, const int *__restrict__ scj, int *reach, int *maxchunks)
 {
-   const int q = blockIdx.x * 256 + threadIdx.x;
-   int       m = 0, k = 0;
-   if (q < n)
+   int m = 0, k = 0; // (grid-stride, a small grid: the two atomics of a wavefront queue at the L2 behind everybody else's)
+   for (long ql = (long)blockIdx.x * 256 + threadIdx.x; ql < n; ql += (long)gridDim.x * 256)
    {
-      k = srp4[q + 1] - srp4[q];
+      const int q = (int)ql;
+      k           = max(k, srp4[q + 1] - srp4[q]);
       for (int e = 4 * srp4[q]; e < 4 * srp4[q + 1]; e++)
          if (scj[e] >= 0) m = max(m, abs(scj[e] - q));
    }
@@ -1473,7 +1552,7 @@ static void gs_free_plan(const GsPlan &plan, int n)
    if (!plan.sorted || !plan.s_x0.size()) return;
    DArray<int> two(2);
    two.zero();
-   k_gs_reach<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), two.data(), two.data() + 1);
+   k_gs_reach<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), two.data(), two.data() + 1);
    int h[2] = {0, 0};
    two.download(h, 2);
    int maxblock = 0;
@@ -1592,17 +1671,11 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
    }
    const double a = A.avg_row();
    constexpr bool use_sorted = true;
-   // barrier-free kernel or ring kernel: both cost about a microsecond per step (round of 512 / LPR rows, pass of a dependency level);
-   // the one with fewer steps runs -- HDA_GS_FREE=1 / 0 force either
+   // barrier-free kernel or ring kernel (gs_free_beats_ring; the plan holds the level-wise copy only where that said ring) --
+   // HDA_GS_FREE=1 / 0 force either
    bool use_free = plan.free_lpr > 0 && use_sorted;
    if (use_free && plan.ring && !getenv("HDA_GS_FREE"))
-   {
-      int maxblock = 0;
-      for (size_t q = 0; q + 1 < plan.h_part.size(); q++) maxblock = std::max(maxblock, plan.h_part[q + 1] - plan.h_part[q]);
-      const double rounds = std::ceil((double)maxblock / (512 / plan.free_lpr));
-      const double passes = (double)plan.r_pass[0].size() / 8.0 / std::max(plan.nblk, 1) - 3.0; // (mean over the blocks; three spare records each)
-      use_free            = rounds <= 1.3 * passes; // (measured: 1.06 us per round, 1.42 us per pass on the 128^3 series-B levels)
-   }
+      use_free = gs_free_beats_ring(plan, (double)plan.r_pass[0].size() / 8.0 / std::max(plan.nblk, 1) - 3.0); // (three spare records per block)
    if (getenv("HDA_GS_FREE")) use_free = use_free && atoi(getenv("HDA_GS_FREE")) != 0;
    if (use_free)
    {

@@ -99,6 +99,7 @@ void spmv_probe_read(int id, double *avg_ms, int *count);
 void sort_rows(DCsr &A);                                    // column-sort every row in place
 void sort_rows_segmented(DCsr &A);                          // the same by one segmented radix sort (any row length)
 void transpose(const DCsr &A, DCsr &T);                     // rows of T sorted
+void transpose_pattern_unsorted(const DCsr &A, DArray<int> &trp, DArray<int> &tcj); // pattern of A^T, rows unordered
 // 7-pt Laplacian generator on device (examples/src/C_laplacian/laplacian.c:719-921),
 // rows [ilower, iupper] of the block-partitioned numbering; cols are GLOBAL ids (int64).
 void lap7_generate(const int n[3], const int P[3], const int pc[3], const double c[3],

@@ -1784,15 +1784,50 @@ __device__ __forceinline__ unsigned vhash(unsigned long long key)
    key ^= key >> 29;
    return (unsigned)key & (kVHashSlots - 1);
 }
-// histogram of a 1-in-`stride` sample of the values
+// histogram of a 1-in-`stride` sample of the values.  Every workgroup counts its samples in a table of its own in LDS and adds the
+// table to the one in memory at the end: one atomic per (workgroup, value) instead of one per sample -- an operator whose values
+// repeat sends its 2.2 M samples (256^3 series-B level 1) to a few hundred addresses, and atomics on one address are served one
+// after the other at the L2 (5.6 ms per launch in the round-5 trace)
 __global__ __launch_bounds__(256) void k_vhist(long nnz, int stride, const double *__restrict__ v, unsigned long long *keys, int *counts, int *distinct)
 {
+   extern __shared__ unsigned long long lkeys[]; // kVHashSlots keys, then as many counts
+   int                                *lcounts = (int *)(lkeys + kVHashSlots);
+   __shared__ int                      ldistinct, crowded;
+   for (int s = threadIdx.x; s < kVHashSlots; s += 256) { lkeys[s] = kEmptyKey; lcounts[s] = 0; }
+   if (threadIdx.x == 0) ldistinct = crowded = 0;
+   __syncthreads();
    for (long k = ((long)blockIdx.x * 256 + threadIdx.x) * stride; k < nnz; k += (long)gridDim.x * 256 * stride)
    {
-      if (*(volatile int *)distinct > kVHashSlots / 2) return; // too many different values: give up early
+      if (*(volatile int *)&ldistinct > kVHashSlots / 2 || *(volatile int *)&crowded) break; // too many different values: give up early
       const unsigned long long key = (unsigned long long)__double_as_longlong(v[k]);
       unsigned                 s   = vhash(key);
       bool placed = false;
+      for (int probe = 0; probe < 64; probe++)
+      {
+         unsigned long long cur = lkeys[s];
+         if (cur == kEmptyKey)
+         {
+            cur = atomicCAS(&lkeys[s], (unsigned long long)kEmptyKey, key);
+            if (cur == kEmptyKey) { atomicAdd(&ldistinct, 1); cur = key; }
+         }
+         if (cur == key) { atomicAdd(&lcounts[s], 1); placed = true; break; }
+         s = (s + 1) & (kVHashSlots - 1);
+      }
+      if (!placed) { crowded = 1; break; } // 64 occupied slots in a row: far more different values than a dictionary holds
+   }
+   __syncthreads();
+   if (ldistinct > kVHashSlots / 2 || crowded)
+   {
+      if (threadIdx.x == 0) atomicAdd(distinct, kVHashSlots);
+      return;
+   }
+   for (int t = threadIdx.x; t < kVHashSlots; t += 256)
+   {
+      const unsigned long long key = lkeys[t];
+      if (key == kEmptyKey) continue;
+      if (*(volatile int *)distinct > kVHashSlots / 2) return;
+      unsigned s      = vhash(key);
+      bool     placed = false;
       for (int probe = 0; probe < 64; probe++)
       {
          unsigned long long cur = keys[s];
@@ -1801,11 +1836,11 @@ __global__ __launch_bounds__(256) void k_vhist(long nnz, int stride, const doubl
             cur = atomicCAS(&keys[s], (unsigned long long)kEmptyKey, key);
             if (cur == kEmptyKey) { atomicAdd(distinct, 1); cur = key; }
          }
-         if (cur == key) { atomicAdd(&counts[s], 1); placed = true; break; }
+         if (cur == key) { atomicAdd(&counts[s], lcounts[t]); placed = true; break; }
          s = (s + 1) & (kVHashSlots - 1);
       }
       if (!placed)
-      { // 64 occupied slots in a row: the table is crowded, i.e. far more different values than a dictionary holds
+      { // the table in memory is crowded
          atomicAdd(distinct, kVHashSlots);
          return;
       }
@@ -1846,13 +1881,15 @@ static void ensure_vcoded(const DCsr &A)
    // a small strided probe rejects operators with irregular values (every Galerkin coarse operator)
    // before the larger sample that ranks the values by frequency
    int nd = 0;
-   k_vhist<<<64, 256, 0, STREAM>>>(A.nnz, std::max(1, A.nnz / 65536), A.val.data(), keys.data(), counts.data(), distinct.data());
+   constexpr size_t vhist_lds = (size_t)kVHashSlots * (sizeof(unsigned long long) + sizeof(int));
+   HDA_HIP(hipFuncSetAttribute((const void *)k_vhist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vhist_lds));
+   k_vhist<<<64, 256, vhist_lds, STREAM>>>(A.nnz, std::max(1, A.nnz / 65536), A.val.data(), keys.data(), counts.data(), distinct.data());
    distinct.download(&nd, 1);
    if (nd > 2048) return;
    HDA_HIP(hipMemsetAsync(keys.data(), 0xff, sizeof(unsigned long long) * kVHashSlots, STREAM));
    counts.zero();
    distinct.zero();
-   k_vhist<<<1024, 256, 0, STREAM>>>(A.nnz, 64, A.val.data(), keys.data(), counts.data(), distinct.data());
+   k_vhist<<<256, 256, vhist_lds, STREAM>>>(A.nnz, 64, A.val.data(), keys.data(), counts.data(), distinct.data());
    distinct.download(&nd, 1);
    if (nd > kVHashSlots / 2) return;
    std::vector<unsigned long long> hk = keys.to_host();
@@ -2941,6 +2978,25 @@ __global__ __launch_bounds__(256) void k_transpose_fill(int n, const int *__rest
    }
 }
 // T = A^T.  Atomic scatter then per-row sort => deterministic, rows ascending.
+__global__ __launch_bounds__(256) void k_transpose_fill_pattern(int n, const int *__restrict__ rp, const int *__restrict__ cj, int *cursor,
+                                                                int *__restrict__ tj)
+{
+   int i = blockIdx.x * 256 + threadIdx.x;
+   if (i >= n) return;
+   for (int k = rp[i]; k < rp[i + 1]; k++) tj[atomicAdd(&cursor[cj[k]], 1)] = i;
+}
+// the pattern of A^T alone, rows in NO particular order (for consumers that only enumerate a column's rows: no values moved, no sort)
+void transpose_pattern_unsorted(const DCsr &A, DArray<int> &trp, DArray<int> &tcj)
+{
+   trp.alloc((size_t)A.ncols + 1);
+   tcj.alloc((size_t)std::max(A.nnz, 1));
+   DArray<int> cnt((size_t)A.ncols + 1);
+   cnt.zero();
+   if (A.nnz) k_count_cols<<<ew_grid(A.nnz), 256, 0, STREAM>>>(A.nnz, A.col.data(), cnt.data());
+   exclusive_scan(A.ncols, cnt.data(), trp.data(), nullptr);
+   cnt.copy_from(trp); // cursor
+   if (A.nrows) k_transpose_fill_pattern<<<ceil_div(A.nrows, 256), 256, 0, STREAM>>>(A.nrows, A.rowptr.data(), A.col.data(), cnt.data(), tcj.data());
+}
 void transpose(const DCsr &A, DCsr &T)
 {
    T.nrows = A.ncols;
