@@ -963,10 +963,14 @@ __global__ __launch_bounds__(256) void k_gs_to_sweep_order(int n, int zero_in, c
 {
    const int q = xcd_chunk_block() * 256 + threadIdx.x;
    if (q >= n) return;
-   const int    i = perm[q];
-   const double x = zero_in ? 0.0 : xin[i];
-   sx[q]          = x;
-   if (sx0) sx0[q] = x; // (the ring kernel reads the other blocks' columns from this copy, which the sweep leaves alone)
+   const int i = perm[q];
+   if (sx || sx0)
+   { // (the barrier-free kernel reads the sweep-start copy alone -- a zero input is an array of zeros that is never written --
+     //  and writes its result in the caller's numbering: neither pointer, or sx0 only)
+      const double x = zero_in ? 0.0 : xin[i];
+      if (sx) sx[q] = x;
+      if (sx0) sx0[q] = x; // (the ring kernel reads the other blocks' columns from this copy, which the sweep leaves alone)
+   }
    if (b) sb[q] = b[i];       // (nullptr: the sweep-order copy is current -- GsPlan::sb_src / sd_src)
    if (dinv) sd[q] = dinv[i];
 }
@@ -1623,14 +1627,25 @@ static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv,
    const int n = A.nrows;
    constexpr int NT = 512; // (1024 threads leave a lane 128 registers: the four rows in flight spill)
    int *err = gs_free_error_flag(); // (one flag per process: the kernel raises it instead of spinning forever; read by gs_free_check)
-   k_gs_to_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, p.to_b, p.to_d, p.s_x.data(), p.s_b.data(), p.s_d.data(),
-                                                          p.s_x0.data());
-   const size_t lds = sizeof(double) * (size_t)p.free_ring;
+   // (what the kernel reads in sweep order: divisors and right-hand side, gathered when they are new; the sweep-start iterate, gathered
+   //  unless it is zero.  Its result it writes in sweep order too, and a second kernel scatters it: stores to the caller's numbering
+   //  from inside the sweep were tried in round 5 -- 8-byte stores all over a block's part of x, whose lines leave the L2 half
+   //  written on blocks of 65 536 rows and more: 106.6 -> 115.5 ms per 256^3 solve on 64 blocks, nothing gained on 512)
+   if (zero_in && p.s_zero.size() != (size_t)n)
+   { // (made by the first sweep from zero of a level that runs this kernel: a level on the ring kernel never needs it)
+      p.s_zero.alloc((size_t)n);
+      p.s_zero.zero();
+   }
+   if (!zero_in || p.to_b || p.to_d)
+      k_gs_to_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, p.to_b, p.to_d, nullptr, p.s_b.data(), p.s_d.data(),
+                                                             zero_in ? nullptr : p.s_x0.data());
+   const double *x0  = zero_in ? p.s_zero.data() : p.s_x0.data();
+   const size_t  lds = sizeof(double) * (size_t)p.free_ring;
 #define HDA_GS_FREE_LAUNCH(BW)                                                                                                               \
    HDA_HIP(hipFuncSetAttribute((const void *)k_gs_blocks_free<LPR, MAXC, NT, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));  \
    k_gs_blocks_free<LPR, MAXC, NT, BW><<<p.nblk, NT, lds, STREAM>>>(p.free_ring - 1, p.blk_part.data(), p.s_rowptr.data(),                   \
                                                                     (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(), p.s_d.data(), \
-                                                                    p.s_b.data(), p.s_aii.data(), p.s_x0.data(), p.s_x.data(), err)
+                                                                    p.s_b.data(), p.s_aii.data(), x0, p.s_x.data(), err)
    if (forward) { HDA_GS_FREE_LAUNCH(false); }
    else { HDA_GS_FREE_LAUNCH(true); }
 #undef HDA_GS_FREE_LAUNCH
