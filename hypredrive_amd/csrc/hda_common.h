@@ -33,6 +33,16 @@ struct Error : std::runtime_error {
          throw ::hda::Error(_buf);                                                       \
       }                                                                                  \
    } while (0)
+// rocPRIM's device functions return hipGetLastError() after every launch of theirs: whatever an EARLIER launch of this thread left there
+// comes back as their result -- and kernel launches of this library are not checked one by one (a launch over an empty range, grid 0,
+// on a rank or level without rows leaves "invalid configuration argument" behind and does nothing else).  Round 5: the partitioned
+// Galerkin product on a rank with an empty coarse level failed in segmented_radix_sort_pairs that way.  The thread's last error is read
+// (which clears it) before every rocPRIM call.
+#define HDA_ROCPRIM(expr)          \
+   do {                            \
+      (void)hipGetLastError();     \
+      HDA_HIP(expr);               \
+   } while (0)
 
 #define HDA_REQUIRE(cond, msg)                                                     \
    do {                                                                            \

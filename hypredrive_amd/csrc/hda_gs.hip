@@ -154,9 +154,9 @@ static void gs_order_rows(int n, const DArray<int> &level_of_row, const int *d_p
    int bits = 1;
    while (bits < 64 && ((unsigned long long)std::max(nb, 1) * (unsigned long long)std::max(nlev, 1)) >> bits) bits++;
    size_t tmp_bytes = 0;
-   HDA_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.data(), skeys.data(), rows.data(), perm.data(), (size_t)n, 0, bits, STREAM));
+   HDA_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.data(), skeys.data(), rows.data(), perm.data(), (size_t)n, 0, bits, STREAM));
    DArray<char> tmp(std::max<size_t>(tmp_bytes, 1));
-   HDA_HIP(rocprim::radix_sort_pairs(tmp.data(), tmp_bytes, keys.data(), skeys.data(), rows.data(), perm.data(), (size_t)n, 0, bits, STREAM));
+   HDA_ROCPRIM(rocprim::radix_sort_pairs(tmp.data(), tmp_bytes, keys.data(), skeys.data(), rows.data(), perm.data(), (size_t)n, 0, bits, STREAM));
    flag.zero();
    k_gs_group_flags<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, skeys.data(), flag.data());
    exclusive_scan(n, flag.data(), gidx.data(), nullptr);

@@ -2940,10 +2940,10 @@ void sort_rows_segmented(DCsr &C)
    int            bits = 1;
    while (bits < 31 && (std::max(C.ncols, C.nrows) >> bits)) bits++;
    size_t tmp_bytes = 0;
-   HDA_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, C.col.data(), k2.data(), C.val.data(), v2.data(), (unsigned)C.nnz, (unsigned)C.nrows,
+   HDA_ROCPRIM(rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, C.col.data(), k2.data(), C.val.data(), v2.data(), (unsigned)C.nnz, (unsigned)C.nrows,
                                                C.rowptr.data(), C.rowptr.data() + 1, 0, bits, STREAM));
    DArray<char> tmp(std::max<size_t>(tmp_bytes, 1));
-   HDA_HIP(rocprim::segmented_radix_sort_pairs(tmp.data(), tmp_bytes, C.col.data(), k2.data(), C.val.data(), v2.data(), (unsigned)C.nnz, (unsigned)C.nrows,
+   HDA_ROCPRIM(rocprim::segmented_radix_sort_pairs(tmp.data(), tmp_bytes, C.col.data(), k2.data(), C.val.data(), v2.data(), (unsigned)C.nnz, (unsigned)C.nrows,
                                                C.rowptr.data(), C.rowptr.data() + 1, 0, bits, STREAM));
    C.col = std::move(k2);
    C.val = std::move(v2);

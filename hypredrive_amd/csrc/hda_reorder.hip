@@ -174,9 +174,9 @@ void Amg::reorder_levels()
       k_parent<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, nc, P.rowptr.data(), P.col.data(), P.val.data(), parent.data());
       k_keys<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, parent.data(), (l + 1 <= top) ? rank[(size_t)l + 1].data() : nullptr, keys.data());
       size_t tmp_bytes = 0;
-      HDA_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys.data(), sorted.data(), (size_t)n, 0, 64, STREAM));
+      HDA_ROCPRIM(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys.data(), sorted.data(), (size_t)n, 0, 64, STREAM));
       DArray<char> tmp(std::max<size_t>(tmp_bytes, 1));
-      HDA_HIP(rocprim::radix_sort_keys(tmp.data(), tmp_bytes, keys.data(), sorted.data(), (size_t)n, 0, 64, STREAM));
+      HDA_ROCPRIM(rocprim::radix_sort_keys(tmp.data(), tmp_bytes, keys.data(), sorted.data(), (size_t)n, 0, 64, STREAM));
       perm[(size_t)l].alloc((size_t)std::max(n, 1));
       rank[(size_t)l].alloc((size_t)std::max(n, 1));
       k_unpack<<<ceil_div(n, 256), 256, 0, STREAM>>>(n, sorted.data(), perm[(size_t)l].data(), rank[(size_t)l].data());
