@@ -1571,7 +1571,10 @@ static void gs_free_plan(const GsPlan &plan, int n)
    // than two lanes with four each); two where a row would otherwise take 32 or 64 lanes and the blocks are long enough for the halved
    // number of rounds to count (128^3 level 2, rows of up to 69 entries, 7 000 rows per block: 0.47 -> 0.41 ms; level 3, 730 rows per
    // block: 0.079 -> 0.083, left at one)
-   constexpr int maxc2_from = 17;
+   // (round 5: from 9 chunks in the longest row -- 8 lanes x 2 chunks instead of 16 x 1, and with half the rounds the barrier-free kernel
+   //  beats the ring kernel on the level-1 operators of rank-block hierarchies: 69.9 -> 68.4 ms per 256^3 solve, 19.5 -> 18.5 ms at 128^3 on
+   //  -P 4 4 4 blocks, nothing lost on lexicographic slabs; from 2 or 5 chunks -- one lane per 7-point row -- measured the same as 9)
+   constexpr int maxc2_from = 9;
    const int maxc = (h[1] > 64 || (h[1] >= maxc2_from && maxblock >= 2048)) ? 2 : 1;
    int       lpr  = 1;
    while (lpr * maxc < h[1]) lpr <<= 1;
