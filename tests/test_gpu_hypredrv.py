@@ -1205,6 +1205,35 @@ def test_precon_reuse_over_a_sequence_matches_oracle(hd, orc, reuse, rebuild_on)
     h.close()
 
 
+def test_precon_reuse_with_hybrid_gauss_seidel_on_row_blocks(hd, orc, monkeypatch):
+    """The same sequence with the reference's CPU-build smoother (hybrid l1 Gauss-Seidel 13 / 14) on three row blocks, every level on the
+    sweep-order kernels: a kept hierarchy sweeps the NEW level-0 matrix with the divisors of its setup, whose sweep-order copy is kept
+    across cycles and solves (GsPlan::sd_src), the right-hand side's across the sweeps of one cycle (round 5)."""
+    monkeypatch.setenv("HDA_BLOCKS", "3")
+    monkeypatch.setenv("HDA_GS_SORTED_MIN", "0")
+    monkeypatch.setenv("HDA_GS_FREE_CHECK", "1")
+    mats, b = _sequence(orc, 4)
+    n = mats[0].shape[0]
+    h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    print_level: 0\n    relaxation:\n      down_type: 13\n      up_type: 14\n"
+                    "  reuse: always\n")
+    amg_o = None
+    for s, S in enumerate(mats):
+        Ao = orc.Csr.from_scipy(S)
+        if s == 0:
+            amg_o = orc.Amg(Ao, orc.amg_params(True, relax_down=13, relax_up=14, blocks=3))
+        else:
+            amg_o.rebind_level0(Ao)
+        ref = orc.pcg(Ao, b, amg_o)
+        h.set_matrix_csr(0, n - 1, S.indptr, S.indices, S.data)
+        h.set_rhs_array(0, n - 1, b)
+        h.finish_system()
+        for rep in range(2):  # (twice: the second solve finds every sweep-order copy of the first)
+            r = h.solve()
+            assert r["converged"] and r["iters"] == ref["iters"], (s, rep, r["iters"], ref["iters"])
+            assert np.linalg.norm(h.solution() - ref["x"]) / np.linalg.norm(ref["x"]) < 1e-9
+    h.close()
+
+
 def test_precon_reuse_repeated_solves_of_one_system(hd):
     """The laplacian driver's loop (5 x Create/Setup/Apply/Destroy on the same system) with reuse: always builds once."""
     h = hd.Hypredrv("solver: pcg\npreconditioner:\n  amg:\n    print_level: 0\n  reuse: always\n")
