@@ -115,6 +115,7 @@ struct GsPlan {
    mutable DArray<int>    r_pass[2], r_pass_ptr; // [0] forward, [1] backward; r_pass_ptr: nblk + 1 offsets (in passes, 2 spare ones per block)
    mutable int            ring_lpr = 0, ring_nt = 0;
    mutable int            free_lpr = 0, free_ring = 0, free_maxc = 1; // barrier-free kernel (k_gs_blocks_free): lanes per row (0 = not applicable), LDS ring slots, chunks per lane
+   mutable bool           free_long = false;                          // ... and whether rows beyond lanes x chunks exist (kernel with the long-row path)
    std::vector<int>       h_part;                                    // host copy of the blocks' row starts
    std::vector<int>       h_blk_lvl, h_blk_lvl_ptr; // host copies of blk_lvl / blk_lvl_ptr (the copies are rebuilt when a kept plan meets another matrix)
 };

@@ -1347,7 +1347,7 @@ __device__ __forceinline__ int group_and(int x)
    if (LPR >= 64) x &= __shfl_xor(x, 32);
    return x;
 }
-template <int LPR, int MAXC, int NT, bool BACKWARD>
+template <int LPR, int MAXC, int NT, bool BACKWARD, bool LONG>
 __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int *__restrict__ part, const int *__restrict__ srp4,
                                                        const int4 *__restrict__ scj4, const double2 *__restrict__ sv2,
                                                        const double *__restrict__ sd, const double *__restrict__ sb,
@@ -1388,8 +1388,10 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
    // (Deeper pipelines -- leads of 5 / 3 / 1 and 6 / 4 / 2 rounds -- measured the same: a round costs the instructions its eight
    //  wavefronts issue, two to a SIMD, not a memory latency.)
    struct RowA { int t, p, c0, c1; bool has; };
-   struct RowB { int t, p; bool has, mine[MAXC]; int4 c[MAXC]; double2 a01[MAXC], a23[MAXC]; double d, rhs, own, aii; };
-   struct RowX { int t, p; bool has, mine[MAXC]; double a[NE], v[NE], d, rhs, own, aii; int dep[NE]; };
+   // (c0, c1: the row's chunk range; a row of more than LPR * MAXC chunks -- the plan sizes the lanes for all but a few per cent of the
+   //  rows -- has its further chunks read in stage C itself: `long_row`)
+   struct RowB { int t, p, c0, c1; bool has, mine[MAXC]; int4 c[MAXC]; double2 a01[MAXC], a23[MAXC]; double d, rhs, own, aii; };
+   struct RowX { int t, p, c0, c1; bool has, mine[MAXC]; double a[NE], v[NE], d, rhs, own, aii; int dep[NE]; };
    auto stage_a = [&](int r) {
       RowA ra;
       ra.t   = r * G + g;
@@ -1401,7 +1403,7 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
    };
    auto stage_b = [&](const RowA &ra) {
       RowB rb;
-      rb.t = ra.t; rb.p = ra.p; rb.has = ra.has;
+      rb.t = ra.t; rb.p = ra.p; rb.has = ra.has; rb.c0 = ra.c0; rb.c1 = ra.has ? ra.c1 : ra.c0;
 #pragma unroll
       for (int m = 0; m < MAXC; m++)
       {
@@ -1421,7 +1423,7 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
    };
    auto stage_x = [&](const RowB &rb) {
       RowX rx;
-      rx.t = rb.t; rx.p = rb.p; rx.has = rb.has; rx.d = rb.d; rx.rhs = rb.rhs; rx.own = rb.own; rx.aii = rb.aii;
+      rx.t = rb.t; rx.p = rb.p; rx.has = rb.has; rx.c0 = rb.c0; rx.c1 = rb.c1; rx.d = rb.d; rx.rhs = rb.rhs; rx.own = rb.own; rx.aii = rb.aii;
 #pragma unroll
       for (int m = 0; m < MAXC; m++)
       {
@@ -1459,7 +1461,10 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
             if (++spins > (1 << 22)) { bad = 2; break; }
          }
       }
-      double xn = 0.0;
+      double     xn       = 0.0;
+      // (LONG: the plan left rows beyond the lanes' capacity -- few by its rule; without them the kernel is built without this path, which
+      //  costs 34 registers: 154 against 120 with one chunk per lane, one workgroup to a CU instead of two)
+      const bool long_row = LONG && rx.c1 - rx.c0 > LPR * MAXC;
       auto look = [&]() { // are this lane's dependencies done?  (every read unconditional: dep = -1 names the last slot, then ignored)
          int ok = 1;
 #pragma unroll
@@ -1468,6 +1473,21 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
             const int dn = DONE_LD(rx.dep[e] & (G - 1));
             ok &= (rx.dep[e] < 0) | (dn >= rx.dep[e]);
          }
+         if (long_row)
+            for (int ch = rx.c0 + LPR * MAXC + lane; ch < rx.c1; ch += LPR)
+            {
+               const int4 c       = scj4[ch];
+               const int  cols[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+               for (int e = 0; e < 4; e++)
+               {
+                  const int  col   = cols[e];
+                  const bool isdep = col >= 0 && (backward ? col > rx.p : col < rx.p);
+                  const int  dep   = isdep ? (backward ? hi - 1 - col : col - lo) : -1;
+                  const int  dn    = DONE_LD(dep & (G - 1));
+                  ok &= (dep < 0) | (dn >= dep);
+               }
+            }
          return group_and<LPR>(ok);
       };
       auto finish = [&]() { // the row's sum with the ring's values, the update, the new value into the ring and then the flag
@@ -1484,6 +1504,26 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
             for (int e = 4 * m; e < 4 * m + 4; e++) sm += rx.a[e] * (rx.dep[e] >= 0 ? rv[e] : rx.v[e]);
             sum += rx.mine[m] ? sm : 0.0;
          }
+         if (long_row)
+            for (int ch = rx.c0 + LPR * MAXC + lane; ch < rx.c1; ch += LPR)
+            {
+               const int4    c       = scj4[ch];
+               const double2 a01 = sv2[2 * ch], a23 = sv2[2 * ch + 1];
+               const int     cols[4] = {c.x, c.y, c.z, c.w};
+               const double  as[4]   = {a01.x, a01.y, a23.x, a23.y};
+               double        sm      = 0.0;
+#pragma unroll
+               for (int e = 0; e < 4; e++)
+               {
+                  const int  col   = cols[e];
+                  const int  pos   = col ^ (col >> 31);
+                  const bool isdep = col >= 0 && (backward ? col > rx.p : col < rx.p);
+                  const int  dep   = isdep ? (backward ? hi - 1 - col : col - lo) : -1;
+                  const double val = isdep ? RING_LD(dep & ring_mask) : sx0[pos];
+                  sm += as[e] * val;
+               }
+               sum += sm;
+            }
          sum = group_sum<LPR>(sum);
          xn  = rx.own + rx.d * (rx.rhs - (sum + rx.aii * rx.own)); // (the diagonal entry is kept apart: s_aii)
          if (lane == 0 && rx.has)
@@ -1537,28 +1577,43 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
 #undef WDONE_ST
 
 // longest distance, in sweep positions, between a row and an in-block column of it (the reach of a dependency in either direction)
-__global__ __launch_bounds__(256) void k_gs_reach(int n, const int *__restrict__ srp4, const int *__restrict__ scj, int *reach, int *maxchunks)
+__global__ __launch_bounds__(256) void k_gs_reach(int n, const int *__restrict__ srp4, const int *__restrict__ scj, int *reach, int *maxchunks,
+                                                  int *longer)
 {
    int m = 0, k = 0; // (grid-stride, a small grid: the two atomics of a wavefront queue at the L2 behind everybody else's)
+   int lg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // rows of more than 1, 2, 4, ..., 128 chunks
    for (long ql = (long)blockIdx.x * 256 + threadIdx.x; ql < n; ql += (long)gridDim.x * 256)
    {
-      const int q = (int)ql;
-      k           = max(k, srp4[q + 1] - srp4[q]);
+      const int q = (int)ql, nc = srp4[q + 1] - srp4[q];
+#pragma unroll
+      for (int j = 0; j < 8; j++) lg[j] += (nc > (1 << j));
+      k = max(k, nc);
       for (int e = 4 * srp4[q]; e < 4 * srp4[q + 1]; e++)
          if (scj[e] >= 0) m = max(m, abs(scj[e] - q));
    }
    for (int o = 32; o > 0; o >>= 1) { m = max(m, __shfl_xor(m, o)); k = max(k, __shfl_xor(k, o)); }
-   if ((threadIdx.x & 63) == 0) { if (m) atomicMax(reach, m); if (k) atomicMax(maxchunks, k); }
+#pragma unroll
+   for (int j = 0; j < 8; j++)
+      for (int o = 32; o > 0; o >>= 1) lg[j] += __shfl_xor(lg[j], o);
+   if ((threadIdx.x & 63) == 0)
+   {
+      if (m) atomicMax(reach, m);
+      if (k) atomicMax(maxchunks, k);
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+         if (lg[j]) atomicAdd(&longer[j], lg[j]);
+   }
 }
 static void gs_free_plan(const GsPlan &plan, int n)
 { // can the barrier-free kernel take this operator?  ring size, lanes per row and chunks per lane if so
    plan.free_lpr = 0;
    if (!plan.sorted || !plan.s_x0.size()) return;
-   DArray<int> two(2);
+   DArray<int> two(10);
    two.zero();
-   k_gs_reach<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), two.data(), two.data() + 1);
-   int h[2] = {0, 0};
-   two.download(h, 2);
+   k_gs_reach<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), two.data(), two.data() + 1, two.data() + 2);
+   int h[10] = {0};
+   two.download(h, 10);
+   const int *longer = h + 2; // rows of more than 1, 2, 4, ..., 128 chunks
    int maxblock = 0;
    for (size_t q = 0; q + 1 < plan.h_part.size(); q++) maxblock = std::max(maxblock, plan.h_part[q + 1] - plan.h_part[q]);
    int ring = 1024;
@@ -1574,10 +1629,21 @@ static void gs_free_plan(const GsPlan &plan, int n)
    // (round 5: from 9 chunks in the longest row -- 8 lanes x 2 chunks instead of 16 x 1, and with half the rounds the barrier-free kernel
    //  beats the ring kernel on the level-1 operators of rank-block hierarchies: 69.9 -> 68.4 ms per 256^3 solve, 19.5 -> 18.5 ms at 128^3 on
    //  -P 4 4 4 blocks, nothing lost on lexicographic slabs; from 2 or 5 chunks -- one lane per 7-point row -- measured the same as 9)
-   constexpr int maxc2_from = 9;
-   const int maxc = (h[1] > 64 || (h[1] >= maxc2_from && maxblock >= 2048)) ? 2 : 1;
-   int       lpr  = 1;
-   while (lpr * maxc < h[1]) lpr <<= 1;
+   // Round 5, second step: the lanes of a row are sized for MOST rows, not for the longest -- capacity C = lanes x chunks per lane = the
+   // smallest power of two that leaves at most 0.3 % of the rows longer; those read their further chunks inside stage C (`long_row`).  The
+   // level-1 operator of the 256^3 rank-block hierarchy: 4.1 chunks per row on average, 99.86 % of the rows within 8, the longest 11 --
+   // 16 lanes' worth of instructions were issued for every row, a quarter of them for entries; level 2: mean 12, 98 % within 16, longest 24.
+   // (what a long row costs: loads from memory inside the update stage -- the wavefront waits for everything it has requested for the next
+   //  three rounds, then for the L2, and every row behind it in the sweep waits with it.  Measured on the 256^3 rank-block hierarchy: 0.2 % of
+   //  such rows on level 1 still leave 0.86 -> 0.60 ms per sweep for halving the lanes; 2.5 % on level 2 cost 0.44 -> 0.57 ms with half the
+   //  lanes, and on blocks of a few hundred rows a single one shows (0.144 -> 0.184 ms): 0.3 % at most, and blocks of 2048 rows or more.)
+   int C = 1;
+   while (C < h[1] && C < 128 && (maxblock < 2048 || longer[__builtin_ctz(C)] > (int)(0.003 * n))) C <<= 1;
+   constexpr int maxc2_from = 8;
+   // (two chunks per lane cost 188 registers against 120 -- one workgroup to a CU instead of two -- and still win on blocks of 2048 rows
+   //  and more: 64.6 against 66.2 ms per 256^3 solve with (4, 2) / (16, 2) against (8, 1) / (32, 1) lanes x chunks on levels 1 / 2)
+   const int maxc = (C > 64 || (C >= maxc2_from && maxblock >= 2048)) ? 2 : 1;
+   int       lpr  = std::max(C / maxc, 1);
    // the ring's guard (k_gs_blocks_free stage C): round 0 can start only if G = 512 / lpr groups fit twice into what the guard leaves
    // free, G <= RING - RING / 4 - G - 1 -- with one lane per row (rows of <= 4 off-diagonal entries: a 2-D five-point or tridiagonal
    // operator on blocks of more than 16384 rows) that needs 2048 slots where 1024 cover the reach (round-4 ADVICE: every wavefront
@@ -1593,9 +1659,11 @@ static void gs_free_plan(const GsPlan &plan, int n)
    plan.free_ring = ring;
    plan.free_lpr  = lpr;
    plan.free_maxc = maxc;
+   plan.free_long = lpr * maxc < h[1]; // rows beyond the lanes' capacity exist: the kernel with the long-row path
    if (getenv("HDA_VERBOSE"))
-      fprintf(stderr, "[hda] block Gauss-Seidel plan: barrier-free kernel, dependency reach %d positions, largest block %d rows (ring %d), %d lanes per row, %d chunks per lane\n",
-              h[0], maxblock, ring, lpr, maxc);
+      fprintf(stderr, "[hda] block Gauss-Seidel plan: barrier-free kernel, dependency reach %d positions, largest block %d rows (ring %d), %d lanes per row, %d chunks per lane "
+                      "(longest row %d chunks; %.2f %% of the rows beyond the lanes' %d)\n",
+              h[0], maxblock, ring, lpr, maxc, h[1], lpr * maxc < 256 && lpr * maxc <= 128 ? 100.0 * longer[__builtin_ctz(lpr * maxc)] / std::max(n, 1) : 0.0, lpr * maxc);
 }
 static int           *g_free_err = nullptr;
 static std::once_flag g_free_err_once;
@@ -1623,7 +1691,7 @@ void gs_free_check()
    }
 }
 
-template <int LPR, int MAXC>
+template <int LPR, int MAXC, bool LONG>
 static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
                              bool zero_in)
 {
@@ -1645,8 +1713,8 @@ static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv,
    const double *x0  = zero_in ? p.s_zero.data() : p.s_x0.data();
    const size_t  lds = sizeof(double) * (size_t)p.free_ring;
 #define HDA_GS_FREE_LAUNCH(BW)                                                                                                               \
-   HDA_HIP(hipFuncSetAttribute((const void *)k_gs_blocks_free<LPR, MAXC, NT, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));  \
-   k_gs_blocks_free<LPR, MAXC, NT, BW><<<p.nblk, NT, lds, STREAM>>>(p.free_ring - 1, p.blk_part.data(), p.s_rowptr.data(),                   \
+   HDA_HIP(hipFuncSetAttribute((const void *)k_gs_blocks_free<LPR, MAXC, NT, BW, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));  \
+   k_gs_blocks_free<LPR, MAXC, NT, BW, LONG><<<p.nblk, NT, lds, STREAM>>>(p.free_ring - 1, p.blk_part.data(), p.s_rowptr.data(),                   \
                                                                     (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(), p.s_d.data(), \
                                                                     p.s_b.data(), p.s_aii.data(), x0, p.s_x.data(), err)
    if (forward) { HDA_GS_FREE_LAUNCH(false); }
@@ -1700,8 +1768,13 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
 #define HDA_GS_FREE(L)                                                                                      \
    do                                                                                                       \
    {                                                                                                        \
-      if (plan.free_maxc == 2) gs_blocks_free_t<L, 2>(A, plan, dinv, b, xin, xout, forward, zero_in);       \
-      else gs_blocks_free_t<L, 1>(A, plan, dinv, b, xin, xout, forward, zero_in);                           \
+      if (plan.free_long)                                                                                   \
+      {                                                                                                     \
+         if (plan.free_maxc == 2) gs_blocks_free_t<L, 2, true>(A, plan, dinv, b, xin, xout, forward, zero_in);  \
+         else gs_blocks_free_t<L, 1, true>(A, plan, dinv, b, xin, xout, forward, zero_in);                  \
+      }                                                                                                     \
+      else if (plan.free_maxc == 2) gs_blocks_free_t<L, 2, false>(A, plan, dinv, b, xin, xout, forward, zero_in); \
+      else gs_blocks_free_t<L, 1, false>(A, plan, dinv, b, xin, xout, forward, zero_in);                    \
    } while (0)
       switch (plan.free_lpr)
       {

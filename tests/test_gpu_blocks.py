@@ -138,6 +138,38 @@ def test_block_gauss_seidel_short_rows_on_blocks_beyond_16384_rows(orc, hd, monk
             assert rel(Ah.relax_blocks(b, x0, part, rtype, 1.0), xo) < 1e-12, (case, list(part), rtype)
 
 
+def test_block_gauss_seidel_rows_beyond_the_lanes_capacity(orc, hd, monkeypatch):
+    """Round 5: the barrier-free kernel sizes a row's lanes for all but 0.3 % of the rows; the longer ones read their further chunks
+    inside the update stage.  A five-point operator (one chunk per row) in which one row in five hundred is coupled to 40 more unknowns,
+    near and far, earlier and later in the sweep, inside and outside its block."""
+    monkeypatch.setenv("HDA_GS_SORTED_MIN", "0")
+    monkeypatch.setenv("HDA_GS_FREE", "1")
+    monkeypatch.setenv("HDA_GS_FREE_CHECK", "1")
+    nx, ny = 150, 160
+    T = lambda m: sp.diags([-np.ones(m - 1), 2.0 * np.ones(m), -np.ones(m - 1)], [-1, 0, 1])
+    M = (sp.kron(sp.eye(ny), T(nx)) + sp.kron(T(ny), sp.eye(nx))).tolil()
+    n = nx * ny
+    rng = np.random.default_rng(11)
+    for i in rng.choice(n, n // 500, replace=False):
+        near = np.clip(i + rng.integers(-300, 300, 20), 0, n - 1)
+        far = rng.integers(0, n, 20)
+        for j in np.concatenate([near, far]):
+            if j != i:
+                M[i, j] = M[j, i] = -0.05
+    M = M.tocsr()
+    M.setdiag(np.asarray(abs(M).sum(axis=1)).ravel() + 0.5)
+    M = M.tocsr(); M.sort_indices()
+    Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    for part in ([0, n], [0, 5000, 11000, 17000, n]):
+        l1 = orc.l1_norms_blocks(Ao, 4, np.array(part))
+        for rtype in (13, 14):
+            xo = orc.relax_blocks(Ao, l1, rtype, 1.0, b, x0, np.array(part))
+            assert rel(Ah.relax_blocks(b, x0, np.array(part), rtype, 1.0), xo) < 1e-12, (part, rtype)
+            xz = orc.relax_blocks(Ao, l1, rtype, 1.0, b, np.zeros(n), np.array(part))
+            assert rel(Ah.relax_blocks(b, np.zeros(n), np.array(part), rtype, 1.0), xz) < 1e-12, (part, rtype, "zero guess")
+
+
 def test_one_block_is_the_sequential_sweep(orc, hd):
     M = mmatrix(800, 0.01, 21)
     Ao, Ah = orc.Csr.from_scipy(M), hd.Csr.from_scipy(M)
