@@ -108,7 +108,6 @@ struct GsPlan {
    // (block, level) in the order of blk_lvl
    mutable DArray<int>    r_cb, r_w, r_col;
    mutable DArray<double> r_val, s_x0; // (s_x0: the iterate at the start of the sweep in sweep order -- what the other blocks' columns read)
-   mutable DArray<double> s_zero;      // zeros: the sweep-start iterate of a barrier-free sweep from a zero guess (never written)
    mutable bool           ring = false;
    // the sweep as a list of PASSES per block and direction (8 ints each: first position, rows, first chunk, chunks per row, the
    // positions whose values come from the LDS ring, barrier-after flag), so that the kernel's control flow is one scalar load

@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256) void k_gs_to_sweep_order(int n, int zero_in, c
    if (q >= n) return;
    const int i = perm[q];
    if (sx || sx0)
-   { // (the barrier-free kernel reads the sweep-start copy alone -- a zero input is an array of zeros that is never written --
+   { // (the barrier-free kernel reads the sweep-start copy alone -- not even that for a zero input, which it is told of --
      //  and writes its result in the caller's numbering: neither pointer, or sx0 only)
       const double x = zero_in ? 0.0 : xin[i];
       if (sx) sx[q] = x;
@@ -1348,7 +1348,7 @@ __device__ __forceinline__ int group_and(int x)
    return x;
 }
 template <int LPR, int MAXC, int NT, bool BACKWARD, bool LONG>
-__global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int *__restrict__ part, const int *__restrict__ srp4,
+__global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, int zero_in, const int *__restrict__ part, const int *__restrict__ srp4,
                                                        const int4 *__restrict__ scj4, const double2 *__restrict__ sv2,
                                                        const double *__restrict__ sd, const double *__restrict__ sb,
                                                        const double *__restrict__ saii, const double *__restrict__ sx0, double *sx, int *err)
@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
       }
       rb.d   = sd[ra.p];
       rb.rhs = sb[ra.p];
-      rb.own = sx0[ra.p];
+      rb.own = zero_in ? 0.0 : sx0[ra.p]; // (zero_in, the same for every lane of the grid: a sweep from the zero guess reads no iterate)
       rb.aii = saii[ra.p];
       return rb;
    };
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
             const int  col   = cols[e];
             const int  pos   = col ^ (col >> 31); // (another block's column is stored as ~position: the sweep-start copy serves both)
             const bool isdep = col >= 0 && (backward ? col > rb.p : col < rb.p);
-            const double val = sx0[pos];
+            const double val = zero_in ? 0.0 : sx0[pos];
             rx.a[4 * m + e]   = as[e];
             rx.dep[4 * m + e] = isdep ? (backward ? hi - 1 - col : col - lo) : -1;
             rx.v[4 * m + e]   = isdep ? 0.0 : val;
@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(NT) void k_gs_blocks_free(int ring_mask, const int 
                   const int  pos   = col ^ (col >> 31);
                   const bool isdep = col >= 0 && (backward ? col > rx.p : col < rx.p);
                   const int  dep   = isdep ? (backward ? hi - 1 - col : col - lo) : -1;
-                  const double val = isdep ? RING_LD(dep & ring_mask) : sx0[pos];
+                  const double val = isdep ? RING_LD(dep & ring_mask) : (zero_in ? 0.0 : sx0[pos]);
                   sm += as[e] * val;
                }
                sum += sm;
@@ -1702,21 +1702,15 @@ static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv,
    //  unless it is zero.  Its result it writes in sweep order too, and a second kernel scatters it: stores to the caller's numbering
    //  from inside the sweep were tried in round 5 -- 8-byte stores all over a block's part of x, whose lines leave the L2 half
    //  written on blocks of 65 536 rows and more: 106.6 -> 115.5 ms per 256^3 solve on 64 blocks, nothing gained on 512)
-   if (zero_in && p.s_zero.size() != (size_t)n)
-   { // (made by the first sweep from zero of a level that runs this kernel: a level on the ring kernel never needs it)
-      p.s_zero.alloc((size_t)n);
-      p.s_zero.zero();
-   }
    if (!zero_in || p.to_b || p.to_d)
       k_gs_to_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, p.to_b, p.to_d, nullptr, p.s_b.data(), p.s_d.data(),
                                                              zero_in ? nullptr : p.s_x0.data());
-   const double *x0  = zero_in ? p.s_zero.data() : p.s_x0.data();
    const size_t  lds = sizeof(double) * (size_t)p.free_ring;
 #define HDA_GS_FREE_LAUNCH(BW)                                                                                                               \
    HDA_HIP(hipFuncSetAttribute((const void *)k_gs_blocks_free<LPR, MAXC, NT, BW, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));  \
-   k_gs_blocks_free<LPR, MAXC, NT, BW, LONG><<<p.nblk, NT, lds, STREAM>>>(p.free_ring - 1, p.blk_part.data(), p.s_rowptr.data(),                   \
+   k_gs_blocks_free<LPR, MAXC, NT, BW, LONG><<<p.nblk, NT, lds, STREAM>>>(p.free_ring - 1, zero_in ? 1 : 0, p.blk_part.data(), p.s_rowptr.data(),                   \
                                                                     (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(), p.s_d.data(), \
-                                                                    p.s_b.data(), p.s_aii.data(), x0, p.s_x.data(), err)
+                                                                    p.s_b.data(), p.s_aii.data(), p.s_x0.data(), p.s_x.data(), err)
    if (forward) { HDA_GS_FREE_LAUNCH(false); }
    else { HDA_GS_FREE_LAUNCH(true); }
 #undef HDA_GS_FREE_LAUNCH
