@@ -115,6 +115,11 @@ struct GsPlan {
    mutable int            ring_lpr = 0, ring_nt = 0;
    mutable int            free_lpr = 0, free_ring = 0, free_maxc = 1; // barrier-free kernel (k_gs_blocks_free): lanes per row (0 = not applicable), LDS ring slots, chunks per lane
    mutable bool           free_long = false;                          // ... and whether rows beyond lanes x chunks exist (kernel with the long-row path)
+   // the dependency copy: of every row the in-block columns EARLIER in the sweep alone -- all that a forward sweep from the zero guess needs
+   mutable DArray<int>    d_rowptr, d_col;
+   mutable DArray<double> d_val;
+   mutable int            dep_lpr = 0, dep_ring = 0, dep_maxc = 1; // (0 lanes: no such copy)
+   mutable bool           dep_long = false;
    std::vector<int>       h_part;                                    // host copy of the blocks' row starts
    std::vector<int>       h_blk_lvl, h_blk_lvl_ptr; // host copies of blk_lvl / blk_lvl_ptr (the copies are rebuilt when a kept plan meets another matrix)
 };

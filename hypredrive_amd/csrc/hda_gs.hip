@@ -1604,13 +1604,14 @@ __global__ __launch_bounds__(256) void k_gs_reach(int n, const int *__restrict__
          if (lg[j]) atomicAdd(&longer[j], lg[j]);
    }
 }
-static void gs_free_plan(const GsPlan &plan, int n)
-{ // can the barrier-free kernel take this operator?  ring size, lanes per row and chunks per lane if so
-   plan.free_lpr = 0;
-   if (!plan.sorted || !plan.s_x0.size()) return;
+struct GsFreeShape { int ring = 0, lpr = 0, maxc = 1; bool lng = false; };
+// can the barrier-free kernel take this sweep-order copy (chunk offsets rp4, columns cj)?  ring size, lanes per row and chunks per lane if so
+static GsFreeShape gs_free_shape(const GsPlan &plan, int n, const int *rp4, const int *cj, const char *what)
+{
+   GsFreeShape out;
    DArray<int> two(10);
    two.zero();
-   k_gs_reach<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), two.data(), two.data() + 1, two.data() + 2);
+   k_gs_reach<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, rp4, cj, two.data(), two.data() + 1, two.data() + 2);
    int h[10] = {0};
    two.download(h, 10);
    const int *longer = h + 2; // rows of more than 1, 2, 4, ..., 128 chunks
@@ -1654,16 +1655,70 @@ static void gs_free_plan(const GsPlan &plan, int n)
    {
       if (getenv("HDA_VERBOSE"))
          fprintf(stderr, "[hda] block Gauss-Seidel plan: barrier-free kernel not used (dependency reach %d positions, %d chunks in the longest row)\n", h[0], h[1]);
-      return;
+      return out;
    }
-   plan.free_ring = ring;
-   plan.free_lpr  = lpr;
-   plan.free_maxc = maxc;
-   plan.free_long = lpr * maxc < h[1]; // rows beyond the lanes' capacity exist: the kernel with the long-row path
+   out.ring = ring;
+   out.lpr  = lpr;
+   out.maxc = maxc;
+   out.lng  = lpr * maxc < h[1]; // rows beyond the lanes' capacity exist: the kernel with the long-row path
    if (getenv("HDA_VERBOSE"))
-      fprintf(stderr, "[hda] block Gauss-Seidel plan: barrier-free kernel, dependency reach %d positions, largest block %d rows (ring %d), %d lanes per row, %d chunks per lane "
+      fprintf(stderr, "[hda] block Gauss-Seidel plan: barrier-free kernel%s, dependency reach %d positions, largest block %d rows (ring %d), %d lanes per row, %d chunks per lane "
                       "(longest row %d chunks; %.2f %% of the rows beyond the lanes' %d)\n",
-              h[0], maxblock, ring, lpr, maxc, h[1], lpr * maxc < 256 && lpr * maxc <= 128 ? 100.0 * longer[__builtin_ctz(lpr * maxc)] / std::max(n, 1) : 0.0, lpr * maxc);
+              what, h[0], maxblock, ring, lpr, maxc, h[1], lpr * maxc < 256 && lpr * maxc <= 128 ? 100.0 * longer[__builtin_ctz(lpr * maxc)] / std::max(n, 1) : 0.0, lpr * maxc);
+   return out;
+}
+
+// the forward sweep from the zero guess -- every down sweep of a V(1,1) cycle, the L solve of a block ILU -- multiplies everything but a
+// row's in-block columns EARLIER in the sweep by zero: a second copy with those entries alone (about half the operator) is what that sweep
+// streams, with lanes sized for its shorter rows
+__global__ __launch_bounds__(256) void k_gs_dep_count(int n, const int *__restrict__ srp4, const int *__restrict__ scj, int *__restrict__ len4)
+{
+   const int q = xcd_chunk_block() * 256 + threadIdx.x;
+   if (q >= n) return;
+   int c = 0;
+   for (int e = 4 * srp4[q]; e < 4 * srp4[q + 1]; e++) c += (scj[e] >= 0 && scj[e] < q);
+   len4[q] = (c + 3) >> 2;
+}
+__global__ __launch_bounds__(256) void k_gs_dep_fill(int n, const int *__restrict__ srp4, const int *__restrict__ scj, const double *__restrict__ sv,
+                                                     const int *__restrict__ lrp4, int *__restrict__ lcj, double *__restrict__ lv)
+{
+   const int q = xcd_chunk_block() * 256 + threadIdx.x;
+   if (q >= n) return;
+   int d = 4 * lrp4[q];
+   for (int e = 4 * srp4[q]; e < 4 * srp4[q + 1]; e++)
+      if (scj[e] >= 0 && scj[e] < q) { lcj[d] = scj[e]; lv[d] = sv[e]; d++; } // (same order as in the row)
+   for (const int e1 = 4 * lrp4[q + 1]; d < e1; d++) { lcj[d] = q; lv[d] = 0.0; }
+}
+static void gs_free_plan(const GsPlan &plan, int n)
+{
+   plan.free_lpr = plan.dep_lpr = 0;
+   if (!plan.sorted || !plan.s_x0.size()) return;
+   const GsFreeShape f = gs_free_shape(plan, n, plan.s_rowptr.data(), plan.s_col.data(), "");
+   if (f.lpr == 0) return;
+   plan.free_ring = f.ring;
+   plan.free_lpr  = f.lpr;
+   plan.free_maxc = f.maxc;
+   plan.free_long = f.lng;
+   // the dependency copy (forward sweeps from zero)
+   DArray<int> len4((size_t)n + 1);
+   k_gs_dep_count<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), len4.data());
+   plan.d_rowptr.alloc((size_t)n + 1);
+   exclusive_scan(n, len4.data(), plan.d_rowptr.data(), nullptr);
+   int chunks = 0;
+   HDA_HIP(hipMemcpyAsync(&chunks, plan.d_rowptr.data() + n, 4, hipMemcpyDeviceToHost, STREAM));
+   Context::get().sync();
+   plan.d_col.alloc((size_t)4 * chunks + 4); // (one spare chunk, as in the full copy)
+   plan.d_val.alloc((size_t)4 * chunks + 4);
+   HDA_HIP(hipMemsetAsync(plan.d_col.data() + (size_t)4 * chunks, 0, 4 * sizeof(int), STREAM));
+   HDA_HIP(hipMemsetAsync(plan.d_val.data() + (size_t)4 * chunks, 0, 4 * sizeof(double), STREAM));
+   k_gs_dep_fill<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), plan.s_val.data(), plan.d_rowptr.data(),
+                                                      plan.d_col.data(), plan.d_val.data());
+   const GsFreeShape g = gs_free_shape(plan, n, plan.d_rowptr.data(), plan.d_col.data(), " (dependency copy)");
+   if (g.lpr == 0) return;
+   plan.dep_ring = g.ring;
+   plan.dep_lpr  = g.lpr;
+   plan.dep_maxc = g.maxc;
+   plan.dep_long = g.lng;
 }
 static int           *g_free_err = nullptr;
 static std::once_flag g_free_err_once;
@@ -1693,8 +1748,8 @@ void gs_free_check()
 
 template <int LPR, int MAXC, bool LONG>
 static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv, const double *b, const double *xin, double *xout, bool forward,
-                             bool zero_in)
-{
+                             bool zero_in, bool dep)
+{ // dep: the dependency copy (forward from zero: gs_free_plan) instead of the whole operator
    const int n = A.nrows;
    constexpr int NT = 512; // (1024 threads leave a lane 128 registers: the four rows in flight spill)
    int *err = gs_free_error_flag(); // (one flag per process: the kernel raises it instead of spinning forever; read by gs_free_check)
@@ -1705,11 +1760,14 @@ static void gs_blocks_free_t(const DCsr &A, const GsPlan &p, const double *dinv,
    if (!zero_in || p.to_b || p.to_d)
       k_gs_to_sweep_order<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, zero_in ? 1 : 0, p.perm.data(), xin, p.to_b, p.to_d, nullptr, p.s_b.data(), p.s_d.data(),
                                                              zero_in ? nullptr : p.s_x0.data());
-   const size_t  lds = sizeof(double) * (size_t)p.free_ring;
+   const int     ring = dep ? p.dep_ring : p.free_ring;
+   const size_t  lds  = sizeof(double) * (size_t)ring;
+   const int    *rp4  = dep ? p.d_rowptr.data() : p.s_rowptr.data();
+   const int4   *cj4  = (const int4 *)(dep ? p.d_col.data() : p.s_col.data());
+   const double2 *v2  = (const double2 *)(dep ? p.d_val.data() : p.s_val.data());
 #define HDA_GS_FREE_LAUNCH(BW)                                                                                                               \
    HDA_HIP(hipFuncSetAttribute((const void *)k_gs_blocks_free<LPR, MAXC, NT, BW, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));  \
-   k_gs_blocks_free<LPR, MAXC, NT, BW, LONG><<<p.nblk, NT, lds, STREAM>>>(p.free_ring - 1, zero_in ? 1 : 0, p.blk_part.data(), p.s_rowptr.data(),                   \
-                                                                    (const int4 *)p.s_col.data(), (const double2 *)p.s_val.data(), p.s_d.data(), \
+   k_gs_blocks_free<LPR, MAXC, NT, BW, LONG><<<p.nblk, NT, lds, STREAM>>>(ring - 1, zero_in ? 1 : 0, p.blk_part.data(), rp4, cj4, v2, p.s_d.data(), \
                                                                     p.s_b.data(), p.s_aii.data(), p.s_x0.data(), p.s_x.data(), err)
    if (forward) { HDA_GS_FREE_LAUNCH(false); }
    else { HDA_GS_FREE_LAUNCH(true); }
@@ -1762,15 +1820,19 @@ void gs_sweep_blocks(const DCsr &A, const GsPlan &plan, const double *dinv, cons
 #define HDA_GS_FREE(L)                                                                                      \
    do                                                                                                       \
    {                                                                                                        \
-      if (plan.free_long)                                                                                   \
+      if (f_long)                                                                                           \
       {                                                                                                     \
-         if (plan.free_maxc == 2) gs_blocks_free_t<L, 2, true>(A, plan, dinv, b, xin, xout, forward, zero_in);  \
-         else gs_blocks_free_t<L, 1, true>(A, plan, dinv, b, xin, xout, forward, zero_in);                  \
+         if (f_maxc == 2) gs_blocks_free_t<L, 2, true>(A, plan, dinv, b, xin, xout, forward, zero_in, dep); \
+         else gs_blocks_free_t<L, 1, true>(A, plan, dinv, b, xin, xout, forward, zero_in, dep);             \
       }                                                                                                     \
-      else if (plan.free_maxc == 2) gs_blocks_free_t<L, 2, false>(A, plan, dinv, b, xin, xout, forward, zero_in); \
-      else gs_blocks_free_t<L, 1, false>(A, plan, dinv, b, xin, xout, forward, zero_in);                    \
+      else if (f_maxc == 2) gs_blocks_free_t<L, 2, false>(A, plan, dinv, b, xin, xout, forward, zero_in, dep); \
+      else gs_blocks_free_t<L, 1, false>(A, plan, dinv, b, xin, xout, forward, zero_in, dep);               \
    } while (0)
-      switch (plan.free_lpr)
+      // a forward sweep from zero streams the dependency copy where the plan has one (HDA_GS_DEP=0: the whole operator, for the tests)
+      const bool dep    = zero_in && forward && plan.dep_lpr > 0 && !(getenv("HDA_GS_DEP") && atoi(getenv("HDA_GS_DEP")) == 0);
+      const int  f_lpr  = dep ? plan.dep_lpr : plan.free_lpr, f_maxc = dep ? plan.dep_maxc : plan.free_maxc;
+      const bool f_long = dep ? plan.dep_long : plan.free_long;
+      switch (f_lpr)
       {
          case 1: HDA_GS_FREE(1); break;
          case 2: HDA_GS_FREE(2); break;

@@ -138,10 +138,13 @@ def test_block_gauss_seidel_short_rows_on_blocks_beyond_16384_rows(orc, hd, monk
             assert rel(Ah.relax_blocks(b, x0, part, rtype, 1.0), xo) < 1e-12, (case, list(part), rtype)
 
 
-def test_block_gauss_seidel_rows_beyond_the_lanes_capacity(orc, hd, monkeypatch):
+@pytest.mark.parametrize("dep_copy", ["1", "0"])
+def test_block_gauss_seidel_rows_beyond_the_lanes_capacity(orc, hd, monkeypatch, dep_copy):
     """Round 5: the barrier-free kernel sizes a row's lanes for all but 0.3 % of the rows; the longer ones read their further chunks
     inside the update stage.  A five-point operator (one chunk per row) in which one row in five hundred is coupled to 40 more unknowns,
-    near and far, earlier and later in the sweep, inside and outside its block."""
+    near and far, earlier and later in the sweep, inside and outside its block.  dep_copy: forward sweeps from the zero guess on the
+    copy of the in-block earlier columns alone (the default) or on the whole operator."""
+    monkeypatch.setenv("HDA_GS_DEP", dep_copy)
     monkeypatch.setenv("HDA_GS_SORTED_MIN", "0")
     monkeypatch.setenv("HDA_GS_FREE", "1")
     monkeypatch.setenv("HDA_GS_FREE_CHECK", "1")
