@@ -1604,16 +1604,20 @@ __global__ __launch_bounds__(256) void k_gs_reach(int n, const int *__restrict__
          if (lg[j]) atomicAdd(&longer[j], lg[j]);
    }
 }
+__global__ void k_gs_chunk_hist(int n, const int *__restrict__ srp4, int *maxchunks, int *longer);
 struct GsFreeShape { int ring = 0, lpr = 0, maxc = 1; bool lng = false; };
 // can the barrier-free kernel take this sweep-order copy (chunk offsets rp4, columns cj)?  ring size, lanes per row and chunks per lane if so
-static GsFreeShape gs_free_shape(const GsPlan &plan, int n, const int *rp4, const int *cj, const char *what)
+static GsFreeShape gs_free_shape(const GsPlan &plan, int n, const int *rp4, const int *cj, const char *what, int known_reach = -1, int *reach_out = nullptr)
 {
    GsFreeShape out;
    DArray<int> two(10);
    two.zero();
-   k_gs_reach<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, rp4, cj, two.data(), two.data() + 1, two.data() + 2);
+   if (known_reach >= 0) k_gs_chunk_hist<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, rp4, two.data() + 1, two.data() + 2);
+   else k_gs_reach<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, rp4, cj, two.data(), two.data() + 1, two.data() + 2);
    int h[10] = {0};
    two.download(h, 10);
+   if (known_reach >= 0) h[0] = known_reach; // (a bound: the copy holds a subset of the entries the reach was taken over)
+   if (reach_out) *reach_out = h[0];
    const int *longer = h + 2; // rows of more than 1, 2, 4, ..., 128 chunks
    int maxblock = 0;
    for (size_t q = 0; q + 1 < plan.h_part.size(); q++) maxblock = std::max(maxblock, plan.h_part[q + 1] - plan.h_part[q]);
@@ -1681,19 +1685,71 @@ __global__ __launch_bounds__(256) void k_gs_dep_count(int n, const int *__restri
 }
 __global__ __launch_bounds__(256) void k_gs_dep_fill(int n, const int *__restrict__ srp4, const int *__restrict__ scj, const double *__restrict__ sv,
                                                      const int *__restrict__ lrp4, int *__restrict__ lcj, double *__restrict__ lv)
-{
-   const int q = xcd_chunk_block() * 256 + threadIdx.x;
+{ // eight lanes to a row, a chunk of four entries each per step; the entries keep their order
+   constexpr int G = 8;
+   const int     q = xcd_chunk_block() * (256 / G) + (int)threadIdx.x / G, gl = (int)threadIdx.x % G;
    if (q >= n) return;
-   int d = 4 * lrp4[q];
-   for (int e = 4 * srp4[q]; e < 4 * srp4[q + 1]; e++)
-      if (scj[e] >= 0 && scj[e] < q) { lcj[d] = scj[e]; lv[d] = sv[e]; d++; } // (same order as in the row)
-   for (const int e1 = 4 * lrp4[q + 1]; d < e1; d++) { lcj[d] = q; lv[d] = 0.0; }
+   const int c0 = srp4[q], c1 = srp4[q + 1];
+   int       d  = 4 * lrp4[q];
+   for (int base = c0; base < c1; base += G)
+   {
+      const int  ch   = base + gl;
+      const bool mine = ch < c1;
+      int        col[4];
+      double     val[4];
+      int        cnt = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+      {
+         col[e] = mine ? scj[4 * ch + e] : -1;
+         val[e] = mine ? sv[4 * ch + e] : 0.0;
+         cnt += (col[e] >= 0 && col[e] < q);
+      }
+      int before = cnt; // inclusive prefix over the group's lanes
+#pragma unroll
+      for (int o = 1; o < G; o <<= 1)
+      {
+         const int up = __shfl_up(before, o, G);
+         if (gl >= o) before += up;
+      }
+      const int total = __shfl(before, G - 1, G);
+      int       w     = d + before - cnt;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+         if (col[e] >= 0 && col[e] < q) { lcj[w] = col[e]; lv[w] = val[e]; w++; }
+      d += total;
+   }
+   for (int w = d + gl, e1 = 4 * lrp4[q + 1]; w < e1; w += G) { lcj[w] = q; lv[w] = 0.0; }
+}
+// chunks per row alone (maximum and the counts of rows beyond 1, 2, 4, ... chunks): what gs_free_shape needs of a copy whose reach is known
+__global__ __launch_bounds__(256) void k_gs_chunk_hist(int n, const int *__restrict__ srp4, int *maxchunks, int *longer)
+{
+   int k = 0, lg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long)gridDim.x * 256)
+   {
+      const int nc = srp4[q + 1] - srp4[q];
+#pragma unroll
+      for (int j = 0; j < 8; j++) lg[j] += (nc > (1 << j));
+      k = max(k, nc);
+   }
+   for (int o = 32; o > 0; o >>= 1) k = max(k, __shfl_xor(k, o));
+#pragma unroll
+   for (int j = 0; j < 8; j++)
+      for (int o = 32; o > 0; o >>= 1) lg[j] += __shfl_xor(lg[j], o);
+   if ((threadIdx.x & 63) == 0)
+   {
+      if (k) atomicMax(maxchunks, k);
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+         if (lg[j]) atomicAdd(&longer[j], lg[j]);
+   }
 }
 static void gs_free_plan(const GsPlan &plan, int n)
 {
    plan.free_lpr = plan.dep_lpr = 0;
    if (!plan.sorted || !plan.s_x0.size()) return;
-   const GsFreeShape f = gs_free_shape(plan, n, plan.s_rowptr.data(), plan.s_col.data(), "");
+   int               reach = 0;
+   const GsFreeShape f     = gs_free_shape(plan, n, plan.s_rowptr.data(), plan.s_col.data(), "", -1, &reach);
    if (f.lpr == 0) return;
    plan.free_ring = f.ring;
    plan.free_lpr  = f.lpr;
@@ -1711,9 +1767,9 @@ static void gs_free_plan(const GsPlan &plan, int n)
    plan.d_val.alloc((size_t)4 * chunks + 4);
    HDA_HIP(hipMemsetAsync(plan.d_col.data() + (size_t)4 * chunks, 0, 4 * sizeof(int), STREAM));
    HDA_HIP(hipMemsetAsync(plan.d_val.data() + (size_t)4 * chunks, 0, 4 * sizeof(double), STREAM));
-   k_gs_dep_fill<<<xcd_chunk_grid(n), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), plan.s_val.data(), plan.d_rowptr.data(),
+   k_gs_dep_fill<<<8 * ceil_div(ceil_div(n, 32), 8), 256, 0, STREAM>>>(n, plan.s_rowptr.data(), plan.s_col.data(), plan.s_val.data(), plan.d_rowptr.data(),
                                                       plan.d_col.data(), plan.d_val.data());
-   const GsFreeShape g = gs_free_shape(plan, n, plan.d_rowptr.data(), plan.d_col.data(), " (dependency copy)");
+   const GsFreeShape g = gs_free_shape(plan, n, plan.d_rowptr.data(), plan.d_col.data(), " (dependency copy)", reach);
    if (g.lpr == 0) return;
    plan.dep_ring = g.ring;
    plan.dep_lpr  = g.lpr;
