@@ -401,14 +401,47 @@ __global__ __launch_bounds__(64) void k_rs_first_pass_rec(int nblk, const int *_
       }
    };
    // ascending-index insertion; measure-0 points become F and the points they depend on gain weight (re-listed at the tail when
-   // already listed).  64 records per load; a measure-0 point may change the measures of later points: the working lane then reads
-   // the rest of its batch again, one by one
+   // already listed).  64 records per load.  A batch without a measure-0 point -- nearly every batch -- is a stable counting sort of its
+   // rows by measure and is done by the 64 lanes at once: the rows of one measure, in ascending order, are appended to that measure's
+   // list (a lane's neighbours in the list are the lanes next to it in the vote of its measure; the first takes the list's old tail).
+   // The state this leaves is the one the one-by-one insertion leaves.  A batch WITH such a point goes one by one: the point may change
+   // the measures of later points (the working lane then reads the rest of its batch again) and re-list earlier ones.
    for (int base = lo; base < hi; base += 64)
    {
       const int  jv    = base + lane;
       const int4 Rv    = jv < hi ? rs_load(rec, jv) : make_int4(-1, -1, 0, -3);
       const int  cnt   = min(64, hi - base);
-      bool       dirty = false; // (lane 0's)
+      const bool valid = Rv.w == 0;
+      if (__ballot(valid && Rv.z <= 0) == 0ull)
+      {
+         unsigned long long todo = __ballot(valid);
+         int                prev = -1, next = -1;
+         while (todo)
+         {
+            const int                k    = __builtin_amdgcn_readlane(Rv.z, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo)));
+            const bool               mine = valid && Rv.z == k;
+            const unsigned long long m    = __ballot(mine);
+            todo &= ~m;
+            const int first = (int)__builtin_ctzll(m), last = 63 - (int)__builtin_clzll(m);
+            const int told  = tail[k];
+            if (mine)
+            {
+               const unsigned long long below = m & ((1ull << lane) - 1ull), above = lane == 63 ? 0ull : m & ~((2ull << lane) - 1ull);
+               prev = below ? base + 63 - (int)__builtin_clzll(below) : told;
+               next = above ? base + (int)__builtin_ctzll(above) : -1;
+            }
+            if (lane == first)
+            {
+               if (told >= 0) RS_F(told, 1) = base + first;
+               else head[k] = base + first;
+            }
+            if (lane == last) tail[k] = base + last;
+            if (k > maxkey) maxkey = k; // (every lane keeps the value; lane 0's is the one that is used)
+         }
+         if (valid) rec[jv] = make_int4(prev, next, Rv.z, 0);
+         continue;
+      }
+      bool dirty = false; // (lane 0's)
       for (int t = 0; t < cnt; t++)
       {
          const int j = base + t;
