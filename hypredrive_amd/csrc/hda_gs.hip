@@ -444,10 +444,11 @@ static void gs_ring_copy(const DCsr &A, const GsPlan &plan)
 // Kahn's algorithm on one row block per workgroup.  A row's predecessors are its in-block neighbours of smaller index, in A's row or
 // in A^T's: each ENTRY counts (a pair present both ways counts twice and is taken off twice), so the two rows are walked one after
 // the other with independent loads -- the round-4 form merged them into one sorted walk, two dependent loads per step, and kept the
-// counters in memory (returned global atomics, one round trip each): 122 us per level on the 256^3 level 0.  LDSDEG: the counters of
-// a block of up to 32768 rows as 16-bit halves of LDS words (a count is below twice the block size; a half never borrows: every decrement
-// takes off a unit that was counted).
-template <bool LDSDEG>
+// counters in memory (returned global atomics, one round trip each): 122 us per level on the 256^3 level 0.  W > 0: the counters of a
+// block as W-bit fields of LDS words -- 16 bits for blocks of up to 32768 rows (a count is below twice the block size), 8 or 4 bits for
+// larger blocks whose rows are short enough (a count is at most a row's entries plus its column's: gs_levels measures that); a field
+// never borrows: every decrement takes off a unit that was counted.
+template <int W> // W: bits of a row's counter in LDS (16, 8 or 4 -- a count must stay below 2^W), 0: counters in memory
 __global__ __launch_bounds__(1024) void k_gs_levels_blocks(int n, const int *__restrict__ part, const int *__restrict__ rp, const int *__restrict__ cj,
                                                            const int *__restrict__ trp, const int *__restrict__ tcj, int *indeg, int *fr0, int *fr1,
                                                            int *__restrict__ lvl, int *__restrict__ nlev)
@@ -455,9 +456,11 @@ __global__ __launch_bounds__(1024) void k_gs_levels_blocks(int n, const int *__r
    __shared__ int               cnt[2];
    extern __shared__ unsigned int sdeg[];
    const int b = blockIdx.x, lo = part[b], hi = part[b + 1], tid = threadIdx.x;
+   constexpr bool LDSDEG = W > 0;
+   constexpr int  PW = LDSDEG ? 32 / W : 1; // counters per LDS word
    if (tid < 2) cnt[tid] = 0;
    if constexpr (LDSDEG)
-      for (int w = tid; w < (hi - lo + 1) / 2; w += 1024) sdeg[w] = 0u;
+      for (int w = tid; w < (hi - lo + PW - 1) / PW; w += 1024) sdeg[w] = 0u;
    __syncthreads();
    int *cur = fr0 + lo, *nxt = fr1 + lo;
    // G lanes to a row, one entry each per step: a level of a block is a few hundred rows, and what a level costs is the chain
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(1024) void k_gs_levels_blocks(int n, const int *__r
       for (int k = t0 + gl; k < t1; k += G) d += (tcj[k] >= lo && tcj[k] < i);
       for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
       if (gl != 0) continue;
-      if constexpr (LDSDEG) { if (d) atomicAdd(&sdeg[(i - lo) >> 1], (unsigned)d << (16 * ((i - lo) & 1))); }
+      if constexpr (LDSDEG) { if (d) atomicAdd(&sdeg[(i - lo) / PW], (unsigned)d << (W * ((i - lo) % PW))); }
       else indeg[i] = d;
       if (d == 0) cur[atomicAdd(&cnt[0], 1)] = i;
    }
@@ -486,9 +489,9 @@ __global__ __launch_bounds__(1024) void k_gs_levels_blocks(int n, const int *__r
          bool last;
          if constexpr (LDSDEG)
          {
-            const int      sh  = 16 * ((j - lo) & 1);
-            const unsigned old = atomicSub(&sdeg[(j - lo) >> 1], 1u << sh);
-            last               = ((old >> sh) & 0xffffu) == 1u;
+            const int      sh  = W * ((j - lo) % PW);
+            const unsigned old = atomicSub(&sdeg[(j - lo) / PW], 1u << sh);
+            last               = ((old >> sh) & ((1u << W) - 1u)) == 1u;
          }
          else last = atomicSub(&indeg[j], 1) == 1;
          if (last) nxt[atomicAdd(&cnt[c ^ 1], 1)] = j;
@@ -523,6 +526,13 @@ __global__ __launch_bounds__(1024) void k_gs_levels_blocks(int n, const int *__r
 // (device array); one block: plan.lvl_ptr gets the level sizes (Kahn's algorithm with one launch and one counter read-back per level);
 // row blocks: one workgroup per block (k_gs_levels_blocks), plan.nlev = the most levels any block has.  Everything of size n stays on
 // the device since round 5.
+__global__ __launch_bounds__(256) void k_gs_max_degree(int n, const int *__restrict__ rp, const int *__restrict__ trp, int *mx)
+{ // the most entries any row has in its row and its column together (a bound on its predecessor count)
+   int m = 0;
+   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = max(m, rp[i + 1] - rp[i] + trp[i + 1] - trp[i]);
+   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+   if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(mx, m);
+}
 static DArray<int> gs_levels(const DCsr &A, GsPlan &plan, const int *d_part, int nb)
 {
    const int n = A.nrows;
@@ -534,15 +544,32 @@ static DArray<int> gs_levels(const DCsr &A, GsPlan &plan, const int *d_part, int
       int maxblock = 0;
       for (size_t q = 0; q + 1 < plan.h_part.size(); q++) maxblock = std::max(maxblock, plan.h_part[q + 1] - plan.h_part[q]);
       HDA_REQUIRE((int)plan.h_part.size() == nb + 1, "Gauss-Seidel plan: row blocks of the host and of the device differ");
-      if (maxblock <= 32768) // (a count is below twice the block size -- entries of both rows: 16 bits; 64 KB of LDS, two workgroups to a CU)
+      // counter width: 16 bits hold any count of a block of <= 32768 rows; larger blocks get 8 or 4 bits where no row has that many
+      // entries in its row and its column together (64 KB of LDS for 16 bits at 32768 rows, 128 KB for 8 bits at 131072 and 4 bits at 262144)
+      int W = maxblock <= 32768 ? 16 : 0;
+      if (W == 0 && maxblock <= 262144)
       {
-         HDA_HIP(hipFuncSetAttribute((const void *)k_gs_levels_blocks<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-         k_gs_levels_blocks<true><<<nb, 1024, sizeof(unsigned) * (size_t)((maxblock + 1) / 2), STREAM>>>(
-            n, d_part, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(), fr0.data(), fr1.data(), lrow.data(), dnl.data());
+         DArray<int> mx(1);
+         mx.zero();
+         k_gs_max_degree<<<std::min(ceil_div(n, 256), 2048), 256, 0, STREAM>>>(n, A.rowptr.data(), T.rowptr.data(), mx.data());
+         int md = 0;
+         mx.download(&md, 1);
+         if (maxblock <= 131072 && md < 256) W = 8;
+         else if (md < 16) W = 4;
       }
-      else
-         k_gs_levels_blocks<false><<<nb, 1024, 0, STREAM>>>(n, d_part, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(),
-                                                           fr0.data(), fr1.data(), lrow.data(), dnl.data());
+#define HDA_GS_LEVELS(WW)                                                                                                                          \
+   do                                                                                                                                              \
+   {                                                                                                                                               \
+      const size_t lds = WW ? sizeof(unsigned) * (size_t)((maxblock + 32 / (WW ? WW : 32) - 1) / (32 / (WW ? WW : 32))) : 0;                       \
+      if (lds > 48 * 1024) HDA_HIP(hipFuncSetAttribute((const void *)k_gs_levels_blocks<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      k_gs_levels_blocks<WW><<<nb, 1024, lds, STREAM>>>(n, d_part, A.rowptr.data(), A.col.data(), T.rowptr.data(), T.col.data(), indeg.data(),     \
+                                                        fr0.data(), fr1.data(), lrow.data(), dnl.data());                                          \
+   } while (0)
+      if (W == 16) HDA_GS_LEVELS(16);
+      else if (W == 8) HDA_GS_LEVELS(8);
+      else if (W == 4) HDA_GS_LEVELS(4);
+      else HDA_GS_LEVELS(0);
+#undef HDA_GS_LEVELS
       const std::vector<int> hn = dnl.to_host();
       plan.nlev = 0;
       for (int v : hn) plan.nlev = std::max(plan.nlev, v);
